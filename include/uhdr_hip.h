@@ -1,0 +1,234 @@
+/*
+ * uhdr_hip.h -- C ABI of libuhdr_hip.so: the MI355X (gfx950) implementation of libultrahdr's
+ * per-pixel gain-map hot path.  Plain C, plain pointers and sizes; no torch / HIP types leak
+ * through this boundary (streams travel as void*).
+ *
+ * Each entry point is the drop-in for one reference operator (paths under /root/reference):
+ *
+ *   uhdr_hip_apply_gainmap              UltraHdr::applyGainMap        lib/include/ultrahdr/ultrahdrcommon.h:531-534
+ *                                                                     (impl lib/src/jpegr.cpp:1533-1831; replaces the GLES
+ *                                                                      dispatch seam at jpegr.cpp:1633-1649)
+ *   uhdr_hip_generate_gainmap           UltraHdr::generateGainMap     ultrahdrcommon.h:507-510 (impl jpegr.cpp:530-1058)
+ *   uhdr_hip_tone_map                   UltraHdr::toneMap             ultrahdrcommon.h:482      (impl jpegr.cpp:1985-2222)
+ *   uhdr_hip_convert_yuv                UltraHdr::convertYuv          ultrahdrcommon.h:545-546 (impl jpegr.cpp:436-518)
+ *   uhdr_hip_convert_raw_input_to_ycbcr convert_raw_input_to_ycbcr    lib/include/ultrahdr/gainmapmath.h:604-605
+ *                                                                     (impl lib/src/gainmapmath.cpp:1291-1482)
+ *   uhdr_hip_fdct_quant                 the FDCT+quantize stage libjpeg runs inside
+ *                                       JpegEncoderHelper::compressImage  lib/include/ultrahdr/jpegencoderhelper.h:57-58
+ *                                                                     (call sites lib/src/jpegencoderhelper.cpp:187-198,297)
+ *
+ * Same argument meaning and error behaviour as the reference: uhdr_error_info_t is returned by
+ * value, UHDR_CODEC_OK == 0, strides are in PIXELS, outputs go into caller-provided images.
+ * Calls are synchronous unless the name ends in _async.  Host-memory variants stage through the
+ * context's pinned buffers; *_dev variants take DEVICE plane pointers (data already in HBM) and
+ * only enqueue work on the context's stream.
+ */
+#ifndef UHDR_HIP_H
+#define UHDR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- types shared with the reference's public header ------------------------------------------
+ * When ultrahdr_api.h (the reference's public header) is already included, its definitions are
+ * used as they are; otherwise layout-identical ones are declared here (ultrahdr_api.h:108-283). */
+#ifndef ULTRAHDR_API_H
+typedef enum uhdr_img_fmt {
+  UHDR_IMG_FMT_UNSPECIFIED = -1,
+  UHDR_IMG_FMT_24bppYCbCrP010 = 0,
+  UHDR_IMG_FMT_12bppYCbCr420 = 1,
+  UHDR_IMG_FMT_8bppYCbCr400 = 2,
+  UHDR_IMG_FMT_32bppRGBA8888 = 3,
+  UHDR_IMG_FMT_64bppRGBAHalfFloat = 4,
+  UHDR_IMG_FMT_32bppRGBA1010102 = 5,
+  UHDR_IMG_FMT_24bppYCbCr444 = 6,
+  UHDR_IMG_FMT_16bppYCbCr422 = 7,
+  UHDR_IMG_FMT_16bppYCbCr440 = 8,
+  UHDR_IMG_FMT_12bppYCbCr411 = 9,
+  UHDR_IMG_FMT_10bppYCbCr410 = 10,
+  UHDR_IMG_FMT_24bppRGB888 = 11,
+  UHDR_IMG_FMT_30bppYCbCr444 = 12
+} uhdr_img_fmt_t;
+typedef enum uhdr_color_gamut {
+  UHDR_CG_UNSPECIFIED = -1, UHDR_CG_BT_709 = 0, UHDR_CG_DISPLAY_P3 = 1, UHDR_CG_BT_2100 = 2
+} uhdr_color_gamut_t;
+typedef enum uhdr_color_transfer {
+  UHDR_CT_UNSPECIFIED = -1, UHDR_CT_LINEAR = 0, UHDR_CT_HLG = 1, UHDR_CT_PQ = 2, UHDR_CT_SRGB = 3
+} uhdr_color_transfer_t;
+typedef enum uhdr_color_range {
+  UHDR_CR_UNSPECIFIED = -1, UHDR_CR_LIMITED_RANGE = 0, UHDR_CR_FULL_RANGE = 1
+} uhdr_color_range_t;
+typedef enum uhdr_enc_preset { UHDR_USAGE_REALTIME, UHDR_USAGE_BEST_QUALITY } uhdr_enc_preset_t;
+typedef enum uhdr_codec_err {
+  UHDR_CODEC_OK,
+  UHDR_CODEC_ERROR,
+  UHDR_CODEC_UNKNOWN_ERROR,
+  UHDR_CODEC_INVALID_PARAM,
+  UHDR_CODEC_MEM_ERROR,
+  UHDR_CODEC_INVALID_OPERATION,
+  UHDR_CODEC_UNSUPPORTED_FEATURE,
+  UHDR_CODEC_LIST_END
+} uhdr_codec_err_t;
+typedef struct uhdr_error_info {
+  uhdr_codec_err_t error_code;
+  int has_detail;
+  char detail[256];
+} uhdr_error_info_t;
+#define UHDR_PLANE_PACKED 0
+#define UHDR_PLANE_Y 0
+#define UHDR_PLANE_U 1
+#define UHDR_PLANE_UV 1
+#define UHDR_PLANE_V 2
+typedef struct uhdr_raw_image {
+  uhdr_img_fmt_t fmt;
+  uhdr_color_gamut_t cg;
+  uhdr_color_transfer_t ct;
+  uhdr_color_range_t range;
+  unsigned int w, h;
+  void* planes[3];
+  unsigned int stride[3]; /* pixels */
+} uhdr_raw_image_t;
+typedef struct uhdr_gainmap_metadata {
+  float max_content_boost[3];
+  float min_content_boost[3];
+  float gamma[3];
+  float offset_sdr[3];
+  float offset_hdr[3];
+  float hdr_capacity_min;
+  float hdr_capacity_max;
+  int use_base_cg;
+} uhdr_gainmap_metadata_t;
+#endif /* ULTRAHDR_API_H */
+
+/* Encoder knobs: the UltraHdr constructor arguments that reach the hot path plus
+ * generateGainMap's two optional flags (ultrahdrcommon.h:450-457, 507-510).  "unset" sentinels
+ * are the reference's own: FLT_MIN / FLT_MAX / -1.0f. */
+typedef struct uhdr_hip_encode_cfg {
+  int map_dimension_scale_factor; /* mMapDimensionScaleFactor        (C-API default 1, Android 4) */
+  int use_multi_channel_gainmap;  /* mUseMultiChannelGainMap         (C-API default 1)            */
+  float gamma;                    /* mGamma                          (default 1.0)                */
+  int preset;                     /* uhdr_enc_preset_t: REALTIME = one pass, BEST_QUALITY = two   */
+  float min_content_boost;        /* mMinContentBoost, FLT_MIN = unset                            */
+  float max_content_boost;        /* mMaxContentBoost, FLT_MAX = unset                            */
+  float target_disp_peak_nits;    /* mTargetDispPeakBrightness, -1 = unset                        */
+  int sdr_is_601;
+  int use_luminance;
+} uhdr_hip_encode_cfg_t;
+
+typedef struct uhdr_hip_ctx uhdr_hip_ctx_t; /* one per (device, stream); not thread-safe, like a codec handle */
+
+/* ---- context ------------------------------------------------------------------------------- */
+/* device < 0: current device.  Fails (NULL + message in *err, may be NULL) when no gfx950-class
+ * GPU is usable: there is no CPU fallback behind this ABI. */
+uhdr_hip_ctx_t* uhdr_hip_create(int device, uhdr_error_info_t* err);
+void uhdr_hip_destroy(uhdr_hip_ctx_t* ctx);
+/* run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the context's own */
+uhdr_error_info_t uhdr_hip_set_stream(uhdr_hip_ctx_t* ctx, void* hip_stream);
+uhdr_error_info_t uhdr_hip_synchronize(uhdr_hip_ctx_t* ctx);
+const char* uhdr_hip_version(void);
+int uhdr_hip_device_count(void);
+
+/* ---- stage operators, HOST buffers (drop-in for the UltraHdr:: methods) ----------------------- */
+uhdr_error_info_t uhdr_hip_apply_gainmap(uhdr_hip_ctx_t* ctx, const uhdr_raw_image_t* sdr_intent,
+                                         const uhdr_raw_image_t* gainmap_img,
+                                         const uhdr_gainmap_metadata_t* gainmap_metadata,
+                                         uhdr_color_transfer_t output_ct,
+                                         uhdr_img_fmt_t output_format, float max_display_boost,
+                                         uhdr_raw_image_t* dest);
+/* gainmap_img: caller provides planes[0] and stride[0] (>= w/scale; the reference aligns to 64);
+ * fmt / w / h / colour aspects are filled in like the reference's freshly allocated image. */
+uhdr_error_info_t uhdr_hip_generate_gainmap(uhdr_hip_ctx_t* ctx, const uhdr_raw_image_t* sdr_intent,
+                                            const uhdr_raw_image_t* hdr_intent,
+                                            const uhdr_hip_encode_cfg_t* cfg,
+                                            uhdr_gainmap_metadata_t* gainmap_metadata,
+                                            uhdr_raw_image_t* gainmap_img);
+uhdr_error_info_t uhdr_hip_tone_map(uhdr_hip_ctx_t* ctx, const uhdr_raw_image_t* hdr_intent,
+                                    uhdr_raw_image_t* sdr_intent);
+uhdr_error_info_t uhdr_hip_convert_yuv(uhdr_hip_ctx_t* ctx, uhdr_raw_image_t* image,
+                                       uhdr_color_gamut_t src_encoding,
+                                       uhdr_color_gamut_t dst_encoding);
+/* dst: caller provides planes/strides; dst->fmt is set to what the reference would allocate */
+uhdr_error_info_t uhdr_hip_convert_raw_input_to_ycbcr(uhdr_hip_ctx_t* ctx,
+                                                      const uhdr_raw_image_t* src,
+                                                      int chroma_sampling_enabled,
+                                                      uhdr_raw_image_t* dst);
+
+/* ---- stage operators, DEVICE buffers (planes[] are device pointers) -------------------------- */
+/* Row-stripe sharding: sdr/dest may describe only this rank's rows of a taller image; the gain
+ * map is whole and replicated.  y0 = global row of the stripe's first row, full_height = height
+ * of the whole image.  Whole image: y0 = 0, full_height = 0. */
+uhdr_error_info_t uhdr_hip_apply_gainmap_dev(uhdr_hip_ctx_t* ctx, const uhdr_raw_image_t* sdr_intent,
+                                             const uhdr_raw_image_t* gainmap_img,
+                                             const uhdr_gainmap_metadata_t* gainmap_metadata,
+                                             uhdr_color_transfer_t output_ct,
+                                             uhdr_img_fmt_t output_format, float max_display_boost,
+                                             uhdr_raw_image_t* dest, unsigned int y0,
+                                             unsigned int full_height);
+/* one-pass (REALTIME) generation, or the whole two-pass sequence on one device */
+uhdr_error_info_t uhdr_hip_generate_gainmap_dev(uhdr_hip_ctx_t* ctx,
+                                                const uhdr_raw_image_t* sdr_intent,
+                                                const uhdr_raw_image_t* hdr_intent,
+                                                const uhdr_hip_encode_cfg_t* cfg,
+                                                uhdr_gainmap_metadata_t* gainmap_metadata,
+                                                uhdr_raw_image_t* gainmap_img);
+/* two-pass generation split at its only exchange step (jpegr.cpp:932-938: the min/max merge):
+ *   pass1: per map pixel log2 gain -> gain_log2 (device floats, w/scale * h/scale * (3|1)),
+ *          per-channel min/max of this stripe -> minmax_dev[6] = {min0,min1,min2,max0,max1,max2}
+ *          (device floats; initialise nothing, the call does)
+ *   <all-reduce minmax_dev across ranks: MIN on [0..2], MAX on [3..5]>
+ *   finalize: clamp / hints / epsilon guard + metadata fill (jpegr.cpp:969-986, 1031-1048), host
+ *   pass2: affine map to u8 (jpegr.cpp:992-1013) */
+uhdr_error_info_t uhdr_hip_generate_gainmap_pass1_dev(uhdr_hip_ctx_t* ctx,
+                                                      const uhdr_raw_image_t* sdr_intent,
+                                                      const uhdr_raw_image_t* hdr_intent,
+                                                      const uhdr_hip_encode_cfg_t* cfg,
+                                                      float* gain_log2_dev, float* minmax_dev,
+                                                      int* use_base_cg);
+uhdr_error_info_t uhdr_hip_generate_gainmap_finalize(const uhdr_hip_encode_cfg_t* cfg,
+                                                     uhdr_color_transfer_t hdr_ct, int use_base_cg,
+                                                     float minmax[6],
+                                                     uhdr_gainmap_metadata_t* gainmap_metadata);
+uhdr_error_info_t uhdr_hip_generate_gainmap_pass2_dev(uhdr_hip_ctx_t* ctx,
+                                                      const float* gain_log2_dev,
+                                                      const float minmax[6],
+                                                      const uhdr_hip_encode_cfg_t* cfg,
+                                                      uhdr_raw_image_t* gainmap_img);
+uhdr_error_info_t uhdr_hip_tone_map_dev(uhdr_hip_ctx_t* ctx, const uhdr_raw_image_t* hdr_intent,
+                                        uhdr_raw_image_t* sdr_intent);
+uhdr_error_info_t uhdr_hip_convert_yuv_dev(uhdr_hip_ctx_t* ctx, uhdr_raw_image_t* image,
+                                           uhdr_color_gamut_t src_encoding,
+                                           uhdr_color_gamut_t dst_encoding);
+uhdr_error_info_t uhdr_hip_convert_raw_input_to_ycbcr_dev(uhdr_hip_ctx_t* ctx,
+                                                          const uhdr_raw_image_t* src,
+                                                          int chroma_sampling_enabled,
+                                                          uhdr_raw_image_t* dst);
+
+/* ---- JPEG DCT/quantize stage ----------------------------------------------------------------- */
+/* Quant table libjpeg builds for jpeg_set_quality(quality, TRUE): natural (row-major) order. */
+void uhdr_hip_jpeg_quant_table(int quality, int is_chroma, uint16_t qtable[64]);
+/* islow 8x8 FDCT + quantize of one 8-bit plane.  Reads blocks_w*8 x blocks_h*8 samples (the
+ * caller pads to the MCU grid exactly as jpegencoderhelper.cpp:246-309 does); writes blocks in
+ * raster order, 64 int16 each in natural order = libjpeg's JBLOCK layout, ready for
+ * jpeg_write_coefficients().  plane / coef are host (no suffix) or device (_dev) pointers. */
+uhdr_error_info_t uhdr_hip_fdct_quant(uhdr_hip_ctx_t* ctx, const uint8_t* plane, size_t stride,
+                                      int blocks_w, int blocks_h, const uint16_t qtable[64],
+                                      int16_t* coef);
+uhdr_error_info_t uhdr_hip_fdct_quant_dev(uhdr_hip_ctx_t* ctx, const uint8_t* plane, size_t stride,
+                                          int blocks_w, int blocks_h, const uint16_t qtable[64],
+                                          int16_t* coef);
+
+/* ---- timing hook for bench.py ------------------------------------------------------------------
+ * HIP events recorded on the context's stream around every kernel launch of the named family
+ * ("apply_gainmap", "generate_gainmap", ...) since the last reset; returns the number of launches
+ * and their summed duration in milliseconds (synchronises the stream). */
+void uhdr_hip_profile_enable(uhdr_hip_ctx_t* ctx, int enable);
+int uhdr_hip_profile_read(uhdr_hip_ctx_t* ctx, const char* family, double* total_ms, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UHDR_HIP_H */

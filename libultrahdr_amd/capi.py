@@ -1,0 +1,175 @@
+"""ctypes binding of the C ABI in ``include/uhdr_hip.h`` (``libultrahdr_amd/lib/libuhdr_hip.so``).
+
+This is the *only* way the Python host layer reaches the kernels -- the same entry points a cgo /
+JNI / C++ caller binds.  There is no CPU fallback: if the shared library is
+missing the import of :func:`load` raises, and if no GPU is usable ``uhdr_hip_create`` fails.
+
+Struct layouts mirror the reference's public C structs
+(``/root/reference/ultrahdr_api.h:220-283``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+# ---- enums (ultrahdr_api.h:108-207) -----------------------------------------------------------
+UHDR_IMG_FMT_UNSPECIFIED = -1
+UHDR_IMG_FMT_24bppYCbCrP010 = 0
+UHDR_IMG_FMT_12bppYCbCr420 = 1
+UHDR_IMG_FMT_8bppYCbCr400 = 2
+UHDR_IMG_FMT_32bppRGBA8888 = 3
+UHDR_IMG_FMT_64bppRGBAHalfFloat = 4
+UHDR_IMG_FMT_32bppRGBA1010102 = 5
+UHDR_IMG_FMT_24bppYCbCr444 = 6
+UHDR_IMG_FMT_16bppYCbCr422 = 7
+UHDR_IMG_FMT_24bppRGB888 = 11
+UHDR_IMG_FMT_30bppYCbCr444 = 12
+
+UHDR_CG_UNSPECIFIED, UHDR_CG_BT_709, UHDR_CG_DISPLAY_P3, UHDR_CG_BT_2100 = -1, 0, 1, 2
+UHDR_CT_UNSPECIFIED, UHDR_CT_LINEAR, UHDR_CT_HLG, UHDR_CT_PQ, UHDR_CT_SRGB = -1, 0, 1, 2, 3
+UHDR_CR_UNSPECIFIED, UHDR_CR_LIMITED_RANGE, UHDR_CR_FULL_RANGE = -1, 0, 1
+UHDR_USAGE_REALTIME, UHDR_USAGE_BEST_QUALITY = 0, 1
+
+UHDR_CODEC_OK = 0
+UHDR_CODEC_ERROR = 1
+UHDR_CODEC_UNKNOWN_ERROR = 2
+UHDR_CODEC_INVALID_PARAM = 3
+UHDR_CODEC_MEM_ERROR = 4
+UHDR_CODEC_INVALID_OPERATION = 5
+UHDR_CODEC_UNSUPPORTED_FEATURE = 6
+
+FLT_MIN = 1.1754943508222875e-38
+FLT_MAX = 3.4028234663852886e38
+
+
+class ErrorInfo(C.Structure):  # uhdr_error_info_t
+    _fields_ = [("error_code", C.c_int), ("has_detail", C.c_int), ("detail", C.c_char * 256)]
+
+
+class RawImage(C.Structure):  # uhdr_raw_image_t
+    _fields_ = [
+        ("fmt", C.c_int),
+        ("cg", C.c_int),
+        ("ct", C.c_int),
+        ("range", C.c_int),
+        ("w", C.c_uint),
+        ("h", C.c_uint),
+        ("planes", C.c_void_p * 3),
+        ("stride", C.c_uint * 3),
+    ]
+
+
+class GainmapMetadata(C.Structure):  # uhdr_gainmap_metadata_t
+    _fields_ = [
+        ("max_content_boost", C.c_float * 3),
+        ("min_content_boost", C.c_float * 3),
+        ("gamma", C.c_float * 3),
+        ("offset_sdr", C.c_float * 3),
+        ("offset_hdr", C.c_float * 3),
+        ("hdr_capacity_min", C.c_float),
+        ("hdr_capacity_max", C.c_float),
+        ("use_base_cg", C.c_int),
+    ]
+
+    def as_dict(self):
+        return {
+            "max_content_boost": list(self.max_content_boost),
+            "min_content_boost": list(self.min_content_boost),
+            "gamma": list(self.gamma),
+            "offset_sdr": list(self.offset_sdr),
+            "offset_hdr": list(self.offset_hdr),
+            "hdr_capacity_min": self.hdr_capacity_min,
+            "hdr_capacity_max": self.hdr_capacity_max,
+            "use_base_cg": self.use_base_cg,
+        }
+
+
+class EncodeCfg(C.Structure):  # uhdr_hip_encode_cfg_t (same field order as oracle's uo_encode_cfg_t)
+    _fields_ = [
+        ("map_dimension_scale_factor", C.c_int),
+        ("use_multi_channel_gainmap", C.c_int),
+        ("gamma", C.c_float),
+        ("preset", C.c_int),
+        ("min_content_boost", C.c_float),
+        ("max_content_boost", C.c_float),
+        ("target_disp_peak_nits", C.c_float),
+        ("sdr_is_601", C.c_int),
+        ("use_luminance", C.c_int),
+    ]
+
+
+def default_encode_cfg(**kw) -> EncodeCfg:
+    """C-API defaults (ultrahdrcommon.h:422-446): scale 1, multichannel, gamma 1, two-pass."""
+    cfg = EncodeCfg(1, 1, 1.0, UHDR_USAGE_BEST_QUALITY, FLT_MIN, FLT_MAX, -1.0, 0, 1)
+    for k, v in kw.items():
+        if not hasattr(cfg, k):
+            raise AttributeError(k)
+        setattr(cfg, k, v)
+    return cfg
+
+
+class UhdrError(RuntimeError):
+    def __init__(self, code: int, detail: str):
+        super().__init__(f"uhdr error {code}: {detail}")
+        self.code = code
+        self.detail = detail
+
+
+def check(st: ErrorInfo):
+    if st.error_code != UHDR_CODEC_OK:
+        raise UhdrError(st.error_code, st.detail.decode("utf-8", "replace") if st.has_detail else "")
+
+
+LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libuhdr_hip.so")
+
+# every symbol include/uhdr_hip.h declares: (restype, argtypes)
+_P = C.POINTER
+_SIGS = {
+    "uhdr_hip_version": (C.c_char_p, []),
+    "uhdr_hip_device_count": (C.c_int, []),
+    "uhdr_hip_create": (C.c_void_p, [C.c_int, _P(ErrorInfo)]),
+    "uhdr_hip_destroy": (None, [C.c_void_p]),
+    "uhdr_hip_set_stream": (ErrorInfo, [C.c_void_p, C.c_void_p]),
+    "uhdr_hip_synchronize": (ErrorInfo, [C.c_void_p]),
+    "uhdr_hip_apply_gainmap": (ErrorInfo, [C.c_void_p, _P(RawImage), _P(RawImage), _P(GainmapMetadata), C.c_int, C.c_int, C.c_float, _P(RawImage)]),
+    "uhdr_hip_apply_gainmap_dev": (ErrorInfo, [C.c_void_p, _P(RawImage), _P(RawImage), _P(GainmapMetadata), C.c_int, C.c_int, C.c_float, _P(RawImage), C.c_uint, C.c_uint]),
+    "uhdr_hip_generate_gainmap": (ErrorInfo, [C.c_void_p, _P(RawImage), _P(RawImage), _P(EncodeCfg), _P(GainmapMetadata), _P(RawImage)]),
+    "uhdr_hip_generate_gainmap_dev": (ErrorInfo, [C.c_void_p, _P(RawImage), _P(RawImage), _P(EncodeCfg), _P(GainmapMetadata), _P(RawImage)]),
+    "uhdr_hip_generate_gainmap_pass1_dev": (ErrorInfo, [C.c_void_p, _P(RawImage), _P(RawImage), _P(EncodeCfg), C.c_void_p, C.c_void_p, _P(C.c_int)]),
+    "uhdr_hip_generate_gainmap_finalize": (ErrorInfo, [_P(EncodeCfg), C.c_int, C.c_int, _P(C.c_float), _P(GainmapMetadata)]),
+    "uhdr_hip_generate_gainmap_pass2_dev": (ErrorInfo, [C.c_void_p, C.c_void_p, _P(C.c_float), _P(EncodeCfg), _P(RawImage)]),
+    "uhdr_hip_tone_map": (ErrorInfo, [C.c_void_p, _P(RawImage), _P(RawImage)]),
+    "uhdr_hip_tone_map_dev": (ErrorInfo, [C.c_void_p, _P(RawImage), _P(RawImage)]),
+    "uhdr_hip_convert_yuv": (ErrorInfo, [C.c_void_p, _P(RawImage), C.c_int, C.c_int]),
+    "uhdr_hip_convert_yuv_dev": (ErrorInfo, [C.c_void_p, _P(RawImage), C.c_int, C.c_int]),
+    "uhdr_hip_convert_raw_input_to_ycbcr": (ErrorInfo, [C.c_void_p, _P(RawImage), C.c_int, _P(RawImage)]),
+    "uhdr_hip_convert_raw_input_to_ycbcr_dev": (ErrorInfo, [C.c_void_p, _P(RawImage), C.c_int, _P(RawImage)]),
+    "uhdr_hip_jpeg_quant_table": (None, [C.c_int, C.c_int, _P(C.c_uint16)]),
+    "uhdr_hip_fdct_quant": (ErrorInfo, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, _P(C.c_uint16), C.c_void_p]),
+    "uhdr_hip_fdct_quant_dev": (ErrorInfo, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, _P(C.c_uint16), C.c_void_p]),
+    "uhdr_hip_profile_enable": (None, [C.c_void_p, C.c_int]),
+    "uhdr_hip_profile_read": (C.c_int, [C.c_void_p, C.c_char_p, _P(C.c_double), C.c_int]),
+}
+ABI_SYMBOLS = tuple(_SIGS)
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libuhdr_hip.so (built in-tree by ``__graft_entry__.build()`` / csrc/Makefile)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C libultrahdr_amd/csrc).  libultrahdr_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError here == ABI drift
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,460 @@
+// applyGainMap on gfx950: SDR base image + gain map + metadata -> HDR pixels.
+// Reference loop: /root/reference/lib/src/jpegr.cpp:1714-1812 (UltraHdr::applyGainMap).
+//
+// Two kernels:
+//   apply_quad_kernel   -- the hot one.  YCbCr 4:2:0 base (what a JPEG base image decodes to),
+//                          one lane = one chroma sample = one 2x2 luma quad, a wave covers a
+//                          128 x 2 pixel strip, so every global store instruction of the wave
+//                          writes one fully contiguous 1 KiB (F16) / 512 B (1010102) run per row.
+//                          All per-call tables (sRGB-EOTF 4 KiB, gain LUT 4-12 KiB, byte->float,
+//                          byte->factor, IDW weights) are staged in LDS once per workgroup and the
+//                          workgroup then walks strips grid-stride.
+//   apply_generic_kernel-- one thread per pixel, every format / scale combination the reference
+//                          accepts (4:4:4, 4:2:2, RGBA8888, odd sizes, non-integer scale).
+// HBM-bound by design: 1.5 B (4:2:0) + map + 8 B (F16) per pixel, no intermediate buffers.
+#include "uhdr_types.h"
+
+namespace uhdr {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// ---------------------------------------------------------------------------------------------
+// shared tail: linear SDR rgb (after the optional SDR-side gamut conversion) x gain factors ->
+// packed output pixel.  jpegr.cpp:1765-1805.
+// ---------------------------------------------------------------------------------------------
+template <int OUT>  // 0 linear F16, 1 HLG 1010102, 2 PQ 1010102
+struct OutPix {
+  using type = uint32_t;
+};
+template <>
+struct OutPix<0> {
+  using type = uint2;
+};
+
+template <int OUT>
+__device__ __forceinline__ typename OutPix<OUT>::type finish_pixel(Color3 lin, float f0, float f1,
+                                                                   float f2, const ApplyParams& p,
+                                                                   int nch) {
+  // applyGainLUT: ((e + offset_sdr) * factor) - offset_hdr   (gainmapmath.cpp:807-810, 848-855)
+  // single-channel maps use channel-0 metadata for all three colours.
+  Color3 h;
+  if (nch == 1) {
+    h.r = ((lin.r + p.offset_sdr[0]) * f0) - p.offset_hdr[0];
+    h.g = ((lin.g + p.offset_sdr[0]) * f0) - p.offset_hdr[0];
+    h.b = ((lin.b + p.offset_sdr[0]) * f0) - p.offset_hdr[0];
+  } else {
+    h.r = ((lin.r + p.offset_sdr[0]) * f0) - p.offset_hdr[0];
+    h.g = ((lin.g + p.offset_sdr[1]) * f1) - p.offset_hdr[1];
+    h.b = ((lin.b + p.offset_sdr[2]) * f2) - p.offset_hdr[2];
+  }
+  if constexpr (OUT == 0) {
+    if (p.hdr_gamut_on) h = mat3_apply(h, p.gamut);
+    return pack_rgba_f16(clamp_linear(h.r), clamp_linear(h.g), clamp_linear(h.b));
+  } else {
+    const float peak = (OUT == 1) ? 1000.0f : 10000.0f;  // kHlgMaxNits / kPqMaxNits
+    h.r = h.r * 203.0f / peak;                            // two roundings, as written in the reference
+    h.g = h.g * 203.0f / peak;
+    h.b = h.b * 203.0f / peak;
+    if (p.hdr_gamut_on) h = mat3_apply(h, p.gamut);
+    h.r = clamp01(h.r);
+    h.g = clamp01(h.g);
+    h.b = clamp01(h.b);
+    if constexpr (OUT == 1) {  // hlgInverseOotfApprox: powf(v, 1/1.2f)  (gainmapmath.cpp:303-306)
+      h.r = powf(h.r, 1.0f / 1.2f);
+      h.g = powf(h.g, 1.0f / 1.2f);
+      h.b = powf(h.b, 1.0f / 1.2f);
+    }
+    float r = p.oetf_lut[lut_index_f32<kOetfN>(h.r)];
+    float g = p.oetf_lut[lut_index_f32<kOetfN>(h.g)];
+    float b = p.oetf_lut[lut_index_f32<kOetfN>(h.b)];
+    return pack_rgba1010102(r, g, b);
+  }
+}
+
+// gain value (0..1) -> factor through the GainLUT (gainmapmath.h:483-489)
+__device__ __forceinline__ float gain_factor(float gain, const float* gain_tab, int ch,
+                                             const ApplyParams& p) {
+  if (!p.gamma_is_one[ch]) gain = (float)pow((double)gain, (double)p.gamma_inv[ch]);
+  return gain_tab[ch * kGainN + lut_index_f32<kGainN>(gain)];
+}
+
+__device__ __forceinline__ uint32_t div_scale(uint32_t x, const ApplyParams& p) {
+  return p.scale == 1 ? x : __umulhi(x, p.scale_magic);
+}
+
+// ---------------------------------------------------------------------------------------------
+// integer-scale sampler (sampleMap / sampleMap3Channel with ShepardsIDW tables,
+// gainmapmath.cpp:920-956, 1026-1080).  u8f = byte/255.0f table, idw = 4 weight tables.
+// ---------------------------------------------------------------------------------------------
+template <int NCH>
+__device__ __forceinline__ void sample_map_table(const ApplyParams& p, const float* u8f,
+                                                 const float* idw, uint32_t x, uint32_t yg,
+                                                 float out[3]) {
+  const uint32_t s = p.scale;
+  uint32_t xl = div_scale(x, p), yl = div_scale(yg, p);
+  const uint32_t ox = x - xl * s, oy = yg - yl * s;
+  uint32_t xu = xl + 1, yu = yl + 1;
+  xl = min(xl, p.gm.w - 1);
+  xu = min(xu, p.gm.w - 1);
+  yl = min(yl, p.gm.h - 1);
+  yu = min(yu, p.gm.h - 1);
+  int tbl = 0;
+  if (xl == xu && yl == yu) tbl = 3;
+  else if (xl == xu) tbl = 1;
+  else if (yl == yu) tbl = 2;
+  const float* w = idw + (size_t)tbl * s * s * 4 + (oy * s + ox) * 4;
+  const float w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+  const uint8_t* d = (const uint8_t*)p.gm.p[0];
+  const size_t st = p.gm.stride[0];
+  const int bpp = p.map_bpp;
+  const uint8_t* a1 = d + (xl + yl * st) * bpp;
+  const uint8_t* a2 = d + (xl + yu * st) * bpp;
+  const uint8_t* a3 = d + (xu + yl * st) * bpp;
+  const uint8_t* a4 = d + (xu + yu * st) * bpp;
+#pragma unroll
+  for (int c = 0; c < NCH; c++)
+    out[c] = u8f[a1[c]] * w0 + u8f[a2[c]] * w1 + u8f[a3[c]] * w2 + u8f[a4[c]] * w3;
+}
+
+// non-integer scale sampler (gainmapmath.cpp:871-918, 958-1024): per-pixel distances; the
+// reference's pow(d,2)/sqrt are the double libm ones.
+__device__ __forceinline__ float pyth(float dx, float dy) {
+  return (float)sqrt((double)dx * (double)dx + (double)dy * (double)dy);
+}
+template <int NCH>
+__device__ void sample_map_float(const ApplyParams& p, const float* u8f, uint32_t x, uint32_t yg,
+                                 float out[3]) {
+  const float xm = (float)x / p.scale_f, ym = (float)yg / p.scale_f;
+  uint32_t xl = (uint32_t)floorf(xm), yl = (uint32_t)floorf(ym);
+  uint32_t xu = xl + 1, yu = yl + 1;
+  xl = min(xl, p.gm.w - 1);
+  xu = min(xu, p.gm.w - 1);
+  yl = min(yl, p.gm.h - 1);
+  yu = min(yu, p.gm.h - 1);
+  const uint8_t* d = (const uint8_t*)p.gm.p[0];
+  const size_t st = p.gm.stride[0];
+  const int bpp = p.map_bpp;
+  float e1[3], e2[3], e3[3], e4[3];
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    e1[c] = u8f[d[(xl + yl * st) * bpp + c]];
+    e2[c] = u8f[d[(xl + yu * st) * bpp + c]];
+    e3[c] = u8f[d[(xu + yl * st) * bpp + c]];
+    e4[c] = u8f[d[(xu + yu * st) * bpp + c]];
+  }
+  const float d1 = pyth(xm - (float)xl, ym - (float)yl);
+  const float d2 = pyth(xm - (float)xl, ym - (float)yu);
+  const float d3 = pyth(xm - (float)xu, ym - (float)yl);
+  const float d4 = pyth(xm - (float)xu, ym - (float)yu);
+  const float w1 = 1.0f / d1, w2 = 1.0f / d2, w3 = 1.0f / d3, w4 = 1.0f / d4;
+  const float tot = w1 + w2 + w3 + w4;
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    float v = e1[c] * (w1 / tot) + e2[c] * (w2 / tot) + e3[c] * (w3 / tot) + e4[c] * (w4 / tot);
+    // early-outs in source order; the 1-channel sampler returns e2 (not e4) when the 4th
+    // distance is zero (gainmapmath.cpp:908)
+    if (d4 == 0.0f) v = (NCH == 1) ? e2[c] : e4[c];
+    if (d3 == 0.0f) v = e3[c];
+    if (d2 == 0.0f) v = e2[c];
+    if (d1 == 0.0f) v = e1[c];
+    out[c] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic kernel: one thread per pixel, tables read through the cache hierarchy
+// ---------------------------------------------------------------------------------------------
+template <int OUT>
+__global__ __launch_bounds__(kBlock) void apply_generic_kernel(const ApplyParams p) {
+  const float* srgb = p.tables + ApplyTables::kSrgbOff;
+  const float* gain_tab = p.tables + ApplyTables::kGainOff;
+  const float* u8f = p.tables + ApplyTables::kU8fOff;
+  const float* idw = p.tables + ApplyTables::kIdwOff;
+  const uint32_t w = p.sdr.w, h = p.sdr.h;
+  const size_t total = (size_t)w * h;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * kBlock) {
+    const uint32_t y = (uint32_t)(i / w), x = (uint32_t)(i - (size_t)y * w);
+    // get_pixel_fn (gainmapmath.cpp:354-470)
+    Color3 g;
+    const int fmt = p.sdr.fmt;
+    if (fmt == UHDR_IMG_FMT_32bppRGBA8888) {
+      uint32_t v = ((const uint32_t*)p.sdr.p[0])[x + (size_t)y * p.sdr.stride[0]];
+      g.r = (float)(v & 0xff) / 255.0f;
+      g.g = (float)((v >> 8) & 0xff) / 255.0f;
+      g.b = (float)((v >> 16) & 0xff) / 255.0f;
+    } else if (fmt == UHDR_IMG_FMT_24bppRGB888) {
+      const uint8_t* q = (const uint8_t*)p.sdr.p[0] + (size_t)x * 3 + (size_t)y * p.sdr.stride[0] * 3;
+      g.r = (float)q[0] / 255.0f;
+      g.g = (float)q[1] / 255.0f;
+      g.b = (float)q[2] / 255.0f;
+    } else {
+      const uint32_t hf = fmt == UHDR_IMG_FMT_24bppYCbCr444 ? 1 : 2;
+      const uint32_t vf = fmt == UHDR_IMG_FMT_12bppYCbCr420 ? 2 : 1;
+      uint8_t yy = ((const uint8_t*)p.sdr.p[0])[x + (size_t)y * p.sdr.stride[0]];
+      uint8_t uu = ((const uint8_t*)p.sdr.p[1])[x / hf + (size_t)(y / vf) * p.sdr.stride[1]];
+      uint8_t vv = ((const uint8_t*)p.sdr.p[2])[x / hf + (size_t)(y / vf) * p.sdr.stride[2]];
+      g.r = (float)yy * (1 / 255.0f);
+      g.g = (float)((int)uu - 128) * (1 / 255.0f);
+      g.b = (float)((int)vv - 128) * (1 / 255.0f);
+    }
+    if (!p.sdr_is_rgb) g = yuv_to_rgb(g.r, g.g, g.b, p.yuv);  // p3YuvToRgb, always (jpegr.cpp:1723)
+    Color3 lin = {srgb[lut_index_f32<kSrgbN>(g.r)], srgb[lut_index_f32<kSrgbN>(g.g)],
+                  srgb[lut_index_f32<kSrgbN>(g.b)]};
+    if (p.sdr_gamut_on) lin = mat3_apply(lin, p.gamut);
+    float gn[3];
+    const uint32_t yg = y + p.y0;
+    if (p.map_ch == 1) {
+      if (p.scale) sample_map_table<1>(p, u8f, idw, x, yg, gn);
+      else sample_map_float<1>(p, u8f, x, yg, gn);
+      gn[1] = gn[2] = gn[0];
+    } else {
+      if (p.scale) sample_map_table<3>(p, u8f, idw, x, yg, gn);
+      else sample_map_float<3>(p, u8f, x, yg, gn);
+    }
+    float f0 = gain_factor(gn[0], gain_tab, 0, p), f1 = f0, f2 = f0;
+    if (p.map_ch != 1) {
+      f1 = gain_factor(gn[1], gain_tab, 1, p);
+      f2 = gain_factor(gn[2], gain_tab, 2, p);
+    }
+    auto px = finish_pixel<OUT>(lin, f0, f1, f2, p, p.map_ch);
+    using T = typename OutPix<OUT>::type;
+    ((T*)p.dst.p[0])[x + (size_t)y * p.dst.stride[0]] = px;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// quad kernel (4:2:0 base, even geometry).  MAPFMT: 0 Y400, 1 RGB888, 2 RGBA8888.
+// SMODE: 0 scale == 1 (byte -> factor table, no interpolation), 1 even integer scale (the four
+// taps are shared by the whole 2x2 quad; only the weights differ per pixel).
+// ---------------------------------------------------------------------------------------------
+template <int OUT, int MAPFMT, int SMODE>
+__global__ __launch_bounds__(kBlock) void apply_quad_kernel(const ApplyParams p) {
+  constexpr int NCH = (MAPFMT == 0) ? 1 : 3;
+  constexpr int BPP = (MAPFMT == 0) ? 1 : (MAPFMT == 1 ? 3 : 4);
+  __shared__ float s_srgb[kSrgbN];
+  __shared__ float s_gain[(SMODE == 0) ? 1 : NCH * kGainN];
+  __shared__ float s_u8f[(SMODE == 0) ? 1 : 256];
+  __shared__ float s_fac[(SMODE == 0) ? NCH * 256 : 1];
+  __shared__ __attribute__((aligned(16))) float s_idw[(SMODE == 0) ? 4 : 4 * kMaxIdwScaleLds * kMaxIdwScaleLds * 4];
+
+  const int tid = threadIdx.x;
+  for (int i = tid; i < kSrgbN; i += kBlock) s_srgb[i] = p.tables[ApplyTables::kSrgbOff + i];
+  if constexpr (SMODE == 0) {
+    for (int i = tid; i < NCH * 256; i += kBlock) s_fac[i] = p.tables[ApplyTables::kFacOff + i];
+  } else {
+    for (int i = tid; i < NCH * kGainN; i += kBlock) s_gain[i] = p.tables[ApplyTables::kGainOff + i];
+    for (int i = tid; i < 256; i += kBlock) s_u8f[i] = p.tables[ApplyTables::kU8fOff + i];
+    const int nidw = 4 * p.scale * p.scale * 4;
+    for (int i = tid; i < nidw; i += kBlock) s_idw[i] = p.tables[ApplyTables::kIdwOff + i];
+  }
+  __syncthreads();
+
+  const uint32_t qw = p.sdr.w >> 1, qh = p.sdr.h >> 1;
+  const uint32_t strips_x = (qw + 63) >> 6;
+  const uint32_t total = strips_x * qh;
+  const uint32_t lane = tid & 63;
+  const uint32_t wave = (blockIdx.x * (kBlock / 64)) + (tid >> 6);
+  const uint32_t nwaves = gridDim.x * (kBlock / 64);
+
+  const uint8_t* yp = (const uint8_t*)p.sdr.p[0];
+  const uint8_t* up = (const uint8_t*)p.sdr.p[1];
+  const uint8_t* vp = (const uint8_t*)p.sdr.p[2];
+  const uint8_t* mp = (const uint8_t*)p.gm.p[0];
+  const size_t sy = p.sdr.stride[0], su = p.sdr.stride[1], sv = p.sdr.stride[2];
+  const size_t sm = p.gm.stride[0], sd = p.dst.stride[0];
+  using T = typename OutPix<OUT>::type;
+  T* dp = (T*)p.dst.p[0];
+
+  for (uint32_t t = wave; t < total; t += nwaves) {
+    const uint32_t qy = t / strips_x;
+    const uint32_t qx = (t - qy * strips_x) * 64 + lane;
+    if (qx >= qw) continue;
+    const uint32_t x = qx * 2, y = qy * 2;
+    // ---- loads: 2+2 luma bytes, 1+1 chroma bytes ------------------------------------------
+    const uint32_t ya = *(const uint16_t*)(yp + (size_t)y * sy + x);
+    const uint32_t yb = *(const uint16_t*)(yp + (size_t)(y + 1) * sy + x);
+    const int ub = up[(size_t)qy * su + qx], vb = vp[(size_t)qy * sv + qx];
+    // getYuv4abPixel (gainmapmath.cpp:370-374)
+    const float uf = (float)(ub - 128) * (1 / 255.0f);
+    const float vf = (float)(vb - 128) * (1 / 255.0f);
+    // p3YuvToRgb chroma products shared by the four pixels (gainmapmath.cpp:177-181)
+    const float crv = p.yuv.cr * vf, gcbu = p.yuv.gcb * uf, gcrv = p.yuv.gcr * vf, cbu = p.yuv.cb * uf;
+
+    const uint32_t yg = y + p.y0;
+    // ---- gain-map taps --------------------------------------------------------------------
+    float tap[(SMODE == 0) ? 1 : 4][NCH];
+    uint32_t ox = 0, oy = 0, tbl = 0;
+    uint32_t m0[2], m1[2];  // SMODE 0: raw map bytes of row 0 / row 1 (two pixels each)
+    if constexpr (SMODE == 0) {
+      const uint8_t* r0 = mp + ((size_t)yg * sm + x) * BPP;
+      const uint8_t* r1 = r0 + sm * BPP;
+      if constexpr (MAPFMT == 0) {
+        m0[0] = *(const uint16_t*)r0;
+        m1[0] = *(const uint16_t*)r1;
+      } else if constexpr (MAPFMT == 1) {  // 6 bytes per row: three aligned 16-bit loads
+        const uint16_t* a = (const uint16_t*)r0;
+        const uint16_t* b = (const uint16_t*)r1;
+        m0[0] = a[0] | ((uint32_t)a[1] << 16);
+        m0[1] = a[2];
+        m1[0] = b[0] | ((uint32_t)b[1] << 16);
+        m1[1] = b[2];
+      } else {
+        const uint2 a = *(const uint2*)r0, b = *(const uint2*)r1;
+        m0[0] = a.x; m0[1] = a.y;
+        m1[0] = b.x; m1[1] = b.y;
+      }
+    } else {
+      const uint32_t s = p.scale;
+      uint32_t xl = __umulhi(x, p.scale_magic), yl = __umulhi(yg, p.scale_magic);
+      ox = x - xl * s;
+      oy = yg - yl * s;
+      uint32_t xu = min(xl + 1, p.gm.w - 1), yu = min(yl + 1, p.gm.h - 1);
+      xl = min(xl, p.gm.w - 1);
+      yl = min(yl, p.gm.h - 1);
+      tbl = (xl == xu && yl == yu) ? 3 : (xl == xu) ? 1 : (yl == yu) ? 2 : 0;
+      const uint8_t* a1 = mp + (xl + yl * sm) * BPP;
+      const uint8_t* a2 = mp + (xl + yu * sm) * BPP;
+      const uint8_t* a3 = mp + (xu + yl * sm) * BPP;
+      const uint8_t* a4 = mp + (xu + yu * sm) * BPP;
+#pragma unroll
+      for (int c = 0; c < NCH; c++) {
+        tap[0][c] = s_u8f[a1[c]];
+        tap[1][c] = s_u8f[a2[c]];
+        tap[2][c] = s_u8f[a3[c]];
+        tap[3][c] = s_u8f[a4[c]];
+      }
+    }
+
+    T outp[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const uint32_t ybits = r == 0 ? ya : yb;
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        const float yf = (float)((ybits >> (8 * c)) & 0xff) * (1 / 255.0f);
+        const float gr = clamp01(yf + crv);
+        const float gg = clamp01(yf - gcbu - gcrv);
+        const float gb = clamp01(yf + cbu);
+        Color3 lin = {s_srgb[lut_index_f32<kSrgbN>(gr)], s_srgb[lut_index_f32<kSrgbN>(gg)],
+                      s_srgb[lut_index_f32<kSrgbN>(gb)]};
+        if (p.sdr_gamut_on) lin = mat3_apply(lin, p.gamut);
+        float f0, f1, f2;
+        if constexpr (SMODE == 0) {
+          const uint32_t* mrow = r == 0 ? m0 : m1;
+          if constexpr (MAPFMT == 0) {
+            f0 = f1 = f2 = s_fac[(mrow[0] >> (8 * c)) & 0xff];
+          } else if constexpr (MAPFMT == 1) {
+            // bytes: R0 G0 B0 R1 G1 B1 packed little-endian into mrow[0] (4) + mrow[1] (2)
+            const uint64_t v = (uint64_t)mrow[0] | ((uint64_t)mrow[1] << 32);
+            const uint32_t px = (uint32_t)(v >> (24 * c));
+            f0 = s_fac[px & 0xff];
+            f1 = s_fac[256 + ((px >> 8) & 0xff)];
+            f2 = s_fac[512 + ((px >> 16) & 0xff)];
+          } else {
+            const uint32_t px = mrow[c];
+            f0 = s_fac[px & 0xff];
+            f1 = s_fac[256 + ((px >> 8) & 0xff)];
+            f2 = s_fac[512 + ((px >> 16) & 0xff)];
+          }
+        } else {
+          const float4 w = *(const float4*)(s_idw + (size_t)tbl * p.scale * p.scale * 4 +
+                                            ((oy + r) * p.scale + (ox + c)) * 4);
+          float gn[NCH];
+#pragma unroll
+          for (int k = 0; k < NCH; k++)
+            gn[k] = tap[0][k] * w.x + tap[1][k] * w.y + tap[2][k] * w.z + tap[3][k] * w.w;
+          f0 = gain_factor(gn[0], s_gain, 0, p);
+          if constexpr (NCH == 3) {
+            f1 = gain_factor(gn[1], s_gain, 1, p);
+            f2 = gain_factor(gn[2], s_gain, 2, p);
+          } else {
+            f1 = f2 = f0;
+          }
+        }
+        outp[r][c] = finish_pixel<OUT>(lin, f0, f1, f2, p, NCH);
+      }
+    }
+    // ---- stores: two adjacent pixels per row -> one 16 B (F16) / 8 B (1010102) store ------
+    if constexpr (OUT == 0) {
+      uint4 s0 = {outp[0][0].x, outp[0][0].y, outp[0][1].x, outp[0][1].y};
+      uint4 s1 = {outp[1][0].x, outp[1][0].y, outp[1][1].x, outp[1][1].y};
+      *(uint4*)(dp + (size_t)y * sd + x) = s0;
+      *(uint4*)(dp + (size_t)(y + 1) * sd + x) = s1;
+    } else {
+      uint2 s0 = {outp[0][0], outp[0][1]};
+      uint2 s1 = {outp[1][0], outp[1][1]};
+      *(uint2*)(dp + (size_t)y * sd + x) = s0;
+      *(uint2*)(dp + (size_t)(y + 1) * sd + x) = s1;
+    }
+  }
+}
+
+template <int OUT, int MAPFMT>
+hipError_t launch_quad_s(const ApplyParams& p, int smode, int grid, hipStream_t s) {
+  if (smode == 0) hipLaunchKernelGGL((apply_quad_kernel<OUT, MAPFMT, 0>), dim3(grid), dim3(kBlock), 0, s, p);
+  else hipLaunchKernelGGL((apply_quad_kernel<OUT, MAPFMT, 1>), dim3(grid), dim3(kBlock), 0, s, p);
+  return hipGetLastError();
+}
+template <int OUT>
+hipError_t launch_quad_m(const ApplyParams& p, int mapfmt, int smode, int grid, hipStream_t s) {
+  switch (mapfmt) {
+    case 0: return launch_quad_s<OUT, 0>(p, smode, grid, s);
+    case 1: return launch_quad_s<OUT, 1>(p, smode, grid, s);
+    default: return launch_quad_s<OUT, 2>(p, smode, grid, s);
+  }
+}
+
+inline bool aligned_to(const void* ptr, size_t a) { return ((uintptr_t)ptr % a) == 0; }
+
+}  // namespace
+
+// Picks the quad kernel when its layout assumptions hold, otherwise the generic one.
+hipError_t launch_apply_gainmap(const ApplyParams& p, hipStream_t s) {
+  const int out = p.out_ct == UHDR_CT_LINEAR ? 0 : (p.out_ct == UHDR_CT_HLG ? 1 : 2);
+  const int mapfmt = p.gm.fmt == UHDR_IMG_FMT_8bppYCbCr400 ? 0
+                     : (p.gm.fmt == UHDR_IMG_FMT_24bppRGB888 ? 1 : 2);
+  const size_t out_bytes = out == 0 ? 8 : 4;
+  bool quad = p.sdr.fmt == UHDR_IMG_FMT_12bppYCbCr420 && (p.sdr.w % 2 == 0) && (p.sdr.h % 2 == 0) &&
+              (p.y0 % 2 == 0) && (p.sdr.stride[0] % 2 == 0) && aligned_to(p.sdr.p[0], 2) &&
+              aligned_to(p.dst.p[0], 16) && ((p.dst.stride[0] * out_bytes) % 16 == 0) &&
+              p.sdr.w < 65536 && (p.sdr.h + p.y0) < 65536;
+  int smode = -1;
+  if (quad) {
+    if (p.scale == 1) {
+      smode = 0;
+      // the gain map must cover every base pixel and allow the vector loads used per format
+      if (p.gm.w < p.sdr.w || p.gm.h < p.sdr.h + p.y0) quad = false;
+      if (mapfmt == 0 && !(p.gm.stride[0] % 2 == 0 && aligned_to(p.gm.p[0], 2))) quad = false;
+      if (mapfmt == 1 && !((p.gm.stride[0] * 3) % 2 == 0 && aligned_to(p.gm.p[0], 2))) quad = false;
+      if (mapfmt == 2 && !(p.gm.stride[0] % 2 == 0 && aligned_to(p.gm.p[0], 8))) quad = false;
+    } else if (p.scale >= 2 && p.scale % 2 == 0 && p.scale <= (uint32_t)kMaxIdwScaleLds) {
+      smode = 1;
+    } else {
+      quad = false;
+    }
+  }
+  if (quad) {
+    const uint32_t strips = ((p.sdr.w / 2 + 63) / 64) * (p.sdr.h / 2);
+    int grid = (int)min((uint32_t)((strips + 3) / 4), 2048u);
+    if (grid < 1) grid = 1;
+    switch (out) {
+      case 0: return launch_quad_m<0>(p, mapfmt, smode, grid, s);
+      case 1: return launch_quad_m<1>(p, mapfmt, smode, grid, s);
+      default: return launch_quad_m<2>(p, mapfmt, smode, grid, s);
+    }
+  }
+  const size_t total = (size_t)p.sdr.w * p.sdr.h;
+  int grid = (int)min((total + kBlock - 1) / kBlock, (size_t)4096);
+  if (grid < 1) grid = 1;
+  switch (out) {
+    case 0: hipLaunchKernelGGL((apply_generic_kernel<0>), dim3(grid), dim3(kBlock), 0, s, p); break;
+    case 1: hipLaunchKernelGGL((apply_generic_kernel<1>), dim3(grid), dim3(kBlock), 0, s, p); break;
+    default: hipLaunchKernelGGL((apply_generic_kernel<2>), dim3(grid), dim3(kBlock), 0, s, p); break;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace uhdr

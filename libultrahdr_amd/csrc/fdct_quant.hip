@@ -1,0 +1,170 @@
+// 8x8 forward DCT + quantize on gfx950, bit-exact to libjpeg's JDCT_ISLOW path.
+//
+// The arithmetic is NOT in the reference tree: libultrahdr hands planes to libjpeg
+// (/root/reference/lib/src/jpegencoderhelper.cpp:187-198 sets jpeg_set_quality(q, TRUE) and
+// dct_method = JDCT_ISLOW; :297 jpeg_write_raw_data).  What runs there is the public
+// Loeffler-Ligtenberg-Moschytz integer DCT (libjpeg jfdctint.c: CONST_BITS 13, PASS1_BITS 2, a
+// row pass scaled by 4 then a column pass, round-to-nearest descales) followed by jcdctmgr.c's
+// round-half-away division by (quantval << 3).  Integers only => results are exact.
+//
+// Mapping: one wavefront = 8 horizontally adjacent blocks (64 x 8 samples).  Row pass: lane
+// (row r = lane/8, block b = lane%8) loads its 8 samples with one 8-byte load -- 8 consecutive
+// lanes read 64 contiguous bytes -- and runs the 1-D butterfly in registers.  The 8x8 tiles are
+// transposed through LDS (row-padded to 9 words: conflict-free column reads), the column pass and
+// the quantizer run with lane = (block, column), and a second LDS transpose lets every lane emit
+// one coefficient ROW (8 x int16 = 16 bytes), so a wave writes 1 KiB contiguous in libjpeg's
+// JBLOCK order.  The quantizer divides by multiplying with ceil(2^32 / q) (exact for the 19-bit
+// magnitudes that occur; q <= 2040).
+#include "uhdr_types.h"
+
+namespace uhdr {
+namespace {
+
+constexpr int kBlock = 256;  // 4 waves = 32 blocks per workgroup iteration
+
+#define FIX_0_298631336 2446
+#define FIX_0_390180644 3196
+#define FIX_0_541196100 4433
+#define FIX_0_765366865 6270
+#define FIX_0_899976223 7373
+#define FIX_1_175875602 9633
+#define FIX_1_501321110 12299
+#define FIX_1_847759065 15137
+#define FIX_1_961570560 16069
+#define FIX_2_053119869 16819
+#define FIX_2_562915447 20995
+#define FIX_3_072711026 25172
+
+__device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+template <int PASS>
+__device__ __forceinline__ void fdct_1d(const int in[8], int out[8]) {
+  constexpr int sh = PASS == 0 ? 13 - 2 : 13 + 2;
+  int t0 = in[0] + in[7], t7 = in[0] - in[7], t1 = in[1] + in[6], t6 = in[1] - in[6];
+  int t2 = in[2] + in[5], t5 = in[2] - in[5], t3 = in[3] + in[4], t4 = in[3] - in[4];
+  const int t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+  if (PASS == 0) {
+    out[0] = (t10 + t11) * 4;
+    out[4] = (t10 - t11) * 4;
+  } else {
+    out[0] = descale(t10 + t11, 2);
+    out[4] = descale(t10 - t11, 2);
+  }
+  int z1 = (t12 + t13) * FIX_0_541196100;
+  out[2] = descale(z1 + t13 * FIX_0_765366865, sh);
+  out[6] = descale(z1 + t12 * (-FIX_1_847759065), sh);
+  z1 = t4 + t7;
+  int z2 = t5 + t6, z3 = t4 + t6, z4 = t5 + t7;
+  const int z5 = (z3 + z4) * FIX_1_175875602;
+  t4 *= FIX_0_298631336;
+  t5 *= FIX_2_053119869;
+  t6 *= FIX_3_072711026;
+  t7 *= FIX_1_501321110;
+  z1 *= -FIX_0_899976223;
+  z2 *= -FIX_2_562915447;
+  z3 *= -FIX_1_961570560;
+  z4 *= -FIX_0_390180644;
+  z3 += z5;
+  z4 += z5;
+  out[7] = descale(t4 + z1 + z3, sh);
+  out[5] = descale(t5 + z2 + z4, sh);
+  out[3] = descale(t6 + z2 + z3, sh);
+  out[1] = descale(t7 + z1 + z4, sh);
+}
+
+__global__ __launch_bounds__(kBlock) void fdct_quant_kernel(const uint8_t* __restrict__ plane,
+                                                            size_t stride, int bw, int bh,
+                                                            const uint16_t* __restrict__ qt,
+                                                            int16_t* __restrict__ coef) {
+  // per wave: 8 blocks x 8 rows x 9 (padded) words
+  __shared__ int s_ws[kBlock / 64][8 * 8 * 9];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int* ws = s_ws[wv];
+  const int groups_x = (bw + 7) >> 3;              // groups of 8 blocks per block-row
+  const int total = groups_x * bh;
+  const int gwave = blockIdx.x * (kBlock / 64) + wv;
+  const int nwaves = gridDim.x * (kBlock / 64);
+
+  // column-pass role: lane = (block cb, column cc); its 8 divisors never change
+  const int cb = lane >> 3, cc = lane & 7;
+  uint32_t qv[8], qm[8];
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    qv[r] = (uint32_t)qt[r * 8 + cc] << 3;
+    qm[r] = (uint32_t)((0x100000000ull + qv[r] - 1) / qv[r]);
+  }
+  // row-pass / store role: lane = (row rr, block rb)
+  const int rr = lane >> 3, rb = lane & 7;
+
+  for (int t = gwave; t < total; t += nwaves) {
+    const int by = t / groups_x, gx = t - by * groups_x;
+    const int bx = gx * 8 + rb;
+    int in[8], out[8];
+    if (bx < bw) {
+      const uint8_t* src = plane + (size_t)(by * 8 + rr) * stride + (size_t)bx * 8;
+      uint32_t lo, hi;
+      if (((uintptr_t)src & 3) == 0) {
+        lo = ((const uint32_t*)src)[0];
+        hi = ((const uint32_t*)src)[1];
+      } else {
+        lo = src[0] | (src[1] << 8) | (src[2] << 16) | ((uint32_t)src[3] << 24);
+        hi = src[4] | (src[5] << 8) | (src[6] << 16) | ((uint32_t)src[7] << 24);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        in[c] = (int)((lo >> (8 * c)) & 0xff) - 128;
+        in[4 + c] = (int)((hi >> (8 * c)) & 0xff) - 128;
+      }
+      fdct_1d<0>(in, out);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 8; c++) out[c] = 0;
+    }
+#pragma unroll
+    for (int c = 0; c < 8; c++) ws[rb * 72 + rr * 9 + c] = out[c];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS writes of this wave have landed
+    // column pass
+#pragma unroll
+    for (int r = 0; r < 8; r++) in[r] = ws[cb * 72 + r * 9 + cc];
+    fdct_1d<1>(in, out);
+#pragma unroll
+    for (int r = 0; r < 8; r++) {  // jcdctmgr.c forward_DCT quantizer
+      const int v = out[r];
+      uint32_t a = (uint32_t)(v < 0 ? -v : v) + (qv[r] >> 1);
+      uint32_t q = a >= qv[r] ? __umulhi(a, qm[r]) : 0u;
+      out[r] = v < 0 ? -(int)q : (int)q;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 8; r++) ws[cb * 72 + r * 9 + cc] = out[r];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    if (bx < bw) {
+      int v[8];
+#pragma unroll
+      for (int c = 0; c < 8; c++) v[c] = ws[rb * 72 + rr * 9 + c];
+      uint4 o;
+      o.x = (uint32_t)(v[0] & 0xffff) | ((uint32_t)v[1] << 16);
+      o.y = (uint32_t)(v[2] & 0xffff) | ((uint32_t)v[3] << 16);
+      o.z = (uint32_t)(v[4] & 0xffff) | ((uint32_t)v[5] << 16);
+      o.w = (uint32_t)(v[6] & 0xffff) | ((uint32_t)v[7] << 16);
+      *(uint4*)(coef + ((size_t)by * bw + bx) * 64 + rr * 8) = o;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+}  // namespace
+
+hipError_t launch_fdct_quant(const uint8_t* plane, size_t stride, int bw, int bh,
+                             const uint16_t* qt_dev, int16_t* coef, hipStream_t s) {
+  const int total = ((bw + 7) / 8) * bh;
+  int grid = (total + 3) / 4;
+  if (grid > 4096) grid = 4096;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(fdct_quant_kernel, dim3(grid), dim3(kBlock), 0, s, plane, stride, bw, bh, qt_dev, coef);
+  return hipGetLastError();
+}
+
+}  // namespace uhdr

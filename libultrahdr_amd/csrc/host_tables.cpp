@@ -1,0 +1,267 @@
+// Host-side table builders (see host_tables.h).
+//
+// Float-vs-double bookkeeping.  In the reference (as built by GCC/libstdc++ for x86-64) the
+// transfer functions in lib/src/gainmapmath.cpp call pow / log / exp / log2 / exp2 unqualified
+// from inside namespace ultrahdr with no using-directive in scope, so the C library's DOUBLE
+// overloads are selected and float arguments are promoted; results are narrowed when stored to a
+// float.  std::pow(float,float) and explicit powf stay single precision.  The built object's
+// import list (pow, log, exp, log2, exp2, powf, sqrtf) confirms this.  Every expression below is
+// written with the promotions explicit so that any host compiler produces the same tables.
+// This TU is compiled with -ffp-contract=off.
+#include "host_tables.h"
+
+#include <cfloat>
+#include <cmath>
+#include <mutex>
+
+namespace uhdr {
+namespace host {
+
+namespace {
+
+float srgb_inv_oetf(float e) {  // gainmapmath.cpp:114-120
+  if (e <= 0.04045f) return e / 12.92f;
+  return (float)std::pow((double)((e + 0.055f) / 1.055f), (double)2.4f);
+}
+const float kHlgA = 0.17883277f, kHlgB = 0.28466892f, kHlgC = 0.55991073f;
+float hlg_oetf(float e) {  // gainmapmath.cpp:238-244
+  if (e <= 1.0f / 12.0f) return sqrtf(3.0f * e);
+  return (float)((double)kHlgA * std::log((double)(12.0f * e - kHlgB)) + (double)kHlgC);
+}
+float hlg_inv_oetf(float e) {  // gainmapmath.cpp:259-265 (pow(x, 2.0) is x*x in double)
+  if (e <= 0.5f) return (float)(((double)e * (double)e) / (double)3.0f);
+  return (float)((std::exp((double)((e - kHlgC) / kHlgA)) + (double)kHlgB) / (double)12.0f);
+}
+const float kPqM1 = 2610.0f / 16384.0f, kPqM2 = 2523.0f / 4096.0f * 128.0f;
+const float kPqC1 = 3424.0f / 4096.0f, kPqC2 = 2413.0f / 4096.0f * 32.0f, kPqC3 = 2392.0f / 4096.0f * 32.0f;
+float pq_oetf(float e) {  // gainmapmath.cpp:313-316
+  if (e <= 0.0f) return 0.0f;
+  const double pw = std::pow((double)e, (double)kPqM1);
+  return (float)std::pow(((double)kPqC1 + (double)kPqC2 * pw) / (1 + (double)kPqC3 * pw), (double)kPqM2);
+}
+float pq_inv_oetf(float e) {  // gainmapmath.cpp:330-333
+  const float val = (float)std::pow((double)e, (double)(1 / kPqM2));
+  float num = val - kPqC1;
+  if (!(num > 0.0f)) num = 0.0f;
+  return (float)std::pow((double)(num / (kPqC2 - kPqC3 * val)), (double)(1 / kPqM1));
+}
+
+std::vector<float> make_lut(int n, float (*fn)(float)) {  // LookUpTable, gainmapmath.h:345-357
+  std::vector<float> t((size_t)n);
+  for (int i = 0; i < n; i++) t[(size_t)i] = fn((float)i / (float)(n - 1));
+  return t;
+}
+
+const float kSrgbR = 0.212639f, kSrgbG = 0.715169f, kSrgbB = 0.072192f;
+const float kP3R = 0.2289746f, kP3G = 0.6917385f, kP3B = 0.0792869f;
+const float kP3YR = 0.299f, kP3YG = 0.587f, kP3YB = 0.114f, kP3Cb = 1.772f, kP3Cr = 1.402f;
+const float kBt2100R = 0.2627f, kBt2100G = 0.677998f, kBt2100B = 0.059302f;
+
+const float kBt709ToP3[9] = {0.822462f, 0.177537f, 0.000001f, 0.033194f, 0.966807f, -0.000001f, 0.017083f, 0.072398f, 0.91052f};
+const float kBt709ToBt2100[9] = {0.627404f, 0.329282f, 0.043314f, 0.069097f, 0.919541f, 0.011362f, 0.016392f, 0.088013f, 0.895595f};
+const float kP3ToBt709[9] = {1.22494f, -0.22494f, 0.0f, -0.042057f, 1.042057f, 0.0f, -0.019638f, -0.078636f, 1.098274f};
+const float kP3ToBt2100[9] = {0.753833f, 0.198597f, 0.04757f, 0.045744f, 0.941777f, 0.012479f, -0.00121f, 0.017601f, 0.983608f};
+const float kBt2100ToBt709[9] = {1.660491f, -0.587641f, -0.07285f, -0.124551f, 1.1329f, -0.008349f, -0.018151f, -0.100579f, 1.11873f};
+const float kBt2100ToP3[9] = {1.343578f, -0.282179f, -0.061399f, -0.065298f, 1.075788f, -0.01049f, 0.002822f, -0.019598f, 1.016777f};
+
+const float kYuv709To601[9] = {1.0f, 0.101579f, 0.196076f, 0.0f, 0.989854f, -0.110653f, 0.0f, -0.072453f, 0.983398f};
+const float kYuv709To2100[9] = {1.0f, -0.016969f, 0.096312f, 0.0f, 0.995306f, -0.051192f, 0.0f, 0.011507f, 1.002637f};
+const float kYuv601To709[9] = {1.0f, -0.118188f, -0.212685f, 0.0f, 1.018640f, 0.114618f, 0.0f, 0.075049f, 1.025327f};
+const float kYuv601To2100[9] = {1.0f, -0.128245f, -0.115879, 0.0f, 1.010016f, 0.061592f, 0.0f, 0.086969f, 1.029350f};
+const float kYuv2100To709[9] = {1.0f, 0.018149f, -0.095132f, 0.0f, 1.004123f, 0.051267f, 0.0f, -0.011524f, 0.996782f};
+const float kYuv2100To601[9] = {1.0f, 0.117887f, 0.105521f, 0.0f, 0.995211f, -0.059549f, 0.0f, -0.084085f, 0.976518f};
+
+void set_mat(Mat3* o, const float* m) {
+  for (int i = 0; i < 9; i++) o->m[i] = m[i];
+}
+
+}  // namespace
+
+#define UHDR_STATIC_LUT(name, n, fn)                 \
+  const std::vector<float>& name() {                 \
+    static const std::vector<float> t = make_lut(n, fn); \
+    return t;                                        \
+  }
+UHDR_STATIC_LUT(srgb_inv_oetf_lut, kSrgbN, srgb_inv_oetf)
+UHDR_STATIC_LUT(hlg_inv_oetf_lut, kInvOetfN, hlg_inv_oetf)
+UHDR_STATIC_LUT(pq_inv_oetf_lut, kInvOetfN, pq_inv_oetf)
+UHDR_STATIC_LUT(hlg_oetf_lut, kOetfN, hlg_oetf)
+UHDR_STATIC_LUT(pq_oetf_lut, kOetfN, pq_oetf)
+
+Yuv2Rgb yuv2rgb_coeffs(int cg) {
+  Yuv2Rgb k;
+  if (cg == UHDR_CG_BT_709) {
+    const float cb = 2 * (1 - kSrgbB), cr = 2 * (1 - kSrgbR);
+    k.cb = cb; k.cr = cr;
+    k.gcb = kSrgbB * cb / kSrgbG;
+    k.gcr = kSrgbR * cr / kSrgbG;
+  } else if (cg == UHDR_CG_DISPLAY_P3) {
+    k.cb = kP3Cb; k.cr = kP3Cr;
+    k.gcb = kP3YB * kP3Cb / kP3YG;
+    k.gcr = kP3YR * kP3Cr / kP3YG;
+  } else {
+    const float cb = 2 * (1 - kBt2100B), cr = 2 * (1 - kBt2100R);
+    k.cb = cb; k.cr = cr;
+    k.gcb = kBt2100B * cb / kBt2100G;
+    k.gcr = kBt2100R * cr / kBt2100G;
+  }
+  return k;
+}
+Rgb2Yuv rgb2yuv_coeffs(int cg) {
+  Rgb2Yuv k;
+  if (cg == UHDR_CG_BT_709) {
+    k.yr = kSrgbR; k.yg = kSrgbG; k.yb = kSrgbB;
+    k.cb = 2 * (1 - kSrgbB); k.cr = 2 * (1 - kSrgbR);
+  } else if (cg == UHDR_CG_DISPLAY_P3) {
+    k.yr = kP3YR; k.yg = kP3YG; k.yb = kP3YB; k.cb = kP3Cb; k.cr = kP3Cr;
+  } else {
+    k.yr = kBt2100R; k.yg = kBt2100G; k.yb = kBt2100B;
+    k.cb = 2 * (1 - kBt2100B); k.cr = 2 * (1 - kBt2100R);
+  }
+  return k;
+}
+void luminance_coeffs(int cg, float out[3]) {
+  if (cg == UHDR_CG_BT_709) { out[0] = kSrgbR; out[1] = kSrgbG; out[2] = kSrgbB; }
+  else if (cg == UHDR_CG_DISPLAY_P3) { out[0] = kP3R; out[1] = kP3G; out[2] = kP3B; }
+  else { out[0] = kBt2100R; out[1] = kBt2100G; out[2] = kBt2100B; }
+}
+
+bool gamut_matrix(int dst, int src, Mat3* out, bool* identity) {
+  *identity = false;
+  if (dst < 0 || dst > 2 || src < 0 || src > 2) return false;
+  if (dst == src) { *identity = true; return true; }
+  const float* m;
+  if (dst == UHDR_CG_BT_709) m = src == UHDR_CG_DISPLAY_P3 ? kP3ToBt709 : kBt2100ToBt709;
+  else if (dst == UHDR_CG_DISPLAY_P3) m = src == UHDR_CG_BT_709 ? kBt709ToP3 : kBt2100ToP3;
+  else m = src == UHDR_CG_BT_709 ? kBt709ToBt2100 : kP3ToBt2100;
+  set_mat(out, m);
+  return true;
+}
+
+int yuv_encoding_matrix(int src, int dst, Mat3* out) {
+  if (src < 0 || src > 2) return -1;
+  if (dst < 0 || dst > 2) return -2;
+  if (src == dst) return 1;
+  const float* c;
+  if (src == UHDR_CG_BT_709) c = dst == UHDR_CG_DISPLAY_P3 ? kYuv709To601 : kYuv709To2100;
+  else if (src == UHDR_CG_DISPLAY_P3) c = dst == UHDR_CG_BT_709 ? kYuv601To709 : kYuv601To2100;
+  else c = dst == UHDR_CG_BT_709 ? kYuv2100To709 : kYuv2100To601;
+  set_mat(out, c);
+  return 0;
+}
+
+float reference_peak_nits(int ct) {
+  switch (ct) {
+    case UHDR_CT_LINEAR: return 10000.0f;
+    case UHDR_CT_HLG: return 1000.0f;
+    case UHDR_CT_PQ: return 10000.0f;
+    case UHDR_CT_SRGB: return 203.0f;
+    default: return -1.0f;
+  }
+}
+
+bool metadata_channels_identical(const uhdr_gainmap_metadata_t& m) {
+  return m.max_content_boost[0] == m.max_content_boost[1] && m.max_content_boost[0] == m.max_content_boost[2] &&
+         m.min_content_boost[0] == m.min_content_boost[1] && m.min_content_boost[0] == m.min_content_boost[2] &&
+         m.gamma[0] == m.gamma[1] && m.gamma[0] == m.gamma[2] && m.offset_sdr[0] == m.offset_sdr[1] &&
+         m.offset_sdr[0] == m.offset_sdr[2] && m.offset_hdr[0] == m.offset_hdr[1] &&
+         m.offset_hdr[0] == m.offset_hdr[2];
+}
+
+float gainmap_weight(const uhdr_gainmap_metadata_t& m, float max_display_boost) {
+  const float display_boost = max_display_boost < m.hdr_capacity_max ? max_display_boost : m.hdr_capacity_max;
+  if (display_boost == m.hdr_capacity_max) return 1.0f;
+  float w = (log2f(display_boost) - log2f(m.hdr_capacity_min)) /
+            (log2f(m.hdr_capacity_max) - log2f(m.hdr_capacity_min));
+  return (w < 0.0f) ? 0.0f : ((w > 1.0f) ? 1.0f : w);
+}
+
+void fill_idw(float* w, int s, int inc_r, int inc_b) {
+  auto dist = [](float x1, float x2, float y1, float y2) {
+    return sqrtf(((y2 - y1) * (y2 - y1)) + (x2 - x1) * (x2 - x1));
+  };
+  for (int y = 0; y < s; y++)
+    for (int x = 0; x < s; x++) {
+      const float px = ((float)x) / s, py = ((float)y) / s;
+      const int cx = (int)floorf(px), cy = (int)floorf(py);
+      const int nx = cx + inc_r, ny = cy + inc_b;
+      float* o = w + y * s * 4 + x * 4;
+      const float d1 = dist(px, (float)cx, py, (float)cy);
+      if (d1 == 0) {
+        o[0] = 1.f; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f;
+        continue;
+      }
+      const float w1 = 1.f / d1;
+      const float w2 = 1.f / dist(px, (float)cx, py, (float)ny);
+      const float w3 = 1.f / dist(px, (float)nx, py, (float)cy);
+      const float w4 = 1.f / dist(px, (float)nx, py, (float)ny);
+      const float tot = w1 + w2 + w3 + w4;
+      o[0] = w1 / tot; o[1] = w2 / tot; o[2] = w3 / tot; o[3] = w4 / tot;
+    }
+}
+
+void build_apply_tables(const uhdr_gainmap_metadata_t& m, float weight, int s, std::vector<float>* out) {
+  out->assign((size_t)ApplyTables::floats(s), 0.0f);
+  float* t = out->data();
+  const std::vector<float>& srgb = srgb_inv_oetf_lut();
+  for (int i = 0; i < kSrgbN; i++) t[ApplyTables::kSrgbOff + i] = srgb[(size_t)i];
+  // GainLUT (gainmapmath.h:452-470): double log2/exp2, logBoost narrowed to float, float product
+  // logBoost * weight fed to the double exp2.
+  const bool single = metadata_channels_identical(m);
+  for (int c = 0; c < 3; c++) {
+    float* g = t + ApplyTables::kGainOff + c * kGainN;
+    if (single && c > 0) {
+      for (int i = 0; i < kGainN; i++) g[i] = t[ApplyTables::kGainOff + i];
+      continue;
+    }
+    for (int i = 0; i < kGainN; i++) {
+      const float value = (float)i / (float)(kGainN - 1);
+      const float log_boost = (float)(std::log2((double)m.min_content_boost[c]) * (double)(1.0f - value) +
+                                      std::log2((double)m.max_content_boost[c]) * (double)value);
+      g[i] = (float)std::exp2((double)(log_boost * weight));
+    }
+  }
+  for (int b = 0; b < 256; b++) t[ApplyTables::kU8fOff + b] = (float)b / 255.0f;  // mapUintToFloat
+  // byte -> factor (scale-1 shortcut): getGainFactor (gainmapmath.h:483-489) applied to b/255
+  for (int c = 0; c < 3; c++) {
+    const int k = single ? 0 : c;
+    const float gamma_inv = 1.0f / m.gamma[k];
+    for (int b = 0; b < 256; b++) {
+      float gain = (float)b / 255.0f;
+      if (gamma_inv != 1.0f) gain = (float)std::pow((double)gain, (double)gamma_inv);
+      int idx = (int)((double)(gain * (float)(kGainN - 1)) + 0.5);
+      idx = idx < 0 ? 0 : (idx > kGainN - 1 ? kGainN - 1 : idx);
+      t[ApplyTables::kFacOff + c * 256 + b] = t[ApplyTables::kGainOff + k * kGainN + idx];
+    }
+  }
+  float* w = t + ApplyTables::kIdwOff;
+  const size_t n = (size_t)s * s * 4;
+  fill_idw(w, s, 1, 1);          // mWeights
+  fill_idw(w + n, s, 0, 1);      // mWeightsNR
+  fill_idw(w + 2 * n, s, 1, 0);  // mWeightsNB
+  fill_idw(w + 3 * n, s, 0, 0);  // mWeightsC
+}
+
+void jpeg_quant_table(int quality, int is_chroma, uint16_t qt[64]) {
+  static const uint8_t kLuma[64] = {16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55,
+                                    14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
+                                    18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92,
+                                    49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+  static const uint8_t kChroma[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99,
+                                      24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99,
+                                      99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99,
+                                      99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
+  if (quality <= 0) quality = 1;
+  if (quality > 100) quality = 100;
+  const int scale = quality < 50 ? 5000 / quality : 200 - quality * 2;
+  const uint8_t* base = is_chroma ? kChroma : kLuma;
+  for (int i = 0; i < 64; i++) {
+    long v = ((long)base[i] * scale + 50L) / 100L;
+    if (v <= 0L) v = 1L;
+    if (v > 255L) v = 255L;
+    qt[i] = (uint16_t)v;
+  }
+}
+
+}  // namespace host
+}  // namespace uhdr

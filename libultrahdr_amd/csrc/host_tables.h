@@ -1,0 +1,45 @@
+// Host-side table builders.  The look-up tables the reference builds lazily on the CPU
+// (LookUpTable, GainLUT, ShepardsIDW) are built here with the host's own libm -- the same libm the
+// reference would call on this machine -- and uploaded, because device transcendental functions
+// do not round identically to glibc's.  See host_tables.cpp for the per-call-site float/double
+// notes.
+#pragma once
+#include <vector>
+
+#include "uhdr_types.h"
+
+namespace uhdr {
+namespace host {
+
+const std::vector<float>& srgb_inv_oetf_lut();  // 1024  (gainmapmath.cpp:126-131)
+const std::vector<float>& hlg_inv_oetf_lut();   // 4096  (gainmapmath.cpp:271-277)
+const std::vector<float>& pq_inv_oetf_lut();    // 4096  (gainmapmath.cpp:339-345)
+const std::vector<float>& hlg_oetf_lut();       // 65536 (gainmapmath.cpp:248-254)
+const std::vector<float>& pq_oetf_lut();        // 65536 (gainmapmath.cpp:320-326)
+
+Yuv2Rgb yuv2rgb_coeffs(int cg);  // gainmapmath.cpp:94,104-105 / 164,174-175 / 194,226-227
+Rgb2Yuv rgb2yuv_coeffs(int cg);
+void luminance_coeffs(int cg, float out[3]);  // gainmapmath.cpp:86, 156, 187
+// getGamutConversionFn(dst, src) (gainmapmath.cpp:1087-1129): returns false for UNSPECIFIED;
+// *identity set when dst == src.
+bool gamut_matrix(int dst_cg, int src_cg, Mat3* out, bool* identity);
+// convertYuv coefficient choice (jpegr.cpp:436-502): 0 ok, 1 identity (nothing to do), <0 error
+int yuv_encoding_matrix(int src_cg, int dst_cg, Mat3* out);
+
+float reference_peak_nits(int ct);  // getReferenceDisplayPeakLuminanceInNits (gainmapmath.cpp:20-34)
+
+bool metadata_channels_identical(const uhdr_gainmap_metadata_t& m);  // ultrahdrcommon.h:218-226
+// gainmap_weight from the display boost (jpegr.cpp:1678-1689; log2f because jpegr.cpp has
+// `using namespace std`)
+float gainmap_weight(const uhdr_gainmap_metadata_t& m, float max_display_boost);
+// Fills the ApplyTables block (uhdr_types.h) for one applyGainMap call.
+void build_apply_tables(const uhdr_gainmap_metadata_t& m, float weight, int idw_scale,
+                        std::vector<float>* out);
+void fill_idw(float* w, int s, int inc_r, int inc_b);  // gainmapmath.cpp:43-80
+
+// libjpeg quality -> quant table (jcparam.c jpeg_quality_scaling / jpeg_add_quant_table with
+// force_baseline; natural order)
+void jpeg_quant_table(int quality, int is_chroma, uint16_t qt[64]);
+
+}  // namespace host
+}  // namespace uhdr

@@ -1,0 +1,113 @@
+// Device-side pixel fetch for every input format the hot path reads
+// (get*Pixel, /root/reference/lib/src/gainmapmath.cpp:354-492) and the s x s box sampler
+// (samplePixels, gainmapmath.cpp:494-504).
+#pragma once
+#include "uhdr_types.h"
+
+namespace uhdr {
+
+// Returns the pixel as the reference's Color: (y,u,v) for YCbCr formats, (r,g,b) for RGB ones.
+__device__ __forceinline__ Color3 fetch_pixel(const ImageView& im, uint32_t x, uint32_t y) {
+  Color3 c = {0.f, 0.f, 0.f};
+  switch (im.fmt) {
+    case UHDR_IMG_FMT_24bppYCbCr444:
+    case UHDR_IMG_FMT_16bppYCbCr422:
+    case UHDR_IMG_FMT_12bppYCbCr420: {
+      const uint32_t hf = im.fmt == UHDR_IMG_FMT_24bppYCbCr444 ? 1 : 2;
+      const uint32_t vf = im.fmt == UHDR_IMG_FMT_12bppYCbCr420 ? 2 : 1;
+      const int yy = ((const uint8_t*)im.p[0])[x + (size_t)y * im.stride[0]];
+      const int uu = ((const uint8_t*)im.p[1])[x / hf + (size_t)(y / vf) * im.stride[1]];
+      const int vv = ((const uint8_t*)im.p[2])[x / hf + (size_t)(y / vf) * im.stride[2]];
+      c.r = (float)yy * (1 / 255.0f);
+      c.g = (float)(uu - 128) * (1 / 255.0f);
+      c.b = (float)(vv - 128) * (1 / 255.0f);
+      break;
+    }
+    case UHDR_IMG_FMT_8bppYCbCr400:
+      c.r = (float)((const uint8_t*)im.p[0])[x + (size_t)y * im.stride[0]] * (1 / 255.0f);
+      break;
+    case UHDR_IMG_FMT_24bppYCbCrP010:
+    case UHDR_IMG_FMT_30bppYCbCr444: {
+      int yy, uu, vv;
+      if (im.fmt == UHDR_IMG_FMT_24bppYCbCrP010) {
+        const uint16_t* yp = (const uint16_t*)im.p[0];
+        const uint16_t* cp = (const uint16_t*)im.p[1];
+        const size_t ui = (size_t)(y >> 1) * im.stride[1] + (x & ~1u);
+        yy = yp[(size_t)y * im.stride[0] + x] >> 6;
+        uu = cp[ui] >> 6;
+        vv = cp[ui + 1] >> 6;
+      } else {
+        yy = ((const uint16_t*)im.p[0])[(size_t)y * im.stride[0] + x];
+        uu = ((const uint16_t*)im.p[1])[(size_t)y * im.stride[1] + x];
+        vv = ((const uint16_t*)im.p[2])[(size_t)y * im.stride[2] + x];
+      }
+      if (im.range == UHDR_CR_FULL_RANGE) {
+        c.r = (float)yy / 1023.0f;
+        c.g = (float)uu / 1023.0f - 0.5f;
+        c.b = (float)vv / 1023.0f - 0.5f;
+      } else {
+        c.r = (float)(yy - 64) * (1 / 876.0f);
+        c.g = (float)(uu - 64) * (1 / 896.0f) - 0.5f;
+        c.b = (float)(vv - 64) * (1 / 896.0f) - 0.5f;
+      }
+      break;
+    }
+    case UHDR_IMG_FMT_24bppRGB888: {
+      const uint8_t* q = (const uint8_t*)im.p[0] + (size_t)x * 3 + (size_t)y * im.stride[0] * 3;
+      c.r = (float)q[0] / 255.0f;
+      c.g = (float)q[1] / 255.0f;
+      c.b = (float)q[2] / 255.0f;
+      break;
+    }
+    case UHDR_IMG_FMT_32bppRGBA8888: {
+      const uint32_t v = ((const uint32_t*)im.p[0])[x + (size_t)y * im.stride[0]];
+      c.r = (float)(v & 0xff) / 255.0f;
+      c.g = (float)((v >> 8) & 0xff) / 255.0f;
+      c.b = (float)((v >> 16) & 0xff) / 255.0f;
+      break;
+    }
+    case UHDR_IMG_FMT_32bppRGBA1010102: {
+      const uint32_t v = ((const uint32_t*)im.p[0])[x + (size_t)y * im.stride[0]];
+      c.r = (float)(v & 0x3ff) / 1023.0f;
+      c.g = (float)((v >> 10) & 0x3ff) / 1023.0f;
+      c.b = (float)((v >> 20) & 0x3ff) / 1023.0f;
+      break;
+    }
+    case UHDR_IMG_FMT_64bppRGBAHalfFloat: {
+      const uint2 v = ((const uint2*)im.p[0])[x + (size_t)y * im.stride[0]];
+      c.r = sanitize_linear(half_to_float_ref(v.x & 0xffff));
+      c.g = sanitize_linear(half_to_float_ref(v.x >> 16));
+      c.b = sanitize_linear(half_to_float_ref(v.y & 0xffff));
+      break;
+    }
+    default: break;
+  }
+  return c;
+}
+
+// samplePixels: sum over the s x s box (dy outer, dx inner), then one divide per channel.
+__device__ __forceinline__ Color3 sample_box(const ImageView& im, uint32_t s, uint32_t x, uint32_t y) {
+  if (s == 1) {  // e = 0 + p; e / 1.0f  == p bit for bit (0.0f + p == p, p / 1 == p)
+    return fetch_pixel(im, x, y);
+  }
+  Color3 e = {0.0f, 0.0f, 0.0f};
+  for (uint32_t dy = 0; dy < s; ++dy)
+    for (uint32_t dx = 0; dx < s; ++dx) {
+      const Color3 q = fetch_pixel(im, x * s + dx, y * s + dy);
+      e.r += q.r;
+      e.g += q.g;
+      e.b += q.b;
+    }
+  const float d = (float)(s * s);
+  e.r /= d;
+  e.g /= d;
+  e.b /= d;
+  return e;
+}
+
+__device__ __forceinline__ bool is_rgb_fmt(int fmt) {  // isPixelFormatRgb, gainmapmath.cpp:1274-1277
+  return fmt == UHDR_IMG_FMT_64bppRGBAHalfFloat || fmt == UHDR_IMG_FMT_32bppRGBA8888 ||
+         fmt == UHDR_IMG_FMT_32bppRGBA1010102;
+}
+
+}  // namespace uhdr

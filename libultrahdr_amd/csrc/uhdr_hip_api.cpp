@@ -1,0 +1,952 @@
+// C ABI of libuhdr_hip.so (include/uhdr_hip.h): argument validation that mirrors the reference
+// operators, per-call table preparation, host<->device staging and kernel launches.
+// There is deliberately NO CPU implementation behind these entry points: if HIP is unusable the
+// calls fail with UHDR_CODEC_ERROR.
+#include <cfloat>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "host_tables.h"
+#include "uhdr_types.h"
+
+using namespace uhdr;
+
+// -------------------------------------------------------------------------------------------------
+// helpers
+// -------------------------------------------------------------------------------------------------
+static uhdr_error_info_t ok_status() {
+  uhdr_error_info_t s;
+  s.error_code = UHDR_CODEC_OK;
+  s.has_detail = 0;
+  s.detail[0] = 0;
+  return s;
+}
+static uhdr_error_info_t err_status(uhdr_codec_err_t code, const char* fmt, ...) {
+  uhdr_error_info_t s;
+  s.error_code = code;
+  s.has_detail = 1;
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(s.detail, sizeof s.detail, fmt, ap);
+  va_end(ap);
+  return s;
+}
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess)                                                                  \
+      return err_status(e_ == hipErrorOutOfMemory ? UHDR_CODEC_MEM_ERROR : UHDR_CODEC_ERROR, \
+                        "HIP error '%s' at %s:%d", hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+#define UHDR_TRY(expr)                                 \
+  do {                                                 \
+    uhdr_error_info_t s_ = (expr);                     \
+    if (s_.error_code != UHDR_CODEC_OK) return s_;     \
+  } while (0)
+
+namespace {
+
+struct ProfEntry {
+  hipEvent_t a, b;
+  std::string family;
+};
+
+constexpr int kTableSlots = 4;
+
+struct DeviceBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+}  // namespace
+
+struct uhdr_hip_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  // static LUTs on the device
+  float* d_srgb = nullptr;
+  float* d_hlg_inv = nullptr;
+  float* d_pq_inv = nullptr;
+  float* d_hlg_oetf = nullptr;
+  float* d_pq_oetf = nullptr;
+  // per-call apply tables: ring of pinned host slots + matching device slots
+  float* h_tab[kTableSlots] = {};
+  float* d_tab[kTableSlots] = {};
+  size_t tab_cap[kTableSlots] = {};
+  hipEvent_t tab_ev[kTableSlots] = {};
+  std::string tab_key[kTableSlots];
+  int tab_next = 0;
+  // scratch for host-buffer entry points and two-pass generation
+  DeviceBuf scratch[8];
+  DeviceBuf minmax;  // 6 + 2048*6 floats
+  uint16_t* d_qt = nullptr;
+  // profiling
+  bool prof = false;
+  std::vector<ProfEntry> prof_entries;
+};
+
+namespace {
+
+uhdr_error_info_t ensure(DeviceBuf& b, size_t bytes) {
+  if (b.cap >= bytes) return ok_status();
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+  size_t want = bytes + (bytes >> 3) + 256;
+  HIP_TRY(hipMalloc(&b.p, want));
+  b.cap = want;
+  return ok_status();
+}
+
+struct ProfScope {
+  uhdr_hip_ctx* c;
+  ProfEntry e;
+  bool on;
+  ProfScope(uhdr_hip_ctx* ctx, const char* family) : c(ctx), on(ctx->prof) {
+    if (!on) return;
+    e.family = family;
+    if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) { on = false; return; }
+    (void)hipEventRecord(e.a, c->stream);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(e.b, c->stream);
+    c->prof_entries.push_back(e);
+  }
+};
+
+size_t bytes_per_sample(int fmt) {
+  switch (fmt) {
+    case UHDR_IMG_FMT_24bppYCbCrP010:
+    case UHDR_IMG_FMT_30bppYCbCr444: return 2;
+    case UHDR_IMG_FMT_24bppRGB888: return 3;
+    case UHDR_IMG_FMT_32bppRGBA8888:
+    case UHDR_IMG_FMT_32bppRGBA1010102: return 4;
+    case UHDR_IMG_FMT_64bppRGBAHalfFloat: return 8;
+    default: return 1;
+  }
+}
+// rows and row-width (in stride units) of plane `pl`; returns false if the plane does not exist
+bool plane_geom(const uhdr_raw_image_t* im, int pl, size_t* rows, size_t* width) {
+  const size_t w = im->w, h = im->h;
+  switch (im->fmt) {
+    case UHDR_IMG_FMT_24bppYCbCrP010:
+      if (pl == 0) { *rows = h; *width = w; return true; }
+      if (pl == 1) { *rows = (h + 1) / 2; *width = ((w + 1) / 2) * 2; return true; }
+      return false;
+    case UHDR_IMG_FMT_12bppYCbCr420:
+      if (pl == 0) { *rows = h; *width = w; } else { *rows = (h + 1) / 2; *width = (w + 1) / 2; }
+      return true;
+    case UHDR_IMG_FMT_16bppYCbCr422:
+      if (pl == 0) { *rows = h; *width = w; } else { *rows = h; *width = (w + 1) / 2; }
+      return true;
+    case UHDR_IMG_FMT_24bppYCbCr444:
+    case UHDR_IMG_FMT_30bppYCbCr444:
+      *rows = h; *width = w; return true;
+    default:
+      if (pl == 0) { *rows = h; *width = w; return true; }
+      return false;
+  }
+}
+size_t plane_bytes(const uhdr_raw_image_t* im, int pl) {
+  size_t rows, width;
+  if (!plane_geom(im, pl, &rows, &width) || rows == 0) return 0;
+  return ((rows - 1) * (size_t)im->stride[pl] + width) * bytes_per_sample(im->fmt);
+}
+
+ImageView view_of(const uhdr_raw_image_t* im) {
+  ImageView v;
+  for (int i = 0; i < 3; i++) { v.p[i] = im->planes[i]; v.stride[i] = im->stride[i]; }
+  v.w = im->w; v.h = im->h; v.fmt = im->fmt; v.range = im->range;
+  return v;
+}
+ImageViewMut view_mut_of(const uhdr_raw_image_t* im) {
+  ImageViewMut v;
+  for (int i = 0; i < 3; i++) { v.p[i] = im->planes[i]; v.stride[i] = im->stride[i]; }
+  v.w = im->w; v.h = im->h; v.fmt = im->fmt; v.range = im->range;
+  return v;
+}
+
+// Stage a host image into device scratch `slot` (all planes packed back to back, 256-B aligned);
+// *dev gets device plane pointers.  upload=false only reserves space (outputs).
+uhdr_error_info_t stage_in(uhdr_hip_ctx* c, int slot, const uhdr_raw_image_t* host, uhdr_raw_image_t* dev,
+                           bool upload) {
+  size_t off[3] = {0, 0, 0}, total = 0;
+  for (int pl = 0; pl < 3; pl++) {
+    size_t b = plane_bytes(host, pl);
+    if (b && !host->planes[pl])
+      return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for plane %d of image format %d", pl, host->fmt);
+    off[pl] = total;
+    total += (b + 255) & ~(size_t)255;
+  }
+  UHDR_TRY(ensure(c->scratch[slot], total ? total : 256));
+  *dev = *host;
+  for (int pl = 0; pl < 3; pl++) {
+    size_t b = plane_bytes(host, pl);
+    dev->planes[pl] = b ? (char*)c->scratch[slot].p + off[pl] : nullptr;
+    if (b && upload) HIP_TRY(hipMemcpyAsync(dev->planes[pl], host->planes[pl], b, hipMemcpyHostToDevice, c->stream));
+  }
+  return ok_status();
+}
+// Copies back only the w samples of every row, so the caller's stride padding stays untouched
+// (the reference never writes there either).
+uhdr_error_info_t stage_out(uhdr_hip_ctx* c, const uhdr_raw_image_t* dev, uhdr_raw_image_t* host) {
+  for (int pl = 0; pl < 3; pl++) {
+    size_t rows, width;
+    if (!plane_geom(host, pl, &rows, &width) || rows == 0 || !host->planes[pl]) continue;
+    const size_t bps = bytes_per_sample(host->fmt);
+    const size_t pitch = (size_t)host->stride[pl] * bps;
+    if (rows == 1 || pitch == width * bps) {
+      HIP_TRY(hipMemcpyAsync(host->planes[pl], dev->planes[pl], ((rows - 1) * (size_t)host->stride[pl] + width) * bps,
+                             hipMemcpyDeviceToHost, c->stream));
+    } else {
+      HIP_TRY(hipMemcpy2DAsync(host->planes[pl], pitch, dev->planes[pl], pitch, width * bps, rows,
+                               hipMemcpyDeviceToHost, c->stream));
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return ok_status();
+}
+
+uhdr_error_info_t upload_lut(float** dst, const std::vector<float>& src, hipStream_t s) {
+  if (*dst) return ok_status();
+  HIP_TRY(hipMalloc((void**)dst, src.size() * sizeof(float)));
+  HIP_TRY(hipMemcpyAsync(*dst, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return ok_status();
+}
+
+// uhdr_validate_gainmap_metadata_descriptor (ultrahdr_api.cpp:431-503)
+uhdr_error_info_t validate_metadata(const uhdr_gainmap_metadata_t* m) {
+  if (!m) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for gainmap metadata descriptor");
+  uhdr_error_info_t st = ok_status();
+  for (int i = 0; i < 3; i++) {
+    if (!std::isfinite(m->min_content_boost[i]) || !std::isfinite(m->max_content_boost[i]) ||
+        !std::isfinite(m->offset_sdr[i]) || !std::isfinite(m->offset_hdr[i]) ||
+        !std::isfinite(m->hdr_capacity_min) || !std::isfinite(m->hdr_capacity_max) || !std::isfinite(m->gamma[i])) {
+      st = err_status(UHDR_CODEC_INVALID_PARAM, "Field(s) of gainmap metadata descriptor are either NaN or infinite");
+    } else if (m->max_content_boost[i] < m->min_content_boost[i]) {
+      st = err_status(UHDR_CODEC_INVALID_PARAM, "received bad value for content boost max %f, expects to be >= content boost min %f",
+                      m->max_content_boost[i], m->min_content_boost[i]);
+    } else if (m->min_content_boost[i] <= 0.0f) {
+      return err_status(UHDR_CODEC_INVALID_PARAM, "received bad value for min boost %f, expects > 0.0f", m->min_content_boost[i]);
+    } else if (m->gamma[i] <= 0.0f) {
+      st = err_status(UHDR_CODEC_INVALID_PARAM, "received bad value for gamma %f, expects > 0.0f", m->gamma[i]);
+    } else if (m->offset_sdr[i] < 0.0f) {
+      st = err_status(UHDR_CODEC_INVALID_PARAM, "received bad value for offset sdr %f, expects to be >= 0.0f", m->offset_sdr[i]);
+    } else if (m->offset_hdr[i] < 0.0f) {
+      st = err_status(UHDR_CODEC_INVALID_PARAM, "received bad value for offset hdr %f, expects to be >= 0.0f", m->offset_hdr[i]);
+    } else if (m->hdr_capacity_max <= m->hdr_capacity_min) {
+      st = err_status(UHDR_CODEC_INVALID_PARAM, "received bad value for hdr capacity max %f, expects to be > hdr capacity min %f",
+                      m->hdr_capacity_max, m->hdr_capacity_min);
+    } else if (m->hdr_capacity_min < 1.0f) {
+      st = err_status(UHDR_CODEC_INVALID_PARAM, "received bad value for hdr capacity min %f, expects to be >= 1.0f", m->hdr_capacity_min);
+    }
+  }
+  return st;
+}
+
+bool is_rgb_fmt_host(int fmt) {
+  return fmt == UHDR_IMG_FMT_64bppRGBAHalfFloat || fmt == UHDR_IMG_FMT_32bppRGBA8888 ||
+         fmt == UHDR_IMG_FMT_32bppRGBA1010102;
+}
+
+// argument checks of UltraHdr::applyGainMap (jpegr.cpp:1538-1614), in the reference's order
+uhdr_error_info_t validate_apply(const uhdr_raw_image_t* sdr, const uhdr_raw_image_t* gm,
+                                 const uhdr_gainmap_metadata_t* md, uhdr_color_transfer_t out_ct,
+                                 const uhdr_raw_image_t* dest) {
+  if (dest == nullptr || dest->planes[UHDR_PLANE_PACKED] == nullptr)
+    return err_status(UHDR_CODEC_INVALID_PARAM, "apply gainmap method received nullptr for destination image or plane pointer");
+  if (dest->stride[UHDR_PLANE_PACKED] < dest->w)
+    return err_status(UHDR_CODEC_INVALID_PARAM, "destination stride (%u) cannot be less than image width (%u)",
+                      dest->stride[UHDR_PLANE_PACKED], dest->w);
+  if (out_ct != UHDR_CT_LINEAR && out_ct != UHDR_CT_HLG && out_ct != UHDR_CT_PQ)
+    return err_status(UHDR_CODEC_INVALID_PARAM,
+                      "apply gainmap method expects output color transfer to be one of {UHDR_CT_LINEAR, UHDR_CT_HLG, UHDR_CT_PQ}. Received %d", out_ct);
+  if ((out_ct == UHDR_CT_LINEAR && dest->fmt != UHDR_IMG_FMT_64bppRGBAHalfFloat) ||
+      ((out_ct == UHDR_CT_HLG || out_ct == UHDR_CT_PQ) && dest->fmt != UHDR_IMG_FMT_32bppRGBA1010102))
+    return err_status(UHDR_CODEC_INVALID_PARAM, "unsupported destination pixel format %d for output color transfer %d", dest->fmt, out_ct);
+  UHDR_TRY(validate_metadata(md));
+  if (!sdr || !gm) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for base image or gainmap image");
+  if (sdr->fmt != UHDR_IMG_FMT_24bppYCbCr444 && sdr->fmt != UHDR_IMG_FMT_16bppYCbCr422 &&
+      sdr->fmt != UHDR_IMG_FMT_12bppYCbCr420 && sdr->fmt != UHDR_IMG_FMT_24bppRGB888 &&
+      sdr->fmt != UHDR_IMG_FMT_32bppRGBA8888)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "apply gainmap method expects base image color format to be one of "
+                      "{UHDR_IMG_FMT_24bppYCbCr444, UHDR_IMG_FMT_16bppYCbCr422, UHDR_IMG_FMT_12bppYCbCr420, "
+                      "UHDR_IMG_FMT_24bppRGB888, UHDR_IMG_FMT_32bppRGBA8888}. Received %d", sdr->fmt);
+  if (gm->fmt != UHDR_IMG_FMT_8bppYCbCr400 && gm->fmt != UHDR_IMG_FMT_24bppRGB888 && gm->fmt != UHDR_IMG_FMT_32bppRGBA8888)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "apply gainmap method expects gainmap image color format to be one of "
+                      "{UHDR_IMG_FMT_8bppYCbCr400, UHDR_IMG_FMT_24bppRGB888, UHDR_IMG_FMT_32bppRGBA8888}. Received %d", gm->fmt);
+  return ok_status();
+}
+
+// acquire a table slot holding the ApplyTables block for (metadata, weight, scale)
+uhdr_error_info_t get_apply_tables(uhdr_hip_ctx* c, const uhdr_gainmap_metadata_t& md, float weight,
+                                   int idw_scale, const float** d_out) {
+  std::string key((const char*)&md, sizeof md);
+  key.append((const char*)&weight, sizeof weight);
+  key.append((const char*)&idw_scale, sizeof idw_scale);
+  for (int i = 0; i < kTableSlots; i++)
+    if (c->tab_cap[i] && c->tab_key[i] == key) { *d_out = c->d_tab[i]; return ok_status(); }
+  const int slot = c->tab_next;
+  c->tab_next = (c->tab_next + 1) % kTableSlots;
+  std::vector<float> t;
+  host::build_apply_tables(md, weight, idw_scale, &t);
+  const size_t bytes = t.size() * sizeof(float);
+  if (c->tab_cap[slot]) HIP_TRY(hipEventSynchronize(c->tab_ev[slot]));  // previous upload from this slot done
+  if (c->tab_cap[slot] < bytes) {
+    // a kernel may still be reading the old device block: drain the stream before freeing it
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->h_tab[slot]) (void)hipHostFree(c->h_tab[slot]);
+    if (c->d_tab[slot]) (void)hipFree(c->d_tab[slot]);
+    c->h_tab[slot] = nullptr; c->d_tab[slot] = nullptr; c->tab_cap[slot] = 0;
+    HIP_TRY(hipHostMalloc((void**)&c->h_tab[slot], bytes, hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void**)&c->d_tab[slot], bytes));
+    if (!c->tab_ev[slot]) HIP_TRY(hipEventCreateWithFlags(&c->tab_ev[slot], hipEventDisableTiming));
+    c->tab_cap[slot] = bytes;
+  }
+  memcpy(c->h_tab[slot], t.data(), bytes);
+  HIP_TRY(hipMemcpyAsync(c->d_tab[slot], c->h_tab[slot], bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipEventRecord(c->tab_ev[slot], c->stream));
+  c->tab_key[slot] = key;
+  *d_out = c->d_tab[slot];
+  return ok_status();
+}
+
+}  // namespace
+
+// -------------------------------------------------------------------------------------------------
+// context
+// -------------------------------------------------------------------------------------------------
+#pragma GCC visibility push(default)
+extern "C" {
+
+const char* uhdr_hip_version(void) { return "libuhdr_hip 0.1 (gfx950; reference libultrahdr 2.0.2 hot path)"; }
+
+int uhdr_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+uhdr_hip_ctx_t* uhdr_hip_create(int device, uhdr_error_info_t* err) {
+  auto fail = [&](const char* what, hipError_t e) -> uhdr_hip_ctx_t* {
+    if (err) *err = err_status(UHDR_CODEC_ERROR, "uhdr_hip_create: %s failed: %s (no CPU fallback exists behind this library)",
+                               what, hipGetErrorString(e));
+    return nullptr;
+  };
+  if (err) *err = ok_status();
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0) return fail("hipGetDeviceCount", e == hipSuccess ? hipErrorNoDevice : e);
+  if (device < 0) {
+    e = hipGetDevice(&device);
+    if (e != hipSuccess) return fail("hipGetDevice", e);
+  }
+  if (device >= n) return fail("device index", hipErrorInvalidDevice);
+  e = hipSetDevice(device);
+  if (e != hipSuccess) return fail("hipSetDevice", e);
+  uhdr_hip_ctx* c = new uhdr_hip_ctx();
+  c->device = device;
+  e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete c; return fail("hipStreamCreate", e); }
+  c->stream = c->own_stream;
+  uhdr_error_info_t st = upload_lut(&c->d_srgb, host::srgb_inv_oetf_lut(), c->stream);
+  if (st.error_code != UHDR_CODEC_OK) {
+    if (err) *err = st;
+    (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return nullptr;
+  }
+  return c;
+}
+
+void uhdr_hip_destroy(uhdr_hip_ctx_t* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& e : c->prof_entries) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  float* luts[] = {c->d_srgb, c->d_hlg_inv, c->d_pq_inv, c->d_hlg_oetf, c->d_pq_oetf};
+  for (float* p : luts) if (p) (void)hipFree(p);
+  for (int i = 0; i < kTableSlots; i++) {
+    if (c->h_tab[i]) (void)hipHostFree(c->h_tab[i]);
+    if (c->d_tab[i]) (void)hipFree(c->d_tab[i]);
+    if (c->tab_ev[i]) (void)hipEventDestroy(c->tab_ev[i]);
+  }
+  for (auto& b : c->scratch) if (b.p) (void)hipFree(b.p);
+  if (c->minmax.p) (void)hipFree(c->minmax.p);
+  if (c->d_qt) (void)hipFree(c->d_qt);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+uhdr_error_info_t uhdr_hip_set_stream(uhdr_hip_ctx_t* c, void* hip_stream) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+  return ok_status();
+}
+
+uhdr_error_info_t uhdr_hip_synchronize(uhdr_hip_ctx_t* c) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return ok_status();
+}
+
+void uhdr_hip_profile_enable(uhdr_hip_ctx_t* c, int enable) {
+  if (c) c->prof = enable != 0;
+}
+
+int uhdr_hip_profile_read(uhdr_hip_ctx_t* c, const char* family, double* total_ms, int reset) {
+  if (!c) return 0;
+  (void)hipStreamSynchronize(c->stream);
+  int n = 0;
+  double tot = 0.0;
+  std::vector<ProfEntry> keep;
+  for (auto& e : c->prof_entries) {
+    const bool match = !family || e.family == family;
+    if (match) {
+      float ms = 0.0f;
+      if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { tot += ms; n++; }
+    }
+    if (match && reset) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    else keep.push_back(e);
+  }
+  if (reset) c->prof_entries.swap(keep);
+  if (total_ms) *total_ms = tot;
+  return n;
+}
+
+// -------------------------------------------------------------------------------------------------
+// applyGainMap
+// -------------------------------------------------------------------------------------------------
+uhdr_error_info_t uhdr_hip_apply_gainmap_dev(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* sdr,
+                                             const uhdr_raw_image_t* gm, const uhdr_gainmap_metadata_t* md,
+                                             uhdr_color_transfer_t out_ct, uhdr_img_fmt_t out_fmt,
+                                             float max_display_boost, uhdr_raw_image_t* dest, unsigned int y0,
+                                             unsigned int full_height) {
+  (void)out_fmt;
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  UHDR_TRY(validate_apply(sdr, gm, md, out_ct, dest));
+  HIP_TRY(hipSetDevice(c->device));
+
+  // colour-space bookkeeping (jpegr.cpp:1616-1631)
+  const int sdr_cg = sdr->cg == UHDR_CG_UNSPECIFIED ? UHDR_CG_BT_709 : sdr->cg;
+  const int hdr_cg = gm->cg == UHDR_CG_UNSPECIFIED ? sdr_cg : gm->cg;
+  dest->cg = (uhdr_color_gamut_t)hdr_cg;
+  ApplyParams p;
+  memset(&p, 0, sizeof p);
+  bool identity = false;
+  if (!host::gamut_matrix(hdr_cg, sdr_cg, &p.gamut, &identity))
+    return err_status(UHDR_CODEC_ERROR, "No implementation available for converting from gamut %d to %d", sdr_cg, hdr_cg);
+  p.hdr_gamut_on = (md->use_base_cg && !identity) ? 1 : 0;
+  p.sdr_gamut_on = (!md->use_base_cg && !identity) ? 1 : 0;
+
+  if (gm->w == 0 || gm->h == 0 || sdr->w == 0 || sdr->h == 0)
+    return err_status(UHDR_CODEC_INVALID_PARAM, "received image with zero width or height");
+  // aspect-ratio guard (jpegr.cpp:1651-1671) on the WHOLE image's height
+  const unsigned int whole_h = full_height ? full_height : sdr->h;
+  if (full_height == 0 && y0 != 0)
+    return err_status(UHDR_CODEC_INVALID_PARAM, "stripe offset y0=%u given without the full image height", y0);
+  if ((uint64_t)y0 + sdr->h > whole_h)
+    return err_status(UHDR_CODEC_INVALID_PARAM, "stripe rows [%u, %u) exceed the full image height %u", y0, y0 + sdr->h, whole_h);
+  {
+    const float pa = (float)sdr->w / whole_h, ga = (float)gm->w / gm->h;
+    if (fabsf(pa - ga) / pa > 0.01f)
+      return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE,
+                        "gain map aspect ratio differs from the base image (%ux%u vs %ux%u): the reference's "
+                        "resize_image fallback (jpegr.cpp:1659) is outside the HIP hot path",
+                        gm->w, gm->h, sdr->w, whole_h);
+  }
+  const float msf = (float)sdr->w / gm->w;
+  int msf_rnd = (int)roundf(msf);
+  if (msf_rnd < 1) msf_rnd = 1;
+  const bool use_table = (msf == floorf(msf));
+  p.scale = use_table ? (uint32_t)msf : 0u;
+  p.scale_magic = p.scale > 1 ? (uint32_t)((0x100000000ull + p.scale - 1) / p.scale) : 0u;
+  p.scale_f = msf;
+  if (use_table && (sdr->w >= 65536 || (uint64_t)sdr->h + y0 >= 65536))
+    return err_status(UHDR_CODEC_INVALID_PARAM, "image dimensions beyond 65535 are not supported");
+
+  const float weight = host::gainmap_weight(*md, max_display_boost);
+  UHDR_TRY(get_apply_tables(c, *md, weight, use_table ? (int)p.scale : msf_rnd, &p.tables));
+  if (out_ct == UHDR_CT_HLG) {
+    UHDR_TRY(upload_lut(&c->d_hlg_oetf, host::hlg_oetf_lut(), c->stream));
+    p.oetf_lut = c->d_hlg_oetf;
+  } else if (out_ct == UHDR_CT_PQ) {
+    UHDR_TRY(upload_lut(&c->d_pq_oetf, host::pq_oetf_lut(), c->stream));
+    p.oetf_lut = c->d_pq_oetf;
+  }
+  p.sdr = view_of(sdr);
+  p.gm = view_of(gm);
+  p.dst = view_mut_of(dest);
+  p.y0 = y0;
+  p.map_ch = gm->fmt == UHDR_IMG_FMT_8bppYCbCr400 ? 1 : 3;
+  p.map_bpp = gm->fmt == UHDR_IMG_FMT_8bppYCbCr400 ? 1 : (gm->fmt == UHDR_IMG_FMT_32bppRGBA8888 ? 4 : 3);
+  p.out_ct = out_ct;
+  p.sdr_is_rgb = is_rgb_fmt_host(sdr->fmt) ? 1 : 0;  // RGB888 is NOT in isPixelFormatRgb (gainmapmath.cpp:1274)
+  const bool single = host::metadata_channels_identical(*md);
+  for (int i = 0; i < 3; i++) {
+    const int k = single ? 0 : i;
+    p.gamma_inv[i] = 1.0f / md->gamma[k];
+    p.gamma_is_one[i] = p.gamma_inv[i] == 1.0f ? 1 : 0;
+    p.offset_sdr[i] = md->offset_sdr[i];
+    p.offset_hdr[i] = md->offset_hdr[i];
+  }
+  p.yuv = host::yuv2rgb_coeffs(UHDR_CG_DISPLAY_P3);
+  {
+    ProfScope ps(c, "apply_gainmap");
+    HIP_TRY(launch_apply_gainmap(p, c->stream));
+  }
+  return ok_status();
+}
+
+uhdr_error_info_t uhdr_hip_apply_gainmap(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* sdr,
+                                         const uhdr_raw_image_t* gm, const uhdr_gainmap_metadata_t* md,
+                                         uhdr_color_transfer_t out_ct, uhdr_img_fmt_t out_fmt,
+                                         float max_display_boost, uhdr_raw_image_t* dest) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  UHDR_TRY(validate_apply(sdr, gm, md, out_ct, dest));
+  HIP_TRY(hipSetDevice(c->device));
+  uhdr_raw_image_t dsdr, dgm, ddst;
+  UHDR_TRY(stage_in(c, 0, sdr, &dsdr, true));
+  UHDR_TRY(stage_in(c, 1, gm, &dgm, true));
+  UHDR_TRY(stage_in(c, 2, dest, &ddst, false));
+  uhdr_error_info_t st = uhdr_hip_apply_gainmap_dev(c, &dsdr, &dgm, md, out_ct, out_fmt, max_display_boost, &ddst, 0, 0);
+  if (st.error_code != UHDR_CODEC_OK) return st;
+  dest->cg = ddst.cg;
+  return stage_out(c, &ddst, dest);
+}
+
+// -------------------------------------------------------------------------------------------------
+// generateGainMap
+// -------------------------------------------------------------------------------------------------
+static uhdr_error_info_t fill_gen_params(uhdr_hip_ctx* c, const uhdr_raw_image_t* sdr, const uhdr_raw_image_t* hdr,
+                                         const uhdr_hip_encode_cfg_t* cfg, GenParams* p, int* use_base_cg,
+                                         float* hdr_white_nits_out) {
+  if (!sdr || !hdr || !cfg) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument");
+  // format checks: jpegr.cpp:537-562
+  if (sdr->fmt != UHDR_IMG_FMT_24bppYCbCr444 && sdr->fmt != UHDR_IMG_FMT_16bppYCbCr422 &&
+      sdr->fmt != UHDR_IMG_FMT_12bppYCbCr420 && sdr->fmt != UHDR_IMG_FMT_32bppRGBA8888)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "generate gainmap method expects sdr intent color format to be one of "
+                      "{UHDR_IMG_FMT_24bppYCbCr444, UHDR_IMG_FMT_16bppYCbCr422, UHDR_IMG_FMT_12bppYCbCr420, "
+                      "UHDR_IMG_FMT_32bppRGBA8888}. Received %d", sdr->fmt);
+  if (hdr->fmt != UHDR_IMG_FMT_24bppYCbCrP010 && hdr->fmt != UHDR_IMG_FMT_30bppYCbCr444 &&
+      hdr->fmt != UHDR_IMG_FMT_32bppRGBA1010102 && hdr->fmt != UHDR_IMG_FMT_64bppRGBAHalfFloat)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "generate gainmap method expects hdr intent color format to be one of "
+                      "{UHDR_IMG_FMT_24bppYCbCrP010, UHDR_IMG_FMT_30bppYCbCr444, UHDR_IMG_FMT_32bppRGBA1010102, "
+                      "UHDR_IMG_FMT_64bppRGBAHalfFloat}. Received %d", hdr->fmt);
+  if (hdr->ct < UHDR_CT_LINEAR || hdr->ct > UHDR_CT_SRGB)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "No implementation available for converting transfer characteristics %d to linear", hdr->ct);
+  if (hdr->cg < UHDR_CG_BT_709 || hdr->cg > UHDR_CG_BT_2100)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "No implementation available for calculating luminance for color gamut %d", hdr->cg);
+  if (sdr->cg < UHDR_CG_BT_709 || sdr->cg > UHDR_CG_BT_2100)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "No implementation available for converting yuv to rgb for color gamut %d", sdr->cg);
+  if (sdr->w != hdr->w || sdr->h != hdr->h)
+    return err_status(UHDR_CODEC_INVALID_PARAM, "sdr intent resolution %ux%u and hdr intent resolution %ux%u do not match",
+                      sdr->w, sdr->h, hdr->w, hdr->h);
+  if (cfg->map_dimension_scale_factor < 1)
+    return err_status(UHDR_CODEC_INVALID_PARAM, "gainmap scale factor %d is not positive", cfg->map_dimension_scale_factor);
+  memset(p, 0, sizeof *p);
+  const float hdr_white_nits = host::reference_peak_nits(hdr->ct);
+  *hdr_white_nits_out = hdr_white_nits;
+  // gamut handling: jpegr.cpp:605-638 with kWriteXmpMetadata == false (ISO-only build, the default)
+  int use_sdr_cg = 1;
+  bool identity;
+  if (sdr->cg != hdr->cg) {
+    use_sdr_cg = !(hdr->cg == UHDR_CG_BT_2100 || (hdr->cg == UHDR_CG_DISPLAY_P3 && sdr->cg != UHDR_CG_BT_2100));
+    if (use_sdr_cg) {
+      host::gamut_matrix(sdr->cg, hdr->cg, &p->hdr_gamut, &identity);
+      p->hdr_gamut_on = 1;
+    } else {
+      host::gamut_matrix(hdr->cg, sdr->cg, &p->sdr_gamut, &identity);
+      p->sdr_gamut_on = 1;
+    }
+  }
+  *use_base_cg = use_sdr_cg;
+  p->sdr_yuv = host::yuv2rgb_coeffs(cfg->sdr_is_601 ? UHDR_CG_DISPLAY_P3 : sdr->cg);
+  p->hdr_yuv = host::yuv2rgb_coeffs(hdr->cg);
+  host::luminance_coeffs(sdr->cg, p->lum);
+  p->sdr = view_of(sdr);
+  p->hdr = view_of(hdr);
+  uint32_t scale = (uint32_t)cfg->map_dimension_scale_factor;
+  uint32_t mw = sdr->w / scale, mh = sdr->h / scale;
+  if (mw == 0 || mh == 0) {  // jpegr.cpp:696-706
+    uint32_t s = sdr->w < sdr->h ? sdr->w : sdr->h;
+    s = (s >= 8) ? (s / 8) : 1;
+    scale = s;
+    mw = sdr->w / scale;
+    mh = sdr->h / scale;
+  }
+  p->scale = scale; p->map_w = mw; p->map_h = mh;
+  p->srgb_lut = c->d_srgb;
+  p->hdr_is_hlg = hdr->ct == UHDR_CT_HLG;
+  if (hdr->ct == UHDR_CT_HLG) {
+    UHDR_TRY(upload_lut(&c->d_hlg_inv, host::hlg_inv_oetf_lut(), c->stream));
+    p->hdr_inv_lut = c->d_hlg_inv; p->hdr_inv_n = kInvOetfN;
+  } else if (hdr->ct == UHDR_CT_PQ) {
+    UHDR_TRY(upload_lut(&c->d_pq_inv, host::pq_inv_oetf_lut(), c->stream));
+    p->hdr_inv_lut = c->d_pq_inv; p->hdr_inv_n = kInvOetfN;
+  } else if (hdr->ct == UHDR_CT_SRGB) {
+    p->hdr_inv_lut = c->d_srgb; p->hdr_inv_n = kSrgbN;
+  }
+  p->sdr_is_rgb = is_rgb_fmt_host(sdr->fmt);
+  p->hdr_is_rgb = is_rgb_fmt_host(hdr->fmt);
+  p->multichannel = cfg->use_multi_channel_gainmap != 0;
+  p->use_luminance = cfg->use_luminance != 0;
+  p->hdr_nits = hdr->ct == UHDR_CT_LINEAR ? 203.0f : hdr_white_nits;
+  p->gamma = cfg->gamma;
+  return ok_status();
+}
+
+static void fill_gainmap_desc(const uhdr_raw_image_t* hdr, const GenParams& p, uhdr_raw_image_t* gm) {
+  gm->fmt = p.multichannel ? UHDR_IMG_FMT_24bppRGB888 : UHDR_IMG_FMT_8bppYCbCr400;
+  gm->cg = hdr->cg; gm->ct = hdr->ct; gm->range = hdr->range;
+  gm->w = p.map_w; gm->h = p.map_h;
+}
+
+uhdr_error_info_t uhdr_hip_generate_gainmap_finalize(const uhdr_hip_encode_cfg_t* cfg, uhdr_color_transfer_t hdr_ct,
+                                                     int use_base_cg, float mm[6], uhdr_gainmap_metadata_t* md) {
+  if (!cfg || !mm || !md) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument");
+  const int nch = cfg->use_multi_channel_gainmap ? 3 : 1;
+  float* gmin = mm;
+  float* gmax = mm + 3;
+  for (int i = 0; i < nch; i++) {  // jpegr.cpp:969-986
+    gmin[i] = gmin[i] < -14.3f ? -14.3f : (gmin[i] > 15.6f ? 15.6f : gmin[i]);
+    gmax[i] = gmax[i] < -14.3f ? -14.3f : (gmax[i] > 15.6f ? 15.6f : gmax[i]);
+    if (cfg->max_content_boost != FLT_MAX) {
+      const float s = log2f(cfg->max_content_boost);
+      gmax[i] = gmax[i] < s ? gmax[i] : s;
+    }
+    if (cfg->min_content_boost != FLT_MIN) {
+      const float s = log2f(cfg->min_content_boost);
+      gmin[i] = gmin[i] < s ? s : gmin[i];
+    }
+    if (fabsf(gmax[i] - gmin[i]) < FLT_EPSILON) gmax[i] += 0.1f;
+  }
+  for (int i = 0; i < 3; i++) {  // jpegr.cpp:1031-1048
+    const int k = nch == 3 ? i : 0;
+    md->max_content_boost[i] = exp2f(gmax[k]);
+    md->min_content_boost[i] = exp2f(gmin[k]);
+    md->gamma[i] = cfg->gamma;
+    md->offset_sdr[i] = 1e-7f;
+    md->offset_hdr[i] = 1e-7f;
+  }
+  const float hdr_white_nits = host::reference_peak_nits(hdr_ct);
+  md->hdr_capacity_min = 1.0f;
+  md->hdr_capacity_max = cfg->target_disp_peak_nits != -1.0f ? cfg->target_disp_peak_nits / 203.0f : hdr_white_nits / 203.0f;
+  md->use_base_cg = use_base_cg;
+  return ok_status();
+}
+
+uhdr_error_info_t uhdr_hip_generate_gainmap_pass1_dev(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* sdr,
+                                                      const uhdr_raw_image_t* hdr, const uhdr_hip_encode_cfg_t* cfg,
+                                                      float* gain_log2_dev, float* minmax_dev, int* use_base_cg) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  if (!gain_log2_dev || !minmax_dev || !use_base_cg) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument");
+  HIP_TRY(hipSetDevice(c->device));
+  GenParams p;
+  float white;
+  UHDR_TRY(fill_gen_params(c, sdr, hdr, cfg, &p, use_base_cg, &white));
+  UHDR_TRY(ensure(c->minmax, (6 + 2048 * 6) * sizeof(float)));
+  p.gain_log2 = gain_log2_dev;
+  p.minmax = (float*)c->minmax.p;
+  {
+    ProfScope ps(c, "generate_gainmap");
+    HIP_TRY(launch_generate_gainmap(p, true, c->stream));
+  }
+  HIP_TRY(hipMemcpyAsync(minmax_dev, c->minmax.p, 6 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  return ok_status();
+}
+
+uhdr_error_info_t uhdr_hip_generate_gainmap_pass2_dev(uhdr_hip_ctx_t* c, const float* gain_log2_dev, const float mm[6],
+                                                      const uhdr_hip_encode_cfg_t* cfg, uhdr_raw_image_t* gm) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  if (!gain_log2_dev || !mm || !cfg || !gm || !gm->planes[0]) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument");
+  if (gm->stride[0] < gm->w) return err_status(UHDR_CODEC_INVALID_PARAM, "gainmap stride (%u) cannot be less than its width (%u)", gm->stride[0], gm->w);
+  HIP_TRY(hipSetDevice(c->device));
+  AffineParams a;
+  a.gain_log2 = gain_log2_dev;
+  a.out = (uint8_t*)gm->planes[0];
+  a.map_w = gm->w; a.map_h = gm->h; a.out_stride = gm->stride[0];
+  a.nch = cfg->use_multi_channel_gainmap ? 3 : 1;
+  for (int i = 0; i < 3; i++) { a.mn[i] = mm[i]; a.mx[i] = mm[3 + i]; }
+  a.gamma = cfg->gamma;
+  ProfScope ps(c, "generate_gainmap");
+  HIP_TRY(launch_affine_map(a, c->stream));
+  return ok_status();
+}
+
+uhdr_error_info_t uhdr_hip_generate_gainmap_dev(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* sdr, const uhdr_raw_image_t* hdr,
+                                                const uhdr_hip_encode_cfg_t* cfg, uhdr_gainmap_metadata_t* md,
+                                                uhdr_raw_image_t* gm) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  if (!md || !gm || !gm->planes[0]) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for gainmap metadata or image");
+  HIP_TRY(hipSetDevice(c->device));
+  GenParams p;
+  int use_base_cg = 1;
+  float hdr_white_nits;
+  UHDR_TRY(fill_gen_params(c, sdr, hdr, cfg, &p, &use_base_cg, &hdr_white_nits));
+  fill_gainmap_desc(hdr, p, gm);
+  if (gm->stride[0] < gm->w) return err_status(UHDR_CODEC_INVALID_PARAM, "gainmap stride (%u) cannot be less than its width (%u)", gm->stride[0], gm->w);
+  if (cfg->preset == UHDR_USAGE_REALTIME) {  // one pass: jpegr.cpp:724-737
+    for (int i = 0; i < 3; i++) {
+      md->max_content_boost[i] = hdr_white_nits / 203.0f;
+      md->min_content_boost[i] = 1.0f;
+      md->gamma[i] = cfg->gamma;
+      md->offset_sdr[i] = 0.0f;
+      md->offset_hdr[i] = 0.0f;
+    }
+    md->hdr_capacity_min = 1.0f;
+    md->hdr_capacity_max = cfg->target_disp_peak_nits != -1.0f ? cfg->target_disp_peak_nits / 203.0f : md->max_content_boost[0];
+    md->use_base_cg = use_base_cg;
+    p.min_boost = md->min_content_boost[0];
+    p.max_boost = md->max_content_boost[0];
+    p.log2min = log2f(md->min_content_boost[0]);
+    p.log2max = log2f(md->max_content_boost[0]);
+    p.out = (uint8_t*)gm->planes[0];
+    p.out_stride = gm->stride[0];
+    ProfScope ps(c, "generate_gainmap");
+    HIP_TRY(launch_generate_gainmap(p, false, c->stream));
+    return ok_status();
+  }
+  // two pass on one device
+  const size_t nfl = (size_t)p.map_w * p.map_h * (p.multichannel ? 3 : 1);
+  UHDR_TRY(ensure(c->scratch[7], nfl * sizeof(float)));
+  UHDR_TRY(ensure(c->minmax, (6 + 2048 * 6) * sizeof(float)));
+  p.gain_log2 = (float*)c->scratch[7].p;
+  p.minmax = (float*)c->minmax.p;
+  {
+    ProfScope ps(c, "generate_gainmap");
+    HIP_TRY(launch_generate_gainmap(p, true, c->stream));
+  }
+  float mm[6];
+  HIP_TRY(hipMemcpyAsync(mm, c->minmax.p, sizeof mm, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  UHDR_TRY(uhdr_hip_generate_gainmap_finalize(cfg, hdr->ct, use_base_cg, mm, md));
+  return uhdr_hip_generate_gainmap_pass2_dev(c, p.gain_log2, mm, cfg, gm);
+}
+
+uhdr_error_info_t uhdr_hip_generate_gainmap(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* sdr, const uhdr_raw_image_t* hdr,
+                                            const uhdr_hip_encode_cfg_t* cfg, uhdr_gainmap_metadata_t* md,
+                                            uhdr_raw_image_t* gm) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  if (!sdr || !hdr || !cfg || !md || !gm || !gm->planes[0]) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument");
+  HIP_TRY(hipSetDevice(c->device));
+  uhdr_raw_image_t dsdr, dhdr;
+  UHDR_TRY(stage_in(c, 0, sdr, &dsdr, true));
+  UHDR_TRY(stage_in(c, 1, hdr, &dhdr, true));
+  // size the device gain map from the same rule the kernels use
+  uint32_t scale = (uint32_t)(cfg->map_dimension_scale_factor < 1 ? 1 : cfg->map_dimension_scale_factor);
+  uint32_t mw = sdr->w / scale, mh = sdr->h / scale;
+  if (mw == 0 || mh == 0) {
+    uint32_t s = sdr->w < sdr->h ? sdr->w : sdr->h;
+    s = (s >= 8) ? (s / 8) : 1;
+    mw = sdr->w / s; mh = sdr->h / s;
+  }
+  uhdr_raw_image_t tmp = *gm;
+  tmp.fmt = cfg->use_multi_channel_gainmap ? UHDR_IMG_FMT_24bppRGB888 : UHDR_IMG_FMT_8bppYCbCr400;
+  tmp.w = mw; tmp.h = mh;
+  if (tmp.stride[0] < mw) return err_status(UHDR_CODEC_INVALID_PARAM, "gainmap stride (%u) cannot be less than its width (%u)", tmp.stride[0], mw);
+  uhdr_raw_image_t dgm;
+  UHDR_TRY(stage_in(c, 2, &tmp, &dgm, false));
+  UHDR_TRY(uhdr_hip_generate_gainmap_dev(c, &dsdr, &dhdr, cfg, md, &dgm));
+  void* host_plane = gm->planes[0];
+  const unsigned host_stride = gm->stride[0];
+  *gm = dgm;
+  gm->planes[0] = host_plane; gm->planes[1] = gm->planes[2] = nullptr;
+  gm->stride[0] = host_stride; gm->stride[1] = gm->stride[2] = 0;
+  return stage_out(c, &dgm, gm);
+}
+
+// -------------------------------------------------------------------------------------------------
+// toneMap
+// -------------------------------------------------------------------------------------------------
+uhdr_error_info_t uhdr_hip_tone_map_dev(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* hdr, uhdr_raw_image_t* sdr) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  if (!hdr || !sdr) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument");
+  // checks: jpegr.cpp:1986-2103
+  if (hdr->fmt != UHDR_IMG_FMT_24bppYCbCrP010 && hdr->fmt != UHDR_IMG_FMT_30bppYCbCr444 &&
+      hdr->fmt != UHDR_IMG_FMT_32bppRGBA1010102 && hdr->fmt != UHDR_IMG_FMT_64bppRGBAHalfFloat)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "tonemap method expects hdr intent color format to be one of "
+                      "{UHDR_IMG_FMT_24bppYCbCrP010, UHDR_IMG_FMT_30bppYCbCr444, UHDR_IMG_FMT_32bppRGBA1010102, "
+                      "UHDR_IMG_FMT_64bppRGBAHalfFloat}. Received %d", hdr->fmt);
+  if (hdr->fmt == UHDR_IMG_FMT_24bppYCbCrP010 && sdr->fmt != UHDR_IMG_FMT_12bppYCbCr420)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "tonemap method expects sdr intent color format to be UHDR_IMG_FMT_12bppYCbCr420, if "
+                      "hdr intent color format is UHDR_IMG_FMT_24bppYCbCrP010. Received %d", sdr->fmt);
+  if (hdr->fmt == UHDR_IMG_FMT_30bppYCbCr444 && sdr->fmt != UHDR_IMG_FMT_24bppYCbCr444)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "tonemap method expects sdr intent color format to be UHDR_IMG_FMT_24bppYCbCr444, if "
+                      "hdr intent color format is UHDR_IMG_FMT_30bppYCbCr444. Received %d", sdr->fmt);
+  if ((hdr->fmt == UHDR_IMG_FMT_32bppRGBA1010102 || hdr->fmt == UHDR_IMG_FMT_64bppRGBAHalfFloat) &&
+      sdr->fmt != UHDR_IMG_FMT_32bppRGBA8888)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "tonemap method expects sdr intent color format to be UHDR_IMG_FMT_32bppRGBA8888, if "
+                      "hdr intent color format is UHDR_IMG_FMT_32bppRGBA1010102 or UHDR_IMG_FMT_64bppRGBAHalfFloat. Received %d", sdr->fmt);
+  if (hdr->cg < UHDR_CG_BT_709 || hdr->cg > UHDR_CG_BT_2100)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "No implementation available for converting yuv to rgb for color gamut %d", hdr->cg);
+  if (hdr->ct < UHDR_CT_LINEAR || hdr->ct > UHDR_CT_SRGB)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "No implementation available for calculating Ootf for color transfer %d", hdr->ct);
+  if (sdr->w != hdr->w || sdr->h != hdr->h)
+    return err_status(UHDR_CODEC_INVALID_PARAM, "sdr intent resolution %ux%u and hdr intent resolution %ux%u do not match",
+                      sdr->w, sdr->h, hdr->w, hdr->h);
+  HIP_TRY(hipSetDevice(c->device));
+  sdr->cg = UHDR_CG_DISPLAY_P3;
+  sdr->ct = UHDR_CT_SRGB;
+  sdr->range = UHDR_CR_FULL_RANGE;
+  ToneMapParams p;
+  memset(&p, 0, sizeof p);
+  p.hdr = view_of(hdr);
+  p.sdr = view_mut_of(sdr);
+  if (hdr->ct == UHDR_CT_HLG) {
+    UHDR_TRY(upload_lut(&c->d_hlg_inv, host::hlg_inv_oetf_lut(), c->stream));
+    p.hdr_inv_lut = c->d_hlg_inv; p.hdr_inv_n = kInvOetfN;
+  } else if (hdr->ct == UHDR_CT_PQ) {
+    UHDR_TRY(upload_lut(&c->d_pq_inv, host::pq_inv_oetf_lut(), c->stream));
+    p.hdr_inv_lut = c->d_pq_inv; p.hdr_inv_n = kInvOetfN;
+  } else if (hdr->ct == UHDR_CT_SRGB) {
+    p.hdr_inv_lut = c->d_srgb; p.hdr_inv_n = kSrgbN;
+  }
+  p.hdr_is_hlg = hdr->ct == UHDR_CT_HLG;
+  p.hdr_is_rgb = is_rgb_fmt_host(hdr->fmt);
+  p.is_normalized = hdr->ct != UHDR_CT_LINEAR;
+  p.headroom = host::reference_peak_nits(hdr->ct) / 203.0f;
+  bool identity;
+  host::gamut_matrix(UHDR_CG_DISPLAY_P3, hdr->cg, &p.gamut, &identity);
+  p.gamut_on = identity ? 0 : 1;
+  p.hdr_yuv = host::yuv2rgb_coeffs(hdr->cg);
+  p.p3 = host::rgb2yuv_coeffs(UHDR_CG_DISPLAY_P3);
+  ProfScope ps(c, "tone_map");
+  HIP_TRY(launch_tone_map(p, c->stream));
+  return ok_status();
+}
+
+uhdr_error_info_t uhdr_hip_tone_map(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* hdr, uhdr_raw_image_t* sdr) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  if (!hdr || !sdr) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument");
+  HIP_TRY(hipSetDevice(c->device));
+  uhdr_raw_image_t dh, ds;
+  UHDR_TRY(stage_in(c, 0, hdr, &dh, true));
+  UHDR_TRY(stage_in(c, 1, sdr, &ds, false));
+  UHDR_TRY(uhdr_hip_tone_map_dev(c, &dh, &ds));
+  sdr->cg = ds.cg; sdr->ct = ds.ct; sdr->range = ds.range;
+  return stage_out(c, &ds, sdr);
+}
+
+// -------------------------------------------------------------------------------------------------
+// convertYuv / convert_raw_input_to_ycbcr
+// -------------------------------------------------------------------------------------------------
+uhdr_error_info_t uhdr_hip_convert_yuv_dev(uhdr_hip_ctx_t* c, uhdr_raw_image_t* img, uhdr_color_gamut_t src, uhdr_color_gamut_t dst) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  if (!img) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument");
+  YuvXformParams p;
+  const int r = host::yuv_encoding_matrix(src, dst, &p.c);
+  if (r == -1) return err_status(UHDR_CODEC_INVALID_PARAM, "Unrecognized src color gamut %d", src);
+  if (r == -2) return err_status(UHDR_CODEC_INVALID_PARAM, "Unrecognized dest color gamut %d", dst);
+  if (r == 1) return ok_status();
+  if (img->fmt != UHDR_IMG_FMT_12bppYCbCr420 && img->fmt != UHDR_IMG_FMT_24bppYCbCr444)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "No implementation available for performing gamut conversion for color format %d", img->fmt);
+  HIP_TRY(hipSetDevice(c->device));
+  p.img = view_mut_of(img);
+  ProfScope ps(c, "convert_yuv");
+  HIP_TRY(launch_transform_yuv(p, c->stream));
+  return ok_status();
+}
+
+uhdr_error_info_t uhdr_hip_convert_yuv(uhdr_hip_ctx_t* c, uhdr_raw_image_t* img, uhdr_color_gamut_t src, uhdr_color_gamut_t dst) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  if (!img) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument");
+  HIP_TRY(hipSetDevice(c->device));
+  uhdr_raw_image_t d;
+  UHDR_TRY(stage_in(c, 0, img, &d, true));
+  UHDR_TRY(uhdr_hip_convert_yuv_dev(c, &d, src, dst));
+  return stage_out(c, &d, img);
+}
+
+uhdr_error_info_t uhdr_hip_convert_raw_input_to_ycbcr_dev(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* src, int chroma, uhdr_raw_image_t* dst) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  if (!src || !dst) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument");
+  if (src->fmt != UHDR_IMG_FMT_32bppRGBA1010102 && src->fmt != UHDR_IMG_FMT_32bppRGBA8888 && src->fmt != UHDR_IMG_FMT_24bppRGB888)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "convert_raw_input_to_ycbcr on the device handles RGB inputs; format %d is a plain copy in the reference", src->fmt);
+  if (src->cg < UHDR_CG_BT_709 || src->cg > UHDR_CG_BT_2100)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "unrecognized color gamut %d", src->cg);
+  HIP_TRY(hipSetDevice(c->device));
+  const bool ten = src->fmt == UHDR_IMG_FMT_32bppRGBA1010102;
+  dst->fmt = ten ? (chroma ? UHDR_IMG_FMT_24bppYCbCrP010 : UHDR_IMG_FMT_30bppYCbCr444)
+                 : (chroma ? UHDR_IMG_FMT_12bppYCbCr420 : UHDR_IMG_FMT_24bppYCbCr444);
+  dst->cg = src->cg; dst->ct = src->ct; dst->range = UHDR_CR_FULL_RANGE;
+  dst->w = src->w; dst->h = src->h;
+  for (int pl = 0; pl < 3; pl++)
+    if (plane_bytes(dst, pl) && !dst->planes[pl])
+      return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for destination plane %d", pl);
+  RgbToYcbcrParams p;
+  p.src = view_of(src);
+  p.dst = view_mut_of(dst);
+  p.k = host::rgb2yuv_coeffs(src->cg);
+  ProfScope ps(c, "convert_raw_input_to_ycbcr");
+  HIP_TRY(launch_rgb_to_ycbcr(p, c->stream));
+  return ok_status();
+}
+
+uhdr_error_info_t uhdr_hip_convert_raw_input_to_ycbcr(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* src, int chroma, uhdr_raw_image_t* dst) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  if (!src || !dst) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument");
+  HIP_TRY(hipSetDevice(c->device));
+  const bool ten = src->fmt == UHDR_IMG_FMT_32bppRGBA1010102;
+  uhdr_raw_image_t tmp = *dst;
+  tmp.fmt = ten ? (chroma ? UHDR_IMG_FMT_24bppYCbCrP010 : UHDR_IMG_FMT_30bppYCbCr444)
+                : (chroma ? UHDR_IMG_FMT_12bppYCbCr420 : UHDR_IMG_FMT_24bppYCbCr444);
+  tmp.w = src->w; tmp.h = src->h;
+  uhdr_raw_image_t ds, dd;
+  UHDR_TRY(stage_in(c, 0, src, &ds, true));
+  UHDR_TRY(stage_in(c, 1, &tmp, &dd, false));
+  UHDR_TRY(uhdr_hip_convert_raw_input_to_ycbcr_dev(c, &ds, chroma, &dd));
+  dst->fmt = dd.fmt; dst->cg = dd.cg; dst->ct = dd.ct; dst->range = dd.range; dst->w = dd.w; dst->h = dd.h;
+  return stage_out(c, &dd, dst);
+}
+
+// -------------------------------------------------------------------------------------------------
+// JPEG FDCT + quantize
+// -------------------------------------------------------------------------------------------------
+void uhdr_hip_jpeg_quant_table(int quality, int is_chroma, uint16_t qt[64]) { host::jpeg_quant_table(quality, is_chroma, qt); }
+
+uhdr_error_info_t uhdr_hip_fdct_quant_dev(uhdr_hip_ctx_t* c, const uint8_t* plane, size_t stride, int bw, int bh,
+                                          const uint16_t qt[64], int16_t* coef) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  if (!plane || !qt || !coef || bw <= 0 || bh <= 0) return err_status(UHDR_CODEC_INVALID_PARAM, "received bad argument for fdct_quant");
+  if (((uintptr_t)coef & 15) != 0) return err_status(UHDR_CODEC_INVALID_PARAM, "coefficient buffer must be 16-byte aligned");
+  for (int i = 0; i < 64; i++)
+    if (qt[i] == 0 || qt[i] > 255) return err_status(UHDR_CODEC_INVALID_PARAM, "quantization table entry %d out of baseline range", i);
+  HIP_TRY(hipSetDevice(c->device));
+  if (!c->d_qt) HIP_TRY(hipMalloc((void**)&c->d_qt, 64 * sizeof(uint16_t) * 16));
+  // 16 rotating table slots so that back-to-back calls with different tables do not race
+  static thread_local int slot = 0;
+  uint16_t* dq = c->d_qt + 64 * (slot++ & 15);
+  HIP_TRY(hipMemcpyAsync(dq, qt, 64 * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+  ProfScope ps(c, "fdct_quant");
+  HIP_TRY(launch_fdct_quant(plane, stride, bw, bh, dq, coef, c->stream));
+  return ok_status();
+}
+
+uhdr_error_info_t uhdr_hip_fdct_quant(uhdr_hip_ctx_t* c, const uint8_t* plane, size_t stride, int bw, int bh,
+                                      const uint16_t qt[64], int16_t* coef) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  if (!plane || !qt || !coef || bw <= 0 || bh <= 0) return err_status(UHDR_CODEC_INVALID_PARAM, "received bad argument for fdct_quant");
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t in_bytes = ((size_t)bh * 8 - 1) * stride + (size_t)bw * 8;
+  const size_t out_bytes = (size_t)bw * bh * 64 * sizeof(int16_t);
+  UHDR_TRY(ensure(c->scratch[0], in_bytes));
+  UHDR_TRY(ensure(c->scratch[1], out_bytes));
+  HIP_TRY(hipMemcpyAsync(c->scratch[0].p, plane, in_bytes, hipMemcpyHostToDevice, c->stream));
+  UHDR_TRY(uhdr_hip_fdct_quant_dev(c, (const uint8_t*)c->scratch[0].p, stride, bw, bh, qt, (int16_t*)c->scratch[1].p));
+  HIP_TRY(hipMemcpyAsync(coef, c->scratch[1].p, out_bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return ok_status();
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

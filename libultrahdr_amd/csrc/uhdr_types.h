@@ -1,0 +1,141 @@
+// Internal types shared between the host layer (uhdr_hip_api.cpp, host_tables.cpp) and the
+// kernel translation units.  Nothing here is part of the C ABI (include/uhdr_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_math.h"
+#include "uhdr_hip.h"
+
+namespace uhdr {
+
+// Device-side view of a uhdr_raw_image_t: plane pointers + strides in PIXELS (ultrahdr_api.h:245).
+struct ImageView {
+  const void* p[3];
+  uint32_t stride[3];
+  uint32_t w, h;
+  int fmt;
+  int range;
+};
+struct ImageViewMut {
+  void* p[3];
+  uint32_t stride[3];
+  uint32_t w, h;
+  int fmt;
+  int range;
+};
+
+// ---- applyGainMap ------------------------------------------------------------------------------
+// Per-call table block uploaded by the host (one hipMemcpyAsync):
+//   srgb[1024]      sRGB inverse-OETF LUT                     (gainmapmath.cpp:126-131)
+//   gain[3][1024]   GainLUT, one table per channel            (gainmapmath.h:452-470)
+//   u8f[256]        b / 255.0f for every byte b               (mapUintToFloat, gainmapmath.cpp:864)
+//   fac[3][256]     scale-1 shortcut: the gain FACTOR for map byte b, i.e. GainLUT applied to
+//                   u8f[b] (with the 1/gamma pow done on the host) -- at scale 1 the sampler
+//                   returns e1*1 + e2*0 + e3*0 + e4*0 == e1 exactly, so byte -> factor is a table
+//   idw[4][s*s*4]   ShepardsIDW default / NR / NB / C tables  (gainmapmath.cpp:43-80)
+constexpr int kSrgbN = 1024;
+constexpr int kGainN = 1024;
+constexpr int kOetfN = 65536;
+constexpr int kInvOetfN = 4096;
+constexpr int kMaxIdwScaleLds = 8;  // idw tables up to 4*8*8*4 floats = 4 KiB live in LDS
+
+struct ApplyTables {  // layout of the device table block, in floats
+  static constexpr int kSrgbOff = 0;
+  static constexpr int kGainOff = kSrgbOff + kSrgbN;
+  static constexpr int kU8fOff = kGainOff + 3 * kGainN;
+  static constexpr int kFacOff = kU8fOff + 256;
+  static constexpr int kIdwOff = kFacOff + 3 * 256;
+  static int floats(int scale) { return kIdwOff + 4 * scale * scale * 4; }
+};
+
+struct ApplyParams {
+  ImageView sdr;      // base image (this rank's stripe)
+  ImageView gm;       // whole gain map
+  ImageViewMut dst;   // destination stripe
+  const float* tables;      // ApplyTables block
+  const float* oetf_lut;    // 65536-entry HLG or PQ OETF table (null for linear)
+  uint32_t y0;              // global row of stripe row 0
+  uint32_t scale;           // integer map scale factor (table path) or 0
+  uint32_t scale_magic;     // ceil(2^32 / scale): x / scale == umulhi(x, magic) for x < 65536
+  float scale_f;            // (float)w_sdr / w_map, for the non-integer path
+  int map_bpp;              // 1, 3 or 4
+  int map_ch;               // 1 or 3
+  int out_ct;               // uhdr_color_transfer_t
+  int sdr_is_rgb;           // base image read as RGB (RGBA8888) -- no YUV->RGB
+  int sdr_gamut_on, hdr_gamut_on;
+  int gamma_is_one[3];      // per-channel 1/gamma == 1
+  float gamma_inv[3];
+  float offset_sdr[3], offset_hdr[3];
+  Mat3 gamut;               // hdr_cg <- sdr_cg
+  Yuv2Rgb yuv;              // always the BT.601 set (jpegr.cpp:1723)
+};
+
+// ---- generateGainMap -----------------------------------------------------------------------------
+struct GenParams {
+  ImageView sdr, hdr;
+  uint32_t map_w, map_h, scale;
+  const float* srgb_lut;     // 1024
+  const float* hdr_inv_lut;  // 4096 (HLG / PQ) or 1024 (sRGB) or null (linear)
+  int hdr_inv_n;
+  int hdr_is_hlg;
+  int sdr_is_rgb, hdr_is_rgb;
+  int sdr_gamut_on, hdr_gamut_on;
+  Mat3 sdr_gamut, hdr_gamut;
+  Yuv2Rgb sdr_yuv, hdr_yuv;
+  float lum[3];              // luminance coefficients of the SDR gamut (used for both images)
+  int multichannel, use_luminance;
+  float hdr_nits;            // hdrSampleToNitsFactor
+  // one pass
+  float min_boost, max_boost, log2min, log2max, gamma;
+  uint8_t* out;              // map bytes
+  uint32_t out_stride;       // pixels
+  // two pass
+  float* gain_log2;          // map_w*map_h*(3|1)
+  float* minmax;             // 6 floats
+};
+
+struct AffineParams {
+  const float* gain_log2;
+  uint8_t* out;
+  uint32_t map_w, map_h, out_stride, nch;
+  float mn[3], mx[3];
+  float gamma;
+};
+
+// ---- toneMap -------------------------------------------------------------------------------------
+struct ToneMapParams {
+  ImageView hdr;
+  ImageViewMut sdr;
+  const float* hdr_inv_lut;
+  int hdr_inv_n;
+  int hdr_is_hlg, hdr_is_rgb, is_normalized;
+  float headroom;
+  int gamut_on;
+  Mat3 gamut;      // P3 <- hdr gamut
+  Yuv2Rgb hdr_yuv;
+  Rgb2Yuv p3;
+};
+
+// ---- convertYuv / convert_raw_input_to_ycbcr --------------------------------------------------------
+struct YuvXformParams {
+  ImageViewMut img;
+  Mat3 c;
+};
+struct RgbToYcbcrParams {
+  ImageView src;
+  ImageViewMut dst;
+  Rgb2Yuv k;
+};
+
+// launchers (defined in the .hip files)
+hipError_t launch_apply_gainmap(const ApplyParams& p, hipStream_t s);
+hipError_t launch_generate_gainmap(const GenParams& p, bool two_pass, hipStream_t s);
+hipError_t launch_affine_map(const AffineParams& p, hipStream_t s);
+hipError_t launch_tone_map(const ToneMapParams& p, hipStream_t s);
+hipError_t launch_transform_yuv(const YuvXformParams& p, hipStream_t s);
+hipError_t launch_rgb_to_ycbcr(const RgbToYcbcrParams& p, hipStream_t s);
+hipError_t launch_fdct_quant(const uint8_t* plane, size_t stride, int bw, int bh,
+                             const uint16_t* qt_dev, int16_t* coef, hipStream_t s);
+
+}  // namespace uhdr

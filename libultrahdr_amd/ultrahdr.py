@@ -1,0 +1,174 @@
+"""Host-side mirror of the reference's ``ultrahdr::UltraHdr`` operator interface
+(``/root/reference/lib/include/ultrahdr/ultrahdrcommon.h:448-655``): same constructor knobs, same
+four methods with the same argument meaning and error behaviour, but every pixel is computed by
+the gfx950 kernels behind the C ABI (``include/uhdr_hip.h``).  Images may live on the host
+(numpy; the call stages them) or on the GPU (torch CUDA tensors; the call only enqueues kernels).
+
+    u = UltraHdr(device=0, mapDimensionScaleFactor=4, useMultiChannelGainMap=False)
+    md, gm = u.generateGainMap(sdr, hdr)
+    u.applyGainMap(sdr, gm, md, UHDR_CT_LINEAR, UHDR_IMG_FMT_64bppRGBAHalfFloat, float("inf")...)
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi as A
+from .images import Image, _align
+
+
+class Context:
+    """One ``uhdr_hip_ctx_t``: a device + a stream.  Raises if the HIP library or a GPU is missing."""
+
+    def __init__(self, device: int = -1, stream=None):
+        self.lib = A.load()
+        err = A.ErrorInfo()
+        self.handle = self.lib.uhdr_hip_create(device, C.byref(err))
+        if not self.handle:
+            raise A.UhdrError(err.error_code, err.detail.decode("utf-8", "replace"))
+        if stream is not None:
+            self.set_stream(stream)
+
+    def set_stream(self, stream):
+        """``stream``: a raw hipStream_t integer or a ``torch.cuda.Stream``."""
+        ptr = getattr(stream, "cuda_stream", stream)
+        A.check(self.lib.uhdr_hip_set_stream(self.handle, C.c_void_p(ptr)))
+
+    def synchronize(self):
+        A.check(self.lib.uhdr_hip_synchronize(self.handle))
+
+    def profile(self, enable: bool):
+        self.lib.uhdr_hip_profile_enable(self.handle, 1 if enable else 0)
+
+    def profile_read(self, family: str | None, reset=True):
+        ms = C.c_double(0.0)
+        n = self.lib.uhdr_hip_profile_read(self.handle, family.encode() if family else None, C.byref(ms), 1 if reset else 0)
+        return n, ms.value
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.uhdr_hip_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _is_dev(*imgs) -> bool:
+    dev = [im.device is not None for im in imgs]
+    if any(dev) and not all(dev):
+        raise ValueError("mixing host and device images in one call")
+    return all(dev)
+
+
+class UltraHdr:
+    """Mirror of ``ultrahdr::UltraHdr`` (constructor args: ultrahdrcommon.h:450-457)."""
+
+    def __init__(self, ctx: Context | None = None, device: int = -1,
+                 mapDimensionScaleFactor: int = 4, mapCompressQuality: int = 85,
+                 useMultiChannelGainMap: bool = False, gamma: float = 1.0,
+                 preset: int = A.UHDR_USAGE_REALTIME, minContentBoost: float = A.FLT_MIN,
+                 maxContentBoost: float = A.FLT_MAX, targetDispPeakBrightness: float = -1.0):
+        self.ctx = ctx or Context(device)
+        self.lib = self.ctx.lib
+        self.mMapDimensionScaleFactor = mapDimensionScaleFactor
+        self.mMapCompressQuality = mapCompressQuality
+        self.mUseMultiChannelGainMap = useMultiChannelGainMap
+        self.mGamma = gamma
+        self.mEncPreset = preset
+        self.mMinContentBoost = minContentBoost
+        self.mMaxContentBoost = maxContentBoost
+        self.mTargetDispPeakBrightness = targetDispPeakBrightness
+
+    def encode_cfg(self, sdr_is_601=False, use_luminance=True) -> A.EncodeCfg:
+        return A.EncodeCfg(self.mMapDimensionScaleFactor, int(self.mUseMultiChannelGainMap), self.mGamma,
+                           self.mEncPreset, self.mMinContentBoost, self.mMaxContentBoost,
+                           self.mTargetDispPeakBrightness, int(sdr_is_601), int(use_luminance))
+
+    # ---- toneMap (ultrahdrcommon.h:482) ----------------------------------------------------
+    def toneMap(self, hdr_intent: Image, sdr_intent: Image):
+        fn = self.lib.uhdr_hip_tone_map_dev if _is_dev(hdr_intent, sdr_intent) else self.lib.uhdr_hip_tone_map
+        A.check(fn(self.ctx.handle, C.byref(hdr_intent.raw), C.byref(sdr_intent.raw)))
+
+    # ---- generateGainMap (ultrahdrcommon.h:507-510) -------------------------------------------
+    def gainmap_dims(self, w: int, h: int):
+        s = self.mMapDimensionScaleFactor
+        mw, mh = w // s, h // s
+        if mw == 0 or mh == 0:  # jpegr.cpp:696-706
+            s = min(w, h)
+            s = s // 8 if s >= 8 else 1
+            mw, mh = w // s, h // s
+        return mw, mh
+
+    def generateGainMap(self, sdr_intent: Image, hdr_intent: Image, sdr_is_601=False, use_luminance=True):
+        """Returns (metadata, gainmap Image) -- the reference fills a fresh 64-aligned image."""
+        dev = _is_dev(sdr_intent, hdr_intent)
+        mw, mh = self.gainmap_dims(sdr_intent.w, sdr_intent.h)
+        fmt = A.UHDR_IMG_FMT_24bppRGB888 if self.mUseMultiChannelGainMap else A.UHDR_IMG_FMT_8bppYCbCr400
+        gm = Image(fmt, mw, mh, align=64, device=sdr_intent.device)
+        md = A.GainmapMetadata()
+        cfg = self.encode_cfg(sdr_is_601, use_luminance)
+        fn = self.lib.uhdr_hip_generate_gainmap_dev if dev else self.lib.uhdr_hip_generate_gainmap
+        A.check(fn(self.ctx.handle, C.byref(sdr_intent.raw), C.byref(hdr_intent.raw), C.byref(cfg),
+                   C.byref(md), C.byref(gm.raw)))
+        gm.sync_meta_from_raw()
+        return md, gm
+
+    # ---- applyGainMap (ultrahdrcommon.h:531-534) -----------------------------------------------
+    def applyGainMap(self, sdr_intent: Image, gainmap_img: Image, gainmap_metadata: A.GainmapMetadata,
+                     output_ct: int, output_format: int, max_display_boost: float, dest: Image,
+                     y0: int = 0, full_height: int = 0):
+        if _is_dev(sdr_intent, gainmap_img, dest):
+            A.check(self.lib.uhdr_hip_apply_gainmap_dev(
+                self.ctx.handle, C.byref(sdr_intent.raw), C.byref(gainmap_img.raw), C.byref(gainmap_metadata),
+                output_ct, output_format, max_display_boost, C.byref(dest.raw), y0, full_height))
+        else:
+            if y0 or full_height:
+                raise ValueError("stripes are a device-buffer feature")
+            A.check(self.lib.uhdr_hip_apply_gainmap(
+                self.ctx.handle, C.byref(sdr_intent.raw), C.byref(gainmap_img.raw), C.byref(gainmap_metadata),
+                output_ct, output_format, max_display_boost, C.byref(dest.raw)))
+
+    # ---- convertYuv (ultrahdrcommon.h:545-546) -------------------------------------------------
+    def convertYuv(self, image: Image, src_encoding: int, dst_encoding: int):
+        fn = self.lib.uhdr_hip_convert_yuv_dev if _is_dev(image) else self.lib.uhdr_hip_convert_yuv
+        A.check(fn(self.ctx.handle, C.byref(image.raw), src_encoding, dst_encoding))
+
+    # ---- convert_raw_input_to_ycbcr (gainmapmath.h:604-605) -----------------------------------
+    def convert_raw_input_to_ycbcr(self, src: Image, chroma_sampling_enabled=False) -> Image:
+        ten = src.fmt == A.UHDR_IMG_FMT_32bppRGBA1010102
+        if ten:
+            fmt = A.UHDR_IMG_FMT_24bppYCbCrP010 if chroma_sampling_enabled else A.UHDR_IMG_FMT_30bppYCbCr444
+        else:
+            fmt = A.UHDR_IMG_FMT_12bppYCbCr420 if chroma_sampling_enabled else A.UHDR_IMG_FMT_24bppYCbCr444
+        dst = Image(fmt, src.w, src.h, align=64, device=src.device)
+        fn = (self.lib.uhdr_hip_convert_raw_input_to_ycbcr_dev if _is_dev(src)
+              else self.lib.uhdr_hip_convert_raw_input_to_ycbcr)
+        A.check(fn(self.ctx.handle, C.byref(src.raw), int(chroma_sampling_enabled), C.byref(dst.raw)))
+        return dst
+
+    # ---- JPEG stage -----------------------------------------------------------------------------
+    def quant_table(self, quality: int, is_chroma: bool) -> np.ndarray:
+        qt = (C.c_uint16 * 64)()
+        self.lib.uhdr_hip_jpeg_quant_table(quality, int(is_chroma), qt)
+        return np.frombuffer(qt, dtype=np.uint16).copy()
+
+    def fdct_quant(self, plane, stride: int, blocks_w: int, blocks_h: int, qtable: np.ndarray, coef=None):
+        """plane: numpy uint8 array (host) or torch uint8 CUDA tensor (device), covering
+        blocks_h*8 rows of ``stride`` bytes.  Returns int16 [blocks_h, blocks_w, 64]."""
+        qt = (C.c_uint16 * 64)(*[int(v) for v in qtable])
+        if isinstance(plane, np.ndarray):
+            out = np.zeros((blocks_h, blocks_w, 64), dtype=np.int16) if coef is None else coef
+            A.check(self.lib.uhdr_hip_fdct_quant(self.ctx.handle, C.c_void_p(plane.ctypes.data), stride,
+                                                 blocks_w, blocks_h, qt, C.c_void_p(out.ctypes.data)))
+            return out
+        import torch
+
+        out = torch.empty((blocks_h, blocks_w, 64), dtype=torch.int16, device=plane.device) if coef is None else coef
+        A.check(self.lib.uhdr_hip_fdct_quant_dev(self.ctx.handle, C.c_void_p(plane.data_ptr()), stride,
+                                                 blocks_w, blocks_h, qt, C.c_void_p(out.data_ptr())))
+        return out

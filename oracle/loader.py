@@ -1,0 +1,233 @@
+"""TEST INFRASTRUCTURE ONLY: ctypes access to the two CPU checkers.
+
+* ``port()``  -> oracle/libuhdr_oracle.so, the plain-C restatement (always buildable: `make -C oracle port`)
+* ``ref()``   -> oracle/_ref/libuhdr_ref.so, the REAL reference compiled from /root/reference by
+                 oracle/Makefile (`make -C oracle ref`; only where /root/reference exists -- the
+                 prebuilt .so travels to the GPU box with the gpurun snapshot).  ``None`` if absent.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product package (libultrahdr_amd) never does.  The ctypes structs are shared with the product
+binding because all three libraries use the reference's public struct layouts.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from libultrahdr_amd import capi as A
+from libultrahdr_amd.images import Image
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PORT_PATH = os.path.join(HERE, "libuhdr_oracle.so")
+REF_PATH = os.path.join(HERE, "_ref", "libuhdr_ref.so")
+_JPEG_CANDIDATES = ["/opt/conda/lib/libjpeg.so.9"]
+
+_port = None
+_ref = None
+_ref_tried = False
+_P = C.POINTER
+
+
+def build_port():
+    subprocess.check_call(["make", "-s", "-C", HERE, "port"])
+
+
+def port() -> C.CDLL:
+    global _port
+    if _port is not None:
+        return _port
+    if not os.path.exists(PORT_PATH):
+        build_port()
+    lib = C.CDLL(PORT_PATH)
+    lib.uo_apply_gainmap.restype = C.c_int
+    lib.uo_apply_gainmap.argtypes = [_P(A.RawImage), _P(A.RawImage), _P(A.GainmapMetadata), C.c_int, C.c_int, C.c_float, _P(A.RawImage)]
+    lib.uo_generate_gainmap.restype = C.c_int
+    lib.uo_generate_gainmap.argtypes = [_P(A.RawImage), _P(A.RawImage), _P(A.EncodeCfg), _P(A.GainmapMetadata), _P(A.RawImage)]
+    lib.uo_tone_map.restype = C.c_int
+    lib.uo_tone_map.argtypes = [_P(A.RawImage), _P(A.RawImage)]
+    lib.uo_convert_yuv.restype = C.c_int
+    lib.uo_convert_yuv.argtypes = [_P(A.RawImage), C.c_int, C.c_int]
+    lib.uo_convert_raw_input_to_ycbcr.restype = C.c_int
+    lib.uo_convert_raw_input_to_ycbcr.argtypes = [_P(A.RawImage), C.c_int, _P(A.RawImage)]
+    lib.uo_jpeg_quant_table.restype = None
+    lib.uo_jpeg_quant_table.argtypes = [C.c_int, C.c_int, _P(C.c_uint16)]
+    lib.uo_fdct_quant_plane.restype = None
+    lib.uo_fdct_quant_plane.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, _P(C.c_uint16), C.c_void_p]
+    lib.uo_jpeg_rgb_to_ycc.restype = None
+    lib.uo_jpeg_rgb_to_ycc.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    _common_scalar_sigs(lib, "uo_")
+    lib.uo_lut.restype = None
+    lib.uo_lut.argtypes = [C.c_int, C.c_void_p]
+    _port = lib
+    return lib
+
+
+def _common_scalar_sigs(lib, pfx):
+    getattr(lib, pfx + "eval").restype = C.c_int
+    getattr(lib, pfx + "eval").argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+    getattr(lib, pfx + "float_to_half").restype = None
+    getattr(lib, pfx + "float_to_half").argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    getattr(lib, pfx + "color_to_rgba1010102").restype = C.c_uint32
+    getattr(lib, pfx + "color_to_rgba1010102").argtypes = [C.c_float] * 3
+    getattr(lib, pfx + "color_to_rgbaf16").restype = C.c_uint64
+    getattr(lib, pfx + "color_to_rgbaf16").argtypes = [C.c_float] * 3
+    getattr(lib, pfx + "compute_gain").restype = C.c_float
+    getattr(lib, pfx + "compute_gain").argtypes = [C.c_float] * 2
+    getattr(lib, pfx + "affine_map_gain").restype = C.c_uint8
+    getattr(lib, pfx + "affine_map_gain").argtypes = [C.c_float] * 4
+    getattr(lib, pfx + "encode_gain").restype = C.c_uint8
+    getattr(lib, pfx + "encode_gain").argtypes = [C.c_float] * 5
+    getattr(lib, pfx + "apply_gain").restype = None
+    getattr(lib, pfx + "apply_gain").argtypes = [_P(C.c_float), C.c_float, _P(A.GainmapMetadata), C.c_float, C.c_int, _P(C.c_float)]
+    getattr(lib, pfx + "idw_weights").restype = None
+    getattr(lib, pfx + "idw_weights").argtypes = [C.c_int, C.c_int, C.c_void_p]
+    getattr(lib, pfx + "color_fn").restype = None
+    getattr(lib, pfx + "color_fn").argtypes = [C.c_int, _P(C.c_float), _P(C.c_float)]
+
+
+def ref():
+    """The real reference, or None when oracle/_ref was not built / cannot load on this box."""
+    global _ref, _ref_tried
+    if _ref_tried:
+        return _ref
+    _ref_tried = True
+    if not os.path.exists(REF_PATH):
+        return None
+    try:
+        for j in _JPEG_CANDIDATES:  # no RPATH in the .so: bring libjpeg in by absolute path first
+            if os.path.exists(j):
+                C.CDLL(j, mode=C.RTLD_GLOBAL)
+                break
+        lib = C.CDLL(REF_PATH)
+    except OSError:
+        return None
+    lib.ref_apply_gainmap.restype = C.c_int
+    lib.ref_apply_gainmap.argtypes = [_P(A.RawImage), _P(A.RawImage), _P(A.GainmapMetadata), C.c_int, C.c_int, C.c_float, _P(A.RawImage), C.c_char_p]
+    lib.ref_generate_gainmap.restype = C.c_int
+    lib.ref_generate_gainmap.argtypes = [_P(A.RawImage), _P(A.RawImage), _P(A.EncodeCfg), _P(A.GainmapMetadata), _P(A.RawImage), C.c_char_p]
+    lib.ref_tone_map.restype = C.c_int
+    lib.ref_tone_map.argtypes = [_P(A.RawImage), _P(A.RawImage), C.c_char_p]
+    lib.ref_convert_yuv.restype = C.c_int
+    lib.ref_convert_yuv.argtypes = [_P(A.RawImage), C.c_int, C.c_int, C.c_char_p]
+    lib.ref_convert_raw_input_to_ycbcr.restype = C.c_int
+    lib.ref_convert_raw_input_to_ycbcr.argtypes = [_P(A.RawImage), C.c_int, _P(A.RawImage)]
+    lib.ref_jpeg_compress.restype = C.c_long
+    lib.ref_jpeg_compress.argtypes = [_P(A.RawImage), C.c_int, C.c_void_p, C.c_size_t]
+    lib.ref_jpeg_read_coefficients.restype = C.c_int
+    lib.ref_jpeg_read_coefficients.argtypes = [C.c_void_p, C.c_size_t, _P(C.c_void_p), C.c_void_p, _P(C.c_int), _P(C.c_int), _P(C.c_int)]
+    lib.ref_jpeg_decompress.restype = C.c_int
+    lib.ref_jpeg_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_int, _P(A.RawImage), C.c_void_p, C.c_size_t]
+    lib.ref_info.restype = C.c_char_p
+    lib.ref_info.argtypes = []
+    _common_scalar_sigs(lib, "ref_")
+    _ref = lib
+    return lib
+
+
+# ---- convenience wrappers shared by tests / smoke / bench ---------------------------------------
+FN = dict(srgb_inv=0, srgb_inv_lut=1, srgb_oetf=2, hlg_oetf=3, hlg_oetf_lut=4, hlg_inv=5, hlg_inv_lut=6,
+          pq_oetf=7, pq_oetf_lut=8, pq_inv=9, pq_inv_lut=10, half_to_float=11, hlg_ootf=12, hlg_inv_ootf=13)
+
+
+def eval_fn(lib, pfx, name, x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty_like(x)
+    rc = getattr(lib, pfx + "eval")(FN[name], x.ctypes.data, out.ctypes.data, x.size)
+    assert rc == 0
+    return out
+
+
+def apply_gainmap(lib_kind, sdr: Image, gm: Image, md, out_ct, max_display_boost=A.FLT_MAX, dest_align=1) -> Image:
+    """Run applyGainMap on 'port' or 'ref'; returns the destination image."""
+    fmt = A.UHDR_IMG_FMT_64bppRGBAHalfFloat if out_ct == A.UHDR_CT_LINEAR else A.UHDR_IMG_FMT_32bppRGBA1010102
+    dest = Image(fmt, sdr.w, sdr.h, align=dest_align)
+    if lib_kind == "port":
+        rc = port().uo_apply_gainmap(C.byref(sdr.raw), C.byref(gm.raw), C.byref(md), out_ct, fmt, max_display_boost, C.byref(dest.raw))
+        detail = b""
+    else:
+        buf = C.create_string_buffer(256)
+        rc = ref().ref_apply_gainmap(C.byref(sdr.raw), C.byref(gm.raw), C.byref(md), out_ct, fmt, max_display_boost, C.byref(dest.raw), buf)
+        detail = buf.value
+    if rc != 0:
+        raise A.UhdrError(rc, detail.decode("utf-8", "replace"))
+    return dest
+
+
+def generate_gainmap(lib_kind, sdr: Image, hdr: Image, cfg: A.EncodeCfg):
+    s = cfg.map_dimension_scale_factor
+    mw, mh = sdr.w // s, sdr.h // s
+    if mw == 0 or mh == 0:
+        s2 = min(sdr.w, sdr.h)
+        s2 = s2 // 8 if s2 >= 8 else 1
+        mw, mh = sdr.w // s2, sdr.h // s2
+    fmt = A.UHDR_IMG_FMT_24bppRGB888 if cfg.use_multi_channel_gainmap else A.UHDR_IMG_FMT_8bppYCbCr400
+    gm = Image(fmt, mw, mh, align=64)
+    md = A.GainmapMetadata()
+    if lib_kind == "port":
+        rc = port().uo_generate_gainmap(C.byref(sdr.raw), C.byref(hdr.raw), C.byref(cfg), C.byref(md), C.byref(gm.raw))
+        detail = b""
+    else:
+        buf = C.create_string_buffer(256)
+        rc = ref().ref_generate_gainmap(C.byref(sdr.raw), C.byref(hdr.raw), C.byref(cfg), C.byref(md), C.byref(gm.raw), buf)
+        detail = buf.value
+    if rc != 0:
+        raise A.UhdrError(rc, detail.decode("utf-8", "replace"))
+    gm.sync_meta_from_raw()
+    return md, gm
+
+
+def tone_map(lib_kind, hdr: Image, sdr_fmt=None) -> Image:
+    if sdr_fmt is None:
+        sdr_fmt = {A.UHDR_IMG_FMT_24bppYCbCrP010: A.UHDR_IMG_FMT_12bppYCbCr420,
+                   A.UHDR_IMG_FMT_30bppYCbCr444: A.UHDR_IMG_FMT_24bppYCbCr444}.get(hdr.fmt, A.UHDR_IMG_FMT_32bppRGBA8888)
+    sdr = Image(sdr_fmt, hdr.w, hdr.h, align=64)
+    if lib_kind == "port":
+        rc = port().uo_tone_map(C.byref(hdr.raw), C.byref(sdr.raw))
+    else:
+        rc = ref().ref_tone_map(C.byref(hdr.raw), C.byref(sdr.raw), None)
+    if rc != 0:
+        raise A.UhdrError(rc, "tone_map")
+    return sdr
+
+
+def convert_yuv(lib_kind, img: Image, src, dst) -> Image:
+    out = img.clone()
+    if lib_kind == "port":
+        rc = port().uo_convert_yuv(C.byref(out.raw), src, dst)
+    else:
+        rc = ref().ref_convert_yuv(C.byref(out.raw), src, dst, None)
+    if rc != 0:
+        raise A.UhdrError(rc, "convert_yuv")
+    return out
+
+
+def convert_raw_input_to_ycbcr(lib_kind, src: Image, chroma: bool) -> Image:
+    ten = src.fmt == A.UHDR_IMG_FMT_32bppRGBA1010102
+    if ten:
+        fmt = A.UHDR_IMG_FMT_24bppYCbCrP010 if chroma else A.UHDR_IMG_FMT_30bppYCbCr444
+    else:
+        fmt = A.UHDR_IMG_FMT_12bppYCbCr420 if chroma else A.UHDR_IMG_FMT_24bppYCbCr444
+    dst = Image(fmt, src.w, src.h, align=64)
+    if lib_kind == "port":
+        rc = port().uo_convert_raw_input_to_ycbcr(C.byref(src.raw), int(chroma), C.byref(dst.raw))
+    else:
+        rc = ref().ref_convert_raw_input_to_ycbcr(C.byref(src.raw), int(chroma), C.byref(dst.raw))
+    if rc != 0:
+        raise A.UhdrError(rc, "convert_raw_input_to_ycbcr")
+    return dst
+
+
+def fdct_quant_port(plane: np.ndarray, stride: int, bw: int, bh: int, qt: np.ndarray) -> np.ndarray:
+    out = np.zeros((bh, bw, 64), dtype=np.int16)
+    q = (C.c_uint16 * 64)(*[int(v) for v in qt])
+    port().uo_fdct_quant_plane(plane.ctypes.data, stride, bw, bh, q, out.ctypes.data)
+    return out
+
+
+def quant_table_port(quality: int, chroma: bool) -> np.ndarray:
+    q = (C.c_uint16 * 64)()
+    port().uo_jpeg_quant_table(quality, int(chroma), q)
+    return np.frombuffer(q, dtype=np.uint16).copy()
