@@ -1,0 +1,299 @@
+#!/usr/bin/env python
+"""bench.py -- Mpixels/s of the gain-map hot path on MI355X.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the
+driver launches one rank per GPU with torch.distributed.run.  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[1]): decode of 4K (3840x2160) UltraHDR frames -- applyGainMap from
+a YCbCr 4:2:0 base image + 8-bit gain map to linear RGBA_F16 -- with all inputs resident in HBM.
+One "step" = one pass of the hot path over a batch of BATCH distinct frames per rank (distinct
+buffers so the 256 MiB Infinity Cache cannot hold the working set).  Frames are independent, so N
+ranks shard by frame with no data-path collective (weak scaling); `value` = pixels all ranks
+processed / max-over-ranks time.
+
+Extra, rank 0 at N=1 only, outside the timed region: the same kernel at 8K (the north-star
+roofline target), the HLG/PQ outputs, the encode-side kernels, and the CPU baseline (the real
+reference from oracle/_ref when it loads, else the C port) on a bounded sample.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="4K frames per rank per step")
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--map", choices=["A", "B"], default="A", help="A: Y400 scale 4 (9.5625 B/px); B: RGB888 scale 1 (12.5 B/px)")
+    ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def algo_bytes_per_px(map_kind, out_bytes=8):
+    # every input read once, every output written once
+    return 1.5 + (1.0 / 16.0 if map_kind == "A" else 3.0) + out_bytes
+
+
+def make_frames(n, w, h, map_kind, device, out_fmt, seed0=1234):
+    from libultrahdr_amd import capi as A
+    from libultrahdr_amd import synth
+    from libultrahdr_amd.images import Image
+
+    frames = []
+    for i in range(n):
+        sdr = synth.make_sdr_yuv420(w, h, seed=seed0 + i)
+        if map_kind == "A":
+            gm = synth.make_gainmap(w // 4, h // 4, 1, seed=seed0 + 100 + i)
+        else:
+            gm = synth.make_gainmap(w, h, 3, seed=seed0 + 100 + i)
+        dest = Image(out_fmt, w, h, align=64, device=device)
+        frames.append((sdr.to(device), gm.to(device), dest))
+    return frames
+
+
+def time_kernel(ctx, fn, iters=10, warm=3):
+    """Average wall time per call of fn() measured with HIP events on the context's stream
+    (uhdr_hip_profile_* wraps every launch of the family in an event pair)."""
+    for _ in range(warm):
+        fn()
+    ctx.synchronize()
+    ctx.profile(True)
+    ctx.profile_read(None, reset=True)
+    for _ in range(iters):
+        fn()
+    n, ms = ctx.profile_read(None, reset=True)
+    ctx.profile(False)
+    return ms / max(n, 1) * (n / iters)  # ms per fn() call (a call may launch >1 kernel)
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+    else:
+        torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+
+    from libultrahdr_amd import capi as A
+    from libultrahdr_amd import synth
+    from libultrahdr_amd.images import Image
+    from libultrahdr_amd.ultrahdr import Context, UltraHdr
+
+    ctx = Context(local_rank)
+    u = UltraHdr(ctx=ctx)
+    f16 = A.UHDR_IMG_FMT_64bppRGBAHalfFloat
+    w, h = args.width, args.height
+    md = synth.default_metadata(use_base_cg=0)  # BT.709 base, BT.2100 gain-map space: the SDR-side 3x3 is active
+    frames = make_frames(args.batch, w, h, args.map, device, f16, seed0=1234 + 1000 * rank)
+    for _, gm, _ in frames:
+        gm.raw.cg = A.UHDR_CG_BT_2100
+    for sdr, _, _ in frames:
+        sdr.raw.cg = A.UHDR_CG_BT_709
+
+    lib, hnd = ctx.lib, ctx.handle
+    calls = [(C.byref(s.raw), C.byref(g.raw), C.byref(md), C.byref(d.raw)) for s, g, d in frames]
+
+    def step():
+        for s_, g_, m_, d_ in calls:
+            st = lib.uhdr_hip_apply_gainmap_dev(hnd, s_, g_, m_, A.UHDR_CT_LINEAR, f16, A.FLT_MAX, d_, 0, 0)
+            if st.error_code != 0:
+                raise RuntimeError(st.detail)
+
+    def barrier():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    # timed region: exactly K steps, HIP events around every launch (kernel-only durations)
+    ctx.profile(True)
+    ctx.profile_read(None, reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    t1 = time.perf_counter()
+    n_launch, kern_ms = ctx.profile_read("apply_gainmap", reset=True)
+    ctx.profile(False)
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    px_per_step = args.batch * w * h * world
+    value = px_per_step * args.steps / elapsed / 1e6
+    avg_launch_s = (kern_ms / 1e3) / max(n_launch, 1)
+    algo_b = algo_bytes_per_px(args.map) * w * h
+    achieved = algo_b / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+
+    out = {
+        "metric": "Mpixels/s decode (applyGainMap, YCbCr420 + gain map -> RGBA_F16 linear), 4K frames resident in HBM",
+        "value": round(value, 1),
+        "unit": "Mpixels/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"configs[1]: decode {w}x{h} YCbCr420 base + "
+                        + ("Y400 gain map (scale 4)" if args.map == "A" else "RGB888 gain map (scale 1)")
+                        + " -> RGBA_F16 linear, applyGainMap kernel, device-resident",
+            "frames_per_rank_per_step": args.batch,
+            "sharding": f"frames x{world} ranks, no data-path collective",
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "apply_quad_kernel<F16," + ("Y400,scale4>" if args.map == "A" else "RGB888,scale1>"),
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": None,
+            "algorithmic_bytes_per_launch": int(algo_b),
+            "avg_launch_us": round(avg_launch_s * 1e6, 3),
+            "launches_timed": n_launch,
+        },
+    }
+
+    if rank == 0 and world == 1 and not args.no_extra:
+        out["extra"] = extras(ctx, u, device)
+    if rank == 0 and world == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(w, h, args.map, md, args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def extras(ctx, u, device):
+    """Stage-level kernel timings (HIP events), rank 0, N=1.  GB/s = algorithmic bytes / time."""
+    from libultrahdr_amd import capi as A
+    from libultrahdr_amd import synth
+    from libultrahdr_amd.images import Image
+    from libultrahdr_amd.ultrahdr import UltraHdr
+    import torch
+
+    res = {}
+    f16, u32 = A.UHDR_IMG_FMT_64bppRGBAHalfFloat, A.UHDR_IMG_FMT_32bppRGBA1010102
+    md = synth.default_metadata(use_base_cg=0)
+
+    def apply_case(name, w, h, map_kind, ct):
+        fmt = f16 if ct == A.UHDR_CT_LINEAR else u32
+        sets = make_frames(3, w, h, map_kind, device, fmt, seed0=77)  # rotate 3 sets: > L3 at 8K, mostly at 4K
+        for s, g, _ in sets:
+            s.raw.cg, g.raw.cg = A.UHDR_CG_BT_709, A.UHDR_CG_BT_2100
+        k = [0]
+
+        def fn():
+            s, g, d = sets[k[0] % 3]
+            k[0] += 1
+            u.applyGainMap(s, g, md, ct, fmt, A.FLT_MAX, d)
+
+        ms = time_kernel(ctx, fn, iters=12, warm=3)
+        b = algo_bytes_per_px(map_kind, 8 if ct == A.UHDR_CT_LINEAR else 4) * w * h
+        res[name] = {"us": round(ms * 1e3, 2), "GB/s": round(b / (ms / 1e3) / 1e9, 1), "frac_of_8TBs": round(b / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "Mpx/s": round(w * h / (ms / 1e3) / 1e6, 1)}
+        del sets
+        torch.cuda.empty_cache()
+
+    apply_case("apply_8k_f16_mapA", 7680, 4320, "A", A.UHDR_CT_LINEAR)
+    apply_case("apply_8k_f16_mapB", 7680, 4320, "B", A.UHDR_CT_LINEAR)
+    apply_case("apply_4k_f16_mapB", 3840, 2160, "B", A.UHDR_CT_LINEAR)
+    apply_case("apply_4k_hlg_mapA", 3840, 2160, "A", A.UHDR_CT_HLG)
+    apply_case("apply_4k_pq_mapA", 3840, 2160, "A", A.UHDR_CT_PQ)
+
+    # encode side, 4K: API-1 defaults (two-pass, 3-channel, scale 1) and the realtime preset
+    w, h = 3840, 2160
+    sdr = synth.make_sdr_yuv420(w, h).to(device)
+    hdr = synth.make_hdr_p010(w, h, ct=A.UHDR_CT_HLG).to(device)
+    enc = UltraHdr(ctx=ctx, mapDimensionScaleFactor=1, useMultiChannelGainMap=True, preset=A.UHDR_USAGE_BEST_QUALITY)
+    ms = time_kernel(ctx, lambda: enc.generateGainMap(sdr, hdr), iters=5, warm=2)
+    res["generate_4k_2pass_3ch_s1"] = {"us": round(ms * 1e3, 1), "Mpx/s": round(w * h / (ms / 1e3) / 1e6, 1),
+                                       "GB/s": round(31.5 * w * h / (ms / 1e3) / 1e9, 1)}
+    rt = UltraHdr(ctx=ctx, mapDimensionScaleFactor=4, useMultiChannelGainMap=False, preset=A.UHDR_USAGE_REALTIME)
+    ms = time_kernel(ctx, lambda: rt.generateGainMap(sdr, hdr), iters=5, warm=2)
+    res["generate_4k_1pass_1ch_s4"] = {"us": round(ms * 1e3, 1), "Mpx/s": round(w * h / (ms / 1e3) / 1e6, 1),
+                                       "GB/s": round((4.5 + 1 / 16) * w * h / (ms / 1e3) / 1e9, 1)}
+    tm_out = Image(A.UHDR_IMG_FMT_12bppYCbCr420, w, h, align=64, device=device)
+    ms = time_kernel(ctx, lambda: u.toneMap(hdr, tm_out), iters=5, warm=2)
+    res["tonemap_4k_p010"] = {"us": round(ms * 1e3, 1), "Mpx/s": round(w * h / (ms / 1e3) / 1e6, 1), "GB/s": round(4.5 * w * h / (ms / 1e3) / 1e9, 1)}
+    cv = sdr.clone()
+    ms = time_kernel(ctx, lambda: u.convertYuv(cv, A.UHDR_CG_BT_709, A.UHDR_CG_DISPLAY_P3), iters=5, warm=2)
+    res["convert_yuv_4k_420"] = {"us": round(ms * 1e3, 1), "Mpx/s": round(w * h / (ms / 1e3) / 1e6, 1), "GB/s": round(3.0 * w * h / (ms / 1e3) / 1e9, 1)}
+    qt = u.quant_table(95, False)
+    plane = sdr.buf[: sdr.layout[0][0] * sdr.layout[0][1]]
+    coef = torch.empty((h // 8, w // 8, 64), dtype=torch.int16, device=device)
+    ms = time_kernel(ctx, lambda: u.fdct_quant(plane, sdr.layout[0][1], w // 8, h // 8, qt, coef), iters=5, warm=2)
+    res["fdct_quant_4k_luma"] = {"us": round(ms * 1e3, 1), "Mpx/s": round(w * h / (ms / 1e3) / 1e6, 1), "GB/s": round(3.0 * w * h / (ms / 1e3) / 1e9, 1)}
+    return res
+
+
+def cpu_baseline(w, h, map_kind, md, budget_s):
+    """The reference's CPU path on this box's host cores, bounded sample, rank 0 only."""
+    from libultrahdr_amd import capi as A
+    from libultrahdr_amd import synth
+    from oracle import loader as L
+
+    kind = "reference" if L.ref() is not None else "port"
+    sdr = synth.make_sdr_yuv420(w, h, seed=1234)
+    gm = synth.make_gainmap(w // 4, h // 4, 1, seed=1334) if map_kind == "A" else synth.make_gainmap(w, h, 3, seed=1334)
+    sdr.raw.cg, gm.raw.cg = A.UHDR_CG_BT_709, A.UHDR_CG_BT_2100
+    which = "ref" if kind == "reference" else "port"
+    L.apply_gainmap(which, sdr, gm, md, A.UHDR_CT_LINEAR)  # warm-up (builds the reference's static LUTs)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        L.apply_gainmap(which, sdr, gm, md, A.UHDR_CT_LINEAR)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 64:
+            break
+    cores = min(os.cpu_count() or 1, 4) if kind == "reference" else 1
+    return {
+        "value": round(n * w * h / el / 1e6, 2),
+        "unit": "Mpixels/s",
+        "cores": cores,
+        "kind": kind,
+        "sample": f"{n} x applyGainMap {w}x{h} YCbCr420 + map {map_kind} -> RGBA_F16 on host buffers ({el:.1f} s); "
+                  + ("libultrahdr 2.0.2 built from /root/reference, its own min(hw,4)-thread job queue" if kind == "reference"
+                     else "single-threaded C restatement (oracle/uhdr_oracle.c)")
+                  + f"; host has {os.cpu_count()} logical cores",
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -84,7 +84,7 @@ class GainmapMetadata(C.Structure):  # uhdr_gainmap_metadata_t
         }
 
 
-class EncodeCfg(C.Structure):  # uhdr_hip_encode_cfg_t (same field order as oracle's uo_encode_cfg_t)
+class EncodeCfg(C.Structure):  # uhdr_hip_encode_cfg_t
     _fields_ = [
         ("map_dimension_scale_factor", C.c_int),
         ("use_multi_channel_gainmap", C.c_int),

@@ -1,0 +1,89 @@
+"""Row-stripe sharding of one image across the ranks of a node.
+
+Every stage of the hot path computes an output pixel / block from a bounded input neighbourhood,
+so an image splits into independent horizontal stripes -- one per rank / GPU -- with NO data-path
+collective.  The single exception is two-pass gain-map generation, whose only cross-stripe
+dependency is the global per-channel min/max of the log2 gain (the mutex-guarded merge at
+/root/reference/lib/src/jpegr.cpp:932-938).  That becomes one tiny all-reduce (3 floats MIN,
+3 floats MAX; RCCL over xGMI on GPUs, gloo in the CPU tests): latency-bound, never bandwidth-bound.
+
+Stripe boundaries must be multiples of lcm(2 (4:2:0 chroma rows), scale (box sampling), 16 (4:2:0
+MCU rows of the JPEG stage)); ``partition_rows`` takes that granule.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+from . import capi as A
+
+
+def stripe_granule(scale: int = 1, mcu_rows: int = 16) -> int:
+    return math.lcm(2, max(1, scale), mcu_rows)
+
+
+def partition_rows(height: int, world_size: int, granule: int = 16):
+    """[(row0, rows)] per rank: contiguous stripes, sizes multiples of ``granule`` except possibly
+    the last; earlier ranks get the extra granules.  Ranks beyond the available granules get 0 rows."""
+    if height <= 0 or world_size <= 0:
+        raise ValueError("height and world_size must be positive")
+    units = (height + granule - 1) // granule
+    base, extra = divmod(units, world_size)
+    out, row = [], 0
+    for r in range(world_size):
+        n = (base + (1 if r < extra else 0)) * granule
+        n = max(0, min(n, height - row))
+        out.append((row, n))
+        row += n
+    assert row == height
+    return out
+
+
+def allreduce_minmax(minmax, group=None):
+    """In-place all-reduce of a 6-element float32 tensor {min0,min1,min2,max0,max1,max2}:
+    MIN over the first three, MAX over the last three.  Works on CPU tensors (gloo) and CUDA tensors
+    (backend "nccl" == RCCL on ROCm).  Float min/max is order-independent, so the result is
+    bit-identical to the reference's sequential merge."""
+    import torch.distributed as dist
+
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return minmax
+    dist.all_reduce(minmax[:3], op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(minmax[3:], op=dist.ReduceOp.MAX, group=group)
+    return minmax
+
+
+def finalize_minmax(cfg: A.EncodeCfg, hdr_ct: int, use_base_cg: int, minmax6):
+    """Host half of two-pass generation (clamp, user hints, epsilon guard, metadata fill:
+    jpegr.cpp:969-986, 1031-1048) through the C ABI; pure host code, needs no GPU.
+    Returns (finalized [6] list, GainmapMetadata)."""
+    lib = A.load()
+    mm = (C.c_float * 6)(*[float(v) for v in minmax6])
+    md = A.GainmapMetadata()
+    A.check(lib.uhdr_hip_generate_gainmap_finalize(C.byref(cfg), hdr_ct, use_base_cg, mm, C.byref(md)))
+    return list(mm), md
+
+
+def generate_gainmap_two_pass_striped(uhdr, sdr_stripe, hdr_stripe, cfg: A.EncodeCfg, gm_stripe, group=None):
+    """Two-pass generateGainMap for THIS rank's stripe (device images).  ``gm_stripe`` is the
+    destination stripe of the gain map (device Image, rows = stripe rows / scale).
+    pass 1 (kernel) -> all-reduce(min/max) -> finalize (host) -> pass 2 (kernel)."""
+    import torch
+
+    dev = sdr_stripe.buf.device
+    nch = 3 if cfg.use_multi_channel_gainmap else 1
+    s = cfg.map_dimension_scale_factor
+    mw, mh = sdr_stripe.w // s, sdr_stripe.h // s
+    gains = torch.empty(mw * mh * nch, dtype=torch.float32, device=dev)
+    mm = torch.empty(6, dtype=torch.float32, device=dev)
+    ubc = C.c_int(1)
+    lib, h = uhdr.lib, uhdr.ctx.handle
+    A.check(lib.uhdr_hip_generate_gainmap_pass1_dev(h, C.byref(sdr_stripe.raw), C.byref(hdr_stripe.raw), C.byref(cfg),
+                                                    C.c_void_p(gains.data_ptr()), C.c_void_p(mm.data_ptr()), C.byref(ubc)))
+    uhdr.ctx.synchronize()  # mm was produced on the context's stream; the collective runs on torch's
+    allreduce_minmax(mm, group)
+    fin, md = finalize_minmax(cfg, hdr_stripe.raw.ct, ubc.value, mm.cpu().tolist())
+    gm_stripe.raw.w, gm_stripe.raw.h = mw, mh
+    A.check(lib.uhdr_hip_generate_gainmap_pass2_dev(h, C.c_void_p(gains.data_ptr()), (C.c_float * 6)(*fin), C.byref(cfg),
+                                                    C.byref(gm_stripe.raw)))
+    return md

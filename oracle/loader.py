@@ -46,6 +46,10 @@ def port() -> C.CDLL:
     lib.uo_apply_gainmap.argtypes = [_P(A.RawImage), _P(A.RawImage), _P(A.GainmapMetadata), C.c_int, C.c_int, C.c_float, _P(A.RawImage)]
     lib.uo_generate_gainmap.restype = C.c_int
     lib.uo_generate_gainmap.argtypes = [_P(A.RawImage), _P(A.RawImage), _P(A.EncodeCfg), _P(A.GainmapMetadata), _P(A.RawImage)]
+    lib.uo_generate_gainmap_pass1.restype = C.c_int
+    lib.uo_generate_gainmap_pass1.argtypes = [_P(A.RawImage), _P(A.RawImage), _P(A.EncodeCfg), C.c_void_p, _P(C.c_float), _P(C.c_int)]
+    lib.uo_generate_gainmap_pass2.restype = None
+    lib.uo_generate_gainmap_pass2.argtypes = [C.c_void_p, _P(C.c_float), C.c_float, C.c_int, C.c_uint, C.c_uint, C.c_void_p, C.c_size_t]
     lib.uo_tone_map.restype = C.c_int
     lib.uo_tone_map.argtypes = [_P(A.RawImage), _P(A.RawImage)]
     lib.uo_convert_yuv.restype = C.c_int

@@ -671,8 +671,10 @@ int uo_apply_gainmap(const uo_image_t* sdr, const uo_image_t* gm, const uo_metad
 /* ---------------------------------------------------------------------------------------------
  * UltraHdr::generateGainMap: jpegr.cpp:530-1058  (built with UHDR_WRITE_ISO only => no XMP merge)
  * ------------------------------------------------------------------------------------------- */
-int uo_generate_gainmap(const uo_image_t* sdr, const uo_image_t* hdr, const uo_encode_cfg_t* cfg,
-                        uo_metadata_t* md, uo_image_t* gm) {
+/* ext_gbuf/ext_minmax non-NULL: stop after pass 1 of the two-pass mode and hand out the float
+ * log2-gain plane and {min0,min1,min2,max0,max1,max2} (used by the row-stripe tests). */
+static int gen_run(const uo_image_t* sdr, const uo_image_t* hdr, const uo_encode_cfg_t* cfg,
+                   uo_metadata_t* md, uo_image_t* gm, float* ext_gbuf, float* ext_minmax) {
   init_luts();
   if (sdr->fmt != UO_FMT_YUV444 && sdr->fmt != UO_FMT_YUV422 && sdr->fmt != UO_FMT_YUV420 &&
       sdr->fmt != UO_FMT_RGBA8888)
@@ -708,7 +710,7 @@ int uo_generate_gainmap(const uo_image_t* sdr, const uo_image_t* hdr, const uo_e
   gm->fmt = multi ? UO_FMT_RGB888 : UO_FMT_Y400;
   gm->cg = hdr->cg; gm->ct = hdr->ct; gm->range = hdr->range;
   gm->w = mw; gm->h = mh;
-  if (gm->stride[0] < mw) return UO_INVALID_PARAM;
+  if (!ext_gbuf && gm->stride[0] < mw) return UO_INVALID_PARAM;
   uint8_t* out = (uint8_t*)gm->planes[0];
   const size_t ostride = gm->stride[0];
 
@@ -733,7 +735,7 @@ int uo_generate_gainmap(const uo_image_t* sdr, const uo_image_t* hdr, const uo_e
     log2min = log2f(md->min_content_boost[0]);
     log2max = log2f(md->max_content_boost[0]);
   } else {
-    gbuf = (float*)malloc((size_t)mw * mh * sizeof(float) * (multi ? 3 : 1));
+    gbuf = ext_gbuf ? ext_gbuf : (float*)malloc((size_t)mw * mh * sizeof(float) * (multi ? 3 : 1));
     if (!gbuf) return UO_MEM_ERROR;
   }
 
@@ -791,6 +793,10 @@ int uo_generate_gainmap(const uo_image_t* sdr, const uo_image_t* hdr, const uo_e
     }
   }
   if (!two_pass) return UO_OK;
+  if (ext_gbuf) {
+    for (int i = 0; i < 3; i++) { ext_minmax[i] = gmin[i]; ext_minmax[3 + i] = gmax[i]; }
+    return UO_OK;
+  }
 
   const int nch = multi ? 3 : 1;
   for (int i = 0; i < nch; i++) { /* jpegr.cpp:969-986 */
@@ -815,6 +821,30 @@ int uo_generate_gainmap(const uo_image_t* sdr, const uo_image_t* hdr, const uo_e
   md->hdr_capacity_min = 1.0f;
   md->hdr_capacity_max = cfg->target_nits != -1.0f ? cfg->target_nits / kSdrWhiteNits : hdr_white_nits / kSdrWhiteNits;
   return UO_OK;
+}
+
+int uo_generate_gainmap(const uo_image_t* sdr, const uo_image_t* hdr, const uo_encode_cfg_t* cfg,
+                        uo_metadata_t* md, uo_image_t* gm) {
+  return gen_run(sdr, hdr, cfg, md, gm, NULL, NULL);
+}
+int uo_generate_gainmap_pass1(const uo_image_t* sdr, const uo_image_t* hdr, const uo_encode_cfg_t* cfg,
+                              float* gain_log2, float minmax[6], int* use_base_cg) {
+  uo_metadata_t md;
+  uo_image_t gm;
+  memset(&gm, 0, sizeof gm);
+  uo_encode_cfg_t c = *cfg;
+  c.preset = UO_PRESET_BEST_QUALITY;
+  int rc = gen_run(sdr, hdr, &c, &md, &gm, gain_log2, minmax);
+  *use_base_cg = md.use_base_cg;
+  return rc;
+}
+/* pass 2 of jpegr.cpp:992-1013 on an externally reduced min/max (already clamped/finalized) */
+void uo_generate_gainmap_pass2(const float* gain_log2, const float minmax[6], float gamma, int nch,
+                               unsigned mw, unsigned mh, uint8_t* out, size_t out_stride) {
+  for (size_t y = 0; y < mh; ++y)
+    for (size_t i = 0; i < (size_t)mw * nch; i++)
+      out[y * out_stride * nch + i] =
+          affine_map_gain(gain_log2[y * mw * nch + i], minmax[i % nch], minmax[3 + i % nch], gamma);
 }
 
 /* ---------------------------------------------------------------------------------------------

@@ -75,6 +75,11 @@ int uo_apply_gainmap(const uo_image_t* sdr, const uo_image_t* gm, const uo_metad
 /* gm_out->planes[0] caller-allocated, stride taken from gm_out->stride[0] (>= map width). */
 int uo_generate_gainmap(const uo_image_t* sdr, const uo_image_t* hdr, const uo_encode_cfg_t* cfg,
                         uo_metadata_t* md_out, uo_image_t* gm_out);
+/* the two-pass mode split at its only exchange step (jpegr.cpp:932-938), for row-stripe tests */
+int uo_generate_gainmap_pass1(const uo_image_t* sdr, const uo_image_t* hdr, const uo_encode_cfg_t* cfg,
+                              float* gain_log2, float minmax[6], int* use_base_cg);
+void uo_generate_gainmap_pass2(const float* gain_log2, const float minmax[6], float gamma, int nch,
+                               unsigned mw, unsigned mh, uint8_t* out, size_t out_stride);
 int uo_tone_map(const uo_image_t* hdr, uo_image_t* sdr);
 int uo_convert_yuv(uo_image_t* img, int src_cg, int dst_cg);
 /* dst planes/strides caller-provided; dst->fmt decides the variant like the reference does. */

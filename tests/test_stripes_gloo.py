@@ -1,0 +1,80 @@
+"""The N > 1 path on CPU: two gloo ranks shard one image by row stripe and run two-pass gain-map
+generation around the product's one exchange step (libultrahdr_amd.stripes.allreduce_minmax +
+the C ABI's host-side finalize).  Per-stripe pixel math comes from the CPU oracle here (test
+infrastructure -- there is no GPU in this container); the result must equal the whole-image run
+bit for bit, metadata included (float min/max is order independent, jpegr.cpp:932-938)."""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from libultrahdr_amd import capi as A
+from libultrahdr_amd import synth
+from libultrahdr_amd.images import Image, stripe_view
+from libultrahdr_amd.stripes import allreduce_minmax, finalize_minmax, partition_rows, stripe_granule
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, cfg_kw, w, h, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import loader as L
+
+    cfg = A.default_encode_cfg(**cfg_kw)
+    s = cfg.map_dimension_scale_factor
+    nch = 3 if cfg.use_multi_channel_gainmap else 1
+    sdr = synth.make_sdr_yuv420(w, h, noise=0.05)
+    hdr = synth.make_hdr_p010(w, h, ct=A.UHDR_CT_HLG, noise=0.05)
+    row0, rows = partition_rows(h, world, stripe_granule(s))[rank]
+    sv, hv = stripe_view(sdr, row0, rows), stripe_view(hdr, row0, rows)
+    mw, mh = w // s, rows // s
+    gains = np.zeros(mw * mh * nch, dtype=np.float32)
+    mm = (C.c_float * 6)()
+    ubc = C.c_int(0)
+    assert L.port().uo_generate_gainmap_pass1(C.byref(sv), C.byref(hv), C.byref(cfg), gains.ctypes.data, mm, C.byref(ubc)) == 0
+    t = torch.tensor(list(mm), dtype=torch.float32)
+    allreduce_minmax(t)                                    # <- the product's exchange step (gloo here, RCCL on GPUs)
+    fin, md = finalize_minmax(cfg, hdr.raw.ct, ubc.value, t.tolist())  # <- product host logic via the C ABI
+    out = np.zeros((mh, mw * nch), dtype=np.uint8)
+    L.port().uo_generate_gainmap_pass2(gains.ctypes.data, (C.c_float * 6)(*fin), cfg.gamma, nch, mw, mh, out.ctypes.data, mw)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (row0 // s, out, bytes(md)))
+    if rank == 0:
+        full = np.concatenate([g[1] for g in sorted(gathered, key=lambda g: g[0])], axis=0)
+        assert all(g[2] == gathered[0][2] for g in gathered)  # identical metadata on every rank
+        np.save(out_path, full)
+        open(out_path + ".md", "wb").write(gathered[0][2])
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cfg_kw", [dict(), dict(map_dimension_scale_factor=4, use_multi_channel_gainmap=0),
+                                    dict(max_content_boost=3.0, gamma=1.2)])
+def test_two_rank_striped_two_pass_equals_whole_image(tmp_path, cfg_kw):
+    from oracle import loader as L
+
+    w, h = 128, 96
+    out = str(tmp_path / "gm.npy")
+    mp.spawn(_worker, args=(2, _free_port(), cfg_kw, w, h, out), nprocs=2, join=True)
+    cfg = A.default_encode_cfg(**cfg_kw)
+    md_w, gm_w = L.generate_gainmap("port", synth.make_sdr_yuv420(w, h, noise=0.05),
+                                    synth.make_hdr_p010(w, h, ct=A.UHDR_CT_HLG, noise=0.05), cfg)
+    assert np.array_equal(np.load(out), gm_w.valid(0))
+    assert open(out + ".md", "rb").read() == bytes(md_w)
+
+
+def test_allreduce_minmax_single_process_is_identity():
+    t = torch.tensor([1.0, 2.0, 3.0, 4.0, 5.0, 6.0])
+    assert allreduce_minmax(t.clone()).tolist() == t.tolist()
