@@ -161,6 +161,14 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).  Device memory
+    # handed to us comes from torch, so torch's HIP runtime must be the one this process uses: import
+    # it first, then our DT_NEEDED libamdhip64.so.7 binds to the already-loaded copy.  (Loading ours
+    # first gives the process two HIP runtimes and torch then reports "No HIP GPUs are available".)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

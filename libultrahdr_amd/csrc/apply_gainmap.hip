@@ -226,10 +226,32 @@ __global__ __launch_bounds__(kBlock) void apply_generic_kernel(const ApplyParams
 }
 
 // ---------------------------------------------------------------------------------------------
-// quad kernel (4:2:0 base, even geometry).  MAPFMT: 0 Y400, 1 RGB888, 2 RGBA8888.
-// SMODE: 0 scale == 1 (byte -> factor table, no interpolation), 1 even integer scale (the four
-// taps are shared by the whole 2x2 quad; only the weights differ per pixel).
+// quad kernel (4:2:0 base, even geometry, gamma == 1 or scale == 1).
+//   MAPFMT: 0 Y400, 1 RGB888, 2 RGBA8888.
+//   SMODE : 0 scale == 1 (byte -> factor table, no interpolation),
+//           1 even integer scale (the four taps are shared by the whole 2x2 quad; only the
+//             weights differ per pixel).
+// One lane = one chroma sample = a 2x2 luma quad.  The two pixels of a row are carried as a
+// 2-vector so the float pipeline maps onto the packed v_pk_{mul,add}_f32 instructions (each packed
+// op is still one IEEE mul / add per element: bit-identical to scalar code).  All addressing is
+// 32-bit offsets from uniform (SGPR) base pointers.
 // ---------------------------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2 splat(float v) { return (f2){v, v}; }
+__device__ __forceinline__ f2 clamp01_2(f2 v) { return (f2){clamp01(v.x), clamp01(v.y)}; }
+// LUT index for x in [0,1] (no clip needed: clamp01 guarantees the range), as a BYTE offset
+__device__ __forceinline__ uint2 lut_off_1024(f2 x) {
+  const f2 t = x * 1023.0f + 0.5f;
+  return (uint2){(uint32_t)(int)t.x << 2, (uint32_t)(int)t.y << 2};
+}
+__device__ __forceinline__ f2 lds_gather(const float* base, uint2 byte_off) {
+  const char* b = (const char*)base;
+  return (f2){*(const float*)(b + byte_off.x), *(const float*)(b + byte_off.y)};
+}
+// the smallest float whose floatToHalf lands in the normal-half range: bits + 0x1000 >= 113 << 23
+#define UHDR_HALF_FAST_MIN_BITS ((113u << 23) - 0x1000u)
+
 template <int OUT, int MAPFMT, int SMODE>
 __global__ __launch_bounds__(kBlock) void apply_quad_kernel(const ApplyParams p) {
   constexpr int NCH = (MAPFMT == 0) ? 1 : 3;
@@ -238,17 +260,23 @@ __global__ __launch_bounds__(kBlock) void apply_quad_kernel(const ApplyParams p)
   __shared__ float s_gain[(SMODE == 0) ? 1 : NCH * kGainN];
   __shared__ float s_u8f[(SMODE == 0) ? 1 : 256];
   __shared__ float s_fac[(SMODE == 0) ? NCH * 256 : 1];
+  // IDW weights re-laid out for pixel PAIRS: entry (table, oy, ox/2) holds
+  // {w0(ox), w0(ox+1), w1(ox), w1(ox+1), w2(ox), w2(ox+1), w3(ox), w3(ox+1)}
   __shared__ __attribute__((aligned(16))) float s_idw[(SMODE == 0) ? 4 : 4 * kMaxIdwScaleLds * kMaxIdwScaleLds * 4];
 
-  const int tid = threadIdx.x;
-  for (int i = tid; i < kSrgbN; i += kBlock) s_srgb[i] = p.tables[ApplyTables::kSrgbOff + i];
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t i = tid; i < kSrgbN; i += kBlock) s_srgb[i] = p.tables[ApplyTables::kSrgbOff + i];
   if constexpr (SMODE == 0) {
-    for (int i = tid; i < NCH * 256; i += kBlock) s_fac[i] = p.tables[ApplyTables::kFacOff + i];
+    for (uint32_t i = tid; i < NCH * 256; i += kBlock) s_fac[i] = p.tables[ApplyTables::kFacOff + i];
   } else {
-    for (int i = tid; i < NCH * kGainN; i += kBlock) s_gain[i] = p.tables[ApplyTables::kGainOff + i];
-    for (int i = tid; i < 256; i += kBlock) s_u8f[i] = p.tables[ApplyTables::kU8fOff + i];
-    const int nidw = 4 * p.scale * p.scale * 4;
-    for (int i = tid; i < nidw; i += kBlock) s_idw[i] = p.tables[ApplyTables::kIdwOff + i];
+    for (uint32_t i = tid; i < NCH * kGainN; i += kBlock) s_gain[i] = p.tables[ApplyTables::kGainOff + i];
+    for (uint32_t i = tid; i < 256; i += kBlock) s_u8f[i] = p.tables[ApplyTables::kU8fOff + i];
+    const uint32_t s = p.scale, nidw = 4 * s * s * 4;
+    for (uint32_t i = tid; i < nidw; i += kBlock) {
+      // source index i = ((tbl*s + oy)*s + ox)*4 + k  ->  pair layout
+      const uint32_t k = i & 3, pos = i >> 2, ox = pos % s, row = pos / s;  // row = tbl*s + oy
+      s_idw[(row * (s >> 1) + (ox >> 1)) * 8 + k * 2 + (ox & 1)] = p.tables[ApplyTables::kIdwOff + i];
+    }
   }
   __syncthreads();
 
@@ -259,14 +287,20 @@ __global__ __launch_bounds__(kBlock) void apply_quad_kernel(const ApplyParams p)
   const uint32_t wave = (blockIdx.x * (kBlock / 64)) + (tid >> 6);
   const uint32_t nwaves = gridDim.x * (kBlock / 64);
 
-  const uint8_t* yp = (const uint8_t*)p.sdr.p[0];
-  const uint8_t* up = (const uint8_t*)p.sdr.p[1];
-  const uint8_t* vp = (const uint8_t*)p.sdr.p[2];
-  const uint8_t* mp = (const uint8_t*)p.gm.p[0];
-  const size_t sy = p.sdr.stride[0], su = p.sdr.stride[1], sv = p.sdr.stride[2];
-  const size_t sm = p.gm.stride[0], sd = p.dst.stride[0];
-  using T = typename OutPix<OUT>::type;
-  T* dp = (T*)p.dst.p[0];
+  const uint8_t* __restrict__ yp = (const uint8_t*)p.sdr.p[0];
+  const uint8_t* __restrict__ up = (const uint8_t*)p.sdr.p[1];
+  const uint8_t* __restrict__ vp = (const uint8_t*)p.sdr.p[2];
+  const uint8_t* __restrict__ mp = (const uint8_t*)p.gm.p[0];
+  uint8_t* __restrict__ dp = (uint8_t*)p.dst.p[0];
+  const uint32_t sy = p.sdr.stride[0], su = p.sdr.stride[1], sv = p.sdr.stride[2];
+  const uint32_t sm = p.gm.stride[0];
+  constexpr uint32_t OPX = (OUT == 0) ? 8 : 4;  // output bytes per pixel
+  const uint32_t sd = p.dst.stride[0] * OPX;    // destination row pitch in bytes
+  const float k255 = 1 / 255.0f;
+  const Yuv2Rgb yk = p.yuv;
+  const f2 off_s0 = splat(p.offset_sdr[0]), off_h0 = splat(p.offset_hdr[0]);
+  const f2 off_s1 = splat(p.offset_sdr[NCH == 1 ? 0 : 1]), off_h1 = splat(p.offset_hdr[NCH == 1 ? 0 : 1]);
+  const f2 off_s2 = splat(p.offset_sdr[NCH == 1 ? 0 : 2]), off_h2 = splat(p.offset_hdr[NCH == 1 ? 0 : 2]);
 
   for (uint32_t t = wave; t < total; t += nwaves) {
     const uint32_t qy = t / strips_x;
@@ -274,120 +308,163 @@ __global__ __launch_bounds__(kBlock) void apply_quad_kernel(const ApplyParams p)
     if (qx >= qw) continue;
     const uint32_t x = qx * 2, y = qy * 2;
     // ---- loads: 2+2 luma bytes, 1+1 chroma bytes ------------------------------------------
-    const uint32_t ya = *(const uint16_t*)(yp + (size_t)y * sy + x);
-    const uint32_t yb = *(const uint16_t*)(yp + (size_t)(y + 1) * sy + x);
-    const int ub = up[(size_t)qy * su + qx], vb = vp[(size_t)qy * sv + qx];
-    // getYuv4abPixel (gainmapmath.cpp:370-374)
-    const float uf = (float)(ub - 128) * (1 / 255.0f);
-    const float vf = (float)(vb - 128) * (1 / 255.0f);
-    // p3YuvToRgb chroma products shared by the four pixels (gainmapmath.cpp:177-181)
-    const float crv = p.yuv.cr * vf, gcbu = p.yuv.gcb * uf, gcrv = p.yuv.gcr * vf, cbu = p.yuv.cb * uf;
-
+    const uint32_t yoff = y * sy + x;
+    const uint32_t yrow[2] = {*(const uint16_t*)(yp + yoff), *(const uint16_t*)(yp + (yoff + sy))};
+    const int ub = up[qy * su + qx], vb = vp[qy * sv + qx];
     const uint32_t yg = y + p.y0;
-    // ---- gain-map taps --------------------------------------------------------------------
+
+    // ---- gain-map fetch ---------------------------------------------------------------------
     float tap[(SMODE == 0) ? 1 : 4][NCH];
-    uint32_t ox = 0, oy = 0, tbl = 0;
-    uint32_t m0[2], m1[2];  // SMODE 0: raw map bytes of row 0 / row 1 (two pixels each)
+    uint32_t widx = 0;            // SMODE 1: float index of the weight entry for (row 0, this pair)
+    uint32_t mrow[2][2];          // SMODE 0: raw map bytes of the two pixels of row 0 / row 1
     if constexpr (SMODE == 0) {
-      const uint8_t* r0 = mp + ((size_t)yg * sm + x) * BPP;
-      const uint8_t* r1 = r0 + sm * BPP;
-      if constexpr (MAPFMT == 0) {
-        m0[0] = *(const uint16_t*)r0;
-        m1[0] = *(const uint16_t*)r1;
-      } else if constexpr (MAPFMT == 1) {  // 6 bytes per row: three aligned 16-bit loads
-        const uint16_t* a = (const uint16_t*)r0;
-        const uint16_t* b = (const uint16_t*)r1;
-        m0[0] = a[0] | ((uint32_t)a[1] << 16);
-        m0[1] = a[2];
-        m1[0] = b[0] | ((uint32_t)b[1] << 16);
-        m1[1] = b[2];
-      } else {
-        const uint2 a = *(const uint2*)r0, b = *(const uint2*)r1;
-        m0[0] = a.x; m0[1] = a.y;
-        m1[0] = b.x; m1[1] = b.y;
+      const uint32_t moff = (yg * sm + x) * BPP;
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        const uint8_t* q = mp + (moff + r * sm * BPP);
+        if constexpr (MAPFMT == 0) {
+          mrow[r][0] = *(const uint16_t*)q;
+          mrow[r][1] = 0;
+        } else if constexpr (MAPFMT == 1) {  // 6 bytes: three aligned 16-bit loads
+          const uint16_t* a = (const uint16_t*)q;
+          mrow[r][0] = a[0] | ((uint32_t)a[1] << 16);
+          mrow[r][1] = a[2];
+        } else {
+          const uint2 a = *(const uint2*)q;
+          mrow[r][0] = a.x;
+          mrow[r][1] = a.y;
+        }
       }
     } else {
       const uint32_t s = p.scale;
       uint32_t xl = __umulhi(x, p.scale_magic), yl = __umulhi(yg, p.scale_magic);
-      ox = x - xl * s;
-      oy = yg - yl * s;
-      uint32_t xu = min(xl + 1, p.gm.w - 1), yu = min(yl + 1, p.gm.h - 1);
+      const uint32_t ox = x - xl * s, oy = yg - yl * s;
+      const uint32_t xu = min(xl + 1, p.gm.w - 1), yu = min(yl + 1, p.gm.h - 1);
       xl = min(xl, p.gm.w - 1);
       yl = min(yl, p.gm.h - 1);
-      tbl = (xl == xu && yl == yu) ? 3 : (xl == xu) ? 1 : (yl == yu) ? 2 : 0;
-      const uint8_t* a1 = mp + (xl + yl * sm) * BPP;
-      const uint8_t* a2 = mp + (xl + yu * sm) * BPP;
-      const uint8_t* a3 = mp + (xu + yl * sm) * BPP;
-      const uint8_t* a4 = mp + (xu + yu * sm) * BPP;
+      const uint32_t tbl = (xl == xu && yl == yu) ? 3u : (xl == xu) ? 1u : (yl == yu) ? 2u : 0u;
+      widx = ((tbl * s + oy) * (s >> 1) + (ox >> 1)) * 8;
+      const uint32_t a1 = (xl + yl * sm) * BPP, a2 = (xl + yu * sm) * BPP;
+      const uint32_t a3 = (xu + yl * sm) * BPP, a4 = (xu + yu * sm) * BPP;
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
-        tap[0][c] = s_u8f[a1[c]];
-        tap[1][c] = s_u8f[a2[c]];
-        tap[2][c] = s_u8f[a3[c]];
-        tap[3][c] = s_u8f[a4[c]];
+        tap[0][c] = s_u8f[mp[a1 + c]];
+        tap[1][c] = s_u8f[mp[a2 + c]];
+        tap[2][c] = s_u8f[mp[a3 + c]];
+        tap[3][c] = s_u8f[mp[a4 + c]];
       }
     }
 
-    T outp[2][2];
+    // getYuv4abPixel chroma (gainmapmath.cpp:370-374) and the p3YuvToRgb chroma products shared
+    // by the four pixels (gainmapmath.cpp:177-181)
+    const float uf = (float)(ub - 128) * k255, vf = (float)(vb - 128) * k255;
+    const float crv = yk.cr * vf, gcbu = yk.gcb * uf, gcrv = yk.gcr * vf, cbu = yk.cb * uf;
+
 #pragma unroll
     for (int r = 0; r < 2; r++) {
-      const uint32_t ybits = r == 0 ? ya : yb;
-#pragma unroll
-      for (int c = 0; c < 2; c++) {
-        const float yf = (float)((ybits >> (8 * c)) & 0xff) * (1 / 255.0f);
-        const float gr = clamp01(yf + crv);
-        const float gg = clamp01(yf - gcbu - gcrv);
-        const float gb = clamp01(yf + cbu);
-        Color3 lin = {s_srgb[lut_index_f32<kSrgbN>(gr)], s_srgb[lut_index_f32<kSrgbN>(gg)],
-                      s_srgb[lut_index_f32<kSrgbN>(gb)]};
-        if (p.sdr_gamut_on) lin = mat3_apply(lin, p.gamut);
-        float f0, f1, f2;
-        if constexpr (SMODE == 0) {
-          const uint32_t* mrow = r == 0 ? m0 : m1;
-          if constexpr (MAPFMT == 0) {
-            f0 = f1 = f2 = s_fac[(mrow[0] >> (8 * c)) & 0xff];
-          } else if constexpr (MAPFMT == 1) {
-            // bytes: R0 G0 B0 R1 G1 B1 packed little-endian into mrow[0] (4) + mrow[1] (2)
-            const uint64_t v = (uint64_t)mrow[0] | ((uint64_t)mrow[1] << 32);
-            const uint32_t px = (uint32_t)(v >> (24 * c));
-            f0 = s_fac[px & 0xff];
-            f1 = s_fac[256 + ((px >> 8) & 0xff)];
-            f2 = s_fac[512 + ((px >> 16) & 0xff)];
-          } else {
-            const uint32_t px = mrow[c];
-            f0 = s_fac[px & 0xff];
-            f1 = s_fac[256 + ((px >> 8) & 0xff)];
-            f2 = s_fac[512 + ((px >> 16) & 0xff)];
-          }
-        } else {
-          const float4 w = *(const float4*)(s_idw + (size_t)tbl * p.scale * p.scale * 4 +
-                                            ((oy + r) * p.scale + (ox + c)) * 4);
-          float gn[NCH];
-#pragma unroll
-          for (int k = 0; k < NCH; k++)
-            gn[k] = tap[0][k] * w.x + tap[1][k] * w.y + tap[2][k] * w.z + tap[3][k] * w.w;
-          f0 = gain_factor(gn[0], s_gain, 0, p);
-          if constexpr (NCH == 3) {
-            f1 = gain_factor(gn[1], s_gain, 1, p);
-            f2 = gain_factor(gn[2], s_gain, 2, p);
-          } else {
-            f1 = f2 = f0;
-          }
-        }
-        outp[r][c] = finish_pixel<OUT>(lin, f0, f1, f2, p, NCH);
+      const f2 yf = (f2){(float)(yrow[r] & 0xff), (float)(yrow[r] >> 8)} * k255;
+      const f2 gr = clamp01_2(yf + crv);
+      const f2 gg = clamp01_2(yf - gcbu - gcrv);
+      const f2 gb = clamp01_2(yf + cbu);
+      f2 lr = lds_gather(s_srgb, lut_off_1024(gr));
+      f2 lg = lds_gather(s_srgb, lut_off_1024(gg));
+      f2 lb = lds_gather(s_srgb, lut_off_1024(gb));
+      if (p.sdr_gamut_on) {
+        const Mat3& m = p.gamut;
+        const f2 nr = m.m[0] * lr + m.m[1] * lg + m.m[2] * lb;
+        const f2 ng = m.m[3] * lr + m.m[4] * lg + m.m[5] * lb;
+        const f2 nb = m.m[6] * lr + m.m[7] * lg + m.m[8] * lb;
+        lr = nr; lg = ng; lb = nb;
       }
-    }
-    // ---- stores: two adjacent pixels per row -> one 16 B (F16) / 8 B (1010102) store ------
-    if constexpr (OUT == 0) {
-      uint4 s0 = {outp[0][0].x, outp[0][0].y, outp[0][1].x, outp[0][1].y};
-      uint4 s1 = {outp[1][0].x, outp[1][0].y, outp[1][1].x, outp[1][1].y};
-      *(uint4*)(dp + (size_t)y * sd + x) = s0;
-      *(uint4*)(dp + (size_t)(y + 1) * sd + x) = s1;
-    } else {
-      uint2 s0 = {outp[0][0], outp[0][1]};
-      uint2 s1 = {outp[1][0], outp[1][1]};
-      *(uint2*)(dp + (size_t)y * sd + x) = s0;
-      *(uint2*)(dp + (size_t)(y + 1) * sd + x) = s1;
+      f2 f0, f1, f2_;
+      if constexpr (SMODE == 0) {
+        if constexpr (MAPFMT == 0) {
+          f0 = (f2){s_fac[mrow[r][0] & 0xff], s_fac[(mrow[r][0] >> 8) & 0xff]};
+          f1 = f0; f2_ = f0;
+        } else if constexpr (MAPFMT == 1) {  // R0 G0 B0 R1 | G1 B1
+          const uint32_t a = mrow[r][0], b = mrow[r][1];
+          f0 = (f2){s_fac[a & 0xff], s_fac[a >> 24]};
+          f1 = (f2){s_fac[256 + ((a >> 8) & 0xff)], s_fac[256 + (b & 0xff)]};
+          f2_ = (f2){s_fac[512 + ((a >> 16) & 0xff)], s_fac[512 + ((b >> 8) & 0xff)]};
+        } else {
+          const uint32_t a = mrow[r][0], b = mrow[r][1];
+          f0 = (f2){s_fac[a & 0xff], s_fac[b & 0xff]};
+          f1 = (f2){s_fac[256 + ((a >> 8) & 0xff)], s_fac[256 + ((b >> 8) & 0xff)]};
+          f2_ = (f2){s_fac[512 + ((a >> 16) & 0xff)], s_fac[512 + ((b >> 16) & 0xff)]};
+        }
+      } else {
+        const float4 wa = *(const float4*)(s_idw + widx + r * (p.scale >> 1) * 8);
+        const float4 wb = *(const float4*)(s_idw + widx + r * (p.scale >> 1) * 8 + 4);
+        const f2 w0 = {wa.x, wa.y}, w1 = {wa.z, wa.w}, w2 = {wb.x, wb.y}, w3 = {wb.z, wb.w};
+        // sampleMap: e1*w0 + e2*w1 + e3*w2 + e4*w3, left to right (gainmapmath.cpp:955, 1079)
+        const f2 g0 = tap[0][0] * w0 + tap[1][0] * w1 + tap[2][0] * w2 + tap[3][0] * w3;
+        f0 = lds_gather(s_gain, lut_off_1024(g0));  // gain slightly > 1 cannot occur: weights sum <= 1 + 1ulp -> idx <= 1023
+        if constexpr (NCH == 3) {
+          const f2 g1 = tap[0][1] * w0 + tap[1][1] * w1 + tap[2][1] * w2 + tap[3][1] * w3;
+          const f2 g2 = tap[0][2] * w0 + tap[1][2] * w1 + tap[2][2] * w2 + tap[3][2] * w3;
+          f1 = lds_gather(s_gain + kGainN, lut_off_1024(g1));
+          f2_ = lds_gather(s_gain + 2 * kGainN, lut_off_1024(g2));
+        } else {
+          f1 = f0; f2_ = f0;
+        }
+      }
+      // applyGainLUT: ((e + offset_sdr) * factor) - offset_hdr  (gainmapmath.cpp:807-810, 848-855)
+      f2 hr = ((lr + off_s0) * f0) - off_h0;
+      f2 hg = ((lg + off_s1) * f1) - off_h1;
+      f2 hb = ((lb + off_s2) * f2_) - off_h2;
+      uint8_t* drow = dp + ((y + r) * sd + x * OPX);
+      if constexpr (OUT == 0) {
+        if (p.hdr_gamut_on) {
+          const Mat3& m = p.gamut;
+          const f2 nr = m.m[0] * hr + m.m[1] * hg + m.m[2] * hb;
+          const f2 ng = m.m[3] * hr + m.m[4] * hg + m.m[5] * hb;
+          const f2 nb = m.m[6] * hr + m.m[7] * hg + m.m[8] * hb;
+          hr = nr; hg = ng; hb = nb;
+        }
+        const float c0r = clamp_linear(hr.x), c0g = clamp_linear(hg.x), c0b = clamp_linear(hb.x);
+        const float c1r = clamp_linear(hr.y), c1g = clamp_linear(hg.y), c1b = clamp_linear(hb.y);
+        // all six values are >= 0, so "every one is in the 2-op half range" is one min + compare
+        const float mn = fminf(fminf(fminf(c0r, c0g), fminf(c0b, c1r)), fminf(c1g, c1b));
+        uint4 o;
+        if (__builtin_amdgcn_ballot_w64(__float_as_uint(mn) < UHDR_HALF_FAST_MIN_BITS) == 0) {
+          o.x = float_to_half_fast(__float_as_uint(c0r)) | (float_to_half_fast(__float_as_uint(c0g)) << 16);
+          o.y = float_to_half_fast(__float_as_uint(c0b)) | (0x3C00u << 16);
+          o.z = float_to_half_fast(__float_as_uint(c1r)) | (float_to_half_fast(__float_as_uint(c1g)) << 16);
+          o.w = float_to_half_fast(__float_as_uint(c1b)) | (0x3C00u << 16);
+        } else {
+          o.x = float_to_half_general(__float_as_uint(c0r)) | (float_to_half_general(__float_as_uint(c0g)) << 16);
+          o.y = float_to_half_general(__float_as_uint(c0b)) | (0x3C00u << 16);
+          o.z = float_to_half_general(__float_as_uint(c1r)) | (float_to_half_general(__float_as_uint(c1g)) << 16);
+          o.w = float_to_half_general(__float_as_uint(c1b)) | (0x3C00u << 16);
+        }
+        *(uint4*)drow = o;
+      } else {
+        const float peak = (OUT == 1) ? 1000.0f : 10000.0f;  // kHlgMaxNits / kPqMaxNits
+        hr = hr * 203.0f / peak;                              // two roundings, as written in the reference
+        hg = hg * 203.0f / peak;
+        hb = hb * 203.0f / peak;
+        if (p.hdr_gamut_on) {
+          const Mat3& m = p.gamut;
+          const f2 nr = m.m[0] * hr + m.m[1] * hg + m.m[2] * hb;
+          const f2 ng = m.m[3] * hr + m.m[4] * hg + m.m[5] * hb;
+          const f2 nb = m.m[6] * hr + m.m[7] * hg + m.m[8] * hb;
+          hr = nr; hg = ng; hb = nb;
+        }
+        uint2 o;
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+          float vr = clamp01(c ? hr.y : hr.x), vg = clamp01(c ? hg.y : hg.x), vb2 = clamp01(c ? hb.y : hb.x);
+          if constexpr (OUT == 1) {  // hlgInverseOotfApprox: powf(v, 1/1.2f)  (gainmapmath.cpp:303-306)
+            vr = powf(vr, 1.0f / 1.2f);
+            vg = powf(vg, 1.0f / 1.2f);
+            vb2 = powf(vb2, 1.0f / 1.2f);
+          }
+          const uint32_t px = pack_rgba1010102(p.oetf_lut[lut_index_f32<kOetfN>(vr)], p.oetf_lut[lut_index_f32<kOetfN>(vg)],
+                                               p.oetf_lut[lut_index_f32<kOetfN>(vb2)]);
+          if (c == 0) o.x = px; else o.y = px;
+        }
+        *(uint2*)drow = o;
+      }
     }
   }
 }
@@ -420,7 +497,10 @@ hipError_t launch_apply_gainmap(const ApplyParams& p, hipStream_t s) {
   bool quad = p.sdr.fmt == UHDR_IMG_FMT_12bppYCbCr420 && (p.sdr.w % 2 == 0) && (p.sdr.h % 2 == 0) &&
               (p.y0 % 2 == 0) && (p.sdr.stride[0] % 2 == 0) && aligned_to(p.sdr.p[0], 2) &&
               aligned_to(p.dst.p[0], 16) && ((p.dst.stride[0] * out_bytes) % 16 == 0) &&
-              p.sdr.w < 65536 && (p.sdr.h + p.y0) < 65536;
+              p.sdr.w < 65536 && (p.sdr.h + p.y0) < 65536 &&
+              // 32-bit byte offsets inside the kernel
+              (uint64_t)p.dst.stride[0] * out_bytes * p.sdr.h < 0xFFFFFFFFull &&
+              (uint64_t)p.gm.stride[0] * p.gm.h * 4 < 0xFFFFFFFFull;
   int smode = -1;
   if (quad) {
     if (p.scale == 1) {
@@ -430,8 +510,9 @@ hipError_t launch_apply_gainmap(const ApplyParams& p, hipStream_t s) {
       if (mapfmt == 0 && !(p.gm.stride[0] % 2 == 0 && aligned_to(p.gm.p[0], 2))) quad = false;
       if (mapfmt == 1 && !((p.gm.stride[0] * 3) % 2 == 0 && aligned_to(p.gm.p[0], 2))) quad = false;
       if (mapfmt == 2 && !(p.gm.stride[0] % 2 == 0 && aligned_to(p.gm.p[0], 8))) quad = false;
-    } else if (p.scale >= 2 && p.scale % 2 == 0 && p.scale <= (uint32_t)kMaxIdwScaleLds) {
-      smode = 1;
+    } else if (p.scale >= 2 && p.scale % 2 == 0 && p.scale <= (uint32_t)kMaxIdwScaleLds &&
+               p.gamma_is_one[0] && p.gamma_is_one[1] && p.gamma_is_one[2]) {
+      smode = 1;  // gamma != 1 needs pow() per sample: generic kernel
     } else {
       quad = false;
     }

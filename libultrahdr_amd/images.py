@@ -33,9 +33,10 @@ def plane_layout(fmt: int, w: int, h: int, align: int = 64):
     if fmt == A.UHDR_IMG_FMT_24bppYCbCrP010:
         return [(h, aw, w), ((h + 1) // 2, aw, ((w + 1) // 2) * 2), None]
     if fmt == A.UHDR_IMG_FMT_12bppYCbCr420:
-        return [(h, aw, w), ((h + 1) // 2, aw // 2, (w + 1) // 2), ((h + 1) // 2, aw // 2, (w + 1) // 2)]
+        # the reference uses aligned_width / 2; round up so odd unaligned widths keep their last sample
+        return [(h, aw, w), ((h + 1) // 2, (aw + 1) // 2, (w + 1) // 2), ((h + 1) // 2, (aw + 1) // 2, (w + 1) // 2)]
     if fmt == A.UHDR_IMG_FMT_16bppYCbCr422:
-        return [(h, aw, w), (h, aw // 2, (w + 1) // 2), (h, aw // 2, (w + 1) // 2)]
+        return [(h, aw, w), (h, (aw + 1) // 2, (w + 1) // 2), (h, (aw + 1) // 2, (w + 1) // 2)]
     if fmt in (A.UHDR_IMG_FMT_24bppYCbCr444, A.UHDR_IMG_FMT_30bppYCbCr444):
         return [(h, aw, w)] * 3
     return [(h, aw, w), None, None]
