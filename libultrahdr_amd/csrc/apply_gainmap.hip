@@ -252,10 +252,25 @@ __device__ __forceinline__ f2 lds_gather(const float* base, uint2 byte_off) {
 // the smallest float whose floatToHalf lands in the normal-half range: bits + 0x1000 >= 113 << 23
 #define UHDR_HALF_FAST_MIN_BITS ((113u << 23) - 0x1000u)
 
+// Raw bytes of one lane's quad, loaded one tile AHEAD of their use: on gfx9 stores and loads retire
+// through the same in-order vmcnt counter, so a tile whose loads are issued after the previous
+// tile's stores would wait for those stores to be acknowledged by memory.  Issuing the next
+// tile's loads before the current tile's stores takes the store latency off the critical path.
+template <int MAPFMT, int SMODE>
+struct QuadRaw {
+  static constexpr int NCH = (MAPFMT == 0) ? 1 : 3;
+  uint32_t y0, y1;  // two luma bytes of row 0 / row 1
+  uint32_t u, v;    // chroma bytes
+  uint32_t m[(SMODE == 0) ? 4 : 4 * NCH];  // SMODE 0: map bytes {row0 lo, row0 hi, row1 lo, row1 hi}; SMODE 1: tap bytes [tap][ch]
+  uint32_t widx;    // SMODE 1: float index of the (row 0) weight entry
+  uint32_t x, y;    // top-left pixel of the quad
+};
+
 template <int OUT, int MAPFMT, int SMODE>
 __global__ __launch_bounds__(kBlock) void apply_quad_kernel(const ApplyParams p) {
   constexpr int NCH = (MAPFMT == 0) ? 1 : 3;
   constexpr int BPP = (MAPFMT == 0) ? 1 : (MAPFMT == 1 ? 3 : 4);
+  using Raw = QuadRaw<MAPFMT, SMODE>;
   __shared__ float s_srgb[kSrgbN];
   __shared__ float s_gain[(SMODE == 0) ? 1 : NCH * kGainN];
   __shared__ float s_u8f[(SMODE == 0) ? 1 : 256];
@@ -280,12 +295,17 @@ __global__ __launch_bounds__(kBlock) void apply_quad_kernel(const ApplyParams p)
   }
   __syncthreads();
 
-  const uint32_t qw = p.sdr.w >> 1, qh = p.sdr.h >> 1;
+  const uint32_t w = p.sdr.w, qw = p.sdr.w >> 1, qh = p.sdr.h >> 1;
   const uint32_t strips_x = (qw + 63) >> 6;
   const uint32_t total = strips_x * qh;
   const uint32_t lane = tid & 63;
-  const uint32_t wave = (blockIdx.x * (kBlock / 64)) + (tid >> 6);
+  // wave-uniform tile walk (SGPRs).  Every wave runs the same, even number of iterations
+  // (p.tiles_per_wave); indices past the end clamp to the last tile, which is then simply
+  // recomputed (identical bytes), so the loop body has no conditional memory operations and the
+  // compiler can count outstanding loads/stores exactly.
   const uint32_t nwaves = gridDim.x * (kBlock / 64);
+  const uint32_t wave0 = blockIdx.x * (kBlock / 64) + __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t n_iter = p.tiles_per_wave;
 
   const uint8_t* __restrict__ yp = (const uint8_t*)p.sdr.p[0];
   const uint8_t* __restrict__ up = (const uint8_t*)p.sdr.p[1];
@@ -301,68 +321,88 @@ __global__ __launch_bounds__(kBlock) void apply_quad_kernel(const ApplyParams p)
   const f2 off_s0 = splat(p.offset_sdr[0]), off_h0 = splat(p.offset_hdr[0]);
   const f2 off_s1 = splat(p.offset_sdr[NCH == 1 ? 0 : 1]), off_h1 = splat(p.offset_hdr[NCH == 1 ? 0 : 1]);
   const f2 off_s2 = splat(p.offset_sdr[NCH == 1 ? 0 : 2]), off_h2 = splat(p.offset_hdr[NCH == 1 ? 0 : 2]);
+  const uint32_t scale = p.scale, half_scale = p.scale >> 1, magic = p.scale_magic;
+  const uint32_t gmw1 = p.gm.w - 1, gmh1 = p.gm.h - 1, y0g = p.y0;
 
-  for (uint32_t t = wave; t < total; t += nwaves) {
-    const uint32_t qy = t / strips_x;
-    const uint32_t qx = (t - qy * strips_x) * 64 + lane;
-    if (qx >= qw) continue;
-    const uint32_t x = qx * 2, y = qy * 2;
-    // ---- loads: 2+2 luma bytes, 1+1 chroma bytes ------------------------------------------
-    const uint32_t yoff = y * sy + x;
-    const uint32_t yrow[2] = {*(const uint16_t*)(yp + yoff), *(const uint16_t*)(yp + (yoff + sy))};
-    const int ub = up[qy * su + qx], vb = vp[qy * sv + qx];
-    const uint32_t yg = y + p.y0;
-
-    // ---- gain-map fetch ---------------------------------------------------------------------
-    float tap[(SMODE == 0) ? 1 : 4][NCH];
-    uint32_t widx = 0;            // SMODE 1: float index of the weight entry for (row 0, this pair)
-    uint32_t mrow[2][2];          // SMODE 0: raw map bytes of the two pixels of row 0 / row 1
+  // ---- issue the loads of tile (qy_, sx_) ---------------------------------------------------
+  auto fetch = [&](uint32_t t) -> Raw {
+    Raw r;
+    t = min(t, total - 1);
+    const uint32_t qy_ = t / strips_x, sx_ = t - qy_ * strips_x;
+    // a ragged last strip is shifted left so that it ends at the image edge (it overlaps its
+    // neighbour and rewrites identical pixels): every lane is always live
+    const uint32_t xc = (min(sx_ * 64, qw - 64) + lane) * 2;
+    r.x = xc;
+    r.y = qy_ * 2;
+    const uint32_t y = qy_ * 2;
+    const uint32_t yoff = y * sy + xc;
+    r.y0 = *(const uint16_t*)(yp + yoff);
+    r.y1 = *(const uint16_t*)(yp + (yoff + sy));
+    r.u = up[qy_ * su + (xc >> 1)];
+    r.v = vp[qy_ * sv + (xc >> 1)];
+    const uint32_t yg = y + y0g;
     if constexpr (SMODE == 0) {
-      const uint32_t moff = (yg * sm + x) * BPP;
+      const uint32_t moff = (yg * sm + xc) * BPP;
 #pragma unroll
-      for (int r = 0; r < 2; r++) {
-        const uint8_t* q = mp + (moff + r * sm * BPP);
+      for (int k = 0; k < 2; k++) {
+        const uint8_t* q = mp + (moff + k * sm * BPP);
         if constexpr (MAPFMT == 0) {
-          mrow[r][0] = *(const uint16_t*)q;
-          mrow[r][1] = 0;
+          r.m[2 * k] = *(const uint16_t*)q;
+          r.m[2 * k + 1] = 0;
         } else if constexpr (MAPFMT == 1) {  // 6 bytes: three aligned 16-bit loads
           const uint16_t* a = (const uint16_t*)q;
-          mrow[r][0] = a[0] | ((uint32_t)a[1] << 16);
-          mrow[r][1] = a[2];
+          r.m[2 * k] = a[0] | ((uint32_t)a[1] << 16);
+          r.m[2 * k + 1] = a[2];
         } else {
           const uint2 a = *(const uint2*)q;
-          mrow[r][0] = a.x;
-          mrow[r][1] = a.y;
+          r.m[2 * k] = a.x;
+          r.m[2 * k + 1] = a.y;
         }
       }
+      r.widx = 0;
     } else {
-      const uint32_t s = p.scale;
-      uint32_t xl = __umulhi(x, p.scale_magic), yl = __umulhi(yg, p.scale_magic);
-      const uint32_t ox = x - xl * s, oy = yg - yl * s;
-      const uint32_t xu = min(xl + 1, p.gm.w - 1), yu = min(yl + 1, p.gm.h - 1);
-      xl = min(xl, p.gm.w - 1);
-      yl = min(yl, p.gm.h - 1);
-      const uint32_t tbl = (xl == xu && yl == yu) ? 3u : (xl == xu) ? 1u : (yl == yu) ? 2u : 0u;
-      widx = ((tbl * s + oy) * (s >> 1) + (ox >> 1)) * 8;
-      const uint32_t a1 = (xl + yl * sm) * BPP, a2 = (xl + yu * sm) * BPP;
-      const uint32_t a3 = (xu + yl * sm) * BPP, a4 = (xu + yu * sm) * BPP;
+      // rows are wave-uniform (SALU): yl, yu, oy; columns per lane
+      uint32_t yl = __umulhi(yg, magic);
+      const uint32_t oy = yg - yl * scale;
+      const uint32_t yu = min(yl + 1, gmh1);
+      yl = min(yl, gmh1);
+      uint32_t xl = __umulhi(xc, magic);
+      const uint32_t ox = xc - xl * scale;
+      const uint32_t xu = min(xl + 1, gmw1);
+      xl = min(xl, gmw1);
+      const uint32_t tbl = (xl == xu ? 1u : 0u) + (yl == yu ? 2u : 0u);  // 0 default, 1 NR, 2 NB, 3 C
+      r.widx = ((tbl * scale + oy) * half_scale + (ox >> 1)) * 8;
+      const uint32_t rl = yl * sm, ru = yu * sm;
+      const uint32_t a1 = (xl + rl) * BPP, a2 = (xl + ru) * BPP, a3 = (xu + rl) * BPP, a4 = (xu + ru) * BPP;
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
-        tap[0][c] = s_u8f[mp[a1 + c]];
-        tap[1][c] = s_u8f[mp[a2 + c]];
-        tap[2][c] = s_u8f[mp[a3 + c]];
-        tap[3][c] = s_u8f[mp[a4 + c]];
+        r.m[0 * NCH + c] = mp[a1 + c];
+        r.m[1 * NCH + c] = mp[a2 + c];
+        r.m[2 * NCH + c] = mp[a3 + c];
+        r.m[3 * NCH + c] = mp[a4 + c];
       }
     }
+    return r;
+  };
 
+  // ---- compute + store one tile -----------------------------------------------------------------
+  auto process = [&](const Raw& q) {
+    const uint32_t x = q.x, y = q.y;
+    float tap[(SMODE == 0) ? 1 : 4][NCH];
+    if constexpr (SMODE == 1) {
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int c = 0; c < NCH; c++) tap[k][c] = s_u8f[q.m[k * NCH + c]];
+    }
     // getYuv4abPixel chroma (gainmapmath.cpp:370-374) and the p3YuvToRgb chroma products shared
     // by the four pixels (gainmapmath.cpp:177-181)
-    const float uf = (float)(ub - 128) * k255, vf = (float)(vb - 128) * k255;
+    const float uf = (float)((int)q.u - 128) * k255, vf = (float)((int)q.v - 128) * k255;
     const float crv = yk.cr * vf, gcbu = yk.gcb * uf, gcrv = yk.gcr * vf, cbu = yk.cb * uf;
-
 #pragma unroll
     for (int r = 0; r < 2; r++) {
-      const f2 yf = (f2){(float)(yrow[r] & 0xff), (float)(yrow[r] >> 8)} * k255;
+      const uint32_t yb = r == 0 ? q.y0 : q.y1;
+      const f2 yf = (f2){(float)(yb & 0xff), (float)(yb >> 8)} * k255;
       const f2 gr = clamp01_2(yf + crv);
       const f2 gg = clamp01_2(yf - gcbu - gcrv);
       const f2 gb = clamp01_2(yf + cbu);
@@ -378,27 +418,26 @@ __global__ __launch_bounds__(kBlock) void apply_quad_kernel(const ApplyParams p)
       }
       f2 f0, f1, f2_;
       if constexpr (SMODE == 0) {
+        const uint32_t a = q.m[2 * r], b = q.m[2 * r + 1];
         if constexpr (MAPFMT == 0) {
-          f0 = (f2){s_fac[mrow[r][0] & 0xff], s_fac[(mrow[r][0] >> 8) & 0xff]};
+          f0 = (f2){s_fac[a & 0xff], s_fac[(a >> 8) & 0xff]};
           f1 = f0; f2_ = f0;
         } else if constexpr (MAPFMT == 1) {  // R0 G0 B0 R1 | G1 B1
-          const uint32_t a = mrow[r][0], b = mrow[r][1];
           f0 = (f2){s_fac[a & 0xff], s_fac[a >> 24]};
           f1 = (f2){s_fac[256 + ((a >> 8) & 0xff)], s_fac[256 + (b & 0xff)]};
           f2_ = (f2){s_fac[512 + ((a >> 16) & 0xff)], s_fac[512 + ((b >> 8) & 0xff)]};
         } else {
-          const uint32_t a = mrow[r][0], b = mrow[r][1];
           f0 = (f2){s_fac[a & 0xff], s_fac[b & 0xff]};
           f1 = (f2){s_fac[256 + ((a >> 8) & 0xff)], s_fac[256 + ((b >> 8) & 0xff)]};
           f2_ = (f2){s_fac[512 + ((a >> 16) & 0xff)], s_fac[512 + ((b >> 16) & 0xff)]};
         }
       } else {
-        const float4 wa = *(const float4*)(s_idw + widx + r * (p.scale >> 1) * 8);
-        const float4 wb = *(const float4*)(s_idw + widx + r * (p.scale >> 1) * 8 + 4);
+        const float4 wa = *(const float4*)(s_idw + q.widx + r * half_scale * 8);
+        const float4 wb = *(const float4*)(s_idw + q.widx + r * half_scale * 8 + 4);
         const f2 w0 = {wa.x, wa.y}, w1 = {wa.z, wa.w}, w2 = {wb.x, wb.y}, w3 = {wb.z, wb.w};
         // sampleMap: e1*w0 + e2*w1 + e3*w2 + e4*w3, left to right (gainmapmath.cpp:955, 1079)
         const f2 g0 = tap[0][0] * w0 + tap[1][0] * w1 + tap[2][0] * w2 + tap[3][0] * w3;
-        f0 = lds_gather(s_gain, lut_off_1024(g0));  // gain slightly > 1 cannot occur: weights sum <= 1 + 1ulp -> idx <= 1023
+        f0 = lds_gather(s_gain, lut_off_1024(g0));  // weights sum to 1 +- 1ulp: the index stays <= 1023
         if constexpr (NCH == 3) {
           const f2 g1 = tap[0][1] * w0 + tap[1][1] * w1 + tap[2][1] * w2 + tap[3][1] * w3;
           const f2 g2 = tap[0][2] * w0 + tap[1][2] * w1 + tap[2][2] * w2 + tap[3][2] * w3;
@@ -466,6 +505,16 @@ __global__ __launch_bounds__(kBlock) void apply_quad_kernel(const ApplyParams p)
         *(uint2*)drow = o;
       }
     }
+  };
+
+  // software pipeline, ping-pong registers: the loads of tile i+1 are in flight while tile i is
+  // computed and stored
+  Raw a = fetch(wave0);
+  for (uint32_t i = 0; i < n_iter; i += 2) {
+    const Raw b = fetch(wave0 + (i + 1) * nwaves);
+    process(a);
+    a = fetch(wave0 + (i + 2) * nwaves);
+    process(b);
   }
 }
 
@@ -497,7 +546,7 @@ hipError_t launch_apply_gainmap(const ApplyParams& p, hipStream_t s) {
   bool quad = p.sdr.fmt == UHDR_IMG_FMT_12bppYCbCr420 && (p.sdr.w % 2 == 0) && (p.sdr.h % 2 == 0) &&
               (p.y0 % 2 == 0) && (p.sdr.stride[0] % 2 == 0) && aligned_to(p.sdr.p[0], 2) &&
               aligned_to(p.dst.p[0], 16) && ((p.dst.stride[0] * out_bytes) % 16 == 0) &&
-              p.sdr.w < 65536 && (p.sdr.h + p.y0) < 65536 &&
+              p.sdr.w < 65536 && (p.sdr.h + p.y0) < 65536 && p.sdr.w >= 128 &&
               // 32-bit byte offsets inside the kernel
               (uint64_t)p.dst.stride[0] * out_bytes * p.sdr.h < 0xFFFFFFFFull &&
               (uint64_t)p.gm.stride[0] * p.gm.h * 4 < 0xFFFFFFFFull;
@@ -519,12 +568,17 @@ hipError_t launch_apply_gainmap(const ApplyParams& p, hipStream_t s) {
   }
   if (quad) {
     const uint32_t strips = ((p.sdr.w / 2 + 63) / 64) * (p.sdr.h / 2);
-    int grid = (int)min((uint32_t)((strips + 3) / 4), 2048u);
+    // 2 tiles per wave at least (the kernel's loop is unrolled by two), at most 2048 workgroups
+    int grid = (int)min((uint32_t)((strips + 7) / 8), 2048u);
     if (grid < 1) grid = 1;
+    const uint32_t nwaves = (uint32_t)grid * 4;
+    ApplyParams q = p;
+    q.tiles_per_wave = ((strips + nwaves - 1) / nwaves + 1) & ~1u;
+    const ApplyParams& p_ = q;
     switch (out) {
-      case 0: return launch_quad_m<0>(p, mapfmt, smode, grid, s);
-      case 1: return launch_quad_m<1>(p, mapfmt, smode, grid, s);
-      default: return launch_quad_m<2>(p, mapfmt, smode, grid, s);
+      case 0: return launch_quad_m<0>(p_, mapfmt, smode, grid, s);
+      case 1: return launch_quad_m<1>(p_, mapfmt, smode, grid, s);
+      default: return launch_quad_m<2>(p_, mapfmt, smode, grid, s);
     }
   }
   const size_t total = (size_t)p.sdr.w * p.sdr.h;

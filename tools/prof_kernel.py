@@ -1,0 +1,38 @@
+#!/usr/bin/env python
+"""Runs one kernel configuration a few times -- the target for rocprofv3 (tools/profile.sh)."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: F401  (first: see capi.load)
+
+from libultrahdr_amd import capi as A
+from libultrahdr_amd import synth
+from libultrahdr_amd.images import Image
+from libultrahdr_amd.ultrahdr import Context, UltraHdr
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--case", default="8kA")  # <size><map>[hlg|pq]: 8kA 8kB 4kA 4kB 8kAhlg ...
+ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--sets", type=int, default=2)
+args = ap.parse_args()
+
+w, h = (7680, 4320) if args.case.startswith("8k") else (3840, 2160)
+mk = args.case[2]
+ct = A.UHDR_CT_HLG if "hlg" in args.case else A.UHDR_CT_PQ if "pq" in args.case else A.UHDR_CT_LINEAR
+fmt = A.UHDR_IMG_FMT_64bppRGBAHalfFloat if ct == A.UHDR_CT_LINEAR else A.UHDR_IMG_FMT_32bppRGBA1010102
+ctx = Context(0)
+u = UltraHdr(ctx=ctx)
+md = synth.default_metadata(use_base_cg=0)
+sets = []
+for i in range(args.sets):
+    sdr = synth.make_sdr_yuv420(w, h, seed=10 + i)
+    gm = synth.make_gainmap(w // 4, h // 4, 1, seed=50 + i) if mk == "A" else synth.make_gainmap(w, h, 3, alpha=(mk == "C"), seed=50 + i)
+    sdr.raw.cg, gm.raw.cg = A.UHDR_CG_BT_709, A.UHDR_CG_BT_2100
+    sets.append((sdr.to("cuda:0"), gm.to("cuda:0"), Image(fmt, w, h, align=64, device="cuda:0")))
+for i in range(args.iters):
+    s, g, d = sets[i % args.sets]
+    u.applyGainMap(s, g, md, ct, fmt, A.FLT_MAX, d)
+ctx.synchronize()
+print("done", args.case, args.iters)
