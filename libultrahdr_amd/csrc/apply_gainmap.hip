@@ -241,9 +241,18 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 splat(float v) { return (f2){v, v}; }
 __device__ __forceinline__ f2 clamp01_2(f2 v) { return (f2){clamp01(v.x), clamp01(v.y)}; }
 // LUT index for x in [0,1] (no clip needed: clamp01 guarantees the range), as a BYTE offset
+// int(fma(x, 1023, 0.5)) == int(double(float(x * 1023)) + 0.5) for every float x in [0, 1]
+// (exhaustive check: tests/test_host_logic.py::test_lut_index_float_equivalence), so one packed
+// FMA replaces the multiply/add pair.
 __device__ __forceinline__ uint2 lut_off_1024(f2 x) {
-  const f2 t = x * 1023.0f + 0.5f;
+  const f2 t = __builtin_elementwise_fma(x, splat(1023.0f), splat(0.5f));
   return (uint2){(uint32_t)(int)t.x << 2, (uint32_t)(int)t.y << 2};
+}
+// v_cvt_pkrtz_f16_f32 on raw bit patterns: two floats -> two halves, round toward zero
+__device__ __forceinline__ uint32_t pkrtz_bits(uint32_t a, uint32_t b) {
+  typedef __fp16 h2 __attribute__((ext_vector_type(2)));
+  const h2 v = __builtin_amdgcn_cvt_pkrtz(__uint_as_float(a), __uint_as_float(b));
+  return __builtin_bit_cast(uint32_t, v);
 }
 __device__ __forceinline__ f2 lds_gather(const float* base, uint2 byte_off) {
   const char* b = (const char*)base;
@@ -262,12 +271,20 @@ struct QuadRaw {
   uint32_t y0, y1;  // two luma bytes of row 0 / row 1
   uint32_t u, v;    // chroma bytes
   uint32_t m[(SMODE == 0) ? 4 : 4 * NCH];  // SMODE 0: map bytes {row0 lo, row0 hi, row1 lo, row1 hi}; SMODE 1: tap bytes [tap][ch]
-  uint32_t widx;    // SMODE 1: float index of the (row 0) weight entry
-  uint32_t x, y;    // top-left pixel of the quad
+  uint32_t wrow;    // SMODE 1: row part of the weight-table index (wave-uniform)
+  uint32_t y;       // first row of the quad (wave-uniform)
 };
 
+// SGPR budget: a wave may use at most 80 SGPRs if 8 workgroups of 256 threads are to be resident
+// per CU (MI355X_MICROARCH.md, "Residency"); the launcher sizes the grid to exactly that residency
+// so the whole image is processed in a single, balanced round.
+//
+// Work assignment: a wave owns one 128-pixel-wide column strip and walks down the image in steps
+// of p.row_groups quad rows.  Everything that depends on the column (pixel offsets, gain-map tap
+// columns, weight-table column, edge flags) is therefore loop invariant and lives in VGPRs;
+// everything that depends on the row is wave-uniform and is computed on the scalar unit.
 template <int OUT, int MAPFMT, int SMODE>
-__global__ __launch_bounds__(kBlock) void apply_quad_kernel(const ApplyParams p) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void apply_quad_kernel(const ApplyParams p) {
   constexpr int NCH = (MAPFMT == 0) ? 1 : 3;
   constexpr int BPP = (MAPFMT == 0) ? 1 : (MAPFMT == 1 ? 3 : 4);
   using Raw = QuadRaw<MAPFMT, SMODE>;
@@ -295,17 +312,13 @@ __global__ __launch_bounds__(kBlock) void apply_quad_kernel(const ApplyParams p)
   }
   __syncthreads();
 
-  const uint32_t w = p.sdr.w, qw = p.sdr.w >> 1, qh = p.sdr.h >> 1;
+  const uint32_t qw = p.sdr.w >> 1, qh = p.sdr.h >> 1;
   const uint32_t strips_x = (qw + 63) >> 6;
-  const uint32_t total = strips_x * qh;
   const uint32_t lane = tid & 63;
-  // wave-uniform tile walk (SGPRs).  Every wave runs the same, even number of iterations
-  // (p.tiles_per_wave); indices past the end clamp to the last tile, which is then simply
-  // recomputed (identical bytes), so the loop body has no conditional memory operations and the
-  // compiler can count outstanding loads/stores exactly.
-  const uint32_t nwaves = gridDim.x * (kBlock / 64);
-  const uint32_t wave0 = blockIdx.x * (kBlock / 64) + __builtin_amdgcn_readfirstlane(tid >> 6);
-  const uint32_t n_iter = p.tiles_per_wave;
+  const uint32_t wave = blockIdx.x * (kBlock / 64) + __builtin_amdgcn_readfirstlane(tid >> 6);  // SGPR
+  const uint32_t groups = p.row_groups, n_iter = p.tiles_per_wave;
+  if (wave >= groups * strips_x) return;  // a few surplus waves of the last workgroup
+  const uint32_t qy0 = wave / strips_x, sx = wave - qy0 * strips_x;
 
   const uint8_t* __restrict__ yp = (const uint8_t*)p.sdr.p[0];
   const uint8_t* __restrict__ up = (const uint8_t*)p.sdr.p[1];
@@ -322,30 +335,46 @@ __global__ __launch_bounds__(kBlock) void apply_quad_kernel(const ApplyParams p)
   const f2 off_s1 = splat(p.offset_sdr[NCH == 1 ? 0 : 1]), off_h1 = splat(p.offset_hdr[NCH == 1 ? 0 : 1]);
   const f2 off_s2 = splat(p.offset_sdr[NCH == 1 ? 0 : 2]), off_h2 = splat(p.offset_hdr[NCH == 1 ? 0 : 2]);
   const uint32_t scale = p.scale, half_scale = p.scale >> 1, magic = p.scale_magic;
-  const uint32_t gmw1 = p.gm.w - 1, gmh1 = p.gm.h - 1, y0g = p.y0;
+  const uint32_t gmh1 = p.gm.h - 1, y0g = p.y0;
 
-  // ---- issue the loads of tile (qy_, sx_) ---------------------------------------------------
-  auto fetch = [&](uint32_t t) -> Raw {
+  // ---- loop-invariant, per-lane column state --------------------------------------------------
+  // a ragged last strip is shifted left so that it ends at the image edge (it overlaps its
+  // neighbour and rewrites identical pixels): every lane is always live
+  const uint32_t xc = (min(sx * 64, qw - 64) + lane) * 2;  // pixel column of the quad
+  const uint32_t xq = xc >> 1;                             // chroma column
+  const uint32_t xdst = xc * OPX;
+  uint32_t col_l = 0, col_u = 0, wcol = 0;  // SMODE 1: tap column byte offsets, column part of the weight index
+  if constexpr (SMODE == 1) {
+    const uint32_t gmw1 = p.gm.w - 1;
+    uint32_t xl = __umulhi(xc, magic);
+    const uint32_t ox = xc - xl * scale;
+    const uint32_t xu = min(xl + 1, gmw1);
+    xl = min(xl, gmw1);
+    col_l = xl * BPP;
+    col_u = xu * BPP;
+    // table select: 0 default, 1 no-right, 2 no-bottom, 3 corner (gainmapmath.cpp:946-953)
+    wcol = ((xl == xu ? 1u : 0u) * scale * half_scale + (ox >> 1)) * 8;
+  }
+  const uint32_t xmap = xc * BPP;  // SMODE 0
+
+  // ---- issue the loads of quad row qy_ (wave-uniform) -------------------------------------------
+  auto fetch = [&](uint32_t qy_) -> Raw {
     Raw r;
-    t = min(t, total - 1);
-    const uint32_t qy_ = t / strips_x, sx_ = t - qy_ * strips_x;
-    // a ragged last strip is shifted left so that it ends at the image edge (it overlaps its
-    // neighbour and rewrites identical pixels): every lane is always live
-    const uint32_t xc = (min(sx_ * 64, qw - 64) + lane) * 2;
-    r.x = xc;
-    r.y = qy_ * 2;
+    qy_ = min(qy_, qh - 1);  // past the end: recompute the last row (identical bytes)
     const uint32_t y = qy_ * 2;
-    const uint32_t yoff = y * sy + xc;
-    r.y0 = *(const uint16_t*)(yp + yoff);
-    r.y1 = *(const uint16_t*)(yp + (yoff + sy));
-    r.u = up[qy_ * su + (xc >> 1)];
-    r.v = vp[qy_ * sv + (xc >> 1)];
+    r.y = y;
+    // 32-bit offsets from the kernel-argument base pointers (planes < 4 GiB, checked by the
+    // launcher): scalar row offset + per-lane column -> one v_add_u32 and an SGPR-base load
+    const uint32_t yrow = y * sy;
+    r.y0 = *(const uint16_t*)(yp + (yrow + xc));
+    r.y1 = *(const uint16_t*)(yp + (yrow + sy + xc));
+    r.u = up[qy_ * su + xq];
+    r.v = vp[qy_ * sv + xq];
     const uint32_t yg = y + y0g;
     if constexpr (SMODE == 0) {
-      const uint32_t moff = (yg * sm + xc) * BPP;
 #pragma unroll
       for (int k = 0; k < 2; k++) {
-        const uint8_t* q = mp + (moff + k * sm * BPP);
+        const uint8_t* q = mp + ((yg + k) * sm * BPP + xmap);
         if constexpr (MAPFMT == 0) {
           r.m[2 * k] = *(const uint16_t*)q;
           r.m[2 * k + 1] = 0;
@@ -359,35 +388,27 @@ __global__ __launch_bounds__(kBlock) void apply_quad_kernel(const ApplyParams p)
           r.m[2 * k + 1] = a.y;
         }
       }
-      r.widx = 0;
+      r.wrow = 0;
     } else {
-      // rows are wave-uniform (SALU): yl, yu, oy; columns per lane
       uint32_t yl = __umulhi(yg, magic);
       const uint32_t oy = yg - yl * scale;
       const uint32_t yu = min(yl + 1, gmh1);
       yl = min(yl, gmh1);
-      uint32_t xl = __umulhi(xc, magic);
-      const uint32_t ox = xc - xl * scale;
-      const uint32_t xu = min(xl + 1, gmw1);
-      xl = min(xl, gmw1);
-      const uint32_t tbl = (xl == xu ? 1u : 0u) + (yl == yu ? 2u : 0u);  // 0 default, 1 NR, 2 NB, 3 C
-      r.widx = ((tbl * scale + oy) * half_scale + (ox >> 1)) * 8;
-      const uint32_t rl = yl * sm, ru = yu * sm;
-      const uint32_t a1 = (xl + rl) * BPP, a2 = (xl + ru) * BPP, a3 = (xu + rl) * BPP, a4 = (xu + ru) * BPP;
+      r.wrow = ((yl == yu ? 2u : 0u) * scale + oy) * half_scale * 8;
+      const uint32_t rl = yl * sm * BPP, ru = yu * sm * BPP;
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
-        r.m[0 * NCH + c] = mp[a1 + c];
-        r.m[1 * NCH + c] = mp[a2 + c];
-        r.m[2 * NCH + c] = mp[a3 + c];
-        r.m[3 * NCH + c] = mp[a4 + c];
+        r.m[0 * NCH + c] = mp[rl + col_l + c];
+        r.m[1 * NCH + c] = mp[ru + col_l + c];
+        r.m[2 * NCH + c] = mp[rl + col_u + c];
+        r.m[3 * NCH + c] = mp[ru + col_u + c];
       }
     }
     return r;
   };
 
-  // ---- compute + store one tile -----------------------------------------------------------------
+  // ---- compute + store one quad row -----------------------------------------------------------
   auto process = [&](const Raw& q) {
-    const uint32_t x = q.x, y = q.y;
     float tap[(SMODE == 0) ? 1 : 4][NCH];
     if constexpr (SMODE == 1) {
 #pragma unroll
@@ -399,6 +420,7 @@ __global__ __launch_bounds__(kBlock) void apply_quad_kernel(const ApplyParams p)
     // by the four pixels (gainmapmath.cpp:177-181)
     const float uf = (float)((int)q.u - 128) * k255, vf = (float)((int)q.v - 128) * k255;
     const float crv = yk.cr * vf, gcbu = yk.gcb * uf, gcrv = yk.gcr * vf, cbu = yk.cb * uf;
+    const uint32_t drow = q.y * sd;  // wave-uniform row offset
 #pragma unroll
     for (int r = 0; r < 2; r++) {
       const uint32_t yb = r == 0 ? q.y0 : q.y1;
@@ -432,8 +454,9 @@ __global__ __launch_bounds__(kBlock) void apply_quad_kernel(const ApplyParams p)
           f2_ = (f2){s_fac[512 + ((a >> 16) & 0xff)], s_fac[512 + ((b >> 16) & 0xff)]};
         }
       } else {
-        const float4 wa = *(const float4*)(s_idw + q.widx + r * half_scale * 8);
-        const float4 wb = *(const float4*)(s_idw + q.widx + r * half_scale * 8 + 4);
+        const float* wp = s_idw + (q.wrow + r * half_scale * 8) + wcol;  // scalar row part + lane column part
+        const float4 wa = *(const float4*)wp;
+        const float4 wb = *(const float4*)(wp + 4);
         const f2 w0 = {wa.x, wa.y}, w1 = {wa.z, wa.w}, w2 = {wb.x, wb.y}, w3 = {wb.z, wb.w};
         // sampleMap: e1*w0 + e2*w1 + e3*w2 + e4*w3, left to right (gainmapmath.cpp:955, 1079)
         const f2 g0 = tap[0][0] * w0 + tap[1][0] * w1 + tap[2][0] * w2 + tap[3][0] * w3;
@@ -451,7 +474,7 @@ __global__ __launch_bounds__(kBlock) void apply_quad_kernel(const ApplyParams p)
       f2 hr = ((lr + off_s0) * f0) - off_h0;
       f2 hg = ((lg + off_s1) * f1) - off_h1;
       f2 hb = ((lb + off_s2) * f2_) - off_h2;
-      uint8_t* drow = dp + ((y + r) * sd + x * OPX);
+      uint8_t* dpx = dp + (drow + r * sd + xdst);
       if constexpr (OUT == 0) {
         if (p.hdr_gamut_on) {
           const Mat3& m = p.gamut;
@@ -462,21 +485,22 @@ __global__ __launch_bounds__(kBlock) void apply_quad_kernel(const ApplyParams p)
         }
         const float c0r = clamp_linear(hr.x), c0g = clamp_linear(hg.x), c0b = clamp_linear(hb.x);
         const float c1r = clamp_linear(hr.y), c1g = clamp_linear(hg.y), c1b = clamp_linear(hb.y);
-        // all six values are >= 0, so "every one is in the 2-op half range" is one min + compare
+        // all six values are >= 0, so "every one is in the normal-half range" is one min + compare
         const float mn = fminf(fminf(fminf(c0r, c0g), fminf(c0b, c1r)), fminf(c1g, c1b));
         uint4 o;
         if (__builtin_amdgcn_ballot_w64(__float_as_uint(mn) < UHDR_HALF_FAST_MIN_BITS) == 0) {
-          o.x = float_to_half_fast(__float_as_uint(c0r)) | (float_to_half_fast(__float_as_uint(c0g)) << 16);
-          o.y = float_to_half_fast(__float_as_uint(c0b)) | (0x3C00u << 16);
-          o.z = float_to_half_fast(__float_as_uint(c1r)) | (float_to_half_fast(__float_as_uint(c1g)) << 16);
-          o.w = float_to_half_fast(__float_as_uint(c1b)) | (0x3C00u << 16);
+          // floatToHalf for normal halves = add 0x1000 to the bits, then truncate: v_cvt_pkrtz
+          o.x = pkrtz_bits(__float_as_uint(c0r) + 0x1000u, __float_as_uint(c0g) + 0x1000u);
+          o.y = pkrtz_bits(__float_as_uint(c0b) + 0x1000u, 0x3F800000u);
+          o.z = pkrtz_bits(__float_as_uint(c1r) + 0x1000u, __float_as_uint(c1g) + 0x1000u);
+          o.w = pkrtz_bits(__float_as_uint(c1b) + 0x1000u, 0x3F800000u);
         } else {
           o.x = float_to_half_general(__float_as_uint(c0r)) | (float_to_half_general(__float_as_uint(c0g)) << 16);
           o.y = float_to_half_general(__float_as_uint(c0b)) | (0x3C00u << 16);
           o.z = float_to_half_general(__float_as_uint(c1r)) | (float_to_half_general(__float_as_uint(c1g)) << 16);
           o.w = float_to_half_general(__float_as_uint(c1b)) | (0x3C00u << 16);
         }
-        *(uint4*)drow = o;
+        *(uint4*)dpx = o;
       } else {
         const float peak = (OUT == 1) ? 1000.0f : 10000.0f;  // kHlgMaxNits / kPqMaxNits
         hr = hr * 203.0f / peak;                              // two roundings, as written in the reference
@@ -502,34 +526,62 @@ __global__ __launch_bounds__(kBlock) void apply_quad_kernel(const ApplyParams p)
                                                p.oetf_lut[lut_index_f32<kOetfN>(vb2)]);
           if (c == 0) o.x = px; else o.y = px;
         }
-        *(uint2*)drow = o;
+        *(uint2*)dpx = o;
       }
     }
   };
 
-  // software pipeline, ping-pong registers: the loads of tile i+1 are in flight while tile i is
-  // computed and stored
-  Raw a = fetch(wave0);
+  // software pipeline, ping-pong registers: the loads of row i+1 are in flight while row i is
+  // computed and stored.  n_iter is even; rows past the end are clamped (see fetch).
+  Raw a = fetch(qy0);
   for (uint32_t i = 0; i < n_iter; i += 2) {
-    const Raw b = fetch(wave0 + (i + 1) * nwaves);
+    const Raw b = fetch(qy0 + (i + 1) * groups);
     process(a);
-    a = fetch(wave0 + (i + 2) * nwaves);
+    a = fetch(qy0 + (i + 2) * groups);
     process(b);
   }
 }
 
-template <int OUT, int MAPFMT>
-hipError_t launch_quad_s(const ApplyParams& p, int smode, int grid, hipStream_t s) {
-  if (smode == 0) hipLaunchKernelGGL((apply_quad_kernel<OUT, MAPFMT, 0>), dim3(grid), dim3(kBlock), 0, s, p);
-  else hipLaunchKernelGGL((apply_quad_kernel<OUT, MAPFMT, 1>), dim3(grid), dim3(kBlock), 0, s, p);
+// Resident workgroups of a kernel on the current device = CUs x blocks per CU (occupancy API; the
+// quad kernels cap their SGPRs so the API's answer is exact -- MI355X_MICROARCH.md "Residency").
+template <typename K>
+int resident_blocks(K kernel) {
+  int dev = 0, per_cu = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 2048;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
+  if (per_cu > 8) per_cu = 8;
+  return per_cu * cus;
+}
+
+template <int OUT, int MAPFMT, int SMODE>
+hipError_t launch_quad(const ApplyParams& p, hipStream_t s) {
+  static const int resident = resident_blocks(apply_quad_kernel<OUT, MAPFMT, SMODE>);
+  const uint32_t strips_x = (p.sdr.w / 2 + 63) / 64, qh = p.sdr.h / 2;
+  // one balanced round: all workgroups resident; a wave owns a column strip and every
+  // `groups`-th quad row of it
+  const uint32_t max_waves = (uint32_t)resident * (kBlock / 64);
+  uint32_t groups = max_waves / strips_x;
+  if (groups > (qh + 1) / 2) groups = (qh + 1) / 2;  // at least two rows per wave (loop unrolled by 2)
+  if (groups < 1) groups = 1;
+  const uint32_t nwaves = groups * strips_x;
+  ApplyParams q = p;
+  q.row_groups = groups;
+  q.tiles_per_wave = ((qh + groups - 1) / groups + 1) & ~1u;
+  const int grid = (int)((nwaves + kBlock / 64 - 1) / (kBlock / 64));
+  hipLaunchKernelGGL((apply_quad_kernel<OUT, MAPFMT, SMODE>), dim3(grid), dim3(kBlock), 0, s, q);
   return hipGetLastError();
 }
+template <int OUT, int MAPFMT>
+hipError_t launch_quad_s(const ApplyParams& p, int smode, hipStream_t s) {
+  return smode == 0 ? launch_quad<OUT, MAPFMT, 0>(p, s) : launch_quad<OUT, MAPFMT, 1>(p, s);
+}
 template <int OUT>
-hipError_t launch_quad_m(const ApplyParams& p, int mapfmt, int smode, int grid, hipStream_t s) {
+hipError_t launch_quad_m(const ApplyParams& p, int mapfmt, int smode, hipStream_t s) {
   switch (mapfmt) {
-    case 0: return launch_quad_s<OUT, 0>(p, smode, grid, s);
-    case 1: return launch_quad_s<OUT, 1>(p, smode, grid, s);
-    default: return launch_quad_s<OUT, 2>(p, smode, grid, s);
+    case 0: return launch_quad_s<OUT, 0>(p, smode, s);
+    case 1: return launch_quad_s<OUT, 1>(p, smode, s);
+    default: return launch_quad_s<OUT, 2>(p, smode, s);
   }
 }
 
@@ -567,18 +619,10 @@ hipError_t launch_apply_gainmap(const ApplyParams& p, hipStream_t s) {
     }
   }
   if (quad) {
-    const uint32_t strips = ((p.sdr.w / 2 + 63) / 64) * (p.sdr.h / 2);
-    // 2 tiles per wave at least (the kernel's loop is unrolled by two), at most 2048 workgroups
-    int grid = (int)min((uint32_t)((strips + 7) / 8), 2048u);
-    if (grid < 1) grid = 1;
-    const uint32_t nwaves = (uint32_t)grid * 4;
-    ApplyParams q = p;
-    q.tiles_per_wave = ((strips + nwaves - 1) / nwaves + 1) & ~1u;
-    const ApplyParams& p_ = q;
     switch (out) {
-      case 0: return launch_quad_m<0>(p_, mapfmt, smode, grid, s);
-      case 1: return launch_quad_m<1>(p_, mapfmt, smode, grid, s);
-      default: return launch_quad_m<2>(p_, mapfmt, smode, grid, s);
+      case 0: return launch_quad_m<0>(p, mapfmt, smode, s);
+      case 1: return launch_quad_m<1>(p, mapfmt, smode, s);
+      default: return launch_quad_m<2>(p, mapfmt, smode, s);
     }
   }
   const size_t total = (size_t)p.sdr.w * p.sdr.h;

@@ -57,6 +57,7 @@ struct ApplyParams {
   const float* oetf_lut;    // 65536-entry HLG or PQ OETF table (null for linear)
   uint32_t y0;              // global row of stripe row 0
   uint32_t tiles_per_wave;  // quad kernel: loop trip count (even), set by the launcher
+  uint32_t row_groups;      // quad kernel: quad-row step of a wave, set by the launcher
   uint32_t scale;           // integer map scale factor (table path) or 0
   uint32_t scale_magic;     // ceil(2^32 / scale): x / scale == umulhi(x, magic) for x < 65536
   float scale_f;            // (float)w_sdr / w_map, for the non-integer path
