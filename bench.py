@@ -37,16 +37,25 @@ def parse():
     ap.add_argument("--batch", type=int, default=16, help="4K frames per rank per step")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
-    ap.add_argument("--map", choices=["A", "B"], default="A", help="A: Y400 scale 4 (9.5625 B/px); B: RGB888 scale 1 (12.5 B/px)")
+    ap.add_argument("--map", choices=["A", "B", "C"], default="C",
+                    help="gain map of the decoded stream.  C: RGBA8888 full resolution (13.5 B/px) -- what the reference's "
+                         "C-API default encode (3 channels, scale 1) decodes to with its pinned libjpeg-turbo; "
+                         "B: the same as RGB888 (IJG libjpeg layout, 12.5 B/px); A: Y400 at scale 4 (Android default, 9.5625 B/px)")
+    ap.add_argument("--launch", choices=["batch", "single"], default="batch",
+                    help="batch: one kernel launch per step for the whole frame batch (uhdr_hip_apply_gainmap_batch_dev); "
+                         "single: one launch per frame")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
 
+MAP_DESC = {"A": "Y400 gain map (scale 4)", "B": "RGB888 gain map (scale 1)", "C": "RGBA8888 gain map (scale 1)"}
+
+
 def algo_bytes_per_px(map_kind, out_bytes=8):
     # every input read once, every output written once
-    return 1.5 + (1.0 / 16.0 if map_kind == "A" else 3.0) + out_bytes
+    return 1.5 + {"A": 1.0 / 16.0, "B": 3.0, "C": 4.0}[map_kind] + out_bytes
 
 
 def make_frames(n, w, h, map_kind, device, out_fmt, seed0=1234):
@@ -60,7 +69,7 @@ def make_frames(n, w, h, map_kind, device, out_fmt, seed0=1234):
         if map_kind == "A":
             gm = synth.make_gainmap(w // 4, h // 4, 1, seed=seed0 + 100 + i)
         else:
-            gm = synth.make_gainmap(w, h, 3, seed=seed0 + 100 + i)
+            gm = synth.make_gainmap(w, h, 3, alpha=(map_kind == "C"), seed=seed0 + 100 + i)
         dest = Image(out_fmt, w, h, align=64, device=device)
         frames.append((sdr.to(device), gm.to(device), dest))
     return frames
@@ -116,12 +125,22 @@ def main():
 
     lib, hnd = ctx.lib, ctx.handle
     calls = [(C.byref(s.raw), C.byref(g.raw), C.byref(md), C.byref(d.raw)) for s, g, d in frames]
+    nb = len(frames)
+    arr_s = (A.RawImage * nb)(*[s.raw for s, _, _ in frames])
+    arr_g = (A.RawImage * nb)(*[g.raw for _, g, _ in frames])
+    arr_d = (A.RawImage * nb)(*[d.raw for _, _, d in frames])
 
-    def step():
-        for s_, g_, m_, d_ in calls:
-            st = lib.uhdr_hip_apply_gainmap_dev(hnd, s_, g_, m_, A.UHDR_CT_LINEAR, f16, A.FLT_MAX, d_, 0, 0)
+    if args.launch == "batch":
+        def step():
+            st = lib.uhdr_hip_apply_gainmap_batch_dev(hnd, nb, arr_s, arr_g, C.byref(md), A.UHDR_CT_LINEAR, f16, A.FLT_MAX, arr_d)
             if st.error_code != 0:
                 raise RuntimeError(st.detail)
+    else:
+        def step():
+            for s_, g_, m_, d_ in calls:
+                st = lib.uhdr_hip_apply_gainmap_dev(hnd, s_, g_, m_, A.UHDR_CT_LINEAR, f16, A.FLT_MAX, d_, 0, 0)
+                if st.error_code != 0:
+                    raise RuntimeError(st.detail)
 
     def barrier():
         ctx.synchronize()
@@ -152,7 +171,8 @@ def main():
     px_per_step = args.batch * w * h * world
     value = px_per_step * args.steps / elapsed / 1e6
     avg_launch_s = (kern_ms / 1e3) / max(n_launch, 1)
-    algo_b = algo_bytes_per_px(args.map) * w * h
+    frames_per_launch = nb if args.launch == "batch" else 1
+    algo_b = algo_bytes_per_px(args.map) * w * h * frames_per_launch
     achieved = algo_b / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
 
     out = {
@@ -169,15 +189,16 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"configs[1]: decode {w}x{h} YCbCr420 base + "
-                        + ("Y400 gain map (scale 4)" if args.map == "A" else "RGB888 gain map (scale 1)")
+            "workload": f"configs[1]: decode {w}x{h} YCbCr420 base + " + MAP_DESC[args.map]
                         + " -> RGBA_F16 linear, applyGainMap kernel, device-resident",
             "frames_per_rank_per_step": args.batch,
+            "launch": "one batched launch per step" if args.launch == "batch" else "one launch per frame",
             "sharding": f"frames x{world} ranks, no data-path collective",
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "apply_quad_kernel<F16," + ("Y400,scale4>" if args.map == "A" else "RGB888,scale1>"),
+            "kernel": "apply_quad_kernel<F16," + {"A": "Y400,scale4>", "B": "RGB888,scale1>", "C": "RGBA8888,scale1>"}[args.map],
+            "frames_per_launch": frames_per_launch,
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -231,9 +252,11 @@ def extras(ctx, u, device):
         del sets
         torch.cuda.empty_cache()
 
-    apply_case("apply_8k_f16_mapA", 7680, 4320, "A", A.UHDR_CT_LINEAR)
+    apply_case("apply_8k_f16_mapC", 7680, 4320, "C", A.UHDR_CT_LINEAR)
     apply_case("apply_8k_f16_mapB", 7680, 4320, "B", A.UHDR_CT_LINEAR)
-    apply_case("apply_4k_f16_mapB", 3840, 2160, "B", A.UHDR_CT_LINEAR)
+    apply_case("apply_8k_f16_mapA", 7680, 4320, "A", A.UHDR_CT_LINEAR)
+    apply_case("apply_4k_f16_mapC_single_launch", 3840, 2160, "C", A.UHDR_CT_LINEAR)
+    apply_case("apply_4k_f16_mapA_single_launch", 3840, 2160, "A", A.UHDR_CT_LINEAR)
     apply_case("apply_4k_hlg_mapA", 3840, 2160, "A", A.UHDR_CT_HLG)
     apply_case("apply_4k_pq_mapA", 3840, 2160, "A", A.UHDR_CT_PQ)
 
@@ -271,7 +294,8 @@ def cpu_baseline(w, h, map_kind, md, budget_s):
 
     kind = "reference" if L.ref() is not None else "port"
     sdr = synth.make_sdr_yuv420(w, h, seed=1234)
-    gm = synth.make_gainmap(w // 4, h // 4, 1, seed=1334) if map_kind == "A" else synth.make_gainmap(w, h, 3, seed=1334)
+    gm = (synth.make_gainmap(w // 4, h // 4, 1, seed=1334) if map_kind == "A"
+          else synth.make_gainmap(w, h, 3, alpha=(map_kind == "C"), seed=1334))
     sdr.raw.cg, gm.raw.cg = A.UHDR_CG_BT_709, A.UHDR_CG_BT_2100
     which = "ref" if kind == "reference" else "port"
     L.apply_gainmap(which, sdr, gm, md, A.UHDR_CT_LINEAR)  # warm-up (builds the reference's static LUTs)

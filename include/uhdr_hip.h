@@ -168,6 +168,17 @@ uhdr_error_info_t uhdr_hip_apply_gainmap_dev(uhdr_hip_ctx_t* ctx, const uhdr_raw
                                              uhdr_img_fmt_t output_format, float max_display_boost,
                                              uhdr_raw_image_t* dest, unsigned int y0,
                                              unsigned int full_height);
+/* Batch decode (BASELINE config 5): n frames of identical geometry / formats / colour aspects that
+ * share one metadata block (a burst or a video-like sequence), arrays of n descriptors with
+ * DEVICE plane pointers, ONE kernel launch.  Combinations the batch kernel does not cover run
+ * frame by frame with identical results. */
+uhdr_error_info_t uhdr_hip_apply_gainmap_batch_dev(uhdr_hip_ctx_t* ctx, unsigned int n,
+                                                   const uhdr_raw_image_t* sdr_intents,
+                                                   const uhdr_raw_image_t* gainmap_imgs,
+                                                   const uhdr_gainmap_metadata_t* gainmap_metadata,
+                                                   uhdr_color_transfer_t output_ct,
+                                                   uhdr_img_fmt_t output_format, float max_display_boost,
+                                                   uhdr_raw_image_t* dests);
 /* one-pass (REALTIME) generation, or the whole two-pass sequence on one device */
 uhdr_error_info_t uhdr_hip_generate_gainmap_dev(uhdr_hip_ctx_t* ctx,
                                                 const uhdr_raw_image_t* sdr_intent,

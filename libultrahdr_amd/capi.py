@@ -134,6 +134,7 @@ _SIGS = {
     "uhdr_hip_synchronize": (ErrorInfo, [C.c_void_p]),
     "uhdr_hip_apply_gainmap": (ErrorInfo, [C.c_void_p, _P(RawImage), _P(RawImage), _P(GainmapMetadata), C.c_int, C.c_int, C.c_float, _P(RawImage)]),
     "uhdr_hip_apply_gainmap_dev": (ErrorInfo, [C.c_void_p, _P(RawImage), _P(RawImage), _P(GainmapMetadata), C.c_int, C.c_int, C.c_float, _P(RawImage), C.c_uint, C.c_uint]),
+    "uhdr_hip_apply_gainmap_batch_dev": (ErrorInfo, [C.c_void_p, C.c_uint, _P(RawImage), _P(RawImage), _P(GainmapMetadata), C.c_int, C.c_int, C.c_float, _P(RawImage)]),
     "uhdr_hip_generate_gainmap": (ErrorInfo, [C.c_void_p, _P(RawImage), _P(RawImage), _P(EncodeCfg), _P(GainmapMetadata), _P(RawImage)]),
     "uhdr_hip_generate_gainmap_dev": (ErrorInfo, [C.c_void_p, _P(RawImage), _P(RawImage), _P(EncodeCfg), _P(GainmapMetadata), _P(RawImage)]),
     "uhdr_hip_generate_gainmap_pass1_dev": (ErrorInfo, [C.c_void_p, _P(RawImage), _P(RawImage), _P(EncodeCfg), C.c_void_p, C.c_void_p, _P(C.c_int)]),

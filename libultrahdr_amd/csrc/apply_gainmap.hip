@@ -12,6 +12,8 @@
 //   apply_generic_kernel-- one thread per pixel, every format / scale combination the reference
 //                          accepts (4:4:4, 4:2:2, RGBA8888, odd sizes, non-integer scale).
 // HBM-bound by design: 1.5 B (4:2:0) + map + 8 B (F16) per pixel, no intermediate buffers.
+#include <cstdlib>
+
 #include "uhdr_types.h"
 
 namespace uhdr {
@@ -248,6 +250,22 @@ __device__ __forceinline__ uint2 lut_off_1024(f2 x) {
   const f2 t = __builtin_elementwise_fma(x, splat(1023.0f), splat(0.5f));
   return (uint2){(uint32_t)(int)t.x << 2, (uint32_t)(int)t.y << 2};
 }
+// Same index for an UNCLAMPED argument a (the reference clamps to [0,1] first):
+//   a < 0  -> the reference's index is 0; v_cvt_u32_f32 saturates negatives (and NaN) to 0
+//   a > 1  -> the reference's index is 1023; here it is floor(a*1023 + 0.5) >= 1023 and the LDS
+//             copy of the table is padded with entry 1023 up to kSrgbPad entries
+// so clamp01 + index costs add/fma/cvt instead of add/clamp/fma/cvt.  |a| < 2 for every
+// Y'CbCr input (y <= 1, |c*chroma| <= 1.772 * 0.5), i.e. index < 2048.
+constexpr int kSrgbPad = 2048;
+__device__ __forceinline__ uint32_t cvt_u32_sat(float v) {
+  uint32_t r;
+  asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(v));
+  return r;
+}
+__device__ __forceinline__ uint2 lut_off_unclamped(f2 a) {
+  const f2 t = __builtin_elementwise_fma(a, splat(1023.0f), splat(0.5f));
+  return (uint2){cvt_u32_sat(t.x) << 2, cvt_u32_sat(t.y) << 2};
+}
 // v_cvt_pkrtz_f16_f32 on raw bit patterns: two floats -> two halves, round toward zero
 __device__ __forceinline__ uint32_t pkrtz_bits(uint32_t a, uint32_t b) {
   typedef __fp16 h2 __attribute__((ext_vector_type(2)));
@@ -255,6 +273,9 @@ __device__ __forceinline__ uint32_t pkrtz_bits(uint32_t a, uint32_t b) {
   return __builtin_bit_cast(uint32_t, v);
 }
 __device__ __forceinline__ f2 lds_gather(const float* base, uint2 byte_off) {
+#ifdef UHDR_EXP_NOLDS  // experiment (tools/kbench): no LDS traffic
+  return (f2){__uint_as_float(byte_off.x | 0x3f000000u), __uint_as_float(byte_off.y | 0x3f000000u)};
+#endif
   const char* b = (const char*)base;
   return (f2){*(const float*)(b + byte_off.x), *(const float*)(b + byte_off.y)};
 }
@@ -273,6 +294,7 @@ struct QuadRaw {
   uint32_t m[(SMODE == 0) ? 4 : 4 * NCH];  // SMODE 0: map bytes {row0 lo, row0 hi, row1 lo, row1 hi}; SMODE 1: tap bytes [tap][ch]
   uint32_t wrow;    // SMODE 1: row part of the weight-table index (wave-uniform)
   uint32_t y;       // first row of the quad (wave-uniform)
+  uint8_t* dst;     // destination plane of the quad's frame (wave-uniform)
 };
 
 // SGPR budget: a wave may use at most 80 SGPRs if 8 workgroups of 256 threads are to be resident
@@ -288,7 +310,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
   constexpr int NCH = (MAPFMT == 0) ? 1 : 3;
   constexpr int BPP = (MAPFMT == 0) ? 1 : (MAPFMT == 1 ? 3 : 4);
   using Raw = QuadRaw<MAPFMT, SMODE>;
-  __shared__ float s_srgb[kSrgbN];
+  __shared__ float s_srgb[kSrgbPad];
   __shared__ float s_gain[(SMODE == 0) ? 1 : NCH * kGainN];
   __shared__ float s_u8f[(SMODE == 0) ? 1 : 256];
   __shared__ float s_fac[(SMODE == 0) ? NCH * 256 : 1];
@@ -297,7 +319,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
   __shared__ __attribute__((aligned(16))) float s_idw[(SMODE == 0) ? 4 : 4 * kMaxIdwScaleLds * kMaxIdwScaleLds * 4];
 
   const uint32_t tid = threadIdx.x;
-  for (uint32_t i = tid; i < kSrgbN; i += kBlock) s_srgb[i] = p.tables[ApplyTables::kSrgbOff + i];
+  for (uint32_t i = tid; i < kSrgbPad; i += kBlock) s_srgb[i] = p.tables[ApplyTables::kSrgbOff + min(i, (uint32_t)kSrgbN - 1)];
   if constexpr (SMODE == 0) {
     for (uint32_t i = tid; i < NCH * 256; i += kBlock) s_fac[i] = p.tables[ApplyTables::kFacOff + i];
   } else {
@@ -320,11 +342,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
   if (wave >= groups * strips_x) return;  // a few surplus waves of the last workgroup
   const uint32_t qy0 = wave / strips_x, sx = wave - qy0 * strips_x;
 
-  const uint8_t* __restrict__ yp = (const uint8_t*)p.sdr.p[0];
-  const uint8_t* __restrict__ up = (const uint8_t*)p.sdr.p[1];
-  const uint8_t* __restrict__ vp = (const uint8_t*)p.sdr.p[2];
-  const uint8_t* __restrict__ mp = (const uint8_t*)p.gm.p[0];
-  uint8_t* __restrict__ dp = (uint8_t*)p.dst.p[0];
+  const uint32_t n_frames = p.n_frames;  // batch: frames of identical geometry stacked into one virtual image
+  const uint32_t vrows = qh * n_frames;
   const uint32_t sy = p.sdr.stride[0], su = p.sdr.stride[1], sv = p.sdr.stride[2];
   const uint32_t sm = p.gm.stride[0];
   constexpr uint32_t OPX = (OUT == 0) ? 8 : 4;  // output bytes per pixel
@@ -360,7 +379,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
   // ---- issue the loads of quad row qy_ (wave-uniform) -------------------------------------------
   auto fetch = [&](uint32_t qy_) -> Raw {
     Raw r;
-    qy_ = min(qy_, qh - 1);  // past the end: recompute the last row (identical bytes)
+    qy_ = min(qy_, vrows - 1);  // past the end: recompute the last row (identical bytes)
+    // frame of this (virtual) quad row and its plane pointers -- all wave-uniform (s_load)
+    const uint8_t *yp, *up, *vp, *mp;
+    if (n_frames > 1) {
+      const uint32_t f = qy_ / qh;
+      qy_ -= f * qh;
+      const FramePtrs& fp = p.frames[f];
+      yp = fp.y; up = fp.u; vp = fp.v; mp = fp.map; r.dst = fp.dst;
+    } else {
+      yp = (const uint8_t*)p.sdr.p[0]; up = (const uint8_t*)p.sdr.p[1]; vp = (const uint8_t*)p.sdr.p[2];
+      mp = (const uint8_t*)p.gm.p[0]; r.dst = (uint8_t*)p.dst.p[0];
+    }
     const uint32_t y = qy_ * 2;
     r.y = y;
     // 32-bit offsets from the kernel-argument base pointers (planes < 4 GiB, checked by the
@@ -425,12 +455,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
     for (int r = 0; r < 2; r++) {
       const uint32_t yb = r == 0 ? q.y0 : q.y1;
       const f2 yf = (f2){(float)(yb & 0xff), (float)(yb >> 8)} * k255;
-      const f2 gr = clamp01_2(yf + crv);
-      const f2 gg = clamp01_2(yf - gcbu - gcrv);
-      const f2 gb = clamp01_2(yf + cbu);
-      f2 lr = lds_gather(s_srgb, lut_off_1024(gr));
-      f2 lg = lds_gather(s_srgb, lut_off_1024(gg));
-      f2 lb = lds_gather(s_srgb, lut_off_1024(gb));
+      // p3YuvToRgb + clampPixelFloat + srgbInvOetfLUT; the clamp is absorbed by the index
+      // conversion and the padded table (see lut_off_unclamped)
+#ifdef UHDR_EXP_OLDCLAMP
+      f2 lr = lds_gather(s_srgb, lut_off_1024(clamp01_2(yf + crv)));
+      f2 lg = lds_gather(s_srgb, lut_off_1024(clamp01_2(yf - gcbu - gcrv)));
+      f2 lb = lds_gather(s_srgb, lut_off_1024(clamp01_2(yf + cbu)));
+#else
+      f2 lr = lds_gather(s_srgb, lut_off_unclamped(yf + crv));
+      f2 lg = lds_gather(s_srgb, lut_off_unclamped(yf - gcbu - gcrv));
+      f2 lb = lds_gather(s_srgb, lut_off_unclamped(yf + cbu));
+#endif
+#ifndef UHDR_EXP_NOGAMUT
       if (p.sdr_gamut_on) {
         const Mat3& m = p.gamut;
         const f2 nr = m.m[0] * lr + m.m[1] * lg + m.m[2] * lb;
@@ -438,6 +474,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
         const f2 nb = m.m[6] * lr + m.m[7] * lg + m.m[8] * lb;
         lr = nr; lg = ng; lb = nb;
       }
+#endif
       f2 f0, f1, f2_;
       if constexpr (SMODE == 0) {
         const uint32_t a = q.m[2 * r], b = q.m[2 * r + 1];
@@ -474,7 +511,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
       f2 hr = ((lr + off_s0) * f0) - off_h0;
       f2 hg = ((lg + off_s1) * f1) - off_h1;
       f2 hb = ((lb + off_s2) * f2_) - off_h2;
-      uint8_t* dpx = dp + (drow + r * sd + xdst);
+      uint8_t* dpx = q.dst + (drow + r * sd + xdst);
       if constexpr (OUT == 0) {
         if (p.hdr_gamut_on) {
           const Mat3& m = p.gamut;
@@ -500,6 +537,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
           o.z = float_to_half_general(__float_as_uint(c1r)) | (float_to_half_general(__float_as_uint(c1g)) << 16);
           o.w = float_to_half_general(__float_as_uint(c1b)) | (0x3C00u << 16);
         }
+#ifdef UHDR_EXP_NOSTORE  // experiment (tools/kbench): keep the math alive, never store
+        if (o.x == 0x12345678u && o.w == 0x9abcdef0u)
+#endif
         *(uint4*)dpx = o;
       } else {
         const float peak = (OUT == 1) ? 1000.0f : 10000.0f;  // kHlgMaxNits / kPqMaxNits
@@ -551,13 +591,17 @@ int resident_blocks(K kernel) {
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
   if (per_cu > 8) per_cu = 8;
+  if (const char* e = getenv("UHDR_HIP_BLOCKS_PER_CU")) {  // tuning knob (tools/kbench)
+    const int v = atoi(e);
+    if (v >= 1 && v <= 8) per_cu = v;
+  }
   return per_cu * cus;
 }
 
 template <int OUT, int MAPFMT, int SMODE>
 hipError_t launch_quad(const ApplyParams& p, hipStream_t s) {
   static const int resident = resident_blocks(apply_quad_kernel<OUT, MAPFMT, SMODE>);
-  const uint32_t strips_x = (p.sdr.w / 2 + 63) / 64, qh = p.sdr.h / 2;
+  const uint32_t strips_x = (p.sdr.w / 2 + 63) / 64, qh = (p.sdr.h / 2) * (p.n_frames ? p.n_frames : 1);
   // one balanced round: all workgroups resident; a wave owns a column strip and every
   // `groups`-th quad row of it
   const uint32_t max_waves = (uint32_t)resident * (kBlock / 64);
@@ -566,6 +610,7 @@ hipError_t launch_quad(const ApplyParams& p, hipStream_t s) {
   if (groups < 1) groups = 1;
   const uint32_t nwaves = groups * strips_x;
   ApplyParams q = p;
+  if (q.n_frames == 0) q.n_frames = 1;
   q.row_groups = groups;
   q.tiles_per_wave = ((qh + groups - 1) / groups + 1) & ~1u;
   const int grid = (int)((nwaves + kBlock / 64 - 1) / (kBlock / 64));
@@ -589,42 +634,48 @@ inline bool aligned_to(const void* ptr, size_t a) { return ((uintptr_t)ptr % a) 
 
 }  // namespace
 
+// Does the quad kernel's layout contract hold?  Returns its SMODE (0 / 1) or -1.
+int apply_quad_mode(const ApplyParams& p) {
+  const int out = p.out_ct == UHDR_CT_LINEAR ? 0 : (p.out_ct == UHDR_CT_HLG ? 1 : 2);
+  const int mapfmt = p.gm.fmt == UHDR_IMG_FMT_8bppYCbCr400 ? 0 : (p.gm.fmt == UHDR_IMG_FMT_24bppRGB888 ? 1 : 2);
+  const size_t out_bytes = out == 0 ? 8 : 4;
+  const bool quad = p.sdr.fmt == UHDR_IMG_FMT_12bppYCbCr420 && (p.sdr.w % 2 == 0) && (p.sdr.h % 2 == 0) &&
+                    (p.y0 % 2 == 0) && (p.sdr.stride[0] % 2 == 0) && aligned_to(p.sdr.p[0], 2) &&
+                    aligned_to(p.dst.p[0], 16) && ((p.dst.stride[0] * out_bytes) % 16 == 0) &&
+                    p.sdr.w < 65536 && (p.sdr.h + p.y0) < 65536 && p.sdr.w >= 128 &&
+                    // 32-bit byte offsets inside the kernel
+                    (uint64_t)p.dst.stride[0] * out_bytes * p.sdr.h < 0xFFFFFFFFull &&
+                    (uint64_t)p.gm.stride[0] * p.gm.h * 4 < 0xFFFFFFFFull;
+  if (!quad) return -1;
+  if (p.scale == 1) {
+    // the gain map must cover every base pixel and allow the vector loads used per format
+    if (p.gm.w < p.sdr.w || p.gm.h < p.sdr.h + p.y0) return -1;
+    if (mapfmt == 0 && !(p.gm.stride[0] % 2 == 0 && aligned_to(p.gm.p[0], 2))) return -1;
+    if (mapfmt == 1 && !((p.gm.stride[0] * 3) % 2 == 0 && aligned_to(p.gm.p[0], 2))) return -1;
+    if (mapfmt == 2 && !(p.gm.stride[0] % 2 == 0 && aligned_to(p.gm.p[0], 8))) return -1;
+    return 0;
+  }
+  if (p.scale >= 2 && p.scale % 2 == 0 && p.scale <= (uint32_t)kMaxIdwScaleLds && p.gamma_is_one[0] &&
+      p.gamma_is_one[1] && p.gamma_is_one[2])
+    return 1;  // gamma != 1 needs pow() per sample: generic kernel
+  return -1;
+}
+
 // Picks the quad kernel when its layout assumptions hold, otherwise the generic one.
+// Batch mode (p.n_frames > 1) exists on the quad path only; the host layer falls back to one
+// launch per frame when apply_quad_mode() says no.
 hipError_t launch_apply_gainmap(const ApplyParams& p, hipStream_t s) {
   const int out = p.out_ct == UHDR_CT_LINEAR ? 0 : (p.out_ct == UHDR_CT_HLG ? 1 : 2);
-  const int mapfmt = p.gm.fmt == UHDR_IMG_FMT_8bppYCbCr400 ? 0
-                     : (p.gm.fmt == UHDR_IMG_FMT_24bppRGB888 ? 1 : 2);
-  const size_t out_bytes = out == 0 ? 8 : 4;
-  bool quad = p.sdr.fmt == UHDR_IMG_FMT_12bppYCbCr420 && (p.sdr.w % 2 == 0) && (p.sdr.h % 2 == 0) &&
-              (p.y0 % 2 == 0) && (p.sdr.stride[0] % 2 == 0) && aligned_to(p.sdr.p[0], 2) &&
-              aligned_to(p.dst.p[0], 16) && ((p.dst.stride[0] * out_bytes) % 16 == 0) &&
-              p.sdr.w < 65536 && (p.sdr.h + p.y0) < 65536 && p.sdr.w >= 128 &&
-              // 32-bit byte offsets inside the kernel
-              (uint64_t)p.dst.stride[0] * out_bytes * p.sdr.h < 0xFFFFFFFFull &&
-              (uint64_t)p.gm.stride[0] * p.gm.h * 4 < 0xFFFFFFFFull;
-  int smode = -1;
-  if (quad) {
-    if (p.scale == 1) {
-      smode = 0;
-      // the gain map must cover every base pixel and allow the vector loads used per format
-      if (p.gm.w < p.sdr.w || p.gm.h < p.sdr.h + p.y0) quad = false;
-      if (mapfmt == 0 && !(p.gm.stride[0] % 2 == 0 && aligned_to(p.gm.p[0], 2))) quad = false;
-      if (mapfmt == 1 && !((p.gm.stride[0] * 3) % 2 == 0 && aligned_to(p.gm.p[0], 2))) quad = false;
-      if (mapfmt == 2 && !(p.gm.stride[0] % 2 == 0 && aligned_to(p.gm.p[0], 8))) quad = false;
-    } else if (p.scale >= 2 && p.scale % 2 == 0 && p.scale <= (uint32_t)kMaxIdwScaleLds &&
-               p.gamma_is_one[0] && p.gamma_is_one[1] && p.gamma_is_one[2]) {
-      smode = 1;  // gamma != 1 needs pow() per sample: generic kernel
-    } else {
-      quad = false;
-    }
-  }
-  if (quad) {
+  const int mapfmt = p.gm.fmt == UHDR_IMG_FMT_8bppYCbCr400 ? 0 : (p.gm.fmt == UHDR_IMG_FMT_24bppRGB888 ? 1 : 2);
+  const int smode = apply_quad_mode(p);
+  if (smode >= 0) {
     switch (out) {
       case 0: return launch_quad_m<0>(p, mapfmt, smode, s);
       case 1: return launch_quad_m<1>(p, mapfmt, smode, s);
       default: return launch_quad_m<2>(p, mapfmt, smode, s);
     }
   }
+  if (p.n_frames > 1) return hipErrorInvalidValue;
   const size_t total = (size_t)p.sdr.w * p.sdr.h;
   int grid = (int)min((total + kBlock - 1) / kBlock, (size_t)4096);
   if (grid < 1) grid = 1;

@@ -86,6 +86,9 @@ struct uhdr_hip_ctx {
   DeviceBuf scratch[8];
   DeviceBuf minmax;  // 6 + 2048*6 floats
   uint16_t* d_qt = nullptr;
+  FramePtrs* d_frames = nullptr;  // batch frame-pointer tables (rotating slots)
+  size_t frames_cap = 0;
+  unsigned int frames_next = 0;
   // profiling
   bool prof = false;
   std::vector<ProfEntry> prof_entries;
@@ -382,6 +385,7 @@ void uhdr_hip_destroy(uhdr_hip_ctx_t* c) {
   for (auto& b : c->scratch) if (b.p) (void)hipFree(b.p);
   if (c->minmax.p) (void)hipFree(c->minmax.p);
   if (c->d_qt) (void)hipFree(c->d_qt);
+  if (c->d_frames) (void)hipFree(c->d_frames);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -426,21 +430,16 @@ int uhdr_hip_profile_read(uhdr_hip_ctx_t* c, const char* family, double* total_m
 // -------------------------------------------------------------------------------------------------
 // applyGainMap
 // -------------------------------------------------------------------------------------------------
-uhdr_error_info_t uhdr_hip_apply_gainmap_dev(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* sdr,
-                                             const uhdr_raw_image_t* gm, const uhdr_gainmap_metadata_t* md,
-                                             uhdr_color_transfer_t out_ct, uhdr_img_fmt_t out_fmt,
-                                             float max_display_boost, uhdr_raw_image_t* dest, unsigned int y0,
-                                             unsigned int full_height) {
-  (void)out_fmt;
-  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+static uhdr_error_info_t build_apply_params(uhdr_hip_ctx* c, const uhdr_raw_image_t* sdr, const uhdr_raw_image_t* gm,
+                                            const uhdr_gainmap_metadata_t* md, uhdr_color_transfer_t out_ct,
+                                            float max_display_boost, uhdr_raw_image_t* dest, unsigned int y0,
+                                            unsigned int full_height, ApplyParams* out) {
   UHDR_TRY(validate_apply(sdr, gm, md, out_ct, dest));
-  HIP_TRY(hipSetDevice(c->device));
-
   // colour-space bookkeeping (jpegr.cpp:1616-1631)
   const int sdr_cg = sdr->cg == UHDR_CG_UNSPECIFIED ? UHDR_CG_BT_709 : sdr->cg;
   const int hdr_cg = gm->cg == UHDR_CG_UNSPECIFIED ? sdr_cg : gm->cg;
   dest->cg = (uhdr_color_gamut_t)hdr_cg;
-  ApplyParams p;
+  ApplyParams& p = *out;
   memset(&p, 0, sizeof p);
   bool identity = false;
   if (!host::gamut_matrix(hdr_cg, sdr_cg, &p.gamut, &identity))
@@ -500,6 +499,77 @@ uhdr_error_info_t uhdr_hip_apply_gainmap_dev(uhdr_hip_ctx_t* c, const uhdr_raw_i
     p.offset_hdr[i] = md->offset_hdr[i];
   }
   p.yuv = host::yuv2rgb_coeffs(UHDR_CG_DISPLAY_P3);
+  return ok_status();
+}
+
+uhdr_error_info_t uhdr_hip_apply_gainmap_dev(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* sdr,
+                                             const uhdr_raw_image_t* gm, const uhdr_gainmap_metadata_t* md,
+                                             uhdr_color_transfer_t out_ct, uhdr_img_fmt_t out_fmt,
+                                             float max_display_boost, uhdr_raw_image_t* dest, unsigned int y0,
+                                             unsigned int full_height) {
+  (void)out_fmt;
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  HIP_TRY(hipSetDevice(c->device));
+  ApplyParams p;
+  UHDR_TRY(build_apply_params(c, sdr, gm, md, out_ct, max_display_boost, dest, y0, full_height, &p));
+  {
+    ProfScope ps(c, "apply_gainmap");
+    HIP_TRY(launch_apply_gainmap(p, c->stream));
+  }
+  return ok_status();
+}
+
+// Batch of n frames with identical geometry, formats, colour aspects and metadata (burst / video
+// style decode, BASELINE config 5): ONE launch walks all frames, so table staging, launch latency
+// and the pipeline ramp are paid once.
+uhdr_error_info_t uhdr_hip_apply_gainmap_batch_dev(uhdr_hip_ctx_t* c, unsigned int n, const uhdr_raw_image_t* sdr,
+                                                   const uhdr_raw_image_t* gm, const uhdr_gainmap_metadata_t* md,
+                                                   uhdr_color_transfer_t out_ct, uhdr_img_fmt_t out_fmt,
+                                                   float max_display_boost, uhdr_raw_image_t* dest) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  if (n == 0 || !sdr || !gm || !dest) return err_status(UHDR_CODEC_INVALID_PARAM, "received empty batch or nullptr array");
+  HIP_TRY(hipSetDevice(c->device));
+  ApplyParams p;
+  UHDR_TRY(build_apply_params(c, &sdr[0], &gm[0], md, out_ct, max_display_boost, &dest[0], 0, 0, &p));
+  bool uniform = true;
+  for (unsigned int i = 1; i < n && uniform; i++) {
+    uniform = sdr[i].fmt == sdr[0].fmt && sdr[i].w == sdr[0].w && sdr[i].h == sdr[0].h && sdr[i].cg == sdr[0].cg &&
+              gm[i].fmt == gm[0].fmt && gm[i].w == gm[0].w && gm[i].h == gm[0].h && gm[i].cg == gm[0].cg &&
+              dest[i].fmt == dest[0].fmt && dest[i].w == dest[0].w && dest[i].h == dest[0].h &&
+              !memcmp(sdr[i].stride, sdr[0].stride, sizeof sdr[0].stride) && gm[i].stride[0] == gm[0].stride[0] &&
+              dest[i].stride[0] == dest[0].stride[0] && sdr[i].planes[0] && sdr[i].planes[1] && sdr[i].planes[2] &&
+              gm[i].planes[0] && dest[i].planes[0] && ((uintptr_t)sdr[i].planes[0] % 2 == 0) &&
+              ((uintptr_t)dest[i].planes[0] % 16 == 0) && ((uintptr_t)gm[i].planes[0] % 8 == 0);
+  }
+  if (n == 1 || !uniform || apply_quad_mode(p) < 0) {  // no batch kernel for this combination: frame by frame
+    for (unsigned int i = 0; i < n; i++)
+      UHDR_TRY(uhdr_hip_apply_gainmap_dev(c, &sdr[i], &gm[i], md, out_ct, out_fmt, max_display_boost, &dest[i], 0, 0));
+    return ok_status();
+  }
+  // frame pointer table: rotating device slots so an in-flight launch keeps its table
+  constexpr unsigned int kSlots = 8;
+  const size_t bytes = (size_t)n * sizeof(FramePtrs);
+  if (c->frames_cap < bytes) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->d_frames) (void)hipFree(c->d_frames);
+    c->d_frames = nullptr;
+    c->frames_cap = 0;
+    HIP_TRY(hipMalloc((void**)&c->d_frames, bytes * kSlots));
+    c->frames_cap = bytes;
+  }
+  std::vector<FramePtrs> tab(n);
+  for (unsigned int i = 0; i < n; i++) {
+    tab[i].y = (const uint8_t*)sdr[i].planes[0];
+    tab[i].u = (const uint8_t*)sdr[i].planes[1];
+    tab[i].v = (const uint8_t*)sdr[i].planes[2];
+    tab[i].map = (const uint8_t*)gm[i].planes[0];
+    tab[i].dst = (uint8_t*)dest[i].planes[0];
+    dest[i].cg = dest[0].cg;
+  }
+  FramePtrs* slot = (FramePtrs*)((char*)c->d_frames + (size_t)(c->frames_next++ % kSlots) * c->frames_cap);
+  HIP_TRY(hipMemcpyAsync(slot, tab.data(), bytes, hipMemcpyHostToDevice, c->stream));  // pageable source: staged before return
+  p.n_frames = n;
+  p.frames = slot;
   {
     ProfScope ps(c, "apply_gainmap");
     HIP_TRY(launch_apply_gainmap(p, c->stream));

@@ -49,6 +49,12 @@ struct ApplyTables {  // layout of the device table block, in floats
   static int floats(int scale) { return kIdwOff + 4 * scale * scale * 4; }
 };
 
+// batch mode: per-frame plane pointers (device array); geometry / strides / metadata are shared
+struct FramePtrs {
+  const uint8_t *y, *u, *v, *map;
+  uint8_t* dst;
+};
+
 struct ApplyParams {
   ImageView sdr;      // base image (this rank's stripe)
   ImageView gm;       // whole gain map
@@ -58,6 +64,8 @@ struct ApplyParams {
   uint32_t y0;              // global row of stripe row 0
   uint32_t tiles_per_wave;  // quad kernel: loop trip count (even), set by the launcher
   uint32_t row_groups;      // quad kernel: quad-row step of a wave, set by the launcher
+  uint32_t n_frames;        // 0/1: single image; > 1: batch through `frames` (quad kernel only)
+  const FramePtrs* frames;
   uint32_t scale;           // integer map scale factor (table path) or 0
   uint32_t scale_magic;     // ceil(2^32 / scale): x / scale == umulhi(x, magic) for x < 65536
   float scale_f;            // (float)w_sdr / w_map, for the non-integer path
@@ -132,6 +140,7 @@ struct RgbToYcbcrParams {
 
 // launchers (defined in the .hip files)
 hipError_t launch_apply_gainmap(const ApplyParams& p, hipStream_t s);
+int apply_quad_mode(const ApplyParams& p);  // >= 0: the quad kernel (and batch mode) applies
 hipError_t launch_generate_gainmap(const GenParams& p, bool two_pass, hipStream_t s);
 hipError_t launch_affine_map(const AffineParams& p, hipStream_t s);
 hipError_t launch_tone_map(const ToneMapParams& p, hipStream_t s);

@@ -133,6 +133,18 @@ class UltraHdr:
                 self.ctx.handle, C.byref(sdr_intent.raw), C.byref(gainmap_img.raw), C.byref(gainmap_metadata),
                 output_ct, output_format, max_display_boost, C.byref(dest.raw)))
 
+    def applyGainMapBatch(self, sdr_intents, gainmap_imgs, gainmap_metadata: A.GainmapMetadata, output_ct: int,
+                          output_format: int, max_display_boost: float, dests):
+        """n device frames of identical geometry sharing one metadata block -> one kernel launch."""
+        n = len(sdr_intents)
+        assert n == len(gainmap_imgs) == len(dests) and n > 0
+        arr = lambda imgs: (A.RawImage * n)(*[im.raw for im in imgs])
+        s, g, d = arr(sdr_intents), arr(gainmap_imgs), arr(dests)
+        A.check(self.lib.uhdr_hip_apply_gainmap_batch_dev(self.ctx.handle, n, s, g, C.byref(gainmap_metadata), output_ct,
+                                                          output_format, max_display_boost, d))
+        for im, r in zip(dests, d):
+            im.raw.cg = r.cg
+
     # ---- convertYuv (ultrahdrcommon.h:545-546) -------------------------------------------------
     def convertYuv(self, image: Image, src_encoding: int, dst_encoding: int):
         fn = self.lib.uhdr_hip_convert_yuv_dev if _is_dev(image) else self.lib.uhdr_hip_convert_yuv

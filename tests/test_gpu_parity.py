@@ -166,6 +166,33 @@ def test_apply_gainmap_stripes_equal_whole(uhdr):
     assert planes_equal(whole, parts)
 
 
+@pytest.mark.parametrize("ch,alpha,scale", [(1, False, 4), (3, True, 1), (3, False, 1)])
+def test_apply_gainmap_batch_equals_per_frame(uhdr, ch, alpha, scale):
+    """uhdr_hip_apply_gainmap_batch_dev: one launch over n frames == n single launches == oracle."""
+    w, h, n = 256, 128, 5
+    f16 = A.UHDR_IMG_FMT_64bppRGBAHalfFloat
+    md = synth.default_metadata(use_base_cg=0, per_channel=(ch == 3))
+    sdrs = [synth.make_sdr_yuv420(w, h, seed=100 + i, noise=0.05) for i in range(n)]
+    gms = [synth.make_gainmap(w // scale, h // scale, ch, alpha, seed=200 + i, cg=A.UHDR_CG_BT_2100) for i in range(n)]
+    dsdr, dgm = [s.to("cuda:0") for s in sdrs], [g.to("cuda:0") for g in gms]
+    dests = [Image(f16, w, h, align=2, device="cuda:0") for _ in range(n)]
+    uhdr.applyGainMapBatch(dsdr, dgm, md, A.UHDR_CT_LINEAR, f16, A.FLT_MAX, dests)
+    uhdr.ctx.synchronize()
+    for i in range(n):
+        want = L.apply_gainmap(oracle_kind(), sdrs[i], gms[i], md, A.UHDR_CT_LINEAR)
+        assert np.array_equal(dests[i].to_host().valid(0), want.valid(0)), f"frame {i}"
+        assert dests[i].raw.cg == want.raw.cg
+    # a batch the quad kernel does not cover (4:4:4 base) silently runs frame by frame
+    s444 = Image(A.UHDR_IMG_FMT_24bppYCbCr444, 64, 32, A.UHDR_CG_BT_709, A.UHDR_CT_SRGB, A.UHDR_CR_FULL_RANGE)
+    s444.buf[:] = np.random.default_rng(1).integers(0, 256, s444.buf.size, dtype=np.uint8)
+    g1 = synth.make_gainmap(32, 16, 1)
+    d2 = [Image(f16, 64, 32, align=2, device="cuda:0") for _ in range(2)]
+    uhdr.applyGainMapBatch([s444.to("cuda:0")] * 2, [g1.to("cuda:0")] * 2, md, A.UHDR_CT_LINEAR, f16, A.FLT_MAX, d2)
+    uhdr.ctx.synchronize()
+    want = L.apply_gainmap(oracle_kind(), s444, g1, md, A.UHDR_CT_LINEAR)
+    assert np.array_equal(d2[1].to_host().valid(0), want.valid(0))
+
+
 # ---------------------------------------------------------------------------------------------------
 GEN_CASES = [
     (dict(kind="p010", ct=A.UHDR_CT_HLG), "yuv420", dict()),
