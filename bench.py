@@ -260,6 +260,19 @@ def extras(ctx, u, device):
     apply_case("apply_4k_hlg_mapA", 3840, 2160, "A", A.UHDR_CT_HLG)
     apply_case("apply_4k_pq_mapA", 3840, 2160, "A", A.UHDR_CT_PQ)
 
+    # the drop-in boundary with HOST buffers (H2D + kernel + D2H, pageable memory): PCIe-inclusive rate
+    hw, hh = 3840, 2160
+    hs = synth.make_sdr_yuv420(hw, hh, seed=5)
+    hg = synth.make_gainmap(hw, hh, 3, alpha=True, seed=6)
+    hs.raw.cg, hg.raw.cg = A.UHDR_CG_BT_709, A.UHDR_CG_BT_2100
+    hd = Image(f16, hw, hh, align=1)
+    u.applyGainMap(hs, hg, md, A.UHDR_CT_LINEAR, f16, A.FLT_MAX, hd)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        u.applyGainMap(hs, hg, md, A.UHDR_CT_LINEAR, f16, A.FLT_MAX, hd)
+    el = (time.perf_counter() - t0) / 3
+    res["apply_4k_f16_mapC_host_buffers_pcie_inclusive"] = {"ms": round(el * 1e3, 2), "Mpx/s": round(hw * hh / el / 1e6, 1)}
+
     # encode side, 4K: API-1 defaults (two-pass, 3-channel, scale 1) and the realtime preset
     w, h = 3840, 2160
     sdr = synth.make_sdr_yuv420(w, h).to(device)

@@ -1,0 +1,122 @@
+"""Committed golden vectors (tests/golden/hotpath_golden.npz, produced from the real reference by
+tests/golden/make_golden.py).  CPU part: the C oracle reproduces every vector bit for bit (this is
+what pins the oracle on machines without /root/reference).  GPU part (-m gpu): the HIP path
+against the same vectors."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from libultrahdr_amd import capi as A
+from libultrahdr_amd.images import Image
+from oracle import loader as L
+import golden_cases as G
+
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hotpath_golden.npz"))
+CASES = G.cases()
+
+
+def gold(name):
+    pfx = name + "/"
+    return {k[len(pfx):]: GOLD[k] for k in GOLD.files if k.startswith(pfx)}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_reproduces_reference_vectors(name):
+    got, want = G.run(CASES[name], "port"), gold(name)
+    assert set(got) == set(want)
+    for k in want:
+        assert np.array_equal(got[k], want[k]), (name, k)
+
+
+@pytest.mark.parametrize("q", [95, 50])
+def test_oracle_dct_reproduces_libjpeg_coefficients(q):
+    img = G.jpeg_image()
+    for c in range(3):
+        qt = L.quant_table_port(q, c > 0)
+        assert np.array_equal(qt, GOLD[f"jpeg_q{q}/qt{c}"])
+        want = GOLD[f"jpeg_q{q}/coef{c}"]
+        plane = img.plane(c)
+        got = L.fdct_quant_port(plane, plane.shape[1], want.shape[1], want.shape[0], qt)
+        assert np.array_equal(got, want)
+
+
+# ---- GPU ------------------------------------------------------------------------------------------
+EXACT_OPS = {"convert_yuv", "raw2ycc"}
+
+
+def _close(got, want, what):
+    if got.dtype == np.uint32:  # packed 8888 / 1010102
+        if "1010102" in what or "hlg" in what or "pq" in what:
+            g = np.stack([(got >> s) & 0x3FF for s in (0, 10, 20)], -1).astype(np.int64)
+            w = np.stack([(want >> s) & 0x3FF for s in (0, 10, 20)], -1).astype(np.int64)
+        else:
+            g, w = got.view(np.uint8).astype(np.int64), want.view(np.uint8).astype(np.int64)
+    else:
+        g, w = got.astype(np.int64), want.astype(np.int64)
+    d = np.abs(g - w)
+    assert d.max() <= 1 and (d != 0).mean() <= 0.01, (what, int(d.max()), float((d != 0).mean()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_hip_reproduces_reference_vectors(hip_ctx, name):
+    from libultrahdr_amd.ultrahdr import UltraHdr
+
+    case, want = CASES[name], gold(name)
+    op = case["op"]
+    if op == "apply":
+        sdr, gm, md = G.inputs(case)
+        fmt = A.UHDR_IMG_FMT_64bppRGBAHalfFloat if case["ct"] == A.UHDR_CT_LINEAR else A.UHDR_IMG_FMT_32bppRGBA1010102
+        dest = Image(fmt, sdr.w, sdr.h, align=1)
+        UltraHdr(ctx=hip_ctx).applyGainMap(sdr, gm, md, case["ct"], fmt, A.FLT_MAX, dest)
+        if case["ct"] == A.UHDR_CT_HLG:
+            _close(dest.valid(0), want["plane0"], name)
+        else:
+            assert np.array_equal(dest.valid(0), want["plane0"]), name
+        return
+    if op == "gen":
+        sdr, hdr = G.inputs(case)
+        cfg = A.default_encode_cfg(**case["cfg"])
+        u = UltraHdr(ctx=hip_ctx, mapDimensionScaleFactor=cfg.map_dimension_scale_factor,
+                     useMultiChannelGainMap=bool(cfg.use_multi_channel_gainmap), gamma=cfg.gamma, preset=cfg.preset)
+        md, gm = u.generateGainMap(sdr, hdr, bool(cfg.sdr_is_601), bool(cfg.use_luminance))
+        _close(gm.valid(0), want["plane0"], name)
+        ref_md = A.GainmapMetadata.from_buffer_copy(want["metadata"].tobytes())
+        for k, v in ref_md.as_dict().items():
+            assert np.allclose(md.as_dict()[k], v, rtol=1e-5), (name, k)
+        return
+    u = UltraHdr(ctx=hip_ctx)
+    if op == "tonemap":
+        _, hdr = G.inputs(case)
+        fmt = A.UHDR_IMG_FMT_12bppYCbCr420 if case["hdr"] == "p010" else A.UHDR_IMG_FMT_32bppRGBA8888
+        out = Image(fmt, hdr.w, hdr.h, align=64)
+        u.toneMap(hdr, out)
+    elif op == "convert_yuv":
+        (out,) = G.inputs(case)
+        u.convertYuv(out, case["src"], case["dst"])
+    else:
+        (img,) = G.inputs(case)
+        out = u.convert_raw_input_to_ycbcr(img, case["chroma"])
+    for i, p in enumerate(out.planes_valid()):
+        if op in EXACT_OPS:
+            assert np.array_equal(p, want[f"plane{i}"]), (name, i)
+        else:
+            _close(p, want[f"plane{i}"], name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("q", [95, 50])
+def test_hip_dct_reproduces_libjpeg_coefficients(hip_ctx, q):
+    from libultrahdr_amd.ultrahdr import UltraHdr
+
+    u = UltraHdr(ctx=hip_ctx)
+    img = G.jpeg_image()
+    for c in range(3):
+        qt = u.quant_table(q, c > 0)
+        assert np.array_equal(qt, GOLD[f"jpeg_q{q}/qt{c}"])
+        want = GOLD[f"jpeg_q{q}/coef{c}"]
+        plane = np.ascontiguousarray(img.plane(c))
+        got = u.fdct_quant(plane, plane.shape[1], want.shape[1], want.shape[0], qt)
+        assert np.array_equal(got, want)
