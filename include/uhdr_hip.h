@@ -221,6 +221,11 @@ uhdr_error_info_t uhdr_hip_convert_raw_input_to_ycbcr_dev(uhdr_hip_ctx_t* ctx,
 /* ---- JPEG DCT/quantize stage ----------------------------------------------------------------- */
 /* Quant table libjpeg builds for jpeg_set_quality(quality, TRUE): natural (row-major) order. */
 void uhdr_hip_jpeg_quant_table(int quality, int is_chroma, uint16_t qtable[64]);
+/* Host utility (no GPU needed): the table the HLG / PQ decode tail runs on.  thresholds[c], c = 1..1023,
+ * is the smallest clamped linear value whose 10-bit output code (jpegr.cpp:1775-1805: [pow 1/1.2,]
+ * OETF LUT, colorToRgba1010102 quantisation) is >= c, computed with the host's libm; 2.0f = the code is
+ * never reached.  Returns 0, or -1 for a transfer other than HLG / PQ. */
+int uhdr_hip_oetf_code_thresholds(uhdr_color_transfer_t ct, float thresholds[1024]);
 /* islow 8x8 FDCT + quantize of one 8-bit plane.  Reads blocks_w*8 x blocks_h*8 samples (the
  * caller pads to the MCU grid exactly as jpegencoderhelper.cpp:246-309 does); writes blocks in
  * raster order, 64 int16 each in natural order = libjpeg's JBLOCK layout, ready for

@@ -35,6 +35,45 @@ struct OutPix<0> {
   using type = uint2;
 };
 
+// 10-bit output code of the HLG (OUT 1) / PQ (OUT 2) tail for a clamped v in [0,1]:
+//   code(v) = max{ c : T[c] <= v }   with the host-built thresholds T (host_tables.cpp), T[0] = 0.
+// Fast path: an estimate c0 from hardware log2/exp2 (with the reference's 65536-node LUT
+// quantisation emulated) is normally within one code of the truth, so the answer is found by three
+// compares in the window T[lo+1..lo+3], lo = c0 - 1, and the window is VERIFIED against T[lo] and
+// T[lo+4].  Where the verification fails -- near black the LUT quantisation makes the code jump by
+// many steps, and an estimate may land on the wrong side of a node -- a 10-step binary search over
+// T gives the exact code.  Either way the result equals what the reference computes with the host
+// libm: no per-pixel powf, no 256 KiB table gather.
+__device__ __forceinline__ uint32_t oetf_code_search(float v, const float* T) {
+  uint32_t lo = 0;
+#pragma unroll
+  for (uint32_t step = 512; step; step >>= 1)
+    if (v >= T[lo + step]) lo += step;  // lo + step <= 1023; entries above the last reachable code are 2.0f
+  return lo;
+}
+// T layout: [0, kOetfThrN) float thresholds, then kOetfEstN packed bucket entries
+// E[k] = F(k << 18) | F((k+1) << 18) << 16: the codes at both ends of bucket k = bits(v) >> 18
+// (4065 buckets of <= 3 % relative width cover [0,1]).  Linear interpolation inside the bucket on
+// the low mantissa bits gives the code to within a step; the window around it is verified and the
+// binary search is the (rare, near-black) fallback.  No transcendental per pixel.
+template <int OUT>
+__device__ __forceinline__ uint32_t oetf_code(float v, const float* T) {
+  const uint32_t bits = __float_as_uint(v);
+  const uint32_t e = ((const uint32_t*)(T + kOetfThrN))[bits >> 18];
+  const uint32_t c_lo = e & 0xffffu, c_hi = e >> 16;
+  const uint32_t est = c_lo + (((c_hi - c_lo) * (bits & 0x3ffffu)) >> 18);
+  const uint32_t lo = min(max(est, c_lo + 1) - 1, 1022u);  // >= c_lo, so T[lo] <= v unless the estimate overshoots
+  const float* t = T + lo;
+  const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4];
+  const uint32_t cnt = (v >= t1 ? 1u : 0u) + (v >= t2 ? 1u : 0u) + (v >= t3 ? 1u : 0u);
+  uint32_t code = lo + cnt;
+  if (!(v >= t0) || (cnt == 3 && v >= t4)) code = oetf_code_search(v, T);
+  return code;
+}
+__device__ __forceinline__ uint32_t pack_codes_1010102(uint32_t r, uint32_t g, uint32_t b) {
+  return r | (g << 10) | (b << 20) | (0x3u << 30);
+}
+
 template <int OUT>
 __device__ __forceinline__ typename OutPix<OUT>::type finish_pixel(Color3 lin, float f0, float f1,
                                                                    float f2, const ApplyParams& p,
@@ -60,18 +99,14 @@ __device__ __forceinline__ typename OutPix<OUT>::type finish_pixel(Color3 lin, f
     h.g = h.g * 203.0f / peak;
     h.b = h.b * 203.0f / peak;
     if (p.hdr_gamut_on) h = mat3_apply(h, p.gamut);
-    h.r = clamp01(h.r);
-    h.g = clamp01(h.g);
-    h.b = clamp01(h.b);
-    if constexpr (OUT == 1) {  // hlgInverseOotfApprox: powf(v, 1/1.2f)  (gainmapmath.cpp:303-306)
-      h.r = powf(h.r, 1.0f / 1.2f);
-      h.g = powf(h.g, 1.0f / 1.2f);
-      h.b = powf(h.b, 1.0f / 1.2f);
+    if constexpr (OUT == 1) {
+      // clampPixelFloat, hlgInverseOotfApprox (powf), OETF LUT, colorToRgba1010102: one threshold lookup each
+      return pack_codes_1010102(oetf_code<OUT>(clamp01(h.r), p.oetf_thr), oetf_code<OUT>(clamp01(h.g), p.oetf_thr),
+                                oetf_code<OUT>(clamp01(h.b), p.oetf_thr));
+    } else {  // PQ has no per-pixel transcendental: the reference's own 65536-node table (L2 resident) is cheapest
+      return pack_rgba1010102(p.oetf_thr[lut_index_f32<kOetfN>(clamp01(h.r))], p.oetf_thr[lut_index_f32<kOetfN>(clamp01(h.g))],
+                              p.oetf_thr[lut_index_f32<kOetfN>(clamp01(h.b))]);
     }
-    float r = p.oetf_lut[lut_index_f32<kOetfN>(h.r)];
-    float g = p.oetf_lut[lut_index_f32<kOetfN>(h.g)];
-    float b = p.oetf_lut[lut_index_f32<kOetfN>(h.b)];
-    return pack_rgba1010102(r, g, b);
   }
 }
 
@@ -314,12 +349,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
   __shared__ float s_gain[(SMODE == 0) ? 1 : NCH * kGainN];
   __shared__ float s_u8f[(SMODE == 0) ? 1 : 256];
   __shared__ float s_fac[(SMODE == 0) ? NCH * 256 : 1];
+  __shared__ float s_thr[(OUT == 1) ? kOetfTabFloats : 1];  // HLG output-code thresholds + bucket end-point codes
   // IDW weights re-laid out for pixel PAIRS: entry (table, oy, ox/2) holds
   // {w0(ox), w0(ox+1), w1(ox), w1(ox+1), w2(ox), w2(ox+1), w3(ox), w3(ox+1)}
   __shared__ __attribute__((aligned(16))) float s_idw[(SMODE == 0) ? 4 : 4 * kMaxIdwScaleLds * kMaxIdwScaleLds * 4];
 
   const uint32_t tid = threadIdx.x;
   for (uint32_t i = tid; i < kSrgbPad; i += kBlock) s_srgb[i] = p.tables[ApplyTables::kSrgbOff + min(i, (uint32_t)kSrgbN - 1)];
+  if constexpr (OUT == 1) {
+    for (uint32_t i = tid; i < kOetfTabFloats; i += kBlock) s_thr[i] = p.oetf_thr[i];
+  }
   if constexpr (SMODE == 0) {
     for (uint32_t i = tid; i < NCH * 256; i += kBlock) s_fac[i] = p.tables[ApplyTables::kFacOff + i];
   } else {
@@ -554,17 +593,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
           hr = nr; hg = ng; hb = nb;
         }
         uint2 o;
-#pragma unroll
-        for (int c = 0; c < 2; c++) {
-          float vr = clamp01(c ? hr.y : hr.x), vg = clamp01(c ? hg.y : hg.x), vb2 = clamp01(c ? hb.y : hb.x);
-          if constexpr (OUT == 1) {  // hlgInverseOotfApprox: powf(v, 1/1.2f)  (gainmapmath.cpp:303-306)
-            vr = powf(vr, 1.0f / 1.2f);
-            vg = powf(vg, 1.0f / 1.2f);
-            vb2 = powf(vb2, 1.0f / 1.2f);
-          }
-          const uint32_t px = pack_rgba1010102(p.oetf_lut[lut_index_f32<kOetfN>(vr)], p.oetf_lut[lut_index_f32<kOetfN>(vg)],
-                                               p.oetf_lut[lut_index_f32<kOetfN>(vb2)]);
-          if (c == 0) o.x = px; else o.y = px;
+        if constexpr (OUT == 1) {
+          o.x = pack_codes_1010102(oetf_code<OUT>(clamp01(hr.x), s_thr), oetf_code<OUT>(clamp01(hg.x), s_thr),
+                                   oetf_code<OUT>(clamp01(hb.x), s_thr));
+          o.y = pack_codes_1010102(oetf_code<OUT>(clamp01(hr.y), s_thr), oetf_code<OUT>(clamp01(hg.y), s_thr),
+                                   oetf_code<OUT>(clamp01(hb.y), s_thr));
+        } else {
+          const float* lut = p.oetf_thr;  // pqOetfLUT, 65536 nodes
+          o.x = pack_rgba1010102(lut[lut_index_f32<kOetfN>(clamp01(hr.x))], lut[lut_index_f32<kOetfN>(clamp01(hg.x))],
+                                 lut[lut_index_f32<kOetfN>(clamp01(hb.x))]);
+          o.y = pack_rgba1010102(lut[lut_index_f32<kOetfN>(clamp01(hr.y))], lut[lut_index_f32<kOetfN>(clamp01(hg.y))],
+                                 lut[lut_index_f32<kOetfN>(clamp01(hb.y))]);
         }
         *(uint2*)dpx = o;
       }

@@ -12,6 +12,7 @@
 
 #include <cfloat>
 #include <cmath>
+#include <cstring>
 #include <mutex>
 
 namespace uhdr {
@@ -87,6 +88,66 @@ UHDR_STATIC_LUT(hlg_inv_oetf_lut, kInvOetfN, hlg_inv_oetf)
 UHDR_STATIC_LUT(pq_inv_oetf_lut, kInvOetfN, pq_inv_oetf)
 UHDR_STATIC_LUT(hlg_oetf_lut, kOetfN, hlg_oetf)
 UHDR_STATIC_LUT(pq_oetf_lut, kOetfN, pq_oetf)
+
+// ---- output-code threshold tables ----------------------------------------------------------------
+// applyGainMap's HLG / PQ tail maps a clamped float v in [0,1] to a 10-bit code:
+//   HLG: v -> powf(v, 1/1.2f) -> hlgOetfLUT (65536 nodes) -> uint(CLIP(e*1023 + 0.5f))
+//   PQ :                          v -> pqOetfLUT  (65536 nodes) -> uint(CLIP(e*1023 + 0.5f))
+// (jpegr.cpp:1775-1805, gainmapmath.cpp:248-254, 303-306, 320-326, 1279-1284).  The composite is a
+// monotone step function with at most 1024 values, so it is fully described by the 1023 smallest
+// inputs at which the code increases.  They are found here by bisection with the HOST's libm --
+// the same powf the reference would call on this machine -- and the kernel then needs only an
+// approximate code plus three compares, no per-pixel powf and no 256 KiB table gather.
+static uint32_t oetf_code_host(int ct, float v) {
+  float x = v;
+  if (ct == UHDR_CT_HLG) x = powf(v, 1.0f / 1.2f);
+  int idx = (int)((double)(x * (float)(kOetfN - 1)) + 0.5);
+  idx = idx < 0 ? 0 : (idx > kOetfN - 1 ? kOetfN - 1 : idx);
+  const float e = (ct == UHDR_CT_HLG ? hlg_oetf_lut() : pq_oetf_lut())[(size_t)idx];
+  float q = e * 1023 + 0.5f;
+  q = q < 0.0f ? 0.0f : (q > 1023.0f ? 1023.0f : q);
+  return (uint32_t)q;
+}
+uint32_t oetf_code(int ct, float v) { return oetf_code_host(ct, v); }
+
+static std::vector<float> make_thresholds(int ct) {
+  std::vector<float> t((size_t)kOetfThrN, 2.0f);  // "never reached" = above the clamped range
+  t[0] = 0.0f;
+  auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+  auto flt = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
+  const uint32_t top = bits(1.0f);
+  const uint32_t cmax = oetf_code_host(ct, 1.0f);
+  for (uint32_t c = 1; c <= cmax && c < 1024; c++) {
+    uint32_t lo = 0, hi = top;  // invariant: F(lo) < c <= F(hi); non-negative floats order like their bits
+    if (oetf_code_host(ct, 0.0f) >= c) { t[c] = 0.0f; continue; }
+    while (hi - lo > 1) {
+      const uint32_t mid = lo + (hi - lo) / 2;
+      if (oetf_code_host(ct, flt(mid)) >= c) hi = mid; else lo = mid;
+    }
+    t[c] = flt(hi);
+  }
+  return t;
+}
+// thresholds followed by the packed bucket end-point codes (see apply_gainmap.hip::oetf_code)
+static std::vector<float> make_threshold_block(int ct) {
+  std::vector<float> t = make_thresholds(ct);
+  auto code_at = [&](uint32_t k) -> uint32_t {
+    const uint32_t u = k << 18;
+    float f;
+    memcpy(&f, &u, 4);
+    return (f <= 1.0f) ? oetf_code_host(ct, f) : oetf_code_host(ct, 1.0f);
+  };
+  std::vector<uint32_t> e((size_t)kOetfEstN);
+  for (uint32_t k = 0; k < (uint32_t)kOetfEstN; k++) e[k] = code_at(k) | (code_at(k + 1) << 16);
+  t.resize((size_t)kOetfTabFloats, 0.0f);
+  memcpy(t.data() + kOetfThrN, e.data(), (size_t)kOetfEstN * sizeof(uint32_t));
+  return t;
+}
+const std::vector<float>& oetf_code_thresholds(int ct) {
+  static const std::vector<float> hlg = make_threshold_block(UHDR_CT_HLG);
+  static const std::vector<float> pq = make_threshold_block(UHDR_CT_PQ);
+  return ct == UHDR_CT_HLG ? hlg : pq;
+}
 
 Yuv2Rgb yuv2rgb_coeffs(int cg) {
   Yuv2Rgb k;

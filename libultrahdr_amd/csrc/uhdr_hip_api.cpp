@@ -476,11 +476,11 @@ static uhdr_error_info_t build_apply_params(uhdr_hip_ctx* c, const uhdr_raw_imag
   const float weight = host::gainmap_weight(*md, max_display_boost);
   UHDR_TRY(get_apply_tables(c, *md, weight, use_table ? (int)p.scale : msf_rnd, &p.tables));
   if (out_ct == UHDR_CT_HLG) {
-    UHDR_TRY(upload_lut(&c->d_hlg_oetf, host::hlg_oetf_lut(), c->stream));
-    p.oetf_lut = c->d_hlg_oetf;
+    UHDR_TRY(upload_lut(&c->d_hlg_oetf, host::oetf_code_thresholds(UHDR_CT_HLG), c->stream));
+    p.oetf_thr = c->d_hlg_oetf;
   } else if (out_ct == UHDR_CT_PQ) {
     UHDR_TRY(upload_lut(&c->d_pq_oetf, host::pq_oetf_lut(), c->stream));
-    p.oetf_lut = c->d_pq_oetf;
+    p.oetf_thr = c->d_pq_oetf;
   }
   p.sdr = view_of(sdr);
   p.gm = view_of(gm);
@@ -983,6 +983,13 @@ uhdr_error_info_t uhdr_hip_convert_raw_input_to_ycbcr(uhdr_hip_ctx_t* c, const u
 // JPEG FDCT + quantize
 // -------------------------------------------------------------------------------------------------
 void uhdr_hip_jpeg_quant_table(int quality, int is_chroma, uint16_t qt[64]) { host::jpeg_quant_table(quality, is_chroma, qt); }
+
+int uhdr_hip_oetf_code_thresholds(uhdr_color_transfer_t ct, float thresholds[1024]) {
+  if ((ct != UHDR_CT_HLG && ct != UHDR_CT_PQ) || !thresholds) return -1;
+  const std::vector<float>& t = host::oetf_code_thresholds(ct);
+  for (int i = 0; i < 1024; i++) thresholds[i] = t[(size_t)i];
+  return 0;
+}
 
 uhdr_error_info_t uhdr_hip_fdct_quant_dev(uhdr_hip_ctx_t* c, const uint8_t* plane, size_t stride, int bw, int bh,
                                           const uint16_t qt[64], int16_t* coef) {

@@ -37,6 +37,9 @@ struct ImageViewMut {
 constexpr int kSrgbN = 1024;
 constexpr int kGainN = 1024;
 constexpr int kOetfN = 65536;
+constexpr int kOetfThrN = 1028;  // thresholds T[0..1023] + 3 (+1 pad) sentinels for the 3-compare window
+constexpr int kOetfEstN = 4066;  // packed (code at bucket start | code at bucket end << 16), buckets k = bits(v) >> 18
+constexpr int kOetfTabFloats = kOetfThrN + kOetfEstN;
 constexpr int kInvOetfN = 4096;
 constexpr int kMaxIdwScaleLds = 8;  // idw tables up to 4*8*8*4 floats = 4 KiB live in LDS
 
@@ -60,7 +63,7 @@ struct ApplyParams {
   ImageView gm;       // whole gain map
   ImageViewMut dst;   // destination stripe
   const float* tables;      // ApplyTables block
-  const float* oetf_lut;    // 65536-entry HLG or PQ OETF table (null for linear)
+  const float* oetf_thr;    // HLG: output-code threshold block (kOetfTabFloats); PQ: pqOetfLUT (65536); linear: null
   uint32_t y0;              // global row of stripe row 0
   uint32_t tiles_per_wave;  // quad kernel: loop trip count (even), set by the launcher
   uint32_t row_groups;      // quad kernel: quad-row step of a wave, set by the launcher

@@ -63,6 +63,8 @@ def port() -> C.CDLL:
     lib.uo_jpeg_rgb_to_ycc.restype = None
     lib.uo_jpeg_rgb_to_ycc.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     _common_scalar_sigs(lib, "uo_")
+    lib.uo_oetf_code.restype = None
+    lib.uo_oetf_code.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
     lib.uo_lut.restype = None
     lib.uo_lut.argtypes = [C.c_int, C.c_void_p]
     _port = lib

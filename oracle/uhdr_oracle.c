@@ -1219,6 +1219,18 @@ int uo_eval(int fn, const float* in, float* out, size_t n) {
   }
   return 0;
 }
+/* 10-bit output code of applyGainMap's HLG / PQ tail for an already clamped v (jpegr.cpp:1783-1786,
+ * 1799-1801): [hlgInverseOotfApprox,] OETF LUT, colorToRgba1010102's per-channel quantisation. */
+void uo_oetf_code(int ct, const float* in, uint32_t* out, size_t n) {
+  init_luts();
+  for (size_t i = 0; i < n; i++) {
+    float x = in[i];
+    if (ct == UO_CT_HLG) x = powf(x, 1.0f / 1.2f);
+    float e = (ct == UO_CT_HLG ? g_lut_hlg : g_lut_pq)[lut_index(x, N_OETF)];
+    float q = e * 1023 + 0.5f;
+    out[i] = (uint32_t)(q < 0.0f ? 0.0f : (q > 1023.0f ? 1023.0f : q));
+  }
+}
 void uo_float_to_half(const float* in, uint16_t* out, size_t n) {
   for (size_t i = 0; i < n; i++) out[i] = float_to_half(in[i]);
 }

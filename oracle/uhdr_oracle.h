@@ -99,6 +99,7 @@ void uo_jpeg_rgb_to_ycc(const uint8_t* rgb, size_t stride_px, int w, int h, uint
 /* scalar access for known-answer tests */
 int uo_eval(int fn, const float* in, float* out, size_t n); /* ids as in ref_shim.cpp */
 void uo_float_to_half(const float* in, uint16_t* out, size_t n);
+void uo_oetf_code(int ct, const float* in, uint32_t* out, size_t n); /* HLG / PQ tail: clamped linear -> 10-bit code */
 uint32_t uo_color_to_rgba1010102(float r, float g, float b);
 uint64_t uo_color_to_rgbaf16(float r, float g, float b);
 float uo_compute_gain(float sdr, float hdr);

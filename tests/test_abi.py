@@ -98,3 +98,35 @@ def test_finalize_host_entry_point():
     assert mm[0] == 0.0 and mm[3] == f(np.log2(f(3.0)))
     assert list(md.max_content_boost) == [pytest.approx(3.0, rel=1e-6)] * 3 and md.hdr_capacity_max == pytest.approx(4.0)
     assert md.gamma[0] == f(1.3)
+
+
+@pytest.mark.parametrize("ct", [A.UHDR_CT_HLG, A.UHDR_CT_PQ])
+def test_oetf_code_thresholds_describe_the_reference_composite(ct):
+    """The HLG / PQ decode tail runs on a 1023-entry threshold table built by the host layer.  It must
+    reproduce the reference composite (oracle: powf + 65536-node LUT + 10-bit quantisation) exactly:
+    at every threshold, just below every threshold, and on 4M random inputs (monotonicity)."""
+    from oracle import loader as L
+
+    lib = A.load()
+    t = (C.c_float * 1024)()
+    assert lib.uhdr_hip_oetf_code_thresholds(ct, t) == 0
+    T = np.frombuffer(t, dtype=np.float32).copy()
+    assert T[0] == 0.0 and np.all(np.diff(T[1:]) >= 0)
+
+    def composite(v):
+        v = np.ascontiguousarray(v, dtype=np.float32)
+        out = np.zeros(v.size, dtype=np.uint32)
+        L.port().uo_oetf_code(ct, v.ctypes.data, out.ctypes.data, v.size)
+        return out
+
+    def by_table(v):
+        return (np.searchsorted(T[1:], v, side="right")).astype(np.uint32)
+
+    reach = T[1:][T[1:] <= 1.0]
+    below = np.nextafter(reach, np.float32(-1.0)).astype(np.float32)
+    rng = np.random.default_rng(0)
+    dense = np.concatenate([reach, below[below >= 0], rng.random(2_000_000, dtype=np.float32),
+                            (rng.random(2_000_000, dtype=np.float32) ** 8).astype(np.float32),  # emphasise near-black
+                            np.array([0.0, 1.0], dtype=np.float32)])
+    assert np.array_equal(composite(dense), by_table(dense))
+    assert lib.uhdr_hip_oetf_code_thresholds(A.UHDR_CT_LINEAR, t) == -1

@@ -1,8 +1,9 @@
 """Parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same seeded
-inputs.  Bit-exact for integer / LUT-only paths; the tolerance for paths with per-pixel
-transcendentals (hlgOotfApprox, hlgInverseOotfApprox, srgbOetf, encodeGain,
-computeGain -- glibc's own results for these vary with the CPU's ifunc variant) is +-1 output
-code with a stated bound on how many samples may differ.  Run on the GPU box: pytest -m gpu."""
+inputs.  Bit-exact for integer / LUT-only paths and for applyGainMap's HLG tail (host-built
+threshold tables); the tolerance for the remaining per-pixel transcendental sites (SURVEY.md 8a:
+hlgOotfApprox, srgbOetf, encodeGain, computeGain -- glibc's own results for these vary with the
+CPU's ifunc variant) is +-1 output code with a stated bound on how many samples may differ.
+Run on the GPU box: pytest -m gpu."""
 import ctypes as C
 
 import numpy as np
@@ -58,13 +59,10 @@ def hip_apply(uhdr, sdr, gm, md, ct, boost=A.FLT_MAX, device=False):
 def check_apply(uhdr, sdr, gm, md, ct, boost=A.FLT_MAX, device=False, what=""):
     want = L.apply_gainmap(oracle_kind(), sdr, gm, md, ct, boost)
     got = hip_apply(uhdr, sdr, gm, md, ct, boost, device)
-    if ct == A.UHDR_CT_HLG:  # 3 x powf per pixel
-        g, ga = unpack1010102(got.valid(0))
-        w_, wa = unpack1010102(want.valid(0))
-        assert np.array_equal(ga, wa)
-        assert_close_codes(g, w_, 1, 0.01, what)
-    else:  # LINEAR (F16) and PQ are table-only: bit exact
-        assert np.array_equal(got.valid(0), want.valid(0)), f"{what}: {(got.valid(0) != want.valid(0)).sum()} pixels differ"
+    # LINEAR (F16) and PQ are table-only; the HLG tail (3 x powf per pixel in the reference) runs on
+    # threshold tables built with this host's libm: all three are bit exact against the oracle
+    # evaluated on the same host
+    assert np.array_equal(got.valid(0), want.valid(0)), f"{what}: {(got.valid(0) != want.valid(0)).sum()} pixels differ"
     assert got.raw.cg == want.raw.cg
 
 
