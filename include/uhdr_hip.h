@@ -226,6 +226,12 @@ void uhdr_hip_jpeg_quant_table(int quality, int is_chroma, uint16_t qtable[64]);
  * OETF LUT, colorToRgba1010102 quantisation) is >= c, computed with the host's libm; 2.0f = the code is
  * never reached.  Returns 0, or -1 for a transfer other than HLG / PQ. */
 int uhdr_hip_oetf_code_thresholds(uhdr_color_transfer_t ct, float thresholds[1024]);
+/* Host utility (no GPU needed): runs the encode kernels' table-driven float64 math (csrc/exact_math.h,
+ * the same source the device compiles) on the host so it can be compared with libm without a GPU.
+ *   fn 0: srgbOetf(in)                      (gainmapmath.cpp:139-148, powf replaced)
+ *   fn 1: (float)log2((double)in)           (gainmapmath.cpp:767, 774, double log2 replaced)
+ * Returns 0, or -1 for an unknown fn. */
+int uhdr_hip_exact_math_eval(int fn, const float* in, float* out, size_t n);
 /* islow 8x8 FDCT + quantize of one 8-bit plane.  Reads blocks_w*8 x blocks_h*8 samples (the
  * caller pads to the MCU grid exactly as jpegencoderhelper.cpp:246-309 does); writes blocks in
  * raster order, 64 int16 each in natural order = libjpeg's JBLOCK layout, ready for

@@ -148,6 +148,7 @@ _SIGS = {
     "uhdr_hip_convert_raw_input_to_ycbcr_dev": (ErrorInfo, [C.c_void_p, _P(RawImage), C.c_int, _P(RawImage)]),
     "uhdr_hip_jpeg_quant_table": (None, [C.c_int, C.c_int, _P(C.c_uint16)]),
     "uhdr_hip_oetf_code_thresholds": (C.c_int, [C.c_int, _P(C.c_float)]),
+    "uhdr_hip_exact_math_eval": (C.c_int, [C.c_int, _P(C.c_float), _P(C.c_float), C.c_size_t]),
     "uhdr_hip_fdct_quant": (ErrorInfo, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, _P(C.c_uint16), C.c_void_p]),
     "uhdr_hip_fdct_quant_dev": (ErrorInfo, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, _P(C.c_uint16), C.c_void_p]),
     "uhdr_hip_profile_enable": (None, [C.c_void_p, C.c_int]),

@@ -317,6 +317,22 @@ __device__ __forceinline__ f2 lds_gather(const float* base, uint2 byte_off) {
 // the smallest float whose floatToHalf lands in the normal-half range: bits + 0x1000 >= 113 << 23
 #define UHDR_HALF_FAST_MIN_BITS ((113u << 23) - 0x1000u)
 
+// Streaming stores: every output byte is written once and never read back, so the quad kernels
+// store with the nontemporal hint (global_store ... nt).  Measured on MI355X (tools/kbench, 8K):
+// map A 80 -> 61 us, map B 87 -> 82 us, map C 92 -> 85 us.  The same hint on the LOADS is a loss
+// (the 2-byte luma / 1-byte chroma loads of neighbouring instructions share cache lines), so the
+// loads stay ordinary cached loads.  Ceiling for this 5.5 : 8 read : write mix with 16-byte accesses
+// and no arithmetic (tools/ubench3): 80-82 us.
+typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+template <typename T> __device__ __forceinline__ void stream_store(void* a, T v) {
+#ifdef UHDR_EXP_NONT  // experiment (tools/kbench)
+  *(T*)a = v;
+#else
+  __builtin_nontemporal_store(v, (T*)a);
+#endif
+}
+
 // Raw bytes of one lane's quad, loaded one tile AHEAD of their use: on gfx9 stores and loads retire
 // through the same in-order vmcnt counter, so a tile whose loads are issued after the previous
 // tile's stores would wait for those stores to be acknowledged by memory.  Issuing the next
@@ -329,7 +345,6 @@ struct QuadRaw {
   uint32_t m[(SMODE == 0) ? 4 : 4 * NCH];  // SMODE 0: map bytes {row0 lo, row0 hi, row1 lo, row1 hi}; SMODE 1: tap bytes [tap][ch]
   uint32_t wrow;    // SMODE 1: row part of the weight-table index (wave-uniform)
   uint32_t y;       // first row of the quad (wave-uniform)
-  uint8_t* dst;     // destination plane of the quad's frame (wave-uniform)
 };
 
 // SGPR budget: a wave may use at most 80 SGPRs if 8 workgroups of 256 threads are to be resident
@@ -378,11 +393,23 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
   const uint32_t lane = tid & 63;
   const uint32_t wave = blockIdx.x * (kBlock / 64) + __builtin_amdgcn_readfirstlane(tid >> 6);  // SGPR
   const uint32_t groups = p.row_groups, n_iter = p.tiles_per_wave;
-  if (wave >= groups * strips_x) return;  // a few surplus waves of the last workgroup
-  const uint32_t qy0 = wave / strips_x, sx = wave - qy0 * strips_x;
+  const uint32_t per_frame = groups * strips_x;
+  if (wave >= per_frame * p.n_frames) return;  // a few surplus waves of the last workgroup
+  // batch: a wave stays inside ONE frame, so its plane pointers are loop invariant (five scalar
+  // loads from the frame table, before the loop)
+  const uint32_t frame = wave / per_frame, wf = wave - frame * per_frame;
+  const uint32_t qy0 = wf / strips_x, sx = wf - qy0 * strips_x;
+  const uint8_t *yp, *up, *vp, *mp;
+  uint8_t* dp;
+  if (p.n_frames > 1) {
+    typedef const FramePtrs __attribute__((address_space(4))) * ConstFrames;  // constant memory -> s_load
+    ConstFrames fp = (ConstFrames)(uintptr_t)p.frames + frame;
+    yp = fp->y; up = fp->u; vp = fp->v; mp = fp->map; dp = fp->dst;
+  } else {
+    yp = (const uint8_t*)p.sdr.p[0]; up = (const uint8_t*)p.sdr.p[1]; vp = (const uint8_t*)p.sdr.p[2];
+    mp = (const uint8_t*)p.gm.p[0]; dp = (uint8_t*)p.dst.p[0];
+  }
 
-  const uint32_t n_frames = p.n_frames;  // batch: frames of identical geometry stacked into one virtual image
-  const uint32_t vrows = qh * n_frames;
   const uint32_t sy = p.sdr.stride[0], su = p.sdr.stride[1], sv = p.sdr.stride[2];
   const uint32_t sm = p.gm.stride[0];
   constexpr uint32_t OPX = (OUT == 0) ? 8 : 4;  // output bytes per pixel
@@ -418,18 +445,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
   // ---- issue the loads of quad row qy_ (wave-uniform) -------------------------------------------
   auto fetch = [&](uint32_t qy_) -> Raw {
     Raw r;
-    qy_ = min(qy_, vrows - 1);  // past the end: recompute the last row (identical bytes)
-    // frame of this (virtual) quad row and its plane pointers -- all wave-uniform (s_load)
-    const uint8_t *yp, *up, *vp, *mp;
-    if (n_frames > 1) {
-      const uint32_t f = qy_ / qh;
-      qy_ -= f * qh;
-      const FramePtrs& fp = p.frames[f];
-      yp = fp.y; up = fp.u; vp = fp.v; mp = fp.map; r.dst = fp.dst;
-    } else {
-      yp = (const uint8_t*)p.sdr.p[0]; up = (const uint8_t*)p.sdr.p[1]; vp = (const uint8_t*)p.sdr.p[2];
-      mp = (const uint8_t*)p.gm.p[0]; r.dst = (uint8_t*)p.dst.p[0];
-    }
+    qy_ = min(qy_, qh - 1);  // past the end: recompute the last row (identical bytes)
     const uint32_t y = qy_ * 2;
     r.y = y;
     // 32-bit offsets from the kernel-argument base pointers (planes < 4 GiB, checked by the
@@ -445,12 +461,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
       for (int k = 0; k < 2; k++) {
         const uint8_t* q = mp + ((yg + k) * sm * BPP + xmap);
         if constexpr (MAPFMT == 0) {
-          r.m[2 * k] = *(const uint16_t*)q;
+          r.m[2 * k] = *(const uint16_t*)(q);
           r.m[2 * k + 1] = 0;
         } else if constexpr (MAPFMT == 1) {  // 6 bytes: three aligned 16-bit loads
-          const uint16_t* a = (const uint16_t*)q;
-          r.m[2 * k] = a[0] | ((uint32_t)a[1] << 16);
-          r.m[2 * k + 1] = a[2];
+          r.m[2 * k] = *(const uint16_t*)(q) | ((uint32_t)*(const uint16_t*)(q + 2) << 16);
+          r.m[2 * k + 1] = *(const uint16_t*)(q + 4);
         } else {
           const uint2 a = *(const uint2*)q;
           r.m[2 * k] = a.x;
@@ -490,6 +505,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
     const float uf = (float)((int)q.u - 128) * k255, vf = (float)((int)q.v - 128) * k255;
     const float crv = yk.cr * vf, gcbu = yk.gcb * uf, gcrv = yk.gcr * vf, cbu = yk.cb * uf;
     const uint32_t drow = q.y * sd;  // wave-uniform row offset
+#ifdef UHDR_EXP_NOMATH  // experiment (tools/kbench): memory pattern only
+    if constexpr (OUT == 0 && SMODE == 0) {
+      for (int r = 0; r < 2; r++) {
+        const uint32_t yb = r == 0 ? q.y0 : q.y1;
+        uint4 o = {yb ^ q.u, q.m[2 * r] ^ q.v, q.m[2 * r + 1], yb};
+        stream_store<u4v>(dp + (drow + r * sd + xdst), (u4v){o.x, o.y, o.z, o.w});
+      }
+      return;
+    }
+#endif
 #pragma unroll
     for (int r = 0; r < 2; r++) {
       const uint32_t yb = r == 0 ? q.y0 : q.y1;
@@ -550,7 +575,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
       f2 hr = ((lr + off_s0) * f0) - off_h0;
       f2 hg = ((lg + off_s1) * f1) - off_h1;
       f2 hb = ((lb + off_s2) * f2_) - off_h2;
-      uint8_t* dpx = q.dst + (drow + r * sd + xdst);
+      uint8_t* dpx = dp + (drow + r * sd + xdst);
       if constexpr (OUT == 0) {
         if (p.hdr_gamut_on) {
           const Mat3& m = p.gamut;
@@ -579,7 +604,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
 #ifdef UHDR_EXP_NOSTORE  // experiment (tools/kbench): keep the math alive, never store
         if (o.x == 0x12345678u && o.w == 0x9abcdef0u)
 #endif
-        *(uint4*)dpx = o;
+        stream_store<u4v>(dpx, (u4v){o.x, o.y, o.z, o.w});
       } else {
         const float peak = (OUT == 1) ? 1000.0f : 10000.0f;  // kHlgMaxNits / kPqMaxNits
         hr = hr * 203.0f / peak;                              // two roundings, as written in the reference
@@ -605,7 +630,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
           o.y = pack_rgba1010102(lut[lut_index_f32<kOetfN>(clamp01(hr.y))], lut[lut_index_f32<kOetfN>(clamp01(hg.y))],
                                  lut[lut_index_f32<kOetfN>(clamp01(hb.y))]);
         }
-        *(uint2*)dpx = o;
+        stream_store<u2v>(dpx, (u2v){o.x, o.y});
       }
     }
   };
@@ -640,16 +665,17 @@ int resident_blocks(K kernel) {
 template <int OUT, int MAPFMT, int SMODE>
 hipError_t launch_quad(const ApplyParams& p, hipStream_t s) {
   static const int resident = resident_blocks(apply_quad_kernel<OUT, MAPFMT, SMODE>);
-  const uint32_t strips_x = (p.sdr.w / 2 + 63) / 64, qh = (p.sdr.h / 2) * (p.n_frames ? p.n_frames : 1);
-  // one balanced round: all workgroups resident; a wave owns a column strip and every
+  const uint32_t n_frames = p.n_frames ? p.n_frames : 1;
+  const uint32_t strips_x = (p.sdr.w / 2 + 63) / 64, qh = p.sdr.h / 2;
+  // one balanced round: all workgroups resident; a wave owns a column strip of one frame and every
   // `groups`-th quad row of it
   const uint32_t max_waves = (uint32_t)resident * (kBlock / 64);
-  uint32_t groups = max_waves / strips_x;
+  uint32_t groups = max_waves / (strips_x * n_frames);
   if (groups > (qh + 1) / 2) groups = (qh + 1) / 2;  // at least two rows per wave (loop unrolled by 2)
   if (groups < 1) groups = 1;
-  const uint32_t nwaves = groups * strips_x;
+  const uint32_t nwaves = groups * strips_x * n_frames;
   ApplyParams q = p;
-  if (q.n_frames == 0) q.n_frames = 1;
+  q.n_frames = n_frames;
   q.row_groups = groups;
   q.tiles_per_wave = ((qh + groups - 1) / groups + 1) & ~1u;
   const int grid = (int)((nwaves + kBlock / 64 - 1) / (kBlock / 64));

@@ -2,11 +2,19 @@
 // Reference loops: /root/reference/lib/src/jpegr.cpp:753-818 (one pass), 866-931 + 992-1013 (two
 // pass) with encodeGain / computeGain / affineMapGain from lib/src/gainmapmath.cpp:753-789.
 //
-// One thread per map pixel (each reads its s x s box of both images once: the minimum traffic).
+// One thread per map pixel (each reads its s x s box of both images once: the minimum traffic); a
+// workgroup walks tiles of 256 consecutive map pixels of one row.  The kernel is instantiated per
+// (SDR format, HDR format) so the pixel unpack has no per-pixel format dispatch.  All look-up
+// tables live in LDS:
+//   sRGB inverse OETF (1024 floats), HDR inverse OETF (4096 floats; for HLG the host has already
+//   folded hlgOotfApprox's powf(x, 1.2f) into it -- an exact fusion, the composite is evaluated with
+//   the host libm at the 4096 table nodes), and the float64 tables of exact_math.h that replace the
+//   per-pixel double log2.
 // Two-pass mode keeps the float log2-gain plane in HBM between the passes -- the reference does the
 // same (jpegr.cpp:842-844) -- and reduces per-channel min/max with wavefront shuffles -> LDS ->
 // one partial per workgroup -> a single-workgroup final reduction (deterministic, no float
 // atomics).  Across GPUs the 6 floats are all-reduced by the host layer (RCCL MIN / MAX).
+#include "exact_math.h"
 #include "pixel_io.h"
 #include "uhdr_types.h"
 
@@ -14,58 +22,75 @@ namespace uhdr {
 namespace {
 
 constexpr int kBlock = 256;
+constexpr int kMaxGrid = 2048;  // the host layer sizes the partials buffer for this many workgroups
 
-__device__ __forceinline__ Color3 inv_oetf(Color3 e, const GenParams& p) {
-  if (!p.hdr_inv_lut) return e;  // linear input: identityConversion
-  Color3 o;
-  if (p.hdr_inv_n == kInvOetfN) {  // 4096-entry HLG / PQ tables: exact double-form index
-    o.r = p.hdr_inv_lut[lut_index_f64<kInvOetfN>(e.r)];
-    o.g = p.hdr_inv_lut[lut_index_f64<kInvOetfN>(e.g)];
-    o.b = p.hdr_inv_lut[lut_index_f64<kInvOetfN>(e.b)];
-  } else {
-    o.r = p.hdr_inv_lut[lut_index_f32<kSrgbN>(e.r)];
-    o.g = p.hdr_inv_lut[lut_index_f32<kSrgbN>(e.g)];
-    o.b = p.hdr_inv_lut[lut_index_f32<kSrgbN>(e.b)];
-  }
-  return o;
-}
+struct GenLds {
+  float srgb[kSrgbN];
+  float hdr[kInvOetfN];
+  double math[kMathTabDoubles];
+};
 
 // encodeGain (gainmapmath.cpp:758-771): log2 is the DOUBLE libm one in the reference build, the
 // normalisation is double arithmetic narrowed to float, then powf, then truncation.
-__device__ __forceinline__ uint8_t encode_gain(float y_sdr, float y_hdr, const GenParams& p) {
+__device__ __forceinline__ uint8_t encode_gain(float y_sdr, float y_hdr, const GenParams& p, const double* T) {
   float gain = 1.0f;
   if (y_sdr > 0.0f) gain = y_hdr / y_sdr;
   if (gain < p.min_boost) gain = p.min_boost;
   if (gain > p.max_boost) gain = p.max_boost;
-  const float n = (float)((log2((double)gain) - (double)p.log2min) / (double)(p.log2max - p.log2min));
+  const double lg = log2_table_f64(gain, T);
+  const float n = (float)div_by_const_f64(lg - (double)p.log2min, p.log2_range, p.log2_range_rcp);
   const float ng = (p.gamma == 1.0f) ? n : powf(n, p.gamma);  // powf(x, 1) == x exactly
   return (uint8_t)(ng * 255.0f);
 }
 // computeGain (gainmapmath.cpp:773-782)
-__device__ __forceinline__ float compute_gain(float sdr, float hdr) {
-  float gain = (float)log2((double)((hdr + 1e-7f) / (sdr + 1e-7f)));
+__device__ __forceinline__ float compute_gain(float sdr, float hdr, const double* T) {
+  float gain = (float)log2_table_f64((hdr + 1e-7f) / (sdr + 1e-7f), T);
   if (sdr < 2.f / 255.0f) gain = fminf(gain, 2.3f);
   return gain;
 }
 
-template <bool TWO_PASS>
+struct F3 {
+  float a, b, c;
+};
+
+template <int SDRF, int HDRF, bool TWO_PASS>
 __global__ __launch_bounds__(kBlock) void generate_kernel(const GenParams p, float* partials) {
+  __shared__ GenLds L;
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t i = tid; i < kSrgbN; i += kBlock) L.srgb[i] = p.srgb_lut[i];
+  if (p.hdr_inv_lut)
+    for (uint32_t i = tid; i < (uint32_t)p.hdr_inv_n; i += kBlock) L.hdr[i] = p.hdr_inv_lut[i];
+  for (uint32_t i = tid; i < kMathTabDoubles; i += kBlock) L.math[i] = p.math_tab[i];
+  __syncthreads();
+
   const uint32_t mw = p.map_w, mh = p.map_h;
-  const size_t total = (size_t)mw * mh;
+  const uint32_t tiles_x = (mw + kBlock - 1) / kBlock, tiles = tiles_x * mh;
+  const bool hdr_lut = p.hdr_inv_lut != nullptr, hdr_lut_4096 = p.hdr_inv_n == kInvOetfN;
   float mn[3] = {127.0f, 127.0f, 127.0f}, mx[3] = {-128.0f, -128.0f, -128.0f};
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
-    const uint32_t y = (uint32_t)(i / mw), x = (uint32_t)(i - (size_t)y * mw);
-    Color3 s = sample_box(p.sdr, p.scale, x, y);
+  for (uint32_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const uint32_t y = t / tiles_x, x = (t - y * tiles_x) * kBlock + tid;
+    if (x >= mw) continue;
+    Color3 s = sample_box<SDRF>(p.sdr, p.scale, x, y);
     if (!p.sdr_is_rgb) s = yuv_to_rgb(s.r, s.g, s.b, p.sdr_yuv);
-    Color3 sl = {p.srgb_lut[lut_index_f32<kSrgbN>(s.r)], p.srgb_lut[lut_index_f32<kSrgbN>(s.g)],
-                 p.srgb_lut[lut_index_f32<kSrgbN>(s.b)]};
+    Color3 sl = {L.srgb[lut_index_f32<kSrgbN>(s.r)], L.srgb[lut_index_f32<kSrgbN>(s.g)], L.srgb[lut_index_f32<kSrgbN>(s.b)]};
     if (p.sdr_gamut_on) sl = mat3_apply(sl, p.sdr_gamut);
     sl.r = clip_neg(sl.r); sl.g = clip_neg(sl.g); sl.b = clip_neg(sl.b);
 
-    Color3 h = sample_box(p.hdr, p.scale, x, y);
+    Color3 h = sample_box<HDRF>(p.hdr, p.scale, x, y);
     if (!p.hdr_is_rgb) h = yuv_to_rgb(h.r, h.g, h.b, p.hdr_yuv);
-    Color3 hl = inv_oetf(h, p);
-    if (p.hdr_is_hlg) {  // hlgOotfApprox: powf(x, 1.2f) per channel (gainmapmath.cpp:293-295)
+    Color3 hl = h;  // linear input: identityConversion
+    if (hdr_lut) {
+      if (hdr_lut_4096) {  // HLG (+OOTF) / PQ tables: exact double-form index
+        hl.r = L.hdr[lut_index_f64<kInvOetfN>(h.r)];
+        hl.g = L.hdr[lut_index_f64<kInvOetfN>(h.g)];
+        hl.b = L.hdr[lut_index_f64<kInvOetfN>(h.b)];
+      } else {
+        hl.r = L.hdr[lut_index_f32<kSrgbN>(h.r)];
+        hl.g = L.hdr[lut_index_f32<kSrgbN>(h.g)];
+        hl.b = L.hdr[lut_index_f32<kSrgbN>(h.b)];
+      }
+    }
+    if (p.hdr_is_hlg) {  // hlgOotfApprox (gainmapmath.cpp:293-295) when the host did not fold it into the table
       hl.r = powf(hl.r, 1.2f); hl.g = powf(hl.g, 1.2f); hl.b = powf(hl.b, 1.2f);
     }
     if (p.hdr_gamut_on) hl = mat3_apply(hl, p.hdr_gamut);
@@ -75,19 +100,19 @@ __global__ __launch_bounds__(kBlock) void generate_kernel(const GenParams p, flo
       const float sn[3] = {sl.r * 203.0f, sl.g * 203.0f, sl.b * 203.0f};
       const float hn[3] = {hl.r * p.hdr_nits, hl.g * p.hdr_nits, hl.b * p.hdr_nits};
       if constexpr (!TWO_PASS) {
-        uint8_t* o = p.out + ((size_t)x + (size_t)y * p.out_stride) * 3;
-        o[0] = encode_gain(sn[0], hn[0], p);
-        o[1] = encode_gain(sn[1], hn[1], p);
-        o[2] = encode_gain(sn[2], hn[2], p);
+        uint8_t* o = p.out + (size_t)y * p.out_stride * 3 + x * 3;
+        o[0] = encode_gain(sn[0], hn[0], p, L.math);
+        o[1] = encode_gain(sn[1], hn[1], p, L.math);
+        o[2] = encode_gain(sn[2], hn[2], p, L.math);
       } else {
-        float* o = p.gain_log2 + i * 3;
+        float v[3];
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-          const float v = compute_gain(sn[c], hn[c]);
-          o[c] = v;
-          mn[c] = fminf(mn[c], v);
-          mx[c] = fmaxf(mx[c], v);
+          v[c] = compute_gain(sn[c], hn[c], L.math);
+          mn[c] = fminf(mn[c], v[c]);
+          mx[c] = fmaxf(mx[c], v[c]);
         }
+        *(F3*)(p.gain_log2 + ((size_t)y * mw + x) * 3) = F3{v[0], v[1], v[2]};
       }
     } else {
       float sy, hy;
@@ -99,10 +124,10 @@ __global__ __launch_bounds__(kBlock) void generate_kernel(const GenParams p, flo
         hy = fmaxf(hl.r, fmaxf(hl.g, hl.b)) * p.hdr_nits;
       }
       if constexpr (!TWO_PASS) {
-        p.out[(size_t)x + (size_t)y * p.out_stride] = encode_gain(sy, hy, p);
+        p.out[(size_t)y * p.out_stride + x] = encode_gain(sy, hy, p, L.math);
       } else {
-        const float v = compute_gain(sy, hy);
-        p.gain_log2[i] = v;
+        const float v = compute_gain(sy, hy, L.math);
+        p.gain_log2[(size_t)y * mw + x] = v;
         mn[0] = fminf(mn[0], v);
         mx[0] = fmaxf(mx[0], v);
       }
@@ -148,48 +173,90 @@ __global__ void reduce_minmax_kernel(const float* partials, int n, float* out6) 
   }
 }
 
-// affineMapGain (gainmapmath.cpp:784-789) over the float plane (jpegr.cpp:992-1013)
+// affineMapGain (gainmapmath.cpp:784-789) over the float plane (jpegr.cpp:992-1013): one thread per
+// four consecutive samples of a row (16-byte load, 4-byte store) when the geometry allows
+template <bool VEC4>
 __global__ __launch_bounds__(kBlock) void affine_kernel(const AffineParams p) {
-  const size_t row_elems = (size_t)p.map_w * p.nch;
-  const size_t total = row_elems * p.map_h;
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
-    const size_t y = i / row_elems, e = i - y * row_elems;
-    const int c = (int)(e % p.nch);
-    float m = (p.gain_log2[i] - p.mn[c]) / (p.mx[c] - p.mn[c]);
-    if (p.gamma != 1.0f) m = (float)pow((double)m, (double)p.gamma);
-    m *= 255.0f;
-    float t = m + 0.5f;
-    t = (t < 0.0f) ? 0.0f : ((t > 255.0f) ? 255.0f : t);
-    p.out[y * (size_t)p.out_stride * p.nch + e] = (uint8_t)t;
+  const uint32_t row_elems = p.map_w * p.nch;
+  const uint32_t per_row = VEC4 ? row_elems / 4 : row_elems;
+  const uint32_t tiles_x = (per_row + kBlock - 1) / kBlock, tiles = tiles_x * p.map_h;
+  for (uint32_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const uint32_t y = t / tiles_x, j = (t - y * tiles_x) * kBlock + threadIdx.x;
+    if (j >= per_row) continue;
+    const float* src = p.gain_log2 + (size_t)y * row_elems;
+    uint8_t* dst = p.out + (size_t)y * p.out_stride * p.nch;
+    auto map1 = [&](float g, uint32_t e) -> uint32_t {
+      const uint32_t c = p.nch == 3 ? e % 3 : 0;
+      float m = (g - p.mn[c]) / (p.mx[c] - p.mn[c]);
+      if (p.gamma != 1.0f) m = (float)pow((double)m, (double)p.gamma);
+      m *= 255.0f;
+      float t2 = m + 0.5f;
+      t2 = (t2 < 0.0f) ? 0.0f : ((t2 > 255.0f) ? 255.0f : t2);
+      return (uint32_t)t2;
+    };
+    if constexpr (VEC4) {
+      const float4 g = *(const float4*)(src + j * 4);
+      const uint32_t e = j * 4;
+      *(uint32_t*)(dst + e) = map1(g.x, e) | (map1(g.y, e + 1) << 8) | (map1(g.z, e + 2) << 16) | (map1(g.w, e + 3) << 24);
+    } else {
+      dst[j] = (uint8_t)map1(src[j], j);
+    }
+  }
+}
+
+int gen_grid(uint32_t tiles) {
+  static const int resident = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 1024;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    return cus * 6;  // 23 KB of LDS tables per workgroup: six fit in a CU's 160 KB
+  }();
+  uint32_t g = tiles < (uint32_t)resident ? tiles : (uint32_t)resident;
+  if (g > kMaxGrid) g = kMaxGrid;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+template <int SDRF, int HDRF>
+void launch_gen(const GenParams& p, bool two_pass, int grid, float* partials, hipStream_t s) {
+  if (two_pass) hipLaunchKernelGGL((generate_kernel<SDRF, HDRF, true>), dim3(grid), dim3(kBlock), 0, s, p, partials);
+  else hipLaunchKernelGGL((generate_kernel<SDRF, HDRF, false>), dim3(grid), dim3(kBlock), 0, s, p, partials);
+}
+template <int SDRF>
+void launch_gen_h(const GenParams& p, bool two_pass, int grid, float* partials, hipStream_t s) {
+  switch (p.hdr.fmt) {
+    case UHDR_IMG_FMT_24bppYCbCrP010: return launch_gen<SDRF, UHDR_IMG_FMT_24bppYCbCrP010>(p, two_pass, grid, partials, s);
+    case UHDR_IMG_FMT_32bppRGBA1010102: return launch_gen<SDRF, UHDR_IMG_FMT_32bppRGBA1010102>(p, two_pass, grid, partials, s);
+    default: return launch_gen<SDRF, -1>(p, two_pass, grid, partials, s);
   }
 }
 
 }  // namespace
 
-static int gen_grid(size_t total) {
-  size_t g = (total + kBlock - 1) / kBlock;
-  if (g > 2048) g = 2048;
-  if (g < 1) g = 1;
-  return (int)g;
-}
-
-// Two-pass: p.minmax must have room for 6 floats followed by gen_grid*6 floats of partials
+// Two-pass: p.minmax must have room for 6 floats followed by kMaxGrid*6 floats of partials
 // (the host layer allocates 6 + 2048*6).
 hipError_t launch_generate_gainmap(const GenParams& p, bool two_pass, hipStream_t s) {
-  const int grid = gen_grid((size_t)p.map_w * p.map_h);
-  if (!two_pass) {
-    hipLaunchKernelGGL((generate_kernel<false>), dim3(grid), dim3(kBlock), 0, s, p, (float*)nullptr);
-    return hipGetLastError();
+  const uint32_t tiles = ((p.map_w + kBlock - 1) / kBlock) * p.map_h;
+  const int grid = gen_grid(tiles);
+  float* partials = two_pass ? p.minmax + 6 : nullptr;
+  switch (p.sdr.fmt) {
+    case UHDR_IMG_FMT_12bppYCbCr420: launch_gen_h<UHDR_IMG_FMT_12bppYCbCr420>(p, two_pass, grid, partials, s); break;
+    case UHDR_IMG_FMT_32bppRGBA8888: launch_gen_h<UHDR_IMG_FMT_32bppRGBA8888>(p, two_pass, grid, partials, s); break;
+    default: launch_gen_h<-1>(p, two_pass, grid, partials, s); break;
   }
-  float* partials = p.minmax + 6;
-  hipLaunchKernelGGL((generate_kernel<true>), dim3(grid), dim3(kBlock), 0, s, p, partials);
-  hipLaunchKernelGGL(reduce_minmax_kernel, dim3(1), dim3(256), 0, s, (const float*)partials, grid, p.minmax);
+  if (two_pass) hipLaunchKernelGGL(reduce_minmax_kernel, dim3(1), dim3(256), 0, s, (const float*)partials, grid, p.minmax);
   return hipGetLastError();
 }
 
 hipError_t launch_affine_map(const AffineParams& p, hipStream_t s) {
-  const int grid = gen_grid((size_t)p.map_w * p.map_h * p.nch);
-  hipLaunchKernelGGL(affine_kernel, dim3(grid), dim3(kBlock), 0, s, p);
+  const uint32_t row_elems = p.map_w * p.nch;
+  const bool vec4 = (row_elems % 4 == 0) && ((p.out_stride * p.nch) % 4 == 0) && (((uintptr_t)p.out & 3) == 0) &&
+                    (((uintptr_t)p.gain_log2 & 15) == 0);
+  const uint32_t per_row = vec4 ? row_elems / 4 : row_elems;
+  const uint32_t tiles = ((per_row + kBlock - 1) / kBlock) * p.map_h;
+  const int grid = (int)(tiles < 8192u ? (tiles ? tiles : 1u) : 8192u);
+  if (vec4) hipLaunchKernelGGL((affine_kernel<true>), dim3(grid), dim3(kBlock), 0, s, p);
+  else hipLaunchKernelGGL((affine_kernel<false>), dim3(grid), dim3(kBlock), 0, s, p);
   return hipGetLastError();
 }
 

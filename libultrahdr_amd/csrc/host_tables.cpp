@@ -10,6 +10,8 @@
 // This TU is compiled with -ffp-contract=off.
 #include "host_tables.h"
 
+#include "exact_math.h"
+
 #include <cfloat>
 #include <cmath>
 #include <cstring>
@@ -86,6 +88,17 @@ void set_mat(Mat3* o, const float* m) {
 UHDR_STATIC_LUT(srgb_inv_oetf_lut, kSrgbN, srgb_inv_oetf)
 UHDR_STATIC_LUT(hlg_inv_oetf_lut, kInvOetfN, hlg_inv_oetf)
 UHDR_STATIC_LUT(pq_inv_oetf_lut, kInvOetfN, pq_inv_oetf)
+// hlgInvOetfLUT followed by hlgOotfApprox (gainmapmath.cpp:271-277, 293-295: std::pow(float, float) =
+// powf): both encode loops (jpegr.cpp:768-775, 2160-2163) apply the OOTF to the table's output, so
+// the composite is a function of the table index alone.
+const std::vector<float>& hlg_inv_oetf_ootf_lut() {
+  static const std::vector<float> t = [] {
+    std::vector<float> v = hlg_inv_oetf_lut();
+    for (float& x : v) x = powf(x, 1.2f);
+    return v;
+  }();
+  return t;
+}
 UHDR_STATIC_LUT(hlg_oetf_lut, kOetfN, hlg_oetf)
 UHDR_STATIC_LUT(pq_oetf_lut, kOetfN, pq_oetf)
 
@@ -147,6 +160,35 @@ const std::vector<float>& oetf_code_thresholds(int ct) {
   static const std::vector<float> hlg = make_threshold_block(UHDR_CT_HLG);
   static const std::vector<float> pq = make_threshold_block(UHDR_CT_PQ);
   return ct == UHDR_CT_HLG ? hlg : pq;
+}
+
+// Tables of exact_math.h.  Everything is computed in long double (64-bit significand on x86-64)
+// and rounded once to double.
+const std::vector<double>& math_tables() {
+  static const std::vector<double> tab = [] {
+    std::vector<double> t((size_t)kMathTabDoubles, 0.0);
+    const long double p = (long double)(1.0f / 2.4f);  // the float exponent srgbOetf passes to powf
+    for (int i = 0; i <= kPowM; i++) {
+      const long double c = 1.0L + (long double)i / kPowM;
+      t[kPowIcOff + 2 * i] = (double)(1.0L / c);
+      t[kPowIcOff + 2 * i + 1] = (double)powl(c, p);
+    }
+    for (int k = kPowMinExp; k <= 0; k++) t[kPowScOff + (k - kPowMinExp)] = (double)exp2l((long double)k * p);
+    long double binom = 1.0L;
+    for (int j = 1; j <= 5; j++) {
+      binom = binom * (p - (long double)(j - 1)) / (long double)j;  // C(p, j)
+      t[kPowAOff + j - 1] = (double)binom;
+    }
+    for (int i = 0; i <= kLogM; i++) {
+      const long double c = 1.0L + (long double)i / kLogM;
+      t[kLogIcOff + 2 * i] = (double)(1.0L / c);
+      t[kLogIcOff + 2 * i + 1] = (double)log2l(c);
+    }
+    const long double ln2 = logl(2.0L);
+    for (int j = 1; j <= 6; j++) t[kLogBOff + j - 1] = (double)(((j & 1) ? 1.0L : -1.0L) / ((long double)j * ln2));
+    return t;
+  }();
+  return tab;
 }
 
 Yuv2Rgb yuv2rgb_coeffs(int cg) {

@@ -14,12 +14,16 @@ namespace host {
 const std::vector<float>& srgb_inv_oetf_lut();  // 1024  (gainmapmath.cpp:126-131)
 const std::vector<float>& hlg_inv_oetf_lut();   // 4096  (gainmapmath.cpp:271-277)
 const std::vector<float>& pq_inv_oetf_lut();    // 4096  (gainmapmath.cpp:339-345)
+const std::vector<float>& hlg_inv_oetf_ootf_lut();  // 4096: hlgInvOetfLUT then hlgOotfApprox per node
 const std::vector<float>& hlg_oetf_lut();       // 65536 (gainmapmath.cpp:248-254)
 const std::vector<float>& pq_oetf_lut();        // 65536 (gainmapmath.cpp:320-326)
 
 // 10-bit output-code thresholds of the HLG / PQ tail (kOetfThrN floats; see host_tables.cpp)
 const std::vector<float>& oetf_code_thresholds(int ct);
 uint32_t oetf_code(int ct, float v);  // the composite itself, evaluated with the host libm
+
+// float64 tables of exact_math.h (table-driven pow / log2 of the encode path)
+const std::vector<double>& math_tables();
 
 Yuv2Rgb yuv2rgb_coeffs(int cg);  // gainmapmath.cpp:94,104-105 / 164,174-175 / 194,226-227
 Rgb2Yuv rgb2yuv_coeffs(int cg);

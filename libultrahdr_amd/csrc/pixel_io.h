@@ -7,14 +7,18 @@
 namespace uhdr {
 
 // Returns the pixel as the reference's Color: (y,u,v) for YCbCr formats, (r,g,b) for RGB ones.
+// FMT >= 0 fixes the format at compile time (the encode kernels are instantiated per format so the
+// switch folds away); FMT < 0 reads it from the view.
+template <int FMT = -1>
 __device__ __forceinline__ Color3 fetch_pixel(const ImageView& im, uint32_t x, uint32_t y) {
   Color3 c = {0.f, 0.f, 0.f};
-  switch (im.fmt) {
+  const int fmt_ = FMT >= 0 ? FMT : im.fmt;
+  switch (fmt_) {
     case UHDR_IMG_FMT_24bppYCbCr444:
     case UHDR_IMG_FMT_16bppYCbCr422:
     case UHDR_IMG_FMT_12bppYCbCr420: {
-      const uint32_t hf = im.fmt == UHDR_IMG_FMT_24bppYCbCr444 ? 1 : 2;
-      const uint32_t vf = im.fmt == UHDR_IMG_FMT_12bppYCbCr420 ? 2 : 1;
+      const uint32_t hf = fmt_ == UHDR_IMG_FMT_24bppYCbCr444 ? 1 : 2;
+      const uint32_t vf = fmt_ == UHDR_IMG_FMT_12bppYCbCr420 ? 2 : 1;
       const int yy = ((const uint8_t*)im.p[0])[x + (size_t)y * im.stride[0]];
       const int uu = ((const uint8_t*)im.p[1])[x / hf + (size_t)(y / vf) * im.stride[1]];
       const int vv = ((const uint8_t*)im.p[2])[x / hf + (size_t)(y / vf) * im.stride[2]];
@@ -29,7 +33,7 @@ __device__ __forceinline__ Color3 fetch_pixel(const ImageView& im, uint32_t x, u
     case UHDR_IMG_FMT_24bppYCbCrP010:
     case UHDR_IMG_FMT_30bppYCbCr444: {
       int yy, uu, vv;
-      if (im.fmt == UHDR_IMG_FMT_24bppYCbCrP010) {
+      if (fmt_ == UHDR_IMG_FMT_24bppYCbCrP010) {
         const uint16_t* yp = (const uint16_t*)im.p[0];
         const uint16_t* cp = (const uint16_t*)im.p[1];
         const size_t ui = (size_t)(y >> 1) * im.stride[1] + (x & ~1u);
@@ -86,14 +90,15 @@ __device__ __forceinline__ Color3 fetch_pixel(const ImageView& im, uint32_t x, u
 }
 
 // samplePixels: sum over the s x s box (dy outer, dx inner), then one divide per channel.
+template <int FMT = -1>
 __device__ __forceinline__ Color3 sample_box(const ImageView& im, uint32_t s, uint32_t x, uint32_t y) {
   if (s == 1) {  // e = 0 + p; e / 1.0f  == p bit for bit (0.0f + p == p, p / 1 == p)
-    return fetch_pixel(im, x, y);
+    return fetch_pixel<FMT>(im, x, y);
   }
   Color3 e = {0.0f, 0.0f, 0.0f};
   for (uint32_t dy = 0; dy < s; ++dy)
     for (uint32_t dx = 0; dx < s; ++dx) {
-      const Color3 q = fetch_pixel(im, x * s + dx, y * s + dy);
+      const Color3 q = fetch_pixel<FMT>(im, x * s + dx, y * s + dy);
       e.r += q.r;
       e.g += q.g;
       e.b += q.b;

@@ -4,6 +4,12 @@
 //
 // P010 -> YCbCr 4:2:0: one thread per 2x2 quad (chroma is the mean of the four converted pixels,
 // accumulated in (row, col) order like the reference).  Other formats: one thread per pixel.
+//
+// The kernels are instantiated per HDR format; the HDR linearisation table (inverse OETF with, for
+// HLG, hlgOotfApprox folded in by the host -- see generate_gainmap.hip) and the float64 tables
+// behind srgbOetf's pow (exact_math.h) are staged in LDS.  A workgroup walks tiles of 256
+// consecutive quads / pixels of one row.
+#include "exact_math.h"
 #include "pixel_io.h"
 #include "uhdr_types.h"
 
@@ -22,26 +28,32 @@ __device__ __forceinline__ uint32_t put8(float v) {  // put*Pixel: *255, +0.5, c
   v = (v < 0.0f) ? 0.0f : ((v > 255.0f) ? 255.0f : v);
   return (uint32_t)v;
 }
-// srgbOetf (gainmapmath.cpp:139-148): std::pow(float,float) => powf
-__device__ __forceinline__ float srgb_oetf(float e) {
-  if (e <= 0.0031308f) return 12.92f * e;
-  return (1.0f + 0.055f) * powf(e, 1.0f / 2.4f) - 0.055f;
+struct ToneLds {
+  float hdr[kInvOetfN];
+  double math[kMathTabDoubles];
+};
+__device__ __forceinline__ void stage_tables(const ToneMapParams& p, ToneLds& L) {
+  if (p.hdr_inv_lut)
+    for (uint32_t i = threadIdx.x; i < (uint32_t)p.hdr_inv_n; i += kBlock) L.hdr[i] = p.hdr_inv_lut[i];
+  for (uint32_t i = threadIdx.x; i < kMathTabDoubles; i += kBlock) L.math[i] = p.math_tab[i];
+  __syncthreads();
 }
 
 // one HDR pixel -> gamma-encoded Display-P3 SDR rgb
-__device__ __forceinline__ Color3 tone_map_pixel(const ToneMapParams& p, uint32_t x, uint32_t y) {
-  Color3 g = fetch_pixel(p.hdr, x, y);
+template <int HDRF>
+__device__ __forceinline__ Color3 tone_map_pixel(const ToneMapParams& p, const ToneLds& L, uint32_t x, uint32_t y) {
+  Color3 g = fetch_pixel<HDRF>(p.hdr, x, y);
   if (!p.hdr_is_rgb) g = yuv_to_rgb(g.r, g.g, g.b, p.hdr_yuv);
   Color3 l = g;
   if (p.hdr_inv_lut) {
     if (p.hdr_inv_n == kInvOetfN) {
-      l.r = p.hdr_inv_lut[lut_index_f64<kInvOetfN>(g.r)];
-      l.g = p.hdr_inv_lut[lut_index_f64<kInvOetfN>(g.g)];
-      l.b = p.hdr_inv_lut[lut_index_f64<kInvOetfN>(g.b)];
+      l.r = L.hdr[lut_index_f64<kInvOetfN>(g.r)];
+      l.g = L.hdr[lut_index_f64<kInvOetfN>(g.g)];
+      l.b = L.hdr[lut_index_f64<kInvOetfN>(g.b)];
     } else {
-      l.r = p.hdr_inv_lut[lut_index_f32<kSrgbN>(g.r)];
-      l.g = p.hdr_inv_lut[lut_index_f32<kSrgbN>(g.g)];
-      l.b = p.hdr_inv_lut[lut_index_f32<kSrgbN>(g.b)];
+      l.r = L.hdr[lut_index_f32<kSrgbN>(g.r)];
+      l.g = L.hdr[lut_index_f32<kSrgbN>(g.g)];
+      l.b = L.hdr[lut_index_f32<kSrgbN>(g.b)];
     }
   }
   if (p.hdr_is_hlg) {
@@ -63,25 +75,29 @@ __device__ __forceinline__ Color3 tone_map_pixel(const ToneMapParams& p, uint32_
   o.b = c2 > 0.0f ? c2 * ms / mx : 0.0f;
   if (p.gamut_on) o = mat3_apply(o, p.gamut);
   o.r = clamp01(o.r); o.g = clamp01(o.g); o.b = clamp01(o.b);
-  Color3 og = {srgb_oetf(o.r), srgb_oetf(o.g), srgb_oetf(o.b)};
+  // srgbOetf (gainmapmath.cpp:139-148) with the table pow of exact_math.h
+  Color3 og = {srgb_oetf_table(o.r, L.math), srgb_oetf_table(o.g, L.math), srgb_oetf_table(o.b, L.math)};
   return og;
 }
 
 __global__ __launch_bounds__(kBlock) void tonemap_p010_kernel(const ToneMapParams p) {
+  __shared__ ToneLds L;
+  stage_tables(p, L);
   const uint32_t qw = p.hdr.w / 2, qh = p.hdr.h / 2;
-  const size_t total = (size_t)qw * qh;
+  const uint32_t tiles_x = (qw + kBlock - 1) / kBlock, tiles = tiles_x * qh;
   uint8_t* yp = (uint8_t*)p.sdr.p[0];
   uint8_t* up = (uint8_t*)p.sdr.p[1];
   uint8_t* vp = (uint8_t*)p.sdr.p[2];
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
-    const uint32_t qy = (uint32_t)(i / qw), qx = (uint32_t)(i - (size_t)qy * qw);
+  for (uint32_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const uint32_t qy = t / tiles_x, qx = (t - qy * tiles_x) * kBlock + threadIdx.x;
+    if (qx >= qw) continue;
     float su = 0.0f, sv = 0.0f;
     uint32_t yb[2][2];
 #pragma unroll
     for (int r = 0; r < 2; r++)
 #pragma unroll
       for (int c = 0; c < 2; c++) {
-        Color3 og = tone_map_pixel(p, qx * 2 + c, qy * 2 + r);
+        Color3 og = tone_map_pixel<UHDR_IMG_FMT_24bppYCbCrP010>(p, L, qx * 2 + c, qy * 2 + r);
         Color3 yuv = rgb_to_yuv(og, p.p3);
         yuv.g += 0.5f;
         yuv.b += 0.5f;
@@ -92,21 +108,29 @@ __global__ __launch_bounds__(kBlock) void tonemap_p010_kernel(const ToneMapParam
     su /= 4.0f;
     sv /= 4.0f;
     const size_t sy = p.sdr.stride[0];
-    yp[(size_t)(qy * 2) * sy + qx * 2] = (uint8_t)yb[0][0];
-    yp[(size_t)(qy * 2) * sy + qx * 2 + 1] = (uint8_t)yb[0][1];
-    yp[(size_t)(qy * 2 + 1) * sy + qx * 2] = (uint8_t)yb[1][0];
-    yp[(size_t)(qy * 2 + 1) * sy + qx * 2 + 1] = (uint8_t)yb[1][1];
+    uint8_t* y0 = yp + (size_t)(qy * 2) * sy + qx * 2;
+    if (((sy | (uintptr_t)yp) & 1) == 0) {  // two luma bytes per row as one 16-bit store
+      *(uint16_t*)y0 = (uint16_t)(yb[0][0] | (yb[0][1] << 8));
+      *(uint16_t*)(y0 + sy) = (uint16_t)(yb[1][0] | (yb[1][1] << 8));
+    } else {
+      y0[0] = (uint8_t)yb[0][0]; y0[1] = (uint8_t)yb[0][1];
+      y0[sy] = (uint8_t)yb[1][0]; y0[sy + 1] = (uint8_t)yb[1][1];
+    }
     up[(size_t)qy * p.sdr.stride[1] + qx] = scale_to_8bit(su);
     vp[(size_t)qy * p.sdr.stride[2] + qx] = scale_to_8bit(sv);
   }
 }
 
+template <int HDRF>
 __global__ __launch_bounds__(kBlock) void tonemap_pixel_kernel(const ToneMapParams p) {
+  __shared__ ToneLds L;
+  stage_tables(p, L);
   const uint32_t w = p.hdr.w, h = p.hdr.h;
-  const size_t total = (size_t)w * h;
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
-    const uint32_t y = (uint32_t)(i / w), x = (uint32_t)(i - (size_t)y * w);
-    const Color3 og = tone_map_pixel(p, x, y);
+  const uint32_t tiles_x = (w + kBlock - 1) / kBlock, tiles = tiles_x * h;
+  for (uint32_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const uint32_t y = t / tiles_x, x = (t - y * tiles_x) * kBlock + threadIdx.x;
+    if (x >= w) continue;
+    const Color3 og = tone_map_pixel<HDRF>(p, L, x, y);
     if (p.sdr.fmt == UHDR_IMG_FMT_32bppRGBA8888) {  // putRgba8888Pixel (gainmapmath.cpp:538-552)
       ((uint32_t*)p.sdr.p[0])[x + (size_t)y * p.sdr.stride[0]] =
           put8(og.r) | (put8(og.g) << 8) | (put8(og.b) << 16) | (255u << 24);
@@ -121,17 +145,37 @@ __global__ __launch_bounds__(kBlock) void tonemap_pixel_kernel(const ToneMapPara
   }
 }
 
+int tone_grid(uint32_t tiles) {
+  static const int resident = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 1024;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    return cus * 8;  // 19 KB of LDS tables per workgroup: eight fit in a CU's 160 KB
+  }();
+  const uint32_t g = tiles < (uint32_t)resident ? tiles : (uint32_t)resident;
+  return (int)(g < 1 ? 1 : g);
+}
+
 }  // namespace
 
 hipError_t launch_tone_map(const ToneMapParams& p, hipStream_t s) {
   if (p.hdr.fmt == UHDR_IMG_FMT_24bppYCbCrP010) {
-    size_t total = (size_t)(p.hdr.w / 2) * (p.hdr.h / 2);
-    int grid = (int)min((total + kBlock - 1) / kBlock, (size_t)4096);
-    hipLaunchKernelGGL(tonemap_p010_kernel, dim3(max(grid, 1)), dim3(kBlock), 0, s, p);
+    const uint32_t qw = p.hdr.w / 2, qh = p.hdr.h / 2;
+    const int grid = tone_grid(((qw + kBlock - 1) / kBlock) * qh);
+    hipLaunchKernelGGL(tonemap_p010_kernel, dim3(grid), dim3(kBlock), 0, s, p);
   } else {
-    size_t total = (size_t)p.hdr.w * p.hdr.h;
-    int grid = (int)min((total + kBlock - 1) / kBlock, (size_t)4096);
-    hipLaunchKernelGGL(tonemap_pixel_kernel, dim3(max(grid, 1)), dim3(kBlock), 0, s, p);
+    const int grid = tone_grid(((p.hdr.w + kBlock - 1) / kBlock) * p.hdr.h);
+    switch (p.hdr.fmt) {
+      case UHDR_IMG_FMT_32bppRGBA1010102:
+        hipLaunchKernelGGL((tonemap_pixel_kernel<UHDR_IMG_FMT_32bppRGBA1010102>), dim3(grid), dim3(kBlock), 0, s, p);
+        break;
+      case UHDR_IMG_FMT_64bppRGBAHalfFloat:
+        hipLaunchKernelGGL((tonemap_pixel_kernel<UHDR_IMG_FMT_64bppRGBAHalfFloat>), dim3(grid), dim3(kBlock), 0, s, p);
+        break;
+      default:
+        hipLaunchKernelGGL((tonemap_pixel_kernel<-1>), dim3(grid), dim3(kBlock), 0, s, p);
+        break;
+    }
   }
   return hipGetLastError();
 }

@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 
+#include "exact_math.h"
 #include "host_tables.h"
 #include "uhdr_types.h"
 
@@ -75,6 +76,8 @@ struct uhdr_hip_ctx {
   float* d_pq_inv = nullptr;
   float* d_hlg_oetf = nullptr;
   float* d_pq_oetf = nullptr;
+  float* d_hlg_inv_ootf = nullptr;  // hlgInvOetfLUT followed by hlgOotfApprox, per table node
+  double* d_math = nullptr;         // exact_math.h tables
   // per-call apply tables: ring of pinned host slots + matching device slots
   float* h_tab[kTableSlots] = {};
   float* d_tab[kTableSlots] = {};
@@ -217,11 +220,39 @@ uhdr_error_info_t stage_out(uhdr_hip_ctx* c, const uhdr_raw_image_t* dev, uhdr_r
   return ok_status();
 }
 
+uhdr_error_info_t upload_lut(float** dst, const std::vector<float>& src, hipStream_t s);
+uhdr_error_info_t upload_math(uhdr_hip_ctx* c);
+// Linearisation table of an HDR input for the encode kernels: inverse OETF with, for HLG, the
+// per-channel OOTF (hlgOotfApprox, gainmapmath.cpp:293-295) folded in node by node.
+uhdr_error_info_t select_hdr_lut(uhdr_hip_ctx* c, uhdr_color_transfer_t ct, const float** lut, int* n);
+
 uhdr_error_info_t upload_lut(float** dst, const std::vector<float>& src, hipStream_t s) {
   if (*dst) return ok_status();
   HIP_TRY(hipMalloc((void**)dst, src.size() * sizeof(float)));
   HIP_TRY(hipMemcpyAsync(*dst, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice, s));
   HIP_TRY(hipStreamSynchronize(s));
+  return ok_status();
+}
+uhdr_error_info_t upload_math(uhdr_hip_ctx* c) {
+  if (c->d_math) return ok_status();
+  const std::vector<double>& t = host::math_tables();
+  HIP_TRY(hipMalloc((void**)&c->d_math, t.size() * sizeof(double)));
+  HIP_TRY(hipMemcpyAsync(c->d_math, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return ok_status();
+}
+uhdr_error_info_t select_hdr_lut(uhdr_hip_ctx* c, uhdr_color_transfer_t ct, const float** lut, int* n) {
+  *lut = nullptr;
+  *n = 0;
+  if (ct == UHDR_CT_HLG) {
+    UHDR_TRY(upload_lut(&c->d_hlg_inv_ootf, host::hlg_inv_oetf_ootf_lut(), c->stream));
+    *lut = c->d_hlg_inv_ootf; *n = kInvOetfN;
+  } else if (ct == UHDR_CT_PQ) {
+    UHDR_TRY(upload_lut(&c->d_pq_inv, host::pq_inv_oetf_lut(), c->stream));
+    *lut = c->d_pq_inv; *n = kInvOetfN;
+  } else if (ct == UHDR_CT_SRGB) {
+    *lut = c->d_srgb; *n = kSrgbN;
+  }
   return ok_status();
 }
 
@@ -375,7 +406,7 @@ void uhdr_hip_destroy(uhdr_hip_ctx_t* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (auto& e : c->prof_entries) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-  float* luts[] = {c->d_srgb, c->d_hlg_inv, c->d_pq_inv, c->d_hlg_oetf, c->d_pq_oetf};
+  float* luts[] = {c->d_srgb, c->d_hlg_inv, c->d_pq_inv, c->d_hlg_oetf, c->d_pq_oetf, c->d_hlg_inv_ootf, (float*)c->d_math};
   for (float* p : luts) if (p) (void)hipFree(p);
   for (int i = 0; i < kTableSlots; i++) {
     if (c->h_tab[i]) (void)hipHostFree(c->h_tab[i]);
@@ -656,16 +687,10 @@ static uhdr_error_info_t fill_gen_params(uhdr_hip_ctx* c, const uhdr_raw_image_t
   }
   p->scale = scale; p->map_w = mw; p->map_h = mh;
   p->srgb_lut = c->d_srgb;
-  p->hdr_is_hlg = hdr->ct == UHDR_CT_HLG;
-  if (hdr->ct == UHDR_CT_HLG) {
-    UHDR_TRY(upload_lut(&c->d_hlg_inv, host::hlg_inv_oetf_lut(), c->stream));
-    p->hdr_inv_lut = c->d_hlg_inv; p->hdr_inv_n = kInvOetfN;
-  } else if (hdr->ct == UHDR_CT_PQ) {
-    UHDR_TRY(upload_lut(&c->d_pq_inv, host::pq_inv_oetf_lut(), c->stream));
-    p->hdr_inv_lut = c->d_pq_inv; p->hdr_inv_n = kInvOetfN;
-  } else if (hdr->ct == UHDR_CT_SRGB) {
-    p->hdr_inv_lut = c->d_srgb; p->hdr_inv_n = kSrgbN;
-  }
+  p->hdr_is_hlg = 0;  // hlgOotfApprox is folded into the table
+  UHDR_TRY(select_hdr_lut(c, hdr->ct, &p->hdr_inv_lut, &p->hdr_inv_n));
+  UHDR_TRY(upload_math(c));
+  p->math_tab = c->d_math;
   p->sdr_is_rgb = is_rgb_fmt_host(sdr->fmt);
   p->hdr_is_rgb = is_rgb_fmt_host(hdr->fmt);
   p->multichannel = cfg->use_multi_channel_gainmap != 0;
@@ -780,6 +805,8 @@ uhdr_error_info_t uhdr_hip_generate_gainmap_dev(uhdr_hip_ctx_t* c, const uhdr_ra
     p.max_boost = md->max_content_boost[0];
     p.log2min = log2f(md->min_content_boost[0]);
     p.log2max = log2f(md->max_content_boost[0]);
+    p.log2_range = (double)(p.log2max - p.log2min);
+    p.log2_range_rcp = 1.0 / p.log2_range;
     p.out = (uint8_t*)gm->planes[0];
     p.out_stride = gm->stride[0];
     ProfScope ps(c, "generate_gainmap");
@@ -872,16 +899,10 @@ uhdr_error_info_t uhdr_hip_tone_map_dev(uhdr_hip_ctx_t* c, const uhdr_raw_image_
   memset(&p, 0, sizeof p);
   p.hdr = view_of(hdr);
   p.sdr = view_mut_of(sdr);
-  if (hdr->ct == UHDR_CT_HLG) {
-    UHDR_TRY(upload_lut(&c->d_hlg_inv, host::hlg_inv_oetf_lut(), c->stream));
-    p.hdr_inv_lut = c->d_hlg_inv; p.hdr_inv_n = kInvOetfN;
-  } else if (hdr->ct == UHDR_CT_PQ) {
-    UHDR_TRY(upload_lut(&c->d_pq_inv, host::pq_inv_oetf_lut(), c->stream));
-    p.hdr_inv_lut = c->d_pq_inv; p.hdr_inv_n = kInvOetfN;
-  } else if (hdr->ct == UHDR_CT_SRGB) {
-    p.hdr_inv_lut = c->d_srgb; p.hdr_inv_n = kSrgbN;
-  }
-  p.hdr_is_hlg = hdr->ct == UHDR_CT_HLG;
+  UHDR_TRY(select_hdr_lut(c, hdr->ct, &p.hdr_inv_lut, &p.hdr_inv_n));
+  UHDR_TRY(upload_math(c));
+  p.math_tab = c->d_math;
+  p.hdr_is_hlg = 0;  // hlgOotfApprox is folded into the table
   p.hdr_is_rgb = is_rgb_fmt_host(hdr->fmt);
   p.is_normalized = hdr->ct != UHDR_CT_LINEAR;
   p.headroom = host::reference_peak_nits(hdr->ct) / 203.0f;
@@ -988,6 +1009,13 @@ int uhdr_hip_oetf_code_thresholds(uhdr_color_transfer_t ct, float thresholds[102
   if ((ct != UHDR_CT_HLG && ct != UHDR_CT_PQ) || !thresholds) return -1;
   const std::vector<float>& t = host::oetf_code_thresholds(ct);
   for (int i = 0; i < 1024; i++) thresholds[i] = t[(size_t)i];
+  return 0;
+}
+
+int uhdr_hip_exact_math_eval(int fn, const float* in, float* out, size_t n) {
+  if (!in || !out || (fn != 0 && fn != 1)) return -1;
+  const double* T = host::math_tables().data();
+  for (size_t i = 0; i < n; i++) out[i] = fn == 0 ? srgb_oetf_table(in[i], T) : (float)log2_table_f64(in[i], T);
   return 0;
 }
 

@@ -89,9 +89,10 @@ struct GenParams {
   ImageView sdr, hdr;
   uint32_t map_w, map_h, scale;
   const float* srgb_lut;     // 1024
-  const float* hdr_inv_lut;  // 4096 (HLG / PQ) or 1024 (sRGB) or null (linear)
+  const float* hdr_inv_lut;  // 4096 (HLG with the OOTF folded in / PQ) or 1024 (sRGB) or null (linear)
   int hdr_inv_n;
-  int hdr_is_hlg;
+  int hdr_is_hlg;            // apply hlgOotfApprox per pixel (0 when the table already contains it)
+  const double* math_tab;    // exact_math.h tables (kMathTabDoubles)
   int sdr_is_rgb, hdr_is_rgb;
   int sdr_gamut_on, hdr_gamut_on;
   Mat3 sdr_gamut, hdr_gamut;
@@ -101,6 +102,7 @@ struct GenParams {
   float hdr_nits;            // hdrSampleToNitsFactor
   // one pass
   float min_boost, max_boost, log2min, log2max, gamma;
+  double log2_range, log2_range_rcp;  // (double)(log2max - log2min) and its reciprocal
   uint8_t* out;              // map bytes
   uint32_t out_stride;       // pixels
   // two pass
@@ -120,8 +122,9 @@ struct AffineParams {
 struct ToneMapParams {
   ImageView hdr;
   ImageViewMut sdr;
-  const float* hdr_inv_lut;
+  const float* hdr_inv_lut;  // as in GenParams
   int hdr_inv_n;
+  const double* math_tab;    // exact_math.h tables (kMathTabDoubles)
   int hdr_is_hlg, hdr_is_rgb, is_normalized;
   float headroom;
   int gamut_on;

@@ -135,7 +135,8 @@ def ref():
 
 # ---- convenience wrappers shared by tests / smoke / bench ---------------------------------------
 FN = dict(srgb_inv=0, srgb_inv_lut=1, srgb_oetf=2, hlg_oetf=3, hlg_oetf_lut=4, hlg_inv=5, hlg_inv_lut=6,
-          pq_oetf=7, pq_oetf_lut=8, pq_inv=9, pq_inv_lut=10, half_to_float=11, hlg_ootf=12, hlg_inv_ootf=13)
+          pq_oetf=7, pq_oetf_lut=8, pq_inv=9, pq_inv_lut=10, half_to_float=11, hlg_ootf=12, hlg_inv_ootf=13,
+          log2_f64=14)  # 14: port only ((float)log2((double)x), the encodeGain / computeGain call)
 
 
 def eval_fn(lib, pfx, name, x):

@@ -1214,6 +1214,7 @@ int uo_eval(int fn, const float* in, float* out, size_t n) {
       case 11: out[i] = half_to_float((uint16_t)x); break;
       case 12: out[i] = powf(x, 1.2f); break;
       case 13: out[i] = powf(x, 1.0f / 1.2f); break;
+      case 14: out[i] = (float)log2((double)x); break; /* encodeGain / computeGain's log2 (gainmapmath.cpp:767, 774) */
       default: return -1;
     }
   }

@@ -1,0 +1,73 @@
+"""The encode kernels' table-driven float64 pow / log2 (csrc/exact_math.h) against the reference's
+libm calls, evaluated on the HOST through the C ABI (same source as the device code; float64
+mul/add/fma are IEEE on both sides).  No GPU needed."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from libultrahdr_amd import capi as A
+from oracle import loader as O
+
+
+def _eval_product(fn, x):
+    lib = A.load()
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty_like(x)
+    assert lib.uhdr_hip_exact_math_eval(fn, x.ctypes.data_as(C.POINTER(C.c_float)),
+                                        out.ctypes.data_as(C.POINTER(C.c_float)), x.size) == 0
+    return out
+
+
+def _floats_between(lo, hi, step):
+    lo_b = np.float32(lo).view(np.uint32)
+    hi_b = np.float32(hi).view(np.uint32)
+    return np.arange(int(lo_b), int(hi_b) + 1, step, dtype=np.uint32).view(np.float32)
+
+
+def test_srgb_oetf_matches_powf_over_the_whole_domain():
+    # every 61st float of [0, 1] plus the neighbourhood of the branch point and both ends
+    xs = np.concatenate([_floats_between(0.0, 1.0, 61), _floats_between(0.0031300, 0.0031320, 1),
+                         _floats_between(0.99999, 1.0, 1), np.float32([0.0, 1.0, 0.5, 0.0031308])])
+    got = _eval_product(0, xs)
+    want = O.eval_fn(O.port(), "uo_", "srgb_oetf", xs)
+    bad = got.view(np.uint32) != want.view(np.uint32)
+    # glibc's powf is faithfully, not correctly, rounded (and is an ifunc: its FMA and SSE2 variants
+    # need not agree with each other); the table pow is correctly rounded.  Measured here: they
+    # differ on ~5.5e-4 of the inputs of the pow branch, by one ulp of the power, and wherever they differ
+    # the table value is the correctly rounded one (checked against 80-bit long double pow).
+    assert bad.sum() < 2e-3 * np.count_nonzero(xs > np.float32(0.0031308)), f"{bad.sum()} of {xs.size} differ"
+    if bad.any():
+        # one ulp of the pow result; 1.055 * pow - 0.055 is up to ~3x smaller than pow, so up to 4 of its ulps
+        d = np.abs(got[bad].view(np.int32).astype(np.int64) - want[bad].view(np.int32).astype(np.int64))
+        assert d.max() <= 4
+        p = np.longdouble(np.float32(1.0) / np.float32(2.4))
+        cr_pow = (xs[bad].astype(np.longdouble) ** p).astype(np.float32)
+        cr = ((np.float32(1.0) + np.float32(0.055)) * cr_pow - np.float32(0.055)).astype(np.float32)
+        assert np.array_equal(got[bad].view(np.uint32), cr.view(np.uint32))
+    # ... and the 8-bit codes the tone mapper stores (put8 / ScaleTo8Bit of the value) agree
+    q = lambda v: np.clip(np.floor(v * np.float32(255.0) + np.float32(0.5)), 0, 255).astype(np.uint8)
+    assert np.count_nonzero(q(got) != q(want)) <= 2
+
+
+def test_log2_matches_double_log2_narrowed_to_float():
+    rng = np.random.default_rng(7)
+    xs = np.concatenate([
+        _floats_between(1e-10, 1e12, 97),                       # the range computeGain's ratio can take
+        _floats_between(0.9999, 1.0001, 1),                     # cancellation region around 1
+        np.exp2(rng.uniform(-30, 40, 200000)).astype(np.float32),
+        np.float32([1.0, 2.0, 0.5, 4.926108, 49.26108]),
+    ])
+    got = _eval_product(1, xs)
+    want = O.eval_fn(O.port(), "uo_", "log2_f64", xs)
+    bad = got.view(np.uint32) != want.view(np.uint32)
+    assert bad.mean() < 1e-6, f"{bad.sum()} of {xs.size} differ"
+    if bad.any():
+        d = np.abs(got[bad].view(np.int32).astype(np.int64) - want[bad].view(np.int32).astype(np.int64))
+        assert d.max() <= 1
+
+
+def test_unknown_function_is_rejected():
+    lib = A.load()
+    x = np.zeros(1, np.float32)
+    assert lib.uhdr_hip_exact_math_eval(9, x.ctypes.data_as(C.POINTER(C.c_float)), x.ctypes.data_as(C.POINTER(C.c_float)), 1) == -1
