@@ -175,6 +175,9 @@ def main():
     algo_b = algo_bytes_per_px(args.map) * w * h * frames_per_launch
     achieved = algo_b / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
 
+    kernel_name = "apply_quad_kernel<F16," + {"A": "Y400,scale4>", "B": "RGB888,scale1>", "C": "RGBA8888,scale1>"}[args.map]
+    traffic, traffic_src = measured_traffic(f"{kernel_name}|{frames_per_launch}x{w}x{h}")
+
     out = {
         "metric": "Mpixels/s decode (applyGainMap, YCbCr420 + gain map -> RGBA_F16 linear), 4K frames resident in HBM",
         "value": round(value, 1),
@@ -197,13 +200,14 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "apply_quad_kernel<F16," + {"A": "Y400,scale4>", "B": "RGB888,scale1>", "C": "RGBA8888,scale1>"}[args.map],
+            "kernel": kernel_name,
             "frames_per_launch": frames_per_launch,
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None,
+            "traffic": traffic,  # HBM bytes per launch from the PMC counters of a separate rocprofv3 pass (None: not profiled)
+            "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": int(algo_b),
             "avg_launch_us": round(avg_launch_s * 1e6, 3),
             "launches_timed": n_launch,
@@ -219,6 +223,21 @@ def main():
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def measured_traffic(key):
+    """HBM bytes per launch of the dominant kernel as measured with rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE (their own passes, MI355X_MICROARCH.md's gfx950 correction applied) on this exact bench
+    configuration; committed next to the rocprof summaries in profiles/traffic.json."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            e = json.load(f).get(key)
+    except (OSError, ValueError):
+        e = None
+    if not e:
+        return None, None
+    return e["traffic_bytes_per_launch"], e["source"]
 
 
 def extras(ctx, u, device):

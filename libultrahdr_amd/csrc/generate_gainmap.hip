@@ -90,9 +90,6 @@ __global__ __launch_bounds__(kBlock) void generate_kernel(const GenParams p, flo
         hl.b = L.hdr[lut_index_f32<kSrgbN>(h.b)];
       }
     }
-    if (p.hdr_is_hlg) {  // hlgOotfApprox (gainmapmath.cpp:293-295) when the host did not fold it into the table
-      hl.r = powf(hl.r, 1.2f); hl.g = powf(hl.g, 1.2f); hl.b = powf(hl.b, 1.2f);
-    }
     if (p.hdr_gamut_on) hl = mat3_apply(hl, p.hdr_gamut);
     hl.r = clip_neg(hl.r); hl.g = clip_neg(hl.g); hl.b = clip_neg(hl.b);
 

@@ -56,9 +56,6 @@ __device__ __forceinline__ Color3 tone_map_pixel(const ToneMapParams& p, const T
       l.b = L.hdr[lut_index_f32<kSrgbN>(g.b)];
     }
   }
-  if (p.hdr_is_hlg) {
-    l.r = powf(l.r, 1.2f); l.g = powf(l.g, 1.2f); l.b = powf(l.b, 1.2f);
-  }
   // globalTonemap (jpegr.cpp:1951-1977)
   float c0 = l.r, c1 = l.g, c2 = l.b;
   const float hr = p.headroom;

@@ -687,7 +687,6 @@ static uhdr_error_info_t fill_gen_params(uhdr_hip_ctx* c, const uhdr_raw_image_t
   }
   p->scale = scale; p->map_w = mw; p->map_h = mh;
   p->srgb_lut = c->d_srgb;
-  p->hdr_is_hlg = 0;  // hlgOotfApprox is folded into the table
   UHDR_TRY(select_hdr_lut(c, hdr->ct, &p->hdr_inv_lut, &p->hdr_inv_n));
   UHDR_TRY(upload_math(c));
   p->math_tab = c->d_math;
@@ -902,7 +901,6 @@ uhdr_error_info_t uhdr_hip_tone_map_dev(uhdr_hip_ctx_t* c, const uhdr_raw_image_
   UHDR_TRY(select_hdr_lut(c, hdr->ct, &p.hdr_inv_lut, &p.hdr_inv_n));
   UHDR_TRY(upload_math(c));
   p.math_tab = c->d_math;
-  p.hdr_is_hlg = 0;  // hlgOotfApprox is folded into the table
   p.hdr_is_rgb = is_rgb_fmt_host(hdr->fmt);
   p.is_normalized = hdr->ct != UHDR_CT_LINEAR;
   p.headroom = host::reference_peak_nits(hdr->ct) / 203.0f;

@@ -91,7 +91,6 @@ struct GenParams {
   const float* srgb_lut;     // 1024
   const float* hdr_inv_lut;  // 4096 (HLG with the OOTF folded in / PQ) or 1024 (sRGB) or null (linear)
   int hdr_inv_n;
-  int hdr_is_hlg;            // apply hlgOotfApprox per pixel (0 when the table already contains it)
   const double* math_tab;    // exact_math.h tables (kMathTabDoubles)
   int sdr_is_rgb, hdr_is_rgb;
   int sdr_gamut_on, hdr_gamut_on;
@@ -125,7 +124,7 @@ struct ToneMapParams {
   const float* hdr_inv_lut;  // as in GenParams
   int hdr_inv_n;
   const double* math_tab;    // exact_math.h tables (kMathTabDoubles)
-  int hdr_is_hlg, hdr_is_rgb, is_normalized;
+  int hdr_is_rgb, is_normalized;
   float headroom;
   int gamut_on;
   Mat3 gamut;      // P3 <- hdr gamut

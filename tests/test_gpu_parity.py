@@ -227,7 +227,11 @@ def _uhdr_for(hip_ctx, cfg):
 @pytest.mark.parametrize("hdr_kw,sdr_kind,cfg_kw", GEN_CASES)
 @pytest.mark.parametrize("device", [False, True])
 def test_generate_gainmap(hip_ctx, hdr_kw, sdr_kind, cfg_kw, device):
-    """log2/powf per sample: +-1 map code on <= 1% of samples; metadata within 1e-5 relative."""
+    """The per-sample double log2 runs on float64 tables (csrc/exact_math.h) whose result is the
+    correctly rounded float in all but ~1e-8 of the cases, HLG's powf is folded into a host-built
+    table: measured bit-identical to the real reference on every case at 1280x720
+    (tools/parity_stats.py).  Allowed here: +-1 map code on <= 1e-4 of the samples (gamma != 1 keeps a
+    device powf per sample); metadata within 1e-6 relative."""
     sdr, hdr = _pair(256, 128, hdr_kw, sdr_kind)
     cfg = A.default_encode_cfg(**cfg_kw)
     md_w, gm_w = L.generate_gainmap(oracle_kind(), sdr, hdr, cfg)
@@ -240,10 +244,10 @@ def test_generate_gainmap(hip_ctx, hdr_kw, sdr_kind, cfg_kw, device):
         md_g, gm_g = u.generateGainMap(sdr, hdr, bool(cfg.sdr_is_601), bool(cfg.use_luminance))
     assert (gm_g.raw.fmt, gm_g.raw.w, gm_g.raw.h) == (gm_w.raw.fmt, gm_w.raw.w, gm_w.raw.h)
     assert (gm_g.raw.cg, gm_g.raw.ct, gm_g.raw.range) == (gm_w.raw.cg, gm_w.raw.ct, gm_w.raw.range)
-    assert_close_codes(gm_g.valid(0), gm_w.valid(0), 1, 0.01, "gain map")
+    assert_close_codes(gm_g.valid(0), gm_w.valid(0), 1, 1e-4, "gain map")
     dg, dw = md_g.as_dict(), md_w.as_dict()
     for k in dw:
-        assert np.allclose(dg[k], dw[k], rtol=1e-5, atol=0), (k, dg[k], dw[k])
+        assert np.allclose(dg[k], dw[k], rtol=1e-6, atol=0), (k, dg[k], dw[k])
 
 
 def test_generate_then_apply_roundtrip_full_size(uhdr, hip_ctx):
@@ -287,7 +291,10 @@ def test_generate_then_apply_roundtrip_full_size(uhdr, hip_ctx):
                                         ("1010102", A.UHDR_CT_PQ, A.UHDR_CG_BT_2100), ("1010102", A.UHDR_CT_HLG, A.UHDR_CG_BT_709),
                                         ("p010", A.UHDR_CT_LINEAR, A.UHDR_CG_BT_2100)])
 def test_tone_map(uhdr, kind, ct, cg):
-    """srgbOetf is powf per channel: +-1 code on <= 1% of samples."""
+    """srgbOetf's powf runs on float64 tables (correctly rounded; glibc's powf is faithfully rounded and
+    differs from that by one ulp on ~5e-4 of its inputs, which moves an 8-bit code about once per 1e7
+    samples); HLG's OOTF powf is folded into a host-built table.  Measured bit-identical to the real
+    reference on every case at 1280x720 (tools/parity_stats.py).  Allowed: +-1 code on <= 1e-4 of samples."""
     w, h = 256, 128
     hdr = synth.make_hdr_p010(w, h, ct=ct, cg=cg) if kind == "p010" else synth.make_hdr_rgba1010102(w, h, ct=ct, cg=cg)
     want = L.tone_map(oracle_kind(), hdr)
@@ -297,7 +304,7 @@ def test_tone_map(uhdr, kind, ct, cg):
     for pg, pw in zip(got.planes_valid(), want.planes_valid()):
         if pg.dtype == np.uint32:
             pg, pw = pg.view(np.uint8), pw.view(np.uint8)
-        assert_close_codes(pg, pw, 1, 0.01, "tone map")
+        assert_close_codes(pg, pw, 1, 1e-4, "tone map")
     dgot = Image(want.fmt, w, h, align=64, device="cuda:0")
     uhdr.toneMap(hdr.to("cuda:0"), dgot)
     uhdr.ctx.synchronize()
