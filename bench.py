@@ -98,21 +98,26 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # UHDR_BENCH_DIST_BACKEND=gloo lets the N>1 code path be smoke-tested on a box with fewer GPUs than
+    # ranks (ranks then share devices; timing of such a run is meaningless).  Default: RCCL, one GPU per rank.
+    backend = os.environ.get("UHDR_BENCH_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
-    else:
-        torch.cuda.set_device(local_rank)
-    device = f"cuda:{local_rank}"
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{dev_index}"))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    device = f"cuda:{dev_index}"
 
     from libultrahdr_amd import capi as A
     from libultrahdr_amd import synth
     from libultrahdr_amd.images import Image
     from libultrahdr_amd.ultrahdr import Context, UltraHdr
 
-    ctx = Context(local_rank)
+    ctx = Context(dev_index)
     u = UltraHdr(ctx=ctx)
     f16 = A.UHDR_IMG_FMT_64bppRGBAHalfFloat
     w, h = args.width, args.height
@@ -164,7 +169,7 @@ def main():
     ctx.profile(False)
     elapsed = t1 - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

@@ -243,6 +243,37 @@ uhdr_error_info_t uhdr_hip_fdct_quant_dev(uhdr_hip_ctx_t* ctx, const uint8_t* pl
                                           int blocks_w, int blocks_h, const uint16_t qtable[64],
                                           int16_t* coef);
 
+/* ---- JPEG decode stage (the step immediately before applyGainMap) ---------------
+ * Inverse of uhdr_hip_fdct_quant: dequantize + libjpeg's JDCT_ISLOW 8x8 inverse DCT + range limit of
+ * coefficient blocks as jpeg_read_coefficients() yields them (JBLOCK layout, raster block order), so that
+ * only the Huffman decode stays on the CPU and the 8-bit planes JpegDecoderHelper::decompressImage
+ * (jpegdecoderhelper.cpp:169-535, dct_method = JDCT_ISLOW at :283) would produce never visit host memory.
+ * Writes blocks_w*8 x blocks_h*8 samples (plane must have room for the block padding).  coef must be
+ * 16-byte aligned.  Host (no suffix) or device (_dev) pointers. */
+uhdr_error_info_t uhdr_hip_idct_dequant(uhdr_hip_ctx_t* ctx, const int16_t* coef, int blocks_w,
+                                        int blocks_h, const uint16_t qtable[64], uint8_t* plane,
+                                        size_t stride);
+uhdr_error_info_t uhdr_hip_idct_dequant_dev(uhdr_hip_ctx_t* ctx, const int16_t* coef, int blocks_w,
+                                            int blocks_h, const uint16_t qtable[64], uint8_t* plane,
+                                            size_t stride);
+/* libjpeg's colour conversions around a 3-channel gain map.  rgb_to_ycc = jccolor.c rgb_ycc_convert,
+ * what jpeg_write_scanlines applies when the encoder hands the map over as JCS_RGB
+ * (jpegencoderhelper.cpp:165-167, 212-225): src UHDR_IMG_FMT_24bppRGB888 or 32bppRGBA8888 (alpha
+ * ignored), dst UHDR_IMG_FMT_24bppYCbCr444 planes for uhdr_hip_fdct_quant.  ycc_to_rgb = jdcolor.c
+ * ycc_rgb_convert, what jpeg_read_scanlines applies when the decoder asks for RGB / RGBA output
+ * (jpegdecoderhelper.cpp:400-470): src 24bppYCbCr444, dst RGB888 or RGBA8888 (alpha 255).
+ * libjpeg_variant selects the green-channel constants: 0 = libjpeg 6b / libjpeg-turbo (0.71414,
+ * 0.34414; the reference pins libjpeg-turbo), 1 = IJG 9 (0.714136286, 0.344136286); they differ for 59
+ * of the 65536 (Cb, Cr) pairs.  rgb_to_ycc has no variant: both constant sets give identical bytes. */
+uhdr_error_info_t uhdr_hip_jpeg_rgb_to_ycc(uhdr_hip_ctx_t* ctx, const uhdr_raw_image_t* rgb,
+                                           uhdr_raw_image_t* ycc);
+uhdr_error_info_t uhdr_hip_jpeg_rgb_to_ycc_dev(uhdr_hip_ctx_t* ctx, const uhdr_raw_image_t* rgb,
+                                               uhdr_raw_image_t* ycc);
+uhdr_error_info_t uhdr_hip_jpeg_ycc_to_rgb(uhdr_hip_ctx_t* ctx, const uhdr_raw_image_t* ycc,
+                                           int libjpeg_variant, uhdr_raw_image_t* rgb);
+uhdr_error_info_t uhdr_hip_jpeg_ycc_to_rgb_dev(uhdr_hip_ctx_t* ctx, const uhdr_raw_image_t* ycc,
+                                               int libjpeg_variant, uhdr_raw_image_t* rgb);
+
 /* ---- timing hook for bench.py ------------------------------------------------------------------
  * HIP events recorded on the context's stream around every kernel launch of the named family
  * ("apply_gainmap", "generate_gainmap", ...) since the last reset; returns the number of launches

@@ -14,7 +14,11 @@
 // the quantizer run with lane = (block, column), and a second LDS transpose lets every lane emit
 // one coefficient ROW (8 x int16 = 16 bytes), so a wave writes 1 KiB contiguous in libjpeg's
 // JBLOCK order.  The quantizer divides by multiplying with ceil(2^32 / q) (exact for the 19-bit
-// magnitudes that occur; q <= 2040).
+// magnitudes that occur; q <= 2040); divisors and their reciprocals are computed on the host and
+// travel in the kernel arguments.  Every butterfly operand is below 2^23 in magnitude (samples
+// +-128 -> row pass <= 2^13 -> column pass <= 2^16; constants < 2^15), so the multiplies are the
+// full-rate 24-bit ones (v_mul_i32_i24 returns the low 32 bits of the exact product).
+// A wave keeps walking tiles (grid = resident waves) so the set-up is paid once.
 #include "uhdr_types.h"
 
 namespace uhdr {
@@ -50,20 +54,20 @@ __device__ __forceinline__ void fdct_1d(const int in[8], int out[8]) {
     out[0] = descale(t10 + t11, 2);
     out[4] = descale(t10 - t11, 2);
   }
-  int z1 = (t12 + t13) * FIX_0_541196100;
-  out[2] = descale(z1 + t13 * FIX_0_765366865, sh);
-  out[6] = descale(z1 + t12 * (-FIX_1_847759065), sh);
+  int z1 = __mul24(t12 + t13, FIX_0_541196100);
+  out[2] = descale(z1 + __mul24(t13, FIX_0_765366865), sh);
+  out[6] = descale(z1 + __mul24(t12, -FIX_1_847759065), sh);
   z1 = t4 + t7;
   int z2 = t5 + t6, z3 = t4 + t6, z4 = t5 + t7;
-  const int z5 = (z3 + z4) * FIX_1_175875602;
-  t4 *= FIX_0_298631336;
-  t5 *= FIX_2_053119869;
-  t6 *= FIX_3_072711026;
-  t7 *= FIX_1_501321110;
-  z1 *= -FIX_0_899976223;
-  z2 *= -FIX_2_562915447;
-  z3 *= -FIX_1_961570560;
-  z4 *= -FIX_0_390180644;
+  const int z5 = __mul24(z3 + z4, FIX_1_175875602);
+  t4 = __mul24(t4, FIX_0_298631336);
+  t5 = __mul24(t5, FIX_2_053119869);
+  t6 = __mul24(t6, FIX_3_072711026);
+  t7 = __mul24(t7, FIX_1_501321110);
+  z1 = __mul24(z1, -FIX_0_899976223);
+  z2 = __mul24(z2, -FIX_2_562915447);
+  z3 = __mul24(z3, -FIX_1_961570560);
+  z4 = __mul24(z4, -FIX_0_390180644);
   z3 += z5;
   z4 += z5;
   out[7] = descale(t4 + z1 + z3, sh);
@@ -72,9 +76,14 @@ __device__ __forceinline__ void fdct_1d(const int in[8], int out[8]) {
   out[1] = descale(t7 + z1 + z4, sh);
 }
 
+struct QuantArgs {
+  uint32_t qv[64];  // quantval << 3, natural order
+  uint32_t qm[64];  // ceil(2^32 / qv)
+};
+
 __global__ __launch_bounds__(kBlock) void fdct_quant_kernel(const uint8_t* __restrict__ plane,
                                                             size_t stride, int bw, int bh,
-                                                            const uint16_t* __restrict__ qt,
+                                                            const QuantArgs qa,
                                                             int16_t* __restrict__ coef) {
   // per wave: 8 blocks x 8 rows x 9 (padded) words
   __shared__ int s_ws[kBlock / 64][8 * 8 * 9];
@@ -90,8 +99,8 @@ __global__ __launch_bounds__(kBlock) void fdct_quant_kernel(const uint8_t* __res
   uint32_t qv[8], qm[8];
 #pragma unroll
   for (int r = 0; r < 8; r++) {
-    qv[r] = (uint32_t)qt[r * 8 + cc] << 3;
-    qm[r] = (uint32_t)((0x100000000ull + qv[r] - 1) / qv[r]);
+    qv[r] = qa.qv[r * 8 + cc];
+    qm[r] = qa.qm[r * 8 + cc];
   }
   // row-pass / store role: lane = (row rr, block rb)
   const int rr = lane >> 3, rb = lane & 7;
@@ -158,12 +167,23 @@ __global__ __launch_bounds__(kBlock) void fdct_quant_kernel(const uint8_t* __res
 }  // namespace
 
 hipError_t launch_fdct_quant(const uint8_t* plane, size_t stride, int bw, int bh,
-                             const uint16_t* qt_dev, int16_t* coef, hipStream_t s) {
+                             const uint16_t* qt_host, int16_t* coef, hipStream_t s) {
+  QuantArgs qa;
+  for (int i = 0; i < 64; i++) {
+    qa.qv[i] = (uint32_t)qt_host[i] << 3;
+    qa.qm[i] = (uint32_t)((0x100000000ull + qa.qv[i] - 1) / qa.qv[i]);
+  }
   const int total = ((bw + 7) / 8) * bh;
+  static const int resident = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 2048;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    return cus * 8;
+  }();
   int grid = (total + 3) / 4;
-  if (grid > 4096) grid = 4096;
+  if (grid > resident) grid = resident;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(fdct_quant_kernel, dim3(grid), dim3(kBlock), 0, s, plane, stride, bw, bh, qt_dev, coef);
+  hipLaunchKernelGGL(fdct_quant_kernel, dim3(grid), dim3(kBlock), 0, s, plane, stride, bw, bh, qa, coef);
   return hipGetLastError();
 }
 

@@ -1,0 +1,341 @@
+// JPEG decode stage on gfx950: dequantize + 8x8 inverse DCT + range limit, and
+// libjpeg's two colour conversions for 3-channel gain maps -- all bit-exact integer work.
+//
+// Like the forward DCT this arithmetic is NOT in the reference tree: JpegDecoderHelper
+// (/root/reference/lib/src/jpegdecoderhelper.cpp:169-535) sets dct_method = JDCT_ISLOW and pulls
+// raw data (base image, Y400 map) or RGB scanlines (3-channel map) out of libjpeg; the encoder hands
+// an RGB map to libjpeg as JCS_RGB (jpegencoderhelper.cpp:165-167, 212-225).  What runs there is the
+// public Loeffler-Ligtenberg-Moschytz integer IDCT of jidctint.c (CONST_BITS 13, PASS1_BITS 2:
+// column pass from the dequantized coefficients, row pass, descale by 2^18, +128, range-limit
+// table indexed modulo 1024) and jccolor.c / jdcolor.c's 16-bit fixed-point colour transforms.
+//
+// IDCT mapping (mirror image of fdct_quant.hip): one wavefront = 8 horizontally adjacent blocks.
+// Lane (row r, block b) loads one coefficient row (8 x int16 = 16 bytes: a wave reads 1 KiB of
+// contiguous JBLOCKs), dequantizes it and parks it in LDS (rows padded to 9 words); lane
+// (block, column) runs the column pass; lane (row, block) runs the row pass on its workspace row,
+// range-limits and stores 8 samples as one 8-byte store (8 lanes = 64 contiguous bytes of a row).
+// When every dequantized coefficient of the tile is below 2^13 in magnitude -- always, for
+// coefficients that came out of an 8-bit forward DCT -- all butterfly operands are below 2^23 and
+// the multiplies are the full-rate 24-bit ones; otherwise (corrupt streams) the tile takes the
+// 32-bit multiply path, whose wrap-around equals libjpeg's INT32 arithmetic.
+#include "uhdr_types.h"
+
+namespace uhdr {
+namespace {
+
+constexpr int kBlock = 256;
+
+#define FIX_0_298631336 2446
+#define FIX_0_390180644 3196
+#define FIX_0_541196100 4433
+#define FIX_0_765366865 6270
+#define FIX_0_899976223 7373
+#define FIX_1_175875602 9633
+#define FIX_1_501321110 12299
+#define FIX_1_847759065 15137
+#define FIX_1_961570560 16069
+#define FIX_2_053119869 16819
+#define FIX_2_562915447 20995
+#define FIX_3_072711026 25172
+
+template <bool M24>
+__device__ __forceinline__ int mulc(int a, int c) {
+  if constexpr (M24) return __mul24(a, c);
+  else return (int)((uint32_t)a * (uint32_t)c);
+}
+__device__ __forceinline__ int descale(int x, int n) { return (int)((uint32_t)x + (1u << (n - 1))) >> n; }
+
+// jidctint.c jpeg_idct_islow, one 1-D pass (PASS 0: columns, descale 11; PASS 1: rows, descale 18)
+template <int PASS, bool M24>
+__device__ __forceinline__ void idct_1d(const int in[8], int out[8]) {
+  constexpr int sh = PASS == 0 ? 13 - 2 : 13 + 2 + 3;
+  int z2 = in[2], z3 = in[6];
+  int z1 = mulc<M24>(z2 + z3, FIX_0_541196100);
+  int tmp2 = z1 + mulc<M24>(z3, -FIX_1_847759065);
+  int tmp3 = z1 + mulc<M24>(z2, FIX_0_765366865);
+  z2 = in[0]; z3 = in[4];
+  int tmp0 = (int)((uint32_t)(z2 + z3) << 13);
+  int tmp1 = (int)((uint32_t)(z2 - z3) << 13);
+  const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+  tmp0 = in[7]; tmp1 = in[5]; tmp2 = in[3]; tmp3 = in[1];
+  z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
+  int z4 = tmp1 + tmp3;
+  const int z5 = mulc<M24>(z3 + z4, FIX_1_175875602);
+  tmp0 = mulc<M24>(tmp0, FIX_0_298631336);
+  tmp1 = mulc<M24>(tmp1, FIX_2_053119869);
+  tmp2 = mulc<M24>(tmp2, FIX_3_072711026);
+  tmp3 = mulc<M24>(tmp3, FIX_1_501321110);
+  z1 = mulc<M24>(z1, -FIX_0_899976223);
+  z2 = mulc<M24>(z2, -FIX_2_562915447);
+  z3 = mulc<M24>(z3, -FIX_1_961570560);
+  z4 = mulc<M24>(z4, -FIX_0_390180644);
+  z3 += z5; z4 += z5;
+  tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+  out[0] = descale(tmp10 + tmp3, sh); out[7] = descale(tmp10 - tmp3, sh);
+  out[1] = descale(tmp11 + tmp2, sh); out[6] = descale(tmp11 - tmp2, sh);
+  out[2] = descale(tmp12 + tmp1, sh); out[5] = descale(tmp12 - tmp1, sh);
+  out[3] = descale(tmp13 + tmp0, sh); out[4] = descale(tmp13 - tmp0, sh);
+}
+
+// range_limit[(x) & RANGE_MASK] with the table centred on 128 (jdmaster.c prepare_range_limit_table)
+__device__ __forceinline__ uint32_t range_limit(int x) {
+  const uint32_t v = (uint32_t)(x + 128) & 1023u;
+  return v <= 255u ? v : (v < 640u ? 255u : 0u);
+}
+
+struct DequantArgs {
+  uint16_t q[64];  // natural order
+};
+
+__global__ __launch_bounds__(kBlock) void idct_dequant_kernel(const int16_t* __restrict__ coef, int bw, int bh,
+                                                              const DequantArgs qa, uint8_t* __restrict__ plane,
+                                                              size_t stride) {
+  __shared__ int s_ws[kBlock / 64][8 * 8 * 9];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int* ws = s_ws[wv];
+  const int groups_x = (bw + 7) >> 3, total = groups_x * bh;
+  const int gwave = blockIdx.x * (kBlock / 64) + wv, nwaves = gridDim.x * (kBlock / 64);
+  const int rr = lane >> 3, rb = lane & 7;  // load / row-pass / store role: (row, block)
+  const int cb = lane >> 3, cc = lane & 7;  // column-pass role: (block, column)
+  int q[8];
+#pragma unroll
+  for (int c = 0; c < 8; c++) q[c] = qa.q[rr * 8 + c];
+  const bool vec_store = ((stride | (uintptr_t)plane) & 7) == 0;
+
+  for (int t = gwave; t < total; t += nwaves) {
+    const int by = t / groups_x, gx = t - by * groups_x;
+    const int bx = gx * 8 + rb;
+    int v[8];
+    int big = 0;
+    if (bx < bw) {
+      const uint4 raw = *(const uint4*)(coef + ((size_t)by * bw + bx) * 64 + rr * 8);
+      const uint32_t w4[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        v[2 * c] = __mul24((int)(int16_t)(w4[c] & 0xffff), q[2 * c]);  // |coef| < 2^15, q < 2^16: exact
+        v[2 * c + 1] = __mul24((int)(int16_t)(w4[c] >> 16), q[2 * c + 1]);
+      }
+#pragma unroll
+      for (int c = 0; c < 8; c++) big |= (v[c] < 0 ? -v[c] : v[c]) >> 13;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 8; c++) v[c] = 0;
+    }
+    const bool fast = __builtin_amdgcn_ballot_w64(big != 0) == 0;  // wave-uniform
+#pragma unroll
+    for (int c = 0; c < 8; c++) ws[rb * 72 + rr * 9 + c] = v[c];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed
+    int in[8], out[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) in[r] = ws[cb * 72 + r * 9 + cc];
+    if (fast) idct_1d<0, true>(in, out); else idct_1d<0, false>(in, out);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 8; r++) ws[cb * 72 + r * 9 + cc] = out[r];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+    for (int c = 0; c < 8; c++) in[c] = ws[rb * 72 + rr * 9 + c];
+    if (fast) idct_1d<1, true>(in, out); else idct_1d<1, false>(in, out);
+    if (bx < bw) {
+      uint32_t lo = 0, hi = 0;
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        lo |= range_limit(out[c]) << (8 * c);
+        hi |= range_limit(out[4 + c]) << (8 * c);
+      }
+      uint8_t* dst = plane + (size_t)(by * 8 + rr) * stride + (size_t)bx * 8;
+      if (vec_store) {
+        *(uint2*)dst = make_uint2(lo, hi);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; c++) { dst[c] = (uint8_t)(lo >> (8 * c)); dst[4 + c] = (uint8_t)(hi >> (8 * c)); }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---- libjpeg colour conversions (16-bit fixed point) -----------------------------------------------
+#define FIX16(x) ((int)((x) * 65536.0 + 0.5))
+
+// jccolor.c rgb_ycc_convert.  (The 6b / libjpeg-turbo constants and IJG 9's longer ones give the same
+// result for every 8-bit (r, g, b): checked exhaustively, tests/test_host_logic.py.)
+__device__ __forceinline__ void rgb_to_ycc_px(uint32_t r, uint32_t g, uint32_t b, uint32_t& y, uint32_t& cb, uint32_t& cr) {
+  const int half = 1 << 15, off = 128 << 16;
+  const int ri = (int)r, gi = (int)g, bi = (int)b;
+  y = (uint32_t)((FIX16(0.29900) * ri + FIX16(0.58700) * gi + FIX16(0.11400) * bi + half) >> 16);
+  cb = (uint32_t)(((-FIX16(0.16874)) * ri + (-FIX16(0.33126)) * gi + FIX16(0.50000) * bi + off + half - 1) >> 16);
+  cr = (uint32_t)((FIX16(0.50000) * ri + (-FIX16(0.41869)) * gi + (-FIX16(0.08131)) * bi + off + half - 1) >> 16);
+}
+
+struct JpegColorParams {
+  const uint8_t* rgb;   // packed RGB888 / RGBA8888
+  uint8_t* rgb_out;
+  const uint8_t* p[3];  // planes (ycc -> rgb input)
+  uint8_t* po[3];       // planes (rgb -> ycc output)
+  uint32_t w, h, rgb_stride_px, stride[3];
+  int bpp;              // 3 or 4
+  int k_cr_g, k_cb_g;   // ycc -> rgb green constants (libjpeg variant)
+};
+
+// one lane = 4 horizontally adjacent pixels when VEC (w % 4 == 0, 4-byte aligned rows), else 1 pixel
+template <int BPP, bool VEC>
+__global__ __launch_bounds__(kBlock) void jpeg_rgb_to_ycc_kernel(const JpegColorParams p) {
+  const uint32_t per_row = VEC ? p.w / 4 : p.w;
+  const uint32_t tiles_x = (per_row + kBlock - 1) / kBlock, tiles = tiles_x * p.h;
+  for (uint32_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const uint32_t y = t / tiles_x, j = (t - y * tiles_x) * kBlock + threadIdx.x;
+    if (j >= per_row) continue;
+    const uint8_t* src = p.rgb + (size_t)y * p.rgb_stride_px * BPP;
+    if constexpr (VEC) {
+      uint32_t r[4], g[4], b[4];
+      if constexpr (BPP == 4) {
+        const uint4 v = *(const uint4*)(src + j * 16);
+        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) { r[k] = w4[k] & 0xff; g[k] = (w4[k] >> 8) & 0xff; b[k] = (w4[k] >> 16) & 0xff; }
+      } else {
+        const uint32_t* s3 = (const uint32_t*)(src + j * 12);
+        const uint32_t a = s3[0], bq = s3[1], c = s3[2];  // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+        r[0] = a & 0xff; g[0] = (a >> 8) & 0xff; b[0] = (a >> 16) & 0xff;
+        r[1] = a >> 24; g[1] = bq & 0xff; b[1] = (bq >> 8) & 0xff;
+        r[2] = (bq >> 16) & 0xff; g[2] = bq >> 24; b[2] = c & 0xff;
+        r[3] = (c >> 8) & 0xff; g[3] = (c >> 16) & 0xff; b[3] = c >> 24;
+      }
+      uint32_t yo = 0, cbo = 0, cro = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        uint32_t yy, cb, cr;
+        rgb_to_ycc_px(r[k], g[k], b[k], yy, cb, cr);
+        yo |= yy << (8 * k); cbo |= cb << (8 * k); cro |= cr << (8 * k);
+      }
+      *(uint32_t*)(p.po[0] + (size_t)y * p.stride[0] + j * 4) = yo;
+      *(uint32_t*)(p.po[1] + (size_t)y * p.stride[1] + j * 4) = cbo;
+      *(uint32_t*)(p.po[2] + (size_t)y * p.stride[2] + j * 4) = cro;
+    } else {
+      uint32_t yy, cb, cr;
+      rgb_to_ycc_px(src[j * BPP], src[j * BPP + 1], src[j * BPP + 2], yy, cb, cr);
+      p.po[0][(size_t)y * p.stride[0] + j] = (uint8_t)yy;
+      p.po[1][(size_t)y * p.stride[1] + j] = (uint8_t)cb;
+      p.po[2][(size_t)y * p.stride[2] + j] = (uint8_t)cr;
+    }
+  }
+}
+
+// jdcolor.c ycc_rgb_convert: r = y + ((FIX(1.402) v + half) >> 16), b likewise with 1.772 u,
+// g = y + ((-k_cb_g u + half - k_cr_g v) >> 16), each clamped to [0, 255]
+__device__ __forceinline__ uint32_t clamp255(int v) { return (uint32_t)min(max(v, 0), 255); }
+__device__ __forceinline__ uint32_t ycc_to_rgb_px(uint32_t y, uint32_t cb, uint32_t cr, int k_cr_g, int k_cb_g) {
+  const int half = 1 << 15;
+  const int yy = (int)y, u = (int)cb - 128, v = (int)cr - 128;
+  const uint32_t r = clamp255(yy + ((FIX16(1.40200) * v + half) >> 16));
+  const uint32_t g = clamp255(yy + (((-k_cb_g) * u + half + (-k_cr_g) * v) >> 16));
+  const uint32_t b = clamp255(yy + ((FIX16(1.77200) * u + half) >> 16));
+  return r | (g << 8) | (b << 16) | (255u << 24);
+}
+
+template <int BPP, bool VEC>
+__global__ __launch_bounds__(kBlock) void jpeg_ycc_to_rgb_kernel(const JpegColorParams p) {
+  const uint32_t per_row = VEC ? p.w / 4 : p.w;
+  const uint32_t tiles_x = (per_row + kBlock - 1) / kBlock, tiles = tiles_x * p.h;
+  for (uint32_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const uint32_t y = t / tiles_x, j = (t - y * tiles_x) * kBlock + threadIdx.x;
+    if (j >= per_row) continue;
+    uint8_t* dst = p.rgb_out + (size_t)y * p.rgb_stride_px * BPP;
+    if constexpr (VEC) {
+      const uint32_t yv = *(const uint32_t*)(p.p[0] + (size_t)y * p.stride[0] + j * 4);
+      const uint32_t uv = *(const uint32_t*)(p.p[1] + (size_t)y * p.stride[1] + j * 4);
+      const uint32_t vv = *(const uint32_t*)(p.p[2] + (size_t)y * p.stride[2] + j * 4);
+      uint32_t px[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        px[k] = ycc_to_rgb_px((yv >> (8 * k)) & 0xff, (uv >> (8 * k)) & 0xff, (vv >> (8 * k)) & 0xff, p.k_cr_g, p.k_cb_g);
+      if constexpr (BPP == 4) {
+        *(uint4*)(dst + j * 16) = make_uint4(px[0], px[1], px[2], px[3]);
+      } else {
+        uint32_t* d3 = (uint32_t*)(dst + j * 12);
+        d3[0] = (px[0] & 0xffffff) | (px[1] << 24);
+        d3[1] = ((px[1] >> 8) & 0xffff) | (px[2] << 16);
+        d3[2] = ((px[2] >> 16) & 0xff) | (px[3] << 8);
+      }
+    } else {
+      const uint32_t px = ycc_to_rgb_px(p.p[0][(size_t)y * p.stride[0] + j], p.p[1][(size_t)y * p.stride[1] + j],
+                                        p.p[2][(size_t)y * p.stride[2] + j], p.k_cr_g, p.k_cb_g);
+      dst[j * BPP] = (uint8_t)px; dst[j * BPP + 1] = (uint8_t)(px >> 8); dst[j * BPP + 2] = (uint8_t)(px >> 16);
+      if constexpr (BPP == 4) dst[j * BPP + 3] = 255;
+    }
+  }
+}
+
+int resident_grid(uint32_t tiles, int per_cu) {
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
+  }();
+  const uint32_t r = (uint32_t)(cus * per_cu);
+  return (int)(tiles < r ? (tiles ? tiles : 1u) : r);
+}
+
+inline bool al(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
+
+}  // namespace
+
+hipError_t launch_idct_dequant(const int16_t* coef, int bw, int bh, const uint16_t* qt_host, uint8_t* plane,
+                               size_t stride, hipStream_t s) {
+  DequantArgs qa;
+  for (int i = 0; i < 64; i++) qa.q[i] = qt_host[i];
+  const int total = ((bw + 7) / 8) * bh;
+  const int grid = resident_grid((uint32_t)(total + 3) / 4, 8);
+  hipLaunchKernelGGL(idct_dequant_kernel, dim3(grid), dim3(kBlock), 0, s, coef, bw, bh, qa, plane, stride);
+  return hipGetLastError();
+}
+
+// rgb: 24bppRGB888 or 32bppRGBA8888 -> ycc: three 8-bit planes of the same size
+hipError_t launch_jpeg_rgb_to_ycc(const ImageView& rgb, const ImageViewMut& ycc, hipStream_t s) {
+  JpegColorParams p = {};
+  p.rgb = (const uint8_t*)rgb.p[0];
+  p.w = rgb.w; p.h = rgb.h; p.rgb_stride_px = rgb.stride[0];
+  p.bpp = rgb.fmt == UHDR_IMG_FMT_32bppRGBA8888 ? 4 : 3;
+  for (int c = 0; c < 3; c++) { p.po[c] = (uint8_t*)ycc.p[c]; p.stride[c] = ycc.stride[c]; }
+  const bool vec = (p.w % 4 == 0) && al(p.rgb, p.bpp == 4 ? 16 : 4) && ((size_t)p.rgb_stride_px * p.bpp) % (p.bpp == 4 ? 16 : 4) == 0 &&
+                   al(p.po[0], 4) && al(p.po[1], 4) && al(p.po[2], 4) && p.stride[0] % 4 == 0 && p.stride[1] % 4 == 0 && p.stride[2] % 4 == 0;
+  const uint32_t per_row = vec ? p.w / 4 : p.w;
+  const int grid = resident_grid(((per_row + kBlock - 1) / kBlock) * p.h, 8);
+  if (p.bpp == 4) {
+    if (vec) hipLaunchKernelGGL((jpeg_rgb_to_ycc_kernel<4, true>), dim3(grid), dim3(kBlock), 0, s, p);
+    else hipLaunchKernelGGL((jpeg_rgb_to_ycc_kernel<4, false>), dim3(grid), dim3(kBlock), 0, s, p);
+  } else {
+    if (vec) hipLaunchKernelGGL((jpeg_rgb_to_ycc_kernel<3, true>), dim3(grid), dim3(kBlock), 0, s, p);
+    else hipLaunchKernelGGL((jpeg_rgb_to_ycc_kernel<3, false>), dim3(grid), dim3(kBlock), 0, s, p);
+  }
+  return hipGetLastError();
+}
+
+// variant 0: libjpeg 6b / libjpeg-turbo constants (the reference's pinned libjpeg-turbo); 1: IJG 9
+hipError_t launch_jpeg_ycc_to_rgb(const ImageView& ycc, const ImageViewMut& rgb, int variant, hipStream_t s) {
+  JpegColorParams p = {};
+  p.rgb_out = (uint8_t*)rgb.p[0];
+  p.w = ycc.w; p.h = ycc.h; p.rgb_stride_px = rgb.stride[0];
+  p.bpp = rgb.fmt == UHDR_IMG_FMT_32bppRGBA8888 ? 4 : 3;
+  for (int c = 0; c < 3; c++) { p.p[c] = (const uint8_t*)ycc.p[c]; p.stride[c] = ycc.stride[c]; }
+  p.k_cr_g = variant ? FIX16(0.714136286) : FIX16(0.71414);
+  p.k_cb_g = variant ? FIX16(0.344136286) : FIX16(0.34414);
+  const bool vec = (p.w % 4 == 0) && al(p.rgb_out, p.bpp == 4 ? 16 : 4) && ((size_t)p.rgb_stride_px * p.bpp) % (p.bpp == 4 ? 16 : 4) == 0 &&
+                   al(p.p[0], 4) && al(p.p[1], 4) && al(p.p[2], 4) && p.stride[0] % 4 == 0 && p.stride[1] % 4 == 0 && p.stride[2] % 4 == 0;
+  const uint32_t per_row = vec ? p.w / 4 : p.w;
+  const int grid = resident_grid(((per_row + kBlock - 1) / kBlock) * p.h, 8);
+  if (p.bpp == 4) {
+    if (vec) hipLaunchKernelGGL((jpeg_ycc_to_rgb_kernel<4, true>), dim3(grid), dim3(kBlock), 0, s, p);
+    else hipLaunchKernelGGL((jpeg_ycc_to_rgb_kernel<4, false>), dim3(grid), dim3(kBlock), 0, s, p);
+  } else {
+    if (vec) hipLaunchKernelGGL((jpeg_ycc_to_rgb_kernel<3, true>), dim3(grid), dim3(kBlock), 0, s, p);
+    else hipLaunchKernelGGL((jpeg_ycc_to_rgb_kernel<3, false>), dim3(grid), dim3(kBlock), 0, s, p);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace uhdr

@@ -88,7 +88,6 @@ struct uhdr_hip_ctx {
   // scratch for host-buffer entry points and two-pass generation
   DeviceBuf scratch[8];
   DeviceBuf minmax;  // 6 + 2048*6 floats
-  uint16_t* d_qt = nullptr;
   FramePtrs* d_frames = nullptr;  // batch frame-pointer tables (rotating slots)
   size_t frames_cap = 0;
   unsigned int frames_next = 0;
@@ -415,7 +414,6 @@ void uhdr_hip_destroy(uhdr_hip_ctx_t* c) {
   }
   for (auto& b : c->scratch) if (b.p) (void)hipFree(b.p);
   if (c->minmax.p) (void)hipFree(c->minmax.p);
-  if (c->d_qt) (void)hipFree(c->d_qt);
   if (c->d_frames) (void)hipFree(c->d_frames);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -1025,13 +1023,8 @@ uhdr_error_info_t uhdr_hip_fdct_quant_dev(uhdr_hip_ctx_t* c, const uint8_t* plan
   for (int i = 0; i < 64; i++)
     if (qt[i] == 0 || qt[i] > 255) return err_status(UHDR_CODEC_INVALID_PARAM, "quantization table entry %d out of baseline range", i);
   HIP_TRY(hipSetDevice(c->device));
-  if (!c->d_qt) HIP_TRY(hipMalloc((void**)&c->d_qt, 64 * sizeof(uint16_t) * 16));
-  // 16 rotating table slots so that back-to-back calls with different tables do not race
-  static thread_local int slot = 0;
-  uint16_t* dq = c->d_qt + 64 * (slot++ & 15);
-  HIP_TRY(hipMemcpyAsync(dq, qt, 64 * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
   ProfScope ps(c, "fdct_quant");
-  HIP_TRY(launch_fdct_quant(plane, stride, bw, bh, dq, coef, c->stream));
+  HIP_TRY(launch_fdct_quant(plane, stride, bw, bh, qt, coef, c->stream));  // the table travels in the kernel arguments
   return ok_status();
 }
 
@@ -1049,6 +1042,114 @@ uhdr_error_info_t uhdr_hip_fdct_quant(uhdr_hip_ctx_t* c, const uint8_t* plane, s
   HIP_TRY(hipMemcpyAsync(coef, c->scratch[1].p, out_bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return ok_status();
+}
+
+// -------------------------------------------------------------------------------------------------
+// JPEG decode stage: dequant + IDCT, libjpeg colour conversions
+// -------------------------------------------------------------------------------------------------
+uhdr_error_info_t uhdr_hip_idct_dequant_dev(uhdr_hip_ctx_t* c, const int16_t* coef, int bw, int bh, const uint16_t qt[64],
+                                            uint8_t* plane, size_t stride) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  if (!plane || !qt || !coef || bw <= 0 || bh <= 0) return err_status(UHDR_CODEC_INVALID_PARAM, "received bad argument for idct_dequant");
+  if (((uintptr_t)coef & 15) != 0) return err_status(UHDR_CODEC_INVALID_PARAM, "coefficient buffer must be 16-byte aligned");
+  if (stride < (size_t)bw * 8) return err_status(UHDR_CODEC_INVALID_PARAM, "plane stride (%zu) cannot be less than blocks_w * 8 (%d)", stride, bw * 8);
+  for (int i = 0; i < 64; i++)
+    if (qt[i] == 0) return err_status(UHDR_CODEC_INVALID_PARAM, "quantization table entry %d is zero", i);
+  HIP_TRY(hipSetDevice(c->device));
+  ProfScope ps(c, "idct_dequant");
+  HIP_TRY(launch_idct_dequant(coef, bw, bh, qt, plane, stride, c->stream));
+  return ok_status();
+}
+
+uhdr_error_info_t uhdr_hip_idct_dequant(uhdr_hip_ctx_t* c, const int16_t* coef, int bw, int bh, const uint16_t qt[64],
+                                        uint8_t* plane, size_t stride) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  if (!plane || !qt || !coef || bw <= 0 || bh <= 0) return err_status(UHDR_CODEC_INVALID_PARAM, "received bad argument for idct_dequant");
+  if (stride < (size_t)bw * 8) return err_status(UHDR_CODEC_INVALID_PARAM, "plane stride (%zu) cannot be less than blocks_w * 8 (%d)", stride, bw * 8);
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t in_bytes = (size_t)bw * bh * 64 * sizeof(int16_t);
+  const size_t dpitch = ((size_t)bw * 8 + 63) & ~(size_t)63;
+  UHDR_TRY(ensure(c->scratch[0], in_bytes));
+  UHDR_TRY(ensure(c->scratch[1], dpitch * (size_t)bh * 8));
+  HIP_TRY(hipMemcpyAsync(c->scratch[0].p, coef, in_bytes, hipMemcpyHostToDevice, c->stream));
+  UHDR_TRY(uhdr_hip_idct_dequant_dev(c, (const int16_t*)c->scratch[0].p, bw, bh, qt, (uint8_t*)c->scratch[1].p, dpitch));
+  HIP_TRY(hipMemcpy2DAsync(plane, stride, c->scratch[1].p, dpitch, (size_t)bw * 8, (size_t)bh * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return ok_status();
+}
+
+static uhdr_error_info_t check_jpeg_color(const uhdr_raw_image_t* rgb, const uhdr_raw_image_t* ycc, bool ycc_is_dst) {
+  if (!rgb || !ycc) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument");
+  if (rgb->fmt != UHDR_IMG_FMT_24bppRGB888 && rgb->fmt != UHDR_IMG_FMT_32bppRGBA8888)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "libjpeg colour conversion expects UHDR_IMG_FMT_24bppRGB888 or UHDR_IMG_FMT_32bppRGBA8888 on the RGB side. Received %d", rgb->fmt);
+  const uhdr_raw_image_t* src = ycc_is_dst ? rgb : ycc;
+  const uhdr_raw_image_t* dst = ycc_is_dst ? ycc : rgb;
+  if (!ycc_is_dst && ycc->fmt != UHDR_IMG_FMT_24bppYCbCr444)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "libjpeg colour conversion expects UHDR_IMG_FMT_24bppYCbCr444 on the YCbCr side. Received %d", ycc->fmt);
+  if (src->w == 0 || src->h == 0) return err_status(UHDR_CODEC_INVALID_PARAM, "image dimensions cannot be zero, received %ux%u", src->w, src->h);
+  const int np_src = ycc_is_dst ? 1 : 3, np_dst = ycc_is_dst ? 3 : 1;
+  for (int i = 0; i < np_src; i++) {
+    if (!src->planes[i]) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for source plane %d", i);
+    if (src->stride[i] < src->w) return err_status(UHDR_CODEC_INVALID_PARAM, "source stride (%u) cannot be less than width (%u)", src->stride[i], src->w);
+  }
+  for (int i = 0; i < np_dst; i++) {
+    if (!dst->planes[i]) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for destination plane %d", i);
+    if (dst->stride[i] < src->w) return err_status(UHDR_CODEC_INVALID_PARAM, "destination stride (%u) cannot be less than width (%u)", dst->stride[i], src->w);
+  }
+  return ok_status();
+}
+
+uhdr_error_info_t uhdr_hip_jpeg_rgb_to_ycc_dev(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* rgb, uhdr_raw_image_t* ycc) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  UHDR_TRY(check_jpeg_color(rgb, ycc, true));
+  HIP_TRY(hipSetDevice(c->device));
+  ycc->fmt = UHDR_IMG_FMT_24bppYCbCr444;
+  ycc->cg = rgb->cg; ycc->ct = rgb->ct; ycc->range = UHDR_CR_FULL_RANGE;
+  ycc->w = rgb->w; ycc->h = rgb->h;
+  ProfScope ps(c, "jpeg_color");
+  HIP_TRY(launch_jpeg_rgb_to_ycc(view_of(rgb), view_mut_of(ycc), c->stream));
+  return ok_status();
+}
+
+uhdr_error_info_t uhdr_hip_jpeg_rgb_to_ycc(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* rgb, uhdr_raw_image_t* ycc) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  UHDR_TRY(check_jpeg_color(rgb, ycc, true));
+  HIP_TRY(hipSetDevice(c->device));
+  uhdr_raw_image_t tmp = *ycc;
+  tmp.fmt = UHDR_IMG_FMT_24bppYCbCr444;
+  tmp.w = rgb->w; tmp.h = rgb->h;
+  uhdr_raw_image_t ds, dd;
+  UHDR_TRY(stage_in(c, 0, rgb, &ds, true));
+  UHDR_TRY(stage_in(c, 1, &tmp, &dd, false));
+  UHDR_TRY(uhdr_hip_jpeg_rgb_to_ycc_dev(c, &ds, &dd));
+  ycc->fmt = dd.fmt; ycc->cg = dd.cg; ycc->ct = dd.ct; ycc->range = dd.range; ycc->w = dd.w; ycc->h = dd.h;
+  return stage_out(c, &dd, ycc);
+}
+
+uhdr_error_info_t uhdr_hip_jpeg_ycc_to_rgb_dev(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* ycc, int variant, uhdr_raw_image_t* rgb) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  UHDR_TRY(check_jpeg_color(rgb, ycc, false));
+  if (variant != 0 && variant != 1) return err_status(UHDR_CODEC_INVALID_PARAM, "unknown libjpeg variant %d", variant);
+  HIP_TRY(hipSetDevice(c->device));
+  rgb->cg = ycc->cg; rgb->ct = ycc->ct; rgb->range = UHDR_CR_FULL_RANGE;
+  rgb->w = ycc->w; rgb->h = ycc->h;
+  ProfScope ps(c, "jpeg_color");
+  HIP_TRY(launch_jpeg_ycc_to_rgb(view_of(ycc), view_mut_of(rgb), variant, c->stream));
+  return ok_status();
+}
+
+uhdr_error_info_t uhdr_hip_jpeg_ycc_to_rgb(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* ycc, int variant, uhdr_raw_image_t* rgb) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  UHDR_TRY(check_jpeg_color(rgb, ycc, false));
+  HIP_TRY(hipSetDevice(c->device));
+  uhdr_raw_image_t tmp = *rgb;
+  tmp.w = ycc->w; tmp.h = ycc->h;
+  uhdr_raw_image_t ds, dd;
+  UHDR_TRY(stage_in(c, 0, ycc, &ds, true));
+  UHDR_TRY(stage_in(c, 1, &tmp, &dd, false));
+  UHDR_TRY(uhdr_hip_jpeg_ycc_to_rgb_dev(c, &ds, variant, &dd));
+  rgb->cg = dd.cg; rgb->ct = dd.ct; rgb->range = dd.range; rgb->w = dd.w; rgb->h = dd.h;
+  return stage_out(c, &dd, rgb);
 }
 
 }  // extern "C"

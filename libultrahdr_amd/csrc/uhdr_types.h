@@ -152,6 +152,11 @@ hipError_t launch_tone_map(const ToneMapParams& p, hipStream_t s);
 hipError_t launch_transform_yuv(const YuvXformParams& p, hipStream_t s);
 hipError_t launch_rgb_to_ycbcr(const RgbToYcbcrParams& p, hipStream_t s);
 hipError_t launch_fdct_quant(const uint8_t* plane, size_t stride, int bw, int bh,
-                             const uint16_t* qt_dev, int16_t* coef, hipStream_t s);
+                             const uint16_t* qt_host, int16_t* coef, hipStream_t s);
+
+hipError_t launch_idct_dequant(const int16_t* coef, int bw, int bh, const uint16_t* qt_host, uint8_t* plane,
+                               size_t stride, hipStream_t s);
+hipError_t launch_jpeg_rgb_to_ycc(const ImageView& rgb, const ImageViewMut& ycc, hipStream_t s);
+hipError_t launch_jpeg_ycc_to_rgb(const ImageView& ycc, const ImageViewMut& rgb, int variant, hipStream_t s);
 
 }  // namespace uhdr

@@ -69,6 +69,9 @@ class Image:
             self.buf = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
             if fill is not None:
                 self.buf.fill_(fill)
+            # torch's fill runs asynchronously on torch's stream; the library works on its own
+            # (non-blocking) stream, so make the memory quiescent before anybody else touches it
+            torch.cuda.current_stream(self.buf.device).synchronize()
             base = self.buf.data_ptr()
         self.raw = A.RawImage()
         self.raw.fmt, self.raw.cg, self.raw.ct, self.raw.range = fmt, cg, ct, rng
@@ -100,6 +103,13 @@ class Image:
     def planes_valid(self):
         return [self.valid(i) for i, pl in enumerate(self.layout) if pl is not None]
 
+    def plane_tensor(self, i):
+        """Device images: plane i as a (rows, stride * bytes_per_sample) uint8 torch view (no copy)."""
+        assert self.device is not None
+        rows, stride, _ = self.layout[i]
+        bps = bytes_per_sample(self.fmt)
+        return self.buf[self.offsets[i]: self.offsets[i] + rows * stride * bps].view(rows, stride * bps)
+
     # ---- movement ----------------------------------------------------------------------------
     def to(self, device):
         out = Image(self.fmt, self.w, self.h, self.raw.cg, self.raw.ct, self.raw.range, self.align, device)
@@ -109,6 +119,7 @@ class Image:
             out.buf.copy_(torch.from_numpy(self.buf))
         else:
             out.buf.copy_(self.buf)
+        torch.cuda.current_stream(out.buf.device).synchronize()
         return out
 
     def to_host(self):
@@ -128,7 +139,10 @@ class Image:
         if self.device is None:
             out.buf[:] = self.buf
         else:
+            import torch
+
             out.buf.copy_(self.buf)
+            torch.cuda.current_stream(out.buf.device).synchronize()
         return out
 
 

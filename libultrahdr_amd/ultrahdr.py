@@ -184,3 +184,37 @@ class UltraHdr:
         A.check(self.lib.uhdr_hip_fdct_quant_dev(self.ctx.handle, C.c_void_p(plane.data_ptr()), stride,
                                                  blocks_w, blocks_h, qt, C.c_void_p(out.data_ptr())))
         return out
+
+    def idct_dequant(self, coef, qtable: np.ndarray, plane=None, stride: int = 0):
+        """Inverse of fdct_quant.  coef: int16 [blocks_h, blocks_w, 64] numpy array (host) or CUDA
+        tensor (device).  Returns the uint8 plane [blocks_h*8, stride] (stride defaults to blocks_w*8)."""
+        qt = (C.c_uint16 * 64)(*[int(v) for v in qtable])
+        blocks_h, blocks_w = int(coef.shape[0]), int(coef.shape[1])
+        stride = stride or blocks_w * 8
+        if isinstance(coef, np.ndarray):
+            coef = np.ascontiguousarray(coef, dtype=np.int16)
+            out = np.zeros((blocks_h * 8, stride), dtype=np.uint8) if plane is None else plane
+            A.check(self.lib.uhdr_hip_idct_dequant(self.ctx.handle, C.c_void_p(coef.ctypes.data), blocks_w, blocks_h, qt,
+                                                   C.c_void_p(out.ctypes.data), stride))
+            return out
+        import torch
+
+        out = torch.empty((blocks_h * 8, stride), dtype=torch.uint8, device=coef.device) if plane is None else plane
+        A.check(self.lib.uhdr_hip_idct_dequant_dev(self.ctx.handle, C.c_void_p(coef.data_ptr()), blocks_w, blocks_h, qt,
+                                                   C.c_void_p(out.data_ptr()), stride))
+        return out
+
+    def jpeg_rgb_to_ycc(self, rgb: Image) -> Image:
+        """libjpeg's JCS_RGB -> YCbCr (what happens to a 3-channel gain map inside jpeg_write_scanlines):
+        RGB888 / RGBA8888 -> YCbCr 4:4:4 planes, ready for fdct_quant."""
+        dst = Image(A.UHDR_IMG_FMT_24bppYCbCr444, rgb.w, rgb.h, align=64, device=rgb.device)
+        fn = self.lib.uhdr_hip_jpeg_rgb_to_ycc_dev if _is_dev(rgb) else self.lib.uhdr_hip_jpeg_rgb_to_ycc
+        A.check(fn(self.ctx.handle, C.byref(rgb.raw), C.byref(dst.raw)))
+        return dst
+
+    def jpeg_ycc_to_rgb(self, ycc: Image, fmt=A.UHDR_IMG_FMT_24bppRGB888, libjpeg_variant: int = 0) -> Image:
+        """libjpeg's YCbCr -> RGB of a decoded 3-channel gain map (variant 0: 6b / turbo, 1: IJG 9)."""
+        dst = Image(fmt, ycc.w, ycc.h, align=64, device=ycc.device)
+        fn = self.lib.uhdr_hip_jpeg_ycc_to_rgb_dev if _is_dev(ycc) else self.lib.uhdr_hip_jpeg_ycc_to_rgb
+        A.check(fn(self.ctx.handle, C.byref(ycc.raw), libjpeg_variant, C.byref(dst.raw)))
+        return dst

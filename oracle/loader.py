@@ -62,6 +62,10 @@ def port() -> C.CDLL:
     lib.uo_fdct_quant_plane.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, _P(C.c_uint16), C.c_void_p]
     lib.uo_jpeg_rgb_to_ycc.restype = None
     lib.uo_jpeg_rgb_to_ycc.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.uo_idct_dequant_plane.restype = None
+    lib.uo_idct_dequant_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, _P(C.c_uint16), C.c_void_p, C.c_size_t]
+    lib.uo_jpeg_ycc_to_rgb.restype = None
+    lib.uo_jpeg_ycc_to_rgb.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int]
     _common_scalar_sigs(lib, "uo_")
     lib.uo_oetf_code.restype = None
     lib.uo_oetf_code.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
@@ -231,6 +235,33 @@ def fdct_quant_port(plane: np.ndarray, stride: int, bw: int, bh: int, qt: np.nda
     out = np.zeros((bh, bw, 64), dtype=np.int16)
     q = (C.c_uint16 * 64)(*[int(v) for v in qt])
     port().uo_fdct_quant_plane(plane.ctypes.data, stride, bw, bh, q, out.ctypes.data)
+    return out
+
+
+def idct_dequant_port(coef: np.ndarray, qt: np.ndarray) -> np.ndarray:
+    """coef: (bh, bw, 64) int16 in JBLOCK layout -> (bh*8, bw*8) uint8 plane."""
+    coef = np.ascontiguousarray(coef, dtype=np.int16)
+    bh, bw = coef.shape[:2]
+    out = np.zeros((bh * 8, bw * 8), dtype=np.uint8)
+    q = (C.c_uint16 * 64)(*[int(v) for v in qt])
+    port().uo_idct_dequant_plane(coef.ctypes.data, bw, bh, q, out.ctypes.data, bw * 8)
+    return out
+
+
+def jpeg_rgb_to_ycc_port(rgb: np.ndarray, stride_px: int, w: int, h: int):
+    """rgb: packed RGB888 rows (uint8) -> three (h, w) uint8 planes (libjpeg rgb_ycc_convert)."""
+    planes = [np.zeros((h, w), dtype=np.uint8) for _ in range(3)]
+    rgb = np.ascontiguousarray(rgb)
+    port().uo_jpeg_rgb_to_ycc(rgb.ctypes.data, stride_px, w, h, planes[0].ctypes.data, planes[1].ctypes.data, planes[2].ctypes.data, w)
+    return planes
+
+
+def jpeg_ycc_to_rgb_port(y: np.ndarray, cb: np.ndarray, cr: np.ndarray, out_bpp: int = 3, variant: int = 0) -> np.ndarray:
+    """three (h, w) uint8 planes -> (h, w*out_bpp) packed RGB / RGBA (libjpeg ycc_rgb_convert)."""
+    y, cb, cr = [np.ascontiguousarray(p) for p in (y, cb, cr)]
+    h, w = y.shape
+    out = np.zeros((h, w * out_bpp), dtype=np.uint8)
+    port().uo_jpeg_ycc_to_rgb(y.ctypes.data, cb.ctypes.data, cr.ctypes.data, w, w, h, out.ctypes.data, w, out_bpp, variant)
     return out
 
 

@@ -1193,6 +1193,93 @@ void uo_jpeg_rgb_to_ycc(const uint8_t* rgb, size_t stride_px, int w, int h, uint
 }
 
 /* ---------------------------------------------------------------------------------------------
+ * JPEG decode stage: dequantize + islow inverse DCT + range limit, and the
+ * YCbCr -> RGB conversion libjpeg applies to a 3-channel gain map.  Like the forward DCT this
+ * arithmetic lives in libjpeg, not in the reference tree: JpegDecoderHelper
+ * (/root/reference/lib/src/jpegdecoderhelper.cpp:169-535) sets dct_method = JDCT_ISLOW and reads
+ * raw data (base image, Y400 map) or scanlines (RGB map).  Restated from the published
+ * Loeffler-Ligtenberg-Moschytz routine of libjpeg's jidctint.c (CONST_BITS 13, PASS1_BITS 2:
+ * column pass from the dequantized coefficients into a workspace scaled by 4, then a row pass,
+ * final descale by 2^18, +128, range limit) and jdcolor.c's table-driven ycc_rgb_convert.
+ * ------------------------------------------------------------------------------------------- */
+static void idct_islow_1d(const int32_t in[8], int32_t out[8], int pass) {
+  /* pass 0: descale by CONST_BITS - PASS1_BITS; pass 1: by CONST_BITS + PASS1_BITS + 3 */
+  const int sh = pass == 0 ? 13 - 2 : 13 + 2 + 3;
+  int32_t z2 = in[2], z3 = in[6];
+  int32_t z1 = (z2 + z3) * FIX_0_541196100;
+  int32_t tmp2 = z1 + z3 * (-FIX_1_847759065);
+  int32_t tmp3 = z1 + z2 * FIX_0_765366865;
+  z2 = in[0]; z3 = in[4];
+  int32_t tmp0 = (int32_t)((uint32_t)(z2 + z3) << 13);
+  int32_t tmp1 = (int32_t)((uint32_t)(z2 - z3) << 13);
+  const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+  tmp0 = in[7]; tmp1 = in[5]; tmp2 = in[3]; tmp3 = in[1];
+  z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
+  int32_t z4 = tmp1 + tmp3;
+  const int32_t z5 = (z3 + z4) * FIX_1_175875602;
+  tmp0 *= FIX_0_298631336; tmp1 *= FIX_2_053119869; tmp2 *= FIX_3_072711026; tmp3 *= FIX_1_501321110;
+  z1 *= -FIX_0_899976223; z2 *= -FIX_2_562915447; z3 *= -FIX_1_961570560; z4 *= -FIX_0_390180644;
+  z3 += z5; z4 += z5;
+  tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+  out[0] = DESCALE(tmp10 + tmp3, sh); out[7] = DESCALE(tmp10 - tmp3, sh);
+  out[1] = DESCALE(tmp11 + tmp2, sh); out[6] = DESCALE(tmp11 - tmp2, sh);
+  out[2] = DESCALE(tmp12 + tmp1, sh); out[5] = DESCALE(tmp12 - tmp1, sh);
+  out[3] = DESCALE(tmp13 + tmp0, sh); out[4] = DESCALE(tmp13 - tmp0, sh);
+}
+/* libjpeg's range_limit table indexed with (x & RANGE_MASK), RANGE_MASK = 1023, centred on 128:
+ * v = (x + 128) mod 1024 -> v for v <= 255, 255 up to 639, 0 above (the wrap only matters for
+ * corrupt streams). */
+static uint8_t idct_range_limit(int32_t x) {
+  const uint32_t v = (uint32_t)(x + 128) & 1023u;
+  return (uint8_t)(v <= 255 ? v : (v < 640 ? 255 : 0));
+}
+void uo_idct_dequant_plane(const int16_t* coef, int bw, int bh, const uint16_t qt[64], uint8_t* plane, size_t stride) {
+  for (int by = 0; by < bh; by++)
+    for (int bx = 0; bx < bw; bx++) {
+      const int16_t* in = coef + ((size_t)by * bw + bx) * 64;
+      int32_t ws[64];
+      for (int c = 0; c < 8; c++) { /* pass 1: columns */
+        int32_t col[8], o[8];
+        for (int r = 0; r < 8; r++) col[r] = (int32_t)in[r * 8 + c] * (int32_t)qt[r * 8 + c];
+        idct_islow_1d(col, o, 0);
+        for (int r = 0; r < 8; r++) ws[r * 8 + c] = o[r];
+      }
+      for (int r = 0; r < 8; r++) { /* pass 2: rows */
+        int32_t o[8];
+        idct_islow_1d(ws + r * 8, o, 1);
+        uint8_t* dst = plane + (size_t)(by * 8 + r) * stride + (size_t)bx * 8;
+        for (int c = 0; c < 8; c++) dst[c] = idct_range_limit(o[c]);
+      }
+    }
+}
+/* jdcolor.c ycc_rgb_convert.  variant 0: libjpeg 6b / libjpeg-turbo constants (1.40200 1.77200
+ * 0.71414 0.34414) -- the reference pins libjpeg-turbo 3.1.0; variant 1: IJG 9 constants
+ * (1.402 1.772 0.714136286 0.344136286) -- the library in this image, used to pin the restatement.
+ * The two differ in the green term for 59 of the 65536 (Cb, Cr) pairs.  out_bpp 3 (RGB888) or 4
+ * (RGBA8888, alpha 255). */
+void uo_jpeg_ycc_to_rgb(const uint8_t* y, const uint8_t* cb, const uint8_t* cr, size_t in_stride, int w, int h,
+                        uint8_t* rgb, size_t out_stride_px, int out_bpp, int variant) {
+#define FIX16(x) ((int32_t)((x) * 65536.0 + 0.5))
+  const int32_t k_cr_r = FIX16(1.40200), k_cb_b = FIX16(1.77200);
+  const int32_t k_cr_g = variant ? FIX16(0.714136286) : FIX16(0.71414);
+  const int32_t k_cb_g = variant ? FIX16(0.344136286) : FIX16(0.34414);
+  const int32_t half = 1 << 15;
+  for (int j = 0; j < h; j++)
+    for (int i = 0; i < w; i++) {
+      const int32_t yy = y[j * in_stride + i], u = (int32_t)cb[j * in_stride + i] - 128, v = (int32_t)cr[j * in_stride + i] - 128;
+      int32_t r = yy + ((k_cr_r * v + half) >> 16);
+      int32_t g = yy + (((-k_cb_g) * u + half + (-k_cr_g) * v) >> 16);
+      int32_t b = yy + ((k_cb_b * u + half) >> 16);
+      uint8_t* o = rgb + ((size_t)j * out_stride_px + i) * out_bpp;
+      o[0] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+      o[1] = (uint8_t)(g < 0 ? 0 : (g > 255 ? 255 : g));
+      o[2] = (uint8_t)(b < 0 ? 0 : (b > 255 ? 255 : b));
+      if (out_bpp == 4) o[3] = 255;
+    }
+#undef FIX16
+}
+
+/* ---------------------------------------------------------------------------------------------
  * scalar access for KATs (function ids mirror oracle/ref_shim.cpp)
  * ------------------------------------------------------------------------------------------- */
 int uo_eval(int fn, const float* in, float* out, size_t n) {

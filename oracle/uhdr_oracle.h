@@ -96,6 +96,14 @@ void uo_fdct_quant_plane(const uint8_t* plane, size_t stride, int blocks_w, int 
 void uo_jpeg_rgb_to_ycc(const uint8_t* rgb, size_t stride_px, int w, int h, uint8_t* y,
                         uint8_t* cb, uint8_t* cr, size_t out_stride);
 
+/* JPEG decode stage: dequantize + islow IDCT + range limit of coefficient blocks (JBLOCK layout, as
+ * uo_fdct_quant_plane writes them) into an 8-bit plane; libjpeg's YCbCr -> RGB for 3-channel maps
+ * (variant 0: 6b / libjpeg-turbo constants, 1: IJG 9 constants; out_bpp 3 or 4). */
+void uo_idct_dequant_plane(const int16_t* coef, int blocks_w, int blocks_h, const uint16_t qt[64],
+                           uint8_t* plane, size_t stride);
+void uo_jpeg_ycc_to_rgb(const uint8_t* y, const uint8_t* cb, const uint8_t* cr, size_t in_stride, int w,
+                        int h, uint8_t* rgb, size_t out_stride_px, int out_bpp, int variant);
+
 /* scalar access for known-answer tests */
 int uo_eval(int fn, const float* in, float* out, size_t n); /* ids as in ref_shim.cpp */
 void uo_float_to_half(const float* in, uint16_t* out, size_t n);

@@ -377,3 +377,99 @@ def test_fdct_quant_full_size_properties(uhdr):
     dc = blocks  # the islow output is scaled by 8, the quantizer divides by q << 3: DC == sum of (p - 128)
     want_dc = np.sign(dc) * ((np.abs(dc) + (q >> 1)) // q)
     assert np.array_equal(coef[..., 0].astype(np.int64), want_dc)
+
+
+# ---- JPEG decode stage ------------------------------------------------------------------
+@pytest.mark.parametrize("quality", [95, 40])
+def test_idct_dequant_bit_exact(uhdr, quality):
+    """dequant + islow IDCT + range limit == the oracle (itself pinned against libjpeg through the
+    reference's JpegDecoderHelper, tests/test_oracle_vs_ref.py), host and device entry points; the last
+    case feeds garbage coefficients (the 32-bit multiply / modulo-1024 range-limit path)."""
+    import torch
+
+    rng = np.random.default_rng(23)
+    for (w, h) in ((512, 256), (72, 40)):
+        plane = np.ascontiguousarray(synth.make_sdr_yuv420(w, h, align=8, noise=0.1).plane(0)[:h, :w])
+        qt = uhdr.quant_table(quality, False)
+        coef = L.fdct_quant_port(plane, w, w // 8, h // 8, qt)
+        want = L.idct_dequant_port(coef, qt)
+        got = uhdr.idct_dequant(coef, qt)
+        assert np.array_equal(got, want)
+        dgot = uhdr.idct_dequant(torch.from_numpy(coef).to("cuda:0"), qt)
+        uhdr.ctx.synchronize()
+        assert np.array_equal(dgot.cpu().numpy(), want)
+        # ragged stride (byte stores) and a round trip: decode(encode(x)) stays within the quantisation error
+        got2 = uhdr.idct_dequant(coef, qt, stride=w + 3)
+        assert np.array_equal(got2[:, :w], want)
+        assert np.abs(want.astype(np.int32) - plane.astype(np.int32)).mean() <= (2.0 if quality == 95 else 16.0)
+    wild = rng.integers(-32768, 32768, (4, 9, 64), dtype=np.int16)
+    qt = np.full(64, 255, dtype=np.uint16)
+    assert np.array_equal(uhdr.idct_dequant(wild, qt), L.idct_dequant_port(wild, qt))
+
+
+@pytest.mark.parametrize("fmt", [A.UHDR_IMG_FMT_24bppRGB888, A.UHDR_IMG_FMT_32bppRGBA8888])
+@pytest.mark.parametrize("size", [(256, 64), (131, 17)])
+def test_jpeg_colour_conversions_bit_exact(uhdr, fmt, size):
+    """libjpeg's rgb_ycc_convert / ycc_rgb_convert (both constant variants), vector and scalar paths."""
+    w, h = size
+    bpp = 4 if fmt == A.UHDR_IMG_FMT_32bppRGBA8888 else 3
+    rng = np.random.default_rng(29)
+    rgb = Image(fmt, w, h, align=4 if w % 4 == 0 else 1)
+    rgb.buf[:] = rng.integers(0, 256, rgb.buf.size, dtype=np.uint8)
+    packed = np.ascontiguousarray(rgb.valid(0).view(np.uint8).reshape(h, -1)[:, : w * bpp])
+    rgb888 = packed if bpp == 3 else np.ascontiguousarray(packed.reshape(h, w, 4)[:, :, :3].reshape(h, w * 3))
+    want = L.jpeg_rgb_to_ycc_port(rgb888, w, w, h)
+    for src in (rgb, rgb.to("cuda:0")):
+        ycc = uhdr.jpeg_rgb_to_ycc(src)
+        uhdr.ctx.synchronize()
+        ycc = ycc.to_host()
+        assert ycc.raw.fmt == A.UHDR_IMG_FMT_24bppYCbCr444
+        for c in range(3):
+            assert np.array_equal(ycc.valid(c), want[c]), f"plane {c}"
+    # back: random YCbCr (covers out-of-gamut triples that exercise the clamps)
+    ycc = Image(A.UHDR_IMG_FMT_24bppYCbCr444, w, h, align=4 if w % 4 == 0 else 1)
+    ycc.buf[:] = rng.integers(0, 256, ycc.buf.size, dtype=np.uint8)
+    for variant in (0, 1):
+        want_rgb = L.jpeg_ycc_to_rgb_port(ycc.valid(0), ycc.valid(1), ycc.valid(2), out_bpp=bpp, variant=variant)
+        for src in (ycc, ycc.to("cuda:0")):
+            out = uhdr.jpeg_ycc_to_rgb(src, fmt, variant)
+            uhdr.ctx.synchronize()
+            got = out.to_host().valid(0).view(np.uint8).reshape(h, -1)[:, : w * bpp]
+            assert np.array_equal(got, want_rgb), f"variant {variant}"
+
+
+def test_decode_stage_feeds_apply_gainmap(uhdr):
+    """The 8f-1 chain on the device: coefficient blocks of the base image (Y, Cb, Cr at 4:2:0) and of a
+    Y400 gain map -> idct_dequant -> planes -> applyGainMap == the oracle on the oracle's own decode."""
+    import torch
+
+    w, h = 256, 128
+    f16 = A.UHDR_IMG_FMT_64bppRGBAHalfFloat
+    sdr = synth.make_sdr_yuv420(w, h, align=8, noise=0.05)
+    gm = synth.make_gainmap(w // 4, h // 4, 1, align=8)
+    md = synth.default_metadata()
+    qy, qc = uhdr.quant_table(95, False), uhdr.quant_table(95, True)
+    # host: what the Huffman decoder would hand over
+    coefs = [L.fdct_quant_port(np.ascontiguousarray(sdr.valid(c)), sdr.valid(c).shape[1], sdr.valid(c).shape[1] // 8,
+                               sdr.valid(c).shape[0] // 8, qy if c == 0 else qc) for c in range(3)]
+    coef_gm = L.fdct_quant_port(np.ascontiguousarray(gm.valid(0)), w // 4, w // 32, h // 32, qy)
+    # oracle chain
+    sdr_dec = Image(A.UHDR_IMG_FMT_12bppYCbCr420, w, h, sdr.raw.cg, sdr.raw.ct, sdr.raw.range, align=8)
+    for c in range(3):
+        sdr_dec.valid(c)[:] = L.idct_dequant_port(coefs[c], qy if c == 0 else qc)
+    gm_dec = Image(A.UHDR_IMG_FMT_8bppYCbCr400, w // 4, h // 4, gm.raw.cg, align=8)
+    gm_dec.valid(0)[:] = L.idct_dequant_port(coef_gm, qy)
+    want = L.apply_gainmap(oracle_kind(), sdr_dec, gm_dec, md, A.UHDR_CT_LINEAR)
+    # device chain: only the coefficients cross PCIe
+    dsdr = Image(A.UHDR_IMG_FMT_12bppYCbCr420, w, h, sdr.raw.cg, sdr.raw.ct, sdr.raw.range, align=8, device="cuda:0")
+    for c in range(3):
+        pl = dsdr.plane_tensor(c)
+        uhdr.idct_dequant(torch.from_numpy(coefs[c]).to("cuda:0"), qy if c == 0 else qc, plane=pl, stride=pl.shape[1])
+    dgm = Image(A.UHDR_IMG_FMT_8bppYCbCr400, w // 4, h // 4, gm.raw.cg, align=8, device="cuda:0")
+    pl = dgm.plane_tensor(0)
+    uhdr.idct_dequant(torch.from_numpy(coef_gm).to("cuda:0"), qy, plane=pl, stride=pl.shape[1])
+    dest = Image(f16, w, h, align=2, device="cuda:0")
+    uhdr.applyGainMap(dsdr, dgm, md, A.UHDR_CT_LINEAR, f16, A.FLT_MAX, dest)
+    uhdr.ctx.synchronize()
+    assert planes_equal(dsdr, sdr_dec) and planes_equal(dgm, gm_dec)
+    assert np.array_equal(dest.to_host().valid(0), want.valid(0))

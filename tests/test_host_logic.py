@@ -96,3 +96,22 @@ def test_lut_index_float_equivalence():
         subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-o", f"{d}/t", f"{d}/t.c"])
         out = subprocess.check_output([f"{d}/t"], text=True).split()
     assert out == ["0", "0"]
+
+
+def test_jpeg_rgb_to_ycc_constant_sets_are_equivalent():
+    """jccolor.c's rgb_ycc_convert: libjpeg 6b / libjpeg-turbo use 0.16874 / 0.33126 / 0.41869 / 0.08131,
+    IJG 9 the longer 0.168735892 ... -- the 16-bit fixed-point results are identical for every 8-bit
+    (r, g, b), which is why uhdr_hip_jpeg_rgb_to_ycc has no variant argument (the decode direction does)."""
+    fix = lambda x: int(x * 65536.0 + 0.5)
+    sets = [(0.29900, 0.58700, 0.11400, 0.16874, 0.33126, 0.50000, 0.41869, 0.08131),
+            (0.299, 0.587, 0.114, 0.168735892, 0.331264108, 0.5, 0.418687589, 0.081312411)]
+    r, g, b = np.meshgrid(*[np.arange(256, dtype=np.int64)] * 3, indexing="ij")
+    half, off = 1 << 15, 128 << 16
+    res = []
+    for c in sets:
+        y = (fix(c[0]) * r + fix(c[1]) * g + fix(c[2]) * b + half) >> 16
+        cb = (-fix(c[3]) * r - fix(c[4]) * g + fix(c[5]) * b + off + half - 1) >> 16
+        cr = (fix(c[5]) * r - fix(c[6]) * g - fix(c[7]) * b + off + half - 1) >> 16
+        res.append((y, cb, cr))
+    for a, bb in zip(*res):
+        assert np.array_equal(a, bb)

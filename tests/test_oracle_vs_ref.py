@@ -207,3 +207,64 @@ def test_fdct_quant_against_libjpeg(ref, quality):
     coefs, qt = _read_coefficients(ref, out[:n].tobytes())
     got = L.fdct_quant_port(gm.plane(0), gm.plane(0).shape[1], 12, 6, L.quant_table_port(quality, False))
     assert np.array_equal(got, coefs[0][:6, :12])
+
+
+def test_jpeg_rgb_map_colour_conversion_and_dct_against_libjpeg(ref):
+    """3-channel gain maps enter libjpeg as JCS_RGB (jpegencoderhelper.cpp:165-167): rgb_ycc_convert +
+    islow FDCT of each component == jpeg_read_coefficients of the reference helper's output.  Random RGB at
+    quality 100 (all divisors 1) makes a one-LSB colour-conversion error visible in the coefficients."""
+    w, h = 256, 128
+    gm = Image(A.UHDR_IMG_FMT_24bppRGB888, w, h, align=1)
+    gm.valid(0)[:] = np.random.default_rng(3).integers(0, 256, size=gm.valid(0).shape, dtype=np.uint8)
+    out = np.zeros(1 << 22, dtype=np.uint8)
+    for quality in (100, 90):
+        n = ref.ref_jpeg_compress(C.byref(gm.raw), quality, out.ctypes.data, out.size)
+        assert n > 0
+        coefs, qt = _read_coefficients(ref, out[:n].tobytes())
+        planes = L.jpeg_rgb_to_ycc_port(gm.valid(0), w, w, h)
+        for c in range(3):
+            q = L.quant_table_port(quality, c > 0)
+            assert np.array_equal(qt[c], q)
+            assert np.array_equal(L.fdct_quant_port(planes[c], w, w // 8, h // 8, q), coefs[c][: h // 8, : w // 8]), (quality, c)
+
+
+def _decode_with_reference(ref, jpeg: bytes, mode: int):
+    buf = np.frombuffer(jpeg, dtype=np.uint8)
+    dst = A.RawImage()
+    store = np.zeros(1 << 22, dtype=np.uint8)
+    assert ref.ref_jpeg_decompress(buf.ctypes.data, buf.size, mode, C.byref(dst), store.ctypes.data, store.size) == 0
+    return dst, store
+
+
+@pytest.mark.parametrize("quality", [95, 60, 100])
+def test_idct_dequant_against_libjpeg(ref, quality):
+    """dequantize + islow IDCT restatement == JpegDecoderHelper's raw-data decode (base image
+    4:2:0, Y400 map) and, with ycc_rgb_convert (IJG 9 constants = the library linked here), its RGB decode."""
+    w, h = 128, 64
+    out = np.zeros(1 << 20, dtype=np.uint8)
+    img = synth.make_sdr_yuv420(w, h, noise=0.08)
+    n = ref.ref_jpeg_compress(C.byref(img.raw), quality, out.ctypes.data, out.size)
+    jpeg = out[:n].tobytes()
+    coefs, qt = _read_coefficients(ref, jpeg)
+    dst, store = _decode_with_reference(ref, jpeg, 0)
+    assert dst.fmt == A.UHDR_IMG_FMT_12bppYCbCr420
+    off = 0
+    for c in range(3):
+        pw, ph = (w, h) if c == 0 else (w // 2, h // 2)
+        stride = dst.stride[c]
+        want = store[off: off + stride * ph].reshape(ph, stride)[:, :pw]
+        off += stride * ph
+        got = L.idct_dequant_port(coefs[c], qt[c])[:ph, :pw]
+        assert np.array_equal(got, want), f"component {c}"
+    # 3-channel map: IDCT of the three components, then libjpeg's colour conversion
+    gm = synth.make_gainmap(96, 48, 3)
+    n = ref.ref_jpeg_compress(C.byref(gm.raw), quality, out.ctypes.data, out.size)
+    jpeg = out[:n].tobytes()
+    coefs, qt = _read_coefficients(ref, jpeg)
+    dst, store = _decode_with_reference(ref, jpeg, 1)
+    bpp = 4 if dst.fmt == A.UHDR_IMG_FMT_32bppRGBA8888 else 3
+    assert dst.fmt in (A.UHDR_IMG_FMT_24bppRGB888, A.UHDR_IMG_FMT_32bppRGBA8888)
+    want = store[: dst.stride[0] * bpp * 48].reshape(48, dst.stride[0] * bpp)[:, : 96 * bpp]
+    planes = [L.idct_dequant_port(coefs[c], qt[c])[:48, :96] for c in range(3)]
+    got = L.jpeg_ycc_to_rgb_port(*planes, out_bpp=bpp, variant=1)
+    assert np.array_equal(got, want)
