@@ -320,6 +320,73 @@ def extras(ctx, u, device):
     coef = torch.empty((h // 8, w // 8, 64), dtype=torch.int16, device=device)
     ms = time_kernel(ctx, lambda: u.fdct_quant(plane, sdr.layout[0][1], w // 8, h // 8, qt, coef), iters=5, warm=2)
     res["fdct_quant_4k_luma"] = {"us": round(ms * 1e3, 1), "Mpx/s": round(w * h / (ms / 1e3) / 1e6, 1), "GB/s": round(3.0 * w * h / (ms / 1e3) / 1e9, 1)}
+    dec_plane = torch.empty((h, w), dtype=torch.uint8, device=device)
+    ms = time_kernel(ctx, lambda: u.idct_dequant(coef, qt, plane=dec_plane, stride=w), iters=5, warm=2)
+    res["idct_dequant_4k_luma"] = {"us": round(ms * 1e3, 1), "Mpx/s": round(w * h / (ms / 1e3) / 1e6, 1), "GB/s": round(3.0 * w * h / (ms / 1e3) / 1e9, 1)}
+
+    # ---- whole stage chains, device resident (sum of the kernels' HIP-event durations per pass) ----------------
+    def blocks(n):
+        return (n + 7) // 8
+
+    def fdct_planes(img, planes, tables):
+        for c in planes:
+            rows, stride, wv = img.layout[c]
+            u.fdct_quant(img.plane_tensor(c), stride, wv // 8, rows // 8, tables[c])
+
+    qy, qc = u.quant_table(95, False), u.quant_table(95, True)
+    # (1) API-1 encode, 4K P010 + 4:2:0 (BASELINE config 1/4 shape on one GPU): two-pass 3-channel map,
+    #     convertYuv of the base to BT.601, FDCT of base (Y, Cb, Cr) and of the map (libjpeg rgb->ycc, 3 planes)
+    base = sdr.clone()
+
+    def api1():
+        md_, gm_ = enc.generateGainMap(sdr, hdr)
+        u.convertYuv(base, A.UHDR_CG_BT_709, A.UHDR_CG_DISPLAY_P3)
+        fdct_planes(base, (0, 1, 2), (qy, qc, qc))
+        fdct_planes(u.jpeg_rgb_to_ycc(gm_), (0, 1, 2), (qy, qc, qc))
+
+    ms = time_kernel(ctx, api1, iters=4, warm=2)
+    res["encode_api1_4k_p010_420_2pass_3ch_chain"] = {"us": round(ms * 1e3, 1), "Mpx/s": round(w * h / (ms / 1e3) / 1e6, 1),
+                                                       "stages": "generate(2 pass) + convertYuv + fdct(base 3 planes) + rgb_to_ycc + fdct(map 3 planes); entropy coding not included"}
+    # (2) API-0 encode, 8K RGBA1010102 PQ (BASELINE config 3): tonemap, one-pass max-RGB 3-channel map, RGB->YCbCr 4:4:4, FDCTs
+    w8, h8 = 7680, 4320
+    hdr8 = synth.make_hdr_rgba1010102(w8, h8, ct=A.UHDR_CT_PQ).to(device)
+    sdr8 = Image(A.UHDR_IMG_FMT_32bppRGBA8888, w8, h8, align=64, device=device)
+    api0_enc = UltraHdr(ctx=ctx, mapDimensionScaleFactor=1, useMultiChannelGainMap=True, preset=A.UHDR_USAGE_REALTIME)
+
+    def api0():
+        u.toneMap(hdr8, sdr8)
+        md_, gm_ = api0_enc.generateGainMap(sdr8, hdr8, False, False)
+        fdct_planes(u.convert_raw_input_to_ycbcr(sdr8, False), (0, 1, 2), (qy, qc, qc))
+        fdct_planes(u.jpeg_rgb_to_ycc(gm_), (0, 1, 2), (qy, qc, qc))
+
+    ms = time_kernel(ctx, api0, iters=3, warm=1)
+    res["encode_api0_8k_rgba1010102_chain"] = {"us": round(ms * 1e3, 1), "Mpx/s": round(w8 * h8 / (ms / 1e3) / 1e6, 1),
+                                                "GB/s_unfused_44B_per_px": round(44.0 * w8 * h8 / (ms / 1e3) / 1e9, 1),
+                                                "stages": "tonemap + generate(1 pass, max-RGB) + rgb->ycbcr444 + fdct(base 3) + rgb_to_ycc + fdct(map 3); entropy coding not included"}
+    del hdr8, sdr8
+    torch.cuda.empty_cache()
+    # (3) decode chain, 4K: coefficient blocks -> IDCT (Y, Cb, Cr, Y400 map s=4) -> applyGainMap -> F16
+    dsdr = Image(A.UHDR_IMG_FMT_12bppYCbCr420, w, h, A.UHDR_CG_BT_709, A.UHDR_CT_SRGB, A.UHDR_CR_FULL_RANGE, align=64, device=device)
+    mw, mh = w // 4, (h // 4 + 7) // 8 * 8  # 960 x 544: the block grid of the 960 x 540 map
+    dgm = Image(A.UHDR_IMG_FMT_8bppYCbCr400, mw, mh, A.UHDR_CG_BT_2100, align=64, device=device)
+    cf = [torch.zeros((blocks(r), blocks(wv), 64), dtype=torch.int16, device=device) for (r, _, wv) in dsdr.layout]
+    cfm = torch.zeros((mh // 8, mw // 8, 64), dtype=torch.int16, device=device)
+    for t in cf + [cfm]:
+        t[..., 0] = 37  # a DC-only image is as expensive as any other for this kernel
+    dst4 = Image(f16, w, h, align=64, device=device)
+    dgm_view = Image(A.UHDR_IMG_FMT_8bppYCbCr400, mw, h // 4, A.UHDR_CG_BT_2100, align=64, device=device)
+
+    def decode_chain():
+        for c in range(3):
+            rows, stride, wv = dsdr.layout[c]
+            u.idct_dequant(cf[c], qy if c == 0 else qc, plane=dsdr.plane_tensor(c), stride=stride)
+        u.idct_dequant(cfm, qy, plane=dgm.plane_tensor(0), stride=dgm.layout[0][1])
+        dgm_view.raw.planes[0] = dgm.raw.planes[0]
+        u.applyGainMap(dsdr, dgm_view, md, A.UHDR_CT_LINEAR, f16, A.FLT_MAX, dst4)
+
+    ms = time_kernel(ctx, decode_chain, iters=5, warm=2)
+    res["decode_chain_4k_idct_plus_apply_mapA"] = {"us": round(ms * 1e3, 1), "Mpx/s": round(w * h / (ms / 1e3) / 1e6, 1),
+                                                    "stages": "idct_dequant(Y, Cb, Cr, Y400 map) + applyGainMap -> RGBA_F16; Huffman decode not included"}
     return res
 
 

@@ -41,6 +41,27 @@ def main():
         for c in range(3):
             out[f"jpeg_q{q}/coef{c}"] = coefs[c]
             out[f"jpeg_q{q}/qt{c}"] = qt[c]
+        # decode stage: the planes JpegDecoderHelper (libjpeg, JDCT_ISLOW, raw-data mode) returns for that JPEG
+        from test_oracle_vs_ref import _decode_with_reference
+
+        dst, store = _decode_with_reference(L.ref(), buf[:n].tobytes(), 0)
+        off = 0
+        for c in range(3):
+            pw, ph = (G.W, G.H) if c == 0 else (G.W // 2, G.H // 2)
+            st = dst.stride[c]
+            out[f"jpeg_q{q}/dec{c}"] = store[off: off + st * ph].reshape(ph, st)[:, :pw].copy()
+            off += st * ph
+        # 3-channel gain map: JCS_RGB in, RGB scanlines out (IJG 9 colour constants = the library linked here)
+        gm = G.jpeg_rgb_map()
+        n = L.ref().ref_jpeg_compress(C.byref(gm.raw), q, buf.ctypes.data, buf.size)
+        coefs, qt = _read_coefficients(L.ref(), buf[:n].tobytes())
+        for c in range(3):
+            out[f"jpegrgb_q{q}/coef{c}"] = coefs[c]
+            out[f"jpegrgb_q{q}/qt{c}"] = qt[c]
+        dst, store = _decode_with_reference(L.ref(), buf[:n].tobytes(), 1)
+        bpp = 4 if dst.fmt == A.UHDR_IMG_FMT_32bppRGBA8888 else 3
+        out[f"jpegrgb_q{q}/dec_rgb"] = store[: dst.stride[0] * bpp * gm.h].reshape(gm.h, dst.stride[0] * bpp)[:, : gm.w * bpp].copy()
+        out[f"jpegrgb_q{q}/dec_bpp"] = np.array([bpp])
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hotpath_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")

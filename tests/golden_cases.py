@@ -15,6 +15,10 @@ def jpeg_image():
     return synth.make_sdr_yuv420(W, H, seed=4242, noise=0.08)
 
 
+def jpeg_rgb_map():
+    return synth.make_gainmap(96, 48, 3, seed=4343)
+
+
 def cases():
     c = {}
     for tag, (ch, alpha, scale) in {"y400_s4": (1, False, 4), "rgb_s1": (3, False, 1), "rgba_s1": (3, True, 1), "y400_s2": (1, False, 2)}.items():

@@ -42,6 +42,24 @@ def test_oracle_dct_reproduces_libjpeg_coefficients(q):
         assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("q", [95, 50])
+def test_oracle_decode_stage_reproduces_libjpeg(q):
+    """dequant + IDCT (+ colour conversion for the RGB map) == what the reference's JpegDecoderHelper got
+    from libjpeg for the same JPEGs (vectors generated in the build container, IJG libjpeg 9d)."""
+    for c in range(3):
+        got = L.idct_dequant_port(GOLD[f"jpeg_q{q}/coef{c}"], GOLD[f"jpeg_q{q}/qt{c}"])
+        want = GOLD[f"jpeg_q{q}/dec{c}"]
+        assert np.array_equal(got[: want.shape[0], : want.shape[1]], want)
+    gm = G.jpeg_rgb_map()
+    planes = L.jpeg_rgb_to_ycc_port(gm.valid(0), gm.w, gm.w, gm.h)
+    for c in range(3):
+        qt = GOLD[f"jpegrgb_q{q}/qt{c}"]
+        assert np.array_equal(L.fdct_quant_port(planes[c], gm.w, gm.w // 8, gm.h // 8, qt), GOLD[f"jpegrgb_q{q}/coef{c}"])
+    dec = [L.idct_dequant_port(GOLD[f"jpegrgb_q{q}/coef{c}"], GOLD[f"jpegrgb_q{q}/qt{c}"])[: gm.h, : gm.w] for c in range(3)]
+    bpp = int(GOLD[f"jpegrgb_q{q}/dec_bpp"][0])
+    assert np.array_equal(L.jpeg_ycc_to_rgb_port(*dec, out_bpp=bpp, variant=1), GOLD[f"jpegrgb_q{q}/dec_rgb"])
+
+
 # ---- GPU ------------------------------------------------------------------------------------------
 EXACT_OPS = {"convert_yuv", "raw2ycc"}
 
@@ -56,7 +74,7 @@ def _close(got, want, what):
     else:
         g, w = got.astype(np.int64), want.astype(np.int64)
     d = np.abs(g - w)
-    assert d.max() <= 1 and (d != 0).mean() <= 0.01, (what, int(d.max()), float((d != 0).mean()))
+    assert d.max() <= 1 and (d != 0).mean() <= 1e-4, (what, int(d.max()), float((d != 0).mean()))
 
 
 @pytest.mark.gpu
@@ -120,3 +138,29 @@ def test_hip_dct_reproduces_libjpeg_coefficients(hip_ctx, q):
         plane = np.ascontiguousarray(img.plane(c))
         got = u.fdct_quant(plane, plane.shape[1], want.shape[1], want.shape[0], qt)
         assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("q", [95, 50])
+def test_hip_decode_stage_reproduces_libjpeg(hip_ctx, q):
+    from libultrahdr_amd.ultrahdr import UltraHdr
+
+    u = UltraHdr(ctx=hip_ctx)
+    for c in range(3):
+        got = u.idct_dequant(GOLD[f"jpeg_q{q}/coef{c}"], GOLD[f"jpeg_q{q}/qt{c}"])
+        want = GOLD[f"jpeg_q{q}/dec{c}"]
+        assert np.array_equal(got[: want.shape[0], : want.shape[1]], want)
+    gm = G.jpeg_rgb_map()
+    ycc = u.jpeg_rgb_to_ycc(gm)
+    for c in range(3):
+        qt = GOLD[f"jpegrgb_q{q}/qt{c}"]
+        plane = np.ascontiguousarray(ycc.plane(c))
+        assert np.array_equal(u.fdct_quant(plane, plane.shape[1], gm.w // 8, gm.h // 8, qt), GOLD[f"jpegrgb_q{q}/coef{c}"])
+    dec = Image(A.UHDR_IMG_FMT_24bppYCbCr444, gm.w, gm.h, align=8)
+    for c in range(3):
+        dec.valid(c)[:] = u.idct_dequant(GOLD[f"jpegrgb_q{q}/coef{c}"], GOLD[f"jpegrgb_q{q}/qt{c}"])[: gm.h, : gm.w]
+    bpp = int(GOLD[f"jpegrgb_q{q}/dec_bpp"][0])
+    fmt = A.UHDR_IMG_FMT_32bppRGBA8888 if bpp == 4 else A.UHDR_IMG_FMT_24bppRGB888
+    rgb = u.jpeg_ycc_to_rgb(dec, fmt, libjpeg_variant=1)
+    got = rgb.valid(0).view(np.uint8).reshape(gm.h, -1)[:, : gm.w * bpp]
+    assert np.array_equal(got, GOLD[f"jpegrgb_q{q}/dec_rgb"])
