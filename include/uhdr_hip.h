@@ -230,6 +230,8 @@ int uhdr_hip_oetf_code_thresholds(uhdr_color_transfer_t ct, float thresholds[102
  * the same source the device compiles) on the host so it can be compared with libm without a GPU.
  *   fn 0: srgbOetf(in)                      (gainmapmath.cpp:139-148, powf replaced)
  *   fn 1: (float)log2((double)in)           (gainmapmath.cpp:767, 774, double log2 replaced)
+ *   fn 2: division by a library constant: in[0] = b, out[0] = 1/b, out[i] = in[i] / b by the kernels'
+ *         reciprocal-multiply-and-correct sequence (csrc/device_math.h div_const), i >= 1
  * Returns 0, or -1 for an unknown fn. */
 int uhdr_hip_exact_math_eval(int fn, const float* in, float* out, size_t n);
 /* islow 8x8 FDCT + quantize of one 8-bit plane.  Reads blocks_w*8 x blocks_h*8 samples (the

@@ -35,39 +35,34 @@ struct OutPix<0> {
   using type = uint2;
 };
 
-// 10-bit output code of the HLG (OUT 1) / PQ (OUT 2) tail for a clamped v in [0,1]:
+// 10-bit output code of the HLG tail for a clamped v in [0,1]:
 //   code(v) = max{ c : T[c] <= v }   with the host-built thresholds T (host_tables.cpp), T[0] = 0.
-// Fast path: an estimate c0 from hardware log2/exp2 (with the reference's 65536-node LUT
-// quantisation emulated) is normally within one code of the truth, so the answer is found by three
-// compares in the window T[lo+1..lo+3], lo = c0 - 1, and the window is VERIFIED against T[lo] and
-// T[lo+4].  Where the verification fails -- near black the LUT quantisation makes the code jump by
-// many steps, and an estimate may land on the wrong side of a node -- a 10-step binary search over
-// T gives the exact code.  Either way the result equals what the reference computes with the host
-// libm: no per-pixel powf, no 256 KiB table gather.
+// T layout: [0, kOetfThrN) float thresholds (entries above the last reachable code are 2.0f), then
+// kOetfEstN packed bucket entries E[k] = c_lo | needs_search << 15 | c_hi << 16 for bucket
+// k = bits(v) >> 18 (4065 buckets of <= 3 % relative width cover [0,1]); c_lo / c_hi are the codes at
+// the bucket's ends.  Linear interpolation on the low 18 bits estimates the code; the two
+// thresholds around the estimate settle it.  The host has PROVEN, bucket by bucket, that this gives
+// the exact code (the estimate never strays more than one step; see make_threshold_block) and flags
+// the buckets where it does not -- there a 10-step binary search over T runs instead.  Either way
+// the result is what the reference computes with the host libm: no per-pixel powf, no 256 KiB gather.
 __device__ __forceinline__ uint32_t oetf_code_search(float v, const float* T) {
   uint32_t lo = 0;
 #pragma unroll
   for (uint32_t step = 512; step; step >>= 1)
-    if (v >= T[lo + step]) lo += step;  // lo + step <= 1023; entries above the last reachable code are 2.0f
+    if (v >= T[lo + step]) lo += step;  // lo + step <= 1023
   return lo;
 }
-// T layout: [0, kOetfThrN) float thresholds, then kOetfEstN packed bucket entries
-// E[k] = F(k << 18) | F((k+1) << 18) << 16: the codes at both ends of bucket k = bits(v) >> 18
-// (4065 buckets of <= 3 % relative width cover [0,1]).  Linear interpolation inside the bucket on
-// the low mantissa bits gives the code to within a step; the window around it is verified and the
-// binary search is the (rare, near-black) fallback.  No transcendental per pixel.
 template <int OUT>
 __device__ __forceinline__ uint32_t oetf_code(float v, const float* T) {
   const uint32_t bits = __float_as_uint(v);
   const uint32_t e = ((const uint32_t*)(T + kOetfThrN))[bits >> 18];
-  const uint32_t c_lo = e & 0xffffu, c_hi = e >> 16;
-  const uint32_t est = c_lo + (((c_hi - c_lo) * (bits & 0x3ffffu)) >> 18);
-  const uint32_t lo = min(max(est, c_lo + 1) - 1, 1022u);  // >= c_lo, so T[lo] <= v unless the estimate overshoots
-  const float* t = T + lo;
-  const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4];
-  const uint32_t cnt = (v >= t1 ? 1u : 0u) + (v >= t2 ? 1u : 0u) + (v >= t3 ? 1u : 0u);
-  uint32_t code = lo + cnt;
-  if (!(v >= t0) || (cnt == 3 && v >= t4)) code = oetf_code_search(v, T);
+  const uint32_t c_lo = e & 0x7fffu, c_hi = e >> 16;
+  const uint32_t est = c_lo + (__umul24(c_hi - c_lo, bits & 0x3ffffu) >> 18);  // 10-bit x 18-bit: exact in the 24-bit multiplier
+  const float t0 = T[est], t1 = T[est + 1];
+  uint32_t code = est + (v >= t1 ? 1u : 0u) - (v < t0 ? 1u : 0u);
+  if (__builtin_amdgcn_ballot_w64((e & 0x8000u) != 0) != 0) {  // some lane sits in a flagged bucket
+    if (e & 0x8000u) code = oetf_code_search(v, T);
+  }
   return code;
 }
 __device__ __forceinline__ uint32_t pack_codes_1010102(uint32_t r, uint32_t g, uint32_t b) {
@@ -95,9 +90,9 @@ __device__ __forceinline__ typename OutPix<OUT>::type finish_pixel(Color3 lin, f
     return pack_rgba_f16(clamp_linear(h.r), clamp_linear(h.g), clamp_linear(h.b));
   } else {
     const float peak = (OUT == 1) ? 1000.0f : 10000.0f;  // kHlgMaxNits / kPqMaxNits
-    h.r = h.r * 203.0f / peak;                            // two roundings, as written in the reference
-    h.g = h.g * 203.0f / peak;
-    h.b = h.b * 203.0f / peak;
+    h.r = div_const(h.r * 203.0f, peak, 1.0f / peak);     // two roundings, as written in the reference
+    h.g = div_const(h.g * 203.0f, peak, 1.0f / peak);
+    h.b = div_const(h.b * 203.0f, peak, 1.0f / peak);
     if (p.hdr_gamut_on) h = mat3_apply(h, p.gamut);
     if constexpr (OUT == 1) {
       // clampPixelFloat, hlgInverseOotfApprox (powf), OETF LUT, colorToRgba1010102: one threshold lookup each
@@ -607,9 +602,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
         stream_store<u4v>(dpx, (u4v){o.x, o.y, o.z, o.w});
       } else {
         const float peak = (OUT == 1) ? 1000.0f : 10000.0f;  // kHlgMaxNits / kPqMaxNits
-        hr = hr * 203.0f / peak;                              // two roundings, as written in the reference
-        hg = hg * 203.0f / peak;
-        hb = hb * 203.0f / peak;
+        const f2 p203 = splat(203.0f), pk = splat(peak), rpk = splat(1.0f / peak);
+        // (x * 203) / peak, two roundings as written in the reference; the division is div_const's
+        // exact three-instruction form (device_math.h), packed
+        auto div_peak = [&](f2 x) {
+          const f2 a = x * p203, q0 = a * rpk;
+          const f2 r = __builtin_elementwise_fma(-pk, q0, a);
+          return __builtin_elementwise_fma(r, rpk, q0);
+        };
+        hr = div_peak(hr);
+        hg = div_peak(hg);
+        hb = div_peak(hb);
         if (p.hdr_gamut_on) {
           const Mat3& m = p.gamut;
           const f2 nr = m.m[0] * hr + m.m[1] * hg + m.m[2] * hb;

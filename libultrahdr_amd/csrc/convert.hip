@@ -20,13 +20,14 @@ __device__ __forceinline__ uint8_t st8(float v) {  // static_cast<uint8_t>(CLIP3
 // One thread per 2x2 quad.  In place is safe: a quad reads only its own 4 lumas + 1 chroma pair.
 __global__ __launch_bounds__(kBlock) void transform_yuv420_kernel(const YuvXformParams p) {
   const uint32_t qw = p.img.w / 2, qh = p.img.h / 2;
-  const size_t total = (size_t)qw * qh;
+  const uint32_t tiles_x = (qw + kBlock - 1) / kBlock, tiles = tiles_x * qh;
   uint8_t* yp = (uint8_t*)p.img.p[0];
   uint8_t* up = (uint8_t*)p.img.p[1];
   uint8_t* vp = (uint8_t*)p.img.p[2];
   const size_t sy = p.img.stride[0];
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
-    const uint32_t qy = (uint32_t)(i / qw), qx = (uint32_t)(i - (size_t)qy * qw);
+  for (uint32_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const uint32_t qy = t / tiles_x, qx = (t - qy * tiles_x) * kBlock + threadIdx.x;
+    if (qx >= qw) continue;
     uint8_t* y0 = yp + (size_t)(qy * 2) * sy + qx * 2;
     uint8_t* y1 = y0 + sy;
     uint8_t* uq = up + (size_t)qy * p.img.stride[1] + qx;
@@ -50,9 +51,10 @@ __global__ __launch_bounds__(kBlock) void transform_yuv420_kernel(const YuvXform
 
 __global__ __launch_bounds__(kBlock) void transform_yuv444_kernel(const YuvXformParams p) {
   const uint32_t w = p.img.w, h = p.img.h;
-  const size_t total = (size_t)w * h;
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
-    const uint32_t y = (uint32_t)(i / w), x = (uint32_t)(i - (size_t)y * w);
+  const uint32_t tiles_x = (w + kBlock - 1) / kBlock, tiles = tiles_x * h;
+  for (uint32_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const uint32_t y = t / tiles_x, x = (t - y * tiles_x) * kBlock + threadIdx.x;
+    if (x >= w) continue;
     uint8_t* yq = (uint8_t*)p.img.p[0] + (size_t)y * p.img.stride[0] + x;
     uint8_t* uq = (uint8_t*)p.img.p[1] + (size_t)y * p.img.stride[1] + x;
     uint8_t* vq = (uint8_t*)p.img.p[2] + (size_t)y * p.img.stride[2] + x;
@@ -69,15 +71,19 @@ __device__ __forceinline__ float clipf(float v, float hi) { return (v < 0.0f) ? 
 // chroma-subsampled variants: one thread per 2x2 quad; 4:4:4 variants: one thread per pixel
 template <bool TEN_BIT>
 __global__ __launch_bounds__(kBlock) void rgb_to_ycbcr420_kernel(const RgbToYcbcrParams p) {
+  __shared__ UnormTables ut;  // sample / 255.0f, sample / 1023.0f (the reference divides)
+  fill_unorm_tables(ut, threadIdx.x, kBlock);
+  __syncthreads();
   const uint32_t qw = p.src.w / 2, qh = p.src.h / 2;
-  const size_t total = (size_t)qw * qh;
+  const uint32_t tiles_x = (qw + kBlock - 1) / kBlock, tiles = tiles_x * qh;
   const float scale = TEN_BIT ? 1023.0f : 255.0f;
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
-    const uint32_t qy = (uint32_t)(i / qw), qx = (uint32_t)(i - (size_t)qy * qw);
+  for (uint32_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const uint32_t qy = t / tiles_x, qx = (t - qy * tiles_x) * kBlock + threadIdx.x;
+    if (qx >= qw) continue;
     Color3 q[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      q[k] = rgb_to_yuv(fetch_pixel(p.src, qx * 2 + (k & 1), qy * 2 + (k >> 1)), p.k);
+      q[k] = rgb_to_yuv(fetch_pixel(p.src, qx * 2 + (k & 1), qy * 2 + (k >> 1), &ut), p.k);
       q[k].r = clipf(q[k].r * scale + 0.5f, scale);
     }
     float u = (q[0].g + q[1].g + q[2].g + q[3].g) / 4;
@@ -109,11 +115,15 @@ __global__ __launch_bounds__(kBlock) void rgb_to_ycbcr420_kernel(const RgbToYcbc
 
 template <bool TEN_BIT>
 __global__ __launch_bounds__(kBlock) void rgb_to_ycbcr444_kernel(const RgbToYcbcrParams p) {
+  __shared__ UnormTables ut;
+  fill_unorm_tables(ut, threadIdx.x, kBlock);
+  __syncthreads();
   const uint32_t w = p.src.w, h = p.src.h;
-  const size_t total = (size_t)w * h;
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
-    const uint32_t y = (uint32_t)(i / w), x = (uint32_t)(i - (size_t)y * w);
-    const Color3 q = rgb_to_yuv(fetch_pixel(p.src, x, y), p.k);
+  const uint32_t tiles_x = (w + kBlock - 1) / kBlock, tiles = tiles_x * h;
+  for (uint32_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const uint32_t y = t / tiles_x, x = (t - y * tiles_x) * kBlock + threadIdx.x;
+    if (x >= w) continue;
+    const Color3 q = rgb_to_yuv(fetch_pixel(p.src, x, y, &ut), p.k);
     if constexpr (TEN_BIT) {  // gainmapmath.cpp:1386-1402
       ((uint16_t*)p.dst.p[0])[(size_t)y * p.dst.stride[0] + x] = (uint16_t)clipf((q.r * 1023.0f) + 0.5f, 1023.0f);
       ((uint16_t*)p.dst.p[1])[(size_t)y * p.dst.stride[1] + x] = (uint16_t)clipf((q.g * 1023.0f) + 512.0f + 0.5f, 1023.0f);

@@ -122,7 +122,27 @@ struct Yuv2Rgb {  // coefficients built on the host exactly as the reference's s
 };
 struct Rgb2Yuv {
   float yr, yg, yb, cb, cr;
+  float rcb, rcr;  // 1.0f / cb, 1.0f / cr (correctly rounded, host-computed) for div_const
 };
+
+// a / b for a divisor that is a library constant: q0 = a * (1/b), one FMA residual, one FMA
+// correction -- three full-rate instructions instead of the ~11 of an IEEE division.  For EVERY
+// divisor the library uses this way (the chroma scale factors of the three gamuts, 1000, 10000, the
+// squared tone-map headrooms) the result equals the correctly rounded quotient for every float
+// mantissa: tests/test_exact_math.py::test_div_const_is_exact_for_every_library_constant runs all
+// 2^23 of them per constant through this same source on the host (the sequence is scale invariant,
+// so one binade covers all normal operands).  Only the sign of a zero quotient can differ (-0 / b
+// gives +0), which no consumer observes.
+#if defined(__HIPCC__)
+#define UHDR_HD_MATH __host__ __device__ __forceinline__
+#else
+#define UHDR_HD_MATH inline
+#endif
+UHDR_HD_MATH float div_const(float a, float b, float rb) {
+  const float q0 = a * rb;
+  const float r = __builtin_fmaf(-b, q0, a);
+  return __builtin_fmaf(r, rb, q0);
+}
 // *YuvToRgb (gainmapmath.cpp:107-111, 177-181, 229-233)
 __device__ __forceinline__ Color3 yuv_to_rgb(float y, float u, float v, const Yuv2Rgb& k) {
   Color3 o;
@@ -134,7 +154,7 @@ __device__ __forceinline__ Color3 yuv_to_rgb(float y, float u, float v, const Yu
 // *RgbToYuv (gainmapmath.cpp:96-99, 166-169, 196-199)
 __device__ __forceinline__ Color3 rgb_to_yuv(Color3 e, const Rgb2Yuv& k) {
   float y = k.yr * e.r + k.yg * e.g + k.yb * e.b;
-  Color3 o = {y, (e.b - y) / k.cb, (e.r - y) / k.cr};
+  Color3 o = {y, div_const(e.b - y, k.cb, k.rcb), div_const(e.r - y, k.cr, k.rcr)};
   return o;
 }
 // ConvertGamut / yuvColorGamutConversion (gainmapmath.cpp:617-621, 676-684): row . (r,g,b)

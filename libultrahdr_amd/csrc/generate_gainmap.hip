@@ -28,6 +28,7 @@ struct GenLds {
   float srgb[kSrgbN];
   float hdr[kInvOetfN];
   double math[kMathTabDoubles];
+  UnormTables unorm;  // x / 255.0f, x / 1023.0f
 };
 
 // encodeGain (gainmapmath.cpp:758-771): log2 is the DOUBLE libm one in the reference build, the
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(kBlock) void generate_kernel(const GenParams p, flo
   if (p.hdr_inv_lut)
     for (uint32_t i = tid; i < (uint32_t)p.hdr_inv_n; i += kBlock) L.hdr[i] = p.hdr_inv_lut[i];
   for (uint32_t i = tid; i < kMathTabDoubles; i += kBlock) L.math[i] = p.math_tab[i];
+  fill_unorm_tables(L.unorm, tid, kBlock);
   __syncthreads();
 
   const uint32_t mw = p.map_w, mh = p.map_h;
@@ -70,13 +72,13 @@ __global__ __launch_bounds__(kBlock) void generate_kernel(const GenParams p, flo
   for (uint32_t t = blockIdx.x; t < tiles; t += gridDim.x) {
     const uint32_t y = t / tiles_x, x = (t - y * tiles_x) * kBlock + tid;
     if (x >= mw) continue;
-    Color3 s = sample_box<SDRF>(p.sdr, p.scale, x, y);
+    Color3 s = sample_box<SDRF>(p.sdr, p.scale, x, y, &L.unorm);
     if (!p.sdr_is_rgb) s = yuv_to_rgb(s.r, s.g, s.b, p.sdr_yuv);
     Color3 sl = {L.srgb[lut_index_f32<kSrgbN>(s.r)], L.srgb[lut_index_f32<kSrgbN>(s.g)], L.srgb[lut_index_f32<kSrgbN>(s.b)]};
     if (p.sdr_gamut_on) sl = mat3_apply(sl, p.sdr_gamut);
     sl.r = clip_neg(sl.r); sl.g = clip_neg(sl.g); sl.b = clip_neg(sl.b);
 
-    Color3 h = sample_box<HDRF>(p.hdr, p.scale, x, y);
+    Color3 h = sample_box<HDRF>(p.hdr, p.scale, x, y, &L.unorm);
     if (!p.hdr_is_rgb) h = yuv_to_rgb(h.r, h.g, h.b, p.hdr_yuv);
     Color3 hl = h;  // linear input: identityConversion
     if (hdr_lut) {
@@ -206,7 +208,7 @@ int gen_grid(uint32_t tiles) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 1024;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    return cus * 6;  // 23 KB of LDS tables per workgroup: six fit in a CU's 160 KB
+    return cus * 5;  // 29 KB of LDS tables per workgroup: five fit in a CU's 160 KB
   }();
   uint32_t g = tiles < (uint32_t)resident ? tiles : (uint32_t)resident;
   if (g > kMaxGrid) g = kMaxGrid;

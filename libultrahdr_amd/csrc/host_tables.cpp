@@ -141,17 +141,46 @@ static std::vector<float> make_thresholds(int ct) {
   }
   return t;
 }
-// thresholds followed by the packed bucket end-point codes (see apply_gainmap.hip::oetf_code)
+// thresholds followed by the packed bucket entries (see apply_gainmap.hip::oetf_code):
+//   E[k] = c_lo | needs_search << 15 | c_hi << 16,  c_lo = F(k << 18), c_hi = F((k + 1) << 18)
+// The device estimates the code by linear interpolation between c_lo and c_hi on the low 18 bits and
+// settles it with the two thresholds around the estimate, which is right whenever the estimate is
+// within one code of the truth.  Both the estimate (monotone inside a bucket) and the truth (a step
+// function) are checked here at every point where either can change -- the bucket's first and last
+// float and, for every threshold inside it, the threshold and its predecessor; a bucket in which
+// any probe fails gets the needs_search flag and the device uses the binary search there.
+static uint32_t device_fast_code(const std::vector<float>& t, uint32_t c_lo, uint32_t c_hi, float v) {
+  uint32_t bits;
+  memcpy(&bits, &v, 4);
+  const uint32_t est = c_lo + (((c_hi - c_lo) * (bits & 0x3ffffu)) >> 18);
+  return est + (v >= t[est + 1] ? 1u : 0u) - (v < t[est] ? 1u : 0u);
+}
 static std::vector<float> make_threshold_block(int ct) {
   std::vector<float> t = make_thresholds(ct);
-  auto code_at = [&](uint32_t k) -> uint32_t {
-    const uint32_t u = k << 18;
-    float f;
-    memcpy(&f, &u, 4);
-    return (f <= 1.0f) ? oetf_code_host(ct, f) : oetf_code_host(ct, 1.0f);
-  };
+  auto flt = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
+  auto bits_of = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+  const uint32_t one = bits_of(1.0f);
+  auto code_at = [&](uint32_t u) -> uint32_t { return oetf_code_host(ct, flt(u < one ? u : one)); };
   std::vector<uint32_t> e((size_t)kOetfEstN);
-  for (uint32_t k = 0; k < (uint32_t)kOetfEstN; k++) e[k] = code_at(k) | (code_at(k + 1) << 16);
+  std::vector<std::vector<uint32_t>> probes((size_t)kOetfEstN);
+  for (uint32_t c = 1; c < 1024; c++) {
+    if (!(t[c] <= 1.0f)) break;
+    const uint32_t u = bits_of(t[c]);
+    probes[u >> 18].push_back(u);
+    if (u > 0) probes[(u - 1) >> 18].push_back(u - 1);
+  }
+  for (uint32_t k = 0; k < (uint32_t)kOetfEstN; k++) {
+    const uint32_t first = k << 18, last = first + 0x3ffffu;
+    const uint32_t c_lo = code_at(first), c_hi = code_at(first + 0x40000u);
+    bool ok = true;
+    if (first <= one) {
+      probes[k].push_back(first);
+      probes[k].push_back(last < one ? last : one);
+      for (uint32_t u : probes[k])
+        if (u <= one && device_fast_code(t, c_lo, c_hi, flt(u)) != oetf_code_host(ct, flt(u))) ok = false;
+    }
+    e[k] = c_lo | (ok ? 0u : 0x8000u) | (c_hi << 16);
+  }
   t.resize((size_t)kOetfTabFloats, 0.0f);
   memcpy(t.data() + kOetfThrN, e.data(), (size_t)kOetfEstN * sizeof(uint32_t));
   return t;
@@ -221,6 +250,8 @@ Rgb2Yuv rgb2yuv_coeffs(int cg) {
     k.yr = kBt2100R; k.yg = kBt2100G; k.yb = kBt2100B;
     k.cb = 2 * (1 - kBt2100B); k.cr = 2 * (1 - kBt2100R);
   }
+  k.rcb = 1.0f / k.cb;
+  k.rcr = 1.0f / k.cr;
   return k;
 }
 void luminance_coeffs(int cg, float out[3]) {

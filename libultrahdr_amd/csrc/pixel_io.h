@@ -9,8 +9,23 @@ namespace uhdr {
 // Returns the pixel as the reference's Color: (y,u,v) for YCbCr formats, (r,g,b) for RGB ones.
 // FMT >= 0 fixes the format at compile time (the encode kernels are instantiated per format so the
 // switch folds away); FMT < 0 reads it from the view.
+//
+// The reference normalises RGBA8888 / RGB888 samples with a float DIVISION by 255.0f and full-range
+// 10-bit samples by 1023.0f (gainmapmath.cpp:461-481, 438-441); x * (1/255.0f) is not the same
+// float for every x.  UnormTables holds those quotients for every possible sample (filled with the
+// device's own correctly rounded division, see fill_unorm_tables): one LDS read instead of an
+// 11-instruction IEEE division per channel.  Pass nullptr to divide in place.
+struct UnormTables {
+  float u8[256];    // i / 255.0f
+  float u10[1024];  // i / 1023.0f
+};
+__device__ __forceinline__ void fill_unorm_tables(UnormTables& t, uint32_t tid, uint32_t nthreads) {
+  for (uint32_t i = tid; i < 256; i += nthreads) t.u8[i] = (float)i / 255.0f;
+  for (uint32_t i = tid; i < 1024; i += nthreads) t.u10[i] = (float)i / 1023.0f;
+}
+
 template <int FMT = -1>
-__device__ __forceinline__ Color3 fetch_pixel(const ImageView& im, uint32_t x, uint32_t y) {
+__device__ __forceinline__ Color3 fetch_pixel(const ImageView& im, uint32_t x, uint32_t y, const UnormTables* ut = nullptr) {
   Color3 c = {0.f, 0.f, 0.f};
   const int fmt_ = FMT >= 0 ? FMT : im.fmt;
   switch (fmt_) {
@@ -46,9 +61,15 @@ __device__ __forceinline__ Color3 fetch_pixel(const ImageView& im, uint32_t x, u
         vv = ((const uint16_t*)im.p[2])[(size_t)y * im.stride[2] + x];
       }
       if (im.range == UHDR_CR_FULL_RANGE) {
-        c.r = (float)yy / 1023.0f;
-        c.g = (float)uu / 1023.0f - 0.5f;
-        c.b = (float)vv / 1023.0f - 0.5f;
+        if (ut) {  // 10-bit samples: P010 carries them in the top bits (>> 6 above), 4:4:4 may exceed 1023 only if corrupt
+          c.r = ut->u10[yy & 1023];
+          c.g = ut->u10[uu & 1023] - 0.5f;
+          c.b = ut->u10[vv & 1023] - 0.5f;
+        } else {
+          c.r = (float)yy / 1023.0f;
+          c.g = (float)uu / 1023.0f - 0.5f;
+          c.b = (float)vv / 1023.0f - 0.5f;
+        }
       } else {
         c.r = (float)(yy - 64) * (1 / 876.0f);
         c.g = (float)(uu - 64) * (1 / 896.0f) - 0.5f;
@@ -58,23 +79,35 @@ __device__ __forceinline__ Color3 fetch_pixel(const ImageView& im, uint32_t x, u
     }
     case UHDR_IMG_FMT_24bppRGB888: {
       const uint8_t* q = (const uint8_t*)im.p[0] + (size_t)x * 3 + (size_t)y * im.stride[0] * 3;
-      c.r = (float)q[0] / 255.0f;
-      c.g = (float)q[1] / 255.0f;
-      c.b = (float)q[2] / 255.0f;
+      if (ut) {
+        c.r = ut->u8[q[0]]; c.g = ut->u8[q[1]]; c.b = ut->u8[q[2]];
+      } else {
+        c.r = (float)q[0] / 255.0f;
+        c.g = (float)q[1] / 255.0f;
+        c.b = (float)q[2] / 255.0f;
+      }
       break;
     }
     case UHDR_IMG_FMT_32bppRGBA8888: {
       const uint32_t v = ((const uint32_t*)im.p[0])[x + (size_t)y * im.stride[0]];
-      c.r = (float)(v & 0xff) / 255.0f;
-      c.g = (float)((v >> 8) & 0xff) / 255.0f;
-      c.b = (float)((v >> 16) & 0xff) / 255.0f;
+      if (ut) {
+        c.r = ut->u8[v & 0xff]; c.g = ut->u8[(v >> 8) & 0xff]; c.b = ut->u8[(v >> 16) & 0xff];
+      } else {
+        c.r = (float)(v & 0xff) / 255.0f;
+        c.g = (float)((v >> 8) & 0xff) / 255.0f;
+        c.b = (float)((v >> 16) & 0xff) / 255.0f;
+      }
       break;
     }
     case UHDR_IMG_FMT_32bppRGBA1010102: {
       const uint32_t v = ((const uint32_t*)im.p[0])[x + (size_t)y * im.stride[0]];
-      c.r = (float)(v & 0x3ff) / 1023.0f;
-      c.g = (float)((v >> 10) & 0x3ff) / 1023.0f;
-      c.b = (float)((v >> 20) & 0x3ff) / 1023.0f;
+      if (ut) {
+        c.r = ut->u10[v & 0x3ff]; c.g = ut->u10[(v >> 10) & 0x3ff]; c.b = ut->u10[(v >> 20) & 0x3ff];
+      } else {
+        c.r = (float)(v & 0x3ff) / 1023.0f;
+        c.g = (float)((v >> 10) & 0x3ff) / 1023.0f;
+        c.b = (float)((v >> 20) & 0x3ff) / 1023.0f;
+      }
       break;
     }
     case UHDR_IMG_FMT_64bppRGBAHalfFloat: {
@@ -91,14 +124,14 @@ __device__ __forceinline__ Color3 fetch_pixel(const ImageView& im, uint32_t x, u
 
 // samplePixels: sum over the s x s box (dy outer, dx inner), then one divide per channel.
 template <int FMT = -1>
-__device__ __forceinline__ Color3 sample_box(const ImageView& im, uint32_t s, uint32_t x, uint32_t y) {
+__device__ __forceinline__ Color3 sample_box(const ImageView& im, uint32_t s, uint32_t x, uint32_t y, const UnormTables* ut = nullptr) {
   if (s == 1) {  // e = 0 + p; e / 1.0f  == p bit for bit (0.0f + p == p, p / 1 == p)
-    return fetch_pixel<FMT>(im, x, y);
+    return fetch_pixel<FMT>(im, x, y, ut);
   }
   Color3 e = {0.0f, 0.0f, 0.0f};
   for (uint32_t dy = 0; dy < s; ++dy)
     for (uint32_t dx = 0; dx < s; ++dx) {
-      const Color3 q = fetch_pixel<FMT>(im, x * s + dx, y * s + dy);
+      const Color3 q = fetch_pixel<FMT>(im, x * s + dx, y * s + dy, ut);
       e.r += q.r;
       e.g += q.g;
       e.b += q.b;

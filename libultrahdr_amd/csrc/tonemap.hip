@@ -31,18 +31,20 @@ __device__ __forceinline__ uint32_t put8(float v) {  // put*Pixel: *255, +0.5, c
 struct ToneLds {
   float hdr[kInvOetfN];
   double math[kMathTabDoubles];
+  UnormTables unorm;
 };
 __device__ __forceinline__ void stage_tables(const ToneMapParams& p, ToneLds& L) {
   if (p.hdr_inv_lut)
     for (uint32_t i = threadIdx.x; i < (uint32_t)p.hdr_inv_n; i += kBlock) L.hdr[i] = p.hdr_inv_lut[i];
   for (uint32_t i = threadIdx.x; i < kMathTabDoubles; i += kBlock) L.math[i] = p.math_tab[i];
+  fill_unorm_tables(L.unorm, threadIdx.x, kBlock);
   __syncthreads();
 }
 
 // one HDR pixel -> gamma-encoded Display-P3 SDR rgb
 template <int HDRF>
 __device__ __forceinline__ Color3 tone_map_pixel(const ToneMapParams& p, const ToneLds& L, uint32_t x, uint32_t y) {
-  Color3 g = fetch_pixel<HDRF>(p.hdr, x, y);
+  Color3 g = fetch_pixel<HDRF>(p.hdr, x, y, &L.unorm);
   if (!p.hdr_is_rgb) g = yuv_to_rgb(g.r, g.g, g.b, p.hdr_yuv);
   Color3 l = g;
   if (p.hdr_inv_lut) {
@@ -63,7 +65,7 @@ __device__ __forceinline__ Color3 tone_map_pixel(const ToneMapParams& p, const T
   float mx = c0;
   if (c1 > mx) mx = c1;
   if (c2 > mx) mx = c2;
-  float ms = 1.0f + mx / (hr * hr);  // ReinhardMap
+  float ms = 1.0f + div_const(mx, p.headroom_sq, p.headroom_sq_rcp);  // ReinhardMap: mx / (hr * hr), divisor is a per-transfer constant
   ms /= 1.0f + mx;
   ms = ms * mx;
   Color3 o;
@@ -147,7 +149,7 @@ int tone_grid(uint32_t tiles) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 1024;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    return cus * 8;  // 19 KB of LDS tables per workgroup: eight fit in a CU's 160 KB
+    return cus * 6;  // 24 KB of LDS tables per workgroup: six fit in a CU's 160 KB
   }();
   const uint32_t g = tiles < (uint32_t)resident ? tiles : (uint32_t)resident;
   return (int)(g < 1 ? 1 : g);

@@ -902,6 +902,8 @@ uhdr_error_info_t uhdr_hip_tone_map_dev(uhdr_hip_ctx_t* c, const uhdr_raw_image_
   p.hdr_is_rgb = is_rgb_fmt_host(hdr->fmt);
   p.is_normalized = hdr->ct != UHDR_CT_LINEAR;
   p.headroom = host::reference_peak_nits(hdr->ct) / 203.0f;
+  p.headroom_sq = p.headroom * p.headroom;
+  p.headroom_sq_rcp = 1.0f / p.headroom_sq;
   bool identity;
   host::gamut_matrix(UHDR_CG_DISPLAY_P3, hdr->cg, &p.gamut, &identity);
   p.gamut_on = identity ? 0 : 1;
@@ -1009,8 +1011,15 @@ int uhdr_hip_oetf_code_thresholds(uhdr_color_transfer_t ct, float thresholds[102
 }
 
 int uhdr_hip_exact_math_eval(int fn, const float* in, float* out, size_t n) {
-  if (!in || !out || (fn != 0 && fn != 1)) return -1;
+  if (!in || !out || fn < 0 || fn > 2) return -1;
   const double* T = host::math_tables().data();
+  if (fn == 2) {  // in[0] = the constant divisor b; out[i] = div_const(in[i], b, 1/b) for i >= 1
+    if (n < 1) return -1;
+    const float b = in[0], rb = 1.0f / b;
+    out[0] = rb;
+    for (size_t i = 1; i < n; i++) out[i] = div_const(in[i], b, rb);
+    return 0;
+  }
   for (size_t i = 0; i < n; i++) out[i] = fn == 0 ? srgb_oetf_table(in[i], T) : (float)log2_table_f64(in[i], T);
   return 0;
 }

@@ -125,7 +125,7 @@ struct ToneMapParams {
   int hdr_inv_n;
   const double* math_tab;    // exact_math.h tables (kMathTabDoubles)
   int hdr_is_rgb, is_normalized;
-  float headroom;
+  float headroom, headroom_sq, headroom_sq_rcp;  // hdr_white / 203, its square (float product) and 1 / square
   int gamut_on;
   Mat3 gamut;      // P3 <- hdr gamut
   Yuv2Rgb hdr_yuv;

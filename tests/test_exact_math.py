@@ -71,3 +71,31 @@ def test_unknown_function_is_rejected():
     lib = A.load()
     x = np.zeros(1, np.float32)
     assert lib.uhdr_hip_exact_math_eval(9, x.ctypes.data_as(C.POINTER(C.c_float)), x.ctypes.data_as(C.POINTER(C.c_float)), 1) == -1
+
+
+def _library_division_constants():
+    """Every divisor the kernels feed to div_const, computed the way the library computes them."""
+    f = np.float32
+    c = []
+    for (r, b) in ((0.2126, 0.0722), (0.2627, 0.059302)):   # BT.709 / BT.2100 luma -> chroma scale 2 * (1 - k)
+        c += [f(2) * (f(1) - f(b)), f(2) * (f(1) - f(r))]
+    c += [f(1.772), f(1.402)]                                  # Display-P3 rows use the BT.601 literals
+    c += [f(1000.0), f(10000.0)]                               # kHlgMaxNits, kPqMaxNits (decode tail)
+    for peak in (1000.0, 10000.0, 203.0):                      # tone-map headroom^2 per transfer
+        h = f(peak) / f(203.0)
+        c.append(h * h)
+    return [float(v) for v in c]
+
+
+@pytest.mark.parametrize("b", _library_division_constants())
+def test_div_const_is_exact_for_every_library_constant(b):
+    """a / b == div_const(a, b) for all 2^23 mantissas of a (the three-instruction sequence is scale
+    invariant, so one binade proves it for every normal a), for each constant divisor in the kernels."""
+    lib = A.load()
+    a = (np.arange(1 << 23, dtype=np.uint32) | np.uint32(0x3F800000)).view(np.float32)
+    buf = np.concatenate([np.float32([b]), a, -a[::4097]])
+    out = np.empty_like(buf)
+    assert lib.uhdr_hip_exact_math_eval(2, buf.ctypes.data_as(C.POINTER(C.c_float)), out.ctypes.data_as(C.POINTER(C.c_float)), buf.size) == 0
+    assert out[0] == np.float32(1.0) / np.float32(b)
+    want = buf[1:] / np.float32(b)
+    assert np.array_equal(out[1:].view(np.uint32), want.view(np.uint32))
