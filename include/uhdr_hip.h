@@ -245,6 +245,13 @@ uhdr_error_info_t uhdr_hip_fdct_quant_dev(uhdr_hip_ctx_t* ctx, const uint8_t* pl
                                           int blocks_w, int blocks_h, const uint16_t qtable[64],
                                           int16_t* coef);
 
+/* copy_raw_image(src, dst) (lib/src/gainmapmath.cpp:1492-1613) between device images: strided plane copies
+ * for equal formats, RGB888 -> RGBA8888 (alpha 0xff), RGBA8888 -> Y400 (R byte); same error codes
+ * (UHDR_CODEC_MEM_ERROR for a size mismatch, UHDR_CODEC_UNSUPPORTED_FEATURE for other format pairs).
+ * The host <-> device direction of this function is what the host-buffer entry points do internally. */
+uhdr_error_info_t uhdr_hip_copy_raw_image_dev(uhdr_hip_ctx_t* ctx, const uhdr_raw_image_t* src,
+                                              uhdr_raw_image_t* dst);
+
 /* ---- JPEG decode stage (the step immediately before applyGainMap) ---------------
  * Inverse of uhdr_hip_fdct_quant: dequantize + libjpeg's JDCT_ISLOW 8x8 inverse DCT + range limit of
  * coefficient blocks as jpeg_read_coefficients() yields them (JBLOCK layout, raster block order), so that

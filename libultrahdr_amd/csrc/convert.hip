@@ -136,6 +136,25 @@ __global__ __launch_bounds__(kBlock) void rgb_to_ycbcr444_kernel(const RgbToYcbc
   }
 }
 
+// copy_raw_image's two repacking cases (gainmapmath.cpp:1565-1597): RGB888 -> RGBA8888 (alpha 0xff) and
+// RGBA8888 -> Y400 (the R byte).  MODE 0 / 1.  One lane per pixel, tiles of 256 pixels of one row.
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void repack_kernel(const uint8_t* __restrict__ src, size_t src_pitch,
+                                                        uint8_t* __restrict__ dst, size_t dst_pitch, uint32_t w, uint32_t h) {
+  const uint32_t tiles_x = (w + kBlock - 1) / kBlock, tiles = tiles_x * h;
+  for (uint32_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const uint32_t y = t / tiles_x, x = (t - y * tiles_x) * kBlock + threadIdx.x;
+    if (x >= w) continue;
+    const uint8_t* s = src + (size_t)y * src_pitch;
+    uint8_t* d = dst + (size_t)y * dst_pitch;
+    if constexpr (MODE == 0) {
+      ((uint32_t*)d)[x] = s[3 * x] | ((uint32_t)s[3 * x + 1] << 8) | ((uint32_t)s[3 * x + 2] << 16) | (0xffu << 24);
+    } else {
+      d[x] = (uint8_t)(((const uint32_t*)s)[x] & 0xff);
+    }
+  }
+}
+
 inline int grid_for(size_t total) {
   size_t g = (total + kBlock - 1) / kBlock;
   if (g > 4096) g = 4096;
@@ -151,6 +170,14 @@ hipError_t launch_transform_yuv(const YuvXformParams& p, hipStream_t s) {
   } else {
     hipLaunchKernelGGL(transform_yuv444_kernel, dim3(grid_for((size_t)p.img.w * p.img.h)), dim3(kBlock), 0, s, p);
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_repack(int mode, const void* src, size_t src_pitch, void* dst, size_t dst_pitch, uint32_t w, uint32_t h,
+                         hipStream_t s) {
+  const int g = grid_for((size_t)w * h);
+  if (mode == 0) hipLaunchKernelGGL((repack_kernel<0>), dim3(g), dim3(kBlock), 0, s, (const uint8_t*)src, src_pitch, (uint8_t*)dst, dst_pitch, w, h);
+  else hipLaunchKernelGGL((repack_kernel<1>), dim3(g), dim3(kBlock), 0, s, (const uint8_t*)src, src_pitch, (uint8_t*)dst, dst_pitch, w, h);
   return hipGetLastError();
 }
 

@@ -1054,6 +1054,52 @@ uhdr_error_info_t uhdr_hip_fdct_quant(uhdr_hip_ctx_t* c, const uint8_t* plane, s
 }
 
 // -------------------------------------------------------------------------------------------------
+// copy_raw_image (gainmapmath.cpp:1492-1613), device to device
+// -------------------------------------------------------------------------------------------------
+uhdr_error_info_t uhdr_hip_copy_raw_image_dev(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* src, uhdr_raw_image_t* dst) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  if (!src || !dst) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument");
+  if (dst->w != src->w || dst->h != src->h)
+    return err_status(UHDR_CODEC_MEM_ERROR, "destination image dimensions %dx%d and source image dimensions %dx%d are not identical for copy_raw_image",
+                      dst->w, dst->h, src->w, src->h);
+  HIP_TRY(hipSetDevice(c->device));
+  dst->cg = src->cg; dst->ct = src->ct; dst->range = src->range;
+  const size_t w = src->w, h = src->h;
+  auto copy2d = [&](int pl, size_t bps, size_t width, size_t rows) -> hipError_t {
+    if (!width || !rows) return hipSuccess;
+    return hipMemcpy2DAsync(dst->planes[pl], (size_t)dst->stride[pl] * bps, src->planes[pl], (size_t)src->stride[pl] * bps,
+                            width * bps, rows, hipMemcpyDeviceToDevice, c->stream);
+  };
+  if (dst->fmt == src->fmt) {
+    switch (src->fmt) {
+      case UHDR_IMG_FMT_24bppYCbCrP010:  // h / 2 chroma rows of w samples, as the reference copies them
+        HIP_TRY(copy2d(0, 2, w, h));
+        HIP_TRY(copy2d(1, 2, w, h / 2));
+        return ok_status();
+      case UHDR_IMG_FMT_12bppYCbCr420:
+        HIP_TRY(copy2d(0, 1, w, h));
+        HIP_TRY(copy2d(1, 1, w / 2, h / 2));
+        HIP_TRY(copy2d(2, 1, w / 2, h / 2));
+        return ok_status();
+      case UHDR_IMG_FMT_8bppYCbCr400: HIP_TRY(copy2d(0, 1, w, h)); return ok_status();
+      case UHDR_IMG_FMT_32bppRGBA8888:
+      case UHDR_IMG_FMT_32bppRGBA1010102: HIP_TRY(copy2d(0, 4, w, h)); return ok_status();
+      case UHDR_IMG_FMT_64bppRGBAHalfFloat: HIP_TRY(copy2d(0, 8, w, h)); return ok_status();
+      case UHDR_IMG_FMT_24bppRGB888: HIP_TRY(copy2d(0, 3, w, h)); return ok_status();
+      default: break;
+    }
+  } else if (src->fmt == UHDR_IMG_FMT_24bppRGB888 && dst->fmt == UHDR_IMG_FMT_32bppRGBA8888) {
+    HIP_TRY(launch_repack(0, src->planes[0], (size_t)src->stride[0] * 3, dst->planes[0], (size_t)dst->stride[0] * 4, src->w, src->h, c->stream));
+    return ok_status();
+  } else if (src->fmt == UHDR_IMG_FMT_32bppRGBA8888 && dst->fmt == UHDR_IMG_FMT_8bppYCbCr400) {
+    HIP_TRY(launch_repack(1, src->planes[0], (size_t)src->stride[0] * 4, dst->planes[0], (size_t)dst->stride[0], src->w, src->h, c->stream));
+    return ok_status();
+  }
+  return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "unsupported source / destinations color formats in copy_raw_image, src fmt %d, dst fmt %d",
+                    src->fmt, dst->fmt);
+}
+
+// -------------------------------------------------------------------------------------------------
 // JPEG decode stage: dequant + IDCT, libjpeg colour conversions
 // -------------------------------------------------------------------------------------------------
 uhdr_error_info_t uhdr_hip_idct_dequant_dev(uhdr_hip_ctx_t* c, const int16_t* coef, int bw, int bh, const uint16_t qt[64],

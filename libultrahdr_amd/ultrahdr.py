@@ -163,6 +163,11 @@ class UltraHdr:
         A.check(fn(self.ctx.handle, C.byref(src.raw), int(chroma_sampling_enabled), C.byref(dst.raw)))
         return dst
 
+    def copy_raw_image(self, src: Image, dst: Image) -> Image:
+        """copy_raw_image(src, dst) between device images (equal formats, RGB888 -> RGBA8888, RGBA8888 -> Y400)."""
+        A.check(self.lib.uhdr_hip_copy_raw_image_dev(self.ctx.handle, C.byref(src.raw), C.byref(dst.raw)))
+        return dst
+
     # ---- JPEG stage -----------------------------------------------------------------------------
     def quant_table(self, quality: int, is_chroma: bool) -> np.ndarray:
         qt = (C.c_uint16 * 64)()

@@ -56,6 +56,8 @@ def port() -> C.CDLL:
     lib.uo_convert_yuv.argtypes = [_P(A.RawImage), C.c_int, C.c_int]
     lib.uo_convert_raw_input_to_ycbcr.restype = C.c_int
     lib.uo_convert_raw_input_to_ycbcr.argtypes = [_P(A.RawImage), C.c_int, _P(A.RawImage)]
+    lib.uo_copy_raw_image.restype = C.c_int
+    lib.uo_copy_raw_image.argtypes = [_P(A.RawImage), _P(A.RawImage)]
     lib.uo_jpeg_quant_table.restype = None
     lib.uo_jpeg_quant_table.argtypes = [C.c_int, C.c_int, _P(C.c_uint16)]
     lib.uo_fdct_quant_plane.restype = None
@@ -122,6 +124,8 @@ def ref():
     lib.ref_tone_map.argtypes = [_P(A.RawImage), _P(A.RawImage), C.c_char_p]
     lib.ref_convert_yuv.restype = C.c_int
     lib.ref_convert_yuv.argtypes = [_P(A.RawImage), C.c_int, C.c_int, C.c_char_p]
+    lib.ref_copy_raw_image.restype = C.c_int
+    lib.ref_copy_raw_image.argtypes = [_P(A.RawImage), _P(A.RawImage)]
     lib.ref_convert_raw_input_to_ycbcr.restype = C.c_int
     lib.ref_convert_raw_input_to_ycbcr.argtypes = [_P(A.RawImage), C.c_int, _P(A.RawImage)]
     lib.ref_jpeg_compress.restype = C.c_long
@@ -229,6 +233,13 @@ def convert_raw_input_to_ycbcr(lib_kind, src: Image, chroma: bool) -> Image:
     if rc != 0:
         raise A.UhdrError(rc, "convert_raw_input_to_ycbcr")
     return dst
+
+
+def copy_raw_image(lib_kind, src: Image, dst: Image) -> int:
+    """copy_raw_image(src, dst) on caller-allocated descriptors; returns the uhdr error code."""
+    if lib_kind == "port":
+        return port().uo_copy_raw_image(C.byref(src.raw), C.byref(dst.raw))
+    return ref().ref_copy_raw_image(C.byref(src.raw), C.byref(dst.raw))
 
 
 def fdct_quant_port(plane: np.ndarray, stride: int, bw: int, bh: int, qt: np.ndarray) -> np.ndarray:

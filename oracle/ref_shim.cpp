@@ -130,6 +130,11 @@ REF_API int ref_convert_raw_input_to_ycbcr(uhdr_raw_image_t* src, int chroma_sam
   return 0;
 }
 
+// copy_raw_image(src, dst) (lib/src/gainmapmath.cpp:1492-1613) on caller-provided descriptors
+REF_API int ref_copy_raw_image(uhdr_raw_image_t* src, uhdr_raw_image_t* dst) {
+  return (int)copy_raw_image(src, dst).error_code;
+}
+
 // ---- scalar / small-vector access to gainmapmath for KATs --------------------------------------
 enum {
   REF_FN_SRGB_INVOETF = 0,

@@ -1193,6 +1193,61 @@ void uo_jpeg_rgb_to_ycc(const uint8_t* rgb, size_t stride_px, int w, int h, uint
 }
 
 /* ---------------------------------------------------------------------------------------------
+ * copy_raw_image(src, dst) (gainmapmath.cpp:1492-1613): strided plane copies for equal formats,
+ * RGB888 -> RGBA8888 (alpha 0xff) and RGBA8888 -> Y400 (takes the R byte).  Colour aspects are
+ * copied before the format check (:1505-1507); P010 / 4:2:0 copy h/2 chroma rows of w (resp. w/2)
+ * samples (:1519-1523, 1540-1547), i.e. the last chroma row / column of an odd image is not copied.
+ * ------------------------------------------------------------------------------------------- */
+int uo_copy_raw_image(const uo_image_t* src, uo_image_t* dst) {
+  if (dst->w != src->w || dst->h != src->h) return UO_MEM_ERROR;
+  dst->cg = src->cg; dst->ct = src->ct; dst->range = src->range;
+  const size_t w = src->w, h = src->h;
+  if (dst->fmt == src->fmt) {
+    if (src->fmt == UO_FMT_P010) {
+      for (size_t i = 0; i < h; i++)
+        memcpy((uint8_t*)dst->planes[0] + i * dst->stride[0] * 2, (const uint8_t*)src->planes[0] + i * src->stride[0] * 2, w * 2);
+      for (size_t i = 0; i < h / 2; i++)
+        memcpy((uint8_t*)dst->planes[1] + i * dst->stride[1] * 2, (const uint8_t*)src->planes[1] + i * src->stride[1] * 2, w * 2);
+      return UO_OK;
+    }
+    if (src->fmt == UO_FMT_YUV420) {
+      for (size_t i = 0; i < h; i++)
+        memcpy((uint8_t*)dst->planes[0] + i * dst->stride[0], (const uint8_t*)src->planes[0] + i * src->stride[0], w);
+      for (size_t i = 0; i < h / 2; i++) {
+        memcpy((uint8_t*)dst->planes[1] + i * dst->stride[1], (const uint8_t*)src->planes[1] + i * src->stride[1], w / 2);
+        memcpy((uint8_t*)dst->planes[2] + i * dst->stride[2], (const uint8_t*)src->planes[2] + i * src->stride[2], w / 2);
+      }
+      return UO_OK;
+    }
+    size_t bpp = 0;
+    if (src->fmt == UO_FMT_Y400) bpp = 1;
+    else if (src->fmt == UO_FMT_RGBA1010102 || src->fmt == UO_FMT_RGBA8888) bpp = 4;
+    else if (src->fmt == UO_FMT_RGBAF16) bpp = 8;
+    else if (src->fmt == UO_FMT_RGB888) bpp = 3;
+    if (bpp) {
+      for (size_t i = 0; i < h; i++)
+        memcpy((uint8_t*)dst->planes[0] + i * dst->stride[0] * bpp, (const uint8_t*)src->planes[0] + i * src->stride[0] * bpp, w * bpp);
+      return UO_OK;
+    }
+  } else if (src->fmt == UO_FMT_RGB888 && dst->fmt == UO_FMT_RGBA8888) {
+    for (size_t i = 0; i < h; i++) {
+      const uint8_t* s = (const uint8_t*)src->planes[0] + i * src->stride[0] * 3;
+      uint32_t* d = (uint32_t*)dst->planes[0] + i * dst->stride[0];
+      for (size_t j = 0; j < w; j++) d[j] = s[3 * j] | ((uint32_t)s[3 * j + 1] << 8) | ((uint32_t)s[3 * j + 2] << 16) | (0xffu << 24);
+    }
+    return UO_OK;
+  } else if (src->fmt == UO_FMT_RGBA8888 && dst->fmt == UO_FMT_Y400) {
+    for (size_t i = 0; i < h; i++) {
+      const uint8_t* s = (const uint8_t*)src->planes[0] + i * src->stride[0] * 4;
+      uint8_t* d = (uint8_t*)dst->planes[0] + i * dst->stride[0];
+      for (size_t j = 0; j < w; j++) d[j] = s[4 * j];
+    }
+    return UO_OK;
+  }
+  return UO_UNSUPPORTED;
+}
+
+/* ---------------------------------------------------------------------------------------------
  * JPEG decode stage: dequantize + islow inverse DCT + range limit, and the
  * YCbCr -> RGB conversion libjpeg applies to a 3-channel gain map.  Like the forward DCT this
  * arithmetic lives in libjpeg, not in the reference tree: JpegDecoderHelper

@@ -85,6 +85,9 @@ int uo_convert_yuv(uo_image_t* img, int src_cg, int dst_cg);
 /* dst planes/strides caller-provided; dst->fmt decides the variant like the reference does. */
 int uo_convert_raw_input_to_ycbcr(const uo_image_t* src, int chroma_sampling, uo_image_t* dst);
 
+/* copy_raw_image(src, dst) (gainmapmath.cpp:1492-1613): equal formats, RGB888 -> RGBA8888, RGBA8888 -> Y400 */
+int uo_copy_raw_image(const uo_image_t* src, uo_image_t* dst);
+
 /* JPEG stage: quality -> quant table (natural order), then islow FDCT + quantize of one u8 plane.
  * coef: blocks in raster order, 64 int16 each, natural (row-major) order = libjpeg JBLOCK layout.
  * The plane is read for blocks_w*8 x blocks_h*8 samples: callers pad exactly as the reference's

@@ -507,3 +507,34 @@ def test_apply_gainmap_calls_capture_into_a_hip_graph(uhdr):
         assert all(torch.equal(a.buf, b.buf) for a, b in zip(dst, ref))
     finally:
         uhdr.ctx.set_stream(None)
+
+
+def test_copy_raw_image_bit_exact(uhdr):
+    """uhdr_hip_copy_raw_image_dev == copy_raw_image (oracle), same formats / repacks / error codes."""
+    fmts = [A.UHDR_IMG_FMT_24bppYCbCrP010, A.UHDR_IMG_FMT_12bppYCbCr420, A.UHDR_IMG_FMT_8bppYCbCr400,
+            A.UHDR_IMG_FMT_32bppRGBA8888, A.UHDR_IMG_FMT_64bppRGBAHalfFloat, A.UHDR_IMG_FMT_32bppRGBA1010102,
+            A.UHDR_IMG_FMT_24bppRGB888]
+    pairs = [(f, f) for f in fmts] + [(A.UHDR_IMG_FMT_24bppRGB888, A.UHDR_IMG_FMT_32bppRGBA8888),
+                                      (A.UHDR_IMG_FMT_32bppRGBA8888, A.UHDR_IMG_FMT_8bppYCbCr400)]
+    rng = np.random.default_rng(31)
+
+    def rand(fmt, w, h, align):
+        img = Image(fmt, w, h, A.UHDR_CG_DISPLAY_P3, A.UHDR_CT_SRGB, A.UHDR_CR_FULL_RANGE, align=align)
+        img.buf[:] = rng.integers(0, 256, img.buf.size, dtype=np.uint8)
+        return img
+
+    for sf, df in pairs:
+        for (w, h) in ((256, 64), (37, 19)):
+            src, dst = rand(sf, w, h, 16), rand(df, w, h, 64)
+            want = dst.clone()
+            assert L.copy_raw_image("port", src, want) == 0
+            got = uhdr.copy_raw_image(src.to("cuda:0"), dst.to("cuda:0"))
+            uhdr.ctx.synchronize()
+            assert np.array_equal(got.to_host().buf, want.buf), (sf, df, w, h)
+            assert (got.raw.cg, got.raw.ct, got.raw.range) == (want.raw.cg, want.raw.ct, want.raw.range)
+    with pytest.raises(A.UhdrError) as e:
+        uhdr.copy_raw_image(rand(fmts[2], 32, 16, 16).to("cuda:0"), rand(fmts[2], 32, 18, 16).to("cuda:0"))
+    assert e.value.code == A.UHDR_CODEC_MEM_ERROR
+    with pytest.raises(A.UhdrError) as e:
+        uhdr.copy_raw_image(rand(fmts[2], 32, 16, 16).to("cuda:0"), rand(fmts[3], 32, 16, 16).to("cuda:0"))
+    assert e.value.code == A.UHDR_CODEC_UNSUPPORTED_FEATURE

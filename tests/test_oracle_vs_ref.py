@@ -268,3 +268,36 @@ def test_idct_dequant_against_libjpeg(ref, quality):
     planes = [L.idct_dequant_port(coefs[c], qt[c])[:48, :96] for c in range(3)]
     got = L.jpeg_ycc_to_rgb_port(*planes, out_bpp=bpp, variant=1)
     assert np.array_equal(got, want)
+
+
+COPY_FMTS = [A.UHDR_IMG_FMT_24bppYCbCrP010, A.UHDR_IMG_FMT_12bppYCbCr420, A.UHDR_IMG_FMT_8bppYCbCr400,
+             A.UHDR_IMG_FMT_32bppRGBA8888, A.UHDR_IMG_FMT_64bppRGBAHalfFloat, A.UHDR_IMG_FMT_32bppRGBA1010102,
+             A.UHDR_IMG_FMT_24bppRGB888]
+
+
+def _random_image(fmt, w, h, align, seed):
+    img = Image(fmt, w, h, A.UHDR_CG_DISPLAY_P3, A.UHDR_CT_SRGB, A.UHDR_CR_FULL_RANGE, align=align)
+    img.buf[:] = np.random.default_rng(seed).integers(0, 256, img.buf.size, dtype=np.uint8)
+    return img
+
+
+def test_copy_raw_image_port_equals_reference(ref):
+    """copy_raw_image (gainmapmath.cpp:1492-1613): every same-format case incl. odd sizes (the reference
+    copies h/2 chroma rows), both repacking cases, both error codes; destination padding untouched."""
+    pairs = [(f, f) for f in COPY_FMTS] + [(A.UHDR_IMG_FMT_24bppRGB888, A.UHDR_IMG_FMT_32bppRGBA8888),
+                                           (A.UHDR_IMG_FMT_32bppRGBA8888, A.UHDR_IMG_FMT_8bppYCbCr400),
+                                           (A.UHDR_IMG_FMT_8bppYCbCr400, A.UHDR_IMG_FMT_32bppRGBA8888),
+                                           (A.UHDR_IMG_FMT_24bppYCbCr444, A.UHDR_IMG_FMT_24bppYCbCr444)]
+    for sf, df in pairs:
+        for (w, h) in ((64, 32), (37, 19)):
+            src = _random_image(sf, w, h, 16, 5)
+            outs = []
+            for kind in ("port", "ref"):
+                dst = _random_image(df, w, h, 64, 9)  # pre-filled: padding must survive
+                rc = L.copy_raw_image(kind, src, dst)
+                outs.append((rc, dst.buf.copy(), (dst.raw.cg, dst.raw.ct, dst.raw.range)))
+            assert outs[0][0] == outs[1][0], (sf, df, outs[0][0], outs[1][0])
+            assert np.array_equal(outs[0][1], outs[1][1]), (sf, df, w, h)
+            assert outs[0][2] == outs[1][2]
+    src, dst = _random_image(COPY_FMTS[2], 32, 16, 16, 1), _random_image(COPY_FMTS[2], 32, 18, 16, 2)
+    assert L.copy_raw_image("port", src, dst) == L.copy_raw_image("ref", src, dst) == A.UHDR_CODEC_MEM_ERROR
