@@ -284,6 +284,24 @@ def extras(ctx, u, device):
     apply_case("apply_4k_hlg_mapA", 3840, 2160, "A", A.UHDR_CT_HLG)
     apply_case("apply_4k_pq_mapA", 3840, 2160, "A", A.UHDR_CT_PQ)
 
+    # 4:4:4 (what an API-0 stream decodes to) and RGBA8888 bases: the quad kernel's BASE 1 / 2 variants
+    def generic_case(name, base_fmt, map_kind):
+        w_, h_ = 3840, 2160
+        base = Image(base_fmt, w_, h_, A.UHDR_CG_BT_709, A.UHDR_CT_SRGB, A.UHDR_CR_FULL_RANGE, align=64, device=device)
+        base.buf.random_(0, 256)
+        torch.cuda.synchronize()
+        g = (synth.make_gainmap(w_ // 4, h_ // 4, 1, seed=9) if map_kind == "A" else synth.make_gainmap(w_, h_, 3, alpha=True, seed=9)).to(device)
+        g.raw.cg = A.UHDR_CG_BT_2100
+        d = Image(f16, w_, h_, align=64, device=device)
+        ms = time_kernel(ctx, lambda: u.applyGainMap(base, g, md, A.UHDR_CT_LINEAR, f16, A.FLT_MAX, d), iters=6, warm=2)
+        bpp_in = {A.UHDR_IMG_FMT_24bppYCbCr444: 3, A.UHDR_IMG_FMT_32bppRGBA8888: 4}[base_fmt]
+        b = (bpp_in + (1 / 16 if map_kind == "A" else 4) + 8) * w_ * h_
+        res[name] = {"us": round(ms * 1e3, 2), "GB/s": round(b / (ms / 1e3) / 1e9, 1), "Mpx/s": round(w_ * h_ / (ms / 1e3) / 1e6, 1)}
+
+    generic_case("apply_4k_f16_444base_mapC_quad_kernel", A.UHDR_IMG_FMT_24bppYCbCr444, "C")
+    generic_case("apply_4k_f16_444base_mapA_quad_kernel", A.UHDR_IMG_FMT_24bppYCbCr444, "A")
+    generic_case("apply_4k_f16_rgba8888base_mapC_quad_kernel", A.UHDR_IMG_FMT_32bppRGBA8888, "C")
+
     # the drop-in boundary with HOST buffers (H2D + kernel + D2H, pageable memory): PCIe-inclusive rate
     hw, hh = 3840, 2160
     hs = synth.make_sdr_yuv420(hw, hh, seed=5)

@@ -258,7 +258,8 @@ __global__ __launch_bounds__(kBlock) void apply_generic_kernel(const ApplyParams
 }
 
 // ---------------------------------------------------------------------------------------------
-// quad kernel (4:2:0 base, even geometry, gamma == 1 or scale == 1).
+// quad kernel (4:2:0 / 4:4:4 / RGBA8888 base, even geometry, gamma == 1 or scale == 1).
+//   BASE  : 0 YCbCr 4:2:0 (the quad shares one chroma sample), 1 YCbCr 4:4:4, 2 packed RGBA8888.
 //   MAPFMT: 0 Y400, 1 RGB888, 2 RGBA8888.
 //   SMODE : 0 scale == 1 (byte -> factor table, no interpolation),
 //           1 even integer scale (the four taps are shared by the whole 2x2 quad; only the
@@ -332,11 +333,12 @@ template <typename T> __device__ __forceinline__ void stream_store(void* a, T v)
 // through the same in-order vmcnt counter, so a tile whose loads are issued after the previous
 // tile's stores would wait for those stores to be acknowledged by memory.  Issuing the next
 // tile's loads before the current tile's stores takes the store latency off the critical path.
-template <int MAPFMT, int SMODE>
+template <int MAPFMT, int SMODE, int BASE>
 struct QuadRaw {
   static constexpr int NCH = (MAPFMT == 0) ? 1 : 3;
-  uint32_t y0, y1;  // two luma bytes of row 0 / row 1
-  uint32_t u, v;    // chroma bytes
+  uint32_t y0, y1;  // BASE 0/1: two luma bytes of row 0 / row 1; BASE 2: unused
+  uint32_t u, v;    // BASE 0: the quad's chroma bytes; BASE 1: row-0 chroma pairs (two bytes each)
+  uint32_t c[(BASE == 0) ? 1 : 4];  // BASE 1: {.., .., u row 1, v row 1}; BASE 2: the four RGBA8888 pixels {r0p0, r0p1, r1p0, r1p1}
   uint32_t m[(SMODE == 0) ? 4 : 4 * NCH];  // SMODE 0: map bytes {row0 lo, row0 hi, row1 lo, row1 hi}; SMODE 1: tap bytes [tap][ch]
   uint32_t wrow;    // SMODE 1: row part of the weight-table index (wave-uniform)
   uint32_t y;       // first row of the quad (wave-uniform)
@@ -350,14 +352,14 @@ struct QuadRaw {
 // of p.row_groups quad rows.  Everything that depends on the column (pixel offsets, gain-map tap
 // columns, weight-table column, edge flags) is therefore loop invariant and lives in VGPRs;
 // everything that depends on the row is wave-uniform and is computed on the scalar unit.
-template <int OUT, int MAPFMT, int SMODE>
+template <int OUT, int MAPFMT, int SMODE, int BASE>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void apply_quad_kernel(const ApplyParams p) {
   constexpr int NCH = (MAPFMT == 0) ? 1 : 3;
   constexpr int BPP = (MAPFMT == 0) ? 1 : (MAPFMT == 1 ? 3 : 4);
-  using Raw = QuadRaw<MAPFMT, SMODE>;
+  using Raw = QuadRaw<MAPFMT, SMODE, BASE>;
   __shared__ float s_srgb[kSrgbPad];
   __shared__ float s_gain[(SMODE == 0) ? 1 : NCH * kGainN];
-  __shared__ float s_u8f[(SMODE == 0) ? 1 : 256];
+  __shared__ float s_u8f[(SMODE == 0 && BASE != 2) ? 1 : 256];  // byte / 255.0f: map taps (SMODE 1), RGBA8888 base samples (BASE 2)
   __shared__ float s_fac[(SMODE == 0) ? NCH * 256 : 1];
   __shared__ float s_thr[(OUT == 1) ? kOetfTabFloats : 1];  // HLG output-code thresholds + bucket end-point codes
   // IDW weights re-laid out for pixel PAIRS: entry (table, oy, ox/2) holds
@@ -371,6 +373,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
   }
   if constexpr (SMODE == 0) {
     for (uint32_t i = tid; i < NCH * 256; i += kBlock) s_fac[i] = p.tables[ApplyTables::kFacOff + i];
+    if constexpr (BASE == 2)
+      for (uint32_t i = tid; i < 256; i += kBlock) s_u8f[i] = p.tables[ApplyTables::kU8fOff + i];
   } else {
     for (uint32_t i = tid; i < NCH * kGainN; i += kBlock) s_gain[i] = p.tables[ApplyTables::kGainOff + i];
     for (uint32_t i = tid; i < 256; i += kBlock) s_u8f[i] = p.tables[ApplyTables::kU8fOff + i];
@@ -445,11 +449,26 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
     r.y = y;
     // 32-bit offsets from the kernel-argument base pointers (planes < 4 GiB, checked by the
     // launcher): scalar row offset + per-lane column -> one v_add_u32 and an SGPR-base load
-    const uint32_t yrow = y * sy;
-    r.y0 = *(const uint16_t*)(yp + (yrow + xc));
-    r.y1 = *(const uint16_t*)(yp + (yrow + sy + xc));
-    r.u = up[qy_ * su + xq];
-    r.v = vp[qy_ * sv + xq];
+    if constexpr (BASE == 2) {  // packed RGBA8888: two pixels (8 bytes) per row
+      const uint32_t prow = y * sy * 4;
+      const uint2 a = *(const uint2*)(yp + (prow + xc * 4)), b = *(const uint2*)(yp + (prow + sy * 4 + xc * 4));
+      r.c[0] = a.x; r.c[1] = a.y; r.c[2] = b.x; r.c[3] = b.y;
+      r.y0 = r.y1 = r.u = r.v = 0;
+    } else {
+      const uint32_t yrow = y * sy;
+      r.y0 = *(const uint16_t*)(yp + (yrow + xc));
+      r.y1 = *(const uint16_t*)(yp + (yrow + sy + xc));
+      if constexpr (BASE == 0) {
+        r.u = up[qy_ * su + xq];
+        r.v = vp[qy_ * sv + xq];
+      } else {  // 4:4:4: a chroma pair per row
+        r.u = *(const uint16_t*)(up + (y * su + xc));
+        r.v = *(const uint16_t*)(vp + (y * sv + xc));
+        r.c[2] = *(const uint16_t*)(up + (y * su + su + xc));
+        r.c[3] = *(const uint16_t*)(vp + (y * sv + sv + xc));
+        r.c[0] = r.c[1] = 0;
+      }
+    }
     const uint32_t yg = y + y0g;
     if constexpr (SMODE == 0) {
 #pragma unroll
@@ -497,8 +516,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
     }
     // getYuv4abPixel chroma (gainmapmath.cpp:370-374) and the p3YuvToRgb chroma products shared
     // by the four pixels (gainmapmath.cpp:177-181)
-    const float uf = (float)((int)q.u - 128) * k255, vf = (float)((int)q.v - 128) * k255;
-    const float crv = yk.cr * vf, gcbu = yk.gcb * uf, gcrv = yk.gcr * vf, cbu = yk.cb * uf;
+    // BASE 0: one chroma sample for the quad; BASE 1: per pixel (computed per row below)
+    f2 crv = splat(0.0f), gcbu = crv, gcrv = crv, cbu = crv;
+    if constexpr (BASE == 0) {
+      const float uf = (float)((int)q.u - 128) * k255, vf = (float)((int)q.v - 128) * k255;
+      crv = splat(yk.cr * vf); gcbu = splat(yk.gcb * uf); gcrv = splat(yk.gcr * vf); cbu = splat(yk.cb * uf);
+    }
     const uint32_t drow = q.y * sd;  // wave-uniform row offset
 #ifdef UHDR_EXP_NOMATH  // experiment (tools/kbench): memory pattern only
     if constexpr (OUT == 0 && SMODE == 0) {
@@ -512,19 +535,38 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
 #endif
 #pragma unroll
     for (int r = 0; r < 2; r++) {
-      const uint32_t yb = r == 0 ? q.y0 : q.y1;
-      const f2 yf = (f2){(float)(yb & 0xff), (float)(yb >> 8)} * k255;
-      // p3YuvToRgb + clampPixelFloat + srgbInvOetfLUT; the clamp is absorbed by the index
-      // conversion and the padded table (see lut_off_unclamped)
+      f2 lr, lg, lb;
+      if constexpr (BASE == 2) {
+        // getRgba8888Pixel: byte / 255.0f (the host-built table holds exactly those quotients), then
+        // srgbInvOetfLUT; the samples are in [0, 1], no clamp involved
+        const uint32_t a = q.c[2 * r], b = q.c[2 * r + 1];
+        const f2 er = {s_u8f[a & 0xff], s_u8f[b & 0xff]};
+        const f2 eg = {s_u8f[(a >> 8) & 0xff], s_u8f[(b >> 8) & 0xff]};
+        const f2 eb = {s_u8f[(a >> 16) & 0xff], s_u8f[(b >> 16) & 0xff]};
+        lr = lds_gather(s_srgb, lut_off_1024(er));
+        lg = lds_gather(s_srgb, lut_off_1024(eg));
+        lb = lds_gather(s_srgb, lut_off_1024(eb));
+      } else {
+        const uint32_t yb = r == 0 ? q.y0 : q.y1;
+        const f2 yf = (f2){(float)(yb & 0xff), (float)(yb >> 8)} * k255;
+        if constexpr (BASE == 1) {  // 4:4:4: this row's own chroma pair
+          const uint32_t ub = r == 0 ? q.u : q.c[2], vb = r == 0 ? q.v : q.c[3];
+          const f2 uf = (f2){(float)((int)(ub & 0xff) - 128), (float)((int)(ub >> 8) - 128)} * k255;
+          const f2 vf = (f2){(float)((int)(vb & 0xff) - 128), (float)((int)(vb >> 8) - 128)} * k255;
+          crv = yk.cr * vf; gcbu = yk.gcb * uf; gcrv = yk.gcr * vf; cbu = yk.cb * uf;
+        }
+        // p3YuvToRgb + clampPixelFloat + srgbInvOetfLUT; the clamp is absorbed by the index
+        // conversion and the padded table (see lut_off_unclamped)
 #ifdef UHDR_EXP_OLDCLAMP
-      f2 lr = lds_gather(s_srgb, lut_off_1024(clamp01_2(yf + crv)));
-      f2 lg = lds_gather(s_srgb, lut_off_1024(clamp01_2(yf - gcbu - gcrv)));
-      f2 lb = lds_gather(s_srgb, lut_off_1024(clamp01_2(yf + cbu)));
+        lr = lds_gather(s_srgb, lut_off_1024(clamp01_2(yf + crv)));
+        lg = lds_gather(s_srgb, lut_off_1024(clamp01_2(yf - gcbu - gcrv)));
+        lb = lds_gather(s_srgb, lut_off_1024(clamp01_2(yf + cbu)));
 #else
-      f2 lr = lds_gather(s_srgb, lut_off_unclamped(yf + crv));
-      f2 lg = lds_gather(s_srgb, lut_off_unclamped(yf - gcbu - gcrv));
-      f2 lb = lds_gather(s_srgb, lut_off_unclamped(yf + cbu));
+        lr = lds_gather(s_srgb, lut_off_unclamped(yf + crv));
+        lg = lds_gather(s_srgb, lut_off_unclamped(yf - gcbu - gcrv));
+        lb = lds_gather(s_srgb, lut_off_unclamped(yf + cbu));
 #endif
+      }
 #ifndef UHDR_EXP_NOGAMUT
       if (p.sdr_gamut_on) {
         const Mat3& m = p.gamut;
@@ -665,9 +707,9 @@ int resident_blocks(K kernel) {
   return per_cu * cus;
 }
 
-template <int OUT, int MAPFMT, int SMODE>
+template <int OUT, int MAPFMT, int SMODE, int BASE>
 hipError_t launch_quad(const ApplyParams& p, hipStream_t s) {
-  static const int resident = resident_blocks(apply_quad_kernel<OUT, MAPFMT, SMODE>);
+  static const int resident = resident_blocks(apply_quad_kernel<OUT, MAPFMT, SMODE, BASE>);
   const uint32_t n_frames = p.n_frames ? p.n_frames : 1;
   const uint32_t strips_x = (p.sdr.w / 2 + 63) / 64, qh = p.sdr.h / 2;
   // one balanced round: all workgroups resident; a wave owns a column strip of one frame and every
@@ -682,19 +724,27 @@ hipError_t launch_quad(const ApplyParams& p, hipStream_t s) {
   q.row_groups = groups;
   q.tiles_per_wave = ((qh + groups - 1) / groups + 1) & ~1u;
   const int grid = (int)((nwaves + kBlock / 64 - 1) / (kBlock / 64));
-  hipLaunchKernelGGL((apply_quad_kernel<OUT, MAPFMT, SMODE>), dim3(grid), dim3(kBlock), 0, s, q);
+  hipLaunchKernelGGL((apply_quad_kernel<OUT, MAPFMT, SMODE, BASE>), dim3(grid), dim3(kBlock), 0, s, q);
   return hipGetLastError();
 }
-template <int OUT, int MAPFMT>
+template <int OUT, int MAPFMT, int BASE>
 hipError_t launch_quad_s(const ApplyParams& p, int smode, hipStream_t s) {
-  return smode == 0 ? launch_quad<OUT, MAPFMT, 0>(p, s) : launch_quad<OUT, MAPFMT, 1>(p, s);
+  return smode == 0 ? launch_quad<OUT, MAPFMT, 0, BASE>(p, s) : launch_quad<OUT, MAPFMT, 1, BASE>(p, s);
 }
-template <int OUT>
+template <int OUT, int BASE>
 hipError_t launch_quad_m(const ApplyParams& p, int mapfmt, int smode, hipStream_t s) {
   switch (mapfmt) {
-    case 0: return launch_quad_s<OUT, 0>(p, smode, s);
-    case 1: return launch_quad_s<OUT, 1>(p, smode, s);
-    default: return launch_quad_s<OUT, 2>(p, smode, s);
+    case 0: return launch_quad_s<OUT, 0, BASE>(p, smode, s);
+    case 1: return launch_quad_s<OUT, 1, BASE>(p, smode, s);
+    default: return launch_quad_s<OUT, 2, BASE>(p, smode, s);
+  }
+}
+template <int OUT>
+hipError_t launch_quad_b(const ApplyParams& p, int base, int mapfmt, int smode, hipStream_t s) {
+  switch (base) {
+    case 0: return launch_quad_m<OUT, 0>(p, mapfmt, smode, s);
+    case 1: return launch_quad_m<OUT, 1>(p, mapfmt, smode, s);
+    default: return launch_quad_m<OUT, 2>(p, mapfmt, smode, s);
   }
 }
 
@@ -707,8 +757,18 @@ int apply_quad_mode(const ApplyParams& p) {
   const int out = p.out_ct == UHDR_CT_LINEAR ? 0 : (p.out_ct == UHDR_CT_HLG ? 1 : 2);
   const int mapfmt = p.gm.fmt == UHDR_IMG_FMT_8bppYCbCr400 ? 0 : (p.gm.fmt == UHDR_IMG_FMT_24bppRGB888 ? 1 : 2);
   const size_t out_bytes = out == 0 ? 8 : 4;
-  const bool quad = p.sdr.fmt == UHDR_IMG_FMT_12bppYCbCr420 && (p.sdr.w % 2 == 0) && (p.sdr.h % 2 == 0) &&
-                    (p.y0 % 2 == 0) && (p.sdr.stride[0] % 2 == 0) && aligned_to(p.sdr.p[0], 2) &&
+  // base layouts the quad kernel reads: 4:2:0, 4:4:4 (chroma pairs as 16-bit loads), packed RGBA8888 (8-byte loads)
+  bool base_ok = false;
+  if (p.sdr.fmt == UHDR_IMG_FMT_12bppYCbCr420) {
+    base_ok = (p.sdr.stride[0] % 2 == 0) && aligned_to(p.sdr.p[0], 2);
+  } else if (p.sdr.fmt == UHDR_IMG_FMT_24bppYCbCr444) {
+    base_ok = (p.sdr.stride[0] % 2 == 0) && (p.sdr.stride[1] % 2 == 0) && (p.sdr.stride[2] % 2 == 0) &&
+              aligned_to(p.sdr.p[0], 2) && aligned_to(p.sdr.p[1], 2) && aligned_to(p.sdr.p[2], 2);
+  } else if (p.sdr.fmt == UHDR_IMG_FMT_32bppRGBA8888) {
+    base_ok = (p.sdr.stride[0] % 2 == 0) && aligned_to(p.sdr.p[0], 8) && (uint64_t)p.sdr.stride[0] * 4 * p.sdr.h < 0xFFFFFFFFull;
+  }
+  const bool quad = base_ok && (p.sdr.w % 2 == 0) && (p.sdr.h % 2 == 0) &&
+                    (p.y0 % 2 == 0) &&
                     aligned_to(p.dst.p[0], 16) && ((p.dst.stride[0] * out_bytes) % 16 == 0) &&
                     p.sdr.w < 65536 && (p.sdr.h + p.y0) < 65536 && p.sdr.w >= 128 &&
                     // 32-bit byte offsets inside the kernel
@@ -737,10 +797,11 @@ hipError_t launch_apply_gainmap(const ApplyParams& p, hipStream_t s) {
   const int mapfmt = p.gm.fmt == UHDR_IMG_FMT_8bppYCbCr400 ? 0 : (p.gm.fmt == UHDR_IMG_FMT_24bppRGB888 ? 1 : 2);
   const int smode = apply_quad_mode(p);
   if (smode >= 0) {
+    const int base = p.sdr.fmt == UHDR_IMG_FMT_12bppYCbCr420 ? 0 : (p.sdr.fmt == UHDR_IMG_FMT_24bppYCbCr444 ? 1 : 2);
     switch (out) {
-      case 0: return launch_quad_m<0>(p, mapfmt, smode, s);
-      case 1: return launch_quad_m<1>(p, mapfmt, smode, s);
-      default: return launch_quad_m<2>(p, mapfmt, smode, s);
+      case 0: return launch_quad_b<0>(p, base, mapfmt, smode, s);
+      case 1: return launch_quad_b<1>(p, base, mapfmt, smode, s);
+      default: return launch_quad_b<2>(p, base, mapfmt, smode, s);
     }
   }
   if (p.n_frames > 1) return hipErrorInvalidValue;

@@ -538,3 +538,19 @@ def test_copy_raw_image_bit_exact(uhdr):
     with pytest.raises(A.UhdrError) as e:
         uhdr.copy_raw_image(rand(fmts[2], 32, 16, 16).to("cuda:0"), rand(fmts[3], 32, 16, 16).to("cuda:0"))
     assert e.value.code == A.UHDR_CODEC_UNSUPPORTED_FEATURE
+
+
+@pytest.mark.parametrize("base_fmt", [A.UHDR_IMG_FMT_24bppYCbCr444, A.UHDR_IMG_FMT_32bppRGBA8888])
+@pytest.mark.parametrize("ch,alpha,scale", [(1, False, 4), (3, False, 1), (3, True, 1), (3, True, 2)])
+@pytest.mark.parametrize("out_ct", [A.UHDR_CT_LINEAR, A.UHDR_CT_HLG, A.UHDR_CT_PQ])
+def test_apply_gainmap_quad_path_444_and_rgba_bases(uhdr, base_fmt, ch, alpha, scale, out_ct):
+    """The quad kernel's BASE 1 (4:4:4, what an API-0 stream decodes to) and BASE 2 (RGBA8888) variants."""
+    w, h = 384, 192
+    rng = np.random.default_rng(37)
+    sdr = Image(base_fmt, w, h, A.UHDR_CG_BT_709, A.UHDR_CT_SRGB, A.UHDR_CR_FULL_RANGE)
+    sdr.buf[:] = rng.integers(0, 256, sdr.buf.size, dtype=np.uint8)
+    gm = synth.make_gainmap(w // scale, h // scale, ch, alpha, cg=A.UHDR_CG_BT_2100)
+    for use_base_cg in (0, 1):
+        md = synth.default_metadata(use_base_cg=use_base_cg, per_channel=(ch == 3))
+        check_apply(uhdr, sdr, gm, md, out_ct, what=f"host ubc={use_base_cg}")
+    check_apply(uhdr, sdr, gm, synth.default_metadata(), out_ct, device=True, what="device")
