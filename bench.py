@@ -383,6 +383,21 @@ def extras(ctx, u, device):
                                                 "stages": "tonemap + generate(1 pass, max-RGB) + rgb->ycbcr444 + fdct(base 3) + rgb_to_ycc + fdct(map 3); entropy coding not included"}
     del hdr8, sdr8
     torch.cuda.empty_cache()
+    # (2b) BASELINE config 4, the per-GPU share: one 16384 x 2048 row stripe of a 16K x 16K API-1 encode
+    #      (pass 1 -> [all-reduce of 6 floats, not timed here] -> pass 2), 3-channel full-resolution map
+    from libultrahdr_amd import stripes
+
+    ws, hs = 16384, 2048
+    sdr_s = synth.make_sdr_yuv420(ws, hs, noise=0.0).to(device)
+    hdr_s = synth.make_hdr_p010(ws, hs, ct=A.UHDR_CT_HLG, noise=0.0).to(device)
+    gm_s = Image(A.UHDR_IMG_FMT_24bppRGB888, ws, hs, align=64, device=device)
+    cfg4 = A.default_encode_cfg()
+    ms = time_kernel(ctx, lambda: stripes.generate_gainmap_two_pass_striped(enc, sdr_s, hdr_s, cfg4, gm_s), iters=3, warm=1)
+    res["encode_api1_16k_stripe_16384x2048_2pass_3ch"] = {"us": round(ms * 1e3, 1), "Mpx/s": round(ws * hs / (ms / 1e3) / 1e6, 1),
+                                                          "GB/s_31.5B_per_px": round(31.5 * ws * hs / (ms / 1e3) / 1e9, 1),
+                                                          "stages": "generate pass 1 + min/max reduce + pass 2 on one rank's stripe (kernel time; the 24-byte all-reduce is latency only)"}
+    del sdr_s, hdr_s, gm_s
+    torch.cuda.empty_cache()
     # (3) decode chain, 4K: coefficient blocks -> IDCT (Y, Cb, Cr, Y400 map s=4) -> applyGainMap -> F16
     dsdr = Image(A.UHDR_IMG_FMT_12bppYCbCr420, w, h, A.UHDR_CG_BT_709, A.UHDR_CT_SRGB, A.UHDR_CR_FULL_RANGE, align=64, device=device)
     mw, mh = w // 4, (h // 4 + 7) // 8 * 8  # 960 x 544: the block grid of the 960 x 540 map
