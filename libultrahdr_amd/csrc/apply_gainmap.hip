@@ -57,7 +57,7 @@ __device__ __forceinline__ uint32_t oetf_code(float v, const float* T) {
   const uint32_t bits = __float_as_uint(v);
   const uint32_t e = ((const uint32_t*)(T + kOetfThrN))[bits >> 18];
   const uint32_t c_lo = e & 0x7fffu, c_hi = e >> 16;
-  const uint32_t est = c_lo + (__umul24(c_hi - c_lo, bits & 0x3ffffu) >> 18);  // 10-bit x 18-bit: exact in the 24-bit multiplier
+  const uint32_t est = c_lo + ((__umul24(c_hi - c_lo, bits & 0x3ffffu) + 0x20000u) >> 18);  // rounded; 10-bit x 18-bit is exact in the 24-bit multiplier
   const float t0 = T[est], t1 = T[est + 1];
   uint32_t code = est + (v >= t1 ? 1u : 0u) - (v < t0 ? 1u : 0u);
   if (__builtin_amdgcn_ballot_w64((e & 0x8000u) != 0) != 0) {  // some lane sits in a flagged bucket

@@ -152,7 +152,7 @@ static std::vector<float> make_thresholds(int ct) {
 static uint32_t device_fast_code(const std::vector<float>& t, uint32_t c_lo, uint32_t c_hi, float v) {
   uint32_t bits;
   memcpy(&bits, &v, 4);
-  const uint32_t est = c_lo + (((c_hi - c_lo) * (bits & 0x3ffffu)) >> 18);
+  const uint32_t est = c_lo + (((c_hi - c_lo) * (bits & 0x3ffffu) + 0x20000u) >> 18);  // rounded interpolation
   return est + (v >= t[est + 1] ? 1u : 0u) - (v < t[est] ? 1u : 0u);
 }
 static std::vector<float> make_threshold_block(int ct) {
