@@ -1,0 +1,178 @@
+#!/usr/bin/env python
+"""Randomised parity sweep of the HIP path against the oracle (run on the GPU box):
+    python tools/fuzz_parity.py [--seconds 60] [--seed 1]
+Random sizes (odd ones included), formats, map layouts / scales, metadata, strides.  Prints one line per
+mismatch and a summary; exit code 1 if anything that must be bit-exact differs."""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch  # noqa: F401
+
+from libultrahdr_amd import capi as A
+from libultrahdr_amd import synth
+from libultrahdr_amd.images import Image
+from libultrahdr_amd.ultrahdr import Context, UltraHdr
+from oracle import loader as L
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seconds", type=float, default=60)
+ap.add_argument("--seed", type=int, default=1)
+args = ap.parse_args()
+rng = np.random.default_rng(args.seed)
+ctx = Context(0)
+u = UltraHdr(ctx=ctx)
+F16, U32 = A.UHDR_IMG_FMT_64bppRGBAHalfFloat, A.UHDR_IMG_FMT_32bppRGBA1010102
+stats = {}
+bad = 0
+
+
+def rand_image(fmt, w, h, cg=None, align=None):
+    img = Image(fmt, w, h, int(rng.integers(0, 3)) if cg is None else cg, A.UHDR_CT_SRGB, A.UHDR_CR_FULL_RANGE,
+                align=int(rng.choice([1, 2, 8, 64])) if align is None else align)
+    img.buf[:] = rng.integers(0, 256, img.buf.size, dtype=np.uint8)
+    return img
+
+
+def note(op, ok, detail=""):
+    global bad
+    s = stats.setdefault(op, [0, 0])
+    s[0] += 1
+    if not ok:
+        s[1] += 1
+        bad += 1
+        print("MISMATCH", op, detail, flush=True)
+
+
+def fuzz_apply():
+    w = int(rng.choice([64, 130, 131, 200, 256, 384, 515]))
+    h = int(rng.choice([32, 66, 67, 128, 130]))
+    base_fmt = int(rng.choice([A.UHDR_IMG_FMT_12bppYCbCr420, A.UHDR_IMG_FMT_24bppYCbCr444, A.UHDR_IMG_FMT_16bppYCbCr422,
+                               A.UHDR_IMG_FMT_32bppRGBA8888]))
+    if base_fmt == A.UHDR_IMG_FMT_16bppYCbCr422:
+        w += w % 2
+    sdr = rand_image(base_fmt, w, h, align=int(rng.choice([1, 2, 64])) if base_fmt != A.UHDR_IMG_FMT_12bppYCbCr420 else int(rng.choice([2, 64])))
+    scale = int(rng.choice([1, 1, 2, 3, 4, 8]))
+    mw, mh = max(w // scale, 1), max(h // scale, 1)
+    if rng.random() < 0.15:  # non-integer ratio with the same aspect is rare; keep the map covering the image
+        mw, mh = w, h
+    ch = int(rng.choice([1, 3]))
+    alpha = bool(ch == 3 and rng.random() < 0.5)
+    gm = synth.make_gainmap(mw, mh, ch, alpha, seed=int(rng.integers(1 << 30)), cg=int(rng.integers(0, 3)), align=int(rng.choice([1, 2, 64])))
+    md = synth.default_metadata(max_boost=float(rng.uniform(1.5, 16)), min_boost=float(rng.uniform(0.5, 1.0)),
+                                gamma=1.0 if rng.random() < 0.7 else float(rng.uniform(0.5, 2.5)),
+                                offset=float(rng.choice([0.0, 1e-7, 1 / 64])), use_base_cg=int(rng.integers(0, 2)), per_channel=bool(ch == 3 and rng.random() < 0.5))
+    ct = int(rng.choice([A.UHDR_CT_LINEAR, A.UHDR_CT_HLG, A.UHDR_CT_PQ]))
+    boost = A.FLT_MAX if rng.random() < 0.6 else float(rng.uniform(1.0, md.hdr_capacity_max))
+    fmt = F16 if ct == A.UHDR_CT_LINEAR else U32
+    try:
+        want = L.apply_gainmap("port", sdr, gm, md, ct, boost)
+    except A.UhdrError as e:
+        dest = Image(fmt, w, h, align=2)
+        try:
+            u.applyGainMap(sdr, gm, md, ct, fmt, boost, dest)
+            note("apply-error", False, f"oracle raised {e.code}, hip succeeded")
+        except A.UhdrError as e2:
+            note("apply-error", e2.code == e.code, f"codes {e.code} vs {e2.code}")
+        return
+    dest = Image(fmt, w, h, align=2)
+    try:
+        u.applyGainMap(sdr, gm, md, ct, fmt, boost, dest)
+    except A.UhdrError as e:
+        note("apply", False, f"hip raised {e.code} {e}: fmt{base_fmt} {w}x{h} s{scale}")
+        return
+    exact_expected = md.gamma[0] == 1.0 or (mw == w and mh == h)
+    a, b = dest.valid(0), want.valid(0)
+    if exact_expected:
+        note("apply-exact", np.array_equal(a, b), f"fmt{base_fmt} {w}x{h} map {mw}x{mh} ch{ch} a{alpha} ct{ct} diff {(a != b).sum()}")
+    else:
+        if ct == A.UHDR_CT_LINEAR:
+            d = np.abs(a.view(np.uint16).astype(np.int32) - b.view(np.uint16).astype(np.int32))
+        else:
+            d = np.abs(np.stack([(a >> s) & 0x3FF for s in (0, 10, 20)], -1).astype(np.int32) - np.stack([(b >> s) & 0x3FF for s in (0, 10, 20)], -1).astype(np.int32))
+        note("apply-pow", d.max() <= 1 and (d != 0).mean() < 2e-3, f"max {d.max()} frac {(d != 0).mean():.2e}")
+
+
+def fuzz_generate():
+    w, h = int(rng.choice([64, 128, 130, 256])), int(rng.choice([32, 64, 66]))
+    kind = rng.choice(["p010", "1010102"])
+    ct = int(rng.choice([A.UHDR_CT_HLG, A.UHDR_CT_PQ]))
+    if kind == "p010":
+        hdr = synth.make_hdr_p010(w, h, seed=int(rng.integers(1 << 30)), ct=ct, cg=int(rng.integers(0, 3)), noise=0.06,
+                                  rng_range=int(rng.choice([A.UHDR_CR_LIMITED_RANGE, A.UHDR_CR_FULL_RANGE])))
+        sdr = synth.make_sdr_yuv420(w, h, seed=int(rng.integers(1 << 30)), cg=int(rng.integers(0, 3)), noise=0.06)
+    else:
+        hdr = synth.make_hdr_rgba1010102(w, h, seed=int(rng.integers(1 << 30)), ct=ct, cg=int(rng.integers(0, 3)), noise=0.06)
+        sdr = synth.make_sdr_rgba8888(w, h, seed=int(rng.integers(1 << 30)), cg=int(rng.integers(0, 3)), noise=0.06)
+    cfg = A.default_encode_cfg(map_dimension_scale_factor=int(rng.choice([1, 1, 2, 4])), use_multi_channel_gainmap=int(rng.integers(0, 2)),
+                               preset=int(rng.choice([A.UHDR_USAGE_REALTIME, A.UHDR_USAGE_BEST_QUALITY])), use_luminance=int(rng.integers(0, 2)),
+                               sdr_is_601=int(rng.integers(0, 2)), gamma=1.0 if rng.random() < 0.7 else float(rng.uniform(0.6, 2.0)))
+    md_w, gm_w = L.generate_gainmap("port", sdr, hdr, cfg)
+    from libultrahdr_amd.ultrahdr import UltraHdr as UH
+
+    g = UH(ctx=ctx, mapDimensionScaleFactor=cfg.map_dimension_scale_factor, useMultiChannelGainMap=bool(cfg.use_multi_channel_gainmap),
+           gamma=cfg.gamma, preset=cfg.preset, minContentBoost=cfg.min_content_boost, maxContentBoost=cfg.max_content_boost,
+           targetDispPeakBrightness=cfg.target_disp_peak_nits)
+    md_g, gm_g = g.generateGainMap(sdr, hdr, bool(cfg.sdr_is_601), bool(cfg.use_luminance))
+    d = np.abs(gm_g.valid(0).astype(np.int32) - gm_w.valid(0).astype(np.int32))
+    tol = 1e-4 if cfg.gamma == 1.0 else 5e-3
+    note("generate", d.max() <= 1 and (d != 0).mean() <= tol and md_g.as_dict() == md_w.as_dict(),
+         f"{kind} ct{ct} s{cfg.map_dimension_scale_factor} mc{cfg.use_multi_channel_gainmap} preset{cfg.preset} gamma{cfg.gamma:.2f} max {d.max()} frac {(d != 0).mean():.2e} md_eq {md_g.as_dict() == md_w.as_dict()}")
+
+
+def fuzz_tonemap():
+    w, h = int(rng.choice([64, 130, 256])), int(rng.choice([32, 66, 64]))
+    kind = rng.choice(["p010", "1010102"])
+    ct = int(rng.choice([A.UHDR_CT_HLG, A.UHDR_CT_PQ, A.UHDR_CT_LINEAR]))
+    cg = int(rng.integers(0, 3))
+    hdr = (synth.make_hdr_p010(w, h, seed=int(rng.integers(1 << 30)), ct=ct, cg=cg, noise=0.06) if kind == "p010"
+           else synth.make_hdr_rgba1010102(w, h, seed=int(rng.integers(1 << 30)), ct=ct, cg=cg, noise=0.06))
+    want = L.tone_map("port", hdr)
+    got = Image(want.fmt, w, h, align=64)
+    u.toneMap(hdr, got)
+    n = tot = mx = 0
+    for pg, pw in zip(got.planes_valid(), want.planes_valid()):
+        if pg.dtype == np.uint32:
+            pg, pw = pg.view(np.uint8), pw.view(np.uint8)
+        d = np.abs(pg.astype(np.int32) - pw.astype(np.int32))
+        n += int((d != 0).sum()); tot += d.size; mx = max(mx, int(d.max()))
+    note("tonemap", mx <= 1 and n / tot <= 1e-4, f"{kind} ct{ct} cg{cg} max {mx} differ {n}/{tot}")
+
+
+def fuzz_converts():
+    w, h = int(rng.choice([64, 130, 256])), int(rng.choice([32, 66, 64]))
+    fmt = int(rng.choice([A.UHDR_IMG_FMT_32bppRGBA1010102, A.UHDR_IMG_FMT_32bppRGBA8888, A.UHDR_IMG_FMT_24bppRGB888]))
+    img = rand_image(fmt, w, h, align=64)
+    chroma = bool(rng.integers(0, 2))
+    want = L.convert_raw_input_to_ycbcr("port", img, chroma)
+    got = u.convert_raw_input_to_ycbcr(img, chroma)
+    note("raw2ycc", all(np.array_equal(a, b) for a, b in zip(got.planes_valid(), want.planes_valid())), f"fmt{fmt} chroma{chroma}")
+    yfmt = int(rng.choice([A.UHDR_IMG_FMT_12bppYCbCr420, A.UHDR_IMG_FMT_24bppYCbCr444]))
+    src, dst = [int(v) for v in rng.choice(3, 2, replace=False)]
+    img = rand_image(yfmt, w, h, cg=src, align=64)
+    want = L.convert_yuv("port", img, src, dst)
+    got = img.clone()
+    u.convertYuv(got, src, dst)
+    note("convertYuv", all(np.array_equal(a, b) for a, b in zip(got.planes_valid(), want.planes_valid())), f"fmt{yfmt} {src}->{dst}")
+    # JPEG stage
+    bw, bh = int(rng.integers(1, 40)), int(rng.integers(1, 12))
+    plane = np.ascontiguousarray(rng.integers(0, 256, (bh * 8, bw * 8), dtype=np.uint8))
+    q = int(rng.integers(1, 101))
+    qt = u.quant_table(q, bool(rng.integers(0, 2)))
+    coef = u.fdct_quant(plane, bw * 8, bw, bh, qt)
+    note("fdct", np.array_equal(coef, L.fdct_quant_port(plane, bw * 8, bw, bh, qt)), f"{bw}x{bh} q{q}")
+    note("idct", np.array_equal(u.idct_dequant(coef, qt), L.idct_dequant_port(coef, qt)), f"{bw}x{bh} q{q}")
+
+
+t_end = time.time() + args.seconds
+jobs = [fuzz_apply, fuzz_apply, fuzz_apply, fuzz_generate, fuzz_tonemap, fuzz_converts]
+i = 0
+while time.time() < t_end:
+    jobs[i % len(jobs)]()
+    i += 1
+print("cases per op (run, mismatched):", {k: tuple(v) for k, v in stats.items()})
+sys.exit(1 if bad else 0)
