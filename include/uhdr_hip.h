@@ -232,6 +232,10 @@ int uhdr_hip_oetf_code_thresholds(uhdr_color_transfer_t ct, float thresholds[102
  *   fn 1: (float)log2((double)in)           (gainmapmath.cpp:767, 774, double log2 replaced)
  *   fn 2: division by a library constant: in[0] = b, out[0] = 1/b, out[i] = in[i] / b by the kernels'
  *         reciprocal-multiply-and-correct sequence (csrc/device_math.h div_const), i >= 1
+ *   fn 3: division by an arbitrary per-call divisor through its float64 reciprocal: in[0] = b,
+ *         out[i] = (float)((double)in[i] * (1.0 / (double)b)) (csrc/device_math.h div_by_rcp64), i >= 1
+ *   fn 4: (a, b) pairs: out[2i] = a / b through a float64 reciprocal refined from a deliberately
+ *         2-ulp-off float seed (csrc/device_math.h rcp64_of_f32, the tone mapper's shared-divisor divisions)
  * Returns 0, or -1 for an unknown fn. */
 int uhdr_hip_exact_math_eval(int fn, const float* in, float* out, size_t n);
 /* islow 8x8 FDCT + quantize of one 8-bit plane.  Reads blocks_w*8 x blocks_h*8 samples (the

@@ -138,6 +138,27 @@ struct Rgb2Yuv {
 #else
 #define UHDR_HD_MATH inline
 #endif
+// a / b for ANY float divisor whose float64 reciprocal rbd = 1.0 / (double)b the host (or the caller,
+// once per divisor) has computed: RN24((double)a * rbd) == RN24(a / b) for all normal a, b.  Proof: the
+// exact quotient of two 24-bit significands is never closer than 2^-49 (relative) to a midpoint
+// between adjacent floats (|A 2^k - M B| >= 1 for the integer significands A, B and an odd M), while
+// the float64 product is within 2^-52 of the quotient (2^-53 from rbd, 2^-53 from the multiply).
+// Three instructions: cvt, v_mul_f64, cvt.
+UHDR_HD_MATH float div_by_rcp64(float a, double rbd) { return (float)((double)a * rbd); }
+
+// The float64 reciprocal of a VARIABLE float divisor, good to 2^-52: v_rcp_f32 (1 ulp) refined by two
+// Newton steps in float64 (the first residual 1 - b*r0 is exact: both factors are floats).  Worth it
+// when several numerators share the divisor (the three channels of the Reinhard curve): 7 instructions
+// once, then 3 per quotient through div_by_rcp64, against ~11 per IEEE division.
+UHDR_HD_MATH double rcp64_of_f32(float b, float r0 /* ~1/b to within a few float ulps */) {
+  const double bd = (double)b;
+  double r = (double)r0;
+  double e = fma(-bd, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-bd, r, 1.0);
+  return fma(r, e, r);
+}
+
 UHDR_HD_MATH float div_const(float a, float b, float rb) {
   const float q0 = a * rb;
   const float r = __builtin_fmaf(-b, q0, a);

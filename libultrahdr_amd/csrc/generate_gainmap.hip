@@ -186,7 +186,7 @@ __global__ __launch_bounds__(kBlock) void affine_kernel(const AffineParams p) {
     uint8_t* dst = p.out + (size_t)y * p.out_stride * p.nch;
     auto map1 = [&](float g, uint32_t e) -> uint32_t {
       const uint32_t c = p.nch == 3 ? e % 3 : 0;
-      float m = (g - p.mn[c]) / (p.mx[c] - p.mn[c]);
+      float m = div_by_rcp64(g - p.mn[c], p.range_rcp[c]);  // (g - min) / (max - min), exact (device_math.h)
       if (p.gamma != 1.0f) m = (float)pow((double)m, (double)p.gamma);
       m *= 255.0f;
       float t2 = m + 0.5f;

@@ -68,10 +68,13 @@ __device__ __forceinline__ Color3 tone_map_pixel(const ToneMapParams& p, const T
   float ms = 1.0f + div_const(mx, p.headroom_sq, p.headroom_sq_rcp);  // ReinhardMap: mx / (hr * hr), divisor is a per-transfer constant
   ms /= 1.0f + mx;
   ms = ms * mx;
+  // c * max_sdr / max_hdr for the three channels (jpegr.cpp:1968-1972): one shared float64 reciprocal of
+  // max_hdr, each quotient exact (device_math.h: rcp64_of_f32, div_by_rcp64); mx == 0 implies c <= 0
+  const double rmx = rcp64_of_f32(mx, __builtin_amdgcn_rcpf(mx));
   Color3 o;
-  o.r = c0 > 0.0f ? c0 * ms / mx : 0.0f;
-  o.g = c1 > 0.0f ? c1 * ms / mx : 0.0f;
-  o.b = c2 > 0.0f ? c2 * ms / mx : 0.0f;
+  o.r = c0 > 0.0f ? div_by_rcp64(c0 * ms, rmx) : 0.0f;
+  o.g = c1 > 0.0f ? div_by_rcp64(c1 * ms, rmx) : 0.0f;
+  o.b = c2 > 0.0f ? div_by_rcp64(c2 * ms, rmx) : 0.0f;
   if (p.gamut_on) o = mat3_apply(o, p.gamut);
   o.r = clamp01(o.r); o.g = clamp01(o.g); o.b = clamp01(o.b);
   // srgbOetf (gainmapmath.cpp:139-148) with the table pow of exact_math.h

@@ -768,7 +768,10 @@ uhdr_error_info_t uhdr_hip_generate_gainmap_pass2_dev(uhdr_hip_ctx_t* c, const f
   a.out = (uint8_t*)gm->planes[0];
   a.map_w = gm->w; a.map_h = gm->h; a.out_stride = gm->stride[0];
   a.nch = cfg->use_multi_channel_gainmap ? 3 : 1;
-  for (int i = 0; i < 3; i++) { a.mn[i] = mm[i]; a.mx[i] = mm[3 + i]; }
+  for (int i = 0; i < 3; i++) {
+    a.mn[i] = mm[i]; a.mx[i] = mm[3 + i];
+    a.range_rcp[i] = 1.0 / (double)(a.mx[i] - a.mn[i]);
+  }
   a.gamma = cfg->gamma;
   ProfScope ps(c, "generate_gainmap");
   HIP_TRY(launch_affine_map(a, c->stream));
@@ -1011,13 +1014,29 @@ int uhdr_hip_oetf_code_thresholds(uhdr_color_transfer_t ct, float thresholds[102
 }
 
 int uhdr_hip_exact_math_eval(int fn, const float* in, float* out, size_t n) {
-  if (!in || !out || fn < 0 || fn > 2) return -1;
+  if (!in || !out || fn < 0 || fn > 4) return -1;
   const double* T = host::math_tables().data();
   if (fn == 2) {  // in[0] = the constant divisor b; out[i] = div_const(in[i], b, 1/b) for i >= 1
     if (n < 1) return -1;
     const float b = in[0], rb = 1.0f / b;
     out[0] = rb;
     for (size_t i = 1; i < n; i++) out[i] = div_const(in[i], b, rb);
+    return 0;
+  }
+  if (fn == 4) {  // pairs (a, b): out[2i] = a / b through rcp64_of_f32 seeded with a 2-ulp-off float reciprocal
+    for (size_t i = 0; i + 1 < n; i += 2) {
+      const float b = in[i + 1];
+      const float seed = nextafterf(nextafterf(1.0f / b, INFINITY), INFINITY);  // worse than v_rcp_f32's 1 ulp
+      out[i] = div_by_rcp64(in[i], rcp64_of_f32(b, seed));
+      out[i + 1] = seed;
+    }
+    return 0;
+  }
+  if (fn == 3) {  // in[0] = any divisor b; out[i] = div_by_rcp64(in[i], 1.0 / (double)b) for i >= 1
+    if (n < 1) return -1;
+    const double rbd = 1.0 / (double)in[0];
+    out[0] = (float)rbd;
+    for (size_t i = 1; i < n; i++) out[i] = div_by_rcp64(in[i], rbd);
     return 0;
   }
   for (size_t i = 0; i < n; i++) out[i] = fn == 0 ? srgb_oetf_table(in[i], T) : (float)log2_table_f64(in[i], T);

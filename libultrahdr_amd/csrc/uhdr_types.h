@@ -114,6 +114,7 @@ struct AffineParams {
   uint8_t* out;
   uint32_t map_w, map_h, out_stride, nch;
   float mn[3], mx[3];
+  double range_rcp[3];  // 1.0 / (double)(mx[c] - mn[c]) with the float subtraction the reference performs
   float gamma;
 };
 

@@ -99,3 +99,37 @@ def test_div_const_is_exact_for_every_library_constant(b):
     assert out[0] == np.float32(1.0) / np.float32(b)
     want = buf[1:] / np.float32(b)
     assert np.array_equal(out[1:].view(np.uint32), want.view(np.uint32))
+
+
+def test_division_through_a_float64_reciprocal_is_exact_for_any_divisor():
+    """affineMapGain divides by (max - min), a different divisor per image: RN24((double)a * RN53(1/b)) ==
+    RN24(a / b) for all normal floats (proof in csrc/device_math.h).  Random and adversarial divisors."""
+    lib = A.load()
+    rng = np.random.default_rng(11)
+    divisors = np.concatenate([np.exp2(rng.uniform(-20, 20, 300)).astype(np.float32),
+                               (np.uint32(0x3F800000) + rng.integers(0, 1 << 23, 300, dtype=np.uint32)).view(np.float32),
+                               np.float32([3.0, 7.0, 0.1, 5.7, 1.9999999, 1.0000001, 29.9, 1e-3])])
+    a = np.concatenate([(np.uint32(0x3F800000) | rng.integers(0, 1 << 23, 200000, dtype=np.uint32)).view(np.float32),
+                        np.exp2(rng.uniform(-30, 30, 50000)).astype(np.float32) * rng.choice(np.float32([-1, 1]), 50000)])
+    for b in divisors:
+        buf = np.concatenate([np.float32([b]), a, (a[:20000] * b).astype(np.float32)])  # incl. near-exact quotients
+        out = np.empty_like(buf)
+        assert lib.uhdr_hip_exact_math_eval(3, buf.ctypes.data_as(C.POINTER(C.c_float)), out.ctypes.data_as(C.POINTER(C.c_float)), buf.size) == 0
+        want = buf[1:] / np.float32(b)
+        assert np.array_equal(out[1:].view(np.uint32), want.view(np.uint32)), float(b)
+
+
+def test_shared_divisor_division_is_exact():
+    """Reinhard's three c * ms / mx share the divisor: float64 reciprocal by Newton from a float seed (a
+    2-ulp-off one here, worse than v_rcp_f32), then the float64-multiply quotient == IEEE a / b."""
+    lib = A.load()
+    rng = np.random.default_rng(13)
+    n = 4_000_000
+    a = (np.exp2(rng.uniform(-24, 8, n)) * rng.choice([1.0, 1.0, -1.0], n)).astype(np.float32)
+    b = np.exp2(rng.uniform(-24, 8, n)).astype(np.float32)
+    a[: n // 4] = (b[: n // 4] * rng.integers(1, 1 << 12, n // 4).astype(np.float32)).astype(np.float32)  # near-exact quotients
+    buf = np.empty(2 * n, dtype=np.float32)
+    buf[0::2], buf[1::2] = a, b
+    out = np.empty_like(buf)
+    assert lib.uhdr_hip_exact_math_eval(4, buf.ctypes.data_as(C.POINTER(C.c_float)), out.ctypes.data_as(C.POINTER(C.c_float)), buf.size) == 0
+    assert np.array_equal(out[0::2].view(np.uint32), (a / b).view(np.uint32))
