@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Randomised parity sweep of the HIP path against the oracle (run on the GPU box):
-    python tools/fuzz_parity.py [--seconds 60] [--seed 1]
+    python tests/fuzz_parity.py [--seconds 60] [--seed 1]
 Random sizes (odd ones included), formats, map layouts / scales, metadata, strides.  Prints one line per
 mismatch and a summary; exit code 1 if anything that must be bit-exact differs."""
 import argparse
@@ -8,7 +8,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root (this script lives in tests/)
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch  # noqa: F401

@@ -230,7 +230,7 @@ def test_generate_gainmap(hip_ctx, hdr_kw, sdr_kind, cfg_kw, device):
     """The per-sample double log2 runs on float64 tables (csrc/exact_math.h) whose result is the
     correctly rounded float in all but ~1e-8 of the cases, HLG's powf is folded into a host-built
     table: measured bit-identical to the real reference on every case at 1280x720
-    (tools/parity_stats.py).  Allowed here: +-1 map code on <= 1e-4 of the samples (gamma != 1 keeps a
+    (tests/parity_stats.py).  Allowed here: +-1 map code on <= 1e-4 of the samples (gamma != 1 keeps a
     device powf per sample); metadata within 1e-6 relative."""
     sdr, hdr = _pair(256, 128, hdr_kw, sdr_kind)
     cfg = A.default_encode_cfg(**cfg_kw)
@@ -294,7 +294,7 @@ def test_tone_map(uhdr, kind, ct, cg):
     """srgbOetf's powf runs on float64 tables (correctly rounded; glibc's powf is faithfully rounded and
     differs from that by one ulp on ~5e-4 of its inputs, which moves an 8-bit code about once per 1e7
     samples); HLG's OOTF powf is folded into a host-built table.  Measured bit-identical to the real
-    reference on every case at 1280x720 (tools/parity_stats.py).  Allowed: +-1 code on <= 1e-4 of samples."""
+    reference on every case at 1280x720 (tests/parity_stats.py).  Allowed: +-1 code on <= 1e-4 of samples."""
     w, h = 256, 128
     hdr = synth.make_hdr_p010(w, h, ct=ct, cg=cg) if kind == "p010" else synth.make_hdr_rgba1010102(w, h, ct=ct, cg=cg)
     want = L.tone_map(oracle_kind(), hdr)

@@ -18,6 +18,22 @@ ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--sets", type=int, default=2)
 args = ap.parse_args()
 
+if args.case in ("gen4k", "tm4k"):  # encode-side kernels: two-pass 3-channel generate / P010 tone map, 4K
+    w, h = 3840, 2160
+    ctx = Context(0)
+    sdr = synth.make_sdr_yuv420(w, h).to("cuda:0")
+    hdr = synth.make_hdr_p010(w, h, ct=A.UHDR_CT_HLG).to("cuda:0")
+    enc = UltraHdr(ctx=ctx, mapDimensionScaleFactor=1, useMultiChannelGainMap=True, preset=A.UHDR_USAGE_BEST_QUALITY)
+    out = Image(A.UHDR_IMG_FMT_12bppYCbCr420, w, h, align=64, device="cuda:0")
+    for i in range(args.iters):
+        if args.case == "gen4k":
+            enc.generateGainMap(sdr, hdr)
+        else:
+            enc.toneMap(hdr, out)
+    ctx.synchronize()
+    print("done", args.case, args.iters)
+    sys.exit(0)
+
 w, h = (7680, 4320) if args.case.startswith("8k") else (3840, 2160)
 mk = args.case[2]
 ct = A.UHDR_CT_HLG if "hlg" in args.case else A.UHDR_CT_PQ if "pq" in args.case else A.UHDR_CT_LINEAR
