@@ -305,6 +305,22 @@ __device__ __forceinline__ uint32_t pkrtz_bits(uint32_t a, uint32_t b) {
   const h2 v = __builtin_amdgcn_cvt_pkrtz(__uint_as_float(a), __uint_as_float(b));
   return __builtin_bit_cast(uint32_t, v);
 }
+// floatToHalf (gainmapmath.h:160-173) for 0 <= v <= kMaxPixelFloatHdrLinear, including results in the
+// sub-normal half range.  With b = bits + 0x1000 (the routine's round-half-up step): when the exponent
+// of b is in the normal-half range the result is the float of bits b truncated (v_cvt_pkrtz); below it
+// the routine computes (((0x7FF000 + mant(b)) >> (125 - exp(b))) + 1) >> 1, i.e. it takes the +0x1000 back
+// out and rounds the ORIGINAL value: (floor(v * 2^25) + 1) >> 1, which is also 0 exactly where the routine
+// flushes to zero.  Checked against the bit routine for every float of the sub-normal range and across
+// both boundaries: tests/test_host_logic.py::test_half_subnormal_formula.
+__device__ __forceinline__ uint32_t half_small_pair(uint32_t bits0, uint32_t bits1) {
+  const uint32_t b0 = bits0 + 0x1000u, b1 = bits1 + 0x1000u;
+  const uint32_t nrm = pkrtz_bits(b0, b1);
+  const uint32_t s0 = (cvt_u32_sat(__uint_as_float(bits0) * 33554432.0f) + 1u) >> 1;
+  const uint32_t s1 = (cvt_u32_sat(__uint_as_float(bits1) * 33554432.0f) + 1u) >> 1;
+  const uint32_t lo = b0 < (113u << 23) ? s0 : (nrm & 0xffffu);
+  const uint32_t hi = b1 < (113u << 23) ? s1 : (nrm >> 16);
+  return lo | (hi << 16);
+}
 __device__ __forceinline__ f2 lds_gather(const float* base, uint2 byte_off) {
 #ifdef UHDR_EXP_NOLDS  // experiment (tools/kbench): no LDS traffic
   return (f2){__uint_as_float(byte_off.x | 0x3f000000u), __uint_as_float(byte_off.y | 0x3f000000u)};
@@ -651,10 +667,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
           o.z = pkrtz_bits(__float_as_uint(c1r) + 0x1000u, __float_as_uint(c1g) + 0x1000u);
           o.w = pkrtz_bits(__float_as_uint(c1b) + 0x1000u, 0x3F800000u);
         } else {
-          o.x = float_to_half_general(__float_as_uint(c0r)) | (float_to_half_general(__float_as_uint(c0g)) << 16);
-          o.y = float_to_half_general(__float_as_uint(c0b)) | (0x3C00u << 16);
-          o.z = float_to_half_general(__float_as_uint(c1r)) | (float_to_half_general(__float_as_uint(c1g)) << 16);
-          o.w = float_to_half_general(__float_as_uint(c1b)) | (0x3C00u << 16);
+          // some value of the wave lands in the sub-normal half range (black or near-black pixels)
+          o.x = half_small_pair(__float_as_uint(c0r), __float_as_uint(c0g));
+          o.y = half_small_pair(__float_as_uint(c0b), 0x3F800000u - 0x1000u);
+          o.z = half_small_pair(__float_as_uint(c1r), __float_as_uint(c1g));
+          o.w = half_small_pair(__float_as_uint(c1b), 0x3F800000u - 0x1000u);
         }
 #ifdef UHDR_EXP_NOSTORE  // experiment (tools/kbench): keep the math alive, never store
         if (o.x == 0x12345678u && o.w == 0x9abcdef0u)

@@ -115,3 +115,28 @@ def test_jpeg_rgb_to_ycc_constant_sets_are_equivalent():
         res.append((y, cb, cr))
     for a, bb in zip(*res):
         assert np.array_equal(a, bb)
+
+
+def test_half_subnormal_formula():
+    """apply_gainmap.hip::half_small_pair: for non-negative v, floatToHalf's sub-normal branch
+    (((0x7FF000 + mant(b)) >> (125 - exp(b))) + 1) >> 1 with b = bits + 0x1000 equals (floor(v * 2^25) + 1) >> 1 on the
+    ORIGINAL v -- checked against the oracle's bit routine for EVERY float whose rounded exponent is below the
+    normal-half range (incl. the flush-to-zero region) and across the boundary."""
+    from oracle import loader as L
+
+    port = L.port()
+    lo, hi = 96 << 23, (114 << 23) + 4096
+    for start in range(lo, hi, 1 << 24):
+        bits = np.arange(start, min(start + (1 << 24), hi), dtype=np.uint32)
+        want = np.empty(bits.size, dtype=np.uint16)
+        port.uo_float_to_half(bits.view(np.float32).ctypes.data, want.ctypes.data, bits.size)
+        b = bits + np.uint32(0x1000)
+        sub = (np.floor(bits.view(np.float32).astype(np.float64) * 33554432.0).astype(np.uint32) + 1) >> 1
+        e = b >> 23
+        nrm = (((e.astype(np.int64) - 112) << 10) | ((b & 0x7FFFFF) >> 13)).astype(np.uint32)  # what v_cvt_pkrtz yields for normal halves
+        got = np.where(b < (113 << 23), sub, nrm).astype(np.uint16)
+        assert np.array_equal(got, want), hex(start)
+    zero = np.zeros(1, np.float32)
+    out = np.empty(1, np.uint16)
+    port.uo_float_to_half(zero.ctypes.data, out.ctypes.data, 1)
+    assert out[0] == 0
