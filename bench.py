@@ -381,6 +381,14 @@ def extras(ctx, u, device):
     res["encode_api0_8k_rgba1010102_chain"] = {"us": round(ms * 1e3, 1), "Mpx/s": round(w8 * h8 / (ms / 1e3) / 1e6, 1),
                                                 "GB/s_unfused_44B_per_px": round(44.0 * w8 * h8 / (ms / 1e3) / 1e9, 1),
                                                 "stages": "tonemap + generate(1 pass, max-RGB) + rgb->ycbcr444 + fdct(base 3) + rgb_to_ycc + fdct(map 3); entropy coding not included"}
+    def api0_fused():
+        _, ycc_, md_, gm_ = api0_enc.encodeApi0Fused(hdr8, want_sdr_rgba=False, use_luminance=False)
+        fdct_planes(ycc_, (0, 1, 2), (qy, qc, qc))
+        fdct_planes(u.jpeg_rgb_to_ycc(gm_), (0, 1, 2), (qy, qc, qc))
+
+    ms = time_kernel(ctx, api0_fused, iters=3, warm=1)
+    res["encode_api0_8k_rgba1010102_chain_fused_front_end"] = {"us": round(ms * 1e3, 1), "Mpx/s": round(w8 * h8 / (ms / 1e3) / 1e6, 1),
+                                                                "stages": "fused(tonemap + generate 1 pass + rgb->ycbcr444) + fdct(base 3) + rgb_to_ycc + fdct(map 3)"}
     del hdr8, sdr8
     torch.cuda.empty_cache()
     # (2b) BASELINE config 4, the per-GPU share: one 16384 x 2048 row stripe of a 16K x 16K API-1 encode

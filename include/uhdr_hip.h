@@ -249,6 +249,18 @@ uhdr_error_info_t uhdr_hip_fdct_quant_dev(uhdr_hip_ctx_t* ctx, const uint8_t* pl
                                           int blocks_w, int blocks_h, const uint16_t qtable[64],
                                           int16_t* coef);
 
+/* MI355X extension: the three full-image loops JpegR::encodeJPEGR API-0 runs back to back (lib/src/jpegr.cpp:202-251:
+ * toneMap, generateGainMap on the tone-mapped image, convert_raw_input_to_ycbcr for the base JPEG) in ONE pass over the
+ * HDR image: 4 B/px in, 3 + 3 B/px out instead of 26 B/px of traffic.  Device images only.  hdr: RGBA1010102 or
+ * RGBA-F16; cfg->map_dimension_scale_factor must be 1; sdr_rgba (may be NULL, or planes[0] NULL) optionally receives
+ * the RGBA8888 SDR rendition; base_ycc receives YCbCr 4:4:4 planes; md / gainmap as uhdr_hip_generate_gainmap_dev.
+ * Outputs are bit-identical to uhdr_hip_tone_map_dev -> uhdr_hip_generate_gainmap_dev ->
+ * uhdr_hip_convert_raw_input_to_ycbcr_dev(.., 0, ..). */
+uhdr_error_info_t uhdr_hip_encode_api0_fused_dev(uhdr_hip_ctx_t* ctx, const uhdr_raw_image_t* hdr,
+                                                 const uhdr_hip_encode_cfg_t* cfg, uhdr_raw_image_t* sdr_rgba,
+                                                 uhdr_raw_image_t* base_ycc, uhdr_gainmap_metadata_t* metadata,
+                                                 uhdr_raw_image_t* gainmap);
+
 /* copy_raw_image(src, dst) (lib/src/gainmapmath.cpp:1492-1613) between device images: strided plane copies
  * for equal formats, RGB888 -> RGBA8888 (alpha 0xff), RGBA8888 -> Y400 (R byte); same error codes
  * (UHDR_CODEC_MEM_ERROR for a size mismatch, UHDR_CODEC_UNSUPPORTED_FEATURE for other format pairs).

@@ -1,0 +1,106 @@
+// API-0 encode front end in ONE pass over the HDR image (MI355X extension, not a reference operator).
+//
+// JpegR::encodeJPEGR API-0 (/root/reference/lib/src/jpegr.cpp:202-251) runs three full-image loops
+// back to back: toneMap (HDR -> 8-bit SDR RGBA8888), generateGainMap (reads both images again) and
+// convert_raw_input_to_ycbcr (reads the SDR image a third time to make the base JPEG's planes).
+// Unfused that is 4+4, 4+4+3 and 4+3 bytes per pixel of HBM traffic and every HDR pixel is unpacked
+// and linearised twice.  Here one thread carries a pixel through all three stages in registers:
+// 4 bytes in (RGBA1010102; 8 for RGBA-F16), 3 (base YCbCr 4:4:4) + 3 (map, or 12 of float gains in
+// two-pass mode) out, + 4 if the caller also wants the RGBA8888 SDR rendition.
+//
+// The arithmetic is the same sequence of IEEE operations as the three kernels (encode_core.h), and
+// the 8-bit quantisation between the stages is kept: the gain map is computed from the QUANTISED SDR
+// bytes exactly as generateGainMap would read them back.  tests/test_gpu_parity.py checks the fused
+// outputs against tone_map -> generate_gainmap -> convert_raw_input_to_ycbcr, bit for bit.
+// Conditions: RGB HDR input (RGBA1010102 / RGBA-F16), gain map at full resolution (scale 1).
+#include "encode_core.h"
+
+namespace uhdr {
+namespace {
+
+constexpr int kBlock = 256;
+
+struct FusedLds {
+  float srgb[kSrgbN];
+  float hdr[kInvOetfN];
+  double math[kMathTabDoubles];
+  UnormTables unorm;
+};
+
+__device__ __forceinline__ float clipf(float v, float hi) { return (v < 0.0f) ? 0.0f : ((v > hi) ? hi : v); }
+
+template <int HDRF, bool TWO_PASS>
+__global__ __launch_bounds__(kBlock) void encode_api0_fused_kernel(const FusedParams p, float* partials) {
+  __shared__ FusedLds L;
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t i = tid; i < kSrgbN; i += kBlock) L.srgb[i] = p.gen.srgb_lut[i];
+  if (p.tm.hdr_inv_lut)
+    for (uint32_t i = tid; i < (uint32_t)p.tm.hdr_inv_n; i += kBlock) L.hdr[i] = p.tm.hdr_inv_lut[i];
+  for (uint32_t i = tid; i < kMathTabDoubles; i += kBlock) L.math[i] = p.tm.math_tab[i];
+  fill_unorm_tables(L.unorm, tid, kBlock);
+  __syncthreads();
+
+  const uint32_t w = p.tm.hdr.w, h = p.tm.hdr.h;
+  const uint32_t tiles_x = (w + kBlock - 1) / kBlock, tiles = tiles_x * h;
+  const bool hdr_lut = p.tm.hdr_inv_lut != nullptr, hdr_lut_4096 = p.tm.hdr_inv_n == kInvOetfN;
+  float mn[3] = {127.0f, 127.0f, 127.0f}, mx[3] = {-128.0f, -128.0f, -128.0f};
+  for (uint32_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const uint32_t y = t / tiles_x, x = (t - y * tiles_x) * kBlock + tid;
+    if (x >= w) continue;
+    // ---- toneMap (jpegr.cpp:2147-2203) -------------------------------------------------------------------------
+    const Color3 g = fetch_pixel<HDRF>(p.tm.hdr, x, y, &L.unorm);
+    const Color3 l = linearise_hdr(g, L.hdr, hdr_lut, hdr_lut_4096);
+    const Color3 og = tone_curve(l, p.tm, L.math);
+    const uint32_t r8 = put8(og.r), g8 = put8(og.g), b8 = put8(og.b);  // putRgba8888Pixel
+    if (p.tm.sdr.p[0]) ((uint32_t*)p.tm.sdr.p[0])[x + (size_t)y * p.tm.sdr.stride[0]] = r8 | (g8 << 8) | (b8 << 16) | (255u << 24);
+    // ---- generateGainMap on the quantised SDR pixel (jpegr.cpp:753-818 / 866-931), scale 1 ---------------------------
+    const Color3 e = {L.unorm.u8[r8], L.unorm.u8[g8], L.unorm.u8[b8]};  // getRgba8888Pixel: byte / 255.0f
+    Color3 sl = {L.srgb[lut_index_f32<kSrgbN>(e.r)], L.srgb[lut_index_f32<kSrgbN>(e.g)], L.srgb[lut_index_f32<kSrgbN>(e.b)]};
+    if (p.gen.sdr_gamut_on) sl = mat3_apply(sl, p.gen.sdr_gamut);
+    sl.r = clip_neg(sl.r); sl.g = clip_neg(sl.g); sl.b = clip_neg(sl.b);
+    Color3 hl = l;  // the same inverse OETF (+ OOTF) the tone mapper just applied
+    if (p.gen.hdr_gamut_on) hl = mat3_apply(hl, p.gen.hdr_gamut);
+    hl.r = clip_neg(hl.r); hl.g = clip_neg(hl.g); hl.b = clip_neg(hl.b);
+    gain_of_pixel<TWO_PASS>(sl, hl, p.gen, L.math, x, y, mn, mx);
+    // ---- convert_raw_input_to_ycbcr(sdr, 4:4:4) (gainmapmath.cpp:1446-1472) ----------------------------------------------
+    const Color3 q = rgb_to_yuv(e, p.base_k);
+    ((uint8_t*)p.ycc.p[0])[(size_t)y * p.ycc.stride[0] + x] = (uint8_t)clipf(q.r * 255.0f + 0.5f, 255.0f);
+    ((uint8_t*)p.ycc.p[1])[(size_t)y * p.ycc.stride[1] + x] = (uint8_t)clipf(q.g * 255.0f + 0.5f + 128.0f, 255.0f);
+    ((uint8_t*)p.ycc.p[2])[(size_t)y * p.ycc.stride[2] + x] = (uint8_t)clipf(q.b * 255.0f + 0.5f + 128.0f, 255.0f);
+  }
+  if constexpr (TWO_PASS) reduce_block_minmax<kBlock>(mn, mx, partials);
+}
+
+}  // namespace
+
+int fused_grid(uint32_t tiles) {
+  static const int resident = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 1024;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    return cus * 5;  // 29 KB of LDS tables per workgroup
+  }();
+  uint32_t g = tiles < (uint32_t)resident ? tiles : (uint32_t)resident;
+  if (g > 2048) g = 2048;  // the host layer sizes the min/max partials buffer for 2048 workgroups
+  return (int)(g < 1 ? 1 : g);
+}
+
+// two_pass: p.gen.gain_log2 / p.gen.minmax set as for launch_generate_gainmap; returns the grid size
+// through *grid_out so that the caller can run the final min/max reduction (launch_reduce_minmax).
+hipError_t launch_encode_api0_fused(const FusedParams& p, bool two_pass, int* grid_out, hipStream_t s) {
+  const uint32_t tiles = ((p.tm.hdr.w + kBlock - 1) / kBlock) * p.tm.hdr.h;
+  const int grid = fused_grid(tiles);
+  if (grid_out) *grid_out = grid;
+  float* partials = two_pass ? p.gen.minmax + 6 : nullptr;
+  const bool f16 = p.tm.hdr.fmt == UHDR_IMG_FMT_64bppRGBAHalfFloat;
+  if (f16) {
+    if (two_pass) hipLaunchKernelGGL((encode_api0_fused_kernel<UHDR_IMG_FMT_64bppRGBAHalfFloat, true>), dim3(grid), dim3(kBlock), 0, s, p, partials);
+    else hipLaunchKernelGGL((encode_api0_fused_kernel<UHDR_IMG_FMT_64bppRGBAHalfFloat, false>), dim3(grid), dim3(kBlock), 0, s, p, partials);
+  } else {
+    if (two_pass) hipLaunchKernelGGL((encode_api0_fused_kernel<UHDR_IMG_FMT_32bppRGBA1010102, true>), dim3(grid), dim3(kBlock), 0, s, p, partials);
+    else hipLaunchKernelGGL((encode_api0_fused_kernel<UHDR_IMG_FMT_32bppRGBA1010102, false>), dim3(grid), dim3(kBlock), 0, s, p, partials);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace uhdr

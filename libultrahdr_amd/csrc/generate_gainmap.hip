@@ -14,9 +14,7 @@
 // same (jpegr.cpp:842-844) -- and reduces per-channel min/max with wavefront shuffles -> LDS ->
 // one partial per workgroup -> a single-workgroup final reduction (deterministic, no float
 // atomics).  Across GPUs the 6 floats are all-reduced by the host layer (RCCL MIN / MAX).
-#include "exact_math.h"
-#include "pixel_io.h"
-#include "uhdr_types.h"
+#include "encode_core.h"
 
 namespace uhdr {
 namespace {
@@ -29,29 +27,6 @@ struct GenLds {
   float hdr[kInvOetfN];
   double math[kMathTabDoubles];
   UnormTables unorm;  // x / 255.0f, x / 1023.0f
-};
-
-// encodeGain (gainmapmath.cpp:758-771): log2 is the DOUBLE libm one in the reference build, the
-// normalisation is double arithmetic narrowed to float, then powf, then truncation.
-__device__ __forceinline__ uint8_t encode_gain(float y_sdr, float y_hdr, const GenParams& p, const double* T) {
-  float gain = 1.0f;
-  if (y_sdr > 0.0f) gain = y_hdr / y_sdr;
-  if (gain < p.min_boost) gain = p.min_boost;
-  if (gain > p.max_boost) gain = p.max_boost;
-  const double lg = log2_table_f64(gain, T);
-  const float n = (float)div_by_const_f64(lg - (double)p.log2min, p.log2_range, p.log2_range_rcp);
-  const float ng = (p.gamma == 1.0f) ? n : powf(n, p.gamma);  // powf(x, 1) == x exactly
-  return (uint8_t)(ng * 255.0f);
-}
-// computeGain (gainmapmath.cpp:773-782)
-__device__ __forceinline__ float compute_gain(float sdr, float hdr, const double* T) {
-  float gain = (float)log2_table_f64((hdr + 1e-7f) / (sdr + 1e-7f), T);
-  if (sdr < 2.f / 255.0f) gain = fminf(gain, 2.3f);
-  return gain;
-}
-
-struct F3 {
-  float a, b, c;
 };
 
 template <int SDRF, int HDRF, bool TWO_PASS>
@@ -80,74 +55,13 @@ __global__ __launch_bounds__(kBlock) void generate_kernel(const GenParams p, flo
 
     Color3 h = sample_box<HDRF>(p.hdr, p.scale, x, y, &L.unorm);
     if (!p.hdr_is_rgb) h = yuv_to_rgb(h.r, h.g, h.b, p.hdr_yuv);
-    Color3 hl = h;  // linear input: identityConversion
-    if (hdr_lut) {
-      if (hdr_lut_4096) {  // HLG (+OOTF) / PQ tables: exact double-form index
-        hl.r = L.hdr[lut_index_f64<kInvOetfN>(h.r)];
-        hl.g = L.hdr[lut_index_f64<kInvOetfN>(h.g)];
-        hl.b = L.hdr[lut_index_f64<kInvOetfN>(h.b)];
-      } else {
-        hl.r = L.hdr[lut_index_f32<kSrgbN>(h.r)];
-        hl.g = L.hdr[lut_index_f32<kSrgbN>(h.g)];
-        hl.b = L.hdr[lut_index_f32<kSrgbN>(h.b)];
-      }
-    }
+    Color3 hl = linearise_hdr(h, L.hdr, hdr_lut, hdr_lut_4096);
     if (p.hdr_gamut_on) hl = mat3_apply(hl, p.hdr_gamut);
     hl.r = clip_neg(hl.r); hl.g = clip_neg(hl.g); hl.b = clip_neg(hl.b);
 
-    if (p.multichannel) {
-      const float sn[3] = {sl.r * 203.0f, sl.g * 203.0f, sl.b * 203.0f};
-      const float hn[3] = {hl.r * p.hdr_nits, hl.g * p.hdr_nits, hl.b * p.hdr_nits};
-      if constexpr (!TWO_PASS) {
-        uint8_t* o = p.out + (size_t)y * p.out_stride * 3 + x * 3;
-        o[0] = encode_gain(sn[0], hn[0], p, L.math);
-        o[1] = encode_gain(sn[1], hn[1], p, L.math);
-        o[2] = encode_gain(sn[2], hn[2], p, L.math);
-      } else {
-        float v[3];
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-          v[c] = compute_gain(sn[c], hn[c], L.math);
-          mn[c] = fminf(mn[c], v[c]);
-          mx[c] = fmaxf(mx[c], v[c]);
-        }
-        *(F3*)(p.gain_log2 + ((size_t)y * mw + x) * 3) = F3{v[0], v[1], v[2]};
-      }
-    } else {
-      float sy, hy;
-      if (p.use_luminance) {  // SDR-gamut luminance coefficients for BOTH images (jpegr.cpp:803-805)
-        sy = (p.lum[0] * sl.r + p.lum[1] * sl.g + p.lum[2] * sl.b) * 203.0f;
-        hy = (p.lum[0] * hl.r + p.lum[1] * hl.g + p.lum[2] * hl.b) * p.hdr_nits;
-      } else {
-        sy = fmaxf(sl.r, fmaxf(sl.g, sl.b)) * 203.0f;
-        hy = fmaxf(hl.r, fmaxf(hl.g, hl.b)) * p.hdr_nits;
-      }
-      if constexpr (!TWO_PASS) {
-        p.out[(size_t)y * p.out_stride + x] = encode_gain(sy, hy, p, L.math);
-      } else {
-        const float v = compute_gain(sy, hy, L.math);
-        p.gain_log2[(size_t)y * mw + x] = v;
-        mn[0] = fminf(mn[0], v);
-        mx[0] = fmaxf(mx[0], v);
-      }
-    }
+    gain_of_pixel<TWO_PASS>(sl, hl, p, L.math, x, y, mn, mx);
   }
-  if constexpr (TWO_PASS) {
-    __shared__ float s_red[kBlock / 64][6];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      const float a = wave_min(mn[c]), b = wave_max(mx[c]);
-      if (lane == 0) { s_red[wv][c] = a; s_red[wv][3 + c] = b; }
-    }
-    __syncthreads();
-    if (threadIdx.x < 6) {
-      float v = s_red[0][threadIdx.x];
-      for (int k = 1; k < kBlock / 64; k++)
-        v = threadIdx.x < 3 ? fminf(v, s_red[k][threadIdx.x]) : fmaxf(v, s_red[k][threadIdx.x]);
-      partials[(size_t)blockIdx.x * 6 + threadIdx.x] = v;
-    }
-  }
+  if constexpr (TWO_PASS) reduce_block_minmax<kBlock>(mn, mx, partials);
 }
 
 __global__ void reduce_minmax_kernel(const float* partials, int n, float* out6) {
@@ -244,6 +158,11 @@ hipError_t launch_generate_gainmap(const GenParams& p, bool two_pass, hipStream_
     default: launch_gen_h<-1>(p, two_pass, grid, partials, s); break;
   }
   if (two_pass) hipLaunchKernelGGL(reduce_minmax_kernel, dim3(1), dim3(256), 0, s, (const float*)partials, grid, p.minmax);
+  return hipGetLastError();
+}
+
+hipError_t launch_reduce_minmax(const float* partials, int n, float* out6, hipStream_t s) {
+  hipLaunchKernelGGL(reduce_minmax_kernel, dim3(1), dim3(256), 0, s, partials, n, out6);
   return hipGetLastError();
 }
 

@@ -9,9 +9,7 @@
 // HLG, hlgOotfApprox folded in by the host -- see generate_gainmap.hip) and the float64 tables
 // behind srgbOetf's pow (exact_math.h) are staged in LDS.  A workgroup walks tiles of 256
 // consecutive quads / pixels of one row.
-#include "exact_math.h"
-#include "pixel_io.h"
-#include "uhdr_types.h"
+#include "encode_core.h"
 
 namespace uhdr {
 namespace {
@@ -21,12 +19,6 @@ constexpr int kBlock = 256;
 __device__ __forceinline__ uint8_t scale_to_8bit(float v) {  // jpegr.cpp:1979-1983
   int i = (int)roundf(v * 255.0f);
   return (uint8_t)min(max(i, 0), 255);
-}
-__device__ __forceinline__ uint32_t put8(float v) {  // put*Pixel: *255, +0.5, clip, truncate
-  v *= 255.0f;
-  v += 0.5f;
-  v = (v < 0.0f) ? 0.0f : ((v > 255.0f) ? 255.0f : v);
-  return (uint32_t)v;
 }
 struct ToneLds {
   float hdr[kInvOetfN];
@@ -46,40 +38,8 @@ template <int HDRF>
 __device__ __forceinline__ Color3 tone_map_pixel(const ToneMapParams& p, const ToneLds& L, uint32_t x, uint32_t y) {
   Color3 g = fetch_pixel<HDRF>(p.hdr, x, y, &L.unorm);
   if (!p.hdr_is_rgb) g = yuv_to_rgb(g.r, g.g, g.b, p.hdr_yuv);
-  Color3 l = g;
-  if (p.hdr_inv_lut) {
-    if (p.hdr_inv_n == kInvOetfN) {
-      l.r = L.hdr[lut_index_f64<kInvOetfN>(g.r)];
-      l.g = L.hdr[lut_index_f64<kInvOetfN>(g.g)];
-      l.b = L.hdr[lut_index_f64<kInvOetfN>(g.b)];
-    } else {
-      l.r = L.hdr[lut_index_f32<kSrgbN>(g.r)];
-      l.g = L.hdr[lut_index_f32<kSrgbN>(g.g)];
-      l.b = L.hdr[lut_index_f32<kSrgbN>(g.b)];
-    }
-  }
-  // globalTonemap (jpegr.cpp:1951-1977)
-  float c0 = l.r, c1 = l.g, c2 = l.b;
-  const float hr = p.headroom;
-  if (p.is_normalized) { c0 *= hr; c1 *= hr; c2 *= hr; }
-  float mx = c0;
-  if (c1 > mx) mx = c1;
-  if (c2 > mx) mx = c2;
-  float ms = 1.0f + div_const(mx, p.headroom_sq, p.headroom_sq_rcp);  // ReinhardMap: mx / (hr * hr), divisor is a per-transfer constant
-  ms /= 1.0f + mx;
-  ms = ms * mx;
-  // c * max_sdr / max_hdr for the three channels (jpegr.cpp:1968-1972): one shared float64 reciprocal of
-  // max_hdr, each quotient exact (device_math.h: rcp64_of_f32, div_by_rcp64); mx == 0 implies c <= 0
-  const double rmx = rcp64_of_f32(mx, __builtin_amdgcn_rcpf(mx));
-  Color3 o;
-  o.r = c0 > 0.0f ? div_by_rcp64(c0 * ms, rmx) : 0.0f;
-  o.g = c1 > 0.0f ? div_by_rcp64(c1 * ms, rmx) : 0.0f;
-  o.b = c2 > 0.0f ? div_by_rcp64(c2 * ms, rmx) : 0.0f;
-  if (p.gamut_on) o = mat3_apply(o, p.gamut);
-  o.r = clamp01(o.r); o.g = clamp01(o.g); o.b = clamp01(o.b);
-  // srgbOetf (gainmapmath.cpp:139-148) with the table pow of exact_math.h
-  Color3 og = {srgb_oetf_table(o.r, L.math), srgb_oetf_table(o.g, L.math), srgb_oetf_table(o.b, L.math)};
-  return og;
+  const Color3 l = linearise_hdr(g, L.hdr, p.hdr_inv_lut != nullptr, p.hdr_inv_n == kInvOetfN);
+  return tone_curve(l, p, L.math);
 }
 
 __global__ __launch_bounds__(kBlock) void tonemap_p010_kernel(const ToneMapParams p) {

@@ -865,6 +865,27 @@ uhdr_error_info_t uhdr_hip_generate_gainmap(uhdr_hip_ctx_t* c, const uhdr_raw_im
 // -------------------------------------------------------------------------------------------------
 // toneMap
 // -------------------------------------------------------------------------------------------------
+// everything of ToneMapParams that depends on the HDR image only (the caller sets p->sdr)
+static uhdr_error_info_t fill_tone_map_params(uhdr_hip_ctx* c, const uhdr_raw_image_t* hdr, ToneMapParams* pp) {
+  ToneMapParams& p = *pp;
+  memset(&p, 0, sizeof p);
+  p.hdr = view_of(hdr);
+  UHDR_TRY(select_hdr_lut(c, hdr->ct, &p.hdr_inv_lut, &p.hdr_inv_n));
+  UHDR_TRY(upload_math(c));
+  p.math_tab = c->d_math;
+  p.hdr_is_rgb = is_rgb_fmt_host(hdr->fmt);
+  p.is_normalized = hdr->ct != UHDR_CT_LINEAR;
+  p.headroom = host::reference_peak_nits(hdr->ct) / 203.0f;
+  p.headroom_sq = p.headroom * p.headroom;
+  p.headroom_sq_rcp = 1.0f / p.headroom_sq;
+  bool identity;
+  host::gamut_matrix(UHDR_CG_DISPLAY_P3, hdr->cg, &p.gamut, &identity);
+  p.gamut_on = identity ? 0 : 1;
+  p.hdr_yuv = host::yuv2rgb_coeffs(hdr->cg);
+  p.p3 = host::rgb2yuv_coeffs(UHDR_CG_DISPLAY_P3);
+  return ok_status();
+}
+
 uhdr_error_info_t uhdr_hip_tone_map_dev(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* hdr, uhdr_raw_image_t* sdr) {
   if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
   if (!hdr || !sdr) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument");
@@ -896,22 +917,8 @@ uhdr_error_info_t uhdr_hip_tone_map_dev(uhdr_hip_ctx_t* c, const uhdr_raw_image_
   sdr->ct = UHDR_CT_SRGB;
   sdr->range = UHDR_CR_FULL_RANGE;
   ToneMapParams p;
-  memset(&p, 0, sizeof p);
-  p.hdr = view_of(hdr);
+  UHDR_TRY(fill_tone_map_params(c, hdr, &p));
   p.sdr = view_mut_of(sdr);
-  UHDR_TRY(select_hdr_lut(c, hdr->ct, &p.hdr_inv_lut, &p.hdr_inv_n));
-  UHDR_TRY(upload_math(c));
-  p.math_tab = c->d_math;
-  p.hdr_is_rgb = is_rgb_fmt_host(hdr->fmt);
-  p.is_normalized = hdr->ct != UHDR_CT_LINEAR;
-  p.headroom = host::reference_peak_nits(hdr->ct) / 203.0f;
-  p.headroom_sq = p.headroom * p.headroom;
-  p.headroom_sq_rcp = 1.0f / p.headroom_sq;
-  bool identity;
-  host::gamut_matrix(UHDR_CG_DISPLAY_P3, hdr->cg, &p.gamut, &identity);
-  p.gamut_on = identity ? 0 : 1;
-  p.hdr_yuv = host::yuv2rgb_coeffs(hdr->cg);
-  p.p3 = host::rgb2yuv_coeffs(UHDR_CG_DISPLAY_P3);
   ProfScope ps(c, "tone_map");
   HIP_TRY(launch_tone_map(p, c->stream));
   return ok_status();
@@ -1070,6 +1077,92 @@ uhdr_error_info_t uhdr_hip_fdct_quant(uhdr_hip_ctx_t* c, const uint8_t* plane, s
   HIP_TRY(hipMemcpyAsync(coef, c->scratch[1].p, out_bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return ok_status();
+}
+
+// -------------------------------------------------------------------------------------------------
+// API-0 front end fused: toneMap + generateGainMap + convert_raw_input_to_ycbcr(4:4:4) in one pass
+// -------------------------------------------------------------------------------------------------
+uhdr_error_info_t uhdr_hip_encode_api0_fused_dev(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* hdr, const uhdr_hip_encode_cfg_t* cfg,
+                                                 uhdr_raw_image_t* sdr_rgba, uhdr_raw_image_t* base_ycc, uhdr_gainmap_metadata_t* md,
+                                                 uhdr_raw_image_t* gm) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  if (!hdr || !cfg || !base_ycc || !md || !gm || !gm->planes[0]) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument");
+  if (hdr->fmt != UHDR_IMG_FMT_32bppRGBA1010102 && hdr->fmt != UHDR_IMG_FMT_64bppRGBAHalfFloat)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "the fused API-0 front end takes UHDR_IMG_FMT_32bppRGBA1010102 or UHDR_IMG_FMT_64bppRGBAHalfFloat "
+                      "(the inputs toneMap renders to RGBA8888). Received %d", hdr->fmt);
+  if (cfg->map_dimension_scale_factor != 1)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "the fused API-0 front end needs a full-resolution gain map (scale factor 1), received %d; "
+                      "use tone_map + generate_gainmap + convert_raw_input_to_ycbcr", cfg->map_dimension_scale_factor);
+  if (hdr->cg < UHDR_CG_BT_709 || hdr->cg > UHDR_CG_BT_2100)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "No implementation available for color gamut %d", hdr->cg);
+  if (hdr->ct < UHDR_CT_LINEAR || hdr->ct > UHDR_CT_SRGB)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "No implementation available for color transfer %d", hdr->ct);
+  for (int i = 0; i < 3; i++) {
+    if (!base_ycc->planes[i]) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for base image plane %d", i);
+    if (base_ycc->stride[i] < hdr->w) return err_status(UHDR_CODEC_INVALID_PARAM, "base image stride (%u) cannot be less than width (%u)", base_ycc->stride[i], hdr->w);
+  }
+  if (sdr_rgba && sdr_rgba->planes[0] && sdr_rgba->stride[0] < hdr->w)
+    return err_status(UHDR_CODEC_INVALID_PARAM, "sdr stride (%u) cannot be less than width (%u)", sdr_rgba->stride[0], hdr->w);
+  HIP_TRY(hipSetDevice(c->device));
+  // the SDR rendition toneMap would hand to generateGainMap: RGBA8888, Display-P3, sRGB, full range
+  uhdr_raw_image_t sdr_desc;
+  memset(&sdr_desc, 0, sizeof sdr_desc);
+  if (sdr_rgba) sdr_desc = *sdr_rgba;
+  sdr_desc.fmt = UHDR_IMG_FMT_32bppRGBA8888; sdr_desc.cg = UHDR_CG_DISPLAY_P3; sdr_desc.ct = UHDR_CT_SRGB; sdr_desc.range = UHDR_CR_FULL_RANGE;
+  sdr_desc.w = hdr->w; sdr_desc.h = hdr->h;
+  if (!sdr_desc.planes[0]) sdr_desc.stride[0] = hdr->w;
+  if (sdr_rgba) { sdr_rgba->fmt = sdr_desc.fmt; sdr_rgba->cg = sdr_desc.cg; sdr_rgba->ct = sdr_desc.ct; sdr_rgba->range = sdr_desc.range; sdr_rgba->w = hdr->w; sdr_rgba->h = hdr->h; }
+  FusedParams p;
+  UHDR_TRY(fill_tone_map_params(c, hdr, &p.tm));
+  p.tm.sdr = view_mut_of(&sdr_desc);
+  int use_base_cg = 1;
+  float hdr_white_nits;
+  UHDR_TRY(fill_gen_params(c, &sdr_desc, hdr, cfg, &p.gen, &use_base_cg, &hdr_white_nits));
+  fill_gainmap_desc(hdr, p.gen, gm);
+  if (gm->stride[0] < gm->w) return err_status(UHDR_CODEC_INVALID_PARAM, "gainmap stride (%u) cannot be less than its width (%u)", gm->stride[0], gm->w);
+  base_ycc->fmt = UHDR_IMG_FMT_24bppYCbCr444; base_ycc->cg = UHDR_CG_DISPLAY_P3; base_ycc->ct = UHDR_CT_SRGB; base_ycc->range = UHDR_CR_FULL_RANGE;
+  base_ycc->w = hdr->w; base_ycc->h = hdr->h;
+  p.ycc = view_mut_of(base_ycc);
+  p.base_k = host::rgb2yuv_coeffs(UHDR_CG_DISPLAY_P3);
+  if (cfg->preset == UHDR_USAGE_REALTIME) {  // one pass: jpegr.cpp:724-737
+    for (int i = 0; i < 3; i++) {
+      md->max_content_boost[i] = hdr_white_nits / 203.0f;
+      md->min_content_boost[i] = 1.0f;
+      md->gamma[i] = cfg->gamma;
+      md->offset_sdr[i] = 0.0f;
+      md->offset_hdr[i] = 0.0f;
+    }
+    md->hdr_capacity_min = 1.0f;
+    md->hdr_capacity_max = cfg->target_disp_peak_nits != -1.0f ? cfg->target_disp_peak_nits / 203.0f : md->max_content_boost[0];
+    md->use_base_cg = use_base_cg;
+    p.gen.min_boost = md->min_content_boost[0];
+    p.gen.max_boost = md->max_content_boost[0];
+    p.gen.log2min = log2f(md->min_content_boost[0]);
+    p.gen.log2max = log2f(md->max_content_boost[0]);
+    p.gen.log2_range = (double)(p.gen.log2max - p.gen.log2min);
+    p.gen.log2_range_rcp = 1.0 / p.gen.log2_range;
+    p.gen.out = (uint8_t*)gm->planes[0];
+    p.gen.out_stride = gm->stride[0];
+    ProfScope ps(c, "encode_api0_fused");
+    HIP_TRY(launch_encode_api0_fused(p, false, nullptr, c->stream));
+    return ok_status();
+  }
+  const size_t nfl = (size_t)p.gen.map_w * p.gen.map_h * (p.gen.multichannel ? 3 : 1);
+  UHDR_TRY(ensure(c->scratch[7], nfl * sizeof(float)));
+  UHDR_TRY(ensure(c->minmax, (6 + 2048 * 6) * sizeof(float)));
+  p.gen.gain_log2 = (float*)c->scratch[7].p;
+  p.gen.minmax = (float*)c->minmax.p;
+  {
+    ProfScope ps(c, "encode_api0_fused");
+    int grid = 0;
+    HIP_TRY(launch_encode_api0_fused(p, true, &grid, c->stream));
+    HIP_TRY(launch_reduce_minmax(p.gen.minmax + 6, grid, p.gen.minmax, c->stream));
+  }
+  float mm[6];
+  HIP_TRY(hipMemcpyAsync(mm, c->minmax.p, sizeof mm, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  UHDR_TRY(uhdr_hip_generate_gainmap_finalize(cfg, hdr->ct, use_base_cg, mm, md));
+  return uhdr_hip_generate_gainmap_pass2_dev(c, p.gen.gain_log2, mm, cfg, gm);
 }
 
 // -------------------------------------------------------------------------------------------------

@@ -133,6 +133,14 @@ struct ToneMapParams {
   Rgb2Yuv p3;
 };
 
+// ---- fused API-0 front end (encode_fused.hip) --------------------------------------------------------
+struct FusedParams {
+  ToneMapParams tm;  // tm.hdr = input; tm.sdr.p[0] = optional RGBA8888 output (null: not stored)
+  GenParams gen;     // gain-map side; gen.sdr / gen.hdr views are unused (the pixels arrive in registers)
+  Rgb2Yuv base_k;    // Display-P3 (BT.601) coefficients of the base image conversion
+  ImageViewMut ycc;  // base image, YCbCr 4:4:4 planes
+};
+
 // ---- convertYuv / convert_raw_input_to_ycbcr --------------------------------------------------------
 struct YuvXformParams {
   ImageViewMut img;
@@ -149,6 +157,8 @@ hipError_t launch_apply_gainmap(const ApplyParams& p, hipStream_t s);
 int apply_quad_mode(const ApplyParams& p);  // >= 0: the quad kernel (and batch mode) applies
 hipError_t launch_generate_gainmap(const GenParams& p, bool two_pass, hipStream_t s);
 hipError_t launch_affine_map(const AffineParams& p, hipStream_t s);
+hipError_t launch_reduce_minmax(const float* partials, int n, float* out6, hipStream_t s);
+hipError_t launch_encode_api0_fused(const FusedParams& p, bool two_pass, int* grid_out, hipStream_t s);
 hipError_t launch_tone_map(const ToneMapParams& p, hipStream_t s);
 hipError_t launch_transform_yuv(const YuvXformParams& p, hipStream_t s);
 hipError_t launch_rgb_to_ycbcr(const RgbToYcbcrParams& p, hipStream_t s);

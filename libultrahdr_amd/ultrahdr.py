@@ -118,6 +118,24 @@ class UltraHdr:
         gm.sync_meta_from_raw()
         return md, gm
 
+    def encodeApi0Fused(self, hdr_intent: Image, want_sdr_rgba=True, use_luminance=False):
+        """MI355X extension: toneMap + generateGainMap + convert_raw_input_to_ycbcr(4:4:4) of an API-0 encode
+        (jpegr.cpp:202-251) in one pass over a device-resident RGBA1010102 / RGBA-F16 image (scale factor 1).
+        Returns (sdr_rgba or None, base_ycc444, metadata, gainmap), bit-identical to the three separate calls."""
+        assert _is_dev(hdr_intent)
+        w, h, dev = hdr_intent.w, hdr_intent.h, hdr_intent.device
+        sdr = Image(A.UHDR_IMG_FMT_32bppRGBA8888, w, h, align=64, device=dev) if want_sdr_rgba else None
+        ycc = Image(A.UHDR_IMG_FMT_24bppYCbCr444, w, h, align=64, device=dev)
+        fmt = A.UHDR_IMG_FMT_24bppRGB888 if self.mUseMultiChannelGainMap else A.UHDR_IMG_FMT_8bppYCbCr400
+        gm = Image(fmt, w, h, align=64, device=dev)
+        md = A.GainmapMetadata()
+        cfg = self.encode_cfg(False, use_luminance)
+        A.check(self.lib.uhdr_hip_encode_api0_fused_dev(self.ctx.handle, C.byref(hdr_intent.raw), C.byref(cfg),
+                                                        C.byref(sdr.raw) if sdr is not None else None, C.byref(ycc.raw),
+                                                        C.byref(md), C.byref(gm.raw)))
+        gm.sync_meta_from_raw()
+        return sdr, ycc, md, gm
+
     # ---- applyGainMap (ultrahdrcommon.h:531-534) -----------------------------------------------
     def applyGainMap(self, sdr_intent: Image, gainmap_img: Image, gainmap_metadata: A.GainmapMetadata,
                      output_ct: int, output_format: int, max_display_boost: float, dest: Image,

@@ -554,3 +554,51 @@ def test_apply_gainmap_quad_path_444_and_rgba_bases(uhdr, base_fmt, ch, alpha, s
         md = synth.default_metadata(use_base_cg=use_base_cg, per_channel=(ch == 3))
         check_apply(uhdr, sdr, gm, md, out_ct, what=f"host ubc={use_base_cg}")
     check_apply(uhdr, sdr, gm, synth.default_metadata(), out_ct, device=True, what="device")
+
+
+@pytest.mark.parametrize("ct,cg", [(A.UHDR_CT_PQ, A.UHDR_CG_BT_2100), (A.UHDR_CT_HLG, A.UHDR_CG_DISPLAY_P3), (A.UHDR_CT_LINEAR, A.UHDR_CG_BT_709)])
+@pytest.mark.parametrize("cfg_kw", [dict(preset=A.UHDR_USAGE_REALTIME), dict(preset=A.UHDR_USAGE_BEST_QUALITY),
+                                    dict(preset=A.UHDR_USAGE_REALTIME, use_multi_channel_gainmap=0),
+                                    dict(preset=A.UHDR_USAGE_BEST_QUALITY, use_multi_channel_gainmap=0, gamma=1.3)])
+def test_fused_api0_front_end_equals_the_three_operators(hip_ctx, ct, cg, cfg_kw):
+    """uhdr_hip_encode_api0_fused_dev == toneMap -> generateGainMap -> convert_raw_input_to_ycbcr(4:4:4), bit for bit
+    (same arithmetic, the 8-bit quantisation between the stages is kept), and within the tone-map tolerance of the
+    oracle chain."""
+    w, h = 200, 72  # not a multiple of the 256-pixel tile
+    hdr = synth.make_hdr_rgba1010102(w, h, ct=ct, cg=cg, noise=0.05)
+    cfg = A.default_encode_cfg(use_luminance=0, **cfg_kw)
+    u = _uhdr_for(hip_ctx, cfg)
+    dh = hdr.to("cuda:0")
+    sdr_f, ycc_f, md_f, gm_f = u.encodeApi0Fused(dh, want_sdr_rgba=True, use_luminance=False)
+    hip_ctx.synchronize()
+    # the three operators on the device
+    sdr_s = Image(A.UHDR_IMG_FMT_32bppRGBA8888, w, h, align=64, device="cuda:0")
+    u.toneMap(dh, sdr_s)
+    md_s, gm_s = u.generateGainMap(sdr_s, dh, False, False)
+    ycc_s = u.convert_raw_input_to_ycbcr(sdr_s, False)
+    hip_ctx.synchronize()
+    assert planes_equal(sdr_f, sdr_s) and planes_equal(ycc_f, ycc_s) and planes_equal(gm_f, gm_s)
+    assert md_f.as_dict() == md_s.as_dict()
+    assert (ycc_f.raw.fmt, ycc_f.raw.cg, ycc_f.raw.range) == (ycc_s.raw.fmt, ycc_s.raw.cg, ycc_s.raw.range)
+    # without the optional RGBA8888 output
+    _, ycc_n, md_n, gm_n = u.encodeApi0Fused(dh, want_sdr_rgba=False, use_luminance=False)
+    hip_ctx.synchronize()
+    assert planes_equal(ycc_n, ycc_s) and planes_equal(gm_n, gm_s) and md_n.as_dict() == md_s.as_dict()
+    # oracle chain
+    sdr_o = L.tone_map(oracle_kind(), hdr)
+    md_o, gm_o = L.generate_gainmap(oracle_kind(), sdr_o, hdr, cfg)
+    tol = 1e-4 if cfg.gamma == 1.0 else 5e-3
+    assert_close_codes(sdr_f.to_host().valid(0).view(np.uint8), sdr_o.valid(0).view(np.uint8), 1, 1e-4, "fused sdr")
+    if np.array_equal(sdr_f.to_host().valid(0), sdr_o.valid(0)):  # same SDR bytes -> the map must agree like generate does
+        assert_close_codes(gm_f.to_host().valid(0), gm_o.valid(0), 1, tol, "fused gain map")
+
+
+def test_fused_api0_front_end_rejects_what_it_cannot_fuse(hip_ctx):
+    u = _uhdr_for(hip_ctx, A.default_encode_cfg(map_dimension_scale_factor=2))
+    with pytest.raises(A.UhdrError) as e:
+        u.encodeApi0Fused(synth.make_hdr_rgba1010102(64, 32).to("cuda:0"))
+    assert e.value.code == A.UHDR_CODEC_UNSUPPORTED_FEATURE
+    u = _uhdr_for(hip_ctx, A.default_encode_cfg())
+    with pytest.raises(A.UhdrError) as e:
+        u.encodeApi0Fused(synth.make_hdr_p010(64, 32).to("cuda:0"))
+    assert e.value.code == A.UHDR_CODEC_UNSUPPORTED_FEATURE
