@@ -602,3 +602,24 @@ def test_fused_api0_front_end_rejects_what_it_cannot_fuse(hip_ctx):
     with pytest.raises(A.UhdrError) as e:
         u.encodeApi0Fused(synth.make_hdr_p010(64, 32).to("cuda:0"))
     assert e.value.code == A.UHDR_CODEC_UNSUPPORTED_FEATURE
+
+
+@pytest.mark.parametrize("base_fmt", [A.UHDR_IMG_FMT_24bppYCbCr444, A.UHDR_IMG_FMT_32bppRGBA8888])
+def test_apply_gainmap_batch_444_and_rgba_bases(uhdr, base_fmt):
+    """Batch launch with the quad kernel's BASE 1 / BASE 2 variants == per-frame oracle results."""
+    w, h, n = 320, 96, 3
+    f16 = A.UHDR_IMG_FMT_64bppRGBAHalfFloat
+    md = synth.default_metadata(use_base_cg=0, per_channel=True)
+    rng = np.random.default_rng(41)
+    sdrs = []
+    for _ in range(n):
+        s = Image(base_fmt, w, h, A.UHDR_CG_BT_709, A.UHDR_CT_SRGB, A.UHDR_CR_FULL_RANGE)
+        s.buf[:] = rng.integers(0, 256, s.buf.size, dtype=np.uint8)
+        sdrs.append(s)
+    gms = [synth.make_gainmap(w, h, 3, True, seed=300 + i, cg=A.UHDR_CG_BT_2100) for i in range(n)]
+    dests = [Image(f16, w, h, align=2, device="cuda:0") for _ in range(n)]
+    uhdr.applyGainMapBatch([s.to("cuda:0") for s in sdrs], [g.to("cuda:0") for g in gms], md, A.UHDR_CT_LINEAR, f16, A.FLT_MAX, dests)
+    uhdr.ctx.synchronize()
+    for i in range(n):
+        want = L.apply_gainmap(oracle_kind(), sdrs[i], gms[i], md, A.UHDR_CT_LINEAR)
+        assert np.array_equal(dests[i].to_host().valid(0), want.valid(0)), i
