@@ -18,7 +18,7 @@
 namespace uhdr {
 namespace {
 
-constexpr int kBlock = 256;
+constexpr int kBlock = 512;  // 8 waves share one table set in LDS -> 3 workgroups = 24 waves per CU
 
 struct FusedLds {
   float srgb[kSrgbN];
@@ -78,7 +78,7 @@ int fused_grid(uint32_t tiles) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 1024;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    return cus * 5;  // 29 KB of LDS tables per workgroup
+    return cus * 3;  // 512-thread workgroups with 29 KB of LDS tables: three resident per CU
   }();
   uint32_t g = tiles < (uint32_t)resident ? tiles : (uint32_t)resident;
   if (g > 2048) g = 2048;  // the host layer sizes the min/max partials buffer for 2048 workgroups

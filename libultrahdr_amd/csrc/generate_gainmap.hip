@@ -20,6 +20,7 @@ namespace uhdr {
 namespace {
 
 constexpr int kBlock = 256;
+constexpr int kGenBlock = 512;  // generate_kernel: 8 waves share one 29 KB table set -> 3 workgroups = 24 waves per CU (VGPR limit)
 constexpr int kMaxGrid = 2048;  // the host layer sizes the partials buffer for this many workgroups
 
 struct GenLds {
@@ -30,22 +31,22 @@ struct GenLds {
 };
 
 template <int SDRF, int HDRF, bool TWO_PASS>
-__global__ __launch_bounds__(kBlock) void generate_kernel(const GenParams p, float* partials) {
+__global__ __launch_bounds__(kGenBlock) void generate_kernel(const GenParams p, float* partials) {
   __shared__ GenLds L;
   const uint32_t tid = threadIdx.x;
-  for (uint32_t i = tid; i < kSrgbN; i += kBlock) L.srgb[i] = p.srgb_lut[i];
+  for (uint32_t i = tid; i < kSrgbN; i += kGenBlock) L.srgb[i] = p.srgb_lut[i];
   if (p.hdr_inv_lut)
-    for (uint32_t i = tid; i < (uint32_t)p.hdr_inv_n; i += kBlock) L.hdr[i] = p.hdr_inv_lut[i];
-  for (uint32_t i = tid; i < kMathTabDoubles; i += kBlock) L.math[i] = p.math_tab[i];
-  fill_unorm_tables(L.unorm, tid, kBlock);
+    for (uint32_t i = tid; i < (uint32_t)p.hdr_inv_n; i += kGenBlock) L.hdr[i] = p.hdr_inv_lut[i];
+  for (uint32_t i = tid; i < kMathTabDoubles; i += kGenBlock) L.math[i] = p.math_tab[i];
+  fill_unorm_tables(L.unorm, tid, kGenBlock);
   __syncthreads();
 
   const uint32_t mw = p.map_w, mh = p.map_h;
-  const uint32_t tiles_x = (mw + kBlock - 1) / kBlock, tiles = tiles_x * mh;
+  const uint32_t tiles_x = (mw + kGenBlock - 1) / kGenBlock, tiles = tiles_x * mh;
   const bool hdr_lut = p.hdr_inv_lut != nullptr, hdr_lut_4096 = p.hdr_inv_n == kInvOetfN;
   float mn[3] = {127.0f, 127.0f, 127.0f}, mx[3] = {-128.0f, -128.0f, -128.0f};
   for (uint32_t t = blockIdx.x; t < tiles; t += gridDim.x) {
-    const uint32_t y = t / tiles_x, x = (t - y * tiles_x) * kBlock + tid;
+    const uint32_t y = t / tiles_x, x = (t - y * tiles_x) * kGenBlock + tid;
     if (x >= mw) continue;
     Color3 s = sample_box<SDRF>(p.sdr, p.scale, x, y, &L.unorm);
     if (!p.sdr_is_rgb) s = yuv_to_rgb(s.r, s.g, s.b, p.sdr_yuv);
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(kBlock) void generate_kernel(const GenParams p, flo
 
     gain_of_pixel<TWO_PASS>(sl, hl, p, L.math, x, y, mn, mx);
   }
-  if constexpr (TWO_PASS) reduce_block_minmax<kBlock>(mn, mx, partials);
+  if constexpr (TWO_PASS) reduce_block_minmax<kGenBlock>(mn, mx, partials);
 }
 
 __global__ void reduce_minmax_kernel(const float* partials, int n, float* out6) {
@@ -122,7 +123,7 @@ int gen_grid(uint32_t tiles) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 1024;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    return cus * 5;  // 29 KB of LDS tables per workgroup: five fit in a CU's 160 KB
+    return cus * 3;  // 512-thread workgroups, 29 KB of LDS tables each: three are resident per CU (24 waves, the VGPR limit)
   }();
   uint32_t g = tiles < (uint32_t)resident ? tiles : (uint32_t)resident;
   if (g > kMaxGrid) g = kMaxGrid;
@@ -132,8 +133,8 @@ int gen_grid(uint32_t tiles) {
 
 template <int SDRF, int HDRF>
 void launch_gen(const GenParams& p, bool two_pass, int grid, float* partials, hipStream_t s) {
-  if (two_pass) hipLaunchKernelGGL((generate_kernel<SDRF, HDRF, true>), dim3(grid), dim3(kBlock), 0, s, p, partials);
-  else hipLaunchKernelGGL((generate_kernel<SDRF, HDRF, false>), dim3(grid), dim3(kBlock), 0, s, p, partials);
+  if (two_pass) hipLaunchKernelGGL((generate_kernel<SDRF, HDRF, true>), dim3(grid), dim3(kGenBlock), 0, s, p, partials);
+  else hipLaunchKernelGGL((generate_kernel<SDRF, HDRF, false>), dim3(grid), dim3(kGenBlock), 0, s, p, partials);
 }
 template <int SDRF>
 void launch_gen_h(const GenParams& p, bool two_pass, int grid, float* partials, hipStream_t s) {
@@ -149,7 +150,7 @@ void launch_gen_h(const GenParams& p, bool two_pass, int grid, float* partials, 
 // Two-pass: p.minmax must have room for 6 floats followed by kMaxGrid*6 floats of partials
 // (the host layer allocates 6 + 2048*6).
 hipError_t launch_generate_gainmap(const GenParams& p, bool two_pass, hipStream_t s) {
-  const uint32_t tiles = ((p.map_w + kBlock - 1) / kBlock) * p.map_h;
+  const uint32_t tiles = ((p.map_w + kGenBlock - 1) / kGenBlock) * p.map_h;
   const int grid = gen_grid(tiles);
   float* partials = two_pass ? p.minmax + 6 : nullptr;
   switch (p.sdr.fmt) {
