@@ -14,7 +14,7 @@
 namespace uhdr {
 namespace {
 
-constexpr int kBlock = 512;  // 8 waves share one table set in LDS -> 3 workgroups = 24 waves per CU
+constexpr int kBlock = 256;
 
 __device__ __forceinline__ uint8_t scale_to_8bit(float v) {  // jpegr.cpp:1979-1983
   int i = (int)roundf(v * 255.0f);
@@ -112,7 +112,7 @@ int tone_grid(uint32_t tiles) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 1024;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    return cus * 3;  // 512-thread workgroups: three resident per CU (24 waves)
+    return cus * 6;  // 24 KB of LDS tables per workgroup: six fit in a CU's 160 KB
   }();
   const uint32_t g = tiles < (uint32_t)resident ? tiles : (uint32_t)resident;
   return (int)(g < 1 ? 1 : g);
