@@ -30,7 +30,9 @@ struct GenLds {
   UnormTables unorm;  // x / 255.0f, x / 1023.0f
 };
 
-template <int SDRF, int HDRF, bool TWO_PASS>
+// QUAD: 4:2:0 SDR + P010 HDR at scale 1 with even geometry -- one thread per 2x2 quad, both images read
+// with the coalesced quad fetches of pixel_io.h (luma as one vector load per row, chroma once per quad)
+template <int SDRF, int HDRF, bool TWO_PASS, bool QUAD>
 __global__ __launch_bounds__(kGenBlock) void generate_kernel(const GenParams p, float* partials) {
   __shared__ GenLds L;
   const uint32_t tid = threadIdx.x;
@@ -41,26 +43,39 @@ __global__ __launch_bounds__(kGenBlock) void generate_kernel(const GenParams p, 
   fill_unorm_tables(L.unorm, tid, kGenBlock);
   __syncthreads();
 
-  const uint32_t mw = p.map_w, mh = p.map_h;
-  const uint32_t tiles_x = (mw + kGenBlock - 1) / kGenBlock, tiles = tiles_x * mh;
   const bool hdr_lut = p.hdr_inv_lut != nullptr, hdr_lut_4096 = p.hdr_inv_n == kInvOetfN;
   float mn[3] = {127.0f, 127.0f, 127.0f}, mx[3] = {-128.0f, -128.0f, -128.0f};
-  for (uint32_t t = blockIdx.x; t < tiles; t += gridDim.x) {
-    const uint32_t y = t / tiles_x, x = (t - y * tiles_x) * kGenBlock + tid;
-    if (x >= mw) continue;
-    Color3 s = sample_box<SDRF>(p.sdr, p.scale, x, y, &L.unorm);
+  // one map pixel from the two samples as fetch_pixel / sample_box deliver them
+  auto do_pixel = [&](Color3 s, Color3 h, uint32_t x, uint32_t y) {
     if (!p.sdr_is_rgb) s = yuv_to_rgb(s.r, s.g, s.b, p.sdr_yuv);
     Color3 sl = {L.srgb[lut_index_f32<kSrgbN>(s.r)], L.srgb[lut_index_f32<kSrgbN>(s.g)], L.srgb[lut_index_f32<kSrgbN>(s.b)]};
     if (p.sdr_gamut_on) sl = mat3_apply(sl, p.sdr_gamut);
     sl.r = clip_neg(sl.r); sl.g = clip_neg(sl.g); sl.b = clip_neg(sl.b);
-
-    Color3 h = sample_box<HDRF>(p.hdr, p.scale, x, y, &L.unorm);
     if (!p.hdr_is_rgb) h = yuv_to_rgb(h.r, h.g, h.b, p.hdr_yuv);
     Color3 hl = linearise_hdr(h, L.hdr, hdr_lut, hdr_lut_4096);
     if (p.hdr_gamut_on) hl = mat3_apply(hl, p.hdr_gamut);
     hl.r = clip_neg(hl.r); hl.g = clip_neg(hl.g); hl.b = clip_neg(hl.b);
-
     gain_of_pixel<TWO_PASS>(sl, hl, p, L.math, x, y, mn, mx);
+  };
+  if constexpr (QUAD) {
+    const uint32_t qw = p.map_w / 2, qh = p.map_h / 2;
+    const uint32_t tiles_x = (qw + kGenBlock - 1) / kGenBlock, tiles = tiles_x * qh;
+    for (uint32_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+      const uint32_t qy = t / tiles_x, qx = (t - qy * tiles_x) * kGenBlock + tid;
+      if (qx >= qw) continue;
+      const QuadYuv sq = fetch_quad_420(p.sdr, qx, qy);
+      const QuadYuv hq = fetch_quad_p010(p.hdr, qx, qy, &L.unorm);
+#pragma unroll
+      for (int k = 0; k < 4; k++) do_pixel(sq.px[k], hq.px[k], 2 * qx + (k & 1), 2 * qy + (k >> 1));
+    }
+  } else {
+    const uint32_t mw = p.map_w, mh = p.map_h;
+    const uint32_t tiles_x = (mw + kGenBlock - 1) / kGenBlock, tiles = tiles_x * mh;
+    for (uint32_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+      const uint32_t y = t / tiles_x, x = (t - y * tiles_x) * kGenBlock + tid;
+      if (x >= mw) continue;
+      do_pixel(sample_box<SDRF>(p.sdr, p.scale, x, y, &L.unorm), sample_box<HDRF>(p.hdr, p.scale, x, y, &L.unorm), x, y);
+    }
   }
   if constexpr (TWO_PASS) reduce_block_minmax<kGenBlock>(mn, mx, partials);
 }
@@ -133,8 +148,8 @@ int gen_grid(uint32_t tiles) {
 
 template <int SDRF, int HDRF>
 void launch_gen(const GenParams& p, bool two_pass, int grid, float* partials, hipStream_t s) {
-  if (two_pass) hipLaunchKernelGGL((generate_kernel<SDRF, HDRF, true>), dim3(grid), dim3(kGenBlock), 0, s, p, partials);
-  else hipLaunchKernelGGL((generate_kernel<SDRF, HDRF, false>), dim3(grid), dim3(kGenBlock), 0, s, p, partials);
+  if (two_pass) hipLaunchKernelGGL((generate_kernel<SDRF, HDRF, true, false>), dim3(grid), dim3(kGenBlock), 0, s, p, partials);
+  else hipLaunchKernelGGL((generate_kernel<SDRF, HDRF, false, false>), dim3(grid), dim3(kGenBlock), 0, s, p, partials);
 }
 template <int SDRF>
 void launch_gen_h(const GenParams& p, bool two_pass, int grid, float* partials, hipStream_t s) {
@@ -150,9 +165,22 @@ void launch_gen_h(const GenParams& p, bool two_pass, int grid, float* partials, 
 // Two-pass: p.minmax must have room for 6 floats followed by kMaxGrid*6 floats of partials
 // (the host layer allocates 6 + 2048*6).
 hipError_t launch_generate_gainmap(const GenParams& p, bool two_pass, hipStream_t s) {
+  float* partials = two_pass ? p.minmax + 6 : nullptr;
+  if (p.scale == 1 && p.sdr.fmt == UHDR_IMG_FMT_12bppYCbCr420 && p.hdr.fmt == UHDR_IMG_FMT_24bppYCbCrP010 &&
+      quad_layout_ok(p.sdr) && quad_layout_ok(p.hdr)) {  // the API-1 default: quad lanes, coalesced plane loads
+    const uint32_t qtiles = ((p.map_w / 2 + kGenBlock - 1) / kGenBlock) * (p.map_h / 2);
+    const int qgrid = gen_grid(qtiles);
+    constexpr int S = UHDR_IMG_FMT_12bppYCbCr420, H = UHDR_IMG_FMT_24bppYCbCrP010;
+    if (two_pass) {
+      hipLaunchKernelGGL((generate_kernel<S, H, true, true>), dim3(qgrid), dim3(kGenBlock), 0, s, p, partials);
+      hipLaunchKernelGGL(reduce_minmax_kernel, dim3(1), dim3(256), 0, s, (const float*)partials, qgrid, p.minmax);
+    } else {
+      hipLaunchKernelGGL((generate_kernel<S, H, false, true>), dim3(qgrid), dim3(kGenBlock), 0, s, p, partials);
+    }
+    return hipGetLastError();
+  }
   const uint32_t tiles = ((p.map_w + kGenBlock - 1) / kGenBlock) * p.map_h;
   const int grid = gen_grid(tiles);
-  float* partials = two_pass ? p.minmax + 6 : nullptr;
   switch (p.sdr.fmt) {
     case UHDR_IMG_FMT_12bppYCbCr420: launch_gen_h<UHDR_IMG_FMT_12bppYCbCr420>(p, two_pass, grid, partials, s); break;
     case UHDR_IMG_FMT_32bppRGBA8888: launch_gen_h<UHDR_IMG_FMT_32bppRGBA8888>(p, two_pass, grid, partials, s); break;

@@ -149,3 +149,70 @@ __device__ __forceinline__ bool is_rgb_fmt(int fmt) {  // isPixelFormatRgb, gain
 }
 
 }  // namespace uhdr
+
+namespace uhdr {
+
+// ---- 2x2 quad fetch for the two chroma-subsampled layouts -----------------------------------------------
+// One lane reads the four luma samples of a quad with one load per row (P010: a dword = two 16-bit
+// samples; 4:2:0: a 16-bit load = two bytes) and the quad's chroma once (P010: one dword = the U, V
+// pair; 4:2:0: one byte from each plane), instead of three scalar loads per pixel; a wave then covers
+// 128 consecutive pixels of two rows with fully coalesced loads.  The normalisation arithmetic is
+// fetch_pixel's, so px[k] is bit-identical to fetch_pixel(x0 + (k & 1), y0 + (k >> 1)).
+// Layout contract (checked by the launchers): even x0 / y0, row pitches and plane bases that keep the
+// vector loads aligned.
+struct QuadYuv {
+  Color3 px[4];  // (row 0, col 0), (row 0, col 1), (row 1, col 0), (row 1, col 1): y, u, v as fetch_pixel returns them
+};
+
+__device__ __forceinline__ QuadYuv fetch_quad_p010(const ImageView& im, uint32_t qx, uint32_t qy, const UnormTables* ut) {
+  const uint16_t* yp = (const uint16_t*)im.p[0];
+  const uint16_t* cp = (const uint16_t*)im.p[1];
+  const uint32_t ya = *(const uint32_t*)(yp + (size_t)(2 * qy) * im.stride[0] + 2 * qx);
+  const uint32_t yb = *(const uint32_t*)(yp + (size_t)(2 * qy + 1) * im.stride[0] + 2 * qx);
+  const uint32_t uv = *(const uint32_t*)(cp + (size_t)qy * im.stride[1] + 2 * qx);
+  const int ys[4] = {(int)((ya & 0xffff) >> 6), (int)(ya >> 22), (int)((yb & 0xffff) >> 6), (int)(yb >> 22)};
+  const int uu = (int)((uv & 0xffff) >> 6), vv = (int)(uv >> 22);
+  QuadYuv q;
+  float cu, cv;
+  if (im.range == UHDR_CR_FULL_RANGE) {
+    if (ut) { cu = ut->u10[uu] - 0.5f; cv = ut->u10[vv] - 0.5f; }
+    else { cu = (float)uu / 1023.0f - 0.5f; cv = (float)vv / 1023.0f - 0.5f; }
+  } else {
+    cu = (float)(uu - 64) * (1 / 896.0f) - 0.5f;
+    cv = (float)(vv - 64) * (1 / 896.0f) - 0.5f;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    float yf;
+    if (im.range == UHDR_CR_FULL_RANGE) yf = ut ? ut->u10[ys[k]] : (float)ys[k] / 1023.0f;
+    else yf = (float)(ys[k] - 64) * (1 / 876.0f);
+    q.px[k] = {yf, cu, cv};
+  }
+  return q;
+}
+
+__device__ __forceinline__ QuadYuv fetch_quad_420(const ImageView& im, uint32_t qx, uint32_t qy) {
+  const uint8_t* yp = (const uint8_t*)im.p[0];
+  const uint32_t ya = *(const uint16_t*)(yp + (size_t)(2 * qy) * im.stride[0] + 2 * qx);
+  const uint32_t yb = *(const uint16_t*)(yp + (size_t)(2 * qy + 1) * im.stride[0] + 2 * qx);
+  const int uu = ((const uint8_t*)im.p[1])[(size_t)qy * im.stride[1] + qx];
+  const int vv = ((const uint8_t*)im.p[2])[(size_t)qy * im.stride[2] + qx];
+  const float cu = (float)(uu - 128) * (1 / 255.0f), cv = (float)(vv - 128) * (1 / 255.0f);
+  QuadYuv q;
+  q.px[0] = {(float)(int)(ya & 0xff) * (1 / 255.0f), cu, cv};
+  q.px[1] = {(float)(int)(ya >> 8) * (1 / 255.0f), cu, cv};
+  q.px[2] = {(float)(int)(yb & 0xff) * (1 / 255.0f), cu, cv};
+  q.px[3] = {(float)(int)(yb >> 8) * (1 / 255.0f), cu, cv};
+  return q;
+}
+
+// do the vector loads of fetch_quad_* stay aligned for this image?
+__host__ __device__ inline bool quad_layout_ok(const ImageView& im) {
+  if (im.w % 2 || im.h % 2) return false;
+  if (im.fmt == UHDR_IMG_FMT_24bppYCbCrP010)
+    return im.stride[0] % 2 == 0 && im.stride[1] % 2 == 0 && ((uintptr_t)im.p[0] % 4 == 0) && ((uintptr_t)im.p[1] % 4 == 0);
+  if (im.fmt == UHDR_IMG_FMT_12bppYCbCr420) return im.stride[0] % 2 == 0 && ((uintptr_t)im.p[0] % 2 == 0);
+  return false;
+}
+
+}  // namespace uhdr

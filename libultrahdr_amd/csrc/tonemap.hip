@@ -33,13 +33,15 @@ __device__ __forceinline__ void stage_tables(const ToneMapParams& p, ToneLds& L)
   __syncthreads();
 }
 
-// one HDR pixel -> gamma-encoded Display-P3 SDR rgb
-template <int HDRF>
-__device__ __forceinline__ Color3 tone_map_pixel(const ToneMapParams& p, const ToneLds& L, uint32_t x, uint32_t y) {
-  Color3 g = fetch_pixel<HDRF>(p.hdr, x, y, &L.unorm);
+// one HDR sample (as fetch_pixel returns it) -> gamma-encoded Display-P3 SDR rgb
+__device__ __forceinline__ Color3 tone_map_sample(const ToneMapParams& p, const ToneLds& L, Color3 g) {
   if (!p.hdr_is_rgb) g = yuv_to_rgb(g.r, g.g, g.b, p.hdr_yuv);
   const Color3 l = linearise_hdr(g, L.hdr, p.hdr_inv_lut != nullptr, p.hdr_inv_n == kInvOetfN);
   return tone_curve(l, p, L.math);
+}
+template <int HDRF>
+__device__ __forceinline__ Color3 tone_map_pixel(const ToneMapParams& p, const ToneLds& L, uint32_t x, uint32_t y) {
+  return tone_map_sample(p, L, fetch_pixel<HDRF>(p.hdr, x, y, &L.unorm));
 }
 
 __global__ __launch_bounds__(kBlock) void tonemap_p010_kernel(const ToneMapParams p) {
@@ -50,16 +52,24 @@ __global__ __launch_bounds__(kBlock) void tonemap_p010_kernel(const ToneMapParam
   uint8_t* yp = (uint8_t*)p.sdr.p[0];
   uint8_t* up = (uint8_t*)p.sdr.p[1];
   uint8_t* vp = (uint8_t*)p.sdr.p[2];
+  const bool vec_in = quad_layout_ok(p.hdr);
   for (uint32_t t = blockIdx.x; t < tiles; t += gridDim.x) {
     const uint32_t qy = t / tiles_x, qx = (t - qy * tiles_x) * kBlock + threadIdx.x;
     if (qx >= qw) continue;
     float su = 0.0f, sv = 0.0f;
     uint32_t yb[2][2];
+    QuadYuv hq;
+    if (vec_in) {  // coalesced: one dword of luma per row, the (U, V) pair once
+      hq = fetch_quad_p010(p.hdr, qx, qy, &L.unorm);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) hq.px[k] = fetch_pixel<UHDR_IMG_FMT_24bppYCbCrP010>(p.hdr, qx * 2 + (k & 1), qy * 2 + (k >> 1), &L.unorm);
+    }
 #pragma unroll
     for (int r = 0; r < 2; r++)
 #pragma unroll
       for (int c = 0; c < 2; c++) {
-        Color3 og = tone_map_pixel<UHDR_IMG_FMT_24bppYCbCrP010>(p, L, qx * 2 + c, qy * 2 + r);
+        Color3 og = tone_map_sample(p, L, hq.px[r * 2 + c]);
         Color3 yuv = rgb_to_yuv(og, p.p3);
         yuv.g += 0.5f;
         yuv.b += 0.5f;
