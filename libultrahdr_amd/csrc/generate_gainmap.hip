@@ -133,6 +133,50 @@ __global__ __launch_bounds__(kBlock) void affine_kernel(const AffineParams p) {
   }
 }
 
+// Wide variant: one thread maps 16 consecutive map pixels of a row (48 samples for a 3-channel map: twelve
+// 16-byte loads in flight per lane, three 16-byte nontemporal stores; the channel of every sample is a
+// compile-time constant).  The narrow kernel above has one load and one store per thread and is bound by
+// memory latency.
+template <int NCH>
+__global__ __launch_bounds__(kBlock) void affine_wide_kernel(const AffineParams p) {
+  constexpr int NS = 16 * NCH;  // samples per thread
+  const uint32_t row_elems = p.map_w * NCH, per_row = row_elems / NS;
+  const uint32_t total = per_row * p.map_h, tiles = (total + kBlock - 1) / kBlock;  // flat: narrow maps still fill the lanes
+  const float mn[3] = {p.mn[0], p.mn[NCH == 3 ? 1 : 0], p.mn[NCH == 3 ? 2 : 0]};
+  const double rr[3] = {p.range_rcp[0], p.range_rcp[NCH == 3 ? 1 : 0], p.range_rcp[NCH == 3 ? 2 : 0]};
+  typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+  for (uint32_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const uint32_t idx = t * kBlock + threadIdx.x;
+    if (idx >= total) continue;
+    const uint32_t y = idx / per_row, j = idx - y * per_row;
+    const float4* src = (const float4*)(p.gain_log2 + (size_t)y * row_elems + (size_t)j * NS);
+    float4 g[NS / 4];
+#pragma unroll
+    for (int k = 0; k < NS / 4; k++) g[k] = src[k];
+    uint32_t o[NS / 4];
+#pragma unroll
+    for (int k = 0; k < NS / 4; k++) {
+      const float v[4] = {g[k].x, g[k].y, g[k].z, g[k].w};
+      uint32_t w = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int c = (4 * k + i) % NCH;
+        float m = div_by_rcp64(v[i] - mn[c], rr[c]);  // (g - min) / (max - min), exact (device_math.h)
+        if (p.gamma != 1.0f) m = (float)pow((double)m, (double)p.gamma);
+        m *= 255.0f;
+        float t2 = m + 0.5f;
+        t2 = (t2 < 0.0f) ? 0.0f : ((t2 > 255.0f) ? 255.0f : t2);
+        w |= (uint32_t)t2 << (8 * i);
+      }
+      o[k] = w;
+    }
+    uint8_t* dst = p.out + (size_t)y * p.out_stride * NCH + (size_t)j * NS;
+#pragma unroll
+    for (int k = 0; k < NS / 16; k++)
+      __builtin_nontemporal_store((u4v){o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]}, (u4v*)(dst + 16 * k));
+  }
+}
+
 int gen_grid(uint32_t tiles) {
   static const int resident = [] {
     int dev = 0, cus = 0;
@@ -197,6 +241,15 @@ hipError_t launch_reduce_minmax(const float* partials, int n, float* out6, hipSt
 
 hipError_t launch_affine_map(const AffineParams& p, hipStream_t s) {
   const uint32_t row_elems = p.map_w * p.nch;
+  if ((p.nch == 1 || p.nch == 3) && p.map_w % 16 == 0 && ((size_t)p.out_stride * p.nch) % 16 == 0 && (((uintptr_t)p.out & 15) == 0) &&
+      (((uintptr_t)p.gain_log2 & 15) == 0)) {
+    const uint32_t total = (p.map_w / 16) * p.map_h;
+    const uint32_t tiles = (total + kBlock - 1) / kBlock;
+    const int grid = (int)(tiles < 8192u ? (tiles ? tiles : 1u) : 8192u);
+    if (p.nch == 3) hipLaunchKernelGGL((affine_wide_kernel<3>), dim3(grid), dim3(kBlock), 0, s, p);
+    else hipLaunchKernelGGL((affine_wide_kernel<1>), dim3(grid), dim3(kBlock), 0, s, p);
+    return hipGetLastError();
+  }
   const bool vec4 = (row_elems % 4 == 0) && ((p.out_stride * p.nch) % 4 == 0) && (((uintptr_t)p.out & 3) == 0) &&
                     (((uintptr_t)p.gain_log2 & 15) == 0);
   const uint32_t per_row = vec4 ? row_elems / 4 : row_elems;
