@@ -284,6 +284,19 @@ def extras(ctx, u, device):
     apply_case("apply_4k_hlg_mapA", 3840, 2160, "A", A.UHDR_CT_HLG)
     apply_case("apply_4k_pq_mapA", 3840, 2160, "A", A.UHDR_CT_PQ)
 
+    # BASELINE config 5: a batch of 4K frames decoded to HLG RGBA1010102 (map A), one launch
+    nb5 = 16
+    sets5 = make_frames(nb5, 3840, 2160, "A", device, u32, seed0=555)
+    for s5, g5, _ in sets5:
+        s5.raw.cg, g5.raw.cg = A.UHDR_CG_BT_709, A.UHDR_CG_BT_2100
+    ms = time_kernel(ctx, lambda: u.applyGainMapBatch([f[0] for f in sets5], [f[1] for f in sets5], md, A.UHDR_CT_HLG, u32, A.FLT_MAX,
+                                                      [f[2] for f in sets5]), iters=5, warm=2)
+    b5 = algo_bytes_per_px("A", 4) * 3840 * 2160 * nb5
+    res["apply_4k_hlg_mapA_batch16_one_launch"] = {"us": round(ms * 1e3, 1), "us_per_frame": round(ms * 1e3 / nb5, 2),
+                                                    "GB/s": round(b5 / (ms / 1e3) / 1e9, 1), "Mpx/s": round(nb5 * 3840 * 2160 / (ms / 1e3) / 1e6, 1)}
+    del sets5
+    torch.cuda.empty_cache()
+
     # 4:4:4 (what an API-0 stream decodes to) and RGBA8888 bases: the quad kernel's BASE 1 / 2 variants
     def generic_case(name, base_fmt, map_kind):
         w_, h_ = 3840, 2160
