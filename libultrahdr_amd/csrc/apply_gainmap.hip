@@ -2,15 +2,16 @@
 // Reference loop: /root/reference/lib/src/jpegr.cpp:1714-1812 (UltraHdr::applyGainMap).
 //
 // Two kernels:
-//   apply_quad_kernel   -- the hot one.  YCbCr 4:2:0 base (what a JPEG base image decodes to),
-//                          one lane = one chroma sample = one 2x2 luma quad, a wave covers a
-//                          128 x 2 pixel strip, so every global store instruction of the wave
-//                          writes one fully contiguous 1 KiB (F16) / 512 B (1010102) run per row.
-//                          All per-call tables (sRGB-EOTF 4 KiB, gain LUT 4-12 KiB, byte->float,
-//                          byte->factor, IDW weights) are staged in LDS once per workgroup and the
-//                          workgroup then walks strips grid-stride.
-//   apply_generic_kernel-- one thread per pixel, every format / scale combination the reference
-//                          accepts (4:4:4, 4:2:2, RGBA8888, odd sizes, non-integer scale).
+//   apply_quad_kernel   -- the hot one.  YCbCr 4:2:0 base (what a JPEG base image decodes to), or 4:4:4 /
+//                          RGBA8888 (API-0 streams); one work item of a lane = one 2x2 luma quad, a lane
+//                          owns two quads 128 pixels apart, a wave a 256 x 2 pixel strip, so every global
+//                          store instruction of the wave writes one contiguous 1 KiB (F16) / 512 B
+//                          (1010102) run and the two runs of a row follow each other.  All per-call
+//                          tables (sRGB-EOTF, gain LUT / byte->factor, byte->float, IDW weights, the HLG
+//                          output-code thresholds) are staged in LDS once per workgroup; exactly the
+//                          resident workgroups are launched and each wave walks its column strip.
+//   apply_generic_kernel-- one thread per pixel, every other format / scale combination the reference
+//                          accepts (4:2:2, RGB888, odd sizes, odd or non-integer scale, gamma != 1 at scale > 1).
 // HBM-bound by design: 1.5 B (4:2:0) + map + 8 B (F16) per pixel, no intermediate buffers.
 #include <cstdlib>
 #include <type_traits>
