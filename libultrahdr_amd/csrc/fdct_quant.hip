@@ -138,11 +138,14 @@ __global__ __launch_bounds__(kBlock) void fdct_quant_kernel(const uint8_t* __res
     for (int r = 0; r < 8; r++) in[r] = ws[cb * 72 + r * 9 + cc];
     fdct_1d<1>(in, out);
 #pragma unroll
-    for (int r = 0; r < 8; r++) {  // jcdctmgr.c forward_DCT quantizer
+    for (int r = 0; r < 8; r++) {  // jcdctmgr.c forward_DCT quantizer: sign(v) * ((|v| + q/2) / q)
+      // branch-free: |v| through the sign mask, the quotient through the reciprocal (0 for |v| + q/2 < q by
+      // itself: a * ceil(2^32 / q) < 2^32 whenever a < q < 65536), the sign put back the same way
       const int v = out[r];
-      uint32_t a = (uint32_t)(v < 0 ? -v : v) + (qv[r] >> 1);
-      uint32_t q = a >= qv[r] ? __umulhi(a, qm[r]) : 0u;
-      out[r] = v < 0 ? -(int)q : (int)q;
+      const int sgn = v >> 31;
+      const uint32_t a = (uint32_t)((v ^ sgn) - sgn) + (qv[r] >> 1);
+      const uint32_t q = __umulhi(a, qm[r]);
+      out[r] = (int)(q ^ (uint32_t)sgn) - sgn;
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
