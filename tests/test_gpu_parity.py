@@ -623,3 +623,38 @@ def test_apply_gainmap_batch_444_and_rgba_bases(uhdr, base_fmt):
     for i in range(n):
         want = L.apply_gainmap(oracle_kind(), sdrs[i], gms[i], md, A.UHDR_CT_LINEAR)
         assert np.array_equal(dests[i].to_host().valid(0), want.valid(0)), i
+
+
+def test_apply_gainmap_at_the_reference_maximum_dimension(uhdr):
+    """8192 x 8192 (UHDR_MAX_DIMENSION, ultrahdrcommon.h): the quad kernel's 32-bit addressing, the
+    resident-grid / row-group arithmetic and the batch-free path at the largest image the reference accepts.
+    Size-independent checks: a 64-row band at the top and one at the bottom equal the oracle on the same rows
+    (scale-1 RGBA map: no cross-row taps), and the same call twice gives the same bytes."""
+    import torch
+
+    w = h = 8192
+    rng = np.random.default_rng(43)
+    f16 = A.UHDR_IMG_FMT_64bppRGBAHalfFloat
+    sdr = Image(A.UHDR_IMG_FMT_12bppYCbCr420, w, h, A.UHDR_CG_BT_709, A.UHDR_CT_SRGB, A.UHDR_CR_FULL_RANGE)
+    sdr.buf[:] = rng.integers(0, 256, sdr.buf.size, dtype=np.uint8)
+    gm = Image(A.UHDR_IMG_FMT_32bppRGBA8888, w, h, A.UHDR_CG_BT_2100)
+    gm.buf[:] = rng.integers(0, 256, gm.buf.size, dtype=np.uint8)
+    md = synth.default_metadata(use_base_cg=0, per_channel=True)
+    dsdr, dgm = sdr.to("cuda:0"), gm.to("cuda:0")
+    out1 = Image(f16, w, h, align=64, device="cuda:0")
+    out2 = Image(f16, w, h, align=64, device="cuda:0")
+    uhdr.applyGainMap(dsdr, dgm, md, A.UHDR_CT_LINEAR, f16, A.FLT_MAX, out1)
+    uhdr.applyGainMap(dsdr, dgm, md, A.UHDR_CT_LINEAR, f16, A.FLT_MAX, out2)
+    uhdr.ctx.synchronize()
+    assert torch.equal(out1.buf, out2.buf)
+    got = out1.to_host().valid(0)
+    band = 64
+    for r0 in (0, h - band):
+        s_b = Image(A.UHDR_IMG_FMT_12bppYCbCr420, w, band, sdr.raw.cg, sdr.raw.ct, sdr.raw.range)
+        s_b.valid(0)[:] = sdr.valid(0)[r0: r0 + band]
+        s_b.valid(1)[:] = sdr.valid(1)[r0 // 2: (r0 + band) // 2]
+        s_b.valid(2)[:] = sdr.valid(2)[r0 // 2: (r0 + band) // 2]
+        g_b = Image(A.UHDR_IMG_FMT_32bppRGBA8888, w, band, gm.raw.cg)
+        g_b.valid(0)[:] = gm.valid(0)[r0: r0 + band]
+        want = L.apply_gainmap("port", s_b, g_b, md, A.UHDR_CT_LINEAR)
+        assert np.array_equal(got[r0: r0 + band], want.valid(0)), r0
