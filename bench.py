@@ -373,11 +373,11 @@ def extras(ctx, u, device):
         md_, gm_ = enc.generateGainMap(sdr, hdr)
         u.convertYuv(base, A.UHDR_CG_BT_709, A.UHDR_CG_DISPLAY_P3)
         fdct_planes(base, (0, 1, 2), (qy, qc, qc))
-        fdct_planes(u.jpeg_rgb_to_ycc(gm_), (0, 1, 2), (qy, qc, qc))
+        u.fdct_quant_rgb(gm_, qy, qc)
 
     ms = time_kernel(ctx, api1, iters=4, warm=2)
     res["encode_api1_4k_p010_420_2pass_3ch_chain"] = {"us": round(ms * 1e3, 1), "Mpx/s": round(w * h / (ms / 1e3) / 1e6, 1),
-                                                       "stages": "generate(2 pass) + convertYuv + fdct(base 3 planes) + rgb_to_ycc + fdct(map 3 planes); entropy coding not included"}
+                                                       "stages": "generate(2 pass) + convertYuv + fdct(base 3 planes) + fused(rgb_to_ycc + fdct of the 3 map components); entropy coding not included"}
     # (2) API-0 encode, 8K RGBA1010102 PQ (BASELINE config 3): tonemap, one-pass max-RGB 3-channel map, RGB->YCbCr 4:4:4, FDCTs
     w8, h8 = 7680, 4320
     hdr8 = synth.make_hdr_rgba1010102(w8, h8, ct=A.UHDR_CT_PQ).to(device)
@@ -397,11 +397,11 @@ def extras(ctx, u, device):
     def api0_fused():
         _, ycc_, md_, gm_ = api0_enc.encodeApi0Fused(hdr8, want_sdr_rgba=False, use_luminance=False)
         fdct_planes(ycc_, (0, 1, 2), (qy, qc, qc))
-        fdct_planes(u.jpeg_rgb_to_ycc(gm_), (0, 1, 2), (qy, qc, qc))
+        u.fdct_quant_rgb(gm_, qy, qc)
 
     ms = time_kernel(ctx, api0_fused, iters=3, warm=1)
     res["encode_api0_8k_rgba1010102_chain_fused_front_end"] = {"us": round(ms * 1e3, 1), "Mpx/s": round(w8 * h8 / (ms / 1e3) / 1e6, 1),
-                                                                "stages": "fused(tonemap + generate 1 pass + rgb->ycbcr444) + fdct(base 3) + rgb_to_ycc + fdct(map 3)"}
+                                                                "stages": "fused(tonemap + generate 1 pass + rgb->ycbcr444) + fdct(base 3) + fused(rgb_to_ycc + fdct of the 3 map components)"}
     del hdr8, sdr8
     torch.cuda.empty_cache()
     # (2b) BASELINE config 4, the per-GPU share: one 16384 x 2048 row stripe of a 16K x 16K API-1 encode

@@ -268,6 +268,15 @@ uhdr_error_info_t uhdr_hip_encode_api0_fused_dev(uhdr_hip_ctx_t* ctx, const uhdr
 uhdr_error_info_t uhdr_hip_copy_raw_image_dev(uhdr_hip_ctx_t* ctx, const uhdr_raw_image_t* src,
                                               uhdr_raw_image_t* dst);
 
+/* MI355X extension for 3-channel gain maps: uhdr_hip_jpeg_rgb_to_ycc followed by uhdr_hip_fdct_quant of Y (luma
+ * table), Cb and Cr (chroma table) -- what libjpeg does to a JCS_RGB image at 4:4:4 (jpegencoderhelper.cpp:165-167,
+ * 212-225) -- in one pass: 3 (4) B/px in, 6 B/px out instead of 15 B/px.  Device image, RGB888 or RGBA8888, w and h
+ * multiples of 8, rows 8- (16-) byte aligned; three coefficient arrays of (w/8)*(h/8) JBLOCKs, bit-identical to the
+ * two-step route. */
+uhdr_error_info_t uhdr_hip_fdct_quant_rgb_dev(uhdr_hip_ctx_t* ctx, const uhdr_raw_image_t* rgb,
+                                              const uint16_t qtable_luma[64], const uint16_t qtable_chroma[64],
+                                              int16_t* coef_y, int16_t* coef_cb, int16_t* coef_cr);
+
 /* ---- JPEG decode stage (the step immediately before applyGainMap) ---------------
  * Inverse of uhdr_hip_fdct_quant: dequantize + libjpeg's JDCT_ISLOW 8x8 inverse DCT + range limit of
  * coefficient blocks as jpeg_read_coefficients() yields them (JBLOCK layout, raster block order), so that

@@ -153,6 +153,7 @@ _SIGS = {
     "uhdr_hip_fdct_quant_dev": (ErrorInfo, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, _P(C.c_uint16), C.c_void_p]),
     "uhdr_hip_encode_api0_fused_dev": (ErrorInfo, [C.c_void_p, _P(RawImage), _P(EncodeCfg), _P(RawImage), _P(RawImage), _P(GainmapMetadata), _P(RawImage)]),
     "uhdr_hip_copy_raw_image_dev": (ErrorInfo, [C.c_void_p, _P(RawImage), _P(RawImage)]),
+    "uhdr_hip_fdct_quant_rgb_dev": (ErrorInfo, [C.c_void_p, _P(RawImage), _P(C.c_uint16), _P(C.c_uint16), C.c_void_p, C.c_void_p, C.c_void_p]),
     "uhdr_hip_idct_dequant": (ErrorInfo, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _P(C.c_uint16), C.c_void_p, C.c_size_t]),
     "uhdr_hip_idct_dequant_dev": (ErrorInfo, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _P(C.c_uint16), C.c_void_p, C.c_size_t]),
     "uhdr_hip_jpeg_rgb_to_ycc": (ErrorInfo, [C.c_void_p, _P(RawImage), _P(RawImage)]),

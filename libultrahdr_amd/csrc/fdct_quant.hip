@@ -167,6 +167,119 @@ __global__ __launch_bounds__(kBlock) void fdct_quant_kernel(const uint8_t* __res
   }
 }
 
+// ---- 3-channel gain map: libjpeg's JCS_RGB -> YCbCr conversion + FDCT + quantize in one pass -----------------
+// What jpeg_write_scanlines does to an RGB888 gain map (jpegencoderhelper.cpp:165-167, 212-225): jccolor.c
+// rgb_ycc_convert, then the islow FDCT and the quantizer per component (luma table for Y, chroma table for
+// Cb / Cr, 4:4:4).  Unfused that is uhdr_hip_jpeg_rgb_to_ycc (3 B in, 3 B out) followed by three
+// uhdr_hip_fdct_quant launches (1 B in, 2 B out each): 15 B/px.  Here a lane reads its 8 pixels once
+// (24 or 32 bytes), converts them in registers and runs the three transforms back to back through the same
+// LDS workspace: 3 (4) B/px in, 6 B/px out.
+struct QuantArgs2 {
+  QuantArgs y, c;
+};
+#define FIX16(x) ((int)((x) * 65536.0 + 0.5))
+
+template <int BPP>
+__global__ __launch_bounds__(kBlock) void fdct_quant_rgb_kernel(const uint8_t* __restrict__ rgb, size_t pitch /* bytes */, int bw, int bh,
+                                                                const QuantArgs2 qa, int16_t* __restrict__ coef_y,
+                                                                int16_t* __restrict__ coef_cb, int16_t* __restrict__ coef_cr) {
+  __shared__ int s_ws[kBlock / 64][8 * 8 * 9];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int* ws = s_ws[wv];
+  const int groups_x = (bw + 7) >> 3, total = groups_x * bh;
+  const int gwave = blockIdx.x * (kBlock / 64) + wv, nwaves = gridDim.x * (kBlock / 64);
+  const int cb = lane >> 3, cc = lane & 7;  // column-pass role
+  const int rr = lane >> 3, rb = lane & 7;  // row-pass / store role
+  uint32_t qvy[8], qmy[8], qvc[8], qmc[8];
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    qvy[r] = qa.y.qv[r * 8 + cc]; qmy[r] = qa.y.qm[r * 8 + cc];
+    qvc[r] = qa.c.qv[r * 8 + cc]; qmc[r] = qa.c.qm[r * 8 + cc];
+  }
+  for (int t = gwave; t < total; t += nwaves) {
+    const int by = t / groups_x, gx = t - by * groups_x;
+    const int bx = gx * 8 + rb;
+    int comp[3][8];
+    if (bx < bw) {
+      const uint8_t* src = rgb + (size_t)(by * 8 + rr) * pitch + (size_t)bx * 8 * BPP;
+      uint32_t w[2 * BPP];
+      if constexpr (BPP == 4) {
+        const uint4 a = ((const uint4*)src)[0], b = ((const uint4*)src)[1];
+        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+      } else {
+        const uint2 a = ((const uint2*)src)[0], b = ((const uint2*)src)[1], c = ((const uint2*)src)[2];
+        w[0] = a.x; w[1] = a.y; w[2] = b.x; w[3] = b.y; w[4] = c.x; w[5] = c.y;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        int r, g, b;
+        if constexpr (BPP == 4) {
+          r = w[k] & 0xff; g = (w[k] >> 8) & 0xff; b = (w[k] >> 16) & 0xff;
+        } else {  // byte 3k, 3k+1, 3k+2 of the 24-byte run
+          auto byte_at = [&](int i) { return (int)((w[i >> 2] >> (8 * (i & 3))) & 0xff); };
+          r = byte_at(3 * k); g = byte_at(3 * k + 1); b = byte_at(3 * k + 2);
+        }
+        // jccolor.c rgb_ycc_convert (see jpeg_decode.hip: both published constant sets give these bytes)
+        const int half = 1 << 15, off = 128 << 16;
+        comp[0][k] = ((__mul24(FIX16(0.29900), r) + __mul24(FIX16(0.58700), g) + __mul24(FIX16(0.11400), b) + half) >> 16) - 128;
+        comp[1][k] = ((__mul24(-FIX16(0.16874), r) + __mul24(-FIX16(0.33126), g) + __mul24(FIX16(0.50000), b) + off + half - 1) >> 16) - 128;
+        comp[2][k] = ((__mul24(FIX16(0.50000), r) + __mul24(-FIX16(0.41869), g) + __mul24(-FIX16(0.08131), b) + off + half - 1) >> 16) - 128;
+      }
+    }
+#pragma unroll
+    for (int ci = 0; ci < 3; ci++) {
+      int in[8], out[8];
+      if (bx < bw) {
+        fdct_1d<0>(comp[ci], out);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 8; c++) out[c] = 0;
+      }
+#pragma unroll
+      for (int c = 0; c < 8; c++) ws[rb * 72 + rr * 9 + c] = out[c];
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+      for (int r = 0; r < 8; r++) in[r] = ws[cb * 72 + r * 9 + cc];
+      fdct_1d<1>(in, out);
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+        const int v = out[r];
+        const int sgn = v >> 31;
+        const uint32_t qv = ci == 0 ? qvy[r] : qvc[r], qm = ci == 0 ? qmy[r] : qmc[r];
+        const uint32_t a = (uint32_t)((v ^ sgn) - sgn) + (qv >> 1);
+        const uint32_t q = __umulhi(a, qm);
+        out[r] = (int)(q ^ (uint32_t)sgn) - sgn;
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int r = 0; r < 8; r++) ws[cb * 72 + r * 9 + cc] = out[r];
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      if (bx < bw) {
+        int v[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) v[c] = ws[rb * 72 + rr * 9 + c];
+        uint4 o;
+        o.x = (uint32_t)(v[0] & 0xffff) | ((uint32_t)v[1] << 16);
+        o.y = (uint32_t)(v[2] & 0xffff) | ((uint32_t)v[3] << 16);
+        o.z = (uint32_t)(v[4] & 0xffff) | ((uint32_t)v[5] << 16);
+        o.w = (uint32_t)(v[6] & 0xffff) | ((uint32_t)v[7] << 16);
+        int16_t* dst = ci == 0 ? coef_y : (ci == 1 ? coef_cb : coef_cr);
+        *(uint4*)(dst + ((size_t)by * bw + bx) * 64 + rr * 8) = o;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+static void fill_quant_args(const uint16_t* qt_host, QuantArgs* qa) {
+  for (int i = 0; i < 64; i++) {
+    qa->qv[i] = (uint32_t)qt_host[i] << 3;
+    qa->qm[i] = (uint32_t)((0x100000000ull + qa->qv[i] - 1) / qa->qv[i]);
+  }
+}
+
 }  // namespace
 
 hipError_t launch_fdct_quant(const uint8_t* plane, size_t stride, int bw, int bh,
@@ -187,6 +300,23 @@ hipError_t launch_fdct_quant(const uint8_t* plane, size_t stride, int bw, int bh
   if (grid > resident) grid = resident;
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL(fdct_quant_kernel, dim3(grid), dim3(kBlock), 0, s, plane, stride, bw, bh, qa, coef);
+  return hipGetLastError();
+}
+
+// bpp 3 (RGB888) or 4 (RGBA8888, alpha ignored); pitch in bytes; rows and base 8- (bpp 3) / 16-byte (bpp 4) aligned
+hipError_t launch_fdct_quant_rgb(const uint8_t* rgb, size_t pitch, int bpp, int bw, int bh, const uint16_t* qt_luma_host,
+                                 const uint16_t* qt_chroma_host, int16_t* coef_y, int16_t* coef_cb, int16_t* coef_cr, hipStream_t s) {
+  QuantArgs2 qa;
+  fill_quant_args(qt_luma_host, &qa.y);
+  fill_quant_args(qt_chroma_host, &qa.c);
+  const int total = ((bw + 7) / 8) * bh;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  int grid = (total + 3) / 4;
+  if (grid > cus * 6) grid = cus * 6;
+  if (grid < 1) grid = 1;
+  if (bpp == 4) hipLaunchKernelGGL((fdct_quant_rgb_kernel<4>), dim3(grid), dim3(kBlock), 0, s, rgb, pitch, bw, bh, qa, coef_y, coef_cb, coef_cr);
+  else hipLaunchKernelGGL((fdct_quant_rgb_kernel<3>), dim3(grid), dim3(kBlock), 0, s, rgb, pitch, bw, bh, qa, coef_y, coef_cb, coef_cr);
   return hipGetLastError();
 }
 

@@ -1080,6 +1080,36 @@ uhdr_error_info_t uhdr_hip_fdct_quant(uhdr_hip_ctx_t* c, const uint8_t* plane, s
 }
 
 // -------------------------------------------------------------------------------------------------
+// 3-channel gain map: libjpeg's RGB -> YCbCr + FDCT + quantize of all three components in one pass
+// -------------------------------------------------------------------------------------------------
+uhdr_error_info_t uhdr_hip_fdct_quant_rgb_dev(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* rgb, const uint16_t qt_luma[64],
+                                              const uint16_t qt_chroma[64], int16_t* coef_y, int16_t* coef_cb, int16_t* coef_cr) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  if (!rgb || !rgb->planes[0] || !qt_luma || !qt_chroma || !coef_y || !coef_cb || !coef_cr)
+    return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument");
+  if (rgb->fmt != UHDR_IMG_FMT_24bppRGB888 && rgb->fmt != UHDR_IMG_FMT_32bppRGBA8888)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "fdct_quant_rgb expects UHDR_IMG_FMT_24bppRGB888 or UHDR_IMG_FMT_32bppRGBA8888. Received %d", rgb->fmt);
+  const int bpp = rgb->fmt == UHDR_IMG_FMT_32bppRGBA8888 ? 4 : 3;
+  const size_t pitch = (size_t)rgb->stride[0] * bpp, al = bpp == 4 ? 16 : 8;
+  if (rgb->w == 0 || rgb->h == 0 || rgb->w % 8 || rgb->h % 8)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "fdct_quant_rgb needs dimensions that are multiples of 8 (received %ux%u); "
+                      "pad to the MCU grid as jpegencoderhelper.cpp:246-309 does, or use jpeg_rgb_to_ycc + fdct_quant", rgb->w, rgb->h);
+  if (rgb->stride[0] < rgb->w) return err_status(UHDR_CODEC_INVALID_PARAM, "stride (%u) cannot be less than width (%u)", rgb->stride[0], rgb->w);
+  if (pitch % al || ((uintptr_t)rgb->planes[0] % al))
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "fdct_quant_rgb needs %zu-byte aligned rows; use jpeg_rgb_to_ycc + fdct_quant", al);
+  if (((uintptr_t)coef_y | (uintptr_t)coef_cb | (uintptr_t)coef_cr) & 15)
+    return err_status(UHDR_CODEC_INVALID_PARAM, "coefficient buffers must be 16-byte aligned");
+  for (int i = 0; i < 64; i++)
+    if (qt_luma[i] == 0 || qt_luma[i] > 255 || qt_chroma[i] == 0 || qt_chroma[i] > 255)
+      return err_status(UHDR_CODEC_INVALID_PARAM, "quantization table entry %d out of baseline range", i);
+  HIP_TRY(hipSetDevice(c->device));
+  ProfScope ps(c, "fdct_quant");
+  HIP_TRY(launch_fdct_quant_rgb((const uint8_t*)rgb->planes[0], pitch, bpp, (int)(rgb->w / 8), (int)(rgb->h / 8), qt_luma, qt_chroma,
+                                coef_y, coef_cb, coef_cr, c->stream));
+  return ok_status();
+}
+
+// -------------------------------------------------------------------------------------------------
 // API-0 front end fused: toneMap + generateGainMap + convert_raw_input_to_ycbcr(4:4:4) in one pass
 // -------------------------------------------------------------------------------------------------
 uhdr_error_info_t uhdr_hip_encode_api0_fused_dev(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* hdr, const uhdr_hip_encode_cfg_t* cfg,

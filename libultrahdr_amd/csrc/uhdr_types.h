@@ -165,6 +165,8 @@ hipError_t launch_rgb_to_ycbcr(const RgbToYcbcrParams& p, hipStream_t s);
 hipError_t launch_fdct_quant(const uint8_t* plane, size_t stride, int bw, int bh,
                              const uint16_t* qt_host, int16_t* coef, hipStream_t s);
 
+hipError_t launch_fdct_quant_rgb(const uint8_t* rgb, size_t pitch, int bpp, int bw, int bh, const uint16_t* qt_luma_host,
+                                 const uint16_t* qt_chroma_host, int16_t* coef_y, int16_t* coef_cb, int16_t* coef_cr, hipStream_t s);
 hipError_t launch_repack(int mode, const void* src, size_t src_pitch, void* dst, size_t dst_pitch, uint32_t w, uint32_t h,
                          hipStream_t s);  // 0: RGB888 -> RGBA8888, 1: RGBA8888 -> Y400
 hipError_t launch_idct_dequant(const int16_t* coef, int bw, int bh, const uint16_t* qt_host, uint8_t* plane,

@@ -208,6 +208,18 @@ class UltraHdr:
                                                  blocks_w, blocks_h, qt, C.c_void_p(out.data_ptr())))
         return out
 
+    def fdct_quant_rgb(self, rgb: Image, qt_luma: np.ndarray, qt_chroma: np.ndarray):
+        """3-channel gain map (device RGB888 / RGBA8888 image, w and h multiples of 8): libjpeg's RGB -> YCbCr and the
+        FDCT + quantize of all three components in one pass.  Returns three int16 [h/8, w/8, 64] CUDA tensors."""
+        import torch
+
+        assert _is_dev(rgb)
+        ql = (C.c_uint16 * 64)(*[int(v) for v in qt_luma])
+        qc = (C.c_uint16 * 64)(*[int(v) for v in qt_chroma])
+        outs = [torch.empty((rgb.h // 8, rgb.w // 8, 64), dtype=torch.int16, device=rgb.buf.device) for _ in range(3)]
+        A.check(self.lib.uhdr_hip_fdct_quant_rgb_dev(self.ctx.handle, C.byref(rgb.raw), ql, qc, *[C.c_void_p(o.data_ptr()) for o in outs]))
+        return outs
+
     def idct_dequant(self, coef, qtable: np.ndarray, plane=None, stride: int = 0):
         """Inverse of fdct_quant.  coef: int16 [blocks_h, blocks_w, 64] numpy array (host) or CUDA
         tensor (device).  Returns the uint8 plane [blocks_h*8, stride] (stride defaults to blocks_w*8)."""

@@ -658,3 +658,26 @@ def test_apply_gainmap_at_the_reference_maximum_dimension(uhdr):
         g_b.valid(0)[:] = gm.valid(0)[r0: r0 + band]
         want = L.apply_gainmap("port", s_b, g_b, md, A.UHDR_CT_LINEAR)
         assert np.array_equal(got[r0: r0 + band], want.valid(0)), r0
+
+
+@pytest.mark.parametrize("fmt", [A.UHDR_IMG_FMT_24bppRGB888, A.UHDR_IMG_FMT_32bppRGBA8888])
+@pytest.mark.parametrize("quality", [95, 60])
+def test_fdct_quant_rgb_fused_equals_two_step_route(uhdr, fmt, quality):
+    """uhdr_hip_fdct_quant_rgb_dev == libjpeg's rgb_ycc_convert followed by the FDCT of each component (oracle)."""
+    rng = np.random.default_rng(47)
+    for (w, h) in ((256, 64), (72, 40)):  # second: block count not a multiple of 8
+        rgb = Image(fmt, w, h, align=64)
+        rgb.buf[:] = rng.integers(0, 256, rgb.buf.size, dtype=np.uint8)
+        bpp = 4 if fmt == A.UHDR_IMG_FMT_32bppRGBA8888 else 3
+        packed = np.ascontiguousarray(rgb.valid(0).view(np.uint8).reshape(h, -1)[:, : w * bpp])
+        rgb888 = packed if bpp == 3 else np.ascontiguousarray(packed.reshape(h, w, 4)[:, :, :3].reshape(h, w * 3))
+        planes = L.jpeg_rgb_to_ycc_port(rgb888, w, w, h)
+        ql, qc = uhdr.quant_table(quality, False), uhdr.quant_table(quality, True)
+        got = uhdr.fdct_quant_rgb(rgb.to("cuda:0"), ql, qc)
+        uhdr.ctx.synchronize()
+        for c in range(3):
+            want = L.fdct_quant_port(planes[c], w, w // 8, h // 8, ql if c == 0 else qc)
+            assert np.array_equal(got[c].cpu().numpy(), want), (w, h, c)
+    with pytest.raises(A.UhdrError) as e:
+        uhdr.fdct_quant_rgb(Image(fmt, 36, 16, align=64, device="cuda:0"), ql, qc)
+    assert e.value.code == A.UHDR_CODEC_UNSUPPORTED_FEATURE
