@@ -26,8 +26,9 @@ def _floats_between(lo, hi, step):
 
 
 def test_srgb_oetf_matches_powf_over_the_whole_domain():
-    # every 61st float of [0, 1] plus the neighbourhood of the branch point and both ends
-    xs = np.concatenate([_floats_between(0.0, 1.0, 61), _floats_between(0.0031300, 0.0031320, 1),
+    # every 61st float of the pow branch (the linear branch below 0.0031308 is one multiply) plus a sparse sweep of
+    # [0, 1], the neighbourhood of the branch point and both ends
+    xs = np.concatenate([_floats_between(0.0031308, 1.0, 61), _floats_between(0.0, 0.0031308, 4099), _floats_between(0.0031300, 0.0031320, 1),
                          _floats_between(0.99999, 1.0, 1), np.float32([0.0, 1.0, 0.5, 0.0031308])])
     got = _eval_product(0, xs)
     want = O.eval_fn(O.port(), "uo_", "srgb_oetf", xs)
@@ -92,13 +93,14 @@ def test_div_const_is_exact_for_every_library_constant(b):
     """a / b == div_const(a, b) for all 2^23 mantissas of a (the three-instruction sequence is scale
     invariant, so one binade proves it for every normal a), for each constant divisor in the kernels."""
     lib = A.load()
-    a = (np.arange(1 << 23, dtype=np.uint32) | np.uint32(0x3F800000)).view(np.float32)
-    buf = np.concatenate([np.float32([b]), a, -a[::4097]])
-    out = np.empty_like(buf)
-    assert lib.uhdr_hip_exact_math_eval(2, buf.ctypes.data_as(C.POINTER(C.c_float)), out.ctypes.data_as(C.POINTER(C.c_float)), buf.size) == 0
-    assert out[0] == np.float32(1.0) / np.float32(b)
-    want = buf[1:] / np.float32(b)
-    assert np.array_equal(out[1:].view(np.uint32), want.view(np.uint32))
+    for start in range(0, 1 << 23, 1 << 20):  # all 2^23 mantissas, 1 M at a time
+        a = (np.arange(start, start + (1 << 20), dtype=np.uint32) | np.uint32(0x3F800000)).view(np.float32)
+        buf = np.concatenate([np.float32([b]), a, -a[::4097]])
+        out = np.empty_like(buf)
+        assert lib.uhdr_hip_exact_math_eval(2, buf.ctypes.data_as(C.POINTER(C.c_float)), out.ctypes.data_as(C.POINTER(C.c_float)), buf.size) == 0
+        assert out[0] == np.float32(1.0) / np.float32(b)
+        want = buf[1:] / np.float32(b)
+        assert np.array_equal(out[1:].view(np.uint32), want.view(np.uint32))
 
 
 def test_division_through_a_float64_reciprocal_is_exact_for_any_divisor():

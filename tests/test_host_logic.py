@@ -105,16 +105,17 @@ def test_jpeg_rgb_to_ycc_constant_sets_are_equivalent():
     fix = lambda x: int(x * 65536.0 + 0.5)
     sets = [(0.29900, 0.58700, 0.11400, 0.16874, 0.33126, 0.50000, 0.41869, 0.08131),
             (0.299, 0.587, 0.114, 0.168735892, 0.331264108, 0.5, 0.418687589, 0.081312411)]
-    r, g, b = np.meshgrid(*[np.arange(256, dtype=np.int64)] * 3, indexing="ij")
+    g, b = np.meshgrid(np.arange(256, dtype=np.int32), np.arange(256, dtype=np.int32), indexing="ij")
     half, off = 1 << 15, 128 << 16
-    res = []
-    for c in sets:
-        y = (fix(c[0]) * r + fix(c[1]) * g + fix(c[2]) * b + half) >> 16
-        cb = (-fix(c[3]) * r - fix(c[4]) * g + fix(c[5]) * b + off + half - 1) >> 16
-        cr = (fix(c[5]) * r - fix(c[6]) * g - fix(c[7]) * b + off + half - 1) >> 16
-        res.append((y, cb, cr))
-    for a, bb in zip(*res):
-        assert np.array_equal(a, bb)
+    for r in range(256):  # one red value at a time: 64 K triples per step, no large temporaries
+        res = []
+        for c in sets:
+            y = (fix(c[0]) * r + fix(c[1]) * g + fix(c[2]) * b + half) >> 16
+            cb = (-fix(c[3]) * r - fix(c[4]) * g + fix(c[5]) * b + off + half - 1) >> 16
+            cr = (fix(c[5]) * r - fix(c[6]) * g - fix(c[7]) * b + off + half - 1) >> 16
+            res.append((y, cb, cr))
+        for a, bb in zip(*res):
+            assert np.array_equal(a, bb), r
 
 
 def test_half_subnormal_formula():
@@ -126,8 +127,8 @@ def test_half_subnormal_formula():
 
     port = L.port()
     lo, hi = 96 << 23, (114 << 23) + 4096
-    for start in range(lo, hi, 1 << 24):
-        bits = np.arange(start, min(start + (1 << 24), hi), dtype=np.uint32)
+    for start in range(lo, hi, 1 << 21):  # 2 M floats per step keeps the temporaries small
+        bits = np.arange(start, min(start + (1 << 21), hi), dtype=np.uint32)
         want = np.empty(bits.size, dtype=np.uint16)
         port.uo_float_to_half(bits.view(np.float32).ctypes.data, want.ctypes.data, bits.size)
         b = bits + np.uint32(0x1000)
