@@ -130,3 +130,15 @@ def test_oetf_code_thresholds_describe_the_reference_composite(ct):
                             np.array([0.0, 1.0], dtype=np.float32)])
     assert np.array_equal(composite(dense), by_table(dense))
     assert lib.uhdr_hip_oetf_code_thresholds(A.UHDR_CT_LINEAR, t) == -1
+
+
+def test_public_headers_compile_as_plain_c_and_cpp(tmp_path):
+    """include/uhdr_hip.h is C99 (the ABI a cgo / JNI / ctypes binding would consume); include/uhdr_hip.hpp is
+    C++14.  Neither needs HIP, torch or the reference's headers."""
+    inc = os.path.join(ROOT, "include")
+    c = tmp_path / "c99.c"
+    c.write_text('#include "uhdr_hip.h"\nint main(void) { return 0; }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(c)], check=True)
+    cpp = tmp_path / "cpp.cpp"
+    cpp.write_text('#include "uhdr_hip.hpp"\nint main() { uhdr_hip::UltraHdr* p = nullptr; (void)p; return 0; }\n')
+    subprocess.run(["g++", "-std=c++14", "-Wall", "-Wextra", "-Werror", "-I", inc, "-fsyntax-only", str(cpp)], check=True)
