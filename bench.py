@@ -176,7 +176,8 @@ def main():
     px_per_step = args.batch * w * h * world
     value = px_per_step * args.steps / elapsed / 1e6
     avg_launch_s = (kern_ms / 1e3) / max(n_launch, 1)
-    frames_per_launch = nb if args.launch == "batch" else 1
+    # the library issues batches above 16 frames as several launches: derive the frames per launch from the count
+    frames_per_launch = (args.steps * nb) // max(n_launch, 1) if args.launch == "batch" else 1
     algo_b = algo_bytes_per_px(args.map) * w * h * frames_per_launch
     achieved = algo_b / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
 

@@ -597,11 +597,22 @@ uhdr_error_info_t uhdr_hip_apply_gainmap_batch_dev(uhdr_hip_ctx_t* c, unsigned i
   }
   FramePtrs* slot = (FramePtrs*)((char*)c->d_frames + (size_t)(c->frames_next++ % kSlots) * c->frames_cap);
   HIP_TRY(hipMemcpyAsync(slot, tab.data(), bytes, hipMemcpyHostToDevice, c->stream));  // pageable source: staged before return
-  p.n_frames = n;
-  p.frames = slot;
-  {
+  // Launch in chunks of at most 16 frames: the waves of one launch are spread over all of its frames, and beyond
+  // ~16 separate frame allocations the concurrent access streams lose DRAM locality (measured: 16 frames 5.7 TB/s,
+  // 32 frames 5.3 TB/s in one launch); back-to-back launches cost ~3 us each.
+  constexpr unsigned int kBatchChunk = 16;
+  for (unsigned int f0 = 0; f0 < n; f0 += kBatchChunk) {
+    const unsigned int nf = (n - f0 < kBatchChunk) ? (n - f0) : kBatchChunk;
+    ApplyParams q = p;
+    q.n_frames = nf;
+    q.frames = slot + f0;
+    if (nf == 1) {  // a single frame goes through the kernel's direct-pointer path
+      q.sdr.p[0] = tab[f0].y; q.sdr.p[1] = tab[f0].u; q.sdr.p[2] = tab[f0].v;
+      q.gm.p[0] = tab[f0].map;
+      q.dst.p[0] = tab[f0].dst;
+    }
     ProfScope ps(c, "apply_gainmap");
-    HIP_TRY(launch_apply_gainmap(p, c->stream));
+    HIP_TRY(launch_apply_gainmap(q, c->stream));
   }
   return ok_status();
 }

@@ -681,3 +681,19 @@ def test_fdct_quant_rgb_fused_equals_two_step_route(uhdr, fmt, quality):
     with pytest.raises(A.UhdrError) as e:
         uhdr.fdct_quant_rgb(Image(fmt, 36, 16, align=64, device="cuda:0"), ql, qc)
     assert e.value.code == A.UHDR_CODEC_UNSUPPORTED_FEATURE
+
+
+@pytest.mark.parametrize("n", [16, 17, 33])
+def test_apply_gainmap_batch_chunking(uhdr, n):
+    """Batches above 16 frames are issued as several launches (incl. a last launch of a single frame)."""
+    w, h = 256, 64
+    u32 = A.UHDR_IMG_FMT_32bppRGBA1010102
+    md = synth.default_metadata()
+    sdrs = [synth.make_sdr_yuv420(w, h, seed=400 + i, noise=0.05) for i in range(n)]
+    gms = [synth.make_gainmap(w // 2, h // 2, 1, seed=500 + i) for i in range(n)]
+    dests = [Image(u32, w, h, align=4, device="cuda:0") for _ in range(n)]
+    uhdr.applyGainMapBatch([s.to("cuda:0") for s in sdrs], [g.to("cuda:0") for g in gms], md, A.UHDR_CT_PQ, u32, A.FLT_MAX, dests)
+    uhdr.ctx.synchronize()
+    for i in (0, 15, n - 1):
+        want = L.apply_gainmap(oracle_kind(), sdrs[i], gms[i], md, A.UHDR_CT_PQ)
+        assert np.array_equal(dests[i].to_host().valid(0), want.valid(0)), i
