@@ -308,13 +308,14 @@ def extras(ctx, u, device):
         g.raw.cg = A.UHDR_CG_BT_2100
         d = Image(f16, w_, h_, align=64, device=device)
         ms = time_kernel(ctx, lambda: u.applyGainMap(base, g, md, A.UHDR_CT_LINEAR, f16, A.FLT_MAX, d), iters=6, warm=2)
-        bpp_in = {A.UHDR_IMG_FMT_24bppYCbCr444: 3, A.UHDR_IMG_FMT_32bppRGBA8888: 4}[base_fmt]
+        bpp_in = {A.UHDR_IMG_FMT_24bppYCbCr444: 3, A.UHDR_IMG_FMT_32bppRGBA8888: 4, A.UHDR_IMG_FMT_16bppYCbCr422: 2}[base_fmt]
         b = (bpp_in + (1 / 16 if map_kind == "A" else 4) + 8) * w_ * h_
         res[name] = {"us": round(ms * 1e3, 2), "GB/s": round(b / (ms / 1e3) / 1e9, 1), "Mpx/s": round(w_ * h_ / (ms / 1e3) / 1e6, 1)}
 
     generic_case("apply_4k_f16_444base_mapC_quad_kernel", A.UHDR_IMG_FMT_24bppYCbCr444, "C")
     generic_case("apply_4k_f16_444base_mapA_quad_kernel", A.UHDR_IMG_FMT_24bppYCbCr444, "A")
     generic_case("apply_4k_f16_rgba8888base_mapC_quad_kernel", A.UHDR_IMG_FMT_32bppRGBA8888, "C")
+    generic_case("apply_4k_f16_422base_mapC_generic_kernel", A.UHDR_IMG_FMT_16bppYCbCr422, "C")  # one thread per pixel
 
     # the drop-in boundary with HOST buffers (H2D + kernel + D2H, pageable memory): PCIe-inclusive rate
     hw, hh = 3840, 2160

@@ -198,32 +198,41 @@ __device__ void sample_map_float(const ApplyParams& p, const float* u8f, uint32_
 }
 
 // ---------------------------------------------------------------------------------------------
-// generic kernel: one thread per pixel, tables read through the cache hierarchy
+// generic kernel: one thread per pixel, every base format / scale; the sRGB, gain and byte -> float tables
+// live in LDS (the IDW weights, whose size depends on the scale, stay in global memory), a workgroup
+// walks tiles of 256 consecutive pixels of one row
 // ---------------------------------------------------------------------------------------------
 template <int OUT>
 __global__ __launch_bounds__(kBlock) void apply_generic_kernel(const ApplyParams p) {
-  const float* srgb = p.tables + ApplyTables::kSrgbOff;
-  const float* gain_tab = p.tables + ApplyTables::kGainOff;
-  const float* u8f = p.tables + ApplyTables::kU8fOff;
+  __shared__ float s_srgb[kSrgbN];
+  __shared__ float s_gain[3 * kGainN];
+  __shared__ float s_u8f[256];
+  for (uint32_t i = threadIdx.x; i < kSrgbN; i += kBlock) s_srgb[i] = p.tables[ApplyTables::kSrgbOff + i];
+  for (uint32_t i = threadIdx.x; i < 3 * kGainN; i += kBlock) s_gain[i] = p.tables[ApplyTables::kGainOff + i];
+  for (uint32_t i = threadIdx.x; i < 256; i += kBlock) s_u8f[i] = p.tables[ApplyTables::kU8fOff + i];
+  __syncthreads();
+  const float* srgb = s_srgb;
+  const float* gain_tab = s_gain;
+  const float* u8f = s_u8f;  // b / 255.0f for every byte b: also the reference's RGBA8888 / RGB888 sample normalisation
   const float* idw = p.tables + ApplyTables::kIdwOff;
   const uint32_t w = p.sdr.w, h = p.sdr.h;
-  const size_t total = (size_t)w * h;
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total;
-       i += (size_t)gridDim.x * kBlock) {
-    const uint32_t y = (uint32_t)(i / w), x = (uint32_t)(i - (size_t)y * w);
+  const uint32_t tiles_x = (w + kBlock - 1) / kBlock, tiles = tiles_x * h;
+  for (uint32_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const uint32_t y = t / tiles_x, x = (t - y * tiles_x) * kBlock + threadIdx.x;
+    if (x >= w) continue;
     // get_pixel_fn (gainmapmath.cpp:354-470)
     Color3 g;
     const int fmt = p.sdr.fmt;
     if (fmt == UHDR_IMG_FMT_32bppRGBA8888) {
       uint32_t v = ((const uint32_t*)p.sdr.p[0])[x + (size_t)y * p.sdr.stride[0]];
-      g.r = (float)(v & 0xff) / 255.0f;
-      g.g = (float)((v >> 8) & 0xff) / 255.0f;
-      g.b = (float)((v >> 16) & 0xff) / 255.0f;
+      g.r = u8f[v & 0xff];
+      g.g = u8f[(v >> 8) & 0xff];
+      g.b = u8f[(v >> 16) & 0xff];
     } else if (fmt == UHDR_IMG_FMT_24bppRGB888) {
       const uint8_t* q = (const uint8_t*)p.sdr.p[0] + (size_t)x * 3 + (size_t)y * p.sdr.stride[0] * 3;
-      g.r = (float)q[0] / 255.0f;
-      g.g = (float)q[1] / 255.0f;
-      g.b = (float)q[2] / 255.0f;
+      g.r = u8f[q[0]];
+      g.g = u8f[q[1]];
+      g.b = u8f[q[2]];
     } else {
       const uint32_t hf = fmt == UHDR_IMG_FMT_24bppYCbCr444 ? 1 : 2;
       const uint32_t vf = fmt == UHDR_IMG_FMT_12bppYCbCr420 ? 2 : 1;
@@ -845,8 +854,8 @@ hipError_t launch_apply_gainmap(const ApplyParams& p, hipStream_t s) {
     }
   }
   if (p.n_frames > 1) return hipErrorInvalidValue;
-  const size_t total = (size_t)p.sdr.w * p.sdr.h;
-  int grid = (int)min((total + kBlock - 1) / kBlock, (size_t)4096);
+  const size_t total = (size_t)((p.sdr.w + kBlock - 1) / kBlock) * p.sdr.h;  // tiles
+  int grid = (int)min(total, (size_t)2048);
   if (grid < 1) grid = 1;
   switch (out) {
     case 0: hipLaunchKernelGGL((apply_generic_kernel<0>), dim3(grid), dim3(kBlock), 0, s, p); break;
