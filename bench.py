@@ -220,10 +220,18 @@ def main():
         },
     }
 
+    # the stage measurements and the CPU baseline run AFTER the timed region; a failure there (e.g. an
+    # out-of-memory on a smaller device) must not cost the headline line
     if rank == 0 and world == 1 and not args.no_extra:
-        out["extra"] = extras(ctx, u, device)
+        try:
+            out["extra"] = extras(ctx, u, device)
+        except Exception as e:  # noqa: BLE001
+            out["extra"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(w, h, args.map, md, args.cpu_seconds)
+        try:
+            out["cpu_baseline"] = cpu_baseline(w, h, args.map, md, args.cpu_seconds)
+        except Exception as e:  # noqa: BLE001
+            out["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port", "sample": f"failed: {type(e).__name__}: {e}"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     ctx.close()
