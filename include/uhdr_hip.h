@@ -16,11 +16,20 @@
  *   uhdr_hip_fdct_quant                 the FDCT+quantize stage libjpeg runs inside
  *                                       JpegEncoderHelper::compressImage  lib/include/ultrahdr/jpegencoderhelper.h:57-58
  *                                                                     (call sites lib/src/jpegencoderhelper.cpp:187-198,297)
+ *   uhdr_hip_copy_raw_image_dev         copy_raw_image                lib/src/gainmapmath.cpp:1492-1613
+ *   uhdr_hip_jpeg_rgb_to_ycc            libjpeg's JCS_RGB -> YCbCr for 3-channel gain maps  lib/src/jpegencoderhelper.cpp:165-167, 212-225
+ *   uhdr_hip_idct_dequant,
+ *   uhdr_hip_jpeg_ycc_to_rgb            the dequantize + IDCT (+ colour conversion) stage libjpeg runs inside
+ *                                       JpegDecoderHelper::decompressImage  lib/src/jpegdecoderhelper.cpp:169-535
+ *   MI355X extensions without a single reference counterpart (each documented at its declaration):
+ *   uhdr_hip_apply_gainmap_batch_dev (n frames, one launch), uhdr_hip_generate_gainmap_pass1_dev / _finalize /
+ *   _pass2_dev (two-pass generation split at its only exchange step, for row stripes across GPUs),
+ *   uhdr_hip_encode_api0_fused_dev (toneMap + generateGainMap + convert_raw_input_to_ycbcr in one pass),
+ *   uhdr_hip_fdct_quant_rgb_dev (colour conversion + FDCT of a 3-channel map in one pass)
  *
  * Same argument meaning and error behaviour as the reference: uhdr_error_info_t is returned by
  * value, UHDR_CODEC_OK == 0, strides are in PIXELS, outputs go into caller-provided images.
- * Calls are synchronous unless the name ends in _async.  Host-memory variants stage through the
- * context's pinned buffers; *_dev variants take DEVICE plane pointers (data already in HBM) and
+ * Host-memory variants are synchronous and stage through the context's device buffers; *_dev variants take DEVICE plane pointers (data already in HBM) and
  * only enqueue work on the context's stream.
  */
 #ifndef UHDR_HIP_H
