@@ -100,9 +100,10 @@ __device__ __forceinline__ typename OutPix<OUT>::type finish_pixel(Color3 lin, f
       // clampPixelFloat, hlgInverseOotfApprox (powf), OETF LUT, colorToRgba1010102: one threshold lookup each
       return pack_codes_1010102(oetf_code<OUT>(clamp01(h.r), p.oetf_thr), oetf_code<OUT>(clamp01(h.g), p.oetf_thr),
                                 oetf_code<OUT>(clamp01(h.b), p.oetf_thr));
-    } else {  // PQ has no per-pixel transcendental: the reference's own 65536-node table (L2 resident) is cheapest
-      return pack_rgba1010102(p.oetf_thr[lut_index_f32<kOetfN>(clamp01(h.r))], p.oetf_thr[lut_index_f32<kOetfN>(clamp01(h.g))],
-                              p.oetf_thr[lut_index_f32<kOetfN>(clamp01(h.b))]);
+    } else {  // PQ has no per-pixel transcendental: gather the 10-bit code of the reference's own 65536-node table
+      const uint16_t* lut = (const uint16_t*)p.oetf_thr;  // pqOetfLUT + colorToRgba1010102 per node (host_tables.cpp)
+      return pack_codes_1010102(lut[lut_index_f32<kOetfN>(clamp01(h.r))], lut[lut_index_f32<kOetfN>(clamp01(h.g))],
+                                lut[lut_index_f32<kOetfN>(clamp01(h.b))]);
     }
   }
 }
@@ -714,11 +715,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
           o.y = pack_codes_1010102(oetf_code<OUT>(clamp01(hr.y), s_thr), oetf_code<OUT>(clamp01(hg.y), s_thr),
                                    oetf_code<OUT>(clamp01(hb.y), s_thr));
         } else {
-          const float* lut = p.oetf_thr;  // pqOetfLUT, 65536 nodes
-          o.x = pack_rgba1010102(lut[lut_index_f32<kOetfN>(clamp01(hr.x))], lut[lut_index_f32<kOetfN>(clamp01(hg.x))],
-                                 lut[lut_index_f32<kOetfN>(clamp01(hb.x))]);
-          o.y = pack_rgba1010102(lut[lut_index_f32<kOetfN>(clamp01(hr.y))], lut[lut_index_f32<kOetfN>(clamp01(hg.y))],
-                                 lut[lut_index_f32<kOetfN>(clamp01(hb.y))]);
+          const uint16_t* lut = (const uint16_t*)p.oetf_thr;  // 10-bit codes of pqOetfLUT's 65536 nodes (128 KiB, L2 resident)
+          o.x = pack_codes_1010102(lut[lut_index_f32<kOetfN>(clamp01(hr.x))], lut[lut_index_f32<kOetfN>(clamp01(hg.x))],
+                                   lut[lut_index_f32<kOetfN>(clamp01(hb.x))]);
+          o.y = pack_codes_1010102(lut[lut_index_f32<kOetfN>(clamp01(hr.y))], lut[lut_index_f32<kOetfN>(clamp01(hg.y))],
+                                   lut[lut_index_f32<kOetfN>(clamp01(hb.y))]);
         }
         stream_store<u2v>(dpx, (u2v){o.x, o.y});
       }

@@ -102,6 +102,25 @@ const std::vector<float>& hlg_inv_oetf_ootf_lut() {
 UHDR_STATIC_LUT(hlg_oetf_lut, kOetfN, hlg_oetf)
 UHDR_STATIC_LUT(pq_oetf_lut, kOetfN, pq_oetf)
 
+// pqOetfLUT followed by colorToRgba1010102's quantisation (gainmapmath.cpp:320-326, 1279-1284), per table
+// node: the PQ decode tail gathers the 10-bit code directly (65536 x uint16 = 128 KiB, two codes per float
+// of the returned vector).  code = uint32(CLIP3(e * 1023.0f + 0.5f, 0, 1023)), the same float operations.
+const std::vector<float>& pq_oetf_code_lut() {
+  static const std::vector<float> t = [] {
+    const std::vector<float>& lut = pq_oetf_lut();
+    std::vector<uint16_t> codes(lut.size());
+    for (size_t i = 0; i < lut.size(); i++) {
+      float v = lut[i] * 1023.0f + 0.5f;
+      v = v < 0.0f ? 0.0f : (v > 1023.0f ? 1023.0f : v);
+      codes[i] = (uint16_t)(uint32_t)v;
+    }
+    std::vector<float> packed(lut.size() / 2);
+    memcpy(packed.data(), codes.data(), codes.size() * sizeof(uint16_t));
+    return packed;
+  }();
+  return t;
+}
+
 // ---- output-code threshold tables ----------------------------------------------------------------
 // applyGainMap's HLG / PQ tail maps a clamped float v in [0,1] to a 10-bit code:
 //   HLG: v -> powf(v, 1/1.2f) -> hlgOetfLUT (65536 nodes) -> uint(CLIP(e*1023 + 0.5f))

@@ -17,6 +17,7 @@ const std::vector<float>& pq_inv_oetf_lut();    // 4096  (gainmapmath.cpp:339-34
 const std::vector<float>& hlg_inv_oetf_ootf_lut();  // 4096: hlgInvOetfLUT then hlgOotfApprox per node
 const std::vector<float>& hlg_oetf_lut();       // 65536 (gainmapmath.cpp:248-254)
 const std::vector<float>& pq_oetf_lut();        // 65536 (gainmapmath.cpp:320-326)
+const std::vector<float>& pq_oetf_code_lut();   // 65536 uint16 codes (pqOetfLUT then colorToRgba1010102), packed two per float
 
 // 10-bit output-code thresholds of the HLG / PQ tail (kOetfThrN floats; see host_tables.cpp)
 const std::vector<float>& oetf_code_thresholds(int ct);

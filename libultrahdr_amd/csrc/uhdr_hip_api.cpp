@@ -508,7 +508,7 @@ static uhdr_error_info_t build_apply_params(uhdr_hip_ctx* c, const uhdr_raw_imag
     UHDR_TRY(upload_lut(&c->d_hlg_oetf, host::oetf_code_thresholds(UHDR_CT_HLG), c->stream));
     p.oetf_thr = c->d_hlg_oetf;
   } else if (out_ct == UHDR_CT_PQ) {
-    UHDR_TRY(upload_lut(&c->d_pq_oetf, host::pq_oetf_lut(), c->stream));
+    UHDR_TRY(upload_lut(&c->d_pq_oetf, host::pq_oetf_code_lut(), c->stream));
     p.oetf_thr = c->d_pq_oetf;
   }
   p.sdr = view_of(sdr);

@@ -63,7 +63,7 @@ struct ApplyParams {
   ImageView gm;       // whole gain map
   ImageViewMut dst;   // destination stripe
   const float* tables;      // ApplyTables block
-  const float* oetf_thr;    // HLG: output-code threshold block (kOetfTabFloats); PQ: pqOetfLUT (65536); linear: null
+  const float* oetf_thr;    // HLG: output-code threshold block (kOetfTabFloats); PQ: 65536 uint16 output codes of pqOetfLUT's nodes; linear: null
   uint32_t y0;              // global row of stripe row 0
   uint32_t tiles_per_wave;  // quad kernel: loop trip count (even), set by the launcher
   uint32_t row_groups;      // quad kernel: quad-row step of a wave, set by the launcher
