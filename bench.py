@@ -306,7 +306,7 @@ def extras(ctx, u, device):
     del sets5
     torch.cuda.empty_cache()
 
-    # 4:4:4 (what an API-0 stream decodes to) and RGBA8888 bases: the quad kernel's BASE 1 / 2 variants
+    # 4:4:4 (what an API-0 stream decodes to) and RGBA8888 bases: the quad kernel's BASE 1 / 2 / 3 variants
     def generic_case(name, base_fmt, map_kind):
         w_, h_ = 3840, 2160
         base = Image(base_fmt, w_, h_, A.UHDR_CG_BT_709, A.UHDR_CT_SRGB, A.UHDR_CR_FULL_RANGE, align=64, device=device)
@@ -323,7 +323,7 @@ def extras(ctx, u, device):
     generic_case("apply_4k_f16_444base_mapC_quad_kernel", A.UHDR_IMG_FMT_24bppYCbCr444, "C")
     generic_case("apply_4k_f16_444base_mapA_quad_kernel", A.UHDR_IMG_FMT_24bppYCbCr444, "A")
     generic_case("apply_4k_f16_rgba8888base_mapC_quad_kernel", A.UHDR_IMG_FMT_32bppRGBA8888, "C")
-    generic_case("apply_4k_f16_422base_mapC_generic_kernel", A.UHDR_IMG_FMT_16bppYCbCr422, "C")  # one thread per pixel
+    generic_case("apply_4k_f16_422base_mapC_quad_kernel", A.UHDR_IMG_FMT_16bppYCbCr422, "C")
 
     # the drop-in boundary with HOST buffers (H2D + kernel + D2H, pageable memory): PCIe-inclusive rate
     hw, hh = 3840, 2160
@@ -451,6 +451,37 @@ def extras(ctx, u, device):
     ms = time_kernel(ctx, decode_chain, iters=5, warm=2)
     res["decode_chain_4k_idct_plus_apply_mapA"] = {"us": round(ms * 1e3, 1), "Mpx/s": round(w * h / (ms / 1e3) / 1e6, 1),
                                                     "stages": "idct_dequant(Y, Cb, Cr, Y400 map) + applyGainMap -> RGBA_F16; Huffman decode not included"}
+    # (3b) the same with a full-resolution 3-channel map (what the default encoder settings produce): the map's
+    #      three coefficient planes -> RGBA8888 either in one pass or as three IDCTs + ycc_rgb_convert
+    rgba = A.UHDR_IMG_FMT_32bppRGBA8888
+    cf3 = [torch.zeros((h // 8, w // 8, 64), dtype=torch.int16, device=device) for _ in range(3)]
+    for t in cf3:
+        t[..., 0] = 37
+    gm3 = Image(rgba, w, h, A.UHDR_CG_BT_2100, align=64, device=device)
+    ycc3 = Image(A.UHDR_IMG_FMT_24bppYCbCr444, w, h, align=64, device=device)
+    ms_f = time_kernel(ctx, lambda: u.idct_dequant_rgb(cf3, qy, qc, w, h, rgba, 0, dst=gm3), iters=5, warm=2)
+    res["idct_dequant_rgb_4k_fused"] = {"us": round(ms_f * 1e3, 1), "Mpx/s": round(w * h / (ms_f / 1e3) / 1e6, 1),
+                                        "GB/s_10B_per_px": round(10.0 * w * h / (ms_f / 1e3) / 1e9, 1)}
+
+    def map_four_step():
+        for c in range(3):
+            u.idct_dequant(cf3[c], qy if c == 0 else qc, plane=ycc3.plane_tensor(c), stride=ycc3.layout[c][1])
+        A.check(u.lib.uhdr_hip_jpeg_ycc_to_rgb_dev(ctx.handle, C.byref(ycc3.raw), 0, C.byref(gm3.raw)))
+
+    ms_u = time_kernel(ctx, map_four_step, iters=5, warm=2)
+    res["idct_dequant_rgb_4k_four_step"] = {"us": round(ms_u * 1e3, 1), "Mpx/s": round(w * h / (ms_u / 1e3) / 1e6, 1),
+                                            "GB/s_16B_per_px": round(16.0 * w * h / (ms_u / 1e3) / 1e9, 1)}
+
+    def decode_chain_c():
+        for c in range(3):
+            rows, stride, wv = dsdr.layout[c]
+            u.idct_dequant(cf[c], qy if c == 0 else qc, plane=dsdr.plane_tensor(c), stride=stride)
+        u.idct_dequant_rgb(cf3, qy, qc, w, h, rgba, 0, dst=gm3)
+        u.applyGainMap(dsdr, gm3, md, A.UHDR_CT_LINEAR, f16, A.FLT_MAX, dst4)
+
+    ms = time_kernel(ctx, decode_chain_c, iters=5, warm=2)
+    res["decode_chain_4k_idct_plus_apply_mapC"] = {"us": round(ms * 1e3, 1), "Mpx/s": round(w * h / (ms / 1e3) / 1e6, 1),
+                                                    "stages": "idct_dequant(Y, Cb, Cr) + idct_dequant_rgb(3-ch map) + applyGainMap -> RGBA_F16; Huffman decode not included"}
     return res
 
 

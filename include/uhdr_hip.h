@@ -25,7 +25,8 @@
  *   uhdr_hip_apply_gainmap_batch_dev (n frames, one launch), uhdr_hip_generate_gainmap_pass1_dev / _finalize /
  *   _pass2_dev (two-pass generation split at its only exchange step, for row stripes across GPUs),
  *   uhdr_hip_encode_api0_fused_dev (toneMap + generateGainMap + convert_raw_input_to_ycbcr in one pass),
- *   uhdr_hip_fdct_quant_rgb_dev (colour conversion + FDCT of a 3-channel map in one pass)
+ *   uhdr_hip_fdct_quant_rgb_dev (colour conversion + FDCT of a 3-channel map in one pass),
+ *   uhdr_hip_idct_dequant_rgb_dev (its decode-side mirror: dequant + IDCT + colour conversion in one pass)
  *
  * Same argument meaning and error behaviour as the reference: uhdr_error_info_t is returned by
  * value, UHDR_CODEC_OK == 0, strides are in PIXELS, outputs go into caller-provided images.
@@ -316,6 +317,20 @@ uhdr_error_info_t uhdr_hip_jpeg_ycc_to_rgb(uhdr_hip_ctx_t* ctx, const uhdr_raw_i
                                            int libjpeg_variant, uhdr_raw_image_t* rgb);
 uhdr_error_info_t uhdr_hip_jpeg_ycc_to_rgb_dev(uhdr_hip_ctx_t* ctx, const uhdr_raw_image_t* ycc,
                                                int libjpeg_variant, uhdr_raw_image_t* rgb);
+
+/* MI355X extension, the decode-side mirror of uhdr_hip_fdct_quant_rgb_dev: three uhdr_hip_idct_dequant calls (Y with
+ * the luma table, Cb and Cr with the chroma table) followed by uhdr_hip_jpeg_ycc_to_rgb -- what libjpeg does when
+ * JpegDecoderHelper asks for RGB / RGBA scanlines of a 3-channel (4:4:4) gain-map JPEG (jpegdecoderhelper.cpp:400-470)
+ * -- in one pass: 6 B/px in, 3 (4) B/px out instead of 16 B/px over four launches.  Device pointers; three coefficient
+ * arrays of blocks_w * blocks_h JBLOCKs, 16-byte aligned; rgb is a device image (RGB888 or RGBA8888, alpha 255) with
+ * ceil(w/8) == blocks_w and ceil(h/8) == blocks_h: only the w x h valid pixels are stored.  Bit-identical to the
+ * four-step route. */
+uhdr_error_info_t uhdr_hip_idct_dequant_rgb_dev(uhdr_hip_ctx_t* ctx, const int16_t* coef_y,
+                                                const int16_t* coef_cb, const int16_t* coef_cr,
+                                                int blocks_w, int blocks_h,
+                                                const uint16_t qtable_luma[64],
+                                                const uint16_t qtable_chroma[64], int libjpeg_variant,
+                                                uhdr_raw_image_t* rgb);
 
 /* ---- timing hook for bench.py ------------------------------------------------------------------
  * HIP events recorded on the context's stream around every kernel launch of the named family

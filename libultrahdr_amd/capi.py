@@ -160,6 +160,8 @@ _SIGS = {
     "uhdr_hip_jpeg_rgb_to_ycc_dev": (ErrorInfo, [C.c_void_p, _P(RawImage), _P(RawImage)]),
     "uhdr_hip_jpeg_ycc_to_rgb": (ErrorInfo, [C.c_void_p, _P(RawImage), C.c_int, _P(RawImage)]),
     "uhdr_hip_jpeg_ycc_to_rgb_dev": (ErrorInfo, [C.c_void_p, _P(RawImage), C.c_int, _P(RawImage)]),
+    "uhdr_hip_idct_dequant_rgb_dev": (ErrorInfo, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, _P(C.c_uint16), _P(C.c_uint16),
+                                                  C.c_int, _P(RawImage)]),
     "uhdr_hip_profile_enable": (None, [C.c_void_p, C.c_int]),
     "uhdr_hip_profile_read": (C.c_int, [C.c_void_p, C.c_char_p, _P(C.c_double), C.c_int]),
 }

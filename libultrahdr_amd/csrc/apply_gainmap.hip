@@ -2,8 +2,8 @@
 // Reference loop: /root/reference/lib/src/jpegr.cpp:1714-1812 (UltraHdr::applyGainMap).
 //
 // Two kernels:
-//   apply_quad_kernel   -- the hot one.  YCbCr 4:2:0 base (what a JPEG base image decodes to), or 4:4:4 /
-//                          RGBA8888 (API-0 streams); one work item of a lane = one 2x2 luma quad, a lane
+//   apply_quad_kernel   -- the hot one.  YCbCr 4:2:0 base (what a JPEG base image decodes to), or 4:2:2 / 4:4:4 /
+//                          RGBA8888 (camera / API-0 streams); one work item of a lane = one 2x2 luma quad, a lane
 //                          owns two quads 128 pixels apart, a wave a 256 x 2 pixel strip, so every global
 //                          store instruction of the wave writes one contiguous 1 KiB (F16) / 512 B
 //                          (1010102) run and the two runs of a row follow each other.  All per-call
@@ -11,7 +11,7 @@
 //                          output-code thresholds) are staged in LDS once per workgroup; exactly the
 //                          resident workgroups are launched and each wave walks its column strip.
 //   apply_generic_kernel-- one thread per pixel, every other format / scale combination the reference
-//                          accepts (4:2:2, RGB888, odd sizes, odd or non-integer scale, gamma != 1 at scale > 1).
+//                          accepts (RGB888 base, odd sizes, odd or non-integer scale, gamma != 1 at scale > 1).
 // HBM-bound by design: 1.5 B (4:2:0) + map + 8 B (F16) per pixel, no intermediate buffers.
 #include <cstdlib>
 #include <type_traits>
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(kBlock) void apply_generic_kernel(const ApplyParams
 }
 
 // ---------------------------------------------------------------------------------------------
-// quad kernel (4:2:0 / 4:4:4 / RGBA8888 base, even geometry, gamma == 1 or scale == 1).
+// quad kernel (4:2:0 / 4:2:2 / 4:4:4 / RGBA8888 base, even geometry, gamma == 1 or scale == 1).
 //   BASE  : 0 YCbCr 4:2:0 (the quad shares one chroma sample), 1 YCbCr 4:4:4, 2 packed RGBA8888.
 //   MAPFMT: 0 Y400, 1 RGB888, 2 RGBA8888.
 //   SMODE : 0 scale == 1 (byte -> factor table, no interpolation),
@@ -366,8 +366,8 @@ template <int MAPFMT, int SMODE, int BASE>
 struct QuadRaw {
   static constexpr int NCH = (MAPFMT == 0) ? 1 : 3;
   uint32_t y0, y1;  // BASE 0/1: two luma bytes of row 0 / row 1; BASE 2: unused
-  uint32_t u, v;    // BASE 0: the quad's chroma bytes; BASE 1: row-0 chroma pairs (two bytes each)
-  uint32_t c[(BASE == 0) ? 1 : 4];  // BASE 1: {.., .., u row 1, v row 1}; BASE 2: the four RGBA8888 pixels {r0p0, r0p1, r1p0, r1p1}
+  uint32_t u, v;    // BASE 0: the quad's chroma bytes; BASE 1: row-0 chroma pairs (two bytes each); BASE 3: row-0 chroma bytes
+  uint32_t c[(BASE == 0) ? 1 : 4];  // BASE 1 / 3: {.., .., u row 1, v row 1}; BASE 2: the four RGBA8888 pixels {r0p0, r0p1, r1p0, r1p1}
   uint32_t m[(SMODE == 0) ? 4 : 4 * NCH];  // SMODE 0: map bytes {row0 lo, row0 hi, row1 lo, row1 hi}; SMODE 1: tap bytes [tap][ch]
   uint32_t wrow;    // SMODE 1: row part of the weight-table index (wave-uniform)
   uint32_t y;       // first row of the quad (wave-uniform)
@@ -503,6 +503,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
       if constexpr (BASE == 0) {
         r.u = up[qy_ * su + xq];
         r.v = vp[qy_ * sv + xq];
+      } else if constexpr (BASE == 3) {  // 4:2:2: one chroma sample per row of the quad
+        r.u = up[y * su + xq];
+        r.v = vp[y * sv + xq];
+        r.c[2] = up[y * su + su + xq];
+        r.c[3] = vp[y * sv + sv + xq];
+        r.c[0] = r.c[1] = 0;
       } else {  // 4:4:4: a chroma pair per row
         r.u = *(const uint16_t*)(up + (y * su + xc));
         r.v = *(const uint16_t*)(vp + (y * sv + xc));
@@ -594,6 +600,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
       } else {
         const uint32_t yb = r == 0 ? q.y0 : q.y1;
         const f2 yf = (f2){(float)(yb & 0xff), (float)(yb >> 8)} * k255;
+        if constexpr (BASE == 3) {  // 4:2:2: this row's chroma sample, shared by its two pixels
+          const float uf = (float)((int)(r == 0 ? q.u : q.c[2]) - 128) * k255, vf = (float)((int)(r == 0 ? q.v : q.c[3]) - 128) * k255;
+          crv = splat(yk.cr * vf); gcbu = splat(yk.gcb * uf); gcrv = splat(yk.gcr * vf); cbu = splat(yk.cb * uf);
+        }
         if constexpr (BASE == 1) {  // 4:4:4: this row's own chroma pair
           const uint32_t ub = r == 0 ? q.u : q.c[2], vb = r == 0 ? q.v : q.c[3];
           const f2 uf = (f2){(float)((int)(ub & 0xff) - 128), (float)((int)(ub >> 8) - 128)} * k255;
@@ -794,6 +804,7 @@ hipError_t launch_quad_b(const ApplyParams& p, int base, int mapfmt, int smode, 
   switch (base) {
     case 0: return launch_quad_m<OUT, 0>(p, mapfmt, smode, s);
     case 1: return launch_quad_m<OUT, 1>(p, mapfmt, smode, s);
+    case 3: return launch_quad_m<OUT, 3>(p, mapfmt, smode, s);
     default: return launch_quad_m<OUT, 2>(p, mapfmt, smode, s);
   }
 }
@@ -807,9 +818,9 @@ int apply_quad_mode(const ApplyParams& p) {
   const int out = p.out_ct == UHDR_CT_LINEAR ? 0 : (p.out_ct == UHDR_CT_HLG ? 1 : 2);
   const int mapfmt = p.gm.fmt == UHDR_IMG_FMT_8bppYCbCr400 ? 0 : (p.gm.fmt == UHDR_IMG_FMT_24bppRGB888 ? 1 : 2);
   const size_t out_bytes = out == 0 ? 8 : 4;
-  // base layouts the quad kernel reads: 4:2:0, 4:4:4 (chroma pairs as 16-bit loads), packed RGBA8888 (8-byte loads)
+  // base layouts the quad kernel reads: 4:2:0, 4:2:2, 4:4:4 (chroma pairs as 16-bit loads), packed RGBA8888 (8-byte loads)
   bool base_ok = false;
-  if (p.sdr.fmt == UHDR_IMG_FMT_12bppYCbCr420) {
+  if (p.sdr.fmt == UHDR_IMG_FMT_12bppYCbCr420 || p.sdr.fmt == UHDR_IMG_FMT_16bppYCbCr422) {
     base_ok = (p.sdr.stride[0] % 2 == 0) && aligned_to(p.sdr.p[0], 2);
   } else if (p.sdr.fmt == UHDR_IMG_FMT_24bppYCbCr444) {
     base_ok = (p.sdr.stride[0] % 2 == 0) && (p.sdr.stride[1] % 2 == 0) && (p.sdr.stride[2] % 2 == 0) &&
@@ -847,7 +858,8 @@ hipError_t launch_apply_gainmap(const ApplyParams& p, hipStream_t s) {
   const int mapfmt = p.gm.fmt == UHDR_IMG_FMT_8bppYCbCr400 ? 0 : (p.gm.fmt == UHDR_IMG_FMT_24bppRGB888 ? 1 : 2);
   const int smode = apply_quad_mode(p);
   if (smode >= 0) {
-    const int base = p.sdr.fmt == UHDR_IMG_FMT_12bppYCbCr420 ? 0 : (p.sdr.fmt == UHDR_IMG_FMT_24bppYCbCr444 ? 1 : 2);
+    const int base = p.sdr.fmt == UHDR_IMG_FMT_12bppYCbCr420 ? 0 : (p.sdr.fmt == UHDR_IMG_FMT_24bppYCbCr444 ? 1 :
+                     (p.sdr.fmt == UHDR_IMG_FMT_16bppYCbCr422 ? 3 : 2));
     switch (out) {
       case 0: return launch_quad_b<0>(p, base, mapfmt, smode, s);
       case 1: return launch_quad_b<1>(p, base, mapfmt, smode, s);

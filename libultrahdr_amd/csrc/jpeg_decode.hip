@@ -87,6 +87,52 @@ struct DequantArgs {
   uint16_t q[64];  // natural order
 };
 
+// Lane (row rr, block rb) fetches and dequantizes its coefficient row of block (by, bx); `big` collects the
+// magnitude bits that rule out the 24-bit multiply path.
+__device__ __forceinline__ void load_dequant_row(const int16_t* __restrict__ coef, int bw, int by, int bx, int rr,
+                                                 const int q[8], int v[8], int& big) {
+  if (bx < bw) {
+    const uint4 raw = *(const uint4*)(coef + ((size_t)by * bw + bx) * 64 + rr * 8);
+    const uint32_t w4[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      v[2 * c] = __mul24((int)(int16_t)(w4[c] & 0xffff), q[2 * c]);  // |coef| < 2^15, q < 2^16: exact
+      v[2 * c + 1] = __mul24((int)(int16_t)(w4[c] >> 16), q[2 * c + 1]);
+    }
+#pragma unroll
+    for (int c = 0; c < 8; c++) big |= (v[c] < 0 ? -v[c] : v[c]) >> 13;
+  } else {
+#pragma unroll
+    for (int c = 0; c < 8; c++) v[c] = 0;
+  }
+}
+
+// One wavefront, eight blocks: dequantized rows in (lane role (row rr, block rb)) -> that lane's eight
+// range-limited output samples.  ws is the wave's private 8 x 8 x 9-word workspace; on return it may be reused.
+__device__ __forceinline__ void idct_wave(int* ws, const int v[8], int big, int rr, int rb, uint32_t s[8]) {
+  const int cb = rr, cc = rb;  // column-pass role: (block, column)
+  const bool fast = __builtin_amdgcn_ballot_w64(big != 0) == 0;  // wave-uniform
+#pragma unroll
+  for (int c = 0; c < 8; c++) ws[rb * 72 + rr * 9 + c] = v[c];
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed
+  int in[8], out[8];
+#pragma unroll
+  for (int r = 0; r < 8; r++) in[r] = ws[cb * 72 + r * 9 + cc];
+  if (fast) idct_1d<0, true>(in, out); else idct_1d<0, false>(in, out);
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < 8; r++) ws[cb * 72 + r * 9 + cc] = out[r];
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+  for (int c = 0; c < 8; c++) in[c] = ws[rb * 72 + rr * 9 + c];
+  if (fast) idct_1d<1, true>(in, out); else idct_1d<1, false>(in, out);
+#pragma unroll
+  for (int c = 0; c < 8; c++) s[c] = range_limit(out[c]);
+  __builtin_amdgcn_wave_barrier();
+}
+
 __global__ __launch_bounds__(kBlock) void idct_dequant_kernel(const int16_t* __restrict__ coef, int bw, int bh,
                                                               const DequantArgs qa, uint8_t* __restrict__ plane,
                                                               size_t stride) {
@@ -96,7 +142,6 @@ __global__ __launch_bounds__(kBlock) void idct_dequant_kernel(const int16_t* __r
   const int groups_x = (bw + 7) >> 3, total = groups_x * bh;
   const int gwave = blockIdx.x * (kBlock / 64) + wv, nwaves = gridDim.x * (kBlock / 64);
   const int rr = lane >> 3, rb = lane & 7;  // load / row-pass / store role: (row, block)
-  const int cb = lane >> 3, cc = lane & 7;  // column-pass role: (block, column)
   int q[8];
 #pragma unroll
   for (int c = 0; c < 8; c++) q[c] = qa.q[rr * 8 + c];
@@ -107,44 +152,12 @@ __global__ __launch_bounds__(kBlock) void idct_dequant_kernel(const int16_t* __r
     const int bx = gx * 8 + rb;
     int v[8];
     int big = 0;
+    load_dequant_row(coef, bw, by, bx, rr, q, v, big);
+    uint32_t s[8];
+    idct_wave(ws, v, big, rr, rb, s);
     if (bx < bw) {
-      const uint4 raw = *(const uint4*)(coef + ((size_t)by * bw + bx) * 64 + rr * 8);
-      const uint32_t w4[4] = {raw.x, raw.y, raw.z, raw.w};
-#pragma unroll
-      for (int c = 0; c < 4; c++) {
-        v[2 * c] = __mul24((int)(int16_t)(w4[c] & 0xffff), q[2 * c]);  // |coef| < 2^15, q < 2^16: exact
-        v[2 * c + 1] = __mul24((int)(int16_t)(w4[c] >> 16), q[2 * c + 1]);
-      }
-#pragma unroll
-      for (int c = 0; c < 8; c++) big |= (v[c] < 0 ? -v[c] : v[c]) >> 13;
-    } else {
-#pragma unroll
-      for (int c = 0; c < 8; c++) v[c] = 0;
-    }
-    const bool fast = __builtin_amdgcn_ballot_w64(big != 0) == 0;  // wave-uniform
-#pragma unroll
-    for (int c = 0; c < 8; c++) ws[rb * 72 + rr * 9 + c] = v[c];
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed
-    int in[8], out[8];
-#pragma unroll
-    for (int r = 0; r < 8; r++) in[r] = ws[cb * 72 + r * 9 + cc];
-    if (fast) idct_1d<0, true>(in, out); else idct_1d<0, false>(in, out);
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int r = 0; r < 8; r++) ws[cb * 72 + r * 9 + cc] = out[r];
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-#pragma unroll
-    for (int c = 0; c < 8; c++) in[c] = ws[rb * 72 + rr * 9 + c];
-    if (fast) idct_1d<1, true>(in, out); else idct_1d<1, false>(in, out);
-    if (bx < bw) {
-      uint32_t lo = 0, hi = 0;
-#pragma unroll
-      for (int c = 0; c < 4; c++) {
-        lo |= range_limit(out[c]) << (8 * c);
-        hi |= range_limit(out[4 + c]) << (8 * c);
-      }
+      const uint32_t lo = s[0] | (s[1] << 8) | (s[2] << 16) | (s[3] << 24);
+      const uint32_t hi = s[4] | (s[5] << 8) | (s[6] << 16) | (s[7] << 24);
       uint8_t* dst = plane + (size_t)(by * 8 + rr) * stride + (size_t)bx * 8;
       if (vec_store) {
         *(uint2*)dst = make_uint2(lo, hi);
@@ -153,7 +166,6 @@ __global__ __launch_bounds__(kBlock) void idct_dequant_kernel(const int16_t* __r
         for (int c = 0; c < 4; c++) { dst[c] = (uint8_t)(lo >> (8 * c)); dst[4 + c] = (uint8_t)(hi >> (8 * c)); }
       }
     }
-    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -269,6 +281,86 @@ __global__ __launch_bounds__(kBlock) void jpeg_ycc_to_rgb_kernel(const JpegColor
   }
 }
 
+// ---- 3-channel gain map: dequant + IDCT of Y, Cb, Cr and ycc_rgb_convert in one pass ------------------
+// The decode-side mirror of fdct_quant_rgb_kernel: a 3-channel map is a 4:4:4 JPEG (the encoder hands it to
+// libjpeg as JCS_RGB, jpegencoderhelper.cpp:165-167), and the decoder asks libjpeg for RGB / RGBA scanlines
+// (jpegdecoderhelper.cpp:400-470).  Unfused that is three IDCT launches and a colour-conversion launch,
+// 6 + 3 + 3 + 4 = 16 B/px of traffic; here a wave runs the three inverse transforms of its eight blocks back to
+// back through the same LDS workspace, keeps the 3 x 8 samples of its row in registers, converts and stores
+// 8 pixels (32 or 24 contiguous bytes per lane, 256 / 192 per eight lanes): 6 B/px in, 4 (3) B/px out.
+struct IdctRgbArgs {
+  const int16_t* coef[3];
+  uint8_t* rgb;
+  size_t pitch;       // bytes
+  uint32_t w, h;      // pixels actually stored (<= blocks * 8)
+  int bw, bh;
+  int k_cr_g, k_cb_g;
+  uint16_t q[2][64];  // luma, chroma (natural order)
+};
+
+template <int BPP>
+__global__ __launch_bounds__(kBlock) void idct_dequant_rgb_kernel(const IdctRgbArgs a) {
+  __shared__ int s_ws[kBlock / 64][8 * 8 * 9];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int* ws = s_ws[wv];
+  const int bw = a.bw;
+  const int groups_x = (bw + 7) >> 3, total = groups_x * a.bh;
+  const int gwave = blockIdx.x * (kBlock / 64) + wv, nwaves = gridDim.x * (kBlock / 64);
+  const int rr = lane >> 3, rb = lane & 7;
+  int ql[8], qc[8];
+#pragma unroll
+  for (int c = 0; c < 8; c++) { ql[c] = a.q[0][rr * 8 + c]; qc[c] = a.q[1][rr * 8 + c]; }
+  const bool vec_ok = ((a.pitch | (uintptr_t)a.rgb) & (BPP == 4 ? 15 : 7)) == 0;
+
+  for (int t = gwave; t < total; t += nwaves) {
+    const int by = t / groups_x, gx = t - by * groups_x;
+    const int bx = gx * 8 + rb;
+    // all three coefficient rows are requested before the first transform starts
+    int vy[8], vb[8], vr[8];
+    int big_y = 0, big_b = 0, big_r = 0;
+    load_dequant_row(a.coef[0], bw, by, bx, rr, ql, vy, big_y);
+    load_dequant_row(a.coef[1], bw, by, bx, rr, qc, vb, big_b);
+    load_dequant_row(a.coef[2], bw, by, bx, rr, qc, vr, big_r);
+    uint32_t sy[8], sb[8], sr[8];
+    idct_wave(ws, vy, big_y, rr, rb, sy);
+    idct_wave(ws, vb, big_b, rr, rb, sb);
+    idct_wave(ws, vr, big_r, rr, rb, sr);
+    const uint32_t y = (uint32_t)(by * 8 + rr), x0 = (uint32_t)bx * 8;
+    if (bx < bw && y < a.h && x0 < a.w) {
+      uint32_t px[8];
+#pragma unroll
+      for (int c = 0; c < 8; c++) px[c] = ycc_to_rgb_px(sy[c], sb[c], sr[c], a.k_cr_g, a.k_cb_g);
+      uint8_t* dst = a.rgb + (size_t)y * a.pitch + (size_t)x0 * BPP;
+      if (vec_ok && x0 + 8 <= a.w) {
+        if constexpr (BPP == 4) {
+          *(uint4*)dst = make_uint4(px[0], px[1], px[2], px[3]);
+          *(uint4*)(dst + 16) = make_uint4(px[4], px[5], px[6], px[7]);
+        } else {
+          uint32_t d[6];
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            const uint32_t* q4 = px + 4 * h;
+            d[3 * h + 0] = (q4[0] & 0xffffff) | (q4[1] << 24);
+            d[3 * h + 1] = ((q4[1] >> 8) & 0xffff) | (q4[2] << 16);
+            d[3 * h + 2] = ((q4[2] >> 16) & 0xff) | (q4[3] << 8);
+          }
+          *(uint2*)dst = make_uint2(d[0], d[1]);
+          *(uint2*)(dst + 8) = make_uint2(d[2], d[3]);
+          *(uint2*)(dst + 16) = make_uint2(d[4], d[5]);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+          if (x0 + c < a.w) {
+            dst[c * BPP] = (uint8_t)px[c]; dst[c * BPP + 1] = (uint8_t)(px[c] >> 8); dst[c * BPP + 2] = (uint8_t)(px[c] >> 16);
+            if constexpr (BPP == 4) dst[c * BPP + 3] = 255;
+          }
+        }
+      }
+    }
+  }
+}
+
 int resident_grid(uint32_t tiles, int per_cu) {
   static const int cus = [] {
     int dev = 0, n = 0;
@@ -291,6 +383,25 @@ hipError_t launch_idct_dequant(const int16_t* coef, int bw, int bh, const uint16
   const int total = ((bw + 7) / 8) * bh;
   const int grid = resident_grid((uint32_t)(total + 3) / 4, 8);
   hipLaunchKernelGGL(idct_dequant_kernel, dim3(grid), dim3(kBlock), 0, s, coef, bw, bh, qa, plane, stride);
+  return hipGetLastError();
+}
+
+hipError_t launch_idct_dequant_rgb(const int16_t* coef_y, const int16_t* coef_cb, const int16_t* coef_cr, int bw, int bh,
+                                   const uint16_t* qt_luma_host, const uint16_t* qt_chroma_host, int variant,
+                                   const ImageViewMut& rgb, hipStream_t s) {
+  IdctRgbArgs a = {};
+  a.coef[0] = coef_y; a.coef[1] = coef_cb; a.coef[2] = coef_cr;
+  a.rgb = (uint8_t*)rgb.p[0];
+  const int bpp = rgb.fmt == UHDR_IMG_FMT_32bppRGBA8888 ? 4 : 3;
+  a.pitch = (size_t)rgb.stride[0] * bpp;
+  a.w = rgb.w; a.h = rgb.h; a.bw = bw; a.bh = bh;
+  a.k_cr_g = variant ? FIX16(0.714136286) : FIX16(0.71414);
+  a.k_cb_g = variant ? FIX16(0.344136286) : FIX16(0.34414);
+  for (int i = 0; i < 64; i++) { a.q[0][i] = qt_luma_host[i]; a.q[1][i] = qt_chroma_host[i]; }
+  const int total = ((bw + 7) / 8) * bh;
+  const int grid = resident_grid((uint32_t)(total + 3) / 4, 8);
+  if (bpp == 4) hipLaunchKernelGGL((idct_dequant_rgb_kernel<4>), dim3(grid), dim3(kBlock), 0, s, a);
+  else hipLaunchKernelGGL((idct_dequant_rgb_kernel<3>), dim3(grid), dim3(kBlock), 0, s, a);
   return hipGetLastError();
 }
 

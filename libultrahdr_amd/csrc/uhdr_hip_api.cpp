@@ -1360,5 +1360,30 @@ uhdr_error_info_t uhdr_hip_jpeg_ycc_to_rgb(uhdr_hip_ctx_t* c, const uhdr_raw_ima
   return stage_out(c, &dd, rgb);
 }
 
+// 3-channel gain map: dequant + IDCT of the three components + ycc_rgb_convert in one pass
+uhdr_error_info_t uhdr_hip_idct_dequant_rgb_dev(uhdr_hip_ctx_t* c, const int16_t* coef_y, const int16_t* coef_cb, const int16_t* coef_cr,
+                                                int bw, int bh, const uint16_t qt_luma[64], const uint16_t qt_chroma[64], int variant,
+                                                uhdr_raw_image_t* rgb) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  if (!coef_y || !coef_cb || !coef_cr || !qt_luma || !qt_chroma || !rgb || !rgb->planes[0] || bw <= 0 || bh <= 0)
+    return err_status(UHDR_CODEC_INVALID_PARAM, "received bad argument for idct_dequant_rgb");
+  if (rgb->fmt != UHDR_IMG_FMT_24bppRGB888 && rgb->fmt != UHDR_IMG_FMT_32bppRGBA8888)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "idct_dequant_rgb expects UHDR_IMG_FMT_24bppRGB888 or UHDR_IMG_FMT_32bppRGBA8888. Received %d", rgb->fmt);
+  if (variant != 0 && variant != 1) return err_status(UHDR_CODEC_INVALID_PARAM, "unknown libjpeg variant %d", variant);
+  if (rgb->w == 0 || rgb->h == 0) return err_status(UHDR_CODEC_INVALID_PARAM, "image dimensions cannot be zero, received %ux%u", rgb->w, rgb->h);
+  if ((rgb->w + 7) / 8 != (unsigned)bw || (rgb->h + 7) / 8 != (unsigned)bh)
+    return err_status(UHDR_CODEC_INVALID_PARAM, "image %ux%u does not match a %dx%d block grid", rgb->w, rgb->h, bw, bh);
+  if (rgb->stride[0] < rgb->w) return err_status(UHDR_CODEC_INVALID_PARAM, "stride (%u) cannot be less than width (%u)", rgb->stride[0], rgb->w);
+  if (((uintptr_t)coef_y | (uintptr_t)coef_cb | (uintptr_t)coef_cr) & 15)
+    return err_status(UHDR_CODEC_INVALID_PARAM, "coefficient buffers must be 16-byte aligned");
+  for (int i = 0; i < 64; i++)
+    if (qt_luma[i] == 0 || qt_chroma[i] == 0) return err_status(UHDR_CODEC_INVALID_PARAM, "quantization table entry %d is zero", i);
+  HIP_TRY(hipSetDevice(c->device));
+  rgb->range = UHDR_CR_FULL_RANGE;
+  ProfScope ps(c, "idct_dequant");
+  HIP_TRY(launch_idct_dequant_rgb(coef_y, coef_cb, coef_cr, bw, bh, qt_luma, qt_chroma, variant, view_mut_of(rgb), c->stream));
+  return ok_status();
+}
+
 }  // extern "C"
 #pragma GCC visibility pop

@@ -171,6 +171,9 @@ hipError_t launch_repack(int mode, const void* src, size_t src_pitch, void* dst,
                          hipStream_t s);  // 0: RGB888 -> RGBA8888, 1: RGBA8888 -> Y400
 hipError_t launch_idct_dequant(const int16_t* coef, int bw, int bh, const uint16_t* qt_host, uint8_t* plane,
                                size_t stride, hipStream_t s);
+hipError_t launch_idct_dequant_rgb(const int16_t* coef_y, const int16_t* coef_cb, const int16_t* coef_cr, int bw, int bh,
+                                   const uint16_t* qt_luma_host, const uint16_t* qt_chroma_host, int variant,
+                                   const ImageViewMut& rgb, hipStream_t s);
 hipError_t launch_jpeg_rgb_to_ycc(const ImageView& rgb, const ImageViewMut& ycc, hipStream_t s);
 hipError_t launch_jpeg_ycc_to_rgb(const ImageView& ycc, const ImageViewMut& rgb, int variant, hipStream_t s);
 

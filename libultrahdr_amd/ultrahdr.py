@@ -239,6 +239,20 @@ class UltraHdr:
                                                    C.c_void_p(out.data_ptr()), stride))
         return out
 
+    def idct_dequant_rgb(self, coefs, qt_luma: np.ndarray, qt_chroma: np.ndarray, w: int, h: int,
+                         fmt=A.UHDR_IMG_FMT_32bppRGBA8888, libjpeg_variant: int = 0, dst: Image = None) -> Image:
+        """Decoded 3-channel gain map straight from its coefficients: dequant + IDCT of Y, Cb, Cr (three int16
+        [ceil(h/8), ceil(w/8), 64] CUDA tensors) and libjpeg's YCbCr -> RGB in one pass.  Returns the device image."""
+        assert all(c.is_cuda for c in coefs)
+        blocks_h, blocks_w = int(coefs[0].shape[0]), int(coefs[0].shape[1])
+        ql = (C.c_uint16 * 64)(*[int(v) for v in qt_luma])
+        qc = (C.c_uint16 * 64)(*[int(v) for v in qt_chroma])
+        if dst is None:
+            dst = Image(fmt, w, h, align=64, device=str(coefs[0].device))
+        A.check(self.lib.uhdr_hip_idct_dequant_rgb_dev(self.ctx.handle, *[C.c_void_p(c.data_ptr()) for c in coefs], blocks_w, blocks_h,
+                                                       ql, qc, libjpeg_variant, C.byref(dst.raw)))
+        return dst
+
     def jpeg_rgb_to_ycc(self, rgb: Image) -> Image:
         """libjpeg's JCS_RGB -> YCbCr (what happens to a 3-channel gain map inside jpeg_write_scanlines):
         RGB888 / RGBA8888 -> YCbCr 4:4:4 planes, ready for fdct_quant."""

@@ -540,11 +540,11 @@ def test_copy_raw_image_bit_exact(uhdr):
     assert e.value.code == A.UHDR_CODEC_UNSUPPORTED_FEATURE
 
 
-@pytest.mark.parametrize("base_fmt", [A.UHDR_IMG_FMT_24bppYCbCr444, A.UHDR_IMG_FMT_32bppRGBA8888])
+@pytest.mark.parametrize("base_fmt", [A.UHDR_IMG_FMT_24bppYCbCr444, A.UHDR_IMG_FMT_32bppRGBA8888, A.UHDR_IMG_FMT_16bppYCbCr422])
 @pytest.mark.parametrize("ch,alpha,scale", [(1, False, 4), (3, False, 1), (3, True, 1), (3, True, 2)])
 @pytest.mark.parametrize("out_ct", [A.UHDR_CT_LINEAR, A.UHDR_CT_HLG, A.UHDR_CT_PQ])
 def test_apply_gainmap_quad_path_444_and_rgba_bases(uhdr, base_fmt, ch, alpha, scale, out_ct):
-    """The quad kernel's BASE 1 (4:4:4, what an API-0 stream decodes to) and BASE 2 (RGBA8888) variants."""
+    """The quad kernel's BASE 1 (4:4:4, what an API-0 stream decodes to), BASE 2 (RGBA8888) and BASE 3 (4:2:2) variants."""
     w, h = 384, 192
     rng = np.random.default_rng(37)
     sdr = Image(base_fmt, w, h, A.UHDR_CG_BT_709, A.UHDR_CT_SRGB, A.UHDR_CR_FULL_RANGE)
@@ -604,7 +604,7 @@ def test_fused_api0_front_end_rejects_what_it_cannot_fuse(hip_ctx):
     assert e.value.code == A.UHDR_CODEC_UNSUPPORTED_FEATURE
 
 
-@pytest.mark.parametrize("base_fmt", [A.UHDR_IMG_FMT_24bppYCbCr444, A.UHDR_IMG_FMT_32bppRGBA8888])
+@pytest.mark.parametrize("base_fmt", [A.UHDR_IMG_FMT_24bppYCbCr444, A.UHDR_IMG_FMT_32bppRGBA8888, A.UHDR_IMG_FMT_16bppYCbCr422])
 def test_apply_gainmap_batch_444_and_rgba_bases(uhdr, base_fmt):
     """Batch launch with the quad kernel's BASE 1 / BASE 2 variants == per-frame oracle results."""
     w, h, n = 320, 96, 3
@@ -681,6 +681,50 @@ def test_fdct_quant_rgb_fused_equals_two_step_route(uhdr, fmt, quality):
     with pytest.raises(A.UhdrError) as e:
         uhdr.fdct_quant_rgb(Image(fmt, 36, 16, align=64, device="cuda:0"), ql, qc)
     assert e.value.code == A.UHDR_CODEC_UNSUPPORTED_FEATURE
+
+
+@pytest.mark.parametrize("fmt", [A.UHDR_IMG_FMT_24bppRGB888, A.UHDR_IMG_FMT_32bppRGBA8888])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_idct_dequant_rgb_fused_equals_four_step_route(uhdr, fmt, variant):
+    """uhdr_hip_idct_dequant_rgb_dev == three IDCTs + libjpeg's ycc_rgb_convert (oracle), incl. images that are not
+    a whole number of blocks (cropped stores), strides that break the vector-store alignment, and garbage
+    coefficients (32-bit multiply path, range-limit wrap)."""
+    import torch
+
+    rng = np.random.default_rng(53)
+    bpp = 4 if fmt == A.UHDR_IMG_FMT_32bppRGBA8888 else 3
+    for (w, h, align, quality) in ((256, 64, 64, 95), (100, 52, 64, 60), (75, 21, 1, 80)):
+        bw, bh = (w + 7) // 8, (h + 7) // 8
+        ql, qc = uhdr.quant_table(quality, False), uhdr.quant_table(quality, True)
+        src = rng.integers(0, 256, (3, bh * 8, bw * 8), dtype=np.uint8)
+        coefs = [L.fdct_quant_port(np.ascontiguousarray(src[c]), bw * 8, bw, bh, ql if c == 0 else qc) for c in range(3)]
+        planes = [L.idct_dequant_port(coefs[c], ql if c == 0 else qc) for c in range(3)]
+        want = L.jpeg_ycc_to_rgb_port(*[np.ascontiguousarray(pl[:h, :w]) for pl in planes], out_bpp=bpp, variant=variant)
+        dst = Image(fmt, w, h, align=align, device="cuda:0")
+        out = uhdr.idct_dequant_rgb([torch.from_numpy(c).to("cuda:0") for c in coefs], ql, qc, w, h, fmt, variant, dst=dst)
+        uhdr.ctx.synchronize()
+        got = out.to_host().valid(0).view(np.uint8).reshape(h, -1)[:, : w * bpp]
+        assert np.array_equal(got, want), (w, h)
+        # the same through the library's own four-step route
+        ycc = Image(A.UHDR_IMG_FMT_24bppYCbCr444, w, h, align=64, device="cuda:0")
+        for c in range(3):
+            pl = uhdr.idct_dequant(torch.from_numpy(coefs[c]).to("cuda:0"), ql if c == 0 else qc)
+            uhdr.ctx.synchronize()  # the library's stream is not torch's
+            ycc.plane_tensor(c)[:h, :w] = pl[:h, :w]
+        torch.cuda.synchronize()
+        four = uhdr.jpeg_ycc_to_rgb(ycc, fmt, variant)
+        uhdr.ctx.synchronize()
+        assert np.array_equal(four.to_host().valid(0).view(np.uint8).reshape(h, -1)[:, : w * bpp], want)
+    wild = [rng.integers(-32768, 32768, (3, 9, 64), dtype=np.int16) for _ in range(3)]
+    q255 = np.full(64, 255, dtype=np.uint16)
+    planes = [L.idct_dequant_port(c, q255) for c in wild]
+    want = L.jpeg_ycc_to_rgb_port(*planes, out_bpp=bpp, variant=variant)
+    out = uhdr.idct_dequant_rgb([torch.from_numpy(c).to("cuda:0") for c in wild], q255, q255, 72, 24, fmt, variant)
+    uhdr.ctx.synchronize()
+    assert np.array_equal(out.to_host().valid(0).view(np.uint8).reshape(24, -1)[:, : 72 * bpp], want)
+    with pytest.raises(A.UhdrError) as e:  # block grid must match the image
+        uhdr.idct_dequant_rgb([torch.from_numpy(c).to("cuda:0") for c in wild], q255, q255, 64, 24, fmt, variant)
+    assert e.value.code == A.UHDR_CODEC_INVALID_PARAM
 
 
 @pytest.mark.parametrize("n", [16, 17, 33])
