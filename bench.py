@@ -479,6 +479,25 @@ def extras(ctx, u, device):
         u.idct_dequant_rgb(cf3, qy, qc, w, h, rgba, 0, dst=gm3)
         u.applyGainMap(dsdr, gm3, md, A.UHDR_CT_LINEAR, f16, A.FLT_MAX, dst4)
 
+    # (3c) SURVEY 8f-1 as worded: the base image's dequant + IDCT inside the applyGainMap kernel
+    qts = [qy, qc, qc]
+
+    def fused_chain_a():
+        u.idct_dequant(cfm, qy, plane=dgm.plane_tensor(0), stride=dgm.layout[0][1])
+        dgm_view.raw.planes[0] = dgm.raw.planes[0]
+        u.applyGainMapFromCoefficients(cf, qts, w, h, A.UHDR_CG_BT_709, dgm_view, md, A.UHDR_CT_LINEAR, f16, A.FLT_MAX, dst4)
+
+    ms = time_kernel(ctx, fused_chain_a, iters=5, warm=2)
+    res["decode_chain_4k_apply_from_coefficients_mapA"] = {"us": round(ms * 1e3, 1), "Mpx/s": round(w * h / (ms / 1e3) / 1e6, 1),
+                                                            "stages": "idct_dequant(Y400 map) + applyGainMap with the base image's dequant + IDCT inside the kernel"}
+
+    def fused_chain_c():
+        u.idct_dequant_rgb(cf3, qy, qc, w, h, rgba, 0, dst=gm3)
+        u.applyGainMapFromCoefficients(cf, qts, w, h, A.UHDR_CG_BT_709, gm3, md, A.UHDR_CT_LINEAR, f16, A.FLT_MAX, dst4)
+
+    ms = time_kernel(ctx, fused_chain_c, iters=5, warm=2)
+    res["decode_chain_4k_apply_from_coefficients_mapC"] = {"us": round(ms * 1e3, 1), "Mpx/s": round(w * h / (ms / 1e3) / 1e6, 1),
+                                                            "stages": "idct_dequant_rgb(3-ch map) + applyGainMap with the base image's dequant + IDCT inside the kernel"}
     ms = time_kernel(ctx, decode_chain_c, iters=5, warm=2)
     res["decode_chain_4k_idct_plus_apply_mapC"] = {"us": round(ms * 1e3, 1), "Mpx/s": round(w * h / (ms / 1e3) / 1e6, 1),
                                                     "stages": "idct_dequant(Y, Cb, Cr) + idct_dequant_rgb(3-ch map) + applyGainMap -> RGBA_F16; Huffman decode not included"}

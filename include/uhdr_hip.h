@@ -26,7 +26,8 @@
  *   _pass2_dev (two-pass generation split at its only exchange step, for row stripes across GPUs),
  *   uhdr_hip_encode_api0_fused_dev (toneMap + generateGainMap + convert_raw_input_to_ycbcr in one pass),
  *   uhdr_hip_fdct_quant_rgb_dev (colour conversion + FDCT of a 3-channel map in one pass),
- *   uhdr_hip_idct_dequant_rgb_dev (its decode-side mirror: dequant + IDCT + colour conversion in one pass)
+ *   uhdr_hip_idct_dequant_rgb_dev (its decode-side mirror: dequant + IDCT + colour conversion in one pass),
+ *   uhdr_hip_apply_gainmap_coef_dev (applyGainMap on a base image still in coefficient form: IDCT inside the kernel)
  *
  * Same argument meaning and error behaviour as the reference: uhdr_error_info_t is returned by
  * value, UHDR_CODEC_OK == 0, strides are in PIXELS, outputs go into caller-provided images.
@@ -331,6 +332,33 @@ uhdr_error_info_t uhdr_hip_idct_dequant_rgb_dev(uhdr_hip_ctx_t* ctx, const int16
                                                 const uint16_t qtable_luma[64],
                                                 const uint16_t qtable_chroma[64], int libjpeg_variant,
                                                 uhdr_raw_image_t* rgb);
+
+/* MI355X extension, SURVEY.md 8f-1 as worded ("GPU dequant + IDCT fused into apply_gainmap"): applyGainMap on a
+ * 4:2:0 base image that is still in coefficient form -- what jpeg_read_coefficients() yields after the CPU's Huffman
+ * decode (JBLOCK arrays of width_in_blocks x height_in_blocks blocks per component, compact, raster block order,
+ * DEVICE pointers, 16-byte aligned; quantval tables in natural order).  The kernel dequantizes and inverse-transforms
+ * (JDCT_ISLOW, as jpegdecoderhelper.cpp:283 selects) each 128 x 16 pixel tile in LDS and applies the gain map from
+ * there: the 8-bit Y / Cb / Cr planes never exist in memory (3 B/px of coefficients in instead of 3 in + 1.5 out +
+ * 1.5 in over four launches).  Result == uhdr_hip_idct_dequant_dev x 3 followed by uhdr_hip_apply_gainmap_dev on the
+ * w x h image, bit for bit.  base_cg is the colour gamut of the base image (what uhdr_raw_image_t::cg would carry);
+ * gainmap_img is a decoded device image as for uhdr_hip_apply_gainmap_dev.  Covers the cases of the library's 2x2-quad
+ * kernel (even w and h, w >= 128, destination rows 16-byte aligned, map at scale 1 or an even scale <= 8 with
+ * gamma 1); UHDR_CODEC_UNSUPPORTED_FEATURE otherwise (decode with uhdr_hip_idct_dequant_dev, then apply). */
+typedef struct uhdr_hip_jpeg_coefficients {
+  const int16_t* coef[3];  /* Y, Cb, Cr */
+  int blocks_w[3];         /* jpeg_component_info::width_in_blocks */
+  int blocks_h[3];         /* jpeg_component_info::height_in_blocks */
+  uint16_t qtable[3][64];  /* comp_info[c].quant_table->quantval */
+} uhdr_hip_jpeg_coefficients_t;
+uhdr_error_info_t uhdr_hip_apply_gainmap_coef_dev(uhdr_hip_ctx_t* ctx,
+                                                  const uhdr_hip_jpeg_coefficients_t* base,
+                                                  unsigned int w, unsigned int h,
+                                                  uhdr_color_gamut_t base_cg,
+                                                  const uhdr_raw_image_t* gainmap_img,
+                                                  const uhdr_gainmap_metadata_t* gainmap_metadata,
+                                                  uhdr_color_transfer_t output_ct,
+                                                  uhdr_img_fmt_t output_format, float max_display_boost,
+                                                  uhdr_raw_image_t* dest);
 
 /* ---- timing hook for bench.py ------------------------------------------------------------------
  * HIP events recorded on the context's stream around every kernel launch of the named family

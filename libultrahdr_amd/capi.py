@@ -98,6 +98,15 @@ class EncodeCfg(C.Structure):  # uhdr_hip_encode_cfg_t
     ]
 
 
+class JpegCoefficients(C.Structure):  # uhdr_hip_jpeg_coefficients_t
+    _fields_ = [
+        ("coef", C.c_void_p * 3),
+        ("blocks_w", C.c_int * 3),
+        ("blocks_h", C.c_int * 3),
+        ("qtable", (C.c_uint16 * 64) * 3),
+    ]
+
+
 def default_encode_cfg(**kw) -> EncodeCfg:
     """C-API defaults (ultrahdrcommon.h:422-446): scale 1, multichannel, gamma 1, two-pass."""
     cfg = EncodeCfg(1, 1, 1.0, UHDR_USAGE_BEST_QUALITY, FLT_MIN, FLT_MAX, -1.0, 0, 1)
@@ -162,6 +171,8 @@ _SIGS = {
     "uhdr_hip_jpeg_ycc_to_rgb_dev": (ErrorInfo, [C.c_void_p, _P(RawImage), C.c_int, _P(RawImage)]),
     "uhdr_hip_idct_dequant_rgb_dev": (ErrorInfo, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, _P(C.c_uint16), _P(C.c_uint16),
                                                   C.c_int, _P(RawImage)]),
+    "uhdr_hip_apply_gainmap_coef_dev": (ErrorInfo, [C.c_void_p, _P(JpegCoefficients), C.c_uint, C.c_uint, C.c_int, _P(RawImage), _P(GainmapMetadata),
+                                                    C.c_int, C.c_int, C.c_float, _P(RawImage)]),
     "uhdr_hip_profile_enable": (None, [C.c_void_p, C.c_int]),
     "uhdr_hip_profile_read": (C.c_int, [C.c_void_p, C.c_char_p, _P(C.c_double), C.c_int]),
 }

@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include "idct_core.h"
 #include "uhdr_types.h"
 
 namespace uhdr {
@@ -381,8 +382,15 @@ struct QuadRaw {
 // of p.row_groups quad rows.  Everything that depends on the column (pixel offsets, gain-map tap
 // columns, weight-table column, edge flags) is therefore loop invariant and lives in VGPRs;
 // everything that depends on the row is wave-uniform and is computed on the scalar unit.
-template <int OUT, int MAPFMT, int SMODE, int BASE>
+//
+// SRC 1 (BASE 0 only): the base image arrives as JPEG coefficient blocks (p.coef_src, what jpeg_read_coefficients()
+// yields) and never exists as planes in HBM.  A wave then owns 128 x 16 pixel tiles (one 4:2:0 MCU row of sixteen
+// luma blocks): it dequantizes and inverse-transforms the tile's 32 + 8 + 8 blocks into its private LDS tile
+// (idct_core.h, six eight-block passes) and feeds the same per-quad arithmetic from there; the gain map is still
+// read from memory.  3 B/px of coefficients in instead of 3 in + 1.5 out + 1.5 in over four launches.
+template <int OUT, int MAPFMT, int SMODE, int BASE, int SRC = 0>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void apply_quad_kernel(const ApplyParams p) {
+  static_assert(SRC == 0 || BASE == 0, "coefficient input is a 4:2:0 base image");
   constexpr int NCH = (MAPFMT == 0) ? 1 : 3;
   constexpr int BPP = (MAPFMT == 0) ? 1 : (MAPFMT == 1 ? 3 : 4);
   using Raw = QuadRaw<MAPFMT, SMODE, BASE>;
@@ -422,7 +430,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
   const uint32_t wave = blockIdx.x * (kBlock / 64) + __builtin_amdgcn_readfirstlane(tid >> 6);  // SGPR
   const uint32_t groups = p.row_groups, n_iter = p.tiles_per_wave;
   const uint32_t per_frame = groups * strips_x;
-  if (wave >= per_frame * p.n_frames) return;  // a few surplus waves of the last workgroup
+  if constexpr (SRC == 0) {
+    if (wave >= per_frame * p.n_frames) return;  // a few surplus waves of the last workgroup
+  }
   // batch: a wave stays inside ONE frame, so its plane pointers are loop invariant (five scalar
   // loads from the frame table, before the loop)
   const uint32_t frame = wave / per_frame, wf = wave - frame * per_frame;
@@ -462,23 +472,28 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
     uint32_t col_l, col_u, wcol;   // SMODE 1: tap column byte offsets, column part of the weight index
   };
   Col col[kQuadsPerLane];
-#pragma unroll
-  for (int hq = 0; hq < kQuadsPerLane; hq++) {
-    const uint32_t xc = (min((sx * kQuadsPerLane + hq) * 64, qw - 64) + lane) * 2;
-    col[hq].xc = xc;
-    col[hq].col_l = col[hq].col_u = col[hq].wcol = 0;
+  auto make_col = [&](uint32_t xc) -> Col {
+    Col c;
+    c.xc = xc;
+    c.col_l = c.col_u = c.wcol = 0;
     if constexpr (SMODE == 1) {
       const uint32_t gmw1 = p.gm.w - 1;
       uint32_t xl = __umulhi(xc, magic);
       const uint32_t ox = xc - xl * scale;
       const uint32_t xu = min(xl + 1, gmw1);
       xl = min(xl, gmw1);
-      col[hq].col_l = xl * BPP;
-      col[hq].col_u = xu * BPP;
+      c.col_l = xl * BPP;
+      c.col_u = xu * BPP;
       // table select: 0 default, 1 no-right, 2 no-bottom, 3 corner (gainmapmath.cpp:946-953)
-      col[hq].wcol = ((xl == xu ? 1u : 0u) * scale * half_scale + (ox >> 1)) * 8;
+      c.wcol = ((xl == xu ? 1u : 0u) * scale * half_scale + (ox >> 1)) * 8;
     }
-  }
+    return c;
+  };
+#pragma unroll
+  for (int hq = 0; hq < kQuadsPerLane; hq++)
+    col[hq] = make_col(SRC == 0 ? (min((sx * kQuadsPerLane + hq) * 64, qw - 64) + lane) * 2 : lane * 2);  // SRC 1: set per tile
+  bool store_ok = true;  // SRC 1: lanes / rows of a tile that lie outside the image compute but do not store
+  (void)store_ok;
 
   // ---- issue the loads of quad row qy_ (wave-uniform) -------------------------------------------
   auto fetch = [&](uint32_t qy_, auto HQ) -> Raw {
@@ -491,7 +506,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
     r.y = y;
     // 32-bit offsets from the kernel-argument base pointers (planes < 4 GiB, checked by the
     // launcher): scalar row offset + per-lane column -> one v_add_u32 and an SGPR-base load
-    if constexpr (BASE == 2) {  // packed RGBA8888: two pixels (8 bytes) per row
+    if constexpr (SRC == 1) {  // luma / chroma come from the wave's LDS tile (filled in by the tile loop)
+      r.y0 = r.y1 = r.u = r.v = 0;
+    } else if constexpr (BASE == 2) {  // packed RGBA8888: two pixels (8 bytes) per row
       const uint32_t prow = y * sy * 4;
       const uint2 a = *(const uint2*)(yp + (prow + xc * 4)), b = *(const uint2*)(yp + (prow + sy * 4 + xc * 4));
       r.c[0] = a.x; r.c[1] = a.y; r.c[2] = b.x; r.c[3] = b.y;
@@ -697,7 +714,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
 #ifdef UHDR_EXP_NOSTORE  // experiment (tools/kbench): keep the math alive, never store
         if (o.x == 0x12345678u && o.w == 0x9abcdef0u)
 #endif
-        stream_store<u4v>(dpx, (u4v){o.x, o.y, o.z, o.w});
+        if (SRC == 0 || store_ok) stream_store<u4v>(dpx, (u4v){o.x, o.y, o.z, o.w});
       } else {
         const float peak = (OUT == 1) ? 1000.0f : 10000.0f;  // kHlgMaxNits / kPqMaxNits
         const f2 p203 = splat(203.0f), pk = splat(peak), rpk = splat(1.0f / peak);
@@ -731,7 +748,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
           o.y = pack_codes_1010102(lut[lut_index_f32<kOetfN>(clamp01(hr.y))], lut[lut_index_f32<kOetfN>(clamp01(hg.y))],
                                    lut[lut_index_f32<kOetfN>(clamp01(hb.y))]);
         }
-        stream_store<u2v>(dpx, (u2v){o.x, o.y});
+        if (SRC == 0 || store_ok) stream_store<u2v>(dpx, (u2v){o.x, o.y});
       }
     }
   };
@@ -742,12 +759,87 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
   using H0 = std::integral_constant<int, 0>;
   using H1 = std::integral_constant<int, kQuadsPerLane - 1>;
   static_assert(kQuadsPerLane == 2, "the pipeline below alternates between the lane's two quads");
-  Raw a = fetch(qy0, H0{});
-  for (uint32_t i = 0; i < n_iter; i++) {
-    const Raw b = fetch(qy0 + i * groups, H1{});
-    process(a, H0{});
-    a = fetch(qy0 + (i + 1) * groups, H0{});
-    process(b, H1{});
+  if constexpr (SRC == 0) {
+    Raw a = fetch(qy0, H0{});
+    for (uint32_t i = 0; i < n_iter; i++) {
+      const Raw b = fetch(qy0 + i * groups, H1{});
+      process(a, H0{});
+      a = fetch(qy0 + (i + 1) * groups, H0{});
+      process(b, H1{});
+    }
+  } else {
+    // ---- coefficient input: 128 x 16 pixel tiles, IDCT into the wave's LDS tile, then eight quad rows -------
+    __shared__ int s_ws[kBlock / 64][8 * 8 * 9];
+    __shared__ int s_q[3][64];
+    __shared__ __attribute__((aligned(8))) uint8_t s_yt[kBlock / 64][16 * 128];
+    __shared__ __attribute__((aligned(8))) uint8_t s_ct[kBlock / 64][2][8 * 64];
+    const CoefSrc* __restrict__ cs = p.coef_src;
+    if (tid < 192) s_q[tid >> 6][tid & 63] = cs->q[tid >> 6][tid & 63];
+    __syncthreads();
+    const int wv = (int)__builtin_amdgcn_readfirstlane(tid >> 6);
+    int* ws = s_ws[wv];
+    uint8_t* yt = s_yt[wv];
+    uint8_t* cbt = s_ct[wv][0];
+    uint8_t* crt = s_ct[wv][1];
+    const int rr = (int)lane >> 3, rb = (int)lane & 7;
+    const int16_t* cy = cs->coef[0];
+    const int16_t* ccb = cs->coef[1];
+    const int16_t* ccr = cs->coef[2];
+    const int bw0 = cs->bw[0], bh0 = cs->bh[0], bw1 = cs->bw[1], bh1 = cs->bh[1], bw2 = cs->bw[2], bh2 = cs->bh[2];
+    const uint32_t tiles_x = (p.sdr.w + 127) >> 7, tiles_y = (p.sdr.h + 15) >> 4, ntiles = tiles_x * tiles_y;
+    const uint32_t nwaves = gridDim.x * (kBlock / 64);
+    for (uint32_t t = wave; t < ntiles; t += nwaves) {
+      const uint32_t ty = t / tiles_x, tx = t - ty * tiles_x;
+      // the tile's six eight-block units: Y rows 2ty, 2ty+1 x two halves, Cb, Cr (all loads issued up front)
+      int v[6][8];
+      int big[6] = {0, 0, 0, 0, 0, 0};
+      {
+        int q[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) q[c] = s_q[0][rr * 8 + c];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int by = (int)(2 * ty) + (u >> 1);
+          idct::load_dequant_row(cy, bw0, by, (int)(tx * 16) + (u & 1) * 8 + rb, rr, q, v[u], big[u], by < bh0);
+        }
+#pragma unroll
+        for (int c = 0; c < 8; c++) q[c] = s_q[1][rr * 8 + c];
+        idct::load_dequant_row(ccb, bw1, (int)ty, (int)(tx * 8) + rb, rr, q, v[4], big[4], (int)ty < bh1);
+#pragma unroll
+        for (int c = 0; c < 8; c++) q[c] = s_q[2][rr * 8 + c];
+        idct::load_dequant_row(ccr, bw2, (int)ty, (int)(tx * 8) + rb, rr, q, v[5], big[5], (int)ty < bh2);
+      }
+      const uint32_t xraw = tx * 128 + lane * 2;
+      const bool lane_ok = xraw < p.sdr.w;
+      col[0] = make_col(min(xraw, p.sdr.w - 2));
+      Raw a = fetch(ty * 8, H0{});  // the first quad row's gain-map bytes are in flight during the transforms
+#pragma unroll
+      for (int u = 0; u < 6; u++) {
+        uint32_t sm8[8];
+        idct::idct_wave(ws, v[u], big[u], rr, rb, sm8);
+        const uint32_t lo = sm8[0] | (sm8[1] << 8) | (sm8[2] << 16) | (sm8[3] << 24);
+        const uint32_t hi = sm8[4] | (sm8[5] << 8) | (sm8[6] << 16) | (sm8[7] << 24);
+        uint8_t* d = (u < 4) ? yt + ((u >> 1) * 8 + rr) * 128 + ((u & 1) * 8 + rb) * 8
+                             : (u == 4 ? cbt : crt) + rr * 64 + rb * 8;
+        *(uint2*)d = make_uint2(lo, hi);
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the tile is complete in LDS
+#pragma unroll 1
+      for (uint32_t qr = 0; qr < 8; qr++) {
+        const uint32_t qy = ty * 8 + qr;
+        Raw nxt = a;
+        if (qr < 7) nxt = fetch(qy + 1, H0{});
+        a.y0 = *(const uint16_t*)(yt + (2 * qr) * 128 + lane * 2);
+        a.y1 = *(const uint16_t*)(yt + (2 * qr + 1) * 128 + lane * 2);
+        a.u = cbt[qr * 64 + lane];
+        a.v = crt[qr * 64 + lane];
+        store_ok = lane_ok && (qy < qh);
+        process(a, H0{});
+        a = nxt;
+      }
+      __builtin_amdgcn_wave_barrier();  // the next tile overwrites the LDS tile
+    }
   }
 }
 
@@ -787,6 +879,33 @@ hipError_t launch_quad(const ApplyParams& p, hipStream_t s) {
   hipLaunchKernelGGL((apply_quad_kernel<OUT, MAPFMT, SMODE, BASE>), dim3(grid), dim3(kBlock), 0, s, q);
   return hipGetLastError();
 }
+// coefficient input (SRC 1): resident workgroups, waves stride over the 128 x 16 pixel tiles
+template <int OUT, int MAPFMT, int SMODE>
+hipError_t launch_quad_coef(const ApplyParams& p, hipStream_t s) {
+  static const int resident = resident_blocks(apply_quad_kernel<OUT, MAPFMT, SMODE, 0, 1>);
+  const uint32_t ntiles = ((p.sdr.w + 127) / 128) * ((p.sdr.h + 15) / 16);
+  uint32_t grid = (ntiles + kBlock / 64 - 1) / (kBlock / 64);
+  if (grid > (uint32_t)resident) grid = (uint32_t)resident;
+  ApplyParams q = p;
+  q.n_frames = 1;
+  q.row_groups = 1;
+  q.tiles_per_wave = 0;
+  hipLaunchKernelGGL((apply_quad_kernel<OUT, MAPFMT, SMODE, 0, 1>), dim3(grid), dim3(kBlock), 0, s, q);
+  return hipGetLastError();
+}
+template <int OUT, int MAPFMT>
+hipError_t launch_quad_coef_s(const ApplyParams& p, int smode, hipStream_t s) {
+  return smode == 0 ? launch_quad_coef<OUT, MAPFMT, 0>(p, s) : launch_quad_coef<OUT, MAPFMT, 1>(p, s);
+}
+template <int OUT>
+hipError_t launch_quad_coef_m(const ApplyParams& p, int mapfmt, int smode, hipStream_t s) {
+  switch (mapfmt) {
+    case 0: return launch_quad_coef_s<OUT, 0>(p, smode, s);
+    case 1: return launch_quad_coef_s<OUT, 1>(p, smode, s);
+    default: return launch_quad_coef_s<OUT, 2>(p, smode, s);
+  }
+}
+
 template <int OUT, int MAPFMT, int BASE>
 hipError_t launch_quad_s(const ApplyParams& p, int smode, hipStream_t s) {
   return smode == 0 ? launch_quad<OUT, MAPFMT, 0, BASE>(p, s) : launch_quad<OUT, MAPFMT, 1, BASE>(p, s);
@@ -848,6 +967,20 @@ int apply_quad_mode(const ApplyParams& p) {
       p.gamma_is_one[1] && p.gamma_is_one[2])
     return 1;  // gamma != 1 needs pow() per sample: generic kernel
   return -1;
+}
+
+// Base image in coefficient form (p.coef_src, a device CoefSrc; p.sdr carries the geometry of the 4:2:0 image the
+// coefficients decode to).  Only the quad kernel has this input: hipErrorInvalidValue when its contract does not hold.
+hipError_t launch_apply_gainmap_coef(const ApplyParams& p, hipStream_t s) {
+  const int out = p.out_ct == UHDR_CT_LINEAR ? 0 : (p.out_ct == UHDR_CT_HLG ? 1 : 2);
+  const int mapfmt = p.gm.fmt == UHDR_IMG_FMT_8bppYCbCr400 ? 0 : (p.gm.fmt == UHDR_IMG_FMT_24bppRGB888 ? 1 : 2);
+  const int smode = apply_quad_mode(p);
+  if (smode < 0 || p.sdr.fmt != UHDR_IMG_FMT_12bppYCbCr420 || !p.coef_src || p.n_frames > 1) return hipErrorInvalidValue;
+  switch (out) {
+    case 0: return launch_quad_coef_m<0>(p, mapfmt, smode, s);
+    case 1: return launch_quad_coef_m<1>(p, mapfmt, smode, s);
+    default: return launch_quad_coef_m<2>(p, mapfmt, smode, s);
+  }
 }
 
 // Picks the quad kernel when its layout assumptions hold, otherwise the generic one.

@@ -91,6 +91,8 @@ struct uhdr_hip_ctx {
   FramePtrs* d_frames = nullptr;  // batch frame-pointer tables (rotating slots)
   size_t frames_cap = 0;
   unsigned int frames_next = 0;
+  CoefSrc* d_coef_src = nullptr;  // apply_gainmap_coef descriptors (rotating slots)
+  unsigned int coef_src_next = 0;
   // profiling
   bool prof = false;
   std::vector<ProfEntry> prof_entries;
@@ -415,6 +417,7 @@ void uhdr_hip_destroy(uhdr_hip_ctx_t* c) {
   for (auto& b : c->scratch) if (b.p) (void)hipFree(b.p);
   if (c->minmax.p) (void)hipFree(c->minmax.p);
   if (c->d_frames) (void)hipFree(c->d_frames);
+  if (c->d_coef_src) (void)hipFree(c->d_coef_src);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -613,6 +616,59 @@ uhdr_error_info_t uhdr_hip_apply_gainmap_batch_dev(uhdr_hip_ctx_t* c, unsigned i
     }
     ProfScope ps(c, "apply_gainmap");
     HIP_TRY(launch_apply_gainmap(q, c->stream));
+  }
+  return ok_status();
+}
+
+// applyGainMap with the base image still in coefficient form: JpegDecoderHelper's dequantize + IDCT stage
+// (jpegdecoderhelper.cpp:468-535) runs inside the applyGainMap kernel, the 8-bit planes never exist in memory.
+uhdr_error_info_t uhdr_hip_apply_gainmap_coef_dev(uhdr_hip_ctx_t* c, const uhdr_hip_jpeg_coefficients_t* base, unsigned int w,
+                                                  unsigned int h, uhdr_color_gamut_t base_cg, const uhdr_raw_image_t* gm,
+                                                  const uhdr_gainmap_metadata_t* md, uhdr_color_transfer_t out_ct,
+                                                  uhdr_img_fmt_t out_fmt, float max_display_boost, uhdr_raw_image_t* dest) {
+  (void)out_fmt;
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  if (!base) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for the base image coefficients");
+  if (w == 0 || h == 0) return err_status(UHDR_CODEC_INVALID_PARAM, "image dimensions cannot be zero, received %ux%u", w, h);
+  // the block grid of a 4:2:0 frame (jpeg_component_info::width_in_blocks / height_in_blocks)
+  const unsigned int cw = (w + 1) / 2, ch = (h + 1) / 2;
+  const unsigned int want_w[3] = {(w + 7) / 8, (cw + 7) / 8, (cw + 7) / 8}, want_h[3] = {(h + 7) / 8, (ch + 7) / 8, (ch + 7) / 8};
+  CoefSrc cs;
+  for (int i = 0; i < 3; i++) {
+    if (!base->coef[i] || ((uintptr_t)base->coef[i] & 15))
+      return err_status(UHDR_CODEC_INVALID_PARAM, "coefficient buffer %d is null or not 16-byte aligned", i);
+    if (base->blocks_w[i] != (int)want_w[i] || base->blocks_h[i] != (int)want_h[i])
+      return err_status(UHDR_CODEC_INVALID_PARAM, "component %d: a %dx%d block grid does not match a 4:2:0 image of %ux%u (expected %ux%u)", i,
+                        base->blocks_w[i], base->blocks_h[i], w, h, want_w[i], want_h[i]);
+    cs.coef[i] = base->coef[i];
+    cs.bw[i] = base->blocks_w[i];
+    cs.bh[i] = base->blocks_h[i];
+    for (int k = 0; k < 64; k++) {
+      if (base->qtable[i][k] == 0) return err_status(UHDR_CODEC_INVALID_PARAM, "component %d: quantization table entry %d is zero", i, k);
+      cs.q[i][k] = base->qtable[i][k];
+    }
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  // geometry-only view of the image the coefficients decode to (the kernel never dereferences these planes)
+  uhdr_raw_image_t sdr;
+  memset(&sdr, 0, sizeof sdr);
+  sdr.fmt = UHDR_IMG_FMT_12bppYCbCr420;
+  sdr.cg = base_cg; sdr.ct = UHDR_CT_SRGB; sdr.range = UHDR_CR_FULL_RANGE;
+  sdr.w = w; sdr.h = h;
+  for (int i = 0; i < 3; i++) { sdr.planes[i] = (void*)base->coef[i]; sdr.stride[i] = (unsigned int)base->blocks_w[i] * 8; }
+  ApplyParams p;
+  UHDR_TRY(build_apply_params(c, &sdr, gm, md, out_ct, max_display_boost, dest, 0, 0, &p));
+  if (apply_quad_mode(p) < 0)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "apply_gainmap_coef covers the 2x2-quad kernel's cases (even dimensions, width >= 128, 16-byte "
+                      "aligned destination rows, gain map at scale 1 or an even scale <= 8 with gamma 1); decode with idct_dequant and call apply_gainmap");
+  constexpr unsigned int kSlots = 8;
+  if (!c->d_coef_src) HIP_TRY(hipMalloc((void**)&c->d_coef_src, sizeof(CoefSrc) * kSlots));
+  CoefSrc* slot = c->d_coef_src + (c->coef_src_next++ % kSlots);
+  HIP_TRY(hipMemcpyAsync(slot, &cs, sizeof cs, hipMemcpyHostToDevice, c->stream));  // pageable source: staged before return
+  p.coef_src = slot;
+  {
+    ProfScope ps(c, "apply_gainmap");
+    HIP_TRY(launch_apply_gainmap_coef(p, c->stream));
   }
   return ok_status();
 }

@@ -58,6 +58,14 @@ struct FramePtrs {
   uint8_t* dst;
 };
 
+// applyGainMap straight from JPEG coefficients: the 4:2:0 base image as jpeg_read_coefficients() yields it
+// (device-resident descriptor; JBLOCK arrays in raster block order, tables in natural order)
+struct CoefSrc {
+  const int16_t* coef[3];  // Y, Cb, Cr
+  int bw[3], bh[3];        // comp_info[c].width_in_blocks / height_in_blocks
+  int q[3][64];            // comp_info[c].quant_table->quantval
+};
+
 struct ApplyParams {
   ImageView sdr;      // base image (this rank's stripe)
   ImageView gm;       // whole gain map
@@ -82,6 +90,7 @@ struct ApplyParams {
   float offset_sdr[3], offset_hdr[3];
   Mat3 gamut;               // hdr_cg <- sdr_cg
   Yuv2Rgb yuv;              // always the BT.601 set (jpegr.cpp:1723)
+  const CoefSrc* coef_src;  // quad kernel, SRC 1 only: the base image in coefficient form (p.sdr then carries geometry only)
 };
 
 // ---- generateGainMap -----------------------------------------------------------------------------
@@ -154,6 +163,7 @@ struct RgbToYcbcrParams {
 
 // launchers (defined in the .hip files)
 hipError_t launch_apply_gainmap(const ApplyParams& p, hipStream_t s);
+hipError_t launch_apply_gainmap_coef(const ApplyParams& p, hipStream_t s);
 int apply_quad_mode(const ApplyParams& p);  // >= 0: the quad kernel (and batch mode) applies
 hipError_t launch_generate_gainmap(const GenParams& p, bool two_pass, hipStream_t s);
 hipError_t launch_affine_map(const AffineParams& p, hipStream_t s);

@@ -151,6 +151,23 @@ class UltraHdr:
                 self.ctx.handle, C.byref(sdr_intent.raw), C.byref(gainmap_img.raw), C.byref(gainmap_metadata),
                 output_ct, output_format, max_display_boost, C.byref(dest.raw)))
 
+    def applyGainMapFromCoefficients(self, coefs, qtables, w: int, h: int, base_cg: int, gainmap_img: Image,
+                                     gainmap_metadata: A.GainmapMetadata, output_ct: int, output_format: int,
+                                     max_display_boost: float, dest: Image):
+        """applyGainMap on a 4:2:0 base image still in coefficient form (what jpeg_read_coefficients() yields): coefs =
+        three int16 [blocks_h, blocks_w, 64] CUDA tensors (Y, Cb, Cr), qtables = their three quantization tables; the
+        dequantize + IDCT stage runs inside the kernel.  == idct_dequant x 3 + applyGainMap, bit for bit."""
+        assert all(c.is_cuda for c in coefs) and _is_dev(gainmap_img, dest)
+        jc = A.JpegCoefficients()
+        for i in range(3):
+            jc.coef[i] = coefs[i].data_ptr()
+            jc.blocks_h[i], jc.blocks_w[i] = int(coefs[i].shape[0]), int(coefs[i].shape[1])
+            for k in range(64):
+                jc.qtable[i][k] = int(qtables[i][k])
+        A.check(self.lib.uhdr_hip_apply_gainmap_coef_dev(self.ctx.handle, C.byref(jc), w, h, base_cg, C.byref(gainmap_img.raw),
+                                                         C.byref(gainmap_metadata), output_ct, output_format, max_display_boost,
+                                                         C.byref(dest.raw)))
+
     def applyGainMapBatch(self, sdr_intents, gainmap_imgs, gainmap_metadata: A.GainmapMetadata, output_ct: int,
                           output_format: int, max_display_boost: float, dests):
         """n device frames of identical geometry sharing one metadata block -> one kernel launch."""

@@ -475,6 +475,86 @@ def test_decode_stage_feeds_apply_gainmap(uhdr):
     assert np.array_equal(dest.to_host().valid(0), want.valid(0))
 
 
+def _coef_case(uhdr, w, h, quality, rng, wild=False):
+    """Coefficients of a random 4:2:0 image (as the Huffman decoder would hand them over), the three tables, and the
+    oracle's decode of them as an Image."""
+    cw, chh = (w + 1) // 2, (h + 1) // 2
+    dims = [((w + 7) // 8, (h + 7) // 8), ((cw + 7) // 8, (chh + 7) // 8), ((cw + 7) // 8, (chh + 7) // 8)]
+    qts = [uhdr.quant_table(quality, False), uhdr.quant_table(quality, True), uhdr.quant_table(max(quality - 10, 1), True)]
+    coefs = []
+    for c, (bw, bh) in enumerate(dims):
+        if wild:
+            coefs.append(rng.integers(-32768, 32768, (bh, bw, 64), dtype=np.int16))
+        else:
+            # smooth field + noise so that the decoded image is not just clipped garbage
+            yy, xx = np.mgrid[0:bh * 8, 0:bw * 8]
+            pl = 128 + 90 * np.sin(xx / (13.0 + 5 * c)) * np.cos(yy / (9.0 + 3 * c)) + rng.normal(0, 12, (bh * 8, bw * 8))
+            pl = np.clip(pl, 0, 255).astype(np.uint8)
+            coefs.append(L.fdct_quant_port(np.ascontiguousarray(pl), bw * 8, bw, bh, qts[c]))
+    dec = Image(A.UHDR_IMG_FMT_12bppYCbCr420, w, h, A.UHDR_CG_BT_709, A.UHDR_CT_SRGB, A.UHDR_CR_FULL_RANGE, align=2)
+    for c in range(3):
+        full = L.idct_dequant_port(coefs[c], qts[c])
+        dec.valid(c)[:] = full[: dec.valid(c).shape[0], : dec.valid(c).shape[1]]
+    return coefs, qts, dec
+
+
+@pytest.mark.parametrize("ch,alpha,scale", [(1, False, 4), (1, False, 1), (3, False, 1), (3, True, 1), (3, True, 2), (1, False, 8)])
+@pytest.mark.parametrize("out_ct", [A.UHDR_CT_LINEAR, A.UHDR_CT_HLG, A.UHDR_CT_PQ])
+def test_apply_gainmap_from_coefficients(uhdr, ch, alpha, scale, out_ct):
+    """SURVEY 8f-1 as worded: dequant + IDCT fused into applyGainMap.  == the oracle's IDCT followed by the oracle's
+    applyGainMap, bit for bit; sizes that are not whole tiles (128 x 16) / MCUs, three different quantization tables."""
+    import torch
+
+    rng = np.random.default_rng(61)
+    fmt = A.UHDR_IMG_FMT_64bppRGBAHalfFloat if out_ct == A.UHDR_CT_LINEAR else A.UHDR_IMG_FMT_32bppRGBA1010102
+    for (w, h, quality) in ((512, 64, 95), (392, 200, 70)):
+        if w % scale or h % scale:
+            continue
+        coefs, qts, dec = _coef_case(uhdr, w, h, quality, rng)
+        gm = synth.make_gainmap(w // scale, h // scale, ch, alpha, cg=A.UHDR_CG_BT_2100)
+        md = synth.default_metadata(use_base_cg=0, per_channel=(ch == 3))
+        want = L.apply_gainmap(oracle_kind(), dec, gm, md, out_ct)
+        dest = Image(fmt, w, h, align=4, device="cuda:0")
+        uhdr.applyGainMapFromCoefficients([torch.from_numpy(c).to("cuda:0") for c in coefs], qts, w, h, A.UHDR_CG_BT_709,
+                                          gm.to("cuda:0"), md, out_ct, fmt, A.FLT_MAX, dest)
+        uhdr.ctx.synchronize()
+        assert np.array_equal(dest.to_host().valid(0), want.valid(0)), (w, h)
+
+
+def test_apply_gainmap_from_coefficients_corrupt_and_errors(uhdr):
+    """Garbage coefficients take the 32-bit multiply path and the modulo-1024 range limit, exactly as libjpeg would;
+    geometry the quad kernel does not cover is refused (no silent fallback), a wrong block grid is an invalid parameter."""
+    import torch
+
+    rng = np.random.default_rng(67)
+    f16 = A.UHDR_IMG_FMT_64bppRGBAHalfFloat
+    w, h = 256, 48
+    coefs, qts, dec = _coef_case(uhdr, w, h, 50, rng, wild=True)
+    qts = [np.full(64, 255, dtype=np.uint16)] * 3
+    for c in range(3):
+        full = L.idct_dequant_port(coefs[c], qts[c])
+        dec.valid(c)[:] = full[: dec.valid(c).shape[0], : dec.valid(c).shape[1]]
+    gm = synth.make_gainmap(w // 4, h // 4, 1)
+    md = synth.default_metadata()
+    want = L.apply_gainmap(oracle_kind(), dec, gm, md, A.UHDR_CT_LINEAR)
+    dcoefs = [torch.from_numpy(c).to("cuda:0") for c in coefs]
+    dest = Image(f16, w, h, align=2, device="cuda:0")
+    uhdr.applyGainMapFromCoefficients(dcoefs, qts, w, h, A.UHDR_CG_BT_709, gm.to("cuda:0"), md, A.UHDR_CT_LINEAR, f16, A.FLT_MAX, dest)
+    uhdr.ctx.synchronize()
+    assert np.array_equal(dest.to_host().valid(0), want.valid(0))
+    with pytest.raises(A.UhdrError) as e:  # block grid of a different image
+        uhdr.applyGainMapFromCoefficients(dcoefs, qts, w + 16, h, A.UHDR_CG_BT_709, gm.to("cuda:0"), md, A.UHDR_CT_LINEAR, f16, A.FLT_MAX, dest)
+    assert e.value.code == A.UHDR_CODEC_INVALID_PARAM
+    # a 3 x 3 map scale is the generic kernel's business: refused here
+    w3, h3 = 264, 48
+    coefs3, qts3, _ = _coef_case(uhdr, w3, h3, 80, rng)
+    with pytest.raises(A.UhdrError) as e:
+        uhdr.applyGainMapFromCoefficients([torch.from_numpy(c).to("cuda:0") for c in coefs3], qts3, w3, h3, A.UHDR_CG_BT_709,
+                                          synth.make_gainmap(w3 // 3, h3 // 3, 1).to("cuda:0"), md, A.UHDR_CT_LINEAR, f16, A.FLT_MAX,
+                                          Image(f16, w3, h3, align=2, device="cuda:0"))
+    assert e.value.code == A.UHDR_CODEC_UNSUPPORTED_FEATURE
+
+
 def test_apply_gainmap_calls_capture_into_a_hip_graph(uhdr):
     """BASELINE config 5 (batch decode to HLG, hipGraph-captured): once the per-metadata tables are
     cached a device-resident applyGainMap call enqueues nothing but its kernel, so a burst of calls on a
