@@ -26,19 +26,28 @@ __device__ __forceinline__ int mulc(int a, int c) {
   if constexpr (M24) return __mul24(a, c);
   else return (int)((uint32_t)a * (uint32_t)c);
 }
-__device__ __forceinline__ int descale(int x, int n) { return (int)((uint32_t)x + (1u << (n - 1))) >> n; }
-
-// jidctint.c jpeg_idct_islow, one 1-D pass (PASS 0: columns, descale 11; PASS 1: rows, descale 18)
+// jidctint.c jpeg_idct_islow, one 1-D pass.  PASS 0: columns, descale by 2^11 -> workspace values.  PASS 1: rows,
+// descale by 2^18, then range_limit[(x + 128) & 1023] (jdmaster.c prepare_range_limit_table: identity on 0..255, 255
+// up to 639, 0 from 640) -> the 8-bit samples.
+// Two rewrites that leave every bit unchanged under libjpeg's wrap-around INT32 arithmetic (modular addition is
+// associative, so a constant may be added to the even part's DC terms instead of to each of the eight outputs --
+// libjpeg-turbo folds its rounding "fudge factor" the same way):
+//   * the rounding constant 2^(sh-1) of DESCALE rides on tmp0 / tmp1: descale is a bare arithmetic shift;
+//   * the row pass also carries 512 << 18, so that t = bits 18..27 of the sum = (x + 512) & 1023 = (v + 384) & 1023
+//     for the table index v = (x + 128) & 1023, and range_limit[v] = clamp(t - 384, 0, 255)  (v <= 255 -> t - 384 = v;
+//     256 <= v < 640 -> 256..639 -> 255; v >= 640 -> t wraps to 0..383 -> negative -> 0): bit-field extract,
+//     subtract, median -- three instructions per sample instead of nine.
 template <int PASS, bool M24>
 __device__ __forceinline__ void idct_1d(const int in[8], int out[8]) {
   constexpr int sh = PASS == 0 ? 13 - 2 : 13 + 2 + 3;
+  constexpr uint32_t fudge = (1u << (sh - 1)) + (PASS == 1 ? (512u << 18) : 0u);
   int z2 = in[2], z3 = in[6];
   int z1 = mulc<M24>(z2 + z3, FIX_0_541196100);
   int tmp2 = z1 + mulc<M24>(z3, -FIX_1_847759065);
   int tmp3 = z1 + mulc<M24>(z2, FIX_0_765366865);
   z2 = in[0]; z3 = in[4];
-  int tmp0 = (int)((uint32_t)(z2 + z3) << 13);
-  int tmp1 = (int)((uint32_t)(z2 - z3) << 13);
+  int tmp0 = (int)(((uint32_t)(z2 + z3) << 13) + fudge);
+  int tmp1 = (int)(((uint32_t)(z2 - z3) << 13) + fudge);
   const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
   tmp0 = in[7]; tmp1 = in[5]; tmp2 = in[3]; tmp3 = in[1];
   z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
@@ -54,16 +63,16 @@ __device__ __forceinline__ void idct_1d(const int in[8], int out[8]) {
   z4 = mulc<M24>(z4, -FIX_0_390180644);
   z3 += z5; z4 += z5;
   tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
-  out[0] = descale(tmp10 + tmp3, sh); out[7] = descale(tmp10 - tmp3, sh);
-  out[1] = descale(tmp11 + tmp2, sh); out[6] = descale(tmp11 - tmp2, sh);
-  out[2] = descale(tmp12 + tmp1, sh); out[5] = descale(tmp12 - tmp1, sh);
-  out[3] = descale(tmp13 + tmp0, sh); out[4] = descale(tmp13 - tmp0, sh);
-}
-
-// range_limit[(x) & RANGE_MASK] with the table centred on 128 (jdmaster.c prepare_range_limit_table)
-__device__ __forceinline__ uint32_t range_limit(int x) {
-  const uint32_t v = (uint32_t)(x + 128) & 1023u;
-  return v <= 255u ? v : (v < 640u ? 255u : 0u);
+  const int sum[8] = {tmp10 + tmp3, tmp11 + tmp2, tmp12 + tmp1, tmp13 + tmp0, tmp13 - tmp0, tmp12 - tmp1, tmp11 - tmp2, tmp10 - tmp3};
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    if constexpr (PASS == 0) {
+      out[k] = sum[k] >> sh;
+    } else {
+      const int t = (int)(((uint32_t)sum[k] >> 18) & 1023u) - 384;
+      out[k] = min(max(t, 0), 255);
+    }
+  }
 }
 
 // Lane (row rr, block rb) fetches and dequantizes its coefficient row of block (by, bx); `big` collects the
@@ -78,8 +87,10 @@ __device__ __forceinline__ void load_dequant_row(const int16_t* __restrict__ coe
       v[2 * c] = __mul24((int)(int16_t)(w4[c] & 0xffff), q[2 * c]);  // |coef| < 2^15, q < 2^16: exact
       v[2 * c + 1] = __mul24((int)(int16_t)(w4[c] >> 16), q[2 * c + 1]);
     }
-#pragma unroll
-    for (int c = 0; c < 8; c++) big |= (v[c] < 0 ? -v[c] : v[c]) >> 13;
+    // all |v| < 2^13?  (three-operand max / min: one instruction per sample)
+    const int mx = max(max(max(v[0], v[1]), max(v[2], v[3])), max(max(v[4], v[5]), max(v[6], v[7])));
+    const int mn = min(min(min(v[0], v[1]), min(v[2], v[3])), min(min(v[4], v[5]), min(v[6], v[7])));
+    big |= (int)(mx > 8191) | (int)(mn < -8191);
   } else {
 #pragma unroll
     for (int c = 0; c < 8; c++) v[c] = 0;
@@ -108,7 +119,7 @@ __device__ __forceinline__ void idct_wave(int* ws, const int v[8], int big, int 
   for (int c = 0; c < 8; c++) in[c] = ws[rb * 72 + rr * 9 + c];
   if (fast) idct_1d<1, true>(in, out); else idct_1d<1, false>(in, out);
 #pragma unroll
-  for (int c = 0; c < 8; c++) s[c] = range_limit(out[c]);
+  for (int c = 0; c < 8; c++) s[c] = (uint32_t)out[c];
   __builtin_amdgcn_wave_barrier();
 }
 

@@ -168,8 +168,63 @@ def fuzz_converts():
     note("idct", np.array_equal(u.idct_dequant(coef, qt), L.idct_dequant_port(coef, qt)), f"{bw}x{bh} q{q}")
 
 
+def fuzz_decode_fused():
+    """apply_gainmap_coef (IDCT inside the apply kernel) and idct_dequant_rgb (3-channel map in one pass) against the
+    oracle's IDCT / colour conversion / applyGainMap chain."""
+    w = int(rng.choice([128, 130, 200, 256, 384, 514]))
+    h = int(rng.choice([16, 34, 66, 128, 130]))
+    cw, chh = (w + 1) // 2, (h + 1) // 2
+    dims = [((w + 7) // 8, (h + 7) // 8), ((cw + 7) // 8, (chh + 7) // 8), ((cw + 7) // 8, (chh + 7) // 8)]
+    wild = rng.random() < 0.2
+    qts = [np.full(64, 255, dtype=np.uint16)] * 3 if wild else [u.quant_table(int(rng.integers(1, 101)), c > 0) for c in range(3)]
+    coefs = []
+    for c, (bw, bh) in enumerate(dims):
+        if wild:
+            coefs.append(rng.integers(-32768, 32768, (bh, bw, 64), dtype=np.int16))
+        else:
+            pl = np.ascontiguousarray(rng.integers(0, 256, (bh * 8, bw * 8), dtype=np.uint8))
+            coefs.append(L.fdct_quant_port(pl, bw * 8, bw, bh, qts[c]))
+    dec = Image(A.UHDR_IMG_FMT_12bppYCbCr420, w, h, int(rng.integers(0, 3)), A.UHDR_CT_SRGB, A.UHDR_CR_FULL_RANGE, align=2)
+    for c in range(3):
+        full = L.idct_dequant_port(coefs[c], qts[c])
+        dec.valid(c)[:] = full[: dec.valid(c).shape[0], : dec.valid(c).shape[1]]
+    scale = int(rng.choice([1, 1, 2, 4, 8]))
+    if w % scale or h % scale:
+        scale = 1
+    ch = int(rng.choice([1, 3]))
+    alpha = bool(ch == 3 and rng.random() < 0.5)
+    gm = synth.make_gainmap(w // scale, h // scale, ch, alpha, seed=int(rng.integers(1 << 30)), cg=int(rng.integers(0, 3)), align=int(rng.choice([2, 64])))
+    md = synth.default_metadata(max_boost=float(rng.uniform(1.5, 16)), min_boost=float(rng.uniform(0.5, 1.0)),
+                                gamma=1.0 if scale > 1 or rng.random() < 0.7 else float(rng.uniform(0.5, 2.5)),
+                                use_base_cg=int(rng.integers(0, 2)), per_channel=bool(ch == 3 and rng.random() < 0.5))
+    ct = int(rng.choice([A.UHDR_CT_LINEAR, A.UHDR_CT_HLG, A.UHDR_CT_PQ]))
+    fmt = F16 if ct == A.UHDR_CT_LINEAR else U32
+    want = L.apply_gainmap("port", dec, gm, md, ct, A.FLT_MAX)
+    dest = Image(fmt, w, h, align=4, device="cuda:0")
+    u.applyGainMapFromCoefficients([torch.from_numpy(c).to("cuda:0") for c in coefs], qts, w, h, dec.raw.cg, gm.to("cuda:0"), md, ct, fmt,
+                                   A.FLT_MAX, dest)
+    ctx.synchronize()
+    a, b = dest.to_host().valid(0), want.valid(0)
+    note("apply-coef", np.array_equal(a, b), f"{w}x{h} s{scale} ch{ch} a{alpha} ct{ct} wild{wild} diff {(a != b).sum()}")
+    # 3-channel map straight from its coefficients
+    mw, mh = int(rng.integers(1, 300)), int(rng.integers(1, 70))
+    bw, bh = (mw + 7) // 8, (mh + 7) // 8
+    ql, qc = u.quant_table(int(rng.integers(1, 101)), False), u.quant_table(int(rng.integers(1, 101)), True)
+    mco = [L.fdct_quant_port(np.ascontiguousarray(rng.integers(0, 256, (bh * 8, bw * 8), dtype=np.uint8)), bw * 8, bw, bh, ql if c == 0 else qc)
+           for c in range(3)]
+    planes = [L.idct_dequant_port(mco[c], ql if c == 0 else qc)[:mh, :mw] for c in range(3)]
+    variant, bpp = int(rng.integers(0, 2)), int(rng.choice([3, 4]))
+    want_rgb = L.jpeg_ycc_to_rgb_port(*[np.ascontiguousarray(p_) for p_ in planes], out_bpp=bpp, variant=variant)
+    mfmt = A.UHDR_IMG_FMT_32bppRGBA8888 if bpp == 4 else A.UHDR_IMG_FMT_24bppRGB888
+    mdst = Image(mfmt, mw, mh, align=int(rng.choice([1, 4, 64])), device="cuda:0")
+    u.idct_dequant_rgb([torch.from_numpy(c).to("cuda:0") for c in mco], ql, qc, mw, mh, mfmt, variant, dst=mdst)
+    ctx.synchronize()
+    got = mdst.to_host().valid(0).view(np.uint8).reshape(mh, -1)[:, : mw * bpp]
+    note("idct-rgb", np.array_equal(got, want_rgb), f"{mw}x{mh} bpp{bpp} v{variant}")
+
+
 t_end = time.time() + args.seconds
-jobs = [fuzz_apply, fuzz_apply, fuzz_apply, fuzz_generate, fuzz_tonemap, fuzz_converts]
+jobs = [fuzz_apply, fuzz_apply, fuzz_apply, fuzz_generate, fuzz_tonemap, fuzz_converts, fuzz_decode_fused]
 i = 0
 while time.time() < t_end:
     jobs[i % len(jobs)]()
