@@ -141,3 +141,56 @@ def test_half_subnormal_formula():
     out = np.empty(1, np.uint16)
     port.uo_float_to_half(zero.ctypes.data, out.ctypes.data, 1)
     assert out[0] == 0
+
+
+def test_idct_rewrites_preserve_every_bit():
+    """idct_core.h evaluates jidctint.c with two rewrites: DESCALE's rounding constant is added to the even part's DC
+    terms instead of to each output, and the row pass also carries 512 << 18 so that range_limit[(x + 128) & 1023]
+    becomes  clamp(((sum >> 18) & 1023) - 384, 0, 255).  Emulated here in wrap-around int32 arithmetic (numpy) and
+    compared with the oracle's plain restatement of libjpeg, for ordinary, large and garbage coefficients."""
+    from oracle import loader as L
+
+    K = dict(f0298=2446, f0390=3196, f0541=4433, f0765=6270, f0899=7373, f1175=9633, f1501=12299, f1847=15137, f1961=16069,
+             f2053=16819, f2562=20995, f3072=25172)
+
+    def w32(x):
+        x = np.asarray(x, dtype=np.int64) & 0xFFFFFFFF
+        return np.where(x >= 2 ** 31, x - 2 ** 32, x)
+
+    def mul(a, c):
+        return w32(a * c)
+
+    def pass_1d(v, fudge):
+        i = [v[..., k] for k in range(8)]
+        z2, z3 = i[2], i[6]
+        z1 = mul(w32(z2 + z3), K["f0541"])
+        t2 = w32(z1 + mul(z3, -K["f1847"]))
+        t3 = w32(z1 + mul(z2, K["f0765"]))
+        z2, z3 = i[0], i[4]
+        t0 = w32((w32(z2 + z3) << 13) + fudge)
+        t1 = w32((w32(z2 - z3) << 13) + fudge)
+        t10, t13, t11, t12 = w32(t0 + t3), w32(t0 - t3), w32(t1 + t2), w32(t1 - t2)
+        t0, t1, t2, t3 = i[7], i[5], i[3], i[1]
+        z1, z2, z3, z4 = w32(t0 + t3), w32(t1 + t2), w32(t0 + t2), w32(t1 + t3)
+        z5 = mul(w32(z3 + z4), K["f1175"])
+        t0, t1, t2, t3 = mul(t0, K["f0298"]), mul(t1, K["f2053"]), mul(t2, K["f3072"]), mul(t3, K["f1501"])
+        z1, z2, z3, z4 = mul(z1, -K["f0899"]), mul(z2, -K["f2562"]), mul(z3, -K["f1961"]), mul(z4, -K["f0390"])
+        z3, z4 = w32(z3 + z5), w32(z4 + z5)
+        t0, t1, t2, t3 = w32(t0 + w32(z1 + z3)), w32(t1 + w32(z2 + z4)), w32(t2 + w32(z2 + z3)), w32(t3 + w32(z1 + z4))
+        return np.stack([w32(t10 + t3), w32(t11 + t2), w32(t12 + t1), w32(t13 + t0), w32(t13 - t0), w32(t12 - t1), w32(t11 - t2),
+                         w32(t10 - t3)], -1)
+
+    def device_formula(block):  # block [..., row, col], dequantized
+        ws = np.swapaxes(pass_1d(np.swapaxes(block, -1, -2), 1 << 10) >> 11, -1, -2)
+        s = pass_1d(ws, (1 << 17) + (512 << 18))
+        return np.clip((((s & 0xFFFFFFFF) >> 18) & 1023) - 384, 0, 255).astype(np.uint8)
+
+    rng = np.random.default_rng(71)
+    for lo, hi, q in ((-200, 200, 16), (-1024, 1024, 8), (-32768, 32768, 255), (-32768, 32768, 65535)):
+        coef = rng.integers(lo, hi, (6, 40, 64), dtype=np.int64).astype(np.int16)
+        qt = rng.integers(1, q + 1, 64).astype(np.uint16)
+        want = L.idct_dequant_port(coef, qt)  # [6 * 8, 40 * 8]
+        deq = w32(coef.astype(np.int64) * qt.astype(np.int64)).reshape(6, 40, 8, 8)
+        got = device_formula(deq)  # [6, 40, 8, 8]
+        got = got.transpose(0, 2, 1, 3).reshape(48, 320)
+        assert np.array_equal(got, want), (lo, hi, q)
