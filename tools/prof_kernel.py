@@ -34,6 +34,28 @@ if args.case in ("gen4k", "tm4k"):  # encode-side kernels: two-pass 3-channel ge
     print("done", args.case, args.iters)
     sys.exit(0)
 
+if args.case.startswith("coef"):  # coef4kA / coef8kC: applyGainMap with the base image in coefficient form (IDCT in the kernel)
+    w, h = (7680, 4320) if "8k" in args.case else (3840, 2160)
+    mk = args.case[-1]
+    ctx = Context(0)
+    u = UltraHdr(ctx=ctx)
+    md = synth.default_metadata(use_base_cg=0)
+    f16 = A.UHDR_IMG_FMT_64bppRGBAHalfFloat
+    qts = [u.quant_table(95, False), u.quant_table(95, True), u.quant_table(95, True)]
+    coefs = [torch.zeros(((h // d + 7) // 8, (w // d + 7) // 8, 64), dtype=torch.int16, device="cuda:0") for d in (1, 2, 2)]
+    for c in coefs:
+        c[..., 0] = 37
+        c[..., 1] = -3
+    gm = (synth.make_gainmap(w // 4, h // 4, 1, seed=50) if mk == "A" else synth.make_gainmap(w, h, 3, alpha=True, seed=50)).to("cuda:0")
+    gm.raw.cg = A.UHDR_CG_BT_2100
+    dst = Image(f16, w, h, align=64, device="cuda:0")
+    torch.cuda.synchronize()
+    for i in range(args.iters):
+        u.applyGainMapFromCoefficients(coefs, qts, w, h, A.UHDR_CG_BT_709, gm, md, A.UHDR_CT_LINEAR, f16, A.FLT_MAX, dst)
+    ctx.synchronize()
+    print("done", args.case, args.iters)
+    sys.exit(0)
+
 w, h = (7680, 4320) if args.case.startswith("8k") else (3840, 2160)
 mk = args.case[2]
 ct = A.UHDR_CT_HLG if "hlg" in args.case else A.UHDR_CT_PQ if "pq" in args.case else A.UHDR_CT_LINEAR
