@@ -35,6 +35,11 @@ def build_port():
     subprocess.check_call(["make", "-s", "-C", HERE, "port"])
 
 
+class ScanDesc(C.Structure):  # uo_scan_t
+    _fields_ = [("ncomp", C.c_int), ("coef", C.c_void_p * 3), ("bw", C.c_int * 3), ("bh", C.c_int * 3), ("hs", C.c_int * 3),
+                ("vs", C.c_int * 3), ("w", C.c_uint), ("h", C.c_uint), ("restart_interval", C.c_int)]
+
+
 def port() -> C.CDLL:
     global _port
     if _port is not None:
@@ -64,6 +69,12 @@ def port() -> C.CDLL:
     lib.uo_fdct_quant_plane.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, _P(C.c_uint16), C.c_void_p]
     lib.uo_jpeg_rgb_to_ycc.restype = None
     lib.uo_jpeg_rgb_to_ycc.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.uo_huffman_encode_scan.restype = C.c_size_t
+    lib.uo_huffman_encode_scan.argtypes = [_P(ScanDesc), C.c_void_p, C.c_size_t]
+    lib.uo_jpeg_assemble.restype = C.c_size_t
+    lib.uo_jpeg_assemble.argtypes = [_P(ScanDesc), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    lib.uo_std_huff_table.restype = None
+    lib.uo_std_huff_table.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, _P(C.c_int)]
     lib.uo_idct_dequant_plane.restype = None
     lib.uo_idct_dequant_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, _P(C.c_uint16), C.c_void_p, C.c_size_t]
     lib.uo_jpeg_ycc_to_rgb.restype = None
@@ -257,6 +268,43 @@ def idct_dequant_port(coef: np.ndarray, qt: np.ndarray) -> np.ndarray:
     q = (C.c_uint16 * 64)(*[int(v) for v in qt])
     port().uo_idct_dequant_plane(coef.ctypes.data, bw, bh, q, out.ctypes.data, bw * 8)
     return out
+
+
+def scan_desc(coefs, w: int, h: int, sampling, restart_interval: int) -> ScanDesc:
+    """coefs: list of (bh, bw, 64) int16 arrays (kept alive by the caller); sampling: [(h, v)] per component."""
+    sd = ScanDesc()
+    sd.ncomp = len(coefs)
+    for c, a in enumerate(coefs):
+        assert a.dtype == np.int16 and a.flags["C_CONTIGUOUS"]
+        sd.coef[c] = a.ctypes.data
+        sd.bh[c], sd.bw[c] = a.shape[0], a.shape[1]
+        sd.hs[c], sd.vs[c] = sampling[c]
+    sd.w, sd.h, sd.restart_interval = w, h, restart_interval
+    return sd
+
+
+def huffman_encode_port(coefs, w: int, h: int, sampling, restart_interval: int = 0) -> bytes:
+    """Entropy-coded data of the scan (between the SOS header and EOI), Annex K tables."""
+    coefs = [np.ascontiguousarray(c, dtype=np.int16) for c in coefs]
+    sd = scan_desc(coefs, w, h, sampling, restart_interval)
+    cap = sum(c.size for c in coefs) * 4 + 4096
+    out = np.zeros(cap, dtype=np.uint8)
+    n = port().uo_huffman_encode_scan(C.byref(sd), out.ctypes.data, cap)
+    assert n > 0
+    return out[:n].tobytes()
+
+
+def jpeg_assemble_port(coefs, w: int, h: int, sampling, restart_interval: int, qt_luma, qt_chroma, scan: bytes) -> bytes:
+    """A complete baseline JFIF file around entropy-coded data."""
+    coefs = [np.ascontiguousarray(c, dtype=np.int16) for c in coefs]
+    sd = scan_desc(coefs, w, h, sampling, restart_interval)
+    qt = np.stack([np.asarray(qt_luma, dtype=np.uint16), np.asarray(qt_chroma, dtype=np.uint16)])
+    qt = np.ascontiguousarray(qt)
+    sc = np.frombuffer(scan, dtype=np.uint8)
+    out = np.zeros(len(scan) + 2048, dtype=np.uint8)
+    n = port().uo_jpeg_assemble(C.byref(sd), qt.ctypes.data, sc.ctypes.data, sc.size, out.ctypes.data, out.size)
+    assert n > 0
+    return out[:n].tobytes()
 
 
 def jpeg_rgb_to_ycc_port(rgb: np.ndarray, stride_px: int, w: int, h: int):

@@ -1426,3 +1426,229 @@ void uo_lut(int which, float* out) {
     case 4: memcpy(out, g_lut_pq, sizeof g_lut_pq); break;
   }
 }
+
+/* =================================================================================================
+ * Baseline Huffman entropy coding of quantized coefficient blocks (the step after
+ * fdct_quant).  In the reference this is libjpeg behind JpegEncoderHelper::compressImage
+ * (/root/reference/lib/src/jpegencoderhelper.cpp:131-244: jpeg_set_defaults -> the Annex K tables,
+ * optimize_coding off, no restart markers).  Restated from the public algorithm: ITU-T T.81 Annex C
+ * (code generation), F.1.2 (DC differences, run/size AC symbols, ZRL, EOB), F.1.2.3 (byte stuffing),
+ * E.1.4 / B.2.4.4 (restart intervals), as implemented by jchuff.c encode_mcu_huff / encode_one_block /
+ * emit_restart and jctrans.c compress_output (dummy blocks at the right and bottom edges: AC zero, DC
+ * equal to the previous block of the MCU).  Header writing follows jcmarker.c's marker order.
+ * ================================================================================================= */
+static const uint8_t kZigzagToNatural[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                             41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                             30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+/* T.81 Annex K.3 typical tables (jpeg_set_defaults installs exactly these) */
+static const uint8_t kBitsDcLuma[17] = {0, 0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0};
+static const uint8_t kBitsDcChroma[17] = {0, 0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0};
+static const uint8_t kValDc[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+static const uint8_t kBitsAcLuma[17] = {0, 0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7d};
+static const uint8_t kValAcLuma[162] = {
+    0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71, 0x14, 0x32, 0x81,
+    0x91, 0xa1, 0x08, 0x23, 0x42, 0xb1, 0xc1, 0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72, 0x82, 0x09, 0x0a, 0x16, 0x17, 0x18,
+    0x19, 0x1a, 0x25, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x34, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48,
+    0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75,
+    0x76, 0x77, 0x78, 0x79, 0x7a, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99,
+    0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3,
+    0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2, 0xe3, 0xe4, 0xe5,
+    0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+static const uint8_t kBitsAcChroma[17] = {0, 0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 0x77};
+static const uint8_t kValAcChroma[162] = {
+    0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71, 0x13, 0x22, 0x32, 0x81, 0x08,
+    0x14, 0x42, 0x91, 0xa1, 0xb1, 0xc1, 0x09, 0x23, 0x33, 0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1, 0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25,
+    0xf1, 0x17, 0x18, 0x19, 0x1a, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47,
+    0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74,
+    0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x82, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97,
+    0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba,
+    0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe2, 0xe3, 0xe4,
+    0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+
+void uo_std_huff_table(int is_ac, int is_chroma, uint8_t bits[17], uint8_t vals[256], int* nvals) {
+  const uint8_t* b = is_ac ? (is_chroma ? kBitsAcChroma : kBitsAcLuma) : (is_chroma ? kBitsDcChroma : kBitsDcLuma);
+  const uint8_t* v = is_ac ? (is_chroma ? kValAcChroma : kValAcLuma) : kValDc;
+  int n = 0;
+  for (int i = 0; i <= 16; i++) {
+    bits[i] = b[i];
+    if (i) n += b[i];
+  }
+  memset(vals, 0, 256);
+  memcpy(vals, v, (size_t)n);
+  *nvals = n;
+}
+
+/* T.81 Annex C: code sizes and codes from BITS / HUFFVAL (jpeg_make_c_derived_tbl) */
+typedef struct {
+  uint16_t code[256];
+  uint8_t len[256];
+} uo_huff_enc_t;
+static void make_derived(int is_ac, int is_chroma, uo_huff_enc_t* t) {
+  uint8_t bits[17], vals[256];
+  int n;
+  uo_std_huff_table(is_ac, is_chroma, bits, vals, &n);
+  memset(t, 0, sizeof *t);
+  unsigned code = 0;
+  int k = 0;
+  for (int l = 1; l <= 16; l++) {
+    for (int i = 0; i < bits[l]; i++, k++) {
+      t->code[vals[k]] = (uint16_t)code;
+      t->len[vals[k]] = (uint8_t)l;
+      code++;
+    }
+    code <<= 1;
+  }
+}
+
+typedef struct {
+  uint8_t* out;
+  size_t cap, n;
+  uint64_t acc; /* bits not yet written, right aligned */
+  int nacc;
+  int overflow;
+} uo_bitw_t;
+static void bw_byte(uo_bitw_t* w, unsigned b) {
+  if (w->n < w->cap) w->out[w->n] = (uint8_t)b; else w->overflow = 1;
+  w->n++;
+}
+static void bw_put(uo_bitw_t* w, unsigned code, int len) { /* emit_bits: MSB first, 0xFF followed by a stuffed 0x00 */
+  w->acc = (w->acc << len) | (code & ((1u << len) - 1u));
+  w->nacc += len;
+  while (w->nacc >= 8) {
+    const unsigned b = (unsigned)(w->acc >> (w->nacc - 8)) & 0xffu;
+    bw_byte(w, b);
+    if (b == 0xff) bw_byte(w, 0);
+    w->nacc -= 8;
+  }
+}
+static void bw_flush(uo_bitw_t* w) { /* flush_bits: fill the partial byte with ones */
+  if (w->nacc > 0) bw_put(w, 0x7f, 8 - w->nacc);
+  w->acc = 0;
+  w->nacc = 0;
+}
+static int bit_length(unsigned v) {
+  int n = 0;
+  while (v) { n++; v >>= 1; }
+  return n;
+}
+static void encode_block(uo_bitw_t* w, const int16_t blk[64], int dc_only_value, int is_dummy, int* last_dc,
+                         const uo_huff_enc_t* dct, const uo_huff_enc_t* act) {
+  /* jchuff.c encode_one_block */
+  const int dc = is_dummy ? dc_only_value : blk[0];
+  int temp = dc - *last_dc, temp2 = temp;
+  *last_dc = dc;
+  if (temp < 0) { temp = -temp; temp2--; }
+  int nbits = bit_length((unsigned)temp);
+  bw_put(w, dct->code[nbits], dct->len[nbits]);
+  if (nbits) bw_put(w, (unsigned)temp2, nbits);
+  int r = 0;
+  if (!is_dummy) {
+    for (int k = 1; k < 64; k++) {
+      temp = blk[kZigzagToNatural[k]];
+      if (temp == 0) { r++; continue; }
+      while (r > 15) { bw_put(w, act->code[0xf0], act->len[0xf0]); r -= 16; }
+      temp2 = temp;
+      if (temp < 0) { temp = -temp; temp2--; }
+      nbits = bit_length((unsigned)temp);
+      const int sym = (r << 4) + nbits;
+      bw_put(w, act->code[sym], act->len[sym]);
+      bw_put(w, (unsigned)temp2, nbits);
+      r = 0;
+    }
+  } else {
+    r = 63;
+  }
+  if (r > 0) bw_put(w, act->code[0], act->len[0]);
+}
+
+static void scan_geometry(const uo_scan_t* sc, int* mcus_per_row, int* mcu_rows) {
+  if (sc->ncomp == 1) { /* non-interleaved: an MCU is one block, no dummy blocks (jcmaster.c per_scan_setup) */
+    *mcus_per_row = sc->bw[0];
+    *mcu_rows = sc->bh[0];
+    return;
+  }
+  int hmax = 1, vmax = 1;
+  for (int c = 0; c < sc->ncomp; c++) {
+    if (sc->hs[c] > hmax) hmax = sc->hs[c];
+    if (sc->vs[c] > vmax) vmax = sc->vs[c];
+  }
+  *mcus_per_row = (int)((sc->w + 8u * hmax - 1) / (8u * hmax));
+  *mcu_rows = (int)((sc->h + 8u * vmax - 1) / (8u * vmax));
+}
+
+/* entropy-coded data of the single scan: everything between the SOS header and EOI, RSTn markers included */
+size_t uo_huffman_encode_scan(const uo_scan_t* sc, uint8_t* out, size_t cap) {
+  uo_huff_enc_t dct[2], act[2];
+  for (int t = 0; t < 2; t++) { make_derived(0, t, &dct[t]); make_derived(1, t, &act[t]); }
+  int mpr, mrows;
+  scan_geometry(sc, &mpr, &mrows);
+  uo_bitw_t w = {out, cap, 0, 0, 0, 0};
+  int last_dc[3] = {0, 0, 0};
+  int to_go = sc->restart_interval, next_rst = 0;
+  for (int my = 0; my < mrows; my++) {
+    for (int mx = 0; mx < mpr; mx++) {
+      if (sc->restart_interval) {
+        if (to_go == 0) { /* emit_restart */
+          bw_flush(&w);
+          bw_byte(&w, 0xff);
+          bw_byte(&w, 0xd0u + (unsigned)next_rst);
+          last_dc[0] = last_dc[1] = last_dc[2] = 0;
+          to_go = sc->restart_interval;
+          next_rst = (next_rst + 1) & 7;
+        }
+        to_go--;
+      }
+      int prev_dc = 0; /* DC of the previous block in MCU order (jctrans.c dummy rule) */
+      for (int c = 0; c < sc->ncomp; c++) {
+        const int hs = sc->ncomp == 1 ? 1 : sc->hs[c], vs = sc->ncomp == 1 ? 1 : sc->vs[c], tbl = c ? 1 : 0;
+        for (int yi = 0; yi < vs; yi++) {
+          for (int xi = 0; xi < hs; xi++) {
+            const int by = my * vs + yi, bx = mx * hs + xi;
+            const int real = by < sc->bh[c] && bx < sc->bw[c];
+            const int16_t* blk = real ? sc->coef[c] + ((size_t)by * sc->bw[c] + bx) * 64 : NULL;
+            encode_block(&w, blk, prev_dc, !real, &last_dc[c], &dct[tbl], &act[tbl]);
+            prev_dc = real ? blk[0] : prev_dc;
+          }
+        }
+      }
+    }
+  }
+  bw_flush(&w);
+  return w.overflow ? 0 : w.n;
+}
+
+/* A complete baseline JFIF file around the entropy-coded data (jcmarker.c: SOI, APP0, DQT, SOF0, DHT, DRI, SOS ... EOI).
+ * qt: natural order, table 0 for component 0, table 1 for the others. */
+size_t uo_jpeg_assemble(const uo_scan_t* sc, const uint16_t qt[2][64], const uint8_t* scan, size_t scan_len, uint8_t* out, size_t cap) {
+  size_t n = 0;
+#define PUT(b) do { if (n < cap) out[n] = (uint8_t)(b); n++; } while (0)
+#define PUT16(v) do { PUT((v) >> 8); PUT((v) & 0xff); } while (0)
+  PUT(0xff); PUT(0xd8);
+  PUT(0xff); PUT(0xe0); PUT16(16); PUT('J'); PUT('F'); PUT('I'); PUT('F'); PUT(0); PUT(1); PUT(1); PUT(0); PUT16(1); PUT16(1); PUT(0); PUT(0);
+  const int ntab = sc->ncomp > 1 ? 2 : 1;
+  for (int t = 0; t < ntab; t++) {
+    PUT(0xff); PUT(0xdb); PUT16(67); PUT(t);
+    for (int i = 0; i < 64; i++) PUT(qt[t][kZigzagToNatural[i]]);
+  }
+  PUT(0xff); PUT(0xc0); PUT16(8 + 3 * sc->ncomp); PUT(8); PUT16(sc->h); PUT16(sc->w); PUT(sc->ncomp);
+  for (int c = 0; c < sc->ncomp; c++) { PUT(c + 1); PUT(((sc->ncomp == 1 ? 1 : sc->hs[c]) << 4) | (sc->ncomp == 1 ? 1 : sc->vs[c])); PUT(c ? 1 : 0); }
+  for (int t = 0; t < ntab; t++) {
+    for (int ac = 0; ac < 2; ac++) {
+      uint8_t bits[17], vals[256];
+      int nv;
+      uo_std_huff_table(ac, t, bits, vals, &nv);
+      PUT(0xff); PUT(0xc4); PUT16(2 + 1 + 16 + nv); PUT((ac << 4) | t);
+      for (int i = 1; i <= 16; i++) PUT(bits[i]);
+      for (int i = 0; i < nv; i++) PUT(vals[i]);
+    }
+  }
+  if (sc->restart_interval) { PUT(0xff); PUT(0xdd); PUT16(4); PUT16(sc->restart_interval); }
+  PUT(0xff); PUT(0xda); PUT16(6 + 2 * sc->ncomp); PUT(sc->ncomp);
+  for (int c = 0; c < sc->ncomp; c++) { PUT(c + 1); PUT(c ? 0x11 : 0x00); }
+  PUT(0); PUT(63); PUT(0);
+  for (size_t i = 0; i < scan_len; i++) PUT(scan[i]);
+  PUT(0xff); PUT(0xd9);
+#undef PUT
+#undef PUT16
+  return n <= cap ? n : 0;
+}

@@ -107,6 +107,22 @@ void uo_idct_dequant_plane(const int16_t* coef, int blocks_w, int blocks_h, cons
 void uo_jpeg_ycc_to_rgb(const uint8_t* y, const uint8_t* cb, const uint8_t* cr, size_t in_stride, int w,
                         int h, uint8_t* rgb, size_t out_stride_px, int out_bpp, int variant);
 
+/* Entropy stage: baseline Huffman coding of quantized coefficient blocks with the Annex K tables, as
+ * libjpeg does behind JpegEncoderHelper (jpegencoderhelper.cpp:131-244), optionally with restart intervals.
+ * coef[c]: JBLOCK arrays of bw[c] x bh[c] REAL blocks (width_in_blocks x height_in_blocks); blocks an MCU needs beyond
+ * them are libjpeg's dummy blocks.  hs / vs: sampling factors (ignored for ncomp == 1).  restart_interval in MCUs, 0 = none. */
+typedef struct uo_scan {
+  int ncomp;
+  const int16_t* coef[3];
+  int bw[3], bh[3];
+  int hs[3], vs[3];
+  unsigned w, h;
+  int restart_interval;
+} uo_scan_t;
+size_t uo_huffman_encode_scan(const uo_scan_t* sc, uint8_t* out, size_t cap); /* bytes between the SOS header and EOI; 0 = overflow */
+size_t uo_jpeg_assemble(const uo_scan_t* sc, const uint16_t qt[2][64], const uint8_t* scan, size_t scan_len, uint8_t* out, size_t cap);
+void uo_std_huff_table(int is_ac, int is_chroma, uint8_t bits[17], uint8_t vals[256], int* nvals);
+
 /* scalar access for known-answer tests */
 int uo_eval(int fn, const float* in, float* out, size_t n); /* ids as in ref_shim.cpp */
 void uo_float_to_half(const float* in, uint16_t* out, size_t n);

@@ -301,3 +301,88 @@ def test_copy_raw_image_port_equals_reference(ref):
             assert outs[0][2] == outs[1][2]
     src, dst = _random_image(COPY_FMTS[2], 32, 16, 16, 1), _random_image(COPY_FMTS[2], 32, 18, 16, 2)
     assert L.copy_raw_image("port", src, dst) == L.copy_raw_image("ref", src, dst) == A.UHDR_CODEC_MEM_ERROR
+
+
+# ---- entropy stage ------------------------------------------------------------------
+def _scan_data(jpeg: bytes) -> bytes:
+    """Entropy-coded bytes of a single-scan baseline JPEG: after the SOS header, before the final EOI."""
+    i = 2
+    while True:
+        assert jpeg[i] == 0xFF, i
+        m, ln = jpeg[i + 1], (jpeg[i + 2] << 8) | jpeg[i + 3]
+        if m == 0xDA:
+            start = i + 2 + ln
+            break
+        i += 2 + ln
+    assert jpeg[-2:] == b"\xff\xd9"
+    return jpeg[start:-2]
+
+
+def _dht_tables(jpeg: bytes):
+    out, i = {}, 2
+    while jpeg[i + 1] != 0xDA:
+        m, ln = jpeg[i + 1], (jpeg[i + 2] << 8) | jpeg[i + 3]
+        if m == 0xC4:
+            seg, j = jpeg[i + 4: i + 2 + ln], 0
+            while j < len(seg):
+                n = sum(seg[j + 1: j + 17])
+                out[seg[j]] = (bytes(seg[j + 1: j + 17]), bytes(seg[j + 17: j + 17 + n]))
+                j += 17 + n
+        i += 2 + ln
+    return out
+
+
+@pytest.mark.parametrize("quality", [95, 50, 100, 5])
+def test_huffman_restatement_equals_the_reference_encoder_byte_for_byte(ref, quality):
+    """The reference's encoder (JpegEncoderHelper -> libjpeg, Annex K tables, no restart markers) and the oracle's
+    Huffman restatement fed with the same quantized coefficients produce the same entropy-coded bytes, for the 4:2:0
+    base image, a Y400 map and a 3-channel (4:4:4) map; the tables are the ones in the reference's own DHT segments."""
+    out = np.zeros(1 << 22, dtype=np.uint8)
+    rng = np.random.default_rng(5)
+    cases = []
+    img = synth.make_sdr_yuv420(128, 64, noise=0.2)
+    cases.append((img, 128, 64, [(2, 2), (1, 1), (1, 1)]))
+    cases.append((synth.make_gainmap(96, 48, 1), 96, 48, [(1, 1)]))
+    gm3 = Image(A.UHDR_IMG_FMT_24bppRGB888, 64, 40, align=1)
+    gm3.valid(0)[:] = rng.integers(0, 256, size=gm3.valid(0).shape, dtype=np.uint8)
+    cases.append((gm3, 64, 40, [(1, 1)] * 3))
+    for img, w, h, sampling in cases:
+        n = ref.ref_jpeg_compress(C.byref(img.raw), quality, out.ctypes.data, out.size)
+        assert n > 0
+        jpeg = out[:n].tobytes()
+        coefs, qt = _read_coefficients(ref, jpeg)
+        want = _scan_data(jpeg)
+        got = L.huffman_encode_port(coefs, w, h, sampling, 0)
+        assert got == want, (img.raw.fmt, quality, len(got), len(want))
+        dht = _dht_tables(jpeg)
+        for ac in (0, 1):
+            for chroma in range(2 if len(coefs) > 1 else 1):
+                bits, vals, nv = np.zeros(17, np.uint8), np.zeros(256, np.uint8), C.c_int(0)
+                L.port().uo_std_huff_table(ac, chroma, bits.ctypes.data, vals.ctypes.data, C.byref(nv))
+                assert dht[(ac << 4) | chroma] == (bits[1:].tobytes(), vals[: nv.value].tobytes())
+
+
+@pytest.mark.parametrize("ri", [1, 3, 8, 1000])
+def test_huffman_restart_intervals_decode_to_the_same_coefficients(ref, ri):
+    """With restart intervals the bytes differ from the reference's (DRI + RSTn markers) but libjpeg decodes the file to
+    exactly the coefficients that went in -- including odd sizes, where the MCUs at the right / bottom edge contain
+    libjpeg's dummy blocks."""
+    rng = np.random.default_rng(9)
+    for (w, h, sampling) in ((72, 40, [(2, 2), (1, 1), (1, 1)]), (50, 30, [(2, 2), (1, 1), (1, 1)]), (41, 23, [(1, 1)] * 3), (37, 19, [(1, 1)])):
+        hmax, vmax = max(s[0] for s in sampling), max(s[1] for s in sampling)
+        coefs = []
+        for c, (hs, vs) in enumerate(sampling):
+            cw, ch = -(-w * hs // hmax), -(-h * vs // vmax)
+            bw, bh = -(-cw // 8), -(-ch // 8)
+            a = (rng.normal(0, 30, (bh, bw, 64)) * (rng.random((bh, bw, 64)) < 0.3)).astype(np.int16)
+            a[..., 0] = rng.integers(-1000, 1000, (bh, bw))
+            a[0, 0, 1:] = rng.integers(-1023, 1024, 63)  # a dense block with large magnitudes
+            coefs.append(np.ascontiguousarray(a))
+        ql, qc = L.quant_table_port(90, False), L.quant_table_port(90, True)
+        scan = L.huffman_encode_port(coefs, w, h, sampling, ri)
+        jpeg = L.jpeg_assemble_port(coefs, w, h, sampling, ri, ql, qc, scan)
+        back, qt = _read_coefficients(ref, jpeg)
+        assert len(back) == len(coefs)
+        for c in range(len(coefs)):
+            assert back[c].shape == coefs[c].shape and np.array_equal(back[c], coefs[c]), (w, h, c)
+        assert np.array_equal(qt[0], ql) and (len(coefs) == 1 or np.array_equal(qt[1], qc))
