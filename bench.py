@@ -365,6 +365,24 @@ def extras(ctx, u, device):
     ms = time_kernel(ctx, lambda: u.idct_dequant(coef, qt, plane=dec_plane, stride=w), iters=5, warm=2)
     res["idct_dequant_4k_luma"] = {"us": round(ms * 1e3, 1), "Mpx/s": round(w * h / (ms / 1e3) / 1e6, 1), "GB/s": round(3.0 * w * h / (ms / 1e3) / 1e9, 1)}
 
+    # entropy stage: the 4K base frame's quantized coefficients (q 95, 4:2:0) -> entropy-coded bytes
+    hq = [u.quant_table(95, False), u.quant_table(95, True), u.quant_table(95, True)]
+    hco = []
+    for c in range(3):
+        rows, stride, wv = sdr.layout[c]
+        hco.append(u.fdct_quant(sdr.plane_tensor(c), stride, wv // 8, rows // 8, hq[c]))
+    hout = torch.empty(w * h * 2, dtype=torch.uint8, device=device)
+    nbytes = [0]
+
+    def huff():
+        nbytes[0] = int(u.huffman_encode(hco, w, h, [(2, 2), (1, 1), (1, 1)], 10, out=hout).numel())
+
+    ms = time_kernel(ctx, huff, iters=5, warm=2)
+    res["huffman_encode_4k_420_q95"] = {"us": round(ms * 1e3, 1), "Mpx/s": round(w * h / (ms / 1e3) / 1e6, 1), "jpeg_scan_bytes": nbytes[0],
+                                        "GB/s_coef_in": round(3.0 * w * h / (ms / 1e3) / 1e9, 1),
+                                        "stages": "3 kernels: one wavefront per restart interval (10 MCUs) -> interval sizes -> offsets -> gather with RSTn markers"}
+    del hco, hout
+
     # ---- whole stage chains, device resident (sum of the kernels' HIP-event durations per pass) ----------------
     def blocks(n):
         return (n + 7) // 8

@@ -27,7 +27,9 @@
  *   uhdr_hip_encode_api0_fused_dev (toneMap + generateGainMap + convert_raw_input_to_ycbcr in one pass),
  *   uhdr_hip_fdct_quant_rgb_dev (colour conversion + FDCT of a 3-channel map in one pass),
  *   uhdr_hip_idct_dequant_rgb_dev (its decode-side mirror: dequant + IDCT + colour conversion in one pass),
- *   uhdr_hip_apply_gainmap_coef_dev (applyGainMap on a base image still in coefficient form: IDCT inside the kernel)
+ *   uhdr_hip_apply_gainmap_coef_dev (applyGainMap on a base image still in coefficient form: IDCT inside the kernel),
+ *   uhdr_hip_huffman_encode_dev + uhdr_hip_jpeg_assemble (baseline Huffman entropy coding, one restart interval per
+ *   wavefront, and the file wrapper around it)
  *
  * Same argument meaning and error behaviour as the reference: uhdr_error_info_t is returned by
  * value, UHDR_CODEC_OK == 0, strides are in PIXELS, outputs go into caller-provided images.
@@ -359,6 +361,42 @@ uhdr_error_info_t uhdr_hip_apply_gainmap_coef_dev(uhdr_hip_ctx_t* ctx,
                                                   uhdr_color_transfer_t output_ct,
                                                   uhdr_img_fmt_t output_format, float max_display_boost,
                                                   uhdr_raw_image_t* dest);
+
+/* ---- JPEG entropy stage (the step after uhdr_hip_fdct_quant) ---------------------------------
+ * Baseline Huffman coding of quantized coefficient blocks with the Annex K tables -- what libjpeg does behind
+ * JpegEncoderHelper::compressImage (jpegencoderhelper.cpp:131-244: jpeg_set_defaults, optimize_coding off).  libjpeg's
+ * single sequential pass chains every block to its predecessor through the DC prediction; the parallel form uses
+ * JPEG's own restart intervals (T.81 B.2.4.4): every restart_interval MCUs the stream is byte-aligned, an RSTn marker
+ * is written and the predictors reset, so one wavefront encodes one interval (<= 64 blocks: restart_interval <= 10
+ * for 4:2:0, <= 21 for 4:4:4, <= 64 for one component).  Parity policy: the entropy-coded data is byte-identical to
+ * what libjpeg emits for the same coefficients with cinfo.restart_interval set to the same value (dummy blocks at the
+ * right / bottom edge included); relative to the reference's files that adds a DRI segment and the RSTn markers, the
+ * decoded coefficients are identical.
+ * coef[c]: DEVICE JBLOCK arrays (as uhdr_hip_fdct_quant_dev writes them) of blocks_w[c] x blocks_h[c] blocks, between
+ * the component's real grid (jpeg_component_info::width_in_blocks / height_in_blocks) and the MCU-padded grid; blocks
+ * an MCU needs beyond the array are libjpeg's dummy blocks.  One component: non-interleaved scan (an MCU is a block).
+ * out: DEVICE buffer; receives everything between the SOS header and EOI, RSTn markers included; *out_bytes its
+ * length (UHDR_CODEC_MEM_ERROR with the needed size in *out_bytes when out_capacity is too small).  Synchronous.
+ * Coefficients must be in the baseline range (as an 8-bit FDCT produces): UHDR_CODEC_INVALID_PARAM otherwise. */
+typedef struct uhdr_hip_jpeg_scan {
+  int num_components;     /* 1 or 3 */
+  const int16_t* coef[3];
+  int blocks_w[3];
+  int blocks_h[3];
+  int h_samp[3];          /* sampling factors, 1 or 2 (ignored for one component) */
+  int v_samp[3];
+  unsigned int w, h;      /* image dimensions in pixels */
+  int restart_interval;   /* in MCUs */
+} uhdr_hip_jpeg_scan_t;
+uhdr_error_info_t uhdr_hip_huffman_encode_dev(uhdr_hip_ctx_t* ctx, const uhdr_hip_jpeg_scan_t* scan,
+                                              uint8_t* out, size_t out_capacity, size_t* out_bytes);
+/* Host helper (no device work): wraps entropy-coded data (HOST pointer) into a complete baseline JFIF file -- SOI,
+ * APP0, DQT (natural-order tables as uhdr_hip_jpeg_quant_table returns them; component 0 uses qtable_luma, the others
+ * qtable_chroma), SOF0, DHT (Annex K), DRI, SOS, data, EOI, the marker order of libjpeg's jcmarker.c.  scan->coef is
+ * not read.  Returns the file size, 0 when out_capacity is too small or the description is invalid. */
+size_t uhdr_hip_jpeg_assemble(const uhdr_hip_jpeg_scan_t* scan, const uint16_t qtable_luma[64],
+                              const uint16_t qtable_chroma[64], const uint8_t* scan_data, size_t scan_bytes,
+                              uint8_t* out, size_t out_capacity);
 
 /* ---- timing hook for bench.py ------------------------------------------------------------------
  * HIP events recorded on the context's stream around every kernel launch of the named family

@@ -107,6 +107,20 @@ class JpegCoefficients(C.Structure):  # uhdr_hip_jpeg_coefficients_t
     ]
 
 
+class JpegScan(C.Structure):  # uhdr_hip_jpeg_scan_t
+    _fields_ = [
+        ("num_components", C.c_int),
+        ("coef", C.c_void_p * 3),
+        ("blocks_w", C.c_int * 3),
+        ("blocks_h", C.c_int * 3),
+        ("h_samp", C.c_int * 3),
+        ("v_samp", C.c_int * 3),
+        ("w", C.c_uint),
+        ("h", C.c_uint),
+        ("restart_interval", C.c_int),
+    ]
+
+
 def default_encode_cfg(**kw) -> EncodeCfg:
     """C-API defaults (ultrahdrcommon.h:422-446): scale 1, multichannel, gamma 1, two-pass."""
     cfg = EncodeCfg(1, 1, 1.0, UHDR_USAGE_BEST_QUALITY, FLT_MIN, FLT_MAX, -1.0, 0, 1)
@@ -173,6 +187,8 @@ _SIGS = {
                                                   C.c_int, _P(RawImage)]),
     "uhdr_hip_apply_gainmap_coef_dev": (ErrorInfo, [C.c_void_p, _P(JpegCoefficients), C.c_uint, C.c_uint, C.c_int, _P(RawImage), _P(GainmapMetadata),
                                                     C.c_int, C.c_int, C.c_float, _P(RawImage)]),
+    "uhdr_hip_huffman_encode_dev": (ErrorInfo, [C.c_void_p, _P(JpegScan), C.c_void_p, C.c_size_t, _P(C.c_size_t)]),
+    "uhdr_hip_jpeg_assemble": (C.c_size_t, [_P(JpegScan), _P(C.c_uint16), _P(C.c_uint16), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "uhdr_hip_profile_enable": (None, [C.c_void_p, C.c_int]),
     "uhdr_hip_profile_read": (C.c_int, [C.c_void_p, C.c_char_p, _P(C.c_double), C.c_int]),
 }

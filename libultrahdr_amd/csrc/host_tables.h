@@ -50,5 +50,11 @@ void fill_idw(float* w, int s, int inc_r, int inc_b);  // gainmapmath.cpp:43-80
 // force_baseline; natural order)
 void jpeg_quant_table(int quality, int is_chroma, uint16_t qt[64]);
 
+// baseline Huffman stage (T.81 Annex K.3 tables, Annex C codes)
+constexpr int kHuffTabWords = 2 * (16 + 256);
+const uint8_t* jpeg_zigzag_to_natural();  // 64 entries
+int jpeg_std_huff_table(int is_ac, int is_chroma, uint8_t bits[17], uint8_t vals[256]);  // returns the number of symbols
+const std::vector<uint32_t>& jpeg_huff_code_tables();  // kHuffTabWords packed entries (length << 16 | code)
+
 }  // namespace host
 }  // namespace uhdr

@@ -1,0 +1,273 @@
+// Baseline Huffman entropy coding on gfx950 (the step after fdct_quant).
+//
+// In the reference this is libjpeg behind JpegEncoderHelper::compressImage
+// (/root/reference/lib/src/jpegencoderhelper.cpp:131-244): one sequential pass over all MCUs with the Annex K
+// tables, DC prediction chaining every block to its predecessor, no restart markers -- inherently serial.
+// JPEG's own mechanism for cutting that chain is the restart interval (ITU-T T.81 B.2.4.4 / E.1.4): every
+// `restart_interval` MCUs the bit stream is padded to a byte boundary, an RSTn marker is written and the DC
+// predictors return to zero, so the intervals are independent.  That changes the bytes (a DRI segment and the RSTn
+// markers) but not a single decoded coefficient -- the parity policy here is: for a given restart interval the
+// entropy-coded segment equals, byte for byte, what libjpeg emits for the same coefficients with the same
+// cinfo.restart_interval (the oracle's restatement of jchuff.c, itself pinned against the reference encoder at
+// restart_interval 0 and through libjpeg's decoder at all others).
+//
+// Mapping: one wavefront = one restart interval, one lane = one 8x8 block (<= 64 blocks per interval).
+//   1. the lane stages its block's 64 coefficients in LDS (rows of 33 words: conflict-free zig-zag reads) and the
+//      interval's DC values are exchanged through LDS (prediction, libjpeg's dummy-block rule at the image edges);
+//   2. a first walk over the block in zig-zag order adds up the code lengths (DC size category, run/size symbols,
+//      ZRL, EOB); a wave prefix sum turns them into bit offsets inside the interval;
+//   3. a second walk emits the bits into the interval's LDS bit buffer (MSB first; words are OR-ed in, the first and
+//      last word of a lane are shared with its neighbours);
+//   4. the buffer is padded with one bits to a byte boundary, byte-stuffed (0xFF -> 0xFF 0x00, positions from a wave
+//      prefix sum of the 0xFF counts) and written to the interval's slot in device memory.
+// A second, tiny kernel turns the interval sizes into offsets; a third copies the slots into the final stream with
+// the RSTn markers in between.
+#include "uhdr_types.h"
+
+namespace uhdr {
+namespace {
+
+constexpr int kSegBlocks = 64;       // blocks per restart interval = lanes
+constexpr int kWordsPerBlock = 52;   // 1664 bits >= the worst case of a baseline block (11 + 11 + 63 * (16 + 10) = 1660)
+constexpr int kCoefRow = 33;         // LDS words per staged block (64 halfwords + 1 word of padding)
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t y = (uint32_t)__shfl_up((int)v, d, 64);
+    if (lane >= (uint32_t)d) v += y;
+  }
+  return v;
+}
+
+// jchuff.c encode_one_block as a walk that reports every (code, length) pair to `put`
+template <typename Put>
+__device__ __forceinline__ void walk_block(const uint32_t* dct, const uint32_t* act, int dc_diff, bool real, const uint32_t* coef_row,
+                                           const uint8_t* zz, uint32_t& out_of_range, Put put) {
+  int temp = dc_diff, temp2 = dc_diff;
+  if (temp < 0) { temp = -temp; temp2--; }
+  uint32_t nbits = 32u - (uint32_t)__clz(temp);  // 0 for temp == 0
+  out_of_range |= nbits > 11u;                   // jchuff.c: ERREXIT(JERR_BAD_DCT_COEF) beyond MAX_COEF_BITS + 1
+  uint32_t e = dct[nbits & 15u];
+  put(e & 0xffffu, e >> 16);
+  if (nbits) put((uint32_t)temp2 & ((1u << nbits) - 1u), nbits);
+  uint32_t r = 0;
+  if (real) {
+    for (int k = 1; k < 64; k++) {
+      const uint32_t idx = zz[k];
+      const uint32_t wd = coef_row[idx >> 1];
+      temp = (idx & 1u) ? ((int)wd >> 16) : (int)(int16_t)(wd & 0xffffu);
+      if (temp == 0) { r++; continue; }
+      while (r > 15) {
+        e = act[0xf0];
+        put(e & 0xffffu, e >> 16);
+        r -= 16;
+      }
+      temp2 = temp;
+      if (temp < 0) { temp = -temp; temp2--; }
+      nbits = 32u - (uint32_t)__clz(temp);
+      out_of_range |= nbits > 10u;  // MAX_COEF_BITS
+      e = act[((r << 4) + nbits) & 255u];
+      put(e & 0xffffu, e >> 16);
+      put((uint32_t)temp2 & ((1u << (nbits & 31u)) - 1u), nbits);
+      r = 0;
+    }
+  } else {
+    r = 63;  // dummy block: all AC terms zero
+  }
+  if (r > 0) {
+    e = act[0];
+    put(e & 0xffffu, e >> 16);
+  }
+}
+
+__global__ __launch_bounds__(64) void huff_encode_kernel(const HuffArgs a) {
+  __shared__ uint32_t s_tab[2 * (16 + 256)];
+  __shared__ uint32_t s_coef[kSegBlocks * kCoefRow];
+  __shared__ uint32_t s_bits[kSegBlocks * kWordsPerBlock + 2];
+  __shared__ int s_dc[kSegBlocks];
+  __shared__ int s_real[kSegBlocks];
+  __shared__ uint8_t s_zz[64];
+  const uint32_t lane = threadIdx.x;
+  for (uint32_t i = lane; i < 2 * (16 + 256); i += 64) s_tab[i] = a.tables[i];
+  s_zz[lane] = a.zigzag[lane];
+  const int bpm = a.blocks_per_mcu;
+
+  for (int seg = (int)blockIdx.x; seg < a.nseg; seg += (int)gridDim.x) {
+    __syncthreads();  // the previous interval's LDS contents are dead
+    // ---- which block is this lane's? -------------------------------------------------------------------------
+    const int mcu_local = (int)lane / bpm, k_in_mcu = (int)lane - mcu_local * bpm;
+    const int mcu = seg * a.ri + mcu_local;
+    const bool active = mcu_local < a.ri && mcu < a.total_mcus;
+    int c = 0, kk = k_in_mcu;
+    if (a.ncomp > 1) {
+      while (c < a.ncomp - 1 && kk >= a.hs[c] * a.vs[c]) { kk -= a.hs[c] * a.vs[c]; c++; }
+    }
+    const int hs = a.ncomp > 1 ? a.hs[c] : 1, vs = a.ncomp > 1 ? a.vs[c] : 1;
+    const int yi = kk / hs, xi = kk - yi * hs;
+    const int my = mcu / a.mcus_per_row, mx = mcu - my * a.mcus_per_row;
+    const int by = my * vs + yi, bx = mx * hs + xi;
+    const bool real = active && by < a.bh[c] && bx < a.bw[c];
+    uint32_t* crow = s_coef + lane * kCoefRow;
+    if (real) {
+      const uint4* src = (const uint4*)(a.coef[c] + ((size_t)by * a.bw[c] + bx) * 64);
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const uint4 q = src[i];
+        crow[4 * i] = q.x; crow[4 * i + 1] = q.y; crow[4 * i + 2] = q.z; crow[4 * i + 3] = q.w;
+      }
+    }
+    s_real[lane] = real ? 1 : 0;
+    s_dc[lane] = real ? (int)(int16_t)(crow[0] & 0xffffu) : 0;
+    __syncthreads();
+    // dummy blocks (jctrans.c compress_output): DC of the previous block of the MCU; the first block of a component
+    // inside an MCU is always real, so the search is bounded by the component's block count
+    int dcv = s_dc[lane];
+    if (active && !real) {
+      for (int d = 1; d <= 3; d++) {
+        if ((int)lane >= d && s_real[lane - d]) { dcv = s_dc[lane - d]; break; }
+      }
+    }
+    __syncthreads();
+    s_dc[lane] = dcv;
+    __syncthreads();
+    // DC prediction: the previous block of the same component inside the interval (0 at its start)
+    int pred = 0;
+    if (active) {
+      if (kk > 0) pred = s_dc[lane - 1];
+      else if (mcu_local > 0) pred = s_dc[(int)lane - bpm + hs * vs - 1];
+    }
+    const uint32_t* dct = s_tab + (c ? (16 + 256) : 0);
+    const uint32_t* act = dct + 16;
+    const int diff = dcv - pred;
+
+    // ---- pass 1: code lengths -> bit offsets -----------------------------------------------------------------------
+    uint32_t len = 0, oob = 0;
+    if (active) walk_block(dct, act, diff, real, crow, s_zz, oob, [&](uint32_t, uint32_t n) { len += n; });
+    const uint32_t incl = wave_incl_scan(len, lane);
+    const uint32_t total_bits = (uint32_t)__shfl((int)incl, 63, 64);
+    const uint32_t off = incl - len;
+    const uint32_t cap_bits = (uint32_t)(kSegBlocks * kWordsPerBlock) * 32u;
+    if (total_bits > cap_bits || __builtin_amdgcn_ballot_w64(oob != 0) != 0) {  // coefficients outside the baseline range: report, do not write
+      if (lane == 0) a.seg_bytes[seg] = 0xFFFFFFFFu;
+      continue;
+    }
+    const uint32_t nwords = (total_bits + 31u) / 32u + 1u;
+    for (uint32_t i = lane; i < nwords; i += 64) s_bits[i] = 0u;
+    __syncthreads();
+
+    // ---- pass 2: emit ------------------------------------------------------------------------------------------------
+    if (active) {
+      uint64_t acc = 0;
+      uint32_t cnt = off & 31u, w = off >> 5;
+      walk_block(dct, act, diff, real, crow, s_zz, oob, [&](uint32_t code, uint32_t n) {
+        acc = (acc << n) | (uint64_t)code;
+        cnt += n;
+        if (cnt >= 32u) {
+          cnt -= 32u;
+          atomicOr(&s_bits[w++], (uint32_t)(acc >> cnt));
+        }
+      });
+      if (cnt) atomicOr(&s_bits[w], (uint32_t)(acc << (32u - cnt)));
+    }
+    __syncthreads();
+    // flush_bits: fill the last partial byte with ones
+    if (lane == 0 && (total_bits & 7u)) {
+      const uint32_t pad = 8u - (total_bits & 7u), pos = total_bits & 31u;
+      atomicOr(&s_bits[total_bits >> 5], ((1u << pad) - 1u) << (32u - pos - pad));
+    }
+    __syncthreads();
+
+    // ---- byte stuffing + store -----------------------------------------------------------------------------------------
+    const uint32_t nbytes = (total_bits + 7u) >> 3;
+    uint8_t* dst = a.slots + (size_t)seg * a.slot_stride;
+    uint32_t carry = 0;  // 0xFF bytes before this chunk
+    for (uint32_t base = 0; base < nbytes; base += 256) {
+      const uint32_t i0 = base + lane * 4;
+      const uint32_t wd = i0 < nbytes ? s_bits[i0 >> 2] : 0u;
+      const uint32_t nv = i0 < nbytes ? min(nbytes - i0, 4u) : 0u;
+      uint32_t b[4], nff = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        b[k] = (wd >> (24 - 8 * k)) & 0xffu;
+        if ((uint32_t)k < nv && b[k] == 0xffu) nff++;
+      }
+      const uint32_t incl_ff = wave_incl_scan(nff, lane);
+      uint32_t pos = i0 + carry + (incl_ff - nff);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if ((uint32_t)k < nv) {
+          dst[pos++] = (uint8_t)b[k];
+          if (b[k] == 0xffu) dst[pos++] = 0;
+        }
+      }
+      carry += (uint32_t)__shfl((int)incl_ff, 63, 64);
+    }
+    if (lane == 0) a.seg_bytes[seg] = nbytes + carry;
+  }
+}
+
+// offsets[s] = sum over t < s of (seg_bytes[t] + 2)  (an RSTn marker follows every interval but the last);
+// offsets[nseg] = total length; status = 1 when an interval reported out-of-range coefficients
+__global__ __launch_bounds__(1024) void huff_offsets_kernel(const uint32_t* __restrict__ seg_bytes, int nseg, uint64_t* __restrict__ offsets,
+                                                            uint32_t* __restrict__ status) {
+  __shared__ uint64_t s_sum[1024];
+  __shared__ uint32_t s_bad;
+  const int tid = (int)threadIdx.x;
+  if (tid == 0) s_bad = 0;
+  __syncthreads();
+  const int per = (nseg + 1023) / 1024, lo = min(tid * per, nseg), hi = min(lo + per, nseg);
+  uint64_t sum = 0;
+  bool bad = false;
+  for (int i = lo; i < hi; i++) {
+    const uint32_t n = seg_bytes[i];
+    bad |= n == 0xFFFFFFFFu;
+    sum += (uint64_t)n + 2u;
+  }
+  if (bad) atomicOr(&s_bad, 1u);
+  s_sum[tid] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan
+    const uint64_t y = tid >= d ? s_sum[tid - d] : 0;
+    __syncthreads();
+    s_sum[tid] += y;
+    __syncthreads();
+  }
+  uint64_t run = s_sum[tid] - sum;
+  for (int i = lo; i < hi; i++) {
+    offsets[i] = run;
+    run += (uint64_t)seg_bytes[i] + 2u;
+  }
+  if (tid == 1023) offsets[nseg] = s_sum[1023] - 2u;  // no marker after the last interval
+  if (tid == 0) *status = s_bad;
+}
+
+__global__ __launch_bounds__(256) void huff_gather_kernel(const uint8_t* __restrict__ slots, uint32_t slot_stride,
+                                                          const uint32_t* __restrict__ seg_bytes, const uint64_t* __restrict__ offsets, int nseg,
+                                                          uint8_t* __restrict__ out, uint64_t cap) {
+  for (int seg = (int)blockIdx.x; seg < nseg; seg += (int)gridDim.x) {
+    const uint32_t n = seg_bytes[seg];
+    const uint64_t off = offsets[seg];
+    if (n == 0xFFFFFFFFu || off + n + 2u > cap + (seg == nseg - 1 ? 2u : 0u)) continue;  // the host reports the error
+    const uint8_t* src = slots + (size_t)seg * slot_stride;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) out[off + i] = src[i];
+    if (threadIdx.x == 0 && seg < nseg - 1) {
+      out[off + n] = 0xff;
+      out[off + n + 1] = (uint8_t)(0xd0 + (seg & 7));  // emit_restart: RST0..RST7 in rotation
+    }
+  }
+}
+
+}  // namespace
+
+uint32_t huff_slot_stride() { return (uint32_t)(kSegBlocks * kWordsPerBlock * 4 * 2); }  // every byte could be stuffed
+
+hipError_t launch_huffman_encode(const HuffArgs& a, uint64_t* offsets, uint32_t* status, uint8_t* out, uint64_t cap, hipStream_t s) {
+  int grid = a.nseg < 8192 ? a.nseg : 8192;
+  hipLaunchKernelGGL(huff_encode_kernel, dim3(grid), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(huff_offsets_kernel, dim3(1), dim3(1024), 0, s, a.seg_bytes, a.nseg, offsets, status);
+  hipLaunchKernelGGL(huff_gather_kernel, dim3(grid), dim3(256), 0, s, a.slots, a.slot_stride, a.seg_bytes, offsets, a.nseg, out, cap);
+  return hipGetLastError();
+}
+
+}  // namespace uhdr

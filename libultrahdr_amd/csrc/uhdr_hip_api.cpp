@@ -91,6 +91,7 @@ struct uhdr_hip_ctx {
   FramePtrs* d_frames = nullptr;  // batch frame-pointer tables (rotating slots)
   size_t frames_cap = 0;
   unsigned int frames_next = 0;
+  uint32_t* d_huff = nullptr;     // Annex K code tables (kHuffTabWords) followed by the 64-byte zig-zag map
   CoefSrc* d_coef_src = nullptr;  // apply_gainmap_coef descriptors (rotating slots)
   unsigned int coef_src_next = 0;
   // profiling
@@ -418,6 +419,7 @@ void uhdr_hip_destroy(uhdr_hip_ctx_t* c) {
   if (c->minmax.p) (void)hipFree(c->minmax.p);
   if (c->d_frames) (void)hipFree(c->d_frames);
   if (c->d_coef_src) (void)hipFree(c->d_coef_src);
+  if (c->d_huff) (void)hipFree(c->d_huff);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -1439,6 +1441,151 @@ uhdr_error_info_t uhdr_hip_idct_dequant_rgb_dev(uhdr_hip_ctx_t* c, const int16_t
   ProfScope ps(c, "idct_dequant");
   HIP_TRY(launch_idct_dequant_rgb(coef_y, coef_cb, coef_cr, bw, bh, qt_luma, qt_chroma, variant, view_mut_of(rgb), c->stream));
   return ok_status();
+}
+
+// -------------------------------------------------------------------------------------------------
+// JPEG entropy stage: baseline Huffman coding of coefficient blocks, one restart interval per wavefront
+// -------------------------------------------------------------------------------------------------
+static uhdr_error_info_t check_scan(const uhdr_hip_jpeg_scan_t* sc, bool need_coef, int* mcus_per_row, int* mcu_rows, int* blocks_per_mcu) {
+  if (!sc) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for the scan description");
+  if (sc->num_components != 1 && sc->num_components != 3)
+    return err_status(UHDR_CODEC_INVALID_PARAM, "a scan has 1 or 3 components, received %d", sc->num_components);
+  if (sc->w == 0 || sc->h == 0 || sc->w > 65535 || sc->h > 65535)
+    return err_status(UHDR_CODEC_INVALID_PARAM, "image dimensions %ux%u are outside JPEG's 1..65535", sc->w, sc->h);
+  int hmax = 1, vmax = 1, bpm = 0;
+  for (int i = 0; i < sc->num_components; i++) {
+    const int hs = sc->num_components == 1 ? 1 : sc->h_samp[i], vs = sc->num_components == 1 ? 1 : sc->v_samp[i];
+    if (hs < 1 || hs > 2 || vs < 1 || vs > 2) return err_status(UHDR_CODEC_INVALID_PARAM, "component %d: sampling factors %dx%d not in {1, 2}", i, hs, vs);
+    if (hs > hmax) hmax = hs;
+    if (vs > vmax) vmax = vs;
+    bpm += hs * vs;
+    if (need_coef && (!sc->coef[i] || ((uintptr_t)sc->coef[i] & 15)))
+      return err_status(UHDR_CODEC_INVALID_PARAM, "coefficient buffer %d is null or not 16-byte aligned", i);
+    if (sc->blocks_w[i] < 1 || sc->blocks_h[i] < 1) return err_status(UHDR_CODEC_INVALID_PARAM, "component %d: empty block grid", i);
+  }
+  if (sc->num_components == 1) {  // non-interleaved: an MCU is one block (jcmaster.c per_scan_setup)
+    *mcus_per_row = sc->blocks_w[0];
+    *mcu_rows = sc->blocks_h[0];
+    if ((unsigned)sc->blocks_w[0] != (sc->w + 7) / 8 || (unsigned)sc->blocks_h[0] != (sc->h + 7) / 8)
+      return err_status(UHDR_CODEC_INVALID_PARAM, "a %dx%d block grid does not match a %ux%u image", sc->blocks_w[0], sc->blocks_h[0], sc->w, sc->h);
+  } else {
+    *mcus_per_row = (int)((sc->w + 8u * hmax - 1) / (8u * hmax));
+    *mcu_rows = (int)((sc->h + 8u * vmax - 1) / (8u * vmax));
+    for (int i = 0; i < 3; i++) {
+      // jpeg_component_info::width_in_blocks (real blocks; libjpeg pads MCUs with dummy blocks) up to the MCU-padded grid
+      const unsigned cw = (sc->w * sc->h_samp[i] + hmax - 1) / hmax, chh = (sc->h * sc->v_samp[i] + vmax - 1) / vmax;
+      const int min_w = (int)((cw + 7) / 8), min_h = (int)((chh + 7) / 8);
+      if (sc->blocks_w[i] < min_w || sc->blocks_w[i] > *mcus_per_row * sc->h_samp[i] || sc->blocks_h[i] < min_h ||
+          sc->blocks_h[i] > *mcu_rows * sc->v_samp[i])
+        return err_status(UHDR_CODEC_INVALID_PARAM, "component %d: a %dx%d block grid does not match a %ux%u image at %dx%d sampling", i,
+                          sc->blocks_w[i], sc->blocks_h[i], sc->w, sc->h, sc->h_samp[i], sc->v_samp[i]);
+    }
+  }
+  *blocks_per_mcu = bpm;
+  return ok_status();
+}
+
+uhdr_error_info_t uhdr_hip_huffman_encode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_jpeg_scan_t* sc, uint8_t* out, size_t out_capacity,
+                                              size_t* out_bytes) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  if (!out || !out_bytes) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for the output buffer or size");
+  int mpr = 0, mrows = 0, bpm = 0;
+  UHDR_TRY(check_scan(sc, true, &mpr, &mrows, &bpm));
+  if (sc->restart_interval < 1 || sc->restart_interval > 65535 || sc->restart_interval * bpm > 64)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "restart_interval must be in 1..%d for %d blocks per MCU (one wavefront encodes one "
+                      "restart interval of at most 64 blocks); received %d", 64 / bpm, bpm, sc->restart_interval);
+  HIP_TRY(hipSetDevice(c->device));
+  if (!c->d_huff) {
+    std::vector<uint32_t> blob(host::jpeg_huff_code_tables());
+    blob.resize((size_t)host::kHuffTabWords + 16);
+    memcpy(blob.data() + host::kHuffTabWords, host::jpeg_zigzag_to_natural(), 64);
+    HIP_TRY(hipMalloc((void**)&c->d_huff, blob.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpyAsync(c->d_huff, blob.data(), blob.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  HuffArgs a;
+  memset(&a, 0, sizeof a);
+  a.ncomp = sc->num_components;
+  for (int i = 0; i < a.ncomp; i++) {
+    a.coef[i] = sc->coef[i];
+    a.bw[i] = sc->blocks_w[i]; a.bh[i] = sc->blocks_h[i];
+    a.hs[i] = a.ncomp == 1 ? 1 : sc->h_samp[i]; a.vs[i] = a.ncomp == 1 ? 1 : sc->v_samp[i];
+  }
+  a.mcus_per_row = mpr;
+  a.total_mcus = mpr * mrows;
+  a.ri = sc->restart_interval;
+  a.blocks_per_mcu = bpm;
+  a.nseg = (a.total_mcus + a.ri - 1) / a.ri;
+  a.tables = c->d_huff;
+  a.zigzag = (const uint8_t*)(c->d_huff + host::kHuffTabWords);
+  a.slot_stride = huff_slot_stride();
+  // scratch: interval slots | interval sizes | offsets (nseg + 1) | status
+  UHDR_TRY(ensure(c->scratch[4], (size_t)a.nseg * a.slot_stride));
+  const size_t meta = (size_t)a.nseg * sizeof(uint32_t) + 16 + ((size_t)a.nseg + 1) * sizeof(uint64_t) + 16;
+  UHDR_TRY(ensure(c->scratch[5], meta));
+  a.slots = (uint8_t*)c->scratch[4].p;
+  uint64_t* offsets = (uint64_t*)c->scratch[5].p;                       // 8-byte aligned first
+  uint32_t* status = (uint32_t*)(offsets + (size_t)a.nseg + 1);
+  a.seg_bytes = status + 2;
+  {
+    ProfScope ps(c, "huffman_encode");
+    HIP_TRY(launch_huffman_encode(a, offsets, status, out, (uint64_t)out_capacity, c->stream));
+  }
+  uint64_t total = 0;
+  uint32_t bad = 0;
+  HIP_TRY(hipMemcpyAsync(&total, offsets + a.nseg, sizeof total, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(&bad, status, sizeof bad, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (bad) return err_status(UHDR_CODEC_INVALID_PARAM, "coefficients outside the baseline range (DC difference beyond 11 bits / AC beyond 10 bits)");
+  *out_bytes = (size_t)total;
+  if (total > out_capacity)
+    return err_status(UHDR_CODEC_MEM_ERROR, "entropy-coded data needs %llu bytes, the output buffer holds %zu", (unsigned long long)total, out_capacity);
+  return ok_status();
+}
+
+// Host helper: a complete baseline JFIF file around entropy-coded data (marker order of jcmarker.c: SOI, APP0, DQT,
+// SOF0, DHT, DRI, SOS ... EOI).  Returns the file size, or 0 when `cap` is too small / the description is invalid.
+size_t uhdr_hip_jpeg_assemble(const uhdr_hip_jpeg_scan_t* sc, const uint16_t qt_luma[64], const uint16_t qt_chroma[64], const uint8_t* scan_data,
+                              size_t scan_bytes, uint8_t* out, size_t cap) {
+  int mpr = 0, mrows = 0, bpm = 0;
+  if (check_scan(sc, false, &mpr, &mrows, &bpm).error_code != UHDR_CODEC_OK || !qt_luma || !scan_data || !out) return 0;
+  if (sc->num_components > 1 && !qt_chroma) return 0;
+  const int nc = sc->num_components, ntab = nc > 1 ? 2 : 1;
+  const uint8_t* zz = host::jpeg_zigzag_to_natural();
+  std::vector<uint8_t> v;
+  v.reserve(scan_bytes + 1024);
+  auto put = [&](unsigned b) { v.push_back((uint8_t)b); };
+  auto put16 = [&](unsigned x) { put(x >> 8); put(x & 0xff); };
+  put(0xff); put(0xd8);
+  put(0xff); put(0xe0); put16(16); for (char ch : {'J', 'F', 'I', 'F'}) put((unsigned char)ch); put(0); put(1); put(1); put(0); put16(1); put16(1); put(0); put(0);
+  for (int t = 0; t < ntab; t++) {
+    const uint16_t* q = t ? qt_chroma : qt_luma;
+    put(0xff); put(0xdb); put16(67); put(t);
+    for (int i = 0; i < 64; i++) {
+      if (q[zz[i]] == 0 || q[zz[i]] > 255) return 0;  // baseline: 8-bit tables
+      put(q[zz[i]]);
+    }
+  }
+  put(0xff); put(0xc0); put16(8 + 3 * nc); put(8); put16(sc->h); put16(sc->w); put(nc);
+  for (int i = 0; i < nc; i++) { put(i + 1); put(((nc == 1 ? 1 : sc->h_samp[i]) << 4) | (nc == 1 ? 1 : sc->v_samp[i])); put(i ? 1 : 0); }
+  for (int t = 0; t < ntab; t++) {
+    for (int ac = 0; ac < 2; ac++) {
+      uint8_t bits[17], vals[256];
+      const int nv = host::jpeg_std_huff_table(ac, t, bits, vals);
+      put(0xff); put(0xc4); put16(2 + 1 + 16 + nv); put((ac << 4) | t);
+      for (int i = 1; i <= 16; i++) put(bits[i]);
+      for (int i = 0; i < nv; i++) put(vals[i]);
+    }
+  }
+  if (sc->restart_interval > 0) { put(0xff); put(0xdd); put16(4); put16((unsigned)sc->restart_interval); }
+  put(0xff); put(0xda); put16(6 + 2 * nc); put(nc);
+  for (int i = 0; i < nc; i++) { put(i + 1); put(i ? 0x11 : 0x00); }
+  put(0); put(63); put(0);
+  v.insert(v.end(), scan_data, scan_data + scan_bytes);
+  put(0xff); put(0xd9);
+  if (v.size() > cap) return 0;
+  memcpy(out, v.data(), v.size());
+  return v.size();
 }
 
 }  // extern "C"

@@ -179,6 +179,25 @@ hipError_t launch_fdct_quant_rgb(const uint8_t* rgb, size_t pitch, int bpp, int 
                                  const uint16_t* qt_chroma_host, int16_t* coef_y, int16_t* coef_cb, int16_t* coef_cr, hipStream_t s);
 hipError_t launch_repack(int mode, const void* src, size_t src_pitch, void* dst, size_t dst_pitch, uint32_t w, uint32_t h,
                          hipStream_t s);  // 0: RGB888 -> RGBA8888, 1: RGBA8888 -> Y400
+// ---- baseline Huffman entropy coding (huffman_encode.hip) -------------------------------------------
+struct HuffArgs {
+  const int16_t* coef[3];  // JBLOCK arrays of bw x bh REAL blocks
+  int bw[3], bh[3];
+  int hs[3], vs[3];        // sampling factors (ncomp > 1)
+  int ncomp;
+  int mcus_per_row, total_mcus;
+  int ri;                  // MCUs per restart interval
+  int blocks_per_mcu;
+  int nseg;                // restart intervals
+  const uint32_t* tables;  // host::jpeg_huff_code_tables()
+  const uint8_t* zigzag;   // zig-zag position -> natural index
+  uint8_t* slots;          // nseg x slot_stride bytes of scratch
+  uint32_t slot_stride;
+  uint32_t* seg_bytes;     // [nseg] stuffed bytes per interval (0xFFFFFFFF: coefficients outside the baseline range)
+};
+uint32_t huff_slot_stride();
+hipError_t launch_huffman_encode(const HuffArgs& a, uint64_t* offsets, uint32_t* status, uint8_t* out, uint64_t cap, hipStream_t s);
+
 hipError_t launch_idct_dequant(const int16_t* coef, int bw, int bh, const uint16_t* qt_host, uint8_t* plane,
                                size_t stride, hipStream_t s);
 hipError_t launch_idct_dequant_rgb(const int16_t* coef_y, const int16_t* coef_cb, const int16_t* coef_cr, int bw, int bh,

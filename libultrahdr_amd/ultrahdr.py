@@ -237,6 +237,46 @@ class UltraHdr:
         A.check(self.lib.uhdr_hip_fdct_quant_rgb_dev(self.ctx.handle, C.byref(rgb.raw), ql, qc, *[C.c_void_p(o.data_ptr()) for o in outs]))
         return outs
 
+    # ---- entropy stage ------------------------------------------------------------------
+    @staticmethod
+    def _scan(coefs, w, h, sampling, restart_interval) -> "A.JpegScan":
+        sc = A.JpegScan()
+        sc.num_components = len(coefs)
+        for i, cf in enumerate(coefs):
+            sc.coef[i] = cf.data_ptr() if hasattr(cf, "data_ptr") else None
+            sc.blocks_h[i], sc.blocks_w[i] = int(cf.shape[0]), int(cf.shape[1])
+            sc.h_samp[i], sc.v_samp[i] = sampling[i]
+        sc.w, sc.h, sc.restart_interval = w, h, restart_interval
+        return sc
+
+    def huffman_encode(self, coefs, w: int, h: int, sampling, restart_interval: int, out=None):
+        """Baseline Huffman coding (Annex K tables) of quantized coefficients: coefs = int16 [blocks_h, blocks_w, 64] CUDA
+        tensors per component, sampling = [(h, v)] per component, restart_interval in MCUs (one wavefront per interval).
+        Returns a uint8 CUDA tensor holding the entropy-coded data (between the SOS header and EOI, RSTn markers included)."""
+        import torch
+
+        assert all(c.is_cuda for c in coefs)
+        sc = self._scan(coefs, w, h, sampling, restart_interval)
+        if out is None:
+            # worst case: 1660 bits per block, every byte stuffed
+            out = torch.empty(sum(int(c.numel()) for c in coefs) // 64 * 416 + 4096, dtype=torch.uint8, device=coefs[0].device)
+            torch.cuda.current_stream(out.device).synchronize()
+        n = C.c_size_t(0)
+        A.check(self.lib.uhdr_hip_huffman_encode_dev(self.ctx.handle, C.byref(sc), C.c_void_p(out.data_ptr()), out.numel(), C.byref(n)))
+        return out[: n.value]
+
+    def jpeg_assemble(self, coefs, w: int, h: int, sampling, restart_interval: int, qt_luma, qt_chroma, scan_data: bytes) -> bytes:
+        """Host helper: a complete baseline JFIF file around entropy-coded data (coefs only supply the block grids)."""
+        sc = self._scan(coefs, w, h, sampling, restart_interval)
+        ql = (C.c_uint16 * 64)(*[int(v) for v in qt_luma])
+        qc = (C.c_uint16 * 64)(*[int(v) for v in qt_chroma])
+        src = np.frombuffer(scan_data, dtype=np.uint8)
+        out = np.zeros(src.size + 2048, dtype=np.uint8)
+        n = self.lib.uhdr_hip_jpeg_assemble(C.byref(sc), ql, qc, C.c_void_p(src.ctypes.data), src.size, C.c_void_p(out.ctypes.data), out.size)
+        if n == 0:
+            raise ValueError("uhdr_hip_jpeg_assemble rejected the scan description")
+        return out[:n].tobytes()
+
     def idct_dequant(self, coef, qtable: np.ndarray, plane=None, stride: int = 0):
         """Inverse of fdct_quant.  coef: int16 [blocks_h, blocks_w, 64] numpy array (host) or CUDA
         tensor (device).  Returns the uint8 plane [blocks_h*8, stride] (stride defaults to blocks_w*8)."""

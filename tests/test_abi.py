@@ -142,3 +142,38 @@ def test_public_headers_compile_as_plain_c_and_cpp(tmp_path):
     cpp = tmp_path / "cpp.cpp"
     cpp.write_text('#include "uhdr_hip.hpp"\nint main() { uhdr_hip::UltraHdr* p = nullptr; (void)p; return 0; }\n')
     subprocess.run(["g++", "-std=c++14", "-Wall", "-Wextra", "-Werror", "-I", inc, "-fsyntax-only", str(cpp)], check=True)
+
+
+def test_jpeg_assemble_host_entry_point():
+    """uhdr_hip_jpeg_assemble is pure host code: the file it writes around entropy-coded data equals the oracle's, byte
+    for byte (4:2:0 with a restart interval, one component without), and bad descriptions are refused."""
+    from oracle import loader as L
+
+    lib = A.load()
+    rng = np.random.default_rng(3)
+    for (w, h, sampling, ri) in ((72, 40, [(2, 2), (1, 1), (1, 1)], 3), (37, 19, [(1, 1)], 0), (64, 32, [(1, 1)] * 3, 7)):
+        hmax, vmax = max(s[0] for s in sampling), max(s[1] for s in sampling)
+        coefs = []
+        for hs, vs in sampling:
+            cw, chh = -(-w * hs // hmax), -(-h * vs // vmax)
+            a = (rng.normal(0, 20, (-(-chh // 8), -(-cw // 8), 64)) * (rng.random((-(-chh // 8), -(-cw // 8), 64)) < 0.3)).astype(np.int16)
+            coefs.append(np.ascontiguousarray(a))
+        ql, qc = L.quant_table_port(80, False), L.quant_table_port(80, True)
+        scan = L.huffman_encode_port(coefs, w, h, sampling, ri)
+        want = L.jpeg_assemble_port(coefs, w, h, sampling, ri, ql, qc, scan)
+        sc = A.JpegScan()
+        sc.num_components = len(coefs)
+        for i, cf in enumerate(coefs):
+            sc.blocks_h[i], sc.blocks_w[i] = cf.shape[0], cf.shape[1]
+            sc.h_samp[i], sc.v_samp[i] = sampling[i]
+        sc.w, sc.h, sc.restart_interval = w, h, ri
+        src = np.frombuffer(scan, dtype=np.uint8)
+        out = np.zeros(src.size + 2048, dtype=np.uint8)
+        n = lib.uhdr_hip_jpeg_assemble(C.byref(sc), (C.c_uint16 * 64)(*ql.tolist()), (C.c_uint16 * 64)(*qc.tolist()), src.ctypes.data, src.size,
+                                       out.ctypes.data, out.size)
+        assert n == len(want) and out[:n].tobytes() == want
+        assert lib.uhdr_hip_jpeg_assemble(C.byref(sc), (C.c_uint16 * 64)(*ql.tolist()), (C.c_uint16 * 64)(*qc.tolist()), src.ctypes.data, src.size,
+                                          out.ctypes.data, 100) == 0  # capacity
+        sc.blocks_w[0] += 5
+        assert lib.uhdr_hip_jpeg_assemble(C.byref(sc), (C.c_uint16 * 64)(*ql.tolist()), (C.c_uint16 * 64)(*qc.tolist()), src.ctypes.data, src.size,
+                                          out.ctypes.data, out.size) == 0  # block grid of another image

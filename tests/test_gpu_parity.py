@@ -555,6 +555,108 @@ def test_apply_gainmap_from_coefficients_corrupt_and_errors(uhdr):
     assert e.value.code == A.UHDR_CODEC_UNSUPPORTED_FEATURE
 
 
+# ---- entropy stage ----------------------------------------------------------------------------------
+def _random_coefs(rng, w, h, sampling, kind):
+    hmax, vmax = max(s[0] for s in sampling), max(s[1] for s in sampling)
+    coefs = []
+    for hs, vs in sampling:
+        cw, chh = -(-w * hs // hmax), -(-h * vs // vmax)
+        bw, bh = -(-cw // 8), -(-chh // 8)
+        if kind == "sparse":  # what a q ~ 90 photo looks like: few non-zero terms, long zero runs (ZRL), many EOBs
+            a = (rng.normal(0, 25, (bh, bw, 64)) * (rng.random((bh, bw, 64)) < 0.12)).astype(np.int16)
+            a[..., 0] = rng.integers(-1000, 1000, (bh, bw))
+            a[..., 63] = np.where(rng.random((bh, bw)) < 0.3, 1, a[..., 63])  # runs of > 16 zeros ending in the last term
+        elif kind == "dense":  # every term non-zero, all size categories
+            a = rng.integers(-1023, 1024, (bh, bw, 64)).astype(np.int16)
+            a[a == 0] = 1
+        elif kind == "worst":  # 16-bit codes + 10 magnitude bits for every AC term: 1660 bits per block
+            a = np.full((bh, bw, 64), 1023, dtype=np.int16)
+            a[..., 1::2] = -1023
+            a[..., 0] = np.where(rng.random((bh, bw)) < 0.5, 1023, -1024)
+        else:  # "zero": only EOBs
+            a = np.zeros((bh, bw, 64), dtype=np.int16)
+        coefs.append(np.ascontiguousarray(a))
+    return coefs
+
+
+@pytest.mark.parametrize("kind", ["sparse", "dense", "worst", "zero"])
+def test_huffman_encode_equals_oracle_byte_for_byte(uhdr, kind):
+    """One wavefront per restart interval == the sequential restatement of libjpeg's encoder (itself byte-identical to the
+    reference encoder, tests/test_oracle_vs_ref.py), for 4:2:0 / 4:4:4 / single-component scans, sizes with dummy blocks
+    at the right and bottom edges, the smallest and the largest restart intervals, byte stuffing included."""
+    import torch
+
+    rng = np.random.default_rng(83)
+    cases = [(256, 64, [(2, 2), (1, 1), (1, 1)], 10), (72, 40, [(2, 2), (1, 1), (1, 1)], 1), (50, 30, [(2, 2), (1, 1), (1, 1)], 3),
+             (41, 23, [(1, 1)] * 3, 21), (200, 24, [(1, 1)] * 3, 4), (37, 19, [(1, 1)], 64), (520, 16, [(1, 1)], 7)]
+    for (w, h, sampling, ri) in cases:
+        coefs = _random_coefs(rng, w, h, sampling, kind)
+        want = L.huffman_encode_port(coefs, w, h, sampling, ri)
+        got = uhdr.huffman_encode([torch.from_numpy(c).to("cuda:0") for c in coefs], w, h, sampling, ri)
+        got = got.cpu().numpy().tobytes()
+        assert len(got) == len(want), (kind, w, h, ri, len(got), len(want))
+        assert got == want, (kind, w, h, ri)
+
+
+def test_huffman_encode_of_a_real_frame_decodes_with_libjpeg(uhdr):
+    """The full device encode chain of a 4:2:0 frame -- FDCT + quantize, Huffman coding, file wrapper -- read back by the
+    real libjpeg (through the reference build, when it travelled with the snapshot): same coefficients, same tables."""
+    import torch
+
+    w, h, ri = 384, 160, 8
+    img = synth.make_sdr_yuv420(w, h, align=8, noise=0.1)
+    ql, qc = uhdr.quant_table(90, False), uhdr.quant_table(90, True)
+    coefs = []
+    for c in range(3):
+        pl = np.ascontiguousarray(img.valid(c))
+        coefs.append(uhdr.fdct_quant(torch.from_numpy(pl).to("cuda:0"), pl.shape[1], pl.shape[1] // 8, pl.shape[0] // 8, ql if c == 0 else qc))
+    sampling = [(2, 2), (1, 1), (1, 1)]
+    scan = uhdr.huffman_encode(coefs, w, h, sampling, ri).cpu().numpy().tobytes()
+    host = [c.cpu().numpy() for c in coefs]
+    assert scan == L.huffman_encode_port(host, w, h, sampling, ri)
+    jpeg = uhdr.jpeg_assemble(coefs, w, h, sampling, ri, ql, qc, scan)
+    assert jpeg == L.jpeg_assemble_port(host, w, h, sampling, ri, ql, qc, scan)
+    if oracle_kind() == "ref":
+        ref = L.ref()
+        qt = np.zeros((3, 64), dtype=np.uint16)
+        bw, bh, nc = (C.c_int * 3)(), (C.c_int * 3)(), C.c_int(0)
+        back = [np.zeros_like(c) for c in host]
+        ptrs = (C.c_void_p * 3)(*[b.ctypes.data for b in back])
+        buf = np.frombuffer(jpeg, dtype=np.uint8)
+        assert ref.ref_jpeg_read_coefficients(buf.ctypes.data, buf.size, ptrs, qt.ctypes.data, bw, bh, C.byref(nc)) == 0
+        assert nc.value == 3 and list(bw) == [c.shape[1] for c in host] and list(bh) == [c.shape[0] for c in host]
+        for c in range(3):
+            assert np.array_equal(back[c], host[c]), c
+        assert np.array_equal(qt[0], ql) and np.array_equal(qt[1], qc)
+
+
+def test_huffman_encode_error_behaviour(uhdr):
+    import torch
+
+    rng = np.random.default_rng(89)
+    w, h, sampling = 64, 32, [(2, 2), (1, 1), (1, 1)]
+    coefs = [torch.from_numpy(c).to("cuda:0") for c in _random_coefs(rng, w, h, sampling, "sparse")]
+    with pytest.raises(A.UhdrError) as e:  # 11 MCUs x 6 blocks > one wavefront
+        uhdr.huffman_encode(coefs, w, h, sampling, 11)
+    assert e.value.code == A.UHDR_CODEC_UNSUPPORTED_FEATURE
+    with pytest.raises(A.UhdrError) as e:
+        uhdr.huffman_encode(coefs, w, h, sampling, 0)
+    assert e.value.code == A.UHDR_CODEC_UNSUPPORTED_FEATURE
+    with pytest.raises(A.UhdrError) as e:  # block grid of another image
+        uhdr.huffman_encode(coefs, w + 64, h, sampling, 4)
+    assert e.value.code == A.UHDR_CODEC_INVALID_PARAM
+    small = torch.empty(16, dtype=torch.uint8, device="cuda:0")
+    with pytest.raises(A.UhdrError) as e:
+        uhdr.huffman_encode(coefs, w, h, sampling, 4, out=small)
+    assert e.value.code == A.UHDR_CODEC_MEM_ERROR
+    wild = [torch.full_like(c, 32767) for c in coefs]
+    for c in wild:
+        c[..., 1::2] = -32768
+    with pytest.raises(A.UhdrError) as e:  # far outside the baseline range: more bits than a block can have
+        uhdr.huffman_encode(wild, w, h, sampling, 10)
+    assert e.value.code == A.UHDR_CODEC_INVALID_PARAM
+
+
 def test_apply_gainmap_calls_capture_into_a_hip_graph(uhdr):
     """BASELINE config 5 (batch decode to HLG, hipGraph-captured): once the per-metadata tables are
     cached a device-resident applyGainMap call enqueues nothing but its kernel, so a burst of calls on a
