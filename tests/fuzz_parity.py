@@ -223,8 +223,32 @@ def fuzz_decode_fused():
     note("idct-rgb", np.array_equal(got, want_rgb), f"{mw}x{mh} bpp{bpp} v{variant}")
 
 
+def fuzz_huffman():
+    """huffman_encode against the oracle's sequential restatement: random geometry / sampling / restart interval / density."""
+    ncomp = int(rng.choice([1, 3]))
+    sampling = [(1, 1)] if ncomp == 1 else ([(2, 2), (1, 1), (1, 1)] if rng.random() < 0.6 else ([(2, 1), (1, 1), (1, 1)] if rng.random() < 0.5 else [(1, 1)] * 3))
+    bpm = sum(a * b for a, b in sampling)
+    ri = int(rng.integers(1, 64 // bpm + 1))
+    w, h = int(rng.integers(1, 400)), int(rng.integers(1, 120))
+    hmax, vmax = max(s_[0] for s_ in sampling), max(s_[1] for s_ in sampling)
+    density = float(rng.choice([0.02, 0.1, 0.4, 1.0]))
+    amp = int(rng.choice([3, 40, 1023]))
+    coefs = []
+    for hs, vs in sampling:
+        cw, chh = -(-w * hs // hmax), -(-h * vs // vmax)
+        bw, bh = -(-cw // 8), -(-chh // 8)
+        if rng.random() < 0.3 and ncomp > 1:  # MCU-padded grid (what fdct_quant of padded planes yields): no dummy blocks
+            bw, bh = -(-w // (8 * hmax)) * hs, -(-h // (8 * vmax)) * vs
+        a = (rng.integers(-amp, amp + 1, (bh, bw, 64)) * (rng.random((bh, bw, 64)) < density)).astype(np.int16)
+        a[..., 0] = rng.integers(-1020, 1021, (bh, bw))
+        coefs.append(np.ascontiguousarray(a))
+    want = L.huffman_encode_port(coefs, w, h, sampling, ri)
+    got = u.huffman_encode([torch.from_numpy(c).to("cuda:0") for c in coefs], w, h, sampling, ri).cpu().numpy().tobytes()
+    note("huffman", got == want, f"{w}x{h} {sampling} ri{ri} density{density} amp{amp} len {len(got)} vs {len(want)}")
+
+
 t_end = time.time() + args.seconds
-jobs = [fuzz_apply, fuzz_apply, fuzz_apply, fuzz_generate, fuzz_tonemap, fuzz_converts, fuzz_decode_fused]
+jobs = [fuzz_huffman, fuzz_apply, fuzz_apply, fuzz_apply, fuzz_generate, fuzz_tonemap, fuzz_converts, fuzz_decode_fused]
 i = 0
 while time.time() < t_end:
     jobs[i % len(jobs)]()

@@ -368,7 +368,8 @@ def test_huffman_restart_intervals_decode_to_the_same_coefficients(ref, ri):
     exactly the coefficients that went in -- including odd sizes, where the MCUs at the right / bottom edge contain
     libjpeg's dummy blocks."""
     rng = np.random.default_rng(9)
-    for (w, h, sampling) in ((72, 40, [(2, 2), (1, 1), (1, 1)]), (50, 30, [(2, 2), (1, 1), (1, 1)]), (41, 23, [(1, 1)] * 3), (37, 19, [(1, 1)])):
+    for (w, h, sampling) in ((72, 40, [(2, 2), (1, 1), (1, 1)]), (50, 30, [(2, 2), (1, 1), (1, 1)]), (41, 23, [(1, 1)] * 3), (37, 19, [(1, 1)]),
+                             (45, 21, [(2, 1), (1, 1), (1, 1)])):
         hmax, vmax = max(s[0] for s in sampling), max(s[1] for s in sampling)
         coefs = []
         for c, (hs, vs) in enumerate(sampling):
