@@ -380,7 +380,7 @@ def extras(ctx, u, device):
     ms = time_kernel(ctx, huff, iters=5, warm=2)
     res["huffman_encode_4k_420_q95"] = {"us": round(ms * 1e3, 1), "Mpx/s": round(w * h / (ms / 1e3) / 1e6, 1), "jpeg_scan_bytes": nbytes[0],
                                         "GB/s_coef_in": round(3.0 * w * h / (ms / 1e3) / 1e9, 1),
-                                        "stages": "3 kernels: one wavefront per restart interval (10 MCUs) -> interval sizes -> offsets -> gather with RSTn markers"}
+                                        "stages": "one wavefront per restart interval (10 MCUs; two launches = two LDS size classes) -> interval sizes -> offsets -> gather with RSTn markers"}
     del hco, hout
 
     # ---- whole stage chains, device resident (sum of the kernels' HIP-event durations per pass) ----------------

@@ -20,8 +20,8 @@
 //      last word of a lane are shared with its neighbours);
 //   4. the buffer is padded with one bits to a byte boundary, byte-stuffed (0xFF -> 0xFF 0x00, positions from a wave
 //      prefix sum of the 0xFF counts) and written to the interval's slot in device memory.
-// A second, tiny kernel turns the interval sizes into offsets; a third copies the slots into the final stream with
-// the RSTn markers in between.
+// Two launches of that kernel (size classes of the LDS bit buffer, see below), then a tiny kernel turns the interval
+// sizes into offsets and a gather kernel copies the slots into the final stream with the RSTn markers in between.
 #include "uhdr_types.h"
 
 namespace uhdr {
@@ -81,10 +81,18 @@ __device__ __forceinline__ void walk_block(const uint32_t* dct, const uint32_t* 
   }
 }
 
+// Size classes: almost every interval of a real image needs a small fraction of the worst-case bit buffer, and LDS per
+// wavefront decides how many intervals a CU encodes at once.  The first launch (WORDS = kWordsSmall: 512 bits per
+// block on average, 4 KB) encodes every interval that fits and marks the others 0xFFFFFFFE; the second launch
+// (RETRY, worst-case buffer) only picks those up.
+constexpr int kWordsSmall = 16;
+constexpr uint32_t kRetry = 0xFFFFFFFEu, kBadCoef = 0xFFFFFFFFu;
+
+template <int WORDS, bool RETRY>
 __global__ __launch_bounds__(64) void huff_encode_kernel(const HuffArgs a) {
   __shared__ uint32_t s_tab[2 * (16 + 256)];
   __shared__ uint32_t s_coef[kSegBlocks * kCoefRow];
-  __shared__ uint32_t s_bits[kSegBlocks * kWordsPerBlock + 2];
+  __shared__ uint32_t s_bits[kSegBlocks * WORDS + 2];
   __shared__ int s_dc[kSegBlocks];
   __shared__ int s_real[kSegBlocks];
   __shared__ uint8_t s_zz[64];
@@ -95,6 +103,9 @@ __global__ __launch_bounds__(64) void huff_encode_kernel(const HuffArgs a) {
 
   for (int seg = (int)blockIdx.x; seg < a.nseg; seg += (int)gridDim.x) {
     __syncthreads();  // the previous interval's LDS contents are dead
+    if constexpr (RETRY) {
+      if (a.seg_bytes[seg] != kRetry) continue;  // wave-uniform
+    }
     // ---- which block is this lane's? -------------------------------------------------------------------------
     const int mcu_local = (int)lane / bpm, k_in_mcu = (int)lane - mcu_local * bpm;
     const int mcu = seg * a.ri + mcu_local;
@@ -147,9 +158,13 @@ __global__ __launch_bounds__(64) void huff_encode_kernel(const HuffArgs a) {
     const uint32_t incl = wave_incl_scan(len, lane);
     const uint32_t total_bits = (uint32_t)__shfl((int)incl, 63, 64);
     const uint32_t off = incl - len;
-    const uint32_t cap_bits = (uint32_t)(kSegBlocks * kWordsPerBlock) * 32u;
-    if (total_bits > cap_bits || __builtin_amdgcn_ballot_w64(oob != 0) != 0) {  // coefficients outside the baseline range: report, do not write
-      if (lane == 0) a.seg_bytes[seg] = 0xFFFFFFFFu;
+    const uint32_t cap_bits = (uint32_t)(kSegBlocks * WORDS) * 32u;
+    if (__builtin_amdgcn_ballot_w64(oob != 0) != 0) {  // coefficients outside the baseline range: report, do not write
+      if (lane == 0) a.seg_bytes[seg] = kBadCoef;
+      continue;
+    }
+    if (total_bits > cap_bits) {  // next size class (cannot happen in the worst-case class for in-range coefficients)
+      if (lane == 0) a.seg_bytes[seg] = RETRY ? kBadCoef : kRetry;
       continue;
     }
     const uint32_t nwords = (total_bits + 31u) / 32u + 1u;
@@ -221,7 +236,7 @@ __global__ __launch_bounds__(1024) void huff_offsets_kernel(const uint32_t* __re
   bool bad = false;
   for (int i = lo; i < hi; i++) {
     const uint32_t n = seg_bytes[i];
-    bad |= n == 0xFFFFFFFFu;
+    bad |= n >= kRetry;
     sum += (uint64_t)n + 2u;
   }
   if (bad) atomicOr(&s_bad, 1u);
@@ -248,7 +263,7 @@ __global__ __launch_bounds__(256) void huff_gather_kernel(const uint8_t* __restr
   for (int seg = (int)blockIdx.x; seg < nseg; seg += (int)gridDim.x) {
     const uint32_t n = seg_bytes[seg];
     const uint64_t off = offsets[seg];
-    if (n == 0xFFFFFFFFu || off + n + 2u > cap + (seg == nseg - 1 ? 2u : 0u)) continue;  // the host reports the error
+    if (n >= kRetry || off + n + 2u > cap + (seg == nseg - 1 ? 2u : 0u)) continue;  // the host reports the error
     const uint8_t* src = slots + (size_t)seg * slot_stride;
     for (uint32_t i = threadIdx.x; i < n; i += 256) out[off + i] = src[i];
     if (threadIdx.x == 0 && seg < nseg - 1) {
@@ -264,7 +279,8 @@ uint32_t huff_slot_stride() { return (uint32_t)(kSegBlocks * kWordsPerBlock * 4 
 
 hipError_t launch_huffman_encode(const HuffArgs& a, uint64_t* offsets, uint32_t* status, uint8_t* out, uint64_t cap, hipStream_t s) {
   int grid = a.nseg < 8192 ? a.nseg : 8192;
-  hipLaunchKernelGGL(huff_encode_kernel, dim3(grid), dim3(64), 0, s, a);
+  hipLaunchKernelGGL((huff_encode_kernel<kWordsSmall, false>), dim3(grid), dim3(64), 0, s, a);
+  hipLaunchKernelGGL((huff_encode_kernel<kWordsPerBlock, true>), dim3(grid < 2048 ? grid : 2048), dim3(64), 0, s, a);
   hipLaunchKernelGGL(huff_offsets_kernel, dim3(1), dim3(1024), 0, s, a.seg_bytes, a.nseg, offsets, status);
   hipLaunchKernelGGL(huff_gather_kernel, dim3(grid), dim3(256), 0, s, a.slots, a.slot_stride, a.seg_bytes, offsets, a.nseg, out, cap);
   return hipGetLastError();
