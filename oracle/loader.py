@@ -73,6 +73,8 @@ def port() -> C.CDLL:
     lib.uo_huffman_encode_scan.argtypes = [_P(ScanDesc), C.c_void_p, C.c_size_t]
     lib.uo_jpeg_assemble.restype = C.c_size_t
     lib.uo_jpeg_assemble.argtypes = [_P(ScanDesc), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    lib.uo_huffman_decode_scan.restype = C.c_int
+    lib.uo_huffman_decode_scan.argtypes = [_P(ScanDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, _P(C.c_void_p)]
     lib.uo_std_huff_table.restype = None
     lib.uo_std_huff_table.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, _P(C.c_int)]
     lib.uo_idct_dequant_plane.restype = None
@@ -292,6 +294,27 @@ def huffman_encode_port(coefs, w: int, h: int, sampling, restart_interval: int =
     n = port().uo_huffman_encode_scan(C.byref(sd), out.ctypes.data, cap)
     assert n > 0
     return out[:n].tobytes()
+
+
+def std_dht_tables():
+    """(bits[4][17], vals[4][256]) uint8 arrays: DC luma, AC luma, DC chroma, AC chroma (Annex K)."""
+    bits, vals = np.zeros((4, 17), dtype=np.uint8), np.zeros((4, 256), dtype=np.uint8)
+    for t, (ac, chroma) in enumerate(((0, 0), (1, 0), (0, 1), (1, 1))):
+        nv = C.c_int(0)
+        port().uo_std_huff_table(ac, chroma, bits[t].ctypes.data, vals[t].ctypes.data, C.byref(nv))
+    return bits, vals
+
+
+def huffman_decode_port(shapes, w: int, h: int, sampling, restart_interval: int, data: bytes, tables=None):
+    """Entropy-coded data -> list of (bh, bw, 64) int16 arrays; shapes = [(bh, bw)] per component."""
+    out = [np.zeros((bh, bw, 64), dtype=np.int16) for (bh, bw) in shapes]
+    sd = scan_desc(out, w, h, sampling, restart_interval)
+    bits, vals = tables if tables is not None else std_dht_tables()
+    bits, vals = np.ascontiguousarray(bits, dtype=np.uint8), np.ascontiguousarray(vals, dtype=np.uint8)
+    src = np.frombuffer(data, dtype=np.uint8)
+    ptrs = (C.c_void_p * 3)(*[out[c].ctypes.data if c < len(out) else None for c in range(3)])
+    rc = port().uo_huffman_decode_scan(C.byref(sd), bits.ctypes.data, vals.ctypes.data, src.ctypes.data, src.size, ptrs)
+    return rc, out
 
 
 def jpeg_assemble_port(coefs, w: int, h: int, sampling, restart_interval: int, qt_luma, qt_chroma, scan: bytes) -> bytes:

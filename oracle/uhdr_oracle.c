@@ -1652,3 +1652,126 @@ size_t uo_jpeg_assemble(const uo_scan_t* sc, const uint16_t qt[2][64], const uin
 #undef PUT16
   return n <= cap ? n : 0;
 }
+
+/* ---- Huffman decoding of a scan with restart intervals (the inverse of uo_huffman_encode_scan) -------------------
+ * jdhuff.c decode_mcu_huff / process_restart restated per restart interval: the intervals are located by their RSTn
+ * markers (inside entropy-coded data 0xFF is followed by 0x00 or by a marker), each is decoded on its own with the DC
+ * predictors starting at zero.  Tables come as DHT content (BITS / HUFFVAL): [0] DC luma, [1] AC luma, [2] DC chroma,
+ * [3] AC chroma.  coef_out[c]: bw[c] x bh[c] real blocks, natural order; dummy blocks are decoded and dropped.
+ * Returns 0, or a negative number for a malformed stream. */
+typedef struct {
+  int maxcode[18]; /* largest code of length l, -1 if none; [17] sentinel */
+  int valoff[17];  /* index into vals of the first symbol of length l minus its code */
+  uint8_t vals[256];
+} uo_huff_dec_t;
+static void make_decoder(const uint8_t bits[17], const uint8_t* vals, uo_huff_dec_t* d) {
+  int code = 0, k = 0;
+  memset(d, 0, sizeof *d);
+  for (int l = 1; l <= 16; l++) {
+    if (bits[l]) {
+      d->valoff[l] = k - code;
+      k += bits[l];
+      code += bits[l];
+      d->maxcode[l] = code - 1;
+    } else {
+      d->maxcode[l] = -1;
+    }
+    code <<= 1;
+  }
+  d->maxcode[17] = 0x7fffffff;
+  memcpy(d->vals, vals, (size_t)k);
+}
+typedef struct {
+  const uint8_t* p;
+  const uint8_t* end;
+  uint32_t acc;
+  int n;
+} uo_bitr_t;
+static int br_bit(uo_bitr_t* r) {
+  if (r->n == 0) {
+    unsigned b = 0; /* past the end of the interval: zeros (jdhuff.c fills with zeros after a marker) */
+    if (r->p < r->end) {
+      b = *r->p++;
+      if (b == 0xff && r->p < r->end && *r->p == 0) r->p++; /* stuffed zero */
+    }
+    r->acc = b;
+    r->n = 8;
+  }
+  r->n--;
+  return (int)((r->acc >> r->n) & 1u);
+}
+static int br_symbol(uo_bitr_t* r, const uo_huff_dec_t* d) {
+  int code = 0;
+  for (int l = 1; l <= 16; l++) {
+    code = (code << 1) | br_bit(r);
+    if (d->maxcode[l] >= 0 && code <= d->maxcode[l]) return d->vals[(d->valoff[l] + code) & 255];
+  }
+  return -1;
+}
+static int br_receive_extend(uo_bitr_t* r, int s) {
+  int v = 0;
+  for (int i = 0; i < s; i++) v = (v << 1) | br_bit(r);
+  return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; /* HUFF_EXTEND */
+}
+int uo_huffman_decode_scan(const uo_scan_t* sc, const uint8_t dht_bits[4][17], const uint8_t dht_vals[4][256], const uint8_t* data,
+                           size_t size, int16_t* coef_out[3]) {
+  uo_huff_dec_t dec[4];
+  for (int t = 0; t < 4; t++) make_decoder(dht_bits[t], dht_vals[t], &dec[t]);
+  int mpr, mrows;
+  scan_geometry(sc, &mpr, &mrows);
+  const int total = mpr * mrows, ri = sc->restart_interval > 0 ? sc->restart_interval : total;
+  for (int c = 0; c < sc->ncomp; c++) memset(coef_out[c], 0, (size_t)sc->bw[c] * sc->bh[c] * 64 * sizeof(int16_t));
+  size_t pos = 0;
+  int expect = 0;
+  for (int m0 = 0; m0 < total; m0 += ri) {
+    /* the interval ends at the next marker (or at the end of the data) */
+    size_t e = pos;
+    while (e + 1 < size && !(data[e] == 0xff && data[e + 1] != 0)) e++;
+    if (e + 1 >= size) e = size;
+    uo_bitr_t r = {data + pos, data + e, 0, 0};
+    int last_dc[3] = {0, 0, 0};
+    for (int m = m0; m < m0 + ri && m < total; m++) {
+      const int my = m / mpr, mx = m % mpr;
+      for (int c = 0; c < sc->ncomp; c++) {
+        const int hs = sc->ncomp == 1 ? 1 : sc->hs[c], vs = sc->ncomp == 1 ? 1 : sc->vs[c];
+        const uo_huff_dec_t *dct = &dec[c ? 2 : 0], *act = &dec[c ? 3 : 1];
+        for (int yi = 0; yi < vs; yi++) {
+          for (int xi = 0; xi < hs; xi++) {
+            const int by = my * vs + yi, bx = mx * hs + xi;
+            int16_t scratch[64];
+            int16_t* blk = (by < sc->bh[c] && bx < sc->bw[c]) ? coef_out[c] + ((size_t)by * sc->bw[c] + bx) * 64 : scratch;
+            int s = br_symbol(&r, dct);
+            if (s < 0 || s > 15) return -2;
+            const int diff = s ? br_receive_extend(&r, s) : 0;
+            last_dc[c] += diff;
+            blk[0] = (int16_t)last_dc[c];
+            for (int k = 1; k < 64;) {
+              const int rs = br_symbol(&r, act);
+              if (rs < 0) return -3;
+              const int run = rs >> 4;
+              s = rs & 15;
+              if (s) {
+                k += run;
+                if (k > 63) return -4;
+                blk[kZigzagToNatural[k]] = (int16_t)br_receive_extend(&r, s);
+                k++;
+              } else if (run == 15) {
+                k += 16;
+              } else {
+                break;
+              }
+            }
+          }
+        }
+      }
+    }
+    if (e < size) { /* RSTn */
+      if (data[e + 1] != 0xd0 + expect) return -5;
+      expect = (expect + 1) & 7;
+      pos = e + 2;
+    } else {
+      pos = size;
+    }
+  }
+  return 0;
+}

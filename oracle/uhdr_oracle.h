@@ -122,6 +122,10 @@ typedef struct uo_scan {
 size_t uo_huffman_encode_scan(const uo_scan_t* sc, uint8_t* out, size_t cap); /* bytes between the SOS header and EOI; 0 = overflow */
 size_t uo_jpeg_assemble(const uo_scan_t* sc, const uint16_t qt[2][64], const uint8_t* scan, size_t scan_len, uint8_t* out, size_t cap);
 void uo_std_huff_table(int is_ac, int is_chroma, uint8_t bits[17], uint8_t vals[256], int* nvals);
+/* inverse: entropy-coded data (RSTn markers included) -> coefficient blocks; tables as DHT content, order DC luma, AC luma,
+ * DC chroma, AC chroma; coef_out[c] has room for bw[c] x bh[c] blocks.  0 on success. */
+int uo_huffman_decode_scan(const uo_scan_t* sc, const uint8_t dht_bits[4][17], const uint8_t dht_vals[4][256], const uint8_t* data,
+                           size_t size, int16_t* coef_out[3]);
 
 /* scalar access for known-answer tests */
 int uo_eval(int fn, const float* in, float* out, size_t n); /* ids as in ref_shim.cpp */

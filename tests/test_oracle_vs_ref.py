@@ -387,3 +387,53 @@ def test_huffman_restart_intervals_decode_to_the_same_coefficients(ref, ri):
         for c in range(len(coefs)):
             assert back[c].shape == coefs[c].shape and np.array_equal(back[c], coefs[c]), (w, h, c)
         assert np.array_equal(qt[0], ql) and (len(coefs) == 1 or np.array_equal(qt[1], qc))
+
+
+@pytest.mark.parametrize("ri", [1, 4, 1000])
+def test_huffman_decode_restatement_agrees_with_libjpeg(ref, ri):
+    """uo_huffman_decode_scan (per restart interval) reads a stream back to what libjpeg's jpeg_read_coefficients reads:
+    4:2:0 with dummy blocks, 4:2:2, 4:4:4 and single-component scans."""
+    rng = np.random.default_rng(19)
+    for (w, h, sampling) in ((72, 40, [(2, 2), (1, 1), (1, 1)]), (50, 30, [(2, 2), (1, 1), (1, 1)]), (41, 23, [(1, 1)] * 3), (37, 19, [(1, 1)]),
+                             (45, 21, [(2, 1), (1, 1), (1, 1)])):
+        hmax, vmax = max(s[0] for s in sampling), max(s[1] for s in sampling)
+        coefs = []
+        for c, (hs, vs) in enumerate(sampling):
+            cw, ch = -(-w * hs // hmax), -(-h * vs // vmax)
+            bw, bh = -(-cw // 8), -(-ch // 8)
+            a = (rng.normal(0, 30, (bh, bw, 64)) * (rng.random((bh, bw, 64)) < 0.3)).astype(np.int16)
+            a[..., 0] = rng.integers(-1000, 1000, (bh, bw))
+            a[0, 0, 1:] = rng.integers(-1023, 1024, 63)
+            coefs.append(np.ascontiguousarray(a))
+        ql, qc = L.quant_table_port(90, False), L.quant_table_port(90, True)
+        scan = L.huffman_encode_port(coefs, w, h, sampling, ri)
+        jpeg = L.jpeg_assemble_port(coefs, w, h, sampling, ri, ql, qc, scan)
+        back, _ = _read_coefficients(ref, jpeg)  # libjpeg's reading of the file
+        rc, mine = L.huffman_decode_port([c.shape[:2] for c in coefs], w, h, sampling, ri, scan)
+        assert rc == 0
+        for c in range(len(coefs)):
+            assert np.array_equal(mine[c], back[c]) and np.array_equal(mine[c], coefs[c]), (w, h, c)
+
+
+def test_huffman_decode_restatement_reads_the_reference_encoders_files(ref):
+    """The reference's own output (no restart markers = one interval), decoded with the tables found in its DHT segments,
+    equals jpeg_read_coefficients: 4:2:0 base image, Y400 map, 3-channel map."""
+    out = np.zeros(1 << 22, dtype=np.uint8)
+    rng = np.random.default_rng(23)
+    gm3 = Image(A.UHDR_IMG_FMT_24bppRGB888, 64, 40, align=1)
+    gm3.valid(0)[:] = rng.integers(0, 256, size=gm3.valid(0).shape, dtype=np.uint8)
+    for img, w, h, sampling in ((synth.make_sdr_yuv420(128, 64, noise=0.2), 128, 64, [(2, 2), (1, 1), (1, 1)]),
+                                (synth.make_gainmap(96, 48, 1), 96, 48, [(1, 1)]), (gm3, 64, 40, [(1, 1)] * 3)):
+        n = ref.ref_jpeg_compress(C.byref(img.raw), 90, out.ctypes.data, out.size)
+        jpeg = out[:n].tobytes()
+        want, _ = _read_coefficients(ref, jpeg)
+        dht = _dht_tables(jpeg)
+        bits, vals = np.zeros((4, 17), np.uint8), np.zeros((4, 256), np.uint8)
+        for t, key in enumerate((0x00, 0x10, 0x01, 0x11)):
+            if key in dht:
+                bits[t, 1:] = np.frombuffer(dht[key][0], np.uint8)
+                vals[t, : len(dht[key][1])] = np.frombuffer(dht[key][1], np.uint8)
+        rc, got = L.huffman_decode_port([c.shape[:2] for c in want], w, h, sampling, 0, _scan_data(jpeg), (bits, vals))
+        assert rc == 0
+        for c in range(len(want)):
+            assert np.array_equal(got[c], want[c]), (img.raw.fmt, c)
