@@ -29,7 +29,7 @@
  *   uhdr_hip_idct_dequant_rgb_dev (its decode-side mirror: dequant + IDCT + colour conversion in one pass),
  *   uhdr_hip_apply_gainmap_coef_dev (applyGainMap on a base image still in coefficient form: IDCT inside the kernel),
  *   uhdr_hip_huffman_encode_dev + uhdr_hip_jpeg_assemble (baseline Huffman entropy coding, one restart interval per
- *   wavefront, and the file wrapper around it)
+ *   wavefront, and the file wrapper around it), uhdr_hip_huffman_decode_dev (its inverse, one interval per lane)
  *
  * Same argument meaning and error behaviour as the reference: uhdr_error_info_t is returned by
  * value, UHDR_CODEC_OK == 0, strides are in PIXELS, outputs go into caller-provided images.
@@ -390,6 +390,23 @@ typedef struct uhdr_hip_jpeg_scan {
 } uhdr_hip_jpeg_scan_t;
 uhdr_error_info_t uhdr_hip_huffman_encode_dev(uhdr_hip_ctx_t* ctx, const uhdr_hip_jpeg_scan_t* scan,
                                               uint8_t* out, size_t out_capacity, size_t* out_bytes);
+/* The inverse (what libjpeg's jdhuff.c does behind JpegDecoderHelper::decompressImage, jpegdecoderhelper.cpp:169-535):
+ * entropy-coded data -> quantized coefficient blocks, ready for uhdr_hip_idct_dequant_dev / uhdr_hip_apply_gainmap_coef_dev.
+ * A stream with restart markers is a sequence of independent intervals; the markers are located on the device and every
+ * interval is decoded by its own lane.  A stream without them (restart_interval 0 -- every file the reference writes) is
+ * ONE interval: decoded correctly, but by a single lane; such files are better left to the CPU.
+ * scan->coef[c]: DEVICE arrays of blocks_w[c] x blocks_h[c] JBLOCKs, WRITTEN by this call (dummy blocks of edge MCUs are
+ * dropped); data: DEVICE pointer to the bytes between the SOS header and EOI; tables: the file's DHT content in the order
+ * DC luma (Tc 0, Th 0), AC luma, DC chroma, AC chroma -- NULL selects the Annex K tables; component 0 uses the luma pair,
+ * the others the chroma pair.  Synchronous.  UHDR_CODEC_INVALID_PARAM for malformed data (undefined code, run past the
+ * end of a block, marker count / numbering that does not fit the restart interval). */
+typedef struct uhdr_hip_huff_tables {
+  uint8_t bits[4][17]; /* BITS: bits[t][l] = number of codes of length l (index 0 unused) */
+  uint8_t vals[4][256]; /* HUFFVAL */
+} uhdr_hip_huff_tables_t;
+uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* ctx, const uhdr_hip_jpeg_scan_t* scan,
+                                              const uhdr_hip_huff_tables_t* tables, const uint8_t* data,
+                                              size_t data_bytes);
 /* Host helper (no device work): wraps entropy-coded data (HOST pointer) into a complete baseline JFIF file -- SOI,
  * APP0, DQT (natural-order tables as uhdr_hip_jpeg_quant_table returns them; component 0 uses qtable_luma, the others
  * qtable_chroma), SOF0, DHT (Annex K), DRI, SOS, data, EOI, the marker order of libjpeg's jcmarker.c.  scan->coef is

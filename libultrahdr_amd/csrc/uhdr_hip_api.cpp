@@ -1543,7 +1543,110 @@ uhdr_error_info_t uhdr_hip_huffman_encode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
   return ok_status();
 }
 
-// Host helper: a complete baseline JFIF file around entropy-coded data (marker order of jcmarker.c: SOI, APP0, DQT,
+// jdhuff.c jpeg_make_d_derived_tbl: decode form of one DHT table; false for an invalid table
+static bool make_dec_table(const uint8_t bits[17], const uint8_t vals[256], HuffDecTable* t) {
+  memset(t, 0, sizeof *t);
+  int nsym = 0;
+  for (int l = 1; l <= 16; l++) nsym += bits[l];
+  if (nsym > 256) return false;
+  int code = 0, k = 0;
+  for (int l = 1; l <= 16; l++) {
+    if (bits[l]) {
+      t->valoff[l] = k - code;
+      for (int i = 0; i < bits[l]; i++, k++, code++) {
+        if (code >= (1 << l)) return false;  // over-subscribed
+        if (l <= 9) {
+          const int lo = code << (9 - l);
+          for (int x = 0; x < (1 << (9 - l)); x++) t->lut[lo + x] = (uint16_t)((l << 8) | vals[k]);
+        }
+      }
+      t->maxcode[l] = code - 1;
+    } else {
+      t->maxcode[l] = -1;
+    }
+    code <<= 1;
+  }
+  t->maxcode[17] = 0x7fffffff;
+  memcpy(t->vals, vals, 256);
+  return true;
+}
+
+uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_jpeg_scan_t* sc, const uhdr_hip_huff_tables_t* tables,
+                                              const uint8_t* data, size_t data_bytes) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  if (!data || data_bytes == 0 || data_bytes > 0xFFFFFFF0ull) return err_status(UHDR_CODEC_INVALID_PARAM, "received no (or more than 4 GiB of) entropy-coded data");
+  int mpr = 0, mrows = 0, bpm = 0;
+  UHDR_TRY(check_scan(sc, true, &mpr, &mrows, &bpm));
+  if (sc->restart_interval < 0 || sc->restart_interval > 65535) return err_status(UHDR_CODEC_INVALID_PARAM, "restart_interval %d out of range", sc->restart_interval);
+  HIP_TRY(hipSetDevice(c->device));
+  if (!c->d_huff) {  // the zig-zag map lives behind the encoder's code tables
+    std::vector<uint32_t> blob(host::jpeg_huff_code_tables());
+    blob.resize((size_t)host::kHuffTabWords + 16);
+    memcpy(blob.data() + host::kHuffTabWords, host::jpeg_zigzag_to_natural(), 64);
+    HIP_TRY(hipMalloc((void**)&c->d_huff, blob.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpyAsync(c->d_huff, blob.data(), blob.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  std::vector<HuffDecTable> tabs(4);
+  for (int t = 0; t < 4; t++) {
+    uint8_t bits[17], vals[256];
+    if (tables) {
+      memcpy(bits, tables->bits[t], 17);
+      memcpy(vals, tables->vals[t], 256);
+    } else {
+      host::jpeg_std_huff_table(t & 1, t >> 1, bits, vals);
+    }
+    if (!make_dec_table(bits, vals, &tabs[(size_t)t])) return err_status(UHDR_CODEC_INVALID_PARAM, "Huffman table %d is not a valid DHT table", t);
+  }
+  HuffDecArgs a;
+  memset(&a, 0, sizeof a);
+  a.ncomp = sc->num_components;
+  size_t zero_bytes[3] = {0, 0, 0};
+  for (int i = 0; i < a.ncomp; i++) {
+    a.coef[i] = const_cast<int16_t*>(sc->coef[i]);
+    a.bw[i] = sc->blocks_w[i]; a.bh[i] = sc->blocks_h[i];
+    a.hs[i] = a.ncomp == 1 ? 1 : sc->h_samp[i]; a.vs[i] = a.ncomp == 1 ? 1 : sc->v_samp[i];
+    zero_bytes[i] = (size_t)a.bw[i] * a.bh[i] * 64 * sizeof(int16_t);
+  }
+  a.mcus_per_row = mpr;
+  a.total_mcus = mpr * mrows;
+  a.ri = sc->restart_interval;
+  a.nseg = a.ri > 0 ? (a.total_mcus + a.ri - 1) / a.ri : 1;
+  a.data = data;
+  a.nbytes = (uint32_t)data_bytes;
+  a.zigzag = (const uint8_t*)(c->d_huff + host::kHuffTabWords);
+  // scratch: tables | status[2] | chunk counts | starts | ends
+  const int nchunks = huff_marker_chunks(data_bytes);
+  const size_t tab_bytes = sizeof(HuffDecTable) * 4;
+  const size_t need = tab_bytes + 16 + ((size_t)nchunks + 2 * (size_t)a.nseg) * sizeof(uint32_t);
+  UHDR_TRY(ensure(c->scratch[5], need));
+  uint8_t* base = (uint8_t*)c->scratch[5].p;
+  a.tabs = (const HuffDecTable*)base;
+  a.status = (uint32_t*)(base + tab_bytes);
+  uint32_t* counts = a.status + 4;
+  uint32_t* starts = counts + nchunks;
+  uint32_t* ends = starts + a.nseg;
+  a.starts = starts;
+  a.ends = ends;
+  HIP_TRY(hipMemcpyAsync(base, tabs.data(), tab_bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemsetAsync(a.status, 0, 16, c->stream));
+  for (int i = 0; i < a.ncomp; i++) HIP_TRY(hipMemsetAsync(a.coef[i], 0, zero_bytes[i], c->stream));
+  {
+    ProfScope ps(c, "huffman_decode");
+    HIP_TRY(launch_huffman_decode(a, counts, starts, ends, c->stream));
+  }
+  uint32_t st[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(st, a.status, sizeof st, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));  // also keeps `tabs` alive until the upload has happened
+  if (st[1] != (uint32_t)(a.nseg - 1))
+    return err_status(UHDR_CODEC_INVALID_PARAM, "found %u restart markers, a restart interval of %d MCUs over %d MCUs needs %d", st[1], a.ri,
+                      a.total_mcus, a.nseg - 1);
+  if (st[0] & 4u) return err_status(UHDR_CODEC_INVALID_PARAM, "restart markers out of sequence");
+  if (st[0] & 2u) return err_status(UHDR_CODEC_INVALID_PARAM, "corrupt entropy-coded data (undefined Huffman code or a run past the end of a block)");
+  return ok_status();
+}
+
+// Host helper: a complete baseline JFIF file around entropy-coded data// Host helper: a complete baseline JFIF file around entropy-coded data (marker order of jcmarker.c: SOI, APP0, DQT,
 // SOF0, DHT, DRI, SOS ... EOI).  Returns the file size, or 0 when `cap` is too small / the description is invalid.
 size_t uhdr_hip_jpeg_assemble(const uhdr_hip_jpeg_scan_t* sc, const uint16_t qt_luma[64], const uint16_t qt_chroma[64], const uint8_t* scan_data,
                               size_t scan_bytes, uint8_t* out, size_t cap) {

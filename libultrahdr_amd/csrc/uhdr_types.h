@@ -198,6 +198,28 @@ struct HuffArgs {
 uint32_t huff_slot_stride();
 hipError_t launch_huffman_encode(const HuffArgs& a, uint64_t* offsets, uint32_t* status, uint8_t* out, uint64_t cap, hipStream_t s);
 
+// ---- baseline Huffman decoding (huffman_decode.hip) ---------------------------------------------------
+struct HuffDecTable {    // one DHT table, decode form (jdhuff.c jpeg_make_d_derived_tbl)
+  uint16_t lut[512];     // 9-bit look-ahead: code length << 8 | symbol, 0 = longer than 9 bits
+  int maxcode[18];       // largest code of length l (-1: none)
+  int valoff[17];        // vals index of the first symbol of length l minus its code
+  uint8_t vals[256];
+};
+struct HuffDecArgs {
+  const uint8_t* data;   // entropy-coded bytes (device)
+  uint32_t nbytes;
+  const uint32_t* starts;
+  const uint32_t* ends;  // interval k = [starts[k], ends[k])
+  int nseg, ri, total_mcus, mcus_per_row, ncomp;
+  int bw[3], bh[3], hs[3], vs[3];
+  int16_t* coef[3];      // zero-initialised JBLOCK arrays
+  const HuffDecTable* tabs;  // DC luma, AC luma, DC chroma, AC chroma
+  const uint8_t* zigzag;
+  uint32_t* status;      // [0]: 2 = bad code / block overrun, 4 = markers out of sequence; [1]: markers found
+};
+int huff_marker_chunks(uint64_t nbytes);
+hipError_t launch_huffman_decode(const HuffDecArgs& a, uint32_t* counts, uint32_t* starts, uint32_t* ends, hipStream_t s);
+
 hipError_t launch_idct_dequant(const int16_t* coef, int bw, int bh, const uint16_t* qt_host, uint8_t* plane,
                                size_t stride, hipStream_t s);
 hipError_t launch_idct_dequant_rgb(const int16_t* coef_y, const int16_t* coef_cb, const int16_t* coef_cr, int bw, int bh,

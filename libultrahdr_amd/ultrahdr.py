@@ -265,6 +265,28 @@ class UltraHdr:
         A.check(self.lib.uhdr_hip_huffman_encode_dev(self.ctx.handle, C.byref(sc), C.c_void_p(out.data_ptr()), out.numel(), C.byref(n)))
         return out[: n.value]
 
+    def huffman_decode(self, data, shapes, w: int, h: int, sampling, restart_interval: int, tables=None):
+        """Entropy-coded data (uint8 CUDA tensor: the bytes between the SOS header and EOI) -> int16 [blocks_h, blocks_w, 64]
+        CUDA tensors per component (shapes = [(blocks_h, blocks_w)]).  tables: (bits[4][17], vals[4][256]) from the file's
+        DHT segments, None = Annex K.  One lane per restart interval."""
+        import torch
+
+        assert data.is_cuda and data.dtype == torch.uint8
+        coefs = [torch.empty((bh, bw, 64), dtype=torch.int16, device=data.device) for (bh, bw) in shapes]
+        torch.cuda.current_stream(data.device).synchronize()
+        sc = self._scan(coefs, w, h, sampling, restart_interval)
+        ht = None
+        if tables is not None:
+            ht = A.HuffTables()
+            for t in range(4):
+                for i in range(17):
+                    ht.bits[t][i] = int(tables[0][t][i])
+                for i in range(256):
+                    ht.vals[t][i] = int(tables[1][t][i])
+        A.check(self.lib.uhdr_hip_huffman_decode_dev(self.ctx.handle, C.byref(sc), C.byref(ht) if ht is not None else None,
+                                                     C.c_void_p(data.data_ptr()), data.numel()))
+        return coefs
+
     def jpeg_assemble(self, coefs, w: int, h: int, sampling, restart_interval: int, qt_luma, qt_chroma, scan_data: bytes) -> bytes:
         """Host helper: a complete baseline JFIF file around entropy-coded data (coefs only supply the block grids)."""
         sc = self._scan(coefs, w, h, sampling, restart_interval)

@@ -289,7 +289,7 @@ def huffman_encode_port(coefs, w: int, h: int, sampling, restart_interval: int =
     """Entropy-coded data of the scan (between the SOS header and EOI), Annex K tables."""
     coefs = [np.ascontiguousarray(c, dtype=np.int16) for c in coefs]
     sd = scan_desc(coefs, w, h, sampling, restart_interval)
-    cap = sum(c.size for c in coefs) * 4 + 4096
+    cap = sum(c.size for c in coefs) * 8 + 4096  # worst case: 1660 bits per block, every byte stuffed
     out = np.zeros(cap, dtype=np.uint8)
     n = port().uo_huffman_encode_scan(C.byref(sd), out.ctypes.data, cap)
     assert n > 0

@@ -630,6 +630,101 @@ def test_huffman_encode_of_a_real_frame_decodes_with_libjpeg(uhdr):
         assert np.array_equal(qt[0], ql) and np.array_equal(qt[1], qc)
 
 
+@pytest.mark.parametrize("kind", ["sparse", "dense", "worst", "zero"])
+def test_huffman_decode_inverts_the_encoder(uhdr, kind):
+    """One lane per restart interval: the oracle's streams (byte-identical to libjpeg's) decode to exactly the coefficients
+    that went in -- dummy blocks dropped, every sampling layout, restart intervals from 1 MCU to none at all."""
+    import torch
+
+    rng = np.random.default_rng(97)
+    cases = [(256, 64, [(2, 2), (1, 1), (1, 1)], 10), (72, 40, [(2, 2), (1, 1), (1, 1)], 1), (50, 30, [(2, 2), (1, 1), (1, 1)], 3),
+             (41, 23, [(1, 1)] * 3, 21), (45, 21, [(2, 1), (1, 1), (1, 1)], 2), (37, 19, [(1, 1)], 64), (520, 16, [(1, 1)], 7),
+             (64, 48, [(2, 2), (1, 1), (1, 1)], 0), (2000, 24, [(1, 1)], 5)]
+    for (w, h, sampling, ri) in cases:
+        coefs = _random_coefs(rng, w, h, sampling, kind)
+        scan = L.huffman_encode_port(coefs, w, h, sampling, ri)
+        data = torch.from_numpy(np.frombuffer(scan, dtype=np.uint8).copy()).to("cuda:0")
+        got = uhdr.huffman_decode(data, [c.shape[:2] for c in coefs], w, h, sampling, ri)
+        for c in range(len(coefs)):
+            assert np.array_equal(got[c].cpu().numpy(), coefs[c]), (kind, w, h, ri, c)
+
+
+def test_huffman_device_round_trip_and_reference_files(uhdr):
+    """FDCT -> Huffman encode -> Huffman decode on the device is the identity; and a file written by the REFERENCE encoder
+    (no restart markers: one interval), decoded with the tables from its own DHT segments, gives libjpeg's coefficients."""
+    import torch
+
+    w, h, ri = 384, 160, 4
+    img = synth.make_sdr_yuv420(w, h, align=8, noise=0.1)
+    ql, qc = uhdr.quant_table(90, False), uhdr.quant_table(90, True)
+    coefs = []
+    for c in range(3):
+        pl = np.ascontiguousarray(img.valid(c))
+        coefs.append(uhdr.fdct_quant(torch.from_numpy(pl).to("cuda:0"), pl.shape[1], pl.shape[1] // 8, pl.shape[0] // 8, ql if c == 0 else qc))
+    sampling = [(2, 2), (1, 1), (1, 1)]
+    scan = uhdr.huffman_encode(coefs, w, h, sampling, ri)
+    back = uhdr.huffman_decode(scan.clone(), [tuple(c.shape[:2]) for c in coefs], w, h, sampling, ri)
+    for c in range(3):
+        assert torch.equal(back[c], coefs[c]), c
+    if oracle_kind() != "ref":
+        return
+    ref = L.ref()
+    out = np.zeros(1 << 22, dtype=np.uint8)
+    n = ref.ref_jpeg_compress(C.byref(img.raw), 90, out.ctypes.data, out.size)
+    jpeg = out[:n].tobytes()
+    # parse the file: DHT tables and the entropy-coded data
+    bits, vals = np.zeros((4, 17), np.uint8), np.zeros((4, 256), np.uint8)
+    i = 2
+    while jpeg[i + 1] != 0xDA:
+        m, ln = jpeg[i + 1], (jpeg[i + 2] << 8) | jpeg[i + 3]
+        if m == 0xC4:
+            seg, j = jpeg[i + 4: i + 2 + ln], 0
+            while j < len(seg):
+                nsym = sum(seg[j + 1: j + 17])
+                t = {0x00: 0, 0x10: 1, 0x01: 2, 0x11: 3}[seg[j]]
+                bits[t, 1:] = np.frombuffer(seg[j + 1: j + 17], np.uint8)
+                vals[t, :nsym] = np.frombuffer(seg[j + 17: j + 17 + nsym], np.uint8)
+                j += 17 + nsym
+        i += 2 + ln
+    start = i + 2 + ((jpeg[i + 2] << 8) | jpeg[i + 3])
+    data = torch.from_numpy(np.frombuffer(jpeg[start:-2], dtype=np.uint8).copy()).to("cuda:0")
+    qt = np.zeros((3, 64), dtype=np.uint16)
+    bw, bh, nc = (C.c_int * 3)(), (C.c_int * 3)(), C.c_int(0)
+    want = [np.zeros(tuple(c.shape), dtype=np.int16) for c in coefs]
+    ptrs = (C.c_void_p * 3)(*[b.ctypes.data for b in want])
+    buf = np.frombuffer(jpeg, dtype=np.uint8)
+    assert ref.ref_jpeg_read_coefficients(buf.ctypes.data, buf.size, ptrs, qt.ctypes.data, bw, bh, C.byref(nc)) == 0
+    got = uhdr.huffman_decode(data, [w_.shape[:2] for w_ in want], w, h, sampling, 0, tables=(bits, vals))
+    for c in range(3):
+        assert np.array_equal(got[c].cpu().numpy(), want[c]), c
+
+
+def test_huffman_decode_error_behaviour(uhdr):
+    import torch
+
+    rng = np.random.default_rng(101)
+    w, h, sampling, ri = 128, 32, [(2, 2), (1, 1), (1, 1)], 2
+    coefs = _random_coefs(rng, w, h, sampling, "sparse")
+    scan = bytearray(L.huffman_encode_port(coefs, w, h, sampling, ri))
+    shapes = [c.shape[:2] for c in coefs]
+
+    def dec(buf, ri_=ri):
+        return uhdr.huffman_decode(torch.from_numpy(np.frombuffer(bytes(buf), dtype=np.uint8).copy()).to("cuda:0"), shapes, w, h, sampling, ri_)
+
+    with pytest.raises(A.UhdrError) as e:  # the stream has markers every 2 MCUs, not every 4
+        dec(scan, 4)
+    assert e.value.code == A.UHDR_CODEC_INVALID_PARAM
+    k = scan.find(b"\xff\xd1")
+    swapped = bytearray(scan)
+    swapped[k + 1] = 0xD5  # marker out of sequence
+    with pytest.raises(A.UhdrError) as e:
+        dec(swapped)
+    assert e.value.code == A.UHDR_CODEC_INVALID_PARAM
+    with pytest.raises(A.UhdrError) as e:  # block grid of another image
+        uhdr.huffman_decode(torch.from_numpy(np.frombuffer(bytes(scan), dtype=np.uint8).copy()).to("cuda:0"), shapes, w + 64, h, sampling, ri)
+    assert e.value.code == A.UHDR_CODEC_INVALID_PARAM
+
+
 def test_huffman_encode_error_behaviour(uhdr):
     import torch
 
