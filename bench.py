@@ -381,6 +381,17 @@ def extras(ctx, u, device):
     res["huffman_encode_4k_420_q95"] = {"us": round(ms * 1e3, 1), "Mpx/s": round(w * h / (ms / 1e3) / 1e6, 1), "jpeg_scan_bytes": nbytes[0],
                                         "GB/s_coef_in": round(3.0 * w * h / (ms / 1e3) / 1e9, 1),
                                         "stages": "one wavefront per restart interval (10 MCUs; two launches = two LDS size classes) -> interval sizes -> offsets -> gather with RSTn markers"}
+    # ... and back: the same stream -> coefficients, one lane per restart interval (markers located on the device)
+    try:
+        for ri_ in (10, 2):
+            stream = u.huffman_encode(hco, w, h, [(2, 2), (1, 1), (1, 1)], ri_, out=hout).clone()
+            shp = [tuple(c.shape[:2]) for c in hco]
+            ms = time_kernel(ctx, lambda: u.huffman_decode(stream, shp, w, h, [(2, 2), (1, 1), (1, 1)], ri_), iters=3, warm=1)
+            res[f"huffman_decode_4k_420_q95_ri{ri_}"] = {"us": round(ms * 1e3, 1), "Mpx/s": round(w * h / (ms / 1e3) / 1e6, 1),
+                                                          "jpeg_scan_bytes": int(stream.numel()),
+                                                          "stages": "marker count -> scan -> interval table -> decode (one lane per restart interval)"}
+    except Exception as e:  # noqa: BLE001  (a failure here must not cost the other stage measurements)
+        res["huffman_decode_4k_420_q95"] = {"error": f"{type(e).__name__}: {e}"}
     del hco, hout
 
     # ---- whole stage chains, device resident (sum of the kernels' HIP-event durations per pass) ----------------
