@@ -245,6 +245,10 @@ def fuzz_huffman():
     want = L.huffman_encode_port(coefs, w, h, sampling, ri)
     got = u.huffman_encode([torch.from_numpy(c).to("cuda:0") for c in coefs], w, h, sampling, ri).cpu().numpy().tobytes()
     note("huffman", got == want, f"{w}x{h} {sampling} ri{ri} density{density} amp{amp} len {len(got)} vs {len(want)}")
+    # and back: the oracle's stream through the device decoder (dummy blocks dropped: compare the real grid)
+    data = torch.from_numpy(np.frombuffer(want, dtype=np.uint8).copy()).to("cuda:0")
+    back = u.huffman_decode(data, [c.shape[:2] for c in coefs], w, h, sampling, ri)
+    note("huffman-decode", all(np.array_equal(b.cpu().numpy(), c) for b, c in zip(back, coefs)), f"{w}x{h} {sampling} ri{ri}")
 
 
 t_end = time.time() + args.seconds
