@@ -87,3 +87,72 @@ def generate_gainmap_two_pass_striped(uhdr, sdr_stripe, hdr_stripe, cfg: A.Encod
     A.check(lib.uhdr_hip_generate_gainmap_pass2_dev(h, C.c_void_p(gains.data_ptr()), (C.c_float * 6)(*fin), C.byref(cfg),
                                                     C.byref(gm_stripe.raw)))
     return md
+
+
+# ---- entropy stage across ranks (SURVEY.md 8e, last bullet; DESIGN.md 5.5) ---------------------------------------------
+# With restart intervals every interval is independent, so a rank can entropy-code the MCU rows of its own stripe and
+# the compressed streams only have to be concatenated.  Two conditions make the concatenation EQUAL to the single-rank
+# stream: a stripe holds a whole number of intervals, and (because RSTn markers are numbered modulo 8 from the start of
+# the scan, T.81 E.1.4) every stripe but the last holds a multiple of 8 of them -- then each rank's own numbering,
+# starting at RST0, is already the global one and the marker that joins two stripes is always RST7.
+def entropy_stripe_plan(mcu_rows: int, mcus_per_row: int, restart_interval: int, world_size: int):
+    """[(mcu_row0, n_mcu_rows)] per rank for rank-local Huffman coding, or ValueError when the geometry does not allow
+    it.  Stripes are multiples of the smallest row count g with (g * mcus_per_row) % (8 * restart_interval) == 0."""
+    if min(mcu_rows, mcus_per_row, restart_interval, world_size) <= 0:
+        raise ValueError("all arguments must be positive")
+    g = (8 * restart_interval) // math.gcd(8 * restart_interval, mcus_per_row)
+    units = mcu_rows // g  # whole granules; the remainder rows go to the last non-empty stripe
+    if units == 0:
+        return [(0, mcu_rows)] + [(mcu_rows, 0)] * (world_size - 1)
+    base, extra = divmod(units, world_size)
+    plan, row = [], 0
+    for r in range(world_size):
+        n = (base + (1 if r < extra else 0)) * g
+        plan.append([row, n])
+        row += n
+    last = max(i for i, (_, n) in enumerate(plan) if n > 0)
+    plan[last][1] += mcu_rows - row
+    for i in range(last + 1, world_size):
+        plan[i][0] = mcu_rows
+    return [tuple(p) for p in plan]
+
+
+def stitch_entropy_streams(streams) -> bytes:
+    """Concatenates per-stripe entropy-coded streams (in stripe order, empty ones skipped) with the RST7 markers that
+    sit between them in the single-rank stream (see entropy_stripe_plan for why it is always RST7)."""
+    parts = [bytes(s) for s in streams if len(s)]
+    return b"\xff\xd7".join(parts)
+
+
+def stripe_scan_slices(shapes, sampling, w: int, h: int, mcu_row0: int, n_mcu_rows: int):
+    """Geometry of one stripe as its own scan: per component (block_row0, block_rows) into the [blocks_h, blocks_w, 64]
+    arrays (clipped to the real grid: what lies below it are libjpeg's dummy blocks, produced by the encoder), and
+    the pixel height to put in the stripe's scan description."""
+    hmax, vmax = max(s[0] for s in sampling), max(s[1] for s in sampling)
+    if len(shapes) == 1:  # non-interleaved: an MCU is a block
+        vmax = 1
+    px0 = mcu_row0 * 8 * vmax
+    px_h = min(n_mcu_rows * 8 * vmax, h - px0)
+    out = []
+    for (bh, _bw), (_hs, vs) in zip(shapes, sampling):
+        v = vs if len(shapes) > 1 else 1
+        b0 = min(mcu_row0 * v, bh)
+        out.append((b0, min(n_mcu_rows * v, bh - b0)))
+    return out, px_h
+
+
+def huffman_encode_striped(encode, coefs, w: int, h: int, sampling, restart_interval: int, rank: int, world_size: int):
+    """This rank's share of the entropy coding of one image.  ``encode(coef_slices, w, stripe_h, sampling, ri)`` is the
+    stripe encoder -- ``UltraHdr.huffman_encode`` on a GPU rank -- and ``coefs`` the whole image's coefficient arrays
+    (or any object sliceable along block rows; only this rank's rows are touched).  Returns the rank's stream (bytes-like,
+    possibly empty); ``stitch_entropy_streams`` of all ranks' results in rank order is the single-rank stream."""
+    hmax, vmax = max(s[0] for s in sampling), max(s[1] for s in sampling)
+    ncomp = len(coefs)
+    mcus_per_row = int(coefs[0].shape[1]) if ncomp == 1 else (w + 8 * hmax - 1) // (8 * hmax)
+    mcu_rows = int(coefs[0].shape[0]) if ncomp == 1 else (h + 8 * vmax - 1) // (8 * vmax)
+    row0, rows = entropy_stripe_plan(mcu_rows, mcus_per_row, restart_interval, world_size)[rank]
+    if rows == 0:
+        return b""
+    slices, px_h = stripe_scan_slices([tuple(c.shape[:2]) for c in coefs], sampling, w, h, row0, rows)
+    part = [c[b0: b0 + n] for c, (b0, n) in zip(coefs, slices)]
+    return encode(part, w, px_h, sampling, restart_interval)
