@@ -41,6 +41,10 @@ def main():
         for c in range(3):
             out[f"jpeg_q{q}/coef{c}"] = coefs[c]
             out[f"jpeg_q{q}/qt{c}"] = qt[c]
+        # entropy stage: the reference encoder's own entropy-coded bytes (Annex K tables, no restart markers)
+        from test_oracle_vs_ref import _scan_data
+
+        out[f"jpeg_q{q}/scan"] = np.frombuffer(_scan_data(buf[:n].tobytes()), dtype=np.uint8).copy()
         # decode stage: the planes JpegDecoderHelper (libjpeg, JDCT_ISLOW, raw-data mode) returns for that JPEG
         from test_oracle_vs_ref import _decode_with_reference
 
@@ -58,6 +62,7 @@ def main():
         for c in range(3):
             out[f"jpegrgb_q{q}/coef{c}"] = coefs[c]
             out[f"jpegrgb_q{q}/qt{c}"] = qt[c]
+        out[f"jpegrgb_q{q}/scan"] = np.frombuffer(_scan_data(buf[:n].tobytes()), dtype=np.uint8).copy()
         dst, store = _decode_with_reference(L.ref(), buf[:n].tobytes(), 1)
         bpp = 4 if dst.fmt == A.UHDR_IMG_FMT_32bppRGBA8888 else 3
         out[f"jpegrgb_q{q}/dec_rgb"] = store[: dst.stride[0] * bpp * gm.h].reshape(gm.h, dst.stride[0] * bpp)[:, : gm.w * bpp].copy()
