@@ -29,7 +29,8 @@
  *   uhdr_hip_idct_dequant_rgb_dev (its decode-side mirror: dequant + IDCT + colour conversion in one pass),
  *   uhdr_hip_apply_gainmap_coef_dev (applyGainMap on a base image still in coefficient form: IDCT inside the kernel),
  *   uhdr_hip_huffman_encode_dev + uhdr_hip_jpeg_assemble (baseline Huffman entropy coding, one restart interval per
- *   wavefront, and the file wrapper around it), uhdr_hip_huffman_decode_dev (its inverse, one interval per lane)
+ *   wavefront, and the file wrapper around it), uhdr_hip_huffman_decode_dev (its inverse, one interval per lane), uhdr_hip_jpeg_parse (host: the headers of a
+ *   baseline JPEG file, in the form those entry points take)
  *
  * Same argument meaning and error behaviour as the reference: uhdr_error_info_t is returned by
  * value, UHDR_CODEC_OK == 0, strides are in PIXELS, outputs go into caller-provided images.
@@ -414,6 +415,23 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* ctx, const uhdr_hi
 size_t uhdr_hip_jpeg_assemble(const uhdr_hip_jpeg_scan_t* scan, const uint16_t qtable_luma[64],
                               const uint16_t qtable_chroma[64], const uint8_t* scan_data, size_t scan_bytes,
                               uint8_t* out, size_t out_capacity);
+
+/* Host helper (no device work), the counterpart of uhdr_hip_jpeg_assemble: reads the headers of a baseline JPEG file --
+ * what jpeg_read_header does for JpegDecoderHelper (jpegdecoderhelper.cpp:212-222) -- and returns what the device decode
+ * path needs: the scan description (component grids = jpeg_component_info::width_in_blocks / height_in_blocks, sampling
+ * factors, restart interval; coef pointers left NULL for the caller's device arrays), the Huffman tables in
+ * uhdr_hip_huffman_decode_dev's order, each component's quantization table in natural order, and where the entropy-coded
+ * data sits inside the file.  Accepts what libjpeg writes with default settings (hence every base image / gain map of an
+ * UltraHDR file): SOF0, 8 bit, 1 or 3 components in one scan, sampling factors 1 or 2, components 1 and 2 sharing their
+ * tables.  Returns 0, or a negative number naming the first thing it does not handle (-8: not baseline sequential). */
+typedef struct uhdr_hip_jpeg_header {
+  uhdr_hip_jpeg_scan_t scan;
+  uhdr_hip_huff_tables_t tables;
+  uint16_t qtable[3][64];
+  size_t scan_offset; /* first byte after the SOS header */
+  size_t scan_bytes;  /* up to (not including) the marker that ends the entropy-coded data */
+} uhdr_hip_jpeg_header_t;
+int uhdr_hip_jpeg_parse(const uint8_t* file, size_t size, uhdr_hip_jpeg_header_t* out);
 
 /* ---- timing hook for bench.py ------------------------------------------------------------------
  * HIP events recorded on the context's stream around every kernel launch of the named family

@@ -125,6 +125,11 @@ class HuffTables(C.Structure):  # uhdr_hip_huff_tables_t
     _fields_ = [("bits", (C.c_uint8 * 17) * 4), ("vals", (C.c_uint8 * 256) * 4)]
 
 
+class JpegHeader(C.Structure):  # uhdr_hip_jpeg_header_t
+    _fields_ = [("scan", JpegScan), ("tables", HuffTables), ("qtable", (C.c_uint16 * 64) * 3), ("scan_offset", C.c_size_t),
+                ("scan_bytes", C.c_size_t)]
+
+
 def default_encode_cfg(**kw) -> EncodeCfg:
     """C-API defaults (ultrahdrcommon.h:422-446): scale 1, multichannel, gamma 1, two-pass."""
     cfg = EncodeCfg(1, 1, 1.0, UHDR_USAGE_BEST_QUALITY, FLT_MIN, FLT_MAX, -1.0, 0, 1)
@@ -193,6 +198,7 @@ _SIGS = {
                                                     C.c_int, C.c_int, C.c_float, _P(RawImage)]),
     "uhdr_hip_huffman_encode_dev": (ErrorInfo, [C.c_void_p, _P(JpegScan), C.c_void_p, C.c_size_t, _P(C.c_size_t)]),
     "uhdr_hip_huffman_decode_dev": (ErrorInfo, [C.c_void_p, _P(JpegScan), _P(HuffTables), C.c_void_p, C.c_size_t]),
+    "uhdr_hip_jpeg_parse": (C.c_int, [C.c_void_p, C.c_size_t, _P(JpegHeader)]),
     "uhdr_hip_jpeg_assemble": (C.c_size_t, [_P(JpegScan), _P(C.c_uint16), _P(C.c_uint16), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "uhdr_hip_profile_enable": (None, [C.c_void_p, C.c_int]),
     "uhdr_hip_profile_read": (C.c_int, [C.c_void_p, C.c_char_p, _P(C.c_double), C.c_int]),

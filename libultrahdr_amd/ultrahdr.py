@@ -287,6 +287,31 @@ class UltraHdr:
                                                      C.c_void_p(data.data_ptr()), data.numel()))
         return coefs
 
+    def jpeg_parse(self, jpeg: bytes) -> "A.JpegHeader":
+        """Host helper: the headers of a baseline JPEG file in the form the device decode path takes (ValueError with the
+        library's code for files outside that path, e.g. -8 for progressive)."""
+        hdr = A.JpegHeader()
+        buf = np.frombuffer(jpeg, dtype=np.uint8)
+        rc = self.lib.uhdr_hip_jpeg_parse(C.c_void_p(buf.ctypes.data), buf.size, C.byref(hdr))
+        if rc != 0:
+            raise ValueError(f"uhdr_hip_jpeg_parse: {rc}")
+        return hdr
+
+    def jpeg_to_coefficients(self, jpeg: bytes, device="cuda:0"):
+        """JPEG file bytes -> (header, [int16 [blocks_h, blocks_w, 64] CUDA tensors]): headers parsed on the host, the
+        entropy-coded data decoded on the device (one lane per restart interval)."""
+        import torch
+
+        hdr = self.jpeg_parse(jpeg)
+        sc = hdr.scan
+        nc = sc.num_components
+        data = torch.from_numpy(np.frombuffer(jpeg, dtype=np.uint8)[hdr.scan_offset: hdr.scan_offset + hdr.scan_bytes].copy()).to(device)
+        bits = np.frombuffer(hdr.tables.bits, dtype=np.uint8).reshape(4, 17)
+        vals = np.frombuffer(hdr.tables.vals, dtype=np.uint8).reshape(4, 256)
+        coefs = self.huffman_decode(data, [(sc.blocks_h[c], sc.blocks_w[c]) for c in range(nc)], sc.w, sc.h,
+                                    [(sc.h_samp[c], sc.v_samp[c]) for c in range(nc)], sc.restart_interval, tables=(bits, vals))
+        return hdr, coefs
+
     def jpeg_assemble(self, coefs, w: int, h: int, sampling, restart_interval: int, qt_luma, qt_chroma, scan_data: bytes) -> bytes:
         """Host helper: a complete baseline JFIF file around entropy-coded data (coefs only supply the block grids)."""
         sc = self._scan(coefs, w, h, sampling, restart_interval)

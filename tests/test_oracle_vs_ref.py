@@ -437,3 +437,68 @@ def test_huffman_decode_restatement_reads_the_reference_encoders_files(ref):
         assert rc == 0
         for c in range(len(want)):
             assert np.array_equal(got[c], want[c]), (img.raw.fmt, c)
+
+
+def _parse_with_library(jpeg: bytes):
+    lib = A.load()
+    hdr = A.JpegHeader()
+    buf = np.frombuffer(jpeg, dtype=np.uint8)
+    rc = lib.uhdr_hip_jpeg_parse(buf.ctypes.data, buf.size, C.byref(hdr))
+    return rc, hdr
+
+
+def test_jpeg_parse_reads_the_reference_encoders_files_like_libjpeg(ref):
+    """uhdr_hip_jpeg_parse (host code of the product) on files written by the reference encoder: geometry, sampling,
+    quantization tables and block grids as libjpeg reports them, Huffman tables as in the DHT segments, and the
+    entropy-coded data it points at decodes (oracle decoder, the parsed tables) to libjpeg's coefficients."""
+    out = np.zeros(1 << 22, dtype=np.uint8)
+    rng = np.random.default_rng(29)
+    gm3 = Image(A.UHDR_IMG_FMT_24bppRGB888, 72, 40, align=1)
+    gm3.valid(0)[:] = rng.integers(0, 256, size=gm3.valid(0).shape, dtype=np.uint8)
+    for img, w, h, sampling in ((synth.make_sdr_yuv420(128, 64, noise=0.2), 128, 64, [(2, 2), (1, 1), (1, 1)]),
+                                (synth.make_gainmap(96, 48, 1), 96, 48, [(1, 1)]), (gm3, 72, 40, [(1, 1)] * 3)):
+        for quality in (95, 30):
+            n = ref.ref_jpeg_compress(C.byref(img.raw), quality, out.ctypes.data, out.size)
+            jpeg = out[:n].tobytes()
+            want, qt = _read_coefficients(ref, jpeg)
+            rc, hdr = _parse_with_library(jpeg)
+            assert rc == 0
+            sc = hdr.scan
+            assert (sc.num_components, sc.w, sc.h, sc.restart_interval) == (len(want), w, h, 0)
+            for c in range(len(want)):
+                assert (sc.blocks_h[c], sc.blocks_w[c]) == want[c].shape[:2]
+                assert (sc.h_samp[c], sc.v_samp[c]) == tuple(sampling[c])
+                assert np.array_equal(np.frombuffer(hdr.qtable[c], dtype=np.uint16), qt[c])
+            assert jpeg[hdr.scan_offset: hdr.scan_offset + hdr.scan_bytes] == _scan_data(jpeg)
+            dht = _dht_tables(jpeg)
+            bits = np.frombuffer(hdr.tables.bits, dtype=np.uint8).reshape(4, 17)
+            vals = np.frombuffer(hdr.tables.vals, dtype=np.uint8).reshape(4, 256)
+            for t, key in enumerate((0x00, 0x10, 0x01 if len(want) == 3 else 0x00, 0x11 if len(want) == 3 else 0x10)):
+                assert bits[t, 1:].tobytes() == dht[key][0] and vals[t, : len(dht[key][1])].tobytes() == dht[key][1]
+            rc, got = L.huffman_decode_port([c.shape[:2] for c in want], w, h, sampling, 0,
+                                            jpeg[hdr.scan_offset: hdr.scan_offset + hdr.scan_bytes], (bits, vals))
+            assert rc == 0 and all(np.array_equal(g, c) for g, c in zip(got, want))
+
+
+def test_jpeg_parse_round_trips_assembled_files_and_refuses_what_it_does_not_handle():
+    rng = np.random.default_rng(31)
+    w, h, sampling, ri = 50, 30, [(2, 2), (1, 1), (1, 1)], 3
+    coefs = []
+    for hs, vs in sampling:
+        cw, ch = -(-w * hs // 2), -(-h * vs // 2)
+        a = (rng.normal(0, 20, (-(-ch // 8), -(-cw // 8), 64)) * (rng.random((-(-ch // 8), -(-cw // 8), 64)) < 0.3)).astype(np.int16)
+        coefs.append(np.ascontiguousarray(a))
+    ql, qc = L.quant_table_port(75, False), L.quant_table_port(75, True)
+    scan = L.huffman_encode_port(coefs, w, h, sampling, ri)
+    jpeg = L.jpeg_assemble_port(coefs, w, h, sampling, ri, ql, qc, scan)
+    rc, hdr = _parse_with_library(jpeg)
+    assert rc == 0 and hdr.scan.restart_interval == ri and (hdr.scan.w, hdr.scan.h) == (w, h)
+    assert jpeg[hdr.scan_offset: hdr.scan_offset + hdr.scan_bytes] == scan  # RSTn markers are part of the data
+    assert [(hdr.scan.blocks_h[c], hdr.scan.blocks_w[c]) for c in range(3)] == [c.shape[:2] for c in coefs]
+    assert np.array_equal(np.frombuffer(hdr.qtable[0], dtype=np.uint16), ql) and np.array_equal(np.frombuffer(hdr.qtable[2], dtype=np.uint16), qc)
+    # refusals: not a JPEG, truncated, progressive (SOF2)
+    assert _parse_with_library(b"\x89PNG\r\n\x1a\n" + bytes(32))[0] < 0
+    assert _parse_with_library(jpeg[: hdr.scan_offset + 10])[0] < 0
+    prog = bytearray(jpeg)
+    prog[prog.find(b"\xff\xc0") + 1] = 0xC2
+    assert _parse_with_library(bytes(prog))[0] == -8
