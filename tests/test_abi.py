@@ -177,3 +177,33 @@ def test_jpeg_assemble_host_entry_point():
         sc.blocks_w[0] += 5
         assert lib.uhdr_hip_jpeg_assemble(C.byref(sc), (C.c_uint16 * 64)(*ql.tolist()), (C.c_uint16 * 64)(*qc.tolist()), src.ctypes.data, src.size,
                                           out.ctypes.data, out.size) == 0  # block grid of another image
+
+
+def test_jpeg_parse_survives_mutated_files():
+    """Untrusted bytes: random mutations / truncations of a valid file never crash the parser, and whatever it accepts
+    stays inside the buffer."""
+    from oracle import loader as L
+
+    lib = A.load()
+    rng = np.random.default_rng(1)
+    w, h, ri, sampling = 50, 30, 3, [(2, 2), (1, 1), (1, 1)]
+    coefs = []
+    for hs, vs in sampling:
+        cw, ch = -(-w * hs // 2), -(-h * vs // 2)
+        coefs.append(np.ascontiguousarray((rng.normal(0, 20, (-(-ch // 8), -(-cw // 8), 64)) * (rng.random((-(-ch // 8), -(-cw // 8), 64)) < 0.3)).astype(np.int16)))
+    ql, qc = L.quant_table_port(75, False), L.quant_table_port(75, True)
+    jpeg = L.jpeg_assemble_port(coefs, w, h, sampling, ri, ql, qc, L.huffman_encode_port(coefs, w, h, sampling, ri))
+    base = np.frombuffer(jpeg, dtype=np.uint8)
+    hdr = A.JpegHeader()
+    accepted = 0
+    for _ in range(20000):
+        b = base.copy()
+        k = int(rng.integers(1, 6))
+        b[rng.integers(0, min(len(b), 700), k)] = rng.integers(0, 256, k)
+        n = int(rng.integers(4, len(b) + 1)) if rng.random() < 0.3 else len(b)
+        buf = (C.c_uint8 * n).from_buffer_copy(b[:n].tobytes())
+        if lib.uhdr_hip_jpeg_parse(buf, n, C.byref(hdr)) == 0:
+            accepted += 1
+            assert hdr.scan_offset + hdr.scan_bytes <= n and hdr.scan.num_components in (1, 3)
+            assert all(1 <= hdr.scan.h_samp[c] <= 2 and 1 <= hdr.scan.v_samp[c] <= 2 for c in range(hdr.scan.num_components))
+    assert accepted > 0
