@@ -275,8 +275,7 @@ __global__ __launch_bounds__(256) void huff_gather_kernel(const uint8_t* __restr
 
 }  // namespace
 
-// bytes of slot per block of an interval: the worst-case block (kWordsPerBlock words), every byte stuffed
-uint32_t huff_slot_stride(int blocks_per_interval) { return (uint32_t)(blocks_per_interval * kWordsPerBlock * 4 * 2); }
+uint32_t huff_slot_stride() { return (uint32_t)(kSegBlocks * kWordsPerBlock * 4 * 2); }  // every byte could be stuffed
 
 hipError_t launch_huffman_encode(const HuffArgs& a, uint64_t* offsets, uint32_t* status, uint8_t* out, uint64_t cap, hipStream_t s) {
   int grid = a.nseg < 8192 ? a.nseg : 8192;

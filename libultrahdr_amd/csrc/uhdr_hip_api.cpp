@@ -1518,7 +1518,7 @@ uhdr_error_info_t uhdr_hip_huffman_encode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
   a.nseg = (a.total_mcus + a.ri - 1) / a.ri;
   a.tables = c->d_huff;
   a.zigzag = (const uint8_t*)(c->d_huff + host::kHuffTabWords);
-  a.slot_stride = huff_slot_stride(a.ri * bpm);
+  a.slot_stride = huff_slot_stride();
   // scratch: interval slots | interval sizes | offsets (nseg + 1) | status
   UHDR_TRY(ensure(c->scratch[4], (size_t)a.nseg * a.slot_stride));
   const size_t meta = (size_t)a.nseg * sizeof(uint32_t) + 16 + ((size_t)a.nseg + 1) * sizeof(uint64_t) + 16;

@@ -195,7 +195,7 @@ struct HuffArgs {
   uint32_t slot_stride;
   uint32_t* seg_bytes;     // [nseg] stuffed bytes per interval (0xFFFFFFFF: coefficients outside the baseline range)
 };
-uint32_t huff_slot_stride(int blocks_per_interval);
+uint32_t huff_slot_stride();
 hipError_t launch_huffman_encode(const HuffArgs& a, uint64_t* offsets, uint32_t* status, uint8_t* out, uint64_t cap, hipStream_t s);
 
 // ---- baseline Huffman decoding (huffman_decode.hip) ---------------------------------------------------
