@@ -699,36 +699,6 @@ def test_huffman_device_round_trip_and_reference_files(uhdr):
         assert np.array_equal(got[c].cpu().numpy(), want[c]), c
 
 
-def test_jpeg_file_to_hdr_pixels_without_the_cpu_decoder(uhdr):
-    """The whole device decode chain from file bytes: headers parsed by the library's host parser, entropy-coded data
-    decoded per restart interval, the base image's IDCT inside applyGainMap -- against the oracle's decode of the same
-    coefficients.  The file comes from the oracle's encoder (restart interval 3, i.e. what uhdr_hip_huffman_encode_dev writes)."""
-    w, h, ri = 256, 96, 3
-    f16 = A.UHDR_IMG_FMT_64bppRGBAHalfFloat
-    sampling = [(2, 2), (1, 1), (1, 1)]
-    sdr = synth.make_sdr_yuv420(w, h, align=8, noise=0.05)
-    ql, qc = uhdr.quant_table(92, False), uhdr.quant_table(92, True)
-    coefs = [L.fdct_quant_port(np.ascontiguousarray(sdr.valid(c)), sdr.valid(c).shape[1], sdr.valid(c).shape[1] // 8, sdr.valid(c).shape[0] // 8,
-                               ql if c == 0 else qc) for c in range(3)]
-    jpeg = L.jpeg_assemble_port(coefs, w, h, sampling, ri, ql, qc, L.huffman_encode_port(coefs, w, h, sampling, ri))
-    hdr, dev = uhdr.jpeg_to_coefficients(jpeg)
-    assert hdr.scan.restart_interval == ri and (hdr.scan.w, hdr.scan.h) == (w, h)
-    for c in range(3):
-        assert np.array_equal(dev[c].cpu().numpy(), coefs[c]), c
-    qts = [np.frombuffer(hdr.qtable[c], dtype=np.uint16).copy() for c in range(3)]
-    assert np.array_equal(qts[0], ql) and np.array_equal(qts[1], qc)
-    gm = synth.make_gainmap(w // 4, h // 4, 1)
-    md = synth.default_metadata()
-    dest = Image(f16, w, h, align=2, device="cuda:0")
-    uhdr.applyGainMapFromCoefficients(dev, qts, w, h, A.UHDR_CG_BT_709, gm.to("cuda:0"), md, A.UHDR_CT_LINEAR, f16, A.FLT_MAX, dest)
-    uhdr.ctx.synchronize()
-    dec = Image(A.UHDR_IMG_FMT_12bppYCbCr420, w, h, A.UHDR_CG_BT_709, A.UHDR_CT_SRGB, A.UHDR_CR_FULL_RANGE, align=2)
-    for c in range(3):
-        dec.valid(c)[:] = L.idct_dequant_port(coefs[c], ql if c == 0 else qc)[: dec.valid(c).shape[0], : dec.valid(c).shape[1]]
-    want = L.apply_gainmap(oracle_kind(), dec, gm, md, A.UHDR_CT_LINEAR)
-    assert np.array_equal(dest.to_host().valid(0), want.valid(0))
-
-
 def test_huffman_decode_error_behaviour(uhdr):
     import torch
 
