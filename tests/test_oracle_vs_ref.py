@@ -502,3 +502,32 @@ def test_jpeg_parse_round_trips_assembled_files_and_refuses_what_it_does_not_han
     prog = bytearray(jpeg)
     prog[prog.find(b"\xff\xc0") + 1] = 0xC2
     assert _parse_with_library(bytes(prog))[0] == -8
+
+
+def test_huffman_restatements_randomised_against_libjpeg(ref):
+    """150 random scans (geometry, sampling incl. 4:2:2 / 4:4:0-style 1x2, restart interval, coefficient statistics): the
+    oracle's stream is read by libjpeg and by the oracle's own decoder to exactly the input."""
+    rng = np.random.default_rng(37)
+    layouts = [[(1, 1)], [(1, 1)] * 3, [(2, 2), (1, 1), (1, 1)], [(2, 1), (1, 1), (1, 1)], [(1, 2), (1, 1), (1, 1)]]
+    ql, qc = L.quant_table_port(85, False), L.quant_table_port(85, True)
+    for it in range(150):
+        sampling = layouts[int(rng.integers(len(layouts)))]
+        w, h = int(rng.integers(1, 120)), int(rng.integers(1, 90))
+        hmax, vmax = max(s[0] for s in sampling), max(s[1] for s in sampling)
+        ri = int(rng.choice([0, 1, 2, 3, 7, 50]))
+        density, amp = float(rng.choice([0.0, 0.05, 0.3, 1.0])), int(rng.choice([1, 30, 1023]))
+        coefs = []
+        for hs, vs in sampling:
+            cw, ch = -(-w * hs // hmax), -(-h * vs // vmax)
+            a = (rng.integers(-amp, amp + 1, (-(-ch // 8), -(-cw // 8), 64)) * (rng.random((-(-ch // 8), -(-cw // 8), 64)) < density)).astype(np.int16)
+            a[..., 0] = rng.integers(-1020, 1021, a.shape[:2])
+            coefs.append(np.ascontiguousarray(a))
+        scan = L.huffman_encode_port(coefs, w, h, sampling, ri)
+        rc, mine = L.huffman_decode_port([c.shape[:2] for c in coefs], w, h, sampling, ri, scan)
+        assert rc == 0 and all(np.array_equal(m, c) for m, c in zip(mine, coefs)), (it, w, h, sampling, ri)
+        if it % 3 == 0:
+            jpeg = L.jpeg_assemble_port(coefs, w, h, sampling, ri, ql, qc, scan)
+            back, _ = _read_coefficients(ref, jpeg)
+            assert all(np.array_equal(b, c) for b, c in zip(back, coefs)), (it, w, h, sampling, ri)
+            rc2, hdr = _parse_with_library(jpeg)
+            assert rc2 == 0 and jpeg[hdr.scan_offset: hdr.scan_offset + hdr.scan_bytes] == scan
