@@ -142,6 +142,9 @@ uhdr_hip_ctx_t* uhdr_hip_create(int device, uhdr_error_info_t* err);
 void uhdr_hip_destroy(uhdr_hip_ctx_t* ctx);
 /* run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the context's own */
 uhdr_error_info_t uhdr_hip_set_stream(uhdr_hip_ctx_t* ctx, void* hip_stream);
+/* the hipStream_t the context currently enqueues on (its own non-blocking stream unless uhdr_hip_set_stream changed
+ * it): lets a caller order its own streams against the library's with events instead of host synchronisation */
+void* uhdr_hip_get_stream(uhdr_hip_ctx_t* ctx);
 uhdr_error_info_t uhdr_hip_synchronize(uhdr_hip_ctx_t* ctx);
 const char* uhdr_hip_version(void);
 int uhdr_hip_device_count(void);

@@ -163,6 +163,7 @@ _SIGS = {
     "uhdr_hip_create": (C.c_void_p, [C.c_int, _P(ErrorInfo)]),
     "uhdr_hip_destroy": (None, [C.c_void_p]),
     "uhdr_hip_set_stream": (ErrorInfo, [C.c_void_p, C.c_void_p]),
+    "uhdr_hip_get_stream": (C.c_void_p, [C.c_void_p]),
     "uhdr_hip_synchronize": (ErrorInfo, [C.c_void_p]),
     "uhdr_hip_apply_gainmap": (ErrorInfo, [C.c_void_p, _P(RawImage), _P(RawImage), _P(GainmapMetadata), C.c_int, C.c_int, C.c_float, _P(RawImage)]),
     "uhdr_hip_apply_gainmap_dev": (ErrorInfo, [C.c_void_p, _P(RawImage), _P(RawImage), _P(GainmapMetadata), C.c_int, C.c_int, C.c_float, _P(RawImage), C.c_uint, C.c_uint]),

@@ -334,9 +334,6 @@ __device__ __forceinline__ uint32_t half_small_pair(uint32_t bits0, uint32_t bit
   return lo | (hi << 16);
 }
 __device__ __forceinline__ f2 lds_gather(const float* base, uint2 byte_off) {
-#ifdef UHDR_EXP_NOLDS  // experiment (tools/kbench): no LDS traffic
-  return (f2){__uint_as_float(byte_off.x | 0x3f000000u), __uint_as_float(byte_off.y | 0x3f000000u)};
-#endif
   const char* b = (const char*)base;
   return (f2){*(const float*)(b + byte_off.x), *(const float*)(b + byte_off.y)};
 }
@@ -352,11 +349,7 @@ __device__ __forceinline__ f2 lds_gather(const float* base, uint2 byte_off) {
 typedef uint32_t u2v __attribute__((ext_vector_type(2)));
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 template <typename T> __device__ __forceinline__ void stream_store(void* a, T v) {
-#ifdef UHDR_EXP_NONT  // experiment (tools/kbench)
-  *(T*)a = v;
-#else
   __builtin_nontemporal_store(v, (T*)a);
-#endif
 }
 
 // Raw bytes of one lane's quad, loaded one tile AHEAD of their use: on gfx9 stores and loads retire
@@ -591,16 +584,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
       crv = splat(yk.cr * vf); gcbu = splat(yk.gcb * uf); gcrv = splat(yk.gcr * vf); cbu = splat(yk.cb * uf);
     }
     const uint32_t drow = q.y * sd;  // wave-uniform row offset
-#ifdef UHDR_EXP_NOMATH  // experiment (tools/kbench): memory pattern only
-    if constexpr (OUT == 0 && SMODE == 0) {
-      for (int r = 0; r < 2; r++) {
-        const uint32_t yb = r == 0 ? q.y0 : q.y1;
-        uint4 o = {yb ^ q.u, q.m[2 * r] ^ q.v, q.m[2 * r + 1], yb};
-        stream_store<u4v>(dp + (drow + r * sd + xdst), (u4v){o.x, o.y, o.z, o.w});
-      }
-      return;
-    }
-#endif
 #pragma unroll
     for (int r = 0; r < 2; r++) {
       f2 lr, lg, lb;
@@ -629,17 +612,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
         }
         // p3YuvToRgb + clampPixelFloat + srgbInvOetfLUT; the clamp is absorbed by the index
         // conversion and the padded table (see lut_off_unclamped)
-#ifdef UHDR_EXP_OLDCLAMP
-        lr = lds_gather(s_srgb, lut_off_1024(clamp01_2(yf + crv)));
-        lg = lds_gather(s_srgb, lut_off_1024(clamp01_2(yf - gcbu - gcrv)));
-        lb = lds_gather(s_srgb, lut_off_1024(clamp01_2(yf + cbu)));
-#else
         lr = lds_gather(s_srgb, lut_off_unclamped(yf + crv));
         lg = lds_gather(s_srgb, lut_off_unclamped(yf - gcbu - gcrv));
         lb = lds_gather(s_srgb, lut_off_unclamped(yf + cbu));
-#endif
       }
-#ifndef UHDR_EXP_NOGAMUT
       if (p.sdr_gamut_on) {
         const Mat3& m = p.gamut;
         const f2 nr = m.m[0] * lr + m.m[1] * lg + m.m[2] * lb;
@@ -647,7 +623,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
         const f2 nb = m.m[6] * lr + m.m[7] * lg + m.m[8] * lb;
         lr = nr; lg = ng; lb = nb;
       }
-#endif
       f2 f0, f1, f2_;
       if constexpr (SMODE == 0) {
         const uint32_t a = q.m[2 * r], b = q.m[2 * r + 1];
@@ -711,9 +686,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
           o.z = half_small_pair(__float_as_uint(c1r), __float_as_uint(c1g));
           o.w = half_small_pair(__float_as_uint(c1b), 0x3F800000u - 0x1000u);
         }
-#ifdef UHDR_EXP_NOSTORE  // experiment (tools/kbench): keep the math alive, never store
-        if (o.x == 0x12345678u && o.w == 0x9abcdef0u)
-#endif
         if (SRC == 0 || store_ok) stream_store<u4v>(dpx, (u4v){o.x, o.y, o.z, o.w});
       } else {
         const float peak = (OUT == 1) ? 1000.0f : 10000.0f;  // kHlgMaxNits / kPqMaxNits
@@ -939,11 +911,14 @@ int apply_quad_mode(const ApplyParams& p) {
   const size_t out_bytes = out == 0 ? 8 : 4;
   // base layouts the quad kernel reads: 4:2:0, 4:2:2, 4:4:4 (chroma pairs as 16-bit loads), packed RGBA8888 (8-byte loads)
   bool base_ok = false;
+  // the kernel addresses every base plane with 32-bit byte offsets (row * stride + column): rows + 1 covers the
+  // clamped look-ahead row of the software pipeline
+  auto fits32 = [&](int pl) { return (uint64_t)p.sdr.stride[pl] * ((uint64_t)p.sdr.h + 1) < 0xFFFFFFFFull; };
   if (p.sdr.fmt == UHDR_IMG_FMT_12bppYCbCr420 || p.sdr.fmt == UHDR_IMG_FMT_16bppYCbCr422) {
-    base_ok = (p.sdr.stride[0] % 2 == 0) && aligned_to(p.sdr.p[0], 2);
+    base_ok = (p.sdr.stride[0] % 2 == 0) && aligned_to(p.sdr.p[0], 2) && fits32(0) && fits32(1) && fits32(2);
   } else if (p.sdr.fmt == UHDR_IMG_FMT_24bppYCbCr444) {
     base_ok = (p.sdr.stride[0] % 2 == 0) && (p.sdr.stride[1] % 2 == 0) && (p.sdr.stride[2] % 2 == 0) &&
-              aligned_to(p.sdr.p[0], 2) && aligned_to(p.sdr.p[1], 2) && aligned_to(p.sdr.p[2], 2);
+              aligned_to(p.sdr.p[0], 2) && aligned_to(p.sdr.p[1], 2) && aligned_to(p.sdr.p[2], 2) && fits32(0) && fits32(1) && fits32(2);
   } else if (p.sdr.fmt == UHDR_IMG_FMT_32bppRGBA8888) {
     base_ok = (p.sdr.stride[0] % 2 == 0) && aligned_to(p.sdr.p[0], 8) && (uint64_t)p.sdr.stride[0] * 4 * p.sdr.h < 0xFFFFFFFFull;
   }

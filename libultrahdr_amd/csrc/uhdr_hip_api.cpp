@@ -168,6 +168,24 @@ size_t plane_bytes(const uhdr_raw_image_t* im, int pl) {
   return ((rows - 1) * (size_t)im->stride[pl] + width) * bytes_per_sample(im->fmt);
 }
 
+// Shared descriptor check of the *_dev entry points (the reference allocates these images itself, a C ABI caller
+// fills them by hand): every plane the format has must be non-null and every stride must cover the plane's row.
+uhdr_error_info_t validate_image(const uhdr_raw_image_t* im, const char* what) {
+  if (!im) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for %s image descriptor", what);
+  if (im->w == 0 || im->h == 0)
+    return err_status(UHDR_CODEC_INVALID_PARAM, "%s image dimensions cannot be zero, received %ux%u", what, im->w, im->h);
+  for (int pl = 0; pl < 3; pl++) {
+    size_t rows, width;
+    if (!plane_geom(im, pl, &rows, &width)) continue;
+    if (!im->planes[pl])
+      return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for plane %d of %s image (format %d)", pl, what, im->fmt);
+    if ((size_t)im->stride[pl] < width)
+      return err_status(UHDR_CODEC_INVALID_PARAM, "%s image: stride %u of plane %d is less than its row width %zu", what,
+                        im->stride[pl], pl, width);
+  }
+  return ok_status();
+}
+
 ImageView view_of(const uhdr_raw_image_t* im) {
   ImageView v;
   for (int i = 0; i < 3; i++) { v.p[i] = im->planes[i]; v.stride[i] = im->stride[i]; }
@@ -430,6 +448,8 @@ uhdr_error_info_t uhdr_hip_set_stream(uhdr_hip_ctx_t* c, void* hip_stream) {
   c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
   return ok_status();
 }
+
+void* uhdr_hip_get_stream(uhdr_hip_ctx_t* c) { return c ? (void*)c->stream : nullptr; }
 
 uhdr_error_info_t uhdr_hip_synchronize(uhdr_hip_ctx_t* c) {
   if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
@@ -721,6 +741,8 @@ static uhdr_error_info_t fill_gen_params(uhdr_hip_ctx* c, const uhdr_raw_image_t
                       sdr->w, sdr->h, hdr->w, hdr->h);
   if (cfg->map_dimension_scale_factor < 1)
     return err_status(UHDR_CODEC_INVALID_PARAM, "gainmap scale factor %d is not positive", cfg->map_dimension_scale_factor);
+  UHDR_TRY(validate_image(sdr, "sdr intent"));
+  UHDR_TRY(validate_image(hdr, "hdr intent"));
   memset(p, 0, sizeof *p);
   const float hdr_white_nits = host::reference_peak_nits(hdr->ct);
   *hdr_white_nits_out = hdr_white_nits;
@@ -815,6 +837,13 @@ uhdr_error_info_t uhdr_hip_generate_gainmap_pass1_dev(uhdr_hip_ctx_t* c, const u
   GenParams p;
   float white;
   UHDR_TRY(fill_gen_params(c, sdr, hdr, cfg, &p, use_base_cg, &white));
+  // The small-image fallback of jpegr.cpp:696-706 belongs to the WHOLE image; a stripe must keep the configured scale
+  // factor (its caller sizes gain_log2_dev as (w / scale) * (h / scale) samples), so a stripe too short for one map
+  // row is an error here -- such a rank launches nothing and contributes the identity {127, -128} to the merge.
+  if (p.scale != (uint32_t)cfg->map_dimension_scale_factor)
+    return err_status(UHDR_CODEC_INVALID_PARAM, "stripe %ux%u holds no map sample at scale factor %d (pass1 takes stripes of at least "
+                      "scale rows / columns; the reference's small-image fallback applies to whole images only)", sdr->w, sdr->h,
+                      cfg->map_dimension_scale_factor);
   UHDR_TRY(ensure(c->minmax, (6 + 2048 * 6) * sizeof(float)));
   p.gain_log2 = gain_log2_dev;
   p.minmax = (float*)c->minmax.p;
@@ -981,6 +1010,8 @@ uhdr_error_info_t uhdr_hip_tone_map_dev(uhdr_hip_ctx_t* c, const uhdr_raw_image_
   if (sdr->w != hdr->w || sdr->h != hdr->h)
     return err_status(UHDR_CODEC_INVALID_PARAM, "sdr intent resolution %ux%u and hdr intent resolution %ux%u do not match",
                       sdr->w, sdr->h, hdr->w, hdr->h);
+  UHDR_TRY(validate_image(hdr, "hdr intent"));
+  UHDR_TRY(validate_image(sdr, "sdr intent"));
   HIP_TRY(hipSetDevice(c->device));
   sdr->cg = UHDR_CG_DISPLAY_P3;
   sdr->ct = UHDR_CT_SRGB;
@@ -1018,6 +1049,7 @@ uhdr_error_info_t uhdr_hip_convert_yuv_dev(uhdr_hip_ctx_t* c, uhdr_raw_image_t* 
   if (r == 1) return ok_status();
   if (img->fmt != UHDR_IMG_FMT_12bppYCbCr420 && img->fmt != UHDR_IMG_FMT_24bppYCbCr444)
     return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "No implementation available for performing gamut conversion for color format %d", img->fmt);
+  UHDR_TRY(validate_image(img, "yuv"));
   HIP_TRY(hipSetDevice(c->device));
   p.img = view_mut_of(img);
   ProfScope ps(c, "convert_yuv");
@@ -1048,9 +1080,8 @@ uhdr_error_info_t uhdr_hip_convert_raw_input_to_ycbcr_dev(uhdr_hip_ctx_t* c, con
                  : (chroma ? UHDR_IMG_FMT_12bppYCbCr420 : UHDR_IMG_FMT_24bppYCbCr444);
   dst->cg = src->cg; dst->ct = src->ct; dst->range = UHDR_CR_FULL_RANGE;
   dst->w = src->w; dst->h = src->h;
-  for (int pl = 0; pl < 3; pl++)
-    if (plane_bytes(dst, pl) && !dst->planes[pl])
-      return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for destination plane %d", pl);
+  UHDR_TRY(validate_image(src, "source"));
+  UHDR_TRY(validate_image(dst, "destination"));
   RgbToYcbcrParams p;
   p.src = view_of(src);
   p.dst = view_mut_of(dst);
@@ -1273,6 +1304,8 @@ uhdr_error_info_t uhdr_hip_copy_raw_image_dev(uhdr_hip_ctx_t* c, const uhdr_raw_
   if (dst->w != src->w || dst->h != src->h)
     return err_status(UHDR_CODEC_MEM_ERROR, "destination image dimensions %dx%d and source image dimensions %dx%d are not identical for copy_raw_image",
                       dst->w, dst->h, src->w, src->h);
+  UHDR_TRY(validate_image(src, "source"));
+  UHDR_TRY(validate_image(dst, "destination"));
   HIP_TRY(hipSetDevice(c->device));
   dst->cg = src->cg; dst->ct = src->ct; dst->range = src->range;
   const size_t w = src->w, h = src->h;

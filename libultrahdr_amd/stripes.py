@@ -4,8 +4,8 @@ Every stage of the hot path computes an output pixel / block from a bounded inpu
 so an image splits into independent horizontal stripes -- one per rank / GPU -- with NO data-path
 collective.  The single exception is two-pass gain-map generation, whose only cross-stripe
 dependency is the global per-channel min/max of the log2 gain (the mutex-guarded merge at
-/root/reference/lib/src/jpegr.cpp:932-938).  That becomes one tiny all-reduce (3 floats MIN,
-3 floats MAX; RCCL over xGMI on GPUs, gloo in the CPU tests): latency-bound, never bandwidth-bound.
+/root/reference/lib/src/jpegr.cpp:932-938).  That becomes ONE tiny all-reduce (MIN over the 6 floats
+{min0..2, -max0..2}; RCCL over xGMI on GPUs, gloo in the CPU tests): latency-bound, never bandwidth-bound.
 
 Stripe boundaries must be multiples of lcm(2 (4:2:0 chroma rows), scale (box sampling), 16 (4:2:0
 MCU rows of the JPEG stage)); ``partition_rows`` takes that granule.
@@ -39,17 +39,32 @@ def partition_rows(height: int, world_size: int, granule: int = 16):
     return out
 
 
+def merge_minmax(parts):
+    """Sequential merge of per-stripe {min0,min1,min2,max0,max1,max2} lists -- what the reference's mutex-guarded
+    merge does (jpegr.cpp:932-938) and what the all-reduce below computes across ranks."""
+    out = [127.0, 127.0, 127.0, -128.0, -128.0, -128.0]
+    for p in parts:
+        for i in range(3):
+            out[i] = min(out[i], float(p[i]))
+            out[3 + i] = max(out[3 + i], float(p[3 + i]))
+    return out
+
+
 def allreduce_minmax(minmax, group=None):
-    """In-place all-reduce of a 6-element float32 tensor {min0,min1,min2,max0,max1,max2}:
-    MIN over the first three, MAX over the last three.  Works on CPU tensors (gloo) and CUDA tensors
-    (backend "nccl" == RCCL on ROCm).  Float min/max is order-independent, so the result is
-    bit-identical to the reference's sequential merge."""
+    """In-place all-reduce of a 6-element float32 tensor {min0,min1,min2,max0,max1,max2} with ONE collective:
+    MIN over {min0, min1, min2, -max0, -max1, -max2} (negation is exact, so max == -min(-x) bit for bit).  Works on
+    CPU tensors (gloo) and CUDA tensors (backend "nccl" == RCCL on ROCm).  Float min/max is order-independent, so
+    the result is bit-identical to the reference's sequential merge.  (The C++ host layer does the same on the
+    context's own stream without leaving the device: uhdr_hip_generate_gainmap_two_pass_striped_dev.)"""
+    import torch
     import torch.distributed as dist
 
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return minmax
-    dist.all_reduce(minmax[:3], op=dist.ReduceOp.MIN, group=group)
-    dist.all_reduce(minmax[3:], op=dist.ReduceOp.MAX, group=group)
+    t = torch.cat([minmax[:3], -minmax[3:]])
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    minmax[:3] = t[:3]
+    minmax[3:] = -t[3:]
     return minmax
 
 
@@ -74,18 +89,23 @@ def generate_gainmap_two_pass_striped(uhdr, sdr_stripe, hdr_stripe, cfg: A.Encod
     nch = 3 if cfg.use_multi_channel_gainmap else 1
     s = cfg.map_dimension_scale_factor
     mw, mh = sdr_stripe.w // s, sdr_stripe.h // s
-    gains = torch.empty(mw * mh * nch, dtype=torch.float32, device=dev)
-    mm = torch.empty(6, dtype=torch.float32, device=dev)
+    gains = torch.empty(max(mw * mh * nch, 1), dtype=torch.float32, device=dev)
+    mm = torch.tensor([127.0] * 3 + [-128.0] * 3, dtype=torch.float32, device=dev)  # the identity of the merge
+    torch.cuda.current_stream(dev).synchronize()
     ubc = C.c_int(1)
     lib, h = uhdr.lib, uhdr.ctx.handle
-    A.check(lib.uhdr_hip_generate_gainmap_pass1_dev(h, C.byref(sdr_stripe.raw), C.byref(hdr_stripe.raw), C.byref(cfg),
-                                                    C.c_void_p(gains.data_ptr()), C.c_void_p(mm.data_ptr()), C.byref(ubc)))
+    # a last stripe with fewer rows than the scale factor holds no map row (the whole image's map has H // s rows): it
+    # launches nothing and contributes the identity; uhdr_hip_generate_gainmap_pass1_dev refuses such a stripe
+    if mh > 0:
+        A.check(lib.uhdr_hip_generate_gainmap_pass1_dev(h, C.byref(sdr_stripe.raw), C.byref(hdr_stripe.raw), C.byref(cfg),
+                                                        C.c_void_p(gains.data_ptr()), C.c_void_p(mm.data_ptr()), C.byref(ubc)))
     uhdr.ctx.synchronize()  # mm was produced on the context's stream; the collective runs on torch's
     allreduce_minmax(mm, group)
     fin, md = finalize_minmax(cfg, hdr_stripe.raw.ct, ubc.value, mm.cpu().tolist())
     gm_stripe.raw.w, gm_stripe.raw.h = mw, mh
-    A.check(lib.uhdr_hip_generate_gainmap_pass2_dev(h, C.c_void_p(gains.data_ptr()), (C.c_float * 6)(*fin), C.byref(cfg),
-                                                    C.byref(gm_stripe.raw)))
+    if mh > 0:
+        A.check(lib.uhdr_hip_generate_gainmap_pass2_dev(h, C.c_void_p(gains.data_ptr()), (C.c_float * 6)(*fin), C.byref(cfg),
+                                                        C.byref(gm_stripe.raw)))
     return md
 
 

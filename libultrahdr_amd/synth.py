@@ -131,3 +131,60 @@ def checksum(img: Image) -> int:
     for p in img.to_host().planes_valid():
         acc = zlib.crc32(np.ascontiguousarray(p).tobytes(), acc)
     return acc
+
+
+# ---- the remaining input formats the encode operators accept (gainmapmath.cpp:398-492) -----------------
+def make_sdr_planar(fmt, w, h, seed=SEED, cg=A.UHDR_CG_BT_709, align=64, noise=0.02) -> Image:
+    """YCbCr 4:2:2 / 4:4:4 (or 4:2:0) SDR rendition of the same field as make_sdr_yuv420."""
+    rng = np.random.default_rng(seed)
+    luma = _field(w, h, rng, noise)
+    img = Image(fmt, w, h, cg, A.UHDR_CT_SRGB, A.UHDR_CR_FULL_RANGE, align)
+    img.valid(0)[:] = np.clip(np.rint(255.0 * luma ** 0.8), 0, 255).astype(np.uint8)
+    ch, cw = img.valid(1).shape
+    sx, sy = w / cw, h / ch
+    x = (np.arange(cw, dtype=np.float64) * sx / 2.0)[None, :]
+    y = (np.arange(ch, dtype=np.float64) * sy / 2.0)[:, None]
+    for pl, ph in ((1, 0.3), (2, 1.1)):
+        c = 0.5 + 0.12 * np.sin(x / 53.0 + ph) * np.sin(y / 71.0 + 2 * ph)
+        img.valid(pl)[:] = np.clip(np.rint(255.0 * c + rng.normal(0.0, 255.0 * noise / 2, c.shape)), 0, 255).astype(np.uint8)
+    return img
+
+
+def make_hdr_yuv444_10bit(w, h, seed=SEED, ct=A.UHDR_CT_PQ, cg=A.UHDR_CG_BT_2100, align=64, noise=0.02,
+                          rng_range=A.UHDR_CR_LIMITED_RANGE) -> Image:
+    """UHDR_IMG_FMT_30bppYCbCr444: three planes of 10-bit samples in the LOW bits of uint16 (gainmapmath.cpp:398-420)."""
+    rng = np.random.default_rng(seed)
+    luma = _field(w, h, rng, noise)
+    img = Image(A.UHDR_IMG_FMT_30bppYCbCr444, w, h, cg, ct, rng_range, align)
+    if rng_range == A.UHDR_CR_LIMITED_RANGE:
+        yv, cscale, coff = 64 + np.rint(876.0 * luma), 896.0, 64.0
+    else:
+        yv, cscale, coff = np.rint(1023.0 * luma), 1023.0, 0.0
+    img.valid(0)[:] = np.clip(yv, 0, 1023).astype(np.uint16)
+    for pl, ph in ((1, 0.7), (2, 1.9)):
+        c = _chroma(w, h, ph) + rng.normal(0.0, noise / 2, (h, w))
+        img.valid(pl)[:] = np.clip(coff + np.rint(cscale * c), 0, 1023).astype(np.uint16)
+    return img
+
+
+def make_hdr_rgba_f16(w, h, seed=SEED, cg=A.UHDR_CG_BT_2100, align=64, noise=0.02, peak=20.0, specials=True) -> Image:
+    """UHDR_IMG_FMT_64bppRGBAHalfFloat, linear light (1.0 = SDR white).  specials: a sprinkle of +inf, -inf, NaN,
+    negative, sub-normal and over-range values -- what getRgbaF16Pixel's sanitizePixel exists for (gainmapmath.cpp:483-492)."""
+    rng = np.random.default_rng(seed)
+    base = _field(w, h, rng, noise) ** 2.2 * peak
+    x = np.arange(w, dtype=np.float64)[None, :]
+    y = np.arange(h, dtype=np.float64)[:, None]
+    px = np.empty((h, w, 4), dtype=np.float16)
+    px[..., 0] = base * (0.85 + 0.15 * np.sin(x / 41.0))
+    px[..., 1] = base * (0.85 + 0.15 * np.cos(y / 37.0))
+    px[..., 2] = base * (0.85 + 0.15 * np.sin((x + y) / 59.0))
+    px[..., 3] = 1.0
+    if specials:
+        bits = px.view(np.uint16)
+        n = max(8, (w * h) // 97)
+        ys, xs, cs = rng.integers(0, h, n), rng.integers(0, w, n), rng.integers(0, 3, n)
+        vals = np.array([0x7C00, 0xFC00, 0x7E00, 0xFE01, 0xBC00, 0x8001, 0x0001, 0x03FF, 0x7BFF, 0x5640, 0x0000, 0x8000], dtype=np.uint16)
+        bits[ys, xs, cs] = vals[rng.integers(0, vals.size, n)]
+    img = Image(A.UHDR_IMG_FMT_64bppRGBAHalfFloat, w, h, cg, A.UHDR_CT_LINEAR, A.UHDR_CR_FULL_RANGE, align)
+    img.valid(0)[:] = px.view(np.uint64).reshape(h, w)
+    return img

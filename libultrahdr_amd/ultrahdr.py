@@ -19,14 +19,26 @@ from .images import Image, _align
 
 
 class Context:
-    """One ``uhdr_hip_ctx_t``: a device + a stream.  Raises if the HIP library or a GPU is missing."""
+    """One ``uhdr_hip_ctx_t``: a device + a stream.  Raises if the HIP library or a GPU is missing.
 
-    def __init__(self, device: int = -1, stream=None):
+    Stream contract of the Python binding.  The library enqueues on the context's own non-blocking stream, torch on
+    its current stream.  With ``stream_safe=True`` (the default) every device-buffer method of ``UltraHdr`` is ordered
+    against torch by events, never by host synchronisation: before the call the library's stream waits for everything
+    queued on torch's current stream (inputs still being produced by torch kernels / copies), after the call torch's
+    current stream waits for the library's work (a returned tensor can be used at once: ``u.idct_dequant(c).cpu()``).
+    ``stream_safe=False`` leaves ordering to the caller (``ctx.synchronize()`` / ``torch.cuda.synchronize()``), e.g.
+    for timing loops that must not record extra events."""
+
+    def __init__(self, device: int = -1, stream=None, stream_safe: bool = True):
         self.lib = A.load()
         err = A.ErrorInfo()
         self.handle = self.lib.uhdr_hip_create(device, C.byref(err))
         if not self.handle:
             raise A.UhdrError(err.error_code, err.detail.decode("utf-8", "replace"))
+        self.stream_safe = stream_safe
+        self._ext = None
+        self._ext_ptr = None
+        self._device = device
         if stream is not None:
             self.set_stream(stream)
 
@@ -34,6 +46,24 @@ class Context:
         """``stream``: a raw hipStream_t integer or a ``torch.cuda.Stream``."""
         ptr = getattr(stream, "cuda_stream", stream)
         A.check(self.lib.uhdr_hip_set_stream(self.handle, C.c_void_p(ptr)))
+
+    def stream_ptr(self) -> int:
+        return int(self.lib.uhdr_hip_get_stream(self.handle) or 0)
+
+    def ordered(self):
+        """Context manager that orders the library's stream after torch's current stream on entry and torch's current
+        stream after the library's on exit (events only; a no-op when both are the same stream or stream_safe is off)."""
+        return _Ordered(self)
+
+    def _streams(self):
+        import torch
+
+        ptr = self.stream_ptr()
+        if self._ext is None or self._ext_ptr != ptr:
+            dev = self._device if self._device >= 0 else torch.cuda.current_device()
+            self._ext = torch.cuda.ExternalStream(ptr, device=dev)
+            self._ext_ptr = ptr
+        return torch.cuda.current_stream(self._ext.device), self._ext
 
     def synchronize(self):
         A.check(self.lib.uhdr_hip_synchronize(self.handle))
@@ -56,6 +86,25 @@ class Context:
             self.close()
         except Exception:
             pass
+
+
+class _Ordered:
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self.pair = None
+
+    def __enter__(self):
+        if self.ctx.stream_safe:
+            cur, ext = self.ctx._streams()
+            if cur.cuda_stream != ext.cuda_stream:
+                ext.wait_stream(cur)
+                self.pair = (cur, ext)
+        return self
+
+    def __exit__(self, *exc):
+        if self.pair is not None:
+            self.pair[0].wait_stream(self.pair[1])
+        return False
 
 
 def _is_dev(*imgs) -> bool:
@@ -84,6 +133,14 @@ class UltraHdr:
         self.mMaxContentBoost = maxContentBoost
         self.mTargetDispPeakBrightness = targetDispPeakBrightness
 
+    def _call(self, dev: bool, fn, *args):
+        """One C-ABI call; device-buffer calls are ordered against torch's current stream (Context.ordered)."""
+        if dev:
+            with self.ctx.ordered():
+                A.check(fn(*args))
+        else:
+            A.check(fn(*args))
+
     def encode_cfg(self, sdr_is_601=False, use_luminance=True) -> A.EncodeCfg:
         return A.EncodeCfg(self.mMapDimensionScaleFactor, int(self.mUseMultiChannelGainMap), self.mGamma,
                            self.mEncPreset, self.mMinContentBoost, self.mMaxContentBoost,
@@ -91,8 +148,9 @@ class UltraHdr:
 
     # ---- toneMap (ultrahdrcommon.h:482) ----------------------------------------------------
     def toneMap(self, hdr_intent: Image, sdr_intent: Image):
-        fn = self.lib.uhdr_hip_tone_map_dev if _is_dev(hdr_intent, sdr_intent) else self.lib.uhdr_hip_tone_map
-        A.check(fn(self.ctx.handle, C.byref(hdr_intent.raw), C.byref(sdr_intent.raw)))
+        dev = _is_dev(hdr_intent, sdr_intent)
+        fn = self.lib.uhdr_hip_tone_map_dev if dev else self.lib.uhdr_hip_tone_map
+        self._call(dev, fn, self.ctx.handle, C.byref(hdr_intent.raw), C.byref(sdr_intent.raw))
 
     # ---- generateGainMap (ultrahdrcommon.h:507-510) -------------------------------------------
     def gainmap_dims(self, w: int, h: int):
@@ -113,8 +171,7 @@ class UltraHdr:
         md = A.GainmapMetadata()
         cfg = self.encode_cfg(sdr_is_601, use_luminance)
         fn = self.lib.uhdr_hip_generate_gainmap_dev if dev else self.lib.uhdr_hip_generate_gainmap
-        A.check(fn(self.ctx.handle, C.byref(sdr_intent.raw), C.byref(hdr_intent.raw), C.byref(cfg),
-                   C.byref(md), C.byref(gm.raw)))
+        self._call(dev, fn, self.ctx.handle, C.byref(sdr_intent.raw), C.byref(hdr_intent.raw), C.byref(cfg), C.byref(md), C.byref(gm.raw))
         gm.sync_meta_from_raw()
         return md, gm
 
@@ -130,9 +187,8 @@ class UltraHdr:
         gm = Image(fmt, w, h, align=64, device=dev)
         md = A.GainmapMetadata()
         cfg = self.encode_cfg(False, use_luminance)
-        A.check(self.lib.uhdr_hip_encode_api0_fused_dev(self.ctx.handle, C.byref(hdr_intent.raw), C.byref(cfg),
-                                                        C.byref(sdr.raw) if sdr is not None else None, C.byref(ycc.raw),
-                                                        C.byref(md), C.byref(gm.raw)))
+        self._call(True, self.lib.uhdr_hip_encode_api0_fused_dev, self.ctx.handle, C.byref(hdr_intent.raw), C.byref(cfg),
+                   C.byref(sdr.raw) if sdr is not None else None, C.byref(ycc.raw), C.byref(md), C.byref(gm.raw))
         gm.sync_meta_from_raw()
         return sdr, ycc, md, gm
 
@@ -141,9 +197,9 @@ class UltraHdr:
                      output_ct: int, output_format: int, max_display_boost: float, dest: Image,
                      y0: int = 0, full_height: int = 0):
         if _is_dev(sdr_intent, gainmap_img, dest):
-            A.check(self.lib.uhdr_hip_apply_gainmap_dev(
-                self.ctx.handle, C.byref(sdr_intent.raw), C.byref(gainmap_img.raw), C.byref(gainmap_metadata),
-                output_ct, output_format, max_display_boost, C.byref(dest.raw), y0, full_height))
+            self._call(True, self.lib.uhdr_hip_apply_gainmap_dev,
+                       self.ctx.handle, C.byref(sdr_intent.raw), C.byref(gainmap_img.raw), C.byref(gainmap_metadata),
+                       output_ct, output_format, max_display_boost, C.byref(dest.raw), y0, full_height)
         else:
             if y0 or full_height:
                 raise ValueError("stripes are a device-buffer feature")
@@ -164,9 +220,8 @@ class UltraHdr:
             jc.blocks_h[i], jc.blocks_w[i] = int(coefs[i].shape[0]), int(coefs[i].shape[1])
             for k in range(64):
                 jc.qtable[i][k] = int(qtables[i][k])
-        A.check(self.lib.uhdr_hip_apply_gainmap_coef_dev(self.ctx.handle, C.byref(jc), w, h, base_cg, C.byref(gainmap_img.raw),
-                                                         C.byref(gainmap_metadata), output_ct, output_format, max_display_boost,
-                                                         C.byref(dest.raw)))
+        self._call(True, self.lib.uhdr_hip_apply_gainmap_coef_dev, self.ctx.handle, C.byref(jc), w, h, base_cg, C.byref(gainmap_img.raw),
+                   C.byref(gainmap_metadata), output_ct, output_format, max_display_boost, C.byref(dest.raw))
 
     def applyGainMapBatch(self, sdr_intents, gainmap_imgs, gainmap_metadata: A.GainmapMetadata, output_ct: int,
                           output_format: int, max_display_boost: float, dests):
@@ -175,15 +230,16 @@ class UltraHdr:
         assert n == len(gainmap_imgs) == len(dests) and n > 0
         arr = lambda imgs: (A.RawImage * n)(*[im.raw for im in imgs])
         s, g, d = arr(sdr_intents), arr(gainmap_imgs), arr(dests)
-        A.check(self.lib.uhdr_hip_apply_gainmap_batch_dev(self.ctx.handle, n, s, g, C.byref(gainmap_metadata), output_ct,
-                                                          output_format, max_display_boost, d))
+        self._call(True, self.lib.uhdr_hip_apply_gainmap_batch_dev, self.ctx.handle, n, s, g, C.byref(gainmap_metadata), output_ct,
+                   output_format, max_display_boost, d)
         for im, r in zip(dests, d):
             im.raw.cg = r.cg
 
     # ---- convertYuv (ultrahdrcommon.h:545-546) -------------------------------------------------
     def convertYuv(self, image: Image, src_encoding: int, dst_encoding: int):
-        fn = self.lib.uhdr_hip_convert_yuv_dev if _is_dev(image) else self.lib.uhdr_hip_convert_yuv
-        A.check(fn(self.ctx.handle, C.byref(image.raw), src_encoding, dst_encoding))
+        dev = _is_dev(image)
+        fn = self.lib.uhdr_hip_convert_yuv_dev if dev else self.lib.uhdr_hip_convert_yuv
+        self._call(dev, fn, self.ctx.handle, C.byref(image.raw), src_encoding, dst_encoding)
 
     # ---- convert_raw_input_to_ycbcr (gainmapmath.h:604-605) -----------------------------------
     def convert_raw_input_to_ycbcr(self, src: Image, chroma_sampling_enabled=False) -> Image:
@@ -193,14 +249,14 @@ class UltraHdr:
         else:
             fmt = A.UHDR_IMG_FMT_12bppYCbCr420 if chroma_sampling_enabled else A.UHDR_IMG_FMT_24bppYCbCr444
         dst = Image(fmt, src.w, src.h, align=64, device=src.device)
-        fn = (self.lib.uhdr_hip_convert_raw_input_to_ycbcr_dev if _is_dev(src)
-              else self.lib.uhdr_hip_convert_raw_input_to_ycbcr)
-        A.check(fn(self.ctx.handle, C.byref(src.raw), int(chroma_sampling_enabled), C.byref(dst.raw)))
+        dev = _is_dev(src)
+        fn = self.lib.uhdr_hip_convert_raw_input_to_ycbcr_dev if dev else self.lib.uhdr_hip_convert_raw_input_to_ycbcr
+        self._call(dev, fn, self.ctx.handle, C.byref(src.raw), int(chroma_sampling_enabled), C.byref(dst.raw))
         return dst
 
     def copy_raw_image(self, src: Image, dst: Image) -> Image:
         """copy_raw_image(src, dst) between device images (equal formats, RGB888 -> RGBA8888, RGBA8888 -> Y400)."""
-        A.check(self.lib.uhdr_hip_copy_raw_image_dev(self.ctx.handle, C.byref(src.raw), C.byref(dst.raw)))
+        self._call(True, self.lib.uhdr_hip_copy_raw_image_dev, self.ctx.handle, C.byref(src.raw), C.byref(dst.raw))
         return dst
 
     # ---- JPEG stage -----------------------------------------------------------------------------
@@ -221,8 +277,8 @@ class UltraHdr:
         import torch
 
         out = torch.empty((blocks_h, blocks_w, 64), dtype=torch.int16, device=plane.device) if coef is None else coef
-        A.check(self.lib.uhdr_hip_fdct_quant_dev(self.ctx.handle, C.c_void_p(plane.data_ptr()), stride,
-                                                 blocks_w, blocks_h, qt, C.c_void_p(out.data_ptr())))
+        self._call(True, self.lib.uhdr_hip_fdct_quant_dev, self.ctx.handle, C.c_void_p(plane.data_ptr()), stride, blocks_w, blocks_h, qt,
+                   C.c_void_p(out.data_ptr()))
         return out
 
     def fdct_quant_rgb(self, rgb: Image, qt_luma: np.ndarray, qt_chroma: np.ndarray):
@@ -234,7 +290,7 @@ class UltraHdr:
         ql = (C.c_uint16 * 64)(*[int(v) for v in qt_luma])
         qc = (C.c_uint16 * 64)(*[int(v) for v in qt_chroma])
         outs = [torch.empty((rgb.h // 8, rgb.w // 8, 64), dtype=torch.int16, device=rgb.buf.device) for _ in range(3)]
-        A.check(self.lib.uhdr_hip_fdct_quant_rgb_dev(self.ctx.handle, C.byref(rgb.raw), ql, qc, *[C.c_void_p(o.data_ptr()) for o in outs]))
+        self._call(True, self.lib.uhdr_hip_fdct_quant_rgb_dev, self.ctx.handle, C.byref(rgb.raw), ql, qc, *[C.c_void_p(o.data_ptr()) for o in outs])
         return outs
 
     # ---- entropy stage ------------------------------------------------------------------
@@ -260,9 +316,8 @@ class UltraHdr:
         if out is None:
             # worst case: 1660 bits per block, every byte stuffed
             out = torch.empty(sum(int(c.numel()) for c in coefs) // 64 * 416 + 4096, dtype=torch.uint8, device=coefs[0].device)
-            torch.cuda.current_stream(out.device).synchronize()
         n = C.c_size_t(0)
-        A.check(self.lib.uhdr_hip_huffman_encode_dev(self.ctx.handle, C.byref(sc), C.c_void_p(out.data_ptr()), out.numel(), C.byref(n)))
+        self._call(True, self.lib.uhdr_hip_huffman_encode_dev, self.ctx.handle, C.byref(sc), C.c_void_p(out.data_ptr()), out.numel(), C.byref(n))
         return out[: n.value]
 
     def huffman_decode(self, data, shapes, w: int, h: int, sampling, restart_interval: int, tables=None):
@@ -273,7 +328,6 @@ class UltraHdr:
 
         assert data.is_cuda and data.dtype == torch.uint8
         coefs = [torch.empty((bh, bw, 64), dtype=torch.int16, device=data.device) for (bh, bw) in shapes]
-        torch.cuda.current_stream(data.device).synchronize()
         sc = self._scan(coefs, w, h, sampling, restart_interval)
         ht = None
         if tables is not None:
@@ -283,8 +337,8 @@ class UltraHdr:
                     ht.bits[t][i] = int(tables[0][t][i])
                 for i in range(256):
                     ht.vals[t][i] = int(tables[1][t][i])
-        A.check(self.lib.uhdr_hip_huffman_decode_dev(self.ctx.handle, C.byref(sc), C.byref(ht) if ht is not None else None,
-                                                     C.c_void_p(data.data_ptr()), data.numel()))
+        self._call(True, self.lib.uhdr_hip_huffman_decode_dev, self.ctx.handle, C.byref(sc), C.byref(ht) if ht is not None else None,
+                   C.c_void_p(data.data_ptr()), data.numel())
         return coefs
 
     def jpeg_parse(self, jpeg: bytes) -> "A.JpegHeader":
@@ -339,8 +393,8 @@ class UltraHdr:
         import torch
 
         out = torch.empty((blocks_h * 8, stride), dtype=torch.uint8, device=coef.device) if plane is None else plane
-        A.check(self.lib.uhdr_hip_idct_dequant_dev(self.ctx.handle, C.c_void_p(coef.data_ptr()), blocks_w, blocks_h, qt,
-                                                   C.c_void_p(out.data_ptr()), stride))
+        self._call(True, self.lib.uhdr_hip_idct_dequant_dev, self.ctx.handle, C.c_void_p(coef.data_ptr()), blocks_w, blocks_h, qt,
+                   C.c_void_p(out.data_ptr()), stride)
         return out
 
     def idct_dequant_rgb(self, coefs, qt_luma: np.ndarray, qt_chroma: np.ndarray, w: int, h: int,
@@ -353,21 +407,23 @@ class UltraHdr:
         qc = (C.c_uint16 * 64)(*[int(v) for v in qt_chroma])
         if dst is None:
             dst = Image(fmt, w, h, align=64, device=str(coefs[0].device))
-        A.check(self.lib.uhdr_hip_idct_dequant_rgb_dev(self.ctx.handle, *[C.c_void_p(c.data_ptr()) for c in coefs], blocks_w, blocks_h,
-                                                       ql, qc, libjpeg_variant, C.byref(dst.raw)))
+        self._call(True, self.lib.uhdr_hip_idct_dequant_rgb_dev, self.ctx.handle, *[C.c_void_p(c.data_ptr()) for c in coefs], blocks_w, blocks_h,
+                   ql, qc, libjpeg_variant, C.byref(dst.raw))
         return dst
 
     def jpeg_rgb_to_ycc(self, rgb: Image) -> Image:
         """libjpeg's JCS_RGB -> YCbCr (what happens to a 3-channel gain map inside jpeg_write_scanlines):
         RGB888 / RGBA8888 -> YCbCr 4:4:4 planes, ready for fdct_quant."""
         dst = Image(A.UHDR_IMG_FMT_24bppYCbCr444, rgb.w, rgb.h, align=64, device=rgb.device)
-        fn = self.lib.uhdr_hip_jpeg_rgb_to_ycc_dev if _is_dev(rgb) else self.lib.uhdr_hip_jpeg_rgb_to_ycc
-        A.check(fn(self.ctx.handle, C.byref(rgb.raw), C.byref(dst.raw)))
+        dev = _is_dev(rgb)
+        fn = self.lib.uhdr_hip_jpeg_rgb_to_ycc_dev if dev else self.lib.uhdr_hip_jpeg_rgb_to_ycc
+        self._call(dev, fn, self.ctx.handle, C.byref(rgb.raw), C.byref(dst.raw))
         return dst
 
     def jpeg_ycc_to_rgb(self, ycc: Image, fmt=A.UHDR_IMG_FMT_24bppRGB888, libjpeg_variant: int = 0) -> Image:
         """libjpeg's YCbCr -> RGB of a decoded 3-channel gain map (variant 0: 6b / turbo, 1: IJG 9)."""
         dst = Image(fmt, ycc.w, ycc.h, align=64, device=ycc.device)
-        fn = self.lib.uhdr_hip_jpeg_ycc_to_rgb_dev if _is_dev(ycc) else self.lib.uhdr_hip_jpeg_ycc_to_rgb
-        A.check(fn(self.ctx.handle, C.byref(ycc.raw), libjpeg_variant, C.byref(dst.raw)))
+        dev = _is_dev(ycc)
+        fn = self.lib.uhdr_hip_jpeg_ycc_to_rgb_dev if dev else self.lib.uhdr_hip_jpeg_ycc_to_rgb
+        self._call(dev, fn, self.ctx.handle, C.byref(ycc.raw), libjpeg_variant, C.byref(dst.raw))
         return dst

@@ -1,15 +1,16 @@
 #!/usr/bin/env python
 """Randomised parity sweep of the HIP path against the oracle (run on the GPU box):
-    python tests/fuzz_parity.py [--seconds 60] [--seed 1]
+    python tests/fuzz_parity.py [--seconds 60] [--seed 1] [--log profiles/rNN_fuzz.log]
 Random sizes (odd ones included), formats, map layouts / scales, metadata, strides.  Prints one line per
-mismatch and a summary; exit code 1 if anything that must be bit-exact differs."""
-import argparse
+mismatch and a summary; exit code 1 if anything that must be bit-exact differs.
+Also collected by pytest (tests/test_gpu_fuzz.py runs `run()` with a bounded budget under -m gpu)."""
 import os
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root (this script lives in tests/)
-sys.path.insert(0, ROOT)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 import numpy as np
 import torch  # noqa: F401
 
@@ -19,16 +20,23 @@ from libultrahdr_amd.images import Image
 from libultrahdr_amd.ultrahdr import Context, UltraHdr
 from oracle import loader as L
 
-ap = argparse.ArgumentParser()
-ap.add_argument("--seconds", type=float, default=60)
-ap.add_argument("--seed", type=int, default=1)
-args = ap.parse_args()
-rng = np.random.default_rng(args.seed)
-ctx = Context(0)
-u = UltraHdr(ctx=ctx)
 F16, U32 = A.UHDR_IMG_FMT_64bppRGBAHalfFloat, A.UHDR_IMG_FMT_32bppRGBA1010102
+rng = np.random.default_rng(1)
+ctx = None
+u = None
 stats = {}
 bad = 0
+KIND = "port"  # "ref" when the real reference is loadable: the generate / tonemap arms then compare against it
+
+
+def init(seed, context=None):
+    global rng, ctx, u, stats, bad, KIND
+    rng = np.random.default_rng(seed)
+    ctx = context or Context(0)
+    u = UltraHdr(ctx=ctx)
+    stats = {}
+    bad = 0
+    KIND = "ref" if L.ref() is not None else "port"
 
 
 def rand_image(fmt, w, h, cg=None, align=None):
@@ -111,7 +119,7 @@ def fuzz_generate():
     cfg = A.default_encode_cfg(map_dimension_scale_factor=int(rng.choice([1, 1, 2, 4])), use_multi_channel_gainmap=int(rng.integers(0, 2)),
                                preset=int(rng.choice([A.UHDR_USAGE_REALTIME, A.UHDR_USAGE_BEST_QUALITY])), use_luminance=int(rng.integers(0, 2)),
                                sdr_is_601=int(rng.integers(0, 2)), gamma=1.0 if rng.random() < 0.7 else float(rng.uniform(0.6, 2.0)))
-    md_w, gm_w = L.generate_gainmap("port", sdr, hdr, cfg)
+    md_w, gm_w = L.generate_gainmap(KIND, sdr, hdr, cfg)
     from libultrahdr_amd.ultrahdr import UltraHdr as UH
 
     g = UH(ctx=ctx, mapDimensionScaleFactor=cfg.map_dimension_scale_factor, useMultiChannelGainMap=bool(cfg.use_multi_channel_gainmap),
@@ -131,7 +139,7 @@ def fuzz_tonemap():
     cg = int(rng.integers(0, 3))
     hdr = (synth.make_hdr_p010(w, h, seed=int(rng.integers(1 << 30)), ct=ct, cg=cg, noise=0.06) if kind == "p010"
            else synth.make_hdr_rgba1010102(w, h, seed=int(rng.integers(1 << 30)), ct=ct, cg=cg, noise=0.06))
-    want = L.tone_map("port", hdr)
+    want = L.tone_map(KIND, hdr)
     got = Image(want.fmt, w, h, align=64)
     u.toneMap(hdr, got)
     n = tot = mx = 0
@@ -141,6 +149,72 @@ def fuzz_tonemap():
         d = np.abs(pg.astype(np.int32) - pw.astype(np.int32))
         n += int((d != 0).sum()); tot += d.size; mx = max(mx, int(d.max()))
     note("tonemap", mx <= 1 and n / tot <= 1e-4, f"{kind} ct{ct} cg{cg} max {mx} differ {n}/{tot}")
+
+
+def _uh_for(cfg):
+    return UltraHdr(ctx=ctx, mapDimensionScaleFactor=cfg.map_dimension_scale_factor, useMultiChannelGainMap=bool(cfg.use_multi_channel_gainmap),
+                    gamma=cfg.gamma, preset=cfg.preset, minContentBoost=cfg.min_content_boost, maxContentBoost=cfg.max_content_boost,
+                    targetDispPeakBrightness=cfg.target_disp_peak_nits)
+
+
+def fuzz_generate_formats():
+    """generateGainMap over the input formats the API-1 default does not use: SDR 4:2:2 / 4:4:4 / 4:2:0 / RGBA8888 x
+    HDR 30bppYCbCr444 (both ranges) / RGBA-F16 (with inf, NaN, negatives) / P010 / RGBA1010102, host and device buffers."""
+    w, h = int(rng.choice([64, 128, 130, 258])), int(rng.choice([32, 64, 66]))
+    sk = int(rng.choice([A.UHDR_IMG_FMT_16bppYCbCr422, A.UHDR_IMG_FMT_24bppYCbCr444, A.UHDR_IMG_FMT_12bppYCbCr420, A.UHDR_IMG_FMT_32bppRGBA8888]))
+    seed = int(rng.integers(1 << 30))
+    sdr = (synth.make_sdr_rgba8888(w, h, seed=seed, cg=int(rng.integers(0, 3)), noise=0.06) if sk == A.UHDR_IMG_FMT_32bppRGBA8888
+           else synth.make_sdr_planar(sk, w, h, seed=seed, cg=int(rng.integers(0, 3)), noise=0.06))
+    hk = int(rng.choice([0, 0, 1, 1, 2, 3]))
+    seed = int(rng.integers(1 << 30))
+    ct = int(rng.choice([A.UHDR_CT_HLG, A.UHDR_CT_PQ]))
+    if hk == 0:
+        hdr = synth.make_hdr_yuv444_10bit(w, h, seed=seed, ct=ct, cg=int(rng.integers(0, 3)), noise=0.06,
+                                          rng_range=int(rng.choice([A.UHDR_CR_LIMITED_RANGE, A.UHDR_CR_FULL_RANGE])))
+    elif hk == 1:
+        hdr = synth.make_hdr_rgba_f16(w, h, seed=seed, cg=int(rng.integers(0, 3)), noise=0.06, peak=float(rng.choice([4.0, 20.0, 60.0])))
+    elif hk == 2:
+        hdr = synth.make_hdr_p010(w, h, seed=seed, ct=ct, cg=int(rng.integers(0, 3)), noise=0.06)
+    else:
+        hdr = synth.make_hdr_rgba1010102(w, h, seed=seed, ct=ct, cg=int(rng.integers(0, 3)), noise=0.06)
+    cfg = A.default_encode_cfg(map_dimension_scale_factor=int(rng.choice([1, 1, 2, 4])), use_multi_channel_gainmap=int(rng.integers(0, 2)),
+                               preset=int(rng.choice([A.UHDR_USAGE_REALTIME, A.UHDR_USAGE_BEST_QUALITY])), use_luminance=int(rng.integers(0, 2)),
+                               sdr_is_601=int(rng.integers(0, 2)))
+    md_w, gm_w = L.generate_gainmap(KIND, sdr, hdr, cfg)
+    g = _uh_for(cfg)
+    if rng.random() < 0.5:
+        md_g, gm_g = g.generateGainMap(sdr.to("cuda:0"), hdr.to("cuda:0"), bool(cfg.sdr_is_601), bool(cfg.use_luminance))
+        ctx.synchronize()
+        gm_g = gm_g.to_host()
+    else:
+        md_g, gm_g = g.generateGainMap(sdr, hdr, bool(cfg.sdr_is_601), bool(cfg.use_luminance))
+    d = np.abs(gm_g.valid(0).astype(np.int32) - gm_w.valid(0).astype(np.int32))
+    md_ok = all(np.allclose(md_g.as_dict()[k], md_w.as_dict()[k], rtol=1e-6, atol=0) for k in md_w.as_dict())
+    note("generate-formats", d.max() <= 1 and (d != 0).mean() <= 1e-4 and md_ok,
+         f"sdr fmt{sk} hdr kind{hk} ct{ct} {w}x{h} s{cfg.map_dimension_scale_factor} mc{cfg.use_multi_channel_gainmap} preset{cfg.preset} max {d.max()} frac {(d != 0).mean():.2e} md_ok {md_ok}")
+
+
+def fuzz_tonemap_formats():
+    """toneMap of 30bppYCbCr444 -> YCbCr444 and RGBA-F16 -> RGBA8888 (jpegr.cpp:1986-2103)."""
+    w, h = int(rng.choice([64, 130, 256])), int(rng.choice([32, 66, 64]))
+    seed = int(rng.integers(1 << 30))
+    if rng.random() < 0.5:
+        hdr = synth.make_hdr_yuv444_10bit(w, h, seed=seed, ct=int(rng.choice([A.UHDR_CT_HLG, A.UHDR_CT_PQ, A.UHDR_CT_LINEAR])), cg=int(rng.integers(0, 3)),
+                                          noise=0.06, rng_range=int(rng.choice([A.UHDR_CR_LIMITED_RANGE, A.UHDR_CR_FULL_RANGE])))
+    else:
+        hdr = synth.make_hdr_rgba_f16(w, h, seed=seed, cg=int(rng.integers(0, 3)), noise=0.06, peak=float(rng.choice([4.0, 20.0, 60.0])))
+    want = L.tone_map(KIND, hdr)
+    got = Image(want.fmt, w, h, align=64, device="cuda:0")
+    u.toneMap(hdr.to("cuda:0"), got)
+    ctx.synchronize()
+    got = got.to_host()
+    n = tot = mx = 0
+    for pg, pw in zip(got.planes_valid(), want.planes_valid()):
+        if pg.dtype == np.uint32:
+            pg, pw = pg.view(np.uint8), pw.view(np.uint8)
+        d = np.abs(pg.astype(np.int32) - pw.astype(np.int32))
+        n += int((d != 0).sum()); tot += d.size; mx = max(mx, int(d.max()))
+    note("tonemap-formats", mx <= 1 and n / tot <= 1e-4, f"fmt{hdr.fmt} ct{hdr.raw.ct} cg{hdr.raw.cg} max {mx} differ {n}/{tot}")
 
 
 def fuzz_converts():
@@ -251,11 +325,36 @@ def fuzz_huffman():
     note("huffman-decode", all(np.array_equal(b.cpu().numpy(), c) for b, c in zip(back, coefs)), f"{w}x{h} {sampling} ri{ri}")
 
 
-t_end = time.time() + args.seconds
-jobs = [fuzz_huffman, fuzz_apply, fuzz_apply, fuzz_apply, fuzz_generate, fuzz_tonemap, fuzz_converts, fuzz_decode_fused]
-i = 0
-while time.time() < t_end:
-    jobs[i % len(jobs)]()
-    i += 1
-print("cases per op (run, mismatched):", {k: tuple(v) for k, v in stats.items()})
-sys.exit(1 if bad else 0)
+JOBS = None
+
+
+def run(seconds, seed=1, context=None, log=None):
+    """Runs the sweep for `seconds`; returns (stats, mismatches).  `log`: a path that receives the summary line."""
+    init(seed, context)
+    jobs = [fuzz_huffman, fuzz_apply, fuzz_apply, fuzz_apply, fuzz_generate, fuzz_generate_formats, fuzz_tonemap, fuzz_tonemap_formats,
+            fuzz_converts, fuzz_decode_fused]
+    t_end = time.time() + seconds
+    i = 0
+    while time.time() < t_end:
+        jobs[i % len(jobs)]()
+        i += 1
+    summary = {k: tuple(v) for k, v in stats.items()}
+    line = f"fuzz_parity seed={seed} seconds={seconds} oracle={KIND} cases per op (run, mismatched): {summary}"
+    print(line)
+    if log:
+        os.makedirs(os.path.dirname(os.path.abspath(log)), exist_ok=True)
+        with open(log, "a") as f:
+            f.write(line + "\n")
+    return summary, bad
+
+
+if __name__ == "__main__":
+    import argparse
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=60)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--log", default=None)
+    args = ap.parse_args()
+    _, nbad = run(args.seconds, args.seed, log=args.log)
+    sys.exit(1 if nbad else 0)

@@ -176,3 +176,34 @@ def test_hip_decode_stage_reproduces_libjpeg(hip_ctx, q):
     rgb = u.jpeg_ycc_to_rgb(dec, fmt, libjpeg_variant=1)
     got = rgb.valid(0).view(np.uint8).reshape(gm.h, -1)[:, : gm.w * bpp]
     assert np.array_equal(got, GOLD[f"jpegrgb_q{q}/dec_rgb"])
+
+
+# ---- the reference's own 1280x720 raw fixture (BASELINE config 1's inputs) ------------------------------------------
+def test_fixture_720p_oracle_reproduces_the_reference():
+    """C oracle == real reference on tests/data/raw_p010_image.p010 + raw_yuv420_image.yuv420: generateGainMap (two
+    pass, 3 channels), convertYuv, FDCT + quantize of the base image and of the map (libjpeg's own coefficients),
+    applyGainMap to all three output transfers."""
+    import fixture720 as F
+
+    g = F.gold()
+    sdr, hdr = F.inputs()
+    md, gm = L.generate_gainmap("port", sdr, hdr, A.default_encode_cfg())
+    assert np.array_equal(gm.valid(0), g["gainmap"])
+    assert md.as_dict() == F.metadata().as_dict()
+    conv = L.convert_yuv("port", sdr, A.UHDR_CG_BT_709, A.UHDR_CG_DISPLAY_P3)
+    for c in range(3):
+        assert np.array_equal(conv.valid(c), g[f"sdr601_{c}"])
+        want = g[f"base_coef{c}"]
+        qt = L.quant_table_port(95, c > 0)
+        assert np.array_equal(qt, g[f"base_qt{c}"])
+        # the encoder pads planes to the MCU grid by edge replication (jpegencoderhelper.cpp:246-309); 1280x720 is MCU aligned
+        plane = np.ascontiguousarray(conv.valid(c))
+        assert np.array_equal(L.fdct_quant_port(plane, plane.shape[1], want.shape[1], want.shape[0], qt), want)
+    planes = L.jpeg_rgb_to_ycc_port(np.ascontiguousarray(gm.valid(0)), gm.w, gm.w, gm.h)
+    for c in range(3):
+        want = g[f"map_coef{c}"]
+        assert np.array_equal(L.fdct_quant_port(planes[c], gm.w, want.shape[1], want.shape[0], g[f"map_qt{c}"]), want)
+    for name, ct in (("linear", A.UHDR_CT_LINEAR), ("hlg", A.UHDR_CT_HLG), ("pq", A.UHDR_CT_PQ)):
+        res = L.apply_gainmap("port", sdr, F.gainmap(), F.metadata(), ct)
+        assert np.array_equal(res.valid(0)[::45], g[f"apply_{name}_rows"]), name
+        assert F.crc(res.valid(0)) == int(g[f"apply_{name}_crc"][0]), name

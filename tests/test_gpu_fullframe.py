@@ -1,0 +1,245 @@
+"""Whole-frame parity at BASELINE.json's own shapes, against the REAL reference (oracle/_ref, which travels to the GPU
+box prebuilt; the C restatement stands in only where it cannot be loaded):
+
+  config 1  the reference's own 1280x720 raw fixture (tests/data/raw_p010_image.p010 + raw_yuv420_image.yuv420, committed
+            as tests/golden/fixture_720p.npz together with the reference's outputs): API-1 encode stages + decode
+  config 2  4K decode: applyGainMap, Android-style map (Y400, scale 4) and the C-API default stream (full-resolution
+            3-channel map decoded to RGBA8888), all three output transfers, every pixel
+  config 3  8K API-0 encode: toneMap + one-pass generateGainMap + rgb -> YCbCr 4:4:4 + the six FDCTs, every stage
+            against the reference / libjpeg's own coefficients (jpeg_read_coefficients of the JPEG the reference writes)
+  config 4  one 16384 x 2048 row stripe of the 16K API-1 encode: two-pass generateGainMap, whole stripe vs the reference,
+            and the stripe cut in two and run through pass1 -> min/max merge -> finalize -> pass2 on the GPU kernels
+
+Bars as everywhere else: applyGainMap / converters / FDCT bit-exact; toneMap / generateGainMap +-1 code on <= 1e-4 of the
+samples, metadata 1e-6 relative (measured: identical)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from libultrahdr_amd import capi as A
+from libultrahdr_amd import synth
+from libultrahdr_amd.images import Image, stripe_view
+from oracle import loader as L
+
+pytestmark = pytest.mark.gpu
+F16, U32 = A.UHDR_IMG_FMT_64bppRGBAHalfFloat, A.UHDR_IMG_FMT_32bppRGBA1010102
+
+
+def oracle_kind():
+    return "ref" if L.ref() is not None else "port"
+
+
+@pytest.fixture(scope="module")
+def uhdr(hip_ctx):
+    from libultrahdr_amd.ultrahdr import UltraHdr
+
+    return UltraHdr(ctx=hip_ctx)
+
+
+def _uhdr_for(hip_ctx, cfg):
+    from libultrahdr_amd.ultrahdr import UltraHdr
+
+    return UltraHdr(ctx=hip_ctx, mapDimensionScaleFactor=cfg.map_dimension_scale_factor,
+                    useMultiChannelGainMap=bool(cfg.use_multi_channel_gainmap), gamma=cfg.gamma, preset=cfg.preset,
+                    minContentBoost=cfg.min_content_boost, maxContentBoost=cfg.max_content_boost,
+                    targetDispPeakBrightness=cfg.target_disp_peak_nits)
+
+
+def assert_close_codes(got, want, max_frac=1e-4, what=""):
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    nz = int(np.count_nonzero(d))
+    assert int(d.max()) <= 1, f"{what}: max code diff {d.max()}"
+    assert nz <= max_frac * d.size, f"{what}: {nz} of {d.size} samples differ"
+    return nz
+
+
+def md_close(got, want):
+    dg, dw = got.as_dict(), want.as_dict()
+    for k in dw:
+        assert np.allclose(dg[k], dw[k], rtol=1e-6, atol=0), (k, dg[k], dw[k])
+
+
+def _ref_coefficients(img: Image, quality: int):
+    """libjpeg's quantized coefficients of the JPEG the reference's JpegEncoderHelper writes for img."""
+    from test_oracle_vs_ref import _read_coefficients
+
+    ref = L.ref()
+    buf = np.zeros(img.w * img.h * 3 + (1 << 20), dtype=np.uint8)
+    n = ref.ref_jpeg_compress(C.byref(img.raw), quality, buf.ctypes.data, buf.size)
+    assert n > 0
+    return _read_coefficients(ref, buf[:n].tobytes())
+
+
+# ---- config 1: the reference's own raw fixture -------------------------------------------------------------------------
+def test_config1_real_fixture_720p_encode_stages_and_decode(uhdr, hip_ctx):
+    import torch
+
+    import fixture720 as F
+
+    g = F.gold()
+    sdr, hdr = F.inputs()
+    dsdr, dhdr = sdr.to("cuda:0"), hdr.to("cuda:0")
+    cfg = A.default_encode_cfg()
+    u = _uhdr_for(hip_ctx, cfg)
+    md, gm = u.generateGainMap(dsdr, dhdr)  # jpegr.cpp:255-258
+    hip_ctx.synchronize()
+    nz = assert_close_codes(gm.to_host().valid(0), g["gainmap"], 1e-4, "fixture gain map")
+    md_close(md, F.metadata())
+    conv = dsdr.clone()
+    u.convertYuv(conv, A.UHDR_CG_BT_709, A.UHDR_CG_DISPLAY_P3)  # jpegr.cpp:281
+    hip_ctx.synchronize()
+    conv_h = conv.to_host()
+    for c in range(3):
+        assert np.array_equal(conv_h.valid(c), g[f"sdr601_{c}"]), c
+    for c in range(3):  # the base image's FDCT + quantize == libjpeg's own coefficients
+        want = g[f"base_coef{c}"]
+        coef = u.fdct_quant(conv.plane_tensor(c), conv.layout[c][1], want.shape[1], want.shape[0], g[f"base_qt{c}"])
+        hip_ctx.synchronize()
+        assert np.array_equal(coef.cpu().numpy(), want), c
+    if nz == 0:  # same map bytes as the reference -> the map's JPEG stage must give libjpeg's coefficients
+        coefs = u.fdct_quant_rgb(gm, g["map_qt0"], g["map_qt1"])
+        hip_ctx.synchronize()
+        for c in range(3):
+            assert np.array_equal(coefs[c].cpu().numpy(), g[f"map_coef{c}"]), c
+    # decode direction on the reference's own map + metadata
+    gmr, mdr = F.gainmap(), F.metadata()
+    for name, ct in (("linear", A.UHDR_CT_LINEAR), ("hlg", A.UHDR_CT_HLG), ("pq", A.UHDR_CT_PQ)):
+        fmt = F16 if ct == A.UHDR_CT_LINEAR else U32
+        dest = Image(fmt, F.W, F.H, align=2, device="cuda:0")
+        uhdr.applyGainMap(dsdr, gmr.to("cuda:0"), mdr, ct, fmt, A.FLT_MAX, dest)
+        hip_ctx.synchronize()
+        got = dest.to_host().valid(0)
+        want = L.apply_gainmap(oracle_kind(), sdr, gmr, mdr, ct).valid(0)  # same host libm as the kernel's HLG tables
+        assert np.array_equal(got, want), name
+        if name != "hlg":  # LUT-only transfers do not depend on the host's libm: must equal the committed reference output
+            assert np.array_equal(got[::45], g[f"apply_{name}_rows"]) and F.crc(got) == int(g[f"apply_{name}_crc"][0]), name
+        else:
+            a = np.stack([(got[::45] >> s) & 0x3FF for s in (0, 10, 20)], -1)
+            b = np.stack([(g["apply_hlg_rows"] >> s) & 0x3FF for s in (0, 10, 20)], -1)
+            assert_close_codes(a, b, 1e-4, "HLG rows vs the build container's libm")
+    del torch
+
+
+# ---- config 2: 4K decode, every pixel ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mapk", ["A", "C"])
+def test_config2_4k_decode_whole_frame(uhdr, hip_ctx, mapk):
+    w, h = 3840, 2160
+    sdr = synth.make_sdr_yuv420(w, h)
+    gm = synth.make_gainmap(w // 4, h // 4, 1) if mapk == "A" else synth.make_gainmap(w, h, 3, alpha=True, cg=A.UHDR_CG_DISPLAY_P3)
+    md = synth.default_metadata(per_channel=(mapk == "C"))
+    dsdr, dgm = sdr.to("cuda:0"), gm.to("cuda:0")
+    for ct in (A.UHDR_CT_LINEAR, A.UHDR_CT_HLG, A.UHDR_CT_PQ):
+        fmt = F16 if ct == A.UHDR_CT_LINEAR else U32
+        dest = Image(fmt, w, h, align=64, device="cuda:0")
+        uhdr.applyGainMap(dsdr, dgm, md, ct, fmt, A.FLT_MAX, dest)
+        hip_ctx.synchronize()
+        want = L.apply_gainmap(oracle_kind(), sdr, gm, md, ct)
+        got = dest.to_host()
+        assert np.array_equal(got.valid(0), want.valid(0)), (mapk, ct, int((got.valid(0) != want.valid(0)).sum()))
+        assert got.raw.cg == want.raw.cg
+
+
+# ---- config 3: 8K API-0 encode, stage by stage ---------------------------------------------------------------------------------
+def test_config3_8k_api0_encode_every_stage(hip_ctx):
+    w, h = 7680, 4320
+    kind = oracle_kind()
+    hdr = synth.make_hdr_rgba1010102(w, h, ct=A.UHDR_CT_PQ, cg=A.UHDR_CG_BT_2100)
+    # API-0 (jpegr.cpp:202-251): toneMap, then generateGainMap with the preset forced to REALTIME, sdr_is_601 false, max-RGB
+    cfg = A.default_encode_cfg(preset=A.UHDR_USAGE_REALTIME, use_luminance=0)
+    u = _uhdr_for(hip_ctx, cfg)
+    dh = hdr.to("cuda:0")
+    sdr_g = Image(A.UHDR_IMG_FMT_32bppRGBA8888, w, h, align=64, device="cuda:0")
+    u.toneMap(dh, sdr_g)
+    hip_ctx.synchronize()
+    sdr_w = L.tone_map(kind, hdr)
+    sdr_gh = sdr_g.to_host()
+    nz = assert_close_codes(sdr_gh.valid(0).view(np.uint8), sdr_w.valid(0).view(np.uint8), 1e-4, "8K tone map")
+    assert (sdr_gh.raw.cg, sdr_gh.raw.ct, sdr_gh.raw.range) == (sdr_w.raw.cg, sdr_w.raw.ct, sdr_w.raw.range)
+    # from here on both sides start from the REFERENCE's SDR rendition, so that each stage is compared on identical input
+    dsdr = sdr_w.to("cuda:0") if nz else sdr_g
+    md_g, gm_g = u.generateGainMap(dsdr, dh, False, False)
+    hip_ctx.synchronize()
+    md_w, gm_w = L.generate_gainmap(kind, sdr_w, hdr, cfg)
+    gm_gh = gm_g.to_host()
+    assert (gm_gh.raw.fmt, gm_gh.raw.w, gm_gh.raw.h) == (gm_w.raw.fmt, gm_w.raw.w, gm_w.raw.h)
+    nzm = assert_close_codes(gm_gh.valid(0), gm_w.valid(0), 1e-4, "8K gain map (one pass)")
+    md_close(md_g, md_w)
+    ycc_g = u.convert_raw_input_to_ycbcr(dsdr, False)
+    hip_ctx.synchronize()
+    ycc_w = L.convert_raw_input_to_ycbcr(kind, sdr_w, False)
+    ycc_gh = ycc_g.to_host()
+    assert ycc_gh.raw.fmt == ycc_w.raw.fmt == A.UHDR_IMG_FMT_24bppYCbCr444
+    for c in range(3):
+        assert np.array_equal(ycc_gh.valid(c), ycc_w.valid(c)), c
+    # the fused front end gives the same three outputs in one pass
+    _, ycc_f, md_f, gm_f = u.encodeApi0Fused(dh, want_sdr_rgba=False, use_luminance=False)
+    hip_ctx.synchronize()
+    if nz == 0:
+        assert all(np.array_equal(a, b) for a, b in zip(ycc_f.to_host().planes_valid(), ycc_gh.planes_valid()))
+        assert np.array_equal(gm_f.to_host().valid(0), gm_gh.valid(0)) and md_f.as_dict() == md_g.as_dict()
+    # JPEG stage: base image (4:4:4, quality 95) and the 3-channel map (quality 95) against libjpeg's coefficients
+    if L.ref() is not None:
+        coefs_w, qt_w = _ref_coefficients(ycc_w, 95)
+        for c in range(3):
+            assert np.array_equal(qt_w[c], u.quant_table(95, c > 0))
+            got = u.fdct_quant(ycc_g.plane_tensor(c), ycc_g.layout[c][1], w // 8, h // 8, qt_w[c])
+            hip_ctx.synchronize()
+            assert np.array_equal(got.cpu().numpy(), coefs_w[c]), f"8K base FDCT component {c}"
+        if nzm == 0:
+            mco_w, mqt_w = _ref_coefficients(gm_w, 95)
+            got = u.fdct_quant_rgb(gm_g, mqt_w[0], mqt_w[1])
+            hip_ctx.synchronize()
+            for c in range(3):
+                assert np.array_equal(got[c].cpu().numpy(), mco_w[c]), f"8K map FDCT component {c}"
+    else:
+        for c in range(3):
+            qt = u.quant_table(95, c > 0)
+            plane = np.ascontiguousarray(ycc_w.valid(c))
+            got = u.fdct_quant(ycc_g.plane_tensor(c), ycc_g.layout[c][1], w // 8, h // 8, qt)
+            hip_ctx.synchronize()
+            assert np.array_equal(got.cpu().numpy(), L.fdct_quant_port(plane, w, w // 8, h // 8, qt)), c
+
+
+# ---- config 4: one row stripe of the 16K API-1 encode ----------------------------------------------------------------------------
+def test_config4_16k_stripe_two_pass_whole_and_split(hip_ctx):
+    import torch
+
+    from libultrahdr_amd.stripes import finalize_minmax, merge_minmax
+
+    w, h = 16384, 2048
+    kind = oracle_kind()
+    sdr = synth.make_sdr_yuv420(w, h)
+    hdr = synth.make_hdr_p010(w, h, ct=A.UHDR_CT_HLG)
+    cfg = A.default_encode_cfg()  # two pass, 3 channels, scale 1
+    u = _uhdr_for(hip_ctx, cfg)
+    dsdr, dhdr = sdr.to("cuda:0"), hdr.to("cuda:0")
+    md_g, gm_g = u.generateGainMap(dsdr, dhdr)
+    hip_ctx.synchronize()
+    md_w, gm_w = L.generate_gainmap(kind, sdr, hdr, cfg)
+    gm_gh = gm_g.to_host()
+    assert_close_codes(gm_gh.valid(0), gm_w.valid(0), 1e-4, "16384x2048 two-pass gain map")
+    md_close(md_g, md_w)
+    # the same stripe cut in two, each half through the GPU kernels, merged exactly as ranks would merge (MIN / MAX of
+    # the per-stripe extrema), finalized once, pass 2 per half: whole-image equality incl. metadata
+    halves = [(0, h // 2), (h // 2, h // 2)]
+    gains, mms, ubc = [], [], C.c_int(1)
+    for r0, rows in halves:
+        sv, hv = stripe_view(dsdr, r0, rows), stripe_view(dhdr, r0, rows)
+        gbuf = torch.empty(w * rows * 3, dtype=torch.float32, device="cuda:0")
+        mm = torch.empty(6, dtype=torch.float32, device="cuda:0")
+        torch.cuda.synchronize()
+        A.check(u.lib.uhdr_hip_generate_gainmap_pass1_dev(hip_ctx.handle, C.byref(sv), C.byref(hv), C.byref(cfg), C.c_void_p(gbuf.data_ptr()),
+                                                          C.c_void_p(mm.data_ptr()), C.byref(ubc)))
+        hip_ctx.synchronize()
+        gains.append(gbuf)
+        mms.append(mm.cpu().tolist())
+    fin, md_s = finalize_minmax(cfg, hdr.raw.ct, ubc.value, merge_minmax(mms))
+    out = Image(A.UHDR_IMG_FMT_24bppRGB888, w, h, align=64, device="cuda:0")
+    for (r0, rows), gbuf in zip(halves, gains):
+        ov = stripe_view(out, r0, rows)
+        A.check(u.lib.uhdr_hip_generate_gainmap_pass2_dev(hip_ctx.handle, C.c_void_p(gbuf.data_ptr()), (C.c_float * 6)(*fin), C.byref(cfg), C.byref(ov)))
+    hip_ctx.synchronize()
+    assert np.array_equal(out.to_host().valid(0), gm_gh.valid(0))
+    assert md_s.as_dict() == md_g.as_dict()
