@@ -717,7 +717,8 @@ uhdr_error_info_t uhdr_hip_apply_gainmap(uhdr_hip_ctx_t* c, const uhdr_raw_image
 // -------------------------------------------------------------------------------------------------
 static uhdr_error_info_t fill_gen_params(uhdr_hip_ctx* c, const uhdr_raw_image_t* sdr, const uhdr_raw_image_t* hdr,
                                          const uhdr_hip_encode_cfg_t* cfg, GenParams* p, int* use_base_cg,
-                                         float* hdr_white_nits_out) {
+                                         float* hdr_white_nits_out, bool sdr_in_registers = false) {
+  // sdr_in_registers: the fused API-0 front end renders the SDR pixel itself and never reads SDR planes
   if (!sdr || !hdr || !cfg) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument");
   // format checks: jpegr.cpp:537-562
   if (sdr->fmt != UHDR_IMG_FMT_24bppYCbCr444 && sdr->fmt != UHDR_IMG_FMT_16bppYCbCr422 &&
@@ -741,7 +742,7 @@ static uhdr_error_info_t fill_gen_params(uhdr_hip_ctx* c, const uhdr_raw_image_t
                       sdr->w, sdr->h, hdr->w, hdr->h);
   if (cfg->map_dimension_scale_factor < 1)
     return err_status(UHDR_CODEC_INVALID_PARAM, "gainmap scale factor %d is not positive", cfg->map_dimension_scale_factor);
-  UHDR_TRY(validate_image(sdr, "sdr intent"));
+  if (!sdr_in_registers) UHDR_TRY(validate_image(sdr, "sdr intent"));
   UHDR_TRY(validate_image(hdr, "hdr intent"));
   memset(p, 0, sizeof *p);
   const float hdr_white_nits = host::reference_peak_nits(hdr->ct);
@@ -1247,7 +1248,7 @@ uhdr_error_info_t uhdr_hip_encode_api0_fused_dev(uhdr_hip_ctx_t* c, const uhdr_r
   p.tm.sdr = view_mut_of(&sdr_desc);
   int use_base_cg = 1;
   float hdr_white_nits;
-  UHDR_TRY(fill_gen_params(c, &sdr_desc, hdr, cfg, &p.gen, &use_base_cg, &hdr_white_nits));
+  UHDR_TRY(fill_gen_params(c, &sdr_desc, hdr, cfg, &p.gen, &use_base_cg, &hdr_white_nits, /*sdr_in_registers=*/true));
   fill_gainmap_desc(hdr, p.gen, gm);
   if (gm->stride[0] < gm->w) return err_status(UHDR_CODEC_INVALID_PARAM, "gainmap stride (%u) cannot be less than its width (%u)", gm->stride[0], gm->w);
   base_ycc->fmt = UHDR_IMG_FMT_24bppYCbCr444; base_ycc->cg = UHDR_CG_DISPLAY_P3; base_ycc->ct = UHDR_CT_SRGB; base_ycc->range = UHDR_CR_FULL_RANGE;
