@@ -1,0 +1,126 @@
+#!/usr/bin/env python
+"""Regenerates facade/reference_hip_seam.patch: applies the seam insertions below to scratch copies of the
+reference files (under /tmp, never inside this repository) and diffs them against the originals with one line of
+context.  The patch is what a libultrahdr maintainer would review; facade/Makefile applies it out of tree."""
+import difflib
+import os
+import sys
+
+REF = os.environ.get("REF", "/root/reference")
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_hip_seam.patch")
+
+
+def insert_before(text, anchor, new, nth=0):
+    idx = -1
+    for _ in range(nth + 1):
+        idx = text.index(anchor, idx + 1)
+    return text[:idx] + new + text[idx:]
+
+
+def insert_after(text, anchor, new, nth=0):
+    idx = -1
+    for _ in range(nth + 1):
+        idx = text.index(anchor, idx + 1)
+    idx += len(anchor)
+    return text[:idx] + new + text[idx:]
+
+
+EDITS = {}
+
+# ---- ultrahdrcommon.h: per-codec switch + lazily created context (next to the GLES members) -------------------
+def common_h(t):
+    return insert_before(t, "  bool m_sailed;\n\n  virtual ~uhdr_codec_private();",
+                         "#ifdef UHDR_ENABLE_HIP\n  bool m_enable_hip = false;         // uhdr_enable_gpu_acceleration()\n"
+                         "  void* m_uhdr_hip_ctxt = nullptr;   // uhdr_hip context, created by the first accelerated call\n#endif\n")
+EDITS["lib/include/ultrahdr/ultrahdrcommon.h"] = common_h
+
+# ---- ultrahdr_api.cpp -------------------------------------------------------------------------------------------
+def api_cpp(t):
+    t = insert_after(t, '#include "ultrahdr/jpegr.h"\n', '#ifdef UHDR_ENABLE_HIP\n#include "uhdr_hip_seam.h"\n#endif\n')
+    t = insert_after(t, "uhdr_codec_private::~uhdr_codec_private() {\n",
+                     "#ifdef UHDR_ENABLE_HIP\n  uhdr_hip_seam::release(m_uhdr_hip_ctxt);\n#endif\n")
+    scope = ("#ifdef UHDR_ENABLE_HIP\n  uhdr_hip_seam::Scope hip_scope(handle->m_enable_hip, &handle->m_uhdr_hip_ctxt);\n"
+             "  if (hip_scope.failed()) {\n    status = hip_scope.error();\n    return status;\n  }\n#endif\n")
+    t = insert_after(t, "  uhdr_error_info_t& status = handle->m_encode_call_status;\n", scope)
+    t = insert_after(t, "  status = uhdr_dec_probe(dec);\n  if (status.error_code != UHDR_CODEC_OK) return status;\n\n  handle->m_sailed = true;\n", scope)
+    t = insert_after(t, "#ifdef UHDR_ENABLE_GLES\n  codec->m_enable_gles = enable;\n#endif\n",
+                     "#ifdef UHDR_ENABLE_HIP\n  codec->m_enable_hip = enable;\n#endif\n")
+    for nth in (0, 1):  # uhdr_reset_encoder, uhdr_reset_decoder
+        t = insert_before(t, "    handle->m_sailed = false;\n", "#ifdef UHDR_ENABLE_HIP\n    handle->m_enable_hip = false;\n#endif\n", nth)
+    return t
+EDITS["lib/src/ultrahdr_api.cpp"] = api_cpp
+
+# ---- jpegr.cpp: the four stage operators ---------------------------------------------------------------------
+def jpegr_cpp(t):
+    t = insert_after(t, '#include "ultrahdr/jpegr.h"\n', '#ifdef UHDR_ENABLE_HIP\n#include "uhdr_hip_seam.h"\n#endif\n')
+    t = insert_after(t, "uhdr_error_info_t UltraHdr::convertYuv(uhdr_raw_image_t* image, uhdr_color_gamut_t src_encoding,\n"
+                        "                                       uhdr_color_gamut_t dst_encoding) {\n",
+                     "#ifdef UHDR_ENABLE_HIP\n  {\n    uhdr_error_info_t hip_status;\n"
+                     "    if (uhdr_hip_seam::convert_yuv(image, src_encoding, dst_encoding, &hip_status)) return hip_status;\n  }\n#endif\n")
+    t = insert_after(t, "                                            bool sdr_is_601, bool use_luminance) {\n  uhdr_error_info_t status = g_no_error;\n",
+                     "#ifdef UHDR_ENABLE_HIP\n"
+                     "  if (uhdr_hip_seam::generate_gainmap(sdr_intent, hdr_intent, gainmap_metadata, gainmap_img, sdr_is_601,\n"
+                     "                                      use_luminance, &mMapDimensionScaleFactor, mUseMultiChannelGainMap, mGamma,\n"
+                     "                                      mEncPreset, mMinContentBoost, mMaxContentBoost,\n"
+                     "                                      mTargetDispPeakBrightness, &status))\n    return status;\n"
+                     "  status = g_no_error;\n#endif\n")
+    t = insert_before(t, "#ifdef UHDR_ENABLE_GLES\n  if (mUhdrGLESCtxt != nullptr) {\n",
+                      "#ifdef UHDR_ENABLE_HIP\n  {\n    uhdr_error_info_t hip_status;\n"
+                      "    if (uhdr_hip_seam::apply_gainmap(sdr_intent, gainmap_img, gainmap_metadata, output_ct, output_format,\n"
+                      "                                     max_display_boost, dest, &hip_status))\n      return hip_status;\n  }\n#endif\n")
+    t = insert_after(t, "uhdr_error_info_t UltraHdr::toneMap(uhdr_raw_image_t* hdr_intent, uhdr_raw_image_t* sdr_intent) {\n",
+                     "#ifdef UHDR_ENABLE_HIP\n  {\n    uhdr_error_info_t hip_status;\n"
+                     "    if (uhdr_hip_seam::tone_map(hdr_intent, sdr_intent, &hip_status)) return hip_status;\n  }\n#endif\n")
+    return t
+EDITS["lib/src/jpegr.cpp"] = jpegr_cpp
+
+# ---- gainmapmath.cpp: convert_raw_input_to_ycbcr --------------------------------------------------------------
+def gmm_cpp(t):
+    t = insert_after(t, '#include "ultrahdr/gainmapmath.h"\n', '#ifdef UHDR_ENABLE_HIP\n#include "uhdr_hip_seam.h"\n#endif\n')
+    t = insert_after(t, "std::unique_ptr<uhdr_raw_image_ext_t> convert_raw_input_to_ycbcr(uhdr_raw_image_t* src,\n"
+                        "                                                                 bool chroma_sampling_enabled) {\n"
+                        "  std::unique_ptr<uhdr_raw_image_ext_t> dst = nullptr;\n",
+                     "#ifdef UHDR_ENABLE_HIP\n  if (uhdr_hip_seam::convert_raw_input_to_ycbcr(src, chroma_sampling_enabled, &dst)) return dst;\n#endif\n")
+    return t
+EDITS["lib/src/gainmapmath.cpp"] = gmm_cpp
+
+# ---- the JPEG block stage (FDCT / IDCT on the device, entropy coding stays in libjpeg) -------------------------
+def jenc_cpp(t):
+    t = insert_after(t, '#include "ultrahdr/jpegencoderhelper.h"\n', '#ifdef UHDR_ENABLE_HIP\n#include "uhdr_hip_jpeg_seam.h"\n#endif\n')
+    t = insert_before(t, "    // start compress\n    jpeg_start_compress(&cinfo, TRUE);\n",
+                      "#ifdef UHDR_ENABLE_HIP\n    {\n      char hip_comment[255];\n"
+                      "      snprintf(hip_comment, sizeof hip_comment,\n"
+                      "               \"Source: google libuhdr v%s, Coder: libjpeg v%d, Attrib: GainMap Image\",\n"
+                      "               UHDR_LIB_VERSION_STR, JPEG_LIB_VERSION);\n"
+                      "      if (uhdr_hip_seam::jpeg_compress_on_device(&cinfo, planes, strides, format, iccBuffer, iccSize,\n"
+                      "                                                 isGainMapImg ? hip_comment : nullptr, &status)) {\n"
+                      "        jpeg_destroy_compress(&cinfo);\n        return status;\n      }\n    }\n#endif\n")
+    return t
+EDITS["lib/src/jpegencoderhelper.cpp"] = jenc_cpp
+
+def jdec_cpp(t):
+    t = insert_after(t, '#include "ultrahdr/jpegdecoderhelper.h"\n', '#ifdef UHDR_ENABLE_HIP\n#include "uhdr_hip_jpeg_seam.h"\n#endif\n')
+    t = insert_before(t, "    cinfo.dct_method = JDCT_ISLOW;\n    jpeg_start_decompress(&cinfo);\n",
+                      "#ifdef UHDR_ENABLE_HIP\n"
+                      "    if (uhdr_hip_seam::jpeg_decompress_on_device(&cinfo, DECODE_TO_RGB_CS == mode, mResultBuffer.data(),\n"
+                      "                                                 mPlaneHStride, mPlaneVStride, &mOutFormat, &status)) {\n"
+                      "      jpeg_destroy_decompress(&cinfo);\n      return status;\n    }\n#endif\n")
+    return t
+EDITS["lib/src/jpegdecoderhelper.cpp"] = jdec_cpp
+
+
+def main():
+    chunks = []
+    for rel, fn in EDITS.items():
+        with open(os.path.join(REF, rel)) as f:
+            old = f.read()
+        new = fn(old)
+        d = difflib.unified_diff(old.splitlines(True), new.splitlines(True), "a/" + rel, "b/" + rel, n=1)
+        chunks.append("".join(d))
+    with open(OUT, "w") as f:
+        f.write("".join(chunks))
+    print("wrote", OUT, sum(c.count("\n") for c in chunks), "lines")
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,192 @@
+// uhdr_hip_seam.cpp -- implementation of the facade's HIP seam (see uhdr_hip_seam.h).
+// Compiled by g++ with the REFERENCE's headers on the include path (facade/Makefile) and linked against
+// libuhdr_hip.so; it only marshals between the reference's C++ types and the C ABI of include/uhdr_hip.h.
+#include "uhdr_hip_seam.h"
+
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "uhdr_hip.h"  // after ultrahdr_api.h: reuses the reference's own structs
+
+namespace uhdr_hip_seam {
+
+namespace {
+thread_local void* tl_ctxt = nullptr;
+std::atomic<unsigned long> g_calls{0};
+
+uhdr_hip_ctx_t* cur() { return static_cast<uhdr_hip_ctx_t*>(tl_ctxt); }
+
+// true: the device produced the call's result.  UNSUPPORTED_FEATURE from the device library means "this
+// combination is the reference's to handle" (uhdr_enable_gpu_acceleration may have no effect).
+// UHDR_HIP_SEAM_TRACE=1 in the environment: one stderr line per stage call saying where it ran (tests use it to
+// prove that an accelerated run really went through the device)
+bool trace_on() {
+  static const bool on = getenv("UHDR_HIP_SEAM_TRACE") != nullptr;
+  return on;
+}
+bool handled(const uhdr_error_info_t& s, const char* stage) {
+  const bool dev = s.error_code != UHDR_CODEC_UNSUPPORTED_FEATURE;
+  if (trace_on())
+    fprintf(stderr, "uhdr_hip_seam: %s -> %s%s%s\n", stage, dev ? "device" : "reference CPU path (", dev ? "" : (s.has_detail ? s.detail : ""),
+            dev ? "" : ")");
+  if (dev) g_calls.fetch_add(1, std::memory_order_relaxed);
+  return dev;
+}
+}  // namespace
+
+Scope::Scope(bool enable, void** slot) : mPrev(tl_ctxt), mFailed(false) {
+  memset(&mError, 0, sizeof mError);
+  if (!enable) {
+    tl_ctxt = nullptr;
+    return;
+  }
+  if (*slot == nullptr) {
+    uhdr_error_info_t err;
+    memset(&err, 0, sizeof err);
+    *slot = uhdr_hip_create(-1, &err);
+    if (*slot == nullptr) {  // GPU acceleration was asked for and cannot be had: say so, do not compute on the CPU silently
+      mFailed = true;
+      mError = err;
+      if (mError.error_code == UHDR_CODEC_OK) mError.error_code = UHDR_CODEC_ERROR;
+      tl_ctxt = nullptr;
+      return;
+    }
+  }
+  tl_ctxt = *slot;
+}
+Scope::~Scope() { tl_ctxt = mPrev; }
+
+void release(void* ctxt) {
+  if (ctxt) uhdr_hip_destroy(static_cast<uhdr_hip_ctx_t*>(ctxt));
+}
+unsigned long calls_on_device() { return g_calls.load(std::memory_order_relaxed); }
+
+bool apply_gainmap(uhdr_raw_image_t* sdr_intent, uhdr_raw_image_t* gainmap_img,
+                   ultrahdr::uhdr_gainmap_metadata_ext_t* gainmap_metadata, uhdr_color_transfer_t output_ct,
+                   uhdr_img_fmt_t output_format, float max_display_boost, uhdr_raw_image_t* dest,
+                   uhdr_error_info_t* st) {
+  if (!cur() || !gainmap_metadata) return false;
+  // the version check is the one thing uhdr_gainmap_metadata_ext_t adds (jpegr.cpp:1546-1555)
+  if (gainmap_metadata->version.compare(ultrahdr::kJpegrVersion)) return false;  // the reference words that error
+  const uhdr_gainmap_metadata_t md = *gainmap_metadata;  // slice off the version string
+  *st = uhdr_hip_apply_gainmap(cur(), sdr_intent, gainmap_img, &md, output_ct, output_format, max_display_boost, dest);
+  return handled(*st, "apply_gainmap");
+}
+
+bool generate_gainmap(uhdr_raw_image_t* sdr_intent, uhdr_raw_image_t* hdr_intent,
+                      ultrahdr::uhdr_gainmap_metadata_ext_t* gainmap_metadata,
+                      std::unique_ptr<ultrahdr::uhdr_raw_image_ext_t>& gainmap_img, bool sdr_is_601,
+                      bool use_luminance, int* scale_factor, bool multi_channel, float gamma,
+                      uhdr_enc_preset_t preset, float min_content_boost, float max_content_boost,
+                      float target_disp_peak_brightness, uhdr_error_info_t* st) {
+  if (!cur() || !sdr_intent || !hdr_intent || !gainmap_metadata) return false;
+  // map geometry and the tiny-image fallback exactly as jpegr.cpp:690-706
+  const unsigned w = sdr_intent->w, h = sdr_intent->h;
+  int s = *scale_factor;
+  if (s < 1) return false;
+  unsigned mw = w / s, mh = h / s;
+  if (mw == 0 || mh == 0) {
+    const unsigned m = w < h ? w : h;
+    s = m / 8 ? (int)(m / 8) : 1;
+    mw = w / s;
+    mh = h / s;
+  }
+  if (mw == 0 || mh == 0) return false;
+  uhdr_hip_encode_cfg_t cfg;
+  cfg.map_dimension_scale_factor = s;
+  cfg.use_multi_channel_gainmap = multi_channel;
+  cfg.gamma = gamma;
+  cfg.preset = preset;
+  cfg.min_content_boost = min_content_boost;
+  cfg.max_content_boost = max_content_boost;
+  cfg.target_disp_peak_nits = target_disp_peak_brightness;
+  cfg.sdr_is_601 = sdr_is_601;
+  cfg.use_luminance = use_luminance;
+  auto img = std::make_unique<ultrahdr::uhdr_raw_image_ext_t>(
+      multi_channel ? UHDR_IMG_FMT_24bppRGB888 : UHDR_IMG_FMT_8bppYCbCr400, hdr_intent->cg, hdr_intent->ct,
+      hdr_intent->range, mw, mh, 64);  // jpegr.cpp:714-716
+  uhdr_gainmap_metadata_t md;
+  memset(&md, 0, sizeof md);
+  *st = uhdr_hip_generate_gainmap(cur(), sdr_intent, hdr_intent, &cfg, &md, img.get());
+  if (!handled(*st, "generate_gainmap")) return false;
+  if (st->error_code == UHDR_CODEC_OK) {
+    static_cast<uhdr_gainmap_metadata_t&>(*gainmap_metadata) = md;
+    gainmap_img = std::move(img);
+    *scale_factor = s;
+  }
+  return true;
+}
+
+bool tone_map(uhdr_raw_image_t* hdr_intent, uhdr_raw_image_t* sdr_intent, uhdr_error_info_t* st) {
+  if (!cur()) return false;
+  *st = uhdr_hip_tone_map(cur(), hdr_intent, sdr_intent);
+  return handled(*st, "tone_map");
+}
+
+bool convert_yuv(uhdr_raw_image_t* image, uhdr_color_gamut_t src_encoding, uhdr_color_gamut_t dst_encoding,
+                 uhdr_error_info_t* st) {
+  if (!cur()) return false;
+  *st = uhdr_hip_convert_yuv(cur(), image, src_encoding, dst_encoding);
+  return handled(*st, "convert_yuv");
+}
+
+bool convert_raw_input_to_ycbcr(uhdr_raw_image_t* src, bool chroma_sampling_enabled,
+                                std::unique_ptr<ultrahdr::uhdr_raw_image_ext_t>* dst) {
+  if (!cur() || !src) return false;
+  if (src->fmt != UHDR_IMG_FMT_32bppRGBA1010102 && src->fmt != UHDR_IMG_FMT_32bppRGBA8888 && src->fmt != UHDR_IMG_FMT_24bppRGB888)
+    return false;  // YCbCr inputs are a plain copy in the reference (gainmapmath.cpp:1475-1480)
+  if (src->cg != UHDR_CG_BT_709 && src->cg != UHDR_CG_DISPLAY_P3 && src->cg != UHDR_CG_BT_2100) return false;
+  const bool ten = src->fmt == UHDR_IMG_FMT_32bppRGBA1010102;
+  const uhdr_img_fmt_t fmt = ten ? (chroma_sampling_enabled ? UHDR_IMG_FMT_24bppYCbCrP010 : UHDR_IMG_FMT_30bppYCbCr444)
+                                 : (chroma_sampling_enabled ? UHDR_IMG_FMT_12bppYCbCr420 : UHDR_IMG_FMT_24bppYCbCr444);
+  auto img = std::make_unique<ultrahdr::uhdr_raw_image_ext_t>(fmt, src->cg, src->ct, UHDR_CR_FULL_RANGE, src->w, src->h, 64);
+  const uhdr_error_info_t s = uhdr_hip_convert_raw_input_to_ycbcr(cur(), src, chroma_sampling_enabled, img.get());
+  if (!handled(s, "convert_raw_input_to_ycbcr")) return false;
+  if (s.error_code != UHDR_CODEC_OK) {
+    fprintf(stderr, "uhdr_hip_seam: convert_raw_input_to_ycbcr failed on the device: %s\n", s.has_detail ? s.detail : "");
+    *dst = nullptr;  // the reference's own failure value (callers check for nullptr)
+    return true;
+  }
+  *dst = std::move(img);
+  return true;
+}
+
+bool fdct_planes(int ncomp, const unsigned char* const planes[3], const unsigned int strides[3],
+                 const unsigned int blocks_w[3], const unsigned int blocks_h[3], const unsigned short* const qtables[3],
+                 short* const coefs[3], uhdr_error_info_t* st) {
+  if (!cur()) return false;
+  for (int c = 0; c < ncomp; c++) {
+    *st = uhdr_hip_fdct_quant(cur(), planes[c], strides[c], (int)blocks_w[c], (int)blocks_h[c], qtables[c], coefs[c]);
+    if (st->error_code != UHDR_CODEC_OK) return c == 0 ? handled(*st, "fdct_planes") : true;
+  }
+  handled(*st, "fdct_planes");
+  return true;
+}
+
+bool idct_planes(int ncomp, const short* const coefs[3], const unsigned int blocks_w[3], const unsigned int blocks_h[3],
+                 const unsigned short* const qtables[3], unsigned char* const planes[3], const unsigned int strides[3],
+                 uhdr_error_info_t* st) {
+  if (!cur()) return false;
+  for (int c = 0; c < ncomp; c++) {
+    *st = uhdr_hip_idct_dequant(cur(), coefs[c], (int)blocks_w[c], (int)blocks_h[c], qtables[c], planes[c], strides[c]);
+    if (st->error_code != UHDR_CODEC_OK) return c == 0 ? handled(*st, "idct_planes") : true;
+  }
+  handled(*st, "idct_planes");
+  return true;
+}
+
+bool jpeg_rgb_to_ycc(const uhdr_raw_image_t* rgb, uhdr_raw_image_t* ycc, uhdr_error_info_t* st) {
+  if (!cur()) return false;
+  *st = uhdr_hip_jpeg_rgb_to_ycc(cur(), rgb, ycc);
+  return handled(*st, "jpeg_rgb_to_ycc");
+}
+bool jpeg_ycc_to_rgb(const uhdr_raw_image_t* ycc, int libjpeg_variant, uhdr_raw_image_t* rgb, uhdr_error_info_t* st) {
+  if (!cur()) return false;
+  *st = uhdr_hip_jpeg_ycc_to_rgb(cur(), ycc, libjpeg_variant, rgb);
+  return handled(*st, "jpeg_ycc_to_rgb");
+}
+bool enabled() { return cur() != nullptr; }
+
+}  // namespace uhdr_hip_seam

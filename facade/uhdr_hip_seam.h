@@ -1,0 +1,93 @@
+// uhdr_hip_seam.h -- the HIP seam of the 43-symbol libuhdr facade.
+//
+// The facade is the REFERENCE's own control plane (C API state machine, containers, metadata, libjpeg
+// entropy coding: everything SURVEY.md marks out of scope) compiled from /root/reference at build time with
+// facade/reference_hip_seam.patch applied out of tree; the patch adds one call into this header at each
+// place where the reference enters its per-pixel hot path.  Nothing of the reference is stored in this
+// repository.  With uhdr_enable_gpu_acceleration(codec, 1) (ultrahdr_api.h:849) the calls below route the
+// stage to libuhdr_hip.so; without it the library behaves exactly like the reference.
+//
+//   reference site (file:line)                                   seam call
+//   UltraHdr::applyGainMap          lib/src/jpegr.cpp:1533       uhdr_hip_seam::apply_gainmap
+//   UltraHdr::generateGainMap       lib/src/jpegr.cpp:530        uhdr_hip_seam::generate_gainmap
+//   UltraHdr::toneMap               lib/src/jpegr.cpp:1985       uhdr_hip_seam::tone_map
+//   UltraHdr::convertYuv            lib/src/jpegr.cpp:436        uhdr_hip_seam::convert_yuv
+//   convert_raw_input_to_ycbcr      lib/src/gainmapmath.cpp:1291 uhdr_hip_seam::convert_raw_input_to_ycbcr
+//   JpegEncoderHelper::encode       lib/src/jpegencoderhelper.cpp:131  uhdr_hip_seam::fdct_planes (FDCT + quantize on
+//                                                                the device, libjpeg keeps the entropy coding)
+//   JpegDecoderHelper::decode       lib/src/jpegdecoderhelper.cpp:283  uhdr_hip_seam::idct_planes (libjpeg keeps the
+//                                                                entropy decoding, dequantize + IDCT on the device)
+//   uhdr_encode / uhdr_decode       lib/src/ultrahdr_api.cpp:1200, 1918  uhdr_hip_seam::Scope (lazy context, like the
+//                                                                GLES context at :1977-1989)
+//
+// Every seam function returns true when the device handled the call (*st is then the call's result, OK or the
+// reference's own error) and false when the reference's CPU code must run: acceleration not enabled on this
+// codec, or the combination is one the device path reports as UHDR_CODEC_UNSUPPORTED_FEATURE -- the
+// contract of uhdr_enable_gpu_acceleration ("may have no effect", ultrahdr_api.h:839-849).  A device or
+// runtime failure is never hidden: it is returned as the call's error.
+#ifndef UHDR_HIP_SEAM_H
+#define UHDR_HIP_SEAM_H
+
+#include <memory>
+
+#include "ultrahdr_api.h"
+#include "ultrahdr/ultrahdrcommon.h"
+
+namespace uhdr_hip_seam {
+
+// RAII: makes `*slot` (the codec's lazily created uhdr_hip context) current on this thread for one
+// uhdr_encode / uhdr_decode call.  enable == false: nothing happens, every seam returns false.
+class Scope {
+ public:
+  Scope(bool enable, void** slot);
+  ~Scope();
+  bool failed() const { return mFailed; }
+  uhdr_error_info_t error() const { return mError; }
+
+ private:
+  void* mPrev;
+  bool mFailed;
+  uhdr_error_info_t mError;
+};
+// ~uhdr_codec_private
+void release(void* ctxt);
+// counters for tests / the demo app: how many stage calls ran on the device in this process
+unsigned long calls_on_device();
+
+bool apply_gainmap(uhdr_raw_image_t* sdr_intent, uhdr_raw_image_t* gainmap_img,
+                   ultrahdr::uhdr_gainmap_metadata_ext_t* gainmap_metadata, uhdr_color_transfer_t output_ct,
+                   uhdr_img_fmt_t output_format, float max_display_boost, uhdr_raw_image_t* dest,
+                   uhdr_error_info_t* st);
+// scale_factor is UltraHdr::mMapDimensionScaleFactor: updated like setMapDimensionScaleFactor() does when the
+// reference's tiny-image fallback (jpegr.cpp:690-706) triggers
+bool generate_gainmap(uhdr_raw_image_t* sdr_intent, uhdr_raw_image_t* hdr_intent,
+                      ultrahdr::uhdr_gainmap_metadata_ext_t* gainmap_metadata,
+                      std::unique_ptr<ultrahdr::uhdr_raw_image_ext_t>& gainmap_img, bool sdr_is_601,
+                      bool use_luminance, int* scale_factor, bool multi_channel, float gamma,
+                      uhdr_enc_preset_t preset, float min_content_boost, float max_content_boost,
+                      float target_disp_peak_brightness, uhdr_error_info_t* st);
+bool tone_map(uhdr_raw_image_t* hdr_intent, uhdr_raw_image_t* sdr_intent, uhdr_error_info_t* st);
+bool convert_yuv(uhdr_raw_image_t* image, uhdr_color_gamut_t src_encoding, uhdr_color_gamut_t dst_encoding,
+                 uhdr_error_info_t* st);
+bool convert_raw_input_to_ycbcr(uhdr_raw_image_t* src, bool chroma_sampling_enabled,
+                                std::unique_ptr<ultrahdr::uhdr_raw_image_ext_t>* dst);
+
+// JPEG block stage.  fdct_planes: 8-bit component planes (already padded to whole blocks by the caller, which
+// knows the reference's padding rules) -> quantized coefficient blocks in JBLOCK order, one contiguous array per
+// component.  idct_planes: the inverse.  quant tables in natural order (cinfo.quant_tbl_ptrs[..]->quantval).
+bool fdct_planes(int ncomp, const unsigned char* const planes[3], const unsigned int strides[3],
+                 const unsigned int blocks_w[3], const unsigned int blocks_h[3], const unsigned short* const qtables[3],
+                 short* const coefs[3], uhdr_error_info_t* st);
+bool idct_planes(int ncomp, const short* const coefs[3], const unsigned int blocks_w[3], const unsigned int blocks_h[3],
+                 const unsigned short* const qtables[3], unsigned char* const planes[3], const unsigned int strides[3],
+                 uhdr_error_info_t* st);
+
+// libjpeg's colour conversions around a 3-channel gain map (jccolor.c rgb_ycc_convert / jdcolor.c ycc_rgb_convert)
+bool jpeg_rgb_to_ycc(const uhdr_raw_image_t* rgb, uhdr_raw_image_t* ycc, uhdr_error_info_t* st);
+bool jpeg_ycc_to_rgb(const uhdr_raw_image_t* ycc, int libjpeg_variant, uhdr_raw_image_t* rgb, uhdr_error_info_t* st);
+// is a device context current on this thread (i.e. are we inside an accelerated uhdr_encode / uhdr_decode)?
+bool enabled();
+
+}  // namespace uhdr_hip_seam
+
+#endif  // UHDR_HIP_SEAM_H

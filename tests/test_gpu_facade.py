@@ -1,0 +1,110 @@
+"""GPU: the reference's sample app, linked unmodified against the facade libuhdr.so, with -u 1
+(uhdr_enable_gpu_acceleration) -- SURVEY.md 8f-3.  Accelerated runs must (a) really go through the device at every
+stage the seam covers and (b) give the CPU reference's bytes: the encode-side operators are measured identical to
+the reference, FDCT / IDCT / colour conversion are integer exact, so whole files and whole decoded
+frames are compared byte for byte; the two float tails with a stated +-1 bar (tone map, generate) get that bar."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+from tests import facade_util as F
+from tests import fixture720
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not F.built(), reason="facade not built")]
+
+
+def _stages(trace, where="device"):
+    return sorted({l.split()[1] for l in trace if l.endswith("-> " + where)})
+
+
+def _fixture(d):
+    g = fixture720.gold()
+    g["p010"].tofile(os.path.join(d, "in.p010"))
+    g["yuv420"].tofile(os.path.join(d, "in.yuv420"))
+    return os.path.join(d, "in.p010"), os.path.join(d, "in.yuv420")
+
+
+def test_config1_encode_through_the_facade_equals_the_cpu_reference():
+    with tempfile.TemporaryDirectory() as d:
+        p, y = _fixture(d)
+        rc, _, err, _ = F.encode_api1(p, y, 1280, 720, "cpu.jpg", False, d)
+        assert rc == 0, err
+        rc, _, err, trace = F.encode_api1(p, y, 1280, 720, "gpu.jpg", True, d)
+        assert rc == 0, err
+        st = _stages(trace)
+        # API-1: generateGainMap, convertYuv (BT.709 -> the P3/601 encoding of the base JPEG), both JPEG block stages
+        assert "generate_gainmap" in st and "convert_yuv" in st and "fdct_planes" in st, trace
+        a, b = F.read(os.path.join(d, "cpu.jpg")), F.read(os.path.join(d, "gpu.jpg"))
+        assert a.size == b.size == 85449
+        assert np.array_equal(a, b), f"{int((a != b).sum())} differing bytes"
+
+
+@pytest.mark.parametrize("ct,fmt,bpp", [(0, 4, 8), (1, 5, 4), (2, 5, 4)])  # linear F16, HLG 1010102, PQ 1010102
+def test_config1_decode_through_the_facade_equals_the_cpu_reference(ct, fmt, bpp):
+    with tempfile.TemporaryDirectory() as d:
+        p, y = _fixture(d)
+        rc, _, err, _ = F.encode_api1(p, y, 1280, 720, "in.jpg", False, d)
+        assert rc == 0, err
+        rc, _, err, _ = F.decode("in.jpg", ct, fmt, "cpu.raw", False, d)
+        assert rc == 0, err
+        rc, _, err, trace = F.decode("in.jpg", ct, fmt, "gpu.raw", True, d)
+        assert rc == 0, err
+        st = _stages(trace)
+        assert "apply_gainmap" in st and "idct_planes" in st, trace
+        a, b = F.read(os.path.join(d, "cpu.raw")), F.read(os.path.join(d, "gpu.raw"))
+        assert a.size == b.size == 1280 * 720 * bpp
+        assert np.array_equal(a, b), f"{int((a != b).sum())} differing bytes"
+
+
+def test_4k_decode_through_the_facade_equals_the_cpu_reference():
+    """BASELINE config 2 at the API level: a 4K UltraHDR JPEG (encoded by the CPU reference path) -> RGBA_F16."""
+    from libultrahdr_amd import capi as A
+    from libultrahdr_amd import synth
+
+    w, h = 3840, 2160
+    with tempfile.TemporaryDirectory() as d:
+        hdr = synth.make_hdr_p010(w, h, ct=A.UHDR_CT_HLG)
+        sdr = synth.make_sdr_yuv420(w, h)
+        np.concatenate([hdr.valid(0).ravel(), hdr.valid(1).ravel()]).tofile(os.path.join(d, "in.p010"))
+        np.concatenate([sdr.valid(c).ravel() for c in range(3)]).tofile(os.path.join(d, "in.yuv420"))
+        # realtime preset keeps the CPU encode of the test input short; the decode under test does not depend on it
+        rc, _, err, _ = F.encode_api1("in.p010", "in.yuv420", w, h, "in.jpg", False, d, extra=("-D", 0))
+        assert rc == 0, err
+        rc, _, err, _ = F.decode("in.jpg", 0, 4, "cpu.raw", False, d)
+        assert rc == 0, err
+        rc, _, err, trace = F.decode("in.jpg", 0, 4, "gpu.raw", True, d)
+        assert rc == 0, err
+        assert "apply_gainmap" in _stages(trace), trace
+        a, b = F.read(os.path.join(d, "cpu.raw")), F.read(os.path.join(d, "gpu.raw"))
+        assert a.size == b.size == w * h * 8
+        assert np.array_equal(a, b), f"{int((a != b).sum())} differing bytes"
+
+
+def test_api0_encode_through_the_facade():
+    """API-0 (HDR only): toneMap + generateGainMap + convert_raw_input_to_ycbcr on the device.  toneMap's sRGB OETF is
+    correctly rounded on the device and faithfully rounded in glibc: the files may differ in the rare
+    +-1 sample, so the check is on decoded pixels."""
+    from libultrahdr_amd import capi as A
+    from libultrahdr_amd import synth
+
+    w, h = 1280, 720
+    with tempfile.TemporaryDirectory() as d:
+        hdr = synth.make_hdr_rgba1010102(w, h, ct=A.UHDR_CT_PQ)
+        hdr.valid(0).tofile(os.path.join(d, "in.raw"))
+        args = ["-m", 0, "-p", "in.raw", "-w", w, "-h", h, "-a", 5, "-C", 2, "-t", 2, "-R", 1]
+        rc, _, err, _ = F.run_app(args + ["-z", "cpu.jpg"], False, d)
+        assert rc == 0, err
+        rc, _, err, trace = F.run_app(args + ["-z", "gpu.jpg"], True, d)
+        assert rc == 0, err
+        st = _stages(trace)
+        assert "tone_map" in st and "generate_gainmap" in st and "convert_raw_input_to_ycbcr" in st, trace
+        for name in ("cpu", "gpu"):
+            rc, _, err, _ = F.decode(name + ".jpg", 0, 4, name + ".raw", False, d)
+            assert rc == 0, err
+        a = np.fromfile(os.path.join(d, "cpu.raw"), dtype=np.float16).astype(np.float32)
+        b = np.fromfile(os.path.join(d, "gpu.raw"), dtype=np.float16).astype(np.float32)
+        assert a.size == b.size == w * h * 4
+        # a +-1 8-bit sample before the JPEG DCT moves a handful of decoded pixels slightly
+        assert (a != b).mean() < 1e-3 and np.abs(a - b).max() < 0.25
