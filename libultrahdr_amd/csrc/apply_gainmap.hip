@@ -72,6 +72,24 @@ __device__ __forceinline__ uint32_t pack_codes_1010102(uint32_t r, uint32_t g, u
   return r | (g << 10) | (b << 20) | (0x3u << 30);
 }
 
+// Quad kernel: the same step function (HLG: clamp, powf(v, 1/1.2), OETF LUT, 10-bit quantisation; PQ: clamp, OETF LUT,
+// quantisation -- jpegr.cpp:1775-1805) as a bucket table in LDS, built and verified on the host
+// (host_tables.cpp: make_bucket_table).  Non-negative floats order like their bit patterns, so the clamp to [0, 1]
+// is a three-operand integer median (negative values and -0.0 have the sign bit set: negative as integers -> 0),
+// the bucket is bits >> shift, and inside a bucket the code changes at most once:
+//     code = bits >= thr ? hi : lo          entry = {thr, lo | hi << 16}
+// One 8-byte LDS read, one compare and one select per channel; no powf, no 256 KiB gather, no search.
+template <int OUT>
+__device__ __forceinline__ uint32_t oetf_code_bucket(float v, const uint2* tab, uint32_t base8) {
+  constexpr int SH = (OUT == 1) ? kOetfBucketShiftHlg : kOetfBucketShiftPq;
+  const int ib = min(max((int)__float_as_uint(v), 0), 0x3F800000);  // clampPixelFloat on the bit pattern (v_med3_i32)
+  const uint32_t bits = (uint32_t)ib;
+  uint32_t off = (bits >> (SH - 3)) & ~7u;  // bucket * 8 (byte offset of the entry)
+  off = off > base8 ? off - base8 : 0u;     // everything below the first threshold shares bucket 0
+  const uint2 e = *(const uint2*)((const char*)tab + off);
+  return bits >= e.x ? e.y >> 16 : e.y & 0xffffu;
+}
+
 template <int OUT>
 __device__ __forceinline__ typename OutPix<OUT>::type finish_pixel(Color3 lin, float f0, float f1,
                                                                    float f2, const ApplyParams& p,
@@ -381,9 +399,14 @@ struct QuadRaw {
 // luma blocks): it dequantizes and inverse-transforms the tile's 32 + 8 + 8 blocks into its private LDS tile
 // (idct_core.h, six eight-block passes) and feeds the same per-quad arithmetic from there; the gain map is still
 // read from memory.  3 B/px of coefficients in instead of 3 in + 1.5 out + 1.5 in over four launches.
+// Workgroup size: 256 for the linear F16 output (8 workgroups per CU share nothing but 14 KB of tables); 1024 for the
+// HLG / PQ outputs, whose output-code bucket table is 41 / 17 KB -- sixteen waves share one copy and two such
+// workgroups (32 waves) still fit a CU's 160 KB.
+template <int OUT> constexpr int quad_block() { return OUT == 0 ? kBlock : 1024; }
 template <int OUT, int MAPFMT, int SMODE, int BASE, int SRC = 0>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void apply_quad_kernel(const ApplyParams p) {
+__global__ __launch_bounds__(quad_block<OUT>(), (quad_block<OUT>() == 1024 && SRC == 0) ? 8 : (quad_block<OUT>() == 1024 ? 4 : 1)) __attribute__((amdgpu_num_sgpr(80))) void apply_quad_kernel(const ApplyParams p) {
   static_assert(SRC == 0 || BASE == 0, "coefficient input is a 4:2:0 base image");
+  constexpr int BLK = quad_block<OUT>();
   constexpr int NCH = (MAPFMT == 0) ? 1 : 3;
   constexpr int BPP = (MAPFMT == 0) ? 1 : (MAPFMT == 1 ? 3 : 4);
   using Raw = QuadRaw<MAPFMT, SMODE, BASE>;
@@ -391,25 +414,25 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
   __shared__ float s_gain[(SMODE == 0) ? 1 : NCH * kGainN];
   __shared__ float s_u8f[(SMODE == 0 && BASE != 2) ? 1 : 256];  // byte / 255.0f: map taps (SMODE 1), RGBA8888 base samples (BASE 2)
   __shared__ float s_fac[(SMODE == 0) ? NCH * 256 : 1];
-  __shared__ float s_thr[(OUT == 1) ? kOetfTabFloats : 1];  // HLG output-code thresholds + bucket end-point codes
+  __shared__ __attribute__((aligned(8))) uint2 s_code[(OUT == 1) ? kOetfBucketsHlg : (OUT == 2 ? kOetfBucketsPq : 1)];  // HLG / PQ output-code buckets
   // IDW weights re-laid out for pixel PAIRS: entry (table, oy, ox/2) holds
   // {w0(ox), w0(ox+1), w1(ox), w1(ox+1), w2(ox), w2(ox+1), w3(ox), w3(ox+1)}
   __shared__ __attribute__((aligned(16))) float s_idw[(SMODE == 0) ? 4 : 4 * kMaxIdwScaleLds * kMaxIdwScaleLds * 4];
 
   const uint32_t tid = threadIdx.x;
-  for (uint32_t i = tid; i < kSrgbPad; i += kBlock) s_srgb[i] = p.tables[ApplyTables::kSrgbOff + min(i, (uint32_t)kSrgbN - 1)];
-  if constexpr (OUT == 1) {
-    for (uint32_t i = tid; i < kOetfTabFloats; i += kBlock) s_thr[i] = p.oetf_thr[i];
+  for (uint32_t i = tid; i < kSrgbPad; i += BLK) s_srgb[i] = p.tables[ApplyTables::kSrgbOff + min(i, (uint32_t)kSrgbN - 1)];
+  if constexpr (OUT != 0) {
+    for (uint32_t i = tid; i < p.oetf_n; i += BLK) s_code[i] = p.oetf_buckets[i];
   }
   if constexpr (SMODE == 0) {
-    for (uint32_t i = tid; i < NCH * 256; i += kBlock) s_fac[i] = p.tables[ApplyTables::kFacOff + i];
+    for (uint32_t i = tid; i < NCH * 256; i += BLK) s_fac[i] = p.tables[ApplyTables::kFacOff + i];
     if constexpr (BASE == 2)
-      for (uint32_t i = tid; i < 256; i += kBlock) s_u8f[i] = p.tables[ApplyTables::kU8fOff + i];
+      for (uint32_t i = tid; i < 256; i += BLK) s_u8f[i] = p.tables[ApplyTables::kU8fOff + i];
   } else {
-    for (uint32_t i = tid; i < NCH * kGainN; i += kBlock) s_gain[i] = p.tables[ApplyTables::kGainOff + i];
-    for (uint32_t i = tid; i < 256; i += kBlock) s_u8f[i] = p.tables[ApplyTables::kU8fOff + i];
+    for (uint32_t i = tid; i < NCH * kGainN; i += BLK) s_gain[i] = p.tables[ApplyTables::kGainOff + i];
+    for (uint32_t i = tid; i < 256; i += BLK) s_u8f[i] = p.tables[ApplyTables::kU8fOff + i];
     const uint32_t s = p.scale, nidw = 4 * s * s * 4;
-    for (uint32_t i = tid; i < nidw; i += kBlock) {
+    for (uint32_t i = tid; i < nidw; i += BLK) {
       // source index i = ((tbl*s + oy)*s + ox)*4 + k  ->  pair layout
       const uint32_t k = i & 3, pos = i >> 2, ox = pos % s, row = pos / s;  // row = tbl*s + oy
       s_idw[(row * (s >> 1) + (ox >> 1)) * 8 + k * 2 + (ox & 1)] = p.tables[ApplyTables::kIdwOff + i];
@@ -420,7 +443,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
   const uint32_t qw = p.sdr.w >> 1, qh = p.sdr.h >> 1;
   const uint32_t strips_x = (qw + 64 * kQuadsPerLane - 1) / (64 * kQuadsPerLane);  // a wave owns 128 * kQuadsPerLane pixel columns
   const uint32_t lane = tid & 63;
-  const uint32_t wave = blockIdx.x * (kBlock / 64) + __builtin_amdgcn_readfirstlane(tid >> 6);  // SGPR
+  const uint32_t wave = blockIdx.x * (BLK / 64) + __builtin_amdgcn_readfirstlane(tid >> 6);  // SGPR
   const uint32_t groups = p.row_groups, n_iter = p.tiles_per_wave;
   const uint32_t per_frame = groups * strips_x;
   if constexpr (SRC == 0) {
@@ -452,6 +475,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
   const f2 off_s2 = splat(p.offset_sdr[NCH == 1 ? 0 : 2]), off_h2 = splat(p.offset_hdr[NCH == 1 ? 0 : 2]);
   const uint32_t scale = p.scale, half_scale = p.scale >> 1, magic = p.scale_magic;
   const uint32_t gmh1 = p.gm.h - 1, y0g = p.y0;
+  const uint32_t code_base8 = p.oetf_base8;
+  (void)code_base8;
 
   // ---- loop-invariant, per-lane column state --------------------------------------------------
   // A lane owns kQuadsPerLane quads of every quad row, 128 pixels apart: each load / store
@@ -708,18 +733,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
           hr = nr; hg = ng; hb = nb;
         }
         uint2 o;
-        if constexpr (OUT == 1) {
-          o.x = pack_codes_1010102(oetf_code<OUT>(clamp01(hr.x), s_thr), oetf_code<OUT>(clamp01(hg.x), s_thr),
-                                   oetf_code<OUT>(clamp01(hb.x), s_thr));
-          o.y = pack_codes_1010102(oetf_code<OUT>(clamp01(hr.y), s_thr), oetf_code<OUT>(clamp01(hg.y), s_thr),
-                                   oetf_code<OUT>(clamp01(hb.y), s_thr));
-        } else {
-          const uint16_t* lut = (const uint16_t*)p.oetf_thr;  // 10-bit codes of pqOetfLUT's 65536 nodes (128 KiB, L2 resident)
-          o.x = pack_codes_1010102(lut[lut_index_f32<kOetfN>(clamp01(hr.x))], lut[lut_index_f32<kOetfN>(clamp01(hg.x))],
-                                   lut[lut_index_f32<kOetfN>(clamp01(hb.x))]);
-          o.y = pack_codes_1010102(lut[lut_index_f32<kOetfN>(clamp01(hr.y))], lut[lut_index_f32<kOetfN>(clamp01(hg.y))],
-                                   lut[lut_index_f32<kOetfN>(clamp01(hb.y))]);
-        }
+        o.x = pack_codes_1010102(oetf_code_bucket<OUT>(hr.x, s_code, code_base8), oetf_code_bucket<OUT>(hg.x, s_code, code_base8),
+                                 oetf_code_bucket<OUT>(hb.x, s_code, code_base8));
+        o.y = pack_codes_1010102(oetf_code_bucket<OUT>(hr.y, s_code, code_base8), oetf_code_bucket<OUT>(hg.y, s_code, code_base8),
+                                 oetf_code_bucket<OUT>(hb.y, s_code, code_base8));
         if (SRC == 0 || store_ok) stream_store<u2v>(dpx, (u2v){o.x, o.y});
       }
     }
@@ -741,10 +758,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
     }
   } else {
     // ---- coefficient input: 128 x 16 pixel tiles, IDCT into the wave's LDS tile, then eight quad rows -------
-    __shared__ int s_ws[kBlock / 64][8 * 8 * 9];
+    __shared__ int s_ws[BLK / 64][8 * 8 * 9];
     __shared__ int s_q[3][64];
-    __shared__ __attribute__((aligned(8))) uint8_t s_yt[kBlock / 64][16 * 128];
-    __shared__ __attribute__((aligned(8))) uint8_t s_ct[kBlock / 64][2][8 * 64];
+    __shared__ __attribute__((aligned(8))) uint8_t s_yt[BLK / 64][16 * 128];
+    __shared__ __attribute__((aligned(8))) uint8_t s_ct[BLK / 64][2][8 * 64];
     const CoefSrc* __restrict__ cs = p.coef_src;
     if (tid < 192) s_q[tid >> 6][tid & 63] = cs->q[tid >> 6][tid & 63];
     __syncthreads();
@@ -759,7 +776,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
     const int16_t* ccr = cs->coef[2];
     const int bw0 = cs->bw[0], bh0 = cs->bh[0], bw1 = cs->bw[1], bh1 = cs->bh[1], bw2 = cs->bw[2], bh2 = cs->bh[2];
     const uint32_t tiles_x = (p.sdr.w + 127) >> 7, tiles_y = (p.sdr.h + 15) >> 4, ntiles = tiles_x * tiles_y;
-    const uint32_t nwaves = gridDim.x * (kBlock / 64);
+    const uint32_t nwaves = gridDim.x * (BLK / 64);
     for (uint32_t t = wave; t < ntiles; t += nwaves) {
       const uint32_t ty = t / tiles_x, tx = t - ty * tiles_x;
       // the tile's six eight-block units: Y rows 2ty, 2ty+1 x two halves, Cb, Cr (all loads issued up front)
@@ -818,11 +835,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void a
 // Resident workgroups of a kernel on the current device = CUs x blocks per CU (occupancy API; the
 // quad kernels cap their SGPRs so the API's answer is exact -- MI355X_MICROARCH.md "Residency").
 template <typename K>
-int resident_blocks(K kernel) {
+int resident_blocks(K kernel, int block = kBlock) {
   int dev = 0, per_cu = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess) return 2048;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, 0) != hipSuccess || per_cu <= 0) per_cu = block == kBlock ? 4 : 1;
   if (per_cu > 8) per_cu = 8;
   if (const char* e = getenv("UHDR_HIP_BLOCKS_PER_CU")) {  // tuning knob (tools/kbench)
     const int v = atoi(e);
@@ -833,12 +850,13 @@ int resident_blocks(K kernel) {
 
 template <int OUT, int MAPFMT, int SMODE, int BASE>
 hipError_t launch_quad(const ApplyParams& p, hipStream_t s) {
-  static const int resident = resident_blocks(apply_quad_kernel<OUT, MAPFMT, SMODE, BASE>);
+  constexpr int BLK = quad_block<OUT>();
+  static const int resident = resident_blocks(apply_quad_kernel<OUT, MAPFMT, SMODE, BASE>, BLK);
   const uint32_t n_frames = p.n_frames ? p.n_frames : 1;
   const uint32_t strips_x = (p.sdr.w / 2 + 64 * kQuadsPerLane - 1) / (64 * kQuadsPerLane), qh = p.sdr.h / 2;
   // one balanced round: all workgroups resident; a wave owns a column strip of one frame and every
   // `groups`-th quad row of it
-  const uint32_t max_waves = (uint32_t)resident * (kBlock / 64);
+  const uint32_t max_waves = (uint32_t)resident * (BLK / 64);
   uint32_t groups = max_waves / (strips_x * n_frames);
   if (groups > qh) groups = qh;
   if (groups < 1) groups = 1;
@@ -847,22 +865,23 @@ hipError_t launch_quad(const ApplyParams& p, hipStream_t s) {
   q.n_frames = n_frames;
   q.row_groups = groups;
   q.tiles_per_wave = (qh + groups - 1) / groups;  // quad rows per wave
-  const int grid = (int)((nwaves + kBlock / 64 - 1) / (kBlock / 64));
-  hipLaunchKernelGGL((apply_quad_kernel<OUT, MAPFMT, SMODE, BASE>), dim3(grid), dim3(kBlock), 0, s, q);
+  const int grid = (int)((nwaves + BLK / 64 - 1) / (BLK / 64));
+  hipLaunchKernelGGL((apply_quad_kernel<OUT, MAPFMT, SMODE, BASE>), dim3(grid), dim3(BLK), 0, s, q);
   return hipGetLastError();
 }
 // coefficient input (SRC 1): resident workgroups, waves stride over the 128 x 16 pixel tiles
 template <int OUT, int MAPFMT, int SMODE>
 hipError_t launch_quad_coef(const ApplyParams& p, hipStream_t s) {
-  static const int resident = resident_blocks(apply_quad_kernel<OUT, MAPFMT, SMODE, 0, 1>);
+  constexpr int BLK = quad_block<OUT>();
+  static const int resident = resident_blocks(apply_quad_kernel<OUT, MAPFMT, SMODE, 0, 1>, BLK);
   const uint32_t ntiles = ((p.sdr.w + 127) / 128) * ((p.sdr.h + 15) / 16);
-  uint32_t grid = (ntiles + kBlock / 64 - 1) / (kBlock / 64);
+  uint32_t grid = (ntiles + BLK / 64 - 1) / (BLK / 64);
   if (grid > (uint32_t)resident) grid = (uint32_t)resident;
   ApplyParams q = p;
   q.n_frames = 1;
   q.row_groups = 1;
   q.tiles_per_wave = 0;
-  hipLaunchKernelGGL((apply_quad_kernel<OUT, MAPFMT, SMODE, 0, 1>), dim3(grid), dim3(kBlock), 0, s, q);
+  hipLaunchKernelGGL((apply_quad_kernel<OUT, MAPFMT, SMODE, 0, 1>), dim3(grid), dim3(BLK), 0, s, q);
   return hipGetLastError();
 }
 template <int OUT, int MAPFMT>
@@ -930,6 +949,7 @@ int apply_quad_mode(const ApplyParams& p) {
                     (uint64_t)p.dst.stride[0] * out_bytes * p.sdr.h < 0xFFFFFFFFull &&
                     (uint64_t)p.gm.stride[0] * p.gm.h * 4 < 0xFFFFFFFFull;
   if (!quad) return -1;
+  if (out != 0 && (!p.oetf_buckets || p.oetf_n == 0)) return -1;  // HLG / PQ: the verified output-code bucket table
   if (p.scale == 1) {
     // the gain map must cover every base pixel and allow the vector loads used per format
     if (p.gm.w < p.sdr.w || p.gm.h < p.sdr.h + p.y0) return -1;

@@ -210,6 +210,84 @@ const std::vector<float>& oetf_code_thresholds(int ct) {
   return ct == UHDR_CT_HLG ? hlg : pq;
 }
 
+// ---- output-code BUCKET tables (the quad kernel's form of the same step function) -----------------
+// Non-negative floats order like their bit patterns, so cutting [0, 1] into buckets of 2^shift consecutive
+// bit patterns (shift 15 for HLG, 16 for PQ: 0.2 - 0.4 % of the value) leaves at most ONE point per bucket at
+// which the 10-bit code changes -- the thresholds are 0.47 % (HLG, around code 511) / 0.8 % (PQ) apart or
+// more, and where the reference's 65536-node LUT index makes the code jump by several steps at once the
+// jump sits at a single float.  Entry k describes bucket base + k:
+//     .thr  = bit pattern of the threshold inside the bucket (0xFFFFFFFF: none)
+//     .code = code below the threshold | code from the threshold on << 16
+// and the device evaluates   code(v) = bits(v) >= thr ? hi : lo   -- one 8-byte LDS read, one compare, one
+// select per channel.  Everything below the first threshold is bucket 0 (code 0).  The construction is
+// CHECKED here: the table lookup is replayed against the composite at every threshold, its predecessor
+// and both ends of every bucket; `exact` says whether all of them (and the one-threshold property) held.
+static OetfBuckets make_bucket_table(int ct) {
+  OetfBuckets b;
+  const std::vector<float> t = make_thresholds(ct);
+  auto bits_of = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+  auto flt = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
+  const uint32_t one = bits_of(1.0f);
+  b.shift = ct == UHDR_CT_HLG ? kOetfBucketShiftHlg : kOetfBucketShiftPq;
+  uint32_t first = one;  // smallest positive threshold
+  for (uint32_t c = 1; c < 1024; c++)
+    if (t[c] > 0.0f && t[c] <= 1.0f && bits_of(t[c]) < first) first = bits_of(t[c]);
+  b.base = first >> b.shift;
+  b.n = (one >> b.shift) - b.base + 1;
+  b.exact = true;
+  b.entries.assign((size_t)b.n * 2, 0u);
+  std::vector<std::vector<uint32_t>> inside(b.n);
+  for (uint32_t c = 1; c < 1024; c++) {
+    if (!(t[c] <= 1.0f)) continue;
+    const uint32_t u = bits_of(t[c]);
+    if (u == 0) continue;  // codes reached at v = 0 are part of every bucket's `lo`
+    std::vector<uint32_t>& v = inside[(u >> b.shift) - b.base];
+    if (v.empty() || v.back() != u) v.push_back(u);
+  }
+  auto lookup = [&](uint32_t u) -> uint32_t {  // the device's evaluation
+    uint32_t k = u >> b.shift;
+    k = k > b.base ? k - b.base : 0;
+    const uint32_t thr = b.entries[2 * k], cc = b.entries[2 * k + 1];
+    return u >= thr ? cc >> 16 : cc & 0xffffu;
+  };
+  for (uint32_t k = 0; k < b.n; k++) {
+    const uint32_t start = (b.base + k) << b.shift;
+    // bucket 0 also stands for everything below it
+    const uint32_t lo = oetf_code_host(ct, k == 0 ? 0.0f : flt(start));
+    uint32_t thr = 0xFFFFFFFFu, hi = lo;
+    if (!inside[k].empty()) {
+      if (inside[k].size() > 1) b.exact = false;
+      thr = inside[k][0];
+      hi = oetf_code_host(ct, flt(inside[k].back()));
+    }
+    b.entries[2 * k] = thr;
+    b.entries[2 * k + 1] = lo | (hi << 16);
+  }
+  // replay: both ends of every bucket, every threshold and its predecessor, and the range below bucket 0
+  for (uint32_t k = 0; k < b.n && b.exact; k++) {
+    const uint32_t start = (b.base + k) << b.shift;
+    uint32_t probes[6] = {start, start + (1u << b.shift) - 1, 0, 0, 0, 0};
+    int np = 2;
+    for (uint32_t u : inside[k]) {
+      if (np < 6) probes[np++] = u;
+      if (np < 6 && u > 0) probes[np++] = u - 1;
+    }
+    for (int i = 0; i < np; i++) {
+      const uint32_t u = probes[i] > one ? one : probes[i];
+      if (lookup(u) != oetf_code_host(ct, flt(u))) b.exact = false;
+    }
+  }
+  for (uint32_t u : {0u, 1u, first > 0 ? first - 1 : 0u, first, one})
+    if (lookup(u) != oetf_code_host(ct, flt(u))) b.exact = false;
+  if (b.n > (uint32_t)(ct == UHDR_CT_HLG ? kOetfBucketsHlg : kOetfBucketsPq)) b.exact = false;  // the kernel's LDS array
+  return b;
+}
+const OetfBuckets& oetf_code_buckets(int ct) {
+  static const OetfBuckets hlg = make_bucket_table(UHDR_CT_HLG);
+  static const OetfBuckets pq = make_bucket_table(UHDR_CT_PQ);
+  return ct == UHDR_CT_HLG ? hlg : pq;
+}
+
 // Tables of exact_math.h.  Everything is computed in long double (64-bit significand on x86-64)
 // and rounded once to double.
 const std::vector<double>& math_tables() {

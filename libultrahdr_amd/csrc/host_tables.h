@@ -22,6 +22,13 @@ const std::vector<float>& pq_oetf_code_lut();   // 65536 uint16 codes (pqOetfLUT
 // 10-bit output-code thresholds of the HLG / PQ tail (kOetfThrN floats; see host_tables.cpp)
 const std::vector<float>& oetf_code_thresholds(int ct);
 uint32_t oetf_code(int ct, float v);  // the composite itself, evaluated with the host libm
+// the same step function as a bucket table for the quad kernel (see host_tables.cpp)
+struct OetfBuckets {
+  uint32_t shift, base, n;         // bucket k covers bit patterns [(base + k) << shift, (base + k + 1) << shift)
+  bool exact;                      // construction verified (one threshold per bucket, replay against the composite)
+  std::vector<uint32_t> entries;   // n x {thr, lo | hi << 16}
+};
+const OetfBuckets& oetf_code_buckets(int ct);
 
 // float64 tables of exact_math.h (table-driven pow / log2 of the encode path)
 const std::vector<double>& math_tables();

@@ -76,6 +76,8 @@ struct uhdr_hip_ctx {
   float* d_pq_inv = nullptr;
   float* d_hlg_oetf = nullptr;
   float* d_pq_oetf = nullptr;
+  float* d_hlg_buckets = nullptr;   // quad kernel: output-code bucket tables (host_tables.cpp: make_bucket_table)
+  float* d_pq_buckets = nullptr;
   float* d_hlg_inv_ootf = nullptr;  // hlgInvOetfLUT followed by hlgOotfApprox, per table node
   double* d_math = nullptr;         // exact_math.h tables
   // per-call apply tables: ring of pinned host slots + matching device slots
@@ -426,7 +428,8 @@ void uhdr_hip_destroy(uhdr_hip_ctx_t* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (auto& e : c->prof_entries) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-  float* luts[] = {c->d_srgb, c->d_hlg_inv, c->d_pq_inv, c->d_hlg_oetf, c->d_pq_oetf, c->d_hlg_inv_ootf, (float*)c->d_math};
+  float* luts[] = {c->d_srgb, c->d_hlg_inv, c->d_pq_inv, c->d_hlg_oetf, c->d_pq_oetf, c->d_hlg_inv_ootf, (float*)c->d_math,
+                   c->d_hlg_buckets, c->d_pq_buckets};
   for (float* p : luts) if (p) (void)hipFree(p);
   for (int i = 0; i < kTableSlots; i++) {
     if (c->h_tab[i]) (void)hipHostFree(c->h_tab[i]);
@@ -535,6 +538,20 @@ static uhdr_error_info_t build_apply_params(uhdr_hip_ctx* c, const uhdr_raw_imag
   } else if (out_ct == UHDR_CT_PQ) {
     UHDR_TRY(upload_lut(&c->d_pq_oetf, host::pq_oetf_code_lut(), c->stream));
     p.oetf_thr = c->d_pq_oetf;
+  }
+  if (out_ct == UHDR_CT_HLG || out_ct == UHDR_CT_PQ) {
+    const host::OetfBuckets& b = host::oetf_code_buckets(out_ct);
+    if (b.exact) {  // otherwise the quad kernel is not offered this transfer (apply_quad_mode) and the generic kernel runs
+      float** slot = out_ct == UHDR_CT_HLG ? &c->d_hlg_buckets : &c->d_pq_buckets;
+      if (!*slot) {
+        std::vector<float> raw(b.entries.size());
+        memcpy(raw.data(), b.entries.data(), raw.size() * sizeof(float));
+        UHDR_TRY(upload_lut(slot, raw, c->stream));
+      }
+      p.oetf_buckets = (const uint2*)*slot;
+      p.oetf_n = b.n;
+      p.oetf_base8 = b.base * 8;
+    }
   }
   p.sdr = view_of(sdr);
   p.gm = view_of(gm);

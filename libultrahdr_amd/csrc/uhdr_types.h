@@ -41,6 +41,9 @@ constexpr int kOetfThrN = 1028;  // thresholds T[0..1023] + 3 (+1 pad) sentinels
 constexpr int kOetfEstN = 4066;  // packed (code at bucket start | code at bucket end << 16), buckets k = bits(v) >> 18
 constexpr int kOetfTabFloats = kOetfThrN + kOetfEstN;
 constexpr int kInvOetfN = 4096;
+// quad kernel: the HLG / PQ output-code step function as a bucket table in LDS (host_tables.cpp: make_bucket_table)
+constexpr int kOetfBucketShiftHlg = 15, kOetfBucketShiftPq = 16;
+constexpr int kOetfBucketsHlg = 5376, kOetfBucketsPq = 2304;  // LDS capacity in entries (42 / 18 KiB); the host checks n <= capacity
 constexpr int kMaxIdwScaleLds = 8;  // idw tables up to 4*8*8*4 floats = 4 KiB live in LDS
 
 struct ApplyTables {  // layout of the device table block, in floats
@@ -71,7 +74,9 @@ struct ApplyParams {
   ImageView gm;       // whole gain map
   ImageViewMut dst;   // destination stripe
   const float* tables;      // ApplyTables block
-  const float* oetf_thr;    // HLG: output-code threshold block (kOetfTabFloats); PQ: 65536 uint16 output codes of pqOetfLUT's nodes; linear: null
+  const float* oetf_thr;    // generic kernel. HLG: output-code threshold block (kOetfTabFloats); PQ: 65536 uint16 output codes of pqOetfLUT's nodes; linear: null
+  const uint2* oetf_buckets;   // quad kernel, HLG / PQ: bucket table {thr, lo | hi << 16} (null: not verified exact -> generic kernel)
+  uint32_t oetf_n, oetf_base8; // entries, first bucket * 8
   uint32_t y0;              // global row of stripe row 0
   uint32_t tiles_per_wave;  // quad kernel: loop trip count (even), set by the launcher
   uint32_t row_groups;      // quad kernel: quad-row step of a wave, set by the launcher
