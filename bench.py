@@ -32,7 +32,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=16, help="4K frames per rank per step")
     ap.add_argument("--width", type=int, default=3840)
@@ -165,7 +165,8 @@ def main():
         step()
     barrier()
     t1 = time.perf_counter()
-    n_launch, kern_ms = ctx.profile_read("apply_gainmap", reset=True)
+    launch_ms = ctx.profile_read_list("apply_gainmap", reset=True)
+    n_launch, kern_ms = len(launch_ms), sum(launch_ms)
     ctx.profile(False)
     elapsed = t1 - t0
     if world > 1:
@@ -217,16 +218,20 @@ def main():
             "algorithmic_bytes_per_launch": int(algo_b),
             "avg_launch_us": round(avg_launch_s * 1e6, 3),
             "launches_timed": n_launch,
+            "launch_us": launch_stats(launch_ms),  # per-launch HIP-event durations over the timed region
+            "frac_at_median": round(algo_b / (launch_stats(launch_ms)["median"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if launch_ms else None,
         },
     }
 
     # the stage measurements and the CPU baseline run AFTER the timed region; a failure there (e.g. an
     # out-of-memory on a smaller device) must not cost the headline line
     if rank == 0 and world == 1 and not args.no_extra:
-        try:
-            out["extra"] = extras(ctx, u, device)
-        except Exception as e:  # noqa: BLE001
-            out["extra"] = {"error": f"{type(e).__name__}: {e}"}
+        for key, fn in (("encode", lambda: encode_section(ctx, u, device)), ("config5", lambda: config5_section(ctx, u, device)),
+                        ("extra", lambda: extras(ctx, u, device)), ("api_level", lambda: api_level_section())):
+            try:
+                out[key] = fn()
+            except Exception as e:  # noqa: BLE001  (a failure in one section must not cost the headline line)
+                out[key] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu:
         try:
             out["cpu_baseline"] = cpu_baseline(w, h, args.map, md, args.cpu_seconds)
@@ -237,6 +242,35 @@ def main():
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def launch_stats(ms_list):
+    """min / median / max (and the 10th / 90th percentile) of a list of per-launch durations in ms -> us."""
+    if not ms_list:
+        return None
+    v = sorted(ms_list)
+    q = lambda f: v[min(len(v) - 1, int(f * (len(v) - 1) + 0.5))]
+    return {"min": round(v[0] * 1e3, 2), "p10": round(q(0.1) * 1e3, 2), "median": round(q(0.5) * 1e3, 2),
+            "p90": round(q(0.9) * 1e3, 2), "max": round(v[-1] * 1e3, 2), "n": len(v)}
+
+
+def family_times(ctx, fn, families, iters=5, warm=2):
+    """Run fn() `iters` times with the library's per-launch HIP events on; -> {family: us per fn() call}."""
+    for _ in range(warm):
+        fn()
+    ctx.synchronize()
+    ctx.profile(True)
+    ctx.profile_read(None, reset=True)
+    for _ in range(iters):
+        fn()
+    out = {}
+    for f in families:
+        n, ms = ctx.profile_read(f, reset=True)
+        if n:
+            out[f] = {"us": round(ms / iters * 1e3, 2), "launches": n // iters}
+    ctx.profile_read(None, reset=True)
+    ctx.profile(False)
+    return out
 
 
 def measured_traffic(key):
@@ -252,6 +286,181 @@ def measured_traffic(key):
     if not e:
         return None, None
     return e["traffic_bytes_per_launch"], e["source"]
+
+
+def encode_section(ctx, u, device):
+    """The ENCODE half of BASELINE's metric, with its own roofline: per-kernel HIP-event durations inside the stage
+    chains and the algorithmic bytes of SURVEY.md 8(d) for the kernels actually launched.
+      config3: API-0 encode of an 8K RGBA1010102 PQ frame (tone map, one-pass max-RGB 3-channel map at scale 1,
+               RGB -> YCbCr 4:4:4, FDCT + quantize of the base's and the map's three planes)
+      api1_4k: API-1 encode of a 4K P010 + YCbCr 4:2:0 pair (two-pass 3-channel map, convertYuv, FDCTs)
+    Entropy coding is a separate stage (extra.huffman_*)."""
+    from libultrahdr_amd import capi as A
+    from libultrahdr_amd import synth
+    from libultrahdr_amd.images import Image
+    from libultrahdr_amd.ultrahdr import UltraHdr
+    import torch
+
+    res = {}
+    fams = ["tone_map", "generate_gainmap", "convert_raw_input_to_ycbcr", "convert_yuv", "fdct_quant", "jpeg_color", "encode_api0_fused"]
+    qy, qc = u.quant_table(95, False), u.quant_table(95, True)
+
+    def fdct_planes(img, planes, tables):
+        for c in planes:
+            rows, stride, wv = img.layout[c]
+            u.fdct_quant(img.plane_tensor(c), stride, wv // 8, rows // 8, tables[c])
+
+    def roof(px, kernels, bytes_per_px):
+        tot_us = sum(k["us"] for k in kernels.values())
+        b = sum(bytes_per_px.values()) * px
+        for name, k in kernels.items():
+            k["bytes_per_px"] = bytes_per_px.get(name)
+            if bytes_per_px.get(name):
+                k["GB/s"] = round(bytes_per_px[name] * px / (k["us"] * 1e-6) / 1e9, 1)
+                k["frac"] = round(k["GB/s"] / HBM_PEAK_GBS, 4)
+        return {"bound": "hbm", "achieved": round(b / (tot_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(b / (tot_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": int(b), "chain_us": round(tot_us, 1),
+                "traffic": None, "kernels": kernels}
+
+    # ---- BASELINE config 3: API-0, 8K RGBA1010102 PQ ------------------------------------------------------------------
+    w8, h8 = 7680, 4320
+    px8 = w8 * h8
+    hdr8 = synth.make_hdr_rgba1010102(w8, h8, ct=A.UHDR_CT_PQ).to(device)
+    sdr8 = Image(A.UHDR_IMG_FMT_32bppRGBA8888, w8, h8, align=64, device=device)
+    enc0 = UltraHdr(ctx=ctx, mapDimensionScaleFactor=1, useMultiChannelGainMap=True, preset=A.UHDR_USAGE_REALTIME)
+
+    def api0():
+        u.toneMap(hdr8, sdr8)
+        _, gm_ = enc0.generateGainMap(sdr8, hdr8, False, False)
+        fdct_planes(u.convert_raw_input_to_ycbcr(sdr8, False), (0, 1, 2), (qy, qc, qc))
+        fdct_planes(u.jpeg_rgb_to_ycc(gm_), (0, 1, 2), (qy, qc, qc))
+
+    k = family_times(ctx, api0, fams, iters=3, warm=1)
+    r = roof(px8, k, {"tone_map": 8.0, "generate_gainmap": 11.0, "convert_raw_input_to_ycbcr": 7.0, "fdct_quant": 18.0, "jpeg_color": 6.0})
+    res["config3_api0_8k_reference_operators"] = {
+        "workload": "configs[2]: 7680x4320 RGBA1010102 PQ -> toneMap + generateGainMap (1 pass, max-RGB, 3 ch, scale 1) + "
+                    "convert_raw_input_to_ycbcr(4:4:4) + jpeg rgb->ycc of the map + 6 x fdct_quant; entropy coding excluded",
+        "us": r["chain_us"], "Mpx/s": round(px8 / r["chain_us"], 1), "roofline": r}
+
+    def api0_fused():
+        _, ycc_, _, gm_ = enc0.encodeApi0Fused(hdr8, want_sdr_rgba=False, use_luminance=False)
+        fdct_planes(ycc_, (0, 1, 2), (qy, qc, qc))
+        u.fdct_quant_rgb(gm_, qy, qc)
+
+    k = family_times(ctx, api0_fused, fams, iters=3, warm=1)
+    # fused front end: 4 in, 3 + 3 out; base FDCT 3 + 6; fused map rgb->ycc + FDCT 3 + 6 (both under "fdct_quant")
+    r = roof(px8, k, {"encode_api0_fused": 10.0, "fdct_quant": 18.0})
+    res["config3_api0_8k"] = {
+        "workload": "configs[2] with the MI355X-first fusion: one front-end kernel (tone map + gain map + YCbCr 4:4:4) + "
+                    "3 x fdct_quant + fused (rgb->ycc + 3 x fdct_quant) of the map; same bytes out as the reference operators",
+        "us": r["chain_us"], "Mpx/s": round(px8 / r["chain_us"], 1), "fused_floor_16B_per_px_us": round(16.0 * px8 / (HBM_PEAK_GBS * 1e3), 1),
+        "roofline": r}
+    del hdr8, sdr8
+    torch.cuda.empty_cache()
+
+    # ---- API-1, 4K P010 + 4:2:0 (BASELINE configs[0] / [3] shape on one GPU) ---------------------------------------------
+    w, h = 3840, 2160
+    px = w * h
+    sdr = synth.make_sdr_yuv420(w, h).to(device)
+    hdr = synth.make_hdr_p010(w, h, ct=A.UHDR_CT_HLG).to(device)
+    enc1 = UltraHdr(ctx=ctx, mapDimensionScaleFactor=1, useMultiChannelGainMap=True, preset=A.UHDR_USAGE_BEST_QUALITY)
+    base = sdr.clone()
+
+    def api1():
+        _, gm_ = enc1.generateGainMap(sdr, hdr)
+        u.convertYuv(base, A.UHDR_CG_BT_709, A.UHDR_CG_DISPLAY_P3)
+        fdct_planes(base, (0, 1, 2), (qy, qc, qc))
+        u.fdct_quant_rgb(gm_, qy, qc)
+
+    k = family_times(ctx, api1, fams, iters=5, warm=2)
+    r = roof(px, k, {"generate_gainmap": 31.5, "convert_yuv": 3.0, "fdct_quant": 4.5 + 9.0})
+    res["api1_4k"] = {
+        "workload": "3840x2160 P010 (BT.2100 HLG) + YCbCr 4:2:0 -> generateGainMap (2 pass, 3 ch, scale 1: pass 1 4.5 in + 12 out, "
+                    "pass 2 12 in + 3 out) + convertYuv + 3 x fdct_quant (base) + fused (rgb->ycc + 3 x fdct_quant) of the map",
+        "us": r["chain_us"], "Mpx/s": round(px / r["chain_us"], 1), "roofline": r}
+    return res
+
+
+def config5_section(ctx, u, device):
+    """BASELINE configs[4] on one GPU: a batch of 32 4K frames decoded to HLG RGBA1010102 (Y400 map, scale 4),
+    captured into a HIP graph once and replayed."""
+    from libultrahdr_amd import capi as A
+    from libultrahdr_amd import synth
+    import torch
+
+    nb, w, h = 32, 3840, 2160
+    u32 = A.UHDR_IMG_FMT_32bppRGBA1010102
+    md = synth.default_metadata(use_base_cg=0)
+    sets = make_frames(nb, w, h, "A", device, u32, seed0=555)
+    for s5, g5, _ in sets:
+        s5.raw.cg, g5.raw.cg = A.UHDR_CG_BT_709, A.UHDR_CG_BT_2100
+    args5 = ([f[0] for f in sets], [f[1] for f in sets], md, A.UHDR_CT_HLG, u32, A.FLT_MAX, [f[2] for f in sets])
+    u.applyGainMapBatch(*args5)  # warm: tables, occupancy queries
+    ctx.synchronize()
+    ms = time_kernel(ctx, lambda: u.applyGainMapBatch(*args5), iters=10, warm=2)  # kernel time by HIP events, eager launches
+    stream = torch.cuda.Stream()
+    ctx.set_stream(stream.cuda_stream)
+    res = {}
+    try:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            u.applyGainMapBatch(*args5)
+        torch.cuda.synchronize()
+        for _ in range(3):
+            graph.replay()
+        torch.cuda.synchronize()
+        reps, walls = 20, []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                graph.replay()
+            torch.cuda.synchronize()
+            walls.append((time.perf_counter() - t0) / reps)
+        walls.sort()
+        wall = walls[len(walls) // 2]
+        b = algo_bytes_per_px("A", 4) * w * h * nb
+        res = {"workload": "configs[4] per-GPU share scaled to one GPU: 32 x 3840x2160 YCbCr420 + Y400 map (scale 4) -> HLG RGBA1010102, "
+                           "uhdr_hip_apply_gainmap_batch_dev captured in a HIP graph, replayed",
+               "graph_replay_us_per_batch": round(wall * 1e6, 1), "us_per_frame": round(wall * 1e6 / nb, 2),
+               "Mpx/s": round(nb * w * h / wall / 1e6, 1), "GB/s": round(b / wall / 1e9, 1), "frac_of_8TBs": round(b / wall / 1e9 / HBM_PEAK_GBS, 4),
+               "kernel_us_per_batch_eager_hip_events": round(ms * 1e3, 1), "timing": "wall clock around 20 replays, median of 5"}
+    finally:
+        ctx.set_stream(None)
+    del sets
+    torch.cuda.empty_cache()
+    return res
+
+
+def api_level_section():
+    """SURVEY.md 8(d) configs[1] at the API level: the reference's own uhdr_decode / uhdr_encode through the drop-in
+    libuhdr.so (facade/), with uhdr_enable_gpu_acceleration(codec, 1) -- host buffers in and out, PCIe and the CPU-side
+    JPEG entropy coding included.  The CPU-only numbers of the same calls are in cpu_baseline.stages."""
+    from libultrahdr_amd import capi as A
+    from libultrahdr_amd import facade as FA
+    from libultrahdr_amd import synth
+
+    if not FA.available():
+        return {"error": "libuhdr.so facade not built on this machine"}
+    w, h = 3840, 2160
+    hdr = synth.make_hdr_p010(w, h, ct=A.UHDR_CT_HLG)
+    sdr = synth.make_sdr_yuv420(w, h)
+    f16 = A.UHDR_IMG_FMT_64bppRGBAHalfFloat
+
+    def med(fn, n):
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            r = fn()
+            ts.append(time.perf_counter() - t0)
+        return r, sorted(ts)[len(ts) // 2]
+
+    FA.encode(hdr, sdr, gpu=True)  # warm-up: context creation, tables
+    jpg, t_enc = med(lambda: FA.encode(hdr, sdr, gpu=True), 3)
+    _, t_dec = med(lambda: FA.decode(jpg, A.UHDR_CT_LINEAR, f16, gpu=True), 5)
+    return {"uhdr_encode_api1_4k_hip": {"ms": round(t_enc * 1e3, 1), "Mpx/s": round(w * h / t_enc / 1e6, 1), "jpeg_bytes": len(jpg)},
+            "uhdr_decode_4k_f16_hip": {"ms": round(t_dec * 1e3, 1), "Mpx/s": round(w * h / t_dec / 1e6, 1)},
+            "note": "libuhdr.so facade, uhdr_enable_gpu_acceleration(1): pixel stages and FDCT / IDCT on the MI355X, container and "
+                    "Huffman coding in the reference's CPU code, pageable host buffers"}
 
 
 def extras(ctx, u, device):
@@ -404,45 +613,8 @@ def extras(ctx, u, device):
             u.fdct_quant(img.plane_tensor(c), stride, wv // 8, rows // 8, tables[c])
 
     qy, qc = u.quant_table(95, False), u.quant_table(95, True)
-    # (1) API-1 encode, 4K P010 + 4:2:0 (BASELINE config 1/4 shape on one GPU): two-pass 3-channel map,
-    #     convertYuv of the base to BT.601, FDCT of base (Y, Cb, Cr) and of the map (libjpeg rgb->ycc, 3 planes)
+    # (the API-1 4K and API-0 8K encode chains live in encode_section: they carry their own roofline objects)
     base = sdr.clone()
-
-    def api1():
-        md_, gm_ = enc.generateGainMap(sdr, hdr)
-        u.convertYuv(base, A.UHDR_CG_BT_709, A.UHDR_CG_DISPLAY_P3)
-        fdct_planes(base, (0, 1, 2), (qy, qc, qc))
-        u.fdct_quant_rgb(gm_, qy, qc)
-
-    ms = time_kernel(ctx, api1, iters=4, warm=2)
-    res["encode_api1_4k_p010_420_2pass_3ch_chain"] = {"us": round(ms * 1e3, 1), "Mpx/s": round(w * h / (ms / 1e3) / 1e6, 1),
-                                                       "stages": "generate(2 pass) + convertYuv + fdct(base 3 planes) + fused(rgb_to_ycc + fdct of the 3 map components); entropy coding not included"}
-    # (2) API-0 encode, 8K RGBA1010102 PQ (BASELINE config 3): tonemap, one-pass max-RGB 3-channel map, RGB->YCbCr 4:4:4, FDCTs
-    w8, h8 = 7680, 4320
-    hdr8 = synth.make_hdr_rgba1010102(w8, h8, ct=A.UHDR_CT_PQ).to(device)
-    sdr8 = Image(A.UHDR_IMG_FMT_32bppRGBA8888, w8, h8, align=64, device=device)
-    api0_enc = UltraHdr(ctx=ctx, mapDimensionScaleFactor=1, useMultiChannelGainMap=True, preset=A.UHDR_USAGE_REALTIME)
-
-    def api0():
-        u.toneMap(hdr8, sdr8)
-        md_, gm_ = api0_enc.generateGainMap(sdr8, hdr8, False, False)
-        fdct_planes(u.convert_raw_input_to_ycbcr(sdr8, False), (0, 1, 2), (qy, qc, qc))
-        fdct_planes(u.jpeg_rgb_to_ycc(gm_), (0, 1, 2), (qy, qc, qc))
-
-    ms = time_kernel(ctx, api0, iters=3, warm=1)
-    res["encode_api0_8k_rgba1010102_chain"] = {"us": round(ms * 1e3, 1), "Mpx/s": round(w8 * h8 / (ms / 1e3) / 1e6, 1),
-                                                "GB/s_unfused_44B_per_px": round(44.0 * w8 * h8 / (ms / 1e3) / 1e9, 1),
-                                                "stages": "tonemap + generate(1 pass, max-RGB) + rgb->ycbcr444 + fdct(base 3) + rgb_to_ycc + fdct(map 3); entropy coding not included"}
-    def api0_fused():
-        _, ycc_, md_, gm_ = api0_enc.encodeApi0Fused(hdr8, want_sdr_rgba=False, use_luminance=False)
-        fdct_planes(ycc_, (0, 1, 2), (qy, qc, qc))
-        u.fdct_quant_rgb(gm_, qy, qc)
-
-    ms = time_kernel(ctx, api0_fused, iters=3, warm=1)
-    res["encode_api0_8k_rgba1010102_chain_fused_front_end"] = {"us": round(ms * 1e3, 1), "Mpx/s": round(w8 * h8 / (ms / 1e3) / 1e6, 1),
-                                                                "stages": "fused(tonemap + generate 1 pass + rgb->ycbcr444) + fdct(base 3) + fused(rgb_to_ycc + fdct of the 3 map components)"}
-    del hdr8, sdr8
-    torch.cuda.empty_cache()
     # (2b) BASELINE config 4, the per-GPU share: one 16384 x 2048 row stripe of a 16K x 16K API-1 encode
     #      (pass 1 -> [all-reduce of 6 floats, not timed here] -> pass 2), 3-channel full-resolution map
     from libultrahdr_amd import stripes
@@ -554,7 +726,14 @@ def cpu_baseline(w, h, map_kind, md, budget_s):
         if el >= budget_s or n >= 64:
             break
     cores = min(os.cpu_count() or 1, 4) if kind == "reference" else 1
+    stages = None
+    if kind == "reference":
+        try:
+            stages = cpu_stage_baselines(3840, 2160)
+        except Exception as e:  # noqa: BLE001
+            stages = {"error": f"{type(e).__name__}: {e}"}
     return {
+        "stages": stages,
         "value": round(n * w * h / el / 1e6, 2),
         "unit": "Mpixels/s",
         "cores": cores,
@@ -564,6 +743,51 @@ def cpu_baseline(w, h, map_kind, md, budget_s):
                      else "single-threaded C restatement (oracle/uhdr_oracle.c)")
                   + f"; host has {os.cpu_count()} logical cores",
     }
+
+
+def cpu_stage_baselines(w, h):
+    """the reference's stage calls and its whole uhdr_encode / uhdr_decode on identical host buffers,
+    on this box's host cores (the reference uses min(N, 4) threads for the pixel stages and one thread for libjpeg,
+    convertYuv and the converters, jpegr.cpp:739).  Bounded: one warm-up + 1-3 timed calls per stage, median."""
+    import numpy as np
+
+    from libultrahdr_amd import capi as A
+    from libultrahdr_amd import synth
+    from oracle import loader as L
+
+    px = w * h
+    sdr = synth.make_sdr_yuv420(w, h)
+    hdr = synth.make_hdr_p010(w, h, ct=A.UHDR_CT_HLG)
+    out = {}
+
+    def timed(name, fn, reps, note=None, warm=False):
+        if warm:  # the reference builds its static LUTs on first use
+            fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            r = fn()
+            ts.append(time.perf_counter() - t0)
+        t = sorted(ts)[len(ts) // 2]
+        out[name] = {"ms": round(t * 1e3, 1), "Mpx/s": round(px / t / 1e6, 1)}
+        if note:
+            out[name]["note"] = note
+        return r
+
+    cfg2 = A.default_encode_cfg()  # C-API defaults: two passes, 3 channels, scale 1
+    timed("toneMap_p010_to_420", lambda: L.tone_map("ref", hdr), 2, warm=True)
+    _, gm = timed("generateGainMap_2pass_3ch_s1", lambda: L.generate_gainmap("ref", sdr, hdr, cfg2), 1, warm=True)
+    timed("convertYuv_709_to_p3", lambda: L.convert_yuv("ref", sdr, A.UHDR_CG_BT_709, A.UHDR_CG_DISPLAY_P3), 3, "single-threaded in the reference")
+    base_jpg = timed("compressImage_base_420_q95", lambda: L.ref_jpeg_compress(sdr, 95), 2, "libjpeg, one thread")
+    map_jpg = timed("compressImage_map_rgb888_q95", lambda: L.ref_jpeg_compress(gm, 95), 1, "libjpeg, one thread")
+    timed("decompressImage_base", lambda: L.ref_jpeg_decompress(base_jpg, 0), 2, "libjpeg, one thread")
+    timed("decompressImage_map", lambda: L.ref_jpeg_decompress(map_jpg, 1), 1, "libjpeg, one thread")
+    jpg = timed("uhdr_encode_api1", lambda: L.ref_uhdr_encode(hdr, sdr), 1, "whole C API call: ultrahdr_api.cpp:1200")
+    dest = np.empty((h, w, 8), dtype=np.uint8)
+    timed("uhdr_decode_to_f16", lambda: L.ref_uhdr_decode(jpg, A.UHDR_CT_LINEAR, A.UHDR_IMG_FMT_64bppRGBAHalfFloat, dest), 2,
+          "whole C API call: ultrahdr_api.cpp:1918")
+    out["image"] = f"{w}x{h} P010 (BT.2100 HLG) + YCbCr 4:2:0 (BT.709), synthetic seed 1234"
+    return out
 
 
 if __name__ == "__main__":

@@ -442,6 +442,8 @@ int uhdr_hip_jpeg_parse(const uint8_t* file, size_t size, uhdr_hip_jpeg_header_t
  * and their summed duration in milliseconds (synchronises the stream). */
 void uhdr_hip_profile_enable(uhdr_hip_ctx_t* ctx, int enable);
 int uhdr_hip_profile_read(uhdr_hip_ctx_t* ctx, const char* family, double* total_ms, int reset);
+/* the same, launch by launch: the first min(n, capacity) durations go to ms[] in launch order; returns n */
+int uhdr_hip_profile_read_list(uhdr_hip_ctx_t* ctx, const char* family, double* ms, int capacity, int reset);
 
 #ifdef __cplusplus
 }

@@ -203,6 +203,7 @@ _SIGS = {
     "uhdr_hip_jpeg_assemble": (C.c_size_t, [_P(JpegScan), _P(C.c_uint16), _P(C.c_uint16), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "uhdr_hip_profile_enable": (None, [C.c_void_p, C.c_int]),
     "uhdr_hip_profile_read": (C.c_int, [C.c_void_p, C.c_char_p, _P(C.c_double), C.c_int]),
+    "uhdr_hip_profile_read_list": (C.c_int, [C.c_void_p, C.c_char_p, _P(C.c_double), C.c_int, C.c_int]),
 }
 ABI_SYMBOLS = tuple(_SIGS)
 

@@ -455,10 +455,9 @@ __global__ __launch_bounds__(quad_block<OUT>(), (quad_block<OUT>() == 1024 && SR
   const uint32_t qy0 = wf / strips_x, sx = wf - qy0 * strips_x;
   const uint8_t *yp, *up, *vp, *mp;
   uint8_t* dp;
-  if (p.n_frames > 1) {
-    typedef const FramePtrs __attribute__((address_space(4))) * ConstFrames;  // constant memory -> s_load
-    ConstFrames fp = (ConstFrames)(uintptr_t)p.frames + frame;
-    yp = fp->y; up = fp->u; vp = fp->v; mp = fp->map; dp = fp->dst;
+  if (p.n_frames > 1) {  // the frame's five plane pointers: scalar loads from the kernel-argument segment
+    const FramePtrs& fp = p.frame_tab[frame];
+    yp = fp.y; up = fp.u; vp = fp.v; mp = fp.map; dp = fp.dst;
   } else {
     yp = (const uint8_t*)p.sdr.p[0]; up = (const uint8_t*)p.sdr.p[1]; vp = (const uint8_t*)p.sdr.p[2];
     mp = (const uint8_t*)p.gm.p[0]; dp = (uint8_t*)p.dst.p[0];

@@ -90,9 +90,6 @@ struct uhdr_hip_ctx {
   // scratch for host-buffer entry points and two-pass generation
   DeviceBuf scratch[8];
   DeviceBuf minmax;  // 6 + 2048*6 floats
-  FramePtrs* d_frames = nullptr;  // batch frame-pointer tables (rotating slots)
-  size_t frames_cap = 0;
-  unsigned int frames_next = 0;
   uint32_t* d_huff = nullptr;     // Annex K code tables (kHuffTabWords) followed by the 64-byte zig-zag map
   CoefSrc* d_coef_src = nullptr;  // apply_gainmap_coef descriptors (rotating slots)
   unsigned int coef_src_next = 0;
@@ -438,7 +435,6 @@ void uhdr_hip_destroy(uhdr_hip_ctx_t* c) {
   }
   for (auto& b : c->scratch) if (b.p) (void)hipFree(b.p);
   if (c->minmax.p) (void)hipFree(c->minmax.p);
-  if (c->d_frames) (void)hipFree(c->d_frames);
   if (c->d_coef_src) (void)hipFree(c->d_coef_src);
   if (c->d_huff) (void)hipFree(c->d_huff);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -481,6 +477,27 @@ int uhdr_hip_profile_read(uhdr_hip_ctx_t* c, const char* family, double* total_m
   }
   if (reset) c->prof_entries.swap(keep);
   if (total_ms) *total_ms = tot;
+  return n;
+}
+
+int uhdr_hip_profile_read_list(uhdr_hip_ctx_t* c, const char* family, double* ms_out, int capacity, int reset) {
+  if (!c) return 0;
+  (void)hipStreamSynchronize(c->stream);
+  int n = 0;
+  std::vector<ProfEntry> keep;
+  for (auto& e : c->prof_entries) {
+    const bool match = !family || e.family == family;
+    if (match) {
+      float ms = 0.0f;
+      if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+        if (ms_out && n < capacity) ms_out[n] = ms;
+        n++;
+      }
+    }
+    if (match && reset) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    else keep.push_back(e);
+  }
+  if (reset) c->prof_entries.swap(keep);
   return n;
 }
 
@@ -617,17 +634,8 @@ uhdr_error_info_t uhdr_hip_apply_gainmap_batch_dev(uhdr_hip_ctx_t* c, unsigned i
       UHDR_TRY(uhdr_hip_apply_gainmap_dev(c, &sdr[i], &gm[i], md, out_ct, out_fmt, max_display_boost, &dest[i], 0, 0));
     return ok_status();
   }
-  // frame pointer table: rotating device slots so an in-flight launch keeps its table
-  constexpr unsigned int kSlots = 8;
-  const size_t bytes = (size_t)n * sizeof(FramePtrs);
-  if (c->frames_cap < bytes) {
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->d_frames) (void)hipFree(c->d_frames);
-    c->d_frames = nullptr;
-    c->frames_cap = 0;
-    HIP_TRY(hipMalloc((void**)&c->d_frames, bytes * kSlots));
-    c->frames_cap = bytes;
-  }
+  // The frame pointers travel in the kernel arguments (ApplyParams::frame_tab, <= kMaxBatchFrames per launch): no
+  // table upload, nothing for an in-flight launch to lose, and the call records into a HIP graph as kernel nodes only.
   std::vector<FramePtrs> tab(n);
   for (unsigned int i = 0; i < n; i++) {
     tab[i].y = (const uint8_t*)sdr[i].planes[0];
@@ -637,17 +645,15 @@ uhdr_error_info_t uhdr_hip_apply_gainmap_batch_dev(uhdr_hip_ctx_t* c, unsigned i
     tab[i].dst = (uint8_t*)dest[i].planes[0];
     dest[i].cg = dest[0].cg;
   }
-  FramePtrs* slot = (FramePtrs*)((char*)c->d_frames + (size_t)(c->frames_next++ % kSlots) * c->frames_cap);
-  HIP_TRY(hipMemcpyAsync(slot, tab.data(), bytes, hipMemcpyHostToDevice, c->stream));  // pageable source: staged before return
   // Launch in chunks of at most 16 frames: the waves of one launch are spread over all of its frames, and beyond
   // ~16 separate frame allocations the concurrent access streams lose DRAM locality (measured: 16 frames 5.7 TB/s,
   // 32 frames 5.3 TB/s in one launch); back-to-back launches cost ~3 us each.
-  constexpr unsigned int kBatchChunk = 16;
+  constexpr unsigned int kBatchChunk = kMaxBatchFrames;
   for (unsigned int f0 = 0; f0 < n; f0 += kBatchChunk) {
     const unsigned int nf = (n - f0 < kBatchChunk) ? (n - f0) : kBatchChunk;
     ApplyParams q = p;
     q.n_frames = nf;
-    q.frames = slot + f0;
+    for (unsigned int i = 0; i < nf; i++) q.frame_tab[i] = tab[f0 + i];
     if (nf == 1) {  // a single frame goes through the kernel's direct-pointer path
       q.sdr.p[0] = tab[f0].y; q.sdr.p[1] = tab[f0].u; q.sdr.p[2] = tab[f0].v;
       q.gm.p[0] = tab[f0].map;

@@ -55,7 +55,8 @@ struct ApplyTables {  // layout of the device table block, in floats
   static int floats(int scale) { return kIdwOff + 4 * scale * scale * 4; }
 };
 
-// batch mode: per-frame plane pointers (device array); geometry / strides / metadata are shared
+// batch mode: per-frame plane pointers; geometry / strides / metadata are shared
+constexpr int kMaxBatchFrames = 16;  // frames per launch (uhdr_hip_api.cpp: beyond ~16 separate allocations DRAM locality drops)
 struct FramePtrs {
   const uint8_t *y, *u, *v, *map;
   uint8_t* dst;
@@ -80,8 +81,7 @@ struct ApplyParams {
   uint32_t y0;              // global row of stripe row 0
   uint32_t tiles_per_wave;  // quad kernel: loop trip count (even), set by the launcher
   uint32_t row_groups;      // quad kernel: quad-row step of a wave, set by the launcher
-  uint32_t n_frames;        // 0/1: single image; > 1: batch through `frames` (quad kernel only)
-  const FramePtrs* frames;
+  uint32_t n_frames;        // 0/1: single image; > 1: batch through `frame_tab` (quad kernel only)
   uint32_t scale;           // integer map scale factor (table path) or 0
   uint32_t scale_magic;     // ceil(2^32 / scale): x / scale == umulhi(x, magic) for x < 65536
   float scale_f;            // (float)w_sdr / w_map, for the non-integer path
@@ -96,6 +96,7 @@ struct ApplyParams {
   Mat3 gamut;               // hdr_cg <- sdr_cg
   Yuv2Rgb yuv;              // always the BT.601 set (jpegr.cpp:1723)
   const CoefSrc* coef_src;  // quad kernel, SRC 1 only: the base image in coefficient form (p.sdr then carries geometry only)
+  FramePtrs frame_tab[kMaxBatchFrames];  // batch: plane pointers of the launch's frames, read with scalar loads from the kernel arguments
 };
 
 // ---- generateGainMap -----------------------------------------------------------------------------

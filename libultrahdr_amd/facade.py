@@ -1,0 +1,109 @@
+"""ctypes binding of the drop-in libuhdr.so (facade/): the reference's own 43-function C API
+(ultrahdr_api.h:296-905) with uhdr_enable_gpu_acceleration() routed to libuhdr_hip.so.  Only what the API-level
+measurements and tests need is wrapped: encode (API-0 / API-1), decode, the acceleration switch."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import capi as A
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PATH = os.path.join(_HERE, "lib", "libuhdr.so")
+
+
+class CompressedImage(C.Structure):  # uhdr_compressed_image_t, ultrahdr_api.h:248-256
+    _fields_ = [("data", C.c_void_p), ("data_sz", C.c_size_t), ("capacity", C.c_size_t),
+                ("cg", C.c_int), ("ct", C.c_int), ("range", C.c_int)]
+
+
+_lib = None
+
+
+def available():
+    return os.path.isfile(PATH)
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (libamdhip64 first, see capi.load)
+
+    A.load()  # libuhdr_hip.so, RTLD_GLOBAL order
+    jpeg = os.path.join(_HERE, "lib", "libjpeg.so.9")
+    if os.path.exists(jpeg):
+        C.CDLL(jpeg, mode=C.RTLD_GLOBAL)
+    lib = C.CDLL(PATH)
+    E, P = A.ErrorInfo, C.c_void_p
+    lib.uhdr_create_encoder.restype = P
+    lib.uhdr_create_decoder.restype = P
+    lib.uhdr_release_encoder.argtypes = [P]
+    lib.uhdr_release_decoder.argtypes = [P]
+    for name, args in (("uhdr_enc_set_raw_image", [P, C.POINTER(A.RawImage), C.c_int]),
+                       ("uhdr_enc_set_quality", [P, C.c_int, C.c_int]),
+                       ("uhdr_enc_set_preset", [P, C.c_int]),
+                       ("uhdr_enc_set_using_multi_channel_gainmap", [P, C.c_int]),
+                       ("uhdr_enc_set_gainmap_scale_factor", [P, C.c_int]),
+                       ("uhdr_enable_gpu_acceleration", [P, C.c_int]),
+                       ("uhdr_encode", [P]),
+                       ("uhdr_dec_set_image", [P, C.POINTER(CompressedImage)]),
+                       ("uhdr_dec_set_out_color_transfer", [P, C.c_int]),
+                       ("uhdr_dec_set_out_img_format", [P, C.c_int]),
+                       ("uhdr_decode", [P])):
+        f = getattr(lib, name)
+        f.restype, f.argtypes = E, args
+    lib.uhdr_get_encoded_stream.restype = C.POINTER(CompressedImage)
+    lib.uhdr_get_encoded_stream.argtypes = [P]
+    lib.uhdr_get_decoded_image.restype = C.POINTER(A.RawImage)
+    lib.uhdr_get_decoded_image.argtypes = [P]
+    _lib = lib
+    return lib
+
+
+UHDR_HDR_IMG, UHDR_SDR_IMG, UHDR_BASE_IMG, UHDR_GAIN_MAP_IMG = 0, 1, 2, 3  # uhdr_img_label_t
+
+
+def _chk(st):
+    if st.error_code != 0:
+        raise A.UhdrError(st.error_code, st.detail.decode("utf-8", "replace") if st.has_detail else "")
+
+
+def encode(hdr, sdr=None, gpu=False, quality=95, preset=A.UHDR_USAGE_BEST_QUALITY) -> bytes:
+    """uhdr_encode: API-1 (hdr + sdr raw intents) or API-0 (hdr only); host images (libultrahdr_amd.images.Image)."""
+    lib = load()
+    h = lib.uhdr_create_encoder()
+    try:
+        _chk(lib.uhdr_enc_set_raw_image(h, C.byref(hdr.raw), UHDR_HDR_IMG))
+        if sdr is not None:
+            _chk(lib.uhdr_enc_set_raw_image(h, C.byref(sdr.raw), UHDR_SDR_IMG))
+        _chk(lib.uhdr_enc_set_quality(h, quality, UHDR_BASE_IMG))
+        _chk(lib.uhdr_enc_set_preset(h, preset))
+        if gpu:
+            _chk(lib.uhdr_enable_gpu_acceleration(h, 1))
+        _chk(lib.uhdr_encode(h))
+        o = lib.uhdr_get_encoded_stream(h).contents
+        return C.string_at(o.data, o.data_sz)
+    finally:
+        lib.uhdr_release_encoder(h)
+
+
+def decode(jpeg: bytes, out_ct, out_fmt, gpu=False) -> np.ndarray:
+    """uhdr_decode -> packed pixels as a (h, w, bytes-per-pixel) uint8 array."""
+    lib = load()
+    h = lib.uhdr_create_decoder()
+    try:
+        buf = (C.c_uint8 * len(jpeg)).from_buffer_copy(jpeg)
+        ci = CompressedImage(C.cast(buf, C.c_void_p), len(jpeg), len(jpeg), 0, 0, 0)
+        _chk(lib.uhdr_dec_set_image(h, C.byref(ci)))
+        _chk(lib.uhdr_dec_set_out_color_transfer(h, out_ct))
+        _chk(lib.uhdr_dec_set_out_img_format(h, out_fmt))
+        if gpu:
+            _chk(lib.uhdr_enable_gpu_acceleration(h, 1))
+        _chk(lib.uhdr_decode(h))
+        o = lib.uhdr_get_decoded_image(h).contents
+        bpp = 8 if o.fmt == A.UHDR_IMG_FMT_64bppRGBAHalfFloat else 4
+        a = np.ctypeslib.as_array(C.cast(o.planes[0], C.POINTER(C.c_uint8)), shape=(o.h, o.stride[0] * bpp))
+        return a[:, : o.w * bpp].reshape(o.h, o.w, bpp).copy()
+    finally:
+        lib.uhdr_release_decoder(h)

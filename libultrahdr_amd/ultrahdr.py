@@ -76,6 +76,12 @@ class Context:
         n = self.lib.uhdr_hip_profile_read(self.handle, family.encode() if family else None, C.byref(ms), 1 if reset else 0)
         return n, ms.value
 
+    def profile_read_list(self, family: str | None, reset=True, capacity=65536):
+        """Durations (ms) of the recorded launches of a family, in launch order."""
+        buf = (C.c_double * capacity)()
+        n = self.lib.uhdr_hip_profile_read_list(self.handle, family.encode() if family else None, buf, capacity, 1 if reset else 0)
+        return list(buf[: min(n, capacity)])
+
     def close(self):
         if getattr(self, "handle", None):
             self.lib.uhdr_hip_destroy(self.handle)

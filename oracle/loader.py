@@ -149,6 +149,10 @@ def ref():
     lib.ref_jpeg_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_int, _P(A.RawImage), C.c_void_p, C.c_size_t]
     lib.ref_info.restype = C.c_char_p
     lib.ref_info.argtypes = []
+    lib.ref_uhdr_encode.restype = C.c_long
+    lib.ref_uhdr_encode.argtypes = [_P(A.RawImage), _P(A.RawImage), C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    lib.ref_uhdr_decode.restype = C.c_int
+    lib.ref_uhdr_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t, _P(C.c_int), _P(C.c_int)]
     _common_scalar_sigs(lib, "ref_")
     _ref = lib
     return lib
@@ -351,3 +355,51 @@ def quant_table_port(quality: int, chroma: bool) -> np.ndarray:
     q = (C.c_uint16 * 64)()
     port().uo_jpeg_quant_table(quality, int(chroma), q)
     return np.frombuffer(q, dtype=np.uint16).copy()
+
+
+# ---- the reference's whole public API (CPU baseline of uhdr_encode / uhdr_decode) and its JPEG helpers ---------------
+def ref_uhdr_encode(hdr: Image, sdr, quality=95, preset=A.UHDR_USAGE_BEST_QUALITY) -> bytes:
+    """uhdr_encode (ultrahdr_api.cpp:1200) through the real reference: API-1 (hdr + sdr) or API-0 (sdr None)."""
+    lib = ref()
+    cap = max(hdr.raw.w * hdr.raw.h * 6, 1 << 16)
+    buf = (C.c_uint8 * cap)()
+    n = lib.ref_uhdr_encode(C.byref(hdr.raw), C.byref(sdr.raw) if sdr is not None else None, quality, preset, buf, cap)
+    if n <= 0:
+        raise RuntimeError(f"ref_uhdr_encode failed: {n}")
+    return bytes(buf[:n])
+
+
+def ref_uhdr_decode(jpeg: bytes, out_ct, out_fmt, dest: np.ndarray = None):
+    """uhdr_decode (ultrahdr_api.cpp:1918) through the real reference -> (w, h) [+ packed pixels into dest]."""
+    lib = ref()
+    w, h = C.c_int(0), C.c_int(0)
+    src = (C.c_uint8 * len(jpeg)).from_buffer_copy(jpeg)
+    rc = lib.ref_uhdr_decode(src, len(jpeg), out_ct, out_fmt, dest.ctypes.data if dest is not None else None,
+                             dest.nbytes if dest is not None else 0, C.byref(w), C.byref(h))
+    if rc != 0:
+        raise RuntimeError(f"ref_uhdr_decode failed: {rc}")
+    return w.value, h.value
+
+
+def ref_jpeg_compress(img: Image, quality: int) -> bytes:
+    """JpegEncoderHelper::compressImage (jpegencoderhelper.cpp:101) through the real reference."""
+    lib = ref()
+    cap = max(img.raw.w * img.raw.h * 4, 1 << 16)
+    buf = (C.c_uint8 * cap)()
+    n = lib.ref_jpeg_compress(C.byref(img.raw), quality, buf, cap)
+    if n <= 0:
+        raise RuntimeError(f"ref_jpeg_compress failed: {n}")
+    return bytes(buf[:n])
+
+
+def ref_jpeg_decompress(jpeg: bytes, mode: int):
+    """JpegDecoderHelper::decompressImage (jpegdecoderhelper.cpp:169): mode 0 planar YCbCr, 1 the stream's own space."""
+    lib = ref()
+    src = (C.c_uint8 * len(jpeg)).from_buffer_copy(jpeg)
+    cap = 1 << 28
+    buf = np.empty(cap, dtype=np.uint8)
+    desc = A.RawImage()
+    rc = lib.ref_jpeg_decompress(src, len(jpeg), mode, C.byref(desc), buf.ctypes.data, cap)
+    if rc != 0:
+        raise RuntimeError(f"ref_jpeg_decompress failed: {rc}")
+    return desc, buf

@@ -15,6 +15,7 @@
 //   convert_raw_input_to_ycbcr   lib/src/gainmapmath.cpp:1291
 //   scalar math                  lib/src/gainmapmath.cpp / lib/include/ultrahdr/gainmapmath.h
 //   JpegEncoderHelper            lib/src/jpegencoderhelper.cpp:101 (-> external libjpeg)
+//   uhdr_encode / uhdr_decode    lib/src/ultrahdr_api.cpp:1200, 1918 (whole-API CPU baseline)
 #include <csetjmp>
 #include <cstdio>
 #include <cstring>
@@ -25,6 +26,7 @@
 #include "ultrahdr/jpegdecoderhelper.h"
 #include "ultrahdr/jpegr.h"
 #include "ultrahdr/ultrahdrcommon.h"
+#include "ultrahdr_api.h"
 
 using namespace ultrahdr;
 
@@ -334,6 +336,59 @@ REF_API int ref_jpeg_decompress(const uint8_t* data, size_t size, int mode, uhdr
     off += sz;
   }
   return 0;
+}
+
+// ---- the whole public API (ultrahdr_api.cpp:1200 uhdr_encode, :1918 uhdr_decode): CPU baseline of the end-to-end calls ----
+// API-1 (raw HDR + raw SDR) or API-0 (sdr == nullptr) encode with the C API's own defaults except what is passed.
+// Returns the stream size (> 0), or -(error code).
+REF_API long ref_uhdr_encode(uhdr_raw_image_t* hdr, uhdr_raw_image_t* sdr, int quality, int preset, uint8_t* out, size_t cap) {
+  uhdr_codec_private_t* enc = uhdr_create_encoder();
+  if (!enc) return -1000;
+  uhdr_error_info_t st = uhdr_enc_set_raw_image(enc, hdr, UHDR_HDR_IMG);
+  if (st.error_code == UHDR_CODEC_OK && sdr) st = uhdr_enc_set_raw_image(enc, sdr, UHDR_SDR_IMG);
+  if (st.error_code == UHDR_CODEC_OK) st = uhdr_enc_set_quality(enc, quality, UHDR_BASE_IMG);
+  if (st.error_code == UHDR_CODEC_OK) st = uhdr_enc_set_preset(enc, (uhdr_enc_preset_t)preset);
+  if (st.error_code == UHDR_CODEC_OK) st = uhdr_encode(enc);
+  long n = -(long)st.error_code;
+  if (st.error_code == UHDR_CODEC_OK) {
+    uhdr_compressed_image_t* o = uhdr_get_encoded_stream(enc);
+    if (o && o->data_sz <= cap) {
+      memcpy(out, o->data, o->data_sz);
+      n = (long)o->data_sz;
+    } else {
+      n = -100;
+    }
+  }
+  uhdr_release_encoder(enc);
+  return n;
+}
+// dest: caller-allocated packed buffer of w * h * (8 for RGBA_F16, 4 otherwise) bytes.  Returns 0 or -(error code).
+REF_API int ref_uhdr_decode(const uint8_t* data, size_t size, int out_ct, int out_fmt, uint8_t* dest, size_t cap, int* w, int* h) {
+  uhdr_codec_private_t* dec = uhdr_create_decoder();
+  if (!dec) return -1000;
+  uhdr_compressed_image_t in;
+  memset(&in, 0, sizeof in);
+  in.data = const_cast<uint8_t*>(data);
+  in.data_sz = in.capacity = size;
+  uhdr_error_info_t st = uhdr_dec_set_image(dec, &in);
+  if (st.error_code == UHDR_CODEC_OK) st = uhdr_dec_set_out_color_transfer(dec, (uhdr_color_transfer_t)out_ct);
+  if (st.error_code == UHDR_CODEC_OK) st = uhdr_dec_set_out_img_format(dec, (uhdr_img_fmt_t)out_fmt);
+  if (st.error_code == UHDR_CODEC_OK) st = uhdr_decode(dec);
+  int rc = -(int)st.error_code;
+  if (st.error_code == UHDR_CODEC_OK) {
+    uhdr_raw_image_t* o = uhdr_get_decoded_image(dec);
+    const size_t bpp = o->fmt == UHDR_IMG_FMT_64bppRGBAHalfFloat ? 8 : 4;
+    *w = (int)o->w;
+    *h = (int)o->h;
+    if (dest && (size_t)o->w * o->h * bpp <= cap) {
+      for (unsigned y = 0; y < o->h; y++)
+        memcpy(dest + (size_t)y * o->w * bpp, (const uint8_t*)o->planes[0] + (size_t)y * o->stride[0] * bpp, (size_t)o->w * bpp);
+    } else if (dest) {
+      rc = -100;
+    }
+  }
+  uhdr_release_decoder(dec);
+  return rc;
 }
 
 REF_API const char* ref_info() {

@@ -20,12 +20,15 @@ dev = "cuda:0"
 md = synth.default_metadata(use_base_cg=0)
 f16, u32 = A.UHDR_IMG_FMT_64bppRGBAHalfFloat, A.UHDR_IMG_FMT_32bppRGBA1010102
 REPS = int(os.environ.get("QB_REPS", "3"))
+ITERS = int(os.environ.get("QB_ITERS", "0"))  # > 0: override every case's iteration count (profiling runs)
+_tk = B.time_kernel
+B.time_kernel = lambda ctx_, fn, iters=10, warm=3: _tk(ctx_, fn, iters=ITERS or iters, warm=1 if ITERS else warm)
 
 
 def report(name, ms_list, bytes_, px):
     ms = sorted(ms_list)
     med = ms[len(ms) // 2]
-    print(f"{name:28s} min {ms[0]*1e3:8.1f} med {med*1e3:8.1f} max {ms[-1]*1e3:8.1f} us   {bytes_/med/1e6:8.1f} GB/s ({bytes_/med/1e6/80:5.1f}% of 8 TB/s)  {px/med/1e3:9.0f} Mpx/s", flush=True)
+    print(f"{name:28s} min {ms[0]*1e6:8.1f} med {med*1e6:8.1f} max {ms[-1]*1e6:8.1f} us   {bytes_/med/1e9:8.1f} GB/s ({bytes_/med/1e9/80:5.1f}% of 8 TB/s)  {px/med/1e6:9.0f} Mpx/s", flush=True)
 
 
 def apply_case(name, w, h, mk, ct, nsets=3):
@@ -86,6 +89,37 @@ def main():
                  else UltraHdr(ctx=ctx, mapDimensionScaleFactor=4, useMultiChannelGainMap=False, preset=A.UHDR_USAGE_REALTIME))
             r = [B.time_kernel(ctx, lambda: e.generateGainMap(sdr, hdr), iters=10, warm=2) / 1e3 for _ in range(REPS)]
             report(c, r, (31.5 if c == "gen4k" else 4.5 + 1 / 16) * w4 * h4, w4 * h4)
+        elif c in ("fdct4k", "idct4k", "huff4k", "cvt4k"):
+            sdr, hdr = enc()
+            qt = u.quant_table(95, False)
+            qts = [qt, u.quant_table(95, True), u.quant_table(95, True)]
+            if c == "cvt4k":
+                cv = sdr.clone()
+                r = [B.time_kernel(ctx, lambda: u.convertYuv(cv, A.UHDR_CG_BT_709, A.UHDR_CG_DISPLAY_P3), iters=10, warm=2) / 1e3 for _ in range(REPS)]
+                report(c, r, 3.0 * w4 * h4, w4 * h4)
+            elif c in ("fdct4k", "idct4k"):
+                plane = sdr.plane_tensor(0)
+                coef = torch.empty((h4 // 8, w4 // 8, 64), dtype=torch.int16, device=dev)
+                dec_plane = torch.empty((h4, w4), dtype=torch.uint8, device=dev)
+                u.fdct_quant(plane, sdr.layout[0][1], w4 // 8, h4 // 8, qt, coef)
+                fn = ((lambda: u.fdct_quant(plane, sdr.layout[0][1], w4 // 8, h4 // 8, qt, coef)) if c == "fdct4k"
+                      else (lambda: u.idct_dequant(coef, qt, plane=dec_plane, stride=w4)))
+                r = [B.time_kernel(ctx, fn, iters=10, warm=2) / 1e3 for _ in range(REPS)]
+                report(c, r, 3.0 * w4 * h4, w4 * h4)
+            else:
+                hco = []
+                for k in range(3):
+                    rows, stride, wv = sdr.layout[k]
+                    hco.append(u.fdct_quant(sdr.plane_tensor(k), stride, wv // 8, rows // 8, qts[k]))
+                hout = torch.empty(w4 * h4 * 2, dtype=torch.uint8, device=dev)
+                samp = [(2, 2), (1, 1), (1, 1)]
+                r = [B.time_kernel(ctx, lambda: u.huffman_encode(hco, w4, h4, samp, 10, out=hout), iters=5, warm=2) / 1e3 for _ in range(REPS)]
+                report("huff4k_encode_ri10", r, 4.5 * w4 * h4, w4 * h4)
+                for ri in (2, 10):
+                    stream = u.huffman_encode(hco, w4, h4, samp, ri, out=hout).clone()
+                    shp = [tuple(t.shape[:2]) for t in hco]
+                    r = [B.time_kernel(ctx, lambda: u.huffman_decode(stream, shp, w4, h4, samp, ri), iters=3, warm=1) / 1e3 for _ in range(REPS)]
+                    report(f"huff4k_decode_ri{ri}", r, 4.5 * w4 * h4, w4 * h4)
         elif c in ("api0", "api0f", "tm8k"):
             w8, h8 = 7680, 4320
             hdr8 = synth.make_hdr_rgba1010102(w8, h8, ct=A.UHDR_CT_PQ).to(dev)
