@@ -45,6 +45,7 @@ def parse():
                     help="batch: one kernel launch per step for the whole frame batch (uhdr_hip_apply_gainmap_batch_dev); "
                          "single: one launch per frame")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--no-config4", action="store_true", help="skip the row-striped two-pass encode leg (the RCCL collective)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -223,6 +224,16 @@ def main():
         },
     }
 
+    # BASELINE configs[3]: the row-striped API-1 two-pass encode, the one place where the path has a collective.  Every
+    # rank runs it (also at N = 1: a one-rank communicator), after the headline's timed region.
+    if not args.no_config4:
+        try:
+            c4 = config4_section(ctx, u, device, rank, world, backend)
+        except Exception as e:  # noqa: BLE001
+            c4 = {"error": f"{type(e).__name__}: {e}"}
+        if rank == 0:
+            out["config4"] = c4
+
     # the stage measurements and the CPU baseline run AFTER the timed region; a failure there (e.g. an
     # out-of-memory on a smaller device) must not cost the headline line
     if rank == 0 and world == 1 and not args.no_extra:
@@ -238,8 +249,18 @@ def main():
         except Exception as e:  # noqa: BLE001
             out["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port", "sample": f"failed: {type(e).__name__}: {e}"}
     if rank == 0:
+        # RCCL reports its version through C stdio; drain that first so that the JSON line is the LAST line on stdout
+        try:
+            C.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
+        sys.stdout.flush()
         print(json.dumps(out), flush=True)
     ctx.close()
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
     if world > 1:
         dist.destroy_process_group()
 
@@ -379,6 +400,63 @@ def encode_section(ctx, u, device):
                     "pass 2 12 in + 3 out) + convertYuv + 3 x fdct_quant (base) + fused (rgb->ycc + 3 x fdct_quant) of the map",
         "us": r["chain_us"], "Mpx/s": round(px / r["chain_us"], 1), "roofline": r}
     return res
+
+
+def config4_section(ctx, u, device, rank, world, backend):
+    """BASELINE configs[3]: API-1 two-pass encode of a 16384-wide P010 + YCbCr 4:2:0 image sharded by row stripe, 2048
+    rows per rank (at 8 ranks: 16K x 16K).  Per image and rank: pass 1 on the stripe -> ONE ncclAllReduce(min) of
+    {min0..2, -max0..2} over xGMI, issued by the C++ host layer on its own stream -> range finalised on the device ->
+    pass 2.  Weak scaling: the image grows with the rank count.  value = pixels of all ranks / max-over-ranks time."""
+    import torch
+    import torch.distributed as dist
+
+    from libultrahdr_amd import capi as A
+    from libultrahdr_amd import stripes, synth
+    from libultrahdr_amd.images import Image
+    from libultrahdr_amd.ultrahdr import UltraHdr
+
+    ws, hs, iters = 16384, 2048, 10
+    if world > 1 and backend != "nccl":
+        return {"skipped": "the stripe exchange runs on RCCL: one GPU per rank is required (UHDR_BENCH_DIST_BACKEND=gloo shares devices)"}
+    nranks = stripes.init_comm(ctx)  # RCCL communicator owned by the library context (ncclCommCount)
+    enc = UltraHdr(ctx=ctx, mapDimensionScaleFactor=1, useMultiChannelGainMap=True, preset=A.UHDR_USAGE_BEST_QUALITY)
+    cfg = enc.encode_cfg()
+    sdr_s = synth.make_sdr_yuv420(ws, hs, noise=0.0, seed=1234 + rank).to(device)
+    hdr_s = synth.make_hdr_p010(ws, hs, ct=A.UHDR_CT_HLG, noise=0.0, seed=1234 + rank).to(device)
+    gm_s = Image(A.UHDR_IMG_FMT_24bppRGB888, ws, hs, align=64, device=device)
+
+    def sync_all():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    md = None
+    for _ in range(2):
+        md = stripes.generate_gainmap_striped(enc, sdr_s, hdr_s, cfg, gm_s)
+    sync_all()
+    ctx.profile(True)
+    ctx.profile_read(None, reset=True)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        md = stripes.generate_gainmap_striped(enc, sdr_s, hdr_s, cfg, gm_s)
+    sync_all()
+    el = time.perf_counter() - t0
+    n_x, ms_x = ctx.profile_read("stripe_exchange", reset=True)
+    n_k, ms_k = ctx.profile_read("generate_gainmap", reset=True)
+    ctx.profile(False)
+    if world > 1:
+        tt = torch.tensor([el], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    px = ws * hs * world
+    return {"workload": f"configs[3]: API-1 two-pass 3-channel generateGainMap of a {ws}x{hs * world} P010 + YCbCr 4:2:0 image, "
+                        f"{hs} rows per rank, {world} rank(s)",
+            "collective": "one ncclAllReduce(ncclMin, 6 x float32 {min0..2, -max0..2}) per image, issued by libuhdr_hip.so on its own stream "
+                          "between pass 1 and pass 2; range finalised on the device; one host synchronisation per image (metadata)",
+            "ncclCommCount": nranks, "images": iters, "ms_per_image": round(el / iters * 1e3, 3), "Mpx/s": round(px * iters / el / 1e6, 1),
+            "rank0_kernel_us_per_image": round(ms_k / iters * 1e3, 1), "rank0_exchange_us_per_image": round(ms_x / iters * 1e3, 1),
+            "max_content_boost": [round(float(v), 6) for v in md.max_content_boost]}
 
 
 def config5_section(ctx, u, device):
@@ -615,21 +693,6 @@ def extras(ctx, u, device):
     qy, qc = u.quant_table(95, False), u.quant_table(95, True)
     # (the API-1 4K and API-0 8K encode chains live in encode_section: they carry their own roofline objects)
     base = sdr.clone()
-    # (2b) BASELINE config 4, the per-GPU share: one 16384 x 2048 row stripe of a 16K x 16K API-1 encode
-    #      (pass 1 -> [all-reduce of 6 floats, not timed here] -> pass 2), 3-channel full-resolution map
-    from libultrahdr_amd import stripes
-
-    ws, hs = 16384, 2048
-    sdr_s = synth.make_sdr_yuv420(ws, hs, noise=0.0).to(device)
-    hdr_s = synth.make_hdr_p010(ws, hs, ct=A.UHDR_CT_HLG, noise=0.0).to(device)
-    gm_s = Image(A.UHDR_IMG_FMT_24bppRGB888, ws, hs, align=64, device=device)
-    cfg4 = A.default_encode_cfg()
-    ms = time_kernel(ctx, lambda: stripes.generate_gainmap_two_pass_striped(enc, sdr_s, hdr_s, cfg4, gm_s), iters=3, warm=1)
-    res["encode_api1_16k_stripe_16384x2048_2pass_3ch"] = {"us": round(ms * 1e3, 1), "Mpx/s": round(ws * hs / (ms / 1e3) / 1e6, 1),
-                                                          "GB/s_31.5B_per_px": round(31.5 * ws * hs / (ms / 1e3) / 1e9, 1),
-                                                          "stages": "generate pass 1 + min/max reduce + pass 2 on one rank's stripe (kernel time; the 24-byte all-reduce is latency only)"}
-    del sdr_s, hdr_s, gm_s
-    torch.cuda.empty_cache()
     # (3) decode chain, 4K: coefficient blocks -> IDCT (Y, Cb, Cr, Y400 map s=4) -> applyGainMap -> F16
     dsdr = Image(A.UHDR_IMG_FMT_12bppYCbCr420, w, h, A.UHDR_CG_BT_709, A.UHDR_CT_SRGB, A.UHDR_CR_FULL_RANGE, align=64, device=device)
     mw, mh = w // 4, (h // 4 + 7) // 8 * 8  # 960 x 544: the block grid of the 960 x 540 map

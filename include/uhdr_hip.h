@@ -225,6 +225,27 @@ uhdr_error_info_t uhdr_hip_generate_gainmap_pass2_dev(uhdr_hip_ctx_t* ctx,
                                                       const float minmax[6],
                                                       const uhdr_hip_encode_cfg_t* cfg,
                                                       uhdr_raw_image_t* gainmap_img);
+/* ---- multi-GPU: one process per GPU, images sharded by row stripe -----------------------------
+ * Every stage of the path is stripe-local except two-pass generateGainMap's per-channel min / max merge
+ * (jpegr.cpp:932-938).  uhdr_hip_generate_gainmap_striped_dev runs the whole two-pass sequence on this rank's stripe:
+ *   pass 1 -> ONE ncclAllReduce(min) over {min0..2, -max0..2} (RCCL over xGMI, on the context's stream) ->
+ *   finalisation of the range on the device (jpegr.cpp:969-986) -> pass 2
+ * as one stream-ordered sequence; the host synchronises once, at the end, to fill the metadata (identical on every rank).
+ * sdr / hdr describe this rank's rows (a multiple of lcm(2, scale) rows, except the last stripe); gainmap_img this rank's
+ * rows of the map (planes[0] / stride[0] from the caller).  A stripe too short for one map row launches nothing and
+ * contributes the merge's identity.  Without a communicator (uhdr_hip_comm_init not called) the same sequence runs
+ * for a single stripe = the whole image.
+ * Communicator set-up is the usual NCCL bootstrap: rank 0 calls uhdr_hip_comm_unique_id, the application sends the
+ * 128 bytes to the other ranks (torch.distributed, MPI, a file ...), every rank calls uhdr_hip_comm_init.  RCCL is
+ * bound at run time (the copy already in the process, else librccl.so.1); the library does not link against it. */
+#define UHDR_HIP_COMM_ID_BYTES 128
+int uhdr_hip_comm_unique_id(unsigned char id[UHDR_HIP_COMM_ID_BYTES]); /* 0, or -1 when RCCL is unavailable */
+uhdr_error_info_t uhdr_hip_comm_init(uhdr_hip_ctx_t* ctx, const unsigned char id[UHDR_HIP_COMM_ID_BYTES], int rank, int nranks);
+void uhdr_hip_comm_destroy(uhdr_hip_ctx_t* ctx);
+int uhdr_hip_comm_size(uhdr_hip_ctx_t* ctx); /* ncclCommCount of the context's communicator, 0 without one */
+uhdr_error_info_t uhdr_hip_generate_gainmap_striped_dev(uhdr_hip_ctx_t* ctx, const uhdr_raw_image_t* sdr_stripe,
+                                                        const uhdr_raw_image_t* hdr_stripe, const uhdr_hip_encode_cfg_t* cfg,
+                                                        uhdr_gainmap_metadata_t* gainmap_metadata, uhdr_raw_image_t* gainmap_stripe);
 uhdr_error_info_t uhdr_hip_tone_map_dev(uhdr_hip_ctx_t* ctx, const uhdr_raw_image_t* hdr_intent,
                                         uhdr_raw_image_t* sdr_intent);
 uhdr_error_info_t uhdr_hip_convert_yuv_dev(uhdr_hip_ctx_t* ctx, uhdr_raw_image_t* image,

@@ -116,7 +116,9 @@ __global__ __launch_bounds__(kBlock) void affine_kernel(const AffineParams p) {
     uint8_t* dst = p.out + (size_t)y * p.out_stride * p.nch;
     auto map1 = [&](float g, uint32_t e) -> uint32_t {
       const uint32_t c = p.nch == 3 ? e % 3 : 0;
-      float m = div_by_rcp64(g - p.mn[c], p.range_rcp[c]);  // (g - min) / (max - min), exact (device_math.h)
+      const float mn_c = p.dev ? p.dev->mn[c] : p.mn[c];
+      const double rr_c = p.dev ? p.dev->range_rcp[c] : p.range_rcp[c];
+      float m = div_by_rcp64(g - mn_c, rr_c);  // (g - min) / (max - min), exact (device_math.h)
       if (p.gamma != 1.0f) m = (float)pow((double)m, (double)p.gamma);
       m *= 255.0f;
       float t2 = m + 0.5f;
@@ -142,8 +144,10 @@ __global__ __launch_bounds__(kBlock) void affine_wide_kernel(const AffineParams 
   constexpr int NS = 16 * NCH;  // samples per thread
   const uint32_t row_elems = p.map_w * NCH, per_row = row_elems / NS;
   const uint32_t total = per_row * p.map_h, tiles = (total + kBlock - 1) / kBlock;  // flat: narrow maps still fill the lanes
-  const float mn[3] = {p.mn[0], p.mn[NCH == 3 ? 1 : 0], p.mn[NCH == 3 ? 2 : 0]};
-  const double rr[3] = {p.range_rcp[0], p.range_rcp[NCH == 3 ? 1 : 0], p.range_rcp[NCH == 3 ? 2 : 0]};
+  const float* pmn = p.dev ? p.dev->mn : p.mn;  // wave-uniform: scalar loads either way
+  const double* prr = p.dev ? p.dev->range_rcp : p.range_rcp;
+  const float mn[3] = {pmn[0], pmn[NCH == 3 ? 1 : 0], pmn[NCH == 3 ? 2 : 0]};
+  const double rr[3] = {prr[0], prr[NCH == 3 ? 1 : 0], prr[NCH == 3 ? 2 : 0]};
   typedef uint32_t u4v __attribute__((ext_vector_type(4)));
   for (uint32_t t = blockIdx.x; t < tiles; t += gridDim.x) {
     const uint32_t idx = t * kBlock + threadIdx.x;
@@ -231,6 +235,43 @@ hipError_t launch_generate_gainmap(const GenParams& p, bool two_pass, hipStream_
     default: launch_gen_h<-1>(p, two_pass, grid, partials, s); break;
   }
   if (two_pass) hipLaunchKernelGGL(reduce_minmax_kernel, dim3(1), dim3(256), 0, s, (const float*)partials, grid, p.minmax);
+  return hipGetLastError();
+}
+
+// ---- striped two-pass generation: the exchange step on the device ------------------------------------------------------
+// {min0..2, max0..2} -> {min0..2, -max0..2}: negating the maxima turns the per-channel min AND max merge of
+// jpegr.cpp:932-938 into ONE elementwise minimum, i.e. a single all-reduce(min) over 6 floats.  `empty`: this rank's
+// stripe holds no map sample; it contributes the identity of the merge (the reference's initial values 127 / -128).
+__global__ void minmax_pack_kernel(const float* mm6, float* merged6, int empty) {
+  const int i = threadIdx.x;
+  if (i < 3) merged6[i] = empty ? 127.0f : mm6[i];
+  else if (i < 6) merged6[i] = empty ? 128.0f : -mm6[i];
+}
+// jpegr.cpp:969-986: clamp to [-14.3, 15.6], the user's min / max content-boost hints, the epsilon guard; then the
+// affine map's per-channel constants exactly as the host computes them (float subtraction, float64 reciprocal).
+__global__ void minmax_finalize_kernel(const FinalizeParams p) {
+  const int i = threadIdx.x;
+  if (i >= 3) return;
+  float gmin = p.merged[i], gmax = -p.merged[3 + i];
+  if (i < p.nch) {
+    gmin = gmin < -14.3f ? -14.3f : (gmin > 15.6f ? 15.6f : gmin);
+    gmax = gmax < -14.3f ? -14.3f : (gmax > 15.6f ? 15.6f : gmax);
+    if (p.has_max_hint) gmax = gmax < p.log2_max_hint ? gmax : p.log2_max_hint;
+    if (p.has_min_hint) gmin = gmin < p.log2_min_hint ? p.log2_min_hint : gmin;
+    if (fabsf(gmax - gmin) < 1.1920928955078125e-07f) gmax += 0.1f;  // FLT_EPSILON
+  }
+  p.out->mn[i] = gmin;
+  p.out->mx[i] = gmax;
+  p.out->range_rcp[i] = 1.0 / (double)(gmax - gmin);
+  p.out_mm[i] = gmin;
+  p.out_mm[3 + i] = gmax;
+}
+hipError_t launch_minmax_pack(const float* mm6, float* merged6, int empty, hipStream_t s) {
+  hipLaunchKernelGGL(minmax_pack_kernel, dim3(1), dim3(64), 0, s, mm6, merged6, empty);
+  return hipGetLastError();
+}
+hipError_t launch_minmax_finalize(const FinalizeParams& p, hipStream_t s) {
+  hipLaunchKernelGGL(minmax_finalize_kernel, dim3(1), dim3(64), 0, s, p);
   return hipGetLastError();
 }
 

@@ -14,6 +14,7 @@
 #include "exact_math.h"
 #include "host_tables.h"
 #include "uhdr_types.h"
+#include "rccl_bind.h"
 
 using namespace uhdr;
 
@@ -93,6 +94,11 @@ struct uhdr_hip_ctx {
   uint32_t* d_huff = nullptr;     // Annex K code tables (kHuffTabWords) followed by the 64-byte zig-zag map
   CoefSrc* d_coef_src = nullptr;  // apply_gainmap_coef descriptors (rotating slots)
   unsigned int coef_src_next = 0;
+  // multi-GPU (row stripes): RCCL communicator of this rank + the exchange buffers of two-pass generation
+  void* comm = nullptr;          // ncclComm_t
+  int comm_rank = 0, comm_size = 0;
+  DeviceBuf exchange;            // merged[6] | AffineDev | final mm[6]
+  float* h_mm = nullptr;         // pinned: the final {min, max} for the metadata fill
   // profiling
   bool prof = false;
   std::vector<ProfEntry> prof_entries;
@@ -437,6 +443,9 @@ void uhdr_hip_destroy(uhdr_hip_ctx_t* c) {
   if (c->minmax.p) (void)hipFree(c->minmax.p);
   if (c->d_coef_src) (void)hipFree(c->d_coef_src);
   if (c->d_huff) (void)hipFree(c->d_huff);
+  uhdr_hip_comm_destroy(c);
+  if (c->exchange.p) (void)hipFree(c->exchange.p);
+  if (c->h_mm) (void)hipHostFree(c->h_mm);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -818,6 +827,8 @@ static void fill_gainmap_desc(const uhdr_raw_image_t* hdr, const GenParams& p, u
   gm->w = p.map_w; gm->h = p.map_h;
 }
 
+static uhdr_error_info_t uhdr_hip_generate_gainmap_finalize_md(const uhdr_hip_encode_cfg_t* cfg, uhdr_color_transfer_t hdr_ct,
+                                                               int use_base_cg, const float mm[6], uhdr_gainmap_metadata_t* md);
 uhdr_error_info_t uhdr_hip_generate_gainmap_finalize(const uhdr_hip_encode_cfg_t* cfg, uhdr_color_transfer_t hdr_ct,
                                                      int use_base_cg, float mm[6], uhdr_gainmap_metadata_t* md) {
   if (!cfg || !mm || !md) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument");
@@ -837,6 +848,15 @@ uhdr_error_info_t uhdr_hip_generate_gainmap_finalize(const uhdr_hip_encode_cfg_t
     }
     if (fabsf(gmax[i] - gmin[i]) < FLT_EPSILON) gmax[i] += 0.1f;
   }
+  return uhdr_hip_generate_gainmap_finalize_md(cfg, hdr_ct, use_base_cg, mm, md);
+}
+
+// the metadata fill of jpegr.cpp:1031-1048 from a FINAL per-channel range
+static uhdr_error_info_t uhdr_hip_generate_gainmap_finalize_md(const uhdr_hip_encode_cfg_t* cfg, uhdr_color_transfer_t hdr_ct,
+                                                               int use_base_cg, const float mm[6], uhdr_gainmap_metadata_t* md) {
+  const int nch = cfg->use_multi_channel_gainmap ? 3 : 1;
+  const float* gmin = mm;
+  const float* gmax = mm + 3;
   for (int i = 0; i < 3; i++) {  // jpegr.cpp:1031-1048
     const int k = nch == 3 ? i : 0;
     md->max_content_boost[i] = exp2f(gmax[k]);
@@ -886,6 +906,7 @@ uhdr_error_info_t uhdr_hip_generate_gainmap_pass2_dev(uhdr_hip_ctx_t* c, const f
   if (gm->stride[0] < gm->w) return err_status(UHDR_CODEC_INVALID_PARAM, "gainmap stride (%u) cannot be less than its width (%u)", gm->stride[0], gm->w);
   HIP_TRY(hipSetDevice(c->device));
   AffineParams a;
+  a.dev = nullptr;
   a.gain_log2 = gain_log2_dev;
   a.out = (uint8_t*)gm->planes[0];
   a.map_w = gm->w; a.map_h = gm->h; a.out_stride = gm->stride[0];
@@ -950,6 +971,130 @@ uhdr_error_info_t uhdr_hip_generate_gainmap_dev(uhdr_hip_ctx_t* c, const uhdr_ra
   HIP_TRY(hipStreamSynchronize(c->stream));
   UHDR_TRY(uhdr_hip_generate_gainmap_finalize(cfg, hdr->ct, use_base_cg, mm, md));
   return uhdr_hip_generate_gainmap_pass2_dev(c, p.gain_log2, mm, cfg, gm);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Row-striped two-pass generation across GPUs (one process per GPU): the one exchange step of the whole hot path
+// (jpegr.cpp:932-938, the per-channel min / max merge) as ONE ncclAllReduce(min) over {min0..2, -max0..2}, issued
+// from here on the context's stream, with the finalisation (jpegr.cpp:969-986) on the device: pass 1 -> all-reduce ->
+// finalize -> pass 2 is one stream-ordered sequence, the host synchronises once at the end for the metadata.
+// RCCL is bound at run time (rccl_bind.cpp): no link-time dependency, single-GPU users never load it.
+// -------------------------------------------------------------------------------------------------
+namespace {
+#define RCCL_TRY(expr)                                                                                             \
+  do {                                                                                                             \
+    ncclResult_t r_ = (expr);                                                                                      \
+    if (r_ != ncclSuccess) return err_status(UHDR_CODEC_ERROR, "RCCL: %s failed: %s", #expr, rccl().GetErrorString(r_)); \
+  } while (0)
+}  // namespace
+
+int uhdr_hip_comm_unique_id(unsigned char id[UHDR_HIP_COMM_ID_BYTES]) {
+  static_assert(sizeof(ncclUniqueId) == UHDR_HIP_COMM_ID_BYTES, "ncclUniqueId size");
+  if (!id || !rccl().ok) return -1;
+  ncclUniqueId u;
+  if (rccl().GetUniqueId(&u) != ncclSuccess) return -1;
+  memcpy(id, &u, sizeof u);
+  return 0;
+}
+
+uhdr_error_info_t uhdr_hip_comm_init(uhdr_hip_ctx_t* c, const unsigned char id[UHDR_HIP_COMM_ID_BYTES], int rank, int nranks) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  if (!id || nranks < 1 || rank < 0 || rank >= nranks) return err_status(UHDR_CODEC_INVALID_PARAM, "bad communicator arguments (rank %d of %d)", rank, nranks);
+  if (!rccl().ok) return err_status(UHDR_CODEC_ERROR, "RCCL is not available in this process (librccl.so.1 could not be loaded)");
+  if (c->comm) return err_status(UHDR_CODEC_INVALID_OPERATION, "this context already has a communicator");
+  HIP_TRY(hipSetDevice(c->device));
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof u);
+  ncclComm_t comm = nullptr;
+  RCCL_TRY(rccl().CommInitRank(&comm, nranks, u, rank));
+  c->comm = comm;
+  c->comm_rank = rank;
+  RCCL_TRY(rccl().CommCount(comm, &c->comm_size));
+  return ok_status();
+}
+
+void uhdr_hip_comm_destroy(uhdr_hip_ctx_t* c) {
+  if (!c || !c->comm) return;
+  (void)hipStreamSynchronize(c->stream);
+  (void)rccl().CommDestroy((ncclComm_t)c->comm);
+  c->comm = nullptr;
+  c->comm_size = 0;
+}
+
+int uhdr_hip_comm_size(uhdr_hip_ctx_t* c) { return c ? c->comm_size : 0; }
+
+uhdr_error_info_t uhdr_hip_generate_gainmap_striped_dev(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* sdr, const uhdr_raw_image_t* hdr,
+                                                        const uhdr_hip_encode_cfg_t* cfg, uhdr_gainmap_metadata_t* md,
+                                                        uhdr_raw_image_t* gm) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  if (!sdr || !hdr || !cfg || !md || !gm) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument");
+  if (cfg->preset == UHDR_USAGE_REALTIME)  // one pass has no exchange step: every stripe is an independent image
+    return uhdr_hip_generate_gainmap_dev(c, sdr, hdr, cfg, md, gm);
+  if (cfg->map_dimension_scale_factor < 1) return err_status(UHDR_CODEC_INVALID_PARAM, "gainmap scale factor %d is not positive", cfg->map_dimension_scale_factor);
+  HIP_TRY(hipSetDevice(c->device));
+  const uint32_t scale = (uint32_t)cfg->map_dimension_scale_factor;
+  // a stripe shorter than one map row (the last rank of an uneven split) launches nothing and contributes the identity
+  const bool empty = sdr->h < scale || sdr->w < scale;
+  UHDR_TRY(ensure(c->exchange, 256));
+  float* merged = (float*)c->exchange.p;                       // 6 floats
+  AffineDev* adev = (AffineDev*)((char*)c->exchange.p + 64);   // 48 bytes
+  float* final_mm = (float*)((char*)c->exchange.p + 192);      // 6 floats
+  if (!c->h_mm) HIP_TRY(hipHostMalloc((void**)&c->h_mm, 6 * sizeof(float), hipHostMallocDefault));
+  GenParams p;
+  int use_base_cg = 1;
+  float hdr_white_nits;
+  if (!empty) {
+    if (!gm->planes[0]) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for the gainmap stripe");
+    UHDR_TRY(fill_gen_params(c, sdr, hdr, cfg, &p, &use_base_cg, &hdr_white_nits));
+    if (p.scale != scale)
+      return err_status(UHDR_CODEC_INVALID_PARAM, "stripe %ux%u holds no map sample at scale factor %d", sdr->w, sdr->h, cfg->map_dimension_scale_factor);
+    fill_gainmap_desc(hdr, p, gm);
+    if (gm->stride[0] < gm->w) return err_status(UHDR_CODEC_INVALID_PARAM, "gainmap stride (%u) cannot be less than its width (%u)", gm->stride[0], gm->w);
+    const size_t nfl = (size_t)p.map_w * p.map_h * (p.multichannel ? 3 : 1);
+    UHDR_TRY(ensure(c->scratch[7], nfl * sizeof(float)));
+    UHDR_TRY(ensure(c->minmax, (6 + 2048 * 6) * sizeof(float)));
+    p.gain_log2 = (float*)c->scratch[7].p;
+    p.minmax = (float*)c->minmax.p;
+    ProfScope ps(c, "generate_gainmap");
+    HIP_TRY(launch_generate_gainmap(p, true, c->stream));  // pass 1: float log2 gains + this stripe's {min, max}
+  } else {
+    UHDR_TRY(ensure(c->minmax, (6 + 2048 * 6) * sizeof(float)));
+    use_base_cg = !(hdr->cg == UHDR_CG_BT_2100 || (hdr->cg == UHDR_CG_DISPLAY_P3 && sdr->cg != UHDR_CG_BT_2100)) || sdr->cg == hdr->cg;
+  }
+  {
+    ProfScope ps(c, "stripe_exchange");
+    HIP_TRY(launch_minmax_pack((const float*)c->minmax.p, merged, empty ? 1 : 0, c->stream));
+    if (c->comm)  // THE collective of the path: 24 bytes, latency bound, in place, on the library's own stream
+      RCCL_TRY(rccl().AllReduce(merged, merged, 6, ncclFloat, ncclMin, (ncclComm_t)c->comm, c->stream));
+    FinalizeParams f;
+    f.merged = merged;
+    f.out = adev;
+    f.out_mm = final_mm;
+    f.nch = cfg->use_multi_channel_gainmap ? 3 : 1;
+    f.has_max_hint = cfg->max_content_boost != FLT_MAX;
+    f.has_min_hint = cfg->min_content_boost != FLT_MIN;
+    f.log2_max_hint = f.has_max_hint ? log2f(cfg->max_content_boost) : 0.0f;
+    f.log2_min_hint = f.has_min_hint ? log2f(cfg->min_content_boost) : 0.0f;
+    HIP_TRY(launch_minmax_finalize(f, c->stream));
+  }
+  if (!empty) {
+    AffineParams a;
+    memset(&a, 0, sizeof a);
+    a.dev = adev;
+    a.gain_log2 = p.gain_log2;
+    a.out = (uint8_t*)gm->planes[0];
+    a.map_w = gm->w; a.map_h = gm->h; a.out_stride = gm->stride[0];
+    a.nch = cfg->use_multi_channel_gainmap ? 3 : 1;
+    a.gamma = cfg->gamma;
+    ProfScope ps(c, "generate_gainmap");
+    HIP_TRY(launch_affine_map(a, c->stream));  // pass 2
+  }
+  HIP_TRY(hipMemcpyAsync(c->h_mm, final_mm, 6 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));  // the only host synchronisation: the metadata needs the merged range
+  float mm[6];
+  memcpy(mm, c->h_mm, sizeof mm);
+  // metadata from the already-final range (the clamp / hint / epsilon steps are idempotent on it)
+  return uhdr_hip_generate_gainmap_finalize_md(cfg, hdr->ct, use_base_cg, mm, md);
 }
 
 uhdr_error_info_t uhdr_hip_generate_gainmap(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* sdr, const uhdr_raw_image_t* hdr,

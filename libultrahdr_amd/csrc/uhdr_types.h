@@ -124,6 +124,12 @@ struct GenParams {
   float* minmax;             // 6 floats
 };
 
+// Row-striped two-pass generation: the final per-channel range lives in device memory between the all-reduce and
+// pass 2, so the sequence pass 1 -> all-reduce -> finalize -> pass 2 needs no host round trip.
+struct AffineDev {
+  float mn[3], mx[3];
+  double range_rcp[3];
+};
 struct AffineParams {
   const float* gain_log2;
   uint8_t* out;
@@ -131,6 +137,16 @@ struct AffineParams {
   float mn[3], mx[3];
   double range_rcp[3];  // 1.0 / (double)(mx[c] - mn[c]) with the float subtraction the reference performs
   float gamma;
+  const AffineDev* dev;  // non-null: mn / mx / range_rcp are read from here instead (written by minmax_finalize_kernel)
+};
+// jpegr.cpp:969-986 on the device: the merged min / max -> clamp, user hints, epsilon guard
+struct FinalizeParams {
+  const float* merged;  // {min0, min1, min2, -max0, -max1, -max2}: the form in which ONE min-all-reduce merges both
+  AffineDev* out;
+  float* out_mm;        // the final {min0..2, max0..2}, for the host's metadata fill
+  int nch;
+  int has_max_hint, has_min_hint;
+  float log2_max_hint, log2_min_hint;  // log2f of the user's content-boost recommendations (host-computed)
 };
 
 // ---- toneMap -------------------------------------------------------------------------------------
@@ -174,6 +190,8 @@ int apply_quad_mode(const ApplyParams& p);  // >= 0: the quad kernel (and batch 
 hipError_t launch_generate_gainmap(const GenParams& p, bool two_pass, hipStream_t s);
 hipError_t launch_affine_map(const AffineParams& p, hipStream_t s);
 hipError_t launch_reduce_minmax(const float* partials, int n, float* out6, hipStream_t s);
+hipError_t launch_minmax_pack(const float* mm6, float* merged6, int empty, hipStream_t s);
+hipError_t launch_minmax_finalize(const FinalizeParams& p, hipStream_t s);
 hipError_t launch_encode_api0_fused(const FusedParams& p, bool two_pass, int* grid_out, hipStream_t s);
 hipError_t launch_tone_map(const ToneMapParams& p, hipStream_t s);
 hipError_t launch_transform_yuv(const YuvXformParams& p, hipStream_t s);

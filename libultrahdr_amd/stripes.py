@@ -55,7 +55,7 @@ def allreduce_minmax(minmax, group=None):
     MIN over {min0, min1, min2, -max0, -max1, -max2} (negation is exact, so max == -min(-x) bit for bit).  Works on
     CPU tensors (gloo) and CUDA tensors (backend "nccl" == RCCL on ROCm).  Float min/max is order-independent, so
     the result is bit-identical to the reference's sequential merge.  (The C++ host layer does the same on the
-    context's own stream without leaving the device: uhdr_hip_generate_gainmap_two_pass_striped_dev.)"""
+    context's own stream without leaving the device: generate_gainmap_striped below.)"""
     import torch
     import torch.distributed as dist
 
@@ -106,6 +106,43 @@ def generate_gainmap_two_pass_striped(uhdr, sdr_stripe, hdr_stripe, cfg: A.Encod
     if mh > 0:
         A.check(lib.uhdr_hip_generate_gainmap_pass2_dev(h, C.c_void_p(gains.data_ptr()), (C.c_float * 6)(*fin), C.byref(cfg),
                                                         C.byref(gm_stripe.raw)))
+    return md
+
+
+# ---- the same through the C++ host layer: RCCL on the library's own stream, no host round trip -----------------------
+def init_comm(ctx, group=None):
+    """Give ``ctx`` (libultrahdr_amd.ultrahdr.Context) an RCCL communicator spanning the torch.distributed group
+    (one process per GPU): rank 0 draws the NCCL unique id, torch.distributed carries the 128 bytes to the other
+    ranks (any bootstrap would do), every rank calls uhdr_hip_comm_init.  World size 1 (no process group): a
+    one-rank communicator, so the collective still executes.  Returns ncclCommCount."""
+    import torch
+    import torch.distributed as dist
+
+    lib = ctx.lib
+    have_pg = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank(group) if have_pg else 0
+    world = dist.get_world_size(group) if have_pg else 1
+    ident = (C.c_ubyte * 128)()
+    if rank == 0 and lib.uhdr_hip_comm_unique_id(ident) != 0:
+        raise RuntimeError("RCCL is not available in this process")
+    if world > 1:
+        backend = dist.get_backend(group)
+        t = torch.tensor(list(ident), dtype=torch.uint8, device="cuda" if backend == "nccl" else "cpu")
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ident = (C.c_ubyte * 128)(*t.cpu().tolist())
+    A.check(lib.uhdr_hip_comm_init(ctx.handle, ident, rank, world))
+    return int(lib.uhdr_hip_comm_size(ctx.handle))
+
+
+def generate_gainmap_striped(uhdr, sdr_stripe, hdr_stripe, cfg: A.EncodeCfg, gm_stripe):
+    """Two-pass generateGainMap for THIS rank's stripe, entirely inside the C++ host layer
+    (uhdr_hip_generate_gainmap_striped_dev): pass 1 -> ncclAllReduce(min) over {min0..2, -max0..2} on the context's
+    stream -> finalisation on the device -> pass 2; one host synchronisation at the end.  Device images.  Returns the
+    metadata (identical on every rank)."""
+    md = A.GainmapMetadata()
+    with uhdr.ctx.ordered():
+        A.check(uhdr.lib.uhdr_hip_generate_gainmap_striped_dev(uhdr.ctx.handle, C.byref(sdr_stripe.raw), C.byref(hdr_stripe.raw),
+                                                               C.byref(cfg), C.byref(md), C.byref(gm_stripe.raw)))
     return md
 
 
