@@ -276,6 +276,15 @@ int uhdr_hip_oetf_code_thresholds(uhdr_color_transfer_t ct, float thresholds[102
  *         2-ulp-off float seed (csrc/device_math.h rcp64_of_f32, the tone mapper's shared-divisor divisions)
  * Returns 0, or -1 for an unknown fn. */
 int uhdr_hip_exact_math_eval(int fn, const float* in, float* out, size_t n);
+/* Host utility (no GPU needed): evaluates one of the kernels' step tables (monotone float -> code functions stored as
+ * bucket tables in LDS: csrc/host_tables.cpp build_step_table) exactly as the device does, so that tests can compare it
+ * with the composite it stands for.
+ *   which 0: toneMap's sRGB byte  put8(srgbOetf(clamp01(x)))         (jpegr.cpp:1976-1977, gainmapmath.cpp:139-148, 538-552)
+ *   which 1: encodeGain's byte for gain x with min / max boost a / b, gamma 1  (gainmapmath.cpp:758-771)
+ *   which 2 / 3: the HLG / PQ decode tail's 10-bit code               (jpegr.cpp:1775-1805)
+ * info (may be NULL) receives {verified exact, entries, shift, first bucket}.  Returns 0; 1 when the table could not be
+ * verified exact for these parameters (the kernels then keep the arithmetic evaluation); -1 for a bad argument. */
+int uhdr_hip_step_table_eval(int which, float a, float b, const float* in, uint32_t* out, size_t n, uint32_t info[4]);
 /* islow 8x8 FDCT + quantize of one 8-bit plane.  Reads blocks_w*8 x blocks_h*8 samples (the
  * caller pads to the MCU grid exactly as jpegencoderhelper.cpp:246-309 does); writes blocks in
  * raster order, 64 int16 each in natural order = libjpeg's JBLOCK layout, ready for

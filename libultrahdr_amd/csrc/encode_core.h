@@ -33,6 +33,60 @@ __device__ __forceinline__ Color3 linearise_hdr(Color3 g, const float* lut, bool
   return l;
 }
 
+// A monotone step function float -> small code as a bucket table in LDS (host_tables.cpp: build_step_table; the decode
+// kernel's HLG / PQ tail is the same construction): clamp the bit pattern into the table's domain, bucket = bits >> shift,
+// at most one threshold per bucket.  One 8-byte LDS read, one compare, one select.
+__device__ __forceinline__ uint32_t step_code(float v, const uint2* tab, const StepTab& t) {
+  const int ib = min(max((int)__float_as_uint(v), (int)t.lo_bits), (int)t.hi_bits);
+  const uint32_t bits = (uint32_t)ib;
+  uint32_t off = (bits >> t.shm3) & ~7u;
+  off = off > t.base8 ? off - t.base8 : 0u;
+  const uint2 e = *(const uint2*)((const char*)tab + off);
+  return bits >= e.x ? e.y >> 16 : e.y & 0xffffu;
+}
+__device__ __forceinline__ void stage_step_tab(uint2* dst, const StepTab& t, uint32_t tid, uint32_t nthreads) {
+  if (t.tab)
+    for (uint32_t i = tid; i < t.n; i += nthreads) dst[i] = t.tab[i];
+}
+
+// linear HDR rgb -> linear Display-P3 SDR rgb in [0, 1]: globalTonemap (jpegr.cpp:1951-1977), gamut conversion to P3, clamp
+__device__ __forceinline__ Color3 tone_curve_linear(Color3 l, const ToneMapParams& p) {
+  float c0 = l.r, c1 = l.g, c2 = l.b;
+  const float hr = p.headroom;
+  if (p.is_normalized) { c0 *= hr; c1 *= hr; c2 *= hr; }
+  float mx = c0;
+  if (c1 > mx) mx = c1;
+  if (c2 > mx) mx = c2;
+  float ms = 1.0f + div_const(mx, p.headroom_sq, p.headroom_sq_rcp);  // ReinhardMap: mx / (hr * hr), divisor is a per-transfer constant
+  ms /= 1.0f + mx;
+  ms = ms * mx;
+  // c * max_sdr / max_hdr for the three channels (jpegr.cpp:1968-1972): one shared float64 reciprocal of
+  // max_hdr, each quotient exact (device_math.h: rcp64_of_f32, div_by_rcp64); mx == 0 implies c <= 0
+  const double rmx = rcp64_of_f32(mx, __builtin_amdgcn_rcpf(mx));
+  Color3 o;
+  o.r = c0 > 0.0f ? div_by_rcp64(c0 * ms, rmx) : 0.0f;
+  o.g = c1 > 0.0f ? div_by_rcp64(c1 * ms, rmx) : 0.0f;
+  o.b = c2 > 0.0f ? div_by_rcp64(c2 * ms, rmx) : 0.0f;
+  if (p.gamut_on) o = mat3_apply(o, p.gamut);
+  o.r = clamp01(o.r); o.g = clamp01(o.g); o.b = clamp01(o.b);
+  return o;
+}
+// ... -> the three sRGB BYTES of putRgba8888Pixel (srgbOetf, * 255 + 0.5, clip, truncate): through the step table when
+// the call has one (identical bytes: the table is built from the same srgb_oetf_table), else evaluated per channel
+__device__ __forceinline__ void tone_curve_bytes(Color3 l, const ToneMapParams& p, const double* math, const uint2* srgb8,
+                                                 uint32_t& r8, uint32_t& g8, uint32_t& b8) {
+  const Color3 o = tone_curve_linear(l, p);
+  if (p.srgb8.tab) {
+    r8 = step_code(o.r, srgb8, p.srgb8);
+    g8 = step_code(o.g, srgb8, p.srgb8);
+    b8 = step_code(o.b, srgb8, p.srgb8);
+  } else {
+    r8 = put8(srgb_oetf_table(o.r, math));
+    g8 = put8(srgb_oetf_table(o.g, math));
+    b8 = put8(srgb_oetf_table(o.b, math));
+  }
+}
+
 // linear HDR rgb -> gamma-encoded Display-P3 SDR rgb: globalTonemap (jpegr.cpp:1951-1977), gamut
 // conversion to P3, clamp, srgbOetf (gainmapmath.cpp:139-148, pow through exact_math.h)
 __device__ __forceinline__ Color3 tone_curve(Color3 l, const ToneMapParams& p, const double* math) {
@@ -60,9 +114,12 @@ __device__ __forceinline__ Color3 tone_curve(Color3 l, const ToneMapParams& p, c
 
 // encodeGain (gainmapmath.cpp:758-771): log2 is the DOUBLE libm one in the reference build, the
 // normalisation is double arithmetic narrowed to float, then powf, then truncation.
-__device__ __forceinline__ uint8_t encode_gain(float y_sdr, float y_hdr, const GenParams& p, const double* T) {
+__device__ __forceinline__ uint8_t encode_gain(float y_sdr, float y_hdr, const GenParams& p, const double* T, const uint2* gain8 = nullptr) {
   float gain = 1.0f;
   if (y_sdr > 0.0f) gain = y_hdr / y_sdr;
+  // the clamp, log2, normalisation and truncation as one table lookup (gamma == 1; same bytes: the table is built from
+  // log2_table_f64 / div_by_const_f64 on the host); its domain clamp IS the clamp to [min_boost, max_boost]
+  if (gain8 && p.gain8.tab) return (uint8_t)step_code(gain, gain8, p.gain8);
   if (gain < p.min_boost) gain = p.min_boost;
   if (gain > p.max_boost) gain = p.max_boost;
   const double lg = log2_table_f64(gain, T);
@@ -86,15 +143,15 @@ struct F3 {
 // folds them into the running per-channel min / max).
 template <bool TWO_PASS>
 __device__ __forceinline__ void gain_of_pixel(Color3 sl, Color3 hl, const GenParams& p, const double* math, uint32_t x, uint32_t y,
-                                              float mn[3], float mx[3]) {
+                                              float mn[3], float mx[3], const uint2* gain8 = nullptr) {
   if (p.multichannel) {
     const float sn[3] = {sl.r * 203.0f, sl.g * 203.0f, sl.b * 203.0f};
     const float hn[3] = {hl.r * p.hdr_nits, hl.g * p.hdr_nits, hl.b * p.hdr_nits};
     if constexpr (!TWO_PASS) {
       uint8_t* o = p.out + (size_t)y * p.out_stride * 3 + x * 3;
-      o[0] = encode_gain(sn[0], hn[0], p, math);
-      o[1] = encode_gain(sn[1], hn[1], p, math);
-      o[2] = encode_gain(sn[2], hn[2], p, math);
+      o[0] = encode_gain(sn[0], hn[0], p, math, gain8);
+      o[1] = encode_gain(sn[1], hn[1], p, math, gain8);
+      o[2] = encode_gain(sn[2], hn[2], p, math, gain8);
     } else {
       float v[3];
 #pragma unroll
@@ -115,7 +172,7 @@ __device__ __forceinline__ void gain_of_pixel(Color3 sl, Color3 hl, const GenPar
       hy = fmaxf(hl.r, fmaxf(hl.g, hl.b)) * p.hdr_nits;
     }
     if constexpr (!TWO_PASS) {
-      p.out[(size_t)y * p.out_stride + x] = encode_gain(sy, hy, p, math);
+      p.out[(size_t)y * p.out_stride + x] = encode_gain(sy, hy, p, math, gain8);
     } else {
       const float v = compute_gain(sy, hy, math);
       p.gain_log2[(size_t)y * p.map_w + x] = v;

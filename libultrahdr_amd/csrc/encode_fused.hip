@@ -20,22 +20,33 @@ namespace {
 
 constexpr int kBlock = 512;  // 8 waves share one table set in LDS -> 3 workgroups = 24 waves per CU
 
+template <int HDRF>
 struct FusedLds {
   float srgb[kSrgbN];
-  float hdr[kInvOetfN];
+  // RGBA1010102 input: 10-bit code -> linear value (the host always provides it); RGBA-F16: the inverse-OETF table, if any
+  float hdr[HDRF == UHDR_IMG_FMT_32bppRGBA1010102 ? 1024 : kInvOetfN];
   double math[kMathTabDoubles];
   UnormTables unorm;
+  uint2 srgb8[kStepTabMax];  // tone map: clamped linear value -> sRGB byte
+  uint2 gain8[kStepTabMax];  // one pass: clamped gain -> map byte
 };
 
 __device__ __forceinline__ float clipf(float v, float hi) { return (v < 0.0f) ? 0.0f : ((v > hi) ? hi : v); }
 
 template <int HDRF, bool TWO_PASS>
 __global__ __launch_bounds__(kBlock) void encode_api0_fused_kernel(const FusedParams p, float* partials) {
-  __shared__ FusedLds L;
+  __shared__ FusedLds<HDRF> L;
   const uint32_t tid = threadIdx.x;
   for (uint32_t i = tid; i < kSrgbN; i += kBlock) L.srgb[i] = p.gen.srgb_lut[i];
-  if (p.tm.hdr_inv_lut)
-    for (uint32_t i = tid; i < (uint32_t)p.tm.hdr_inv_n; i += kBlock) L.hdr[i] = p.tm.hdr_inv_lut[i];
+  constexpr bool code_lin = HDRF == UHDR_IMG_FMT_32bppRGBA1010102;  // launch_encode_api0_fused checks that lin10 is there
+  if constexpr (code_lin) {
+    for (uint32_t i = tid; i < 1024; i += kBlock) L.hdr[i] = p.tm.lin10[i];
+  } else {
+    if (p.tm.hdr_inv_lut)
+      for (uint32_t i = tid; i < (uint32_t)p.tm.hdr_inv_n; i += kBlock) L.hdr[i] = p.tm.hdr_inv_lut[i];
+  }
+  stage_step_tab(L.srgb8, p.tm.srgb8, tid, kBlock);
+  stage_step_tab(L.gain8, p.gen.gain8, tid, kBlock);
   for (uint32_t i = tid; i < kMathTabDoubles; i += kBlock) L.math[i] = p.tm.math_tab[i];
   fill_unorm_tables(L.unorm, tid, kBlock);
   __syncthreads();
@@ -48,10 +59,16 @@ __global__ __launch_bounds__(kBlock) void encode_api0_fused_kernel(const FusedPa
     const uint32_t y = t / tiles_x, x = (t - y * tiles_x) * kBlock + tid;
     if (x >= w) continue;
     // ---- toneMap (jpegr.cpp:2147-2203) -------------------------------------------------------------------------
-    const Color3 g = fetch_pixel<HDRF>(p.tm.hdr, x, y, &L.unorm);
-    const Color3 l = linearise_hdr(g, L.hdr, hdr_lut, hdr_lut_4096);
-    const Color3 og = tone_curve(l, p.tm, L.math);
-    const uint32_t r8 = put8(og.r), g8 = put8(og.g), b8 = put8(og.b);  // putRgba8888Pixel
+    Color3 l;
+    if constexpr (code_lin) {  // unpack + inverse OETF (+ OOTF) of a 10-bit code is one table entry
+      const uint32_t v = ((const uint32_t*)p.tm.hdr.p[0])[x + (size_t)y * p.tm.hdr.stride[0]];
+      l = Color3{L.hdr[v & 0x3ffu], L.hdr[(v >> 10) & 0x3ffu], L.hdr[(v >> 20) & 0x3ffu]};
+    } else {
+      const Color3 g = fetch_pixel<HDRF>(p.tm.hdr, x, y, &L.unorm);
+      l = linearise_hdr(g, L.hdr, hdr_lut, hdr_lut_4096);
+    }
+    uint32_t r8, g8, b8;  // putRgba8888Pixel's bytes
+    tone_curve_bytes(l, p.tm, L.math, L.srgb8, r8, g8, b8);
     if (p.tm.sdr.p[0]) ((uint32_t*)p.tm.sdr.p[0])[x + (size_t)y * p.tm.sdr.stride[0]] = r8 | (g8 << 8) | (b8 << 16) | (255u << 24);
     // ---- generateGainMap on the quantised SDR pixel (jpegr.cpp:753-818 / 866-931), scale 1 ---------------------------
     const Color3 e = {L.unorm.u8[r8], L.unorm.u8[g8], L.unorm.u8[b8]};  // getRgba8888Pixel: byte / 255.0f
@@ -61,7 +78,7 @@ __global__ __launch_bounds__(kBlock) void encode_api0_fused_kernel(const FusedPa
     Color3 hl = l;  // the same inverse OETF (+ OOTF) the tone mapper just applied
     if (p.gen.hdr_gamut_on) hl = mat3_apply(hl, p.gen.hdr_gamut);
     hl.r = clip_neg(hl.r); hl.g = clip_neg(hl.g); hl.b = clip_neg(hl.b);
-    gain_of_pixel<TWO_PASS>(sl, hl, p.gen, L.math, x, y, mn, mx);
+    gain_of_pixel<TWO_PASS>(sl, hl, p.gen, L.math, x, y, mn, mx, L.gain8);
     // ---- convert_raw_input_to_ycbcr(sdr, 4:4:4) (gainmapmath.cpp:1446-1472) ----------------------------------------------
     const Color3 q = rgb_to_yuv(e, p.base_k);
     ((uint8_t*)p.ycc.p[0])[(size_t)y * p.ycc.stride[0] + x] = (uint8_t)clipf(q.r * 255.0f + 0.5f, 255.0f);
@@ -73,13 +90,14 @@ __global__ __launch_bounds__(kBlock) void encode_api0_fused_kernel(const FusedPa
 
 }  // namespace
 
-int fused_grid(uint32_t tiles) {
-  static const int resident = [] {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 1024;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    return cus * 3;  // 512-thread workgroups with 29 KB of LDS tables: three resident per CU
+int fused_grid(uint32_t tiles, int per_cu) {
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
   }();
+  const int resident = cus * per_cu;  // 512-thread workgroups: 48 KB of LDS tables (RGBA1010102) -> 3 per CU, 60 KB (RGBA-F16) -> 2
   uint32_t g = tiles < (uint32_t)resident ? tiles : (uint32_t)resident;
   if (g > 2048) g = 2048;  // the host layer sizes the min/max partials buffer for 2048 workgroups
   return (int)(g < 1 ? 1 : g);
@@ -89,10 +107,11 @@ int fused_grid(uint32_t tiles) {
 // through *grid_out so that the caller can run the final min/max reduction (launch_reduce_minmax).
 hipError_t launch_encode_api0_fused(const FusedParams& p, bool two_pass, int* grid_out, hipStream_t s) {
   const uint32_t tiles = ((p.tm.hdr.w + kBlock - 1) / kBlock) * p.tm.hdr.h;
-  const int grid = fused_grid(tiles);
+  const bool f16 = p.tm.hdr.fmt == UHDR_IMG_FMT_64bppRGBAHalfFloat;
+  if (!f16 && !p.tm.lin10) return hipErrorInvalidValue;  // the host layer always builds the code -> linear table
+  const int grid = fused_grid(tiles, f16 ? 2 : 3);
   if (grid_out) *grid_out = grid;
   float* partials = two_pass ? p.gen.minmax + 6 : nullptr;
-  const bool f16 = p.tm.hdr.fmt == UHDR_IMG_FMT_64bppRGBAHalfFloat;
   if (f16) {
     if (two_pass) hipLaunchKernelGGL((encode_api0_fused_kernel<UHDR_IMG_FMT_64bppRGBAHalfFloat, true>), dim3(grid), dim3(kBlock), 0, s, p, partials);
     else hipLaunchKernelGGL((encode_api0_fused_kernel<UHDR_IMG_FMT_64bppRGBAHalfFloat, false>), dim3(grid), dim3(kBlock), 0, s, p, partials);

@@ -35,7 +35,9 @@ struct GenLds {
 template <int SDRF, int HDRF, bool TWO_PASS, bool QUAD>
 __global__ __launch_bounds__(kGenBlock) void generate_kernel(const GenParams p, float* partials) {
   __shared__ GenLds L;
+  __shared__ uint2 s_gain8[TWO_PASS ? 1 : kStepTabMax];  // one pass: clamped gain -> map byte (host_tables.cpp)
   const uint32_t tid = threadIdx.x;
+  if constexpr (!TWO_PASS) stage_step_tab(s_gain8, p.gain8, tid, kGenBlock);
   for (uint32_t i = tid; i < kSrgbN; i += kGenBlock) L.srgb[i] = p.srgb_lut[i];
   if (p.hdr_inv_lut)
     for (uint32_t i = tid; i < (uint32_t)p.hdr_inv_n; i += kGenBlock) L.hdr[i] = p.hdr_inv_lut[i];
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(kGenBlock) void generate_kernel(const GenParams p, 
     Color3 hl = linearise_hdr(h, L.hdr, hdr_lut, hdr_lut_4096);
     if (p.hdr_gamut_on) hl = mat3_apply(hl, p.hdr_gamut);
     hl.r = clip_neg(hl.r); hl.g = clip_neg(hl.g); hl.b = clip_neg(hl.b);
-    gain_of_pixel<TWO_PASS>(sl, hl, p, L.math, x, y, mn, mx);
+    gain_of_pixel<TWO_PASS>(sl, hl, p, L.math, x, y, mn, mx, TWO_PASS ? nullptr : s_gain8);
   };
   if constexpr (QUAD) {
     const uint32_t qw = p.map_w / 2, qh = p.map_h / 2;

@@ -15,6 +15,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <mutex>
 
 namespace uhdr {
@@ -222,70 +223,155 @@ const std::vector<float>& oetf_code_thresholds(int ct) {
 // select per channel.  Everything below the first threshold is bucket 0 (code 0).  The construction is
 // CHECKED here: the table lookup is replayed against the composite at every threshold, its predecessor
 // and both ends of every bucket; `exact` says whether all of them (and the one-threshold property) held.
-static OetfBuckets make_bucket_table(int ct) {
+// Generic form: any monotone step function code(v) of a float restricted to [lo, hi] (bit patterns lo_bits <= hi_bits
+// of non-negative floats), given as a callable on the bit pattern.  Thresholds by bisection, buckets of 2^shift bit
+// patterns, first bucket = the one holding the smallest threshold.
+OetfBuckets build_step_table(const std::function<uint32_t(uint32_t)>& code_of_bits, uint32_t lo_bits, uint32_t hi_bits,
+                             uint32_t shift, uint32_t capacity) {
   OetfBuckets b;
-  const std::vector<float> t = make_thresholds(ct);
-  auto bits_of = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
-  auto flt = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
-  const uint32_t one = bits_of(1.0f);
-  b.shift = ct == UHDR_CT_HLG ? kOetfBucketShiftHlg : kOetfBucketShiftPq;
-  uint32_t first = one;  // smallest positive threshold
-  for (uint32_t c = 1; c < 1024; c++)
-    if (t[c] > 0.0f && t[c] <= 1.0f && bits_of(t[c]) < first) first = bits_of(t[c]);
-  b.base = first >> b.shift;
-  b.n = (one >> b.shift) - b.base + 1;
+  b.shift = shift;
+  b.lo_bits = lo_bits;
+  b.hi_bits = hi_bits;
   b.exact = true;
+  const uint32_t c_lo = code_of_bits(lo_bits), c_hi = code_of_bits(hi_bits);
+  std::vector<uint32_t> thr;  // thr[i]: smallest bit pattern whose code is >= c_lo + 1 + i
+  for (uint32_t c = c_lo + 1; c <= c_hi; c++) {
+    uint32_t lo = lo_bits, hi = hi_bits;  // invariant: code(lo) < c <= code(hi)
+    while (hi - lo > 1) {
+      const uint32_t mid = lo + (hi - lo) / 2;
+      if (code_of_bits(mid) >= c) hi = mid; else lo = mid;
+    }
+    thr.push_back(hi);
+  }
+  const uint32_t first = thr.empty() ? hi_bits : thr[0];
+  b.base = first >> shift;
+  b.n = (hi_bits >> shift) - b.base + 1;
+  if (b.n > capacity) { b.exact = false; b.n = 1; }
   b.entries.assign((size_t)b.n * 2, 0u);
+  if (!b.exact) return b;
   std::vector<std::vector<uint32_t>> inside(b.n);
-  for (uint32_t c = 1; c < 1024; c++) {
-    if (!(t[c] <= 1.0f)) continue;
-    const uint32_t u = bits_of(t[c]);
-    if (u == 0) continue;  // codes reached at v = 0 are part of every bucket's `lo`
-    std::vector<uint32_t>& v = inside[(u >> b.shift) - b.base];
+  for (uint32_t u : thr) {
+    std::vector<uint32_t>& v = inside[(u >> shift) - b.base];
     if (v.empty() || v.back() != u) v.push_back(u);
   }
-  auto lookup = [&](uint32_t u) -> uint32_t {  // the device's evaluation
-    uint32_t k = u >> b.shift;
+  auto clampb = [&](uint32_t u) { return u < lo_bits ? lo_bits : (u > hi_bits ? hi_bits : u); };
+  auto lookup = [&](uint32_t u) -> uint32_t {  // the device's evaluation (u already clamped to [lo_bits, hi_bits])
+    uint32_t k = u >> shift;
     k = k > b.base ? k - b.base : 0;
-    const uint32_t thr = b.entries[2 * k], cc = b.entries[2 * k + 1];
-    return u >= thr ? cc >> 16 : cc & 0xffffu;
+    const uint32_t t = b.entries[2 * k], cc = b.entries[2 * k + 1];
+    return u >= t ? cc >> 16 : cc & 0xffffu;
   };
   for (uint32_t k = 0; k < b.n; k++) {
-    const uint32_t start = (b.base + k) << b.shift;
-    // bucket 0 also stands for everything below it
-    const uint32_t lo = oetf_code_host(ct, k == 0 ? 0.0f : flt(start));
-    uint32_t thr = 0xFFFFFFFFu, hi = lo;
+    const uint32_t start = (b.base + k) << shift;
+    const uint32_t lo = k == 0 ? c_lo : code_of_bits(clampb(start));  // bucket 0 also stands for everything below it
+    uint32_t t = 0xFFFFFFFFu, hi = lo;
     if (!inside[k].empty()) {
       if (inside[k].size() > 1) b.exact = false;
-      thr = inside[k][0];
-      hi = oetf_code_host(ct, flt(inside[k].back()));
+      t = inside[k][0];
+      hi = code_of_bits(inside[k].back());
     }
-    b.entries[2 * k] = thr;
+    b.entries[2 * k] = t;
     b.entries[2 * k + 1] = lo | (hi << 16);
   }
-  // replay: both ends of every bucket, every threshold and its predecessor, and the range below bucket 0
+  // replay: both ends of every bucket, every threshold and its predecessor, and the ends of the domain
   for (uint32_t k = 0; k < b.n && b.exact; k++) {
-    const uint32_t start = (b.base + k) << b.shift;
-    uint32_t probes[6] = {start, start + (1u << b.shift) - 1, 0, 0, 0, 0};
+    const uint32_t start = (b.base + k) << shift;
+    uint32_t probes[6] = {start, start + (1u << shift) - 1, 0, 0, 0, 0};
     int np = 2;
     for (uint32_t u : inside[k]) {
       if (np < 6) probes[np++] = u;
       if (np < 6 && u > 0) probes[np++] = u - 1;
     }
     for (int i = 0; i < np; i++) {
-      const uint32_t u = probes[i] > one ? one : probes[i];
-      if (lookup(u) != oetf_code_host(ct, flt(u))) b.exact = false;
+      const uint32_t u = clampb(probes[i]);
+      if (lookup(u) != code_of_bits(u)) b.exact = false;
     }
   }
-  for (uint32_t u : {0u, 1u, first > 0 ? first - 1 : 0u, first, one})
-    if (lookup(u) != oetf_code_host(ct, flt(u))) b.exact = false;
-  if (b.n > (uint32_t)(ct == UHDR_CT_HLG ? kOetfBucketsHlg : kOetfBucketsPq)) b.exact = false;  // the kernel's LDS array
+  for (uint32_t u : {lo_bits, clampb(lo_bits + 1), clampb(first > 0 ? first - 1 : 0u), clampb(first), hi_bits})
+    if (lookup(u) != code_of_bits(u)) b.exact = false;
   return b;
+}
+static OetfBuckets make_bucket_table(int ct) {
+  auto flt = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
+  uint32_t one;
+  const float onef = 1.0f;
+  memcpy(&one, &onef, 4);
+  return build_step_table([&](uint32_t u) { return oetf_code_host(ct, flt(u)); }, 0u, one,
+                          ct == UHDR_CT_HLG ? kOetfBucketShiftHlg : kOetfBucketShiftPq,
+                          ct == UHDR_CT_HLG ? kOetfBucketsHlg : kOetfBucketsPq);
 }
 const OetfBuckets& oetf_code_buckets(int ct) {
   static const OetfBuckets hlg = make_bucket_table(UHDR_CT_HLG);
   static const OetfBuckets pq = make_bucket_table(UHDR_CT_PQ);
   return ct == UHDR_CT_HLG ? hlg : pq;
+}
+
+// ---- step tables of the ENCODE side ------------------------------------------------------------------------------------
+// toneMap's last stage for RGBA8888 output: clampPixelFloat -> srgbOetf -> putRgba8888Pixel's byte
+// (jpegr.cpp:1976-1977, gainmapmath.cpp:139-148, 538-552) is a monotone step function of the linear value with 255
+// steps.  The composite is evaluated here through exact_math.h's srgb_oetf_table -- the very function the kernels ran
+// per channel before (float64, ~20 instructions) -- so the table changes no result, only its cost.
+const OetfBuckets& srgb_code8_buckets() {
+  static const OetfBuckets t = [] {
+    const std::vector<double>& T = math_tables();
+    auto code = [&](uint32_t u) -> uint32_t {
+      float x;
+      memcpy(&x, &u, 4);
+      float v = srgb_oetf_table(x, T.data()) * 255.0f;
+      v += 0.5f;
+      v = (v < 0.0f) ? 0.0f : ((v > 255.0f) ? 255.0f : v);
+      return (uint32_t)v;
+    };
+    uint32_t one;
+    const float onef = 1.0f;
+    memcpy(&one, &onef, 4);
+    for (uint32_t sh : {16u, 15u, 14u}) {
+      OetfBuckets b = build_step_table(code, 0u, one, sh, kStepTabMax);
+      if (b.exact) return b;
+    }
+    OetfBuckets none;
+    none.exact = false;
+    return none;
+  }();
+  return t;
+}
+// encodeGain (gainmapmath.cpp:758-771) after its clamp to [min_boost, max_boost], gamma == 1: the byte is a monotone
+// step function of the clamped gain, evaluated here through the kernels' own log2_table_f64 / div_by_const_f64.
+OetfBuckets gain_code8_buckets(float min_boost, float max_boost, float log2min, double log2_range, double log2_range_rcp) {
+  const std::vector<double>& T = math_tables();
+  auto code = [&](uint32_t u) -> uint32_t {
+    float g;
+    memcpy(&g, &u, 4);
+    const double lg = log2_table_f64(g, T.data());
+    const float n = (float)div_by_const_f64(lg - (double)log2min, log2_range, log2_range_rcp);
+    return (uint32_t)(uint8_t)(n * 255.0f);
+  };
+  uint32_t lo, hi;
+  memcpy(&lo, &min_boost, 4);
+  memcpy(&hi, &max_boost, 4);
+  OetfBuckets none;
+  none.exact = false;
+  if (!(min_boost > 0.0f) || !(max_boost > min_boost) || !std::isfinite(max_boost) || lo < 0x00800000u) return none;
+  if (code(hi) < code(lo)) return none;
+  for (uint32_t sh : {16u, 15u, 14u}) {
+    OetfBuckets b = build_step_table(code, lo, hi, sh, kStepTabMax);
+    if (b.exact) return b;
+  }
+  return none;
+}
+// RGBA1010102 HDR input: 10-bit code -> linear value = the 1010102 unpack (code / 1023.0f, gainmapmath.cpp:472-481)
+// followed by the HDR inverse-OETF table lookup the kernels did per channel (lut_index of device_math.h), per code
+std::vector<float> lin10_table(const float* lut, int n) {
+  std::vector<float> t(1024);
+  for (int c = 0; c < 1024; c++) {
+    const float x = (float)c / 1023.0f;
+    if (!lut) { t[c] = x; continue; }
+    const float f = x * (float)(n - 1);
+    int i = (n == kInvOetfN) ? (int)((double)f + 0.5) : (int)(f + 0.5f);
+    i = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+    t[c] = lut[i];
+  }
+  return t;
 }
 
 // Tables of exact_math.h.  Everything is computed in long double (64-bit significand on x86-64)

@@ -24,11 +24,16 @@ const std::vector<float>& oetf_code_thresholds(int ct);
 uint32_t oetf_code(int ct, float v);  // the composite itself, evaluated with the host libm
 // the same step function as a bucket table for the quad kernel (see host_tables.cpp)
 struct OetfBuckets {
-  uint32_t shift, base, n;         // bucket k covers bit patterns [(base + k) << shift, (base + k + 1) << shift)
-  bool exact;                      // construction verified (one threshold per bucket, replay against the composite)
-  std::vector<uint32_t> entries;   // n x {thr, lo | hi << 16}
+  uint32_t shift = 0, base = 0, n = 0;  // bucket k covers bit patterns [(base + k) << shift, (base + k + 1) << shift)
+  uint32_t lo_bits = 0, hi_bits = 0;    // the domain: the device clamps the bit pattern into it first
+  bool exact = false;                   // construction verified (one threshold per bucket, replay against the composite)
+  std::vector<uint32_t> entries;        // n x {thr, lo | hi << 16}
 };
 const OetfBuckets& oetf_code_buckets(int ct);
+// encode side (see host_tables.cpp): toneMap's sRGB byte, encodeGain's byte, RGBA1010102 code -> linear value
+const OetfBuckets& srgb_code8_buckets();
+OetfBuckets gain_code8_buckets(float min_boost, float max_boost, float log2min, double log2_range, double log2_range_rcp);
+std::vector<float> lin10_table(const float* lut, int n);
 
 // float64 tables of exact_math.h (table-driven pow / log2 of the encode path)
 const std::vector<double>& math_tables();

@@ -21,7 +21,7 @@ __device__ __forceinline__ uint8_t scale_to_8bit(float v) {  // jpegr.cpp:1979-1
   return (uint8_t)min(max(i, 0), 255);
 }
 struct ToneLds {
-  float hdr[kInvOetfN];
+  float hdr[kInvOetfN];  // RGBA1010102 input with p.lin10: the first 1024 entries hold code -> linear value
   double math[kMathTabDoubles];
   UnormTables unorm;
 };
@@ -96,17 +96,38 @@ __global__ __launch_bounds__(kBlock) void tonemap_p010_kernel(const ToneMapParam
 template <int HDRF>
 __global__ __launch_bounds__(kBlock) void tonemap_pixel_kernel(const ToneMapParams p) {
   __shared__ ToneLds L;
-  stage_tables(p, L);
+  __shared__ uint2 s_srgb8[kStepTabMax];  // RGBA8888 output: clamped linear value -> sRGB byte
+  const bool code_lin = HDRF == UHDR_IMG_FMT_32bppRGBA1010102 && p.lin10 != nullptr;
+  if (code_lin)
+    for (uint32_t i = threadIdx.x; i < 1024; i += kBlock) L.hdr[i] = p.lin10[i];
+  stage_step_tab(s_srgb8, p.srgb8, threadIdx.x, kBlock);
+  if (code_lin) {  // everything of stage_tables except the inverse-OETF table
+    for (uint32_t i = threadIdx.x; i < kMathTabDoubles; i += kBlock) L.math[i] = p.math_tab[i];
+    fill_unorm_tables(L.unorm, threadIdx.x, kBlock);
+    __syncthreads();
+  } else {
+    stage_tables(p, L);
+  }
   const uint32_t w = p.hdr.w, h = p.hdr.h;
   const uint32_t tiles_x = (w + kBlock - 1) / kBlock, tiles = tiles_x * h;
   for (uint32_t t = blockIdx.x; t < tiles; t += gridDim.x) {
     const uint32_t y = t / tiles_x, x = (t - y * tiles_x) * kBlock + threadIdx.x;
     if (x >= w) continue;
-    const Color3 og = tone_map_pixel<HDRF>(p, L, x, y);
     if (p.sdr.fmt == UHDR_IMG_FMT_32bppRGBA8888) {  // putRgba8888Pixel (gainmapmath.cpp:538-552)
-      ((uint32_t*)p.sdr.p[0])[x + (size_t)y * p.sdr.stride[0]] =
-          put8(og.r) | (put8(og.g) << 8) | (put8(og.b) << 16) | (255u << 24);
+      Color3 l;
+      if (code_lin) {  // unpack + inverse OETF (+ OOTF) of a 10-bit code is one table entry
+        const uint32_t v = ((const uint32_t*)p.hdr.p[0])[x + (size_t)y * p.hdr.stride[0]];
+        l = Color3{L.hdr[v & 0x3ffu], L.hdr[(v >> 10) & 0x3ffu], L.hdr[(v >> 20) & 0x3ffu]};
+      } else {
+        Color3 g = fetch_pixel<HDRF>(p.hdr, x, y, &L.unorm);
+        if (!p.hdr_is_rgb) g = yuv_to_rgb(g.r, g.g, g.b, p.hdr_yuv);
+        l = linearise_hdr(g, L.hdr, p.hdr_inv_lut != nullptr, p.hdr_inv_n == kInvOetfN);
+      }
+      uint32_t r8, g8, b8;
+      tone_curve_bytes(l, p, L.math, s_srgb8, r8, g8, b8);
+      ((uint32_t*)p.sdr.p[0])[x + (size_t)y * p.sdr.stride[0]] = r8 | (g8 << 8) | (b8 << 16) | (255u << 24);
     } else {  // 4:4:4: p3RgbToYuv, +0.5 chroma offset, putYuv444Pixel (gainmapmath.cpp:579-596)
+      const Color3 og = tone_map_pixel<HDRF>(p, L, x, y);
       Color3 yuv = rgb_to_yuv(og, p.p3);
       yuv.g += 0.5f;
       yuv.b += 0.5f;
@@ -117,13 +138,16 @@ __global__ __launch_bounds__(kBlock) void tonemap_pixel_kernel(const ToneMapPara
   }
 }
 
-int tone_grid(uint32_t tiles) {
-  static const int resident = [] {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 1024;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    return cus * 6;  // 24 KB of LDS tables per workgroup: six fit in a CU's 160 KB
+// per_cu: workgroups of LDS tables that fit a CU's 160 KB -- 24 KB each (P010 kernel): six; 40 KB (pixel kernel, with the
+// sRGB byte table): four
+int tone_grid(uint32_t tiles, int per_cu) {
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
   }();
+  const int resident = cus * per_cu;
   const uint32_t g = tiles < (uint32_t)resident ? tiles : (uint32_t)resident;
   return (int)(g < 1 ? 1 : g);
 }
@@ -133,10 +157,10 @@ int tone_grid(uint32_t tiles) {
 hipError_t launch_tone_map(const ToneMapParams& p, hipStream_t s) {
   if (p.hdr.fmt == UHDR_IMG_FMT_24bppYCbCrP010) {
     const uint32_t qw = p.hdr.w / 2, qh = p.hdr.h / 2;
-    const int grid = tone_grid(((qw + kBlock - 1) / kBlock) * qh);
+    const int grid = tone_grid(((qw + kBlock - 1) / kBlock) * qh, 6);
     hipLaunchKernelGGL(tonemap_p010_kernel, dim3(grid), dim3(kBlock), 0, s, p);
   } else {
-    const int grid = tone_grid(((p.hdr.w + kBlock - 1) / kBlock) * p.hdr.h);
+    const int grid = tone_grid(((p.hdr.w + kBlock - 1) / kBlock) * p.hdr.h, 4);
     switch (p.hdr.fmt) {
       case UHDR_IMG_FMT_32bppRGBA1010102:
         hipLaunchKernelGGL((tonemap_pixel_kernel<UHDR_IMG_FMT_32bppRGBA1010102>), dim3(grid), dim3(kBlock), 0, s, p);

@@ -94,6 +94,13 @@ struct uhdr_hip_ctx {
   uint32_t* d_huff = nullptr;     // Annex K code tables (kHuffTabWords) followed by the 64-byte zig-zag map
   CoefSrc* d_coef_src = nullptr;  // apply_gainmap_coef descriptors (rotating slots)
   unsigned int coef_src_next = 0;
+  // encode-side step tables (host_tables.cpp): sRGB byte of the tone mapper (one per context), 10-bit code -> linear
+  // value per HDR transfer, encodeGain's byte per (min boost, max boost)
+  float* d_srgb8 = nullptr;
+  StepTab srgb8_meta = {};
+  float* d_lin10[5] = {};
+  struct GainTab { float mn, mx; float* d; StepTab meta; };
+  std::vector<GainTab> gain_tabs;
   // multi-GPU (row stripes): RCCL communicator of this rank + the exchange buffers of two-pass generation
   void* comm = nullptr;          // ncclComm_t
   int comm_rank = 0, comm_size = 0;
@@ -266,6 +273,39 @@ uhdr_error_info_t upload_math(uhdr_hip_ctx* c) {
   HIP_TRY(hipStreamSynchronize(c->stream));
   return ok_status();
 }
+// a verified host step table -> device copy + the kernel-side descriptor (tab == nullptr when the table is not exact)
+static uhdr_error_info_t upload_step_table(const host::OetfBuckets& b, float** slot, StepTab* meta, hipStream_t s) {
+  memset(meta, 0, sizeof *meta);
+  if (!b.exact || b.n == 0 || b.n > (uint32_t)kStepTabMax) return ok_status();
+  if (!*slot) {
+    std::vector<float> raw(b.entries.size());
+    memcpy(raw.data(), b.entries.data(), raw.size() * sizeof(float));
+    UHDR_TRY(upload_lut(slot, raw, s));
+  }
+  meta->tab = (const uint2*)*slot;
+  meta->n = b.n;
+  meta->base8 = b.base * 8;
+  meta->shm3 = b.shift - 3;
+  meta->lo_bits = b.lo_bits;
+  meta->hi_bits = b.hi_bits;
+  return ok_status();
+}
+// encodeGain's byte for the clamped gain (one pass, gamma 1), cached per boost range
+static uhdr_error_info_t gain_step_table(uhdr_hip_ctx* c, const GenParams& p, StepTab* out) {
+  memset(out, 0, sizeof *out);
+  if (p.gamma != 1.0f) return ok_status();
+  for (auto& g : c->gain_tabs)
+    if (g.mn == p.min_boost && g.mx == p.max_boost) { *out = g.meta; return ok_status(); }
+  if (c->gain_tabs.size() >= 16) return ok_status();  // a caller cycling through boost ranges keeps the float64 evaluation
+  uhdr_hip_ctx::GainTab g;
+  g.mn = p.min_boost; g.mx = p.max_boost; g.d = nullptr;
+  const host::OetfBuckets b = host::gain_code8_buckets(p.min_boost, p.max_boost, p.log2min, p.log2_range, p.log2_range_rcp);
+  UHDR_TRY(upload_step_table(b, &g.d, &g.meta, c->stream));
+  c->gain_tabs.push_back(g);
+  *out = g.meta;
+  return ok_status();
+}
+
 uhdr_error_info_t select_hdr_lut(uhdr_hip_ctx* c, uhdr_color_transfer_t ct, const float** lut, int* n) {
   *lut = nullptr;
   *n = 0;
@@ -443,6 +483,9 @@ void uhdr_hip_destroy(uhdr_hip_ctx_t* c) {
   if (c->minmax.p) (void)hipFree(c->minmax.p);
   if (c->d_coef_src) (void)hipFree(c->d_coef_src);
   if (c->d_huff) (void)hipFree(c->d_huff);
+  if (c->d_srgb8) (void)hipFree(c->d_srgb8);
+  for (float* q : c->d_lin10) if (q) (void)hipFree(q);
+  for (auto& g : c->gain_tabs) if (g.d) (void)hipFree(g.d);
   uhdr_hip_comm_destroy(c);
   if (c->exchange.p) (void)hipFree(c->exchange.p);
   if (c->h_mm) (void)hipHostFree(c->h_mm);
@@ -950,6 +993,7 @@ uhdr_error_info_t uhdr_hip_generate_gainmap_dev(uhdr_hip_ctx_t* c, const uhdr_ra
     p.log2max = log2f(md->max_content_boost[0]);
     p.log2_range = (double)(p.log2max - p.log2min);
     p.log2_range_rcp = 1.0 / p.log2_range;
+    UHDR_TRY(gain_step_table(c, p, &p.gain8));
     p.out = (uint8_t*)gm->planes[0];
     p.out_stride = gm->stride[0];
     ProfScope ps(c, "generate_gainmap");
@@ -1140,6 +1184,18 @@ static uhdr_error_info_t fill_tone_map_params(uhdr_hip_ctx* c, const uhdr_raw_im
   UHDR_TRY(select_hdr_lut(c, hdr->ct, &p.hdr_inv_lut, &p.hdr_inv_n));
   UHDR_TRY(upload_math(c));
   p.math_tab = c->d_math;
+  if (!c->srgb8_meta.tab && !c->d_srgb8) UHDR_TRY(upload_step_table(host::srgb_code8_buckets(), &c->d_srgb8, &c->srgb8_meta, c->stream));
+  p.srgb8 = c->srgb8_meta;
+  if (hdr->fmt == UHDR_IMG_FMT_32bppRGBA1010102 && (int)hdr->ct >= 0 && (int)hdr->ct < 5) {
+    if (!c->d_lin10[hdr->ct]) {
+      const std::vector<float>* src = nullptr;
+      if (hdr->ct == UHDR_CT_HLG) src = &host::hlg_inv_oetf_ootf_lut();
+      else if (hdr->ct == UHDR_CT_PQ) src = &host::pq_inv_oetf_lut();
+      else if (hdr->ct == UHDR_CT_SRGB) src = &host::srgb_inv_oetf_lut();
+      UHDR_TRY(upload_lut(&c->d_lin10[hdr->ct], host::lin10_table(src ? src->data() : nullptr, src ? (int)src->size() : 0), c->stream));
+    }
+    p.lin10 = c->d_lin10[hdr->ct];
+  }
   p.hdr_is_rgb = is_rgb_fmt_host(hdr->fmt);
   p.is_normalized = hdr->ct != UHDR_CT_LINEAR;
   p.headroom = host::reference_peak_nits(hdr->ct) / 203.0f;
@@ -1319,6 +1375,33 @@ int uhdr_hip_exact_math_eval(int fn, const float* in, float* out, size_t n) {
   return 0;
 }
 
+int uhdr_hip_step_table_eval(int which, float a, float b, const float* in, uint32_t* out, size_t n, uint32_t info[4]) {
+  host::OetfBuckets tmp;
+  const host::OetfBuckets* t = nullptr;
+  if (which == 0) t = &host::srgb_code8_buckets();
+  else if (which == 1) {
+    const float l2min = log2f(a), l2max = log2f(b);
+    const double range = (double)(l2max - l2min);
+    tmp = host::gain_code8_buckets(a, b, l2min, range, 1.0 / range);
+    t = &tmp;
+  } else if (which == 2 || which == 3) t = &host::oetf_code_buckets(which == 2 ? UHDR_CT_HLG : UHDR_CT_PQ);
+  if (!t) return -1;
+  if (info) { info[0] = t->exact ? 1u : 0u; info[1] = t->n; info[2] = t->shift; info[3] = t->base; }
+  if (!t->exact) return 1;
+  for (size_t i = 0; i < n; i++) {  // the kernels' step_code / oetf_code_bucket, on the host
+    uint32_t bits;
+    memcpy(&bits, &in[i], 4);
+    int ib = (int)bits;
+    ib = ib < (int)t->lo_bits ? (int)t->lo_bits : (ib > (int)t->hi_bits ? (int)t->hi_bits : ib);
+    const uint32_t u = (uint32_t)ib;
+    uint32_t off = (u >> (t->shift - 3)) & ~7u;
+    off = off > t->base * 8 ? off - t->base * 8 : 0u;
+    const uint32_t thr = t->entries[off / 4], cc = t->entries[off / 4 + 1];
+    out[i] = u >= thr ? cc >> 16 : cc & 0xffffu;
+  }
+  return 0;
+}
+
 uhdr_error_info_t uhdr_hip_fdct_quant_dev(uhdr_hip_ctx_t* c, const uint8_t* plane, size_t stride, int bw, int bh,
                                           const uint16_t qt[64], int16_t* coef) {
   if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
@@ -1440,6 +1523,7 @@ uhdr_error_info_t uhdr_hip_encode_api0_fused_dev(uhdr_hip_ctx_t* c, const uhdr_r
     p.gen.log2max = log2f(md->max_content_boost[0]);
     p.gen.log2_range = (double)(p.gen.log2max - p.gen.log2min);
     p.gen.log2_range_rcp = 1.0 / p.gen.log2_range;
+    UHDR_TRY(gain_step_table(c, p.gen, &p.gen.gain8));
     p.gen.out = (uint8_t*)gm->planes[0];
     p.gen.out_stride = gm->stride[0];
     ProfScope ps(c, "encode_api0_fused");

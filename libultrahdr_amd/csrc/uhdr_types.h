@@ -44,6 +44,13 @@ constexpr int kInvOetfN = 4096;
 // quad kernel: the HLG / PQ output-code step function as a bucket table in LDS (host_tables.cpp: make_bucket_table)
 constexpr int kOetfBucketShiftHlg = 15, kOetfBucketShiftPq = 16;
 constexpr int kOetfBucketsHlg = 5376, kOetfBucketsPq = 2304;  // LDS capacity in entries (42 / 18 KiB); the host checks n <= capacity
+// encode kernels: step tables (sRGB byte of the tone mapper, encodeGain's byte) in the same {thr, lo | hi << 16} form
+constexpr int kStepTabMax = 2048;  // entries (16 KiB of LDS each)
+struct StepTab {
+  const uint2* tab;  // null: not available for this call (the kernels then run the float64 evaluation)
+  uint32_t n, base8, shm3;  // entries, first bucket * 8, shift - 3
+  uint32_t lo_bits, hi_bits;
+};
 constexpr int kMaxIdwScaleLds = 8;  // idw tables up to 4*8*8*4 floats = 4 KiB live in LDS
 
 struct ApplyTables {  // layout of the device table block, in floats
@@ -107,6 +114,8 @@ struct GenParams {
   const float* hdr_inv_lut;  // 4096 (HLG with the OOTF folded in / PQ) or 1024 (sRGB) or null (linear)
   int hdr_inv_n;
   const double* math_tab;    // exact_math.h tables (kMathTabDoubles)
+  const float* lin10;        // RGBA1010102 HDR at scale 1: 10-bit code -> linear value, 1024 floats; else null
+  StepTab gain8;             // one pass, gamma 1: clamped gain -> map byte
   int sdr_is_rgb, hdr_is_rgb;
   int sdr_gamut_on, hdr_gamut_on;
   Mat3 sdr_gamut, hdr_gamut;
@@ -156,6 +165,8 @@ struct ToneMapParams {
   const float* hdr_inv_lut;  // as in GenParams
   int hdr_inv_n;
   const double* math_tab;    // exact_math.h tables (kMathTabDoubles)
+  const float* lin10;        // RGBA1010102 input: 10-bit code -> linear value (unpack + inverse OETF [+ OOTF]), 1024 floats; else null
+  StepTab srgb8;             // RGBA8888 output: clamped linear value -> sRGB byte
   int hdr_is_rgb, is_normalized;
   float headroom, headroom_sq, headroom_sq_rcp;  // hdr_white / 203, its square (float product) and 1 / square
   int gamut_on;

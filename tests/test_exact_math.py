@@ -135,3 +135,64 @@ def test_shared_divisor_division_is_exact():
     out = np.empty_like(buf)
     assert lib.uhdr_hip_exact_math_eval(4, buf.ctypes.data_as(C.POINTER(C.c_float)), out.ctypes.data_as(C.POINTER(C.c_float)), buf.size) == 0
     assert np.array_equal(out[0::2].view(np.uint32), (a / b).view(np.uint32))
+
+
+# ---- step tables (csrc/host_tables.cpp: build_step_table) -------------------------------------------------------------
+def _step_eval(which, a, b, x):
+    import ctypes as C
+
+    lib = A.load()
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty(x.size, dtype=np.uint32)
+    info = (C.c_uint32 * 4)()
+    rc = lib.uhdr_hip_step_table_eval(which, C.c_float(a), C.c_float(b), x.ctypes.data, out.ctypes.data, x.size, info)
+    return rc, out, list(info)
+
+
+def _around_every_float_step(lo, hi, n_random, seed):
+    """Random floats of [lo, hi] plus both neighbours of each (bit pattern +- 1): steps of a table sit between neighbours."""
+    rng = np.random.default_rng(seed)
+    x = (lo + rng.random(n_random, dtype=np.float32) * np.float32(hi - lo)).astype(np.float32)
+    bits = x.view(np.uint32)
+    allb = np.concatenate([bits, bits + 1, np.maximum(bits, 1) - 1])
+    v = allb.view(np.float32)
+    return v[(v >= lo) & (v <= hi)]
+
+
+def test_srgb_byte_step_table_equals_the_evaluation_it_replaces():
+    """toneMap's RGBA8888 tail through the LDS step table == put8(srgb_oetf_table(x)) for 6 M floats of [0, 1] (dense
+    near zero too), the domain ends and out-of-range inputs (the table's domain clamp is clampPixelFloat)."""
+    x = np.concatenate([_around_every_float_step(0.0, 1.0, 1_500_000, 3), _around_every_float_step(0.0, 0.01, 500_000, 4),
+                        np.array([0.0, 1.0, -0.0, -1.0, 2.0, 1e-30, 0.0031308, np.nextafter(np.float32(0.0031308), np.float32(1))], dtype=np.float32)])
+    rc, got, info = _step_eval(0, 0.0, 0.0, x)
+    assert rc == 0 and info[0] == 1, info
+    xc = np.clip(x, 0.0, 1.0).astype(np.float32)
+    want = _eval_product(0, xc) * np.float32(255.0)
+    want = np.clip(want + np.float32(0.5), 0.0, 255.0).astype(np.uint32)
+    assert np.array_equal(got, want), int((got != want).sum())
+
+
+@pytest.mark.parametrize("mn,mx", [(1.0, 1000.0 / 203.0), (1.0, 10000.0 / 203.0), (0.5, 8.0)])
+def test_encode_gain_step_table_equals_the_evaluation_it_replaces(mn, mx):
+    """encodeGain's byte (one pass, gamma 1) through the step table == (uint8)(n * 255) with n from log2_table_f64 and the
+    float64 normalisation the kernels used per sample, for 3 M gains across [min boost, max boost] and outside it."""
+    mn32, mx32 = np.float32(mn), np.float32(mx)
+    x = np.concatenate([_around_every_float_step(float(mn32), float(mx32), 1_000_000, 5),
+                        np.array([0.0, float(mn32) / 2, float(mx32) * 2, np.inf, float(mn32), float(mx32)], dtype=np.float32)])
+    rc, got, info = _step_eval(1, float(mn32), float(mx32), x)
+    assert rc == 0 and info[0] == 1, info
+    g = np.clip(x, mn32, mx32).astype(np.float32)
+    l2min, l2max = np.float32(np.log2(mn32)), np.float32(np.log2(mx32))
+    rng_ = np.float64(np.float32(l2max - l2min))
+    pass
+    # the table is built from the float64 log2 (not its float narrowing); compare through a float64 log2 that is exact to
+    # well below the float64 -> float rounding of n: allow no more than the rare sample where that narrowing matters
+    n = ((np.log2(g.astype(np.float64)) - np.float64(l2min)) / rng_).astype(np.float32)
+    want = (n * np.float32(255.0)).astype(np.uint32) & 0xff
+    assert (got != want).mean() < 1e-5, int((got != want).sum())
+    assert np.abs(got.astype(np.int64) - want.astype(np.int64)).max() <= 1
+
+
+def test_a_boost_range_too_dense_for_the_table_is_reported_not_exact():
+    rc, _, info = _step_eval(1, 1.0, 1.0 + 2.0 ** -10, np.array([1.0], dtype=np.float32))
+    assert rc == 1 and info[0] == 0
