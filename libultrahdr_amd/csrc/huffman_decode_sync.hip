@@ -1,0 +1,451 @@
+// Baseline Huffman decoding of a scan WITHOUT restart markers on gfx950 -- every file the reference writes
+// (/root/reference/lib/src/jpegencoderhelper.cpp:187-201 never sets restart_interval), i.e. what libjpeg's
+// decode_mcu_huff (jdhuff.c) walks bit-serially behind JpegDecoderHelper::decompressImage
+// (lib/src/jpegdecoderhelper.cpp:169-535).  One entropy-coded segment has no byte-aligned entry points, but Huffman
+// codes re-synchronise: a decoder started at an arbitrary bit soon falls in step with the true one.  The classic
+// self-synchronising parallel decode (Klein & Wiseman 2003; Weissenberger & Schmidt 2018 / 2021 for JPEG) in five steps,
+// all on the device:
+//   1. unstuff: drop the 0x00 after every 0xFF (count per 4 KiB chunk -> scan -> compact), so that positions are plain
+//      bit indices;
+//   2. the clean stream is cut into subsequences of S bits, one lane each.  A lane's decoder state is
+//      (bit position, block within the MCU, zig-zag index).  Round 0: every lane starts at the first bit of its
+//      subsequence in state (0, 0) -- right for lane 0 only -- decodes to the first symbol boundary at or beyond the end
+//      of its subsequence and publishes that END state;
+//   3. rounds 1..: lane i restarts from lane i-1's published end state; if its new end state equals the one it published
+//      before, everything downstream of it is unchanged.  Only lanes whose predecessor changed run; a fixed point is
+//      reached after (longest unsynchronised chain) rounds -- typically 2-4 -- and is, by induction from lane 0, the
+//      true decode.  Each lane also counts the blocks it completed;
+//   4. exclusive scan of the block counts = the index of the block a lane starts in; the lanes decode once more, now
+//      storing coefficients (natural order, into zero-initialised JBLOCK arrays) and the DC DIFFERENCE of every block
+//      in scan order;
+//   5. the DC predictions (a running sum per component over the scan order, dummy blocks of edge MCUs included) are one
+//      workgroup-wide scan per component.
+// Malformed streams (undefined code, run past the end of a block) only count as errors in step 4, where every lane is
+// on the true path; steps 2-3 treat them as ordinary (deterministic) state transitions of a decoder that is lost.
+#include "uhdr_types.h"
+
+namespace uhdr {
+namespace {
+
+constexpr int kChunk = 4096;   // bytes per workgroup of the unstuff passes (256 threads x 16 bytes)
+constexpr int kSyncBlock = 64; // one wave per workgroup: a wave's lanes decode neighbouring subsequences
+
+__device__ __forceinline__ bool is_stuffed(const uint8_t* __restrict__ d, uint32_t i) { return i > 0 && d[i] == 0 && d[i - 1] == 0xffu; }
+
+__global__ __launch_bounds__(256) void unstuff_count_kernel(const uint8_t* __restrict__ data, uint32_t n, uint32_t* __restrict__ counts) {
+  __shared__ uint32_t s_cnt;
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  const uint32_t base = blockIdx.x * kChunk + threadIdx.x * 16;
+  uint32_t c = 0;
+  for (uint32_t i = base; i < base + 16 && i < n; i++) c += is_stuffed(data, i) ? 1u : 0u;
+  if (c) atomicAdd(&s_cnt, c);
+  __syncthreads();
+  if (threadIdx.x == 0) counts[blockIdx.x] = s_cnt;
+}
+// single workgroup: counts[nchunks] -> exclusive prefix sums in place, total -> *total
+__global__ __launch_bounds__(1024) void sync_scan_kernel(uint32_t* __restrict__ counts, int n, uint32_t* __restrict__ total) {
+  __shared__ uint32_t s_sum[1024];
+  const int tid = (int)threadIdx.x;
+  const int per = (n + 1023) / 1024, lo = min(tid * per, n), hi = min(lo + per, n);
+  uint32_t sum = 0;
+  for (int i = lo; i < hi; i++) sum += counts[i];
+  s_sum[tid] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const uint32_t y = tid >= d ? s_sum[tid - d] : 0u;
+    __syncthreads();
+    s_sum[tid] += y;
+    __syncthreads();
+  }
+  uint32_t run = s_sum[tid] - sum;
+  for (int i = lo; i < hi; i++) {
+    const uint32_t c = counts[i];
+    counts[i] = run;
+    run += c;
+  }
+  if (tid == 1023 && total) *total = s_sum[1023];
+}
+__global__ __launch_bounds__(256) void unstuff_compact_kernel(const uint8_t* __restrict__ data, uint32_t n, const uint32_t* __restrict__ chunk_base,
+                                                              uint8_t* __restrict__ clean) {
+  __shared__ uint32_t s_scan[256];
+  const uint32_t tid = threadIdx.x, base = blockIdx.x * kChunk + tid * 16;
+  uint32_t c = 0;
+  for (uint32_t i = base; i < base + 16 && i < n; i++) c += is_stuffed(data, i) ? 1u : 0u;
+  s_scan[tid] = c;
+  __syncthreads();
+  for (uint32_t d = 1; d < 256; d <<= 1) {
+    const uint32_t y = tid >= d ? s_scan[tid - d] : 0u;
+    __syncthreads();
+    s_scan[tid] += y;
+    __syncthreads();
+  }
+  uint32_t dropped = chunk_base[blockIdx.x] + s_scan[tid] - c;  // stuffed bytes before this thread's first byte
+  for (uint32_t i = base; i < base + 16 && i < n; i++) {
+    if (is_stuffed(data, i)) dropped++;
+    else clean[i - dropped] = data[i];
+  }
+}
+
+// ---- the decoder --------------------------------------------------------------------------------------------------
+// A wave stages the 64 subsequences of its lanes (+ 16 bytes of the next one) in LDS with coalesced 16-byte loads; every
+// lane then reads ITS bytes from LDS, 32 bits at a time -- a decode step never waits for global memory.  A lane's chunk
+// is padded by one word so that the lanes' simultaneous reads fall into different banks.
+struct Staged {
+  const uint32_t* w;   // the wave's LDS region, as words
+  uint32_t cshift;     // log2(bytes per subsequence)
+  __device__ __forceinline__ uint32_t word(uint32_t byte_off) const {  // byte_off: multiple of 4, relative to the region
+    const uint32_t chunk = byte_off >> cshift, in = byte_off & ((1u << cshift) - 1u);
+    return __builtin_bswap32(w[chunk * ((1u << (cshift - 2)) + 1u) + (in >> 2)]);
+  }
+};
+struct Bits {  // MSB-first reader over a staged region; region_bit = global bit index of the region's first bit
+  Staged st;
+  uint32_t region_bit, next;  // next: byte offset (relative, multiple of 4) of the next word to load
+  uint64_t acc;
+  int n;
+  __device__ __forceinline__ void seek(uint32_t bit) {
+    const uint32_t rel = bit - region_bit;
+    next = (rel >> 5) << 2;
+    acc = 0;
+    n = 0;
+    fill();
+    fill();
+    n -= (int)(rel & 31u);
+  }
+  __device__ __forceinline__ void fill() {
+    if (n <= 32) {
+      acc = (acc << 32) | st.word(next);
+      next += 4;
+      n += 32;
+    }
+  }
+  __device__ __forceinline__ uint32_t pos() const { return region_bit + next * 8u - (uint32_t)n; }
+  __device__ __forceinline__ uint32_t peek(int k) const { return (uint32_t)(acc >> (n - k)) & ((1u << k) - 1u); }
+  __device__ __forceinline__ void skip(int k) { n -= k; }
+};
+// stage bytes [first, first + 64 * cb + 16) of the clean stream (zeros past its end) into the wave's LDS region
+__device__ __forceinline__ void stage_wave(const uint8_t* __restrict__ clean, uint32_t nclean, uint32_t first, uint32_t cshift, uint32_t* lds,
+                                           uint32_t lane) {
+  const uint32_t cb = 1u << cshift, total = 64u * cb + 16u, pitch = (cb >> 2) + 1u;
+  for (uint32_t off = lane * 16u; off < total; off += 64u * 16u) {
+    const uint32_t g = first + off;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (g + 16u <= nclean && ((uintptr_t)(clean + g) & 15u) == 0) {
+      v = *(const uint4*)(clean + g);
+    } else {
+      uint32_t t[4] = {0, 0, 0, 0};
+      for (uint32_t k = 0; k < 16; k++)
+        if (g + k < nclean) t[k >> 2] |= (uint32_t)clean[g + k] << (8 * (k & 3));
+      v = make_uint4(t[0], t[1], t[2], t[3]);
+    }
+    const uint32_t chunk = off >> cshift, in = off & (cb - 1u);
+    uint32_t* d = lds + chunk * pitch + (in >> 2);
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+}
+
+// One decode step: a Huffman code (two-level table: 9 bits, then 7 more for the long codes) and its magnitude bits.
+// Written without data-dependent branches -- the 64 lanes of a wave are in 64 different places of 64 different blocks,
+// and every branch would be paid by all of them.  k == 0 is the DC step (symbol = size category), k > 0 an AC step
+// (symbol = run << 4 | size).  Returns the coefficient value and where it goes; k is advanced (64 = block finished).
+struct Step {
+  int value;
+  uint32_t zzpos;
+  bool store, is_dc, bad;
+};
+__device__ __forceinline__ Step decode_step(Bits& r, const HuffFastTable* tabs, uint32_t comp, uint32_t& k) {
+  const bool is_dc = k == 0;
+  const HuffFastTable& t = tabs[(comp ? 2u : 0u) + (is_dc ? 0u : 1u)];
+  const uint32_t w16 = r.peek(16);
+  uint32_t e = t.l1[w16 >> 7];
+  if (__builtin_amdgcn_ballot_w64((e & 0x8000u) != 0) != 0) {  // some lane holds a code longer than 9 bits
+    const uint32_t e2 = t.l2[(e & 0x8000u) ? (e & 31u) : 0u][w16 & 127u];
+    e = (e & 0x8000u) ? e2 : e;
+  }
+  Step o;
+  o.bad = e == 0;
+  const uint32_t len = o.bad ? 16u : (e >> 8) & 31u, rs = o.bad ? 0u : e & 255u;
+  r.skip((int)len);
+  uint32_t s = is_dc ? rs : rs & 15u;
+  const uint32_t run = is_dc ? 0u : rs >> 4;
+  if (s > 15u) { o.bad = true; s = 0; }  // a DC size category beyond 15
+  r.fill();
+  const int raw = s ? (int)r.peek((int)s) : 0;
+  r.skip((int)s);
+  o.value = (s && raw < (1 << (s - 1))) ? raw - (1 << s) + 1 : raw;  // HUFF_EXTEND
+  o.is_dc = is_dc;
+  const bool marker = !is_dc && s == 0;  // EOB or ZRL
+  const uint32_t k2 = k + run;
+  const bool over = !marker && k2 > 63u;
+  o.bad = o.bad || over;
+  o.zzpos = k2 & 63u;
+  o.store = !marker && !over && !is_dc;
+  k = marker ? (run == 15u ? k + 16u : 64u) : (over ? 64u : k2 + 1u);
+  return o;
+}
+
+__device__ __forceinline__ uint64_t pack_state(uint32_t p, uint32_t b, uint32_t k) { return (uint64_t)p | ((uint64_t)b << 32) | ((uint64_t)k << 40); }
+
+// per-workgroup constants of the scan layout, in LDS
+struct ScanLds {
+  HuffFastTable t[4];
+  uint8_t zz[64];
+  uint8_t comp[16], yo[16], xo[16];  // block inside the MCU -> component, row / column of the block inside the component's MCU tile
+  int vs[4], hs[4], bw[4], bh[4];
+  int16_t* coef[4];
+};
+__device__ __forceinline__ void load_scan_lds(const HuffSyncArgs& a, ScanLds& L) {
+  const uint32_t* src = (const uint32_t*)a.ftabs;
+  uint32_t* dst = (uint32_t*)L.t;
+  for (uint32_t i = threadIdx.x; i < sizeof(HuffFastTable) * 4 / 4; i += kSyncBlock) dst[i] = src[i];
+  L.zz[threadIdx.x] = a.zigzag[threadIdx.x];
+  if (threadIdx.x < 16) {
+    const int j = (int)threadIdx.x;
+    int c = a.comp_of[j];
+    if (c >= a.ncomp) c = 0;
+    const int jj = j - a.first_blk[c];
+    L.comp[j] = (uint8_t)c;
+    L.yo[j] = (uint8_t)(jj >= 0 ? jj / a.hs[c] : 0);
+    L.xo[j] = (uint8_t)(jj >= 0 ? jj % a.hs[c] : 0);
+  }
+  if (threadIdx.x < 3) {
+    const int c = (int)threadIdx.x;
+    L.vs[c] = a.vs[c]; L.hs[c] = a.hs[c]; L.bw[c] = a.bw[c]; L.bh[c] = a.bh[c]; L.coef[c] = a.coef[c];
+  }
+}
+
+// Decodes from state (p, b, k) to the first symbol boundary at or beyond end_bit.  WRITE: store coefficients / DC
+// differences for the blocks [blk, total_blocks) and flag malformed data; else just track the state.
+template <bool WRITE>
+__device__ __forceinline__ void run_span(const HuffSyncArgs& a, const Staged& st, uint32_t region_bit, const ScanLds& L, uint32_t& p, uint32_t& b,
+                                         uint32_t& k, uint32_t end_bit, uint32_t& nblk, uint32_t blk) {
+  Bits r;
+  r.st = st;
+  r.region_bit = region_bit;
+  r.seek(p);
+  bool bad = false;
+  const uint32_t bpm = (uint32_t)a.blocks_per_mcu;
+  // WRITE: the block's position, tracked incrementally (MCU column / row, block inside the MCU)
+  int mx = 0, my = 0;
+  int16_t* dst = nullptr;
+  auto locate = [&]() {  // the JBLOCK of the current block, nullptr for a dummy block of an edge MCU
+    const int c = L.comp[b];
+    const int by = my * L.vs[c] + L.yo[b], bx = mx * L.hs[c] + L.xo[b];
+    dst = (by < L.bh[c] && bx < L.bw[c]) ? L.coef[c] + ((size_t)by * L.bw[c] + bx) * 64 : nullptr;
+  };
+  if (WRITE) {
+    const uint32_t m = blk / bpm;
+    my = (int)(m / (uint32_t)a.mcus_per_row);
+    mx = (int)(m - (uint32_t)my * (uint32_t)a.mcus_per_row);
+    locate();
+  }
+  while (r.pos() < end_bit && (!WRITE || blk < a.total_blocks)) {
+    r.fill();
+    const Step o = decode_step(r, L.t, L.comp[b], k);
+    bad = bad || o.bad;
+    if (WRITE) {
+      if (o.is_dc) a.dcd[blk] = o.value;
+      if (o.store && dst) dst[L.zz[o.zzpos]] = (int16_t)o.value;
+    }
+    if (k >= 64u) {
+      k = 0;
+      b++;
+      nblk++;
+      blk++;
+      if (b == bpm) {
+        b = 0;
+        if (WRITE) {
+          mx++;
+          if (mx == a.mcus_per_row) { mx = 0; my++; }
+        }
+      }
+      if (WRITE) locate();
+    }
+  }
+  p = r.pos();
+  if (WRITE && bad) atomicOr(a.flags + 1, 2u);
+}
+
+// rounds of step 2 / 3.  state[cur] is read, state[cur ^ 1] written; changed[] likewise.  flags[4 + r % 3] counts the
+// changes of round r; a round clears the counter of the round after it.
+__global__ __launch_bounds__(kSyncBlock) void sync_round_kernel(const HuffSyncArgs a, int round) {
+  extern __shared__ uint32_t s_stage[];
+  __shared__ ScanLds L;
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.flags[4 + (round + 1) % 3] = 0;  // always: also a round that returns early
+  if (round > 0 && a.flags[4 + (round - 1) % 3] == 0) return;  // the previous round changed nothing: fixed point reached
+  const uint32_t i = blockIdx.x * kSyncBlock + threadIdx.x;
+  const uint32_t nclean = a.nbytes - *a.nstuffed, nbits = nclean * 8u;
+  const uint32_t nsub = (nbits + a.sub_bits - 1) / a.sub_bits;
+  const int cur = round & 1;
+  const uint64_t* sin = a.state[cur];
+  uint64_t* sout = a.state[cur ^ 1];
+  const uint8_t* cin = a.changed[cur];
+  uint8_t* cout = a.changed[cur ^ 1];
+  // does any lane of this wave have work?  (round > 0: only lanes whose predecessor's end state changed)
+  bool active = i < nsub && (round == 0 || (i > 0 && cin[i - 1]));
+  if (__builtin_amdgcn_ballot_w64(active) == 0) {
+    if (i < nsub) { sout[i] = sin[i]; cout[i] = 0; }
+    return;
+  }
+  load_scan_lds(a, L);
+  const uint32_t cshift = 31u - (uint32_t)__builtin_clz(a.sub_bits >> 3);
+  const uint32_t first_byte = blockIdx.x * kSyncBlock * (a.sub_bits >> 3);
+  stage_wave(a.clean, nclean, first_byte, cshift, s_stage, threadIdx.x);
+  __syncthreads();
+  if (i >= nsub) return;
+  if (!active) {  // my start state is what it was: so is my end state
+    sout[i] = sin[i];
+    cout[i] = 0;
+    return;
+  }
+  uint32_t p, b, k;
+  if (round == 0) {
+    p = i * a.sub_bits; b = 0; k = 0;
+  } else {
+    const uint64_t s = sin[i - 1];
+    p = (uint32_t)s; b = (uint32_t)(s >> 32) & 0xffu; k = (uint32_t)(s >> 40) & 0xffu;
+  }
+  const uint32_t end_bit = min((i + 1) * a.sub_bits, nbits);
+  uint32_t nblk = 0;
+  const Staged st = {s_stage, cshift};
+  if (p < end_bit) run_span<false>(a, st, first_byte * 8u, L, p, b, k, end_bit, nblk, 0);
+  const uint64_t e = pack_state(p, b, k);
+  const bool ch = round == 0 || e != sin[i];
+  sout[i] = e;
+  cout[i] = ch ? 1 : 0;
+  a.nblk[i] = nblk;
+  if (ch) atomicAdd(a.flags + 4 + round % 3, 1u);
+}
+
+__global__ __launch_bounds__(kSyncBlock) void sync_write_kernel(const HuffSyncArgs a, int final_buf) {
+  extern __shared__ uint32_t s_stage[];
+  __shared__ ScanLds L;
+  load_scan_lds(a, L);
+  const uint32_t i = blockIdx.x * kSyncBlock + threadIdx.x;
+  const uint32_t nclean = a.nbytes - *a.nstuffed, nbits = nclean * 8u;
+  const uint32_t nsub = (nbits + a.sub_bits - 1) / a.sub_bits;
+  const uint32_t cshift = 31u - (uint32_t)__builtin_clz(a.sub_bits >> 3);
+  const uint32_t first_byte = blockIdx.x * kSyncBlock * (a.sub_bits >> 3);
+  stage_wave(a.clean, nclean, first_byte, cshift, s_stage, threadIdx.x);
+  __syncthreads();
+  if (i >= nsub) return;
+  uint32_t p = 0, b = 0, k = 0;
+  if (i > 0) {
+    const uint64_t s = a.state[final_buf][i - 1];
+    p = (uint32_t)s; b = (uint32_t)(s >> 32) & 0xffu; k = (uint32_t)(s >> 40) & 0xffu;
+  }
+  const uint32_t end_bit = min((i + 1) * a.sub_bits, nbits);
+  uint32_t nblk = 0;
+  const Staged st = {s_stage, cshift};
+  if (p < end_bit) run_span<true>(a, st, first_byte * 8u, L, p, b, k, end_bit, nblk, a.nblk[i]);  // nblk[] holds the exclusive scan by now
+  if (i == nsub - 1) {
+    // the scan must hold exactly total_blocks blocks: fewer = truncated data, more cannot be seen (the loop stops there)
+    if (a.nblk[i] + nblk < a.total_blocks) atomicOr(a.flags + 1, 8u);
+  }
+}
+
+// step 5: DC prediction = running sum of the differences over the component's blocks in scan order, as a three-kernel
+// scan over chunks of 1024 scan positions (per-chunk sums per component -> scan of the chunk sums -> rescan + store).
+__device__ __forceinline__ void dc_block_scan(int v[3], int* s_sum /* 3 x 1024 */, int tid) {
+#pragma unroll
+  for (int c = 0; c < 3; c++) s_sum[c * 1024 + tid] = v[c];
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    int y[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) y[c] = tid >= d ? s_sum[c * 1024 + tid - d] : 0;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 3; c++) s_sum[c * 1024 + tid] += y[c];
+    __syncthreads();
+  }
+#pragma unroll
+  for (int c = 0; c < 3; c++) v[c] = s_sum[c * 1024 + tid];  // inclusive
+}
+__global__ __launch_bounds__(1024) void dc_partial_kernel(const HuffSyncArgs a, int* __restrict__ partial) {
+  __shared__ int s_sum[3 * 1024];
+  const int tid = (int)threadIdx.x;
+  const uint32_t t = blockIdx.x * 1024u + (uint32_t)tid;
+  int v[3] = {0, 0, 0};
+  if (t < a.total_blocks) v[a.comp_of[t % (uint32_t)a.blocks_per_mcu]] = a.dcd[t];
+  dc_block_scan(v, s_sum, tid);
+  if (tid == 1023) { partial[blockIdx.x * 3] = v[0]; partial[blockIdx.x * 3 + 1] = v[1]; partial[blockIdx.x * 3 + 2] = v[2]; }
+}
+__global__ __launch_bounds__(1024) void dc_scan_partials_kernel(int* __restrict__ partial, int nchunks) {  // exclusive, in place
+  __shared__ int s_sum[3 * 1024];
+  const int tid = (int)threadIdx.x;
+  const int per = (nchunks + 1023) / 1024, lo = min(tid * per, nchunks), hi = min(lo + per, nchunks);
+  int v[3] = {0, 0, 0};
+  for (int i = lo; i < hi; i++)
+    for (int c = 0; c < 3; c++) v[c] += partial[i * 3 + c];
+  int own[3] = {v[0], v[1], v[2]};
+  dc_block_scan(v, s_sum, tid);
+  int run[3] = {v[0] - own[0], v[1] - own[1], v[2] - own[2]};
+  for (int i = lo; i < hi; i++)
+    for (int c = 0; c < 3; c++) {
+      const int x = partial[i * 3 + c];
+      partial[i * 3 + c] = run[c];
+      run[c] += x;
+    }
+}
+__global__ __launch_bounds__(1024) void dc_apply_kernel(const HuffSyncArgs a, const int* __restrict__ partial) {
+  __shared__ int s_sum[3 * 1024];
+  const int tid = (int)threadIdx.x;
+  const uint32_t t = blockIdx.x * 1024u + (uint32_t)tid;
+  const uint32_t bpm = (uint32_t)a.blocks_per_mcu;
+  int v[3] = {0, 0, 0};
+  int c = 0;
+  uint32_t m = 0, j = 0;
+  if (t < a.total_blocks) {
+    m = t / bpm;
+    j = t - m * bpm;
+    c = a.comp_of[j];
+    v[c] = a.dcd[t];
+  }
+  dc_block_scan(v, s_sum, tid);
+  if (t >= a.total_blocks) return;
+  const int dc = partial[blockIdx.x * 3 + c] + v[c];
+  const int my = (int)(m / (uint32_t)a.mcus_per_row), mx = (int)(m - (uint32_t)my * (uint32_t)a.mcus_per_row);
+  const int jj = (int)j - a.first_blk[c];
+  const int by = my * a.vs[c] + jj / a.hs[c], bx = mx * a.hs[c] + jj % a.hs[c];
+  if (by < a.bh[c] && bx < a.bw[c]) a.coef[c][((size_t)by * a.bw[c] + bx) * 64] = (int16_t)dc;
+}
+
+}  // namespace
+
+int huff_sync_chunks(uint64_t nbytes) { return (int)((nbytes + kChunk - 1) / kChunk); }
+
+// Step 1 (unstuff): chunk_counts becomes the exclusive scan, *nstuffed_dev the number of dropped bytes.
+hipError_t launch_huffman_unstuff(const uint8_t* data, uint32_t nbytes, uint32_t* chunk_counts, uint32_t* nstuffed_dev, uint8_t* clean, hipStream_t s) {
+  const int nchunks = huff_sync_chunks(nbytes);
+  hipLaunchKernelGGL(unstuff_count_kernel, dim3(nchunks), dim3(256), 0, s, data, nbytes, chunk_counts);
+  hipLaunchKernelGGL(sync_scan_kernel, dim3(1), dim3(1024), 0, s, chunk_counts, nchunks, nstuffed_dev);
+  hipLaunchKernelGGL(unstuff_compact_kernel, dim3(nchunks), dim3(256), 0, s, data, nbytes, (const uint32_t*)chunk_counts, clean);
+  return hipGetLastError();
+}
+
+uint32_t huff_sync_max_subsequences(uint64_t nbytes, uint32_t sub_bits) { return (uint32_t)((nbytes * 8 + sub_bits - 1) / sub_bits); }
+
+// Steps 2-5 on the clean stream.  Its size lives on the device (nbytes - *nstuffed): the grids are sized for the stuffed
+// size, surplus lanes exit.  max_rounds bounds step 3; flags[4 + max_rounds % 3] != 0 afterwards means "not yet at the
+// fixed point" and the caller falls back to the serial decoder.  nblk[], dcd[] and flags[] must be zero-initialised;
+// dc_partial: 3 * ceil(total_blocks / 1024) ints of scratch.
+hipError_t launch_huffman_decode_sync(const HuffSyncArgs& a, int max_rounds, int* dc_partial, int* final_buf, hipStream_t s) {
+  const uint32_t nsub = huff_sync_max_subsequences(a.nbytes, a.sub_bits);
+  const int grid = (int)((nsub + kSyncBlock - 1) / kSyncBlock);
+  const size_t lds = (size_t)kSyncBlock * ((a.sub_bits >> 3) + 4) + 64;  // 64 padded chunks + the 16-byte overhang
+  for (int r = 0; r <= max_rounds; r++) hipLaunchKernelGGL(sync_round_kernel, dim3(grid), dim3(kSyncBlock), lds, s, a, r);
+  // Every executed round writes a complete state buffer; a round that finds its predecessor unchanged returns at once.
+  // At the fixed point the two buffers are equal, so either one is final.
+  *final_buf = 0;
+  hipLaunchKernelGGL(sync_scan_kernel, dim3(1), dim3(1024), 0, s, a.nblk, (int)nsub, (uint32_t*)nullptr);
+  hipLaunchKernelGGL(sync_write_kernel, dim3(grid), dim3(kSyncBlock), lds, s, a, *final_buf);
+  const int nch = (int)((a.total_blocks + 1023) / 1024);
+  hipLaunchKernelGGL(dc_partial_kernel, dim3(nch), dim3(1024), 0, s, a, dc_partial);
+  hipLaunchKernelGGL(dc_scan_partials_kernel, dim3(1), dim3(1024), 0, s, dc_partial, nch);
+  hipLaunchKernelGGL(dc_apply_kernel, dim3(nch), dim3(1024), 0, s, a, (const int*)dc_partial);
+  return hipGetLastError();
+}
+
+}  // namespace uhdr

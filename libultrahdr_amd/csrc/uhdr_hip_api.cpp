@@ -1857,6 +1857,34 @@ static bool make_dec_table(const uint8_t bits[17], const uint8_t vals[256], Huff
   return true;
 }
 
+// two-level form for the self-synchronising decoder; false when the table needs more than kHuffL2Max sub-tables
+static bool make_fast_table(const uint8_t bits[17], const uint8_t vals[256], HuffFastTable* t) {
+  memset(t, 0, sizeof *t);
+  int code = 0, k = 0, nsub = 0;
+  int sub_of[512];
+  for (int i = 0; i < 512; i++) sub_of[i] = -1;
+  for (int l = 1; l <= 16; l++) {
+    for (int i = 0; i < bits[l]; i++, k++, code++) {
+      if (code >= (1 << l) || k >= 256) return false;
+      if (l <= 9) {
+        const int lo = code << (9 - l);
+        for (int x = 0; x < (1 << (9 - l)); x++) t->l1[lo + x] = (uint16_t)((l << 8) | vals[k]);
+      } else {
+        const int prefix = code >> (l - 9);
+        if (sub_of[prefix] < 0) {
+          if (nsub >= kHuffL2Max) return false;
+          sub_of[prefix] = nsub++;
+          t->l1[prefix] = (uint16_t)(0x8000u | (unsigned)sub_of[prefix]);
+        }
+        const int rest = (code << (16 - l)) & 127;
+        for (int x = 0; x < (1 << (16 - l)); x++) t->l2[sub_of[prefix]][rest + x] = (uint16_t)((l << 8) | vals[k]);
+      }
+    }
+    code <<= 1;
+  }
+  return true;
+}
+
 uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_jpeg_scan_t* sc, const uhdr_hip_huff_tables_t* tables,
                                               const uint8_t* data, size_t data_bytes) {
   if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
@@ -1874,6 +1902,8 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
     HIP_TRY(hipStreamSynchronize(c->stream));
   }
   std::vector<HuffDecTable> tabs(4);
+  std::vector<HuffFastTable> ftabs(4);
+  bool fast_ok = true;
   for (int t = 0; t < 4; t++) {
     uint8_t bits[17], vals[256];
     if (tables) {
@@ -1883,6 +1913,7 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
       host::jpeg_std_huff_table(t & 1, t >> 1, bits, vals);
     }
     if (!make_dec_table(bits, vals, &tabs[(size_t)t])) return err_status(UHDR_CODEC_INVALID_PARAM, "Huffman table %d is not a valid DHT table", t);
+    fast_ok = make_fast_table(bits, vals, &ftabs[(size_t)t]) && fast_ok;
   }
   HuffDecArgs a;
   memset(&a, 0, sizeof a);
@@ -1917,6 +1948,74 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
   HIP_TRY(hipMemcpyAsync(base, tabs.data(), tab_bytes, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemsetAsync(a.status, 0, 16, c->stream));
   for (int i = 0; i < a.ncomp; i++) HIP_TRY(hipMemsetAsync(a.coef[i], 0, zero_bytes[i], c->stream));
+  // A scan without restart markers (every file the reference writes) is ONE interval: the per-interval kernel would
+  // decode it on a single lane.  The self-synchronising decoder (huffman_decode_sync.hip) parallelises it; should its
+  // fixed-point search not settle within the round budget (never seen; pathological streams), the serial kernel runs.
+  bool sync_done = false;
+  if (a.nseg == 1 && data_bytes >= 4096 && fast_ok && !getenv("UHDR_HIP_HUFF_SERIAL")) {
+    uint32_t sub_bits = 1024;  // a power of two >= 256 (the lanes' chunks are staged in LDS: 64 x sub_bits / 8 bytes per wave)
+    if (const char* e = getenv("UHDR_HIP_HUFF_SUB_BITS")) {
+      const int v = atoi(e);
+      if (v >= 256 && v <= 4096 && (v & (v - 1)) == 0) sub_bits = (uint32_t)v;
+    }
+    const int max_rounds = 40;
+    const int nch = huff_sync_chunks(data_bytes);
+    const uint32_t nsub = huff_sync_max_subsequences(data_bytes, sub_bits);
+    const uint32_t total_blocks = (uint32_t)a.total_mcus * (uint32_t)bpm;
+    // scratch[6]: clean | chunk counts | flags[8] | state x 2 | nblk | dcd | changed x 2
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_clean = take(data_bytes + 16), o_cnt = take((size_t)nch * 4), o_flags = take(64), o_s0 = take((size_t)nsub * 8),
+                 o_s1 = take((size_t)nsub * 8), o_nblk = take((size_t)nsub * 4 + 4), o_dcd = take((size_t)total_blocks * 4),
+                 o_c0 = take(nsub), o_c1 = take(nsub), o_dcp = take((size_t)((total_blocks + 1023) / 1024) * 12 + 16),
+                 o_ft = take(sizeof(HuffFastTable) * 4);
+    UHDR_TRY(ensure(c->scratch[6], off));
+    uint8_t* sb = (uint8_t*)c->scratch[6].p;
+    HuffSyncArgs y;
+    memset(&y, 0, sizeof y);
+    y.clean = sb + o_clean;
+    y.nbytes = (uint32_t)data_bytes;
+    y.flags = (uint32_t*)(sb + o_flags);
+    y.nstuffed = y.flags + 8;
+    y.sub_bits = sub_bits;
+    y.state[0] = (uint64_t*)(sb + o_s0); y.state[1] = (uint64_t*)(sb + o_s1);
+    y.changed[0] = sb + o_c0; y.changed[1] = sb + o_c1;
+    y.nblk = (uint32_t*)(sb + o_nblk);
+    y.dcd = (int*)(sb + o_dcd);
+    y.total_blocks = total_blocks;
+    y.blocks_per_mcu = bpm; y.ncomp = a.ncomp; y.mcus_per_row = a.mcus_per_row;
+    int j = 0;
+    for (int i = 0; i < a.ncomp; i++) {
+      y.bw[i] = a.bw[i]; y.bh[i] = a.bh[i]; y.hs[i] = a.hs[i]; y.vs[i] = a.vs[i]; y.coef[i] = a.coef[i];
+      y.first_blk[i] = j;
+      for (int k = 0; k < a.hs[i] * a.vs[i] && j < 16; k++) y.comp_of[j++] = (uint8_t)i;
+    }
+    y.ftabs = (const HuffFastTable*)(sb + o_ft);
+    y.zigzag = a.zigzag;
+    if (j == bpm && bpm <= 16) {
+      HIP_TRY(hipMemcpyAsync(sb + o_ft, ftabs.data(), sizeof(HuffFastTable) * 4, hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(hipMemsetAsync(y.flags, 0, 64, c->stream));
+      HIP_TRY(hipMemsetAsync(y.nblk, 0, (size_t)nsub * 4 + 4, c->stream));
+      HIP_TRY(hipMemsetAsync(y.dcd, 0, (size_t)total_blocks * 4, c->stream));
+      int final_buf = 0;
+      {
+        ProfScope ps(c, "huffman_decode");
+        HIP_TRY(launch_huffman_unstuff(data, (uint32_t)data_bytes, (uint32_t*)(sb + o_cnt), y.flags + 8, sb + o_clean, c->stream));
+        HIP_TRY(launch_huffman_decode_sync(y, max_rounds, (int*)(sb + o_dcp), &final_buf, c->stream));
+      }
+      uint32_t fl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      HIP_TRY(hipMemcpyAsync(fl, y.flags, sizeof fl, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      if (fl[4 + max_rounds % 3] == 0) {  // the fixed point was reached: the decode is the true one
+        if (fl[1] & 8u) return err_status(UHDR_CODEC_INVALID_PARAM, "corrupt entropy-coded data (the scan ends before its last block)");
+        if (fl[1] & 2u) return err_status(UHDR_CODEC_INVALID_PARAM, "corrupt entropy-coded data (undefined Huffman code or a run past the end of a block)");
+        sync_done = true;
+      } else {  // not settled: start over on the serial path
+        for (int i = 0; i < a.ncomp; i++) HIP_TRY(hipMemsetAsync(a.coef[i], 0, zero_bytes[i], c->stream));
+      }
+    }
+  }
+  if (sync_done) return ok_status();
   {
     ProfScope ps(c, "huffman_decode");
     HIP_TRY(launch_huffman_decode(a, counts, starts, ends, c->stream));

@@ -252,6 +252,34 @@ struct HuffDecArgs {
   const uint8_t* zigzag;
   uint32_t* status;      // [0]: 2 = bad code / block overrun, 4 = markers out of sequence; [1]: markers found
 };
+// the self-synchronising decoder for scans without restart markers (huffman_decode_sync.hip)
+constexpr int kHuffL2Max = 16;  // second-level sub-tables (one per 9-bit prefix that has longer codes; Annex K tables need 2-8)
+struct HuffFastTable {          // two-level decode form of one DHT table: 9 bits, then 7 more
+  uint16_t l1[512];             // length << 8 | symbol;  0x8000 | sub-table for a longer code;  0 = undefined
+  uint16_t l2[kHuffL2Max][128]; // length << 8 | symbol;  0 = undefined
+};
+struct HuffSyncArgs {
+  const uint8_t* clean;       // unstuffed entropy-coded bytes (device)
+  uint32_t nbytes;            // size of the STUFFED stream (upper bound of the clean size)
+  const uint32_t* nstuffed;   // device word: bytes dropped by the unstuff pass
+  uint32_t sub_bits;          // subsequence size in bits
+  uint64_t* state[2];         // end state per subsequence, double buffered: bit position | block in MCU << 32 | zig-zag index << 40
+  uint8_t* changed[2];
+  uint32_t* nblk;             // blocks completed per subsequence; later their exclusive scan
+  uint32_t* flags;            // [1]: status bits (2 bad code / run, 8 truncated); [4..6]: change counters of the rounds (r % 3); [8]: stuffed bytes
+  int* dcd;                   // DC differences of all blocks in scan order
+  uint32_t total_blocks;
+  int blocks_per_mcu, ncomp, mcus_per_row;
+  int bw[3], bh[3], hs[3], vs[3], first_blk[3];  // first_blk[c]: index of component c's first block inside an MCU
+  uint8_t comp_of[16];        // block inside the MCU -> component
+  int16_t* coef[3];           // zero-initialised JBLOCK arrays
+  const HuffFastTable* ftabs; // DC luma, AC luma, DC chroma, AC chroma
+  const uint8_t* zigzag;
+};
+int huff_sync_chunks(uint64_t nbytes);
+uint32_t huff_sync_max_subsequences(uint64_t nbytes, uint32_t sub_bits);
+hipError_t launch_huffman_unstuff(const uint8_t* data, uint32_t nbytes, uint32_t* chunk_counts, uint32_t* nstuffed_dev, uint8_t* clean, hipStream_t s);
+hipError_t launch_huffman_decode_sync(const HuffSyncArgs& a, int max_rounds, int* dc_partial, int* final_buf, hipStream_t s);
 int huff_marker_chunks(uint64_t nbytes);
 hipError_t launch_huffman_decode(const HuffDecArgs& a, uint32_t* counts, uint32_t* starts, uint32_t* ends, hipStream_t s);
 

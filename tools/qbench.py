@@ -115,6 +115,24 @@ def main():
                 samp = [(2, 2), (1, 1), (1, 1)]
                 r = [B.time_kernel(ctx, lambda: u.huffman_encode(hco, w4, h4, samp, 10, out=hout), iters=5, warm=2) / 1e3 for _ in range(REPS)]
                 report("huff4k_encode_ri10", r, 4.5 * w4 * h4, w4 * h4)
+                # a scan without restart markers, as the reference writes it: the primary image of an UltraHDR file encoded
+                # through the drop-in facade (the reference's own libjpeg Huffman coder)
+                from libultrahdr_amd import facade as FA
+                if FA.available():
+                    jpg = FA.encode(hdr.to_host(), sdr.to_host(), gpu=True)
+                    hd = u.jpeg_parse(jpg)
+                    import numpy as np
+                    sc = hd.scan
+                    data = torch.from_numpy(np.frombuffer(jpg, dtype=np.uint8)[hd.scan_offset: hd.scan_offset + hd.scan_bytes].copy()).to(dev)
+                    bits = np.frombuffer(hd.tables.bits, dtype=np.uint8).reshape(4, 17)
+                    vals = np.frombuffer(hd.tables.vals, dtype=np.uint8).reshape(4, 256)
+                    shp0 = [(sc.blocks_h[c], sc.blocks_w[c]) for c in range(3)]
+                    for env in ("", "SERIAL"):
+                        if env:
+                            os.environ["UHDR_HIP_HUFF_SERIAL"] = "1"
+                        r = [B.time_kernel(ctx, lambda: u.huffman_decode(data, shp0, sc.w, sc.h, samp, 0, tables=(bits, vals)), iters=3, warm=1) / 1e3 for _ in range(REPS)]
+                        os.environ.pop("UHDR_HIP_HUFF_SERIAL", None)
+                        report(f"huff4k_decode_ri0{'_serial_lane' if env else '_sync'} ({hd.scan_bytes} B)", r, 4.5 * w4 * h4, w4 * h4)
                 for ri in (2, 10):
                     stream = u.huffman_encode(hco, w4, h4, samp, ri, out=hout).clone()
                     shp = [tuple(t.shape[:2]) for t in hco]
