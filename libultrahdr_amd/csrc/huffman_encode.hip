@@ -88,6 +88,10 @@ __device__ __forceinline__ void walk_block(const uint32_t* dct, const uint32_t* 
 constexpr int kWordsSmall = 16;
 constexpr uint32_t kRetry = 0xFFFFFFFEu, kBadCoef = 0xFFFFFFFFu;
 
+// Short intervals: a wavefront encodes G = 64 / (blocks per interval) intervals side by side (first launch only) -- at a
+// restart interval of 2 MCUs (12 blocks at 4:2:0) five intervals share a wave instead of leaving 52 lanes idle.  The
+// groups only differ in where their bits go: every group owns an equal slice of the LDS bit buffer, bit offsets come from
+// one wave-wide scan minus the scan value in front of the group, and the pad / stuff / store steps run once per group.
 template <int WORDS, bool RETRY>
 __global__ __launch_bounds__(64) void huff_encode_kernel(const HuffArgs a) {
   __shared__ uint32_t s_tab[2 * (16 + 256)];
@@ -95,21 +99,28 @@ __global__ __launch_bounds__(64) void huff_encode_kernel(const HuffArgs a) {
   __shared__ uint32_t s_bits[kSegBlocks * WORDS + 2];
   __shared__ int s_dc[kSegBlocks];
   __shared__ int s_real[kSegBlocks];
+  __shared__ uint32_t s_gbits[kSegBlocks];  // bits of group g's interval
   __shared__ uint8_t s_zz[64];
   const uint32_t lane = threadIdx.x;
   for (uint32_t i = lane; i < 2 * (16 + 256); i += 64) s_tab[i] = a.tables[i];
   s_zz[lane] = a.zigzag[lane];
   const int bpm = a.blocks_per_mcu;
+  const int per = a.ri * bpm;                                // blocks per interval (<= 64, checked by the host)
+  const int G = (RETRY || per > 32) ? 1 : 64 / per;          // intervals per wavefront
+  const uint32_t group_words = (uint32_t)(kSegBlocks * WORDS) / (uint32_t)G;
+  const int nwseg = (a.nseg + G - 1) / G;
 
-  for (int seg = (int)blockIdx.x; seg < a.nseg; seg += (int)gridDim.x) {
-    __syncthreads();  // the previous interval's LDS contents are dead
+  for (int wseg = (int)blockIdx.x; wseg < nwseg; wseg += (int)gridDim.x) {
+    __syncthreads();  // the previous intervals' LDS contents are dead
+    // ---- which interval and which block is this lane's? ---------------------------------------------------------
+    const int g = (int)lane / per, l = (int)lane - g * per;  // group, block inside the interval
+    const int seg = wseg * G + g;
     if constexpr (RETRY) {
-      if (a.seg_bytes[seg] != kRetry) continue;  // wave-uniform
+      if (a.seg_bytes[wseg] != kRetry) continue;  // wave-uniform: G == 1, the wave's one interval is wseg
     }
-    // ---- which block is this lane's? -------------------------------------------------------------------------
-    const int mcu_local = (int)lane / bpm, k_in_mcu = (int)lane - mcu_local * bpm;
+    const int mcu_local = l / bpm, k_in_mcu = l - mcu_local * bpm;
     const int mcu = seg * a.ri + mcu_local;
-    const bool active = mcu_local < a.ri && mcu < a.total_mcus;
+    const bool active = g < G && seg < a.nseg && mcu_local < a.ri && mcu < a.total_mcus;
     int c = 0, kk = k_in_mcu;
     if (a.ncomp > 1) {
       while (c < a.ncomp - 1 && kk >= a.hs[c] * a.vs[c]) { kk -= a.hs[c] * a.vs[c]; c++; }
@@ -132,11 +143,11 @@ __global__ __launch_bounds__(64) void huff_encode_kernel(const HuffArgs a) {
     s_dc[lane] = real ? (int)(int16_t)(crow[0] & 0xffffu) : 0;
     __syncthreads();
     // dummy blocks (jctrans.c compress_output): DC of the previous block of the MCU; the first block of a component
-    // inside an MCU is always real, so the search is bounded by the component's block count
+    // inside an MCU is always real, so the search is bounded by the component's block count (and stays inside the MCU)
     int dcv = s_dc[lane];
     if (active && !real) {
       for (int d = 1; d <= 3; d++) {
-        if ((int)lane >= d && s_real[lane - d]) { dcv = s_dc[lane - d]; break; }
+        if (k_in_mcu >= d && s_real[lane - d]) { dcv = s_dc[lane - d]; break; }
       }
     }
     __syncthreads();
@@ -152,29 +163,32 @@ __global__ __launch_bounds__(64) void huff_encode_kernel(const HuffArgs a) {
     const uint32_t* act = dct + 16;
     const int diff = dcv - pred;
 
-    // ---- pass 1: code lengths -> bit offsets -----------------------------------------------------------------------
+    // ---- pass 1: code lengths -> bit offsets inside the lane's interval ---------------------------------------------------
     uint32_t len = 0, oob = 0;
     if (active) walk_block(dct, act, diff, real, crow, s_zz, oob, [&](uint32_t, uint32_t n) { len += n; });
     const uint32_t incl = wave_incl_scan(len, lane);
-    const uint32_t total_bits = (uint32_t)__shfl((int)incl, 63, 64);
-    const uint32_t off = incl - len;
-    const uint32_t cap_bits = (uint32_t)(kSegBlocks * WORDS) * 32u;
+    // every lane takes part in both shuffles (a lane that sits out cannot be read from)
+    const int first = g * per, last = min(first + per - 1, 63);
+    const uint32_t v_before = (uint32_t)__shfl((int)incl, min(max(first - 1, 0), 63), 64);
+    const uint32_t v_last = (uint32_t)__shfl((int)incl, last, 64);
+    const uint32_t before = (first > 0 && first < 64) ? v_before : 0u;
+    const uint32_t total_bits = g < G ? v_last - before : 0u;  // of this lane's interval
+    const uint32_t off = incl - len - before;
+    const uint32_t cap_bits = group_words * 32u;
     if (__builtin_amdgcn_ballot_w64(oob != 0) != 0) {  // coefficients outside the baseline range: report, do not write
-      if (lane == 0) a.seg_bytes[seg] = kBadCoef;
+      if (l == 0 && g < G && seg < a.nseg) a.seg_bytes[seg] = kBadCoef;
       continue;
     }
-    if (total_bits > cap_bits) {  // next size class (cannot happen in the worst-case class for in-range coefficients)
-      if (lane == 0) a.seg_bytes[seg] = RETRY ? kBadCoef : kRetry;
-      continue;
-    }
-    const uint32_t nwords = (total_bits + 31u) / 32u + 1u;
-    for (uint32_t i = lane; i < nwords; i += 64) s_bits[i] = 0u;
+    const bool fits = total_bits <= cap_bits;  // else: next size class (cannot happen in the worst-case class for in-range coefficients)
+    if (l == 0 && g < G) s_gbits[g] = fits ? total_bits : 0xFFFFFFFFu;
+    for (uint32_t i = lane; i < (uint32_t)(kSegBlocks * WORDS) + 2u; i += 64) s_bits[i] = 0u;
     __syncthreads();
 
-    // ---- pass 2: emit ------------------------------------------------------------------------------------------------
-    if (active) {
+    // ---- pass 2: emit into the group's slice of the bit buffer ---------------------------------------------------------------
+    const uint32_t gbase = (uint32_t)g * group_words;
+    if (active && fits) {
       uint64_t acc = 0;
-      uint32_t cnt = off & 31u, w = off >> 5;
+      uint32_t cnt = off & 31u, w = gbase + (off >> 5);
       walk_block(dct, act, diff, real, crow, s_zz, oob, [&](uint32_t code, uint32_t n) {
         acc = (acc << n) | (uint64_t)code;
         cnt += n;
@@ -186,39 +200,49 @@ __global__ __launch_bounds__(64) void huff_encode_kernel(const HuffArgs a) {
       if (cnt) atomicOr(&s_bits[w], (uint32_t)(acc << (32u - cnt)));
     }
     __syncthreads();
-    // flush_bits: fill the last partial byte with ones
-    if (lane == 0 && (total_bits & 7u)) {
+    // flush_bits: fill the last partial byte of every interval with ones
+    if (l == 0 && g < G && fits && (total_bits & 7u)) {
       const uint32_t pad = 8u - (total_bits & 7u), pos = total_bits & 31u;
-      atomicOr(&s_bits[total_bits >> 5], ((1u << pad) - 1u) << (32u - pos - pad));
+      atomicOr(&s_bits[gbase + (total_bits >> 5)], ((1u << pad) - 1u) << (32u - pos - pad));
     }
     __syncthreads();
 
-    // ---- byte stuffing + store -----------------------------------------------------------------------------------------
-    const uint32_t nbytes = (total_bits + 7u) >> 3;
-    uint8_t* dst = a.slots + (size_t)seg * a.slot_stride;
-    uint32_t carry = 0;  // 0xFF bytes before this chunk
-    for (uint32_t base = 0; base < nbytes; base += 256) {
-      const uint32_t i0 = base + lane * 4;
-      const uint32_t wd = i0 < nbytes ? s_bits[i0 >> 2] : 0u;
-      const uint32_t nv = i0 < nbytes ? min(nbytes - i0, 4u) : 0u;
-      uint32_t b[4], nff = 0;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        b[k] = (wd >> (24 - 8 * k)) & 0xffu;
-        if ((uint32_t)k < nv && b[k] == 0xffu) nff++;
+    // ---- byte stuffing + store, one interval after the other ------------------------------------------------------------------
+    for (int gg = 0; gg < G; gg++) {
+      const int sg = wseg * G + gg;
+      if (sg >= a.nseg) break;
+      const uint32_t tb = s_gbits[gg];
+      if (tb == 0xFFFFFFFFu) {
+        if (lane == 0) a.seg_bytes[sg] = RETRY ? kBadCoef : kRetry;
+        continue;
       }
-      const uint32_t incl_ff = wave_incl_scan(nff, lane);
-      uint32_t pos = i0 + carry + (incl_ff - nff);
+      const uint32_t nbytes = (tb + 7u) >> 3;
+      const uint32_t* bits = s_bits + (uint32_t)gg * group_words;
+      uint8_t* dst = a.slots + (size_t)sg * a.slot_stride;
+      uint32_t carry = 0;  // 0xFF bytes before this chunk
+      for (uint32_t base = 0; base < nbytes; base += 256) {
+        const uint32_t i0 = base + lane * 4;
+        const uint32_t wd = i0 < nbytes ? bits[i0 >> 2] : 0u;
+        const uint32_t nv = i0 < nbytes ? min(nbytes - i0, 4u) : 0u;
+        uint32_t b[4], nff = 0;
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        if ((uint32_t)k < nv) {
-          dst[pos++] = (uint8_t)b[k];
-          if (b[k] == 0xffu) dst[pos++] = 0;
+        for (int k = 0; k < 4; k++) {
+          b[k] = (wd >> (24 - 8 * k)) & 0xffu;
+          if ((uint32_t)k < nv && b[k] == 0xffu) nff++;
         }
+        const uint32_t incl_ff = wave_incl_scan(nff, lane);
+        uint32_t pos = i0 + carry + (incl_ff - nff);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          if ((uint32_t)k < nv) {
+            dst[pos++] = (uint8_t)b[k];
+            if (b[k] == 0xffu) dst[pos++] = 0;
+          }
+        }
+        carry += (uint32_t)__shfl((int)incl_ff, 63, 64);
       }
-      carry += (uint32_t)__shfl((int)incl_ff, 63, 64);
+      if (lane == 0) a.seg_bytes[sg] = nbytes + carry;
     }
-    if (lane == 0) a.seg_bytes[seg] = nbytes + carry;
   }
 }
 
@@ -279,7 +303,9 @@ uint32_t huff_slot_stride() { return (uint32_t)(kSegBlocks * kWordsPerBlock * 4 
 
 hipError_t launch_huffman_encode(const HuffArgs& a, uint64_t* offsets, uint32_t* status, uint8_t* out, uint64_t cap, hipStream_t s) {
   int grid = a.nseg < 8192 ? a.nseg : 8192;
-  hipLaunchKernelGGL((huff_encode_kernel<kWordsSmall, false>), dim3(grid), dim3(64), 0, s, a);
+  const int per = a.ri * a.blocks_per_mcu, groups = per > 32 ? 1 : 64 / per;  // intervals per wavefront in the first launch
+  const int nwseg = (a.nseg + groups - 1) / groups;
+  hipLaunchKernelGGL((huff_encode_kernel<kWordsSmall, false>), dim3(nwseg < 8192 ? nwseg : 8192), dim3(64), 0, s, a);
   hipLaunchKernelGGL((huff_encode_kernel<kWordsPerBlock, true>), dim3(grid < 2048 ? grid : 2048), dim3(64), 0, s, a);
   hipLaunchKernelGGL(huff_offsets_kernel, dim3(1), dim3(1024), 0, s, a.seg_bytes, a.nseg, offsets, status);
   hipLaunchKernelGGL(huff_gather_kernel, dim3(grid), dim3(256), 0, s, a.slots, a.slot_stride, a.seg_bytes, offsets, a.nseg, out, cap);

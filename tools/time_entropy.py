@@ -36,7 +36,7 @@ def timed(family, fn, iters=3):
     return ms / max(n, 1) * 1e3
 
 
-for ri in (1, 2, 4, 10):
+for ri in (1, 2, 3, 4, 5, 10):
     stream = u.huffman_encode(coefs, w, h, sampling, ri, out=out).clone()
     t_enc = timed("huffman_encode", lambda: u.huffman_encode(coefs, w, h, sampling, ri, out=out))
     t_dec = timed("huffman_decode", lambda: u.huffman_decode(stream, shapes, w, h, sampling, ri))
