@@ -109,6 +109,35 @@ def jdec_cpp(t):
 EDITS["lib/src/jpegdecoderhelper.cpp"] = jdec_cpp
 
 
+# ---- editorhelper.cpp: the four effects ---------------------------------------------------------------------------------
+def editor_cpp(t):
+    t = insert_after(t, '#include "ultrahdr/editorhelper.h"\n', '#ifdef UHDR_ENABLE_HIP\n#include "uhdr_hip_seam.h"\n#endif\n')
+    def seam(call):
+        return ("#ifdef UHDR_ENABLE_HIP\n  {\n    std::unique_ptr<uhdr_raw_image_ext_t> hip_dst;\n"
+                "    if (" + call + ") return hip_dst;\n  }\n#endif\n")
+    t = insert_after(t, "std::unique_ptr<uhdr_raw_image_ext_t> apply_rotate(ultrahdr::uhdr_rotate_effect_t* desc,\n"
+                        "                                                   uhdr_raw_image_t* src,\n"
+                        "                                                   [[maybe_unused]] void* gl_ctxt,\n"
+                        "                                                   [[maybe_unused]] void* texture) {\n",
+                     seam("(desc->m_degree == 90 || desc->m_degree == 180 || desc->m_degree == 270) &&\n"
+                          "        uhdr_hip_seam::effect(0, desc->m_degree, 0, desc->m_degree == 180 ? src->w : src->h,\n"
+                          "                              desc->m_degree == 180 ? src->h : src->w, src, &hip_dst)"))
+    t = insert_after(t, "std::unique_ptr<uhdr_raw_image_ext_t> apply_mirror(ultrahdr::uhdr_mirror_effect_t* desc,\n"
+                        "                                                   uhdr_raw_image_t* src,\n"
+                        "                                                   [[maybe_unused]] void* gl_ctxt,\n"
+                        "                                                   [[maybe_unused]] void* texture) {\n",
+                     seam("uhdr_hip_seam::effect(1, (int)desc->m_direction, 0, src->w, src->h, src, &hip_dst)"))
+    t = insert_after(t, "                                                 int ht, [[maybe_unused]] void* gl_ctxt,\n"
+                        "                                                 [[maybe_unused]] void* texture) {\n",
+                     seam("uhdr_hip_seam::effect(2, left, top, wd, ht, src, &hip_dst)"))
+    t = insert_after(t, "                                                   uhdr_raw_image_t* src, int dst_w, int dst_h,\n"
+                        "                                                   [[maybe_unused]] void* gl_ctxt,\n"
+                        "                                                   [[maybe_unused]] void* texture) {\n",
+                     seam("uhdr_hip_seam::effect(3, 0, 0, dst_w, dst_h, src, &hip_dst)"))
+    return t
+EDITS["lib/src/editorhelper.cpp"] = editor_cpp
+
+
 def main():
     chunks = []
     for rel, fn in EDITS.items():

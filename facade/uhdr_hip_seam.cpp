@@ -177,6 +177,20 @@ bool idct_planes(int ncomp, const short* const coefs[3], const unsigned int bloc
   return true;
 }
 
+bool effect(int kind, int p0, int p1, int dst_w, int dst_h, uhdr_raw_image_t* src,
+            std::unique_ptr<ultrahdr::uhdr_raw_image_ext_t>* dst) {
+  if (!cur() || !src || dst_w <= 0 || dst_h <= 0) return false;
+  auto img = std::make_unique<ultrahdr::uhdr_raw_image_ext_t>(src->fmt, src->cg, src->ct, src->range, (unsigned)dst_w, (unsigned)dst_h, 64);
+  const uhdr_error_info_t s = uhdr_hip_apply_effect(cur(), kind, p0, p1, src, img.get());
+  if (!handled(s, kind == 0 ? "effect_rotate" : kind == 1 ? "effect_mirror" : kind == 2 ? "effect_crop" : "effect_resize")) return false;
+  if (s.error_code != UHDR_CODEC_OK) {  // an argument the reference's own code would also refuse, or a device error: let the CPU code speak
+    fprintf(stderr, "uhdr_hip_seam: effect %d failed on the device: %s\n", kind, s.has_detail ? s.detail : "");
+    return false;
+  }
+  *dst = std::move(img);
+  return true;
+}
+
 bool jpeg_rgb_to_ycc(const uhdr_raw_image_t* rgb, uhdr_raw_image_t* ycc, uhdr_error_info_t* st) {
   if (!cur()) return false;
   *st = uhdr_hip_jpeg_rgb_to_ycc(cur(), rgb, ycc);

@@ -17,6 +17,7 @@
 //                                                                the device, libjpeg keeps the entropy coding)
 //   JpegDecoderHelper::decode       lib/src/jpegdecoderhelper.cpp:283  uhdr_hip_seam::idct_planes (libjpeg keeps the
 //                                                                entropy decoding, dequantize + IDCT on the device)
+//   apply_rotate / _mirror / _crop / _resize  lib/src/editorhelper.cpp:210, 285, 351, 417  uhdr_hip_seam::effect
 //   uhdr_encode / uhdr_decode       lib/src/ultrahdr_api.cpp:1200, 1918  uhdr_hip_seam::Scope (lazy context, like the
 //                                                                GLES context at :1977-1989)
 //
@@ -82,6 +83,11 @@ bool idct_planes(int ncomp, const short* const coefs[3], const unsigned int bloc
                  const unsigned short* const qtables[3], unsigned char* const planes[3], const unsigned int strides[3],
                  uhdr_error_info_t* st);
 
+// the effects chain (lib/src/editorhelper.cpp:210-520): kind 0 rotate (p0 = degrees), 1 mirror (p0 = direction), 2 crop
+// (p0 = left, p1 = top), 3 resize; dst_w x dst_h = size of the result.  *dst receives a freshly allocated image exactly
+// as the reference allocates it (strides aligned to 64).
+bool effect(int kind, int p0, int p1, int dst_w, int dst_h, uhdr_raw_image_t* src,
+            std::unique_ptr<ultrahdr::uhdr_raw_image_ext_t>* dst);
 // libjpeg's colour conversions around a 3-channel gain map (jccolor.c rgb_ycc_convert / jdcolor.c ycc_rgb_convert)
 bool jpeg_rgb_to_ycc(const uhdr_raw_image_t* rgb, uhdr_raw_image_t* ycc, uhdr_error_info_t* st);
 bool jpeg_ycc_to_rgb(const uhdr_raw_image_t* ycc, int libjpeg_variant, uhdr_raw_image_t* rgb, uhdr_error_info_t* st);

@@ -256,6 +256,19 @@ uhdr_error_info_t uhdr_hip_convert_raw_input_to_ycbcr_dev(uhdr_hip_ctx_t* ctx,
                                                           int chroma_sampling_enabled,
                                                           uhdr_raw_image_t* dst);
 
+/* ---- image effects ---------------------------------------------------------------
+ * apply_rotate / apply_mirror / apply_crop / apply_resize of the reference's effects chain (lib/src/editorhelper.cpp:
+ * 210-520; resize = the chain's nearest-sample resize_buffer, :77-87), bit-exact element remaps.
+ *   effect 0 rotate:  p0 = degrees clockwise (90, 180, 270)            dst is h x w for 90 / 270
+ *   effect 1 mirror:  p0 = uhdr_mirror_direction_t (0 vertical, 1 horizontal)
+ *   effect 2 crop:    p0 = left, p1 = top; the crop size is dst->w x dst->h
+ *   effect 3 resize:  to dst->w x dst->h
+ * dst: caller provides fmt (== src->fmt), w, h, planes and strides (the reference allocates with strides aligned to 64).
+ * Formats: every raw format of the library (P010, YCbCr 4:2:0 / 4:4:4, 10-bit 4:4:4, Y400, RGBA8888, RGBA1010102,
+ * RGBA-F16).  Host (no suffix) or device (_dev) plane pointers. */
+uhdr_error_info_t uhdr_hip_apply_effect(uhdr_hip_ctx_t* ctx, int effect, int p0, int p1, const uhdr_raw_image_t* src, uhdr_raw_image_t* dst);
+uhdr_error_info_t uhdr_hip_apply_effect_dev(uhdr_hip_ctx_t* ctx, int effect, int p0, int p1, const uhdr_raw_image_t* src, uhdr_raw_image_t* dst);
+
 /* ---- JPEG DCT/quantize stage ----------------------------------------------------------------- */
 /* Quant table libjpeg builds for jpeg_set_quality(quality, TRUE): natural (row-major) order. */
 void uhdr_hip_jpeg_quant_table(int quality, int is_chroma, uint16_t qtable[64]);

@@ -201,6 +201,8 @@ _SIGS = {
     "uhdr_hip_huffman_decode_dev": (ErrorInfo, [C.c_void_p, _P(JpegScan), _P(HuffTables), C.c_void_p, C.c_size_t]),
     "uhdr_hip_jpeg_parse": (C.c_int, [C.c_void_p, C.c_size_t, _P(JpegHeader)]),
     "uhdr_hip_jpeg_assemble": (C.c_size_t, [_P(JpegScan), _P(C.c_uint16), _P(C.c_uint16), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    "uhdr_hip_apply_effect": (ErrorInfo, [C.c_void_p, C.c_int, C.c_int, C.c_int, _P(RawImage), _P(RawImage)]),
+    "uhdr_hip_apply_effect_dev": (ErrorInfo, [C.c_void_p, C.c_int, C.c_int, C.c_int, _P(RawImage), _P(RawImage)]),
     "uhdr_hip_step_table_eval": (C.c_int, [C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "uhdr_hip_comm_unique_id": (C.c_int, [C.c_void_p]),
     "uhdr_hip_comm_init": (ErrorInfo, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),

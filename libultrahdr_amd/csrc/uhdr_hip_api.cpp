@@ -1375,6 +1375,90 @@ int uhdr_hip_exact_math_eval(int fn, const float* in, float* out, size_t n) {
   return 0;
 }
 
+// -------------------------------------------------------------------------------------------------
+// image effects (editorhelper.cpp:210-520)
+// -------------------------------------------------------------------------------------------------
+uhdr_error_info_t uhdr_hip_apply_effect_dev(uhdr_hip_ctx_t* c, int effect, int p0, int p1, const uhdr_raw_image_t* src, uhdr_raw_image_t* dst) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  if (!src || !dst) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument");
+  UHDR_TRY(validate_image(src, "source"));
+  if (dst->fmt != src->fmt) return err_status(UHDR_CODEC_INVALID_PARAM, "effect destination format %d differs from the source format %d", dst->fmt, src->fmt);
+  UHDR_TRY(validate_image(dst, "destination"));
+  uint32_t mode = 0, a0 = 0, a1 = 0;
+  const uint32_t sw = src->w, sh = src->h, dw = dst->w, dh = dst->h;
+  switch (effect) {
+    case 0:
+      if (p0 == 90 || p0 == 270) {
+        if (dw != sh || dh != sw) return err_status(UHDR_CODEC_INVALID_PARAM, "rotation by %d degrees of a %ux%u image needs a %ux%u destination", p0, sw, sh, sh, sw);
+        mode = p0 == 90 ? 0u : 2u;
+      } else if (p0 == 180) {
+        if (dw != sw || dh != sh) return err_status(UHDR_CODEC_INVALID_PARAM, "rotation by 180 degrees keeps the image size");
+        mode = 1;
+      } else {
+        return err_status(UHDR_CODEC_INVALID_PARAM, "unsupported degrees, expects one of {90, 180, 270}");  // ultrahdr_api.cpp uhdr_add_effect_rotate
+      }
+      break;
+    case 1:
+      if (p0 != 0 && p0 != 1) return err_status(UHDR_CODEC_INVALID_PARAM, "unsupported direction, expects one of {UHDR_MIRROR_HORIZONTAL, UHDR_MIRROR_VERTICAL}");
+      if (dw != sw || dh != sh) return err_status(UHDR_CODEC_INVALID_PARAM, "mirroring keeps the image size");
+      mode = p0 == 0 ? 3u : 4u;
+      break;
+    case 2:
+      if (p0 < 0 || p1 < 0 || (uint64_t)p0 + dw > sw || (uint64_t)p1 + dh > sh)
+        return err_status(UHDR_CODEC_INVALID_PARAM, "crop window %ux%u at (%d, %d) leaves the %ux%u image", dw, dh, p0, p1, sw, sh);
+      mode = 5; a0 = (uint32_t)p0; a1 = (uint32_t)p1;
+      break;
+    case 3:
+      if (dw == 0 || dh == 0) return err_status(UHDR_CODEC_INVALID_PARAM, "resize to an empty image");
+      mode = 6; a0 = sw / dw; a1 = sh / dh;
+      break;
+    default:
+      return err_status(UHDR_CODEC_INVALID_PARAM, "unknown effect %d", effect);
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  // the planes as the reference walks them: element size, geometry in elements (P010 chroma: one 4-byte element per U, V pair)
+  struct Pl { int idx; uint32_t elem, div, stride_div; };
+  Pl pls[3];
+  int npl = 0;
+  switch (src->fmt) {
+    case UHDR_IMG_FMT_24bppYCbCrP010: pls[0] = {0, 2, 1, 1}; pls[1] = {1, 4, 2, 2}; npl = 2; break;
+    case UHDR_IMG_FMT_12bppYCbCr420: pls[0] = {0, 1, 1, 1}; pls[1] = {1, 1, 2, 1}; pls[2] = {2, 1, 2, 1}; npl = 3; break;
+    case UHDR_IMG_FMT_8bppYCbCr400: pls[0] = {0, 1, 1, 1}; npl = 1; break;
+    case UHDR_IMG_FMT_24bppYCbCr444: for (int i = 0; i < 3; i++) pls[i] = {i, 1, 1, 1}; npl = 3; break;
+    case UHDR_IMG_FMT_30bppYCbCr444: for (int i = 0; i < 3; i++) pls[i] = {i, 2, 1, 1}; npl = 3; break;
+    case UHDR_IMG_FMT_32bppRGBA8888:
+    case UHDR_IMG_FMT_32bppRGBA1010102: pls[0] = {0, 4, 1, 1}; npl = 1; break;
+    case UHDR_IMG_FMT_64bppRGBAHalfFloat: pls[0] = {0, 8, 1, 1}; npl = 1; break;
+    default:
+      return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "image effects are not implemented for color format %d", src->fmt);
+  }
+  ProfScope ps(c, "effect");
+  for (int k = 0; k < npl; k++) {
+    EffectPlane e;
+    e.src = src->planes[pls[k].idx];
+    e.dst = dst->planes[pls[k].idx];
+    e.elem = pls[k].elem;
+    e.src_w = sw / pls[k].div; e.src_h = sh / pls[k].div; e.src_stride = src->stride[pls[k].idx] / pls[k].stride_div;
+    e.dst_w = dw / pls[k].div; e.dst_h = dh / pls[k].div; e.dst_stride = dst->stride[pls[k].idx] / pls[k].stride_div;
+    e.mode = mode;
+    e.a0 = mode == 5 ? a0 / pls[k].div : (mode == 6 ? e.src_w / (e.dst_w ? e.dst_w : 1) : 0);
+    e.a1 = mode == 5 ? a1 / pls[k].div : (mode == 6 ? e.src_h / (e.dst_h ? e.dst_h : 1) : 0);
+    HIP_TRY(launch_effect_plane(e, c->stream));
+  }
+  return ok_status();
+}
+
+uhdr_error_info_t uhdr_hip_apply_effect(uhdr_hip_ctx_t* c, int effect, int p0, int p1, const uhdr_raw_image_t* src, uhdr_raw_image_t* dst) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  if (!src || !dst) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument");
+  HIP_TRY(hipSetDevice(c->device));
+  uhdr_raw_image_t dsrc, ddst;
+  UHDR_TRY(stage_in(c, 0, src, &dsrc, true));
+  UHDR_TRY(stage_in(c, 1, dst, &ddst, false));
+  UHDR_TRY(uhdr_hip_apply_effect_dev(c, effect, p0, p1, &dsrc, &ddst));
+  return stage_out(c, &ddst, dst);
+}
+
 int uhdr_hip_step_table_eval(int which, float a, float b, const float* in, uint32_t* out, size_t n, uint32_t info[4]) {
   host::OetfBuckets tmp;
   const host::OetfBuckets* t = nullptr;

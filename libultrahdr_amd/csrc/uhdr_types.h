@@ -214,6 +214,18 @@ hipError_t launch_fdct_quant_rgb(const uint8_t* rgb, size_t pitch, int bpp, int 
                                  const uint16_t* qt_chroma_host, int16_t* coef_y, int16_t* coef_cb, int16_t* coef_cr, hipStream_t s);
 hipError_t launch_repack(int mode, const void* src, size_t src_pitch, void* dst, size_t dst_pitch, uint32_t w, uint32_t h,
                          hipStream_t s);  // 0: RGB888 -> RGBA8888, 1: RGBA8888 -> Y400
+// ---- image effects (effects.hip) -----------------------------------------------------------------------
+struct EffectPlane {
+  const void* src;
+  void* dst;
+  uint32_t elem;                       // bytes per element: 1, 2, 4, 8
+  uint32_t src_w, src_h, src_stride;   // in elements
+  uint32_t dst_w, dst_h, dst_stride;
+  uint32_t mode;                       // 0 / 1 / 2 rotate 90 / 180 / 270, 3 mirror vertical, 4 mirror horizontal, 5 crop, 6 resize
+  uint32_t a0, a1;                     // crop: left, top; resize: src_w / dst_w, src_h / dst_h
+};
+hipError_t launch_effect_plane(const EffectPlane& p, hipStream_t s);
+
 // ---- baseline Huffman entropy coding (huffman_encode.hip) -------------------------------------------
 struct HuffArgs {
   const int16_t* coef[3];  // JBLOCK arrays of bw x bh REAL blocks

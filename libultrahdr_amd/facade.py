@@ -46,6 +46,10 @@ def load():
                        ("uhdr_enc_set_using_multi_channel_gainmap", [P, C.c_int]),
                        ("uhdr_enc_set_gainmap_scale_factor", [P, C.c_int]),
                        ("uhdr_enable_gpu_acceleration", [P, C.c_int]),
+                       ("uhdr_add_effect_mirror", [P, C.c_int]),
+                       ("uhdr_add_effect_rotate", [P, C.c_int]),
+                       ("uhdr_add_effect_crop", [P, C.c_int, C.c_int, C.c_int, C.c_int]),
+                       ("uhdr_add_effect_resize", [P, C.c_int, C.c_int]),
                        ("uhdr_encode", [P]),
                        ("uhdr_dec_set_image", [P, C.POINTER(CompressedImage)]),
                        ("uhdr_dec_set_out_color_transfer", [P, C.c_int]),
@@ -69,11 +73,27 @@ def _chk(st):
         raise A.UhdrError(st.error_code, st.detail.decode("utf-8", "replace") if st.has_detail else "")
 
 
-def encode(hdr, sdr=None, gpu=False, quality=95, preset=A.UHDR_USAGE_BEST_QUALITY) -> bytes:
+def _add_effects(lib, h, effects):
+    """effects: [("rotate", degrees) | ("mirror", direction) | ("crop", left, right, top, bottom) | ("resize", w, h)]"""
+    for e in effects or ():
+        if e[0] == "rotate":
+            _chk(lib.uhdr_add_effect_rotate(h, e[1]))
+        elif e[0] == "mirror":
+            _chk(lib.uhdr_add_effect_mirror(h, e[1]))
+        elif e[0] == "crop":
+            _chk(lib.uhdr_add_effect_crop(h, *e[1:5]))
+        elif e[0] == "resize":
+            _chk(lib.uhdr_add_effect_resize(h, e[1], e[2]))
+        else:
+            raise ValueError(e)
+
+
+def encode(hdr, sdr=None, gpu=False, quality=95, preset=A.UHDR_USAGE_BEST_QUALITY, effects=None) -> bytes:
     """uhdr_encode: API-1 (hdr + sdr raw intents) or API-0 (hdr only); host images (libultrahdr_amd.images.Image)."""
     lib = load()
     h = lib.uhdr_create_encoder()
     try:
+        _add_effects(lib, h, effects)
         _chk(lib.uhdr_enc_set_raw_image(h, C.byref(hdr.raw), UHDR_HDR_IMG))
         if sdr is not None:
             _chk(lib.uhdr_enc_set_raw_image(h, C.byref(sdr.raw), UHDR_SDR_IMG))
@@ -88,11 +108,12 @@ def encode(hdr, sdr=None, gpu=False, quality=95, preset=A.UHDR_USAGE_BEST_QUALIT
         lib.uhdr_release_encoder(h)
 
 
-def decode(jpeg: bytes, out_ct, out_fmt, gpu=False) -> np.ndarray:
+def decode(jpeg: bytes, out_ct, out_fmt, gpu=False, effects=None) -> np.ndarray:
     """uhdr_decode -> packed pixels as a (h, w, bytes-per-pixel) uint8 array."""
     lib = load()
     h = lib.uhdr_create_decoder()
     try:
+        _add_effects(lib, h, effects)
         buf = (C.c_uint8 * len(jpeg)).from_buffer_copy(jpeg)
         ci = CompressedImage(C.cast(buf, C.c_void_p), len(jpeg), len(jpeg), 0, 0, 0)
         _chk(lib.uhdr_dec_set_image(h, C.byref(ci)))
