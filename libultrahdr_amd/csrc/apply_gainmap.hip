@@ -80,9 +80,10 @@ __device__ __forceinline__ uint32_t pack_codes_1010102(uint32_t r, uint32_t g, u
 //     code = bits >= thr ? hi : lo          entry = {thr, lo | hi << 16}
 // One 8-byte LDS read, one compare and one select per channel; no powf, no 256 KiB gather, no search.
 template <int OUT>
-__device__ __forceinline__ uint32_t oetf_code_bucket(float v, const uint2* tab, uint32_t base8) {
+__device__ __forceinline__ uint32_t oetf_code_bucket(float v, const uint2* tab, uint32_t base8, uint32_t hi_bits) {
   constexpr int SH = (OUT == 1) ? kOetfBucketShiftHlg : kOetfBucketShiftPq;
-  const int ib = min(max((int)__float_as_uint(v), 0), 0x3F800000);  // clampPixelFloat on the bit pattern (v_med3_i32)
+  // clampPixelFloat on the bit pattern (v_med3_i32); hi_bits = 1.0f, or the saturation point of a prescaled table
+  const int ib = min(max((int)__float_as_uint(v), 0), (int)hi_bits);
   const uint32_t bits = (uint32_t)ib;
   uint32_t off = (bits >> (SH - 3)) & ~7u;  // bucket * 8 (byte offset of the entry)
   off = off > base8 ? off - base8 : 0u;     // everything below the first threshold shares bucket 0
@@ -474,8 +475,8 @@ __global__ __launch_bounds__(quad_block<OUT>(), (quad_block<OUT>() == 1024 && SR
   const f2 off_s2 = splat(p.offset_sdr[NCH == 1 ? 0 : 2]), off_h2 = splat(p.offset_hdr[NCH == 1 ? 0 : 2]);
   const uint32_t scale = p.scale, half_scale = p.scale >> 1, magic = p.scale_magic;
   const uint32_t gmh1 = p.gm.h - 1, y0g = p.y0;
-  const uint32_t code_base8 = p.oetf_base8;
-  (void)code_base8;
+  const uint32_t code_base8 = p.oetf_base8, code_hi = p.oetf_hi_bits;
+  (void)code_base8; (void)code_hi;
 
   // ---- loop-invariant, per-lane column state --------------------------------------------------
   // A lane owns kQuadsPerLane quads of every quad row, 128 pixels apart: each load / store
@@ -721,9 +722,11 @@ __global__ __launch_bounds__(quad_block<OUT>(), (quad_block<OUT>() == 1024 && SR
           const f2 r = __builtin_elementwise_fma(-pk, q0, a);
           return __builtin_elementwise_fma(r, rpk, q0);
         };
-        hr = div_peak(hr);
-        hg = div_peak(hg);
-        hb = div_peak(hb);
+        if (!p.oetf_prescaled) {  // else the code table was built on the unscaled value (host_tables.cpp: make_bucket_table)
+          hr = div_peak(hr);
+          hg = div_peak(hg);
+          hb = div_peak(hb);
+        }
         if (p.hdr_gamut_on) {
           const Mat3& m = p.gamut;
           const f2 nr = m.m[0] * hr + m.m[1] * hg + m.m[2] * hb;
@@ -732,10 +735,10 @@ __global__ __launch_bounds__(quad_block<OUT>(), (quad_block<OUT>() == 1024 && SR
           hr = nr; hg = ng; hb = nb;
         }
         uint2 o;
-        o.x = pack_codes_1010102(oetf_code_bucket<OUT>(hr.x, s_code, code_base8), oetf_code_bucket<OUT>(hg.x, s_code, code_base8),
-                                 oetf_code_bucket<OUT>(hb.x, s_code, code_base8));
-        o.y = pack_codes_1010102(oetf_code_bucket<OUT>(hr.y, s_code, code_base8), oetf_code_bucket<OUT>(hg.y, s_code, code_base8),
-                                 oetf_code_bucket<OUT>(hb.y, s_code, code_base8));
+        o.x = pack_codes_1010102(oetf_code_bucket<OUT>(hr.x, s_code, code_base8, code_hi), oetf_code_bucket<OUT>(hg.x, s_code, code_base8, code_hi),
+                                 oetf_code_bucket<OUT>(hb.x, s_code, code_base8, code_hi));
+        o.y = pack_codes_1010102(oetf_code_bucket<OUT>(hr.y, s_code, code_base8, code_hi), oetf_code_bucket<OUT>(hg.y, s_code, code_base8, code_hi),
+                                 oetf_code_bucket<OUT>(hb.y, s_code, code_base8, code_hi));
         if (SRC == 0 || store_ok) stream_store<u2v>(dpx, (u2v){o.x, o.y});
       }
     }

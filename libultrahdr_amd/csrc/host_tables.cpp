@@ -291,19 +291,31 @@ OetfBuckets build_step_table(const std::function<uint32_t(uint32_t)>& code_of_bi
     if (lookup(u) != code_of_bits(u)) b.exact = false;
   return b;
 }
-static OetfBuckets make_bucket_table(int ct) {
+// prescaled: the table takes the value BEFORE the decode tail's nit scaling, (x * 203.0f) / peak -- two float roundings
+// as written in jpegr.cpp:1775-1805 -- so that the kernel can skip those operations when no gamut conversion sits between
+// them and the OETF (both are monotone, the composite stays a step function of x).
+static OetfBuckets make_bucket_table(int ct, bool prescaled) {
   auto flt = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
-  uint32_t one;
-  const float onef = 1.0f;
-  memcpy(&one, &onef, 4);
-  return build_step_table([&](uint32_t u) { return oetf_code_host(ct, flt(u)); }, 0u, one,
-                          ct == UHDR_CT_HLG ? kOetfBucketShiftHlg : kOetfBucketShiftPq,
-                          ct == UHDR_CT_HLG ? kOetfBucketsHlg : kOetfBucketsPq);
+  auto bits_of = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+  const float peak = ct == UHDR_CT_HLG ? 1000.0f : 10000.0f;
+  auto code = [&](uint32_t u) -> uint32_t {
+    float v = flt(u);
+    if (prescaled) {
+      v = (v * 203.0f) / peak;
+      v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+    }
+    return oetf_code_host(ct, v);
+  };
+  const uint32_t hi = prescaled ? bits_of(peak / 203.0f * 1.03125f) : bits_of(1.0f);  // beyond: the clamp, code stays
+  OetfBuckets b = build_step_table(code, 0u, hi, ct == UHDR_CT_HLG ? kOetfBucketShiftHlg : kOetfBucketShiftPq,
+                                   ct == UHDR_CT_HLG ? kOetfBucketsHlg : kOetfBucketsPq);
+  if (prescaled && b.exact && code(hi) != code(bits_of(1.0e6f))) b.exact = false;  // the domain must reach the saturated code
+  return b;
 }
-const OetfBuckets& oetf_code_buckets(int ct) {
-  static const OetfBuckets hlg = make_bucket_table(UHDR_CT_HLG);
-  static const OetfBuckets pq = make_bucket_table(UHDR_CT_PQ);
-  return ct == UHDR_CT_HLG ? hlg : pq;
+const OetfBuckets& oetf_code_buckets(int ct, bool prescaled) {
+  static const OetfBuckets hlg = make_bucket_table(UHDR_CT_HLG, false), hlg_pre = make_bucket_table(UHDR_CT_HLG, true);
+  static const OetfBuckets pq = make_bucket_table(UHDR_CT_PQ, false), pq_pre = make_bucket_table(UHDR_CT_PQ, true);
+  return ct == UHDR_CT_HLG ? (prescaled ? hlg_pre : hlg) : (prescaled ? pq_pre : pq);
 }
 
 // ---- step tables of the ENCODE side ------------------------------------------------------------------------------------

@@ -29,7 +29,7 @@ struct OetfBuckets {
   bool exact = false;                   // construction verified (one threshold per bucket, replay against the composite)
   std::vector<uint32_t> entries;        // n x {thr, lo | hi << 16}
 };
-const OetfBuckets& oetf_code_buckets(int ct);
+const OetfBuckets& oetf_code_buckets(int ct, bool prescaled = false);  // prescaled: argument is the value before (x * 203) / peak
 // encode side (see host_tables.cpp): toneMap's sRGB byte, encodeGain's byte, RGBA1010102 code -> linear value
 const OetfBuckets& srgb_code8_buckets();
 OetfBuckets gain_code8_buckets(float min_boost, float max_boost, float log2min, double log2_range, double log2_range_rcp);

@@ -79,6 +79,8 @@ struct uhdr_hip_ctx {
   float* d_pq_oetf = nullptr;
   float* d_hlg_buckets = nullptr;   // quad kernel: output-code bucket tables (host_tables.cpp: make_bucket_table)
   float* d_pq_buckets = nullptr;
+  float* d_hlg_buckets_pre = nullptr;  // ... taking the value before the nit scaling
+  float* d_pq_buckets_pre = nullptr;
   float* d_hlg_inv_ootf = nullptr;  // hlgInvOetfLUT followed by hlgOotfApprox, per table node
   double* d_math = nullptr;         // exact_math.h tables
   // per-call apply tables: ring of pinned host slots + matching device slots
@@ -472,7 +474,7 @@ void uhdr_hip_destroy(uhdr_hip_ctx_t* c) {
   (void)hipStreamSynchronize(c->stream);
   for (auto& e : c->prof_entries) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   float* luts[] = {c->d_srgb, c->d_hlg_inv, c->d_pq_inv, c->d_hlg_oetf, c->d_pq_oetf, c->d_hlg_inv_ootf, (float*)c->d_math,
-                   c->d_hlg_buckets, c->d_pq_buckets};
+                   c->d_hlg_buckets, c->d_pq_buckets, c->d_hlg_buckets_pre, c->d_pq_buckets_pre};
   for (float* p : luts) if (p) (void)hipFree(p);
   for (int i = 0; i < kTableSlots; i++) {
     if (c->h_tab[i]) (void)hipHostFree(c->h_tab[i]);
@@ -609,9 +611,11 @@ static uhdr_error_info_t build_apply_params(uhdr_hip_ctx* c, const uhdr_raw_imag
     p.oetf_thr = c->d_pq_oetf;
   }
   if (out_ct == UHDR_CT_HLG || out_ct == UHDR_CT_PQ) {
-    const host::OetfBuckets& b = host::oetf_code_buckets(out_ct);
+    // no HDR-side gamut conversion between the nit scaling and the OETF: the table absorbs (x * 203) / peak as well
+    const bool pre = !p.hdr_gamut_on && host::oetf_code_buckets(out_ct, true).exact;
+    const host::OetfBuckets& b = host::oetf_code_buckets(out_ct, pre);
     if (b.exact) {  // otherwise the quad kernel is not offered this transfer (apply_quad_mode) and the generic kernel runs
-      float** slot = out_ct == UHDR_CT_HLG ? &c->d_hlg_buckets : &c->d_pq_buckets;
+      float** slot = out_ct == UHDR_CT_HLG ? (pre ? &c->d_hlg_buckets_pre : &c->d_hlg_buckets) : (pre ? &c->d_pq_buckets_pre : &c->d_pq_buckets);
       if (!*slot) {
         std::vector<float> raw(b.entries.size());
         memcpy(raw.data(), b.entries.data(), raw.size() * sizeof(float));
@@ -620,6 +624,8 @@ static uhdr_error_info_t build_apply_params(uhdr_hip_ctx* c, const uhdr_raw_imag
       p.oetf_buckets = (const uint2*)*slot;
       p.oetf_n = b.n;
       p.oetf_base8 = b.base * 8;
+      p.oetf_hi_bits = b.hi_bits;
+      p.oetf_prescaled = pre ? 1 : 0;
     }
   }
   p.sdr = view_of(sdr);
@@ -1469,6 +1475,7 @@ int uhdr_hip_step_table_eval(int which, float a, float b, const float* in, uint3
     tmp = host::gain_code8_buckets(a, b, l2min, range, 1.0 / range);
     t = &tmp;
   } else if (which == 2 || which == 3) t = &host::oetf_code_buckets(which == 2 ? UHDR_CT_HLG : UHDR_CT_PQ);
+  else if (which == 4 || which == 5) t = &host::oetf_code_buckets(which == 4 ? UHDR_CT_HLG : UHDR_CT_PQ, true);
   if (!t) return -1;
   if (info) { info[0] = t->exact ? 1u : 0u; info[1] = t->n; info[2] = t->shift; info[3] = t->base; }
   if (!t->exact) return 1;

@@ -85,6 +85,8 @@ struct ApplyParams {
   const float* oetf_thr;    // generic kernel. HLG: output-code threshold block (kOetfTabFloats); PQ: 65536 uint16 output codes of pqOetfLUT's nodes; linear: null
   const uint2* oetf_buckets;   // quad kernel, HLG / PQ: bucket table {thr, lo | hi << 16} (null: not verified exact -> generic kernel)
   uint32_t oetf_n, oetf_base8; // entries, first bucket * 8
+  uint32_t oetf_hi_bits;       // upper end of the table's domain (bit pattern)
+  int oetf_prescaled;          // the table takes the value before the nit scaling (x * 203) / peak (no HDR-side gamut conversion)
   uint32_t y0;              // global row of stripe row 0
   uint32_t tiles_per_wave;  // quad kernel: loop trip count (even), set by the launcher
   uint32_t row_groups;      // quad kernel: quad-row step of a wave, set by the launcher

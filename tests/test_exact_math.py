@@ -196,3 +196,20 @@ def test_encode_gain_step_table_equals_the_evaluation_it_replaces(mn, mx):
 def test_a_boost_range_too_dense_for_the_table_is_reported_not_exact():
     rc, _, info = _step_eval(1, 1.0, 1.0 + 2.0 ** -10, np.array([1.0], dtype=np.float32))
     assert rc == 1 and info[0] == 0
+
+
+@pytest.mark.parametrize("which,peak", [(4, 1000.0), (5, 10000.0)])
+def test_prescaled_output_code_table_equals_scaling_then_the_plain_table(which, peak):
+    """The decode tail's table that absorbs (x * 203) / peak (used when no HDR-side gamut conversion sits in between) ==
+    the two float operations followed by the plain table, for 3 M values incl. both neighbours, negatives and values past
+    the saturation point."""
+    hi = peak / 203.0 * 1.2
+    x = np.concatenate([_around_every_float_step(0.0, hi, 800_000, 11), _around_every_float_step(0.0, hi / 500, 200_000, 12),
+                        np.array([0.0, -0.0, -3.0, hi * 2, 1e-30, peak / 203.0], dtype=np.float32)])
+    rc, got, info = _step_eval(which, 0.0, 0.0, x)
+    assert rc == 0 and info[0] == 1, info
+    v = (x * np.float32(203.0)) / np.float32(peak)  # numpy float32: one rounding per operation, like the reference's two statements
+    v = np.clip(v, 0.0, 1.0).astype(np.float32)
+    rc, want, info2 = _step_eval(which - 2, 0.0, 0.0, v)
+    assert rc == 0 and info2[0] == 1
+    assert np.array_equal(got, want), int((got != want).sum())
