@@ -421,25 +421,29 @@ __global__ __launch_bounds__(quad_block<OUT>(), (quad_block<OUT>() == 1024 && SR
   __shared__ __attribute__((aligned(16))) float s_idw[(SMODE == 0) ? 4 : 4 * kMaxIdwScaleLds * kMaxIdwScaleLds * 4];
 
   const uint32_t tid = threadIdx.x;
-  for (uint32_t i = tid; i < kSrgbPad; i += BLK) s_srgb[i] = p.tables[ApplyTables::kSrgbOff + min(i, (uint32_t)kSrgbN - 1)];
-  if constexpr (OUT != 0) {
-    for (uint32_t i = tid; i < p.oetf_n; i += BLK) s_code[i] = p.oetf_buckets[i];
-  }
-  if constexpr (SMODE == 0) {
-    for (uint32_t i = tid; i < NCH * 256; i += BLK) s_fac[i] = p.tables[ApplyTables::kFacOff + i];
-    if constexpr (BASE == 2)
-      for (uint32_t i = tid; i < 256; i += BLK) s_u8f[i] = p.tables[ApplyTables::kU8fOff + i];
-  } else {
-    for (uint32_t i = tid; i < NCH * kGainN; i += BLK) s_gain[i] = p.tables[ApplyTables::kGainOff + i];
-    for (uint32_t i = tid; i < 256; i += BLK) s_u8f[i] = p.tables[ApplyTables::kU8fOff + i];
-    const uint32_t s = p.scale, nidw = 4 * s * s * 4;
-    for (uint32_t i = tid; i < nidw; i += BLK) {
-      // source index i = ((tbl*s + oy)*s + ox)*4 + k  ->  pair layout
-      const uint32_t k = i & 3, pos = i >> 2, ox = pos % s, row = pos / s;  // row = tbl*s + oy
-      s_idw[(row * (s >> 1) + (ox >> 1)) * 8 + k * 2 + (ox & 1)] = p.tables[ApplyTables::kIdwOff + i];
+  // Per-workgroup tables -> LDS.  Called AFTER the wave has issued the global loads of its first work item, so that the
+  // staging (a round trip to L2 per table) overlaps the first HBM accesses instead of preceding them.
+  auto stage_tables = [&]() {
+    for (uint32_t i = tid; i < kSrgbPad; i += BLK) s_srgb[i] = p.tables[ApplyTables::kSrgbOff + min(i, (uint32_t)kSrgbN - 1)];
+    if constexpr (OUT != 0) {
+      for (uint32_t i = tid; i < p.oetf_n; i += BLK) s_code[i] = p.oetf_buckets[i];
     }
-  }
-  __syncthreads();
+    if constexpr (SMODE == 0) {
+      for (uint32_t i = tid; i < NCH * 256; i += BLK) s_fac[i] = p.tables[ApplyTables::kFacOff + i];
+      if constexpr (BASE == 2)
+        for (uint32_t i = tid; i < 256; i += BLK) s_u8f[i] = p.tables[ApplyTables::kU8fOff + i];
+    } else {
+      for (uint32_t i = tid; i < NCH * kGainN; i += BLK) s_gain[i] = p.tables[ApplyTables::kGainOff + i];
+      for (uint32_t i = tid; i < 256; i += BLK) s_u8f[i] = p.tables[ApplyTables::kU8fOff + i];
+      const uint32_t s = p.scale, nidw = 4 * s * s * 4;
+      for (uint32_t i = tid; i < nidw; i += BLK) {
+        // source index i = ((tbl*s + oy)*s + ox)*4 + k  ->  pair layout
+        const uint32_t k = i & 3, pos = i >> 2, ox = pos % s, row = pos / s;  // row = tbl*s + oy
+        s_idw[(row * (s >> 1) + (ox >> 1)) * 8 + k * 2 + (ox & 1)] = p.tables[ApplyTables::kIdwOff + i];
+      }
+    }
+    __syncthreads();
+  };
 
   const uint32_t qw = p.sdr.w >> 1, qh = p.sdr.h >> 1;
   const uint32_t strips_x = (qw + 64 * kQuadsPerLane - 1) / (64 * kQuadsPerLane);  // a wave owns 128 * kQuadsPerLane pixel columns
@@ -447,12 +451,11 @@ __global__ __launch_bounds__(quad_block<OUT>(), (quad_block<OUT>() == 1024 && SR
   const uint32_t wave = blockIdx.x * (BLK / 64) + __builtin_amdgcn_readfirstlane(tid >> 6);  // SGPR
   const uint32_t groups = p.row_groups, n_iter = p.tiles_per_wave;
   const uint32_t per_frame = groups * strips_x;
-  if constexpr (SRC == 0) {
-    if (wave >= per_frame * p.n_frames) return;  // a few surplus waves of the last workgroup
-  }
+  // a few surplus waves of the last workgroup have no work: they help staging the tables and leave
+  const bool live = SRC != 0 || wave < per_frame * p.n_frames;
   // batch: a wave stays inside ONE frame, so its plane pointers are loop invariant (five scalar
   // loads from the frame table, before the loop)
-  const uint32_t frame = wave / per_frame, wf = wave - frame * per_frame;
+  const uint32_t frame = live ? wave / per_frame : 0u, wf = live ? wave - frame * per_frame : 0u;
   const uint32_t qy0 = wf / strips_x, sx = wf - qy0 * strips_x;
   const uint8_t *yp, *up, *vp, *mp;
   uint8_t* dp;
@@ -751,7 +754,9 @@ __global__ __launch_bounds__(quad_block<OUT>(), (quad_block<OUT>() == 1024 && SR
   using H1 = std::integral_constant<int, kQuadsPerLane - 1>;
   static_assert(kQuadsPerLane == 2, "the pipeline below alternates between the lane's two quads");
   if constexpr (SRC == 0) {
-    Raw a = fetch(qy0, H0{});
+    Raw a = fetch(qy0, H0{});  // in flight while the tables are staged
+    stage_tables();
+    if (!live) return;
     for (uint32_t i = 0; i < n_iter; i++) {
       const Raw b = fetch(qy0 + i * groups, H1{});
       process(a, H0{});
@@ -760,6 +765,7 @@ __global__ __launch_bounds__(quad_block<OUT>(), (quad_block<OUT>() == 1024 && SR
     }
   } else {
     // ---- coefficient input: 128 x 16 pixel tiles, IDCT into the wave's LDS tile, then eight quad rows -------
+    stage_tables();
     __shared__ int s_ws[BLK / 64][8 * 8 * 9];
     __shared__ int s_q[3][64];
     __shared__ __attribute__((aligned(8))) uint8_t s_yt[BLK / 64][16 * 128];
