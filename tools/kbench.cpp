@@ -15,15 +15,18 @@ int main(int argc, char** argv) {
   const uint32_t w = 7680, h = 4320;
   const char* which = argc > 1 ? argv[1] : "A";
   const bool noise = !(argc > 2 && !strcmp(argv[2], "smooth"));
+  const bool white = argc > 2 && !strcmp(argv[2], "white");  // white-noise map bytes: the worst case for the factor-table gathers
+  const bool gauss = argc > 2 && !strcmp(argv[2], "gauss");  // Gaussian noise like libultrahdr_amd/synth.py: sigma 5 levels on luma, 7.6 on the map
+  auto gn = [&](float sigma) { float a = 0; for (int k = 0; k < 12; k++) a += rand() / (float)RAND_MAX; return (a - 6.0f) * sigma; };
   const int mapfmt = which[0] == 'A' ? 0 : (which[0] == 'B' ? 1 : 2);
   const uint32_t scale = mapfmt == 0 ? 4 : 1, mw = w / scale, mh = h / scale, bpp = mapfmt == 0 ? 1 : (mapfmt == 1 ? 3 : 4);
   std::vector<uint8_t> y((size_t)w * h), u((size_t)w * h / 4), v((size_t)w * h / 4), m((size_t)mw * mh * bpp);
   srand(1);
-  for (size_t i = 0; i < y.size(); i++) { size_t yy = i / w, xx = i % w; y[i] = (uint8_t)(128 + 100 * sinf(xx / 97.f) * cosf(yy / 61.f) + (noise ? (rand() % 11) - 5 : 0)); }
+  for (size_t i = 0; i < y.size(); i++) { size_t yy = i / w, xx = i % w; float v = 128 + 100 * sinf(xx / 97.f) * cosf(yy / 61.f) + (gauss ? gn(5.0f) : (noise ? (rand() % 11) - 5 : 0)); y[i] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
   for (size_t i = 0; i < u.size(); i++) { u[i] = 128 + (i % 31); v[i] = 128 - (i % 17); }
-  for (size_t i = 0; i < m.size(); i++) m[i] = (uint8_t)(128 + 90 * sinf((i % (mw * bpp)) / 50.f) + (noise ? rand() % 7 : 0));
-  const int NSET = 2;
-  uint8_t *dy[NSET], *du[NSET], *dv[NSET], *dm[NSET], *dd[NSET];
+  for (size_t i = 0; i < m.size(); i++) { float v = 128 + 90 * sinf((i % (mw * bpp)) / 50.f) + (gauss ? gn(7.6f) : (noise ? rand() % 7 : 0)); m[i] = white ? (uint8_t)(rand() & 255) : (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+  const int NSET = getenv("KB_NSET") ? atoi(getenv("KB_NSET")) : 2;
+  uint8_t *dy[8], *du[8], *dv[8], *dm[8], *dd[8];
   for (int s = 0; s < NSET; s++) {
     CK(hipMalloc(&dy[s], y.size())); CK(hipMalloc(&du[s], u.size())); CK(hipMalloc(&dv[s], v.size())); CK(hipMalloc(&dm[s], m.size())); CK(hipMalloc(&dd[s], (size_t)w * h * 8));
     CK(hipMemcpy(dy[s], y.data(), y.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(du[s], u.data(), u.size(), hipMemcpyHostToDevice));
@@ -52,13 +55,15 @@ int main(int argc, char** argv) {
   };
   for (int i = 0; i < 3; i++) launch(i % NSET);
   CK(hipStreamSynchronize(st));
-  const int N = 10;
+  const int N = getenv("KB_N") ? atoi(getenv("KB_N")) : 10;
+  for (int rep = 0; rep < (getenv("KB_REPS") ? atoi(getenv("KB_REPS")) : 1); rep++) {
   CK(hipEventRecord(e0, st));
   for (int i = 0; i < N; i++) launch(i % NSET);
   CK(hipEventRecord(e1, st));
   CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   double us = ms * 1e3 / N, bytes = (1.5 + (double)bpp / (scale * scale) + 8) * w * h;
-  printf("%-28s map %s %s: %.1f us  %.0f GB/s (%.1f%% of 8 TB/s)\n", argv[0], which, noise ? "noisy" : "smooth", us, bytes / us / 1e3, bytes / us / 1e3 / 80.0);
+  printf("%-28s map %s %s: %.1f us  %.0f GB/s (%.1f%% of 8 TB/s)\n", argv[0], which, white ? "white" : (gauss ? "gauss" : (noise ? "noisy" : "smooth")), us, bytes / us / 1e3, bytes / us / 1e3 / 80.0);
+  }
   return 0;
 }
