@@ -41,6 +41,100 @@ unsigned ceil_div(unsigned a, unsigned b) { return (a + b - 1) / b; }
 
 }  // namespace
 
+namespace {
+
+void emit(jpeg_compress_struct* cinfo, const unsigned char* p, size_t n) {  // through the helper's own destination manager
+  jpeg_destination_mgr* d = cinfo->dest;
+  while (n > 0) {
+    if (d->free_in_buffer == 0) (*d->empty_output_buffer)(cinfo);
+    const size_t k = n < d->free_in_buffer ? n : d->free_in_buffer;
+    memcpy(d->next_output_byte, p, k);
+    d->next_output_byte += k;
+    d->free_in_buffer -= k;
+    p += k;
+    n -= k;
+  }
+}
+void emit_marker(jpeg_compress_struct* cinfo, int code, const void* data, size_t n) {  // jpeg_write_marker's bytes
+  const unsigned char h[4] = {0xff, (unsigned char)code, (unsigned char)((n + 2) >> 8), (unsigned char)((n + 2) & 0xff)};
+  emit(cinfo, h, 4);
+  emit(cinfo, static_cast<const unsigned char*>(data), n);
+}
+
+// UHDR_HIP_SEAM_DEVICE_ENTROPY=1: the whole compressImage on the device, Huffman pass included.  One wavefront encodes one
+// restart interval, so the file carries a DRI segment and RSTn markers the reference's files do not have; every decoder
+// reconstructs the same coefficients (T.81 B.2.4.4, F.1.3).  Off by default: the default keeps the reference's bytes.
+// true: the file is written (*st = result); false: not a configuration for this path, nothing written.
+bool device_scan_encode(jpeg_compress_struct* cinfo, int nc, const unsigned char* const planes[3], const unsigned int strides[3], bool rgb,
+                        const unsigned bw[3], const unsigned bh[3], const void* icc, size_t icc_size, const char* comment,
+                        uhdr_error_info_t* st) {
+  if (cinfo->arith_code || cinfo->optimize_coding || cinfo->scan_info != nullptr || cinfo->data_precision != 8) return false;
+  if (cinfo->restart_interval != 0 || cinfo->restart_in_rows != 0) return false;
+  if (!cinfo->write_JFIF_header || cinfo->write_Adobe_marker) return false;  // the header writer below emits what jcmarker.c emits for JFIF files
+  if (cinfo->jpeg_color_space != (nc == 3 ? JCS_YCbCr : JCS_GRAYSCALE)) return false;
+  if (icc_size > 65533 || (comment && strlen(comment) > 65533) || cinfo->image_width > 65535 || cinfo->image_height > 65535) return false;
+  uhdr_hip_jpeg_scan_t scan;
+  memset(&scan, 0, sizeof scan);
+  uint16_t qt[3][64];
+  memset(qt, 0, sizeof qt);
+  scan.num_components = nc;
+  scan.w = cinfo->image_width;
+  scan.h = cinfo->image_height;
+  int bpm = 0;
+  for (int c = 0; c < nc; c++) {
+    const jpeg_component_info* ci = &cinfo->comp_info[c];
+    if (ci->h_samp_factor < 1 || ci->h_samp_factor > 2 || ci->v_samp_factor < 1 || ci->v_samp_factor > 2) return false;
+    if (ci->quant_tbl_no != (c ? 1 : 0) || ci->dc_tbl_no != (c ? 1 : 0) || ci->ac_tbl_no != (c ? 1 : 0)) return false;  // jpeg_set_defaults' assignment
+    const JQUANT_TBL* q = cinfo->quant_tbl_ptrs[ci->quant_tbl_no];
+    if (!q) return false;
+    for (int i = 0; i < 64; i++) {
+      if (q->quantval[i] == 0 || q->quantval[i] > 255) return false;  // baseline tables
+      qt[c][i] = q->quantval[i];
+    }
+    scan.blocks_w[c] = (int)bw[c];
+    scan.blocks_h[c] = (int)bh[c];
+    scan.h_samp[c] = nc == 1 ? 1 : ci->h_samp_factor;
+    scan.v_samp[c] = nc == 1 ? 1 : ci->v_samp_factor;
+    bpm += scan.h_samp[c] * scan.v_samp[c];
+  }
+  scan.restart_interval = 64 / bpm;  // the longest interval one wavefront (64 blocks) holds
+  size_t cap = 1u << 16;
+  for (int c = 0; c < nc; c++) cap += (size_t)bw[c] * bh[c] * 64;
+  Scratch sc;
+  unsigned char* data = static_cast<unsigned char*>(sc.get(cap));
+  if (!data) { *st = mem_error(); return true; }
+  size_t n = 0;
+  uhdr_error_info_t r;
+  bool on_device = encode_scan(&scan, qt, planes, strides, rgb ? 3 : 0, data, cap, &n, &r);
+  if (on_device && r.error_code == UHDR_CODEC_MEM_ERROR && n > cap) {  // data busier than the raw samples: the call said how much it needs
+    sc.drop();
+    cap = n;
+    data = static_cast<unsigned char*>(sc.get(cap));
+    if (!data) { *st = mem_error(); return true; }
+    on_device = encode_scan(&scan, qt, planes, strides, rgb ? 3 : 0, data, cap, &n, &r);
+  }
+  if (!on_device) { sc.drop(); return false; }
+  if (r.error_code != UHDR_CODEC_OK) { sc.drop(); *st = r; return true; }
+  // headers: SOI, JFIF APP0 | the helper's markers | DQT, SOF0, DHT, DRI, SOS | data | EOI  (jcmarker.c's order)
+  unsigned char hdr[2048];
+  const unsigned char none = 0;
+  const size_t hn = uhdr_hip_jpeg_assemble(&scan, qt[0], qt[nc == 3 ? 1 : 0], &none, 0, hdr, sizeof hdr);
+  if (hn < 22) { sc.drop(); return false; }
+  (*cinfo->dest->init_destination)(cinfo);
+  emit(cinfo, hdr, 20);  // SOI + the 18-byte APP0
+  if (icc != nullptr && icc_size > 0) emit_marker(cinfo, 0xe2, icc, icc_size);
+  if (comment) emit_marker(cinfo, 0xfe, comment, strlen(comment));
+  emit(cinfo, hdr + 20, hn - 22);
+  emit(cinfo, data, n);
+  emit(cinfo, hdr + hn - 2, 2);  // EOI
+  (*cinfo->dest->term_destination)(cinfo);
+  sc.drop();
+  memset(st, 0, sizeof *st);
+  return true;
+}
+
+}  // namespace
+
 bool jpeg_compress_on_device(jpeg_compress_struct* cinfo, const unsigned char* planes[3], const unsigned int strides[3],
                              uhdr_img_fmt_t format, const void* icc, size_t icc_size, const char* comment,
                              uhdr_error_info_t* st) {
@@ -64,6 +158,7 @@ bool jpeg_compress_on_device(jpeg_compress_struct* cinfo, const unsigned char* p
   }
   const bool rgb = format == UHDR_IMG_FMT_24bppRGB888;
   if (rgb && nc != 3) return false;
+  if (getenv("UHDR_HIP_SEAM_DEVICE_ENTROPY") && device_scan_encode(cinfo, nc, planes, strides, rgb, bw, bh, icc, icc_size, comment, st)) return true;
 
   Scratch sc;
   const unsigned char* src[3] = {planes[0], planes[1], planes[2]};
@@ -130,6 +225,70 @@ bool jpeg_compress_on_device(jpeg_compress_struct* cinfo, const unsigned char* p
   return true;
 }
 
+namespace {
+
+// true: the device decoded the whole scan (*st = result).  false: not a file for the device path; nothing consumed.
+bool device_scan_decode(jpeg_decompress_struct* cinfo, bool want_rgb, unsigned char* dest, const unsigned int hstride[3],
+                        const unsigned int vstride[3], uhdr_img_fmt_t planar_fmt, uhdr_img_fmt_t* out_fmt, uhdr_error_info_t* st) {
+  const int nc = cinfo->num_components;
+  if (cinfo->progressive_mode || cinfo->arith_code || cinfo->data_precision != 8) return false;
+  if (cinfo->comps_in_scan != nc || cinfo->Ss != 0 || cinfo->Se != 63 || cinfo->Ah != 0 || cinfo->Al != 0) return false;
+  if (!cinfo->src || !cinfo->src->next_input_byte || cinfo->src->bytes_in_buffer < 2) return false;
+  if (cinfo->image_width > 65535 || cinfo->image_height > 65535) return false;
+  uhdr_hip_jpeg_header_t hdr;
+  memset(&hdr, 0, sizeof hdr);
+  hdr.scan.num_components = nc;
+  hdr.scan.w = cinfo->image_width;
+  hdr.scan.h = cinfo->image_height;
+  hdr.scan.restart_interval = (int)cinfo->restart_interval;
+  for (int c = 0; c < nc; c++) {
+    const jpeg_component_info* ci = &cinfo->comp_info[c];
+    if (cinfo->cur_comp_info[c] != ci) return false;  // scan order == frame order
+    if (ci->h_samp_factor < 1 || ci->h_samp_factor > 2 || ci->v_samp_factor < 1 || ci->v_samp_factor > 2) return false;
+    hdr.scan.blocks_w[c] = (int)ci->width_in_blocks;
+    hdr.scan.blocks_h[c] = (int)ci->height_in_blocks;
+    hdr.scan.h_samp[c] = nc == 1 ? 1 : ci->h_samp_factor;
+    hdr.scan.v_samp[c] = nc == 1 ? 1 : ci->v_samp_factor;
+    if (ci->quant_tbl_no < 0 || ci->quant_tbl_no >= NUM_QUANT_TBLS) return false;
+    const JQUANT_TBL* q = cinfo->quant_tbl_ptrs[ci->quant_tbl_no];
+    if (!q) return false;
+    for (int i = 0; i < 64; i++) hdr.qtable[c][i] = q->quantval[i];
+  }
+  if (nc == 3 && (cinfo->comp_info[1].dc_tbl_no != cinfo->comp_info[2].dc_tbl_no || cinfo->comp_info[1].ac_tbl_no != cinfo->comp_info[2].ac_tbl_no))
+    return false;  // the device decoder takes one (DC, AC) pair for component 0 and one for the other two
+  const int second = nc == 3 ? 1 : 0;
+  const JHUFF_TBL* ht[4] = {cinfo->dc_huff_tbl_ptrs[cinfo->comp_info[0].dc_tbl_no & 3], cinfo->ac_huff_tbl_ptrs[cinfo->comp_info[0].ac_tbl_no & 3],
+                            cinfo->dc_huff_tbl_ptrs[cinfo->comp_info[second].dc_tbl_no & 3], cinfo->ac_huff_tbl_ptrs[cinfo->comp_info[second].ac_tbl_no & 3]};
+  for (int t = 0; t < 4; t++) {
+    if (!ht[t]) return false;
+    memcpy(hdr.tables.bits[t], ht[t]->bits, 17);
+    memcpy(hdr.tables.vals[t], ht[t]->huffval, 256);
+  }
+  int channels = 0, variant = 0;
+  if (want_rgb) {
+#ifdef JCS_ALPHA_EXTENSIONS
+    channels = 4;  // libjpeg-turbo: the helper asks for JCS_EXT_RGBA
+#else
+    channels = 3;
+    variant = JPEG_LIB_VERSION >= 90 ? 1 : 0;  // IJG 9 refined the green-term constants (jdcolor.c)
+#endif
+  }
+  unsigned char* planes[3] = {nullptr, nullptr, nullptr};
+  size_t off = 0;
+  for (int c = 0; c < (want_rgb ? 1 : nc); c++) {
+    planes[c] = dest + off;
+    off += (size_t)hstride[c] * vstride[c];
+  }
+  uhdr_error_info_t r;
+  if (!decode_scan(&hdr, cinfo->src->next_input_byte, cinfo->src->bytes_in_buffer, channels, variant, planes, hstride, vstride, &r)) return false;
+  *st = r;
+  if (r.error_code == UHDR_CODEC_OK)
+    *out_fmt = want_rgb ? (channels == 4 ? UHDR_IMG_FMT_32bppRGBA8888 : UHDR_IMG_FMT_24bppRGB888) : planar_fmt;
+  return true;
+}
+
+}  // namespace
+
 bool jpeg_decompress_on_device(jpeg_decompress_struct* cinfo, bool want_rgb, unsigned char* dest,
                                const unsigned int hstride[3], const unsigned int vstride[3], uhdr_img_fmt_t* out_fmt,
                                uhdr_error_info_t* st) {
@@ -153,6 +312,11 @@ bool jpeg_decompress_on_device(jpeg_decompress_struct* cinfo, bool want_rgb, uns
     else return false;
     if (want_rgb && fmt != UHDR_IMG_FMT_24bppYCbCr444) return false;  // libjpeg's fancy upsampling stays libjpeg's
   }
+
+  // Whole decode on the device when the file is what libjpeg writes by default (baseline, one interleaved scan, 8 bit):
+  // the entropy-coded bytes go up, the samples come down.  Anything else -- progressive, arithmetic coding, several
+  // scans, a source manager that does not hold the rest of the file -- takes jpeg_read_coefficients() below.
+  if (!getenv("UHDR_HIP_SEAM_CPU_ENTROPY") && device_scan_decode(cinfo, want_rgb, dest, hstride, vstride, fmt, out_fmt, st)) return true;
 
   jvirt_barray_ptr* arrays = jpeg_read_coefficients(cinfo);  // the Huffman decode of the whole scan
   Scratch sc;

@@ -4,6 +4,7 @@
 #include "uhdr_hip_seam.h"
 
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -28,9 +29,11 @@ bool trace_on() {
 }
 bool handled(const uhdr_error_info_t& s, const char* stage) {
   const bool dev = s.error_code != UHDR_CODEC_UNSUPPORTED_FEATURE;
-  if (trace_on())
-    fprintf(stderr, "uhdr_hip_seam: %s -> %s%s%s\n", stage, dev ? "device" : "reference CPU path (", dev ? "" : (s.has_detail ? s.detail : ""),
+  if (trace_on()) {
+    static const auto t0 = std::chrono::steady_clock::now();
+    fprintf(stderr, "uhdr_hip_seam: [%8.2f ms] %s -> %s%s%s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), stage, dev ? "device" : "reference CPU path (", dev ? "" : (s.has_detail ? s.detail : ""),
             dev ? "" : ")");
+  }
   if (dev) g_calls.fetch_add(1, std::memory_order_relaxed);
   return dev;
 }
@@ -175,6 +178,28 @@ bool idct_planes(int ncomp, const short* const coefs[3], const unsigned int bloc
   }
   handled(*st, "idct_planes");
   return true;
+}
+
+bool decode_scan(const void* hdr, const unsigned char* data, size_t bytes, int out_channels, int libjpeg_variant,
+                 unsigned char* const planes[3], const unsigned int hstride[3], const unsigned int vstride[3],
+                 uhdr_error_info_t* st) {
+  if (!cur()) return false;
+  *st = uhdr_hip_jpeg_decode_scan(cur(), static_cast<const uhdr_hip_jpeg_header_t*>(hdr), data, bytes, out_channels, libjpeg_variant, planes,
+                                  hstride, vstride);
+  // corrupt entropy-coded data: libjpeg decodes such files with warnings and padding; that behaviour stays libjpeg's
+  if (st->error_code == UHDR_CODEC_INVALID_PARAM) {
+    if (trace_on()) fprintf(stderr, "uhdr_hip_seam: jpeg_decode_scan -> reference CPU path (%s)\n", st->has_detail ? st->detail : "");
+    return false;
+  }
+  return handled(*st, "jpeg_decode_scan");
+}
+
+bool encode_scan(const void* scan, const void* qtables, const unsigned char* const planes[3], const unsigned int strides[3],
+                 int rgb_channels, unsigned char* out, size_t cap, size_t* bytes, uhdr_error_info_t* st) {
+  if (!cur()) return false;
+  *st = uhdr_hip_jpeg_encode_scan(cur(), static_cast<const uhdr_hip_jpeg_scan_t*>(scan), static_cast<const uint16_t(*)[64]>(qtables), planes, strides,
+                                  rgb_channels, out, cap, bytes);
+  return handled(*st, "jpeg_encode_scan");
 }
 
 bool effect(int kind, int p0, int p1, int dst_w, int dst_h, uhdr_raw_image_t* src,

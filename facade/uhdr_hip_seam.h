@@ -83,6 +83,18 @@ bool idct_planes(int ncomp, const short* const coefs[3], const unsigned int bloc
                  const unsigned short* const qtables[3], unsigned char* const planes[3], const unsigned int strides[3],
                  uhdr_error_info_t* st);
 
+// Whole baseline scan on the device (uhdr_hip_jpeg_decode_scan): hdr is a uhdr_hip_jpeg_header_t filled in from
+// jpeg_decompress_struct after jpeg_read_header; data / bytes = what the source manager still holds.  false: the device
+// path does not take this file (the caller goes on with jpeg_read_coefficients).
+bool decode_scan(const void* hdr, const unsigned char* data, size_t bytes, int out_channels, int libjpeg_variant,
+                 unsigned char* const planes[3], const unsigned int hstride[3], const unsigned int vstride[3],
+                 uhdr_error_info_t* st);
+
+// The mirror for the encoder (uhdr_hip_jpeg_encode_scan): samples -> entropy-coded data with restart markers, on the device.
+// scan is a uhdr_hip_jpeg_scan_t, qtables a uint16_t[3][64].
+bool encode_scan(const void* scan, const void* qtables, const unsigned char* const planes[3], const unsigned int strides[3],
+                 int rgb_channels, unsigned char* out, size_t cap, size_t* bytes, uhdr_error_info_t* st);
+
 // the effects chain (lib/src/editorhelper.cpp:210-520): kind 0 rotate (p0 = degrees), 1 mirror (p0 = direction), 2 crop
 // (p0 = left, p1 = top), 3 resize; dst_w x dst_h = size of the result.  *dst receives a freshly allocated image exactly
 // as the reference allocates it (strides aligned to 64).

@@ -442,7 +442,9 @@ uhdr_error_info_t uhdr_hip_huffman_encode_dev(uhdr_hip_ctx_t* ctx, const uhdr_hi
  * entropy-coded data -> quantized coefficient blocks, ready for uhdr_hip_idct_dequant_dev / uhdr_hip_apply_gainmap_coef_dev.
  * A stream with restart markers is a sequence of independent intervals; the markers are located on the device and every
  * interval is decoded by its own lane.  A stream without them (restart_interval 0 -- every file the reference writes) is
- * ONE interval: decoded correctly, but by a single lane; such files are better left to the CPU.
+ * ONE interval: it is decoded by the self-synchronising parallel decoder (huffman_decode_sync.hip: sub-sequences of the
+ * bit stream are decoded speculatively and re-decoded until every hand-over state agrees with its predecessor's end
+ * state), falling back to a single lane only for streams shorter than 4 KiB or if the search does not settle.
  * scan->coef[c]: DEVICE arrays of blocks_w[c] x blocks_h[c] JBLOCKs, WRITTEN by this call (dummy blocks of edge MCUs are
  * dropped); data: DEVICE pointer to the bytes between the SOS header and EOI; tables: the file's DHT content in the order
  * DC luma (Tc 0, Th 0), AC luma, DC chroma, AC chroma -- NULL selects the Annex K tables; component 0 uses the luma pair,
@@ -479,6 +481,41 @@ typedef struct uhdr_hip_jpeg_header {
   size_t scan_bytes;  /* up to (not including) the marker that ends the entropy-coded data */
 } uhdr_hip_jpeg_header_t;
 int uhdr_hip_jpeg_parse(const uint8_t* file, size_t size, uhdr_hip_jpeg_header_t* out);
+
+/* JpegDecoderHelper::decompressImage (jpegdecoderhelper.cpp:169-535) for one baseline JPEG whose headers are already
+ * parsed -- by uhdr_hip_jpeg_parse, or by libjpeg's jpeg_read_header as in facade/uhdr_hip_jpeg_seam.cpp, which fills the
+ * same struct from jpeg_decompress_struct.  Entropy decode (uhdr_hip_huffman_decode_dev), dequantization + JDCT_ISLOW
+ * IDCT (uhdr_hip_idct_dequant_dev) and, for RGB output, ycc_rgb_convert (uhdr_hip_idct_dequant_rgb_dev) all run on the
+ * device: the compressed bytes go up, the decoded samples come down, nothing else crosses PCIe.
+ * hdr: scan geometry (coef pointers ignored), Huffman tables, per-component quantization tables; scan_offset / scan_bytes
+ * ignored.  scan_data: HOST pointer to the first byte after the SOS header; scan_bytes: bytes available from there (the
+ * rest of the file is fine: the data is cut at the first marker that is not RSTn).
+ * out_channels 0: planar output as libjpeg's raw-data mode gives it -- plane i gets min(hstride[i], blocks_w[i]*8) columns
+ * of min(vstride[i], blocks_h[i]*8) rows (HOST pointers, row pitch hstride[i] bytes), i.e. hstride / vstride describe the
+ * caller's buffer like JpegDecoderHelper's mPlaneHStride / mPlaneVStride.  out_channels 3 / 4: packed RGB888 / RGBA8888
+ * (alpha 255) of a 3-component 4:4:4 file into planes[0], hstride[0] in PIXELS; libjpeg_variant as for
+ * uhdr_hip_jpeg_ycc_to_rgb.  UHDR_CODEC_UNSUPPORTED_FEATURE: RGB output of a subsampled file (libjpeg's fancy upsampling).
+ * Synchronous. */
+uhdr_error_info_t uhdr_hip_jpeg_decode_scan(uhdr_hip_ctx_t* ctx, const uhdr_hip_jpeg_header_t* hdr,
+                                            const uint8_t* scan_data, size_t scan_bytes, int out_channels,
+                                            int libjpeg_variant, uint8_t* const planes[3],
+                                            const unsigned int hstride[3], const unsigned int vstride[3]);
+
+/* The encode-side mirror: JpegEncoderHelper::compressImage's sample -> entropy-coded-data part
+ * (jpegencoderhelper.cpp:131-309) on the device.  FDCT + quantization (uhdr_hip_fdct_quant_dev; for a packed RGB gain map
+ * uhdr_hip_fdct_quant_rgb_dev, i.e. rgb_ycc_convert included) feed uhdr_hip_huffman_encode_dev without the coefficient
+ * blocks leaving HBM: the samples go up, the compressed bytes come down.
+ * scan: geometry (coef pointers ignored); restart_interval must satisfy uhdr_hip_huffman_encode_dev (1..64 / blocks per
+ * MCU) -- the data therefore carries RSTn markers, see that function's parity policy.  qtable[c]: natural order.
+ * rgb_channels 0: planes[c] = HOST plane of blocks_w[c]*8 x blocks_h[c]*8 samples (the caller pads to whole blocks as
+ * jpegencoderhelper.cpp:246-309 does), strides in bytes; 3 / 4: planes[0] = HOST packed RGB888 / RGBA8888 image of
+ * scan->w x scan->h pixels (multiples of 8), strides[0] in PIXELS, for a 3-component 4:4:4 scan.
+ * out (HOST) receives everything between the SOS header and EOI; *out_bytes its length (UHDR_CODEC_MEM_ERROR with the
+ * needed size in *out_bytes when out_capacity is too small).  Wrap it with uhdr_hip_jpeg_assemble.  Synchronous. */
+uhdr_error_info_t uhdr_hip_jpeg_encode_scan(uhdr_hip_ctx_t* ctx, const uhdr_hip_jpeg_scan_t* scan,
+                                            const uint16_t qtable[3][64], const uint8_t* const planes[3],
+                                            const unsigned int strides[3], int rgb_channels, uint8_t* out,
+                                            size_t out_capacity, size_t* out_bytes);
 
 /* ---- timing hook for bench.py ------------------------------------------------------------------
  * HIP events recorded on the context's stream around every kernel launch of the named family

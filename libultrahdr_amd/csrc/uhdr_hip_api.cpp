@@ -92,6 +92,8 @@ struct uhdr_hip_ctx {
   int tab_next = 0;
   // scratch for host-buffer entry points and two-pass generation
   DeviceBuf scratch[8];
+  bool huff_serial_ok = true;  // uhdr_hip_jpeg_decode_scan clears it: a large marker-less scan that the parallel decoder cannot settle goes back to the caller
+  DeviceBuf jpg[6];  // uhdr_hip_jpeg_decode_scan: entropy-coded data | coefficient arrays x 3 | decoded planes / pixels
   DeviceBuf minmax;  // 6 + 2048*6 floats
   uint32_t* d_huff = nullptr;     // Annex K code tables (kHuffTabWords) followed by the 64-byte zig-zag map
   CoefSrc* d_coef_src = nullptr;  // apply_gainmap_coef descriptors (rotating slots)
@@ -482,6 +484,7 @@ void uhdr_hip_destroy(uhdr_hip_ctx_t* c) {
     if (c->tab_ev[i]) (void)hipEventDestroy(c->tab_ev[i]);
   }
   for (auto& b : c->scratch) if (b.p) (void)hipFree(b.p);
+  for (auto& b : c->jpg) if (b.p) (void)hipFree(b.p);
   if (c->minmax.p) (void)hipFree(c->minmax.p);
   if (c->d_coef_src) (void)hipFree(c->d_coef_src);
   if (c->d_huff) (void)hipFree(c->d_huff);
@@ -2102,6 +2105,8 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
         if (fl[1] & 2u) return err_status(UHDR_CODEC_INVALID_PARAM, "corrupt entropy-coded data (undefined Huffman code or a run past the end of a block)");
         sync_done = true;
       } else {  // not settled: start over on the serial path
+        if (!c->huff_serial_ok && data_bytes > (256u << 10))
+          return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "the parallel entropy decode did not settle in %d rounds; %zu bytes on one lane would take longer than the CPU", max_rounds, data_bytes);
         for (int i = 0; i < a.ncomp; i++) HIP_TRY(hipMemsetAsync(a.coef[i], 0, zero_bytes[i], c->stream));
       }
     }
@@ -2122,7 +2127,159 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
   return ok_status();
 }
 
-// Host helper: a complete baseline JFIF file around entropy-coded data// Host helper: a complete baseline JFIF file around entropy-coded data (marker order of jcmarker.c: SOI, APP0, DQT,
+// JpegEncoderHelper::compressImage's sample -> entropy-coded-data part (jpegencoderhelper.cpp:131-309) on the device: FDCT +
+// quantization (and rgb_ycc_convert for a packed RGB gain map) feed the restart-interval Huffman encoder without the
+// coefficients leaving HBM; only the samples go up and only the compressed bytes come down.
+uhdr_error_info_t uhdr_hip_jpeg_encode_scan(uhdr_hip_ctx_t* c, const uhdr_hip_jpeg_scan_t* scan, const uint16_t qtable[3][64],
+                                            const uint8_t* const planes[3], const unsigned int strides[3], int rgb_channels, uint8_t* out,
+                                            size_t out_capacity, size_t* out_bytes) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  if (!scan || !qtable || !planes || !strides || !out || !out_bytes) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument for jpeg_encode_scan");
+  if (rgb_channels != 0 && rgb_channels != 3 && rgb_channels != 4) return err_status(UHDR_CODEC_INVALID_PARAM, "rgb_channels is 0 (planes), 3 (RGB888) or 4 (RGBA8888), received %d", rgb_channels);
+  uhdr_hip_jpeg_scan_t sc = *scan;
+  const int nc = sc.num_components;
+  int mpr = 0, mrows = 0, bpm = 0;
+  UHDR_TRY(check_scan(&sc, false, &mpr, &mrows, &bpm));
+  if (sc.restart_interval < 1 || sc.restart_interval * bpm > 64)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "restart_interval must be in 1..%d for %d blocks per MCU, received %d", 64 / bpm, bpm, sc.restart_interval);
+  HIP_TRY(hipSetDevice(c->device));
+  size_t coef_bytes = 0;
+  for (int i = 0; i < nc; i++) {
+    if (sc.blocks_w[i] <= 0 || sc.blocks_h[i] <= 0) return err_status(UHDR_CODEC_INVALID_PARAM, "component %d has an empty block grid", i);
+    const size_t b = (size_t)sc.blocks_w[i] * sc.blocks_h[i] * 64 * sizeof(int16_t);
+    UHDR_TRY(ensure(c->jpg[1 + i], b));
+    sc.coef[i] = (const int16_t*)c->jpg[1 + i].p;
+    coef_bytes += b;
+  }
+  if (rgb_channels == 0) {
+    size_t pitch[3] = {0, 0, 0}, off[3] = {0, 0, 0}, total = 0;
+    for (int i = 0; i < nc; i++) {
+      if (!planes[i] || strides[i] < (unsigned)sc.blocks_w[i] * 8) return err_status(UHDR_CODEC_INVALID_PARAM, "plane %d: nullptr or stride below blocks_w * 8", i);
+      pitch[i] = ((size_t)sc.blocks_w[i] * 8 + 63) & ~(size_t)63;
+      off[i] = total;
+      total += pitch[i] * (size_t)sc.blocks_h[i] * 8;
+    }
+    UHDR_TRY(ensure(c->jpg[4], total));
+    for (int i = 0; i < nc; i++) {
+      uint8_t* d = (uint8_t*)c->jpg[4].p + off[i];
+      HIP_TRY(hipMemcpy2DAsync(d, pitch[i], planes[i], strides[i], (size_t)sc.blocks_w[i] * 8, (size_t)sc.blocks_h[i] * 8, hipMemcpyHostToDevice, c->stream));
+      UHDR_TRY(uhdr_hip_fdct_quant_dev(c, d, pitch[i], sc.blocks_w[i], sc.blocks_h[i], qtable[i], (int16_t*)c->jpg[1 + i].p));
+    }
+  } else {
+    if (nc != 3 || bpm != 3) return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "packed RGB input is a 3-component 4:4:4 scan");
+    if (sc.w % 8 || sc.h % 8 || (unsigned)sc.blocks_w[0] * 8 != sc.w || (unsigned)sc.blocks_h[0] * 8 != sc.h)
+      return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "packed RGB input needs dimensions that are multiples of 8 (libjpeg's edge replication is outside the HIP path)");
+    if (memcmp(qtable[1], qtable[2], 64 * sizeof(uint16_t)))
+      return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "packed RGB input with different Cb and Cr quantization tables is outside the HIP path");
+    if (!planes[0] || strides[0] < sc.w) return err_status(UHDR_CODEC_INVALID_PARAM, "RGB image: nullptr or stride below the width");
+    const size_t pitch_px = ((size_t)sc.w + 15) & ~(size_t)15;
+    UHDR_TRY(ensure(c->jpg[4], pitch_px * (size_t)rgb_channels * sc.h));
+    HIP_TRY(hipMemcpy2DAsync(c->jpg[4].p, pitch_px * rgb_channels, planes[0], (size_t)strides[0] * rgb_channels, (size_t)sc.w * rgb_channels, sc.h,
+                             hipMemcpyHostToDevice, c->stream));
+    uhdr_raw_image_t rgb;
+    memset(&rgb, 0, sizeof rgb);
+    rgb.fmt = rgb_channels == 3 ? UHDR_IMG_FMT_24bppRGB888 : UHDR_IMG_FMT_32bppRGBA8888;
+    rgb.w = sc.w;
+    rgb.h = sc.h;
+    rgb.planes[0] = c->jpg[4].p;
+    rgb.stride[0] = (unsigned int)pitch_px;
+    UHDR_TRY(uhdr_hip_fdct_quant_rgb_dev(c, &rgb, qtable[0], qtable[1], (int16_t*)c->jpg[1].p, (int16_t*)c->jpg[2].p, (int16_t*)c->jpg[3].p));
+  }
+  size_t cap = coef_bytes / 4 + (1u << 20), n = 0;
+  UHDR_TRY(ensure(c->jpg[0], cap));
+  uhdr_error_info_t hs = uhdr_hip_huffman_encode_dev(c, &sc, (uint8_t*)c->jpg[0].p, c->jpg[0].cap, &n);
+  if (hs.error_code == UHDR_CODEC_MEM_ERROR && n > c->jpg[0].cap) {  // busier data than the guess: the call reported the size it needs
+    UHDR_TRY(ensure(c->jpg[0], n));
+    hs = uhdr_hip_huffman_encode_dev(c, &sc, (uint8_t*)c->jpg[0].p, c->jpg[0].cap, &n);
+  }
+  if (hs.error_code != UHDR_CODEC_OK) return hs;
+  *out_bytes = n;
+  if (n > out_capacity) return err_status(UHDR_CODEC_MEM_ERROR, "output buffer of %zu bytes is too small for %zu bytes of entropy-coded data", out_capacity, n);
+  HIP_TRY(hipMemcpyAsync(out, c->jpg[0].p, n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return ok_status();
+}
+
+// JpegDecoderHelper::decompressImage (jpegdecoderhelper.cpp:169-535) for a baseline file whose headers are parsed: entropy
+// decode, dequantization, JDCT_ISLOW IDCT and (for RGB / RGBA output of a 4:4:4 file) ycc_rgb_convert on the device; only
+// the compressed bytes go up and only the decoded samples come down.
+uhdr_error_info_t uhdr_hip_jpeg_decode_scan(uhdr_hip_ctx_t* c, const uhdr_hip_jpeg_header_t* hdr, const uint8_t* scan_data, size_t scan_bytes,
+                                            int out_channels, int variant, uint8_t* const planes[3], const unsigned int hstride[3],
+                                            const unsigned int vstride[3]) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  if (!hdr || !scan_data || !planes || !hstride || !vstride) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument for jpeg_decode_scan");
+  if (out_channels != 0 && out_channels != 3 && out_channels != 4) return err_status(UHDR_CODEC_INVALID_PARAM, "out_channels is 0 (planes), 3 (RGB888) or 4 (RGBA8888), received %d", out_channels);
+  uhdr_hip_jpeg_scan_t sc = hdr->scan;
+  const int nc = sc.num_components;
+  int mpr = 0, mrows = 0, bpm = 0;
+  UHDR_TRY(check_scan(&sc, false, &mpr, &mrows, &bpm));
+  if (out_channels != 0) {
+    if (nc != 3 || sc.h_samp[0] != 1 || sc.v_samp[0] != 1 || sc.h_samp[1] != 1 || sc.v_samp[1] != 1 || sc.h_samp[2] != 1 || sc.v_samp[2] != 1)
+      return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "RGB output needs a 3-component 4:4:4 file (libjpeg's upsampling is outside the HIP path)");
+    if (memcmp(hdr->qtable[1], hdr->qtable[2], sizeof hdr->qtable[1]))
+      return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "RGB output with different Cb and Cr quantization tables is outside the HIP path");
+    if (!planes[0] || hstride[0] < sc.w || vstride[0] < sc.h) return err_status(UHDR_CODEC_INVALID_PARAM, "destination smaller than the %ux%u image", sc.w, sc.h);
+  }
+  // the entropy-coded data ends at the first marker that is neither a stuffed zero, a fill byte nor RSTn (T.81 B.1.1.2 / B.2.1)
+  size_t e = 0;
+  while (e < scan_bytes) {
+    const uint8_t* f = (const uint8_t*)memchr(scan_data + e, 0xff, scan_bytes - e);
+    if (!f) { e = scan_bytes; break; }
+    e = (size_t)(f - scan_data);
+    if (e + 1 >= scan_bytes) { e = scan_bytes; break; }
+    const uint8_t m = scan_data[e + 1];
+    if (m == 0x00 || (m & 0xf8) == 0xd0) { e += 2; continue; }
+    if (m == 0xff) { e += 1; continue; }
+    break;
+  }
+  const size_t nbytes = e;
+  if (nbytes == 0) return err_status(UHDR_CODEC_INVALID_PARAM, "no entropy-coded data");
+  HIP_TRY(hipSetDevice(c->device));
+  UHDR_TRY(ensure(c->jpg[0], nbytes + 64));
+  HIP_TRY(hipMemcpyAsync(c->jpg[0].p, scan_data, nbytes, hipMemcpyHostToDevice, c->stream));
+  for (int i = 0; i < nc; i++) {
+    UHDR_TRY(ensure(c->jpg[1 + i], (size_t)sc.blocks_w[i] * sc.blocks_h[i] * 64 * sizeof(int16_t)));
+    sc.coef[i] = (const int16_t*)c->jpg[1 + i].p;
+  }
+  c->huff_serial_ok = false;
+  const uhdr_error_info_t hs = uhdr_hip_huffman_decode_dev(c, &sc, &hdr->tables, (const uint8_t*)c->jpg[0].p, nbytes);
+  c->huff_serial_ok = true;
+  if (hs.error_code != UHDR_CODEC_OK) return hs;
+  if (out_channels == 0) {
+    size_t pitch[3] = {0, 0, 0}, off[3] = {0, 0, 0}, total = 0;
+    for (int i = 0; i < nc; i++) {
+      pitch[i] = ((size_t)sc.blocks_w[i] * 8 + 63) & ~(size_t)63;
+      off[i] = total;
+      total += pitch[i] * (size_t)sc.blocks_h[i] * 8;
+    }
+    UHDR_TRY(ensure(c->jpg[4], total));
+    for (int i = 0; i < nc; i++) {
+      if (!planes[i]) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for destination plane %d", i);
+      uint8_t* d = (uint8_t*)c->jpg[4].p + off[i];
+      UHDR_TRY(uhdr_hip_idct_dequant_dev(c, sc.coef[i], sc.blocks_w[i], sc.blocks_h[i], hdr->qtable[i], d, pitch[i]));
+      const size_t cols = hstride[i] < (unsigned)sc.blocks_w[i] * 8 ? hstride[i] : (size_t)sc.blocks_w[i] * 8;
+      const size_t rows = vstride[i] < (unsigned)sc.blocks_h[i] * 8 ? vstride[i] : (size_t)sc.blocks_h[i] * 8;
+      HIP_TRY(hipMemcpy2DAsync(planes[i], hstride[i], d, pitch[i], cols, rows, hipMemcpyDeviceToHost, c->stream));
+    }
+  } else {
+    uhdr_raw_image_t rgb;
+    memset(&rgb, 0, sizeof rgb);
+    rgb.fmt = out_channels == 3 ? UHDR_IMG_FMT_24bppRGB888 : UHDR_IMG_FMT_32bppRGBA8888;
+    rgb.w = sc.w;
+    rgb.h = sc.h;
+    const size_t pitch_px = ((size_t)sc.w + 63) & ~(size_t)63;
+    UHDR_TRY(ensure(c->jpg[4], pitch_px * (size_t)out_channels * sc.h));
+    rgb.planes[0] = c->jpg[4].p;
+    rgb.stride[0] = (unsigned int)pitch_px;
+    UHDR_TRY(uhdr_hip_idct_dequant_rgb_dev(c, sc.coef[0], sc.coef[1], sc.coef[2], sc.blocks_w[0], sc.blocks_h[0], hdr->qtable[0], hdr->qtable[1], variant, &rgb));
+    HIP_TRY(hipMemcpy2DAsync(planes[0], (size_t)hstride[0] * out_channels, c->jpg[4].p, pitch_px * out_channels, (size_t)sc.w * out_channels, sc.h,
+                             hipMemcpyDeviceToHost, c->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return ok_status();
+}
+
+// Host helper: a complete baseline JFIF file around entropy-coded data (marker order of jcmarker.c: SOI, APP0, DQT,
 // SOF0, DHT, DRI, SOS ... EOI).  Returns the file size, or 0 when `cap` is too small / the description is invalid.
 size_t uhdr_hip_jpeg_assemble(const uhdr_hip_jpeg_scan_t* sc, const uint16_t qt_luma[64], const uint16_t qt_chroma[64], const uint8_t* scan_data,
                               size_t scan_bytes, uint8_t* out, size_t cap) {

@@ -372,6 +372,57 @@ class UltraHdr:
                                     [(sc.h_samp[c], sc.v_samp[c]) for c in range(nc)], sc.restart_interval, tables=(bits, vals))
         return hdr, coefs
 
+    def jpeg_decode(self, jpeg: bytes, rgb_channels: int = 0, libjpeg_variant: int = 0):
+        """JpegDecoderHelper::decompressImage for a baseline JPEG file, entirely on the device (entropy decode, dequantization,
+        IDCT, and ycc -> rgb when rgb_channels is 3 / 4): host bytes in, numpy arrays out.  rgb_channels 0: the list of
+        component planes [blocks_h*8, blocks_w*8] uint8 (block padding included, as libjpeg's raw-data mode);
+        3 / 4: one [h, w, channels] array (4:4:4 files only)."""
+        hdr = self.jpeg_parse(jpeg)
+        sc = hdr.scan
+        nc = sc.num_components
+        buf = np.frombuffer(jpeg, dtype=np.uint8)
+        if rgb_channels:
+            outs = [np.empty((sc.h, sc.w, rgb_channels), dtype=np.uint8)]
+            hs = [sc.w, 0, 0]
+            vs = [sc.h, 0, 0]
+        else:
+            outs = [np.empty((sc.blocks_h[c] * 8, sc.blocks_w[c] * 8), dtype=np.uint8) for c in range(nc)]
+            hs = [sc.blocks_w[c] * 8 if c < nc else 0 for c in range(3)]
+            vs = [sc.blocks_h[c] * 8 if c < nc else 0 for c in range(3)]
+        ptrs = (C.c_void_p * 3)(*[o.ctypes.data for o in outs] + [None] * (3 - len(outs)))
+        self._call(False, self.lib.uhdr_hip_jpeg_decode_scan, self.ctx.handle, C.byref(hdr), C.c_void_p(buf.ctypes.data + hdr.scan_offset),
+                   buf.size - hdr.scan_offset, rgb_channels, libjpeg_variant, ptrs, (C.c_uint * 3)(*hs), (C.c_uint * 3)(*vs))
+        return outs[0] if rgb_channels else outs
+
+    def jpeg_encode(self, planes, w: int, h: int, sampling, qt_luma, qt_chroma, rgb_channels: int = 0) -> bytes:
+        """JpegEncoderHelper::compressImage on the device, Huffman pass included (restart intervals of 64 // blocks-per-MCU
+        MCUs: one wavefront each): host samples in, a complete baseline JFIF file out.  planes: uint8 numpy arrays
+        [blocks_h*8, blocks_w*8] per component (padded to whole blocks), or -- rgb_channels 3 / 4 -- one [h, w, channels]
+        array for a 4:4:4 file (libjpeg's rgb_ycc_convert included)."""
+        class _Grid:  # what _scan reads from a coefficient array
+            def __init__(self, bh, bw):
+                self.shape = (bh, bw, 64)
+
+        if rgb_channels:
+            img = np.ascontiguousarray(planes, dtype=np.uint8)
+            grids = [_Grid(h // 8, w // 8)] * 3
+            srcs, strides = [img], [w, 0, 0]
+        else:
+            srcs = [np.ascontiguousarray(p, dtype=np.uint8) for p in planes]
+            grids = [_Grid(p.shape[0] // 8, p.shape[1] // 8) for p in srcs]
+            strides = [p.shape[1] for p in srcs] + [0] * (3 - len(srcs))
+        bpm = sum(hs * vs for hs, vs in sampling) if len(sampling) > 1 else 1
+        ri = 64 // bpm
+        sc = self._scan(grids, w, h, sampling, ri)
+        qt = np.zeros((3, 64), dtype=np.uint16)
+        qt[0], qt[1], qt[2] = qt_luma, qt_chroma, qt_chroma
+        ptrs = (C.c_void_p * 3)(*[p.ctypes.data for p in srcs] + [None] * (3 - len(srcs)))
+        out = np.zeros(sum(p.size for p in srcs) + (1 << 16), dtype=np.uint8)
+        n = C.c_size_t(0)
+        self._call(False, self.lib.uhdr_hip_jpeg_encode_scan, self.ctx.handle, C.byref(sc), C.c_void_p(qt.ctypes.data), ptrs,
+                   (C.c_uint * 3)(*strides), rgb_channels, C.c_void_p(out.ctypes.data), out.size, C.byref(n))
+        return self.jpeg_assemble(grids, w, h, sampling, ri, qt_luma, qt_chroma, out[: n.value].tobytes())
+
     def jpeg_assemble(self, coefs, w: int, h: int, sampling, restart_interval: int, qt_luma, qt_chroma, scan_data: bytes) -> bytes:
         """Host helper: a complete baseline JFIF file around entropy-coded data (coefs only supply the block grids)."""
         sc = self._scan(coefs, w, h, sampling, restart_interval)

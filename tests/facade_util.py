@@ -27,20 +27,21 @@ def built():
     return os.path.isfile(APP) and os.path.isfile(FACADE)
 
 
-def run_app(args, gpu, cwd, timeout=600):
+def run_app(args, gpu, cwd, timeout=600, env_extra=None):
     """-> (returncode, stdout, stderr, stage lines of the seam trace)."""
     env = dict(os.environ)
     env["UHDR_HIP_SEAM_TRACE"] = "1"
+    env.update(env_extra or {})
     cmd = [APP] + [str(a) for a in args] + (["-u", "1"] if gpu else [])
     p = subprocess.run(cmd, cwd=cwd, env=env, capture_output=True, text=True, timeout=timeout)
     trace = [l for l in p.stderr.splitlines() if l.startswith("uhdr_hip_seam:")]
     return p.returncode, p.stdout, p.stderr, trace
 
 
-def encode_api1(p010_path, yuv_path, w, h, out, gpu, cwd, extra=()):
+def encode_api1(p010_path, yuv_path, w, h, out, gpu, cwd, extra=(), env_extra=None):
     """BASELINE config 1's command line: P010 (P3... here BT.2100 / HLG / narrow) + YUV420 (BT.709) -> UltraHDR JPEG."""
     return run_app(["-m", 0, "-p", p010_path, "-y", yuv_path, "-w", w, "-h", h, "-a", 0, "-b", 1, "-C", 2, "-c", 0, "-t", 1,
-                    "-R", 0, "-z", out] + list(extra), gpu, cwd)
+                    "-R", 0, "-z", out] + list(extra), gpu, cwd, env_extra=env_extra)
 
 
 def decode(jpg, ct, fmt, out, gpu, cwd):

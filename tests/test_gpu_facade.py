@@ -16,7 +16,7 @@ pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not F.built(), reason="facade 
 
 
 def _stages(trace, where="device"):
-    return sorted({l.split()[1] for l in trace if l.endswith("-> " + where)})
+    return sorted({l.split(" -> ")[0].split()[-1] for l in trace if l.endswith("-> " + where)})
 
 
 def _fixture(d):
@@ -52,7 +52,8 @@ def test_config1_decode_through_the_facade_equals_the_cpu_reference(ct, fmt, bpp
         rc, _, err, trace = F.decode("in.jpg", ct, fmt, "gpu.raw", True, d)
         assert rc == 0, err
         st = _stages(trace)
-        assert "apply_gainmap" in st and "idct_planes" in st, trace
+        # the base image and the gain map are decoded on the device from their compressed bytes (entropy decode included)
+        assert "apply_gainmap" in st and "jpeg_decode_scan" in st and "idct_planes" not in st, trace
         a, b = F.read(os.path.join(d, "cpu.raw")), F.read(os.path.join(d, "gpu.raw"))
         assert a.size == b.size == 1280 * 720 * bpp
         assert np.array_equal(a, b), f"{int((a != b).sum())} differing bytes"
@@ -108,3 +109,33 @@ def test_api0_encode_through_the_facade():
         assert a.size == b.size == w * h * 4
         # a +-1 8-bit sample before the JPEG DCT moves a handful of decoded pixels slightly
         assert (a != b).mean() < 1e-3 and np.abs(a - b).max() < 0.25
+
+
+@pytest.mark.parametrize("multi", [False, True])
+def test_encode_with_device_entropy_coding_decodes_to_the_same_pixels(multi):
+    """UHDR_HIP_SEAM_DEVICE_ENTROPY=1 (opt-in): compressImage runs on the device including the Huffman pass,
+    one restart interval per wavefront.  The file differs from the reference's by the DRI segments and RSTn markers only:
+    decoded by the CPU reference (no acceleration) it gives exactly the pixels of the CPU-encoded file, and the accelerated
+    decoder -- whose entropy stage then takes the one-lane-per-interval kernel -- agrees."""
+    with tempfile.TemporaryDirectory() as d:
+        p, y = _fixture(d)
+        extra = ("-M", 1, "-s", 1) if multi else ()  # 3-channel map at full resolution: the packed-RGB route
+        rc, _, err, _ = F.encode_api1(p, y, 1280, 720, "cpu.jpg", False, d, extra=extra)
+        assert rc == 0, err
+        rc, _, err, trace = F.encode_api1(p, y, 1280, 720, "dev.jpg", True, d, extra=extra, env_extra={"UHDR_HIP_SEAM_DEVICE_ENTROPY": "1"})
+        assert rc == 0, err
+        lines = [l for l in trace if "jpeg_encode_scan -> device" in l]
+        assert len(lines) == 2 and "fdct_planes" not in _stages(trace), trace  # base image and gain map
+        a, b = F.read(os.path.join(d, "cpu.jpg")), F.read(os.path.join(d, "dev.jpg"))
+        assert b.size > a.size and bytes(b[:2]) == b"\xff\xd8"
+        assert bytes([0xff, 0xdd]) in b.tobytes() and bytes([0xff, 0xdd]) not in a.tobytes()[:2000]
+        for name in ("cpu", "dev"):
+            rc, _, err, _ = F.decode(name + ".jpg", 0, 4, name + ".raw", False, d)
+            assert rc == 0, err
+        pa, pb = F.read(os.path.join(d, "cpu.raw")), F.read(os.path.join(d, "dev.raw"))
+        assert pa.size == pb.size == 1280 * 720 * 8
+        assert np.array_equal(pa, pb), f"{int((pa != pb).sum())} differing bytes"
+        rc, _, err, trace = F.decode("dev.jpg", 0, 4, "dev_gpu.raw", True, d)
+        assert rc == 0, err
+        assert "jpeg_decode_scan" in _stages(trace), trace
+        assert np.array_equal(F.read(os.path.join(d, "dev_gpu.raw")), pa)

@@ -1,0 +1,176 @@
+"""GPU: uhdr_hip_jpeg_decode_scan -- JpegDecoderHelper::decompressImage (jpegdecoderhelper.cpp:169-535) for baseline files
+with every stage on the device (entropy decode, dequantization, JDCT_ISLOW IDCT, ycc_rgb_convert).  Checked bit for bit
+against (a) the oracle's IDCT / colour conversion of the coefficients that went into the file, for every sampling layout,
+with and without restart markers, sizes with partial blocks, and (b) the real reference's decompressImage on files the
+real reference wrote (planar and RGB modes)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from libultrahdr_amd import capi as A
+from libultrahdr_amd import synth
+from oracle import loader as L
+
+from test_gpu_parity import _random_coefs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def uhdr(hip_ctx):
+    from libultrahdr_amd.ultrahdr import UltraHdr
+
+    return UltraHdr(ctx=hip_ctx)
+
+
+S420, S444, S422, GRAY = [(2, 2), (1, 1), (1, 1)], [(1, 1)] * 3, [(2, 1), (1, 1), (1, 1)], [(1, 1)]
+CASES = [(640, 480, S420, 0), (333, 211, S420, 0), (500, 300, S444, 0), (401, 203, S422, 0), (1000, 400, GRAY, 0),
+         (640, 480, S420, 4), (333, 211, S444, 7), (1000, 400, GRAY, 50), (64, 48, S420, 0), (1920, 1080, S420, 0)]
+
+
+def _file(rng, w, h, sampling, ri, quality=90, kind="sparse"):
+    coefs = _random_coefs(rng, w, h, sampling, kind)
+    scan = L.huffman_encode_port(coefs, w, h, sampling, ri)
+    ql, qc = L.quant_table_port(quality, False), L.quant_table_port(quality, True)
+    return coefs, (ql, qc), L.jpeg_assemble_port(coefs, w, h, sampling, ri, ql, qc, scan)
+
+
+@pytest.mark.parametrize("w,h,sampling,ri", CASES)
+def test_planes_equal_the_oracles_idct_of_the_coefficients(uhdr, w, h, sampling, ri):
+    rng = np.random.default_rng(1000 + w + ri)
+    coefs, (ql, qc), jpeg = _file(rng, w, h, sampling, ri)
+    got = uhdr.jpeg_decode(jpeg)
+    assert len(got) == len(coefs)
+    for c in range(len(coefs)):
+        want = L.idct_dequant_port(coefs[c], ql if c == 0 else qc)
+        assert got[c].shape == want.shape, c
+        assert np.array_equal(got[c], want), (c, int((got[c] != want).sum()))
+
+
+@pytest.mark.parametrize("channels,variant", [(3, 0), (3, 1), (4, 0), (4, 1)])
+def test_rgb_output_equals_the_oracles_colour_conversion(uhdr, channels, variant):
+    rng = np.random.default_rng(77 + channels * 2 + variant)
+    for (w, h, ri) in ((500, 300, 0), (333, 211, 7), (1280, 720, 0)):
+        coefs, (ql, qc), jpeg = _file(rng, w, h, S444, ri, quality=95)
+        planes = [L.idct_dequant_port(coefs[c], ql if c == 0 else qc)[:h, :w] for c in range(3)]
+        want = L.jpeg_ycc_to_rgb_port(*planes, out_bpp=channels, variant=variant).reshape(h, w, channels)
+        got = uhdr.jpeg_decode(jpeg, channels, variant)
+        assert np.array_equal(got, want), (w, h, ri, int((got != want).sum()))
+
+
+def test_rgb_output_of_a_subsampled_file_is_refused(uhdr):
+    rng = np.random.default_rng(5)
+    _, _, jpeg = _file(rng, 640, 480, S420, 0)
+    with pytest.raises(A.UhdrError) as e:
+        uhdr.jpeg_decode(jpeg, 3)
+    assert e.value.code == A.UHDR_CODEC_UNSUPPORTED_FEATURE
+
+
+def test_truncated_data_is_reported_and_the_context_stays_usable(uhdr):
+    rng = np.random.default_rng(6)
+    coefs, (ql, qc), jpeg = _file(rng, 640, 480, S420, 0)
+    hdr = uhdr.jpeg_parse(jpeg)
+    cut = jpeg[: hdr.scan_offset + hdr.scan_bytes // 2] + b"\xff\xd9"
+    with pytest.raises(A.UhdrError) as e:
+        uhdr.jpeg_decode(cut)
+    assert e.value.code == A.UHDR_CODEC_INVALID_PARAM
+    got = uhdr.jpeg_decode(jpeg)
+    assert np.array_equal(got[0], L.idct_dequant_port(coefs[0], ql))
+
+
+def _ref_decode(jpeg, mode):
+    ref = L.ref()
+    buf = np.frombuffer(jpeg, dtype=np.uint8)
+    dst = A.RawImage()
+    store = np.zeros(1 << 26, dtype=np.uint8)
+    assert ref.ref_jpeg_decompress(buf.ctypes.data, buf.size, mode, C.byref(dst), store.ctypes.data, store.size) == 0
+    return dst, store
+
+
+@pytest.mark.parametrize("w,h", [(1280, 720), (3840, 2160), (1366, 768)])
+def test_reference_written_base_image_decodes_like_the_reference(uhdr, w, h):
+    """4:2:0 q95 file from JpegEncoderHelper::compressImage; planes vs JpegDecoderHelper::decompressImage(DECODE_TO_YCBCR_CS)."""
+    if L.ref() is None:
+        pytest.skip("oracle/_ref not built")
+    img = synth.make_sdr_yuv420(w, h, align=8)
+    jpeg = L.ref_jpeg_compress(img, 95)
+    dst, store = _ref_decode(jpeg, 0)
+    assert dst.fmt == A.UHDR_IMG_FMT_12bppYCbCr420
+    got = uhdr.jpeg_decode(jpeg)
+    off = 0
+    for c in range(3):  # oracle/ref_shim.cpp packs the planes back to back: stride x h rows of luma, stride x h/2 of each chroma
+        pw, ph = (w, h) if c == 0 else (w // 2, h // 2)
+        stride = dst.stride[c]
+        want = store[off: off + stride * ph].reshape(ph, stride)[:, :pw]
+        off += stride * ph
+        assert np.array_equal(got[c][:ph, :pw], want), c
+
+
+def test_reference_written_three_channel_map_decodes_like_the_reference(uhdr):
+    """3-channel gain map (JCS_RGB in, 4:4:4): RGB output vs JpegDecoderHelper::decompressImage(DECODE_STREAM)."""
+    if L.ref() is None:
+        pytest.skip("oracle/_ref not built")
+    w, h = 1920, 1080
+    gm = synth.make_gainmap(w, h, 3)
+    jpeg = L.ref_jpeg_compress(gm, 95)
+    dst, store = _ref_decode(jpeg, 1)
+    bpp = 4 if dst.fmt == A.UHDR_IMG_FMT_32bppRGBA8888 else 3
+    want = store[: dst.stride[0] * bpp * h].reshape(h, dst.stride[0] * bpp)[:, : w * bpp].reshape(h, w, bpp)
+    got = uhdr.jpeg_decode(jpeg, bpp, 1)  # oracle/_ref links the image's IJG libjpeg 9: the refined green constants
+    assert np.array_equal(got, want), int((got != want).sum())
+
+
+# ---- the encode-side mirror: uhdr_hip_jpeg_encode_scan ----------------------------------------------------------------------
+def _planes(rng, w, h, sampling):
+    hmax, vmax = max(s[0] for s in sampling), max(s[1] for s in sampling)
+    out = []
+    for (hs, vs) in sampling:
+        pw, ph = -(-w * hs // hmax), -(-h * vs // vmax)
+        pw, ph = -(-pw // 8) * 8, -(-ph // 8) * 8
+        yy, xx = np.mgrid[0:ph, 0:pw]
+        base = 128 + 90 * np.sin(xx / 37.0) * np.cos(yy / 23.0) + rng.normal(0, 6, (ph, pw))
+        out.append(np.clip(base, 0, 255).astype(np.uint8))
+    return out
+
+
+@pytest.mark.parametrize("w,h,sampling", [(640, 480, S420), (1920, 1080, S420), (512, 256, S444), (400, 200, S422), (1000, 400, GRAY), (64, 64, S420)])
+def test_device_encoded_file_holds_the_oracles_fdct_coefficients(uhdr, w, h, sampling):
+    """samples -> FDCT + quantize + Huffman on the device -> file; libjpeg-style decode of that file (the oracle's entropy
+    decoder) gives the oracle's FDCT coefficients of the same samples, and the device decoder inverts it."""
+    rng = np.random.default_rng(w * 3 + h)
+    planes = _planes(rng, w, h, sampling)
+    ql, qc = L.quant_table_port(95, False), L.quant_table_port(95, True)
+    jpeg = uhdr.jpeg_encode(planes, w, h, sampling, ql, qc)
+    hdr = uhdr.jpeg_parse(jpeg)
+    bpm = sum(a * b for a, b in sampling) if len(sampling) > 1 else 1
+    assert hdr.scan.restart_interval == 64 // bpm
+    want = [L.fdct_quant_port(p, p.shape[1], p.shape[1] // 8, p.shape[0] // 8, ql if c == 0 else qc) for c, p in enumerate(planes)]
+    # real component grids (the planes may be padded beyond them up to the MCU grid)
+    shapes = [(hdr.scan.blocks_h[c], hdr.scan.blocks_w[c]) for c in range(len(planes))]
+    rc, got = L.huffman_decode_port(shapes, w, h, sampling, hdr.scan.restart_interval, jpeg[hdr.scan_offset: hdr.scan_offset + hdr.scan_bytes])
+    assert rc == 0
+    for c in range(len(planes)):
+        bh, bw = shapes[c]
+        assert np.array_equal(got[c], want[c][:bh, :bw]), c
+    back = uhdr.jpeg_decode(jpeg)
+    for c in range(len(planes)):
+        bh, bw = shapes[c]
+        assert np.array_equal(back[c], L.idct_dequant_port(want[c][:bh, :bw], ql if c == 0 else qc)), c
+
+
+def test_device_encoded_rgb_map_holds_the_oracles_coefficients(uhdr):
+    rng = np.random.default_rng(31)
+    w, h = 640, 360
+    yy, xx = np.mgrid[0:h, 0:w]
+    rgb = np.stack([np.clip(128 + 80 * np.sin(xx / (30.0 + 7 * k)) * np.cos(yy / 19.0) + rng.normal(0, 5, (h, w)), 0, 255) for k in range(3)], axis=-1).astype(np.uint8)
+    ql, qc = L.quant_table_port(95, False), L.quant_table_port(95, True)
+    jpeg = uhdr.jpeg_encode(rgb, w, h, S444, ql, qc, rgb_channels=3)
+    hdr = uhdr.jpeg_parse(jpeg)
+    assert hdr.scan.restart_interval == 21
+    ycc = L.jpeg_rgb_to_ycc_port(rgb.reshape(h, w * 3), w, w, h)
+    want = [L.fdct_quant_port(ycc[c], w, w // 8, h // 8, ql if c == 0 else qc) for c in range(3)]
+    rc, got = L.huffman_decode_port([(h // 8, w // 8)] * 3, w, h, S444, 21, jpeg[hdr.scan_offset: hdr.scan_offset + hdr.scan_bytes])
+    assert rc == 0
+    for c in range(3):
+        assert np.array_equal(got[c], want[c]), c
