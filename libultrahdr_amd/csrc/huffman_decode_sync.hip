@@ -22,6 +22,9 @@
 //      workgroup-wide scan per component.
 // Malformed streams (undefined code, run past the end of a block) only count as errors in step 4, where every lane is
 // on the true path; steps 2-3 treat them as ordinary (deterministic) state transitions of a decoder that is lost.
+#include <cstdio>
+#include <cstdlib>
+
 #include "uhdr_types.h"
 
 namespace uhdr {
@@ -95,13 +98,14 @@ struct Staged {
   const uint32_t* w;   // the wave's LDS region, as words
   uint32_t cshift;     // log2(bytes per subsequence)
   __device__ __forceinline__ uint32_t word(uint32_t byte_off) const {  // byte_off: multiple of 4, relative to the region
-    const uint32_t chunk = byte_off >> cshift, in = byte_off & ((1u << cshift) - 1u);
-    return __builtin_bswap32(w[chunk * ((1u << (cshift - 2)) + 1u) + (in >> 2)]);
+    // chunk * (words per chunk + 1 pad word) + word inside the chunk == byte_off / 4 + chunk
+    return __builtin_bswap32(w[(byte_off >> 2) + (byte_off >> cshift)]);
   }
 };
 struct Bits {  // MSB-first reader over a staged region; region_bit = global bit index of the region's first bit
   Staged st;
-  uint32_t region_bit, next;  // next: byte offset (relative, multiple of 4) of the next word to load
+  uint32_t region_bit, next;  // next: byte offset (relative, multiple of 4) of the next word to append
+  uint32_t pre;               // that word, already loaded: the LDS read of a refill is never on a symbol's critical path
   uint64_t acc;
   int n;
   __device__ __forceinline__ void seek(uint32_t bit) {
@@ -109,15 +113,18 @@ struct Bits {  // MSB-first reader over a staged region; region_bit = global bit
     next = (rel >> 5) << 2;
     acc = 0;
     n = 0;
+    pre = st.word(next);
     fill();
     fill();
     n -= (int)(rel & 31u);
   }
+  // after fill(): n > 32, enough for one whole symbol (code <= 16 bits + magnitude <= 15 bits)
   __device__ __forceinline__ void fill() {
     if (n <= 32) {
-      acc = (acc << 32) | st.word(next);
+      acc = (acc << 32) | pre;
       next += 4;
       n += 32;
+      pre = st.word(next);
     }
   }
   __device__ __forceinline__ uint32_t pos() const { return region_bit + next * 8u - (uint32_t)n; }
@@ -126,9 +133,9 @@ struct Bits {  // MSB-first reader over a staged region; region_bit = global bit
 };
 // stage bytes [first, first + 64 * cb + 16) of the clean stream (zeros past its end) into the wave's LDS region
 __device__ __forceinline__ void stage_wave(const uint8_t* __restrict__ clean, uint32_t nclean, uint32_t first, uint32_t cshift, uint32_t* lds,
-                                           uint32_t lane) {
-  const uint32_t cb = 1u << cshift, total = 64u * cb + 16u, pitch = (cb >> 2) + 1u;
-  for (uint32_t off = lane * 16u; off < total; off += 64u * 16u) {
+                                           uint32_t lane, uint32_t nchunks = 64u, uint32_t nthreads = 64u) {
+  const uint32_t cb = 1u << cshift, total = nchunks * cb + 16u, pitch = (cb >> 2) + 1u;
+  for (uint32_t off = lane * 16u; off < total; off += nthreads * 16u) {
     const uint32_t g = first + off;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (g + 16u <= nclean && ((uintptr_t)(clean + g) & 15u) == 0) {
@@ -170,7 +177,6 @@ __device__ __forceinline__ Step decode_step(Bits& r, const HuffFastTable* tabs, 
   uint32_t s = is_dc ? rs : rs & 15u;
   const uint32_t run = is_dc ? 0u : rs >> 4;
   if (s > 15u) { o.bad = true; s = 0; }  // a DC size category beyond 15
-  r.fill();
   const int raw = s ? (int)r.peek((int)s) : 0;
   r.skip((int)s);
   o.value = (s && raw < (1 << (s - 1))) ? raw - (1 << s) + 1 : raw;  // HUFF_EXTEND
@@ -195,11 +201,13 @@ struct ScanLds {
   int vs[4], hs[4], bw[4], bh[4];
   int16_t* coef[4];
 };
+// TRACK: the state-tracking form of the tables (see track_span) instead of the symbol form
+template <bool TRACK = false>
 __device__ __forceinline__ void load_scan_lds(const HuffSyncArgs& a, ScanLds& L) {
-  const uint32_t* src = (const uint32_t*)a.ftabs;
+  const uint32_t* src = (const uint32_t*)(TRACK ? a.ttabs : a.ftabs);
   uint32_t* dst = (uint32_t*)L.t;
-  for (uint32_t i = threadIdx.x; i < sizeof(HuffFastTable) * 4 / 4; i += kSyncBlock) dst[i] = src[i];
-  L.zz[threadIdx.x] = a.zigzag[threadIdx.x];
+  for (uint32_t i = threadIdx.x; i < sizeof(HuffFastTable) * 4 / 4; i += blockDim.x) dst[i] = src[i];
+  if (threadIdx.x < 64) L.zz[threadIdx.x] = a.zigzag[threadIdx.x];
   if (threadIdx.x < 16) {
     const int j = (int)threadIdx.x;
     int c = a.comp_of[j];
@@ -213,6 +221,48 @@ __device__ __forceinline__ void load_scan_lds(const HuffSyncArgs& a, ScanLds& L)
     const int c = (int)threadIdx.x;
     L.vs[c] = a.vs[c]; L.hs[c] = a.hs[c]; L.bw[c] = a.bw[c]; L.bh[c] = a.bh[c]; L.coef[c] = a.coef[c];
   }
+}
+
+// State tracking without symbols: the passes that only need to know WHERE the decoder is (bit position, block in the
+// MCU, zig-zag index) read tables whose entries hold the bits a symbol consumes (code + magnitude bits) and the zig-zag
+// advance (run + 1; 16 for ZRL; 64 = to the end of the block for EOB and for undefined codes; 1 for a DC symbol) --
+// host: make_track_table.  Identical state transitions to decode_step, at about half the instructions per symbol.
+__device__ __forceinline__ void track_span(const HuffSyncArgs& a, const Staged& st, uint32_t region_bit, const ScanLds& L, uint32_t& p, uint32_t& b,
+                                           uint32_t& k, uint32_t end_bit, uint32_t& nblk) {
+  Bits r;
+  r.st = st;
+  r.region_bit = region_bit;
+  r.seek(p);
+  const uint32_t bpm = (uint32_t)a.blocks_per_mcu;
+  uint32_t cpack = 0;
+#pragma unroll
+  for (int j = 0; j < 16; j++) cpack |= ((uint32_t)a.comp_of[j] & 3u) << (2 * j);
+  constexpr uint32_t kWords = sizeof(HuffFastTable) / 2;
+  const uint16_t* T = (const uint16_t*)L.t;
+  uint32_t cbase = ((cpack >> (2u * b)) & 3u) ? 2u * kWords : 0u;  // the component's DC table; its AC table follows
+  int left = (int)(end_bit - p);
+  while (left > 0) {
+    r.fill();
+    const uint32_t w16 = r.peek(16);
+    const uint32_t tb = cbase + (k ? kWords : 0u);
+    uint32_t e = T[tb + (w16 >> 7)];
+    if (__builtin_amdgcn_ballot_w64((e & 0x8000u) != 0) != 0) {
+      const uint32_t e2 = T[tb + 512u + ((e & 0x8000u) ? (e & 31u) : 0u) * 128u + (w16 & 127u)];
+      e = (e & 0x8000u) ? e2 : e;
+    }
+    const int adv = (int)(e & 31u);
+    r.skip(adv);
+    left -= adv;
+    k += (e >> 5) & 127u;
+    if (k >= 64u) {
+      k = 0;
+      b++;
+      nblk++;
+      if (b == bpm) b = 0;
+      cbase = ((cpack >> (2u * b)) & 3u) ? 2u * kWords : 0u;
+    }
+  }
+  p = r.pos();
 }
 
 // Decodes from state (p, b, k) to the first symbol boundary at or beyond end_bit.  WRITE: store coefficients / DC
@@ -240,9 +290,13 @@ __device__ __forceinline__ void run_span(const HuffSyncArgs& a, const Staged& st
     mx = (int)(m - (uint32_t)my * (uint32_t)a.mcus_per_row);
     locate();
   }
+  // block inside the MCU -> component, two bits each: wave-uniform, so the lookup is a shift instead of an LDS read
+  uint32_t cpack = 0;
+#pragma unroll
+  for (int j = 0; j < 16; j++) cpack |= ((uint32_t)a.comp_of[j] & 3u) << (2 * j);
   while (r.pos() < end_bit && (!WRITE || blk < a.total_blocks)) {
     r.fill();
-    const Step o = decode_step(r, L.t, L.comp[b], k);
+    const Step o = decode_step(r, L.t, (cpack >> (2u * b)) & 3u, k);
     bad = bad || o.bad;
     if (WRITE) {
       if (o.is_dc) a.dcd[blk] = o.value;
@@ -288,7 +342,7 @@ __global__ __launch_bounds__(kSyncBlock) void sync_round_kernel(const HuffSyncAr
     if (i < nsub) { sout[i] = sin[i]; cout[i] = 0; }
     return;
   }
-  load_scan_lds(a, L);
+  load_scan_lds<true>(a, L);
   const uint32_t cshift = 31u - (uint32_t)__builtin_clz(a.sub_bits >> 3);
   const uint32_t first_byte = blockIdx.x * kSyncBlock * (a.sub_bits >> 3);
   stage_wave(a.clean, nclean, first_byte, cshift, s_stage, threadIdx.x);
@@ -309,7 +363,7 @@ __global__ __launch_bounds__(kSyncBlock) void sync_round_kernel(const HuffSyncAr
   const uint32_t end_bit = min((i + 1) * a.sub_bits, nbits);
   uint32_t nblk = 0;
   const Staged st = {s_stage, cshift};
-  if (p < end_bit) run_span<false>(a, st, first_byte * 8u, L, p, b, k, end_bit, nblk, 0);
+  if (p < end_bit) track_span(a, st, first_byte * 8u, L, p, b, k, end_bit, nblk);
   const uint64_t e = pack_state(p, b, k);
   const bool ch = round == 0 || e != sin[i];
   sout[i] = e;
@@ -343,6 +397,170 @@ __global__ __launch_bounds__(kSyncBlock) void sync_write_kernel(const HuffSyncAr
     // the scan must hold exactly total_blocks blocks: fewer = truncated data, more cannot be seen (the loop stops there)
     if (a.nblk[i] + nblk < a.total_blocks) atomicOr(a.flags + 1, 8u);
   }
+}
+
+// ---- hypothesis decode: the fixed point in a fixed number of passes ------------------------------------------------------
+// The rounds above converge slowly on interleaved scans: a lane that starts in the wrong BLOCK OF THE MCU reads luma
+// blocks with the chroma tables (or the reverse) and can only fall in step with the true decoder by luck, so the correct
+// state advances about one subsequence per round (4:2:0: ~18 rounds for a 4K frame).  Here every subsequence is decoded
+// once per possible block position h (H = blocks per MCU hypotheses, one wave each, sharing the staged bytes):
+//   pass 0   slot h of subsequence i: start at its first bit as block h, zig-zag 0 -> state at the end of i;
+//   pass 1   every path goes on through i+1, i+2, ... (at most `levels` subsequences) until its state at the end of
+//            subsequence j equals a FRESH slot g of j -- from there on it IS that path.  Until then it occupies slot
+//            l*H + h of j (l = j - i).  map[j-1][slot] = the slot it is in at the end of j; cnt[j-1][slot] = blocks it
+//            completed inside j;
+//   chain    the true path is slot 0 of subsequence 0; g(i+1) = map[i][g(i)] -- a scan over function composition.  It
+//            yields every subsequence's true start state (state[0][i] = hyp_state[i][g(i)]) and block count;
+//   then the write pass and the DC scan of the round scheme, unchanged.
+// A path that does not merge within `levels` subsequences leaves map = 0xff; if the true path hits one, flags[2] is set
+// and the caller runs the rounds instead.
+
+__global__ __launch_bounds__(1024) void hyp_pass0_kernel(const HuffSyncArgs a) {
+  extern __shared__ uint32_t s_stage[];
+  __shared__ ScanLds L;
+  load_scan_lds<true>(a, L);
+  const uint32_t lane = threadIdx.x & 63u, h = threadIdx.x >> 6;
+  const uint32_t i = blockIdx.x * 64u + lane;
+  const uint32_t nclean = a.nbytes - *a.nstuffed, nbits = nclean * 8u;
+  const uint32_t nsub = (nbits + a.sub_bits - 1) / a.sub_bits;
+  const uint32_t cshift = 31u - (uint32_t)__builtin_clz(a.sub_bits >> 3);
+  const uint32_t first_byte = blockIdx.x * 64u * (a.sub_bits >> 3);
+  stage_wave(a.clean, nclean, first_byte, cshift, s_stage, threadIdx.x, 64u, blockDim.x);
+  __syncthreads();
+  if (i >= nsub) return;
+  uint32_t p = i * a.sub_bits, b = h, k = 0, nblk = 0;
+  const uint32_t end_bit = min((i + 1) * a.sub_bits, nbits);
+  const Staged st = {s_stage, cshift};
+  track_span(a, st, first_byte * 8u, L, p, b, k, end_bit, nblk);
+  a.hyp_state[(size_t)i * kHuffHypSlots + h] = pack_state(p, b, k);
+  if (i == 0 && h == 0) a.nblk[0] = nblk;
+}
+
+__global__ __launch_bounds__(1024) void hyp_pass1_kernel(const HuffSyncArgs a) {
+  extern __shared__ uint32_t s_stage[];
+  __shared__ ScanLds L;
+  load_scan_lds<true>(a, L);
+  const uint32_t lane = threadIdx.x & 63u, h = threadIdx.x >> 6, H = (uint32_t)a.hyp_h;
+  const uint32_t i = blockIdx.x * 64u + lane;
+  const uint32_t nclean = a.nbytes - *a.nstuffed, nbits = nclean * 8u;
+  const uint32_t nsub = (nbits + a.sub_bits - 1) / a.sub_bits;
+  const uint32_t cshift = 31u - (uint32_t)__builtin_clz(a.sub_bits >> 3);
+  const uint32_t first_byte = (blockIdx.x * 64u + 1u) * (a.sub_bits >> 3);  // the window starts one subsequence further on
+  stage_wave(a.clean, nclean, first_byte, cshift, s_stage, threadIdx.x, 64u + (uint32_t)a.hyp_levels, blockDim.x);
+  __syncthreads();
+  if (i + 1 >= nsub) return;
+  const uint64_t s0 = a.hyp_state[(size_t)i * kHuffHypSlots + h];
+  uint32_t p = (uint32_t)s0, b = (uint32_t)(s0 >> 32) & 0xffu, k = (uint32_t)(s0 >> 40) & 0xffu;
+  uint32_t slot = h;
+  const Staged st = {s_stage, cshift};
+  for (uint32_t l = 1; l <= (uint32_t)a.hyp_levels; l++) {
+    const uint32_t j = i + l;
+    if (j >= nsub) break;
+    const uint32_t end_bit = min((j + 1) * a.sub_bits, nbits);
+    uint32_t nblk = 0;
+    if (p < end_bit) track_span(a, st, first_byte * 8u, L, p, b, k, end_bit, nblk);
+    const uint64_t e = pack_state(p, b, k);
+    const uint64_t* fresh = a.hyp_state + (size_t)j * kHuffHypSlots;
+    uint32_t g = 0xffu;
+    for (uint32_t t = 0; t < H; t++)
+      if (fresh[t] == e && g == 0xffu) g = t;
+    const size_t at = (size_t)(j - 1) * kHuffHypSlots + slot;
+    a.hyp_cnt[at] = (uint16_t)nblk;
+    if (g != 0xffu) {
+      a.hyp_map[at] = (uint8_t)g;
+      if (a.hyp_hist) atomicAdd(a.flags + 9 + min(l, 6u), 1u);
+      break;
+    }
+    if (l == (uint32_t)a.hyp_levels) {  // map stays 0xff: not merged within the budget
+      atomicAdd(a.flags + 3, 1u);
+      break;
+    }
+    const uint32_t nslot = l * H + h;
+    a.hyp_state[(size_t)j * kHuffHypSlots + nslot] = e;
+    a.hyp_map[at] = (uint8_t)nslot;
+    slot = nslot;
+  }
+}
+
+// chain, step 1 (one workgroup per tile of kChainTile links): the tile's maps are staged in LDS with coalesced loads, every
+// thread composes its kChainPer consecutive links, a workgroup-wide scan over function composition turns these into the
+// map "slot at the tile's entry -> slot at the thread's entry"; that and the tile's total map go to global memory.
+constexpr int kChainPer = 4, kChainThreads = 256, kChainTile = kChainPer * kChainThreads;
+__global__ __launch_bounds__(kChainThreads) void hyp_chain_tiles_kernel(const HuffSyncArgs a, uint8_t* __restrict__ prefix /* [threads total][slots] */,
+                                                                        uint8_t* __restrict__ tile_map /* [tiles][slots] */) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_links[kChainTile * kHuffHypSlots];  // 48 KB
+  __shared__ uint8_t s_map[kChainThreads][kHuffHypSlots];                                // 12 KB
+  const int tid = (int)threadIdx.x;
+  const uint32_t nclean = a.nbytes - *a.nstuffed, nbits = nclean * 8u;
+  const int nsub = (int)((nbits + a.sub_bits - 1) / a.sub_bits);
+  const int nlinks = nsub - 1;
+  const int base = (int)blockIdx.x * kChainTile;
+  if (base >= nlinks) return;
+  const int nhere = min(kChainTile, nlinks - base);
+  {  // coalesced copy of the tile's rows (rows are kHuffHypSlots = 48 bytes: whole 16-byte words)
+    const uint4* src = (const uint4*)(a.hyp_map + (size_t)base * kHuffHypSlots);
+    uint4* dst = (uint4*)s_links;
+    const int nvec = nhere * kHuffHypSlots / 16;
+    for (int v = tid; v < nvec; v += kChainThreads) dst[v] = src[v];
+  }
+  __syncthreads();
+  const int SL = (a.hyp_levels + 1) * a.hyp_h;
+  const int lo = min(tid * kChainPer, nhere), hi = min(lo + kChainPer, nhere);
+  for (int s = 0; s < SL; s++) {
+    uint32_t cur = (uint32_t)s;
+    for (int i = lo; i < hi; i++) cur = cur == 0xffu ? 0xffu : (uint32_t)s_links[i * kHuffHypSlots + (int)cur];
+    s_map[tid][s] = (uint8_t)cur;
+  }
+  __syncthreads();
+  for (int d = 1; d < kChainThreads; d <<= 1) {  // inclusive scan: P[t] = F[t] o P[t - d]
+    uint8_t q[kHuffHypSlots];
+    const bool on = tid >= d;
+    if (on) {
+#pragma unroll
+      for (int s = 0; s < kHuffHypSlots; s++) {
+        const uint32_t v = s_map[tid - d][s];
+        q[s] = v == 0xffu ? (uint8_t)0xffu : s_map[tid][v];
+      }
+    }
+    __syncthreads();
+    if (on) {
+#pragma unroll
+      for (int s = 0; s < kHuffHypSlots; s++) s_map[tid][s] = q[s];
+    }
+    __syncthreads();
+  }
+  // prefix for thread t = inclusive map of thread t - 1 (identity for t = 0)
+  uint8_t* out = prefix + ((size_t)blockIdx.x * kChainThreads + tid) * kHuffHypSlots;
+  for (int s = 0; s < SL; s++) out[s] = tid == 0 ? (uint8_t)s : s_map[tid - 1][s];
+  if (tid == kChainThreads - 1)
+    for (int s = 0; s < SL; s++) tile_map[(size_t)blockIdx.x * kHuffHypSlots + s] = s_map[tid][s];
+}
+// chain, step 2: the tile's entry slot from the tile maps before it (a short sequential walk, the same in every thread),
+// the thread's entry slot from its prefix map, then kChainPer links: state[0][i] = true end state of subsequence i,
+// nblk[i + 1] = blocks completed inside subsequence i + 1
+__global__ __launch_bounds__(kChainThreads) void hyp_chain_walk_kernel(const HuffSyncArgs a, const uint8_t* __restrict__ prefix,
+                                                                       const uint8_t* __restrict__ tile_map) {
+  const int tid = (int)threadIdx.x;
+  const uint32_t nclean = a.nbytes - *a.nstuffed, nbits = nclean * 8u;
+  const int nsub = (int)((nbits + a.sub_bits - 1) / a.sub_bits);
+  const int nlinks = nsub - 1;
+  const int base = (int)blockIdx.x * kChainTile;
+  if (base >= nlinks) return;
+  const int nhere = min(kChainTile, nlinks - base);
+  uint32_t g = 0;  // the true path is slot 0 of subsequence 0
+  for (int t = 0; t < (int)blockIdx.x && g != 0xffu; t++) g = tile_map[(size_t)t * kHuffHypSlots + g];
+  if (g != 0xffu) g = prefix[((size_t)blockIdx.x * kChainThreads + tid) * kHuffHypSlots + g];
+  const int lo = min(tid * kChainPer, nhere), hi = min(lo + kChainPer, nhere);
+  bool lost = false;
+  for (int i = base + lo; i < base + hi; i++) {
+    if (g == 0xffu) { lost = true; break; }
+    const size_t at = (size_t)i * kHuffHypSlots + g;
+    a.state[0][i] = a.hyp_state[at];
+    a.nblk[i + 1] = a.hyp_cnt[at];
+    g = a.hyp_map[at];
+  }
+  if (lo < hi && base + hi == nlinks && !lost && g == 0xffu) lost = true;  // the last link must resolve too
+  if (lost) atomicOr(a.flags + 2, 1u);
 }
 
 // step 5: DC prediction = running sum of the differences over the component's blocks in scan order, as a three-kernel
@@ -445,6 +663,65 @@ hipError_t launch_huffman_decode_sync(const HuffSyncArgs& a, int max_rounds, int
   hipLaunchKernelGGL(dc_partial_kernel, dim3(nch), dim3(1024), 0, s, a, dc_partial);
   hipLaunchKernelGGL(dc_scan_partials_kernel, dim3(1), dim3(1024), 0, s, dc_partial, nch);
   hipLaunchKernelGGL(dc_apply_kernel, dim3(nch), dim3(1024), 0, s, a, (const int*)dc_partial);
+  return hipGetLastError();
+}
+
+size_t huff_hyp_chain_bytes(uint64_t nbytes, uint32_t sub_bits, size_t* tiles_offset) {
+  const size_t nsub = huff_sync_max_subsequences(nbytes, sub_bits), ntiles = (nsub + kChainTile - 1) / kChainTile;
+  const size_t pre = ntiles * kChainThreads * kHuffHypSlots;
+  if (tiles_offset) *tiles_offset = pre;
+  return pre + ntiles * kHuffHypSlots;
+}
+
+// The hypothesis scheme (see above) in place of the rounds.  hyp_map must be filled with 0xff, hyp_cnt / nblk / dcd / flags
+// with zeros; chain_prefix: huff_hyp_chain_bytes(nbytes, sub_bits) bytes of scratch, chain_tiles follows it.  flags[2] != 0 afterwards: the true path did not merge somewhere; run launch_huffman_decode_sync instead.
+hipError_t launch_huffman_decode_hyp(const HuffSyncArgs& a, int* dc_partial, uint8_t* chain_prefix, uint8_t* chain_tiles, hipStream_t s) {
+  const uint32_t nsub = huff_sync_max_subsequences(a.nbytes, a.sub_bits);
+  const int grid = (int)((nsub + 63) / 64);
+  const int threads = 64 * a.hyp_h;
+  const size_t lds0 = (size_t)64 * ((a.sub_bits >> 3) + 4) + 64;
+  const size_t lds1 = (size_t)(64 + a.hyp_levels) * ((a.sub_bits >> 3) + 4) + 64;
+  // UHDR_HIP_HUFF_DEBUG: per-kernel times on stderr (events between the launches)
+  const bool dbg = getenv("UHDR_HIP_HUFF_DEBUG") != nullptr;
+  hipEvent_t ev[9];
+  int nev = 0;
+  auto mark = [&]() {
+    if (dbg && nev < 9) {
+      (void)hipEventCreate(&ev[nev]);
+      (void)hipEventRecord(ev[nev], s);
+      nev++;
+    }
+  };
+  mark();
+  hipLaunchKernelGGL(hyp_pass0_kernel, dim3(grid), dim3(threads), lds0, s, a);
+  mark();
+  hipLaunchKernelGGL(hyp_pass1_kernel, dim3(grid), dim3(threads), lds1, s, a);
+  mark();
+  const int ntiles = (int)((nsub + kChainTile - 1) / kChainTile);
+  hipLaunchKernelGGL(hyp_chain_tiles_kernel, dim3(ntiles), dim3(kChainThreads), 0, s, a, chain_prefix, chain_tiles);
+  hipLaunchKernelGGL(hyp_chain_walk_kernel, dim3(ntiles), dim3(kChainThreads), 0, s, a, (const uint8_t*)chain_prefix, (const uint8_t*)chain_tiles);
+  mark();
+  hipLaunchKernelGGL(sync_scan_kernel, dim3(1), dim3(1024), 0, s, a.nblk, (int)nsub, (uint32_t*)nullptr);
+  mark();
+  hipLaunchKernelGGL(sync_write_kernel, dim3(grid), dim3(kSyncBlock), lds0, s, a, 0);
+  mark();
+  const int nch = (int)((a.total_blocks + 1023) / 1024);
+  hipLaunchKernelGGL(dc_partial_kernel, dim3(nch), dim3(1024), 0, s, a, dc_partial);
+  hipLaunchKernelGGL(dc_scan_partials_kernel, dim3(1), dim3(1024), 0, s, dc_partial, nch);
+  hipLaunchKernelGGL(dc_apply_kernel, dim3(nch), dim3(1024), 0, s, a, (const int*)dc_partial);
+  mark();
+  if (dbg) {
+    (void)hipStreamSynchronize(s);
+    static const char* names[] = {"pass0", "pass1", "chain x2", "nblk scan", "write", "dc x3"};
+    fprintf(stderr, "uhdr_hip: hypothesis decode kernels:");
+    for (int i = 0; i + 1 < nev; i++) {
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+      fprintf(stderr, " %s %.0f us,", names[i], ms * 1e3f);
+    }
+    fprintf(stderr, "\n");
+    for (int i = 0; i < nev; i++) (void)hipEventDestroy(ev[i]);
+  }
   return hipGetLastError();
 }
 

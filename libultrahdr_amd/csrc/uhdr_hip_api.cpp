@@ -1979,6 +1979,38 @@ static bool make_fast_table(const uint8_t bits[17], const uint8_t vals[256], Huf
   return true;
 }
 
+// The state-tracking form of a fast table (huffman_decode_sync.hip: track_span): an entry says how many bits the symbol
+// consumes (code + magnitude bits) and how far the zig-zag index moves -- exactly decode_step's transitions:
+//   DC symbol (size category s):  bits = len + s, advance 1
+//   AC symbol run/size:           bits = len + s, advance run + 1;  ZRL: len, 16;  EOB: len, 64 (to the end of the block)
+//   undefined code:               16 bits; advance 64 (AC) / 1 (DC)
+// l1 entries of long codes keep the 0x8000 | sub-table form.
+static void make_track_table(const HuffFastTable& f, bool is_dc, HuffFastTable* t) {
+  auto conv = [&](uint16_t e) -> uint16_t {
+    if (e & 0x8000u) return e;
+    unsigned adv, kinc;
+    if (e == 0) {
+      adv = 16;
+      kinc = is_dc ? 1 : 64;
+    } else {
+      const unsigned len = (e >> 8) & 31u, rs = e & 255u;
+      if (is_dc) {
+        const unsigned sz = rs > 15u ? 0u : rs;  // decode_step: a category beyond 15 is "bad", no magnitude bits
+        adv = len + sz;
+        kinc = 1;
+      } else {
+        const unsigned sz = rs & 15u, run = rs >> 4;
+        adv = len + sz;
+        kinc = sz ? run + 1 : (run == 15u ? 16u : 64u);
+      }
+    }
+    return (uint16_t)(adv | (kinc << 5));
+  };
+  for (int i = 0; i < 512; i++) t->l1[i] = conv(f.l1[i]);
+  for (int s = 0; s < kHuffL2Max; s++)
+    for (int i = 0; i < 128; i++) t->l2[s][i] = conv(f.l2[s][i]);
+}
+
 uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_jpeg_scan_t* sc, const uhdr_hip_huff_tables_t* tables,
                                               const uint8_t* data, size_t data_bytes) {
   if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
@@ -2062,7 +2094,15 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
     const size_t o_clean = take(data_bytes + 16), o_cnt = take((size_t)nch * 4), o_flags = take(64), o_s0 = take((size_t)nsub * 8),
                  o_s1 = take((size_t)nsub * 8), o_nblk = take((size_t)nsub * 4 + 4), o_dcd = take((size_t)total_blocks * 4),
                  o_c0 = take(nsub), o_c1 = take(nsub), o_dcp = take((size_t)((total_blocks + 1023) / 1024) * 12 + 16),
-                 o_ft = take(sizeof(HuffFastTable) * 4);
+                 o_ft = take(sizeof(HuffFastTable) * 8);  // symbol form x 4, state-tracking form x 4
+    // hypothesis scheme (interleaved scans): one decode per possible block position instead of rounds
+    int hyp_levels = 4;
+    if (const char* e = getenv("UHDR_HIP_HUFF_LEVELS")) hyp_levels = atoi(e);  // 0: the round scheme
+    const bool use_hyp = hyp_levels >= 1 && hyp_levels <= 7 && bpm * (hyp_levels + 1) <= kHuffHypSlots;
+    const size_t o_hs = use_hyp ? take((size_t)nsub * kHuffHypSlots * 8) : 0, o_hm = use_hyp ? take((size_t)nsub * kHuffHypSlots) : 0,
+                 o_hc = use_hyp ? take((size_t)nsub * kHuffHypSlots * 2) : 0;
+    size_t chain_tiles_off = 0;
+    const size_t o_ch = use_hyp ? take(huff_hyp_chain_bytes(data_bytes, sub_bits, &chain_tiles_off)) : 0;
     UHDR_TRY(ensure(c->scratch[6], off));
     uint8_t* sb = (uint8_t*)c->scratch[6].p;
     HuffSyncArgs y;
@@ -2085,22 +2125,60 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
       for (int k = 0; k < a.hs[i] * a.vs[i] && j < 16; k++) y.comp_of[j++] = (uint8_t)i;
     }
     y.ftabs = (const HuffFastTable*)(sb + o_ft);
+    y.ttabs = y.ftabs + 4;
     y.zigzag = a.zigzag;
     if (j == bpm && bpm <= 16) {
-      HIP_TRY(hipMemcpyAsync(sb + o_ft, ftabs.data(), sizeof(HuffFastTable) * 4, hipMemcpyHostToDevice, c->stream));
+      ftabs.resize(8);
+      for (int t = 0; t < 4; t++) make_track_table(ftabs[(size_t)t], (t & 1) == 0, &ftabs[(size_t)t + 4]);
+      HIP_TRY(hipMemcpyAsync(sb + o_ft, ftabs.data(), sizeof(HuffFastTable) * 8, hipMemcpyHostToDevice, c->stream));
       HIP_TRY(hipMemsetAsync(y.flags, 0, 64, c->stream));
       HIP_TRY(hipMemsetAsync(y.nblk, 0, (size_t)nsub * 4 + 4, c->stream));
       HIP_TRY(hipMemsetAsync(y.dcd, 0, (size_t)total_blocks * 4, c->stream));
       int final_buf = 0;
-      {
-        ProfScope ps(c, "huffman_decode");
-        HIP_TRY(launch_huffman_unstuff(data, (uint32_t)data_bytes, (uint32_t*)(sb + o_cnt), y.flags + 8, sb + o_clean, c->stream));
-        HIP_TRY(launch_huffman_decode_sync(y, max_rounds, (int*)(sb + o_dcp), &final_buf, c->stream));
-      }
       uint32_t fl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      HIP_TRY(hipMemcpyAsync(fl, y.flags, sizeof fl, hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(hipStreamSynchronize(c->stream));
-      if (fl[4 + max_rounds % 3] == 0) {  // the fixed point was reached: the decode is the true one
+      bool hyp_done = false;
+      if (use_hyp) {
+        y.hyp_h = bpm;
+        y.hyp_levels = hyp_levels;
+        y.hyp_state = (uint64_t*)(sb + o_hs);
+        y.hyp_map = sb + o_hm;
+        y.hyp_cnt = (uint16_t*)(sb + o_hc);
+        y.hyp_hist = getenv("UHDR_HIP_HUFF_DEBUG") ? 1 : 0;
+        HIP_TRY(hipMemsetAsync(y.hyp_map, 0xff, (size_t)nsub * kHuffHypSlots, c->stream));
+        HIP_TRY(hipMemsetAsync(y.state[0], 0xff, (size_t)nsub * 8, c->stream));  // a start state the write pass skips, should the chain be lost
+        HIP_TRY(hipMemsetAsync(y.hyp_cnt, 0, (size_t)nsub * kHuffHypSlots * 2, c->stream));
+        {
+          ProfScope ps(c, "huffman_decode");
+          HIP_TRY(launch_huffman_unstuff(data, (uint32_t)data_bytes, (uint32_t*)(sb + o_cnt), y.flags + 8, sb + o_clean, c->stream));
+          HIP_TRY(launch_huffman_decode_hyp(y, (int*)(sb + o_dcp), sb + o_ch, sb + o_ch + chain_tiles_off, c->stream));
+        }
+        HIP_TRY(hipMemcpyAsync(fl, y.flags, sizeof fl, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        hyp_done = fl[2] == 0;
+        if (getenv("UHDR_HIP_HUFF_DEBUG"))
+        {
+          uint32_t hist[16] = {};
+          (void)hipMemcpy(hist, y.flags, sizeof hist, hipMemcpyDeviceToHost);
+          fprintf(stderr, "uhdr_hip: hypothesis decode of %zu bytes, %u subsequences x %d: merges per level %u %u %u %u %u %u+, %u paths unmerged after %d levels, true path %s\n",
+                  data_bytes, nsub, bpm, hist[10], hist[11], hist[12], hist[13], hist[14], hist[15], fl[3], hyp_levels, hyp_done ? "resolved" : "LOST (falling back to rounds)");
+        }
+        if (!hyp_done) {  // a stretch of the true path did not merge within the overflow budget: start over with the rounds
+          HIP_TRY(hipMemsetAsync(y.flags, 0, 32, c->stream));  // not [8]: the stuffed-byte count stays
+          HIP_TRY(hipMemsetAsync(y.nblk, 0, (size_t)nsub * 4 + 4, c->stream));
+          HIP_TRY(hipMemsetAsync(y.dcd, 0, (size_t)total_blocks * 4, c->stream));
+          for (int i = 0; i < a.ncomp; i++) HIP_TRY(hipMemsetAsync(a.coef[i], 0, zero_bytes[i], c->stream));
+        }
+      }
+      if (!hyp_done) {
+        {
+          ProfScope ps(c, "huffman_decode");
+          if (!use_hyp) HIP_TRY(launch_huffman_unstuff(data, (uint32_t)data_bytes, (uint32_t*)(sb + o_cnt), y.flags + 8, sb + o_clean, c->stream));
+          HIP_TRY(launch_huffman_decode_sync(y, max_rounds, (int*)(sb + o_dcp), &final_buf, c->stream));
+        }
+        HIP_TRY(hipMemcpyAsync(fl, y.flags, sizeof fl, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+      }
+      if (hyp_done || fl[4 + max_rounds % 3] == 0) {  // the fixed point was reached: the decode is the true one
         if (fl[1] & 8u) return err_status(UHDR_CODEC_INVALID_PARAM, "corrupt entropy-coded data (the scan ends before its last block)");
         if (fl[1] & 2u) return err_status(UHDR_CODEC_INVALID_PARAM, "corrupt entropy-coded data (undefined Huffman code or a run past the end of a block)");
         sync_done = true;

@@ -288,8 +288,20 @@ struct HuffSyncArgs {
   uint8_t comp_of[16];        // block inside the MCU -> component
   int16_t* coef[3];           // zero-initialised JBLOCK arrays
   const HuffFastTable* ftabs; // DC luma, AC luma, DC chroma, AC chroma
+  const HuffFastTable* ttabs; // the same four tables in state-tracking form: bits consumed | zig-zag advance << 5 (make_track_table)
   const uint8_t* zigzag;
+  // hypothesis decode (launch_huffman_decode_hyp): slot s < hyp_h is "started at the subsequence's first bit as block s of
+  // an MCU"; slot l * hyp_h + h is the path of hypothesis h of the subsequence l places back that has not merged yet
+  int hyp_h, hyp_levels;      // hypotheses per subsequence (= blocks per MCU), overflow depth; slots = (levels + 1) * h <= kHuffHypSlots
+  uint64_t* hyp_state;        // [nsub][kHuffHypSlots]: state of the slot's path at the END of the subsequence
+  uint8_t* hyp_map;           // [nsub][kHuffHypSlots]: the slot of subsequence i + 1 the path is in at ITS end (0xff: none)
+  uint16_t* hyp_cnt;          // [nsub][kHuffHypSlots]: blocks the path completes while crossing subsequence i + 1
+  int hyp_hist;               // debug: count the merges per level in flags[10..15]
 };
+constexpr int kHuffHypSlots = 48;
+// scratch of the chain kernels: per-thread prefix maps, then the tile maps
+size_t huff_hyp_chain_bytes(uint64_t nbytes, uint32_t sub_bits, size_t* tiles_offset);
+hipError_t launch_huffman_decode_hyp(const HuffSyncArgs& a, int* dc_partial, uint8_t* chain_prefix, uint8_t* chain_tiles, hipStream_t s);
 int huff_sync_chunks(uint64_t nbytes);
 uint32_t huff_sync_max_subsequences(uint64_t nbytes, uint32_t sub_bits);
 hipError_t launch_huffman_unstuff(const uint8_t* data, uint32_t nbytes, uint32_t* chunk_counts, uint32_t* nstuffed_dev, uint8_t* clean, hipStream_t s);
