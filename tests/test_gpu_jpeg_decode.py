@@ -174,3 +174,27 @@ def test_device_encoded_rgb_map_holds_the_oracles_coefficients(uhdr):
     assert rc == 0
     for c in range(3):
         assert np.array_equal(got[c], want[c]), c
+
+
+def test_damaged_files_never_crash_the_device_path(uhdr):
+    """Random damage inside the entropy-coded data of a good file: the decode either succeeds (Huffman streams rarely hold
+    undefined codes: the result is then simply what the bits say) or reports UHDR_CODEC_INVALID_PARAM /
+    UNSUPPORTED_FEATURE; it never faults or hangs, and the undamaged file decodes correctly afterwards."""
+    rng = np.random.default_rng(99)
+    coefs, (ql, qc), jpeg = _file(rng, 800, 480, S420, 0)
+    hdr = uhdr.jpeg_parse(jpeg)
+    lo, hi = hdr.scan_offset + 16, hdr.scan_offset + hdr.scan_bytes - 16
+    for trial in range(12):
+        bad = bytearray(jpeg)
+        for i in rng.integers(lo, hi, 1 + 40 * (trial % 4)):
+            if bad[i] != 0xFF and bad[i - 1] != 0xFF and bad[i + 1] != 0xFF:
+                bad[i] ^= int(rng.integers(1, 255))
+                if bad[i] == 0xFF:
+                    bad[i] = 0x7F
+        try:
+            uhdr.jpeg_decode(bytes(bad))
+        except A.UhdrError as err:
+            assert err.code in (A.UHDR_CODEC_INVALID_PARAM, A.UHDR_CODEC_UNSUPPORTED_FEATURE), err
+    got = uhdr.jpeg_decode(jpeg)
+    for c in range(3):
+        assert np.array_equal(got[c], L.idct_dequant_port(coefs[c], ql if c == 0 else qc)), c
