@@ -27,12 +27,19 @@ bool trace_on() {
   static const bool on = getenv("UHDR_HIP_SEAM_TRACE") != nullptr;
   return on;
 }
+thread_local double tl_enter_ms = -1.0;
+double now_ms() {
+  static const auto t0 = std::chrono::steady_clock::now();
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+void enter() { if (trace_on()) tl_enter_ms = now_ms(); }
 bool handled(const uhdr_error_info_t& s, const char* stage) {
   const bool dev = s.error_code != UHDR_CODEC_UNSUPPORTED_FEATURE;
   if (trace_on()) {
-    static const auto t0 = std::chrono::steady_clock::now();
-    fprintf(stderr, "uhdr_hip_seam: [%8.2f ms] %s -> %s%s%s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), stage, dev ? "device" : "reference CPU path (", dev ? "" : (s.has_detail ? s.detail : ""),
+    const double t = now_ms();
+    fprintf(stderr, "uhdr_hip_seam: [%8.2f ms, took %6.2f] %s -> %s%s%s\n", t, tl_enter_ms >= 0 ? t - tl_enter_ms : 0.0, stage, dev ? "device" : "reference CPU path (", dev ? "" : (s.has_detail ? s.detail : ""),
             dev ? "" : ")");
+    tl_enter_ms = -1.0;
   }
   if (dev) g_calls.fetch_add(1, std::memory_order_relaxed);
   return dev;
@@ -71,6 +78,7 @@ bool apply_gainmap(uhdr_raw_image_t* sdr_intent, uhdr_raw_image_t* gainmap_img,
                    uhdr_img_fmt_t output_format, float max_display_boost, uhdr_raw_image_t* dest,
                    uhdr_error_info_t* st) {
   if (!cur() || !gainmap_metadata) return false;
+  enter();
   // the version check is the one thing uhdr_gainmap_metadata_ext_t adds (jpegr.cpp:1546-1555)
   if (gainmap_metadata->version.compare(ultrahdr::kJpegrVersion)) return false;  // the reference words that error
   const uhdr_gainmap_metadata_t md = *gainmap_metadata;  // slice off the version string
@@ -85,6 +93,7 @@ bool generate_gainmap(uhdr_raw_image_t* sdr_intent, uhdr_raw_image_t* hdr_intent
                       uhdr_enc_preset_t preset, float min_content_boost, float max_content_boost,
                       float target_disp_peak_brightness, uhdr_error_info_t* st) {
   if (!cur() || !sdr_intent || !hdr_intent || !gainmap_metadata) return false;
+  enter();
   // map geometry and the tiny-image fallback exactly as jpegr.cpp:690-706
   const unsigned w = sdr_intent->w, h = sdr_intent->h;
   int s = *scale_factor;
@@ -184,6 +193,7 @@ bool decode_scan(const void* hdr, const unsigned char* data, size_t bytes, int o
                  unsigned char* const planes[3], const unsigned int hstride[3], const unsigned int vstride[3],
                  uhdr_error_info_t* st) {
   if (!cur()) return false;
+  enter();
   *st = uhdr_hip_jpeg_decode_scan(cur(), static_cast<const uhdr_hip_jpeg_header_t*>(hdr), data, bytes, out_channels, libjpeg_variant, planes,
                                   hstride, vstride);
   // corrupt entropy-coded data: libjpeg decodes such files with warnings and padding; that behaviour stays libjpeg's
@@ -197,6 +207,7 @@ bool decode_scan(const void* hdr, const unsigned char* data, size_t bytes, int o
 bool encode_scan(const void* scan, const void* qtables, const unsigned char* const planes[3], const unsigned int strides[3],
                  int rgb_channels, unsigned char* out, size_t cap, size_t* bytes, uhdr_error_info_t* st) {
   if (!cur()) return false;
+  enter();
   *st = uhdr_hip_jpeg_encode_scan(cur(), static_cast<const uhdr_hip_jpeg_scan_t*>(scan), static_cast<const uint16_t(*)[64]>(qtables), planes, strides,
                                   rgb_channels, out, cap, bytes);
   return handled(*st, "jpeg_encode_scan");

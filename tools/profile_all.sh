@@ -7,15 +7,26 @@ OUT=$PWD/gpurun_out/prof_all
 mkdir -p $OUT
 R=${GRAFT_REPO_ROOT:-/root/repo}
 CASES="${@:-8kC 8kB 8kA 4kAhlg 4kApq b32hlg tm4k gen4k gen4k1 tm8k api0f fdct4k idct4k cvt4k huff4k}"
-export QB_REPS=1 QB_ITERS=4
+export QB_REPS=1 QB_ITERS=4 QB_NO_SERIAL=1
+LIMIT=${LIMIT:-200}
+limited() {  # run "$@" in its own session; SIGKILL the whole group after $LIMIT seconds (a profiler that does not come back must not eat the box's time)
+  setsid "$@" &
+  local pid=$!
+  ( sleep $LIMIT; kill -KILL -- -$pid 2>/dev/null ) &
+  local wd=$!
+  wait $pid
+  local rc=$?
+  kill $wd 2>/dev/null
+  return $rc
+}
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python $R/tools/qbench.py $CASES > $OUT/trace.log 2>&1
+limited rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python $R/tools/qbench.py $CASES > $OUT/trace.log 2>&1
 i=0
 for G in "FETCH_SIZE" "WRITE_SIZE" \
          "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
          "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" ; do
   i=$((i+1))
-  rocprofv3 --pmc $G -d $OUT/pmc$i -o p -- python $R/tools/qbench.py $CASES > $OUT/pmc$i.log 2>&1 || echo "pmc group $i failed" >> $OUT/errors.log
+  limited rocprofv3 --pmc $G -d $OUT/pmc$i -o p -- python $R/tools/qbench.py $CASES > $OUT/pmc$i.log 2>&1 || echo "pmc group $i failed" >> $OUT/errors.log
 done
 python $R/tools/read_prof.py $OUT > $OUT/summary.txt 2>&1
 tail -3 $OUT/trace.log

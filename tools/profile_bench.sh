@@ -1,15 +1,29 @@
 #!/bin/bash
-# rocprofv3 evidence for bench.py's roofline object (run on the GPU box through gpurun):
-#   1. --kernel-trace --stats of the SAME bench command  -> average duration of the dominant kernel
-#   2. FETCH_SIZE / WRITE_SIZE in their own --pmc passes -> HBM traffic per launch
-# Outputs under gpurun_out/prof_bench/, summarised by tools/read_prof.py into profiles/.
+# rocprofv3 evidence for the headline launch of bench.py (run on the GPU box through gpurun): one kernel-trace pass and
+# one pass per PMC group (never combined with API traces), each in its own process group with a hard time limit so that
+# a profiler that does not come back cannot eat the box's time.  Outputs under gpurun_out/prof_bench/;
+#   python tools/read_prof.py gpurun_out/prof_bench > profiles/rNN_bench_mapC_batch16_rocprofv3.txt
 OUT=$PWD/gpurun_out/prof_bench
-mkdir -p $OUT
+rm -rf $OUT && mkdir -p $OUT
 R=${GRAFT_REPO_ROOT:-/root/repo}
-ARGS="--steps 10 --warmup 2 --no-extra --no-cpu $@"
+LIMIT=${LIMIT:-150}
+limited() {  # run "$@" in its own session; SIGKILL the whole group after $LIMIT seconds
+  setsid "$@" &
+  local pid=$!
+  ( sleep $LIMIT; kill -KILL -- -$pid 2>/dev/null ) &
+  local wd=$!
+  wait $pid
+  local rc=$?
+  kill $wd 2>/dev/null
+  return $rc
+}
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python $R/bench.py $ARGS > $OUT/trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc1 -o p -- python $R/bench.py $ARGS > $OUT/pmc1.log 2>&1 || echo "FETCH_SIZE pass failed" >> $OUT/errors.log
-rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc2 -o p -- python $R/bench.py $ARGS > $OUT/pmc2.log 2>&1 || echo "WRITE_SIZE pass failed" >> $OUT/errors.log
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc3 -o p -- python $R/bench.py $ARGS > $OUT/pmc3.log 2>&1 || echo "SQ pass failed" >> $OUT/errors.log
-tail -1 $OUT/trace.log
+CMD="python $R/bench.py --steps 10 --warmup 2 --no-extra --no-cpu"
+limited rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- $CMD > $OUT/trace.log 2>&1 || echo "trace pass failed / timed out" >> $OUT/errors.log
+i=0
+for G in "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  limited rocprofv3 --pmc $G -d $OUT/pmc$i -o p -- $CMD > $OUT/pmc$i.log 2>&1 || echo "pmc group $i failed / timed out" >> $OUT/errors.log
+done
+python $R/tools/read_prof.py $OUT > $OUT/summary.txt 2>&1
+cat $OUT/summary.txt | cut -c1-200 | head -20
