@@ -593,7 +593,7 @@ def extras(ctx, u, device):
     f16, u32 = A.UHDR_IMG_FMT_64bppRGBAHalfFloat, A.UHDR_IMG_FMT_32bppRGBA1010102
     md = synth.default_metadata(use_base_cg=0)
 
-    def apply_case(name, w, h, map_kind, ct):
+    def apply_case(name, w, h, map_kind, ct, extra_modes=False):
         fmt = f16 if ct == A.UHDR_CT_LINEAR else u32
         sets = make_frames(3, w, h, map_kind, device, fmt, seed0=77)  # rotate 3 sets: > L3 at 8K, mostly at 4K
         for s, g, _ in sets:
@@ -614,10 +614,47 @@ def extras(ctx, u, device):
         b = algo_bytes_per_px(map_kind, 8 if ct == A.UHDR_CT_LINEAR else 4) * w * h
         res[name] = {"us": round(ms * 1e3, 2), "timing": "one HIP-event pair around 30 back-to-back launches, median of 3 regions", "GB/s": round(b / (ms / 1e3) / 1e9, 1), "frac_of_8TBs": round(b / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
                      "Mpx/s": round(w * h / (ms / 1e3) / 1e6, 1)}
+        if extra_modes:
+            # (a) a burst: 10 launches after the device sat idle (what a single decode request sees)
+            bursts = []
+            for _ in range(4):
+                ctx.synchronize()
+                time.sleep(0.03)
+                bursts.append(time_region(ctx, fn, iters=10, warm=0, reps=1))
+            mb = min(bursts)
+            # (b) two contexts = two HIP streams, launches alternating: the tail of one launch overlaps the ramp of the next
+            from libultrahdr_amd.ultrahdr import Context
+            ctx2 = Context(ctx._device, stream_safe=False)
+            h2 = ctx2.handle
+            j = [0]
+
+            def both():
+                s_, g_, m_, d_ = argv[j[0] % 3]
+                hh = hnd_ if j[0] % 2 == 0 else h2
+                j[0] += 1
+                st = lib_.uhdr_hip_apply_gainmap_dev(hh, s_, g_, m_, ct, fmt, A.FLT_MAX, d_, 0, 0)
+                if st.error_code != 0:
+                    raise RuntimeError(st.detail)
+
+            for _ in range(6):
+                both()
+            ctx.synchronize(); ctx2.synchronize()
+            walls = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                for _ in range(60):
+                    both()
+                ctx.synchronize(); ctx2.synchronize()
+                walls.append((time.perf_counter() - t0) / 60)
+            m2 = sorted(walls)[1] * 1e3
+            res[name].update({"burst_us": round(mb * 1e3, 2), "burst_frac_of_8TBs": round(b / (mb / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
+                              "two_streams_us": round(m2 * 1e3, 2), "two_streams_frac_of_8TBs": round(b / (m2 / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
+                              "two_streams_timing": "wall clock around 60 launches alternating between two contexts, median of 3"})
+            del ctx2
         del sets
         torch.cuda.empty_cache()
 
-    apply_case("apply_8k_f16_mapC", 7680, 4320, "C", A.UHDR_CT_LINEAR)
+    apply_case("apply_8k_f16_mapC", 7680, 4320, "C", A.UHDR_CT_LINEAR, extra_modes=True)
     apply_case("apply_8k_f16_mapB", 7680, 4320, "B", A.UHDR_CT_LINEAR)
     apply_case("apply_8k_f16_mapA", 7680, 4320, "A", A.UHDR_CT_LINEAR)
     apply_case("apply_4k_f16_mapC_single_launch", 3840, 2160, "C", A.UHDR_CT_LINEAR)
