@@ -78,17 +78,24 @@ __device__ __forceinline__ uint32_t pack_codes_1010102(uint32_t r, uint32_t g, u
 // is a three-operand integer median (negative values and -0.0 have the sign bit set: negative as integers -> 0),
 // the bucket is bits >> shift, and inside a bucket the code changes at most once:
 //     code = bits >= thr ? hi : lo          entry = {thr, lo | hi << 16}
-// One 8-byte LDS read, one compare and one select per channel; no powf, no 256 KiB gather, no search.
+// One 8-byte LDS read, one compare and one select per channel (the select picks the upper or lower 16 bits of the entry's
+// second word directly: v_cndmask_b32_sdwa); no powf, no 256 KiB gather, no search.
 template <int OUT>
 __device__ __forceinline__ uint32_t oetf_code_bucket(float v, const uint2* tab, uint32_t base8, uint32_t hi_bits) {
   constexpr int SH = (OUT == 1) ? kOetfBucketShiftHlg : kOetfBucketShiftPq;
   // clampPixelFloat on the bit pattern (v_med3_i32); hi_bits = 1.0f, or the saturation point of a prescaled table
-  const int ib = min(max((int)__float_as_uint(v), 0), (int)hi_bits);
-  const uint32_t bits = (uint32_t)ib;
+  uint32_t bits;
+  asm("v_med3_i32 %0, %1, 0, %2" : "=v"(bits) : "v"(__float_as_uint(v)), "v"(hi_bits));
   uint32_t off = (bits >> (SH - 3)) & ~7u;  // bucket * 8 (byte offset of the entry)
   off = off > base8 ? off - base8 : 0u;     // everything below the first threshold shares bucket 0
   const uint2 e = *(const uint2*)((const char*)tab + off);
-  return bits >= e.x ? e.y >> 16 : e.y & 0xffffu;
+  uint32_t code;
+  // s_nop 1: a VALU write of vcc needs two wait states before a VALU reads it as a mask (the compiler inserts the same)
+  asm("v_cmp_ge_u32_e32 vcc, %1, %2\n\ts_nop 1\n\tv_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1"
+      : "=v"(code)
+      : "v"(bits), "v"(e.x), "v"(e.y)
+      : "vcc");
+  return code;
 }
 
 template <int OUT>
