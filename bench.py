@@ -346,6 +346,7 @@ def encode_section(ctx, u, device):
     from libultrahdr_amd import synth
     from libultrahdr_amd.images import Image
     from libultrahdr_amd.ultrahdr import UltraHdr
+    import numpy as np
     import torch
 
     res = {}
@@ -587,6 +588,7 @@ def extras(ctx, u, device):
     from libultrahdr_amd import synth
     from libultrahdr_amd.images import Image
     from libultrahdr_amd.ultrahdr import UltraHdr
+    import numpy as np
     import torch
 
     res = {}
@@ -761,6 +763,25 @@ def extras(ctx, u, device):
                                                           "stages": "marker count -> scan -> interval table -> decode (one lane per restart interval)"}
     except Exception as e:  # noqa: BLE001  (a failure here must not cost the other stage measurements)
         res["huffman_decode_4k_420_q95"] = {"error": f"{type(e).__name__}: {e}"}
+    # ... and a scan WITHOUT restart markers, as every file of the reference has it: the primary image of an UltraHDR file
+    # written through the drop-in facade (the reference's own libjpeg Huffman pass), parsed by uhdr_hip_jpeg_parse
+    try:
+        from libultrahdr_amd import facade as FA
+        if FA.available():
+            jpg = FA.encode(synth.make_hdr_p010(w, h, ct=A.UHDR_CT_HLG), synth.make_sdr_yuv420(w, h), gpu=True)
+            hd = u.jpeg_parse(jpg)
+            sc = hd.scan
+            data = torch.from_numpy(np.frombuffer(jpg, dtype=np.uint8)[hd.scan_offset: hd.scan_offset + hd.scan_bytes].copy()).to(device)
+            bits = np.frombuffer(hd.tables.bits, dtype=np.uint8).reshape(4, 17)
+            vals = np.frombuffer(hd.tables.vals, dtype=np.uint8).reshape(4, 256)
+            shp0 = [(sc.blocks_h[c], sc.blocks_w[c]) for c in range(3)]
+            ms = time_kernel(ctx, lambda: u.huffman_decode(data, shp0, sc.w, sc.h, [(2, 2), (1, 1), (1, 1)], 0, tables=(bits, vals)), iters=5, warm=2)
+            res["huffman_decode_4k_420_q95_no_restart_markers"] = {
+                "us": round(ms * 1e3, 1), "Mpx/s": round(w * h / (ms / 1e3) / 1e6, 1), "jpeg_scan_bytes": int(hd.scan_bytes),
+                "stages": "unstuff -> one decode per possible block position (6 hypotheses x 1024-bit subsequences) -> overflow until the paths merge "
+                          "-> true path by a scan over map composition -> write pass -> DC scan (DESIGN.md 5.5)"}
+    except Exception as e:  # noqa: BLE001
+        res["huffman_decode_4k_420_q95_no_restart_markers"] = {"error": f"{type(e).__name__}: {e}"}
     del hco, hout
 
     # ---- whole stage chains, device resident (sum of the kernels' HIP-event durations per pass) ----------------
