@@ -3,7 +3,7 @@
 #   1. --kernel-trace --stats of ONE process that launches each kernel a few times (tools/qbench.py)
 #   2. FETCH_SIZE, WRITE_SIZE and two SQ groups, each --pmc group in its own pass (never combined with API traces)
 # Outputs under gpurun_out/prof_all/; tools/read_prof.py turns them into the text committed under profiles/.
-OUT=$PWD/gpurun_out/prof_all
+OUT=$PWD/gpurun_out/${PROF_DIR:-prof_all}
 mkdir -p $OUT
 R=${GRAFT_REPO_ROOT:-/root/repo}
 CASES="${@:-8kC 8kB 8kA 4kAhlg 4kApq b32hlg tm4k gen4k gen4k1 tm8k api0f fdct4k idct4k cvt4k huff4k}"
@@ -22,7 +22,7 @@ limited() {  # run "$@" in its own session; SIGKILL the whole group after $LIMIT
 cd /tmp && export TMPDIR=/tmp
 limited rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python $R/tools/qbench.py $CASES > $OUT/trace.log 2>&1
 i=0
-for G in "FETCH_SIZE" "WRITE_SIZE" \
+[ "${PMC:-1}" = "0" ] || for G in "FETCH_SIZE" "WRITE_SIZE" \
          "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
          "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" ; do
   i=$((i+1))
