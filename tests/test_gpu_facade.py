@@ -139,3 +139,33 @@ def test_encode_with_device_entropy_coding_decodes_to_the_same_pixels(multi):
         assert rc == 0, err
         assert "jpeg_decode_scan" in _stages(trace), trace
         assert np.array_equal(F.read(os.path.join(d, "dev_gpu.raw")), pa)
+
+
+@pytest.mark.parametrize("w,h", [(1000, 562), (642, 362)])
+def test_sizes_with_partial_blocks_through_the_facade(w, h):
+    """Dimensions that are not multiples of the 16 x 16 MCU: the compress seam leaves such planes to libjpeg (its
+    edge-padding rules), the decode seam takes them (dummy blocks are dropped on the device, only the visible samples come
+    back).  Files and decoded frames equal the CPU reference's byte for byte."""
+    from libultrahdr_amd import capi as A
+    from libultrahdr_amd import synth
+
+    with tempfile.TemporaryDirectory() as d:
+        hdr = synth.make_hdr_p010(w, h, ct=A.UHDR_CT_HLG)
+        sdr = synth.make_sdr_yuv420(w, h)
+        np.concatenate([hdr.valid(0).ravel(), hdr.valid(1).ravel()]).tofile(os.path.join(d, "in.p010"))
+        np.concatenate([sdr.valid(c).ravel() for c in range(3)]).tofile(os.path.join(d, "in.yuv420"))
+        rc, _, err, _ = F.encode_api1("in.p010", "in.yuv420", w, h, "cpu.jpg", False, d)
+        assert rc == 0, err
+        rc, _, err, trace = F.encode_api1("in.p010", "in.yuv420", w, h, "gpu.jpg", True, d)
+        assert rc == 0, err
+        assert "generate_gainmap" in _stages(trace), trace
+        a, b = F.read(os.path.join(d, "cpu.jpg")), F.read(os.path.join(d, "gpu.jpg"))
+        assert np.array_equal(a, b), f"{int((a != b).sum()) if a.size == b.size else 'size'} differing bytes"
+        rc, _, err, _ = F.decode("cpu.jpg", 0, 4, "cpu.raw", False, d)
+        assert rc == 0, err
+        rc, _, err, trace = F.decode("cpu.jpg", 0, 4, "gpu.raw", True, d)
+        assert rc == 0, err
+        assert "apply_gainmap" in _stages(trace) and "jpeg_decode_scan" in _stages(trace), trace
+        pa, pb = F.read(os.path.join(d, "cpu.raw")), F.read(os.path.join(d, "gpu.raw"))
+        assert pa.size == pb.size == w * h * 8
+        assert np.array_equal(pa, pb), f"{int((pa != pb).sum())} differing bytes"
