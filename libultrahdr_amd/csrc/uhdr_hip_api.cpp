@@ -2079,11 +2079,30 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
   // fixed-point search not settle within the round budget (never seen; pathological streams), the serial kernel runs.
   bool sync_done = false;
   if (a.nseg == 1 && data_bytes >= 4096 && fast_ok && !getenv("UHDR_HIP_HUFF_SERIAL")) {
-    uint32_t sub_bits = 1024;  // a power of two >= 256 (the lanes' chunks are staged in LDS: 64 x sub_bits / 8 bytes per wave)
-    if (const char* e = getenv("UHDR_HIP_HUFF_SUB_BITS")) {
-      const int v = atoi(e);
-      if (v >= 256 && v <= 4096 && (v & (v - 1)) == 0) sub_bits = (uint32_t)v;
+    // Subsequence size: a power of two >= 256 bits (the lanes' chunks are staged in LDS: 64 x sub_bits / 8 bytes per wave).
+    // Attempts, in order: the hypothesis scheme at 512 bits with seven overflow levels (4K q95 photo-like data: 485 us), then at
+    // 1024 bits with seven levels (twice the window: streams that synchronise slowly), then the rounds at 1024 bits.
+    struct Attempt { uint32_t sub_bits; int levels; };  // levels 0: the rounds
+    std::vector<Attempt> attempts;
+    {
+      const char* eb = getenv("UHDR_HIP_HUFF_SUB_BITS");
+      const char* el = getenv("UHDR_HIP_HUFF_LEVELS");
+      const int vb = eb ? atoi(eb) : 0;
+      const bool vb_ok = vb >= 256 && vb <= 4096 && (vb & (vb - 1)) == 0;
+      if (vb_ok || el) {  // tuning / tests: exactly this configuration, then the rounds at the same size
+        const uint32_t sbits = vb_ok ? (uint32_t)vb : 1024u;
+        const int lv = el ? atoi(el) : (sbits <= 512 ? 7 : 4);
+        if (lv >= 1 && lv <= 7 && bpm * (lv + 1) <= kHuffHypSlots) attempts.push_back({sbits, lv});
+        attempts.push_back({sbits, 0});
+      } else {
+        if (bpm * 8 <= kHuffHypSlots) { attempts.push_back({512u, 7}); attempts.push_back({1024u, 7}); }
+        else if (bpm * 5 <= kHuffHypSlots) attempts.push_back({1024u, 4});
+        attempts.push_back({1024u, 0});
+      }
     }
+    uint32_t sub_bits = attempts[0].sub_bits;  // the smallest size of the list: it sizes the per-subsequence buffers
+    bool use_hyp = false;
+    for (const Attempt& t : attempts) { if (t.sub_bits < sub_bits) sub_bits = t.sub_bits; use_hyp = use_hyp || t.levels > 0; }
     const int max_rounds = 40;
     const int nch = huff_sync_chunks(data_bytes);
     const uint32_t nsub = huff_sync_max_subsequences(data_bytes, sub_bits);
@@ -2094,15 +2113,14 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
     const size_t o_clean = take(data_bytes + 16), o_cnt = take((size_t)nch * 4), o_flags = take(64), o_s0 = take((size_t)nsub * 8),
                  o_s1 = take((size_t)nsub * 8), o_nblk = take((size_t)nsub * 4 + 4), o_dcd = take((size_t)total_blocks * 4),
                  o_c0 = take(nsub), o_c1 = take(nsub), o_dcp = take((size_t)((total_blocks + 1023) / 1024) * 12 + 16),
-                 o_ft = take(sizeof(HuffFastTable) * 8);  // symbol form x 4, state-tracking form x 4
+                 o_ft = take(sizeof(HuffFastTable) * 8),  // symbol form x 4, state-tracking form x 4
+                 o_st = take(((size_t)nsub / 2048 + 2) * 4);
     // hypothesis scheme (interleaved scans): one decode per possible block position instead of rounds
-    int hyp_levels = 4;
-    if (const char* e = getenv("UHDR_HIP_HUFF_LEVELS")) hyp_levels = atoi(e);  // 0: the round scheme
-    const bool use_hyp = hyp_levels >= 1 && hyp_levels <= 7 && bpm * (hyp_levels + 1) <= kHuffHypSlots;
     const size_t o_hs = use_hyp ? take((size_t)nsub * kHuffHypSlots * 8) : 0, o_hm = use_hyp ? take((size_t)nsub * kHuffHypSlots) : 0,
                  o_hc = use_hyp ? take((size_t)nsub * kHuffHypSlots * 2) : 0;
     size_t chain_tiles_off = 0;
-    const size_t o_ch = use_hyp ? take(huff_hyp_chain_bytes(data_bytes, sub_bits, &chain_tiles_off)) : 0;
+    const size_t o_ch = use_hyp ? take(huff_hyp_chain_bytes(data_bytes, sub_bits, &chain_tiles_off)) : 0;  // sized for the smallest subsequences
+    (void)chain_tiles_off;
     UHDR_TRY(ensure(c->scratch[6], off));
     uint8_t* sb = (uint8_t*)c->scratch[6].p;
     HuffSyncArgs y;
@@ -2115,6 +2133,7 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
     y.state[0] = (uint64_t*)(sb + o_s0); y.state[1] = (uint64_t*)(sb + o_s1);
     y.changed[0] = sb + o_c0; y.changed[1] = sb + o_c1;
     y.nblk = (uint32_t*)(sb + o_nblk);
+    y.scan_tmp = (uint32_t*)(sb + o_st);
     y.dcd = (int*)(sb + o_dcd);
     y.total_blocks = total_blocks;
     y.blocks_per_mcu = bpm; y.ncomp = a.ncomp; y.mcus_per_row = a.mcus_per_row;
@@ -2136,47 +2155,57 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
       HIP_TRY(hipMemsetAsync(y.dcd, 0, (size_t)total_blocks * 4, c->stream));
       int final_buf = 0;
       uint32_t fl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      bool hyp_done = false;
-      if (use_hyp) {
-        y.hyp_h = bpm;
-        y.hyp_levels = hyp_levels;
-        y.hyp_state = (uint64_t*)(sb + o_hs);
-        y.hyp_map = sb + o_hm;
-        y.hyp_cnt = (uint16_t*)(sb + o_hc);
-        y.hyp_hist = getenv("UHDR_HIP_HUFF_DEBUG") ? 1 : 0;
-        HIP_TRY(hipMemsetAsync(y.hyp_map, 0xff, (size_t)nsub * kHuffHypSlots, c->stream));
-        HIP_TRY(hipMemsetAsync(y.state[0], 0xff, (size_t)nsub * 8, c->stream));  // a start state the write pass skips, should the chain be lost
-        HIP_TRY(hipMemsetAsync(y.hyp_cnt, 0, (size_t)nsub * kHuffHypSlots * 2, c->stream));
-        {
-          ProfScope ps(c, "huffman_decode");
-          HIP_TRY(launch_huffman_unstuff(data, (uint32_t)data_bytes, (uint32_t*)(sb + o_cnt), y.flags + 8, sb + o_clean, c->stream));
-          HIP_TRY(launch_huffman_decode_hyp(y, (int*)(sb + o_dcp), sb + o_ch, sb + o_ch + chain_tiles_off, c->stream));
+      bool hyp_done = false, unstuffed = false, rounds_ran = false;
+      auto start_over = [&]() -> uhdr_error_info_t {  // an attempt failed: everything it wrote goes back to its initial state
+        HIP_TRY(hipMemsetAsync(y.flags, 0, 32, c->stream));  // not [8]: the stuffed-byte count stays
+        HIP_TRY(hipMemsetAsync(y.nblk, 0, (size_t)nsub * 4 + 4, c->stream));
+        HIP_TRY(hipMemsetAsync(y.dcd, 0, (size_t)total_blocks * 4, c->stream));
+        for (int i = 0; i < a.ncomp; i++) HIP_TRY(hipMemsetAsync(a.coef[i], 0, zero_bytes[i], c->stream));
+        return ok_status();
+      };
+      for (size_t ti = 0; ti < attempts.size() && !hyp_done && !rounds_ran; ti++) {
+        const Attempt& t = attempts[ti];
+        if (ti > 0) UHDR_TRY(start_over());
+        y.sub_bits = t.sub_bits;
+        const uint32_t nsub_t = huff_sync_max_subsequences(data_bytes, t.sub_bits);
+        if (t.levels > 0) {
+          y.hyp_h = bpm;
+          y.hyp_levels = t.levels;
+          y.hyp_state = (uint64_t*)(sb + o_hs);
+          y.hyp_map = sb + o_hm;
+          y.hyp_cnt = (uint16_t*)(sb + o_hc);
+          y.hyp_hist = getenv("UHDR_HIP_HUFF_DEBUG") ? 1 : 0;
+          HIP_TRY(hipMemsetAsync(y.hyp_map, 0xff, (size_t)nsub_t * kHuffHypSlots, c->stream));
+          HIP_TRY(hipMemsetAsync(y.state[0], 0xff, (size_t)nsub_t * 8, c->stream));  // a start state the write pass skips, should the chain be lost
+          HIP_TRY(hipMemsetAsync(y.hyp_cnt, 0, (size_t)nsub_t * kHuffHypSlots * 2, c->stream));
+          size_t tiles_off = 0;
+          (void)huff_hyp_chain_bytes(data_bytes, t.sub_bits, &tiles_off);
+          {
+            ProfScope ps(c, "huffman_decode");
+            if (!unstuffed) HIP_TRY(launch_huffman_unstuff(data, (uint32_t)data_bytes, (uint32_t*)(sb + o_cnt), y.flags + 8, sb + o_clean, c->stream));
+            unstuffed = true;
+            HIP_TRY(launch_huffman_decode_hyp(y, (int*)(sb + o_dcp), sb + o_ch, sb + o_ch + tiles_off, c->stream));
+          }
+          HIP_TRY(hipMemcpyAsync(fl, y.flags, sizeof fl, hipMemcpyDeviceToHost, c->stream));
+          HIP_TRY(hipStreamSynchronize(c->stream));
+          hyp_done = fl[2] == 0;
+          if (getenv("UHDR_HIP_HUFF_DEBUG")) {
+            uint32_t hist[16] = {};
+            (void)hipMemcpy(hist, y.flags, sizeof hist, hipMemcpyDeviceToHost);
+            fprintf(stderr, "uhdr_hip: hypothesis decode of %zu bytes, %u subsequences of %u bits x %d: merges per level %u %u %u %u %u %u+, %u paths unmerged after %d levels, true path %s\n",
+                    data_bytes, nsub_t, t.sub_bits, bpm, hist[10], hist[11], hist[12], hist[13], hist[14], hist[15], fl[3], t.levels, hyp_done ? "resolved" : "LOST (next attempt)");
+          }
+        } else {
+          {
+            ProfScope ps(c, "huffman_decode");
+            if (!unstuffed) HIP_TRY(launch_huffman_unstuff(data, (uint32_t)data_bytes, (uint32_t*)(sb + o_cnt), y.flags + 8, sb + o_clean, c->stream));
+            unstuffed = true;
+            HIP_TRY(launch_huffman_decode_sync(y, max_rounds, (int*)(sb + o_dcp), &final_buf, c->stream));
+          }
+          HIP_TRY(hipMemcpyAsync(fl, y.flags, sizeof fl, hipMemcpyDeviceToHost, c->stream));
+          HIP_TRY(hipStreamSynchronize(c->stream));
+          rounds_ran = true;
         }
-        HIP_TRY(hipMemcpyAsync(fl, y.flags, sizeof fl, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        hyp_done = fl[2] == 0;
-        if (getenv("UHDR_HIP_HUFF_DEBUG"))
-        {
-          uint32_t hist[16] = {};
-          (void)hipMemcpy(hist, y.flags, sizeof hist, hipMemcpyDeviceToHost);
-          fprintf(stderr, "uhdr_hip: hypothesis decode of %zu bytes, %u subsequences x %d: merges per level %u %u %u %u %u %u+, %u paths unmerged after %d levels, true path %s\n",
-                  data_bytes, nsub, bpm, hist[10], hist[11], hist[12], hist[13], hist[14], hist[15], fl[3], hyp_levels, hyp_done ? "resolved" : "LOST (falling back to rounds)");
-        }
-        if (!hyp_done) {  // a stretch of the true path did not merge within the overflow budget: start over with the rounds
-          HIP_TRY(hipMemsetAsync(y.flags, 0, 32, c->stream));  // not [8]: the stuffed-byte count stays
-          HIP_TRY(hipMemsetAsync(y.nblk, 0, (size_t)nsub * 4 + 4, c->stream));
-          HIP_TRY(hipMemsetAsync(y.dcd, 0, (size_t)total_blocks * 4, c->stream));
-          for (int i = 0; i < a.ncomp; i++) HIP_TRY(hipMemsetAsync(a.coef[i], 0, zero_bytes[i], c->stream));
-        }
-      }
-      if (!hyp_done) {
-        {
-          ProfScope ps(c, "huffman_decode");
-          if (!use_hyp) HIP_TRY(launch_huffman_unstuff(data, (uint32_t)data_bytes, (uint32_t*)(sb + o_cnt), y.flags + 8, sb + o_clean, c->stream));
-          HIP_TRY(launch_huffman_decode_sync(y, max_rounds, (int*)(sb + o_dcp), &final_buf, c->stream));
-        }
-        HIP_TRY(hipMemcpyAsync(fl, y.flags, sizeof fl, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
       }
       if (hyp_done || fl[4 + max_rounds % 3] == 0) {  // the fixed point was reached: the decode is the true one
         if (fl[1] & 8u) return err_status(UHDR_CODEC_INVALID_PARAM, "corrupt entropy-coded data (the scan ends before its last block)");

@@ -280,6 +280,7 @@ struct HuffSyncArgs {
   uint64_t* state[2];         // end state per subsequence, double buffered: bit position | block in MCU << 32 | zig-zag index << 40
   uint8_t* changed[2];
   uint32_t* nblk;             // blocks completed per subsequence; later their exclusive scan
+  uint32_t* scan_tmp;         // scratch of that scan: one word per 2048 subsequences
   uint32_t* flags;            // [1]: status bits (2 bad code / run, 8 truncated); [4..6]: change counters of the rounds (r % 3); [8]: stuffed bytes
   int* dcd;                   // DC differences of all blocks in scan order
   uint32_t total_blocks;
