@@ -253,10 +253,14 @@ def main():
     # BASELINE configs[3]: the row-striped API-1 two-pass encode, the one place where the path has a collective.  Every
     # rank runs it (also at N = 1: a one-rank communicator), after the headline's timed region.
     if not args.no_config4:
+        # The headline is measured; nothing after it may cost the line.  An exception is caught below, but a collective that
+        # never returns (a communicator that cannot form on some node) cannot be: a watchdog prints the line and leaves.
+        dog = arm_watchdog(180.0 if world > 1 else 600.0, out, rank, "config4")
         try:
             c4 = config4_section(ctx, u, device, rank, world, backend)
         except Exception as e:  # noqa: BLE001
             c4 = {"error": f"{type(e).__name__}: {e}"}
+        dog.cancel()
         if rank == 0:
             out["config4"] = c4
 
@@ -282,6 +286,8 @@ def main():
             pass
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
+    if world > 1:  # the line is out: a teardown that hangs must not keep the launcher waiting
+        arm_watchdog(60.0, None, rank, "teardown")
     ctx.close()
     try:
         C.CDLL(None).fflush(None)
@@ -289,6 +295,27 @@ def main():
         pass
     if world > 1:
         dist.destroy_process_group()
+
+
+def arm_watchdog(seconds, out, rank, section):
+    """Daemon timer: if it fires, rank 0 prints the bench line as it stands (with an error note for `section`) and every
+    rank leaves the process.  Cancel it when the section returns."""
+    import threading
+
+    def fire():
+        if rank == 0 and out is not None:
+            out.setdefault(section, {"error": f"section did not return within {seconds:.0f} s (watchdog); the lines above it are complete"})
+            try:
+                C.CDLL(None).fflush(None)
+            except Exception:  # noqa: BLE001
+                pass
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
 
 
 def launch_stats(ms_list):
