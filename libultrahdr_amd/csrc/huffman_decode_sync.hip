@@ -380,6 +380,100 @@ __device__ __forceinline__ void run_span(const HuffSyncArgs& a, const Staged& st
   if (WRITE && bad) atomicOr(a.flags + 1, 2u);
 }
 
+// ---- the write pass ------------------------------------------------------------------------------------------------------
+// Tables in VALUE form (host: make_value_table), one 32-bit word per entry:
+//   bits 0-4 bits consumed (code + magnitude), 5-11 zig-zag advance (as in the tracking form), 12-15 magnitude bits s,
+//   16 malformed (undefined code / DC category beyond 15), 31 "longer code: sub-table in bits 0-4" (first level only).
+// One lookup yields everything a symbol needs: the value is the last s of the consumed bits, HUFF_EXTENDed.
+struct WriteLds {
+  uint32_t t[4][kHuffValWords];
+  uint8_t zz[64];
+  uint8_t comp[16], yo[16], xo[16];
+  int vs[4], hs[4], bw[4], bh[4];
+  int16_t* coef[4];
+};
+__device__ __forceinline__ void load_write_lds(const HuffSyncArgs& a, WriteLds& L) {
+  uint32_t* dst = &L.t[0][0];
+  for (uint32_t i = threadIdx.x; i < 4u * kHuffValWords; i += blockDim.x) dst[i] = a.vtabs[i];
+  if (threadIdx.x < 64) L.zz[threadIdx.x] = a.zigzag[threadIdx.x];
+  if (threadIdx.x < 16) {
+    const int j = (int)threadIdx.x;
+    int c = a.comp_of[j];
+    if (c >= a.ncomp) c = 0;
+    const int jj = j - a.first_blk[c];
+    L.comp[j] = (uint8_t)c;
+    L.yo[j] = (uint8_t)(jj >= 0 ? jj / a.hs[c] : 0);
+    L.xo[j] = (uint8_t)(jj >= 0 ? jj % a.hs[c] : 0);
+  }
+  if (threadIdx.x < 3) {
+    const int c = (int)threadIdx.x;
+    L.vs[c] = a.vs[c]; L.hs[c] = a.hs[c]; L.bw[c] = a.bw[c]; L.bh[c] = a.bh[c]; L.coef[c] = a.coef[c];
+  }
+}
+// Decodes from the TRUE state (p, b, k) to the first symbol boundary at or beyond end_bit, storing coefficients (natural
+// order) and DC differences for the blocks [blk, total_blocks); flags malformed data.  Same transitions as track_span.
+__device__ __forceinline__ void write_span(const HuffSyncArgs& a, const Staged& st, uint32_t region_bit, const WriteLds& L, uint32_t p, uint32_t b,
+                                           uint32_t k, uint32_t end_bit, uint32_t& nblk, uint32_t blk) {
+  Bits r;
+  r.st = st;
+  r.region_bit = region_bit;
+  r.seek(p);
+  bool bad = false;
+  const uint32_t bpm = (uint32_t)a.blocks_per_mcu;
+  uint32_t cpack = 0;
+#pragma unroll
+  for (int j = 0; j < 16; j++) cpack |= ((uint32_t)a.comp_of[j] & 3u) << (2 * j);
+  const uint32_t m0 = blk / bpm;
+  int my = (int)(m0 / (uint32_t)a.mcus_per_row), mx = (int)(m0 - (uint32_t)my * (uint32_t)a.mcus_per_row);
+  int16_t* dst = nullptr;
+  auto locate = [&]() {  // the JBLOCK of the current block, nullptr for a dummy block of an edge MCU
+    const int c = L.comp[b];
+    const int by = my * L.vs[c] + L.yo[b], bx = mx * L.hs[c] + L.xo[b];
+    dst = (by < L.bh[c] && bx < L.bw[c]) ? L.coef[c] + ((size_t)by * L.bw[c] + bx) * 64 : nullptr;
+  };
+  locate();
+  const uint32_t* T = &L.t[0][0];
+  uint32_t cbase = ((cpack >> (2u * b)) & 3u) ? 2u * kHuffValWords : 0u;
+  int left = (int)(end_bit - p);
+  while (left > 0 && blk < a.total_blocks) {
+    r.fill();
+    const uint32_t w16 = r.peek(16);
+    const uint32_t tb = cbase + (k ? (uint32_t)kHuffValWords : 0u);
+    uint32_t e = T[tb + (w16 >> 7)];
+    if (__builtin_amdgcn_ballot_w64((e >> 31) != 0) != 0) {
+      const uint32_t e2 = T[tb + 512u + ((e >> 31) ? (e & 31u) : 0u) * 128u + (w16 & 127u)];
+      e = (e >> 31) ? e2 : e;
+    }
+    const uint32_t adv = e & 31u, kinc = (e >> 5) & 127u, sz = (e >> 12) & 15u;
+    const uint32_t ext = (1u << sz) - 1u;
+    const uint32_t raw = r.peek((int)adv) & ext;  // adv >= 1: every code is at least one bit long
+    const int value = (int)raw - (((raw << 1) > ext) ? 0 : (int)ext);  // HUFF_EXTEND; 0 when there are no magnitude bits
+    const uint32_t zzpos = k + kinc - 1u;  // AC symbol with a value: k + run
+    const bool is_dc = k == 0;
+    const bool over = !is_dc && sz != 0 && zzpos > 63u;
+    bad = bad || ((e >> 16) & 1u) != 0 || over;
+    if (is_dc) a.dcd[blk] = value;
+    if (!is_dc && sz != 0 && !over && dst) dst[L.zz[zzpos & 63u]] = (int16_t)value;
+    r.skip((int)adv);
+    left -= (int)adv;
+    k += kinc;
+    if (k >= 64u) {
+      k = 0;
+      b++;
+      nblk++;
+      blk++;
+      if (b == bpm) {
+        b = 0;
+        mx++;
+        if (mx == a.mcus_per_row) { mx = 0; my++; }
+      }
+      cbase = ((cpack >> (2u * b)) & 3u) ? 2u * kHuffValWords : 0u;
+      locate();
+    }
+  }
+  if (bad) atomicOr(a.flags + 1, 2u);
+}
+
 // rounds of step 2 / 3.  state[cur] is read, state[cur ^ 1] written; changed[] likewise.  flags[4 + r % 3] counts the
 // changes of round r; a round clears the counter of the round after it.
 __global__ __launch_bounds__(kSyncBlock) void sync_round_kernel(const HuffSyncArgs a, int round) {
@@ -431,16 +525,19 @@ __global__ __launch_bounds__(kSyncBlock) void sync_round_kernel(const HuffSyncAr
   if (ch) atomicAdd(a.flags + 4 + round % 3, 1u);
 }
 
-__global__ __launch_bounds__(kSyncBlock) void sync_write_kernel(const HuffSyncArgs a, int final_buf) {
-  extern __shared__ uint32_t s_stage[];
-  __shared__ ScanLds L;
-  load_scan_lds(a, L);
-  const uint32_t i = blockIdx.x * kSyncBlock + threadIdx.x;
+// blockDim.x / 64 waves share one copy of the value tables; every wave stages its own 64 subsequences
+__global__ __launch_bounds__(256) void sync_write_kernel(const HuffSyncArgs a, int final_buf) {
+  extern __shared__ uint32_t s_stage_all[];
+  __shared__ WriteLds L;
+  load_write_lds(a, L);
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t nclean = a.nbytes - *a.nstuffed, nbits = nclean * 8u;
   const uint32_t nsub = (nbits + a.sub_bits - 1) / a.sub_bits;
   const uint32_t cshift = 31u - (uint32_t)__builtin_clz(a.sub_bits >> 3);
-  const uint32_t first_byte = blockIdx.x * kSyncBlock * (a.sub_bits >> 3);
-  stage_wave(a.clean, nclean, first_byte, cshift, s_stage, threadIdx.x);
+  const uint32_t wv = threadIdx.x >> 6;
+  uint32_t* s_stage = s_stage_all + wv * ((64u * ((a.sub_bits >> 3) + 4u) + 64u) >> 2);
+  const uint32_t first_byte = (blockIdx.x * blockDim.x + wv * 64u) * (a.sub_bits >> 3);
+  stage_wave(a.clean, nclean, first_byte, cshift, s_stage, threadIdx.x & 63u);
   __syncthreads();
   if (i >= nsub) return;
   uint32_t p = 0, b = 0, k = 0;
@@ -451,7 +548,7 @@ __global__ __launch_bounds__(kSyncBlock) void sync_write_kernel(const HuffSyncAr
   const uint32_t end_bit = min((i + 1) * a.sub_bits, nbits);
   uint32_t nblk = 0;
   const Staged st = {s_stage, cshift};
-  if (p < end_bit) run_span<true>(a, st, first_byte * 8u, L, p, b, k, end_bit, nblk, a.nblk[i]);  // nblk[] holds the exclusive scan by now
+  if (p < end_bit) write_span(a, st, first_byte * 8u, L, p, b, k, end_bit, nblk, a.nblk[i]);  // nblk[] holds the exclusive scan by now
   if (i == nsub - 1) {
     // the scan must hold exactly total_blocks blocks: fewer = truncated data, more cannot be seen (the loop stops there)
     if (a.nblk[i] + nblk < a.total_blocks) atomicOr(a.flags + 1, 8u);
@@ -691,6 +788,18 @@ __global__ __launch_bounds__(1024) void dc_apply_kernel(const HuffSyncArgs a, co
 
 }  // namespace
 
+// the write pass: up to four waves share the 41 KB of value tables (static LDS) next to their staged bytes (dynamic);
+// beyond 64 KB in total the dynamic part needs the opt-in (gfx950 gives a workgroup up to 160 KB)
+static void launch_write(const HuffSyncArgs& a, uint32_t nsub, int final_buf, hipStream_t s) {
+  const size_t per_wave = (size_t)64 * ((a.sub_bits >> 3) + 4) + 64;
+  const int waves = per_wave * 4 <= (20u << 10) ? 4 : (per_wave * 2 <= (20u << 10) ? 2 : 1);
+  const size_t lds = per_wave * waves;
+  const int threads = 64 * waves;
+  const int grid = (int)((nsub + threads - 1) / threads);
+  if (lds > (20u << 10)) (void)hipFuncSetAttribute((const void*)sync_write_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(sync_write_kernel, dim3(grid), dim3(threads), lds, s, a, final_buf);
+}
+
 int huff_sync_chunks(uint64_t nbytes) { return (int)((nbytes + kChunk - 1) / kChunk); }
 
 // Step 1 (unstuff): chunk_counts becomes the exclusive scan, *nstuffed_dev the number of dropped bytes.
@@ -721,7 +830,7 @@ hipError_t launch_huffman_decode_sync(const HuffSyncArgs& a, int max_rounds, int
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(nt), dim3(kScanThreads), 0, s, a.nblk, (int)nsub, a.scan_tmp);
     if (nt > 1) hipLaunchKernelGGL(scan_add_kernel, dim3(nt), dim3(kScanThreads), 0, s, a.nblk, (int)nsub, (const uint32_t*)a.scan_tmp);
   }
-  hipLaunchKernelGGL(sync_write_kernel, dim3(grid), dim3(kSyncBlock), lds, s, a, *final_buf);
+  launch_write(a, nsub, *final_buf, s);
   const int nch = (int)((a.total_blocks + 1023) / 1024);
   hipLaunchKernelGGL(dc_partial_kernel, dim3(nch), dim3(1024), 0, s, a, dc_partial);
   hipLaunchKernelGGL(dc_scan_partials_kernel, dim3(1), dim3(1024), 0, s, dc_partial, nch);
@@ -770,7 +879,7 @@ hipError_t launch_huffman_decode_hyp(const HuffSyncArgs& a, int* dc_partial, uin
     if (nt > 1) hipLaunchKernelGGL(scan_add_kernel, dim3(nt), dim3(kScanThreads), 0, s, a.nblk, (int)nsub, (const uint32_t*)a.scan_tmp);
   }
   mark();
-  hipLaunchKernelGGL(sync_write_kernel, dim3(grid), dim3(kSyncBlock), lds0, s, a, 0);
+  launch_write(a, nsub, 0, s);
   mark();
   const int nch = (int)((a.total_blocks + 1023) / 1024);
   hipLaunchKernelGGL(dc_partial_kernel, dim3(nch), dim3(1024), 0, s, a, dc_partial);

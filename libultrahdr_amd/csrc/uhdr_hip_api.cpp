@@ -2011,6 +2011,36 @@ static void make_track_table(const HuffFastTable& f, bool is_dc, HuffFastTable* 
     for (int i = 0; i < 128; i++) t->l2[s][i] = conv(f.l2[s][i]);
 }
 
+// The value form of a fast table for the write pass (huffman_decode_sync.hip: write_span): the tracking form's fields plus
+// the number of magnitude bits and a "malformed" flag, one 32-bit word per entry, first level then the sub-tables.
+static void make_value_table(const HuffFastTable& f, bool is_dc, uint32_t* out /* kHuffValWords */) {
+  auto conv = [&](uint16_t e, bool first_level) -> uint32_t {
+    if (first_level && (e & 0x8000u)) return 0x80000000u | (e & 31u);
+    unsigned adv, kinc, sz = 0, bad = 0;
+    if (e == 0) {
+      adv = 16;
+      kinc = is_dc ? 1 : 64;
+      bad = 1;
+    } else {
+      const unsigned len = (e >> 8) & 31u, rs = e & 255u;
+      if (is_dc) {
+        if (rs > 15u) bad = 1; else sz = rs;
+        adv = len + sz;
+        kinc = 1;
+      } else {
+        sz = rs & 15u;
+        const unsigned run = rs >> 4;
+        adv = len + sz;
+        kinc = sz ? run + 1 : (run == 15u ? 16u : 64u);
+      }
+    }
+    return adv | (kinc << 5) | (sz << 12) | (bad << 16);
+  };
+  for (int i = 0; i < 512; i++) out[i] = conv(f.l1[i], true);
+  for (int s = 0; s < kHuffL2Max; s++)
+    for (int i = 0; i < 128; i++) out[512 + s * 128 + i] = conv(f.l2[s][i], false);
+}
+
 uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_jpeg_scan_t* sc, const uhdr_hip_huff_tables_t* tables,
                                               const uint8_t* data, size_t data_bytes) {
   if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
@@ -2114,7 +2144,7 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
                  o_s1 = take((size_t)nsub * 8), o_nblk = take((size_t)nsub * 4 + 4), o_dcd = take((size_t)total_blocks * 4),
                  o_c0 = take(nsub), o_c1 = take(nsub), o_dcp = take((size_t)((total_blocks + 1023) / 1024) * 12 + 16),
                  o_ft = take(sizeof(HuffFastTable) * 8),  // symbol form x 4, state-tracking form x 4
-                 o_st = take(((size_t)nsub / 2048 + 2) * 4);
+                 o_st = take(((size_t)nsub / 2048 + 2) * 4), o_vt = take((size_t)4 * kHuffValWords * 4);
     // hypothesis scheme (interleaved scans): one decode per possible block position instead of rounds
     const size_t o_hs = use_hyp ? take((size_t)nsub * kHuffHypSlots * 8) : 0, o_hm = use_hyp ? take((size_t)nsub * kHuffHypSlots) : 0,
                  o_hc = use_hyp ? take((size_t)nsub * kHuffHypSlots * 2) : 0;
@@ -2145,11 +2175,15 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
     }
     y.ftabs = (const HuffFastTable*)(sb + o_ft);
     y.ttabs = y.ftabs + 4;
+    y.vtabs = (const uint32_t*)(sb + o_vt);
     y.zigzag = a.zigzag;
     if (j == bpm && bpm <= 16) {
       ftabs.resize(8);
       for (int t = 0; t < 4; t++) make_track_table(ftabs[(size_t)t], (t & 1) == 0, &ftabs[(size_t)t + 4]);
       HIP_TRY(hipMemcpyAsync(sb + o_ft, ftabs.data(), sizeof(HuffFastTable) * 8, hipMemcpyHostToDevice, c->stream));
+      std::vector<uint32_t> vtabs((size_t)4 * kHuffValWords);
+      for (int t = 0; t < 4; t++) make_value_table(ftabs[(size_t)t], (t & 1) == 0, vtabs.data() + (size_t)t * kHuffValWords);
+      HIP_TRY(hipMemcpyAsync(sb + o_vt, vtabs.data(), vtabs.size() * 4, hipMemcpyHostToDevice, c->stream));
       HIP_TRY(hipMemsetAsync(y.flags, 0, 64, c->stream));
       HIP_TRY(hipMemsetAsync(y.nblk, 0, (size_t)nsub * 4 + 4, c->stream));
       HIP_TRY(hipMemsetAsync(y.dcd, 0, (size_t)total_blocks * 4, c->stream));

@@ -272,6 +272,7 @@ struct HuffFastTable {          // two-level decode form of one DHT table: 9 bit
   uint16_t l1[512];             // length << 8 | symbol;  0x8000 | sub-table for a longer code;  0 = undefined
   uint16_t l2[kHuffL2Max][128]; // length << 8 | symbol;  0 = undefined
 };
+constexpr int kHuffValWords = 512 + kHuffL2Max * 128;  // one table of the write pass: first level, then the sub-tables
 struct HuffSyncArgs {
   const uint8_t* clean;       // unstuffed entropy-coded bytes (device)
   uint32_t nbytes;            // size of the STUFFED stream (upper bound of the clean size)
@@ -290,6 +291,7 @@ struct HuffSyncArgs {
   int16_t* coef[3];           // zero-initialised JBLOCK arrays
   const HuffFastTable* ftabs; // DC luma, AC luma, DC chroma, AC chroma
   const HuffFastTable* ttabs; // the same four tables in state-tracking form: bits consumed | zig-zag advance << 5 (make_track_table)
+  const uint32_t* vtabs;      // ... and in value form for the write pass, 4 x kHuffValWords words (make_value_table)
   const uint8_t* zigzag;
   // hypothesis decode (launch_huffman_decode_hyp): slot s < hyp_h is "started at the subsequence's first bit as block s of
   // an MCU"; slot l * hyp_h + h is the path of hypothesis h of the subsequence l places back that has not merged yet
