@@ -157,8 +157,9 @@ struct Staged {
   const uint32_t* w;   // the wave's LDS region, as words
   uint32_t cshift;     // log2(bytes per subsequence)
   __device__ __forceinline__ uint32_t word(uint32_t byte_off) const {  // byte_off: multiple of 4, relative to the region
-    // chunk * (words per chunk + 1 pad word) + word inside the chunk == byte_off / 4 + chunk
-    return __builtin_bswap32(w[(byte_off >> 2) + (byte_off >> cshift)]);
+    // chunk * (words per chunk + 1 pad word) + word inside the chunk == byte_off / 4 + chunk.  Raw (little-endian) word: the
+    // reader swaps it when it APPENDS it, so that nothing waits for the load at the place where it is issued
+    return w[(byte_off >> 2) + (byte_off >> cshift)];
   }
 };
 struct Bits {  // MSB-first reader over a staged region; region_bit = global bit index of the region's first bit
@@ -180,7 +181,7 @@ struct Bits {  // MSB-first reader over a staged region; region_bit = global bit
   // after fill(): n > 32, enough for one whole symbol (code <= 16 bits + magnitude <= 15 bits)
   __device__ __forceinline__ void fill() {
     if (n <= 32) {
-      acc = (acc << 32) | pre;
+      acc = (acc << 32) | __builtin_bswap32(pre);
       next += 4;
       n += 32;
       pre = st.word(next);

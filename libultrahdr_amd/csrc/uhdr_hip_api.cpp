@@ -2211,7 +2211,7 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
           y.hyp_hist = getenv("UHDR_HIP_HUFF_DEBUG") ? 1 : 0;
           HIP_TRY(hipMemsetAsync(y.hyp_map, 0xff, (size_t)nsub_t * kHuffHypSlots, c->stream));
           HIP_TRY(hipMemsetAsync(y.state[0], 0xff, (size_t)nsub_t * 8, c->stream));  // a start state the write pass skips, should the chain be lost
-          HIP_TRY(hipMemsetAsync(y.hyp_cnt, 0, (size_t)nsub_t * kHuffHypSlots * 2, c->stream));
+          // hyp_cnt needs no initialisation: a slot's count is written together with its map entry, and only mapped slots are read
           size_t tiles_off = 0;
           (void)huff_hyp_chain_bytes(data_bytes, t.sub_bits, &tiles_off);
           {
