@@ -646,7 +646,7 @@ constexpr int kChainPer = 4, kChainThreads = 256, kChainTile = kChainPer * kChai
 __global__ __launch_bounds__(kChainThreads) void hyp_chain_tiles_kernel(const HuffSyncArgs a, uint8_t* __restrict__ prefix /* [threads total][slots] */,
                                                                         uint8_t* __restrict__ tile_map /* [tiles][slots] */) {
   __shared__ __attribute__((aligned(16))) uint8_t s_links[kChainTile * kHuffHypSlots];  // 48 KB
-  __shared__ uint8_t s_map[kChainThreads][kHuffHypSlots];                                // 12 KB
+  __shared__ __attribute__((aligned(16))) uint8_t s_map[kChainThreads][kHuffHypSlots];   // 12 KB
   const int tid = (int)threadIdx.x;
   const uint32_t nclean = a.nbytes - *a.nstuffed, nbits = nclean * 8u;
   const int nsub = (int)((nbits + a.sub_bits - 1) / a.sub_bits);
@@ -669,20 +669,31 @@ __global__ __launch_bounds__(kChainThreads) void hyp_chain_tiles_kernel(const Hu
     s_map[tid][s] = (uint8_t)cur;
   }
   __syncthreads();
+  static_assert(kHuffHypSlots % 4 == 0, "map rows are moved as 32-bit words");
+  constexpr int kWordsPerMap = kHuffHypSlots / 4;
   for (int d = 1; d < kChainThreads; d <<= 1) {  // inclusive scan: P[t] = F[t] o P[t - d]
-    uint8_t q[kHuffHypSlots];
+    uint32_t q[kWordsPerMap];
     const bool on = tid >= d;
     if (on) {
+      const uint32_t* part = (const uint32_t*)s_map[tid - d];  // the partner's map, four slots per read
 #pragma unroll
-      for (int s = 0; s < kHuffHypSlots; s++) {
-        const uint32_t v = s_map[tid - d][s];
-        q[s] = v == 0xffu ? (uint8_t)0xffu : s_map[tid][v];
+      for (int w = 0; w < kWordsPerMap; w++) {
+        const uint32_t pw = part[w];
+        uint32_t r = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          const uint32_t v = (pw >> (8 * b)) & 255u;
+          const uint32_t x = v == 0xffu ? 0xffu : (uint32_t)s_map[tid][v];
+          r |= x << (8 * b);
+        }
+        q[w] = r;
       }
     }
     __syncthreads();
     if (on) {
+      uint32_t* mine = (uint32_t*)s_map[tid];
 #pragma unroll
-      for (int s = 0; s < kHuffHypSlots; s++) s_map[tid][s] = q[s];
+      for (int w = 0; w < kWordsPerMap; w++) mine[w] = q[w];
     }
     __syncthreads();
   }
