@@ -2110,8 +2110,8 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
   bool sync_done = false;
   if (a.nseg == 1 && data_bytes >= 4096 && fast_ok && !getenv("UHDR_HIP_HUFF_SERIAL")) {
     // Subsequence size: a power of two >= 256 bits (the lanes' chunks are staged in LDS: 64 x sub_bits / 8 bytes per wave).
-    // Attempts, in order: the hypothesis scheme at 512 bits with seven overflow levels (4K q95 photo-like data: 485 us), then at
-    // 1024 bits with seven levels (twice the window: streams that synchronise slowly), then the rounds at 1024 bits.
+    // Attempts, in order: the hypothesis scheme with seven overflow levels at 512 bits (4K q95 photo-like data: 390 us) -- denser
+    // streams start at 2048 / 4096 bits --, then at doubled sizes up to 4096 bits, then the rounds at 1024 bits.
     struct Attempt { uint32_t sub_bits; int levels; };  // levels 0: the rounds
     std::vector<Attempt> attempts;
     {
@@ -2125,8 +2125,12 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
         if (lv >= 1 && lv <= 7 && bpm * (lv + 1) <= kHuffHypSlots) attempts.push_back({sbits, lv});
         attempts.push_back({sbits, 0});
       } else {
-        if (bpm * 8 <= kHuffHypSlots) { attempts.push_back({512u, 7}); attempts.push_back({1024u, 7}); }
-        else if (bpm * 5 <= kHuffHypSlots) attempts.push_back({1024u, 4});
+        // the window a path gets to fall in step (levels x subsequence) must cover the stream's synchronisation distance, which
+        // grows with the bits per block (few EOBs in dense blocks): start where files of this density have settled, then widen
+        const uint64_t bits_per_block = (uint64_t)data_bytes * 8u / (uint64_t)((uint64_t)a.total_mcus * (uint64_t)bpm);
+        const int lv = bpm * 8 <= kHuffHypSlots ? 7 : (bpm * 5 <= kHuffHypSlots ? 4 : 0);
+        if (lv > 0)
+          for (uint32_t sbits = bits_per_block < 200 ? 512u : (bits_per_block < 400 ? 2048u : 4096u); sbits <= 4096u; sbits <<= 1) attempts.push_back({sbits, lv});
         attempts.push_back({1024u, 0});
       }
     }
@@ -2253,6 +2257,11 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
     }
   }
   if (sync_done) return ok_status();
+  // one interval on one lane: fine for a thumbnail, slower than any CPU for a frame.  A caller that has a CPU decoder to
+  // fall back on (uhdr_hip_jpeg_decode_scan behind the facade) gets the stream back instead -- this is also where a file
+  // whose Huffman tables do not fit the two-level form (more than kHuffL2Max long-code prefixes) ends up
+  if (a.nseg == 1 && !c->huff_serial_ok && data_bytes > (256u << 10))
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "a %zu-byte scan without restart markers that the parallel decoder does not take (Huffman tables outside its two-level form)", data_bytes);
   {
     ProfScope ps(c, "huffman_decode");
     HIP_TRY(launch_huffman_decode(a, counts, starts, ends, c->stream));

@@ -198,3 +198,56 @@ def test_damaged_files_never_crash_the_device_path(uhdr):
     got = uhdr.jpeg_decode(jpeg)
     for c in range(3):
         assert np.array_equal(got[c], L.idct_dequant_port(coefs[c], ql if c == 0 else qc)), c
+
+
+@pytest.mark.parametrize("subsampling,quality", [(2, 90), (0, 85), (1, 95), (2, 100)])
+def test_files_with_optimised_huffman_tables(uhdr, subsampling, quality):
+    """Files written by another encoder (Pillow's libjpeg-turbo) with optimize=True: the DHT segments hold per-image tables,
+    not Annex K.  The device decode (file tables -> two-level / value-form tables) against the oracle's entropy decoder and
+    IDCT on the same file."""
+    PILImage = pytest.importorskip("PIL.Image")
+    import io
+
+    rng = np.random.default_rng(400 + subsampling + quality)
+    w, h = 1024, 640
+    yy, xx = np.mgrid[0:h, 0:w]
+    rgb = np.stack([np.clip(128 + 90 * np.sin(xx / (23.0 + 9 * k)) * np.cos(yy / (17.0 + 3 * k)) + rng.normal(0, 10, (h, w)), 0, 255) for k in range(3)],
+                   axis=-1).astype(np.uint8)
+    buf = io.BytesIO()
+    PILImage.fromarray(rgb, "RGB").save(buf, "JPEG", quality=quality, optimize=True, subsampling=subsampling)
+    jpeg = buf.getvalue()
+    hdr = uhdr.jpeg_parse(jpeg)
+    sc = hdr.scan
+    assert sc.num_components == 3 and sc.restart_interval == 0
+    sampling = [(sc.h_samp[c], sc.v_samp[c]) for c in range(3)]
+    bits = np.frombuffer(hdr.tables.bits, dtype=np.uint8).reshape(4, 17)
+    vals = np.frombuffer(hdr.tables.vals, dtype=np.uint8).reshape(4, 256)
+    std_bits, _ = L.std_dht_tables()
+    assert not np.array_equal(bits, std_bits), "the encoder was asked for optimised tables"
+    shapes = [(sc.blocks_h[c], sc.blocks_w[c]) for c in range(3)]
+    rc, coefs = L.huffman_decode_port(shapes, w, h, sampling, 0, jpeg[hdr.scan_offset: hdr.scan_offset + hdr.scan_bytes], tables=(bits, vals))
+    assert rc == 0
+    try:
+        got = uhdr.jpeg_decode(jpeg)
+    except A.UhdrError as err:
+        # quality 100 on a noisy image: nearly every block runs to coefficient 63 without an EOB, decoders started in different
+        # places fall in step only after tens of kilobits, and the parallel schemes give the stream back (the facade then takes
+        # libjpeg's decoder).  The plain entry point still decodes it -- on one lane -- to the same coefficients.
+        assert quality == 100 and err.code == A.UHDR_CODEC_UNSUPPORTED_FEATURE, err
+        _, dev = uhdr.jpeg_to_coefficients(jpeg)
+        for c in range(3):
+            assert np.array_equal(dev[c].cpu().numpy(), coefs[c]), c
+        return
+    for c in range(3):
+        qt = np.frombuffer(hdr.qtable, dtype=np.uint16).reshape(3, 64)[c]
+        assert np.array_equal(got[c], L.idct_dequant_port(coefs[c], qt)), c
+
+
+def test_progressive_files_are_not_for_this_path(uhdr):
+    PILImage = pytest.importorskip("PIL.Image")
+    import io
+
+    buf = io.BytesIO()
+    PILImage.fromarray(np.full((64, 64, 3), 77, dtype=np.uint8), "RGB").save(buf, "JPEG", progressive=True)
+    with pytest.raises(ValueError):
+        uhdr.jpeg_parse(buf.getvalue())
