@@ -37,12 +37,18 @@ __device__ __forceinline__ Color3 linearise_hdr(Color3 g, const float* lut, bool
 // kernel's HLG / PQ tail is the same construction): clamp the bit pattern into the table's domain, bucket = bits >> shift,
 // at most one threshold per bucket.  One 8-byte LDS read, one compare, one select.
 __device__ __forceinline__ uint32_t step_code(float v, const uint2* tab, const StepTab& t) {
-  const int ib = min(max((int)__float_as_uint(v), (int)t.lo_bits), (int)t.hi_bits);
-  const uint32_t bits = (uint32_t)ib;
+  uint32_t bits;  // the clamp into the table's domain on the bit pattern: one three-operand median
+  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(bits) : "v"(__float_as_uint(v)), "v"(t.lo_bits), "v"(t.hi_bits));
   uint32_t off = (bits >> t.shm3) & ~7u;
   off = off > t.base8 ? off - t.base8 : 0u;
   const uint2 e = *(const uint2*)((const char*)tab + off);
-  return bits >= e.x ? e.y >> 16 : e.y & 0xffffu;
+  uint32_t code;  // bits >= threshold ? upper : lower half of the entry's second word, picked by the select itself (SDWA)
+  // s_nop 1: a VALU write of vcc needs two wait states before a VALU reads it as a mask (the compiler inserts the same)
+  asm("v_cmp_ge_u32_e32 vcc, %1, %2\n\ts_nop 1\n\tv_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1"
+      : "=v"(code)
+      : "v"(bits), "v"(e.x), "v"(e.y)
+      : "vcc");
+  return code;
 }
 __device__ __forceinline__ void stage_step_tab(uint2* dst, const StepTab& t, uint32_t tid, uint32_t nthreads) {
   if (t.tab)
