@@ -1,6 +1,6 @@
 // uhdr_hip_jpeg_seam.cpp -- see uhdr_hip_jpeg_seam.h.  libjpeg errors longjmp to the setjmp the reference's helper
-// armed around the call site, exactly as they do for its own libjpeg calls; the scratch buffers here are plain
-// malloc blocks owned by one struct so that nothing with a destructor sits between the two.
+// armed around the call site, exactly as they do for its own libjpeg calls; the scratch buffers here live in the libjpeg
+// object's image pool, so nothing with a destructor sits between the two and nothing leaks on that path.
 #include "uhdr_hip_jpeg_seam.h"
 
 #include <cstdlib>
@@ -13,19 +13,14 @@ namespace uhdr_hip_seam {
 
 namespace {
 
+// Scratch blocks come from the libjpeg object's own JPOOL_IMAGE pool: an error_exit in any libjpeg call made while they are
+// live (destination overflow, memory manager failure) longjmps to the helper's setjmp, and jpeg_destroy_* / jpeg_abort frees
+// the pool on that path too.  alloc_large reports exhaustion through error_exit, like every libjpeg allocation.
 struct Scratch {
-  void* p[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  int n = 0;
-  void* get(size_t bytes) {
-    void* q = nullptr;
-    if (posix_memalign(&q, 64, bytes ? bytes : 64) != 0) return nullptr;
-    p[n++] = q;
-    return q;
-  }
-  void drop() {
-    for (int i = 0; i < n; i++) free(p[i]);
-    n = 0;
-  }
+  j_common_ptr ci;
+  explicit Scratch(j_common_ptr c) : ci(c) {}
+  void* get(size_t bytes) { return (*ci->mem->alloc_large)(ci, JPOOL_IMAGE, bytes ? bytes : 64); }
+  void drop() {}  // the pool is released with the libjpeg object
 };
 
 uhdr_error_info_t mem_error() {
@@ -61,9 +56,11 @@ void emit_marker(jpeg_compress_struct* cinfo, int code, const void* data, size_t
   emit(cinfo, static_cast<const unsigned char*>(data), n);
 }
 
-// UHDR_HIP_SEAM_DEVICE_ENTROPY=1: the whole compressImage on the device, Huffman pass included.  One wavefront encodes one
-// restart interval, so the file carries a DRI segment and RSTn markers the reference's files do not have; every decoder
-// reconstructs the same coefficients (T.81 B.2.4.4, F.1.3).  Off by default: the default keeps the reference's bytes.
+// The whole compressImage on the device, Huffman pass included (the default since round 3).  Without restart markers
+// (restart_interval 0) the entropy-coded segment is the one libjpeg writes -- the file equals the reference's byte for byte.
+// UHDR_HIP_SEAM_RESTART_INTERVAL=<MCUs | max> (also the older UHDR_HIP_SEAM_DEVICE_ENTROPY=1 = max) asks for restart
+// intervals instead: a DRI segment and RSTn markers the reference's files do not have; every decoder reconstructs the same
+// coefficients (T.81 B.2.4.4, F.1.3).  UHDR_HIP_SEAM_CPU_ENTROPY=1 leaves the Huffman pass to libjpeg.
 // true: the file is written (*st = result); false: not a configuration for this path, nothing written.
 bool device_scan_encode(jpeg_compress_struct* cinfo, int nc, const unsigned char* const planes[3], const unsigned int strides[3], bool rgb,
                         const unsigned bw[3], const unsigned bh[3], const void* icc, size_t icc_size, const char* comment,
@@ -97,10 +94,17 @@ bool device_scan_encode(jpeg_compress_struct* cinfo, int nc, const unsigned char
     scan.v_samp[c] = nc == 1 ? 1 : ci->v_samp_factor;
     bpm += scan.h_samp[c] * scan.v_samp[c];
   }
-  scan.restart_interval = 64 / bpm;  // the longest interval one wavefront (64 blocks) holds
+  scan.restart_interval = 0;  // the reference's stream (jpegencoderhelper.cpp:187-201 never sets restart_interval)
+  const char* ri_env = getenv("UHDR_HIP_SEAM_RESTART_INTERVAL");
+  if (!ri_env && getenv("UHDR_HIP_SEAM_DEVICE_ENTROPY")) ri_env = "max";
+  if (ri_env) {
+    const int longest = 64 / bpm;  // what one wavefront (64 blocks) holds
+    const int v = strcmp(ri_env, "max") ? atoi(ri_env) : longest;
+    scan.restart_interval = v < 0 ? 0 : (v > longest ? longest : v);
+  }
   size_t cap = 1u << 16;
   for (int c = 0; c < nc; c++) cap += (size_t)bw[c] * bh[c] * 64;
-  Scratch sc;
+  Scratch sc((j_common_ptr)cinfo);
   unsigned char* data = static_cast<unsigned char*>(sc.get(cap));
   if (!data) { *st = mem_error(); return true; }
   size_t n = 0;
@@ -158,9 +162,9 @@ bool jpeg_compress_on_device(jpeg_compress_struct* cinfo, const unsigned char* p
   }
   const bool rgb = format == UHDR_IMG_FMT_24bppRGB888;
   if (rgb && nc != 3) return false;
-  if (getenv("UHDR_HIP_SEAM_DEVICE_ENTROPY") && device_scan_encode(cinfo, nc, planes, strides, rgb, bw, bh, icc, icc_size, comment, st)) return true;
+  if (!getenv("UHDR_HIP_SEAM_CPU_ENTROPY") && device_scan_encode(cinfo, nc, planes, strides, rgb, bw, bh, icc, icc_size, comment, st)) return true;
 
-  Scratch sc;
+  Scratch sc((j_common_ptr)cinfo);
   const unsigned char* src[3] = {planes[0], planes[1], planes[2]};
   unsigned int sstride[3] = {strides[0], strides[1], strides[2]};
   if (rgb) {  // JCS_RGB -> YCbCr 4:4:4 (jccolor.c rgb_ycc_convert) on the device
@@ -319,7 +323,7 @@ bool jpeg_decompress_on_device(jpeg_decompress_struct* cinfo, bool want_rgb, uns
   if (!getenv("UHDR_HIP_SEAM_CPU_ENTROPY") && device_scan_decode(cinfo, want_rgb, dest, hstride, vstride, fmt, out_fmt, st)) return true;
 
   jvirt_barray_ptr* arrays = jpeg_read_coefficients(cinfo);  // the Huffman decode of the whole scan
-  Scratch sc;
+  Scratch sc((j_common_ptr)cinfo);
   unsigned bw[3] = {0, 0, 0}, bh[3] = {0, 0, 0};
   short* coef[3] = {nullptr, nullptr, nullptr};
   const unsigned short* qt[3] = {nullptr, nullptr, nullptr};

@@ -234,7 +234,9 @@ uhdr_error_info_t uhdr_hip_generate_gainmap_pass2_dev(uhdr_hip_ctx_t* ctx,
  * sdr / hdr describe this rank's rows (a multiple of lcm(2, scale) rows, except the last stripe); gainmap_img this rank's
  * rows of the map (planes[0] / stride[0] from the caller).  A stripe too short for one map row launches nothing and
  * contributes the merge's identity.  Without a communicator (uhdr_hip_comm_init not called) the same sequence runs
- * for a single stripe = the whole image.
+ * for a single stripe = the whole image.  A rank whose arguments are rejected (or whose pass 1 fails to launch) STILL takes
+ * part in the exchange, with the identity, and returns its error afterwards: one bad descriptor never leaves the other
+ * ranks waiting in the collective.
  * Communicator set-up is the usual NCCL bootstrap: rank 0 calls uhdr_hip_comm_unique_id, the application sends the
  * 128 bytes to the other ranks (torch.distributed, MPI, a file ...), every rank calls uhdr_hip_comm_init.  RCCL is
  * bound at run time (the copy already in the process, else librccl.so.1); the library does not link against it. */
@@ -243,6 +245,25 @@ int uhdr_hip_comm_unique_id(unsigned char id[UHDR_HIP_COMM_ID_BYTES]); /* 0, or 
 uhdr_error_info_t uhdr_hip_comm_init(uhdr_hip_ctx_t* ctx, const unsigned char id[UHDR_HIP_COMM_ID_BYTES], int rank, int nranks);
 void uhdr_hip_comm_destroy(uhdr_hip_ctx_t* ctx);
 int uhdr_hip_comm_size(uhdr_hip_ctx_t* ctx); /* ncclCommCount of the context's communicator, 0 without one */
+int uhdr_hip_comm_rank(uhdr_hip_ctx_t* ctx);
+/* The exchange steps over a caller-provided transport instead of RCCL (an MPI / gloo / shared-memory relay where RCCL is not
+ * an option -- e.g. several ranks on one GPU -- or a test double).  The library calls the functions in stream order with
+ * DEVICE pointers and its own hipStream_t (as void*); they return 0 on success.  all_reduce_min_f32 is required (it is the
+ * one collective of the hot path), the gathers are optional (NULL: the corresponding uhdr_hip_comm_*_dev call reports
+ * UHDR_CODEC_UNSUPPORTED_FEATURE). */
+typedef struct uhdr_hip_comm_ops {
+  void* user;
+  int (*all_reduce_min_f32)(void* user, float* buf, size_t n, void* hip_stream);                                    /* in place */
+  int (*all_gather)(void* user, const void* send, void* recv, size_t bytes_per_rank, void* hip_stream);
+  int (*gather_v)(void* user, const void* send, size_t send_bytes, void* recv, const size_t* counts, int root, void* hip_stream);
+} uhdr_hip_comm_ops_t;
+uhdr_error_info_t uhdr_hip_comm_init_custom(uhdr_hip_ctx_t* ctx, const uhdr_hip_comm_ops_t* ops, int rank, int nranks);
+/* Data movement between the ranks' devices on the context's stream (RCCL over xGMI by default): what replaces the
+ * reference's threads writing their stripes into one buffer (jpegr.cpp:845-864).  all_gather: `bytes_per_rank` from every
+ * rank, in rank order, on every rank.  gather: rank r's counts[r] bytes land at recv + sum(counts[0..r)) on `root` (stripes
+ * of unequal height, per-stripe entropy-coded streams); counts is a host array, the same on every rank. */
+uhdr_error_info_t uhdr_hip_comm_all_gather_dev(uhdr_hip_ctx_t* ctx, const void* send, void* recv, size_t bytes_per_rank);
+uhdr_error_info_t uhdr_hip_comm_gather_dev(uhdr_hip_ctx_t* ctx, const void* send, size_t send_bytes, void* recv, const size_t* counts, int root);
 uhdr_error_info_t uhdr_hip_generate_gainmap_striped_dev(uhdr_hip_ctx_t* ctx, const uhdr_raw_image_t* sdr_stripe,
                                                         const uhdr_raw_image_t* hdr_stripe, const uhdr_hip_encode_cfg_t* cfg,
                                                         uhdr_gainmap_metadata_t* gainmap_metadata, uhdr_raw_image_t* gainmap_stripe);

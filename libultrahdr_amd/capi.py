@@ -152,6 +152,16 @@ def check(st: ErrorInfo):
         raise UhdrError(st.error_code, st.detail.decode("utf-8", "replace") if st.has_detail else "")
 
 
+# uhdr_hip_comm_ops_t: a caller-provided transport for the exchange steps (include/uhdr_hip.h)
+ALL_REDUCE_MIN_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+GATHER_V_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t), C.c_int, C.c_void_p)
+
+
+class CommOps(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("all_reduce_min_f32", ALL_REDUCE_MIN_FN), ("all_gather", ALL_GATHER_FN), ("gather_v", GATHER_V_FN)]
+
+
 LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libuhdr_hip.so")
 
@@ -211,6 +221,10 @@ _SIGS = {
     "uhdr_hip_comm_init": (ErrorInfo, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "uhdr_hip_comm_destroy": (None, [C.c_void_p]),
     "uhdr_hip_comm_size": (C.c_int, [C.c_void_p]),
+    "uhdr_hip_comm_rank": (C.c_int, [C.c_void_p]),
+    "uhdr_hip_comm_init_custom": (ErrorInfo, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "uhdr_hip_comm_all_gather_dev": (ErrorInfo, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "uhdr_hip_comm_gather_dev": (ErrorInfo, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, _P(C.c_size_t), C.c_int]),
     "uhdr_hip_generate_gainmap_striped_dev": (ErrorInfo, [C.c_void_p, _P(RawImage), _P(RawImage), _P(EncodeCfg), _P(GainmapMetadata), _P(RawImage)]),
     "uhdr_hip_profile_enable": (None, [C.c_void_p, C.c_int]),
     "uhdr_hip_profile_read": (C.c_int, [C.c_void_p, C.c_char_p, _P(C.c_double), C.c_int]),

@@ -297,6 +297,269 @@ __global__ __launch_bounds__(256) void huff_gather_kernel(const uint8_t* __restr
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Scans WITHOUT restart markers -- the stream the reference itself writes (jpegencoderhelper.cpp:187-201 never sets
+// cinfo.restart_interval).  Nothing in ENCODING is serial: the DC predictor of a block is the DC value of a block whose
+// coefficients are already in memory, the bit position of a block is a prefix sum of code lengths, and byte stuffing is a
+// prefix sum of 0xFF counts.  The scan is cut into SEGMENTS of `ri` MCUs (not restart intervals: no marker, no alignment,
+// no predictor reset), one wavefront each:
+//   pass A  lengths: the wave walks its blocks once and stores the segment's bit count; lanes [0, blocks_per_mcu) hold the
+//           MCU in FRONT of the segment (DC values only) so that the first MCU's predictors, libjpeg's dummy-block rule
+//           included, come out of the same LDS exchange as all the others
+//   scan    exclusive scan of the segment bit counts (one workgroup) -> every segment's first bit in the stream; the words
+//           that two segments share are zeroed
+//   pass B  emit: same walk, bits go to the LDS buffer at phase (first bit & 31) and from there to the unstuffed stream in
+//           memory: interior words are plain stores, the first / last word of a segment is OR-ed in (its neighbour writes the
+//           rest); the last segment appends flush_bits' one-padding
+//   stuff   0xFF counts per 1 KiB chunk -> scan -> scatter with the stuffed zero bytes (jchuff.c emit_bits)
+// The result equals libjpeg's entropy-coded segment byte for byte (oracle: uo_huffman_encode_scan at restart_interval 0,
+// itself pinned against the reference encoder's files).
+constexpr int kStuffChunk = 1024;  // raw bytes per workgroup of the stuffing passes (256 threads x 4 bytes)
+
+template <int WORDS, int PASS>  // PASS 0: lengths; 1: emit, small LDS buffer; 2: emit, worst-case buffer
+__global__ __launch_bounds__(64) void huff_stream_kernel(const HuffArgs a, const HuffStream t) {
+  __shared__ uint32_t s_tab[2 * (16 + 256)];
+  __shared__ uint32_t s_coef[kSegBlocks * kCoefRow];
+  __shared__ uint32_t s_bits[PASS == 0 ? 1 : kSegBlocks * WORDS + 2];
+  __shared__ int s_dc[kSegBlocks];
+  __shared__ int s_real[kSegBlocks];
+  __shared__ uint8_t s_zz[64];
+  const uint32_t lane = threadIdx.x;
+  for (uint32_t i = lane; i < 2 * (16 + 256); i += 64) s_tab[i] = a.tables[i];
+  s_zz[lane] = a.zigzag[lane];
+  const int bpm = a.blocks_per_mcu;
+  constexpr uint32_t kCapBits = (uint32_t)(kSegBlocks * WORDS) * 32u;
+  for (int seg = (int)blockIdx.x; seg < a.nseg; seg += (int)gridDim.x) {
+    __syncthreads();
+    uint64_t start = 0;
+    uint32_t seg_total = 0;
+    if constexpr (PASS != 0) {  // wave-uniform size-class choice
+      seg_total = t.seg_bits[seg];
+      start = t.seg_start[seg];
+      const bool small = seg_total + 32u <= (uint32_t)(kSegBlocks * kWordsSmall) * 32u;
+      if (seg_total >= kRetry || small != (PASS == 1)) continue;
+    }
+    const int mcu_local = (int)lane / bpm, k_in_mcu = (int)lane - mcu_local * bpm;  // MCU 0 of the wave = the one before the segment
+    const int mcu = seg * a.ri + mcu_local - 1;
+    const bool valid = mcu_local <= a.ri && mcu >= 0 && mcu < a.total_mcus;
+    const bool emits = valid && mcu_local >= 1;
+    int c = 0, kk = k_in_mcu;
+    if (a.ncomp > 1) {
+      while (c < a.ncomp - 1 && kk >= a.hs[c] * a.vs[c]) { kk -= a.hs[c] * a.vs[c]; c++; }
+    }
+    const int hs = a.ncomp > 1 ? a.hs[c] : 1, vs = a.ncomp > 1 ? a.vs[c] : 1;
+    const int yi = kk / hs, xi = kk - yi * hs;
+    const int mcu_c = valid ? mcu : 0;
+    const int my = mcu_c / a.mcus_per_row, mx = mcu_c - my * a.mcus_per_row;
+    const int by = my * vs + yi, bx = mx * hs + xi;
+    const bool real = valid && by < a.bh[c] && bx < a.bw[c];
+    uint32_t* crow = s_coef + lane * kCoefRow;
+    if (real) {
+      const uint4* src = (const uint4*)(a.coef[c] + ((size_t)by * a.bw[c] + bx) * 64);
+      if (emits) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const uint4 q = src[i];
+          crow[4 * i] = q.x; crow[4 * i + 1] = q.y; crow[4 * i + 2] = q.z; crow[4 * i + 3] = q.w;
+        }
+      } else {
+        crow[0] = *(const uint32_t*)src;  // the MCU in front of the segment: its DC values are all that matters
+      }
+    }
+    s_real[lane] = real ? 1 : 0;
+    s_dc[lane] = real ? (int)(int16_t)(crow[0] & 0xffffu) : 0;
+    __syncthreads();
+    int dcv = s_dc[lane];
+    if (valid && !real) {  // dummy block (jctrans.c compress_output): DC of the previous block of the MCU
+      for (int d = 1; d <= 3; d++) {
+        if (k_in_mcu >= d && s_real[lane - d]) { dcv = s_dc[lane - d]; break; }
+      }
+    }
+    __syncthreads();
+    s_dc[lane] = dcv;
+    __syncthreads();
+    int pred = 0;
+    if (emits) {
+      if (kk > 0) pred = s_dc[lane - 1];
+      else pred = s_dc[(int)lane - bpm + hs * vs - 1];  // last block of the component in the previous MCU (0 in front of MCU 0)
+    }
+    const uint32_t* dct = s_tab + (c ? (16 + 256) : 0);
+    const uint32_t* act = dct + 16;
+    const int diff = dcv - pred;
+    uint32_t len = 0, oob = 0;
+    if (emits) walk_block(dct, act, diff, real, crow, s_zz, oob, [&](uint32_t, uint32_t n) { len += n; });
+    const uint32_t incl = wave_incl_scan(len, lane);
+    const uint32_t total_bits = (uint32_t)__shfl((int)incl, 63, 64);
+    if constexpr (PASS == 0) {
+      const bool bad = __builtin_amdgcn_ballot_w64(oob != 0) != 0;
+      if (lane == 0) t.seg_bits[seg] = bad ? kBadCoef : total_bits;
+    } else {
+      const uint32_t phase = (uint32_t)(start & 31u);
+      if (phase + total_bits > kCapBits) continue;  // cannot happen: the size class was chosen from the same count
+      const uint32_t nwords = (phase + total_bits + 31u) >> 5;
+      for (uint32_t i = lane; i < nwords + 1u; i += 64) s_bits[i] = 0u;
+      __syncthreads();
+      if (emits) {
+        const uint32_t off = phase + incl - len;
+        uint64_t acc = 0;
+        uint32_t cnt = off & 31u, w = off >> 5;
+        walk_block(dct, act, diff, real, crow, s_zz, oob, [&](uint32_t code, uint32_t n) {
+          acc = (acc << n) | (uint64_t)code;
+          cnt += n;
+          if (cnt >= 32u) {
+            cnt -= 32u;
+            atomicOr(&s_bits[w++], (uint32_t)(acc >> cnt));
+          }
+        });
+        if (cnt) atomicOr(&s_bits[w], (uint32_t)(acc << (32u - cnt)));
+      }
+      __syncthreads();
+      const uint64_t end_bit = start + total_bits;
+      if (seg == a.nseg - 1 && lane == 0 && (end_bit & 7u)) {  // flush_bits: one-fill the last partial byte of the scan
+        const uint32_t e = phase + total_bits, pad = 8u - (e & 7u), pos = e & 31u;
+        s_bits[e >> 5] |= ((1u << pad) - 1u) << (32u - pos - pad);
+      }
+      __syncthreads();
+      // words -> the unstuffed stream (bytes are MSB first: byte-swap the word)
+      const uint64_t w0 = start >> 5;
+      const uint32_t tail = (phase + total_bits) & 31u;
+      for (uint32_t i = lane; i < nwords; i += 64) {
+        if (w0 + i >= t.raw_words) break;  // capacity: the host reports the size the stream needs
+        const uint32_t v = __builtin_bswap32(s_bits[i]);
+        const bool shared = (i == 0 && phase != 0) || (i == nwords - 1 && tail != 0);
+        if (shared) atomicOr(&t.raw[w0 + i], v);
+        else t.raw[w0 + i] = v;
+      }
+    }
+  }
+}
+
+// seg_start = exclusive scan of seg_bits (bit offsets), seg_start[nseg] = total; meta[0..1] = total bits, meta[2] = status
+// (1: coefficients outside the baseline range); every word that two segments share (and the word behind the last bit) is zeroed
+__global__ __launch_bounds__(1024) void huff_stream_scan_kernel(const uint32_t* __restrict__ seg_bits, int nseg, const HuffStream t) {
+  __shared__ uint64_t s_sum[1024];
+  __shared__ uint32_t s_bad;
+  const int tid = (int)threadIdx.x;
+  if (tid == 0) s_bad = 0;
+  __syncthreads();
+  const int per = (nseg + 1023) / 1024, lo = min(tid * per, nseg), hi = min(lo + per, nseg);
+  uint64_t sum = 0;
+  bool bad = false;
+  for (int i = lo; i < hi; i++) {
+    const uint32_t n = seg_bits[i];
+    bad |= n >= kRetry;
+    sum += n;
+  }
+  if (bad) atomicOr(&s_bad, 1u);
+  s_sum[tid] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const uint64_t y = tid >= d ? s_sum[tid - d] : 0;
+    __syncthreads();
+    s_sum[tid] += y;
+    __syncthreads();
+  }
+  uint64_t run = s_sum[tid] - sum;
+  for (int i = lo; i < hi; i++) {
+    t.seg_start[i] = run;
+    if ((run >> 5) < t.raw_words) t.raw[run >> 5] = 0u;
+    run += seg_bits[i];
+  }
+  if (tid == 1023) {
+    const uint64_t total = s_sum[1023];
+    t.seg_start[nseg] = total;
+    if ((total >> 5) < t.raw_words) t.raw[total >> 5] = 0u;
+    t.meta[0] = (uint32_t)total;
+    t.meta[1] = (uint32_t)(total >> 32);
+  }
+  if (tid == 0) t.meta[2] = s_bad;
+}
+
+// 0xFF bytes per chunk of the unstuffed stream
+__global__ __launch_bounds__(256) void huff_stuff_count_kernel(const HuffStream t, uint32_t* __restrict__ counts) {
+  __shared__ uint32_t s_n;
+  const uint64_t total_bits = (uint64_t)t.meta[0] | ((uint64_t)t.meta[1] << 32);
+  const uint64_t nraw = (total_bits + 7u) >> 3;
+  const uint64_t base = (uint64_t)blockIdx.x * kStuffChunk + threadIdx.x * 4u;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  uint32_t n = 0;
+  if (base < nraw && (base >> 2) < t.raw_words) {
+    const uint32_t wd = t.raw[base >> 2];
+    const uint32_t nv = (uint32_t)min((uint64_t)4, nraw - base);
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) n += (k < nv && ((wd >> (8 * k)) & 0xffu) == 0xffu) ? 1u : 0u;
+  }
+  n = wave_incl_scan(n, threadIdx.x & 63);
+  if ((threadIdx.x & 63) == 63) atomicAdd(&s_n, n);
+  __syncthreads();
+  if (threadIdx.x == 0) counts[blockIdx.x] = s_n;
+}
+
+// exclusive scan of the chunk counts in place (one workgroup); out_bytes = raw bytes + stuffed zeros
+__global__ __launch_bounds__(1024) void huff_stuff_scan_kernel(uint32_t* __restrict__ counts, int nchunks, const HuffStream t, uint64_t* __restrict__ out_bytes) {
+  __shared__ uint64_t s_sum[1024];
+  const int tid = (int)threadIdx.x;
+  const int per = (nchunks + 1023) / 1024, lo = min(tid * per, nchunks), hi = min(lo + per, nchunks);
+  uint64_t sum = 0;
+  for (int i = lo; i < hi; i++) sum += counts[i];
+  s_sum[tid] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const uint64_t y = tid >= d ? s_sum[tid - d] : 0;
+    __syncthreads();
+    s_sum[tid] += y;
+    __syncthreads();
+  }
+  uint64_t run = s_sum[tid] - sum;
+  for (int i = lo; i < hi; i++) {
+    const uint32_t n = counts[i];
+    counts[i] = (uint32_t)run;  // < 2^32: the stream is bounded by the 32-bit capacity checked on the host
+    run += n;
+  }
+  if (tid == 1023) {
+    const uint64_t total_bits = (uint64_t)t.meta[0] | ((uint64_t)t.meta[1] << 32);
+    *out_bytes = ((total_bits + 7u) >> 3) + s_sum[1023];
+  }
+}
+
+__global__ __launch_bounds__(256) void huff_stuff_scatter_kernel(const HuffStream t, const uint32_t* __restrict__ chunk_base, uint8_t* __restrict__ out, uint64_t cap) {
+  __shared__ uint32_t s_wave[4];
+  const uint64_t total_bits = (uint64_t)t.meta[0] | ((uint64_t)t.meta[1] << 32);
+  const uint64_t nraw = (total_bits + 7u) >> 3;
+  const uint64_t base = (uint64_t)blockIdx.x * kStuffChunk + threadIdx.x * 4u;
+  uint32_t wd = 0, nv = 0, nff = 0;
+  if (base < nraw && (base >> 2) < t.raw_words) {
+    wd = t.raw[base >> 2];
+    nv = (uint32_t)min((uint64_t)4, nraw - base);
+  }
+  uint32_t b[4];
+#pragma unroll
+  for (uint32_t k = 0; k < 4; k++) {
+    b[k] = (wd >> (8 * k)) & 0xffu;
+    if (k < nv && b[k] == 0xffu) nff++;
+  }
+  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t incl = wave_incl_scan(nff, lane);
+  if (lane == 63) s_wave[wv] = incl;
+  __syncthreads();
+  uint32_t before = chunk_base[blockIdx.x] + incl - nff;
+  for (uint32_t k = 0; k < wv; k++) before += s_wave[k];
+  uint64_t pos = base + before;
+#pragma unroll
+  for (uint32_t k = 0; k < 4; k++) {
+    if (k < nv) {
+      if (pos < cap) out[pos] = (uint8_t)b[k];
+      pos++;
+      if (b[k] == 0xffu) {
+        if (pos < cap) out[pos] = 0;
+        pos++;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 uint32_t huff_slot_stride() { return (uint32_t)(kSegBlocks * kWordsPerBlock * 4 * 2); }  // every byte could be stuffed
@@ -309,6 +572,27 @@ hipError_t launch_huffman_encode(const HuffArgs& a, uint64_t* offsets, uint32_t*
   hipLaunchKernelGGL((huff_encode_kernel<kWordsPerBlock, true>), dim3(grid < 2048 ? grid : 2048), dim3(64), 0, s, a);
   hipLaunchKernelGGL(huff_offsets_kernel, dim3(1), dim3(1024), 0, s, a.seg_bytes, a.nseg, offsets, status);
   hipLaunchKernelGGL(huff_gather_kernel, dim3(grid), dim3(256), 0, s, a.slots, a.slot_stride, a.seg_bytes, offsets, a.nseg, out, cap);
+  return hipGetLastError();
+}
+
+
+// MCUs per wavefront segment of the marker-less encoder: the wave's first blocks_per_mcu lanes carry the MCU in front
+int huff_stream_segment_mcus(int blocks_per_mcu) { return kSegBlocks / blocks_per_mcu - 1; }
+int huff_stuff_chunks(uint64_t raw_bytes) { return (int)((raw_bytes + kStuffChunk - 1) / kStuffChunk); }
+
+// a.ri = huff_stream_segment_mcus(), a.nseg segments; t.raw holds t.raw_words words; chunk_counts: huff_stuff_chunks(raw capacity)
+// words; out_bytes (device): stuffed size.  Everything is stream ordered; the host reads t.meta / out_bytes afterwards.
+hipError_t launch_huffman_encode_stream(const HuffArgs& a, const HuffStream& t, uint32_t* chunk_counts, uint64_t* out_bytes, uint8_t* out, uint64_t cap,
+                                        hipStream_t s) {
+  const int grid = a.nseg < 16384 ? a.nseg : 16384;
+  const int nchunks = huff_stuff_chunks(t.raw_words * 4u);
+  hipLaunchKernelGGL((huff_stream_kernel<1, 0>), dim3(grid), dim3(64), 0, s, a, t);
+  hipLaunchKernelGGL(huff_stream_scan_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)t.seg_bits, a.nseg, t);
+  hipLaunchKernelGGL((huff_stream_kernel<kWordsSmall, 1>), dim3(grid), dim3(64), 0, s, a, t);
+  hipLaunchKernelGGL((huff_stream_kernel<kWordsPerBlock, 2>), dim3(grid < 2048 ? grid : 2048), dim3(64), 0, s, a, t);
+  hipLaunchKernelGGL(huff_stuff_count_kernel, dim3(nchunks), dim3(256), 0, s, t, chunk_counts);
+  hipLaunchKernelGGL(huff_stuff_scan_kernel, dim3(1), dim3(1024), 0, s, chunk_counts, nchunks, t, out_bytes);
+  hipLaunchKernelGGL(huff_stuff_scatter_kernel, dim3(nchunks), dim3(256), 0, s, t, (const uint32_t*)chunk_counts, out, cap);
   return hipGetLastError();
 }
 

@@ -23,10 +23,16 @@ const RcclApi& rccl() {
     a.GetUniqueId = (decltype(a.GetUniqueId))sym("ncclGetUniqueId");
     a.CommInitRank = (decltype(a.CommInitRank))sym("ncclCommInitRank");
     a.AllReduce = (decltype(a.AllReduce))sym("ncclAllReduce");
+    a.AllGather = (decltype(a.AllGather))sym("ncclAllGather");
+    a.Send = (decltype(a.Send))sym("ncclSend");
+    a.Recv = (decltype(a.Recv))sym("ncclRecv");
+    a.GroupStart = (decltype(a.GroupStart))sym("ncclGroupStart");
+    a.GroupEnd = (decltype(a.GroupEnd))sym("ncclGroupEnd");
     a.CommDestroy = (decltype(a.CommDestroy))sym("ncclCommDestroy");
     a.CommCount = (decltype(a.CommCount))sym("ncclCommCount");
     a.GetErrorString = (decltype(a.GetErrorString))sym("ncclGetErrorString");
-    a.ok = a.GetUniqueId && a.CommInitRank && a.AllReduce && a.CommDestroy && a.CommCount && a.GetErrorString;
+    a.ok = a.GetUniqueId && a.CommInitRank && a.AllReduce && a.AllGather && a.Send && a.Recv && a.GroupStart && a.GroupEnd && a.CommDestroy && a.CommCount &&
+           a.GetErrorString;
     return a;
   }();
   return api;

@@ -108,6 +108,8 @@ struct uhdr_hip_ctx {
   // multi-GPU (row stripes): RCCL communicator of this rank + the exchange buffers of two-pass generation
   void* comm = nullptr;          // ncclComm_t
   int comm_rank = 0, comm_size = 0;
+  bool comm_custom = false;      // uhdr_hip_comm_init_custom: the exchange steps go through comm_ops instead of RCCL
+  uhdr_hip_comm_ops_t comm_ops = {};
   DeviceBuf exchange;            // merged[6] | AffineDev | final mm[6]
   float* h_mm = nullptr;         // pinned: the final {min, max} for the metadata fill
   // profiling
@@ -1054,7 +1056,7 @@ uhdr_error_info_t uhdr_hip_comm_init(uhdr_hip_ctx_t* c, const unsigned char id[U
   if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
   if (!id || nranks < 1 || rank < 0 || rank >= nranks) return err_status(UHDR_CODEC_INVALID_PARAM, "bad communicator arguments (rank %d of %d)", rank, nranks);
   if (!rccl().ok) return err_status(UHDR_CODEC_ERROR, "RCCL is not available in this process (librccl.so.1 could not be loaded)");
-  if (c->comm) return err_status(UHDR_CODEC_INVALID_OPERATION, "this context already has a communicator");
+  if (c->comm || c->comm_custom) return err_status(UHDR_CODEC_INVALID_OPERATION, "this context already has a communicator");
   HIP_TRY(hipSetDevice(c->device));
   ncclUniqueId u;
   memcpy(&u, id, sizeof u);
@@ -1066,71 +1068,212 @@ uhdr_error_info_t uhdr_hip_comm_init(uhdr_hip_ctx_t* c, const unsigned char id[U
   return ok_status();
 }
 
+// The same exchange steps over a caller-provided transport (an MPI / gloo / shared-memory relay, or a test double): the
+// library calls the functions in stream order with device pointers and its own stream; RCCL stays the default.
+uhdr_error_info_t uhdr_hip_comm_init_custom(uhdr_hip_ctx_t* c, const uhdr_hip_comm_ops_t* ops, int rank, int nranks) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  if (!ops || !ops->all_reduce_min_f32 || nranks < 1 || rank < 0 || rank >= nranks)
+    return err_status(UHDR_CODEC_INVALID_PARAM, "bad communicator arguments (rank %d of %d, all_reduce_min_f32 is required)", rank, nranks);
+  if (c->comm || c->comm_custom) return err_status(UHDR_CODEC_INVALID_OPERATION, "this context already has a communicator");
+  c->comm_ops = *ops;
+  c->comm_custom = true;
+  c->comm_rank = rank;
+  c->comm_size = nranks;
+  return ok_status();
+}
+
 void uhdr_hip_comm_destroy(uhdr_hip_ctx_t* c) {
-  if (!c || !c->comm) return;
+  if (!c || (!c->comm && !c->comm_custom)) return;
   (void)hipStreamSynchronize(c->stream);
-  (void)rccl().CommDestroy((ncclComm_t)c->comm);
+  if (c->comm) (void)rccl().CommDestroy((ncclComm_t)c->comm);
   c->comm = nullptr;
+  c->comm_custom = false;
+  memset(&c->comm_ops, 0, sizeof c->comm_ops);
   c->comm_size = 0;
 }
 
 int uhdr_hip_comm_size(uhdr_hip_ctx_t* c) { return c ? c->comm_size : 0; }
+int uhdr_hip_comm_rank(uhdr_hip_ctx_t* c) { return c ? c->comm_rank : 0; }
 
+namespace {
+// THE collective of the hot path: MIN over a handful of floats, in place, on the library's own stream
+uhdr_error_info_t comm_all_reduce_min(uhdr_hip_ctx* c, float* buf, size_t n) {
+  if (c->comm_custom) {
+    const int rc = c->comm_ops.all_reduce_min_f32(c->comm_ops.user, buf, n, (void*)c->stream);
+    if (rc != 0) return err_status(UHDR_CODEC_ERROR, "custom transport: all_reduce_min_f32 failed (%d)", rc);
+  } else if (c->comm) {
+    RCCL_TRY(rccl().AllReduce(buf, buf, n, ncclFloat, ncclMin, (ncclComm_t)c->comm, c->stream));
+  }
+  return ok_status();
+}
+}  // namespace
+
+// Every rank contributes `bytes` bytes; recv (nranks * bytes) holds them in rank order on every rank.  Device pointers,
+// enqueued on the context's stream.  Without a communicator: a copy.
+uhdr_error_info_t uhdr_hip_comm_all_gather_dev(uhdr_hip_ctx_t* c, const void* send, void* recv, size_t bytes) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  if (!send || !recv || bytes == 0) return err_status(UHDR_CODEC_INVALID_PARAM, "all_gather: nullptr buffer or zero size");
+  HIP_TRY(hipSetDevice(c->device));
+  if (c->comm_custom) {
+    if (!c->comm_ops.all_gather) return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "custom transport without all_gather");
+    const int rc = c->comm_ops.all_gather(c->comm_ops.user, send, recv, bytes, (void*)c->stream);
+    if (rc != 0) return err_status(UHDR_CODEC_ERROR, "custom transport: all_gather failed (%d)", rc);
+  } else if (c->comm) {
+    RCCL_TRY(rccl().AllGather(send, recv, bytes, ncclUint8, (ncclComm_t)c->comm, c->stream));
+  } else {
+    if (send != recv) HIP_TRY(hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, c->stream));
+  }
+  return ok_status();
+}
+
+// Stripes of unequal size to one rank -- the merge of the stripes' outputs into one image (the reference's threads write
+// into one buffer, jpegr.cpp:845-864; gain-map stripes and per-stripe entropy-coded streams here): rank r's send_bytes ==
+// counts[r] bytes land at recv + sum(counts[0..r)) on `root`; recv is ignored elsewhere.  counts is a host array of nranks
+// entries, identical on every rank.  RCCL: one group of ncclSend / ncclRecv over xGMI, no host staging.
+uhdr_error_info_t uhdr_hip_comm_gather_dev(uhdr_hip_ctx_t* c, const void* send, size_t send_bytes, void* recv, const size_t* counts, int root) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  const int n = c->comm_size > 0 ? c->comm_size : 1, rank = c->comm_size > 0 ? c->comm_rank : 0;
+  if (!counts || root < 0 || root >= n) return err_status(UHDR_CODEC_INVALID_PARAM, "gather: nullptr counts or root %d outside 0..%d", root, n - 1);
+  if (counts[rank] != send_bytes) return err_status(UHDR_CODEC_INVALID_PARAM, "gather: counts[%d] = %zu but this rank sends %zu bytes", rank, counts[rank], send_bytes);
+  if ((send_bytes && !send) || (rank == root && !recv)) return err_status(UHDR_CODEC_INVALID_PARAM, "gather: nullptr buffer");
+  HIP_TRY(hipSetDevice(c->device));
+  if (c->comm_custom) {
+    if (!c->comm_ops.gather_v) return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "custom transport without gather_v");
+    const int rc = c->comm_ops.gather_v(c->comm_ops.user, send, send_bytes, recv, counts, root, (void*)c->stream);
+    if (rc != 0) return err_status(UHDR_CODEC_ERROR, "custom transport: gather_v failed (%d)", rc);
+    return ok_status();
+  }
+  size_t off = 0;
+  if (!c->comm) {
+    if (send_bytes && send != recv) HIP_TRY(hipMemcpyAsync(recv, send, send_bytes, hipMemcpyDeviceToDevice, c->stream));
+    return ok_status();
+  }
+  RCCL_TRY(rccl().GroupStart());
+  ncclResult_t r1 = ncclSuccess;
+  if (rank == root) {
+    for (int r = 0; r < n && r1 == ncclSuccess; r++) {
+      if (r != root && counts[r]) r1 = rccl().Recv((char*)recv + off, counts[r], ncclUint8, r, (ncclComm_t)c->comm, c->stream);
+      off += counts[r];
+    }
+  } else if (send_bytes) {
+    r1 = rccl().Send(send, send_bytes, ncclUint8, root, (ncclComm_t)c->comm, c->stream);
+  }
+  const ncclResult_t r2 = rccl().GroupEnd();
+  if (r1 != ncclSuccess) return err_status(UHDR_CODEC_ERROR, "RCCL: send / recv failed: %s", rccl().GetErrorString(r1));
+  if (r2 != ncclSuccess) return err_status(UHDR_CODEC_ERROR, "RCCL: ncclGroupEnd failed: %s", rccl().GetErrorString(r2));
+  if (rank == root && send_bytes) {
+    size_t mine = 0;
+    for (int r = 0; r < root; r++) mine += counts[r];
+    if ((char*)recv + mine != (const char*)send) HIP_TRY(hipMemcpyAsync((char*)recv + mine, send, send_bytes, hipMemcpyDeviceToDevice, c->stream));
+  }
+  return ok_status();
+}
+
+// A rank must never leave this function without having taken part in the collective: the other ranks would wait in it
+// forever.  So everything that can fail locally -- argument and geometry checks, allocation, the launch of pass 1 -- is
+// recorded in `local`, the rank then contributes the merge's identity {127, -128} exactly like an empty stripe, runs
+// the exchange and the finalisation, and only then returns its error.
 uhdr_error_info_t uhdr_hip_generate_gainmap_striped_dev(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* sdr, const uhdr_raw_image_t* hdr,
                                                         const uhdr_hip_encode_cfg_t* cfg, uhdr_gainmap_metadata_t* md,
                                                         uhdr_raw_image_t* gm) {
   if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
-  if (!sdr || !hdr || !cfg || !md || !gm) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument");
-  if (cfg->preset == UHDR_USAGE_REALTIME)  // one pass has no exchange step: every stripe is an independent image
+  const bool args_ok = sdr && hdr && cfg && md && gm;
+  if (args_ok && cfg->preset == UHDR_USAGE_REALTIME) {  // one pass has no exchange step: every stripe is an independent image
+    if (cfg->map_dimension_scale_factor < 1) return err_status(UHDR_CODEC_INVALID_PARAM, "gainmap scale factor %d is not positive", cfg->map_dimension_scale_factor);
+    const uint32_t s1 = (uint32_t)cfg->map_dimension_scale_factor;
+    if (sdr->h < s1 || sdr->w < s1) {
+      // a stripe too short for one map row launches nothing (the whole image's map has H / scale rows); its metadata is the
+      // one every other stripe computes (jpegr.cpp:724-737 depends on the transfer function and the gamuts only)
+      if (sdr->w != hdr->w || sdr->h != hdr->h) return err_status(UHDR_CODEC_INVALID_PARAM, "sdr intent resolution %ux%u and hdr intent resolution %ux%u do not match", sdr->w, sdr->h, hdr->w, hdr->h);
+      if (hdr->ct < UHDR_CT_LINEAR || hdr->ct > UHDR_CT_SRGB) return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "No implementation available for converting transfer characteristics %d to linear", hdr->ct);
+      const float white = host::reference_peak_nits(hdr->ct);
+      for (int i = 0; i < 3; i++) {
+        md->max_content_boost[i] = white / 203.0f;
+        md->min_content_boost[i] = 1.0f;
+        md->gamma[i] = cfg->gamma;
+        md->offset_sdr[i] = 0.0f;
+        md->offset_hdr[i] = 0.0f;
+      }
+      md->hdr_capacity_min = 1.0f;
+      md->hdr_capacity_max = cfg->target_disp_peak_nits != -1.0f ? cfg->target_disp_peak_nits / 203.0f : md->max_content_boost[0];
+      md->use_base_cg = sdr->cg == hdr->cg || !(hdr->cg == UHDR_CG_BT_2100 || (hdr->cg == UHDR_CG_DISPLAY_P3 && sdr->cg != UHDR_CG_BT_2100));
+      gm->w = sdr->w / s1;
+      gm->h = 0;
+      return ok_status();
+    }
+    // (with a row and a column of map samples the whole-image small-image rule of jpegr.cpp:696-706 cannot re-scale the stripe)
     return uhdr_hip_generate_gainmap_dev(c, sdr, hdr, cfg, md, gm);
-  if (cfg->map_dimension_scale_factor < 1) return err_status(UHDR_CODEC_INVALID_PARAM, "gainmap scale factor %d is not positive", cfg->map_dimension_scale_factor);
+  }
   HIP_TRY(hipSetDevice(c->device));
-  const uint32_t scale = (uint32_t)cfg->map_dimension_scale_factor;
-  // a stripe shorter than one map row (the last rank of an uneven split) launches nothing and contributes the identity
-  const bool empty = sdr->h < scale || sdr->w < scale;
+  uhdr_error_info_t local = ok_status();
+  auto note = [&](const uhdr_error_info_t& e) { if (local.error_code == UHDR_CODEC_OK && e.error_code != UHDR_CODEC_OK) local = e; };
+  auto note_hip = [&](hipError_t e, const char* what) {
+    if (e != hipSuccess) note(err_status(UHDR_CODEC_ERROR, "%s: %s", what, hipGetErrorString(e)));
+  };
+  if (!args_ok) note(err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument"));
+  if (args_ok && cfg->map_dimension_scale_factor < 1) note(err_status(UHDR_CODEC_INVALID_PARAM, "gainmap scale factor %d is not positive", cfg->map_dimension_scale_factor));
+  // ---- phase 0: validation and allocation, no device work yet --------------------------------------------------------
+  // the exchange buffers first: without them this rank cannot even contribute the identity (then, and only then, the
+  // function returns early -- the caller has to abort the communicator)
   UHDR_TRY(ensure(c->exchange, 256));
+  UHDR_TRY(ensure(c->minmax, (6 + 2048 * 6) * sizeof(float)));
+  if (!c->h_mm) HIP_TRY(hipHostMalloc((void**)&c->h_mm, 6 * sizeof(float), hipHostMallocDefault));
   float* merged = (float*)c->exchange.p;                       // 6 floats
   AffineDev* adev = (AffineDev*)((char*)c->exchange.p + 64);   // 48 bytes
   float* final_mm = (float*)((char*)c->exchange.p + 192);      // 6 floats
-  if (!c->h_mm) HIP_TRY(hipHostMalloc((void**)&c->h_mm, 6 * sizeof(float), hipHostMallocDefault));
+  const uint32_t scale = local.error_code == UHDR_CODEC_OK ? (uint32_t)cfg->map_dimension_scale_factor : 1u;
+  // a stripe shorter than one map row (the last rank of an uneven split) launches nothing and contributes the identity
+  const bool empty = local.error_code == UHDR_CODEC_OK && (sdr->h < scale || sdr->w < scale);
   GenParams p;
   int use_base_cg = 1;
-  float hdr_white_nits;
-  if (!empty) {
-    if (!gm->planes[0]) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for the gainmap stripe");
-    UHDR_TRY(fill_gen_params(c, sdr, hdr, cfg, &p, &use_base_cg, &hdr_white_nits));
-    if (p.scale != scale)
-      return err_status(UHDR_CODEC_INVALID_PARAM, "stripe %ux%u holds no map sample at scale factor %d", sdr->w, sdr->h, cfg->map_dimension_scale_factor);
-    fill_gainmap_desc(hdr, p, gm);
-    if (gm->stride[0] < gm->w) return err_status(UHDR_CODEC_INVALID_PARAM, "gainmap stride (%u) cannot be less than its width (%u)", gm->stride[0], gm->w);
-    const size_t nfl = (size_t)p.map_w * p.map_h * (p.multichannel ? 3 : 1);
-    UHDR_TRY(ensure(c->scratch[7], nfl * sizeof(float)));
-    UHDR_TRY(ensure(c->minmax, (6 + 2048 * 6) * sizeof(float)));
+  float hdr_white_nits = 0;
+  bool run = false;
+  if (local.error_code == UHDR_CODEC_OK && !empty) {
+    if (!gm->planes[0]) note(err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for the gainmap stripe"));
+    if (local.error_code == UHDR_CODEC_OK) note(fill_gen_params(c, sdr, hdr, cfg, &p, &use_base_cg, &hdr_white_nits));
+    if (local.error_code == UHDR_CODEC_OK && p.scale != scale)
+      note(err_status(UHDR_CODEC_INVALID_PARAM, "stripe %ux%u holds no map sample at scale factor %d", sdr->w, sdr->h, cfg->map_dimension_scale_factor));
+    if (local.error_code == UHDR_CODEC_OK) {
+      fill_gainmap_desc(hdr, p, gm);
+      if (gm->stride[0] < gm->w) note(err_status(UHDR_CODEC_INVALID_PARAM, "gainmap stride (%u) cannot be less than its width (%u)", gm->stride[0], gm->w));
+    }
+    if (local.error_code == UHDR_CODEC_OK) {
+      const size_t nfl = (size_t)p.map_w * p.map_h * (p.multichannel ? 3 : 1);
+      note(ensure(c->scratch[7], nfl * sizeof(float)));
+    }
+    run = local.error_code == UHDR_CODEC_OK;
+  } else if (empty) {
+    use_base_cg = !(hdr->cg == UHDR_CG_BT_2100 || (hdr->cg == UHDR_CG_DISPLAY_P3 && sdr->cg != UHDR_CG_BT_2100)) || sdr->cg == hdr->cg;
+    gm->w = sdr->w / scale;
+    gm->h = 0;
+  }
+  // ---- phase 1: pass 1 of this stripe ----------------------------------------------------------------------------------------
+  if (run) {
     p.gain_log2 = (float*)c->scratch[7].p;
     p.minmax = (float*)c->minmax.p;
     ProfScope ps(c, "generate_gainmap");
-    HIP_TRY(launch_generate_gainmap(p, true, c->stream));  // pass 1: float log2 gains + this stripe's {min, max}
-  } else {
-    UHDR_TRY(ensure(c->minmax, (6 + 2048 * 6) * sizeof(float)));
-    use_base_cg = !(hdr->cg == UHDR_CG_BT_2100 || (hdr->cg == UHDR_CG_DISPLAY_P3 && sdr->cg != UHDR_CG_BT_2100)) || sdr->cg == hdr->cg;
+    const hipError_t e = launch_generate_gainmap(p, true, c->stream);  // float log2 gains + this stripe's {min, max}
+    note_hip(e, "generate_gainmap pass 1");
+    if (e != hipSuccess) run = false;
   }
+  // ---- phase 2: the exchange -- every rank gets here ----------------------------------------------------------------------
+  uhdr_error_info_t xchg = ok_status();
   {
     ProfScope ps(c, "stripe_exchange");
-    HIP_TRY(launch_minmax_pack((const float*)c->minmax.p, merged, empty ? 1 : 0, c->stream));
-    if (c->comm)  // THE collective of the path: 24 bytes, latency bound, in place, on the library's own stream
-      RCCL_TRY(rccl().AllReduce(merged, merged, 6, ncclFloat, ncclMin, (ncclComm_t)c->comm, c->stream));
+    note_hip(launch_minmax_pack((const float*)c->minmax.p, merged, run ? 0 : 1, c->stream), "minmax pack");
+    xchg = comm_all_reduce_min(c, merged, 6);
     FinalizeParams f;
     f.merged = merged;
     f.out = adev;
     f.out_mm = final_mm;
-    f.nch = cfg->use_multi_channel_gainmap ? 3 : 1;
-    f.has_max_hint = cfg->max_content_boost != FLT_MAX;
-    f.has_min_hint = cfg->min_content_boost != FLT_MIN;
+    f.nch = (args_ok && cfg->use_multi_channel_gainmap) ? 3 : 1;
+    f.has_max_hint = args_ok && cfg->max_content_boost != FLT_MAX;
+    f.has_min_hint = args_ok && cfg->min_content_boost != FLT_MIN;
     f.log2_max_hint = f.has_max_hint ? log2f(cfg->max_content_boost) : 0.0f;
     f.log2_min_hint = f.has_min_hint ? log2f(cfg->min_content_boost) : 0.0f;
-    HIP_TRY(launch_minmax_finalize(f, c->stream));
+    note_hip(launch_minmax_finalize(f, c->stream), "minmax finalize");
   }
-  if (!empty) {
+  if (run && xchg.error_code == UHDR_CODEC_OK) {
     AffineParams a;
     memset(&a, 0, sizeof a);
     a.dev = adev;
@@ -1140,10 +1283,12 @@ uhdr_error_info_t uhdr_hip_generate_gainmap_striped_dev(uhdr_hip_ctx_t* c, const
     a.nch = cfg->use_multi_channel_gainmap ? 3 : 1;
     a.gamma = cfg->gamma;
     ProfScope ps(c, "generate_gainmap");
-    HIP_TRY(launch_affine_map(a, c->stream));  // pass 2
+    note_hip(launch_affine_map(a, c->stream), "generate_gainmap pass 2");
   }
-  HIP_TRY(hipMemcpyAsync(c->h_mm, final_mm, 6 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));  // the only host synchronisation: the metadata needs the merged range
+  note_hip(hipMemcpyAsync(c->h_mm, final_mm, 6 * sizeof(float), hipMemcpyDeviceToHost, c->stream), "metadata copy");
+  note_hip(hipStreamSynchronize(c->stream), "synchronize");  // the only host synchronisation: the metadata needs the merged range
+  if (xchg.error_code != UHDR_CODEC_OK) return xchg;
+  if (local.error_code != UHDR_CODEC_OK) return local;
   float mm[6];
   memcpy(mm, c->h_mm, sizeof mm);
   // metadata from the already-final range (the clamp / hint / epsilon steps are idempotent on it)
@@ -1871,9 +2016,11 @@ uhdr_error_info_t uhdr_hip_huffman_encode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
   if (!out || !out_bytes) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for the output buffer or size");
   int mpr = 0, mrows = 0, bpm = 0;
   UHDR_TRY(check_scan(sc, true, &mpr, &mrows, &bpm));
-  if (sc->restart_interval < 1 || sc->restart_interval > 65535 || sc->restart_interval * bpm > 64)
-    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "restart_interval must be in 1..%d for %d blocks per MCU (one wavefront encodes one "
-                      "restart interval of at most 64 blocks); received %d", 64 / bpm, bpm, sc->restart_interval);
+  const bool stream = sc->restart_interval == 0;  // no restart markers: the reference's own stream (jpegencoderhelper.cpp:187-201)
+  if (!stream && (sc->restart_interval < 1 || sc->restart_interval > 65535 || sc->restart_interval * bpm > 64))
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "restart_interval must be 0 (no markers) or in 1..%d for %d blocks per MCU (one wavefront "
+                      "encodes one restart interval of at most 64 blocks); received %d", 64 / bpm, bpm, sc->restart_interval);
+  if (stream && 2 * bpm > 64) return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "%d blocks per MCU: outside the HIP path", bpm);
   HIP_TRY(hipSetDevice(c->device));
   if (!c->d_huff) {
     std::vector<uint32_t> blob(host::jpeg_huff_code_tables());
@@ -1893,11 +2040,46 @@ uhdr_error_info_t uhdr_hip_huffman_encode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
   }
   a.mcus_per_row = mpr;
   a.total_mcus = mpr * mrows;
-  a.ri = sc->restart_interval;
+  a.ri = stream ? huff_stream_segment_mcus(bpm) : sc->restart_interval;
   a.blocks_per_mcu = bpm;
   a.nseg = (a.total_mcus + a.ri - 1) / a.ri;
   a.tables = c->d_huff;
   a.zigzag = (const uint8_t*)(c->d_huff + host::kHuffTabWords);
+  if (stream) {
+    // scratch[4]: the unstuffed stream (as many bytes as the caller's buffer holds: stuffing only adds bytes);
+    // scratch[5]: segment starts (nseg + 1) | stuffed size | meta (4 words) | segment bit counts | chunk counts
+    if (out_capacity > 0xFFFFFFF0u) out_capacity = 0xFFFFFFF0u;
+    HuffStream t;
+    memset(&t, 0, sizeof t);
+    t.raw_words = ((uint64_t)out_capacity + 3) / 4 + 1;
+    const uint64_t worst_words = (uint64_t)a.total_mcus * bpm * 52 + 2;  // 1660 bits per block at most (11 + 11 + 63 * 26)
+    if (t.raw_words > worst_words) t.raw_words = worst_words;
+    const int nchunks = huff_stuff_chunks(t.raw_words * 4u);
+    UHDR_TRY(ensure(c->scratch[4], (size_t)t.raw_words * 4));
+    UHDR_TRY(ensure(c->scratch[5], ((size_t)a.nseg + 2) * sizeof(uint64_t) + (4 + (size_t)a.nseg + (size_t)nchunks) * sizeof(uint32_t)));
+    t.raw = (uint32_t*)c->scratch[4].p;
+    t.seg_start = (uint64_t*)c->scratch[5].p;
+    uint64_t* d_total = t.seg_start + (size_t)a.nseg + 1;
+    t.meta = (uint32_t*)(d_total + 1);
+    t.seg_bits = t.meta + 4;
+    uint32_t* chunk_counts = t.seg_bits + a.nseg;
+    {
+      ProfScope ps(c, "huffman_encode");
+      HIP_TRY(launch_huffman_encode_stream(a, t, chunk_counts, d_total, out, (uint64_t)out_capacity, c->stream));
+    }
+    uint64_t total = 0;
+    uint32_t meta[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(&total, d_total, sizeof total, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(meta, t.meta, sizeof meta, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (meta[2]) return err_status(UHDR_CODEC_INVALID_PARAM, "coefficients outside the baseline range (DC difference beyond 11 bits / AC beyond 10 bits)");
+    const uint64_t raw_bytes = ((((uint64_t)meta[1] << 32) | meta[0]) + 7) / 8;
+    if (raw_bytes > t.raw_words * 4u) total = raw_bytes + raw_bytes / 64 + 64;  // the stuffing passes saw a truncated stream: ask for room to spare
+    *out_bytes = (size_t)total;
+    if (total > out_capacity)
+      return err_status(UHDR_CODEC_MEM_ERROR, "entropy-coded data needs %llu bytes, the output buffer holds %zu", (unsigned long long)total, out_capacity);
+    return ok_status();
+  }
   a.slot_stride = huff_slot_stride();
   // scratch: interval slots | interval sizes | offsets (nseg + 1) | status
   UHDR_TRY(ensure(c->scratch[4], (size_t)a.nseg * a.slot_stride));
@@ -2290,8 +2472,8 @@ uhdr_error_info_t uhdr_hip_jpeg_encode_scan(uhdr_hip_ctx_t* c, const uhdr_hip_jp
   const int nc = sc.num_components;
   int mpr = 0, mrows = 0, bpm = 0;
   UHDR_TRY(check_scan(&sc, false, &mpr, &mrows, &bpm));
-  if (sc.restart_interval < 1 || sc.restart_interval * bpm > 64)
-    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "restart_interval must be in 1..%d for %d blocks per MCU, received %d", 64 / bpm, bpm, sc.restart_interval);
+  if (sc.restart_interval < 0 || sc.restart_interval * bpm > 64)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "restart_interval must be 0 (no markers) or in 1..%d for %d blocks per MCU, received %d", 64 / bpm, bpm, sc.restart_interval);
   HIP_TRY(hipSetDevice(c->device));
   size_t coef_bytes = 0;
   for (int i = 0; i < nc; i++) {

@@ -245,6 +245,18 @@ struct HuffArgs {
   uint32_t* seg_bytes;     // [nseg] stuffed bytes per interval (0xFFFFFFFF: coefficients outside the baseline range)
 };
 uint32_t huff_slot_stride();
+// marker-less scans (restart_interval 0): the stream the reference writes
+struct HuffStream {
+  uint32_t* seg_bits;   // [nseg] bits per wavefront segment (0xFFFFFFFF: coefficients outside the baseline range)
+  uint64_t* seg_start;  // [nseg + 1] first bit of every segment; [nseg] = total bits
+  uint32_t* raw;        // the unstuffed stream, raw_words words
+  uint64_t raw_words;
+  uint32_t* meta;       // [0..1] total bits, [2] status
+};
+int huff_stream_segment_mcus(int blocks_per_mcu);
+int huff_stuff_chunks(uint64_t raw_bytes);
+hipError_t launch_huffman_encode_stream(const HuffArgs& a, const HuffStream& t, uint32_t* chunk_counts, uint64_t* out_bytes, uint8_t* out, uint64_t cap,
+                                        hipStream_t s);
 hipError_t launch_huffman_encode(const HuffArgs& a, uint64_t* offsets, uint32_t* status, uint8_t* out, uint64_t cap, hipStream_t s);
 
 // ---- baseline Huffman decoding (huffman_decode.hip) ---------------------------------------------------

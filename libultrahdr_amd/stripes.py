@@ -92,7 +92,10 @@ def generate_gainmap_two_pass_striped(uhdr, sdr_stripe, hdr_stripe, cfg: A.Encod
     gains = torch.empty(max(mw * mh * nch, 1), dtype=torch.float32, device=dev)
     mm = torch.tensor([127.0] * 3 + [-128.0] * 3, dtype=torch.float32, device=dev)  # the identity of the merge
     torch.cuda.current_stream(dev).synchronize()
-    ubc = C.c_int(1)
+    # a rank without a map row never runs pass 1: derive use_base_cg from the gamuts with the rule pass 1 uses
+    # (jpegr.cpp:605-638), so that the metadata is the same on every rank
+    s_cg, h_cg = sdr_stripe.raw.cg, hdr_stripe.raw.cg
+    ubc = C.c_int(1 if (s_cg == h_cg or not (h_cg == A.UHDR_CG_BT_2100 or (h_cg == A.UHDR_CG_DISPLAY_P3 and s_cg != A.UHDR_CG_BT_2100))) else 0)
     lib, h = uhdr.lib, uhdr.ctx.handle
     # a last stripe with fewer rows than the scale factor holds no map row (the whole image's map has H // s rows): it
     # launches nothing and contributes the identity; uhdr_hip_generate_gainmap_pass1_dev refuses such a stripe
@@ -132,6 +135,133 @@ def init_comm(ctx, group=None):
         ident = (C.c_ubyte * 128)(*t.cpu().tolist())
     A.check(lib.uhdr_hip_comm_init(ctx.handle, ident, rank, world))
     return int(lib.uhdr_hip_comm_size(ctx.handle))
+
+
+def init_comm_relay(ctx, group=None):
+    """Give ``ctx`` a HOST-RELAY transport over the torch.distributed group (any backend, gloo included) through
+    uhdr_hip_comm_init_custom: every exchange step copies its device buffer to the host on the library's stream, runs the
+    torch.distributed collective there and copies the result back.  For set-ups where RCCL cannot form the communicator
+    -- several ranks sharing one GPU (tests, the bench's one-GPU dry run of the N > 1 path) -- and as the reference
+    implementation of the transport interface; RCCL over xGMI (init_comm) is the product path.  Returns the world size.
+    The callbacks are kept alive on ``ctx``."""
+    import torch
+    import torch.distributed as dist
+
+    lib = ctx.lib
+    have_pg = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank(group) if have_pg else 0
+    world = dist.get_world_size(group) if have_pg else 1
+
+    def _sync(stream):
+        torch.cuda.synchronize()  # the library's stream is a non-blocking HIP stream of this device: drain everything
+
+    def _view(ptr, nbytes):
+        # a uint8 CUDA tensor over raw device memory (no copy): torch's __cuda_array_interface__ protocol
+        class _Raw:
+            __cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+        return torch.as_tensor(_Raw(), device="cuda")
+
+    def all_reduce_min(_user, buf, n, stream):
+        try:
+            _sync(stream)
+            dev = _view(buf, n * 4).view(torch.float32)
+            t = dev.cpu()
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            dev.copy_(t)
+            _sync(stream)
+            return 0
+        except Exception:  # never let an exception cross the C boundary
+            return 1
+
+    def all_gather(_user, send, recv, nbytes, stream):
+        try:
+            _sync(stream)
+            t = _view(send, nbytes).cpu()
+            parts = [torch.empty_like(t) for _ in range(world)]
+            if world > 1:
+                dist.all_gather(parts, t, group=group)
+            else:
+                parts = [t]
+            _view(recv, nbytes * world).copy_(torch.cat(parts))
+            _sync(stream)
+            return 0
+        except Exception:
+            return 1
+
+    def gather_v(_user, send, send_bytes, recv, counts, root, stream):
+        try:
+            _sync(stream)
+            cnt = [int(counts[i]) for i in range(world)]
+            mx = max(max(cnt), 1)
+            t = torch.zeros(mx, dtype=torch.uint8)
+            if send_bytes:
+                t[:send_bytes] = _view(send, send_bytes).cpu()
+            parts = [torch.empty_like(t) for _ in range(world)]
+            if world > 1:
+                dist.all_gather(parts, t, group=group)  # gloo has no gather-v; the relay is not the performance path
+            else:
+                parts = [t]
+            if rank == root and sum(cnt):
+                _view(recv, sum(cnt)).copy_(torch.cat([p_[:n] for p_, n in zip(parts, cnt)]))
+            _sync(stream)
+            return 0
+        except Exception:
+            return 1
+
+    ops = A.CommOps(None, A.ALL_REDUCE_MIN_FN(all_reduce_min), A.ALL_GATHER_FN(all_gather), A.GATHER_V_FN(gather_v))
+    ctx._comm_ops = ops  # keep the ctypes callbacks alive as long as the context
+    A.check(lib.uhdr_hip_comm_init_custom(ctx.handle, C.byref(ops), rank, world))
+    return int(lib.uhdr_hip_comm_size(ctx.handle))
+
+
+def gather_rows_to_root(ctx, stripe, counts_rows, row_bytes: int, root: int = 0):
+    """Device gather of row stripes of unequal height (uhdr_hip_comm_gather_dev: one group of ncclSend / ncclRecv over
+    xGMI, no host staging): ``stripe`` = this rank's rows as a contiguous uint8 CUDA tensor [rows, row_bytes] (rows may be 0),
+    ``counts_rows`` = rows per rank.  Returns the whole [sum(rows), row_bytes] tensor on ``root``, None elsewhere."""
+    import torch
+
+    lib = ctx.lib
+    world = max(1, int(lib.uhdr_hip_comm_size(ctx.handle)))
+    rank = int(lib.uhdr_hip_comm_rank(ctx.handle)) if world > 1 else 0
+    assert len(counts_rows) == world and stripe.is_contiguous()
+    counts = (C.c_size_t * world)(*[int(r) * row_bytes for r in counts_rows])
+    out = torch.empty((sum(counts_rows), row_bytes), dtype=torch.uint8, device=stripe.device) if rank == root else None
+    with ctx.ordered():
+        A.check(lib.uhdr_hip_comm_gather_dev(ctx.handle, C.c_void_p(stripe.data_ptr() if stripe.numel() else 0), stripe.numel(),
+                                             C.c_void_p(out.data_ptr() if out is not None else 0), counts, root))
+    return out
+
+
+def gather_streams_to_root(ctx, stream_bytes, root: int = 0):
+    """Per-stripe entropy-coded streams (uint8 CUDA tensors of different lengths) to ``root``: the sizes travel in one
+    uhdr_hip_comm_all_gather_dev (8 bytes per rank), the bytes in one uhdr_hip_comm_gather_dev.  Returns the list of the
+    ranks' streams (CUDA tensors) on ``root``, None elsewhere -- stitch_entropy_streams joins them."""
+    import torch
+
+    lib = ctx.lib
+    world = max(1, int(lib.uhdr_hip_comm_size(ctx.handle)))
+    rank = int(lib.uhdr_hip_comm_rank(ctx.handle)) if world > 1 else 0
+    dev = stream_bytes.device
+    n_mine = torch.tensor([stream_bytes.numel()], dtype=torch.int64, device=dev)
+    sizes = torch.empty(world, dtype=torch.int64, device=dev)
+    with ctx.ordered():
+        A.check(lib.uhdr_hip_comm_all_gather_dev(ctx.handle, C.c_void_p(n_mine.data_ptr()), C.c_void_p(sizes.data_ptr()), 8))
+    ctx.synchronize()
+    cnt = [int(v) for v in sizes.cpu().tolist()]
+    counts = (C.c_size_t * world)(*cnt)
+    out = torch.empty(max(sum(cnt), 1), dtype=torch.uint8, device=dev) if rank == root else None
+    with ctx.ordered():
+        A.check(lib.uhdr_hip_comm_gather_dev(ctx.handle, C.c_void_p(stream_bytes.data_ptr() if cnt[rank] else 0), cnt[rank],
+                                             C.c_void_p(out.data_ptr() if out is not None else 0), counts, root))
+    ctx.synchronize()
+    if rank != root:
+        return None
+    parts, off = [], 0
+    for n in cnt:
+        parts.append(out[off: off + n])
+        off += n
+    return parts
 
 
 def generate_gainmap_striped(uhdr, sdr_stripe, hdr_stripe, cfg: A.EncodeCfg, gm_stripe):

@@ -34,10 +34,39 @@ def test_config1_encode_through_the_facade_equals_the_cpu_reference():
         rc, _, err, trace = F.encode_api1(p, y, 1280, 720, "gpu.jpg", True, d)
         assert rc == 0, err
         st = _stages(trace)
-        # API-1: generateGainMap, convertYuv (BT.709 -> the P3/601 encoding of the base JPEG), both JPEG block stages
-        assert "generate_gainmap" in st and "convert_yuv" in st and "fdct_planes" in st, trace
+        # API-1: generateGainMap, convertYuv (BT.709 -> the P3/601 encoding of the base JPEG), and both compressImage calls
+        # (base image, gain map) whole on the device: FDCT + quantize + marker-less Huffman coding -- no libjpeg entropy pass
+        assert "generate_gainmap" in st and "convert_yuv" in st and "jpeg_encode_scan" in st and "fdct_planes" not in st, trace
+        assert len([l for l in trace if "jpeg_encode_scan -> device" in l]) == 2, trace
         a, b = F.read(os.path.join(d, "cpu.jpg")), F.read(os.path.join(d, "gpu.jpg"))
         assert a.size == b.size == 85449
+        assert np.array_equal(a, b), f"{int((a != b).sum())} differing bytes"
+        # the older route (device FDCT, libjpeg's Huffman pass) still gives the same file
+        rc, _, err, trace = F.encode_api1(p, y, 1280, 720, "gpu2.jpg", True, d, env_extra={"UHDR_HIP_SEAM_CPU_ENTROPY": "1"})
+        assert rc == 0, err
+        assert "fdct_planes" in _stages(trace) and "jpeg_encode_scan" not in _stages(trace), trace
+        assert np.array_equal(a, F.read(os.path.join(d, "gpu2.jpg")))
+
+
+def test_4k_encode_through_the_facade_equals_the_cpu_reference_file():
+    """API-1 at 4K, three-channel full-resolution map (the C API default): the device-made file -- marker-less Huffman coding
+    of 194 400 + 388 800 blocks in wavefront segments -- is the CPU reference's file byte for byte."""
+    from libultrahdr_amd import capi as A
+    from libultrahdr_amd import synth
+
+    w, h = 3840, 2160
+    with tempfile.TemporaryDirectory() as d:
+        hdr = synth.make_hdr_p010(w, h, ct=A.UHDR_CT_HLG)
+        sdr = synth.make_sdr_yuv420(w, h)
+        np.concatenate([hdr.valid(0).ravel(), hdr.valid(1).ravel()]).tofile(os.path.join(d, "in.p010"))
+        np.concatenate([sdr.valid(c).ravel() for c in range(3)]).tofile(os.path.join(d, "in.yuv420"))
+        rc, _, err, _ = F.encode_api1("in.p010", "in.yuv420", w, h, "cpu.jpg", False, d)
+        assert rc == 0, err
+        rc, _, err, trace = F.encode_api1("in.p010", "in.yuv420", w, h, "gpu.jpg", True, d)
+        assert rc == 0, err
+        assert len([l for l in trace if "jpeg_encode_scan -> device" in l]) == 2 and "fdct_planes" not in _stages(trace), trace
+        a, b = F.read(os.path.join(d, "cpu.jpg")), F.read(os.path.join(d, "gpu.jpg"))
+        assert a.size == b.size, (a.size, b.size)
         assert np.array_equal(a, b), f"{int((a != b).sum())} differing bytes"
 
 
@@ -113,7 +142,7 @@ def test_api0_encode_through_the_facade():
 
 @pytest.mark.parametrize("multi", [False, True])
 def test_encode_with_device_entropy_coding_decodes_to_the_same_pixels(multi):
-    """UHDR_HIP_SEAM_DEVICE_ENTROPY=1 (opt-in): compressImage runs on the device including the Huffman pass,
+    """UHDR_HIP_SEAM_RESTART_INTERVAL=max (opt-in): the device's Huffman pass with restart markers,
     one restart interval per wavefront.  The file differs from the reference's by the DRI segments and RSTn markers only:
     decoded by the CPU reference (no acceleration) it gives exactly the pixels of the CPU-encoded file, and the accelerated
     decoder -- whose entropy stage then takes the one-lane-per-interval kernel -- agrees."""
@@ -122,7 +151,7 @@ def test_encode_with_device_entropy_coding_decodes_to_the_same_pixels(multi):
         extra = ("-M", 1, "-s", 1) if multi else ()  # 3-channel map at full resolution: the packed-RGB route
         rc, _, err, _ = F.encode_api1(p, y, 1280, 720, "cpu.jpg", False, d, extra=extra)
         assert rc == 0, err
-        rc, _, err, trace = F.encode_api1(p, y, 1280, 720, "dev.jpg", True, d, extra=extra, env_extra={"UHDR_HIP_SEAM_DEVICE_ENTROPY": "1"})
+        rc, _, err, trace = F.encode_api1(p, y, 1280, 720, "dev.jpg", True, d, extra=extra, env_extra={"UHDR_HIP_SEAM_RESTART_INTERVAL": "max"})
         assert rc == 0, err
         lines = [l for l in trace if "jpeg_encode_scan -> device" in l]
         assert len(lines) == 2 and "fdct_planes" not in _stages(trace), trace  # base image and gain map

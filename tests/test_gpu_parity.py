@@ -598,6 +598,75 @@ def test_huffman_encode_equals_oracle_byte_for_byte(uhdr, kind):
         assert got == want, (kind, w, h, ri)
 
 
+@pytest.mark.parametrize("kind", ["sparse", "dense", "worst", "zero"])
+def test_huffman_encode_without_restart_markers_equals_oracle_byte_for_byte(uhdr, kind):
+    """restart_interval 0 -- the stream the reference itself writes (jpegencoderhelper.cpp:187-201): DC prediction chained
+    through the whole scan, no byte alignment between the wavefront segments, flush_bits only at the very end.  The device's
+    three passes (lengths, scan, emit + stuff) equal the sequential restatement of jchuff.c byte for byte: every sampling
+    layout, dummy blocks on both edges, scans of a single segment and of hundreds, the 1660-bit worst-case block."""
+    import torch
+
+    rng = np.random.default_rng(131)
+    cases = [(256, 64, [(2, 2), (1, 1), (1, 1)]), (72, 40, [(2, 2), (1, 1), (1, 1)]), (50, 30, [(2, 2), (1, 1), (1, 1)]), (16, 16, [(2, 2), (1, 1), (1, 1)]),
+             (41, 23, [(1, 1)] * 3), (200, 24, [(1, 1)] * 3), (45, 21, [(2, 1), (1, 1), (1, 1)]), (37, 19, [(1, 1)]), (520, 16, [(1, 1)]), (8, 8, [(1, 1)]),
+             (1000, 520, [(2, 2), (1, 1), (1, 1)]), (1030, 260, [(1, 1)] * 3), (2048, 600, [(1, 1)])]
+    for (w, h, sampling) in cases:
+        if kind == "worst" and w * h > 300000:
+            continue  # the oracle walks these serially
+        coefs = _random_coefs(rng, w, h, sampling, kind)
+        want = L.huffman_encode_port(coefs, w, h, sampling, 0)
+        got = uhdr.huffman_encode([torch.from_numpy(c).to("cuda:0") for c in coefs], w, h, sampling, 0)
+        got = got.cpu().numpy().tobytes()
+        assert len(got) == len(want), (kind, w, h, len(got), len(want))
+        assert got == want, (kind, w, h)
+
+
+def test_huffman_encode_without_restart_markers_reports_the_size_it_needs(uhdr):
+    """An output buffer that is too small: UHDR_CODEC_MEM_ERROR and the required size, nothing written beyond the buffer."""
+    import torch
+
+    rng = np.random.default_rng(5)
+    w, h, sampling = 256, 128, [(2, 2), (1, 1), (1, 1)]
+    coefs = _random_coefs(rng, w, h, sampling, "dense")
+    want = L.huffman_encode_port(coefs, w, h, sampling, 0)
+    dev = [torch.from_numpy(c).to("cuda:0") for c in coefs]
+    out = torch.full((len(want) // 2 + 64,), 0xA5, dtype=torch.uint8, device="cuda:0")
+    guard = out[len(want) // 2:]
+    with pytest.raises(A.UhdrError) as e:
+        uhdr.huffman_encode(dev, w, h, sampling, 0, out=out[: len(want) // 2])
+    assert e.value.code == A.UHDR_CODEC_MEM_ERROR
+    assert bool((guard == 0xA5).all())
+    out = torch.empty(len(want), dtype=torch.uint8, device="cuda:0")
+    got = uhdr.huffman_encode(dev, w, h, sampling, 0, out=out)
+    assert got.cpu().numpy().tobytes() == want
+
+
+def test_huffman_encode_without_restart_markers_writes_the_reference_encoders_scan(uhdr):
+    """Device FDCT + quantize + marker-less Huffman coding of a 4:2:0 frame == the entropy-coded segment of the file the
+    REFERENCE's JpegEncoderHelper writes for the same planes and quality (needs the reference build)."""
+    import torch
+
+    if oracle_kind() != "ref":
+        pytest.skip("needs oracle/_ref")
+    ref = L.ref()
+    for (w, h, q) in [(384, 160, 90), (1280, 720, 95)]:
+        img = synth.make_sdr_yuv420(w, h, align=8, noise=0.1)
+        ql, qc = uhdr.quant_table(q, False), uhdr.quant_table(q, True)
+        coefs = []
+        for c in range(3):
+            pl = np.ascontiguousarray(img.valid(c))
+            coefs.append(uhdr.fdct_quant(torch.from_numpy(pl).to("cuda:0"), pl.shape[1], (pl.shape[1] + 7) // 8, (pl.shape[0] + 7) // 8, ql if c == 0 else qc))
+        scan = uhdr.huffman_encode(coefs, w, h, [(2, 2), (1, 1), (1, 1)], 0).cpu().numpy().tobytes()
+        out = np.zeros(1 << 23, dtype=np.uint8)
+        n = ref.ref_jpeg_compress(C.byref(img.raw), q, out.ctypes.data, out.size)
+        jpeg = out[:n].tobytes()
+        i = 2
+        while jpeg[i + 1] != 0xDA:
+            i += 2 + ((jpeg[i + 2] << 8) | jpeg[i + 3])
+        start = i + 2 + ((jpeg[i + 2] << 8) | jpeg[i + 3])
+        assert scan == jpeg[start:-2], (w, h, q, len(scan), len(jpeg) - start - 2)
+
+
 def test_huffman_encode_of_a_real_frame_decodes_with_libjpeg(uhdr):
     """The full device encode chain of a 4:2:0 frame -- FDCT + quantize, Huffman coding, file wrapper -- read back by the
     real libjpeg (through the reference build, when it travelled with the snapshot): same coefficients, same tables."""
@@ -753,7 +822,7 @@ def test_huffman_encode_error_behaviour(uhdr):
         uhdr.huffman_encode(coefs, w, h, sampling, 11)
     assert e.value.code == A.UHDR_CODEC_UNSUPPORTED_FEATURE
     with pytest.raises(A.UhdrError) as e:
-        uhdr.huffman_encode(coefs, w, h, sampling, 0)
+        uhdr.huffman_encode(coefs, w, h, sampling, -1)
     assert e.value.code == A.UHDR_CODEC_UNSUPPORTED_FEATURE
     with pytest.raises(A.UhdrError) as e:  # block grid of another image
         uhdr.huffman_encode(coefs, w + 64, h, sampling, 4)
@@ -767,6 +836,9 @@ def test_huffman_encode_error_behaviour(uhdr):
         c[..., 1::2] = -32768
     with pytest.raises(A.UhdrError) as e:  # far outside the baseline range: more bits than a block can have
         uhdr.huffman_encode(wild, w, h, sampling, 10)
+    assert e.value.code == A.UHDR_CODEC_INVALID_PARAM
+    with pytest.raises(A.UhdrError) as e:  # the same without restart markers
+        uhdr.huffman_encode(wild, w, h, sampling, 0)
     assert e.value.code == A.UHDR_CODEC_INVALID_PARAM
 
 
