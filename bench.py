@@ -250,6 +250,15 @@ def main():
         },
     }
 
+    # the on-box copy ceiling measured in this very run, and the north-star configuration (ONE 8K frame per
+    # launch -> RGBA_F16) as sustained per-launch times, both inside `roofline` (rank 0; they take a few milliseconds)
+    if rank == 0:
+        try:
+            out["roofline"].update(onbox_ceiling(device))
+            out["roofline"]["north_star_8k"] = north_star_8k(ctx, device)
+        except Exception as e:  # noqa: BLE001
+            out["roofline"]["north_star_8k"] = {"error": f"{type(e).__name__}: {e}"}
+
     # BASELINE configs[3]: the row-striped API-1 two-pass encode, the one place where the path has a collective.  Every
     # rank runs it (also at N = 1: a one-rank communicator), after the headline's timed region.
     if not args.no_config4:
@@ -295,6 +304,81 @@ def main():
         pass
     if world > 1:
         dist.destroy_process_group()
+
+
+def onbox_ceiling(device):
+    """What this box's HBM delivers to a plain device-to-device copy right now (torch's copy kernel, 1 GiB read + 1 GiB written
+    per call, beyond the 256 MiB infinity cache): the practical ceiling the roofline fraction should be read against."""
+    import torch
+
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=device)
+    b = torch.empty(n, dtype=torch.uint8, device=device)
+    a.fill_(7)
+    for _ in range(3):
+        b.copy_(a)
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            b.copy_(a)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        best = ms if best is None or ms < best else best
+    del a, b
+    torch.cuda.empty_cache()
+    gbs = 2 * n / (best / 1e3) / 1e9
+    return {"onbox_copy_GBs": round(gbs, 1), "onbox_copy_frac_of_peak": round(gbs / HBM_PEAK_GBS, 4),
+            "onbox_copy_note": "torch device-to-device copy of 1 GiB (bytes read + bytes written) / time, best of 3 x 10 calls, in this run"}
+
+
+def north_star_8k(ctx, device):
+    """BASELINE north star: applyGainMap of ONE 7680x4320 frame per launch -> RGBA_F16, frames rotating through enough buffer
+    sets that neither inputs nor outputs stay in the 256 MiB infinity cache.  Per map kind: the sustained time per launch
+    (one HIP-event pair around 30 back-to-back launches, median of 5 regions) and the spread of the individual launches."""
+    import torch
+
+    from libultrahdr_amd import capi as A
+    from libultrahdr_amd import synth
+
+    res = {}
+    f16 = A.UHDR_IMG_FMT_64bppRGBAHalfFloat
+    md = synth.default_metadata(use_base_cg=0)
+    w, h = 7680, 4320
+    for kind, nsets in (("C", 3), ("A", 6)):
+        sets = make_frames(nsets, w, h, kind, device, f16, seed0=4242)
+        for s_, g_, _ in sets:
+            s_.raw.cg, g_.raw.cg = A.UHDR_CG_BT_709, A.UHDR_CG_BT_2100
+        argv = [(C.byref(s_.raw), C.byref(g_.raw), C.byref(md), C.byref(d_.raw)) for s_, g_, d_ in sets]
+        k = [0]
+
+        def fn():
+            a = argv[k[0] % nsets]
+            k[0] += 1
+            st = ctx.lib.uhdr_hip_apply_gainmap_dev(ctx.handle, a[0], a[1], a[2], A.UHDR_CT_LINEAR, f16, A.FLT_MAX, a[3], 0, 0)
+            if st.error_code != 0:
+                raise RuntimeError(st.detail)
+
+        ms = time_region(ctx, fn, iters=30, warm=10, reps=5)
+        ctx.profile(True)
+        ctx.profile_read(None, reset=True)
+        for _ in range(60):
+            fn()
+        each = ctx.profile_read_list("apply_gainmap", reset=True)
+        ctx.profile(False)
+        b = algo_bytes_per_px(kind) * w * h
+        st = launch_stats(each)
+        res["map" + kind] = {"map": MAP_DESC[kind], "algorithmic_bytes_per_launch": int(b), "sustained_us": round(ms * 1e3, 2),
+                             "frac": round(b / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4), "GB/s": round(b / (ms / 1e3) / 1e9, 1),
+                             "launch_us": st, "p90_over_p10": round(st["p90"] / st["p10"], 3) if st else None, "buffer_sets": nsets}
+        del sets, argv
+        torch.cuda.empty_cache()
+    res["timing"] = ("sustained_us: one HIP-event pair around 30 back-to-back launches, median of 5 regions; launch_us: per-launch HIP events "
+                     "over 60 more launches")
+    return res
 
 
 def arm_watchdog(seconds, out, rank, section):
@@ -586,25 +670,34 @@ def api_level_section():
             ts.append(time.perf_counter() - t0)
         return r, sorted(ts)[len(ts) // 2]
 
+    def with_env(name, value, fn):
+        os.environ[name] = value
+        try:
+            return fn()
+        finally:
+            del os.environ[name]
+
     FA.encode(hdr, sdr, gpu=True)  # warm-up: context creation, tables
-    jpg, t_enc = med(lambda: FA.encode(hdr, sdr, gpu=True), 3)
+    # default since round 3: the whole compressImage on the device, marker-less Huffman coding included -> the reference's bytes
+    jpg, t_enc = med(lambda: FA.encode(hdr, sdr, gpu=True), 5)
     _, t_dec = med(lambda: FA.decode(jpg, A.UHDR_CT_LINEAR, f16, gpu=True), 5)
-    # opt-in: the Huffman pass of compressImage on the device too, one restart interval per wavefront
-    os.environ["UHDR_HIP_SEAM_DEVICE_ENTROPY"] = "1"
-    try:
-        FA.encode(hdr, sdr, gpu=True)
-        jpg_ri, t_enc_ri = med(lambda: FA.encode(hdr, sdr, gpu=True), 5)
-    finally:
-        del os.environ["UHDR_HIP_SEAM_DEVICE_ENTROPY"]
+    # the round-2 default, kept as an option: device FDCT, libjpeg's Huffman pass on one CPU core (same bytes)
+    jpg_cpu, t_enc_cpu = with_env("UHDR_HIP_SEAM_CPU_ENTROPY", "1", lambda: med(lambda: FA.encode(hdr, sdr, gpu=True), 2))
+    # opt-in: restart intervals, one per wavefront
+    with_env("UHDR_HIP_SEAM_RESTART_INTERVAL", "max", lambda: FA.encode(hdr, sdr, gpu=True))
+    jpg_ri, t_enc_ri = with_env("UHDR_HIP_SEAM_RESTART_INTERVAL", "max", lambda: med(lambda: FA.encode(hdr, sdr, gpu=True), 5))
     _, t_dec_ri = med(lambda: FA.decode(jpg_ri, A.UHDR_CT_LINEAR, f16, gpu=True), 5)
 
     def row(t, **kw):
         return dict({"ms": round(t * 1e3, 1), "Mpx/s": round(w * h / t / 1e6, 1)}, **kw)
 
-    return {"uhdr_encode_api1_4k_hip": row(t_enc, jpeg_bytes=len(jpg), entropy_coding="libjpeg on the CPU (files byte-identical to the reference's)"),
+    return {"uhdr_encode_api1_4k_hip": row(t_enc, jpeg_bytes=len(jpg), same_bytes_as_the_libjpeg_entropy_route=bool(jpg == jpg_cpu),
+                                           entropy_coding="device, no restart markers (the default): FDCT + quantize + Huffman coding in three passes, "
+                                                          "the file is the reference's byte for byte"),
             "uhdr_decode_4k_f16_hip": row(t_dec, entropy_decoding="device (self-synchronising decoder: the file has no restart markers)"),
-            "uhdr_encode_api1_4k_hip_device_entropy": row(t_enc_ri, jpeg_bytes=len(jpg_ri), entropy_coding="device, restart intervals (UHDR_HIP_SEAM_DEVICE_ENTROPY=1): DRI + RSTn markers added, decoded pixels identical"),
-            "uhdr_decode_4k_f16_hip_of_that_file": row(t_dec_ri, entropy_decoding="device (one lane per restart interval)"),
+            "uhdr_encode_api1_4k_hip_libjpeg_entropy": row(t_enc_cpu, jpeg_bytes=len(jpg_cpu), entropy_coding="UHDR_HIP_SEAM_CPU_ENTROPY=1: device FDCT, libjpeg's Huffman pass on one CPU core (the round-2 default)"),
+            "uhdr_encode_api1_4k_hip_restart_intervals": row(t_enc_ri, jpeg_bytes=len(jpg_ri), entropy_coding="UHDR_HIP_SEAM_RESTART_INTERVAL=max: device, one restart interval per wavefront: DRI + RSTn markers added, decoded pixels identical"),
+            "uhdr_decode_4k_f16_hip_of_that_file": row(t_dec_ri, entropy_decoding="device (restart-interval file)"),
             "note": "libuhdr.so facade, uhdr_enable_gpu_acceleration(1): host buffers in and out (pageable), PCIe included; container / "
                     "metadata handling is the reference's CPU code.  The CPU-only numbers of the same calls are in cpu_baseline.stages"}
 

@@ -563,12 +563,35 @@ void build_apply_tables(const uhdr_gainmap_metadata_t& m, float weight, int s, s
       t[ApplyTables::kFacOff + c * 256 + b] = t[ApplyTables::kGainOff + k * kGainN + idx];
     }
   }
+  {  // the chroma products of p3YuvToRgb, one entry per chroma byte: the very operations the kernels used to do per quad
+    const Yuv2Rgb yk = yuv2rgb_coeffs(UHDR_CG_DISPLAY_P3);
+    const float k255 = 1 / 255.0f;
+    for (int b = 0; b < 256; b++) {
+      const float cf = (float)(b - 128) * k255;
+      t[ApplyTables::kChromaVOff + 2 * b] = yk.cr * cf;
+      t[ApplyTables::kChromaVOff + 2 * b + 1] = yk.gcr * cf;
+      t[ApplyTables::kChromaUOff + 2 * b] = yk.gcb * cf;
+      t[ApplyTables::kChromaUOff + 2 * b + 1] = yk.cb * cf;
+    }
+  }
   float* w = t + ApplyTables::kIdwOff;
   const size_t n = (size_t)s * s * 4;
   fill_idw(w, s, 1, 1);          // mWeights
   fill_idw(w + n, s, 0, 1);      // mWeightsNR
   fill_idw(w + 2 * n, s, 1, 0);  // mWeightsNB
   fill_idw(w + 3 * n, s, 0, 0);  // mWeightsC
+  // ---- LDS images of the quad kernels (uhdr_types.h: ApplyTables) --------------------------------------------------------
+  for (int i = 0; i < 2048; i++) t[ApplyTables::kSrgbPadOff + i] = srgb[(size_t)(i < kSrgbN ? i : kSrgbN - 1)];
+  for (int b = 0; b < 256; b++) t[ApplyTables::kTapOff + 2 * b] = t[ApplyTables::kTapOff + 2 * b + 1] = t[ApplyTables::kU8fOff + b];
+  if (s % 2 == 0) {
+    // entry (table, oy, ox / 2) = {w0(ox), w0(ox+1), w1(ox), w1(ox+1), w2(ox), w2(ox+1), w3(ox), w3(ox+1)}
+    float* pw = t + ApplyTables::idw_pair_off(s);
+    const int nidw = ApplyTables::idw_floats(s);
+    for (int i = 0; i < nidw; i++) {  // source index i = ((tbl * s + oy) * s + ox) * 4 + k
+      const int k = i & 3, pos = i >> 2, ox = pos % s, row = pos / s;  // row = tbl * s + oy
+      pw[(row * (s >> 1) + (ox >> 1)) * 8 + k * 2 + (ox & 1)] = w[i];
+    }
+  }
 }
 
 void jpeg_quant_table(int quality, int is_chroma, uint16_t qt[64]) {

@@ -313,8 +313,8 @@ __global__ __launch_bounds__(256) void huff_gather_kernel(const uint8_t* __restr
 //           memory: interior words are plain stores, the first / last word of a segment is OR-ed in (its neighbour writes the
 //           rest); the last segment appends flush_bits' one-padding
 //   stuff   0xFF counts per 1 KiB chunk -> scan -> scatter with the stuffed zero bytes (jchuff.c emit_bits)
-// The result equals libjpeg's entropy-coded segment byte for byte (oracle: uo_huffman_encode_scan at restart_interval 0,
-// itself pinned against the reference encoder's files).
+// The result equals libjpeg's entropy-coded segment byte for byte (tests: against the sequential CPU restatement of jchuff.c
+// at restart_interval 0 and against the files the reference encoder writes).
 constexpr int kStuffChunk = 1024;  // raw bytes per workgroup of the stuffing passes (256 threads x 4 bytes)
 
 template <int WORDS, int PASS>  // PASS 0: lengths; 1: emit, small LDS buffer; 2: emit, worst-case buffer

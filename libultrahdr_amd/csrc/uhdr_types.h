@@ -58,8 +58,20 @@ struct ApplyTables {  // layout of the device table block, in floats
   static constexpr int kGainOff = kSrgbOff + kSrgbN;
   static constexpr int kU8fOff = kGainOff + 3 * kGainN;
   static constexpr int kFacOff = kU8fOff + 256;
-  static constexpr int kIdwOff = kFacOff + 3 * 256;
-  static int floats(int scale) { return kIdwOff + 4 * scale * scale * 4; }
+  // p3YuvToRgb's chroma products per chroma byte (gainmapmath.cpp:177-181; applyGainMap always converts with the P3 / BT.601
+  // coefficients, jpegr.cpp:1723): [v] -> {cr * vf, gcr * vf}, [u] -> {gcb * uf, cb * uf}, vf = (v - 128) * (1 / 255.0f)
+  static constexpr int kChromaVOff = kFacOff + 3 * 256;
+  static constexpr int kChromaUOff = kChromaVOff + 2 * 256;
+  // LDS images for the quad kernels, laid out exactly as the kernels keep them so that the per-workgroup staging is a
+  // handful of 16-byte copies: the sRGB LUT padded to 2048 entries with its last value (apply_gainmap.hip: kSrgbPad), the
+  // byte -> float table with every entry doubled ({x, x}: the packed arithmetic reads register pairs), and -- behind the
+  // reference-order IDW tables -- the same weights re-laid out for pixel pairs
+  static constexpr int kSrgbPadOff = kChromaUOff + 2 * 256;
+  static constexpr int kTapOff = kSrgbPadOff + 2048;
+  static constexpr int kIdwOff = kTapOff + 512;
+  static constexpr int idw_floats(int scale) { return 4 * scale * scale * 4; }
+  static constexpr int idw_pair_off(int scale) { return kIdwOff + idw_floats(scale); }  // even scales only (0 floats otherwise)
+  static constexpr int floats(int scale) { return kIdwOff + idw_floats(scale) + (scale % 2 == 0 ? idw_floats(scale) : 0); }
 };
 
 // batch mode: per-frame plane pointers; geometry / strides / metadata are shared
@@ -89,6 +101,7 @@ struct ApplyParams {
   int oetf_prescaled;          // the table takes the value before the nit scaling (x * 203) / peak (no HDR-side gamut conversion)
   uint32_t y0;              // global row of stripe row 0
   uint32_t tiles_per_wave;  // quad kernel: loop trip count (even), set by the launcher
+  uint32_t touch_ahead;     // quad kernel: 1 = the launch opens with a grid-wide read sweep over the input planes (set by the launcher)
   uint32_t row_groups;      // quad kernel: quad-row step of a wave, set by the launcher
   uint32_t n_frames;        // 0/1: single image; > 1: batch through `frame_tab` (quad kernel only)
   uint32_t scale;           // integer map scale factor (table path) or 0

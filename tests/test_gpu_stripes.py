@@ -99,3 +99,127 @@ def test_striped_entry_point_with_an_rccl_communicator(multichannel, scale):
         assert np.array_equal(gm.to_host().valid(0), gm_w2.to_host().valid(0))
     finally:
         ctx.close()
+
+
+# ---- the C++ exchange with MORE THAN ONE rank -----------------------------------------------------------------------
+# RCCL refuses a communicator with two ranks on one device, and the GPU box has one GPU: the two ranks share it and the
+# library's exchange steps run over the host-relay transport (uhdr_hip_comm_init_custom, gloo underneath).  Everything
+# else is the product path: uhdr_hip_generate_gainmap_striped_dev on each rank's stripe (pass 1 -> all-reduce ->
+# device finalisation -> pass 2), uhdr_hip_comm_gather_dev for the stripes of the map.
+def _free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _two_rank_worker(rank, world, port, case, out_dir):
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    from libultrahdr_amd.images import stripe_view
+    from libultrahdr_amd.ultrahdr import Context
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctx = Context(0)
+    try:
+        assert stripes.init_comm_relay(ctx) == world
+        assert ctx.lib.uhdr_hip_comm_size(ctx.handle) == world and ctx.lib.uhdr_hip_comm_rank(ctx.handle) == rank
+        w, h = case["w"], case["h"]
+        u = UltraHdr(ctx=ctx, preset=A.UHDR_USAGE_BEST_QUALITY, **case["kw"])
+        cfg = u.encode_cfg()
+        s, nch = cfg.map_dimension_scale_factor, (3 if cfg.use_multi_channel_gainmap else 1)
+        sdr = synth.make_sdr_yuv420(w, h, seed=21)
+        hdr = synth.make_hdr_p010(w, h, ct=A.UHDR_CT_HLG, seed=22)
+        if case.get("gamuts"):
+            sdr.raw.cg, hdr.raw.cg = case["gamuts"]
+        sdr, hdr = sdr.to("cuda:0"), hdr.to("cuda:0")
+        row0, n = case["rows"][rank]
+        sv, hv = stripe_view(sdr, row0, n), stripe_view(hdr, row0, n)
+        if case.get("break_rank") == rank:
+            hv.cg = 77  # a descriptor the validation rejects -- on this rank only
+        mw, mh = w // s, n // s
+        gm = Image(A.UHDR_IMG_FMT_24bppRGB888 if nch == 3 else A.UHDR_IMG_FMT_8bppYCbCr400, mw, max(mh, 1), align=64, device="cuda:0")
+        md = A.GainmapMetadata()
+        with ctx.ordered():
+            st = ctx.lib.uhdr_hip_generate_gainmap_striped_dev(ctx.handle, C.byref(sv), C.byref(hv), C.byref(cfg), C.byref(md), C.byref(gm.raw))
+        codes = [None] * world
+        dist.all_gather_object(codes, int(st.error_code))
+        result = {"codes": codes, "md": bytes(md)}
+        if all(c == 0 for c in codes):
+            rows_map = [r[1] // s for r in case["rows"]]
+            mine = gm.plane_tensor(0)[:mh, : mw * nch].contiguous() if mh else torch.empty((0, mw * nch), dtype=torch.uint8, device="cuda:0")
+            whole = stripes.gather_rows_to_root(ctx, mine, rows_map, mw * nch, root=0)
+            # per-stripe "streams" of different lengths through the all-gather of sizes + the gather of bytes
+            fake = torch.arange(100 + 37 * rank, dtype=torch.uint8, device="cuda:0") + rank
+            parts = stripes.gather_streams_to_root(ctx, fake, root=0)
+            if rank == 0:
+                result["map"] = whole.cpu().numpy()
+                result["streams"] = [p_.cpu().numpy() for p_ in parts]
+        mds = [None] * world
+        dist.all_gather_object(mds, result["md"])
+        result["mds"] = mds
+        if rank == 0:
+            import pickle
+
+            with open(os.path.join(out_dir, "result.pkl"), "wb") as f:
+                pickle.dump(result, f)
+    finally:
+        ctx.close()
+        dist.destroy_process_group()
+
+
+_TWO_RANK_CASES = [
+    dict(w=512, h=384, kw=dict(mapDimensionScaleFactor=1, useMultiChannelGainMap=True), rows=[(0, 256), (256, 128)]),
+    dict(w=512, h=388, kw=dict(mapDimensionScaleFactor=4, useMultiChannelGainMap=False), rows=[(0, 192), (192, 196)]),
+    dict(w=512, h=256, kw=dict(mapDimensionScaleFactor=1, useMultiChannelGainMap=True, minContentBoost=1.25, maxContentBoost=3.0), rows=[(0, 64), (64, 192)]),
+    # the last rank holds no map row at all (2 rows at scale 4): it launches nothing and contributes the identity; the
+    # gamut pair makes use_base_cg = 0, which an empty rank has to derive without running pass 1
+    dict(w=256, h=130, kw=dict(mapDimensionScaleFactor=4, useMultiChannelGainMap=False), rows=[(0, 128), (128, 2)],
+         gamuts=(A.UHDR_CG_BT_709, A.UHDR_CG_BT_2100)),
+]
+
+
+@pytest.mark.parametrize("case", _TWO_RANK_CASES)
+def test_striped_entry_point_with_two_ranks(tmp_path, hip_ctx, case):
+    """Two processes, one stripe each, through the C ABI: map and metadata equal the single-device two-pass result bit for
+    bit, on both ranks, for unequal stripes, user hints and a rank without a single map row."""
+    import pickle
+
+    import torch.multiprocessing as mp
+
+    mp.spawn(_two_rank_worker, args=(2, _free_port(), case, str(tmp_path)), nprocs=2, join=True)
+    res = pickle.load(open(tmp_path / "result.pkl", "rb"))
+    assert res["codes"] == [0, 0]
+    w, h = case["w"], case["h"]
+    u = UltraHdr(ctx=hip_ctx, preset=A.UHDR_USAGE_BEST_QUALITY, **case["kw"])
+    sdr = synth.make_sdr_yuv420(w, h, seed=21)
+    hdr = synth.make_hdr_p010(w, h, ct=A.UHDR_CT_HLG, seed=22)
+    if case.get("gamuts"):
+        sdr.raw.cg, hdr.raw.cg = case["gamuts"]
+    md_w, gm_w = u.generateGainMap(sdr.to("cuda:0"), hdr.to("cuda:0"))
+    hip_ctx.synchronize()
+    assert res["mds"][0] == res["mds"][1] == bytes(md_w)
+    assert np.array_equal(res["map"], gm_w.to_host().valid(0))
+    for r, got in enumerate(res["streams"]):
+        assert np.array_equal(got, (np.arange(100 + 37 * r) + r).astype(np.uint8))
+
+
+def test_a_rejected_descriptor_on_one_rank_does_not_hang_the_other(tmp_path):
+    """a rank whose arguments fail validation still takes part in the exchange (with the merge's identity) and
+    returns its error afterwards; the healthy rank completes instead of waiting in the collective forever."""
+    import pickle
+
+    import torch.multiprocessing as mp
+
+    case = dict(w=256, h=128, kw=dict(mapDimensionScaleFactor=1, useMultiChannelGainMap=True), rows=[(0, 64), (64, 64)], break_rank=1)
+    mp.spawn(_two_rank_worker, args=(2, _free_port(), case, str(tmp_path)), nprocs=2, join=True)
+    res = pickle.load(open(tmp_path / "result.pkl", "rb"))
+    assert res["codes"][0] == 0 and res["codes"][1] == A.UHDR_CODEC_UNSUPPORTED_FEATURE
