@@ -76,9 +76,29 @@ def make_frames(n, w, h, map_kind, device, out_fmt, seed0=1234):
     return frames
 
 
+CLOCK_RAMP_S = 0.7
+
+
+def clock_ramp(ctx, fn, seconds=CLOCK_RAMP_S):
+    """Untimed: keep the device busy with fn() for `seconds` before a measurement.  The part idles at 1.4 GHz and needs about
+    half a second of continuous load to reach its 2.4 GHz (profiles/r03_clock_ramp.txt: sysfs clocks every 20 ms); every
+    section of this bench starts after host-side work (frame synthesis, allocation), i.e. from an idle device, and a
+    30-launch region lasts 2.5 ms -- without the ramp it reads 25-35 % slow (8K map A: 77-89 us against 59-61 us once the clock
+    is up, tools/kbench with KB_N = 30 / 3000).  A decode service under load sits at the ramped clock."""
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(20):
+            fn()
+        ctx.synchronize()
+        n += 20
+    return n
+
+
 def time_kernel(ctx, fn, iters=10, warm=3):
     """Average wall time per call of fn() measured with HIP events on the context's stream
     (uhdr_hip_profile_* wraps every launch of the family in an event pair)."""
+    clock_ramp(ctx, fn)
     for _ in range(warm):
         fn()
     ctx.synchronize()
@@ -101,6 +121,7 @@ def time_region(ctx, fn, iters=30, warm=6, reps=3):
     import torch
 
     _, ext = ctx._streams()
+    clock_ramp(ctx, fn)
     for _ in range(warm):
         fn()
     ctx.synchronize()
@@ -181,6 +202,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    ramp_steps = clock_ramp(ctx, step)  # untimed, before the W warm-up steps: see clock_ramp
     for _ in range(args.warmup):
         step()
     barrier()
@@ -230,6 +252,8 @@ def main():
                         + " -> RGBA_F16 linear, applyGainMap kernel, device-resident",
             "frames_per_rank_per_step": args.batch,
             "launch": "one batched launch per step" if args.launch == "batch" else "one launch per frame",
+            "clock_ramp": f"{ramp_steps} untimed steps ({CLOCK_RAMP_S} s) before the {args.warmup} warm-up steps: the part needs ~0.5 s of load to "
+                          "leave its 1.4 GHz idle clock (profiles/r03_clock_ramp.txt)",
             "sharding": f"frames x{world} ranks, no data-path collective",
         },
         "roofline": {
@@ -312,8 +336,8 @@ def onbox_ceiling(device):
     import torch
 
     n = 1 << 30
-    a = torch.empty(n, dtype=torch.uint8, device=device)
-    b = torch.empty(n, dtype=torch.uint8, device=device)
+    a = torch.empty(n // 4, dtype=torch.float32, device=device)  # float32: torch's copy kernel moves 16 bytes per lane
+    b = torch.empty(n // 4, dtype=torch.float32, device=device)
     a.fill_(7)
     for _ in range(3):
         b.copy_(a)
@@ -348,7 +372,7 @@ def north_star_8k(ctx, device):
     f16 = A.UHDR_IMG_FMT_64bppRGBAHalfFloat
     md = synth.default_metadata(use_base_cg=0)
     w, h = 7680, 4320
-    for kind, nsets in (("C", 3), ("A", 6)):
+    for key, kind, nsets in (("mapC", "C", 3), ("mapA", "A", 3), ("mapA_cold_inputs", "A", 6)):
         sets = make_frames(nsets, w, h, kind, device, f16, seed0=4242)
         for s_, g_, _ in sets:
             s_.raw.cg, g_.raw.cg = A.UHDR_CG_BT_709, A.UHDR_CG_BT_2100
@@ -371,13 +395,17 @@ def north_star_8k(ctx, device):
         ctx.profile(False)
         b = algo_bytes_per_px(kind) * w * h
         st = launch_stats(each)
-        res["map" + kind] = {"map": MAP_DESC[kind], "algorithmic_bytes_per_launch": int(b), "sustained_us": round(ms * 1e3, 2),
+        res[key] = {"map": MAP_DESC[kind], "algorithmic_bytes_per_launch": int(b), "sustained_us": round(ms * 1e3, 2),
                              "frac": round(b / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4), "GB/s": round(b / (ms / 1e3) / 1e9, 1),
                              "launch_us": st, "p90_over_p10": round(st["p90"] / st["p10"], 3) if st else None, "buffer_sets": nsets}
         del sets, argv
         torch.cuda.empty_cache()
     res["timing"] = ("sustained_us: one HIP-event pair around 30 back-to-back launches, median of 5 regions; launch_us: per-launch HIP events "
                      "over 60 more launches")
+    res["buffer_sets_note"] = ("three rotating buffer sets (the rotation of rounds 1 and 2): 546 MB of map-C inputs per rotation never stay in the 256 MiB "
+                               "infinity cache, but map A's 51 MB per set (153 MB per rotation) do -- mapA_cold_inputs rotates six sets so that they come "
+                               "from HBM as well; its 17-23 us of extra time are the access pattern's (narrow reads inside a saturated write stream, "
+                               "tools/ubench8, profiles/r03_factor_study.txt), the arithmetic is the same")
     return res
 
 
@@ -414,6 +442,7 @@ def launch_stats(ms_list):
 
 def family_times(ctx, fn, families, iters=5, warm=2):
     """Run fn() `iters` times with the library's per-launch HIP events on; -> {family: us per fn() call}."""
+    clock_ramp(ctx, fn)
     for _ in range(warm):
         fn()
     ctx.synchronize()
@@ -541,10 +570,15 @@ def encode_section(ctx, u, device):
 
 
 def config4_section(ctx, u, device, rank, world, backend):
-    """BASELINE configs[3]: API-1 two-pass encode of a 16384-wide P010 + YCbCr 4:2:0 image sharded by row stripe, 2048
-    rows per rank (at 8 ranks: 16K x 16K).  Per image and rank: pass 1 on the stripe -> ONE ncclAllReduce(min) of
-    {min0..2, -max0..2} over xGMI, issued by the C++ host layer on its own stream -> range finalised on the device ->
-    pass 2.  Weak scaling: the image grows with the rank count.  value = pixels of all ranks / max-over-ranks time."""
+    """BASELINE configs[3]: API-1 encode of a 16384-wide P010 + YCbCr 4:2:0 image sharded by row stripe, 2048 rows per rank
+    (at 8 ranks: 16K x 16K), the WHOLE per-stripe chain on every rank:
+      two-pass 3-channel generateGainMap -- pass 1 -> ONE all-reduce(min) of {min0..2, -max0..2}, issued by the C++ host layer on
+      its own stream (RCCL over xGMI) -> range finalised on the device -> pass 2;
+      convertYuv of the base stripe; FDCT + quantize of the base planes and (fused with rgb -> ycc) of the map stripe;
+      Huffman coding of the stripe's MCU rows (restart intervals: stripes are independent, RST7 joins them);
+      device gather of the two entropy-coded streams to rank 0 (one all-gather of the sizes, one group of send / recv).
+    Weak scaling: the image grows with the rank count.  value = pixels of all ranks / max-over-ranks time.
+    UHDR_BENCH_DIST_BACKEND=gloo (ranks share devices) swaps RCCL for the host-relay transport: a dry run of the N > 1 code path."""
     import torch
     import torch.distributed as dist
 
@@ -554,14 +588,16 @@ def config4_section(ctx, u, device, rank, world, backend):
     from libultrahdr_amd.ultrahdr import UltraHdr
 
     ws, hs, iters = 16384, 2048, 10
-    if world > 1 and backend != "nccl":
-        return {"skipped": "the stripe exchange runs on RCCL: one GPU per rank is required (UHDR_BENCH_DIST_BACKEND=gloo shares devices)"}
-    nranks = stripes.init_comm(ctx)  # RCCL communicator owned by the library context (ncclCommCount)
+    relay = world > 1 and backend != "nccl"
+    nranks = stripes.init_comm_relay(ctx) if relay else stripes.init_comm(ctx)
     enc = UltraHdr(ctx=ctx, mapDimensionScaleFactor=1, useMultiChannelGainMap=True, preset=A.UHDR_USAGE_BEST_QUALITY)
     cfg = enc.encode_cfg()
     sdr_s = synth.make_sdr_yuv420(ws, hs, noise=0.0, seed=1234 + rank).to(device)
     hdr_s = synth.make_hdr_p010(ws, hs, ct=A.UHDR_CT_HLG, noise=0.0, seed=1234 + rank).to(device)
     gm_s = Image(A.UHDR_IMG_FMT_24bppRGB888, ws, hs, align=64, device=device)
+    qy, qc = u.quant_table(95, False), u.quant_table(95, True)
+    s420, s444 = [(2, 2), (1, 1), (1, 1)], [(1, 1)] * 3
+    ri420, ri444 = 10, 21  # the longest restart interval one wavefront holds (64 blocks): 10 MCUs at 4:2:0, 21 at 4:4:4
 
     def sync_all():
         ctx.synchronize()
@@ -569,31 +605,55 @@ def config4_section(ctx, u, device, rank, world, backend):
         if world > 1:
             dist.barrier()
 
+    out_bytes = [0, 0]
+
+    def one_image():
+        md_ = stripes.generate_gainmap_striped(enc, sdr_s, hdr_s, cfg, gm_s)
+        u.convertYuv(sdr_s, A.UHDR_CG_BT_709, A.UHDR_CG_DISPLAY_P3)
+        base = []
+        for c in range(3):
+            rows, stride, wv = sdr_s.layout[c]
+            base.append(u.fdct_quant(sdr_s.plane_tensor(c), stride, wv // 8, rows // 8, qy if c == 0 else qc))
+        mapc = u.fdct_quant_rgb(gm_s, qy, qc)
+        e_base = u.huffman_encode(base, ws, hs, s420, ri420)
+        e_map = u.huffman_encode(list(mapc), ws, hs, s444, ri444)
+        pb = stripes.gather_streams_to_root(ctx, e_base, root=0)
+        pm = stripes.gather_streams_to_root(ctx, e_map, root=0)
+        if pb is not None:
+            out_bytes[0] = sum(int(t.numel()) for t in pb) + 2 * (len(pb) - 1)
+            out_bytes[1] = sum(int(t.numel()) for t in pm) + 2 * (len(pm) - 1)
+        return md_
+
     md = None
-    for _ in range(2):
-        md = stripes.generate_gainmap_striped(enc, sdr_s, hdr_s, cfg, gm_s)
+    for _ in range(12):  # warm-up + clock ramp (count based: every rank takes part in the same collectives)
+        md = one_image()
     sync_all()
     ctx.profile(True)
     ctx.profile_read(None, reset=True)
     t0 = time.perf_counter()
     for _ in range(iters):
-        md = stripes.generate_gainmap_striped(enc, sdr_s, hdr_s, cfg, gm_s)
+        md = one_image()
     sync_all()
     el = time.perf_counter() - t0
-    n_x, ms_x = ctx.profile_read("stripe_exchange", reset=True)
-    n_k, ms_k = ctx.profile_read("generate_gainmap", reset=True)
+    fam = {}
+    for f in ("stripe_exchange", "generate_gainmap", "convert_yuv", "fdct_quant", "huffman_encode"):
+        n_f, ms_f = ctx.profile_read(f, reset=True)
+        fam[f] = round(ms_f / iters * 1e3, 1)
+    ctx.profile_read(None, reset=True)
     ctx.profile(False)
     if world > 1:
         tt = torch.tensor([el], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
     px = ws * hs * world
-    return {"workload": f"configs[3]: API-1 two-pass 3-channel generateGainMap of a {ws}x{hs * world} P010 + YCbCr 4:2:0 image, "
-                        f"{hs} rows per rank, {world} rank(s)",
-            "collective": "one ncclAllReduce(ncclMin, 6 x float32 {min0..2, -max0..2}) per image, issued by libuhdr_hip.so on its own stream "
-                          "between pass 1 and pass 2; range finalised on the device; one host synchronisation per image (metadata)",
+    return {"workload": f"configs[3]: API-1 encode of a {ws}x{hs * world} P010 + YCbCr 4:2:0 image, {hs} rows per rank, {world} rank(s): two-pass "
+                        "3-channel generateGainMap + convertYuv + FDCT / quantize (base 4:2:0, map 4:4:4) + Huffman coding (restart intervals) + gather of the "
+                        "entropy-coded streams to rank 0",
+            "collective": "one all-reduce(min, 6 x float32 {min0..2, -max0..2}) per image, issued by libuhdr_hip.so on its own stream between pass 1 "
+                          "and pass 2; range finalised on the device; stream sizes: one 8-byte all-gather, stream bytes: one send / recv group to rank 0",
+            "transport": "host relay over torch.distributed (dry run: the ranks share devices)" if relay else "RCCL (ncclAllReduce / ncclAllGather / ncclSend + ncclRecv)",
             "ncclCommCount": nranks, "images": iters, "ms_per_image": round(el / iters * 1e3, 3), "Mpx/s": round(px * iters / el / 1e6, 1),
-            "rank0_kernel_us_per_image": round(ms_k / iters * 1e3, 1), "rank0_exchange_us_per_image": round(ms_x / iters * 1e3, 1),
+            "rank0_us_per_image": fam, "jpeg_scan_bytes_base_and_map": out_bytes,
             "max_content_boost": [round(float(v), 6) for v in md.max_content_boost]}
 
 
@@ -622,9 +682,11 @@ def config5_section(ctx, u, device):
         with torch.cuda.graph(graph, stream=stream):
             u.applyGainMapBatch(*args5)
         torch.cuda.synchronize()
-        for _ in range(3):
-            graph.replay()
-        torch.cuda.synchronize()
+        t_r = time.perf_counter()
+        while time.perf_counter() - t_r < CLOCK_RAMP_S:  # see clock_ramp
+            for _ in range(10):
+                graph.replay()
+            torch.cuda.synchronize()
         reps, walls = 20, []
         for _ in range(5):
             t0 = time.perf_counter()

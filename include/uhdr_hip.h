@@ -538,6 +538,21 @@ uhdr_error_info_t uhdr_hip_jpeg_encode_scan(uhdr_hip_ctx_t* ctx, const uhdr_hip_
                                             const unsigned int strides[3], int rgb_channels, uint8_t* out,
                                             size_t out_capacity, size_t* out_bytes);
 
+/* ---- which route did the entropy stage take? ---------------------------------------------------------------------
+ * Counters of the context since its creation.  A scan the device declines (entropy_decode_declined: a marker-less stream so
+ * dense that the parallel decoder does not settle, or Huffman tables outside its two-level form) is returned to the caller
+ * with UHDR_CODEC_UNSUPPORTED_FEATURE -- behind the libuhdr.so facade libjpeg then decodes it on the CPU; this is the place
+ * where that shows without a trace. */
+typedef struct uhdr_hip_stats {
+  unsigned long long entropy_decode_parallel;     /* marker-less scans: self-synchronising parallel decode */
+  unsigned long long entropy_decode_intervals;    /* restart-interval scans: one lane per interval */
+  unsigned long long entropy_decode_single_lane;  /* marker-less scans small enough for one lane */
+  unsigned long long entropy_decode_declined;     /* handed back to the caller (see above) */
+  unsigned long long entropy_encode_stream;       /* marker-less scans written (the reference's bytes) */
+  unsigned long long entropy_encode_intervals;    /* restart-interval scans written */
+} uhdr_hip_stats_t;
+void uhdr_hip_get_stats(uhdr_hip_ctx_t* ctx, uhdr_hip_stats_t* out);
+
 /* ---- timing hook for bench.py ------------------------------------------------------------------
  * HIP events recorded on the context's stream around every kernel launch of the named family
  * ("apply_gainmap", "generate_gainmap", ...) since the last reset; returns the number of launches

@@ -92,6 +92,7 @@ struct uhdr_hip_ctx {
   int tab_next = 0;
   // scratch for host-buffer entry points and two-pass generation
   DeviceBuf scratch[8];
+  uhdr_hip_stats_t stats = {};    // uhdr_hip_get_stats: which route the entropy stage took, call by call
   bool huff_serial_ok = true;  // uhdr_hip_jpeg_decode_scan clears it: a large marker-less scan that the parallel decoder cannot settle goes back to the caller
   DeviceBuf jpg[6];  // uhdr_hip_jpeg_decode_scan: entropy-coded data | coefficient arrays x 3 | decoded planes / pixels
   DeviceBuf minmax;  // 6 + 2048*6 floats
@@ -513,6 +514,12 @@ uhdr_error_info_t uhdr_hip_synchronize(uhdr_hip_ctx_t* c) {
   if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
   HIP_TRY(hipStreamSynchronize(c->stream));
   return ok_status();
+}
+
+void uhdr_hip_get_stats(uhdr_hip_ctx_t* c, uhdr_hip_stats_t* out) {
+  if (!out) return;
+  if (!c) { memset(out, 0, sizeof *out); return; }
+  *out = c->stats;
 }
 
 void uhdr_hip_profile_enable(uhdr_hip_ctx_t* c, int enable) {
@@ -2067,6 +2074,7 @@ uhdr_error_info_t uhdr_hip_huffman_encode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
       ProfScope ps(c, "huffman_encode");
       HIP_TRY(launch_huffman_encode_stream(a, t, chunk_counts, d_total, out, (uint64_t)out_capacity, c->stream));
     }
+    c->stats.entropy_encode_stream++;
     uint64_t total = 0;
     uint32_t meta[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(&total, d_total, sizeof total, hipMemcpyDeviceToHost, c->stream));
@@ -2093,6 +2101,7 @@ uhdr_error_info_t uhdr_hip_huffman_encode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
     ProfScope ps(c, "huffman_encode");
     HIP_TRY(launch_huffman_encode(a, offsets, status, out, (uint64_t)out_capacity, c->stream));
   }
+  c->stats.entropy_encode_intervals++;
   uint64_t total = 0;
   uint32_t bad = 0;
   HIP_TRY(hipMemcpyAsync(&total, offsets + a.nseg, sizeof total, hipMemcpyDeviceToHost, c->stream));
@@ -2290,7 +2299,8 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
   // decode it on a single lane.  The self-synchronising decoder (huffman_decode_sync.hip) parallelises it; should its
   // fixed-point search not settle within the round budget (never seen; pathological streams), the serial kernel runs.
   bool sync_done = false;
-  if (a.nseg == 1 && data_bytes >= 4096 && fast_ok && !getenv("UHDR_HIP_HUFF_SERIAL")) {
+  // (the self-synchronising decoder keeps bit positions in 32 bits: scans of 512 MiB and more take the other routes)
+  if (a.nseg == 1 && data_bytes >= 4096 && data_bytes < ((size_t)1 << 29) && fast_ok && !getenv("UHDR_HIP_HUFF_SERIAL")) {
     // Subsequence size: a power of two >= 256 bits (the lanes' chunks are staged in LDS: 64 x sub_bits / 8 bytes per wave).
     // Attempts, in order: the hypothesis scheme with seven overflow levels at 512 bits (4K q95 photo-like data: 390 us) -- denser
     // streams start at 2048 / 4096 bits --, then at doubled sizes up to 4096 bits, then the rounds at 1024 bits.
@@ -2432,22 +2442,31 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
         if (fl[1] & 2u) return err_status(UHDR_CODEC_INVALID_PARAM, "corrupt entropy-coded data (undefined Huffman code or a run past the end of a block)");
         sync_done = true;
       } else {  // not settled: start over on the serial path
-        if (!c->huff_serial_ok && data_bytes > (256u << 10))
+        if (!c->huff_serial_ok && data_bytes > (256u << 10)) {
+          c->stats.entropy_decode_declined++;
           return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "the parallel entropy decode did not settle in %d rounds; %zu bytes on one lane would take longer than the CPU", max_rounds, data_bytes);
+        }
         for (int i = 0; i < a.ncomp; i++) HIP_TRY(hipMemsetAsync(a.coef[i], 0, zero_bytes[i], c->stream));
       }
     }
   }
-  if (sync_done) return ok_status();
+  if (sync_done) {
+    c->stats.entropy_decode_parallel++;
+    return ok_status();
+  }
   // one interval on one lane: fine for a thumbnail, slower than any CPU for a frame.  A caller that has a CPU decoder to
   // fall back on (uhdr_hip_jpeg_decode_scan behind the facade) gets the stream back instead -- this is also where a file
   // whose Huffman tables do not fit the two-level form (more than kHuffL2Max long-code prefixes) ends up
-  if (a.nseg == 1 && !c->huff_serial_ok && data_bytes > (256u << 10))
+  if (a.nseg == 1 && !c->huff_serial_ok && data_bytes > (256u << 10)) {
+    c->stats.entropy_decode_declined++;
     return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "a %zu-byte scan without restart markers that the parallel decoder does not take (Huffman tables outside its two-level form)", data_bytes);
+  }
   {
     ProfScope ps(c, "huffman_decode");
     HIP_TRY(launch_huffman_decode(a, counts, starts, ends, c->stream));
   }
+  if (a.nseg == 1) c->stats.entropy_decode_single_lane++;
+  else c->stats.entropy_decode_intervals++;
   uint32_t st[2] = {0, 0};
   HIP_TRY(hipMemcpyAsync(st, a.status, sizeof st, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));  // also keeps `tabs` alive until the upload has happened

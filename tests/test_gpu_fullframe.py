@@ -243,3 +243,97 @@ def test_config4_16k_stripe_two_pass_whole_and_split(hip_ctx):
     hip_ctx.synchronize()
     assert np.array_equal(out.to_host().valid(0), gm_gh.valid(0))
     assert md_s.as_dict() == md_g.as_dict()
+
+
+# ---- the north-star configuration itself: one 7680 x 4320 frame, every pixel --------------------------------------------------
+@pytest.mark.parametrize("mapk", ["A", "C"])
+def test_north_star_8k_decode_whole_frame(uhdr, hip_ctx, mapk):
+    """applyGainMap of a whole 8K frame -- the Y400 scale-4 map (row-group and IDW-row arithmetic over 1080 map rows) and the
+    full-resolution RGBA8888 map -- to linear RGBA_F16 and to HLG RGBA1010102, against the real reference, every pixel."""
+    w, h = 7680, 4320
+    sdr = synth.make_sdr_yuv420(w, h, seed=808)
+    gm = synth.make_gainmap(w // 4, h // 4, 1, seed=809) if mapk == "A" else synth.make_gainmap(w, h, 3, alpha=True, seed=809)
+    sdr.raw.cg, gm.raw.cg = A.UHDR_CG_BT_709, A.UHDR_CG_BT_2100  # the bench's colour aspects: the SDR-side 3x3 is active
+    md = synth.default_metadata(use_base_cg=0)
+    dsdr, dgm = sdr.to("cuda:0"), gm.to("cuda:0")
+    for ct in (A.UHDR_CT_LINEAR, A.UHDR_CT_HLG):
+        fmt = F16 if ct == A.UHDR_CT_LINEAR else U32
+        dest = Image(fmt, w, h, align=64, device="cuda:0")
+        uhdr.applyGainMap(dsdr, dgm, md, ct, fmt, A.FLT_MAX, dest)
+        hip_ctx.synchronize()
+        got = dest.to_host().valid(0)
+        want = L.apply_gainmap(oracle_kind(), sdr, gm, md, ct).valid(0)
+        assert got.shape == want.shape
+        bad = int(np.count_nonzero(got != want))
+        assert bad == 0, f"map {mapk} ct {ct}: {bad} of {got.size} pixels differ"
+        del dest, got, want
+
+
+def test_config5_as_benchmarked_every_frame(uhdr, hip_ctx):
+    """BASELINE config 5 exactly as bench.py runs it: 32 4K frames (Y400 map, scale 4) -> HLG RGBA1010102 in ONE batched call,
+    captured into a HIP graph and replayed; every frame of the replay compared with the reference."""
+    import torch
+
+    nb, w, h = 32, 3840, 2160
+    md = synth.default_metadata(use_base_cg=0)
+    hosts, sets = [], []
+    for i in range(nb):
+        sdr = synth.make_sdr_yuv420(w, h, seed=555 + i)
+        gm = synth.make_gainmap(w // 4, h // 4, 1, seed=655 + i)
+        sdr.raw.cg, gm.raw.cg = A.UHDR_CG_BT_709, A.UHDR_CG_BT_2100
+        hosts.append((sdr, gm))
+        sets.append((sdr.to("cuda:0"), gm.to("cuda:0"), Image(U32, w, h, align=64, device="cuda:0")))
+    args5 = ([f[0] for f in sets], [f[1] for f in sets], md, A.UHDR_CT_HLG, U32, A.FLT_MAX, [f[2] for f in sets])
+    uhdr.applyGainMapBatch(*args5)  # tables, occupancy queries
+    hip_ctx.synchronize()
+    for f in sets:
+        f[2].buf.zero_()
+    torch.cuda.synchronize()
+    stream = torch.cuda.Stream()
+    hip_ctx.set_stream(stream.cuda_stream)
+    try:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            uhdr.applyGainMapBatch(*args5)
+        torch.cuda.synchronize()
+        for f in sets:
+            f[2].buf.zero_()  # the capture does not execute: the outputs below are the replay's
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+    finally:
+        hip_ctx.set_stream(None)
+    for i, ((sdr, gm), f) in enumerate(zip(hosts, sets)):
+        want = L.apply_gainmap(oracle_kind(), sdr, gm, md, A.UHDR_CT_HLG).valid(0)
+        got = f[2].to_host().valid(0)
+        assert np.array_equal(got, want), f"frame {i}: {int(np.count_nonzero(got != want))} pixels differ"
+
+
+def test_api1_8k_encode_chain_stage_by_stage(uhdr, hip_ctx):
+    """BASELINE's metric names 4K / 8K API-1: the 8K chain -- two-pass 3-channel generateGainMap at scale 1, convertYuv of the
+    base, FDCT + quantize of its planes -- every stage against the real reference at 7680 x 4320."""
+    w, h = 7680, 4320
+    sdr = synth.make_sdr_yuv420(w, h, seed=31)
+    hdr = synth.make_hdr_p010(w, h, ct=A.UHDR_CT_HLG, seed=32)
+    cfg = A.default_encode_cfg()
+    u = _uhdr_for(hip_ctx, cfg)
+    dsdr, dhdr = sdr.to("cuda:0"), hdr.to("cuda:0")
+    md, gm = u.generateGainMap(dsdr, dhdr)
+    hip_ctx.synchronize()
+    md_w, gm_w = L.generate_gainmap(oracle_kind(), sdr, hdr, cfg)
+    assert_close_codes(gm.to_host().valid(0), gm_w.valid(0), 1e-4, "8K gain map")
+    md_close(md, md_w)
+    conv = dsdr.clone()
+    u.convertYuv(conv, A.UHDR_CG_BT_709, A.UHDR_CG_DISPLAY_P3)
+    hip_ctx.synchronize()
+    want = L.convert_yuv(oracle_kind(), sdr, A.UHDR_CG_BT_709, A.UHDR_CG_DISPLAY_P3)
+    conv_h = conv.to_host()
+    for c in range(3):
+        assert np.array_equal(conv_h.valid(c), want.valid(c)), c
+    if oracle_kind() == "ref":  # libjpeg's own coefficients of the JPEG the reference writes for the converted base image
+        coef_w, qts = _ref_coefficients(want, 95)
+        for c in range(3):
+            bh, bw = coef_w[c].shape[:2]
+            coef = u.fdct_quant(conv.plane_tensor(c), conv.layout[c][1], bw, bh, qts[c])
+            hip_ctx.synchronize()
+            assert np.array_equal(coef.cpu().numpy(), coef_w[c]), c

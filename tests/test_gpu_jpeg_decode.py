@@ -227,9 +227,21 @@ def test_files_with_optimised_huffman_tables(uhdr, subsampling, quality):
     shapes = [(sc.blocks_h[c], sc.blocks_w[c]) for c in range(3)]
     rc, coefs = L.huffman_decode_port(shapes, w, h, sampling, 0, jpeg[hdr.scan_offset: hdr.scan_offset + hdr.scan_bytes], tables=(bits, vals))
     assert rc == 0
+    import ctypes as C_
+
+    def stats():
+        st = A.Stats()
+        uhdr.lib.uhdr_hip_get_stats(uhdr.ctx.handle, C_.byref(st))
+        return st
+
+    before = stats()
     try:
         got = uhdr.jpeg_decode(jpeg)
+        after = stats()
+        assert after.entropy_decode_parallel == before.entropy_decode_parallel + 1 and after.entropy_decode_declined == before.entropy_decode_declined
     except A.UhdrError as err:
+        # the decline is visible through the C ABI (uhdr_hip_get_stats), not only in the facade's trace
+        assert stats().entropy_decode_declined == before.entropy_decode_declined + 1
         # quality 100 on a noisy image: nearly every block runs to coefficient 63 without an EOB, decoders started in different
         # places fall in step only after tens of kilobits, and the parallel schemes give the stream back (the facade then takes
         # libjpeg's decoder).  The plain entry point still decodes it -- on one lane -- to the same coefficients.
