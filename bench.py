@@ -76,7 +76,7 @@ def make_frames(n, w, h, map_kind, device, out_fmt, seed0=1234):
     return frames
 
 
-CLOCK_RAMP_S = 0.7
+CLOCK_RAMP_S = float(os.environ.get("UHDR_BENCH_CLOCK_RAMP_S", "0.7"))  # tools/profile_bench.sh shortens it under the profiler
 
 
 def clock_ramp(ctx, fn, seconds=CLOCK_RAMP_S):
@@ -232,7 +232,7 @@ def main():
     achieved = algo_b / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
 
     kernel_name = "apply_quad_kernel<F16," + {"A": "Y400,scale4>", "B": "RGB888,scale1>", "C": "RGBA8888,scale1>"}[args.map]
-    traffic, traffic_src = measured_traffic(f"{kernel_name}|{frames_per_launch}x{w}x{h}")
+    traffic, traffic_src = measured_traffic(f"{kernel_name}|{frames_per_launch}x{w}x{h}", lib.uhdr_hip_version().decode())
 
     out = {
         "metric": "Mpixels/s decode (applyGainMap, YCbCr420 + gain map -> RGBA_F16 linear), 4K frames resident in HBM",
@@ -276,7 +276,7 @@ def main():
 
     # the on-box copy ceiling measured in this very run, and the north-star configuration (ONE 8K frame per
     # launch -> RGBA_F16) as sustained per-launch times, both inside `roofline` (rank 0; they take a few milliseconds)
-    if rank == 0:
+    if rank == 0 and not os.environ.get("UHDR_BENCH_HEADLINE_ONLY"):  # (tools/profile_bench.sh profiles the headline launch alone)
         try:
             out["roofline"].update(onbox_ceiling(device))
             out["roofline"]["north_star_8k"] = north_star_8k(ctx, device)
@@ -460,10 +460,11 @@ def family_times(ctx, fn, families, iters=5, warm=2):
     return out
 
 
-def measured_traffic(key):
+def measured_traffic(key, library_version):
     """HBM bytes per launch of the dominant kernel as measured with rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE (their own passes, MI355X_MICROARCH.md's gfx950 correction applied) on this exact bench
-    configuration; committed next to the rocprof summaries in profiles/traffic.json."""
+    configuration; committed next to the rocprof summaries in profiles/traffic.json.  The entry names the library version it
+    was taken with: a kernel change bumps uhdr_hip_version() and the stale figure is dropped (null) instead of reported."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
     try:
         with open(path) as f:
@@ -472,6 +473,8 @@ def measured_traffic(key):
         e = None
     if not e:
         return None, None
+    if e.get("library_version") != library_version:
+        return None, f"profiles/traffic.json was measured with {e.get('library_version')!r}, this is {library_version!r}: re-run tools/profile_bench.sh"
     return e["traffic_bytes_per_launch"], e["source"]
 
 

@@ -433,7 +433,7 @@ uhdr_error_info_t get_apply_tables(uhdr_hip_ctx* c, const uhdr_gainmap_metadata_
 #pragma GCC visibility push(default)
 extern "C" {
 
-const char* uhdr_hip_version(void) { return "libuhdr_hip 0.1 (gfx950; reference libultrahdr 2.0.2 hot path)"; }
+const char* uhdr_hip_version(void) { return "libuhdr_hip 0.3 (gfx950; reference libultrahdr 2.0.2 hot path)"; }
 
 int uhdr_hip_device_count(void) {
   int n = 0;
