@@ -310,7 +310,7 @@ __global__ __launch_bounds__(kBlock) void apply_generic_kernel(const ApplyParams
 // ---------------------------------------------------------------------------------------------
 typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int kQuadsPerLane = 2;  // 2x2 quads a lane owns per quad row (128 pixels apart)
-constexpr int kOversub = 2;       // launch_quad: workgroups launched per resident workgroup (UHDR_HIP_OVERSUB overrides)
+constexpr int kOversub = 1;       // launch_quad: workgroups launched per resident workgroup (UHDR_HIP_OVERSUB overrides)
 
 __device__ __forceinline__ f2 splat(float v) { return (f2){v, v}; }
 __device__ __forceinline__ f2 clamp01_2(f2 v) { return (f2){clamp01(v.x), clamp01(v.y)}; }

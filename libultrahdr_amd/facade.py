@@ -88,8 +88,14 @@ def _add_effects(lib, h, effects):
             raise ValueError(e)
 
 
+last_call_seconds = 0.0  # wall time of the last uhdr_encode / uhdr_decode call itself (what bench.py's api_level reports)
+
+
 def encode(hdr, sdr=None, gpu=False, quality=95, preset=A.UHDR_USAGE_BEST_QUALITY, effects=None) -> bytes:
     """uhdr_encode: API-1 (hdr + sdr raw intents) or API-0 (hdr only); host images (libultrahdr_amd.images.Image)."""
+    global last_call_seconds
+    import time
+
     lib = load()
     h = lib.uhdr_create_encoder()
     try:
@@ -101,7 +107,10 @@ def encode(hdr, sdr=None, gpu=False, quality=95, preset=A.UHDR_USAGE_BEST_QUALIT
         _chk(lib.uhdr_enc_set_preset(h, preset))
         if gpu:
             _chk(lib.uhdr_enable_gpu_acceleration(h, 1))
-        _chk(lib.uhdr_encode(h))
+        t0 = time.perf_counter()
+        st = lib.uhdr_encode(h)
+        last_call_seconds = time.perf_counter() - t0
+        _chk(st)
         o = lib.uhdr_get_encoded_stream(h).contents
         return C.string_at(o.data, o.data_sz)
     finally:
@@ -110,6 +119,9 @@ def encode(hdr, sdr=None, gpu=False, quality=95, preset=A.UHDR_USAGE_BEST_QUALIT
 
 def decode(jpeg: bytes, out_ct, out_fmt, gpu=False, effects=None) -> np.ndarray:
     """uhdr_decode -> packed pixels as a (h, w, bytes-per-pixel) uint8 array."""
+    global last_call_seconds
+    import time
+
     lib = load()
     h = lib.uhdr_create_decoder()
     try:
@@ -121,7 +133,10 @@ def decode(jpeg: bytes, out_ct, out_fmt, gpu=False, effects=None) -> np.ndarray:
         _chk(lib.uhdr_dec_set_out_img_format(h, out_fmt))
         if gpu:
             _chk(lib.uhdr_enable_gpu_acceleration(h, 1))
-        _chk(lib.uhdr_decode(h))
+        t0 = time.perf_counter()
+        st = lib.uhdr_decode(h)
+        last_call_seconds = time.perf_counter() - t0
+        _chk(st)
         o = lib.uhdr_get_decoded_image(h).contents
         bpp = 8 if o.fmt == A.UHDR_IMG_FMT_64bppRGBAHalfFloat else 4
         a = np.ctypeslib.as_array(C.cast(o.planes[0], C.POINTER(C.c_uint8)), shape=(o.h, o.stride[0] * bpp))
