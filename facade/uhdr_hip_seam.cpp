@@ -42,6 +42,7 @@ bool handled(const uhdr_error_info_t& s, const char* stage) {
     tl_enter_ms = -1.0;
   }
   if (dev) g_calls.fetch_add(1, std::memory_order_relaxed);
+  else if (cur()) uhdr_hip_resident_begin(cur());  // the reference's CPU code runs next and may write in place: drop the device copies
   return dev;
 }
 }  // namespace
@@ -65,8 +66,16 @@ Scope::Scope(bool enable, void** slot) : mPrev(tl_ctxt), mFailed(false) {
     }
   }
   tl_ctxt = *slot;
+  // one uhdr_encode / uhdr_decode: what the JPEG decode stage leaves in the JpegDecoderHelper buffers stays on the device
+  // for the stage that reads those buffers next (decodeJPEGR -> applyGainMap, jpegr.cpp:1478-1530)
+  uhdr_hip_resident_begin(cur());
+  if (trace_on()) fprintf(stderr, "uhdr_hip_seam: [%8.2f ms] accelerated call begins\n", now_ms());
 }
-Scope::~Scope() { tl_ctxt = mPrev; }
+Scope::~Scope() {
+  if (tl_ctxt && trace_on()) fprintf(stderr, "uhdr_hip_seam: [%8.2f ms] accelerated call ends\n", now_ms());
+  if (tl_ctxt) uhdr_hip_resident_end(cur());
+  tl_ctxt = mPrev;
+}
 
 void release(void* ctxt) {
   if (ctxt) uhdr_hip_destroy(static_cast<uhdr_hip_ctx_t*>(ctxt));

@@ -538,6 +538,16 @@ uhdr_error_info_t uhdr_hip_jpeg_encode_scan(uhdr_hip_ctx_t* ctx, const uhdr_hip_
                                             const unsigned int strides[3], int rgb_channels, uint8_t* out,
                                             size_t out_capacity, size_t* out_bytes);
 
+/* ---- device-resident handoff between host-buffer calls -----------------------------------------------------------
+ * JpegR::decodeJPEGR (jpegr.cpp:1467-1530) decodes the base image and the gain map into JpegDecoderHelper buffers and hands
+ * exactly those buffers to applyGainMap.  Between _begin and _end, uhdr_hip_jpeg_decode_scan keeps what it wrote to the
+ * caller's planes on the device (the two most recent images), and a host-buffer entry point that is handed an input image
+ * with the same plane pointers, strides and format reads that copy instead of uploading the planes again.  The caller
+ * promises not to write to those host buffers in between (call _begin again to drop the copies if it does); outside a
+ * _begin/_end pair nothing is kept.  The facade opens one pair per uhdr_encode / uhdr_decode. */
+void uhdr_hip_resident_begin(uhdr_hip_ctx_t* ctx);
+void uhdr_hip_resident_end(uhdr_hip_ctx_t* ctx);
+
 /* ---- which route did the entropy stage take? ---------------------------------------------------------------------
  * Counters of the context since its creation.  A scan the device declines (entropy_decode_declined: a marker-less stream so
  * dense that the parallel decoder does not settle, or Huffman tables outside its two-level form) is returned to the caller
@@ -550,6 +560,7 @@ typedef struct uhdr_hip_stats {
   unsigned long long entropy_decode_declined;     /* handed back to the caller (see above) */
   unsigned long long entropy_encode_stream;       /* marker-less scans written (the reference's bytes) */
   unsigned long long entropy_encode_intervals;    /* restart-interval scans written */
+  unsigned long long resident_hits;               /* host images found on the device (uhdr_hip_resident_begin) instead of uploaded */
 } uhdr_hip_stats_t;
 void uhdr_hip_get_stats(uhdr_hip_ctx_t* ctx, uhdr_hip_stats_t* out);
 

@@ -160,7 +160,7 @@ GATHER_V_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_
 
 class Stats(C.Structure):
     _fields_ = [(n, C.c_ulonglong) for n in ("entropy_decode_parallel", "entropy_decode_intervals", "entropy_decode_single_lane",
-                                              "entropy_decode_declined", "entropy_encode_stream", "entropy_encode_intervals")]
+                                              "entropy_decode_declined", "entropy_encode_stream", "entropy_encode_intervals", "resident_hits")]
 
 
 class CommOps(C.Structure):
@@ -232,6 +232,8 @@ _SIGS = {
     "uhdr_hip_comm_gather_dev": (ErrorInfo, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, _P(C.c_size_t), C.c_int]),
     "uhdr_hip_generate_gainmap_striped_dev": (ErrorInfo, [C.c_void_p, _P(RawImage), _P(RawImage), _P(EncodeCfg), _P(GainmapMetadata), _P(RawImage)]),
     "uhdr_hip_get_stats": (None, [C.c_void_p, C.c_void_p]),
+    "uhdr_hip_resident_begin": (None, [C.c_void_p]),
+    "uhdr_hip_resident_end": (None, [C.c_void_p]),
     "uhdr_hip_profile_enable": (None, [C.c_void_p, C.c_int]),
     "uhdr_hip_profile_read": (C.c_int, [C.c_void_p, C.c_char_p, _P(C.c_double), C.c_int]),
     "uhdr_hip_profile_read_list": (C.c_int, [C.c_void_p, C.c_char_p, _P(C.c_double), C.c_int, C.c_int]),

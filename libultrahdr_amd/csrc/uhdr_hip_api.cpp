@@ -95,6 +95,20 @@ struct uhdr_hip_ctx {
   uhdr_hip_stats_t stats = {};    // uhdr_hip_get_stats: which route the entropy stage took, call by call
   bool huff_serial_ok = true;  // uhdr_hip_jpeg_decode_scan clears it: a large marker-less scan that the parallel decoder cannot settle goes back to the caller
   DeviceBuf jpg[6];  // uhdr_hip_jpeg_decode_scan: entropy-coded data | coefficient arrays x 3 | decoded planes / pixels
+  // uhdr_hip_resident_begin .. _end: the images uhdr_hip_jpeg_decode_scan wrote to the caller's buffers stay on the device,
+  // keyed by those host pointers, so that the host variant of uhdr_hip_apply_gainmap does not upload them again
+  struct Resident {
+    DeviceBuf buf;
+    bool valid = false;
+    uhdr_img_fmt_t fmt = UHDR_IMG_FMT_UNSPECIFIED;
+    unsigned int w = 0, h = 0;          // samples of plane 0 the device copy holds (whole blocks)
+    const void* host[3] = {};           // the caller's planes ...
+    unsigned int host_stride[3] = {};   // ... and their strides, in samples
+    size_t off[3] = {};
+    unsigned int dev_stride[3] = {};
+  } resident[2];
+  bool resident_on = false;
+  unsigned int resident_next = 0;
   DeviceBuf minmax;  // 6 + 2048*6 floats
   uint32_t* d_huff = nullptr;     // Annex K code tables (kHuffTabWords) followed by the 64-byte zig-zag map
   CoefSrc* d_coef_src = nullptr;  // apply_gainmap_coef descriptors (rotating slots)
@@ -222,6 +236,24 @@ ImageViewMut view_mut_of(const uhdr_raw_image_t* im) {
 // *dev gets device plane pointers.  upload=false only reserves space (outputs).
 uhdr_error_info_t stage_in(uhdr_hip_ctx* c, int slot, const uhdr_raw_image_t* host, uhdr_raw_image_t* dev,
                            bool upload) {
+  if (upload && c->resident_on) {  // an image uhdr_hip_jpeg_decode_scan wrote in this session is still on the device
+    for (auto& r : c->resident) {
+      if (!r.valid || r.fmt != host->fmt || host->w > r.w || host->h > r.h) continue;
+      bool same = true;
+      for (int pl = 0; pl < 3; pl++) {
+        const bool has = plane_bytes(host, pl) != 0;
+        same = same && (has ? host->planes[pl] == r.host[pl] && host->stride[pl] == r.host_stride[pl] : r.host[pl] == nullptr);
+      }
+      if (!same) continue;
+      *dev = *host;
+      for (int pl = 0; pl < 3; pl++) {
+        dev->planes[pl] = r.host[pl] ? (char*)r.buf.p + r.off[pl] : nullptr;
+        dev->stride[pl] = r.dev_stride[pl];
+      }
+      c->stats.resident_hits++;
+      return ok_status();
+    }
+  }
   size_t off[3] = {0, 0, 0}, total = 0;
   for (int pl = 0; pl < 3; pl++) {
     size_t b = plane_bytes(host, pl);
@@ -488,6 +520,7 @@ void uhdr_hip_destroy(uhdr_hip_ctx_t* c) {
   }
   for (auto& b : c->scratch) if (b.p) (void)hipFree(b.p);
   for (auto& b : c->jpg) if (b.p) (void)hipFree(b.p);
+  for (auto& r : c->resident) if (r.buf.p) (void)hipFree(r.buf.p);
   if (c->minmax.p) (void)hipFree(c->minmax.p);
   if (c->d_coef_src) (void)hipFree(c->d_coef_src);
   if (c->d_huff) (void)hipFree(c->d_huff);
@@ -2596,6 +2629,9 @@ uhdr_error_info_t uhdr_hip_jpeg_decode_scan(uhdr_hip_ctx_t* c, const uhdr_hip_jp
   const uhdr_error_info_t hs = uhdr_hip_huffman_decode_dev(c, &sc, &hdr->tables, (const uint8_t*)c->jpg[0].p, nbytes);
   c->huff_serial_ok = true;
   if (hs.error_code != UHDR_CODEC_OK) return hs;
+  uhdr_hip_ctx::Resident* res = c->resident_on ? &c->resident[c->resident_next++ % 2] : nullptr;
+  DeviceBuf* out_buf = res ? &res->buf : &c->jpg[4];
+  if (res) { const DeviceBuf keep = res->buf; *res = uhdr_hip_ctx::Resident(); res->buf = keep; }
   if (out_channels == 0) {
     size_t pitch[3] = {0, 0, 0}, off[3] = {0, 0, 0}, total = 0;
     for (int i = 0; i < nc; i++) {
@@ -2603,14 +2639,26 @@ uhdr_error_info_t uhdr_hip_jpeg_decode_scan(uhdr_hip_ctx_t* c, const uhdr_hip_jp
       off[i] = total;
       total += pitch[i] * (size_t)sc.blocks_h[i] * 8;
     }
-    UHDR_TRY(ensure(c->jpg[4], total));
+    UHDR_TRY(ensure(*out_buf, total));
     for (int i = 0; i < nc; i++) {
       if (!planes[i]) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for destination plane %d", i);
-      uint8_t* d = (uint8_t*)c->jpg[4].p + off[i];
+      uint8_t* d = (uint8_t*)out_buf->p + off[i];
       UHDR_TRY(uhdr_hip_idct_dequant_dev(c, sc.coef[i], sc.blocks_w[i], sc.blocks_h[i], hdr->qtable[i], d, pitch[i]));
       const size_t cols = hstride[i] < (unsigned)sc.blocks_w[i] * 8 ? hstride[i] : (size_t)sc.blocks_w[i] * 8;
       const size_t rows = vstride[i] < (unsigned)sc.blocks_h[i] * 8 ? vstride[i] : (size_t)sc.blocks_h[i] * 8;
       HIP_TRY(hipMemcpy2DAsync(planes[i], hstride[i], d, pitch[i], cols, rows, hipMemcpyDeviceToHost, c->stream));
+      if (res) { res->host[i] = planes[i]; res->host_stride[i] = hstride[i]; res->off[i] = off[i]; res->dev_stride[i] = (unsigned int)pitch[i]; }
+    }
+    if (res) {
+      const int hs0 = nc == 3 ? sc.h_samp[0] : 1, vs0 = nc == 3 ? sc.v_samp[0] : 1;
+      res->fmt = nc == 1 ? UHDR_IMG_FMT_8bppYCbCr400
+                 : hs0 == 2 && vs0 == 2 ? UHDR_IMG_FMT_12bppYCbCr420
+                 : hs0 == 2 && vs0 == 1 ? UHDR_IMG_FMT_16bppYCbCr422
+                 : hs0 == 1 && vs0 == 1 ? UHDR_IMG_FMT_24bppYCbCr444 : UHDR_IMG_FMT_UNSPECIFIED;
+      res->w = hstride[0] < (unsigned)sc.blocks_w[0] * 8 ? hstride[0] : (unsigned)sc.blocks_w[0] * 8;
+      res->h = vstride[0] < (unsigned)sc.blocks_h[0] * 8 ? vstride[0] : (unsigned)sc.blocks_h[0] * 8;
+      bool plain = nc == 1 || (sc.h_samp[1] == 1 && sc.v_samp[1] == 1 && sc.h_samp[2] == 1 && sc.v_samp[2] == 1);
+      res->valid = plain && res->fmt != UHDR_IMG_FMT_UNSPECIFIED;
     }
   } else {
     uhdr_raw_image_t rgb;
@@ -2619,15 +2667,36 @@ uhdr_error_info_t uhdr_hip_jpeg_decode_scan(uhdr_hip_ctx_t* c, const uhdr_hip_jp
     rgb.w = sc.w;
     rgb.h = sc.h;
     const size_t pitch_px = ((size_t)sc.w + 63) & ~(size_t)63;
-    UHDR_TRY(ensure(c->jpg[4], pitch_px * (size_t)out_channels * sc.h));
-    rgb.planes[0] = c->jpg[4].p;
+    UHDR_TRY(ensure(*out_buf, pitch_px * (size_t)out_channels * sc.h));
+    rgb.planes[0] = out_buf->p;
     rgb.stride[0] = (unsigned int)pitch_px;
     UHDR_TRY(uhdr_hip_idct_dequant_rgb_dev(c, sc.coef[0], sc.coef[1], sc.coef[2], sc.blocks_w[0], sc.blocks_h[0], hdr->qtable[0], hdr->qtable[1], variant, &rgb));
-    HIP_TRY(hipMemcpy2DAsync(planes[0], (size_t)hstride[0] * out_channels, c->jpg[4].p, pitch_px * out_channels, (size_t)sc.w * out_channels, sc.h,
+    HIP_TRY(hipMemcpy2DAsync(planes[0], (size_t)hstride[0] * out_channels, out_buf->p, pitch_px * out_channels, (size_t)sc.w * out_channels, sc.h,
                              hipMemcpyDeviceToHost, c->stream));
+    if (res) {
+      res->fmt = rgb.fmt; res->w = sc.w; res->h = sc.h;
+      res->host[0] = planes[0]; res->host_stride[0] = hstride[0]; res->off[0] = 0; res->dev_stride[0] = (unsigned int)pitch_px;
+      res->valid = true;
+    }
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
   return ok_status();
+}
+
+// Device-resident handoff between the decode and the apply stage of one uhdr_decode (JpegR::decodeJPEGR, jpegr.cpp:1467-
+// 1530): the planes uhdr_hip_jpeg_decode_scan wrote into the caller's buffers stay on the device until _end, and the host
+// variant of uhdr_hip_apply_gainmap, handed exactly those buffers (same plane pointers, strides and format), reads the
+// device copy instead of uploading 45 MB (4K base + scale-1 RGBA map) it has just downloaded.  The caller promises not
+// to write to those host buffers in between -- decodeJPEGR's are private to its JpegDecoderHelper locals.
+void uhdr_hip_resident_begin(uhdr_hip_ctx_t* c) {
+  if (!c) return;
+  c->resident_on = true;
+  for (auto& r : c->resident) r.valid = false;
+}
+void uhdr_hip_resident_end(uhdr_hip_ctx_t* c) {
+  if (!c) return;
+  c->resident_on = false;
+  for (auto& r : c->resident) r.valid = false;
 }
 
 // Host helper: a complete baseline JFIF file around entropy-coded data (marker order of jcmarker.c: SOI, APP0, DQT,

@@ -372,21 +372,22 @@ class UltraHdr:
                                     [(sc.h_samp[c], sc.v_samp[c]) for c in range(nc)], sc.restart_interval, tables=(bits, vals))
         return hdr, coefs
 
-    def jpeg_decode(self, jpeg: bytes, rgb_channels: int = 0, libjpeg_variant: int = 0):
+    def jpeg_decode(self, jpeg: bytes, rgb_channels: int = 0, libjpeg_variant: int = 0, outs=None):
         """JpegDecoderHelper::decompressImage for a baseline JPEG file, entirely on the device (entropy decode, dequantization,
         IDCT, and ycc -> rgb when rgb_channels is 3 / 4): host bytes in, numpy arrays out.  rgb_channels 0: the list of
         component planes [blocks_h*8, blocks_w*8] uint8 (block padding included, as libjpeg's raw-data mode);
-        3 / 4: one [h, w, channels] array (4:4:4 files only)."""
+        3 / 4: one [h, w, channels] array (4:4:4 files only).  outs: arrays of those shapes to decode into (a list in both
+        modes) instead of fresh ones."""
         hdr = self.jpeg_parse(jpeg)
         sc = hdr.scan
         nc = sc.num_components
         buf = np.frombuffer(jpeg, dtype=np.uint8)
         if rgb_channels:
-            outs = [np.empty((sc.h, sc.w, rgb_channels), dtype=np.uint8)]
+            outs = outs or [np.empty((sc.h, sc.w, rgb_channels), dtype=np.uint8)]
             hs = [sc.w, 0, 0]
             vs = [sc.h, 0, 0]
         else:
-            outs = [np.empty((sc.blocks_h[c] * 8, sc.blocks_w[c] * 8), dtype=np.uint8) for c in range(nc)]
+            outs = outs or [np.empty((sc.blocks_h[c] * 8, sc.blocks_w[c] * 8), dtype=np.uint8) for c in range(nc)]
             hs = [sc.blocks_w[c] * 8 if c < nc else 0 for c in range(3)]
             vs = [sc.blocks_h[c] * 8 if c < nc else 0 for c in range(3)]
         ptrs = (C.c_void_p * 3)(*[o.ctypes.data for o in outs] + [None] * (3 - len(outs)))

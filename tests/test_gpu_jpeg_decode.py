@@ -255,6 +255,71 @@ def test_files_with_optimised_huffman_tables(uhdr, subsampling, quality):
         assert np.array_equal(got[c], L.idct_dequant_port(coefs[c], qt)), c
 
 
+def test_decoded_images_stay_on_the_device_for_the_apply_stage(uhdr):
+    """uhdr_hip_resident_begin / _end: decodeJPEGR's handoff (jpegr.cpp:1478-1530).  The host variant of applyGainMap, handed the
+    very buffers uhdr_hip_jpeg_decode_scan filled, reads the device copies (stats.resident_hits) and produces the bytes of the
+    upload path; outside a session, or after the session is reopened, the host planes are what counts."""
+    from libultrahdr_amd.images import Image
+
+    w, h = 640, 352
+    rng = np.random.default_rng(4242)
+    _, _, base_jpeg = _file(rng, w, h, S420, 0, kind="dense")
+    _, _, map_jpeg = _file(rng, w, h, S444, 0, kind="dense")
+    base = [np.zeros((h, w), np.uint8), np.zeros((h // 2, w // 2), np.uint8), np.zeros((h // 2, w // 2), np.uint8)]
+    gmap = [np.zeros((h, w, 4), np.uint8)]
+
+    def raw(fmt, planes, strides, cg):
+        r = A.RawImage()
+        r.fmt, r.cg, r.ct, r.range, r.w, r.h = fmt, cg, A.UHDR_CT_SRGB, A.UHDR_CR_FULL_RANGE, w, h
+        for i, p in enumerate(planes):
+            r.planes[i], r.stride[i] = p.ctypes.data, strides[i]
+
+        class _Host:
+            device = None
+        o = _Host()
+        o.raw = r
+        return o
+
+    sdr_img = raw(A.UHDR_IMG_FMT_12bppYCbCr420, base, [w, w // 2, w // 2], A.UHDR_CG_DISPLAY_P3)
+    gm_img = raw(A.UHDR_IMG_FMT_32bppRGBA8888, gmap, [w], A.UHDR_CG_UNSPECIFIED)
+    md = synth.default_metadata()
+
+    def stats():
+        st = A.Stats()
+        uhdr.lib.uhdr_hip_get_stats(uhdr.ctx.handle, C.byref(st))
+        return st.resident_hits
+
+    def apply():
+        dest = Image(A.UHDR_IMG_FMT_64bppRGBAHalfFloat, w, h)
+        uhdr.applyGainMap(sdr_img, gm_img, md, A.UHDR_CT_LINEAR, A.UHDR_IMG_FMT_64bppRGBAHalfFloat, 4.0, dest)
+        return dest.buf.copy()
+
+    def decode_both():
+        uhdr.jpeg_decode(base_jpeg, outs=base)
+        uhdr.jpeg_decode(map_jpeg, 4, outs=gmap)
+
+    h0 = stats()
+    decode_both()
+    want = apply()  # no session: both images uploaded
+    assert stats() == h0 and want.any()
+    uhdr.lib.uhdr_hip_resident_begin(uhdr.ctx.handle)
+    try:
+        decode_both()
+        got = apply()
+        assert stats() == h0 + 2, "base and gain map were found on the device"
+        assert np.array_equal(got, want)
+        # the session is reopened (what the facade does when a stage falls back to the reference's CPU code, which may write in
+        # place): the copies are dropped, the host planes count again
+        uhdr.lib.uhdr_hip_resident_begin(uhdr.ctx.handle)
+        base[0][:] = 255 - base[0]
+        changed = apply()
+        assert stats() == h0 + 2 and not np.array_equal(changed, want)
+        base[0][:] = 255 - base[0]
+    finally:
+        uhdr.lib.uhdr_hip_resident_end(uhdr.ctx.handle)
+    assert np.array_equal(apply(), want) and stats() == h0 + 2  # after _end nothing is kept
+
+
 def test_progressive_files_are_not_for_this_path(uhdr):
     PILImage = pytest.importorskip("PIL.Image")
     import io
