@@ -263,8 +263,8 @@ def test_decoded_images_stay_on_the_device_for_the_apply_stage(uhdr):
 
     w, h = 640, 352
     rng = np.random.default_rng(4242)
-    _, _, base_jpeg = _file(rng, w, h, S420, 0, kind="dense")
-    _, _, map_jpeg = _file(rng, w, h, S444, 0, kind="dense")
+    _, _, base_jpeg = _file(rng, w, h, S420, 0)
+    _, _, map_jpeg = _file(rng, w, h, S444, 0)
     base = [np.zeros((h, w), np.uint8), np.zeros((h // 2, w // 2), np.uint8), np.zeros((h // 2, w // 2), np.uint8)]
     gmap = [np.zeros((h, w, 4), np.uint8)]
 
