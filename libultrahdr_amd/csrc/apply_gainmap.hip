@@ -81,14 +81,16 @@ __device__ __forceinline__ uint32_t pack_codes_1010102(uint32_t r, uint32_t g, u
 // One 8-byte LDS read, one compare and one select per channel (the select picks the upper or lower 16 bits of the entry's
 // second word directly: v_cndmask_b32_sdwa); no powf, no 256 KiB gather, no search.
 template <int OUT>
-__device__ __forceinline__ uint32_t oetf_code_bucket(float v, const uint2* tab, uint32_t base8, uint32_t hi_bits) {
+__device__ __forceinline__ uint32_t oetf_code_bucket(float v, uint32_t tab_rel, uint32_t lo_bits, uint32_t hi_bits) {
   constexpr int SH = (OUT == 1) ? kOetfBucketShiftHlg : kOetfBucketShiftPq;
-  // clampPixelFloat on the bit pattern (v_med3_i32); hi_bits = 1.0f, or the saturation point of a prescaled table
-  uint32_t bits;
-  asm("v_med3_i32 %0, %1, 0, %2" : "=v"(bits) : "v"(__float_as_uint(v)), "v"(hi_bits));
-  uint32_t off = (bits >> (SH - 3)) & ~7u;  // bucket * 8 (byte offset of the entry)
-  off = off > base8 ? off - base8 : 0u;     // everything below the first threshold shares bucket 0
-  const uint2 e = *(const uint2*)((const char*)tab + off);
+  // clampPixelFloat on the bit pattern (v_med3_i32; negative values and -0.0 are negative integers): lo_bits = the start of
+  // the table's first bucket (everything below the first threshold compares below it there too -- host_tables.cpp:
+  // build_step_table), hi_bits = 1.0f, or the saturation point of a prescaled table
+  uint32_t bits, addr;
+  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(bits) : "v"(__float_as_uint(v)), "v"(lo_bits), "v"(hi_bits));
+  // LDS address of the entry = table + (bucket - first bucket) * 8: the wave-uniform part (tab_rel) is the add of a v_lshl_add
+  asm("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(addr) : "v"(bits >> SH), "s"(tab_rel));
+  const uint2 e = *(const __attribute__((address_space(3))) uint2*)addr;
   uint32_t code;
   // s_nop 1: a VALU write of vcc needs two wait states before a VALU reads it as a mask (the compiler inserts the same)
   asm("v_cmp_ge_u32_e32 vcc, %1, %2\n\ts_nop 1\n\tv_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1"
@@ -434,7 +436,12 @@ struct QuadRaw {
 // Workgroup size: 256 for the linear F16 output (8 workgroups per CU share nothing but 14 KB of tables); 1024 for the
 // HLG / PQ outputs, whose output-code bucket table is 41 / 17 KB -- sixteen waves share one copy and two such
 // workgroups (32 waves) still fit a CU's 160 KB.
-template <int OUT> constexpr int quad_block() { return OUT == 0 ? kBlock : 1024; }
+// F16 output: 256-thread workgroups.  HLG / PQ output: 768 threads share one copy of the large LDS tables (code buckets,
+// 31 - 72 KB per workgroup); two workgroups per CU = 6 waves per SIMD, which leaves the wave 80 VGPRs and the full SGPR file
+// (at 8 waves per SIMD the compiler may hand out 72 SGPRs -- 800 / 8 minus the trap handler's 16 -- and the HLG variants
+// spilled their kernel-argument pointer and buffer resources into VGPR lanes inside the row loop)
+template <int OUT> constexpr int quad_block() { return OUT == 0 ? kBlock : 768; }
+template <int OUT, int SRC> constexpr int quad_waves_per_eu() { return (OUT != 0 && SRC == 0) ? 6 : 1; }
 // SGPR budget of a variant: 80 keeps eight 256-thread workgroups resident per CU (MI355X_MICROARCH.md "Residency"); the
 // interpolating variants (SMODE 1) and the coefficient input need more scalar state (four buffer resources, the row
 // arithmetic of the taps) and take 96 = seven workgroups per CU rather than spilling SGPRs into VGPR lanes
@@ -533,8 +540,10 @@ __device__ __forceinline__ void apply_quad_body(const ApplyParams& p) {
   const f2 off_s2 = splat(p.offset_sdr[NCH == 1 ? 0 : 2]), off_h2 = splat(p.offset_hdr[NCH == 1 ? 0 : 2]);
   const uint32_t scale = p.scale, half_scale = p.scale >> 1, magic = p.scale_magic;
   const uint32_t gmh1 = p.gm.h - 1, y0g = p.y0;
-  const uint32_t code_base8 = p.oetf_base8, code_hi = p.oetf_hi_bits;
-  (void)code_base8; (void)code_hi;
+  // LDS byte address of the code table minus its first bucket's offset (wraps modulo 2^32, as does the add that uses it)
+  const uint32_t code_rel = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)s_code - p.oetf_base8;
+  const uint32_t code_lo = p.oetf_lo_bits, code_hi = p.oetf_hi_bits;
+  (void)code_rel; (void)code_lo; (void)code_hi;
 
   // ---- loop-invariant, per-lane column state --------------------------------------------------
   // A lane owns kQuadsPerLane quads of every quad row, 128 pixels apart: each load / store
@@ -792,10 +801,10 @@ __device__ __forceinline__ void apply_quad_body(const ApplyParams& p) {
           hr = nr; hg = ng; hb = nb;
         }
         uint2 o;
-        o.x = pack_codes_1010102(oetf_code_bucket<OUT>(hr.x, s_code, code_base8, code_hi), oetf_code_bucket<OUT>(hg.x, s_code, code_base8, code_hi),
-                                 oetf_code_bucket<OUT>(hb.x, s_code, code_base8, code_hi));
-        o.y = pack_codes_1010102(oetf_code_bucket<OUT>(hr.y, s_code, code_base8, code_hi), oetf_code_bucket<OUT>(hg.y, s_code, code_base8, code_hi),
-                                 oetf_code_bucket<OUT>(hb.y, s_code, code_base8, code_hi));
+        o.x = pack_codes_1010102(oetf_code_bucket<OUT>(hr.x, code_rel, code_lo, code_hi), oetf_code_bucket<OUT>(hg.x, code_rel, code_lo, code_hi),
+                                 oetf_code_bucket<OUT>(hb.x, code_rel, code_lo, code_hi));
+        o.y = pack_codes_1010102(oetf_code_bucket<OUT>(hr.y, code_rel, code_lo, code_hi), oetf_code_bucket<OUT>(hg.y, code_rel, code_lo, code_hi),
+                                 oetf_code_bucket<OUT>(hb.y, code_rel, code_lo, code_hi));
         if (SRC == 0 || store_ok) stream_store<u2v>(dp + (drow + r * sd + xdst), (u2v){o.x, o.y});
       }
     }
@@ -951,12 +960,12 @@ __device__ __forceinline__ void apply_quad_body(const ApplyParams& p) {
 
 // The two entry points differ in their SGPR budget only (the attribute takes a literal): see quad_sgprs
 template <int OUT, int MAPFMT, int SMODE, int BASE, int SRC = 0>
-__global__ __launch_bounds__(quad_block<OUT>(), (quad_block<OUT>() == 1024 && SRC == 0) ? 8 : (quad_block<OUT>() == 1024 ? 4 : 1)) __attribute__((amdgpu_num_sgpr(80))) void apply_quad_kernel(const ApplyParams p) {
+__global__ __launch_bounds__(quad_block<OUT>()) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(quad_waves_per_eu<OUT, SRC>(), 8))) void apply_quad_kernel(const ApplyParams p) {
   static_assert(quad_sgprs<SMODE, SRC>() == 80, "this entry point is the 80-SGPR one");
   apply_quad_body<OUT, MAPFMT, SMODE, BASE, SRC>(p);
 }
 template <int OUT, int MAPFMT, int SMODE, int BASE, int SRC = 0>
-__global__ __launch_bounds__(quad_block<OUT>(), (quad_block<OUT>() == 1024 && SRC == 0) ? 8 : (quad_block<OUT>() == 1024 ? 4 : 1)) __attribute__((amdgpu_num_sgpr(96))) void apply_quad_kernel_s96(const ApplyParams p) {
+__global__ __launch_bounds__(quad_block<OUT>()) __attribute__((amdgpu_num_sgpr(96), amdgpu_waves_per_eu(quad_waves_per_eu<OUT, SRC>(), 8))) void apply_quad_kernel_s96(const ApplyParams p) {
   static_assert(quad_sgprs<SMODE, SRC>() == 96, "this entry point is the 96-SGPR one");
   apply_quad_body<OUT, MAPFMT, SMODE, BASE, SRC>(p);
 }

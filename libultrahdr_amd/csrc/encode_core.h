@@ -37,11 +37,13 @@ __device__ __forceinline__ Color3 linearise_hdr(Color3 g, const float* lut, bool
 // kernel's HLG / PQ tail is the same construction): clamp the bit pattern into the table's domain, bucket = bits >> shift,
 // at most one threshold per bucket.  One 8-byte LDS read, one compare, one select.
 __device__ __forceinline__ uint32_t step_code(float v, const uint2* tab, const StepTab& t) {
-  uint32_t bits;  // the clamp into the table's domain on the bit pattern: one three-operand median
+  uint32_t bits, addr;  // the clamp into the table's domain on the bit pattern: one three-operand median
   asm("v_med3_i32 %0, %1, %2, %3" : "=v"(bits) : "v"(__float_as_uint(v)), "v"(t.lo_bits), "v"(t.hi_bits));
-  uint32_t off = (bits >> t.shm3) & ~7u;
-  off = off > t.base8 ? off - t.base8 : 0u;
-  const uint2 e = *(const uint2*)((const char*)tab + off);
+  // tab is an LDS array: entry address = tab + (bucket - first bucket) * 8; t.lo_bits >= the first bucket's start (host_tables.cpp:
+  // build_step_table), so the difference is never negative and the wave-uniform part folds into the add of a v_lshl_add
+  const uint32_t rel = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)tab - t.base8;
+  asm("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(addr) : "v"(bits >> (t.shm3 + 3u)), "s"(rel));
+  const uint2 e = *(const __attribute__((address_space(3))) uint2*)addr;
   uint32_t code;  // bits >= threshold ? upper : lower half of the entry's second word, picked by the select itself (SDWA)
   // s_nop 1: a VALU write of vcc needs two wait states before a VALU reads it as a mask (the compiler inserts the same)
   asm("v_cmp_ge_u32_e32 vcc, %1, %2\n\ts_nop 1\n\tv_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1"

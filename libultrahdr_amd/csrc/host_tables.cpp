@@ -245,6 +245,11 @@ OetfBuckets build_step_table(const std::function<uint32_t(uint32_t)>& code_of_bi
   }
   const uint32_t first = thr.empty() ? hi_bits : thr[0];
   b.base = first >> shift;
+  // the device clamps the bit pattern to max(lo_bits, base << shift) instead of guarding the bucket subtraction: everything
+  // below the first threshold must then still compare below it, so a threshold that sits exactly on the start of its
+  // bucket gets an empty bucket in front of it
+  if (b.base > 0 && (b.base << shift) == first && first > lo_bits) b.base--;
+  b.clamp_lo_bits = std::max(lo_bits, b.base << shift);
   b.n = (hi_bits >> shift) - b.base + 1;
   if (b.n > capacity) { b.exact = false; b.n = 1; }
   b.entries.assign((size_t)b.n * 2, 0u);
@@ -255,9 +260,9 @@ OetfBuckets build_step_table(const std::function<uint32_t(uint32_t)>& code_of_bi
     if (v.empty() || v.back() != u) v.push_back(u);
   }
   auto clampb = [&](uint32_t u) { return u < lo_bits ? lo_bits : (u > hi_bits ? hi_bits : u); };
-  auto lookup = [&](uint32_t u) -> uint32_t {  // the device's evaluation (u already clamped to [lo_bits, hi_bits])
-    uint32_t k = u >> shift;
-    k = k > b.base ? k - b.base : 0;
+  auto lookup = [&](uint32_t u) -> uint32_t {  // the device's evaluation: clamp to [clamp_lo_bits, hi_bits], bucket - base
+    u = u < b.clamp_lo_bits ? b.clamp_lo_bits : u;
+    const uint32_t k = (u >> shift) - b.base;
     const uint32_t t = b.entries[2 * k], cc = b.entries[2 * k + 1];
     return u >= t ? cc >> 16 : cc & 0xffffu;
   };

@@ -26,6 +26,7 @@ uint32_t oetf_code(int ct, float v);  // the composite itself, evaluated with th
 struct OetfBuckets {
   uint32_t shift = 0, base = 0, n = 0;  // bucket k covers bit patterns [(base + k) << shift, (base + k + 1) << shift)
   uint32_t lo_bits = 0, hi_bits = 0;    // the domain: the device clamps the bit pattern into it first
+  uint32_t clamp_lo_bits = 0;           // max(lo_bits, base << shift): the device's lower clamp, so that bucket - base never underflows
   bool exact = false;                   // construction verified (one threshold per bucket, replay against the composite)
   std::vector<uint32_t> entries;        // n x {thr, lo | hi << 16}
 };

@@ -325,7 +325,7 @@ static uhdr_error_info_t upload_step_table(const host::OetfBuckets& b, float** s
   meta->n = b.n;
   meta->base8 = b.base * 8;
   meta->shm3 = b.shift - 3;
-  meta->lo_bits = b.lo_bits;
+  meta->lo_bits = b.clamp_lo_bits;
   meta->hi_bits = b.hi_bits;
   return ok_status();
 }
@@ -669,6 +669,7 @@ static uhdr_error_info_t build_apply_params(uhdr_hip_ctx* c, const uhdr_raw_imag
       p.oetf_buckets = (const uint2*)*slot;
       p.oetf_n = b.n;
       p.oetf_base8 = b.base * 8;
+      p.oetf_lo_bits = b.clamp_lo_bits;
       p.oetf_hi_bits = b.hi_bits;
       p.oetf_prescaled = pre ? 1 : 0;
     }
@@ -1671,10 +1672,9 @@ int uhdr_hip_step_table_eval(int which, float a, float b, const float* in, uint3
     uint32_t bits;
     memcpy(&bits, &in[i], 4);
     int ib = (int)bits;
-    ib = ib < (int)t->lo_bits ? (int)t->lo_bits : (ib > (int)t->hi_bits ? (int)t->hi_bits : ib);
+    ib = ib < (int)t->clamp_lo_bits ? (int)t->clamp_lo_bits : (ib > (int)t->hi_bits ? (int)t->hi_bits : ib);
     const uint32_t u = (uint32_t)ib;
-    uint32_t off = (u >> (t->shift - 3)) & ~7u;
-    off = off > t->base * 8 ? off - t->base * 8 : 0u;
+    const uint32_t off = ((u >> t->shift) - t->base) * 8;  // never negative: clamp_lo_bits >= base << shift
     const uint32_t thr = t->entries[off / 4], cc = t->entries[off / 4 + 1];
     out[i] = u >= thr ? cc >> 16 : cc & 0xffffu;
   }

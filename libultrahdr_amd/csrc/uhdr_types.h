@@ -49,7 +49,7 @@ constexpr int kStepTabMax = 2048;  // entries (16 KiB of LDS each)
 struct StepTab {
   const uint2* tab;  // null: not available for this call (the kernels then run the float64 evaluation)
   uint32_t n, base8, shm3;  // entries, first bucket * 8, shift - 3
-  uint32_t lo_bits, hi_bits;
+  uint32_t lo_bits, hi_bits;  // the device's clamp; lo_bits >= base8 << shm3, so bucket * 8 - base8 cannot underflow
 };
 constexpr int kMaxIdwScaleLds = 8;  // idw tables up to 4*8*8*4 floats = 4 KiB live in LDS
 
@@ -97,6 +97,7 @@ struct ApplyParams {
   const float* oetf_thr;    // generic kernel. HLG: output-code threshold block (kOetfTabFloats); PQ: 65536 uint16 output codes of pqOetfLUT's nodes; linear: null
   const uint2* oetf_buckets;   // quad kernel, HLG / PQ: bucket table {thr, lo | hi << 16} (null: not verified exact -> generic kernel)
   uint32_t oetf_n, oetf_base8; // entries, first bucket * 8
+  uint32_t oetf_lo_bits;       // lower clamp (bit pattern): max(domain start, first bucket's start)
   uint32_t oetf_hi_bits;       // upper end of the table's domain (bit pattern)
   int oetf_prescaled;          // the table takes the value before the nit scaling (x * 203) / peak (no HDR-side gamut conversion)
   uint32_t y0;              // global row of stripe row 0
