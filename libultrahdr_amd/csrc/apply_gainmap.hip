@@ -90,7 +90,8 @@ __device__ __forceinline__ uint32_t oetf_code_bucket(float v, uint32_t tab_rel, 
   asm("v_med3_i32 %0, %1, %2, %3" : "=v"(bits) : "v"(__float_as_uint(v)), "v"(lo_bits), "v"(hi_bits));
   // LDS address of the entry = table + (bucket - first bucket) * 8: the wave-uniform part (tab_rel) is the add of a v_lshl_add
   asm("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(addr) : "v"(bits >> SH), "s"(tab_rel));
-  const uint2 e = *(const __attribute__((address_space(3))) uint2*)addr;
+  typedef uint32_t lds_u2 __attribute__((ext_vector_type(2)));
+  const lds_u2 e = *(const __attribute__((address_space(3))) lds_u2*)addr;
   uint32_t code;
   // s_nop 1: a VALU write of vcc needs two wait states before a VALU reads it as a mask (the compiler inserts the same)
   asm("v_cmp_ge_u32_e32 vcc, %1, %2\n\ts_nop 1\n\tv_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1"

@@ -34,14 +34,26 @@ constexpr int kChunk = 4096;   // bytes per workgroup of the unstuff passes (256
 constexpr int kSyncBlock = 64; // one wave per workgroup: a wave's lanes decode neighbouring subsequences
 
 __device__ __forceinline__ bool is_stuffed(const uint8_t* __restrict__ d, uint32_t i) { return i > 0 && d[i] == 0 && d[i - 1] == 0xffu; }
+// RST: also both bytes of every RSTn marker (0xFF 0xD0..0xD7; inside entropy-coded data a 0xFF that is followed by anything
+// but 0x00 is a marker, T.81 B.1.1.5).  The interval that follows starts at the marker's place in the clean stream.
+__device__ __forceinline__ bool is_rst_first(const uint8_t* __restrict__ d, uint32_t i, uint32_t n) {
+  return d[i] == 0xffu && i + 1 < n && (d[i + 1] & 0xf8u) == 0xd0u;
+}
+template <bool RST>
+__device__ __forceinline__ bool is_dropped(const uint8_t* __restrict__ d, uint32_t i, uint32_t n) {
+  if (is_stuffed(d, i)) return true;
+  if (!RST) return false;
+  return is_rst_first(d, i, n) || (i > 0 && (d[i] & 0xf8u) == 0xd0u && d[i - 1] == 0xffu);
+}
 
+template <bool RST>
 __global__ __launch_bounds__(256) void unstuff_count_kernel(const uint8_t* __restrict__ data, uint32_t n, uint32_t* __restrict__ counts) {
   __shared__ uint32_t s_cnt;
   if (threadIdx.x == 0) s_cnt = 0;
   __syncthreads();
   const uint32_t base = blockIdx.x * kChunk + threadIdx.x * 16;
   uint32_t c = 0;
-  for (uint32_t i = base; i < base + 16 && i < n; i++) c += is_stuffed(data, i) ? 1u : 0u;
+  for (uint32_t i = base; i < base + 16 && i < n; i++) c += is_dropped<RST>(data, i, n) ? 1u : 0u;
   if (c) atomicAdd(&s_cnt, c);
   __syncthreads();
   if (threadIdx.x == 0) counts[blockIdx.x] = s_cnt;
@@ -128,12 +140,14 @@ __global__ __launch_bounds__(kScanThreads) void scan_add_kernel(uint32_t* __rest
     if (i < n) v[i] += off;
   }
 }
+// RST: rst_map gets bit (clean byte index) set where an interval starts (zero-initialised by the caller), *rst_count the markers
+template <bool RST>
 __global__ __launch_bounds__(256) void unstuff_compact_kernel(const uint8_t* __restrict__ data, uint32_t n, const uint32_t* __restrict__ chunk_base,
-                                                              uint8_t* __restrict__ clean) {
+                                                              uint8_t* __restrict__ clean, uint32_t* __restrict__ rst_map, uint32_t* __restrict__ rst_count) {
   __shared__ uint32_t s_scan[256];
   const uint32_t tid = threadIdx.x, base = blockIdx.x * kChunk + tid * 16;
   uint32_t c = 0;
-  for (uint32_t i = base; i < base + 16 && i < n; i++) c += is_stuffed(data, i) ? 1u : 0u;
+  for (uint32_t i = base; i < base + 16 && i < n; i++) c += is_dropped<RST>(data, i, n) ? 1u : 0u;
   s_scan[tid] = c;
   __syncthreads();
   for (uint32_t d = 1; d < 256; d <<= 1) {
@@ -142,9 +156,14 @@ __global__ __launch_bounds__(256) void unstuff_compact_kernel(const uint8_t* __r
     s_scan[tid] += y;
     __syncthreads();
   }
-  uint32_t dropped = chunk_base[blockIdx.x] + s_scan[tid] - c;  // stuffed bytes before this thread's first byte
+  uint32_t dropped = chunk_base[blockIdx.x] + s_scan[tid] - c;  // dropped bytes before this thread's first byte
   for (uint32_t i = base; i < base + 16 && i < n; i++) {
-    if (is_stuffed(data, i)) dropped++;
+    if (RST && is_rst_first(data, i, n)) {
+      const uint32_t at = i - dropped;  // where the next interval's first byte lands
+      atomicOr(rst_map + (at >> 5), 1u << (at & 31u));
+      atomicAdd(rst_count, 1u);
+    }
+    if (is_dropped<RST>(data, i, n)) dropped++;
     else clean[i - dropped] = data[i];
   }
 }
@@ -283,6 +302,24 @@ __device__ __forceinline__ void load_scan_lds(const HuffSyncArgs& a, ScanLds& L)
   }
 }
 
+// Restart intervals in the self-synchronising scheme.  The unstuff pass removes the RSTn markers and flags the byte at
+// which every interval starts; what remains between two intervals are the 0-7 one-bits that pad the last byte (T.81
+// F.1.2.3; libjpeg's emit_restart pads with ones).  Rule, applied by every decoder -- lost or not -- when it has just
+// finished a block at bit `pos`: if the next byte boundary is an interval start and all bits up to it are ones, go to that
+// boundary as block 0 of an MCU.  On the true path this is exactly the end of an interval (a block that is still to come
+// would start with a Huffman code, and no code consists of ones only); on a lost path it is one more deterministic
+// transition, and a very good one: every path that crosses an interval start is in step from there on.
+// Returns the number of bits skipped, kNoJump when the rule does not apply.
+constexpr uint32_t kNoJump = 0xffffffffu;
+__device__ __forceinline__ uint32_t restart_jump(const HuffSyncArgs& a, Bits& r, uint32_t pos) {
+  const uint32_t byte = (pos + 7u) >> 3, pad = (0u - pos) & 7u;
+  if (((a.rst_map[byte >> 5] >> (byte & 31u)) & 1u) == 0) return kNoJump;
+  r.fill();
+  if (r.peek((int)pad) != (1u << pad) - 1u) return kNoJump;
+  r.skip((int)pad);
+  return pad;
+}
+
 // State tracking without symbols: the passes that only need to know WHERE the decoder is (bit position, block in the
 // MCU, zig-zag index) read tables whose entries hold the bits a symbol consumes (code + magnitude bits) and the zig-zag
 // advance (run + 1; 16 for ZRL; 64 = to the end of the block for EOB and for undefined codes; 1 for a DC symbol) --
@@ -319,6 +356,10 @@ __device__ __forceinline__ void track_span(const HuffSyncArgs& a, const Staged& 
       b++;
       nblk++;
       if (b == bpm) b = 0;
+      if (a.rst_map) {  // restart intervals: see restart_jump
+        const uint32_t pad = restart_jump(a, r, end_bit - (uint32_t)left);
+        if (pad != kNoJump) { left -= (int)pad; b = 0; }
+      }
       cbase = ((cpack >> (2u * b)) & 3u) ? 2u * kWords : 0u;
     }
   }
@@ -419,7 +460,7 @@ __device__ __forceinline__ void write_span(const HuffSyncArgs& a, const Staged& 
   r.st = st;
   r.region_bit = region_bit;
   r.seek(p);
-  bool bad = false;
+  bool bad = false, rst_bad = false;
   const uint32_t bpm = (uint32_t)a.blocks_per_mcu;
   uint32_t cpack = 0;
 #pragma unroll
@@ -468,11 +509,19 @@ __device__ __forceinline__ void write_span(const HuffSyncArgs& a, const Staged& 
         mx++;
         if (mx == a.mcus_per_row) { mx = 0; my++; }
       }
+      if (a.rst_map) {
+        // the true path: an interval must end exactly where the frame header says (every rst_blocks blocks), nowhere else
+        const uint32_t pad = restart_jump(a, r, end_bit - (uint32_t)left);
+        const bool due = blk % a.rst_blocks == 0 && blk < a.total_blocks;
+        if ((pad != kNoJump) != due) rst_bad = true;
+        if (pad != kNoJump) { left -= (int)pad; b = 0; }
+      }
       cbase = ((cpack >> (2u * b)) & 3u) ? 2u * kHuffValWords : 0u;
       locate();
     }
   }
   if (bad) atomicOr(a.flags + 1, 2u);
+  if (rst_bad) atomicOr(a.flags + 1, 4u);
 }
 
 // rounds of step 2 / 3.  state[cur] is read, state[cur ^ 1] written; changed[] likewise.  flags[4 + r % 3] counts the
@@ -792,6 +841,29 @@ __global__ __launch_bounds__(1024) void dc_apply_kernel(const HuffSyncArgs a, co
   dc_block_scan(v, s_sum, tid);
   if (t >= a.total_blocks) return;
   const int dc = partial[blockIdx.x * 3 + c] + v[c];
+  if (a.rst_map) {
+    // restart intervals: the prediction starts again at zero every rst_blocks blocks.  The running sums are kept as they
+    // are (dcd[t] <- the component's sum up to t); the last block of an interval also publishes all three sums, and
+    // dc_restart_kernel subtracts what had accumulated before the block's own interval
+    a.dcd[t] = dc;
+    if ((t + 1u) % a.rst_blocks == 0 && t + 1u < a.total_blocks) {
+      int* g = a.dc_seg + (size_t)((t + 1u) / a.rst_blocks) * 3;
+      for (int cc = 0; cc < 3; cc++) g[cc] = partial[blockIdx.x * 3 + cc] + v[cc];
+    }
+    return;
+  }
+  const int my = (int)(m / (uint32_t)a.mcus_per_row), mx = (int)(m - (uint32_t)my * (uint32_t)a.mcus_per_row);
+  const int jj = (int)j - a.first_blk[c];
+  const int by = my * a.vs[c] + jj / a.hs[c], bx = mx * a.hs[c] + jj % a.hs[c];
+  if (by < a.bh[c] && bx < a.bw[c]) a.coef[c][((size_t)by * a.bw[c] + bx) * 64] = (int16_t)dc;
+}
+__global__ __launch_bounds__(256) void dc_restart_kernel(const HuffSyncArgs a) {
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= a.total_blocks) return;
+  const uint32_t bpm = (uint32_t)a.blocks_per_mcu;
+  const uint32_t m = t / bpm, j = t - m * bpm, seg = t / a.rst_blocks;
+  const int c = a.comp_of[j];
+  const int dc = a.dcd[t] - (seg ? a.dc_seg[(size_t)seg * 3 + c] : 0);
   const int my = (int)(m / (uint32_t)a.mcus_per_row), mx = (int)(m - (uint32_t)my * (uint32_t)a.mcus_per_row);
   const int jj = (int)j - a.first_blk[c];
   const int by = my * a.vs[c] + jj / a.hs[c], bx = mx * a.hs[c] + jj % a.hs[c];
@@ -815,12 +887,24 @@ static void launch_write(const HuffSyncArgs& a, uint32_t nsub, int final_buf, hi
 int huff_sync_chunks(uint64_t nbytes) { return (int)((nbytes + kChunk - 1) / kChunk); }
 
 // Step 1 (unstuff): chunk_counts becomes the exclusive scan, *nstuffed_dev the number of dropped bytes.
-hipError_t launch_huffman_unstuff(const uint8_t* data, uint32_t nbytes, uint32_t* chunk_counts, uint32_t* nstuffed_dev, uint8_t* clean, hipStream_t s) {
+// rst_map != nullptr: the stream has restart markers; they are dropped as well, rst_map (zero-initialised, one bit per byte)
+// gets the interval starts and *rst_count the number of markers.
+hipError_t launch_huffman_unstuff(const uint8_t* data, uint32_t nbytes, uint32_t* chunk_counts, uint32_t* nstuffed_dev, uint8_t* clean, hipStream_t s,
+                                  uint32_t* rst_map, uint32_t* rst_count) {
   const int nchunks = huff_sync_chunks(nbytes);
-  hipLaunchKernelGGL(unstuff_count_kernel, dim3(nchunks), dim3(256), 0, s, data, nbytes, chunk_counts);
+  if (rst_map) hipLaunchKernelGGL(unstuff_count_kernel<true>, dim3(nchunks), dim3(256), 0, s, data, nbytes, chunk_counts);
+  else hipLaunchKernelGGL(unstuff_count_kernel<false>, dim3(nchunks), dim3(256), 0, s, data, nbytes, chunk_counts);
   hipLaunchKernelGGL(sync_scan_kernel, dim3(1), dim3(1024), 0, s, chunk_counts, nchunks, nstuffed_dev);
-  hipLaunchKernelGGL(unstuff_compact_kernel, dim3(nchunks), dim3(256), 0, s, data, nbytes, (const uint32_t*)chunk_counts, clean);
+  if (rst_map) hipLaunchKernelGGL(unstuff_compact_kernel<true>, dim3(nchunks), dim3(256), 0, s, data, nbytes, (const uint32_t*)chunk_counts, clean, rst_map, rst_count);
+  else hipLaunchKernelGGL(unstuff_compact_kernel<false>, dim3(nchunks), dim3(256), 0, s, data, nbytes, (const uint32_t*)chunk_counts, clean, rst_map, rst_count);
   return hipGetLastError();
+}
+static void launch_dc(const HuffSyncArgs& a, int* dc_partial, hipStream_t s) {
+  const int nch = (int)((a.total_blocks + 1023) / 1024);
+  hipLaunchKernelGGL(dc_partial_kernel, dim3(nch), dim3(1024), 0, s, a, dc_partial);
+  hipLaunchKernelGGL(dc_scan_partials_kernel, dim3(1), dim3(1024), 0, s, dc_partial, nch);
+  hipLaunchKernelGGL(dc_apply_kernel, dim3(nch), dim3(1024), 0, s, a, (const int*)dc_partial);
+  if (a.rst_map) hipLaunchKernelGGL(dc_restart_kernel, dim3((a.total_blocks + 255) / 256), dim3(256), 0, s, a);
 }
 
 uint32_t huff_sync_max_subsequences(uint64_t nbytes, uint32_t sub_bits) { return (uint32_t)((nbytes * 8 + sub_bits - 1) / sub_bits); }
@@ -843,10 +927,7 @@ hipError_t launch_huffman_decode_sync(const HuffSyncArgs& a, int max_rounds, int
     if (nt > 1) hipLaunchKernelGGL(scan_add_kernel, dim3(nt), dim3(kScanThreads), 0, s, a.nblk, (int)nsub, (const uint32_t*)a.scan_tmp);
   }
   launch_write(a, nsub, *final_buf, s);
-  const int nch = (int)((a.total_blocks + 1023) / 1024);
-  hipLaunchKernelGGL(dc_partial_kernel, dim3(nch), dim3(1024), 0, s, a, dc_partial);
-  hipLaunchKernelGGL(dc_scan_partials_kernel, dim3(1), dim3(1024), 0, s, dc_partial, nch);
-  hipLaunchKernelGGL(dc_apply_kernel, dim3(nch), dim3(1024), 0, s, a, (const int*)dc_partial);
+  launch_dc(a, dc_partial, s);
   return hipGetLastError();
 }
 
@@ -893,10 +974,7 @@ hipError_t launch_huffman_decode_hyp(const HuffSyncArgs& a, int* dc_partial, uin
   mark();
   launch_write(a, nsub, 0, s);
   mark();
-  const int nch = (int)((a.total_blocks + 1023) / 1024);
-  hipLaunchKernelGGL(dc_partial_kernel, dim3(nch), dim3(1024), 0, s, a, dc_partial);
-  hipLaunchKernelGGL(dc_scan_partials_kernel, dim3(1), dim3(1024), 0, s, dc_partial, nch);
-  hipLaunchKernelGGL(dc_apply_kernel, dim3(nch), dim3(1024), 0, s, a, (const int*)dc_partial);
+  launch_dc(a, dc_partial, s);
   mark();
   if (dbg) {
     (void)hipStreamSynchronize(s);

@@ -2333,7 +2333,12 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
   // fixed-point search not settle within the round budget (never seen; pathological streams), the serial kernel runs.
   bool sync_done = false;
   // (the self-synchronising decoder keeps bit positions in 32 bits: scans of 512 MiB and more take the other routes)
-  if (a.nseg == 1 && data_bytes >= 4096 && data_bytes < ((size_t)1 << 29) && fast_ok && !getenv("UHDR_HIP_HUFF_SERIAL")) {
+  // Restart-marker files take the same decoder when their intervals are long enough that one lane per interval leaves the
+  // device idle (3240 intervals of 1 KB in a 4K file with ri = 10: 1081 us on 51 wavefronts): the unstuff pass drops the
+  // markers, the decoders hop over the padding bits at the flagged interval starts and the DC scan starts over there
+  // (huffman_decode_sync.hip: restart_jump).  Short intervals (a few hundred bytes) are faster one lane each.
+  const bool rst_sync = a.nseg > 1 && data_bytes / (size_t)a.nseg >= 320 && !getenv("UHDR_HIP_HUFF_RST_INTERVALS");
+  if ((a.nseg == 1 || rst_sync) && data_bytes >= 4096 && data_bytes < ((size_t)1 << 29) && fast_ok && !getenv("UHDR_HIP_HUFF_SERIAL")) {
     // Subsequence size: a power of two >= 256 bits (the lanes' chunks are staged in LDS: 64 x sub_bits / 8 bytes per wave).
     // Attempts, in order: the hypothesis scheme with seven overflow levels at 512 bits (4K q95 photo-like data: 390 us) -- denser
     // streams start at 2048 / 4096 bits --, then at doubled sizes up to 4096 bits, then the rounds at 1024 bits.
@@ -2380,6 +2385,8 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
     size_t chain_tiles_off = 0;
     const size_t o_ch = use_hyp ? take(huff_hyp_chain_bytes(data_bytes, sub_bits, &chain_tiles_off)) : 0;  // sized for the smallest subsequences
     (void)chain_tiles_off;
+    const size_t rst_words = data_bytes / 32 + 2;
+    const size_t o_rm = rst_sync ? take(rst_words * 4) : 0, o_ds = rst_sync ? take((size_t)a.nseg * 12) : 0;
     UHDR_TRY(ensure(c->scratch[6], off));
     uint8_t* sb = (uint8_t*)c->scratch[6].p;
     HuffSyncArgs y;
@@ -2396,6 +2403,14 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
     y.dcd = (int*)(sb + o_dcd);
     y.total_blocks = total_blocks;
     y.blocks_per_mcu = bpm; y.ncomp = a.ncomp; y.mcus_per_row = a.mcus_per_row;
+    uint32_t* rst_map = nullptr;
+    if (rst_sync) {
+      rst_map = (uint32_t*)(sb + o_rm);
+      y.rst_map = rst_map;
+      y.rst_blocks = (uint32_t)a.ri * (uint32_t)bpm;
+      y.dc_seg = (int*)(sb + o_ds);
+      HIP_TRY(hipMemsetAsync(rst_map, 0, rst_words * 4, c->stream));
+    }
     int j = 0;
     for (int i = 0; i < a.ncomp; i++) {
       y.bw[i] = a.bw[i]; y.bh[i] = a.bh[i]; y.hs[i] = a.hs[i]; y.vs[i] = a.vs[i]; y.coef[i] = a.coef[i];
@@ -2417,7 +2432,7 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
       HIP_TRY(hipMemsetAsync(y.nblk, 0, (size_t)nsub * 4 + 4, c->stream));
       HIP_TRY(hipMemsetAsync(y.dcd, 0, (size_t)total_blocks * 4, c->stream));
       int final_buf = 0;
-      uint32_t fl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      uint32_t fl[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [9]: restart markers the unstuff pass dropped
       bool hyp_done = false, unstuffed = false, rounds_ran = false;
       auto start_over = [&]() -> uhdr_error_info_t {  // an attempt failed: everything it wrote goes back to its initial state
         HIP_TRY(hipMemsetAsync(y.flags, 0, 32, c->stream));  // not [8]: the stuffed-byte count stays
@@ -2445,7 +2460,7 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
           (void)huff_hyp_chain_bytes(data_bytes, t.sub_bits, &tiles_off);
           {
             ProfScope ps(c, "huffman_decode");
-            if (!unstuffed) HIP_TRY(launch_huffman_unstuff(data, (uint32_t)data_bytes, (uint32_t*)(sb + o_cnt), y.flags + 8, sb + o_clean, c->stream));
+            if (!unstuffed) HIP_TRY(launch_huffman_unstuff(data, (uint32_t)data_bytes, (uint32_t*)(sb + o_cnt), y.flags + 8, sb + o_clean, c->stream, rst_map, y.flags + 9));
             unstuffed = true;
             HIP_TRY(launch_huffman_decode_hyp(y, (int*)(sb + o_dcp), sb + o_ch, sb + o_ch + tiles_off, c->stream));
           }
@@ -2461,7 +2476,7 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
         } else {
           {
             ProfScope ps(c, "huffman_decode");
-            if (!unstuffed) HIP_TRY(launch_huffman_unstuff(data, (uint32_t)data_bytes, (uint32_t*)(sb + o_cnt), y.flags + 8, sb + o_clean, c->stream));
+            if (!unstuffed) HIP_TRY(launch_huffman_unstuff(data, (uint32_t)data_bytes, (uint32_t*)(sb + o_cnt), y.flags + 8, sb + o_clean, c->stream, rst_map, y.flags + 9));
             unstuffed = true;
             HIP_TRY(launch_huffman_decode_sync(y, max_rounds, (int*)(sb + o_dcp), &final_buf, c->stream));
           }
@@ -2470,12 +2485,17 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
           rounds_ran = true;
         }
       }
-      if (hyp_done || fl[4 + max_rounds % 3] == 0) {  // the fixed point was reached: the decode is the true one
+      const bool settled = hyp_done || fl[4 + max_rounds % 3] == 0;
+      if (settled && rst_sync && ((fl[1] & 14u) != 0 || fl[9] != (uint32_t)(a.nseg - 1))) {
+        // a restart file that is not what its headers say (markers missing, misplaced or out of step, damaged data): the
+        // interval decoder below looks at every marker and words the error
+        for (int i = 0; i < a.ncomp; i++) HIP_TRY(hipMemsetAsync(a.coef[i], 0, zero_bytes[i], c->stream));
+      } else if (settled) {  // the fixed point was reached: the decode is the true one
         if (fl[1] & 8u) return err_status(UHDR_CODEC_INVALID_PARAM, "corrupt entropy-coded data (the scan ends before its last block)");
         if (fl[1] & 2u) return err_status(UHDR_CODEC_INVALID_PARAM, "corrupt entropy-coded data (undefined Huffman code or a run past the end of a block)");
         sync_done = true;
       } else {  // not settled: start over on the serial path
-        if (!c->huff_serial_ok && data_bytes > (256u << 10)) {
+        if (a.nseg == 1 && !c->huff_serial_ok && data_bytes > (256u << 10)) {
           c->stats.entropy_decode_declined++;
           return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "the parallel entropy decode did not settle in %d rounds; %zu bytes on one lane would take longer than the CPU", max_rounds, data_bytes);
         }

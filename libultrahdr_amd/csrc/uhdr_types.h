@@ -308,7 +308,7 @@ struct HuffSyncArgs {
   uint8_t* changed[2];
   uint32_t* nblk;             // blocks completed per subsequence; later their exclusive scan
   uint32_t* scan_tmp;         // scratch of that scan: one word per 2048 subsequences
-  uint32_t* flags;            // [1]: status bits (2 bad code / run, 8 truncated); [4..6]: change counters of the rounds (r % 3); [8]: stuffed bytes
+  uint32_t* flags;            // [1]: status bits (2 bad code / run, 4 restart marker out of place, 8 truncated); [9]: restart markers found; [4..6]: change counters of the rounds (r % 3); [8]: stuffed bytes
   int* dcd;                   // DC differences of all blocks in scan order
   uint32_t total_blocks;
   int blocks_per_mcu, ncomp, mcus_per_row;
@@ -326,6 +326,10 @@ struct HuffSyncArgs {
   uint8_t* hyp_map;           // [nsub][kHuffHypSlots]: the slot of subsequence i + 1 the path is in at ITS end (0xff: none)
   uint16_t* hyp_cnt;          // [nsub][kHuffHypSlots]: blocks the path completes while crossing subsequence i + 1
   int hyp_hist;               // debug: count the merges per level in flags[10..15]
+  // restart intervals (nullptr / 0: a scan without markers): see restart_jump in huffman_decode_sync.hip
+  const uint32_t* rst_map;    // one bit per byte of the clean stream: an interval starts here
+  uint32_t rst_blocks;        // blocks per interval (restart interval x blocks per MCU)
+  int* dc_seg;                // [intervals][3]: the components' running DC sums before the interval
 };
 constexpr int kHuffHypSlots = 48;
 // scratch of the chain kernels: per-thread prefix maps, then the tile maps
@@ -333,7 +337,8 @@ size_t huff_hyp_chain_bytes(uint64_t nbytes, uint32_t sub_bits, size_t* tiles_of
 hipError_t launch_huffman_decode_hyp(const HuffSyncArgs& a, int* dc_partial, uint8_t* chain_prefix, uint8_t* chain_tiles, hipStream_t s);
 int huff_sync_chunks(uint64_t nbytes);
 uint32_t huff_sync_max_subsequences(uint64_t nbytes, uint32_t sub_bits);
-hipError_t launch_huffman_unstuff(const uint8_t* data, uint32_t nbytes, uint32_t* chunk_counts, uint32_t* nstuffed_dev, uint8_t* clean, hipStream_t s);
+hipError_t launch_huffman_unstuff(const uint8_t* data, uint32_t nbytes, uint32_t* chunk_counts, uint32_t* nstuffed_dev, uint8_t* clean, hipStream_t s,
+                                  uint32_t* rst_map = nullptr, uint32_t* rst_count = nullptr);
 hipError_t launch_huffman_decode_sync(const HuffSyncArgs& a, int max_rounds, int* dc_partial, int* final_buf, hipStream_t s);
 int huff_marker_chunks(uint64_t nbytes);
 hipError_t launch_huffman_decode(const HuffDecArgs& a, uint32_t* counts, uint32_t* starts, uint32_t* ends, hipStream_t s);

@@ -115,3 +115,101 @@ def test_sync_decoder_reports_corrupt_and_truncated_scans(uhdr):
     got = uhdr.huffman_decode(_dev(bytes(scan)), shapes, w, h, sampling, 0)
     for c in range(3):
         assert np.array_equal(got[c].cpu().numpy(), coefs[c]), c
+
+
+def _stats(uhdr):
+    st = A.Stats()
+    uhdr.lib.uhdr_hip_get_stats(uhdr.ctx.handle, C.byref(st))
+    return st
+
+
+RST_CASES = [(640, 480, [(2, 2), (1, 1), (1, 1)], 10), (333, 211, [(2, 2), (1, 1), (1, 1)], 21), (500, 300, [(1, 1)] * 3, 63), (401, 203, [(2, 1), (1, 1), (1, 1)], 7),
+             (1000, 400, [(1, 1)], 125), (1920, 1080, [(2, 2), (1, 1), (1, 1)], 120), (640, 480, [(2, 2), (1, 1), (1, 1)], 1199)]
+
+
+@pytest.mark.parametrize("kind", ["sparse", "dense", "zero"])
+def test_restart_marker_files_take_the_parallel_decoder(uhdr, kind):
+    """Files WITH restart markers whose intervals are long enough (>= 320 bytes on average) go through the same
+    self-synchronising decoder: markers dropped by the unstuff pass, the padding bits hopped over at the flagged interval
+    starts, the DC prediction started over per interval.  Result == the coefficients that went in == the interval decoder
+    (one lane per interval, UHDR_HIP_HUFF_RST_INTERVALS=1)."""
+    rng = np.random.default_rng(307)
+    took = 0
+    for (w, h, sampling, ri) in RST_CASES:
+        if kind == "dense" and w * h > 700_000:
+            continue
+        coefs = _random_coefs(rng, w, h, sampling, kind)
+        scan = L.huffman_encode_port(coefs, w, h, sampling, ri)
+        shapes = [c.shape[:2] for c in coefs]
+        before = _stats(uhdr)
+        got = uhdr.huffman_decode(_dev(scan), shapes, w, h, sampling, ri)
+        after = _stats(uhdr)
+        for c in range(len(coefs)):
+            assert np.array_equal(got[c].cpu().numpy(), coefs[c]), (kind, w, h, ri, c)
+        hmax, vmax = max(s[0] for s in sampling), max(s[1] for s in sampling)
+        mcus = -(-w // (8 * hmax)) * -(-h // (8 * vmax)) if len(sampling) > 1 else -(-w // 8) * -(-h // 8)
+        nseg = -(-mcus // ri)
+        if nseg > 1 and len(scan) >= 4096 and len(scan) // nseg >= 320:
+            assert after.entropy_decode_parallel == before.entropy_decode_parallel + 1, (kind, w, h, ri, len(scan), nseg)
+            took += 1
+            os.environ["UHDR_HIP_HUFF_RST_INTERVALS"] = "1"
+            try:
+                old = uhdr.huffman_decode(_dev(scan), shapes, w, h, sampling, ri)
+            finally:
+                del os.environ["UHDR_HIP_HUFF_RST_INTERVALS"]
+            assert _stats(uhdr).entropy_decode_intervals == after.entropy_decode_intervals + 1
+            for c in range(len(coefs)):
+                assert np.array_equal(old[c].cpu().numpy(), coefs[c]), (kind, w, h, ri, c)
+        else:
+            assert after.entropy_decode_intervals == before.entropy_decode_intervals + 1, (kind, w, h, ri, len(scan), nseg)
+    assert took >= (1 if kind == "zero" else 3), took
+
+
+@pytest.mark.parametrize("sub_bits", ["256", "1024", "4096"])
+def test_restart_files_subsequence_size_does_not_change_the_result(uhdr, sub_bits):
+    rng = np.random.default_rng(311)
+    w, h, sampling, ri = 720, 400, [(2, 2), (1, 1), (1, 1)], 9
+    coefs = _random_coefs(rng, w, h, sampling, "sparse")
+    scan = L.huffman_encode_port(coefs, w, h, sampling, ri)
+    os.environ["UHDR_HIP_HUFF_SUB_BITS"] = sub_bits
+    try:
+        before = _stats(uhdr)
+        got = uhdr.huffman_decode(_dev(scan), [c.shape[:2] for c in coefs], w, h, sampling, ri)
+        assert _stats(uhdr).entropy_decode_parallel == before.entropy_decode_parallel + 1
+    finally:
+        del os.environ["UHDR_HIP_HUFF_SUB_BITS"]
+    for c in range(3):
+        assert np.array_equal(got[c].cpu().numpy(), coefs[c]), c
+
+
+def test_restart_files_that_are_not_what_the_header_says_are_reported(uhdr):
+    """A wrong restart interval in the header, a marker out of sequence, a missing marker, damaged data: the parallel
+    decoder notices (marker count, an interval that ends where none is due) and the interval decoder words the error --
+    the same errors as for short-interval files (test_gpu_parity.py::test_huffman_decode_error_behaviour)."""
+    rng = np.random.default_rng(313)
+    w, h, sampling, ri = 640, 480, [(2, 2), (1, 1), (1, 1)], 20
+    coefs = _random_coefs(rng, w, h, sampling, "sparse")
+    scan = bytearray(L.huffman_encode_port(coefs, w, h, sampling, ri))
+    shapes = [c.shape[:2] for c in coefs]
+    assert len(scan) // 60 >= 320
+    good = uhdr.huffman_decode(_dev(bytes(scan)), shapes, w, h, sampling, ri)
+    assert np.array_equal(good[0].cpu().numpy(), coefs[0])
+
+    def fails(buf, ri_=ri):
+        with pytest.raises(A.UhdrError) as e:
+            uhdr.huffman_decode(_dev(bytes(buf)), shapes, w, h, sampling, ri_)
+        assert e.value.code == A.UHDR_CODEC_INVALID_PARAM, e.value
+
+    fails(scan, 40)  # the stream has a marker every 20 MCUs
+    fails(scan, 10)
+    k = scan.find(b"\xff\xd3")
+    swapped = bytearray(scan)
+    swapped[k + 1] = 0xD6  # out of sequence
+    fails(swapped)
+    dropped = bytearray(scan)
+    del dropped[k:k + 2]  # one marker missing
+    fails(dropped)
+    # and the context is still usable
+    again = uhdr.huffman_decode(_dev(bytes(scan)), shapes, w, h, sampling, ri)
+    for c in range(3):
+        assert np.array_equal(again[c].cpu().numpy(), coefs[c]), c
