@@ -946,7 +946,9 @@ def extras(ctx, u, device):
             ms = time_kernel(ctx, lambda: u.huffman_decode(stream, shp, w, h, [(2, 2), (1, 1), (1, 1)], ri_), iters=3, warm=1)
             res[f"huffman_decode_4k_420_q95_ri{ri_}"] = {"us": round(ms * 1e3, 1), "Mpx/s": round(w * h / (ms / 1e3) / 1e6, 1),
                                                           "jpeg_scan_bytes": int(stream.numel()),
-                                                          "stages": "marker count -> scan -> interval table -> decode (one lane per restart interval)"}
+                                                          "stages": ("unstuff + RSTn markers spliced out -> the self-synchronising decoder of the marker-less case, hopping over "
+                                                                     "the padding bits at the flagged interval starts -> DC scan per interval (DESIGN.md 5.5)") if ri_ == 10 else
+                                                                    "marker count -> scan -> interval table -> decode (one lane per restart interval: short intervals)"}
     except Exception as e:  # noqa: BLE001  (a failure here must not cost the other stage measurements)
         res["huffman_decode_4k_420_q95"] = {"error": f"{type(e).__name__}: {e}"}
     # ... and a scan WITHOUT restart markers, as every file of the reference has it: the primary image of an UltraHDR file

@@ -305,17 +305,19 @@ __device__ __forceinline__ void load_scan_lds(const HuffSyncArgs& a, ScanLds& L)
 // Restart intervals in the self-synchronising scheme.  The unstuff pass removes the RSTn markers and flags the byte at
 // which every interval starts; what remains between two intervals are the 0-7 one-bits that pad the last byte (T.81
 // F.1.2.3; libjpeg's emit_restart pads with ones).  Rule, applied by every decoder -- lost or not -- when it has just
-// finished a block at bit `pos`: if the next byte boundary is an interval start and all bits up to it are ones, go to that
-// boundary as block 0 of an MCU.  On the true path this is exactly the end of an interval (a block that is still to come
-// would start with a Huffman code, and no code consists of ones only); on a lost path it is one more deterministic
-// transition, and a very good one: every path that crosses an interval start is in step from there on.
+// finished the last block of what it takes for an MCU, at bit `pos`: if the next byte boundary is an interval start and all
+// bits up to it are ones, go to that boundary.  On the true path this is exactly the end of an interval (an MCU that is
+// still to come would start with a Huffman code, and no code consists of ones only); on a lost path it is one more
+// deterministic transition -- and one that puts it in step.  Checked after the last block of an MCU only (intervals are whole MCUs): the
+// test sits in a branch that 64 lanes in 64 different places enter almost every step if it is taken per block.
 // Returns the number of bits skipped, kNoJump when the rule does not apply.
 constexpr uint32_t kNoJump = 0xffffffffu;
 __device__ __forceinline__ uint32_t restart_jump(const HuffSyncArgs& a, Bits& r, uint32_t pos) {
   const uint32_t byte = (pos + 7u) >> 3, pad = (0u - pos) & 7u;
-  if (((a.rst_map[byte >> 5] >> (byte & 31u)) & 1u) == 0) return kNoJump;
+  // the bits first (registers): three block ends in four are ruled out without touching the map in global memory
   r.fill();
   if (r.peek((int)pad) != (1u << pad) - 1u) return kNoJump;
+  if (((a.rst_map[byte >> 5] >> (byte & 31u)) & 1u) == 0) return kNoJump;
   r.skip((int)pad);
   return pad;
 }
@@ -355,10 +357,12 @@ __device__ __forceinline__ void track_span(const HuffSyncArgs& a, const Staged& 
       k = 0;
       b++;
       nblk++;
-      if (b == bpm) b = 0;
-      if (a.rst_map) {  // restart intervals: see restart_jump
-        const uint32_t pad = restart_jump(a, r, end_bit - (uint32_t)left);
-        if (pad != kNoJump) { left -= (int)pad; b = 0; }
+      if (b == bpm) {
+        b = 0;
+        if (a.rst_map) {  // restart intervals: see restart_jump
+          const uint32_t pad = restart_jump(a, r, end_bit - (uint32_t)left);
+          if (pad != kNoJump) left -= (int)pad;
+        }
       }
       cbase = ((cpack >> (2u * b)) & 3u) ? 2u * kWords : 0u;
     }
@@ -461,6 +465,7 @@ __device__ __forceinline__ void write_span(const HuffSyncArgs& a, const Staged& 
   r.region_bit = region_bit;
   r.seek(p);
   bool bad = false, rst_bad = false;
+  uint32_t njump = 0;
   const uint32_t bpm = (uint32_t)a.blocks_per_mcu;
   uint32_t cpack = 0;
 #pragma unroll
@@ -508,13 +513,13 @@ __device__ __forceinline__ void write_span(const HuffSyncArgs& a, const Staged& 
         b = 0;
         mx++;
         if (mx == a.mcus_per_row) { mx = 0; my++; }
-      }
-      if (a.rst_map) {
-        // the true path: an interval must end exactly where the frame header says (every rst_blocks blocks), nowhere else
-        const uint32_t pad = restart_jump(a, r, end_bit - (uint32_t)left);
-        const bool due = blk % a.rst_blocks == 0 && blk < a.total_blocks;
-        if ((pad != kNoJump) != due) rst_bad = true;
-        if (pad != kNoJump) { left -= (int)pad; b = 0; }
+        if (a.rst_map) {
+          // the true path: an interval must end exactly where the frame header says (every rst_blocks blocks), nowhere else
+          const uint32_t pad = restart_jump(a, r, end_bit - (uint32_t)left);
+          const bool due = blk % a.rst_blocks == 0 && blk < a.total_blocks;
+          if ((pad != kNoJump) != due) rst_bad = true;
+          if (pad != kNoJump) { left -= (int)pad; njump++; }
+        }
       }
       cbase = ((cpack >> (2u * b)) & 3u) ? 2u * kHuffValWords : 0u;
       locate();
@@ -522,6 +527,7 @@ __device__ __forceinline__ void write_span(const HuffSyncArgs& a, const Staged& 
   }
   if (bad) atomicOr(a.flags + 1, 2u);
   if (rst_bad) atomicOr(a.flags + 1, 4u);
+  if (njump) atomicAdd(a.flags + 7, njump);  // the caller compares with the number of markers: each one must have been an interval end
 }
 
 // rounds of step 2 / 3.  state[cur] is read, state[cur ^ 1] written; changed[] likewise.  flags[4 + r % 3] counts the

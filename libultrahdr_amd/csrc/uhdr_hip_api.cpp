@@ -2486,7 +2486,10 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
         }
       }
       const bool settled = hyp_done || fl[4 + max_rounds % 3] == 0;
-      if (settled && rst_sync && ((fl[1] & 14u) != 0 || fl[9] != (uint32_t)(a.nseg - 1))) {
+      if (rst_sync && getenv("UHDR_HIP_HUFF_DEBUG"))
+        fprintf(stderr, "uhdr_hip: restart file through the parallel decoder: %s, status bits %#x, %u markers dropped (%d expected), %u interval ends on the true path\n",
+                settled ? "settled" : "NOT settled", fl[1], fl[9], a.nseg - 1, fl[7]);
+      if (settled && rst_sync && ((fl[1] & 14u) != 0 || fl[9] != (uint32_t)(a.nseg - 1) || fl[7] != fl[9])) {
         // a restart file that is not what its headers say (markers missing, misplaced or out of step, damaged data): the
         // interval decoder below looks at every marker and words the error
         for (int i = 0; i < a.ncomp; i++) HIP_TRY(hipMemsetAsync(a.coef[i], 0, zero_bytes[i], c->stream));
