@@ -33,6 +33,10 @@ namespace {
 constexpr int kChunk = 4096;   // bytes per workgroup of the unstuff passes (256 threads x 16 bytes)
 constexpr int kSyncBlock = 64; // one wave per workgroup: a wave's lanes decode neighbouring subsequences
 
+// RSTn sequence check without knowing a marker's ordinal where it is found: sum over the markers of (n + 1) x weight(position),
+// two independent weights; equal sums on both sides <=> equal numbers at every position, up to a 2^-64 coincidence
+__device__ __forceinline__ uint32_t rst_weight1(uint32_t at) { return (at * 2654435761u + 0x9e3779b9u) | 1u; }
+__device__ __forceinline__ uint32_t rst_weight2(uint32_t at) { return ((at ^ (at >> 15)) * 0x85ebca6bu + 0xc2b2ae35u) | 1u; }
 __device__ __forceinline__ bool is_stuffed(const uint8_t* __restrict__ d, uint32_t i) { return i > 0 && d[i] == 0 && d[i - 1] == 0xffu; }
 // RST: also both bytes of every RSTn marker (0xFF 0xD0..0xD7; inside entropy-coded data a 0xFF that is followed by anything
 // but 0x00 is a marker, T.81 B.1.1.5).  The interval that follows starts at the marker's place in the clean stream.
@@ -162,6 +166,11 @@ __global__ __launch_bounds__(256) void unstuff_compact_kernel(const uint8_t* __r
       const uint32_t at = i - dropped;  // where the next interval's first byte lands
       atomicOr(rst_map + (at >> 5), 1u << (at & 31u));
       atomicAdd(rst_count, 1u);
+      // the marker's number (RST0..RST7 in turn), folded into two position-weighted sums; the write pass forms the same
+      // sums from the numbers the interval ends SHOULD have (rst_weight below)
+      const uint32_t m = (data[i + 1] & 7u) + 1u;
+      atomicAdd(rst_count + 7, rst_weight1(at) * m);
+      atomicAdd(rst_count + 8, rst_weight2(at) * m);
     }
     if (is_dropped<RST>(data, i, n)) dropped++;
     else clean[i - dropped] = data[i];
@@ -465,7 +474,7 @@ __device__ __forceinline__ void write_span(const HuffSyncArgs& a, const Staged& 
   r.region_bit = region_bit;
   r.seek(p);
   bool bad = false, rst_bad = false;
-  uint32_t njump = 0;
+  uint32_t seq1 = 0, seq2 = 0;
   const uint32_t bpm = (uint32_t)a.blocks_per_mcu;
   uint32_t cpack = 0;
 #pragma unroll
@@ -515,10 +524,16 @@ __device__ __forceinline__ void write_span(const HuffSyncArgs& a, const Staged& 
         if (mx == a.mcus_per_row) { mx = 0; my++; }
         if (a.rst_map) {
           // the true path: an interval must end exactly where the frame header says (every rst_blocks blocks), nowhere else
-          const uint32_t pad = restart_jump(a, r, end_bit - (uint32_t)left);
+          const uint32_t pos0 = end_bit - (uint32_t)left;
+          const uint32_t pad = restart_jump(a, r, pos0);
           const bool due = blk % a.rst_blocks == 0 && blk < a.total_blocks;
           if ((pad != kNoJump) != due) rst_bad = true;
-          if (pad != kNoJump) { left -= (int)pad; njump++; }
+          if (pad != kNoJump) {
+            left -= (int)pad;
+            const uint32_t at = (pos0 + 7u) >> 3, m = ((blk / a.rst_blocks - 1u) & 7u) + 1u;  // the number this marker must have had
+            seq1 += rst_weight1(at) * m;
+            seq2 += rst_weight2(at) * m;
+          }
         }
       }
       cbase = ((cpack >> (2u * b)) & 3u) ? 2u * kHuffValWords : 0u;
@@ -527,7 +542,10 @@ __device__ __forceinline__ void write_span(const HuffSyncArgs& a, const Staged& 
   }
   if (bad) atomicOr(a.flags + 1, 2u);
   if (rst_bad) atomicOr(a.flags + 1, 4u);
-  if (njump) atomicAdd(a.flags + 7, njump);  // the caller compares with the number of markers: each one must have been an interval end
+  if (seq1 | seq2) {  // the caller compares with the sums of the markers that were found: every one an interval end, numbered in turn
+    atomicAdd(a.flags + 0, seq1);
+    atomicAdd(a.flags + 7, seq2);
+  }
 }
 
 // rounds of step 2 / 3.  state[cur] is read, state[cur ^ 1] written; changed[] likewise.  flags[4 + r % 3] counts the

@@ -2374,7 +2374,7 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
     // scratch[6]: clean | chunk counts | flags[8] | state x 2 | nblk | dcd | changed x 2
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    const size_t o_clean = take(data_bytes + 16), o_cnt = take((size_t)nch * 4), o_flags = take(64), o_s0 = take((size_t)nsub * 8),
+    const size_t o_clean = take(data_bytes + 16), o_cnt = take((size_t)nch * 4), o_flags = take(128), o_s0 = take((size_t)nsub * 8),
                  o_s1 = take((size_t)nsub * 8), o_nblk = take((size_t)nsub * 4 + 4), o_dcd = take((size_t)total_blocks * 4),
                  o_c0 = take(nsub), o_c1 = take(nsub), o_dcp = take((size_t)((total_blocks + 1023) / 1024) * 12 + 16),
                  o_ft = take(sizeof(HuffFastTable) * 8),  // symbol form x 4, state-tracking form x 4
@@ -2428,11 +2428,11 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
       std::vector<uint32_t> vtabs((size_t)4 * kHuffValWords);
       for (int t = 0; t < 4; t++) make_value_table(ftabs[(size_t)t], (t & 1) == 0, vtabs.data() + (size_t)t * kHuffValWords);
       HIP_TRY(hipMemcpyAsync(sb + o_vt, vtabs.data(), vtabs.size() * 4, hipMemcpyHostToDevice, c->stream));
-      HIP_TRY(hipMemsetAsync(y.flags, 0, 64, c->stream));
+      HIP_TRY(hipMemsetAsync(y.flags, 0, 128, c->stream));
       HIP_TRY(hipMemsetAsync(y.nblk, 0, (size_t)nsub * 4 + 4, c->stream));
       HIP_TRY(hipMemsetAsync(y.dcd, 0, (size_t)total_blocks * 4, c->stream));
       int final_buf = 0;
-      uint32_t fl[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [9]: restart markers the unstuff pass dropped
+      uint32_t fl[18] = {};  // [9]: restart markers the unstuff pass dropped, [16] [17] / [0] [7]: their sequence sums as found / as due
       bool hyp_done = false, unstuffed = false, rounds_ran = false;
       auto start_over = [&]() -> uhdr_error_info_t {  // an attempt failed: everything it wrote goes back to its initial state
         HIP_TRY(hipMemsetAsync(y.flags, 0, 32, c->stream));  // not [8]: the stuffed-byte count stays
@@ -2487,9 +2487,9 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
       }
       const bool settled = hyp_done || fl[4 + max_rounds % 3] == 0;
       if (rst_sync && getenv("UHDR_HIP_HUFF_DEBUG"))
-        fprintf(stderr, "uhdr_hip: restart file through the parallel decoder: %s, status bits %#x, %u markers dropped (%d expected), %u interval ends on the true path\n",
-                settled ? "settled" : "NOT settled", fl[1], fl[9], a.nseg - 1, fl[7]);
-      if (settled && rst_sync && ((fl[1] & 14u) != 0 || fl[9] != (uint32_t)(a.nseg - 1) || fl[7] != fl[9])) {
+        fprintf(stderr, "uhdr_hip: restart file through the parallel decoder: %s, status bits %#x, %u markers dropped (%d expected), sequence sums %s\n",
+                settled ? "settled" : "NOT settled", fl[1], fl[9], a.nseg - 1, fl[0] == fl[16] && fl[7] == fl[17] ? "equal" : "DIFFERENT");
+      if (settled && rst_sync && ((fl[1] & 14u) != 0 || fl[9] != (uint32_t)(a.nseg - 1) || fl[0] != fl[16] || fl[7] != fl[17])) {
         // a restart file that is not what its headers say (markers missing, misplaced or out of step, damaged data): the
         // interval decoder below looks at every marker and words the error
         for (int i = 0; i < a.ncomp; i++) HIP_TRY(hipMemsetAsync(a.coef[i], 0, zero_bytes[i], c->stream));

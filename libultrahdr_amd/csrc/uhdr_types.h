@@ -308,7 +308,7 @@ struct HuffSyncArgs {
   uint8_t* changed[2];
   uint32_t* nblk;             // blocks completed per subsequence; later their exclusive scan
   uint32_t* scan_tmp;         // scratch of that scan: one word per 2048 subsequences
-  uint32_t* flags;            // [1]: status bits (2 bad code / run, 4 restart marker out of place, 8 truncated); [9]: restart markers found; [4..6]: change counters of the rounds (r % 3); [8]: stuffed bytes
+  uint32_t* flags;            // [1]: status bits (2 bad code / run, 4 restart marker out of place, 8 truncated); [9]: restart markers found, [16] [17]: their sequence sums, [0] [7]: the sums the write pass expects; [4..6]: change counters of the rounds (r % 3); [8]: stuffed bytes
   int* dcd;                   // DC differences of all blocks in scan order
   uint32_t total_blocks;
   int blocks_per_mcu, ncomp, mcus_per_row;
