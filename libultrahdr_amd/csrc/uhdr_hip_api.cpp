@@ -2371,22 +2371,25 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
     const int nch = huff_sync_chunks(data_bytes);
     const uint32_t nsub = huff_sync_max_subsequences(data_bytes, sub_bits);
     const uint32_t total_blocks = (uint32_t)a.total_mcus * (uint32_t)bpm;
-    // scratch[6]: clean | chunk counts | flags[8] | state x 2 | nblk | dcd | changed x 2
+    // scratch[6]: clean | chunk counts | [flags | nblk | dcd | restart map: zeroed with ONE fill] | [state 0 | hypothesis map: one 0xff
+    // fill] | state 1 | ...  (a fill is a 4 us launch of its own on the stream: eleven of them were 45 us of a 395 us decode)
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    const size_t o_clean = take(data_bytes + 16), o_cnt = take((size_t)nch * 4), o_flags = take(128), o_s0 = take((size_t)nsub * 8),
-                 o_s1 = take((size_t)nsub * 8), o_nblk = take((size_t)nsub * 4 + 4), o_dcd = take((size_t)total_blocks * 4),
-                 o_c0 = take(nsub), o_c1 = take(nsub), o_dcp = take((size_t)((total_blocks + 1023) / 1024) * 12 + 16),
+    const size_t rst_words = data_bytes / 32 + 2;
+    const size_t o_clean = take(data_bytes + 16), o_cnt = take((size_t)nch * 4);
+    const size_t o_flags = take(128), o_nblk = take((size_t)nsub * 4 + 4), o_dcd = take((size_t)total_blocks * 4), o_rm = rst_sync ? take(rst_words * 4) : 0;
+    const size_t zero_bytes_sync = off - o_flags;
+    // hypothesis scheme (interleaved scans): one decode per possible block position instead of rounds
+    const size_t o_s0 = take((size_t)nsub * 8), o_hm = use_hyp ? take((size_t)nsub * kHuffHypSlots) : 0;
+    const size_t ff_bytes = off - o_s0;
+    const size_t o_s1 = take((size_t)nsub * 8), o_c0 = take(nsub), o_c1 = take(nsub), o_dcp = take((size_t)((total_blocks + 1023) / 1024) * 12 + 16),
                  o_ft = take(sizeof(HuffFastTable) * 8),  // symbol form x 4, state-tracking form x 4
                  o_st = take(((size_t)nsub / 2048 + 2) * 4), o_vt = take((size_t)4 * kHuffValWords * 4);
-    // hypothesis scheme (interleaved scans): one decode per possible block position instead of rounds
-    const size_t o_hs = use_hyp ? take((size_t)nsub * kHuffHypSlots * 8) : 0, o_hm = use_hyp ? take((size_t)nsub * kHuffHypSlots) : 0,
-                 o_hc = use_hyp ? take((size_t)nsub * kHuffHypSlots * 2) : 0;
+    const size_t o_hs = use_hyp ? take((size_t)nsub * kHuffHypSlots * 8) : 0, o_hc = use_hyp ? take((size_t)nsub * kHuffHypSlots * 2) : 0;
     size_t chain_tiles_off = 0;
     const size_t o_ch = use_hyp ? take(huff_hyp_chain_bytes(data_bytes, sub_bits, &chain_tiles_off)) : 0;  // sized for the smallest subsequences
     (void)chain_tiles_off;
-    const size_t rst_words = data_bytes / 32 + 2;
-    const size_t o_rm = rst_sync ? take(rst_words * 4) : 0, o_ds = rst_sync ? take((size_t)a.nseg * 12) : 0;
+    const size_t o_ds = rst_sync ? take((size_t)a.nseg * 12) : 0, o_rp = rst_sync ? take((size_t)nch * 12) : 0;
     UHDR_TRY(ensure(c->scratch[6], off));
     uint8_t* sb = (uint8_t*)c->scratch[6].p;
     HuffSyncArgs y;
@@ -2409,7 +2412,8 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
       y.rst_map = rst_map;
       y.rst_blocks = (uint32_t)a.ri * (uint32_t)bpm;
       y.dc_seg = (int*)(sb + o_ds);
-      HIP_TRY(hipMemsetAsync(rst_map, 0, rst_words * 4, c->stream));
+      y.rst_partial = (uint32_t*)(sb + o_rp);
+      y.rst_chunks = (uint32_t)nch;
     }
     int j = 0;
     for (int i = 0; i < a.ncomp; i++) {
@@ -2428,9 +2432,7 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
       std::vector<uint32_t> vtabs((size_t)4 * kHuffValWords);
       for (int t = 0; t < 4; t++) make_value_table(ftabs[(size_t)t], (t & 1) == 0, vtabs.data() + (size_t)t * kHuffValWords);
       HIP_TRY(hipMemcpyAsync(sb + o_vt, vtabs.data(), vtabs.size() * 4, hipMemcpyHostToDevice, c->stream));
-      HIP_TRY(hipMemsetAsync(y.flags, 0, 128, c->stream));
-      HIP_TRY(hipMemsetAsync(y.nblk, 0, (size_t)nsub * 4 + 4, c->stream));
-      HIP_TRY(hipMemsetAsync(y.dcd, 0, (size_t)total_blocks * 4, c->stream));
+      HIP_TRY(hipMemsetAsync(y.flags, 0, zero_bytes_sync, c->stream));  // flags, nblk, dcd and the restart map
       int final_buf = 0;
       uint32_t fl[18] = {};  // [9]: restart markers the unstuff pass dropped, [16] [17] / [0] [7]: their sequence sums as found / as due
       bool hyp_done = false, unstuffed = false, rounds_ran = false;
@@ -2453,14 +2455,14 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
           y.hyp_map = sb + o_hm;
           y.hyp_cnt = (uint16_t*)(sb + o_hc);
           y.hyp_hist = getenv("UHDR_HIP_HUFF_DEBUG") ? 1 : 0;
-          HIP_TRY(hipMemsetAsync(y.hyp_map, 0xff, (size_t)nsub_t * kHuffHypSlots, c->stream));
-          HIP_TRY(hipMemsetAsync(y.state[0], 0xff, (size_t)nsub_t * 8, c->stream));  // a start state the write pass skips, should the chain be lost
+          // hyp_map <- 0xff (unmapped); state[0] <- 0xff: a start state the write pass skips, should the chain be lost
+          HIP_TRY(hipMemsetAsync(y.state[0], 0xff, ff_bytes, c->stream));
           // hyp_cnt needs no initialisation: a slot's count is written together with its map entry, and only mapped slots are read
           size_t tiles_off = 0;
           (void)huff_hyp_chain_bytes(data_bytes, t.sub_bits, &tiles_off);
           {
             ProfScope ps(c, "huffman_decode");
-            if (!unstuffed) HIP_TRY(launch_huffman_unstuff(data, (uint32_t)data_bytes, (uint32_t*)(sb + o_cnt), y.flags + 8, sb + o_clean, c->stream, rst_map, y.flags + 9));
+            if (!unstuffed) HIP_TRY(launch_huffman_unstuff(data, (uint32_t)data_bytes, (uint32_t*)(sb + o_cnt), y.flags + 8, sb + o_clean, c->stream, rst_map, y.rst_partial));
             unstuffed = true;
             HIP_TRY(launch_huffman_decode_hyp(y, (int*)(sb + o_dcp), sb + o_ch, sb + o_ch + tiles_off, c->stream));
           }
@@ -2476,7 +2478,7 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
         } else {
           {
             ProfScope ps(c, "huffman_decode");
-            if (!unstuffed) HIP_TRY(launch_huffman_unstuff(data, (uint32_t)data_bytes, (uint32_t*)(sb + o_cnt), y.flags + 8, sb + o_clean, c->stream, rst_map, y.flags + 9));
+            if (!unstuffed) HIP_TRY(launch_huffman_unstuff(data, (uint32_t)data_bytes, (uint32_t*)(sb + o_cnt), y.flags + 8, sb + o_clean, c->stream, rst_map, y.rst_partial));
             unstuffed = true;
             HIP_TRY(launch_huffman_decode_sync(y, max_rounds, (int*)(sb + o_dcp), &final_buf, c->stream));
           }

@@ -330,6 +330,8 @@ struct HuffSyncArgs {
   const uint32_t* rst_map;    // one bit per byte of the clean stream: an interval starts here
   uint32_t rst_blocks;        // blocks per interval (restart interval x blocks per MCU)
   int* dc_seg;                // [intervals][3]: the components' running DC sums before the interval
+  uint32_t* rst_partial;      // [unstuff chunks][3]: markers found | their two sequence sums, per chunk (summed into flags[9], [16], [17])
+  uint32_t rst_chunks;
 };
 constexpr int kHuffHypSlots = 48;
 // scratch of the chain kernels: per-thread prefix maps, then the tile maps
@@ -338,7 +340,7 @@ hipError_t launch_huffman_decode_hyp(const HuffSyncArgs& a, int* dc_partial, uin
 int huff_sync_chunks(uint64_t nbytes);
 uint32_t huff_sync_max_subsequences(uint64_t nbytes, uint32_t sub_bits);
 hipError_t launch_huffman_unstuff(const uint8_t* data, uint32_t nbytes, uint32_t* chunk_counts, uint32_t* nstuffed_dev, uint8_t* clean, hipStream_t s,
-                                  uint32_t* rst_map = nullptr, uint32_t* rst_count = nullptr);
+                                  uint32_t* rst_map = nullptr, uint32_t* rst_partial = nullptr);
 hipError_t launch_huffman_decode_sync(const HuffSyncArgs& a, int max_rounds, int* dc_partial, int* final_buf, hipStream_t s);
 int huff_marker_chunks(uint64_t nbytes);
 hipError_t launch_huffman_decode(const HuffDecArgs& a, uint32_t* counts, uint32_t* starts, uint32_t* ends, hipStream_t s);
