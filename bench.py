@@ -938,7 +938,19 @@ def extras(ctx, u, device):
     res["huffman_encode_4k_420_q95"] = {"us": round(ms * 1e3, 1), "Mpx/s": round(w * h / (ms / 1e3) / 1e6, 1), "jpeg_scan_bytes": nbytes[0],
                                         "GB/s_coef_in": round(3.0 * w * h / (ms / 1e3) / 1e9, 1),
                                         "stages": "one wavefront per restart interval (10 MCUs; two launches = two LDS size classes) -> interval sizes -> offsets -> gather with RSTn markers"}
-    # ... and back: the same stream -> coefficients, one lane per restart interval (markers located on the device)
+    # ... the stream the reference itself writes: no restart markers (three passes over all blocks)
+    try:
+        def huff0():
+            nbytes[0] = int(u.huffman_encode(hco, w, h, [(2, 2), (1, 1), (1, 1)], 0, out=hout).numel())
+
+        ms = time_kernel(ctx, huff0, iters=5, warm=2)
+        res["huffman_encode_4k_420_q95_no_restart_markers"] = {
+            "us": round(ms * 1e3, 1), "Mpx/s": round(w * h / (ms / 1e3) / 1e6, 1), "jpeg_scan_bytes": nbytes[0],
+            "stages": "code lengths per block (DC difference from the neighbour's DC) -> scan of the bit lengths -> emit at bit offsets -> 0xFF count, scan, stuff"}
+    except Exception as e:  # noqa: BLE001
+        res["huffman_encode_4k_420_q95_no_restart_markers"] = {"error": f"{type(e).__name__}: {e}"}
+    # ... and back: the same frame with restart markers -> coefficients (long intervals: the parallel decoder with the markers
+    # spliced out; short ones: one lane per interval)
     try:
         for ri_ in (10, 2):
             stream = u.huffman_encode(hco, w, h, [(2, 2), (1, 1), (1, 1)], ri_, out=hout).clone()
