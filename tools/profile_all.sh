@@ -3,8 +3,10 @@
 #   1. --kernel-trace --stats of ONE process that launches each kernel a few times (tools/qbench.py)
 #   2. FETCH_SIZE, WRITE_SIZE and two SQ groups, each --pmc group in its own pass (never combined with API traces)
 # Outputs under gpurun_out/prof_all/; tools/read_prof.py turns them into the text committed under profiles/.
-OUT=$PWD/gpurun_out/${PROF_DIR:-prof_all}
-mkdir -p $OUT
+# databases stay in /tmp on the GPU box (gpurun copies back at most 64 MiB): only the summary and the logs go to gpurun_out/
+KEEP=$PWD/gpurun_out/${PROF_DIR:-prof_all}
+OUT=/tmp/${PROF_DIR:-prof_all}
+rm -rf $OUT; mkdir -p $OUT $KEEP
 R=${GRAFT_REPO_ROOT:-/root/repo}
 CASES="${@:-8kC 8kB 8kA 4kAhlg 4kApq b32hlg tm4k gen4k gen4k1 tm8k api0f fdct4k idct4k cvt4k huff4k}"
 export QB_REPS=1 QB_ITERS=4 QB_NO_SERIAL=1
@@ -29,4 +31,5 @@ i=0
   limited rocprofv3 --pmc $G -d $OUT/pmc$i -o p -- python $R/tools/qbench.py $CASES > $OUT/pmc$i.log 2>&1 || echo "pmc group $i failed" >> $OUT/errors.log
 done
 python $R/tools/read_prof.py $OUT > $OUT/summary.txt 2>&1
+cp $OUT/summary.txt $OUT/*.log $KEEP/ 2>/dev/null
 tail -3 $OUT/trace.log

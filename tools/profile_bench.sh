@@ -3,8 +3,10 @@
 # one pass per PMC group (never combined with API traces), each in its own process group with a hard time limit so that
 # a profiler that does not come back cannot eat the box's time.  Outputs under gpurun_out/prof_bench/;
 #   python tools/read_prof.py gpurun_out/prof_bench > profiles/rNN_bench_mapC_batch16_rocprofv3.txt
-OUT=$PWD/gpurun_out/prof_bench
-rm -rf $OUT && mkdir -p $OUT
+# databases stay in /tmp on the GPU box (gpurun copies back at most 64 MiB): only the summary and the logs go to gpurun_out/
+KEEP=$PWD/gpurun_out/prof_bench
+OUT=/tmp/prof_bench
+rm -rf $OUT $KEEP && mkdir -p $OUT $KEEP
 R=${GRAFT_REPO_ROOT:-/root/repo}
 LIMIT=${LIMIT:-150}
 limited() {  # run "$@" in its own session; SIGKILL the whole group after $LIMIT seconds
@@ -28,4 +30,5 @@ for G in "FETCH_SIZE" "WRITE_SIZE"; do
   limited rocprofv3 --pmc $G -d $OUT/pmc$i -o p -- $CMD > $OUT/pmc$i.log 2>&1 || echo "pmc group $i failed / timed out" >> $OUT/errors.log
 done
 python $R/tools/read_prof.py $OUT > $OUT/summary.txt 2>&1
+cp $OUT/summary.txt $OUT/*.log $KEEP/ 2>/dev/null
 cat $OUT/summary.txt | cut -c1-200 | head -20
