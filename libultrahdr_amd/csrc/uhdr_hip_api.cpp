@@ -234,8 +234,15 @@ ImageViewMut view_mut_of(const uhdr_raw_image_t* im) {
 
 // Stage a host image into device scratch `slot` (all planes packed back to back, 256-B aligned);
 // *dev gets device plane pointers.  upload=false only reserves space (outputs).
+// a host buffer is about to be (re)written by the library: whatever device copy was kept for it is stale
+void resident_drop(uhdr_hip_ctx* c, const void* host_plane0) {
+  for (auto& r : c->resident)
+    if (r.valid && r.host[0] == host_plane0) r.valid = false;
+}
+
 uhdr_error_info_t stage_in(uhdr_hip_ctx* c, int slot, const uhdr_raw_image_t* host, uhdr_raw_image_t* dev,
                            bool upload) {
+  if (!upload && c->resident_on) resident_drop(c, host->planes[0]);  // an output: stage_out will overwrite the host planes
   if (upload && c->resident_on) {  // an image uhdr_hip_jpeg_decode_scan wrote in this session is still on the device
     for (auto& r : c->resident) {
       if (!r.valid || r.fmt != host->fmt || host->w > r.w || host->h > r.h) continue;
@@ -279,11 +286,12 @@ uhdr_error_info_t stage_out(uhdr_hip_ctx* c, const uhdr_raw_image_t* dev, uhdr_r
     if (!plane_geom(host, pl, &rows, &width) || rows == 0 || !host->planes[pl]) continue;
     const size_t bps = bytes_per_sample(host->fmt);
     const size_t pitch = (size_t)host->stride[pl] * bps;
-    if (rows == 1 || pitch == width * bps) {
+    const size_t dpitch = (size_t)dev->stride[pl] * bps;  // differs from the host's only for a device-resident copy (stage_in)
+    if (dpitch == pitch && (rows == 1 || pitch == width * bps)) {
       HIP_TRY(hipMemcpyAsync(host->planes[pl], dev->planes[pl], ((rows - 1) * (size_t)host->stride[pl] + width) * bps,
                              hipMemcpyDeviceToHost, c->stream));
     } else {
-      HIP_TRY(hipMemcpy2DAsync(host->planes[pl], pitch, dev->planes[pl], pitch, width * bps, rows,
+      HIP_TRY(hipMemcpy2DAsync(host->planes[pl], pitch, dev->planes[pl], dpitch, width * bps, rows,
                                hipMemcpyDeviceToHost, c->stream));
     }
   }
@@ -2656,7 +2664,12 @@ uhdr_error_info_t uhdr_hip_jpeg_decode_scan(uhdr_hip_ctx_t* c, const uhdr_hip_jp
   if (hs.error_code != UHDR_CODEC_OK) return hs;
   uhdr_hip_ctx::Resident* res = c->resident_on ? &c->resident[c->resident_next++ % 2] : nullptr;
   DeviceBuf* out_buf = res ? &res->buf : &c->jpg[4];
-  if (res) { const DeviceBuf keep = res->buf; *res = uhdr_hip_ctx::Resident(); res->buf = keep; }
+  if (res) {
+    const DeviceBuf keep = res->buf;
+    *res = uhdr_hip_ctx::Resident();
+    res->buf = keep;
+    resident_drop(c, planes[0]);  // an older copy of what this call overwrites on the host
+  }
   if (out_channels == 0) {
     size_t pitch[3] = {0, 0, 0}, off[3] = {0, 0, 0}, total = 0;
     for (int i = 0; i < nc; i++) {

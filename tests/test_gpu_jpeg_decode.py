@@ -261,7 +261,7 @@ def test_decoded_images_stay_on_the_device_for_the_apply_stage(uhdr):
     upload path; outside a session, or after the session is reopened, the host planes are what counts."""
     from libultrahdr_amd.images import Image
 
-    w, h = 640, 352
+    w, h = 656, 352  # 656: the device copies have a 64-aligned pitch (704), the host planes do not
     rng = np.random.default_rng(4242)
     _, _, base_jpeg = _file(rng, w, h, S420, 0)
     _, _, map_jpeg = _file(rng, w, h, S444, 0)
@@ -315,9 +315,31 @@ def test_decoded_images_stay_on_the_device_for_the_apply_stage(uhdr):
         changed = apply()
         assert stats() == h0 + 2 and not np.array_equal(changed, want)
         base[0][:] = 255 - base[0]
+        # a second file decoded into the same base buffers: the newer copy counts, the older one is dropped
+        _, _, base_jpeg2 = _file(rng, w, h, S420, 0)
+        uhdr.jpeg_decode(base_jpeg, outs=base)
+        uhdr.jpeg_decode(base_jpeg2, outs=base)
+        uhdr.jpeg_decode(map_jpeg, 4, outs=gmap)
+        newer = apply()
+        assert stats() == h0 + 4
+        uhdr.lib.uhdr_hip_resident_begin(uhdr.ctx.handle)
+        assert np.array_equal(newer, apply()) and not np.array_equal(newer, want)
+        # an in-place operator on a resident image (convertYuv) works on the device copy and brings the host planes along
+        uhdr.jpeg_decode(base_jpeg, outs=base)
+        uhdr.convertYuv(sdr_img, A.UHDR_CG_BT_709, A.UHDR_CG_DISPLAY_P3)
+        assert stats() == h0 + 5
+        converted = [p.copy() for p in base]
+        uhdr.lib.uhdr_hip_resident_begin(uhdr.ctx.handle)
+        uhdr.jpeg_decode(base_jpeg, outs=base)
+        uhdr.lib.uhdr_hip_resident_begin(uhdr.ctx.handle)  # dropped: the upload route
+        uhdr.convertYuv(sdr_img, A.UHDR_CG_BT_709, A.UHDR_CG_DISPLAY_P3)
+        assert stats() == h0 + 5
+        for a, b in zip(converted, base):
+            assert np.array_equal(a, b)
+        uhdr.jpeg_decode(base_jpeg, outs=base)
     finally:
         uhdr.lib.uhdr_hip_resident_end(uhdr.ctx.handle)
-    assert np.array_equal(apply(), want) and stats() == h0 + 2  # after _end nothing is kept
+    assert np.array_equal(apply(), want) and stats() == h0 + 5  # after _end nothing is kept
 
 
 def test_progressive_files_are_not_for_this_path(uhdr):
