@@ -325,6 +325,31 @@ def fuzz_huffman():
     note("huffman-decode", all(np.array_equal(b.cpu().numpy(), c) for b, c in zip(back, coefs)), f"{w}x{h} {sampling} ri{ri}")
 
 
+def fuzz_huffman_streams():
+    """Decode only, frames large enough for the self-synchronising decoder (>= 4 KiB of entropy-coded data): no restart markers
+    -- what the reference writes -- or restart intervals of any length (long ones are spliced out and take the same decoder,
+    short ones one lane each); the oracle's stream must come back as the coefficients that went in."""
+    ncomp = int(rng.choice([1, 3]))
+    sampling = [(1, 1)] if ncomp == 1 else ([(2, 2), (1, 1), (1, 1)] if rng.random() < 0.6 else ([(2, 1), (1, 1), (1, 1)] if rng.random() < 0.5 else [(1, 1)] * 3))
+    w, h = int(rng.integers(200, 1100)), int(rng.integers(64, 420))
+    hmax, vmax = max(s_[0] for s_ in sampling), max(s_[1] for s_ in sampling)
+    mcus = -(-w // (8 * hmax)) * -(-h // (8 * vmax))
+    ri = 0 if rng.random() < 0.3 else int(rng.integers(1, max(2, mcus // 2)))
+    density = float(rng.choice([0.03, 0.08, 0.15]))
+    amp = int(rng.choice([3, 40, 300]))
+    coefs = []
+    for hs, vs in sampling:
+        cw, chh = -(-w * hs // hmax), -(-h * vs // vmax)
+        bw, bh = -(-cw // 8), -(-chh // 8)
+        a = (rng.integers(-amp, amp + 1, (bh, bw, 64)) * (rng.random((bh, bw, 64)) < density)).astype(np.int16)
+        a[..., 0] = rng.integers(-1020, 1021, (bh, bw))
+        coefs.append(np.ascontiguousarray(a))
+    scan = L.huffman_encode_port(coefs, w, h, sampling, ri)
+    data = torch.from_numpy(np.frombuffer(scan, dtype=np.uint8).copy()).to("cuda:0")
+    back = u.huffman_decode(data, [c.shape[:2] for c in coefs], w, h, sampling, ri)
+    note("huffman-decode-streams", all(np.array_equal(b.cpu().numpy(), c) for b, c in zip(back, coefs)), f"{w}x{h} {sampling} ri{ri} density{density} amp{amp} {len(scan)} B")
+
+
 JOBS = None
 
 
@@ -332,7 +357,7 @@ def run(seconds, seed=1, context=None, log=None):
     """Runs the sweep for `seconds`; returns (stats, mismatches).  `log`: a path that receives the summary line."""
     init(seed, context)
     jobs = [fuzz_huffman, fuzz_apply, fuzz_apply, fuzz_apply, fuzz_generate, fuzz_generate_formats, fuzz_tonemap, fuzz_tonemap_formats,
-            fuzz_converts, fuzz_decode_fused]
+            fuzz_converts, fuzz_decode_fused, fuzz_huffman_streams]
     t_end = time.time() + seconds
     i = 0
     while time.time() < t_end:
