@@ -28,8 +28,9 @@
  *   uhdr_hip_fdct_quant_rgb_dev (colour conversion + FDCT of a 3-channel map in one pass),
  *   uhdr_hip_idct_dequant_rgb_dev (its decode-side mirror: dequant + IDCT + colour conversion in one pass),
  *   uhdr_hip_apply_gainmap_coef_dev (applyGainMap on a base image still in coefficient form: IDCT inside the kernel),
- *   uhdr_hip_huffman_encode_dev + uhdr_hip_jpeg_assemble (baseline Huffman entropy coding, one restart interval per
- *   wavefront, and the file wrapper around it), uhdr_hip_huffman_decode_dev (its inverse, one interval per lane), uhdr_hip_jpeg_parse (host: the headers of a
+ *   uhdr_hip_huffman_encode_dev + uhdr_hip_jpeg_assemble (baseline Huffman entropy coding, without restart markers or one
+ *   restart interval per wavefront, and the file wrapper around it), uhdr_hip_huffman_decode_dev (its inverse: the
+ *   self-synchronising parallel decoder, or one interval per lane), uhdr_hip_jpeg_parse (host: the headers of a
  *   baseline JPEG file, in the form those entry points take)
  *
  * Same argument meaning and error behaviour as the reference: uhdr_error_info_t is returned by
@@ -434,13 +435,17 @@ uhdr_error_info_t uhdr_hip_apply_gainmap_coef_dev(uhdr_hip_ctx_t* ctx,
 /* ---- JPEG entropy stage (the step after uhdr_hip_fdct_quant) ---------------------------------
  * Baseline Huffman coding of quantized coefficient blocks with the Annex K tables -- what libjpeg does behind
  * JpegEncoderHelper::compressImage (jpegencoderhelper.cpp:131-244: jpeg_set_defaults, optimize_coding off).  libjpeg's
- * single sequential pass chains every block to its predecessor through the DC prediction; the parallel form uses
- * JPEG's own restart intervals (T.81 B.2.4.4): every restart_interval MCUs the stream is byte-aligned, an RSTn marker
- * is written and the predictors reset, so one wavefront encodes one interval (<= 64 blocks: restart_interval <= 10
- * for 4:2:0, <= 21 for 4:4:4, <= 64 for one component).  Parity policy: the entropy-coded data is byte-identical to
- * what libjpeg emits for the same coefficients with cinfo.restart_interval set to the same value (dummy blocks at the
- * right / bottom edge included); relative to the reference's files that adds a DRI segment and the RSTn markers, the
- * decoded coefficients are identical.
+ * single sequential pass chains every block to its predecessor through the DC prediction.  Two parallel forms:
+ * restart_interval == 0 -- the stream the reference itself writes (jpegencoderhelper.cpp:187-201 never sets
+ * cinfo.restart_interval): nothing in encoding is serial on a device that holds all coefficients (a block's DC
+ * difference needs its predecessor's DC VALUE, its bit position is a prefix sum of code lengths, byte stuffing a prefix
+ * sum of 0xFF counts): lengths -> scan -> emit -> stuff, three passes over all blocks; the bytes are libjpeg's.
+ * restart_interval > 0 -- JPEG's own restart intervals (T.81 B.2.4.4): every restart_interval MCUs the stream is
+ * byte-aligned, an RSTn marker is written and the predictors reset, so one wavefront encodes one interval (<= 64 blocks:
+ * restart_interval <= 10 for 4:2:0, <= 21 for 4:4:4, <= 64 for one component); this is the form that shards over ranks.
+ * Parity policy: the entropy-coded data is byte-identical to what libjpeg emits for the same coefficients with
+ * cinfo.restart_interval set to the same value (dummy blocks at the right / bottom edge included); with intervals that
+ * adds a DRI segment and the RSTn markers relative to the reference's files, the decoded coefficients are identical.
  * coef[c]: DEVICE JBLOCK arrays (as uhdr_hip_fdct_quant_dev writes them) of blocks_w[c] x blocks_h[c] blocks, between
  * the component's real grid (jpeg_component_info::width_in_blocks / height_in_blocks) and the MCU-padded grid; blocks
  * an MCU needs beyond the array are libjpeg's dummy blocks.  One component: non-interleaved scan (an MCU is a block).
@@ -455,7 +460,7 @@ typedef struct uhdr_hip_jpeg_scan {
   int h_samp[3];          /* sampling factors, 1 or 2 (ignored for one component) */
   int v_samp[3];
   unsigned int w, h;      /* image dimensions in pixels */
-  int restart_interval;   /* in MCUs */
+  int restart_interval;   /* in MCUs; 0 = no restart markers */
 } uhdr_hip_jpeg_scan_t;
 uhdr_error_info_t uhdr_hip_huffman_encode_dev(uhdr_hip_ctx_t* ctx, const uhdr_hip_jpeg_scan_t* scan,
                                               uint8_t* out, size_t out_capacity, size_t* out_bytes);
@@ -465,7 +470,10 @@ uhdr_error_info_t uhdr_hip_huffman_encode_dev(uhdr_hip_ctx_t* ctx, const uhdr_hi
  * interval is decoded by its own lane.  A stream without them (restart_interval 0 -- every file the reference writes) is
  * ONE interval: it is decoded by the self-synchronising parallel decoder (huffman_decode_sync.hip: sub-sequences of the
  * bit stream are decoded speculatively and re-decoded until every hand-over state agrees with its predecessor's end
- * state), falling back to a single lane only for streams shorter than 4 KiB or if the search does not settle.
+ * state), falling back to a single lane only for streams shorter than 4 KiB or if the search does not settle.  Restart
+ * files whose intervals are long (>= 320 bytes on average: one lane per interval would leave the device idle) take the
+ * same decoder with the markers spliced out; one that is not what its headers say is handed to the interval decoder,
+ * which words the error.
  * scan->coef[c]: DEVICE arrays of blocks_w[c] x blocks_h[c] JBLOCKs, WRITTEN by this call (dummy blocks of edge MCUs are
  * dropped); data: DEVICE pointer to the bytes between the SOS header and EOI; tables: the file's DHT content in the order
  * DC luma (Tc 0, Th 0), AC luma, DC chroma, AC chroma -- NULL selects the Annex K tables; component 0 uses the luma pair,
@@ -526,8 +534,9 @@ uhdr_error_info_t uhdr_hip_jpeg_decode_scan(uhdr_hip_ctx_t* ctx, const uhdr_hip_
  * (jpegencoderhelper.cpp:131-309) on the device.  FDCT + quantization (uhdr_hip_fdct_quant_dev; for a packed RGB gain map
  * uhdr_hip_fdct_quant_rgb_dev, i.e. rgb_ycc_convert included) feed uhdr_hip_huffman_encode_dev without the coefficient
  * blocks leaving HBM: the samples go up, the compressed bytes come down.
- * scan: geometry (coef pointers ignored); restart_interval must satisfy uhdr_hip_huffman_encode_dev (1..64 / blocks per
- * MCU) -- the data therefore carries RSTn markers, see that function's parity policy.  qtable[c]: natural order.
+ * scan: geometry (coef pointers ignored); restart_interval as for uhdr_hip_huffman_encode_dev: 0 (no markers: the
+ * reference's bytes, what the facade uses) or 1..64 / blocks per MCU (RSTn markers, see that function's parity policy).
+ * qtable[c]: natural order.
  * rgb_channels 0: planes[c] = HOST plane of blocks_w[c]*8 x blocks_h[c]*8 samples (the caller pads to whole blocks as
  * jpegencoderhelper.cpp:246-309 does), strides in bytes; 3 / 4: planes[0] = HOST packed RGB888 / RGBA8888 image of
  * scan->w x scan->h pixels (multiples of 8), strides[0] in PIXELS, for a 3-component 4:4:4 scan.
@@ -554,8 +563,8 @@ void uhdr_hip_resident_end(uhdr_hip_ctx_t* ctx);
  * with UHDR_CODEC_UNSUPPORTED_FEATURE -- behind the libuhdr.so facade libjpeg then decodes it on the CPU; this is the place
  * where that shows without a trace. */
 typedef struct uhdr_hip_stats {
-  unsigned long long entropy_decode_parallel;     /* marker-less scans: self-synchronising parallel decode */
-  unsigned long long entropy_decode_intervals;    /* restart-interval scans: one lane per interval */
+  unsigned long long entropy_decode_parallel;     /* self-synchronising parallel decode: marker-less scans, restart files with long intervals */
+  unsigned long long entropy_decode_intervals;    /* restart-interval scans decoded one lane per interval */
   unsigned long long entropy_decode_single_lane;  /* marker-less scans small enough for one lane */
   unsigned long long entropy_decode_declined;     /* handed back to the caller (see above) */
   unsigned long long entropy_encode_stream;       /* marker-less scans written (the reference's bytes) */
