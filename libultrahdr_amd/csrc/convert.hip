@@ -13,7 +13,9 @@ namespace {
 constexpr int kBlock = 256;
 
 __device__ __forceinline__ uint8_t st8(float v) {  // static_cast<uint8_t>(CLIP3(v, 0, 255))
-  v = (v < 0.0f) ? 0.0f : ((v > 255.0f) ? 255.0f : v);
+  // one three-operand median instead of two compares and two selects (the arguments are finite: sums of products of
+  // 8- / 10-bit samples; a NaN would come out as 0 either way -- v_med3 falls back to min3, the cast of NaN is 0)
+  v = __builtin_amdgcn_fmed3f(v, 0.0f, 255.0f);
   return (uint8_t)v;
 }
 
@@ -80,6 +82,12 @@ typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint32_t byte_of(uint32_t w, int k) { return (w >> (8 * k)) & 0xffu; }
 __device__ __forceinline__ uint32_t cvt8(float v) { return (uint32_t)st8(v); }
 
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2v splat2(float v) { return (f2v){v, v}; }
+// The two pixels of a quad row travel as a 2-vector: every operation below is one IEEE multiply / add per element in
+// the order of mat3_apply ((m0 * y + m1 * u) + m2 * v; the chroma products are the same for the quad's four pixels), so the
+// bytes are those of the per-pixel kernel; written out because the compiler's own pairing came and went with unrelated
+// changes (390 - 421 VALU instructions per 16 pixels, 294 in this form).
 __global__ __launch_bounds__(kBlock) void transform_yuv420_wide_kernel(const YuvXformParams p) {
   const uint32_t tw = p.img.w / 8, qh = p.img.h / 2;  // tiles of 8 x 2 pixels
   const uint32_t total = tw * qh;
@@ -89,6 +97,8 @@ __global__ __launch_bounds__(kBlock) void transform_yuv420_wide_kernel(const Yuv
   const uint32_t sy = p.img.stride[0], su = p.img.stride[1], sv = p.img.stride[2];
   const Mat3 c = p.c;
   const float k255 = 1 / 255.0f;
+  const f2v m0 = splat2(c.m[0]), m3 = splat2(c.m[3]), m6 = splat2(c.m[6]), s255 = splat2(255.0f), half = splat2(0.5f), n255 = splat2(k255);
+  const f2v m12 = {c.m[1], c.m[2]}, m45 = {c.m[4], c.m[5]}, m78 = {c.m[7], c.m[8]};
   for (uint32_t t = blockIdx.x * kBlock + threadIdx.x; t < total; t += gridDim.x * kBlock) {
     const uint32_t qy = t / tw, tx = t - qy * tw;
     uint8_t* y0p = yp + ((size_t)(2 * qy) * sy + tx * 8);
@@ -100,17 +110,21 @@ __global__ __launch_bounds__(kBlock) void transform_yuv420_wide_kernel(const Yuv
     uint32_t o0[2] = {0, 0}, o1[2] = {0, 0}, ou = 0, ov = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) {  // quad q: pixels 2q, 2q + 1 of both rows, chroma sample q
-      const float u = (float)((int)byte_of(uu, q) - 128) * k255, v = (float)((int)byte_of(vv, q) - 128) * k255;
+      const f2v uv = (f2v){(float)((int)byte_of(uu, q) - 128), (float)((int)byte_of(vv, q) - 128)} * n255;  // {u, v}
       const uint32_t w0 = q < 2 ? r0.x : r0.y, w1 = q < 2 ? r1.x : r1.y;
       const int b = (q & 1) * 2;
-      const Color3 a = mat3_apply({(float)byte_of(w0, b) * k255, u, v}, c);
-      const Color3 bb = mat3_apply({(float)byte_of(w0, b + 1) * k255, u, v}, c);
-      const Color3 cc = mat3_apply({(float)byte_of(w1, b) * k255, u, v}, c);
-      const Color3 d = mat3_apply({(float)byte_of(w1, b + 1) * k255, u, v}, c);
-      const float nu = (((a.g + bb.g) + cc.g) + d.g) / 4.0f;
-      const float nv = (((a.b + bb.b) + cc.b) + d.b) / 4.0f;
-      o0[q >> 1] |= (cvt8(a.r * 255.0f + 0.5f) | (cvt8(bb.r * 255.0f + 0.5f) << 8)) << (16 * (q & 1));
-      o1[q >> 1] |= (cvt8(cc.r * 255.0f + 0.5f) | (cvt8(d.r * 255.0f + 0.5f) << 8)) << (16 * (q & 1));
+      const f2v ya = (f2v){(float)byte_of(w0, b), (float)byte_of(w0, b + 1)} * n255;  // row 0: pixels a, bb
+      const f2v yc = (f2v){(float)byte_of(w1, b), (float)byte_of(w1, b + 1)} * n255;  // row 1: pixels cc, d
+      const f2v pr = m12 * uv, pg = m45 * uv, pb = m78 * uv;  // {m1 * u, m2 * v}, ...
+      const f2v ru = splat2(pr.x), rv = splat2(pr.y), gu = splat2(pg.x), gv = splat2(pg.y), bu = splat2(pb.x), bv = splat2(pb.y);
+      const f2v Ra = (m0 * ya + ru) + rv, Rc = (m0 * yc + ru) + rv;
+      const f2v Ga = (m3 * ya + gu) + gv, Gc = (m3 * yc + gu) + gv;
+      const f2v Ba = (m6 * ya + bu) + bv, Bc = (m6 * yc + bu) + bv;
+      const float nu = (((Ga.x + Ga.y) + Gc.x) + Gc.y) / 4.0f;
+      const float nv = (((Ba.x + Ba.y) + Bc.x) + Bc.y) / 4.0f;
+      const f2v La = Ra * s255 + half, Lc = Rc * s255 + half;
+      o0[q >> 1] |= (cvt8(La.x) | (cvt8(La.y) << 8)) << (16 * (q & 1));
+      o1[q >> 1] |= (cvt8(Lc.x) | (cvt8(Lc.y) << 8)) << (16 * (q & 1));
       ou |= cvt8(nu * 255.0f + 128.0f + 0.5f) << (8 * q);
       ov |= cvt8(nv * 255.0f + 128.0f + 0.5f) << (8 * q);
     }
