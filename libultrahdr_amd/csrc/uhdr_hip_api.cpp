@@ -106,6 +106,7 @@ struct uhdr_hip_ctx {
     unsigned int host_stride[3] = {};   // ... and their strides, in samples
     size_t off[3] = {};
     unsigned int dev_stride[3] = {};
+    unsigned int prows[3] = {}, pcols[3] = {};  // samples of every plane the device copy holds
   } resident[2];
   bool resident_on = false;
   unsigned int resident_next = 0;
@@ -278,6 +279,53 @@ uhdr_error_info_t stage_in(uhdr_hip_ctx* c, int slot, const uhdr_raw_image_t* ho
   }
   return ok_status();
 }
+// Inside a resident session an 8-bit image the library has just produced (gain map, tone-mapped / converted base image)
+// stays on the device as well, keyed by the host planes it is being copied to: JpegR::encodeJPEGR hands exactly those
+// planes to JpegEncoderHelper::compressImage next (jpegr.cpp:253-316), and uhdr_hip_jpeg_encode_scan then reads the
+// device copy instead of uploading what was downloaded a moment ago.  One device-to-device copy (25 MB: ~10 us).
+uhdr_error_info_t resident_keep(uhdr_hip_ctx* c, const uhdr_raw_image_t* dev, const uhdr_raw_image_t* host) {
+  switch (host->fmt) {
+    case UHDR_IMG_FMT_12bppYCbCr420: case UHDR_IMG_FMT_16bppYCbCr422: case UHDR_IMG_FMT_24bppYCbCr444: case UHDR_IMG_FMT_8bppYCbCr400:
+    case UHDR_IMG_FMT_24bppRGB888: case UHDR_IMG_FMT_32bppRGBA8888: break;
+    default: return ok_status();
+  }
+  resident_drop(c, host->planes[0]);
+  unsigned int slot = c->resident_next++ % 2;
+  {  // an in-place operator may have worked ON a resident copy: that buffer is the source of the copy below, take the other one
+    const DeviceBuf& b = c->resident[slot].buf;
+    const char* d0 = (const char*)dev->planes[0];
+    if (b.p && d0 >= (const char*)b.p && d0 < (const char*)b.p + b.cap) slot ^= 1u;
+  }
+  uhdr_hip_ctx::Resident& r = c->resident[slot];
+  const DeviceBuf keep = r.buf;
+  r = uhdr_hip_ctx::Resident();
+  r.buf = keep;
+  size_t total = 0, bytes[3] = {0, 0, 0};
+  for (int pl = 0; pl < 3; pl++) {
+    bytes[pl] = host->planes[pl] ? plane_bytes(host, pl) : 0;
+    r.off[pl] = total;
+    total += (bytes[pl] + 255) & ~(size_t)255;
+  }
+  if (total == 0) return ok_status();
+  UHDR_TRY(ensure(r.buf, total));
+  const size_t bps = bytes_per_sample(host->fmt);
+  for (int pl = 0; pl < 3; pl++) {
+    size_t rows = 0, width = 0;
+    if (!bytes[pl] || !plane_geom(host, pl, &rows, &width)) continue;
+    const size_t pitch = (size_t)host->stride[pl] * bps, dpitch = (size_t)dev->stride[pl] * bps;
+    HIP_TRY(hipMemcpy2DAsync((char*)r.buf.p + r.off[pl], pitch, dev->planes[pl], dpitch, width * bps, rows, hipMemcpyDeviceToDevice, c->stream));
+    r.host[pl] = host->planes[pl];
+    r.host_stride[pl] = host->stride[pl];
+    r.dev_stride[pl] = host->stride[pl];
+    r.prows[pl] = (unsigned int)rows;
+    r.pcols[pl] = (unsigned int)width;
+  }
+  r.fmt = host->fmt;
+  r.w = host->w;
+  r.h = host->h;
+  r.valid = true;
+  return ok_status();
+}
 // Copies back only the w samples of every row, so the caller's stride padding stays untouched
 // (the reference never writes there either).
 uhdr_error_info_t stage_out(uhdr_hip_ctx* c, const uhdr_raw_image_t* dev, uhdr_raw_image_t* host) {
@@ -295,6 +343,7 @@ uhdr_error_info_t stage_out(uhdr_hip_ctx* c, const uhdr_raw_image_t* dev, uhdr_r
                                hipMemcpyDeviceToHost, c->stream));
     }
   }
+  if (c->resident_on) UHDR_TRY(resident_keep(c, dev, host));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return ok_status();
 }
@@ -2576,11 +2625,27 @@ uhdr_error_info_t uhdr_hip_jpeg_encode_scan(uhdr_hip_ctx_t* c, const uhdr_hip_jp
       off[i] = total;
       total += pitch[i] * (size_t)sc.blocks_h[i] * 8;
     }
-    UHDR_TRY(ensure(c->jpg[4], total));
-    for (int i = 0; i < nc; i++) {
-      uint8_t* d = (uint8_t*)c->jpg[4].p + off[i];
-      HIP_TRY(hipMemcpy2DAsync(d, pitch[i], planes[i], strides[i], (size_t)sc.blocks_w[i] * 8, (size_t)sc.blocks_h[i] * 8, hipMemcpyHostToDevice, c->stream));
-      UHDR_TRY(uhdr_hip_fdct_quant_dev(c, d, pitch[i], sc.blocks_w[i], sc.blocks_h[i], qtable[i], (int16_t*)c->jpg[1 + i].p));
+    // planes the library itself produced a moment ago (resident_keep) are read where they are
+    const uhdr_hip_ctx::Resident* held = nullptr;
+    if (c->resident_on)
+      for (const auto& r : c->resident) {
+        bool ok = r.valid && r.fmt != UHDR_IMG_FMT_24bppRGB888 && r.fmt != UHDR_IMG_FMT_32bppRGBA8888;
+        for (int i = 0; ok && i < nc; i++)
+          ok = r.host[i] == planes[i] && r.host_stride[i] == strides[i] && r.pcols[i] >= (unsigned)sc.blocks_w[i] * 8 && r.prows[i] >= (unsigned)sc.blocks_h[i] * 8;
+        if (ok) { held = &r; break; }
+      }
+    if (held) {
+      c->stats.resident_hits++;
+      for (int i = 0; i < nc; i++)
+        UHDR_TRY(uhdr_hip_fdct_quant_dev(c, (const uint8_t*)held->buf.p + held->off[i], held->dev_stride[i], sc.blocks_w[i], sc.blocks_h[i], qtable[i],
+                                         (int16_t*)c->jpg[1 + i].p));
+    } else {
+      UHDR_TRY(ensure(c->jpg[4], total));
+      for (int i = 0; i < nc; i++) {
+        uint8_t* d = (uint8_t*)c->jpg[4].p + off[i];
+        HIP_TRY(hipMemcpy2DAsync(d, pitch[i], planes[i], strides[i], (size_t)sc.blocks_w[i] * 8, (size_t)sc.blocks_h[i] * 8, hipMemcpyHostToDevice, c->stream));
+        UHDR_TRY(uhdr_hip_fdct_quant_dev(c, d, pitch[i], sc.blocks_w[i], sc.blocks_h[i], qtable[i], (int16_t*)c->jpg[1 + i].p));
+      }
     }
   } else {
     if (nc != 3 || bpm != 3) return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "packed RGB input is a 3-component 4:4:4 scan");
@@ -2589,17 +2654,28 @@ uhdr_error_info_t uhdr_hip_jpeg_encode_scan(uhdr_hip_ctx_t* c, const uhdr_hip_jp
     if (memcmp(qtable[1], qtable[2], 64 * sizeof(uint16_t)))
       return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "packed RGB input with different Cb and Cr quantization tables is outside the HIP path");
     if (!planes[0] || strides[0] < sc.w) return err_status(UHDR_CODEC_INVALID_PARAM, "RGB image: nullptr or stride below the width");
-    const size_t pitch_px = ((size_t)sc.w + 15) & ~(size_t)15;
-    UHDR_TRY(ensure(c->jpg[4], pitch_px * (size_t)rgb_channels * sc.h));
-    HIP_TRY(hipMemcpy2DAsync(c->jpg[4].p, pitch_px * rgb_channels, planes[0], (size_t)strides[0] * rgb_channels, (size_t)sc.w * rgb_channels, sc.h,
-                             hipMemcpyHostToDevice, c->stream));
     uhdr_raw_image_t rgb;
     memset(&rgb, 0, sizeof rgb);
     rgb.fmt = rgb_channels == 3 ? UHDR_IMG_FMT_24bppRGB888 : UHDR_IMG_FMT_32bppRGBA8888;
     rgb.w = sc.w;
     rgb.h = sc.h;
-    rgb.planes[0] = c->jpg[4].p;
-    rgb.stride[0] = (unsigned int)pitch_px;
+    const uhdr_hip_ctx::Resident* held = nullptr;
+    if (c->resident_on)
+      for (const auto& r : c->resident)
+        if (r.valid && r.fmt == rgb.fmt && r.host[0] == planes[0] && r.host_stride[0] == strides[0] && r.pcols[0] >= sc.w && r.prows[0] >= sc.h &&
+            ((size_t)r.dev_stride[0] * rgb_channels) % (rgb_channels == 4 ? 16 : 8) == 0) { held = &r; break; }  // (the fused kernel's row alignment)
+    if (held) {  // the gain map generateGainMap has just written (resident_keep): read where it is
+      c->stats.resident_hits++;
+      rgb.planes[0] = (char*)held->buf.p + held->off[0];
+      rgb.stride[0] = held->dev_stride[0];
+    } else {
+      const size_t pitch_px = ((size_t)sc.w + 15) & ~(size_t)15;
+      UHDR_TRY(ensure(c->jpg[4], pitch_px * (size_t)rgb_channels * sc.h));
+      HIP_TRY(hipMemcpy2DAsync(c->jpg[4].p, pitch_px * rgb_channels, planes[0], (size_t)strides[0] * rgb_channels, (size_t)sc.w * rgb_channels, sc.h,
+                               hipMemcpyHostToDevice, c->stream));
+      rgb.planes[0] = c->jpg[4].p;
+      rgb.stride[0] = (unsigned int)pitch_px;
+    }
     UHDR_TRY(uhdr_hip_fdct_quant_rgb_dev(c, &rgb, qtable[0], qtable[1], (int16_t*)c->jpg[1].p, (int16_t*)c->jpg[2].p, (int16_t*)c->jpg[3].p));
   }
   size_t cap = coef_bytes / 4 + (1u << 20), n = 0;
@@ -2685,7 +2761,10 @@ uhdr_error_info_t uhdr_hip_jpeg_decode_scan(uhdr_hip_ctx_t* c, const uhdr_hip_jp
       const size_t cols = hstride[i] < (unsigned)sc.blocks_w[i] * 8 ? hstride[i] : (size_t)sc.blocks_w[i] * 8;
       const size_t rows = vstride[i] < (unsigned)sc.blocks_h[i] * 8 ? vstride[i] : (size_t)sc.blocks_h[i] * 8;
       HIP_TRY(hipMemcpy2DAsync(planes[i], hstride[i], d, pitch[i], cols, rows, hipMemcpyDeviceToHost, c->stream));
-      if (res) { res->host[i] = planes[i]; res->host_stride[i] = hstride[i]; res->off[i] = off[i]; res->dev_stride[i] = (unsigned int)pitch[i]; }
+      if (res) {
+        res->host[i] = planes[i]; res->host_stride[i] = hstride[i]; res->off[i] = off[i]; res->dev_stride[i] = (unsigned int)pitch[i];
+        res->prows[i] = (unsigned int)rows; res->pcols[i] = (unsigned int)cols;
+      }
     }
     if (res) {
       const int hs0 = nc == 3 ? sc.h_samp[0] : 1, vs0 = nc == 3 ? sc.v_samp[0] : 1;
@@ -2714,6 +2793,7 @@ uhdr_error_info_t uhdr_hip_jpeg_decode_scan(uhdr_hip_ctx_t* c, const uhdr_hip_jp
     if (res) {
       res->fmt = rgb.fmt; res->w = sc.w; res->h = sc.h;
       res->host[0] = planes[0]; res->host_stride[0] = hstride[0]; res->off[0] = 0; res->dev_stride[0] = (unsigned int)pitch_px;
+      res->prows[0] = sc.h; res->pcols[0] = sc.w;
       res->valid = true;
     }
   }
