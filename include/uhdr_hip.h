@@ -551,9 +551,12 @@ uhdr_error_info_t uhdr_hip_jpeg_encode_scan(uhdr_hip_ctx_t* ctx, const uhdr_hip_
  * JpegR::decodeJPEGR (jpegr.cpp:1467-1530) decodes the base image and the gain map into JpegDecoderHelper buffers and hands
  * exactly those buffers to applyGainMap.  Between _begin and _end, uhdr_hip_jpeg_decode_scan keeps what it wrote to the
  * caller's planes on the device (the two most recent images), and a host-buffer entry point that is handed an input image
- * with the same plane pointers, strides and format reads that copy instead of uploading the planes again.  The caller
- * promises not to write to those host buffers in between (call _begin again to drop the copies if it does); outside a
- * _begin/_end pair nothing is kept.  The facade opens one pair per uhdr_encode / uhdr_decode. */
+ * with the same plane pointers, strides and format reads that copy instead of uploading the planes again.  Likewise on the
+ * way out (JpegR::encodeJPEGR, jpegr.cpp:253-316): an 8-bit image a host-buffer entry point has just produced (gain map,
+ * converted base image) stays on the device too, and uhdr_hip_jpeg_encode_scan, handed those host planes, reads it there.
+ * The caller promises not to write to those host buffers in between (call _begin again to drop the copies if it does; the
+ * library drops a copy itself whenever it rewrites the host buffer); outside a _begin/_end pair nothing is kept.  The
+ * facade opens one pair per uhdr_encode / uhdr_decode. */
 void uhdr_hip_resident_begin(uhdr_hip_ctx_t* ctx);
 void uhdr_hip_resident_end(uhdr_hip_ctx_t* ctx);
 
