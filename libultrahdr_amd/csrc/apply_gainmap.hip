@@ -91,7 +91,7 @@ __device__ __forceinline__ uint32_t oetf_code_bucket(float v, uint32_t tab_rel, 
   // LDS address of the entry = table + (bucket - first bucket) * 8: the wave-uniform part (tab_rel) is the add of a v_lshl_add
   asm("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(addr) : "v"(bits >> SH), "s"(tab_rel));
   typedef uint32_t lds_u2 __attribute__((ext_vector_type(2)));
-  const lds_u2 e = *(const __attribute__((address_space(3))) lds_u2*)addr;
+  const lds_u2 e = *(const __attribute__((address_space(3))) lds_u2*)(uintptr_t)addr;  // (uintptr_t: the host pass of the compiler parses this too)
   uint32_t code;
   // s_nop 1: a VALU write of vcc needs two wait states before a VALU reads it as a mask (the compiler inserts the same)
   asm("v_cmp_ge_u32_e32 vcc, %1, %2\n\ts_nop 1\n\tv_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1"

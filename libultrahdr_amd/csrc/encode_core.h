@@ -44,7 +44,7 @@ __device__ __forceinline__ uint32_t step_code(float v, const uint2* tab, const S
   const uint32_t rel = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)tab - t.base8;
   asm("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(addr) : "v"(bits >> (t.shm3 + 3u)), "s"(rel));
   typedef uint32_t lds_u2 __attribute__((ext_vector_type(2)));
-  const lds_u2 e = *(const __attribute__((address_space(3))) lds_u2*)addr;
+  const lds_u2 e = *(const __attribute__((address_space(3))) lds_u2*)(uintptr_t)addr;  // (uintptr_t: the host pass of the compiler parses this too)
   uint32_t code;  // bits >= threshold ? upper : lower half of the entry's second word, picked by the select itself (SDWA)
   // s_nop 1: a VALU write of vcc needs two wait states before a VALU reads it as a mask (the compiler inserts the same)
   asm("v_cmp_ge_u32_e32 vcc, %1, %2\n\ts_nop 1\n\tv_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1"
