@@ -318,6 +318,8 @@ int uhdr_hip_exact_math_eval(int fn, const float* in, float* out, size_t n);
  *   which 1: encodeGain's byte for gain x with min / max boost a / b, gamma 1  (gainmapmath.cpp:758-771)
  *   which 2 / 3: the HLG / PQ decode tail's 10-bit code               (jpegr.cpp:1775-1805)
  *   which 4 / 5: the same including the nit scaling in front of it, code(clamp01((x * 203) / peak))
+ *   which 6: a synthetic staircase on [0, 1] for tests: code 0 below a (its bit pattern rounded down to a bucket start of
+ *            2^15 patterns), one more at a and every b bit patterns (likewise rounded) after it -- steps exactly on bucket starts
  * info (may be NULL) receives {verified exact, entries, shift, first bucket}.  Returns 0; 1 when the table could not be
  * verified exact for these parameters (the kernels then keep the arithmetic evaluation); -1 for a bad argument. */
 int uhdr_hip_step_table_eval(int which, float a, float b, const float* in, uint32_t* out, size_t n, uint32_t info[4]);

@@ -4,6 +4,7 @@
 // do not round identically to glibc's.  See host_tables.cpp for the per-call-site float/double
 // notes.
 #pragma once
+#include <functional>
 #include <vector>
 
 #include "uhdr_types.h"
@@ -30,6 +31,7 @@ struct OetfBuckets {
   bool exact = false;                   // construction verified (one threshold per bucket, replay against the composite)
   std::vector<uint32_t> entries;        // n x {thr, lo | hi << 16}
 };
+OetfBuckets build_step_table(const std::function<uint32_t(uint32_t)>& code_of_bits, uint32_t lo_bits, uint32_t hi_bits, uint32_t shift, uint32_t capacity);
 const OetfBuckets& oetf_code_buckets(int ct, bool prescaled = false);  // prescaled: argument is the value before (x * 203) / peak
 // encode side (see host_tables.cpp): toneMap's sRGB byte, encodeGain's byte, RGBA1010102 code -> linear value
 const OetfBuckets& srgb_code8_buckets();

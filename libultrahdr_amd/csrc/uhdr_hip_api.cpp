@@ -1722,6 +1722,17 @@ int uhdr_hip_step_table_eval(int which, float a, float b, const float* in, uint3
     t = &tmp;
   } else if (which == 2 || which == 3) t = &host::oetf_code_buckets(which == 2 ? UHDR_CT_HLG : UHDR_CT_PQ);
   else if (which == 4 || which == 5) t = &host::oetf_code_buckets(which == 4 ? UHDR_CT_HLG : UHDR_CT_PQ, true);
+  else if (which == 6) {
+    // a synthetic staircase over [0, 1] whose steps sit EXACTLY on bucket starts (bucket = 2^15 bit patterns): the corner the
+    // builder answers with an empty bucket in front of the first threshold (clamp_lo_bits, host_tables.cpp)
+    uint32_t first, step;
+    memcpy(&first, &a, 4);
+    memcpy(&step, &b, 4);
+    first &= ~0x7fffu;
+    step = (step >> 15) ? (step & ~0x7fffu) : (1u << 15);
+    tmp = host::build_step_table([=](uint32_t u) { return u < first ? 0u : 1u + (u - first) / step; }, 0u, 0x3f800000u, 15, 65536);
+    t = &tmp;
+  }
   if (!t) return -1;
   if (info) { info[0] = t->exact ? 1u : 0u; info[1] = t->n; info[2] = t->shift; info[3] = t->base; }
   if (!t->exact) return 1;

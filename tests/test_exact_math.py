@@ -213,3 +213,31 @@ def test_prescaled_output_code_table_equals_scaling_then_the_plain_table(which, 
     rc, want, info2 = _step_eval(which - 2, 0.0, 0.0, v)
     assert rc == 0 and info2[0] == 1
     assert np.array_equal(got, want), int((got != want).sum())
+
+
+def test_steps_that_sit_exactly_on_bucket_starts():
+    """The device clamps the bit pattern to the first bucket's start instead of guarding `bucket - base` (five instructions
+    per lookup instead of six): a threshold exactly ON a bucket start must then still compare above everything below it,
+    which the builder arranges with an empty bucket in front (OetfBuckets::clamp_lo_bits).  Synthetic staircases whose
+    steps are bucket-aligned, evaluated exactly as the kernels do, against the staircase itself."""
+    for first_v, step_patterns in ((0.25, 1 << 15), (2.0 ** -20, 1 << 17), (0.5, 3 << 15)):
+        first = np.array([first_v], dtype=np.float32).view(np.uint32)[0] & ~np.uint32(0x7fff)
+        step = np.uint32(step_patterns)
+        one = np.array([1.0], dtype=np.float32).view(np.uint32)[0]
+        nsteps = int((one - first) // step) + 1
+        if nsteps > 60000:
+            continue
+        edges = first + step * np.arange(0, min(nsteps, 4000), dtype=np.uint64)
+        edges = edges[edges <= one].astype(np.uint32)
+        probes = np.concatenate([edges, edges - 1, edges + 1, np.array([0, 1, one, one + 5, 0x80000000, 0xbf800000], dtype=np.uint32),
+                                 np.random.default_rng(int(step_patterns)).integers(0, int(one), 200_000, dtype=np.uint32)])
+        x = probes.view(np.float32)
+        rc, got, info = _step_eval(6, float(np.array([first], dtype=np.uint32).view(np.float32)[0]), float(np.array([step], dtype=np.uint32).view(np.float32)[0]), x)
+        if rc == 1:
+            continue  # more than one step per bucket cannot be: steps are >= one bucket apart; a table beyond the capacity may be refused
+        assert rc == 0 and info[0] == 1, (first_v, step_patterns, info)
+        # the composite on the clamped pattern (negative floats and -0.0 are negative integers: they clamp to the domain's start)
+        u = probes.astype(np.int64)
+        u = np.where(probes >= 0x80000000, 0, np.minimum(u, int(one)))
+        want = np.where(u < int(first), 0, 1 + (u - int(first)) // int(step)).astype(np.uint32)
+        assert np.array_equal(got, want), (first_v, step_patterns, int((got != want).sum()))
