@@ -43,7 +43,10 @@ __device__ __forceinline__ float clamp01(float v) { return __builtin_amdgcn_fmed
 __device__ __forceinline__ float clamp_linear(float v) {
   return __builtin_amdgcn_fmed3f(v, 0.0f, UHDR_MAX_LINEAR);
 }
-__device__ __forceinline__ float clip_neg(float v) { return (v < 0.0f) ? 0.0f : v; }
+// clipNegatives (gainmapmath.h): (v < 0) ? 0 : v.  One v_max_f32; it differs from the compare for -0.0 (which it turns into +0.0:
+// every consumer adds a positive offset or multiplies by a positive factor next, where the zero's sign is lost) and NaN (no
+// input produces one).
+__device__ __forceinline__ float clip_neg(float v) { return __builtin_fmaxf(v, 0.0f); }
 
 // ---- float -> half, bit-exact to floatToHalf (gainmapmath.h:160-173) ---------------------------
 // That routine adds 0x1000 (round-half-up on the magnitude), then: normal halves keep

@@ -22,10 +22,9 @@ constexpr int kBlock = 512;  // 8 waves share one table set in LDS -> 3 workgrou
 
 template <int HDRF>
 struct FusedLds {
-  float srgb[kSrgbN];
+  float srgb_of_byte[256];  // byte -> byte / 255.0f -> sRGB inverse-OETF table value (host_tables.cpp)
   // RGBA1010102 input: 10-bit code -> linear value (the host always provides it); RGBA-F16: the inverse-OETF table, if any
   float hdr[HDRF == UHDR_IMG_FMT_32bppRGBA1010102 ? 1024 : kInvOetfN];
-  double math[kMathTabDoubles];
   UnormTables unorm;
   uint2 srgb8[kStepTabMax];  // tone map: clamped linear value -> sRGB byte
   uint2 gain8[kStepTabMax];  // one pass: clamped gain -> map byte
@@ -37,7 +36,7 @@ template <int HDRF, bool TWO_PASS>
 __global__ __launch_bounds__(kBlock) void encode_api0_fused_kernel(const FusedParams p, float* partials) {
   __shared__ FusedLds<HDRF> L;
   const uint32_t tid = threadIdx.x;
-  for (uint32_t i = tid; i < kSrgbN; i += kBlock) L.srgb[i] = p.gen.srgb_lut[i];
+  for (uint32_t i = tid; i < 256; i += kBlock) L.srgb_of_byte[i] = p.gen.srgb_of_byte[i];
   constexpr bool code_lin = HDRF == UHDR_IMG_FMT_32bppRGBA1010102;  // launch_encode_api0_fused checks that lin10 is there
   if constexpr (code_lin) {
     for (uint32_t i = tid; i < 1024; i += kBlock) L.hdr[i] = p.tm.lin10[i];
@@ -47,14 +46,13 @@ __global__ __launch_bounds__(kBlock) void encode_api0_fused_kernel(const FusedPa
   }
   stage_step_tab(L.srgb8, p.tm.srgb8, tid, kBlock);
   stage_step_tab(L.gain8, p.gen.gain8, tid, kBlock);
-  for (uint32_t i = tid; i < kMathTabDoubles; i += kBlock) L.math[i] = p.tm.math_tab[i];
   fill_unorm_tables(L.unorm, tid, kBlock);
   __syncthreads();
 
   const uint32_t w = p.tm.hdr.w, h = p.tm.hdr.h;
   const uint32_t tiles_x = (w + kBlock - 1) / kBlock, tiles = tiles_x * h;
   const bool hdr_lut = p.tm.hdr_inv_lut != nullptr, hdr_lut_4096 = p.tm.hdr_inv_n == kInvOetfN;
-  float mn[3] = {127.0f, 127.0f, 127.0f}, mx[3] = {-128.0f, -128.0f, -128.0f};
+  float mn[3] = {UHDR_RATIO_MIN_INIT, UHDR_RATIO_MIN_INIT, UHDR_RATIO_MIN_INIT}, mx[3] = {UHDR_RATIO_MAX_INIT, UHDR_RATIO_MAX_INIT, UHDR_RATIO_MAX_INIT};
   for (uint32_t t = blockIdx.x; t < tiles; t += gridDim.x) {
     const uint32_t y = t / tiles_x, x = (t - y * tiles_x) * kBlock + tid;
     if (x >= w) continue;
@@ -68,22 +66,26 @@ __global__ __launch_bounds__(kBlock) void encode_api0_fused_kernel(const FusedPa
       l = linearise_hdr(g, L.hdr, hdr_lut, hdr_lut_4096);
     }
     uint32_t r8, g8, b8;  // putRgba8888Pixel's bytes
-    tone_curve_bytes(l, p.tm, L.math, L.srgb8, r8, g8, b8);
+    tone_curve_bytes(l, p.tm, p.tm.math_tab + kPowDirOff, L.srgb8, r8, g8, b8);  // (the pow table stays in global memory: a call without the byte table is the exception)
     if (p.tm.sdr.p[0]) ((uint32_t*)p.tm.sdr.p[0])[x + (size_t)y * p.tm.sdr.stride[0]] = r8 | (g8 << 8) | (b8 << 16) | (255u << 24);
     // ---- generateGainMap on the quantised SDR pixel (jpegr.cpp:753-818 / 866-931), scale 1 ---------------------------
     const Color3 e = {L.unorm.u8[r8], L.unorm.u8[g8], L.unorm.u8[b8]};  // getRgba8888Pixel: byte / 255.0f
-    Color3 sl = {L.srgb[lut_index_f32<kSrgbN>(e.r)], L.srgb[lut_index_f32<kSrgbN>(e.g)], L.srgb[lut_index_f32<kSrgbN>(e.b)]};
-    if (p.gen.sdr_gamut_on) sl = mat3_apply(sl, p.gen.sdr_gamut);
-    sl.r = clip_neg(sl.r); sl.g = clip_neg(sl.g); sl.b = clip_neg(sl.b);
+    Color3 sl = {L.srgb_of_byte[r8], L.srgb_of_byte[g8], L.srgb_of_byte[b8]};  // the sRGB inverse OETF of e, per byte value
+    if (p.gen.sdr_gamut_on) {  // clipNegatives can only bite behind a matrix: table outputs are never negative
+      sl = mat3_apply(sl, p.gen.sdr_gamut);
+      sl.r = clip_neg(sl.r); sl.g = clip_neg(sl.g); sl.b = clip_neg(sl.b);
+    }
     Color3 hl = l;  // the same inverse OETF (+ OOTF) the tone mapper just applied
-    if (p.gen.hdr_gamut_on) hl = mat3_apply(hl, p.gen.hdr_gamut);
-    hl.r = clip_neg(hl.r); hl.g = clip_neg(hl.g); hl.b = clip_neg(hl.b);
-    gain_of_pixel<TWO_PASS>(sl, hl, p.gen, L.math, x, y, mn, mx, L.gain8);
+    if (p.gen.hdr_gamut_on) {
+      hl = mat3_apply(hl, p.gen.hdr_gamut);
+      hl.r = clip_neg(hl.r); hl.g = clip_neg(hl.g); hl.b = clip_neg(hl.b);
+    }
+    gain_of_pixel<TWO_PASS>(sl, hl, p.gen, p.gen.math_tab, x, y, mn, mx, L.gain8);
     // ---- convert_raw_input_to_ycbcr(sdr, 4:4:4) (gainmapmath.cpp:1446-1472) ----------------------------------------------
     const Color3 q = rgb_to_yuv(e, p.base_k);
-    ((uint8_t*)p.ycc.p[0])[(size_t)y * p.ycc.stride[0] + x] = (uint8_t)clipf(q.r * 255.0f + 0.5f, 255.0f);
-    ((uint8_t*)p.ycc.p[1])[(size_t)y * p.ycc.stride[1] + x] = (uint8_t)clipf(q.g * 255.0f + 0.5f + 128.0f, 255.0f);
-    ((uint8_t*)p.ycc.p[2])[(size_t)y * p.ycc.stride[2] + x] = (uint8_t)clipf(q.b * 255.0f + 0.5f + 128.0f, 255.0f);
+    ((uint8_t*)p.ycc.p[0])[(size_t)y * p.ycc.stride[0] + x] = (uint8_t)__builtin_amdgcn_fmed3f(q.r * 255.0f + 0.5f, 0.0f, 255.0f);
+    ((uint8_t*)p.ycc.p[1])[(size_t)y * p.ycc.stride[1] + x] = (uint8_t)__builtin_amdgcn_fmed3f(q.g * 255.0f + 0.5f + 128.0f, 0.0f, 255.0f);
+    ((uint8_t*)p.ycc.p[2])[(size_t)y * p.ycc.stride[2] + x] = (uint8_t)__builtin_amdgcn_fmed3f(q.b * 255.0f + 0.5f + 128.0f, 0.0f, 255.0f);
   }
   if constexpr (TWO_PASS) reduce_block_minmax<kBlock>(mn, mx, partials);
 }
@@ -103,8 +105,8 @@ int fused_grid(uint32_t tiles, int per_cu) {
   return (int)(g < 1 ? 1 : g);
 }
 
-// two_pass: p.gen.gain_log2 / p.gen.minmax set as for launch_generate_gainmap; returns the grid size
-// through *grid_out so that the caller can run the final min/max reduction (launch_reduce_minmax).
+// two_pass: p.gen.gain_log2 / p.gen.minmax set as for launch_generate_gainmap; returns the grid size (= the number of
+// ratio-extrema partials at p.gen.minmax + 6) through *grid_out for launch_minmax_table.
 hipError_t launch_encode_api0_fused(const FusedParams& p, bool two_pass, int* grid_out, hipStream_t s) {
   const uint32_t tiles = ((p.tm.hdr.w + kBlock - 1) / kBlock) * p.tm.hdr.h;
   const bool f16 = p.tm.hdr.fmt == UHDR_IMG_FMT_64bppRGBAHalfFloat;

@@ -86,6 +86,47 @@ UHDR_HD double log2_table_f64(float x, const double* T) {
   return fma(r, q, (double)k + T[kLogIcOff + 2 * i + 1]);
 }
 
+// ---- x^p from a DIRECT table (round 4) ------------------------------------------------------------------------------
+// The same identity with the table indexed by the top 16 bits of x itself (sign, exponent, 7 significand bits): one
+// entry per 2^16 consecutive bit patterns of [2^-9, 1], holding {1 / c, c^p} for the bucket's MIDPOINT c (exponent
+// included).  Then r = x / c - 1 is ONE float64 FMA on (double)x -- no significand extraction, no 2^(k p) table, no
+// integer exponent -- with |r| <= 2^-8, and (1 + r)^p needs four more: degree 4 with the degree-5 term of the binomial
+// series folded into the r and r^3 coefficients by Chebyshev economisation on [-2^-8, 2^-8] (r^5 ~ (20 a^2 r^3 -
+// 5 a^4 r) / 16), truncation error 2^-49 relative -- the accuracy of pow_table_f32 (degree 5 on |r| <= 2^-7: 2^-47.5)
+// at 6 float64 operations instead of 9 and without the integer work.  srgbOetf only raises arguments in
+// (0.0031308, 1], which is why the table starts at 2^-9.
+constexpr int kPowDirShift = 16;
+constexpr uint32_t kPowDirFirst = 0x3B000000u >> kPowDirShift;          // bits(2^-9) >> 16
+constexpr int kPowDirN = (int)((0x3F800000u >> kPowDirShift) - kPowDirFirst) + 1;  // 1153: the last bucket holds x == 1 only
+constexpr int kPowDirDoubles = 2 * kPowDirN;
+constexpr int kPowDirOff = (kMathTabDoubles + 1) & ~1;         // the direct table follows the round-1 tables in the device block
+constexpr int kMathTabDoublesAll = kPowDirOff + kPowDirDoubles;
+// C(p, j) for p = (double)(1.0f / 2.4f) = 0.4166666567325592041015625, economised (host_tables.cpp: pow_direct_table
+// recomputes them in long double and tests/test_exact_math.py compares)
+constexpr double kPowDirC1 = 0.4166666567303992;
+constexpr double kPowDirC2 = -0.12152777694993544;
+constexpr double kPowDirC3 = 0.06414022669132594;
+constexpr double kPowDirC4 = -0.04142353087261225;
+
+// x^p for 2^-9 <= x <= 1, narrowed to float; tab = kPowDirN pairs {1 / c, c^p}
+UHDR_HD float pow_direct_f32(float x, const double* tab) {
+  const uint32_t k = em_bits(x) >> kPowDirShift;
+  const uint32_t i = k > kPowDirFirst ? k - kPowDirFirst : 0u;  // a saturating subtract: arguments below the table read entry 0
+  const double r = fma((double)x, tab[2 * i], -1.0);
+  double q = fma(r, kPowDirC4, kPowDirC3);
+  q = fma(r, q, kPowDirC2);
+  q = fma(r, q, kPowDirC1);
+  q = fma(r, q, 1.0);
+  return (float)(tab[2 * i + 1] * q);
+}
+// srgbOetf (gainmapmath.cpp:139-148) through the direct table, branch-free: both segments are evaluated (arguments of the
+// linear segment read table entry 0 and the value is dropped by the select).  e in [0, 1].
+UHDR_HD float srgb_oetf_direct(float e, const double* tab) {
+  const float lin = 12.92f * e;
+  const float pw = (1.0f + 0.055f) * pow_direct_f32(e, tab) - 0.055f;
+  return (e <= 0.0031308f) ? lin : pw;
+}
+
 // srgbOetf (gainmapmath.cpp:139-148) with the table pow
 UHDR_HD float srgb_oetf_table(float e, const double* T) {
   if (e <= 0.0031308f) return 12.92f * e;

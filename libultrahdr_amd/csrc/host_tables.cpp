@@ -326,15 +326,15 @@ const OetfBuckets& oetf_code_buckets(int ct, bool prescaled) {
 // ---- step tables of the ENCODE side ------------------------------------------------------------------------------------
 // toneMap's last stage for RGBA8888 output: clampPixelFloat -> srgbOetf -> putRgba8888Pixel's byte
 // (jpegr.cpp:1976-1977, gainmapmath.cpp:139-148, 538-552) is a monotone step function of the linear value with 255
-// steps.  The composite is evaluated here through exact_math.h's srgb_oetf_table -- the very function the kernels ran
-// per channel before (float64, ~20 instructions) -- so the table changes no result, only its cost.
+// steps.  The composite is evaluated here through exact_math.h's srgb_oetf_direct -- the very function the kernels run
+// per channel where no table applies (float64) -- so the table changes no result, only its cost.
 const OetfBuckets& srgb_code8_buckets() {
   static const OetfBuckets t = [] {
     const std::vector<double>& T = math_tables();
     auto code = [&](uint32_t u) -> uint32_t {
       float x;
       memcpy(&x, &u, 4);
-      float v = srgb_oetf_table(x, T.data()) * 255.0f;
+      float v = srgb_oetf_direct(x, T.data() + kPowDirOff) * 255.0f;
       v += 0.5f;
       v = (v < 0.0f) ? 0.0f : ((v > 255.0f) ? 255.0f : v);
       return (uint32_t)v;
@@ -349,6 +349,42 @@ const OetfBuckets& srgb_code8_buckets() {
     OetfBuckets none;
     none.exact = false;
     return none;
+  }();
+  return t;
+}
+// computeGain's dark-pixel cap (gainmapmath.cpp:773-782: `if (sdr < 2 / 255) gain = min(gain, 2.3f)` on the float log2) in
+// the RATIO domain, where two-pass generation keeps its samples since round 4: the largest float q with
+// (float)log2(q) <= 2.3f.  min((float)log2(q), 2.3f) == (float)log2(min(q, cap)) for every q needs that bound to be
+// ATTAINED, (float)log2(cap) == 2.3f -- it is (near 4.92 a float ulp moves log2 by 1.4e-7, less than the 2.4e-7 ulp of 2.3f);
+// the function returns 0 otherwise and the host layer refuses two-pass generation rather than guess.
+float gain_cap_ratio() {
+  static const float cap = [] {
+    const std::vector<double>& T = math_tables();
+    auto lg = [&](uint32_t u) { float q; memcpy(&q, &u, 4); return (float)log2_table_f64(q, T.data()); };
+    uint32_t lo = 0x40800000u, hi = 0x41000000u;  // 4.0 (log2 = 2 <= 2.3), 8.0 (3 > 2.3)
+    while (hi - lo > 1) {
+      const uint32_t mid = lo + (hi - lo) / 2;
+      if (lg(mid) <= 2.3f) lo = mid; else hi = mid;
+    }
+    float q;
+    memcpy(&q, &lo, 4);
+    return lg(lo) == 2.3f ? q : 0.0f;
+  }();
+  return cap;
+}
+// the fused API-0 front end reads its own quantised SDR bytes back (generateGainMap would: getRgba8888Pixel's byte / 255.0f,
+// then the sRGB inverse-OETF table lookup, gainmapmath.cpp:126-131): both steps per byte value
+const std::vector<float>& srgb_inv_oetf_of_byte() {
+  static const std::vector<float> t = [] {
+    std::vector<float> v(256);
+    const std::vector<float>& lut = srgb_inv_oetf_lut();
+    for (int b = 0; b < 256; b++) {
+      const float e = (float)b / 255.0f;
+      int i = (int)((double)(e * (float)(kSrgbN - 1)) + 0.5);
+      i = i < 0 ? 0 : (i > kSrgbN - 1 ? kSrgbN - 1 : i);
+      v[b] = lut[i];
+    }
+    return v;
   }();
   return t;
 }
@@ -395,8 +431,17 @@ std::vector<float> lin10_table(const float* lut, int n) {
 // and rounded once to double.
 const std::vector<double>& math_tables() {
   static const std::vector<double> tab = [] {
-    std::vector<double> t((size_t)kMathTabDoubles, 0.0);
+    std::vector<double> t((size_t)kMathTabDoublesAll, 0.0);
     const long double p = (long double)(1.0f / 2.4f);  // the float exponent srgbOetf passes to powf
+    // the direct table of pow_direct_f32: one entry per 2^16 bit patterns of [2^-9, 1], {1 / c, c^p} at the bucket midpoint
+    for (int i = 0; i < kPowDirN; i++) {
+      const uint32_t bits = ((kPowDirFirst + (uint32_t)i) << kPowDirShift) | (1u << (kPowDirShift - 1));
+      float cf;
+      memcpy(&cf, &bits, 4);
+      const long double c = (long double)cf;
+      t[kPowDirOff + 2 * i] = (double)(1.0L / c);
+      t[kPowDirOff + 2 * i + 1] = (double)powl(c, p);
+    }
     for (int i = 0; i <= kPowM; i++) {
       const long double c = 1.0L + (long double)i / kPowM;
       t[kPowIcOff + 2 * i] = (double)(1.0L / c);

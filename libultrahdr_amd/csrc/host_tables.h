@@ -37,6 +37,8 @@ const OetfBuckets& oetf_code_buckets(int ct, bool prescaled = false);  // presca
 const OetfBuckets& srgb_code8_buckets();
 OetfBuckets gain_code8_buckets(float min_boost, float max_boost, float log2min, double log2_range, double log2_range_rcp);
 std::vector<float> lin10_table(const float* lut, int n);
+float gain_cap_ratio();                            // computeGain's 2.3f cap in the ratio domain (0: not representable)
+const std::vector<float>& srgb_inv_oetf_of_byte(); // 256: byte -> byte / 255.0f -> sRGB inverse-OETF table value
 
 // float64 tables of exact_math.h (table-driven pow / log2 of the encode path)
 const std::vector<double>& math_tables();

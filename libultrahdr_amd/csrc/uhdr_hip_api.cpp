@@ -126,7 +126,9 @@ struct uhdr_hip_ctx {
   int comm_rank = 0, comm_size = 0;
   bool comm_custom = false;      // uhdr_hip_comm_init_custom: the exchange steps go through comm_ops instead of RCCL
   uhdr_hip_comm_ops_t comm_ops = {};
-  DeviceBuf exchange;            // merged[6] | AffineDev | final mm[6]
+  DeviceBuf exchange;            // merged[6] | (unused) | final mm[6]
+  DeviceBuf affine;              // AffineDev + pass 2's per-channel step tables (kAffineDevBytes)
+  float* d_srgb_of_byte = nullptr;  // 256: byte -> sRGB inverse OETF (the fused API-0 front end)
   float* h_mm = nullptr;         // pinned: the final {min, max} for the metadata fill
   // profiling
   bool prof = false;
@@ -586,6 +588,8 @@ void uhdr_hip_destroy(uhdr_hip_ctx_t* c) {
   for (auto& g : c->gain_tabs) if (g.d) (void)hipFree(g.d);
   uhdr_hip_comm_destroy(c);
   if (c->exchange.p) (void)hipFree(c->exchange.p);
+  if (c->affine.p) (void)hipFree(c->affine.p);
+  if (c->d_srgb_of_byte) (void)hipFree(c->d_srgb_of_byte);
   if (c->h_mm) (void)hipHostFree(c->h_mm);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -970,7 +974,20 @@ static uhdr_error_info_t fill_gen_params(uhdr_hip_ctx* c, const uhdr_raw_image_t
   p->use_luminance = cfg->use_luminance != 0;
   p->hdr_nits = hdr->ct == UHDR_CT_LINEAR ? 203.0f : hdr_white_nits;
   p->gamma = cfg->gamma;
+  p->gain_cap = host::gain_cap_ratio();
+  if (!(p->gain_cap > 0.0f)) return err_status(UHDR_CODEC_ERROR, "internal: the dark-pixel gain cap has no exact form in the ratio domain");
   return ok_status();
+}
+
+// Everything between the two passes in one launch (generate_gainmap.hip: minmax_table_kernel).  `merged_in` non-null:
+// the striped path's second half (finalize from the all-reduced extrema + table).
+static void fill_finalize(MinmaxTableParams* t, const uhdr_hip_encode_cfg_t* cfg) {
+  t->nch = (cfg && cfg->use_multi_channel_gainmap) ? 3 : 1;
+  t->has_max_hint = cfg && cfg->max_content_boost != FLT_MAX;
+  t->has_min_hint = cfg && cfg->min_content_boost != FLT_MIN;
+  t->log2_max_hint = t->has_max_hint ? log2f(cfg->max_content_boost) : 0.0f;
+  t->log2_min_hint = t->has_min_hint ? log2f(cfg->min_content_boost) : 0.0f;
+  t->gamma = cfg ? cfg->gamma : 1.0f;
 }
 
 static void fill_gainmap_desc(const uhdr_raw_image_t* hdr, const GenParams& p, uhdr_raw_image_t* gm) {
@@ -1046,8 +1063,15 @@ uhdr_error_info_t uhdr_hip_generate_gainmap_pass1_dev(uhdr_hip_ctx_t* c, const u
   {
     ProfScope ps(c, "generate_gainmap");
     HIP_TRY(launch_generate_gainmap(p, true, c->stream));
+    MinmaxTableParams t;  // ratio extrema of the stripe -> the reference's six log2 extrema
+    memset(&t, 0, sizeof t);
+    t.do_reduce = 1;
+    t.partials = p.minmax + 6;
+    t.n_partials = gen_partials_count(p);
+    t.mm6 = minmax_dev;
+    t.math_tab = c->d_math;
+    HIP_TRY(launch_minmax_table(t, c->stream));
   }
-  HIP_TRY(hipMemcpyAsync(minmax_dev, c->minmax.p, 6 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
   return ok_status();
 }
 
@@ -1057,19 +1081,62 @@ uhdr_error_info_t uhdr_hip_generate_gainmap_pass2_dev(uhdr_hip_ctx_t* c, const f
   if (!gain_log2_dev || !mm || !cfg || !gm || !gm->planes[0]) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument");
   if (gm->stride[0] < gm->w) return err_status(UHDR_CODEC_INVALID_PARAM, "gainmap stride (%u) cannot be less than its width (%u)", gm->stride[0], gm->w);
   HIP_TRY(hipSetDevice(c->device));
+  UHDR_TRY(upload_math(c));
+  UHDR_TRY(ensure(c->affine, kAffineDevBytes));
+  MinmaxTableParams t;  // the final range arrives from the host: only the step tables are left to build
+  memset(&t, 0, sizeof t);
+  t.do_table = 1;
+  fill_finalize(&t, cfg);
+  for (int i = 0; i < 6; i++) t.final_mm[i] = mm[i];
+  t.dev = (AffineDev*)c->affine.p;
+  t.math_tab = c->d_math;
   AffineParams a;
-  a.dev = nullptr;
+  memset(&a, 0, sizeof a);
+  a.dev = (const AffineDev*)c->affine.p;
+  a.math_tab = c->d_math;
   a.gain_log2 = gain_log2_dev;
   a.out = (uint8_t*)gm->planes[0];
   a.map_w = gm->w; a.map_h = gm->h; a.out_stride = gm->stride[0];
   a.nch = cfg->use_multi_channel_gainmap ? 3 : 1;
-  for (int i = 0; i < 3; i++) {
-    a.mn[i] = mm[i]; a.mx[i] = mm[3 + i];
-    a.range_rcp[i] = 1.0 / (double)(a.mx[i] - a.mn[i]);
-  }
   a.gamma = cfg->gamma;
   ProfScope ps(c, "generate_gainmap");
+  HIP_TRY(launch_minmax_table(t, c->stream));
   HIP_TRY(launch_affine_map(a, c->stream));
+  return ok_status();
+}
+
+// pass 1's partials -> extrema -> final range -> step tables -> pass 2, all stream ordered; the final range is copied to
+// the pinned c->h_mm for the caller's metadata fill (after ITS synchronisation)
+static uhdr_error_info_t two_pass_tail(uhdr_hip_ctx* c, const GenParams& p, int n_partials, const uhdr_hip_encode_cfg_t* cfg, uhdr_raw_image_t* gm) {
+  UHDR_TRY(ensure(c->affine, kAffineDevBytes));
+  UHDR_TRY(ensure(c->exchange, 256));
+  if (!c->h_mm) HIP_TRY(hipHostMalloc((void**)&c->h_mm, 6 * sizeof(float), hipHostMallocDefault));
+  float* final_mm = (float*)((char*)c->exchange.p + 192);
+  MinmaxTableParams t;
+  memset(&t, 0, sizeof t);
+  t.do_reduce = t.do_finalize = t.do_table = 1;
+  t.partials = p.minmax + 6;
+  t.n_partials = n_partials;
+  t.mm6 = p.minmax;
+  fill_finalize(&t, cfg);
+  t.out_mm = final_mm;
+  t.dev = (AffineDev*)c->affine.p;
+  t.math_tab = c->d_math;
+  AffineParams a;
+  memset(&a, 0, sizeof a);
+  a.dev = (const AffineDev*)c->affine.p;
+  a.math_tab = c->d_math;
+  a.gain_log2 = p.gain_log2;
+  a.out = (uint8_t*)gm->planes[0];
+  a.map_w = gm->w; a.map_h = gm->h; a.out_stride = gm->stride[0];
+  a.nch = cfg->use_multi_channel_gainmap ? 3 : 1;
+  a.gamma = cfg->gamma;
+  {
+    ProfScope ps(c, "generate_gainmap");
+    HIP_TRY(launch_minmax_table(t, c->stream));
+    HIP_TRY(launch_affine_map(a, c->stream));
+  }
+  HIP_TRY(hipMemcpyAsync(c->h_mm, final_mm, 6 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   return ok_status();
 }
 
@@ -1119,11 +1186,11 @@ uhdr_error_info_t uhdr_hip_generate_gainmap_dev(uhdr_hip_ctx_t* c, const uhdr_ra
     ProfScope ps(c, "generate_gainmap");
     HIP_TRY(launch_generate_gainmap(p, true, c->stream));
   }
+  UHDR_TRY(two_pass_tail(c, p, gen_partials_count(p), cfg, gm));
+  HIP_TRY(hipStreamSynchronize(c->stream));  // the only host synchronisation: the metadata needs the final range
   float mm[6];
-  HIP_TRY(hipMemcpyAsync(mm, c->minmax.p, sizeof mm, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  UHDR_TRY(uhdr_hip_generate_gainmap_finalize(cfg, hdr->ct, use_base_cg, mm, md));
-  return uhdr_hip_generate_gainmap_pass2_dev(c, p.gain_log2, mm, cfg, gm);
+  memcpy(mm, c->h_mm, sizeof mm);
+  return uhdr_hip_generate_gainmap_finalize_md(cfg, hdr->ct, use_base_cg, mm, md);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1314,10 +1381,12 @@ uhdr_error_info_t uhdr_hip_generate_gainmap_striped_dev(uhdr_hip_ctx_t* c, const
   // the exchange buffers first: without them this rank cannot even contribute the identity (then, and only then, the
   // function returns early -- the caller has to abort the communicator)
   UHDR_TRY(ensure(c->exchange, 256));
+  UHDR_TRY(ensure(c->affine, kAffineDevBytes));
   UHDR_TRY(ensure(c->minmax, (6 + 2048 * 6) * sizeof(float)));
+  UHDR_TRY(upload_math(c));
   if (!c->h_mm) HIP_TRY(hipHostMalloc((void**)&c->h_mm, 6 * sizeof(float), hipHostMallocDefault));
   float* merged = (float*)c->exchange.p;                       // 6 floats
-  AffineDev* adev = (AffineDev*)((char*)c->exchange.p + 64);   // 48 bytes
+  AffineDev* adev = (AffineDev*)c->affine.p;
   float* final_mm = (float*)((char*)c->exchange.p + 192);      // 6 floats
   const uint32_t scale = local.error_code == UHDR_CODEC_OK ? (uint32_t)cfg->map_dimension_scale_factor : 1u;
   // a stripe shorter than one map row (the last rank of an uneven split) launches nothing and contributes the identity
@@ -1350,7 +1419,7 @@ uhdr_error_info_t uhdr_hip_generate_gainmap_striped_dev(uhdr_hip_ctx_t* c, const
     p.gain_log2 = (float*)c->scratch[7].p;
     p.minmax = (float*)c->minmax.p;
     ProfScope ps(c, "generate_gainmap");
-    const hipError_t e = launch_generate_gainmap(p, true, c->stream);  // float log2 gains + this stripe's {min, max}
+    const hipError_t e = launch_generate_gainmap(p, true, c->stream);  // float gain ratios + this stripe's ratio extrema
     note_hip(e, "generate_gainmap pass 1");
     if (e != hipSuccess) run = false;
   }
@@ -1358,23 +1427,32 @@ uhdr_error_info_t uhdr_hip_generate_gainmap_striped_dev(uhdr_hip_ctx_t* c, const
   uhdr_error_info_t xchg = ok_status();
   {
     ProfScope ps(c, "stripe_exchange");
-    note_hip(launch_minmax_pack((const float*)c->minmax.p, merged, run ? 0 : 1, c->stream), "minmax pack");
+    MinmaxTableParams t;  // this stripe's ratio extrema -> log2 extrema in the {min, -max} form of the single min-all-reduce
+    memset(&t, 0, sizeof t);
+    t.do_reduce = 1;
+    t.partials = (const float*)c->minmax.p + 6;
+    t.n_partials = run ? gen_partials_count(p) : 0;
+    t.empty = run ? 0 : 1;
+    t.mm6 = (float*)c->minmax.p;
+    t.merged6 = merged;
+    t.math_tab = c->d_math;
+    note_hip(launch_minmax_table(t, c->stream), "minmax reduce");
     xchg = comm_all_reduce_min(c, merged, 6);
-    FinalizeParams f;
-    f.merged = merged;
-    f.out = adev;
+    MinmaxTableParams f;  // the merged range -> final range (jpegr.cpp:969-986) -> pass 2's step tables, on the device
+    memset(&f, 0, sizeof f);
+    f.do_finalize = f.do_table = 1;
+    f.merged_in = merged;
+    fill_finalize(&f, args_ok ? cfg : nullptr);
     f.out_mm = final_mm;
-    f.nch = (args_ok && cfg->use_multi_channel_gainmap) ? 3 : 1;
-    f.has_max_hint = args_ok && cfg->max_content_boost != FLT_MAX;
-    f.has_min_hint = args_ok && cfg->min_content_boost != FLT_MIN;
-    f.log2_max_hint = f.has_max_hint ? log2f(cfg->max_content_boost) : 0.0f;
-    f.log2_min_hint = f.has_min_hint ? log2f(cfg->min_content_boost) : 0.0f;
-    note_hip(launch_minmax_finalize(f, c->stream), "minmax finalize");
+    f.dev = adev;
+    f.math_tab = c->d_math;
+    note_hip(launch_minmax_table(f, c->stream), "minmax finalize");
   }
   if (run && xchg.error_code == UHDR_CODEC_OK) {
     AffineParams a;
     memset(&a, 0, sizeof a);
     a.dev = adev;
+    a.math_tab = c->d_math;
     a.gain_log2 = p.gain_log2;
     a.out = (uint8_t*)gm->planes[0];
     a.map_w = gm->w; a.map_h = gm->h; a.out_stride = gm->stride[0];
@@ -1847,6 +1925,8 @@ uhdr_error_info_t uhdr_hip_encode_api0_fused_dev(uhdr_hip_ctx_t* c, const uhdr_r
   int use_base_cg = 1;
   float hdr_white_nits;
   UHDR_TRY(fill_gen_params(c, &sdr_desc, hdr, cfg, &p.gen, &use_base_cg, &hdr_white_nits, /*sdr_in_registers=*/true));
+  UHDR_TRY(upload_lut(&c->d_srgb_of_byte, host::srgb_inv_oetf_of_byte(), c->stream));
+  p.gen.srgb_of_byte = c->d_srgb_of_byte;
   fill_gainmap_desc(hdr, p.gen, gm);
   if (gm->stride[0] < gm->w) return err_status(UHDR_CODEC_INVALID_PARAM, "gainmap stride (%u) cannot be less than its width (%u)", gm->stride[0], gm->w);
   base_ycc->fmt = UHDR_IMG_FMT_24bppYCbCr444; base_ycc->cg = UHDR_CG_DISPLAY_P3; base_ycc->ct = UHDR_CT_SRGB; base_ycc->range = UHDR_CR_FULL_RANGE;
@@ -1882,17 +1962,16 @@ uhdr_error_info_t uhdr_hip_encode_api0_fused_dev(uhdr_hip_ctx_t* c, const uhdr_r
   UHDR_TRY(ensure(c->minmax, (6 + 2048 * 6) * sizeof(float)));
   p.gen.gain_log2 = (float*)c->scratch[7].p;
   p.gen.minmax = (float*)c->minmax.p;
+  int grid = 0;
   {
     ProfScope ps(c, "encode_api0_fused");
-    int grid = 0;
     HIP_TRY(launch_encode_api0_fused(p, true, &grid, c->stream));
-    HIP_TRY(launch_reduce_minmax(p.gen.minmax + 6, grid, p.gen.minmax, c->stream));
   }
-  float mm[6];
-  HIP_TRY(hipMemcpyAsync(mm, c->minmax.p, sizeof mm, hipMemcpyDeviceToHost, c->stream));
+  UHDR_TRY(two_pass_tail(c, p.gen, grid, cfg, gm));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  UHDR_TRY(uhdr_hip_generate_gainmap_finalize(cfg, hdr->ct, use_base_cg, mm, md));
-  return uhdr_hip_generate_gainmap_pass2_dev(c, p.gen.gain_log2, mm, cfg, gm);
+  float mm[6];
+  memcpy(mm, c->h_mm, sizeof mm);
+  return uhdr_hip_generate_gainmap_finalize_md(cfg, hdr->ct, use_base_cg, mm, md);
 }
 
 // -------------------------------------------------------------------------------------------------

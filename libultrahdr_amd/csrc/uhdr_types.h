@@ -129,8 +129,10 @@ struct GenParams {
   const float* srgb_lut;     // 1024
   const float* hdr_inv_lut;  // 4096 (HLG with the OOTF folded in / PQ) or 1024 (sRGB) or null (linear)
   int hdr_inv_n;
-  const double* math_tab;    // exact_math.h tables (kMathTabDoubles)
+  const double* math_tab;    // exact_math.h tables (kMathTabDoublesAll)
   const float* lin10;        // RGBA1010102 HDR at scale 1: 10-bit code -> linear value, 1024 floats; else null
+  const float* srgb_of_byte; // 256: sRGB inverse OETF of byte / 255.0f (the fused front end reads its own SDR bytes back)
+  float gain_cap;            // two pass: the ratio-domain form of computeGain's 2.3f cap (host_tables.cpp: gain_cap_ratio)
   StepTab gain8;             // one pass, gamma 1: clamped gain -> map byte
   int sdr_is_rgb, hdr_is_rgb;
   int sdr_gamut_on, hdr_gamut_on;
@@ -145,33 +147,64 @@ struct GenParams {
   uint8_t* out;              // map bytes
   uint32_t out_stride;       // pixels
   // two pass
-  float* gain_log2;          // map_w*map_h*(3|1)
-  float* minmax;             // 6 floats
+  float* gain_log2;          // map_w*map_h*(3|1): the float gain RATIOS (round 4; log2 of the six extrema only, see encode_core.h)
+  float* minmax;             // 6 floats: the reference's log2 extrema
 };
 
-// Row-striped two-pass generation: the final per-channel range lives in device memory between the all-reduce and
-// pass 2, so the sequence pass 1 -> all-reduce -> finalize -> pass 2 needs no host round trip.
+// Two-pass generation: the final per-channel range and everything derived from it live in device memory, so the
+// sequence pass 1 -> [all-reduce] -> finalize -> pass 2 needs no host round trip.
+// Round 4: pass 1 stores the gain RATIO q = (hdr + eps) / (sdr + eps) (encode_core.h: gain_ratio); pass 2's byte
+//   q -> (float)log2(q) -> (g - min) / (max - min) [-> pow gamma] -> * 255 + 0.5 -> clip -> truncate   (jpegr.cpp:900-1013)
+// is a monotone step function of q with at most 255 steps, tabulated per channel ON THE DEVICE once the range is known
+// (minmax_table_kernel): buckets of 2^shift consecutive bit patterns with at most one threshold each, found by
+// bisection through the exact float64 evaluation -- the same form as the host-built step tables (StepTab).
+constexpr int kAffTabMax = 1024;  // entries per channel (8 KiB of LDS each)
+struct AffineTabDev {
+  uint32_t n, base8, shm3;     // entries, first bucket * 8, shift - 3
+  uint32_t lo_bits, hi_bits;   // the table's domain (bucket aligned); the step function is constant beyond it
+  uint32_t ok;                 // 0: no table for this range (too dense, not monotone) -> pass 2 evaluates per sample
+  uint32_t pad[2];
+};
 struct AffineDev {
   float mn[3], mx[3];
   double range_rcp[3];
+  AffineTabDev tab[3];
 };
+constexpr size_t kAffineTablesOff = 256;  // byte offset of the 3 x kAffTabMax table entries behind an AffineDev
+constexpr size_t kAffineDevBytes = kAffineTablesOff + 3 * (size_t)kAffTabMax * 8;
+static_assert(sizeof(AffineDev) <= kAffineTablesOff, "AffineDev outgrew its slot");
 struct AffineParams {
-  const float* gain_log2;
+  const float* gain_log2;      // the float gain ratios of pass 1
   uint8_t* out;
   uint32_t map_w, map_h, out_stride, nch;
-  float mn[3], mx[3];
-  double range_rcp[3];  // 1.0 / (double)(mx[c] - mn[c]) with the float subtraction the reference performs
   float gamma;
-  const AffineDev* dev;  // non-null: mn / mx / range_rcp are read from here instead (written by minmax_finalize_kernel)
+  const AffineDev* dev;        // range + step tables (written by minmax_table_kernel); the tables follow at kAffineTablesOff
+  const double* math_tab;      // exact_math.h tables in global memory (per-sample evaluation when a table is not ok)
 };
-// jpegr.cpp:969-986 on the device: the merged min / max -> clamp, user hints, epsilon guard
-struct FinalizeParams {
-  const float* merged;  // {min0, min1, min2, -max0, -max1, -max2}: the form in which ONE min-all-reduce merges both
-  AffineDev* out;
-  float* out_mm;        // the final {min0..2, max0..2}, for the host's metadata fill
+// One launch for everything between the passes (generate_gainmap.hip: minmax_table_kernel), one workgroup per channel:
+//   reduce    partials of pass 1 (ratio extrema) -> log2 extrema mm6 {min0..2, max0..2} (+ the {min, -max} form for the
+//             single min-all-reduce of the striped path)
+//   finalize  jpegr.cpp:969-986: clamp, user hints, epsilon guard -> AffineDev, the final {min, max} for the metadata
+//   table     the per-channel step table of pass 2
+struct MinmaxTableParams {
+  int do_reduce, do_finalize, do_table;
+  // reduce
+  const float* partials;  // n_partials x 6 ratio extrema
+  int n_partials;
+  int empty;              // this rank's stripe holds no sample: contribute the identity of the merge (127 / -128)
+  float* mm6;             // out: log2 extrema
+  float* merged6;         // out (may be null): {min0..2, -max0..2}
+  // finalize
+  const float* merged_in; // {min0..2, -max0..2} (after the all-reduce); null: this launch's own mm6
   int nch;
   int has_max_hint, has_min_hint;
   float log2_max_hint, log2_min_hint;  // log2f of the user's content-boost recommendations (host-computed)
+  float* out_mm;          // out (may be null): the final {min0..2, max0..2}, for the host's metadata fill
+  // table (and finalize's output)
+  float final_mm[6];      // do_finalize == 0: the already-final range (uhdr_hip_generate_gainmap_pass2_dev)
+  AffineDev* dev;
+  float gamma;
+  const double* math_tab;
 };
 
 // ---- toneMap -------------------------------------------------------------------------------------
@@ -180,7 +213,7 @@ struct ToneMapParams {
   ImageViewMut sdr;
   const float* hdr_inv_lut;  // as in GenParams
   int hdr_inv_n;
-  const double* math_tab;    // exact_math.h tables (kMathTabDoubles)
+  const double* math_tab;    // exact_math.h tables (kMathTabDoublesAll)
   const float* lin10;        // RGBA1010102 input: 10-bit code -> linear value (unpack + inverse OETF [+ OOTF]), 1024 floats; else null
   StepTab srgb8;             // RGBA8888 output: clamped linear value -> sRGB byte
   int hdr_is_rgb, is_normalized;
@@ -216,9 +249,8 @@ hipError_t launch_apply_gainmap_coef(const ApplyParams& p, hipStream_t s);
 int apply_quad_mode(const ApplyParams& p);  // >= 0: the quad kernel (and batch mode) applies
 hipError_t launch_generate_gainmap(const GenParams& p, bool two_pass, hipStream_t s);
 hipError_t launch_affine_map(const AffineParams& p, hipStream_t s);
-hipError_t launch_reduce_minmax(const float* partials, int n, float* out6, hipStream_t s);
-hipError_t launch_minmax_pack(const float* mm6, float* merged6, int empty, hipStream_t s);
-hipError_t launch_minmax_finalize(const FinalizeParams& p, hipStream_t s);
+hipError_t launch_minmax_table(const MinmaxTableParams& p, hipStream_t s);
+int gen_partials_count(const GenParams& p);  // workgroups (= partials) launch_generate_gainmap(p, two_pass = true) writes
 hipError_t launch_encode_api0_fused(const FusedParams& p, bool two_pass, int* grid_out, hipStream_t s);
 hipError_t launch_tone_map(const ToneMapParams& p, hipStream_t s);
 hipError_t launch_transform_yuv(const YuvXformParams& p, hipStream_t s);
