@@ -307,10 +307,27 @@ int uhdr_hip_oetf_code_thresholds(uhdr_color_transfer_t ct, float thresholds[102
  *         reciprocal-multiply-and-correct sequence (csrc/device_math.h div_const), i >= 1
  *   fn 3: division by an arbitrary per-call divisor through its float64 reciprocal: in[0] = b,
  *         out[i] = (float)((double)in[i] * (1.0 / (double)b)) (csrc/device_math.h div_by_rcp64), i >= 1
+ *   fn 5: srgbOetf(in) through the direct pow table (round 4: csrc/exact_math.h srgb_oetf_direct, what the kernels run now)
  *   fn 4: (a, b) pairs: out[2i] = a / b through a float64 reciprocal refined from a deliberately
  *         2-ulp-off float seed (csrc/device_math.h rcp64_of_f32, the tone mapper's shared-divisor divisions)
  * Returns 0, or -1 for an unknown fn. */
 int uhdr_hip_exact_math_eval(int fn, const float* in, float* out, size_t n);
+/* Device self-test (needs the GPU): exhaustive sweeps of the instruction-level shortcuts of the encode kernels
+ * (csrc/encode_core.h, csrc/selftest.hip) -- what the hardware's v_rcp_f32 / v_cvt_rpi_i32_f32 return cannot be a CPU test.
+ * out[8] receives counters; the caller asserts.
+ *   which 0: v_cvt_rpi_i32_f32(x) == floor(x + 0.5) for every float of [0, 2^23]      out = {mismatches, floats swept}
+ *   which 1: refined reciprocal == RN(1 / b) for every normal float (both signs)      out = {mismatches, floats swept, raw v_rcp_f32 not correctly rounded}
+ *   which 2: Markstein quotient == IEEE a / b on random pairs, biased exponents in [arg0, arg1], RNG seed `seed`
+ *                                                                                      out = {mismatches, pairs}
+ *   which 3: srgbOetf through the direct pow table, LDS form == generic form == round-1 form, every float of [0, 1]
+ *                                                                                      out = {LDS != generic, generic != round-1, floats swept}
+ *   which 4: the device-built ratio -> byte step table of two-pass generateGainMap for the FINAL range mm = {min0..2, max0..2}
+ *            (log2 gains, as uhdr_hip_generate_gainmap_finalize returns it), channel arg0 of arg1 channels, against the
+ *            per-sample evaluation over the table's whole domain and 2^20 bit patterns beyond either end
+ *                                                                                      out = {mismatches, ratios swept, table entries, 1 if the range got no table}
+ * The reference has no counterpart: these pin the arithmetic of jpegr.cpp:753-1013, 1945-1983 and gainmapmath.cpp:127-148 as evaluated here. */
+uhdr_error_info_t uhdr_hip_selftest(uhdr_hip_ctx_t* ctx, int which, unsigned int arg0, unsigned int arg1, unsigned int seed, const float mm[6],
+                                    unsigned long long out[8]);
 /* Host utility (no GPU needed): evaluates one of the kernels' step tables (monotone float -> code functions stored as
  * bucket tables in LDS: csrc/host_tables.cpp build_step_table) exactly as the device does, so that tests can compare it
  * with the composite it stands for.

@@ -197,6 +197,7 @@ _SIGS = {
     "uhdr_hip_jpeg_quant_table": (None, [C.c_int, C.c_int, _P(C.c_uint16)]),
     "uhdr_hip_oetf_code_thresholds": (C.c_int, [C.c_int, _P(C.c_float)]),
     "uhdr_hip_exact_math_eval": (C.c_int, [C.c_int, _P(C.c_float), _P(C.c_float), C.c_size_t]),
+    "uhdr_hip_selftest": (ErrorInfo, [C.c_void_p, C.c_int, C.c_uint, C.c_uint, C.c_uint, _P(C.c_float), _P(C.c_ulonglong)]),
     "uhdr_hip_fdct_quant": (ErrorInfo, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, _P(C.c_uint16), C.c_void_p]),
     "uhdr_hip_fdct_quant_dev": (ErrorInfo, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, _P(C.c_uint16), C.c_void_p]),
     "uhdr_hip_encode_api0_fused_dev": (ErrorInfo, [C.c_void_p, _P(RawImage), _P(EncodeCfg), _P(RawImage), _P(RawImage), _P(GainmapMetadata), _P(RawImage)]),

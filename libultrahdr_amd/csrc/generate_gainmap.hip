@@ -133,10 +133,11 @@ __global__ __launch_bounds__(kGenBlock) void generate_quad_kernel(const GenParam
 // ---- between the passes ------------------------------------------------------------------------------------------------------
 // pass 2's composite for one channel, exactly as the reference evaluates it per sample (jpegr.cpp:900-928 stored the float
 // log2 gain, affineMapGain gainmapmath.cpp:784-789 maps it): ratio -> byte
+template <bool GAMMA = true>
 __device__ __forceinline__ uint32_t affine_code(float q, float mn, double rr, float gamma, const double* T) {
   const float g = gain_log2_of_ratio(q, T);
   float m = div_by_rcp64(g - mn, rr);  // (g - min) / (max - min), exact (device_math.h)
-  if (gamma != 1.0f) m = (float)pow((double)m, (double)gamma);
+  if (GAMMA && gamma != 1.0f) m = (float)pow((double)m, (double)gamma);
   m *= 255.0f;
   float t2 = m + 0.5f;
   t2 = (t2 < 0.0f) ? 0.0f : ((t2 > 255.0f) ? 255.0f : t2);
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(kTabBlock) void minmax_table_kernel(const MinmaxTab
   const double rr = 1.0 / (double)(gmax - gmin);
   AffineTabDev& td = p.dev->tab[c];
   if (tid == 0) { p.dev->mn[c] = gmin; p.dev->mx[c] = gmax; p.dev->range_rcp[c] = rr; }
-  if (!p.do_table || c >= p.nch) {
+  if (!p.do_table || c >= p.nch || p.gamma != 1.0f) {  // (a user gamma: pass 2 evaluates per sample, launch_affine_map)
     if (tid == 0) td.ok = 0;
     return;
   }
@@ -221,8 +222,8 @@ __global__ __launch_bounds__(kTabBlock) void minmax_table_kernel(const MinmaxTab
       n = (hi_bits >> shift) - (lo_bits >> shift) + 1u;
       if (n > (uint32_t)kAffTabMax) ok = 0;
       if (ok) {  // the step function must be saturated at both ends of the domain and beyond
-        const uint32_t c_lo = affine_code(__uint_as_float(lo_bits), gmin, rr, p.gamma, T), c_hi = affine_code(__uint_as_float(hi_bits), gmin, rr, p.gamma, T);
-        if (c_lo != affine_code(0x1p-120f, gmin, rr, p.gamma, T) || c_hi != affine_code(0x1p120f, gmin, rr, p.gamma, T) || c_hi < c_lo) ok = 0;
+        const uint32_t c_lo = affine_code<false>(__uint_as_float(lo_bits), gmin, rr, p.gamma, T), c_hi = affine_code<false>(__uint_as_float(hi_bits), gmin, rr, p.gamma, T);
+        if (c_lo != affine_code<false>(0x1p-120f, gmin, rr, p.gamma, T) || c_hi != affine_code<false>(0x1p120f, gmin, rr, p.gamma, T) || c_hi < c_lo) ok = 0;
       }
     }
     s_geo[0] = ok; s_geo[1] = shift; s_geo[2] = lo_bits; s_geo[3] = hi_bits; s_geo[4] = n;
@@ -234,16 +235,16 @@ __global__ __launch_bounds__(kTabBlock) void minmax_table_kernel(const MinmaxTab
   if (s_geo[0]) {
     for (uint32_t k = tid; k < n; k += kTabBlock) {
       const uint32_t start = lo_bits + (k << shift), end = start + (1u << shift) - 1u;
-      const uint32_t f_lo = affine_code(__uint_as_float(start), gmin, rr, p.gamma, T), f_hi = affine_code(__uint_as_float(end), gmin, rr, p.gamma, T);
+      const uint32_t f_lo = affine_code<false>(__uint_as_float(start), gmin, rr, p.gamma, T), f_hi = affine_code<false>(__uint_as_float(end), gmin, rr, p.gamma, T);
       uint32_t thr = 0xFFFFFFFFu;
       if (f_hi != f_lo) {
         uint32_t a = start, b = end;  // invariant: code(a) == f_lo < code(b)
         while (b - a > 1u) {
           const uint32_t mid = a + (b - a) / 2u;
-          if (affine_code(__uint_as_float(mid), gmin, rr, p.gamma, T) > f_lo) b = mid; else a = mid;
+          if (affine_code<false>(__uint_as_float(mid), gmin, rr, p.gamma, T) > f_lo) b = mid; else a = mid;
         }
         thr = b;
-        if (affine_code(__uint_as_float(b), gmin, rr, p.gamma, T) != f_hi || f_hi < f_lo) atomicAnd(&s_geo[5], 0u);  // a second threshold / not monotone
+        if (affine_code<false>(__uint_as_float(b), gmin, rr, p.gamma, T) != f_hi || f_hi < f_lo) atomicAnd(&s_geo[5], 0u);  // a second threshold / not monotone
       }
       tab[k] = uint2{thr, f_lo | (f_hi << 16)};
     }
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(kBlock) void affine_kernel(const AffineParams p) {
   __shared__ AffineLds L;
   StepTab st[3];
   const bool tabs = p.nch == 3 ? stage_affine_tabs<3>(p, L, st, threadIdx.x, kBlock) : stage_affine_tabs<1>(p, L, st, threadIdx.x, kBlock);
-  if (!tabs) return;  // no table for this range: affine_exact_kernel does the work
+  // (no table: a range too dense for one threshold per bucket; gamma is 1 here, see launch_affine_map)
   const uint32_t row_elems = p.map_w * p.nch;
   const uint32_t per_row = VEC4 ? row_elems / 4 : row_elems;
   const uint32_t tiles_x = (per_row + kBlock - 1) / kBlock, tiles = tiles_x * p.map_h;
@@ -300,6 +301,7 @@ __global__ __launch_bounds__(kBlock) void affine_kernel(const AffineParams p) {
     uint8_t* dst = p.out + (size_t)y * p.out_stride * p.nch;
     auto map1 = [&](float q, uint32_t e) -> uint32_t {
       const uint32_t c = p.nch == 3 ? e % 3 : 0;
+      if (!tabs) return affine_code<false>(q, p.dev->mn[c], p.dev->range_rcp[c], 1.0f, p.math_tab);
       return c == 0 ? step_code(q, L.tab[0], st[0]) : (c == 1 ? step_code(q, L.tab[1], st[1]) : step_code(q, L.tab[2], st[2]));
     };
     if constexpr (VEC4) {
@@ -319,7 +321,7 @@ template <int NCH>
 __global__ __launch_bounds__(kBlock) void affine_wide_kernel(const AffineParams p) {
   __shared__ AffineLds L;
   StepTab st[3];
-  if (!stage_affine_tabs<NCH>(p, L, st, threadIdx.x, kBlock)) return;  // no table for this range: affine_exact_kernel does the work
+  const bool tabs = stage_affine_tabs<NCH>(p, L, st, threadIdx.x, kBlock);
   constexpr int NS = 16 * NCH;  // samples per thread
   const uint32_t row_elems = p.map_w * NCH, per_row = row_elems / NS;
   const uint32_t total = per_row * p.map_h, tiles = (total + kBlock - 1) / kBlock;  // flat: narrow maps still fill the lanes
@@ -330,6 +332,17 @@ __global__ __launch_bounds__(kBlock) void affine_wide_kernel(const AffineParams 
     const uint32_t y = idx / per_row, j = idx - y * per_row;
     const float4* src = (const float4*)(p.gain_log2 + (size_t)y * row_elems + (size_t)j * NS);
     uint8_t* dst = p.out + (size_t)y * p.out_stride * NCH + (size_t)j * NS;
+    if (!tabs) {  // a range too dense for one threshold per bucket (gamma is 1 here: launch_affine_map): per sample through the
+                  // exact evaluation, one load and one store at a time -- register-light, this path must not cost the table
+                  // path its occupancy
+      const float* sp = (const float*)src;
+#pragma unroll 1
+      for (int e = 0; e < NS; e++) {
+        const int c = e % NCH;
+        dst[e] = (uint8_t)affine_code<false>(sp[e], p.dev->mn[c], p.dev->range_rcp[c], 1.0f, p.math_tab);
+      }
+      continue;
+    }
     float4 g[NS / 4];
 #pragma unroll
     for (int k = 0; k < NS / 4; k++) g[k] = src[k];
@@ -351,19 +364,15 @@ __global__ __launch_bounds__(kBlock) void affine_wide_kernel(const AffineParams 
   }
 }
 
-// The per-sample evaluation for a range that got no step table (too dense for one threshold per bucket, a user gamma that
-// breaks monotony -- AffineTabDev::ok == 0, known on the device only): launched behind the table kernels, returns at once
-// when they did the work.  Kept out of them because its float64 pow would cost the table path half its occupancy.
+// The per-sample evaluation for maps with a user gamma != 1 (the host knows: no tables are built, launch_affine_map comes
+// here directly).  Kept out of the table kernels because its float64 pow would cost them half their occupancy.
 __global__ __launch_bounds__(kBlock) void affine_exact_kernel(const AffineParams p) {
-  bool ok = true;
-  for (uint32_t c = 0; c < p.nch; c++) ok = ok && p.dev->tab[c].ok != 0;
-  if (ok) return;
   const uint32_t row_elems = p.map_w * p.nch;
   const size_t total = (size_t)row_elems * p.map_h;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
     const uint32_t y = (uint32_t)(i / row_elems), e = (uint32_t)(i - (size_t)y * row_elems);
     const uint32_t c = p.nch == 3 ? e % 3 : 0;
-    p.out[(size_t)y * p.out_stride * p.nch + e] = (uint8_t)affine_code(p.gain_log2[i], p.dev->mn[c], p.dev->range_rcp[c], p.gamma, p.math_tab);
+    p.out[(size_t)y * p.out_stride * p.nch + e] = (uint8_t)affine_code<true>(p.gain_log2[i], p.dev->mn[c], p.dev->range_rcp[c], p.gamma, p.math_tab);
   }
 }
 
@@ -450,6 +459,10 @@ hipError_t launch_minmax_table(const MinmaxTableParams& p, hipStream_t s) {
 
 hipError_t launch_affine_map(const AffineParams& p, hipStream_t s) {
   const uint32_t row_elems = p.map_w * p.nch;
+  if (p.gamma != 1.0f) {
+    hipLaunchKernelGGL(affine_exact_kernel, dim3(2048), dim3(kBlock), 0, s, p);
+    return hipGetLastError();
+  }
   if ((p.nch == 1 || p.nch == 3) && p.map_w % 16 == 0 && ((size_t)p.out_stride * p.nch) % 16 == 0 && (((uintptr_t)p.out & 15) == 0) &&
       (((uintptr_t)p.gain_log2 & 15) == 0)) {
     const uint32_t total = (p.map_w / 16) * p.map_h;
@@ -457,7 +470,6 @@ hipError_t launch_affine_map(const AffineParams& p, hipStream_t s) {
     const int grid = (int)(tiles < 2048u ? (tiles ? tiles : 1u) : 2048u);  // resident-sized: every workgroup stages the tables once
     if (p.nch == 3) hipLaunchKernelGGL((affine_wide_kernel<3>), dim3(grid), dim3(kBlock), 0, s, p);
     else hipLaunchKernelGGL((affine_wide_kernel<1>), dim3(grid), dim3(kBlock), 0, s, p);
-    hipLaunchKernelGGL(affine_exact_kernel, dim3(256), dim3(kBlock), 0, s, p);
     return hipGetLastError();
   }
   const bool vec4 = (row_elems % 4 == 0) && ((p.out_stride * p.nch) % 4 == 0) && (((uintptr_t)p.out & 3) == 0) &&
@@ -467,7 +479,6 @@ hipError_t launch_affine_map(const AffineParams& p, hipStream_t s) {
   const int grid = (int)(tiles < 2048u ? (tiles ? tiles : 1u) : 2048u);
   if (vec4) hipLaunchKernelGGL((affine_kernel<true>), dim3(grid), dim3(kBlock), 0, s, p);
   else hipLaunchKernelGGL((affine_kernel<false>), dim3(grid), dim3(kBlock), 0, s, p);
-  hipLaunchKernelGGL(affine_exact_kernel, dim3(256), dim3(kBlock), 0, s, p);
   return hipGetLastError();
 }
 

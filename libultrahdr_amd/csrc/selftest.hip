@@ -1,0 +1,131 @@
+// Exhaustive on-device checks of the instruction-level shortcuts the encode kernels rely on (encode_core.h, round 4).
+// None of these can be a CPU test: they pin what THIS part's v_rcp_f32 / v_cvt_rpi_i32_f32 return.  Driven by
+// tests/test_gpu_selftest.py through uhdr_hip_selftest (include/uhdr_hip.h); every sweep reports counts, the caller asserts.
+//   0  v_cvt_rpi_i32_f32(x) == (int)floor((double)x + 0.5) for every float in [0, 2^23]          (LUT indices, ScaleTo8Bit)
+//   1  rcp_rn(b) == RN(1 / b) for every normal float whose reciprocal is normal                  (all divisions)
+//   2  div_rn(a, b) == a / b (the compiler's IEEE division) on random pairs, exponents in [arg0 - 127, arg1 - 127]
+//   3  srgb_oetf_lds (direct table in LDS, the kernels' form) == srgb_oetf_direct (same table, generic pointer, saturating
+//      index) == srgb_oetf_table (round-1 form: nearest-of-65 table, degree 5) for every float in [0, 1]
+//   4  the device-built ratio -> byte step table of two-pass generation against the per-sample evaluation, for a given
+//      (min, max) range: every bit pattern of the table's domain and a margin on both sides (generate_gainmap.hip)
+#include "encode_core.h"
+
+namespace uhdr {
+namespace {
+
+__global__ void sweep_rpi(unsigned long long* out) {
+  const uint64_t n = 0x4B000000ull;  // bit patterns of [0, 2^23]
+  unsigned long long bad = 0;
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i <= n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const float x = __uint_as_float((uint32_t)i);
+    if (rpi(x) != (int)floor((double)x + 0.5)) bad++;
+  }
+  if (bad) atomicAdd(&out[0], bad);
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[1] = n + 1;
+}
+
+__global__ void sweep_rcp(unsigned long long* out) {
+  unsigned long long bad = 0, raw_bad = 0, cnt = 0;
+  for (uint64_t i = 0x00800000ull + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < 0x7F800000ull; i += (uint64_t)gridDim.x * blockDim.x) {
+    const float b = __uint_as_float((uint32_t)i);
+    const float want = (float)(1.0 / (double)b);  // RN24(RN53(1 / b)) == RN24(1 / b): a reciprocal is never within 2^-53 of a float midpoint
+    if (want < 1.1754944e-38f) continue;          // sub-normal reciprocal: outside the kernels' range
+    cnt++;
+    if (rcp_rn(b) != want) bad++;
+    if (__builtin_amdgcn_rcpf(b) != want) raw_bad++;
+    if (rcp_rn(-b) != -want) bad++;
+  }
+  atomicAdd(&out[0], bad);
+  atomicAdd(&out[1], cnt);
+  atomicAdd(&out[2], raw_bad);
+}
+
+__device__ __forceinline__ uint32_t xorshift(uint32_t& s) {
+  s ^= s << 13; s ^= s >> 17; s ^= s << 5;
+  return s;
+}
+__global__ void sweep_div(unsigned long long* out, uint32_t seed, uint32_t elo, uint32_t ehi) {
+  uint32_t s = seed ^ ((blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u) ^ 0x9E3779B9u;
+  if (!s) s = 1;
+  unsigned long long bad = 0;
+  for (int it = 0; it < 4096; it++) {
+    const uint32_t ma = xorshift(s) & 0x7fffffu, mb = xorshift(s) & 0x7fffffu;
+    const uint32_t ea = elo + xorshift(s) % (ehi - elo + 1), eb = elo + xorshift(s) % (ehi - elo + 1);
+    // every 8th pair: significands one or two units apart, the quotients closest to 1 (ties of the residual)
+    const uint32_t mb2 = (it & 7) == 7 ? ((ma + (xorshift(s) & 3u)) & 0x7fffffu) : mb;
+    const float a = __uint_as_float((ea << 23) | ma), b = __uint_as_float((eb << 23) | mb2);
+    if (div_rn(a, b) != a / b) bad++;
+  }
+  atomicAdd(&out[0], bad);
+  atomicAdd(&out[1], 4096ull);
+}
+
+__global__ __launch_bounds__(256) void sweep_srgb(unsigned long long* out, const double* math_tab) {
+  __shared__ double s_pow[kPowDirDoubles];
+  stage_pow_tab(s_pow, math_tab, threadIdx.x, 256);
+  __syncthreads();
+  unsigned long long bad_lds = 0, bad_old = 0;
+  const uint64_t n = 0x3F800000ull;  // bit patterns of [0, 1]
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i <= n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const float x = __uint_as_float((uint32_t)i);
+    const float a = srgb_oetf_lds(x, s_pow), b = srgb_oetf_direct(x, math_tab + kPowDirOff);
+    if (__float_as_uint(a) != __float_as_uint(b)) bad_lds++;
+    // the round-1 evaluation only covers x >= 2^-15 on the pow segment -- all of it: the segment starts at 0.0031308
+    if (__float_as_uint(b) != __float_as_uint(srgb_oetf_table(x, math_tab))) bad_old++;
+  }
+  atomicAdd(&out[0], bad_lds);
+  atomicAdd(&out[1], bad_old);
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[2] = n + 1;
+}
+
+// the per-sample composite of pass 2 (generate_gainmap.hip: affine_code, gamma 1) restated here against the device-built table
+__global__ __launch_bounds__(256) void sweep_affine(unsigned long long* out, const AffineDev* dev, int ch, const double* math_tab) {
+  __shared__ uint2 s_tab[kAffTabMax];
+  const AffineTabDev td = dev->tab[ch];
+  if (!td.ok) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[3] = 1;  // no table for this range
+    return;
+  }
+  const uint2* src = (const uint2*)((const char*)dev + kAffineTablesOff) + (size_t)ch * kAffTabMax;
+  for (uint32_t i = threadIdx.x; i < td.n; i += 256) s_tab[i] = src[i];
+  __syncthreads();
+  StepTab st;
+  st.tab = nullptr; st.n = td.n; st.base8 = td.base8; st.shm3 = td.shm3; st.lo_bits = td.lo_bits; st.hi_bits = td.hi_bits;
+  const float mn = dev->mn[ch];
+  const double rr = dev->range_rcp[ch];
+  const uint32_t margin = 1u << 20;
+  const uint64_t first = td.lo_bits - margin, last = (uint64_t)td.hi_bits + margin;
+  unsigned long long bad = 0;
+  for (uint64_t i = first + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i <= last; i += (uint64_t)gridDim.x * blockDim.x) {
+    const float q = __uint_as_float((uint32_t)i);
+    const float g = (float)log2_table_f64(q, math_tab);
+    float m = div_by_rcp64(g - mn, rr);
+    m *= 255.0f;
+    float t2 = m + 0.5f;
+    t2 = (t2 < 0.0f) ? 0.0f : ((t2 > 255.0f) ? 255.0f : t2);
+    if (step_code(q, s_tab, st) != (uint32_t)t2) bad++;
+  }
+  atomicAdd(&out[0], bad);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { out[1] = last - first + 1; out[2] = td.n; }
+}
+
+}  // namespace
+
+// out: 8 zero-initialised device words.  which 4: dev = the AffineDev + tables to check (built by launch_minmax_table), arg0 = channel
+hipError_t launch_selftest(int which, unsigned long long* out, uint32_t arg0, uint32_t arg1, uint32_t seed, const double* math_tab, const AffineDev* dev,
+                           hipStream_t s) {
+  int cus = 256, devid = 0;
+  if (hipGetDevice(&devid) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, devid);
+  const dim3 grid(cus * 8), block(256);
+  switch (which) {
+    case 0: hipLaunchKernelGGL(sweep_rpi, grid, block, 0, s, out); break;
+    case 1: hipLaunchKernelGGL(sweep_rcp, grid, block, 0, s, out); break;
+    case 2: hipLaunchKernelGGL(sweep_div, grid, block, 0, s, out, seed, arg0, arg1); break;
+    case 3: hipLaunchKernelGGL(sweep_srgb, grid, block, 0, s, out, math_tab); break;
+    case 4: hipLaunchKernelGGL(sweep_affine, grid, block, 0, s, out, dev, (int)arg0, math_tab); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace uhdr

@@ -1675,8 +1675,36 @@ int uhdr_hip_oetf_code_thresholds(uhdr_color_transfer_t ct, float thresholds[102
   return 0;
 }
 
+uhdr_error_info_t uhdr_hip_selftest(uhdr_hip_ctx_t* c, int which, unsigned int arg0, unsigned int arg1, unsigned int seed, const float mm[6],
+                                    unsigned long long out[8]) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  if (!out || which < 0 || which > 4 || (which == 4 && (!mm || arg0 > 2 || arg1 < 1 || arg1 > 3 || arg0 >= arg1)) || (which == 2 && (arg0 < 1 || arg1 > 254 || arg0 > arg1)))
+    return err_status(UHDR_CODEC_INVALID_PARAM, "bad self-test arguments");
+  HIP_TRY(hipSetDevice(c->device));
+  UHDR_TRY(upload_math(c));
+  UHDR_TRY(ensure(c->affine, kAffineDevBytes));
+  UHDR_TRY(ensure(c->exchange, 256));
+  unsigned long long* d_out = (unsigned long long*)c->exchange.p;
+  HIP_TRY(hipMemsetAsync(d_out, 0, 64, c->stream));
+  if (which == 4) {
+    MinmaxTableParams t;
+    memset(&t, 0, sizeof t);
+    t.do_table = 1;
+    t.nch = (int)arg1;
+    t.gamma = 1.0f;
+    for (int i = 0; i < 6; i++) t.final_mm[i] = mm[i];
+    t.dev = (AffineDev*)c->affine.p;
+    t.math_tab = c->d_math;
+    HIP_TRY(launch_minmax_table(t, c->stream));
+  }
+  HIP_TRY(launch_selftest(which, d_out, arg0, arg1, seed, c->d_math, (const AffineDev*)c->affine.p, c->stream));
+  HIP_TRY(hipMemcpyAsync(out, d_out, 64, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return ok_status();
+}
+
 int uhdr_hip_exact_math_eval(int fn, const float* in, float* out, size_t n) {
-  if (!in || !out || fn < 0 || fn > 4) return -1;
+  if (!in || !out || fn < 0 || fn > 5) return -1;
   const double* T = host::math_tables().data();
   if (fn == 2) {  // in[0] = the constant divisor b; out[i] = div_const(in[i], b, 1/b) for i >= 1
     if (n < 1) return -1;
@@ -1699,6 +1727,10 @@ int uhdr_hip_exact_math_eval(int fn, const float* in, float* out, size_t n) {
     const double rbd = 1.0 / (double)in[0];
     out[0] = (float)rbd;
     for (size_t i = 1; i < n; i++) out[i] = div_by_rcp64(in[i], rbd);
+    return 0;
+  }
+  if (fn == 5) {  // the round-4 form of srgbOetf: direct pow table (exact_math.h: srgb_oetf_direct)
+    for (size_t i = 0; i < n; i++) out[i] = srgb_oetf_direct(in[i], T + kPowDirOff);
     return 0;
   }
   for (size_t i = 0; i < n; i++) out[i] = fn == 0 ? srgb_oetf_table(in[i], T) : (float)log2_table_f64(in[i], T);

@@ -250,6 +250,8 @@ int apply_quad_mode(const ApplyParams& p);  // >= 0: the quad kernel (and batch 
 hipError_t launch_generate_gainmap(const GenParams& p, bool two_pass, hipStream_t s);
 hipError_t launch_affine_map(const AffineParams& p, hipStream_t s);
 hipError_t launch_minmax_table(const MinmaxTableParams& p, hipStream_t s);
+hipError_t launch_selftest(int which, unsigned long long* out, uint32_t arg0, uint32_t arg1, uint32_t seed, const double* math_tab, const AffineDev* dev,
+                           hipStream_t s);  // selftest.hip
 int gen_partials_count(const GenParams& p);  // workgroups (= partials) launch_generate_gainmap(p, two_pass = true) writes
 hipError_t launch_encode_api0_fused(const FusedParams& p, bool two_pass, int* grid_out, hipStream_t s);
 hipError_t launch_tone_map(const ToneMapParams& p, hipStream_t s);
