@@ -154,15 +154,20 @@ bool jpeg_compress_on_device(jpeg_compress_struct* cinfo, const unsigned char* p
   for (int c = 0; c < nc; c++) {
     pw[c] = ceil_div(cinfo->image_width * cinfo->comp_info[c].h_samp_factor, max_h);
     ph[c] = ceil_div(cinfo->image_height * cinfo->comp_info[c].v_samp_factor, max_v);
-    // whole blocks only: partial edge blocks take libjpeg's (and the helper's) padding rules
-    if (pw[c] % 8 || ph[c] % 8) return false;
-    bw[c] = pw[c] / 8;
-    bh[c] = ph[c] / 8;
-    if (bw[c] % cinfo->comp_info[c].h_samp_factor || bh[c] % cinfo->comp_info[c].v_samp_factor) return false;  // no dummy blocks
+    bw[c] = ceil_div(pw[c], 8);  // the component's REAL blocks (jpeg_component_info::width_in_blocks / height_in_blocks)
+    bh[c] = ceil_div(ph[c], 8);
   }
   const bool rgb = format == UHDR_IMG_FMT_24bppRGB888;
   if (rgb && nc != 3) return false;
+  // Round 4: partial edge blocks (a 1920x1080 base image has 960x540 chroma planes, a 4K frame a 960x540 gain map) and the
+  // dummy blocks that complete edge MCUs are made on the device by the helper's / libjpeg's own rules
+  // (uhdr_hip_jpeg_encode_image), so every geometry takes the device route.
   if (!getenv("UHDR_HIP_SEAM_CPU_ENTROPY") && device_scan_encode(cinfo, nc, planes, strides, rgb, bw, bh, icc, icc_size, comment, st)) return true;
+  // the route below (device FDCT -> jpeg_write_coefficients, libjpeg's Huffman pass) keeps whole-block planes only
+  for (int c = 0; c < nc; c++) {
+    if (pw[c] % 8 || ph[c] % 8) return false;
+    if (bw[c] % cinfo->comp_info[c].h_samp_factor || bh[c] % cinfo->comp_info[c].v_samp_factor) return false;  // no dummy blocks
+  }
 
   Scratch sc((j_common_ptr)cinfo);
   const unsigned char* src[3] = {planes[0], planes[1], planes[2]};

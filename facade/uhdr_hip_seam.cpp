@@ -217,8 +217,9 @@ bool encode_scan(const void* scan, const void* qtables, const unsigned char* con
                  int rgb_channels, unsigned char* out, size_t cap, size_t* bytes, uhdr_error_info_t* st) {
   if (!cur()) return false;
   enter();
-  *st = uhdr_hip_jpeg_encode_scan(cur(), static_cast<const uhdr_hip_jpeg_scan_t*>(scan), static_cast<const uint16_t(*)[64]>(qtables), planes, strides,
-                                  rgb_channels, out, cap, bytes);
+  // the IMAGE's planes with the caller's strides: partial edge blocks are padded on the device by the helper's own rules
+  *st = uhdr_hip_jpeg_encode_image(cur(), static_cast<const uhdr_hip_jpeg_scan_t*>(scan), static_cast<const uint16_t(*)[64]>(qtables), planes, strides,
+                                   rgb_channels, out, cap, bytes);
   return handled(*st, "jpeg_encode_scan");
 }
 

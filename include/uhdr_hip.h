@@ -565,6 +565,20 @@ uhdr_error_info_t uhdr_hip_jpeg_encode_scan(uhdr_hip_ctx_t* ctx, const uhdr_hip_
                                             const uint16_t qtable[3][64], const uint8_t* const planes[3],
                                             const unsigned int strides[3], int rgb_channels, uint8_t* out,
                                             size_t out_capacity, size_t* out_bytes);
+/* The same with the IMAGE's own planes -- JpegEncoderHelper::compressImage's contract (jpegencoderhelper.cpp:101-309): plane c
+ * holds ceil(w * h_samp[c] / max_h) x ceil(h * v_samp[c] / max_v) samples (scan->blocks_w / _h = its REAL blocks, ceil(.. / 8)),
+ * strides in bytes as the caller has them.  Whatever partial edge blocks need beyond those samples is made up on the device
+ * exactly as the helper does on the host (jpegencoderhelper.cpp:246-309): with a stride that covers the block-aligned width
+ * the columns behind the plane width are the caller's own bytes there and the rows below the plane height are 0 (component 0)
+ * / 128; with a shorter stride the columns are 0 / 128 and the rows below repeat the helper's stale scratch rows (the rows one
+ * MCU row up; zeros in the first MCU row).  Packed RGB (rgb_channels 3 / 4, any w x h): the last column / row is replicated,
+ * which is what libjpeg's scanline pipeline does (jcsample.c expand_right_edge, jcprepct.c expand_bottom_edge).  Dummy blocks
+ * that complete edge MCUs are the entropy coder's business (uhdr_hip_huffman_encode_dev).  A 1920x1080 4:2:0 base image
+ * (960x540 chroma planes) or the 960x540 map of a 4K frame therefore encode on the device, byte-identical to the reference. */
+uhdr_error_info_t uhdr_hip_jpeg_encode_image(uhdr_hip_ctx_t* ctx, const uhdr_hip_jpeg_scan_t* scan,
+                                            const uint16_t qtable[3][64], const uint8_t* const planes[3],
+                                            const unsigned int strides[3], int rgb_channels, uint8_t* out,
+                                            size_t out_capacity, size_t* out_bytes);
 
 /* ---- device-resident handoff between host-buffer calls -----------------------------------------------------------
  * JpegR::decodeJPEGR (jpegr.cpp:1467-1530) decodes the base image and the gain map into JpegDecoderHelper buffers and hands

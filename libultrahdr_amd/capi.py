@@ -219,6 +219,8 @@ _SIGS = {
     "uhdr_hip_jpeg_decode_scan": (ErrorInfo, [C.c_void_p, _P(JpegHeader), C.c_void_p, C.c_size_t, C.c_int, C.c_int, _P(C.c_void_p), _P(C.c_uint), _P(C.c_uint)]),
     "uhdr_hip_jpeg_encode_scan": (ErrorInfo, [C.c_void_p, _P(JpegScan), C.c_void_p, _P(C.c_void_p), _P(C.c_uint), C.c_int, C.c_void_p, C.c_size_t,
                                               _P(C.c_size_t)]),
+    "uhdr_hip_jpeg_encode_image": (ErrorInfo, [C.c_void_p, _P(JpegScan), C.c_void_p, _P(C.c_void_p), _P(C.c_uint), C.c_int, C.c_void_p, C.c_size_t,
+                                              _P(C.c_size_t)]),
     "uhdr_hip_jpeg_assemble": (C.c_size_t, [_P(JpegScan), _P(C.c_uint16), _P(C.c_uint16), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "uhdr_hip_apply_effect": (ErrorInfo, [C.c_void_p, C.c_int, C.c_int, C.c_int, _P(RawImage), _P(RawImage)]),
     "uhdr_hip_apply_effect_dev": (ErrorInfo, [C.c_void_p, C.c_int, C.c_int, C.c_int, _P(RawImage), _P(RawImage)]),

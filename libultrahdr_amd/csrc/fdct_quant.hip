@@ -19,6 +19,8 @@
 // +-128 -> row pass <= 2^13 -> column pass <= 2^16; constants < 2^15), so the multiplies are the
 // full-rate 24-bit ones (v_mul_i32_i24 returns the low 32 bits of the exact product).
 // A wave keeps walking tiles (grid = resident waves) so the set-up is paid once.
+#include <string.h>
+
 #include "uhdr_types.h"
 
 namespace uhdr {
@@ -81,10 +83,34 @@ struct QuantArgs {
   uint32_t qm[64];  // ceil(2^32 / qv)
 };
 
+// The eight samples of row y, columns x0 .. x0 + 7 of a block that reaches beyond the plane's w x h valid samples, by
+// JpegEncoderHelper::compressYCbCr's rules (jpegencoderhelper.cpp:246-309; FdctEdge in uhdr_types.h):
+//   the caller's row pitch covers the block-aligned width (col_mode 0): columns >= w are the bytes that sit there (the
+//     helper hands libjpeg pointers into the caller's rows), rows >= h are a constant row of `fill` (mPlanesMCURow);
+//   it does not (col_mode 1): the helper copies every row into a scratch MCU row whose tail is `fill`; rows >= h are never
+//     written, they still hold what the PREVIOUS MCU row copied there -- row y - mcu_rows of the plane (zeros in the first).
+__device__ __forceinline__ void load8_edge(const uint8_t* plane, size_t stride, int x0, int y, const FdctEdge& e, int in[8]) {
+  int ys = y;
+  bool row_const = false;
+  if (y >= e.h) {
+    if (e.col_mode == 0) row_const = true;
+    else ys = y - e.mcu_rows;
+  }
+#pragma unroll
+  for (int c = 0; c < 8; c++) {
+    const int x = x0 + c;
+    int v;
+    if (row_const) v = e.fill;
+    else if (x >= e.w) v = e.col_mode == 0 ? (int)plane[(size_t)ys * stride + x] : e.fill;
+    else v = ys < 0 ? 0 : (int)plane[(size_t)ys * stride + x];
+    in[c] = v - 128;
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void fdct_quant_kernel(const uint8_t* __restrict__ plane,
                                                             size_t stride, int bw, int bh,
                                                             const QuantArgs qa,
-                                                            int16_t* __restrict__ coef) {
+                                                            int16_t* __restrict__ coef, const FdctEdge edge) {
   // per wave: 8 blocks x 8 rows x 9 (padded) words
   __shared__ int s_ws[kBlock / 64][8 * 8 * 9];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -109,7 +135,10 @@ __global__ __launch_bounds__(kBlock) void fdct_quant_kernel(const uint8_t* __res
     const int by = t / groups_x, gx = t - by * groups_x;
     const int bx = gx * 8 + rb;
     int in[8], out[8];
-    if (bx < bw) {
+    if (bx < bw && edge.on && (bx * 8 + 8 > edge.w || by * 8 + 8 > edge.h)) {  // a partial block of the right / bottom edge
+      load8_edge(plane, stride, bx * 8, by * 8 + rr, edge, in);
+      fdct_1d<0>(in, out);
+    } else if (bx < bw) {
       const uint8_t* src = plane + (size_t)(by * 8 + rr) * stride + (size_t)bx * 8;
       uint32_t lo, hi;
       if (((uintptr_t)src & 3) == 0) {
@@ -182,7 +211,10 @@ struct QuantArgs2 {
 template <int BPP>
 __global__ __launch_bounds__(kBlock) void fdct_quant_rgb_kernel(const uint8_t* __restrict__ rgb, size_t pitch /* bytes */, int bw, int bh,
                                                                 const QuantArgs2 qa, int16_t* __restrict__ coef_y,
-                                                                int16_t* __restrict__ coef_cb, int16_t* __restrict__ coef_cr) {
+                                                                int16_t* __restrict__ coef_cb, int16_t* __restrict__ coef_cr, int vw, int vh) {
+  // vw x vh: the image's valid pixels.  Blocks that reach beyond them repeat the last column / row -- what libjpeg's
+  // jpeg_write_scanlines pipeline does to an RGB gain map (jcsample.c expand_right_edge, jcprepct.c expand_bottom_edge;
+  // the colour conversion is per pixel, so replicating before or after it is the same).
   __shared__ int s_ws[kBlock / 64][8 * 8 * 9];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int* ws = s_ws[wv];
@@ -200,7 +232,19 @@ __global__ __launch_bounds__(kBlock) void fdct_quant_rgb_kernel(const uint8_t* _
     const int by = t / groups_x, gx = t - by * groups_x;
     const int bx = gx * 8 + rb;
     int comp[3][8];
-    if (bx < bw) {
+    const bool partial = bx * 8 + 8 > vw || by * 8 + 8 > vh;
+    if (bx < bw && partial) {
+      const int y = min(by * 8 + rr, vh - 1);
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const uint8_t* q = rgb + (size_t)y * pitch + (size_t)min(bx * 8 + k, vw - 1) * BPP;
+        const int r = q[0], g = q[1], b = q[2];
+        const int half = 1 << 15, off = 128 << 16;
+        comp[0][k] = ((__mul24(FIX16(0.29900), r) + __mul24(FIX16(0.58700), g) + __mul24(FIX16(0.11400), b) + half) >> 16) - 128;
+        comp[1][k] = ((__mul24(-FIX16(0.16874), r) + __mul24(-FIX16(0.33126), g) + __mul24(FIX16(0.50000), b) + off + half - 1) >> 16) - 128;
+        comp[2][k] = ((__mul24(FIX16(0.50000), r) + __mul24(-FIX16(0.41869), g) + __mul24(-FIX16(0.08131), b) + off + half - 1) >> 16) - 128;
+      }
+    } else if (bx < bw) {
       const uint8_t* src = rgb + (size_t)(by * 8 + rr) * pitch + (size_t)bx * 8 * BPP;
       uint32_t w[2 * BPP];
       if constexpr (BPP == 4) {
@@ -283,7 +327,10 @@ static void fill_quant_args(const uint16_t* qt_host, QuantArgs* qa) {
 }  // namespace
 
 hipError_t launch_fdct_quant(const uint8_t* plane, size_t stride, int bw, int bh,
-                             const uint16_t* qt_host, int16_t* coef, hipStream_t s) {
+                             const uint16_t* qt_host, int16_t* coef, hipStream_t s, const FdctEdge* edge) {
+  FdctEdge e;
+  memset(&e, 0, sizeof e);
+  if (edge) e = *edge;
   QuantArgs qa;
   for (int i = 0; i < 64; i++) {
     qa.qv[i] = (uint32_t)qt_host[i] << 3;
@@ -299,13 +346,15 @@ hipError_t launch_fdct_quant(const uint8_t* plane, size_t stride, int bw, int bh
   int grid = (total + 3) / 4;
   if (grid > resident) grid = resident;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(fdct_quant_kernel, dim3(grid), dim3(kBlock), 0, s, plane, stride, bw, bh, qa, coef);
+  hipLaunchKernelGGL(fdct_quant_kernel, dim3(grid), dim3(kBlock), 0, s, plane, stride, bw, bh, qa, coef, e);
   return hipGetLastError();
 }
 
 // bpp 3 (RGB888) or 4 (RGBA8888, alpha ignored); pitch in bytes; rows and base 8- (bpp 3) / 16-byte (bpp 4) aligned
 hipError_t launch_fdct_quant_rgb(const uint8_t* rgb, size_t pitch, int bpp, int bw, int bh, const uint16_t* qt_luma_host,
-                                 const uint16_t* qt_chroma_host, int16_t* coef_y, int16_t* coef_cb, int16_t* coef_cr, hipStream_t s) {
+                                 const uint16_t* qt_chroma_host, int16_t* coef_y, int16_t* coef_cb, int16_t* coef_cr, hipStream_t s, int vw, int vh) {
+  if (vw <= 0) vw = bw * 8;
+  if (vh <= 0) vh = bh * 8;
   QuantArgs2 qa;
   fill_quant_args(qt_luma_host, &qa.y);
   fill_quant_args(qt_chroma_host, &qa.c);
@@ -315,8 +364,8 @@ hipError_t launch_fdct_quant_rgb(const uint8_t* rgb, size_t pitch, int bpp, int 
   int grid = (total + 3) / 4;
   if (grid > cus * 6) grid = cus * 6;
   if (grid < 1) grid = 1;
-  if (bpp == 4) hipLaunchKernelGGL((fdct_quant_rgb_kernel<4>), dim3(grid), dim3(kBlock), 0, s, rgb, pitch, bw, bh, qa, coef_y, coef_cb, coef_cr);
-  else hipLaunchKernelGGL((fdct_quant_rgb_kernel<3>), dim3(grid), dim3(kBlock), 0, s, rgb, pitch, bw, bh, qa, coef_y, coef_cb, coef_cr);
+  if (bpp == 4) hipLaunchKernelGGL((fdct_quant_rgb_kernel<4>), dim3(grid), dim3(kBlock), 0, s, rgb, pitch, bw, bh, qa, coef_y, coef_cb, coef_cr, vw, vh);
+  else hipLaunchKernelGGL((fdct_quant_rgb_kernel<3>), dim3(grid), dim3(kBlock), 0, s, rgb, pitch, bw, bh, qa, coef_y, coef_cb, coef_cr, vw, vh);
   return hipGetLastError();
 }
 

@@ -2718,9 +2718,11 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
 // JpegEncoderHelper::compressImage's sample -> entropy-coded-data part (jpegencoderhelper.cpp:131-309) on the device: FDCT +
 // quantization (and rgb_ycc_convert for a packed RGB gain map) feed the restart-interval Huffman encoder without the
 // coefficients leaving HBM; only the samples go up and only the compressed bytes come down.
-uhdr_error_info_t uhdr_hip_jpeg_encode_scan(uhdr_hip_ctx_t* c, const uhdr_hip_jpeg_scan_t* scan, const uint16_t qtable[3][64],
-                                            const uint8_t* const planes[3], const unsigned int strides[3], int rgb_channels, uint8_t* out,
-                                            size_t out_capacity, size_t* out_bytes) {
+// image_edges: the planes are the IMAGE's planes and partial edge blocks get their missing samples on the device by the
+// reference helper's rules (FdctEdge, fdct_quant.hip); else the caller has padded every plane to whole blocks.
+static uhdr_error_info_t jpeg_encode_impl(uhdr_hip_ctx_t* c, const uhdr_hip_jpeg_scan_t* scan, const uint16_t qtable[3][64],
+                                          const uint8_t* const planes[3], const unsigned int strides[3], int rgb_channels, uint8_t* out,
+                                          size_t out_capacity, size_t* out_bytes, bool image_edges) {
   if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
   if (!scan || !qtable || !planes || !strides || !out || !out_bytes) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument for jpeg_encode_scan");
   if (rgb_channels != 0 && rgb_channels != 3 && rgb_channels != 4) return err_status(UHDR_CODEC_INVALID_PARAM, "rgb_channels is 0 (planes), 3 (RGB888) or 4 (RGBA8888), received %d", rgb_channels);
@@ -2740,65 +2742,108 @@ uhdr_error_info_t uhdr_hip_jpeg_encode_scan(uhdr_hip_ctx_t* c, const uhdr_hip_jp
     coef_bytes += b;
   }
   if (rgb_channels == 0) {
-    size_t pitch[3] = {0, 0, 0}, off[3] = {0, 0, 0}, total = 0;
+    // valid samples per plane (JpegEncoderHelper::encode's mPlaneWidth / mPlaneHeight, jpegencoderhelper.cpp:190-195) and what is copied up
+    int hmax = 1, vmax = 1;
     for (int i = 0; i < nc; i++) {
-      if (!planes[i] || strides[i] < (unsigned)sc.blocks_w[i] * 8) return err_status(UHDR_CODEC_INVALID_PARAM, "plane %d: nullptr or stride below blocks_w * 8", i);
-      pitch[i] = ((size_t)sc.blocks_w[i] * 8 + 63) & ~(size_t)63;
+      if (nc == 3 && sc.h_samp[i] > hmax) hmax = sc.h_samp[i];
+      if (nc == 3 && sc.v_samp[i] > vmax) vmax = sc.v_samp[i];
+    }
+    unsigned pw[3] = {0, 0, 0}, ph[3] = {0, 0, 0}, cols[3] = {0, 0, 0}, rows[3] = {0, 0, 0};
+    FdctEdge edge[3];
+    memset(edge, 0, sizeof edge);
+    size_t pitch[3] = {0, 0, 0}, off[3] = {0, 0, 0}, total = 0;
+    bool width_partial = false;
+    for (int i = 0; i < nc; i++) {
+      const unsigned aligned = (unsigned)sc.blocks_w[i] * 8;
+      if (image_edges) {
+        const int hs = nc == 1 ? 1 : sc.h_samp[i], vs = nc == 1 ? 1 : sc.v_samp[i];
+        pw[i] = (sc.w * hs + hmax - 1) / hmax;
+        ph[i] = (sc.h * vs + vmax - 1) / vmax;
+        if ((unsigned)sc.blocks_w[i] != (pw[i] + 7) / 8 || (unsigned)sc.blocks_h[i] != (ph[i] + 7) / 8)
+          return err_status(UHDR_CODEC_INVALID_PARAM, "component %d: %dx%d blocks are not the real blocks of a %ux%u plane", i, sc.blocks_w[i], sc.blocks_h[i], pw[i], ph[i]);
+        if (!planes[i] || strides[i] < pw[i]) return err_status(UHDR_CODEC_INVALID_PARAM, "plane %d: nullptr or stride below the plane width", i);
+        edge[i].on = (pw[i] % 8 || ph[i] % 8) ? 1 : 0;
+        edge[i].w = (int)pw[i];
+        edge[i].h = (int)ph[i];
+        edge[i].col_mode = strides[i] >= aligned ? 0 : 1;  // jpegencoderhelper.cpp:257: strides[i] < alignedPlaneWidth[i] copies rows into a scratch MCU row
+        edge[i].fill = i == 0 ? 0 : 128;
+        edge[i].mcu_rows = vs * 8;
+        cols[i] = edge[i].col_mode == 0 ? aligned : pw[i];
+        rows[i] = ph[i];
+        if (pw[i] % 8) width_partial = true;
+      } else {
+        if (!planes[i] || strides[i] < aligned) return err_status(UHDR_CODEC_INVALID_PARAM, "plane %d: nullptr or stride below blocks_w * 8", i);
+        pw[i] = cols[i] = aligned;
+        ph[i] = rows[i] = (unsigned)sc.blocks_h[i] * 8;
+      }
+      pitch[i] = ((size_t)aligned + 63) & ~(size_t)63;
       off[i] = total;
       total += pitch[i] * (size_t)sc.blocks_h[i] * 8;
     }
-    // planes the library itself produced a moment ago (resident_keep) are read where they are
+    // planes the library itself produced a moment ago (resident_keep) are read where they are -- unless a plane's width
+    // is not whole blocks: the bytes BEHIND the width are then part of the input (the caller's stride bytes) and only the
+    // host buffer has them
     const uhdr_hip_ctx::Resident* held = nullptr;
-    if (c->resident_on)
+    if (c->resident_on && !width_partial)
       for (const auto& r : c->resident) {
         bool ok = r.valid && r.fmt != UHDR_IMG_FMT_24bppRGB888 && r.fmt != UHDR_IMG_FMT_32bppRGBA8888;
         for (int i = 0; ok && i < nc; i++)
-          ok = r.host[i] == planes[i] && r.host_stride[i] == strides[i] && r.pcols[i] >= (unsigned)sc.blocks_w[i] * 8 && r.prows[i] >= (unsigned)sc.blocks_h[i] * 8;
+          ok = r.host[i] == planes[i] && r.host_stride[i] == strides[i] && r.pcols[i] >= cols[i] && r.prows[i] >= rows[i];
         if (ok) { held = &r; break; }
       }
+    auto fdct = [&](int i, const uint8_t* d, size_t dpitch) -> uhdr_error_info_t {
+      for (int k = 0; k < 64; k++)
+        if (qtable[i][k] == 0 || qtable[i][k] > 255) return err_status(UHDR_CODEC_INVALID_PARAM, "quantization table entry %d out of baseline range", k);
+      ProfScope ps(c, "fdct_quant");
+      HIP_TRY(launch_fdct_quant(d, dpitch, sc.blocks_w[i], sc.blocks_h[i], qtable[i], (int16_t*)c->jpg[1 + i].p, c->stream, image_edges ? &edge[i] : nullptr));
+      return ok_status();
+    };
     if (held) {
       c->stats.resident_hits++;
-      for (int i = 0; i < nc; i++)
-        UHDR_TRY(uhdr_hip_fdct_quant_dev(c, (const uint8_t*)held->buf.p + held->off[i], held->dev_stride[i], sc.blocks_w[i], sc.blocks_h[i], qtable[i],
-                                         (int16_t*)c->jpg[1 + i].p));
+      for (int i = 0; i < nc; i++) UHDR_TRY(fdct(i, (const uint8_t*)held->buf.p + held->off[i], held->dev_stride[i]));
     } else {
       UHDR_TRY(ensure(c->jpg[4], total));
       for (int i = 0; i < nc; i++) {
         uint8_t* d = (uint8_t*)c->jpg[4].p + off[i];
-        HIP_TRY(hipMemcpy2DAsync(d, pitch[i], planes[i], strides[i], (size_t)sc.blocks_w[i] * 8, (size_t)sc.blocks_h[i] * 8, hipMemcpyHostToDevice, c->stream));
-        UHDR_TRY(uhdr_hip_fdct_quant_dev(c, d, pitch[i], sc.blocks_w[i], sc.blocks_h[i], qtable[i], (int16_t*)c->jpg[1 + i].p));
+        HIP_TRY(hipMemcpy2DAsync(d, pitch[i], planes[i], strides[i], cols[i], rows[i], hipMemcpyHostToDevice, c->stream));
+        UHDR_TRY(fdct(i, d, pitch[i]));
       }
     }
   } else {
     if (nc != 3 || bpm != 3) return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "packed RGB input is a 3-component 4:4:4 scan");
-    if (sc.w % 8 || sc.h % 8 || (unsigned)sc.blocks_w[0] * 8 != sc.w || (unsigned)sc.blocks_h[0] * 8 != sc.h)
-      return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "packed RGB input needs dimensions that are multiples of 8 (libjpeg's edge replication is outside the HIP path)");
+    if (!image_edges && (sc.w % 8 || sc.h % 8))
+      return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "packed RGB input needs dimensions that are multiples of 8 here (uhdr_hip_jpeg_encode_image replicates the edges as libjpeg does)");
+    if ((unsigned)sc.blocks_w[0] != (sc.w + 7) / 8 || (unsigned)sc.blocks_h[0] != (sc.h + 7) / 8)
+      return err_status(UHDR_CODEC_INVALID_PARAM, "a %dx%d block grid does not match a %ux%u RGB image", sc.blocks_w[0], sc.blocks_h[0], sc.w, sc.h);
     if (memcmp(qtable[1], qtable[2], 64 * sizeof(uint16_t)))
       return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "packed RGB input with different Cb and Cr quantization tables is outside the HIP path");
     if (!planes[0] || strides[0] < sc.w) return err_status(UHDR_CODEC_INVALID_PARAM, "RGB image: nullptr or stride below the width");
-    uhdr_raw_image_t rgb;
-    memset(&rgb, 0, sizeof rgb);
-    rgb.fmt = rgb_channels == 3 ? UHDR_IMG_FMT_24bppRGB888 : UHDR_IMG_FMT_32bppRGBA8888;
-    rgb.w = sc.w;
-    rgb.h = sc.h;
+    for (int i = 0; i < 64; i++)
+      if (qtable[0][i] == 0 || qtable[0][i] > 255 || qtable[1][i] == 0 || qtable[1][i] > 255)
+        return err_status(UHDR_CODEC_INVALID_PARAM, "quantization table entry %d out of baseline range", i);
+    const uint8_t* dsrc = nullptr;
+    size_t dpitch = 0;
+    const uhdr_img_fmt_t fmt = rgb_channels == 3 ? UHDR_IMG_FMT_24bppRGB888 : UHDR_IMG_FMT_32bppRGBA8888;
     const uhdr_hip_ctx::Resident* held = nullptr;
     if (c->resident_on)
       for (const auto& r : c->resident)
-        if (r.valid && r.fmt == rgb.fmt && r.host[0] == planes[0] && r.host_stride[0] == strides[0] && r.pcols[0] >= sc.w && r.prows[0] >= sc.h &&
+        if (r.valid && r.fmt == fmt && r.host[0] == planes[0] && r.host_stride[0] == strides[0] && r.pcols[0] >= sc.w && r.prows[0] >= sc.h &&
             ((size_t)r.dev_stride[0] * rgb_channels) % (rgb_channels == 4 ? 16 : 8) == 0) { held = &r; break; }  // (the fused kernel's row alignment)
     if (held) {  // the gain map generateGainMap has just written (resident_keep): read where it is
       c->stats.resident_hits++;
-      rgb.planes[0] = (char*)held->buf.p + held->off[0];
-      rgb.stride[0] = held->dev_stride[0];
+      dsrc = (const uint8_t*)held->buf.p + held->off[0];
+      dpitch = (size_t)held->dev_stride[0] * rgb_channels;
     } else {
       const size_t pitch_px = ((size_t)sc.w + 15) & ~(size_t)15;
       UHDR_TRY(ensure(c->jpg[4], pitch_px * (size_t)rgb_channels * sc.h));
       HIP_TRY(hipMemcpy2DAsync(c->jpg[4].p, pitch_px * rgb_channels, planes[0], (size_t)strides[0] * rgb_channels, (size_t)sc.w * rgb_channels, sc.h,
                                hipMemcpyHostToDevice, c->stream));
-      rgb.planes[0] = c->jpg[4].p;
-      rgb.stride[0] = (unsigned int)pitch_px;
+      dsrc = (const uint8_t*)c->jpg[4].p;
+      dpitch = pitch_px * rgb_channels;
     }
-    UHDR_TRY(uhdr_hip_fdct_quant_rgb_dev(c, &rgb, qtable[0], qtable[1], (int16_t*)c->jpg[1].p, (int16_t*)c->jpg[2].p, (int16_t*)c->jpg[3].p));
+    ProfScope ps(c, "fdct_quant");
+    HIP_TRY(launch_fdct_quant_rgb(dsrc, dpitch, rgb_channels, sc.blocks_w[0], sc.blocks_h[0], qtable[0], qtable[1], (int16_t*)c->jpg[1].p,
+                                  (int16_t*)c->jpg[2].p, (int16_t*)c->jpg[3].p, c->stream, (int)sc.w, (int)sc.h));
   }
   size_t cap = coef_bytes / 4 + (1u << 20), n = 0;
   UHDR_TRY(ensure(c->jpg[0], cap));
@@ -2813,6 +2858,17 @@ uhdr_error_info_t uhdr_hip_jpeg_encode_scan(uhdr_hip_ctx_t* c, const uhdr_hip_jp
   HIP_TRY(hipMemcpyAsync(out, c->jpg[0].p, n, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return ok_status();
+}
+
+uhdr_error_info_t uhdr_hip_jpeg_encode_scan(uhdr_hip_ctx_t* c, const uhdr_hip_jpeg_scan_t* scan, const uint16_t qtable[3][64],
+                                            const uint8_t* const planes[3], const unsigned int strides[3], int rgb_channels, uint8_t* out,
+                                            size_t out_capacity, size_t* out_bytes) {
+  return jpeg_encode_impl(c, scan, qtable, planes, strides, rgb_channels, out, out_capacity, out_bytes, false);
+}
+uhdr_error_info_t uhdr_hip_jpeg_encode_image(uhdr_hip_ctx_t* c, const uhdr_hip_jpeg_scan_t* scan, const uint16_t qtable[3][64],
+                                             const uint8_t* const planes[3], const unsigned int strides[3], int rgb_channels, uint8_t* out,
+                                             size_t out_capacity, size_t* out_bytes) {
+  return jpeg_encode_impl(c, scan, qtable, planes, strides, rgb_channels, out, out_capacity, out_bytes, true);
 }
 
 // JpegDecoderHelper::decompressImage (jpegdecoderhelper.cpp:169-535) for a baseline file whose headers are parsed: entropy

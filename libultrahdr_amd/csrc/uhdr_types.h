@@ -257,11 +257,20 @@ hipError_t launch_encode_api0_fused(const FusedParams& p, bool two_pass, int* gr
 hipError_t launch_tone_map(const ToneMapParams& p, hipStream_t s);
 hipError_t launch_transform_yuv(const YuvXformParams& p, hipStream_t s);
 hipError_t launch_rgb_to_ycbcr(const RgbToYcbcrParams& p, hipStream_t s);
+// Samples of partial edge blocks, made up on the device the way JpegEncoderHelper::compressYCbCr does on the host
+// (jpegencoderhelper.cpp:246-309): w x h valid samples; col_mode 0 = the plane's pitch covers the block-aligned width and the
+// bytes beyond w are read as they are, rows beyond h are constant `fill`; col_mode 1 = columns beyond w are `fill`, rows beyond
+// h repeat row y - mcu_rows (the helper's stale scratch row; zeros before the first).  fill: 0 for component 0, 128 else.
+struct FdctEdge {
+  int on, w, h, col_mode, fill, mcu_rows;
+};
 hipError_t launch_fdct_quant(const uint8_t* plane, size_t stride, int bw, int bh,
-                             const uint16_t* qt_host, int16_t* coef, hipStream_t s);
+                             const uint16_t* qt_host, int16_t* coef, hipStream_t s, const FdctEdge* edge = nullptr);
 
+// vw x vh > 0: valid pixels; blocks reaching beyond them replicate the last column / row (libjpeg's own padding of scanline input)
 hipError_t launch_fdct_quant_rgb(const uint8_t* rgb, size_t pitch, int bpp, int bw, int bh, const uint16_t* qt_luma_host,
-                                 const uint16_t* qt_chroma_host, int16_t* coef_y, int16_t* coef_cb, int16_t* coef_cr, hipStream_t s);
+                                 const uint16_t* qt_chroma_host, int16_t* coef_y, int16_t* coef_cb, int16_t* coef_cr, hipStream_t s, int vw = 0,
+                                 int vh = 0);
 hipError_t launch_repack(int mode, const void* src, size_t src_pitch, void* dst, size_t dst_pitch, uint32_t w, uint32_t h,
                          hipStream_t s);  // 0: RGB888 -> RGBA8888, 1: RGBA8888 -> Y400
 // ---- image effects (effects.hip) -----------------------------------------------------------------------

@@ -424,6 +424,38 @@ class UltraHdr:
                    (C.c_uint * 3)(*strides), rgb_channels, C.c_void_p(out.ctypes.data), out.size, C.byref(n))
         return self.jpeg_assemble(grids, w, h, sampling, ri, qt_luma, qt_chroma, out[: n.value].tobytes())
 
+    def jpeg_encode_image(self, planes, w: int, h: int, sampling, qt_luma, qt_chroma, rgb_channels: int = 0, restart_interval: int = 0) -> bytes:
+        """JpegEncoderHelper::compressImage's sample -> entropy-coded-data part for the IMAGE's own planes
+        (uhdr_hip_jpeg_encode_image): partial edge blocks are padded on the device by the helper's rules
+        (jpegencoderhelper.cpp:246-309) / libjpeg's edge replication (packed RGB).  planes: uint8 numpy arrays of at least
+        ceil(h * vs / vmax) rows; the row length of each array is its stride (bytes beyond the plane width are the caller's
+        stride bytes), or -- rgb_channels 3 / 4 -- one [h, stride_px, channels] array.  Returns the entropy-coded bytes."""
+        class _Grid:
+            def __init__(self, bh, bw):
+                self.shape = (bh, bw, 64)
+
+        hmax, vmax = max(s_[0] for s_ in sampling), max(s_[1] for s_ in sampling)
+        if rgb_channels:
+            img = np.ascontiguousarray(planes, dtype=np.uint8)
+            grids = [_Grid(-(-h // 8), -(-w // 8))] * 3
+            srcs, strides = [img], [img.shape[1], 0, 0]
+        else:
+            srcs = [np.ascontiguousarray(p, dtype=np.uint8) for p in planes]
+            grids = []
+            for (hs, vs) in (sampling if len(sampling) > 1 else [(1, 1)]):
+                pw, ph = (-(-w * hs // hmax), -(-h * vs // vmax)) if len(sampling) > 1 else (w, h)
+                grids.append(_Grid(-(-ph // 8), -(-pw // 8)))
+            strides = [p.shape[1] for p in srcs] + [0] * (3 - len(srcs))
+        sc = self._scan(grids, w, h, sampling, restart_interval)
+        qt = np.zeros((3, 64), dtype=np.uint16)
+        qt[0], qt[1], qt[2] = qt_luma, qt_chroma, qt_chroma
+        ptrs = (C.c_void_p * 3)(*[p.ctypes.data for p in srcs] + [None] * (3 - len(srcs)))
+        out = np.zeros(sum(p.size for p in srcs) * 2 + (1 << 16), dtype=np.uint8)
+        n = C.c_size_t(0)
+        self._call(False, self.lib.uhdr_hip_jpeg_encode_image, self.ctx.handle, C.byref(sc), C.c_void_p(qt.ctypes.data), ptrs,
+                   (C.c_uint * 3)(*strides), rgb_channels, C.c_void_p(out.ctypes.data), out.size, C.byref(n))
+        return out[: n.value].tobytes()
+
     def jpeg_assemble(self, coefs, w: int, h: int, sampling, restart_interval: int, qt_luma, qt_chroma, scan_data: bytes) -> bytes:
         """Host helper: a complete baseline JFIF file around entropy-coded data (coefs only supply the block grids)."""
         sc = self._scan(coefs, w, h, sampling, restart_interval)

@@ -170,10 +170,39 @@ def test_encode_with_device_entropy_coding_decodes_to_the_same_pixels(multi):
         assert np.array_equal(F.read(os.path.join(d, "dev_gpu.raw")), pa)
 
 
+@pytest.mark.parametrize("w,h,extra,what", [
+    (1920, 1080, (), "1080p: 960 x 540 chroma planes, a dummy luma block row"),
+    (3840, 2160, ("-M", 0, "-s", 4), "4K with the Android-style scale-4 Y400 map: 960 x 540"),
+    (1920, 1080, ("-M", 1, "-s", 1), "1080p, three-channel full-resolution map (packed RGB route)"),
+    (1000, 562, ("-M", 1, "-s", 2), "odd everything: 500 x 281 RGB map, 500 x 281 chroma"),
+])
+def test_partial_block_encodes_run_on_the_device(w, h, extra, what):
+    """Round 4: planes that are not whole 8 x 8 blocks no longer fall back to libjpeg -- the FDCT pads edge blocks on the device
+    by JpegEncoderHelper::compressYCbCr's own rules (jpegencoderhelper.cpp:246-309) / libjpeg's edge replication for packed
+    RGB, the entropy coder adds the dummy blocks of edge MCUs.  Both compressImage calls of the encode must show up as
+    device stages and the file must be the CPU reference's byte for byte."""
+    from libultrahdr_amd import capi as A
+    from libultrahdr_amd import synth
+
+    with tempfile.TemporaryDirectory() as d:
+        hdr = synth.make_hdr_p010(w, h, ct=A.UHDR_CT_HLG)
+        sdr = synth.make_sdr_yuv420(w, h)
+        np.concatenate([hdr.valid(0).ravel(), hdr.valid(1).ravel()]).tofile(os.path.join(d, "in.p010"))
+        np.concatenate([sdr.valid(c).ravel() for c in range(3)]).tofile(os.path.join(d, "in.yuv420"))
+        rc, _, err, _ = F.encode_api1("in.p010", "in.yuv420", w, h, "cpu.jpg", False, d, extra=extra)
+        assert rc == 0, err
+        rc, _, err, trace = F.encode_api1("in.p010", "in.yuv420", w, h, "gpu.jpg", True, d, extra=extra)
+        assert rc == 0, err
+        assert len([l for l in trace if "jpeg_encode_scan -> device" in l]) == 2, (what, trace)
+        assert not [l for l in trace if "jpeg_encode_scan" in l and "-> device" not in l], (what, trace)
+        a, b = F.read(os.path.join(d, "cpu.jpg")), F.read(os.path.join(d, "gpu.jpg"))
+        assert a.size == b.size and np.array_equal(a, b), (what, a.size, b.size)
+
+
 @pytest.mark.parametrize("w,h", [(1000, 562), (642, 362)])
 def test_sizes_with_partial_blocks_through_the_facade(w, h):
-    """Dimensions that are not multiples of the 16 x 16 MCU: the compress seam leaves such planes to libjpeg (its
-    edge-padding rules), the decode seam takes them (dummy blocks are dropped on the device, only the visible samples come
+    """Dimensions that are not multiples of the 16 x 16 MCU: the compress seam pads edge blocks on the device (round 4), the
+    decode seam takes them too (dummy blocks are dropped on the device, only the visible samples come
     back).  Files and decoded frames equal the CPU reference's byte for byte."""
     from libultrahdr_amd import capi as A
     from libultrahdr_amd import synth
@@ -188,6 +217,7 @@ def test_sizes_with_partial_blocks_through_the_facade(w, h):
         rc, _, err, trace = F.encode_api1("in.p010", "in.yuv420", w, h, "gpu.jpg", True, d)
         assert rc == 0, err
         assert "generate_gainmap" in _stages(trace), trace
+        assert len([l for l in trace if "jpeg_encode_scan -> device" in l]) == 2, trace
         a, b = F.read(os.path.join(d, "cpu.jpg")), F.read(os.path.join(d, "gpu.jpg"))
         assert np.array_equal(a, b), f"{int((a != b).sum()) if a.size == b.size else 'size'} differing bytes"
         rc, _, err, _ = F.decode("cpu.jpg", 0, 4, "cpu.raw", False, d)

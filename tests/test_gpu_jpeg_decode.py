@@ -176,6 +176,70 @@ def test_device_encoded_rgb_map_holds_the_oracles_coefficients(uhdr):
         assert np.array_equal(got[c], want[c]), c
 
 
+# ---- partial edge blocks on the device: uhdr_hip_jpeg_encode_image against the REAL reference's files ---------------------------
+def _ref_scan_bytes(uhdr, img, quality):
+    jpeg = L.ref_jpeg_compress(img, quality)
+    hdr = uhdr.jpeg_parse(jpeg)
+    return jpeg[hdr.scan_offset: hdr.scan_offset + hdr.scan_bytes], hdr
+
+
+@pytest.mark.parametrize("w,h", [(1920, 1080), (1000, 562), (333, 217), (24, 10), (8, 8), (17, 9), (640, 476)])
+@pytest.mark.parametrize("wide_stride", [True, False])
+def test_partial_edge_blocks_420_equal_the_reference_file(uhdr, ref, w, h, wide_stride):
+    """JpegEncoderHelper::compressYCbCr's edge rules (jpegencoderhelper.cpp:246-309) on the device: a stride that covers the
+    block-aligned width hands libjpeg the caller's own stride bytes and constant rows below the plane; a shorter one goes
+    through the helper's scratch MCU rows (constant tail, STALE rows below).  Entropy-coded bytes == the reference's."""
+    from libultrahdr_amd.images import Image
+
+    if w % 2 or h % 2:
+        pytest.skip("4:2:0 needs even dimensions in the reference's API")
+    rng = np.random.default_rng(w * 7 + h + wide_stride)
+    align = 64 if wide_stride else 1
+    img = Image(A.UHDR_IMG_FMT_12bppYCbCr420, w, h, align=align)
+    for i in range(3):
+        st = img.plane(i)
+        st[...] = rng.integers(0, 256, st.shape, dtype=np.uint8)  # the stride bytes are part of the input: fill them too
+    want, hdr = _ref_scan_bytes(uhdr, img, 90)
+    planes = [img.plane(i) for i in range(3)]
+    ql, qc = hdr_qt(hdr)
+    got = uhdr.jpeg_encode_image(planes, w, h, S420, ql, qc)
+    assert got == want, (len(got), len(want))
+
+
+@pytest.mark.parametrize("w,h", [(960, 540), (241, 135), (13, 7), (1000, 562)])
+@pytest.mark.parametrize("wide_stride", [True, False])
+def test_partial_edge_blocks_y400_map_equal_the_reference_file(uhdr, ref, w, h, wide_stride):
+    from libultrahdr_amd.images import Image
+
+    rng = np.random.default_rng(w + h * 5 + wide_stride)
+    img = Image(A.UHDR_IMG_FMT_8bppYCbCr400, w, h, align=64 if wide_stride else 1)
+    st = img.plane(0)
+    st[...] = rng.integers(0, 256, st.shape, dtype=np.uint8)
+    want, hdr = _ref_scan_bytes(uhdr, img, 85)
+    ql, qc = hdr_qt(hdr)
+    got = uhdr.jpeg_encode_image([img.plane(0)], w, h, GRAY, ql, qc)
+    assert got == want, (len(got), len(want))
+
+
+@pytest.mark.parametrize("w,h", [(333, 217), (1000, 562), (8, 8), (21, 3)])
+def test_partial_edge_blocks_rgb_map_equal_the_reference_file(uhdr, ref, w, h):
+    """A packed RGB gain map goes through jpeg_write_scanlines in the reference: libjpeg replicates the last column / row."""
+    from libultrahdr_amd.images import Image
+
+    rng = np.random.default_rng(w * 11 + h)
+    img = Image(A.UHDR_IMG_FMT_24bppRGB888, w, h, align=16)
+    st = img.plane(0)
+    st[...] = rng.integers(0, 256, st.shape, dtype=np.uint8)
+    want, hdr = _ref_scan_bytes(uhdr, img, 92)
+    ql, qc = hdr_qt(hdr)
+    got = uhdr.jpeg_encode_image(img.plane(0).reshape(h, img.raw.stride[0], 3), w, h, S444, ql, qc, rgb_channels=3)
+    assert got == want, (len(got), len(want))
+
+
+def hdr_qt(hdr):
+    return np.array(hdr.qtable[0][:], dtype=np.uint16), np.array(hdr.qtable[1][:] if hdr.scan.num_components == 3 else hdr.qtable[0][:], dtype=np.uint16)
+
+
 def test_damaged_files_never_crash_the_device_path(uhdr):
     """Random damage inside the entropy-coded data of a good file: the decode either succeeds (Huffman streams rarely hold
     undefined codes: the result is then simply what the bits say) or reports UHDR_CODEC_INVALID_PARAM /
