@@ -77,7 +77,7 @@ def make_frames(n, w, h, map_kind, device, out_fmt, seed0=1234):
 
 
 CLOCK_RAMP_S = float(os.environ.get("UHDR_BENCH_CLOCK_RAMP_S", "0.7"))  # tools/profile_bench.sh shortens it under the profiler
-CLOCK_RAMP_MAX_S = float(os.environ.get("UHDR_BENCH_CLOCK_RAMP_MAX_S", "4.0"))
+CLOCK_RAMP_MAX_S = float(os.environ.get("UHDR_BENCH_CLOCK_RAMP_MAX_S", "2.0"))  # the fixed cap of the adaptive ramp (round 4: was 4 s)
 
 
 def clock_ramp(ctx, fn, seconds=CLOCK_RAMP_S, adaptive=False):
@@ -218,6 +218,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the OTHER clock regime first (round 4): the first 20 steps after 2 s of idle, no ramp, no warm-up -- what a service
+    # that decodes one batch now and then sees (the part starts from its 1.4 GHz idle clock)
+    cold = None
+    if not os.environ.get("UHDR_BENCH_HEADLINE_ONLY"):
+        ctx.synchronize()
+        time.sleep(2.0)
+        ctx.profile(True)
+        ctx.profile_read(None, reset=True)
+        for _ in range(20):
+            step()
+        ctx.synchronize()
+        cold = ctx.profile_read_list("apply_gainmap", reset=True)
+        ctx.profile(False)
     ramp_t0 = time.perf_counter()
     ramp_steps = clock_ramp(ctx, step, adaptive=True)  # untimed, before the W warm-up steps: see clock_ramp
     ramp_seconds = time.perf_counter() - ramp_t0
@@ -250,7 +263,7 @@ def main():
     achieved = algo_b / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
 
     kernel_name = "apply_quad_kernel<F16," + {"A": "Y400,scale4>", "B": "RGB888,scale1>", "C": "RGBA8888,scale1>"}[args.map]
-    traffic, traffic_src = measured_traffic(f"{kernel_name}|{frames_per_launch}x{w}x{h}", lib.uhdr_hip_version().decode())
+    traffic, traffic_src = measured_traffic(f"{kernel_name}|{frames_per_launch}x{w}x{h}")
 
     out = {
         "metric": "Mpixels/s decode (applyGainMap, YCbCr420 + gain map -> RGBA_F16 linear), 4K frames resident in HBM",
@@ -270,8 +283,8 @@ def main():
                         + " -> RGBA_F16 linear, applyGainMap kernel, device-resident",
             "frames_per_rank_per_step": args.batch,
             "launch": "one batched launch per step" if args.launch == "batch" else "one launch per frame",
-            "clock_ramp": f"{ramp_steps} untimed steps ({ramp_seconds:.1f} s: at least {CLOCK_RAMP_S} s, then until the step time has stopped falling) before the {args.warmup} warm-up steps: the part needs ~0.5 s of load to "
-                          "leave its 1.4 GHz idle clock (profiles/r03_clock_ramp.txt)",
+            "clock_ramp": f"{ramp_steps} untimed steps ({ramp_seconds:.1f} s: at least {CLOCK_RAMP_S} s, then until the step time has stopped falling, at most {CLOCK_RAMP_MAX_S} s) before the {args.warmup} warm-up steps: the part needs ~0.5 s of load to "
+                          "leave its 1.4 GHz idle clock (profiles/r03_clock_ramp.txt); roofline.cold_start_frac is the same launch WITHOUT any ramp",
             "sharding": f"frames x{world} ranks, no data-path collective",
         },
         "roofline": {
@@ -291,13 +304,28 @@ def main():
             "frac_at_median": round(algo_b / (launch_stats(launch_ms)["median"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if launch_ms else None,
         },
     }
+    if cold:  # per-launch HIP events of the first 20 steps after 2 s of idle (frames_per_launch launches of the same kernel)
+        cold_avg_s = sum(cold) / len(cold) / 1e3
+        out["roofline"]["cold_start_frac"] = round(algo_b / cold_avg_s / 1e9 / HBM_PEAK_GBS, 4)
+        out["roofline"]["cold_start_avg_launch_us"] = round(cold_avg_s * 1e6, 2)
+        out["roofline"]["cold_start_first_launch_us"] = round(cold[0] * 1e3, 2)
+        out["roofline"]["cold_start_note"] = "the first 20 steps after 2 s of idle, no clock ramp, no warm-up (sclk starts at its 1.4 GHz idle state)"
 
     # the on-box copy ceiling measured in this very run, and the north-star configuration (ONE 8K frame per
     # launch -> RGBA_F16) as sustained per-launch times, both inside `roofline` (rank 0; they take a few milliseconds)
     if rank == 0 and not os.environ.get("UHDR_BENCH_HEADLINE_ONLY"):  # (tools/profile_bench.sh profiles the headline launch alone)
         try:
             out["roofline"].update(onbox_ceiling(device))
-            out["roofline"]["north_star_8k"] = north_star_8k(ctx, device)
+            ns = north_star_8k(ctx, device)
+            out["roofline"]["north_star_8k"] = ns
+            # the same figures as scalars of `roofline` (round 4: a reader that keeps only scalars sees them)
+            for key, short in (("mapC", "mapC"), ("mapB", "mapB"), ("mapA", "mapA_hot"), ("mapA_cold_inputs", "mapA_cold")):
+                e = ns.get(key)
+                if isinstance(e, dict) and "frac" in e:
+                    out["roofline"][f"ns8k_{short}_frac"] = e["frac"]
+                    out["roofline"][f"ns8k_{short}_us"] = e["sustained_us"]
+                    out["roofline"][f"ns8k_{short}_p10_us"] = e["launch_us"]["p10"] if e.get("launch_us") else None
+                    out["roofline"][f"ns8k_{short}_p90_us"] = e["launch_us"]["p90"] if e.get("launch_us") else None
         except Exception as e:  # noqa: BLE001
             out["roofline"]["north_star_8k"] = {"error": f"{type(e).__name__}: {e}"}
 
@@ -390,7 +418,7 @@ def north_star_8k(ctx, device):
     f16 = A.UHDR_IMG_FMT_64bppRGBAHalfFloat
     md = synth.default_metadata(use_base_cg=0)
     w, h = 7680, 4320
-    for key, kind, nsets in (("mapC", "C", 3), ("mapA", "A", 3), ("mapA_cold_inputs", "A", 6)):
+    for key, kind, nsets in (("mapC", "C", 3), ("mapB", "B", 3), ("mapA", "A", 3), ("mapA_cold_inputs", "A", 6)):
         sets = make_frames(nsets, w, h, kind, device, f16, seed0=4242)
         for s_, g_, _ in sets:
             s_.raw.cg, g_.raw.cg = A.UHDR_CG_BT_709, A.UHDR_CG_BT_2100
@@ -478,11 +506,23 @@ def family_times(ctx, fn, families, iters=5, warm=2):
     return out
 
 
-def measured_traffic(key, library_version):
+def library_sha256():
+    import hashlib
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libultrahdr_amd", "lib", "libuhdr_hip.so")
+    try:
+        with open(path, "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()
+    except OSError:
+        return None
+
+
+def measured_traffic(key):
     """HBM bytes per launch of the dominant kernel as measured with rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE (their own passes, MI355X_MICROARCH.md's gfx950 correction applied) on this exact bench
-    configuration; committed next to the rocprof summaries in profiles/traffic.json.  The entry names the library version it
-    was taken with: a kernel change bumps uhdr_hip_version() and the stale figure is dropped (null) instead of reported."""
+    configuration; committed next to the rocprof summaries in profiles/traffic.json (tools/update_traffic.py writes it from a
+    tools/profile_bench.sh run).  The entry carries the SHA-256 of the libuhdr_hip.so it was measured with (round 4; the
+    version string did not change when a kernel did): any other binary gets null instead of a stale figure."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
     try:
         with open(path) as f:
@@ -491,8 +531,9 @@ def measured_traffic(key, library_version):
         e = None
     if not e:
         return None, None
-    if e.get("library_version") != library_version:
-        return None, f"profiles/traffic.json was measured with {e.get('library_version')!r}, this is {library_version!r}: re-run tools/profile_bench.sh"
+    sha = library_sha256()
+    if e.get("library_sha256") != sha:
+        return None, f"profiles/traffic.json was measured with another libuhdr_hip.so ({str(e.get('library_sha256'))[:12]}..., this is {str(sha)[:12]}...): re-run tools/profile_bench.sh + tools/update_traffic.py"
     return e["traffic_bytes_per_launch"], e["source"]
 
 
@@ -583,10 +624,42 @@ def encode_section(ctx, u, device):
 
     k = family_times(ctx, api1, fams, iters=5, warm=2)
     r = roof(px, k, {"generate_gainmap": 31.5, "convert_yuv": 3.0, "fdct_quant": 4.5 + 9.0})
-    res["api1_4k"] = {
+    res["api1_4k_reference_operators"] = {
         "workload": "3840x2160 P010 (BT.2100 HLG) + YCbCr 4:2:0 -> generateGainMap (2 pass, 3 ch, scale 1: pass 1 4.5 in + 12 out, "
-                    "pass 2 12 in + 3 out) + convertYuv + 3 x fdct_quant (base) + fused (rgb->ycc + 3 x fdct_quant) of the map",
-        "us": r["chain_us"], "Mpx/s": round(px / r["chain_us"], 1), "roofline": r}
+                    "pass 2 12 in + 3 out) + convertYuv + 3 x fdct_quant (base) + fused (rgb->ycc + 3 x fdct_quant) of the map: 8 launches",
+        "us": r["chain_us"], "wall_us_per_chain": round(time_region(ctx, api1, iters=10, warm=2, reps=3) * 1e3, 1),
+        "Mpx/s": round(px / r["chain_us"], 1), "roofline": r}
+
+    # round 4: the same coefficients in four launches (uhdr_hip_encode_api1_fused_dev): pass 1, range + step tables, pass 2 fused
+    # with the map's rgb->ycc + FDCTs (no 8-bit map round trip), convertYuv fused with the base image's three FDCTs
+    def fused_chain(enc, s_, h_):
+        def fn():
+            enc.encodeApi1Fused(s_, h_, A.UHDR_CG_DISPLAY_P3, (qy, qc), (qy, qc), want_map=False)
+        return fn
+
+    fn4 = fused_chain(enc1, sdr, hdr)
+    k = family_times(ctx, fn4, fams, iters=5, warm=2)
+    r = roof(px, k, {"generate_gainmap": 16.5, "fdct_quant": 18.0 + 4.5})
+    st = A.Stats()
+    ctx.lib.uhdr_hip_get_stats(ctx.handle, C.byref(st))
+    res["api1_4k"] = {
+        "workload": "the API-1 4K chain fused (uhdr_hip_encode_api1_fused_dev, bit-identical coefficients): pass 1 (4.5 in + 12 out) + range / "
+                    "step-table kernel + [pass 2 + rgb->ycc + 3 x fdct_quant] of the map (12 in + 6 out) + [convertYuv + 3 x fdct_quant] of the base "
+                    "(1.5 in + 3 out): 4 launches, 39 B/px",
+        "us": r["chain_us"], "wall_us_per_chain": round(time_region(ctx, fn4, iters=10, warm=2, reps=3) * 1e3, 1),
+        "Mpx/s": round(px / r["chain_us"], 1), "launches": sum(v["launches"] for v in k.values()), "roofline": r,
+        "two_pass_channels_through_step_tables": int(st.generate_channels_tabled), "two_pass_channels_per_sample": int(st.generate_channels_per_sample)}
+    del sdr, hdr, base
+    torch.cuda.empty_cache()
+    w, h = 7680, 4320
+    px = w * h
+    sdr = synth.make_sdr_yuv420(w, h).to(device)
+    hdr = synth.make_hdr_p010(w, h, ct=A.UHDR_CT_HLG).to(device)
+    fn8 = fused_chain(enc1, sdr, hdr)
+    k = family_times(ctx, fn8, fams, iters=3, warm=1)
+    r = roof(px, k, {"generate_gainmap": 16.5, "fdct_quant": 18.0 + 4.5})
+    res["api1_8k"] = {"workload": "the fused API-1 chain at 7680x4320", "us": r["chain_us"],
+                      "wall_us_per_chain": round(time_region(ctx, fn8, iters=6, warm=1, reps=3) * 1e3, 1), "Mpx/s": round(px / r["chain_us"], 1), "roofline": r}
     return res
 
 

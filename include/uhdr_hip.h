@@ -593,6 +593,29 @@ uhdr_error_info_t uhdr_hip_jpeg_encode_image(uhdr_hip_ctx_t* ctx, const uhdr_hip
 void uhdr_hip_resident_begin(uhdr_hip_ctx_t* ctx);
 void uhdr_hip_resident_end(uhdr_hip_ctx_t* ctx);
 
+/* ---- API-1 encode chain without its round trips (MI355X extension, round 4) ---------------------------------------------
+ * JpegR::encodeJPEGR API-1 (jpegr.cpp:253-316) = generateGainMap -> compress the map -> convertYuv of the base copy
+ * (jpegr.cpp:436-518) -> compress the base.  This entry point runs the sample -> coefficient part of all of it in FOUR
+ * launches on device-resident images: pass 1 of two-pass generation (gain ratios + extrema), the range / step-table kernel,
+ * the map's pass 2 fused with libjpeg's rgb_ycc_convert and its three FDCT / quantize transforms (the 8-bit map is written
+ * only if `gm` is given), and convertYuv fused with the FDCT / quantize of Y, Cb and Cr (the converted planes never exist).
+ * Coefficient blocks and metadata are bit-identical to uhdr_hip_generate_gainmap_dev + uhdr_hip_convert_yuv_dev +
+ * uhdr_hip_fdct_quant_dev x 3 + uhdr_hip_fdct_quant_rgb_dev; feed them to uhdr_hip_huffman_encode_dev.
+ * sdr: UHDR_IMG_FMT_12bppYCbCr420, w and h multiples of 16 (read only); hdr as for generateGainMap; cfg: two-pass presets,
+ * gamma 1, a scale factor that leaves map dimensions that are multiples of 8.  base_encoding: convertYuv's destination
+ * encoding (UHDR_CG_DISPLAY_P3 = BT.601 in encodeJPEGR; UHDR_CG_UNSPECIFIED or sdr->cg: no conversion).  qt_*[0] luma,
+ * [1] chroma tables, natural order.  blocks: DEVICE buffers, 16-byte aligned -- base_coef[0] (w/8)*(h/8) JBLOCKs, [1] [2]
+ * (w/16)*(h/16); map_coef[c] (map_w/8)*(map_h/8) for the map's 1 or 3 components.  gm may be null.
+ * UHDR_CODEC_UNSUPPORTED_FEATURE names what falls outside (the operators then do the job).  Synchronises once (metadata). */
+typedef struct uhdr_hip_api1_blocks {
+  int16_t* base_coef[3];
+  int16_t* map_coef[3];
+} uhdr_hip_api1_blocks_t;
+uhdr_error_info_t uhdr_hip_encode_api1_fused_dev(uhdr_hip_ctx_t* ctx, const uhdr_raw_image_t* sdr, const uhdr_raw_image_t* hdr,
+                                                 const uhdr_hip_encode_cfg_t* cfg, uhdr_color_gamut_t base_encoding,
+                                                 const uint16_t qt_base[2][64], const uint16_t qt_map[2][64],
+                                                 const uhdr_hip_api1_blocks_t* blocks, uhdr_gainmap_metadata_t* md, uhdr_raw_image_t* gm);
+
 /* ---- which route did the entropy stage take? ---------------------------------------------------------------------
  * Counters of the context since its creation.  A scan the device declines (entropy_decode_declined: a marker-less stream so
  * dense that the parallel decoder does not settle, or Huffman tables outside its two-level form) is returned to the caller
@@ -606,6 +629,11 @@ typedef struct uhdr_hip_stats {
   unsigned long long entropy_encode_stream;       /* marker-less scans written (the reference's bytes) */
   unsigned long long entropy_encode_intervals;    /* restart-interval scans written */
   unsigned long long resident_hits;               /* host images found on the device (uhdr_hip_resident_begin) instead of uploaded */
+  /* two-pass generateGainMap (round 4): pass 2 maps gain ratios to bytes through per-channel step tables built on the device
+   * from the exact per-sample evaluation; a channel whose range admits no such table (narrower than ~4e-4 log2 units, not
+   * monotone) -- or a user gamma != 1 -- is evaluated per sample instead.  Both give the reference's bytes; this counts which ran. */
+  unsigned long long generate_channels_tabled;    /* channels of two-pass calls mapped through a step table */
+  unsigned long long generate_channels_per_sample;/* channels of two-pass calls evaluated per sample */
 } uhdr_hip_stats_t;
 void uhdr_hip_get_stats(uhdr_hip_ctx_t* ctx, uhdr_hip_stats_t* out);
 

@@ -158,9 +158,14 @@ ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_siz
 GATHER_V_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t), C.c_int, C.c_void_p)
 
 
+class Api1Blocks(C.Structure):  # uhdr_hip_api1_blocks_t
+    _fields_ = [("base_coef", C.c_void_p * 3), ("map_coef", C.c_void_p * 3)]
+
+
 class Stats(C.Structure):
     _fields_ = [(n, C.c_ulonglong) for n in ("entropy_decode_parallel", "entropy_decode_intervals", "entropy_decode_single_lane",
-                                              "entropy_decode_declined", "entropy_encode_stream", "entropy_encode_intervals", "resident_hits")]
+                                              "entropy_decode_declined", "entropy_encode_stream", "entropy_encode_intervals", "resident_hits",
+                                              "generate_channels_tabled", "generate_channels_per_sample")]
 
 
 class CommOps(C.Structure):
@@ -197,6 +202,8 @@ _SIGS = {
     "uhdr_hip_jpeg_quant_table": (None, [C.c_int, C.c_int, _P(C.c_uint16)]),
     "uhdr_hip_oetf_code_thresholds": (C.c_int, [C.c_int, _P(C.c_float)]),
     "uhdr_hip_exact_math_eval": (C.c_int, [C.c_int, _P(C.c_float), _P(C.c_float), C.c_size_t]),
+    "uhdr_hip_encode_api1_fused_dev": (ErrorInfo, [C.c_void_p, _P(RawImage), _P(RawImage), _P(EncodeCfg), C.c_int, C.c_void_p, C.c_void_p, _P(Api1Blocks),
+                                                   _P(GainmapMetadata), _P(RawImage)]),
     "uhdr_hip_selftest": (ErrorInfo, [C.c_void_p, C.c_int, C.c_uint, C.c_uint, C.c_uint, _P(C.c_float), _P(C.c_ulonglong)]),
     "uhdr_hip_fdct_quant": (ErrorInfo, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, _P(C.c_uint16), C.c_void_p]),
     "uhdr_hip_fdct_quant_dev": (ErrorInfo, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, _P(C.c_uint16), C.c_void_p]),

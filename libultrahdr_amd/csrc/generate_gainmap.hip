@@ -197,7 +197,10 @@ __global__ __launch_bounds__(kTabBlock) void minmax_table_kernel(const MinmaxTab
   AffineTabDev& td = p.dev->tab[c];
   if (tid == 0) { p.dev->mn[c] = gmin; p.dev->mx[c] = gmax; p.dev->range_rcp[c] = rr; }
   if (!p.do_table || c >= p.nch || p.gamma != 1.0f) {  // (a user gamma: pass 2 evaluates per sample, launch_affine_map)
-    if (tid == 0) td.ok = 0;
+    if (tid == 0) {
+      td.ok = 0;
+      if (p.out_mm) p.out_mm[6 + c] = 0.0f;
+    }
     return;
   }
   // ---- the ratio -> byte step table of this channel --------------------------------------------------------------------------
@@ -257,6 +260,7 @@ __global__ __launch_bounds__(kTabBlock) void minmax_table_kernel(const MinmaxTab
     td.lo_bits = lo_bits;
     td.hi_bits = s_geo[3];
     td.ok = s_geo[0] & s_geo[5];
+    if (p.out_mm) p.out_mm[6 + c] = td.ok ? 1.0f : 0.0f;  // for uhdr_hip_get_stats
   }
 }
 

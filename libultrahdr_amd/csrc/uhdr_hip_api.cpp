@@ -1105,12 +1105,20 @@ uhdr_error_info_t uhdr_hip_generate_gainmap_pass2_dev(uhdr_hip_ctx_t* c, const f
   return ok_status();
 }
 
+static void note_table_stats(uhdr_hip_ctx* c, const uhdr_hip_encode_cfg_t* cfg) {  // after the synchronisation that landed c->h_mm
+  const int nch = cfg->use_multi_channel_gainmap ? 3 : 1;
+  for (int i = 0; i < nch; i++) {
+    if (c->h_mm[6 + i] != 0.0f) c->stats.generate_channels_tabled++;
+    else c->stats.generate_channels_per_sample++;
+  }
+}
+
 // pass 1's partials -> extrema -> final range -> step tables -> pass 2, all stream ordered; the final range is copied to
 // the pinned c->h_mm for the caller's metadata fill (after ITS synchronisation)
 static uhdr_error_info_t two_pass_tail(uhdr_hip_ctx* c, const GenParams& p, int n_partials, const uhdr_hip_encode_cfg_t* cfg, uhdr_raw_image_t* gm) {
   UHDR_TRY(ensure(c->affine, kAffineDevBytes));
   UHDR_TRY(ensure(c->exchange, 256));
-  if (!c->h_mm) HIP_TRY(hipHostMalloc((void**)&c->h_mm, 6 * sizeof(float), hipHostMallocDefault));
+  if (!c->h_mm) HIP_TRY(hipHostMalloc((void**)&c->h_mm, 9 * sizeof(float), hipHostMallocDefault));
   float* final_mm = (float*)((char*)c->exchange.p + 192);
   MinmaxTableParams t;
   memset(&t, 0, sizeof t);
@@ -1136,7 +1144,7 @@ static uhdr_error_info_t two_pass_tail(uhdr_hip_ctx* c, const GenParams& p, int 
     HIP_TRY(launch_minmax_table(t, c->stream));
     HIP_TRY(launch_affine_map(a, c->stream));
   }
-  HIP_TRY(hipMemcpyAsync(c->h_mm, final_mm, 6 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->h_mm, final_mm, 9 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   return ok_status();
 }
 
@@ -1190,6 +1198,7 @@ uhdr_error_info_t uhdr_hip_generate_gainmap_dev(uhdr_hip_ctx_t* c, const uhdr_ra
   HIP_TRY(hipStreamSynchronize(c->stream));  // the only host synchronisation: the metadata needs the final range
   float mm[6];
   memcpy(mm, c->h_mm, sizeof mm);
+  note_table_stats(c, cfg);
   return uhdr_hip_generate_gainmap_finalize_md(cfg, hdr->ct, use_base_cg, mm, md);
 }
 
@@ -1384,7 +1393,7 @@ uhdr_error_info_t uhdr_hip_generate_gainmap_striped_dev(uhdr_hip_ctx_t* c, const
   UHDR_TRY(ensure(c->affine, kAffineDevBytes));
   UHDR_TRY(ensure(c->minmax, (6 + 2048 * 6) * sizeof(float)));
   UHDR_TRY(upload_math(c));
-  if (!c->h_mm) HIP_TRY(hipHostMalloc((void**)&c->h_mm, 6 * sizeof(float), hipHostMallocDefault));
+  if (!c->h_mm) HIP_TRY(hipHostMalloc((void**)&c->h_mm, 9 * sizeof(float), hipHostMallocDefault));
   float* merged = (float*)c->exchange.p;                       // 6 floats
   AffineDev* adev = (AffineDev*)c->affine.p;
   float* final_mm = (float*)((char*)c->exchange.p + 192);      // 6 floats
@@ -1461,12 +1470,13 @@ uhdr_error_info_t uhdr_hip_generate_gainmap_striped_dev(uhdr_hip_ctx_t* c, const
     ProfScope ps(c, "generate_gainmap");
     note_hip(launch_affine_map(a, c->stream), "generate_gainmap pass 2");
   }
-  note_hip(hipMemcpyAsync(c->h_mm, final_mm, 6 * sizeof(float), hipMemcpyDeviceToHost, c->stream), "metadata copy");
+  note_hip(hipMemcpyAsync(c->h_mm, final_mm, 9 * sizeof(float), hipMemcpyDeviceToHost, c->stream), "metadata copy");
   note_hip(hipStreamSynchronize(c->stream), "synchronize");  // the only host synchronisation: the metadata needs the merged range
   if (xchg.error_code != UHDR_CODEC_OK) return xchg;
   if (local.error_code != UHDR_CODEC_OK) return local;
   float mm[6];
   memcpy(mm, c->h_mm, sizeof mm);
+  note_table_stats(c, cfg);
   // metadata from the already-final range (the clamp / hint / epsilon steps are idempotent on it)
   return uhdr_hip_generate_gainmap_finalize_md(cfg, hdr->ct, use_base_cg, mm, md);
 }
@@ -2003,6 +2013,95 @@ uhdr_error_info_t uhdr_hip_encode_api0_fused_dev(uhdr_hip_ctx_t* c, const uhdr_r
   HIP_TRY(hipStreamSynchronize(c->stream));
   float mm[6];
   memcpy(mm, c->h_mm, sizeof mm);
+  note_table_stats(c, cfg);
+  return uhdr_hip_generate_gainmap_finalize_md(cfg, hdr->ct, use_base_cg, mm, md);
+}
+
+// -------------------------------------------------------------------------------------------------
+// API-1 encode chain fused (encode_api1_fused.hip): pass 1 -> range + tables -> map blocks; base blocks
+// -------------------------------------------------------------------------------------------------
+uhdr_error_info_t uhdr_hip_encode_api1_fused_dev(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* sdr, const uhdr_raw_image_t* hdr,
+                                                 const uhdr_hip_encode_cfg_t* cfg, uhdr_color_gamut_t base_encoding,
+                                                 const uint16_t qt_base[2][64], const uint16_t qt_map[2][64],
+                                                 const uhdr_hip_api1_blocks_t* blocks, uhdr_gainmap_metadata_t* md, uhdr_raw_image_t* gm) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  if (!sdr || !hdr || !cfg || !qt_base || !qt_map || !blocks || !md) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument");
+  if (sdr->fmt != UHDR_IMG_FMT_12bppYCbCr420 || sdr->w % 16 || sdr->h % 16)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "the fused API-1 chain takes a UHDR_IMG_FMT_12bppYCbCr420 base image whose dimensions are multiples of 16 "
+                      "(received format %d, %ux%u); use the operators", sdr->fmt, sdr->w, sdr->h);
+  if (cfg->preset == UHDR_USAGE_REALTIME) return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "the fused API-1 chain is the two-pass (best quality) encode; one pass: generate_gainmap + fdct_quant");
+  if (cfg->gamma != 1.0f) return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "the fused API-1 chain needs gain-map gamma 1 (received %f); use the operators", cfg->gamma);
+  for (int t = 0; t < 2; t++)
+    for (int i = 0; i < 64; i++)
+      if (qt_base[t][i] == 0 || qt_base[t][i] > 255 || qt_map[t][i] == 0 || qt_map[t][i] > 255)
+        return err_status(UHDR_CODEC_INVALID_PARAM, "quantization table entry %d out of baseline range", i);
+  HIP_TRY(hipSetDevice(c->device));
+  GenParams p;
+  int use_base_cg = 1;
+  float hdr_white_nits;
+  UHDR_TRY(fill_gen_params(c, sdr, hdr, cfg, &p, &use_base_cg, &hdr_white_nits));
+  if (p.map_w % 8 || p.map_h % 8)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "the fused API-1 chain needs map dimensions that are multiples of 8 (%ux%u at scale factor %u); use the operators",
+                      p.map_w, p.map_h, p.scale);
+  const int nch = p.multichannel ? 3 : 1;
+  if (((uintptr_t)sdr->planes[0] | sdr->stride[0]) & 1) return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "the fused API-1 chain reads luma in 16-bit pairs: even base address and stride");
+  for (int i = 0; i < 3; i++)
+    if (!blocks->base_coef[i] || ((uintptr_t)blocks->base_coef[i] & 15)) return err_status(UHDR_CODEC_INVALID_PARAM, "base coefficient buffer %d is null or not 16-byte aligned", i);
+  for (int i = 0; i < nch; i++)
+    if (!blocks->map_coef[i] || ((uintptr_t)blocks->map_coef[i] & 15)) return err_status(UHDR_CODEC_INVALID_PARAM, "map coefficient buffer %d is null or not 16-byte aligned", i);
+  uint8_t* map_out = nullptr;
+  uint32_t map_stride = 0;
+  if (gm) {
+    fill_gainmap_desc(hdr, p, gm);
+    if (!gm->planes[0]) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for the gainmap image's plane");
+    if (gm->stride[0] < gm->w) return err_status(UHDR_CODEC_INVALID_PARAM, "gainmap stride (%u) cannot be less than its width (%u)", gm->stride[0], gm->w);
+    if (((uintptr_t)gm->planes[0] | ((size_t)gm->stride[0] * nch)) & 7) return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "the fused API-1 chain stores the map in 8-byte pieces: aligned rows");
+    map_out = (uint8_t*)gm->planes[0];
+    map_stride = gm->stride[0];
+  }
+  Mat3 conv;
+  bool convert = false;
+  if (base_encoding != UHDR_CG_UNSPECIFIED) {
+    const int r = host::yuv_encoding_matrix(sdr->cg, base_encoding, &conv);
+    if (r == -1) return err_status(UHDR_CODEC_INVALID_PARAM, "Unrecognized src color gamut %d", sdr->cg);
+    if (r == -2) return err_status(UHDR_CODEC_INVALID_PARAM, "Unrecognized dest color gamut %d", base_encoding);
+    convert = r == 0;
+  }
+  const size_t nfl = (size_t)p.map_w * p.map_h * nch;
+  UHDR_TRY(ensure(c->scratch[7], nfl * sizeof(float)));
+  UHDR_TRY(ensure(c->minmax, (6 + 2048 * 6) * sizeof(float)));
+  UHDR_TRY(ensure(c->affine, kAffineDevBytes));
+  UHDR_TRY(ensure(c->exchange, 256));
+  if (!c->h_mm) HIP_TRY(hipHostMalloc((void**)&c->h_mm, 9 * sizeof(float), hipHostMallocDefault));
+  p.gain_log2 = (float*)c->scratch[7].p;
+  p.minmax = (float*)c->minmax.p;
+  float* final_mm = (float*)((char*)c->exchange.p + 192);
+  {
+    ProfScope ps(c, "generate_gainmap");
+    HIP_TRY(launch_generate_gainmap(p, true, c->stream));
+    MinmaxTableParams t;
+    memset(&t, 0, sizeof t);
+    t.do_reduce = t.do_finalize = t.do_table = 1;
+    t.partials = p.minmax + 6;
+    t.n_partials = gen_partials_count(p);
+    t.mm6 = p.minmax;
+    fill_finalize(&t, cfg);
+    t.out_mm = final_mm;
+    t.dev = (AffineDev*)c->affine.p;
+    t.math_tab = c->d_math;
+    HIP_TRY(launch_minmax_table(t, c->stream));
+  }
+  {
+    ProfScope ps(c, "fdct_quant");
+    HIP_TRY(launch_map_blocks(p.gain_log2, (const AffineDev*)c->affine.p, c->d_math, nch, (int)(p.map_w / 8), (int)(p.map_h / 8), qt_map[0], qt_map[1],
+                              blocks->map_coef, map_out, map_stride, c->stream));
+    HIP_TRY(launch_base_blocks(view_of(sdr), convert ? &conv : nullptr, qt_base[0], qt_base[1], blocks->base_coef, c->stream));
+  }
+  HIP_TRY(hipMemcpyAsync(c->h_mm, final_mm, 9 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  float mm[6];
+  memcpy(mm, c->h_mm, sizeof mm);
+  note_table_stats(c, cfg);
   return uhdr_hip_generate_gainmap_finalize_md(cfg, hdr->ct, use_base_cg, mm, md);
 }
 

@@ -199,7 +199,7 @@ struct MinmaxTableParams {
   int nch;
   int has_max_hint, has_min_hint;
   float log2_max_hint, log2_min_hint;  // log2f of the user's content-boost recommendations (host-computed)
-  float* out_mm;          // out (may be null): the final {min0..2, max0..2}, for the host's metadata fill
+  float* out_mm;          // out (may be null): 9 floats -- the final {min0..2, max0..2} for the host's metadata fill, then 1 / 0 per channel: it got a step table
   // table (and finalize's output)
   float final_mm[6];      // do_finalize == 0: the already-final range (uhdr_hip_generate_gainmap_pass2_dev)
   AffineDev* dev;
@@ -250,6 +250,11 @@ int apply_quad_mode(const ApplyParams& p);  // >= 0: the quad kernel (and batch 
 hipError_t launch_generate_gainmap(const GenParams& p, bool two_pass, hipStream_t s);
 hipError_t launch_affine_map(const AffineParams& p, hipStream_t s);
 hipError_t launch_minmax_table(const MinmaxTableParams& p, hipStream_t s);
+// encode_api1_fused.hip
+hipError_t launch_map_blocks(const float* ratio, const AffineDev* dev, const double* math_tab, int nch, int bw, int bh, const uint16_t* qt_luma,
+                             const uint16_t* qt_chroma, int16_t* const coef[3], uint8_t* map_out, uint32_t out_stride, hipStream_t s);
+hipError_t launch_base_blocks(const ImageView& yuv420, const Mat3* c, const uint16_t* qt_luma, const uint16_t* qt_chroma, int16_t* const coef[3],
+                              hipStream_t s);
 hipError_t launch_selftest(int which, unsigned long long* out, uint32_t arg0, uint32_t arg1, uint32_t seed, const double* math_tab, const AffineDev* dev,
                            hipStream_t s);  // selftest.hip
 int gen_partials_count(const GenParams& p);  // workgroups (= partials) launch_generate_gainmap(p, two_pass = true) writes

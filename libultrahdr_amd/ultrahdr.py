@@ -198,6 +198,38 @@ class UltraHdr:
         gm.sync_meta_from_raw()
         return sdr, ycc, md, gm
 
+    def encodeApi1Fused(self, sdr_intent: Image, hdr_intent: Image, base_encoding: int, qt_base, qt_map, want_map=True,
+                        sdr_is_601=False, use_luminance=True):
+        """MI355X extension: the sample -> coefficient part of an API-1 encode (jpegr.cpp:253-316) in four launches on
+        device-resident images -- two-pass generateGainMap fused with the map's rgb->ycc + FDCT, convertYuv fused with the base
+        image's three FDCTs.  qt_base / qt_map: (luma, chroma) quantization tables.  Returns (base coefficient tensors [3],
+        map coefficient tensors [1 or 3], metadata, gainmap Image or None), bit-identical to the separate operators."""
+        import torch
+
+        assert _is_dev(sdr_intent, hdr_intent)
+        w, h, dev = sdr_intent.w, sdr_intent.h, sdr_intent.buf.device
+        mw, mh = self.gainmap_dims(w, h)
+        nch = 3 if self.mUseMultiChannelGainMap else 1
+        base = [torch.empty((h // 8, w // 8, 64), dtype=torch.int16, device=dev)] + [torch.empty((h // 16, w // 16, 64), dtype=torch.int16, device=dev) for _ in range(2)]
+        mapc = [torch.empty((mh // 8, mw // 8, 64), dtype=torch.int16, device=dev) for _ in range(nch)]
+        blocks = A.Api1Blocks()
+        for i in range(3):
+            blocks.base_coef[i] = base[i].data_ptr()
+            blocks.map_coef[i] = mapc[i].data_ptr() if i < nch else None
+        qb = np.ascontiguousarray(np.stack([np.asarray(q, dtype=np.uint16) for q in qt_base]))
+        qm = np.ascontiguousarray(np.stack([np.asarray(q, dtype=np.uint16) for q in qt_map]))
+        gm = None
+        if want_map:
+            gm = Image(A.UHDR_IMG_FMT_24bppRGB888 if nch == 3 else A.UHDR_IMG_FMT_8bppYCbCr400, mw, mh, align=64, device=sdr_intent.device)
+        md = A.GainmapMetadata()
+        cfg = self.encode_cfg(sdr_is_601, use_luminance)
+        self._call(True, self.lib.uhdr_hip_encode_api1_fused_dev, self.ctx.handle, C.byref(sdr_intent.raw), C.byref(hdr_intent.raw), C.byref(cfg),
+                   base_encoding, C.c_void_p(qb.ctypes.data), C.c_void_p(qm.ctypes.data), C.byref(blocks), C.byref(md),
+                   C.byref(gm.raw) if gm is not None else None)
+        if gm is not None:
+            gm.sync_meta_from_raw()
+        return base, mapc, md, gm
+
     # ---- applyGainMap (ultrahdrcommon.h:531-534) -----------------------------------------------
     def applyGainMap(self, sdr_intent: Image, gainmap_img: Image, gainmap_metadata: A.GainmapMetadata,
                      output_ct: int, output_format: int, max_display_boost: float, dest: Image,

@@ -960,6 +960,59 @@ def test_fused_api0_front_end_equals_the_three_operators(hip_ctx, ct, cg, cfg_kw
         assert_close_codes(gm_f.to_host().valid(0), gm_o.valid(0), 1, tol, "fused gain map")
 
 
+@pytest.mark.parametrize("w,h,scale,multi,convert", [(640, 352, 1, True, True), (336, 208, 1, True, False), (1280, 704, 4, False, True),
+                                                    (16, 16, 1, True, True), (272, 48, 2, False, True), (1296, 720, 1, True, True)])
+def test_api1_fused_chain_equals_the_operators(hip_ctx, w, h, scale, multi, convert):
+    """uhdr_hip_encode_api1_fused_dev (pass 1 -> range + tables -> pass 2 fused with rgb->ycc + FDCT; convertYuv fused with the
+    base image's three FDCTs) == generateGainMap -> fdct_quant_rgb / fdct_quant, convertYuv -> 3 x fdct_quant: coefficient
+    blocks, the 8-bit map and the metadata, bit for bit."""
+    import torch
+
+    cfg = A.default_encode_cfg(map_dimension_scale_factor=scale, use_multi_channel_gainmap=int(multi), preset=A.UHDR_USAGE_BEST_QUALITY)
+    u = _uhdr_for(hip_ctx, cfg)
+    sdr = synth.make_sdr_yuv420(w, h, seed=w + h)
+    hdr = synth.make_hdr_p010(w, h, ct=A.UHDR_CT_HLG, seed=w * 3 + h)
+    ds, dh = sdr.to("cuda:0"), hdr.to("cuda:0")
+    ql, qc = L.quant_table_port(95, False), L.quant_table_port(95, True)
+    qml, qmc = L.quant_table_port(90, False), L.quant_table_port(90, True)
+    enc = A.UHDR_CG_DISPLAY_P3 if convert else A.UHDR_CG_UNSPECIFIED
+    base_f, map_f, md_f, gm_f = u.encodeApi1Fused(ds, dh, enc, (ql, qc), (qml, qmc), want_map=True)
+    base_n, map_n, md_n, gm_n = u.encodeApi1Fused(ds, dh, enc, (ql, qc), (qml, qmc), want_map=False)
+    hip_ctx.synchronize()
+    assert gm_n is None
+    # the operators
+    md_s, gm_s = u.generateGainMap(ds, dh)
+    base = ds.clone()
+    if convert:
+        u.convertYuv(base, ds.raw.cg, A.UHDR_CG_DISPLAY_P3)
+    base_s = [u.fdct_quant(base.plane_tensor(i), base.raw.stride[i], (w if i == 0 else w // 2) // 8, (h if i == 0 else h // 2) // 8,
+                           ql if i == 0 else qc) for i in range(3)]
+    if multi:
+        map_s = u.fdct_quant_rgb(gm_s, qml, qmc)
+    else:
+        map_s = [u.fdct_quant(gm_s.plane_tensor(0), gm_s.raw.stride[0], gm_s.w // 8, gm_s.h // 8, qml)]
+    hip_ctx.synchronize()
+    assert md_f.as_dict() == md_s.as_dict() == md_n.as_dict()
+    assert planes_equal(gm_f, gm_s)
+    for i in range(3):
+        assert torch.equal(base_f[i], base_s[i].reshape(base_f[i].shape)), f"base component {i}"
+        assert torch.equal(base_n[i], base_f[i])
+    for i in range(len(map_s)):
+        assert torch.equal(map_f[i], map_s[i].reshape(map_f[i].shape)), f"map component {i}"
+        assert torch.equal(map_n[i], map_f[i])
+
+
+def test_api1_fused_chain_rejects_what_it_cannot_fuse(hip_ctx):
+    sdr, hdr = synth.make_sdr_yuv420(72, 40).to("cuda:0"), synth.make_hdr_p010(72, 40).to("cuda:0")
+    q = (L.quant_table_port(90, False), L.quant_table_port(90, True))
+    for cfg in (A.default_encode_cfg(), A.default_encode_cfg(preset=A.UHDR_USAGE_REALTIME), A.default_encode_cfg(gamma=1.5)):
+        u = _uhdr_for(hip_ctx, cfg)
+        a, b = (sdr, hdr) if cfg.preset == A.UHDR_USAGE_BEST_QUALITY and cfg.gamma == 1.0 else (synth.make_sdr_yuv420(64, 32).to("cuda:0"), synth.make_hdr_p010(64, 32).to("cuda:0"))
+        with pytest.raises(A.UhdrError) as e:
+            u.encodeApi1Fused(a, b, A.UHDR_CG_DISPLAY_P3, q, q)
+        assert e.value.code == A.UHDR_CODEC_UNSUPPORTED_FEATURE
+
+
 def test_fused_api0_front_end_rejects_what_it_cannot_fuse(hip_ctx):
     u = _uhdr_for(hip_ctx, A.default_encode_cfg(map_dimension_scale_factor=2))
     with pytest.raises(A.UhdrError) as e:

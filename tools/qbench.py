@@ -89,6 +89,19 @@ def main():
                  else UltraHdr(ctx=ctx, mapDimensionScaleFactor=4, useMultiChannelGainMap=False, preset=A.UHDR_USAGE_REALTIME))
             r = [B.time_kernel(ctx, lambda: e.generateGainMap(sdr, hdr), iters=10, warm=2) / 1e3 for _ in range(REPS)]
             report(c, r, (31.5 if c == "gen4k" else 4.5 + 1 / 16) * w4 * h4, w4 * h4)
+        elif c in ("api1f", "api1f8k"):
+            if c == "api1f":
+                sdr, hdr = enc()
+                ww, hh = w4, h4
+            else:
+                ww, hh = 7680, 4320
+                sdr = synth.make_sdr_yuv420(ww, hh).to(dev)
+                hdr = synth.make_hdr_p010(ww, hh, ct=A.UHDR_CT_HLG).to(dev)
+            e = UltraHdr(ctx=ctx, mapDimensionScaleFactor=1, useMultiChannelGainMap=True, preset=A.UHDR_USAGE_BEST_QUALITY)
+            qy, qc = u.quant_table(95, False), u.quant_table(95, True)
+            r = [B.time_kernel(ctx, lambda: e.encodeApi1Fused(sdr, hdr, A.UHDR_CG_DISPLAY_P3, (qy, qc), (qy, qc), want_map=False), iters=10, warm=2) / 1e3
+                 for _ in range(REPS)]
+            report(c, r, 39.0 * ww * hh, ww * hh)
         elif c in ("fdct4k", "idct4k", "huff4k", "cvt4k"):
             sdr, hdr = enc()
             qt = u.quant_table(95, False)
