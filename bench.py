@@ -688,7 +688,6 @@ def config4_section(ctx, u, device, rank, world, backend):
     cfg = enc.encode_cfg()
     sdr_s = synth.make_sdr_yuv420(ws, hs, noise=0.0, seed=1234 + rank).to(device)
     hdr_s = synth.make_hdr_p010(ws, hs, ct=A.UHDR_CT_HLG, noise=0.0, seed=1234 + rank).to(device)
-    gm_s = Image(A.UHDR_IMG_FMT_24bppRGB888, ws, hs, align=64, device=device)
     qy, qc = u.quant_table(95, False), u.quant_table(95, True)
     s420, s444 = [(2, 2), (1, 1), (1, 1)], [(1, 1)] * 3
     ri420, ri444 = 10, 21  # the longest restart interval one wavefront holds (64 blocks): 10 MCUs at 4:2:0, 21 at 4:4:4
@@ -702,13 +701,9 @@ def config4_section(ctx, u, device, rank, world, backend):
     out_bytes = [0, 0]
 
     def one_image():
-        md_ = stripes.generate_gainmap_striped(enc, sdr_s, hdr_s, cfg, gm_s)
-        u.convertYuv(sdr_s, A.UHDR_CG_BT_709, A.UHDR_CG_DISPLAY_P3)
-        base = []
-        for c in range(3):
-            rows, stride, wv = sdr_s.layout[c]
-            base.append(u.fdct_quant(sdr_s.plane_tensor(c), stride, wv // 8, rows // 8, qy if c == 0 else qc))
-        mapc = u.fdct_quant_rgb(gm_s, qy, qc)
+        # round 4: the fused chain on the striped context (uhdr_hip_encode_api1_fused_dev: pass 1 -> reduce -> ONE all-reduce ->
+        # finalize + tables -> [pass 2 + rgb->ycc + FDCT] of the map stripe, [convertYuv + FDCT] of the base stripe)
+        base, mapc, md_, _ = enc.encodeApi1Fused(sdr_s, hdr_s, A.UHDR_CG_DISPLAY_P3, (qy, qc), (qy, qc), want_map=False)
         e_base = u.huffman_encode(base, ws, hs, s420, ri420)
         e_map = u.huffman_encode(list(mapc), ws, hs, s444, ri444)
         pb = stripes.gather_streams_to_root(ctx, e_base, root=0)
@@ -740,9 +735,9 @@ def config4_section(ctx, u, device, rank, world, backend):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
     px = ws * hs * world
-    return {"workload": f"configs[3]: API-1 encode of a {ws}x{hs * world} P010 + YCbCr 4:2:0 image, {hs} rows per rank, {world} rank(s): two-pass "
-                        "3-channel generateGainMap + convertYuv + FDCT / quantize (base 4:2:0, map 4:4:4) + Huffman coding (restart intervals) + gather of the "
-                        "entropy-coded streams to rank 0",
+    return {"workload": f"configs[3]: API-1 encode of a {ws}x{hs * world} P010 + YCbCr 4:2:0 image, {hs} rows per rank, {world} rank(s): the fused chain "
+                        "(two-pass 3-channel generateGainMap whose pass 2 feeds the map's rgb->ycc + FDCT directly, convertYuv inside the base image's FDCT: "
+                        "uhdr_hip_encode_api1_fused_dev) + Huffman coding (restart intervals) + gather of the entropy-coded streams to rank 0",
             "collective": "one all-reduce(min, 6 x float32 {min0..2, -max0..2}) per image, issued by libuhdr_hip.so on its own stream between pass 1 "
                           "and pass 2; range finalised on the device; stream sizes: one 8-byte all-gather, stream bytes: one send / recv group to rank 0",
             "transport": "host relay over torch.distributed (dry run: the ranks share devices)" if relay else "RCCL (ncclAllReduce / ncclAllGather / ncclSend + ncclRecv)",

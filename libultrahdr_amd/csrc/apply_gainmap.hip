@@ -509,7 +509,54 @@ __device__ __forceinline__ void apply_quad_body(const ApplyParams& p) {
   const uint32_t qw = p.sdr.w >> 1, qh = p.sdr.h >> 1;
   const uint32_t strips_x = (qw + 64 * kQuadsPerLane - 1) / (64 * kQuadsPerLane);  // a wave owns 128 * kQuadsPerLane pixel columns
   const uint32_t lane = tid & 63;
-  const uint32_t wave = blockIdx.x * (BLK / 64) + __builtin_amdgcn_readfirstlane(tid >> 6);  // SGPR
+  // ---- prefetcher workgroups (round 4) ------------------------------------------------------------------------------------
+  // A write-dominated launch (8K, Y400 map at scale 4: 51 MB in, 265 MB out) whose inputs are cold pays 14 us for them: its
+  // loads are latency critical -- every one feeds arithmetic that feeds a store -- and they queue behind a saturated write
+  // stream.  A read sweep ahead of the consumers fixes that (the access pattern alone: 64 -> 55 us, tools/ubench8), but as a
+  // prologue of every wave (touch_ahead, round 3) it holds all stores back for as long as it lasts.  Here the first
+  // p.prefetch_wgs workgroups do nothing but sweep: cooperatively, front to back in the order the row bands will be
+  // consumed (luma : Cb : Cr = 4 : 1 : 1 per step, the small map first), twelve line-touching loads (8 KiB each) in flight per wave and no
+  // dependent work, so their latency costs nothing; everybody else finds the lines in L2 / the infinity cache.  They finish
+  // in the first third of the launch and leave.
+  const uint32_t pf_wgs = SRC == 0 ? p.prefetch_wgs : 0u;
+  if (SRC == 0 && blockIdx.x < pf_wgs) {
+    const uint32_t lane_ = tid & 63, nw = pf_wgs * (BLK / 64), pw = blockIdx.x * (BLK / 64) + (tid >> 6);
+    const uint8_t* py = (const uint8_t*)p.sdr.p[0];
+    const uint8_t* pu = (const uint8_t*)p.sdr.p[1];
+    const uint8_t* pv = (const uint8_t*)p.sdr.p[2];
+    const uint8_t* pm = (const uint8_t*)p.gm.p[0];
+    const uint32_t qh_ = p.sdr.h >> 1;
+    const uint32_t by = (qh_ * 2 - 1) * p.sdr.stride[0] + p.sdr.w, bc = (qh_ - 1) * p.sdr.stride[1] + p.sdr.w / 2;
+    const uint32_t bm = ((p.gm.h - 1) * p.gm.stride[0] + p.gm.w) * BPP;
+    uint32_t acc = 0;
+    // one TOUCH per 128-byte line: lane l of a load reads the first word of line `chunk * 64 + l`, so a single wave instruction
+    // brings 8 KiB of the plane into L2 / the infinity cache (and keeps 64 line fetches in flight instead of the 8 of a
+    // contiguous 16-byte-per-lane read); the word itself is irrelevant
+    auto touch = [&](const uint8_t* base, uint32_t bytes, uint32_t chunk) -> uint32_t {
+      const uint32_t mis = (4u - (uint32_t)((uintptr_t)base & 3u)) & 3u;
+      const uint32_t last = bytes > mis + 4u ? (bytes - mis - 4u) & ~3u : 0u;  // byte offset of the last whole word
+      const uint32_t off = min((chunk * 64u + lane_) * 128u, last);
+      return *(const uint32_t*)(base + mis + off);
+    };
+    for (uint32_t c = pw; c * 8192u < bm; c += nw) acc ^= touch(pm, bm, c);  // the map: small at scale > 1, needed from the first row on
+    const uint32_t steps = (bc / 8192u + nw) / nw;  // every wave runs the same number of steps (its last chunks clamp)
+    for (uint32_t it = 0; it < steps; it += 2) {
+      uint32_t x[12];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const uint32_t c = (it + h) * nw + pw;
+#pragma unroll
+        for (int k = 0; k < 4; k++) x[6 * h + k] = touch(py, by, 4 * c + k);
+        x[6 * h + 4] = touch(pu, bc, c);
+        x[6 * h + 5] = touch(pv, bc, c);
+      }
+#pragma unroll
+      for (int k = 0; k < 12; k++) acc ^= x[k];
+    }
+    if (acc == 0x9e3779b9u && p.n_frames == 0xffffffffu) ((uint8_t*)p.dst.p[0])[0] = 0;  // never true: keeps the loads alive
+    return;
+  }
+  const uint32_t wave = (blockIdx.x - pf_wgs) * (BLK / 64) + __builtin_amdgcn_readfirstlane(tid >> 6);  // SGPR
   const uint32_t groups = p.row_groups;
   const uint32_t per_frame = groups * strips_x;
   // a few surplus waves of the last workgroup have no work: they help staging the tables and leave
@@ -627,9 +674,20 @@ __device__ __forceinline__ void apply_quad_body(const ApplyParams& p) {
         if constexpr (MAPFMT == 0) {
           r.m[2 * k] = ld_u16(rm, xmap, mrow);
           r.m[2 * k + 1] = 0;
-        } else if constexpr (MAPFMT == 1) {  // 6 bytes: three aligned 16-bit loads
-          r.m[2 * k] = ld_u16(rm, xmap, mrow) | (ld_u16(rm, xmap + 2, mrow) << 16);
-          r.m[2 * k + 1] = ld_u16(rm, xmap + 4, mrow);
+        } else if constexpr (MAPFMT == 1) {
+          // 6 bytes at a 2-byte aligned offset: ONE 8-byte load (the part runs with unaligned access enabled; the two bytes
+          // read too many belong to the next lane's pixels or the row's padding and are never looked at) -- three 16-bit
+          // loads per row made this layout issue ten load instructions per quad where the RGBA8888 map needs six, and it ran no
+          // faster for 7 % fewer bytes (round 3: 0.646 against 0.719).  The LAST map row keeps the exact loads: two bytes
+          // beyond it may be beyond the allocation (a 3840 x 2160 x 3 byte plane ends on a page boundary).
+          if ((yg + k) < gmh1) {  // wave-uniform
+            const uint2 a = ld_u64(rm, xmap, mrow);
+            r.m[2 * k] = a.x;
+            r.m[2 * k + 1] = a.y;
+          } else {
+            r.m[2 * k] = ld_u16(rm, xmap, mrow) | (ld_u16(rm, xmap + 2, mrow) << 16);
+            r.m[2 * k + 1] = ld_u16(rm, xmap + 4, mrow);
+          }
         } else {
           const uint2 a = ld_u64(rm, xmap, mrow);
           r.m[2 * k] = a.x;
@@ -1012,7 +1070,20 @@ hipError_t launch_quad(const ApplyParams& p, hipStream_t s) {
     const int v = e ? atoi(e) : kOversub;
     return (uint32_t)(v >= 1 && v <= 16 ? v : kOversub);
   }();
-  const uint32_t max_waves = (uint32_t)resident * (BLK / 64) * over;
+  // prefetcher workgroups (apply_quad_body): single 4:2:0 frames with a subsampled map -- the write-dominated launches whose cold
+  // inputs cost most -- whose inputs the host layer does not expect in the infinity cache.  UHDR_HIP_PREFETCH_WGS=<n> overrides
+  // (0: off).
+  static const int pf_env = [] { const char* e = getenv("UHDR_HIP_PREFETCH_WGS"); return e ? atoi(e) : -1; }();
+  uint32_t pf = 0;
+  if (BASE == 0 && SMODE == 1 && n_frames == 1 && (size_t)p.sdr.w * p.sdr.h >= (size_t)3840 * 2160 && p.sdr.stride[1] == p.sdr.stride[2] &&
+      (!p.inputs_hot || pf_env > 0)) {
+    // a prefetcher's rate is its CU's miss rate (about one 128-byte line per 7 cycles), so the sweep has to be spread over
+    // many CUs to stay ahead of the consumers: 8K, 6 rotating buffer sets: 76 us without, 65 / 62 us with 160 / 320 of 1792
+    // workgroups; inputs that are still cached lose 6 us to the duplicate reads (54.6 -> 60.6), hence `inputs_hot`
+    pf = pf_env >= 0 ? (uint32_t)pf_env : (uint32_t)resident * 5u / 28u;
+    if (pf > (uint32_t)resident / 2u) pf = (uint32_t)resident / 2u;
+  }
+  const uint32_t max_waves = ((uint32_t)resident - pf) * (BLK / 64) * over;
   uint32_t groups = max_waves / (strips_x * n_frames);
   if (groups > qh) groups = qh;
   if (groups < 1) groups = 1;
@@ -1021,6 +1092,7 @@ hipError_t launch_quad(const ApplyParams& p, hipStream_t s) {
   q.n_frames = n_frames;
   q.row_groups = groups;
   q.tiles_per_wave = (qh + groups - 1) / groups;  // quad rows per wave
+  q.prefetch_wgs = pf;
   {
     // touch-ahead is opt-in (UHDR_HIP_TOUCH_AHEAD=1).  Measured at 8K with the Y400 map (51 MB in, 265 MB out): the bare
     // access pattern gains what the read burst promises (cold inputs 64 -> 55 us, tools/ubench8), the kernel only 76.6 ->
@@ -1030,7 +1102,7 @@ hipError_t launch_quad(const ApplyParams& p, hipStream_t s) {
     static const int force = [] { const char* e = getenv("UHDR_HIP_TOUCH_AHEAD"); return e ? atoi(e) : 0; }();
     q.touch_ahead = force > 0 ? 1u : 0u;
   }
-  const int grid = (int)((nwaves + BLK / 64 - 1) / (BLK / 64));
+  const int grid = (int)((nwaves + BLK / 64 - 1) / (BLK / 64)) + (int)pf;
   if constexpr (k80) hipLaunchKernelGGL((apply_quad_kernel<OUT, MAPFMT, SMODE, BASE>), dim3(grid), dim3(BLK), 0, s, q);
   else hipLaunchKernelGGL((apply_quad_kernel_s96<OUT, MAPFMT, SMODE, BASE>), dim3(grid), dim3(BLK), 0, s, q);
   return hipGetLastError();

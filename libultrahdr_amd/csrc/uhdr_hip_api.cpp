@@ -110,6 +110,14 @@ struct uhdr_hip_ctx {
   } resident[2];
   bool resident_on = false;
   unsigned int resident_next = 0;
+  // A host-side model of the 256 MiB infinity cache, for one decision: whether applyGainMap's input planes are worth a read
+  // sweep by prefetcher workgroups (apply_gainmap.hip).  Reads allocate there, the kernels' nontemporal output stores do not
+  // (a frame's inputs are still cached when 102 MB of other frames' inputs were read in between, and are not after 255 MB:
+  // bench.py north_star_8k, three / six rotating buffer sets).  So: remember when (in bytes read by this context) a plane was
+  // last read, call it hot if less than kMallHotBytes have been read since.
+  struct MallEntry { const void* p; uint64_t stamp; };
+  std::vector<MallEntry> mall;
+  uint64_t mall_clock = 0;
   DeviceBuf minmax;  // 6 + 2048*6 floats
   uint32_t* d_huff = nullptr;     // Annex K code tables (kHuffTabWords) followed by the 64-byte zig-zag map
   CoefSrc* d_coef_src = nullptr;  // apply_gainmap_coef descriptors (rotating slots)
@@ -755,6 +763,34 @@ static uhdr_error_info_t build_apply_params(uhdr_hip_ctx* c, const uhdr_raw_imag
   return ok_status();
 }
 
+namespace {
+constexpr uint64_t kMallHotBytes = 160ull << 20;
+size_t input_bytes(const uhdr_raw_image_t* im) {
+  size_t n = 0;
+  const ImageView v = view_of(im);
+  if (im->fmt == UHDR_IMG_FMT_12bppYCbCr420) n = (size_t)v.stride[0] * v.h + (size_t)v.stride[1] * (v.h / 2) + (size_t)v.stride[2] * (v.h / 2);
+  else if (im->fmt == UHDR_IMG_FMT_8bppYCbCr400) n = (size_t)v.stride[0] * v.h;
+  else if (im->fmt == UHDR_IMG_FMT_24bppRGB888) n = (size_t)v.stride[0] * v.h * 3;
+  else n = (size_t)v.stride[0] * v.h * 4;
+  return n;
+}
+// true: `key` (a frame's luma plane stands for all its planes) was read so recently that it should still be cached; records the read
+bool mall_touch(uhdr_hip_ctx* c, const void* key, size_t bytes) {
+  bool hot = false;
+  for (auto& e : c->mall)
+    if (e.p == key) {
+      hot = c->mall_clock - e.stamp < kMallHotBytes;
+      e.stamp = c->mall_clock + bytes;
+      c->mall_clock += bytes;
+      return hot;
+    }
+  if (c->mall.size() >= 64) c->mall.erase(c->mall.begin());
+  c->mall_clock += bytes;
+  c->mall.push_back({key, c->mall_clock});
+  return false;
+}
+}  // namespace
+
 uhdr_error_info_t uhdr_hip_apply_gainmap_dev(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* sdr,
                                              const uhdr_raw_image_t* gm, const uhdr_gainmap_metadata_t* md,
                                              uhdr_color_transfer_t out_ct, uhdr_img_fmt_t out_fmt,
@@ -765,6 +801,7 @@ uhdr_error_info_t uhdr_hip_apply_gainmap_dev(uhdr_hip_ctx_t* c, const uhdr_raw_i
   HIP_TRY(hipSetDevice(c->device));
   ApplyParams p;
   UHDR_TRY(build_apply_params(c, sdr, gm, md, out_ct, max_display_boost, dest, y0, full_height, &p));
+  p.inputs_hot = mall_touch(c, sdr->planes[0], input_bytes(sdr) + input_bytes(gm)) ? 1u : 0u;
   {
     ProfScope ps(c, "apply_gainmap");
     HIP_TRY(launch_apply_gainmap(p, c->stream));
@@ -2020,88 +2057,133 @@ uhdr_error_info_t uhdr_hip_encode_api0_fused_dev(uhdr_hip_ctx_t* c, const uhdr_r
 // -------------------------------------------------------------------------------------------------
 // API-1 encode chain fused (encode_api1_fused.hip): pass 1 -> range + tables -> map blocks; base blocks
 // -------------------------------------------------------------------------------------------------
+// With a communicator on the context (uhdr_hip_comm_init / _init_custom) the images are this rank's ROW STRIPE and the extrema
+// are merged across ranks between the passes, exactly as in uhdr_hip_generate_gainmap_striped_dev: reduce -> ONE all-reduce(min)
+// over {min, -max} -> finalize + tables.  Every rank takes part in that exchange whatever happens locally (a rank that
+// failed validation, or whose stripe is empty -- h == 0 --, contributes the identity), and reports its error afterwards.
 uhdr_error_info_t uhdr_hip_encode_api1_fused_dev(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* sdr, const uhdr_raw_image_t* hdr,
                                                  const uhdr_hip_encode_cfg_t* cfg, uhdr_color_gamut_t base_encoding,
                                                  const uint16_t qt_base[2][64], const uint16_t qt_map[2][64],
                                                  const uhdr_hip_api1_blocks_t* blocks, uhdr_gainmap_metadata_t* md, uhdr_raw_image_t* gm) {
   if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
-  if (!sdr || !hdr || !cfg || !qt_base || !qt_map || !blocks || !md) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument");
-  if (sdr->fmt != UHDR_IMG_FMT_12bppYCbCr420 || sdr->w % 16 || sdr->h % 16)
-    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "the fused API-1 chain takes a UHDR_IMG_FMT_12bppYCbCr420 base image whose dimensions are multiples of 16 "
-                      "(received format %d, %ux%u); use the operators", sdr->fmt, sdr->w, sdr->h);
-  if (cfg->preset == UHDR_USAGE_REALTIME) return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "the fused API-1 chain is the two-pass (best quality) encode; one pass: generate_gainmap + fdct_quant");
-  if (cfg->gamma != 1.0f) return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "the fused API-1 chain needs gain-map gamma 1 (received %f); use the operators", cfg->gamma);
-  for (int t = 0; t < 2; t++)
-    for (int i = 0; i < 64; i++)
-      if (qt_base[t][i] == 0 || qt_base[t][i] > 255 || qt_map[t][i] == 0 || qt_map[t][i] > 255)
-        return err_status(UHDR_CODEC_INVALID_PARAM, "quantization table entry %d out of baseline range", i);
   HIP_TRY(hipSetDevice(c->device));
+  const bool striped = c->comm != nullptr || c->comm_custom;
   GenParams p;
-  int use_base_cg = 1;
-  float hdr_white_nits;
-  UHDR_TRY(fill_gen_params(c, sdr, hdr, cfg, &p, &use_base_cg, &hdr_white_nits));
-  if (p.map_w % 8 || p.map_h % 8)
-    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "the fused API-1 chain needs map dimensions that are multiples of 8 (%ux%u at scale factor %u); use the operators",
-                      p.map_w, p.map_h, p.scale);
-  const int nch = p.multichannel ? 3 : 1;
-  if (((uintptr_t)sdr->planes[0] | sdr->stride[0]) & 1) return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "the fused API-1 chain reads luma in 16-bit pairs: even base address and stride");
-  for (int i = 0; i < 3; i++)
-    if (!blocks->base_coef[i] || ((uintptr_t)blocks->base_coef[i] & 15)) return err_status(UHDR_CODEC_INVALID_PARAM, "base coefficient buffer %d is null or not 16-byte aligned", i);
-  for (int i = 0; i < nch; i++)
-    if (!blocks->map_coef[i] || ((uintptr_t)blocks->map_coef[i] & 15)) return err_status(UHDR_CODEC_INVALID_PARAM, "map coefficient buffer %d is null or not 16-byte aligned", i);
+  int use_base_cg = 1, nch = 1;
+  float hdr_white_nits = 0;
   uint8_t* map_out = nullptr;
   uint32_t map_stride = 0;
-  if (gm) {
-    fill_gainmap_desc(hdr, p, gm);
-    if (!gm->planes[0]) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for the gainmap image's plane");
-    if (gm->stride[0] < gm->w) return err_status(UHDR_CODEC_INVALID_PARAM, "gainmap stride (%u) cannot be less than its width (%u)", gm->stride[0], gm->w);
-    if (((uintptr_t)gm->planes[0] | ((size_t)gm->stride[0] * nch)) & 7) return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "the fused API-1 chain stores the map in 8-byte pieces: aligned rows");
-    map_out = (uint8_t*)gm->planes[0];
-    map_stride = gm->stride[0];
-  }
   Mat3 conv;
-  bool convert = false;
-  if (base_encoding != UHDR_CG_UNSPECIFIED) {
-    const int r = host::yuv_encoding_matrix(sdr->cg, base_encoding, &conv);
-    if (r == -1) return err_status(UHDR_CODEC_INVALID_PARAM, "Unrecognized src color gamut %d", sdr->cg);
-    if (r == -2) return err_status(UHDR_CODEC_INVALID_PARAM, "Unrecognized dest color gamut %d", base_encoding);
-    convert = r == 0;
-  }
-  const size_t nfl = (size_t)p.map_w * p.map_h * nch;
-  UHDR_TRY(ensure(c->scratch[7], nfl * sizeof(float)));
+  bool convert = false, empty = false;
+  auto prepare = [&]() -> uhdr_error_info_t {
+    if (!sdr || !hdr || !cfg || !qt_base || !qt_map || !blocks || !md) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument");
+    if (sdr->fmt != UHDR_IMG_FMT_12bppYCbCr420 || sdr->w % 16 || sdr->h % 16 || sdr->w == 0)
+      return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "the fused API-1 chain takes a UHDR_IMG_FMT_12bppYCbCr420 base image whose dimensions are multiples of 16 "
+                        "(received format %d, %ux%u); use the operators", sdr->fmt, sdr->w, sdr->h);
+    if (cfg->preset == UHDR_USAGE_REALTIME) return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "the fused API-1 chain is the two-pass (best quality) encode; one pass: generate_gainmap + fdct_quant");
+    if (cfg->gamma != 1.0f) return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "the fused API-1 chain needs gain-map gamma 1 (received %f); use the operators", cfg->gamma);
+    for (int t = 0; t < 2; t++)
+      for (int i = 0; i < 64; i++)
+        if (qt_base[t][i] == 0 || qt_base[t][i] > 255 || qt_map[t][i] == 0 || qt_map[t][i] > 255)
+          return err_status(UHDR_CODEC_INVALID_PARAM, "quantization table entry %d out of baseline range", i);
+    if (striped && sdr->h == 0 && hdr->h == 0) {  // a rank without rows: nothing to launch, the identity to contribute
+      empty = true;
+      use_base_cg = !(hdr->cg == UHDR_CG_BT_2100 || (hdr->cg == UHDR_CG_DISPLAY_P3 && sdr->cg != UHDR_CG_BT_2100)) || sdr->cg == hdr->cg;
+      return ok_status();
+    }
+    if (sdr->h == 0) return err_status(UHDR_CODEC_INVALID_PARAM, "empty base image");
+    UHDR_TRY(fill_gen_params(c, sdr, hdr, cfg, &p, &use_base_cg, &hdr_white_nits));
+    if (p.scale != (uint32_t)cfg->map_dimension_scale_factor || p.map_w % 8 || p.map_h % 8)
+      return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "the fused API-1 chain needs map dimensions that are multiples of 8 (%ux%u at scale factor %u); use the operators",
+                        p.map_w, p.map_h, p.scale);
+    nch = p.multichannel ? 3 : 1;
+    if (((uintptr_t)sdr->planes[0] | sdr->stride[0]) & 1) return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "the fused API-1 chain reads luma in 16-bit pairs: even base address and stride");
+    for (int i = 0; i < 3; i++)
+      if (!blocks->base_coef[i] || ((uintptr_t)blocks->base_coef[i] & 15)) return err_status(UHDR_CODEC_INVALID_PARAM, "base coefficient buffer %d is null or not 16-byte aligned", i);
+    for (int i = 0; i < nch; i++)
+      if (!blocks->map_coef[i] || ((uintptr_t)blocks->map_coef[i] & 15)) return err_status(UHDR_CODEC_INVALID_PARAM, "map coefficient buffer %d is null or not 16-byte aligned", i);
+    if (gm) {
+      fill_gainmap_desc(hdr, p, gm);
+      if (!gm->planes[0]) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for the gainmap image's plane");
+      if (gm->stride[0] < gm->w) return err_status(UHDR_CODEC_INVALID_PARAM, "gainmap stride (%u) cannot be less than its width (%u)", gm->stride[0], gm->w);
+      if (((uintptr_t)gm->planes[0] | ((size_t)gm->stride[0] * nch)) & 7) return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "the fused API-1 chain stores the map in 8-byte pieces: aligned rows");
+      map_out = (uint8_t*)gm->planes[0];
+      map_stride = gm->stride[0];
+    }
+    if (base_encoding != UHDR_CG_UNSPECIFIED) {
+      const int r = host::yuv_encoding_matrix(sdr->cg, base_encoding, &conv);
+      if (r == -1) return err_status(UHDR_CODEC_INVALID_PARAM, "Unrecognized src color gamut %d", sdr->cg);
+      if (r == -2) return err_status(UHDR_CODEC_INVALID_PARAM, "Unrecognized dest color gamut %d", base_encoding);
+      convert = r == 0;
+    }
+    UHDR_TRY(ensure(c->scratch[7], (size_t)p.map_w * p.map_h * nch * sizeof(float)));
+    return ok_status();
+  };
+  // the exchange buffers first: without them a rank cannot even contribute the identity
+  UHDR_TRY(upload_math(c));
   UHDR_TRY(ensure(c->minmax, (6 + 2048 * 6) * sizeof(float)));
   UHDR_TRY(ensure(c->affine, kAffineDevBytes));
   UHDR_TRY(ensure(c->exchange, 256));
   if (!c->h_mm) HIP_TRY(hipHostMalloc((void**)&c->h_mm, 9 * sizeof(float), hipHostMallocDefault));
-  p.gain_log2 = (float*)c->scratch[7].p;
-  p.minmax = (float*)c->minmax.p;
+  uhdr_error_info_t local = prepare();
+  if (local.error_code != UHDR_CODEC_OK && !striped) return local;
+  bool run = local.error_code == UHDR_CODEC_OK && !empty;
+  float* merged = (float*)c->exchange.p;
   float* final_mm = (float*)((char*)c->exchange.p + 192);
+  uhdr_error_info_t xchg = ok_status();
+  auto note_hip = [&](hipError_t e, const char* what) {
+    if (e != hipSuccess && local.error_code == UHDR_CODEC_OK) local = err_status(UHDR_CODEC_ERROR, "%s: %s", what, hipGetErrorString(e));
+  };
   {
     ProfScope ps(c, "generate_gainmap");
-    HIP_TRY(launch_generate_gainmap(p, true, c->stream));
+    if (run) {
+      p.gain_log2 = (float*)c->scratch[7].p;
+      p.minmax = (float*)c->minmax.p;
+      const hipError_t e = launch_generate_gainmap(p, true, c->stream);
+      note_hip(e, "generate_gainmap pass 1");
+      if (e != hipSuccess) run = false;
+    }
     MinmaxTableParams t;
     memset(&t, 0, sizeof t);
-    t.do_reduce = t.do_finalize = t.do_table = 1;
-    t.partials = p.minmax + 6;
-    t.n_partials = gen_partials_count(p);
-    t.mm6 = p.minmax;
+    t.partials = (const float*)c->minmax.p + 6;
+    t.n_partials = run ? gen_partials_count(p) : 0;
+    t.empty = run ? 0 : 1;
+    t.mm6 = (float*)c->minmax.p;
     fill_finalize(&t, cfg);
+    if (local.error_code != UHDR_CODEC_OK || empty) t.nch = (cfg && cfg->use_multi_channel_gainmap) ? 3 : 1;
     t.out_mm = final_mm;
     t.dev = (AffineDev*)c->affine.p;
     t.math_tab = c->d_math;
-    HIP_TRY(launch_minmax_table(t, c->stream));
+    if (!striped) {  // one launch for everything between the passes
+      t.do_reduce = t.do_finalize = t.do_table = 1;
+      note_hip(launch_minmax_table(t, c->stream), "minmax / tables");
+    } else {
+      MinmaxTableParams r = t;
+      r.do_reduce = 1;
+      r.merged6 = merged;
+      note_hip(launch_minmax_table(r, c->stream), "minmax reduce");
+      {
+        ProfScope px(c, "stripe_exchange");
+        xchg = comm_all_reduce_min(c, merged, 6);
+      }
+      t.do_finalize = t.do_table = 1;
+      t.merged_in = merged;
+      note_hip(launch_minmax_table(t, c->stream), "minmax finalize / tables");
+    }
   }
-  {
+  if (run && xchg.error_code == UHDR_CODEC_OK) {
     ProfScope ps(c, "fdct_quant");
-    HIP_TRY(launch_map_blocks(p.gain_log2, (const AffineDev*)c->affine.p, c->d_math, nch, (int)(p.map_w / 8), (int)(p.map_h / 8), qt_map[0], qt_map[1],
-                              blocks->map_coef, map_out, map_stride, c->stream));
-    HIP_TRY(launch_base_blocks(view_of(sdr), convert ? &conv : nullptr, qt_base[0], qt_base[1], blocks->base_coef, c->stream));
+    note_hip(launch_map_blocks(p.gain_log2, (const AffineDev*)c->affine.p, c->d_math, nch, (int)(p.map_w / 8), (int)(p.map_h / 8), qt_map[0], qt_map[1],
+                               blocks->map_coef, map_out, map_stride, c->stream), "map blocks");
+    note_hip(launch_base_blocks(view_of(sdr), convert ? &conv : nullptr, qt_base[0], qt_base[1], blocks->base_coef, c->stream), "base blocks");
   }
-  HIP_TRY(hipMemcpyAsync(c->h_mm, final_mm, 9 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  note_hip(hipMemcpyAsync(c->h_mm, final_mm, 9 * sizeof(float), hipMemcpyDeviceToHost, c->stream), "metadata copy");
+  note_hip(hipStreamSynchronize(c->stream), "synchronize");  // the only host synchronisation: the metadata needs the (merged) range
+  if (xchg.error_code != UHDR_CODEC_OK) return xchg;
+  if (local.error_code != UHDR_CODEC_OK) return local;
   float mm[6];
   memcpy(mm, c->h_mm, sizeof mm);
-  note_table_stats(c, cfg);
+  if (run) note_table_stats(c, cfg);
   return uhdr_hip_generate_gainmap_finalize_md(cfg, hdr->ct, use_base_cg, mm, md);
 }
 

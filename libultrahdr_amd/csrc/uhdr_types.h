@@ -103,6 +103,8 @@ struct ApplyParams {
   uint32_t y0;              // global row of stripe row 0
   uint32_t tiles_per_wave;  // quad kernel: loop trip count (even), set by the launcher
   uint32_t touch_ahead;     // quad kernel: 1 = the launch opens with a grid-wide read sweep over the input planes (set by the launcher)
+  uint32_t prefetch_wgs;    // quad kernel: the first prefetch_wgs workgroups only stream the input planes into L2 / the infinity cache (set by the launcher)
+  uint32_t inputs_hot;      // the host layer's guess that the input planes still sit in the infinity cache (uhdr_hip_api.cpp: mall_model): no prefetchers then
   uint32_t row_groups;      // quad kernel: quad-row step of a wave, set by the launcher
   uint32_t n_frames;        // 0/1: single image; > 1: batch through `frame_tab` (quad kernel only)
   uint32_t scale;           // integer map scale factor (table path) or 0

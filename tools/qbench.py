@@ -31,7 +31,7 @@ def report(name, ms_list, bytes_, px):
     print(f"{name:28s} min {ms[0]*1e6:8.1f} med {med*1e6:8.1f} max {ms[-1]*1e6:8.1f} us   {bytes_/med/1e9:8.1f} GB/s ({bytes_/med/1e9/80:5.1f}% of 8 TB/s)  {px/med/1e6:9.0f} Mpx/s", flush=True)
 
 
-def apply_case(name, w, h, mk, ct, nsets=3):
+def apply_case(name, w, h, mk, ct, nsets=int(os.environ.get("QB_NSETS", "3"))):
     fmt = f16 if ct == A.UHDR_CT_LINEAR else u32
     sets = B.make_frames(nsets, w, h, mk, dev, fmt, seed0=77)
     for s, g, _ in sets:
