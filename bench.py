@@ -735,6 +735,56 @@ def config4_section(ctx, u, device, rank, world, backend):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
     px = ws * hs * world
+
+    # ---- the decode counterpart (round 4): ONE 16384 x (2048 * world) frame decoded by row stripes, the gain map replicated ----
+    # JpegR::applyGainMap hands row ranges to its job queue the same way (jpegr.cpp:1714-1812); no exchange step at all:
+    # uhdr_hip_apply_gainmap_dev(..., y0, full_height) on every rank's rows.  Map: the Android-style Y400 map at scale 4 of
+    # the WHOLE frame (every rank holds all of it: 2 MB per 2048 rows).
+    f16 = A.UHDR_IMG_FMT_64bppRGBAHalfFloat
+    full_h = hs * world
+    md_d = synth.default_metadata(use_base_cg=0)
+    sdr_d = synth.make_sdr_yuv420(ws, hs, seed=4321 + rank).to(device)
+    gm_d = synth.make_gainmap(ws // 4, full_h // 4, 1, seed=777).to(device)  # the same map on every rank
+    sdr_d.raw.cg, gm_d.raw.cg = A.UHDR_CG_BT_709, A.UHDR_CG_BT_2100
+    dst_d = [Image(f16, ws, hs, align=64, device=device) for _ in range(3)]
+    kd = [0]
+
+    def decode_stripe():
+        u.applyGainMap(sdr_d, gm_d, md_d, A.UHDR_CT_LINEAR, f16, A.FLT_MAX, dst_d[kd[0] % 3], y0=rank * hs, full_height=full_h)
+        kd[0] += 1
+
+    for _ in range(40):
+        decode_stripe()
+    sync_all()
+    ctx.profile(True)
+    ctx.profile_read(None, reset=True)
+    t0 = time.perf_counter()
+    for _ in range(30):
+        decode_stripe()
+    sync_all()
+    el_d = time.perf_counter() - t0
+    each_d = ctx.profile_read_list("apply_gainmap", reset=True)
+    ctx.profile(False)
+    kern_us_d = sum(each_d) / max(len(each_d), 1) * 1e3
+    if world > 1:
+        tt = torch.tensor([el_d], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el_d = float(tt.item())
+    striped_decode = {"workload": f"decode of ONE {ws}x{full_h} frame (YCbCr 4:2:0 + Y400 map at scale 4 -> RGBA_F16) by row stripes, {hs} rows per rank, the map "
+                                  "replicated: uhdr_hip_apply_gainmap_dev(y0, full_height), no collective",
+                      "wall_us_per_frame": round(el_d / 30 * 1e6, 1), "Mpx/s": round(px * 30 / el_d / 1e6, 1),
+                      "rank0_kernel_us_per_stripe": round(kern_us_d, 1),
+                      "rank0_kernel_frac_of_8TBs": round(algo_bytes_per_px("A") * ws * hs / (kern_us_d * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if kern_us_d else None,
+                      "note": "wall clock = max over ranks around 30 frames, launched from Python (the host loop, not the GPU, bounds it at one rank); the kernel figure is "
+                              "rank 0's HIP-event time per stripe launch"}
+    del sdr_d, gm_d, dst_d
+    torch.cuda.empty_cache()
+    # the exchange on its own: 50 back-to-back min-all-reduces of the six extrema on the library's stream
+    t0 = time.perf_counter()
+    for _ in range(50):
+        stripes.all_reduce_probe(ctx)
+    sync_all()
+    allreduce_us = (time.perf_counter() - t0) / 50 * 1e6
     return {"workload": f"configs[3]: API-1 encode of a {ws}x{hs * world} P010 + YCbCr 4:2:0 image, {hs} rows per rank, {world} rank(s): the fused chain "
                         "(two-pass 3-channel generateGainMap whose pass 2 feeds the map's rgb->ycc + FDCT directly, convertYuv inside the base image's FDCT: "
                         "uhdr_hip_encode_api1_fused_dev) + Huffman coding (restart intervals) + gather of the entropy-coded streams to rank 0",
@@ -742,7 +792,8 @@ def config4_section(ctx, u, device, rank, world, backend):
                           "and pass 2; range finalised on the device; stream sizes: one 8-byte all-gather, stream bytes: one send / recv group to rank 0",
             "transport": "host relay over torch.distributed (dry run: the ranks share devices)" if relay else "RCCL (ncclAllReduce / ncclAllGather / ncclSend + ncclRecv)",
             "ncclCommCount": nranks, "images": iters, "ms_per_image": round(el / iters * 1e3, 3), "Mpx/s": round(px * iters / el / 1e6, 1),
-            "rank0_us_per_image": fam, "jpeg_scan_bytes_base_and_map": out_bytes,
+            "rank0_us_per_image": fam, "all_reduce_us_back_to_back": round(allreduce_us, 1), "jpeg_scan_bytes_base_and_map": out_bytes,
+            "striped_decode": striped_decode,
             "max_content_boost": [round(float(v), 6) for v in md.max_content_boost]}
 
 

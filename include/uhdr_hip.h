@@ -259,6 +259,11 @@ typedef struct uhdr_hip_comm_ops {
   int (*gather_v)(void* user, const void* send, size_t send_bytes, void* recv, const size_t* counts, int root, void* hip_stream);
 } uhdr_hip_comm_ops_t;
 uhdr_error_info_t uhdr_hip_comm_init_custom(uhdr_hip_ctx_t* ctx, const uhdr_hip_comm_ops_t* ops, int rank, int nranks);
+/* The path's ONE collective by itself: elementwise minimum of n floats across the communicator's ranks, in place on a DEVICE
+ * buffer, enqueued on the context's stream (RCCL: ncclAllReduce(ncclMin); custom transport: all_reduce_min_f32).  The striped
+ * entry points issue exactly this over {min0..2, -max0..2} between their passes (jpegr.cpp:932-938's mutex merge).  Without a
+ * communicator the call does nothing. */
+uhdr_error_info_t uhdr_hip_comm_all_reduce_min_dev(uhdr_hip_ctx_t* ctx, float* buf, size_t n);
 /* Data movement between the ranks' devices on the context's stream (RCCL over xGMI by default): what replaces the
  * reference's threads writing their stripes into one buffer (jpegr.cpp:845-864).  all_gather: `bytes_per_rank` from every
  * rank, in rank order, on every rank.  gather: rank r's counts[r] bytes land at recv + sum(counts[0..r)) on `root` (stripes

@@ -1319,6 +1319,16 @@ uhdr_error_info_t comm_all_reduce_min(uhdr_hip_ctx* c, float* buf, size_t n) {
 }
 }  // namespace
 
+// The hot path's one collective on its own (device pointer, in place, enqueued on the context's stream): what
+// uhdr_hip_generate_gainmap_striped_dev / uhdr_hip_encode_api1_fused_dev issue between their passes.  Without a communicator: nothing.
+uhdr_error_info_t uhdr_hip_comm_all_reduce_min_dev(uhdr_hip_ctx_t* c, float* buf, size_t n) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  if (!buf || n == 0) return err_status(UHDR_CODEC_INVALID_PARAM, "all_reduce: nullptr buffer or zero count");
+  HIP_TRY(hipSetDevice(c->device));
+  ProfScope ps(c, "stripe_exchange");
+  return comm_all_reduce_min(c, buf, n);
+}
+
 // Every rank contributes `bytes` bytes; recv (nranks * bytes) holds them in rank order on every rank.  Device pointers,
 // enqueued on the context's stream.  Without a communicator: a copy.
 uhdr_error_info_t uhdr_hip_comm_all_gather_dev(uhdr_hip_ctx_t* c, const void* send, void* recv, size_t bytes) {

@@ -137,6 +137,18 @@ def init_comm(ctx, group=None):
     return int(lib.uhdr_hip_comm_size(ctx.handle))
 
 
+def all_reduce_probe(ctx):
+    """One min-all-reduce of six floats on the library's stream (uhdr_hip_comm_all_reduce_min_dev): the exchange step of the
+    striped encode by itself, for latency measurements."""
+    import torch
+
+    buf = getattr(ctx, "_probe_buf", None)
+    if buf is None:
+        buf = ctx._probe_buf = torch.zeros(6, dtype=torch.float32, device=f"cuda:{torch.cuda.current_device()}")
+        torch.cuda.synchronize()
+    A.check(ctx.lib.uhdr_hip_comm_all_reduce_min_dev(ctx.handle, C.c_void_p(buf.data_ptr()), 6))
+
+
 def init_comm_relay(ctx, group=None):
     """Give ``ctx`` a HOST-RELAY transport over the torch.distributed group (any backend, gloo included) through
     uhdr_hip_comm_init_custom: every exchange step copies its device buffer to the host on the library's stream, runs the
