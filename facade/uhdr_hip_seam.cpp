@@ -86,13 +86,19 @@ bool apply_gainmap(uhdr_raw_image_t* sdr_intent, uhdr_raw_image_t* gainmap_img,
                    ultrahdr::uhdr_gainmap_metadata_ext_t* gainmap_metadata, uhdr_color_transfer_t output_ct,
                    uhdr_img_fmt_t output_format, float max_display_boost, uhdr_raw_image_t* dest,
                    uhdr_error_info_t* st) {
-  if (!cur() || !gainmap_metadata) return false;
-  enter();
-  // the version check is the one thing uhdr_gainmap_metadata_ext_t adds (jpegr.cpp:1546-1555)
-  if (gainmap_metadata->version.compare(ultrahdr::kJpegrVersion)) return false;  // the reference words that error
-  const uhdr_gainmap_metadata_t md = *gainmap_metadata;  // slice off the version string
-  *st = uhdr_hip_apply_gainmap(cur(), sdr_intent, gainmap_img, &md, output_ct, output_format, max_display_boost, dest);
-  return handled(*st, "apply_gainmap");
+  // every exit that leaves the work to the reference's CPU code drops the device-resident copies: that code may write the
+  // host buffers in place
+  const bool on_device_ = [&]() -> bool {
+    if (!cur() || !gainmap_metadata) return false;
+    enter();
+    // the version check is the one thing uhdr_gainmap_metadata_ext_t adds (jpegr.cpp:1546-1555)
+    if (gainmap_metadata->version.compare(ultrahdr::kJpegrVersion)) return false;  // the reference words that error
+    const uhdr_gainmap_metadata_t md = *gainmap_metadata;  // slice off the version string
+    *st = uhdr_hip_apply_gainmap(cur(), sdr_intent, gainmap_img, &md, output_ct, output_format, max_display_boost, dest);
+    return handled(*st, "apply_gainmap");
+  }();
+  if (!on_device_) drop_resident();
+  return on_device_;
 }
 
 bool generate_gainmap(uhdr_raw_image_t* sdr_intent, uhdr_raw_image_t* hdr_intent,
@@ -101,146 +107,206 @@ bool generate_gainmap(uhdr_raw_image_t* sdr_intent, uhdr_raw_image_t* hdr_intent
                       bool use_luminance, int* scale_factor, bool multi_channel, float gamma,
                       uhdr_enc_preset_t preset, float min_content_boost, float max_content_boost,
                       float target_disp_peak_brightness, uhdr_error_info_t* st) {
-  if (!cur() || !sdr_intent || !hdr_intent || !gainmap_metadata) return false;
-  enter();
-  // map geometry and the tiny-image fallback exactly as jpegr.cpp:690-706
-  const unsigned w = sdr_intent->w, h = sdr_intent->h;
-  int s = *scale_factor;
-  if (s < 1) return false;
-  unsigned mw = w / s, mh = h / s;
-  if (mw == 0 || mh == 0) {
-    const unsigned m = w < h ? w : h;
-    s = m / 8 ? (int)(m / 8) : 1;
-    mw = w / s;
-    mh = h / s;
-  }
-  if (mw == 0 || mh == 0) return false;
-  uhdr_hip_encode_cfg_t cfg;
-  cfg.map_dimension_scale_factor = s;
-  cfg.use_multi_channel_gainmap = multi_channel;
-  cfg.gamma = gamma;
-  cfg.preset = preset;
-  cfg.min_content_boost = min_content_boost;
-  cfg.max_content_boost = max_content_boost;
-  cfg.target_disp_peak_nits = target_disp_peak_brightness;
-  cfg.sdr_is_601 = sdr_is_601;
-  cfg.use_luminance = use_luminance;
-  auto img = std::make_unique<ultrahdr::uhdr_raw_image_ext_t>(
-      multi_channel ? UHDR_IMG_FMT_24bppRGB888 : UHDR_IMG_FMT_8bppYCbCr400, hdr_intent->cg, hdr_intent->ct,
-      hdr_intent->range, mw, mh, 64);  // jpegr.cpp:714-716
-  uhdr_gainmap_metadata_t md;
-  memset(&md, 0, sizeof md);
-  *st = uhdr_hip_generate_gainmap(cur(), sdr_intent, hdr_intent, &cfg, &md, img.get());
-  if (!handled(*st, "generate_gainmap")) return false;
-  if (st->error_code == UHDR_CODEC_OK) {
-    static_cast<uhdr_gainmap_metadata_t&>(*gainmap_metadata) = md;
-    gainmap_img = std::move(img);
-    *scale_factor = s;
-  }
-  return true;
+  // every exit that leaves the work to the reference's CPU code drops the device-resident copies: that code may write the
+  // host buffers in place
+  const bool on_device_ = [&]() -> bool {
+    if (!cur() || !sdr_intent || !hdr_intent || !gainmap_metadata) return false;
+    enter();
+    // map geometry and the tiny-image fallback exactly as jpegr.cpp:690-706
+    const unsigned w = sdr_intent->w, h = sdr_intent->h;
+    int s = *scale_factor;
+    if (s < 1) return false;
+    unsigned mw = w / s, mh = h / s;
+    if (mw == 0 || mh == 0) {
+      const unsigned m = w < h ? w : h;
+      s = m / 8 ? (int)(m / 8) : 1;
+      mw = w / s;
+      mh = h / s;
+    }
+    if (mw == 0 || mh == 0) return false;
+    uhdr_hip_encode_cfg_t cfg;
+    cfg.map_dimension_scale_factor = s;
+    cfg.use_multi_channel_gainmap = multi_channel;
+    cfg.gamma = gamma;
+    cfg.preset = preset;
+    cfg.min_content_boost = min_content_boost;
+    cfg.max_content_boost = max_content_boost;
+    cfg.target_disp_peak_nits = target_disp_peak_brightness;
+    cfg.sdr_is_601 = sdr_is_601;
+    cfg.use_luminance = use_luminance;
+    auto img = std::make_unique<ultrahdr::uhdr_raw_image_ext_t>(
+        multi_channel ? UHDR_IMG_FMT_24bppRGB888 : UHDR_IMG_FMT_8bppYCbCr400, hdr_intent->cg, hdr_intent->ct,
+        hdr_intent->range, mw, mh, 64);  // jpegr.cpp:714-716
+    uhdr_gainmap_metadata_t md;
+    memset(&md, 0, sizeof md);
+    *st = uhdr_hip_generate_gainmap(cur(), sdr_intent, hdr_intent, &cfg, &md, img.get());
+    if (!handled(*st, "generate_gainmap")) return false;
+    if (st->error_code == UHDR_CODEC_OK) {
+      static_cast<uhdr_gainmap_metadata_t&>(*gainmap_metadata) = md;
+      gainmap_img = std::move(img);
+      *scale_factor = s;
+    }
+    return true;
+  }();
+  if (!on_device_) drop_resident();
+  return on_device_;
 }
 
 bool tone_map(uhdr_raw_image_t* hdr_intent, uhdr_raw_image_t* sdr_intent, uhdr_error_info_t* st) {
-  if (!cur()) return false;
-  *st = uhdr_hip_tone_map(cur(), hdr_intent, sdr_intent);
-  return handled(*st, "tone_map");
+  // every exit that leaves the work to the reference's CPU code drops the device-resident copies: that code may write the
+  // host buffers in place
+  const bool on_device_ = [&]() -> bool {
+    if (!cur()) return false;
+    *st = uhdr_hip_tone_map(cur(), hdr_intent, sdr_intent);
+    return handled(*st, "tone_map");
+  }();
+  if (!on_device_) drop_resident();
+  return on_device_;
 }
 
 bool convert_yuv(uhdr_raw_image_t* image, uhdr_color_gamut_t src_encoding, uhdr_color_gamut_t dst_encoding,
                  uhdr_error_info_t* st) {
-  if (!cur()) return false;
-  *st = uhdr_hip_convert_yuv(cur(), image, src_encoding, dst_encoding);
-  return handled(*st, "convert_yuv");
+  // every exit that leaves the work to the reference's CPU code drops the device-resident copies: that code may write the
+  // host buffers in place
+  const bool on_device_ = [&]() -> bool {
+    if (!cur()) return false;
+    *st = uhdr_hip_convert_yuv(cur(), image, src_encoding, dst_encoding);
+    return handled(*st, "convert_yuv");
+  }();
+  if (!on_device_) drop_resident();
+  return on_device_;
 }
 
 bool convert_raw_input_to_ycbcr(uhdr_raw_image_t* src, bool chroma_sampling_enabled,
                                 std::unique_ptr<ultrahdr::uhdr_raw_image_ext_t>* dst) {
-  if (!cur() || !src) return false;
-  if (src->fmt != UHDR_IMG_FMT_32bppRGBA1010102 && src->fmt != UHDR_IMG_FMT_32bppRGBA8888 && src->fmt != UHDR_IMG_FMT_24bppRGB888)
-    return false;  // YCbCr inputs are a plain copy in the reference (gainmapmath.cpp:1475-1480)
-  if (src->cg != UHDR_CG_BT_709 && src->cg != UHDR_CG_DISPLAY_P3 && src->cg != UHDR_CG_BT_2100) return false;
-  const bool ten = src->fmt == UHDR_IMG_FMT_32bppRGBA1010102;
-  const uhdr_img_fmt_t fmt = ten ? (chroma_sampling_enabled ? UHDR_IMG_FMT_24bppYCbCrP010 : UHDR_IMG_FMT_30bppYCbCr444)
-                                 : (chroma_sampling_enabled ? UHDR_IMG_FMT_12bppYCbCr420 : UHDR_IMG_FMT_24bppYCbCr444);
-  auto img = std::make_unique<ultrahdr::uhdr_raw_image_ext_t>(fmt, src->cg, src->ct, UHDR_CR_FULL_RANGE, src->w, src->h, 64);
-  const uhdr_error_info_t s = uhdr_hip_convert_raw_input_to_ycbcr(cur(), src, chroma_sampling_enabled, img.get());
-  if (!handled(s, "convert_raw_input_to_ycbcr")) return false;
-  if (s.error_code != UHDR_CODEC_OK) {
-    fprintf(stderr, "uhdr_hip_seam: convert_raw_input_to_ycbcr failed on the device: %s\n", s.has_detail ? s.detail : "");
-    *dst = nullptr;  // the reference's own failure value (callers check for nullptr)
+  // every exit that leaves the work to the reference's CPU code drops the device-resident copies: that code may write the
+  // host buffers in place
+  const bool on_device_ = [&]() -> bool {
+    if (!cur() || !src) return false;
+    if (src->fmt != UHDR_IMG_FMT_32bppRGBA1010102 && src->fmt != UHDR_IMG_FMT_32bppRGBA8888 && src->fmt != UHDR_IMG_FMT_24bppRGB888)
+      return false;  // YCbCr inputs are a plain copy in the reference (gainmapmath.cpp:1475-1480)
+    if (src->cg != UHDR_CG_BT_709 && src->cg != UHDR_CG_DISPLAY_P3 && src->cg != UHDR_CG_BT_2100) return false;
+    const bool ten = src->fmt == UHDR_IMG_FMT_32bppRGBA1010102;
+    const uhdr_img_fmt_t fmt = ten ? (chroma_sampling_enabled ? UHDR_IMG_FMT_24bppYCbCrP010 : UHDR_IMG_FMT_30bppYCbCr444)
+                                   : (chroma_sampling_enabled ? UHDR_IMG_FMT_12bppYCbCr420 : UHDR_IMG_FMT_24bppYCbCr444);
+    auto img = std::make_unique<ultrahdr::uhdr_raw_image_ext_t>(fmt, src->cg, src->ct, UHDR_CR_FULL_RANGE, src->w, src->h, 64);
+    const uhdr_error_info_t s = uhdr_hip_convert_raw_input_to_ycbcr(cur(), src, chroma_sampling_enabled, img.get());
+    if (!handled(s, "convert_raw_input_to_ycbcr")) return false;
+    if (s.error_code != UHDR_CODEC_OK) {
+      fprintf(stderr, "uhdr_hip_seam: convert_raw_input_to_ycbcr failed on the device: %s\n", s.has_detail ? s.detail : "");
+      *dst = nullptr;  // the reference's own failure value (callers check for nullptr)
+      return true;
+    }
+    *dst = std::move(img);
     return true;
-  }
-  *dst = std::move(img);
-  return true;
+  }();
+  if (!on_device_) drop_resident();
+  return on_device_;
 }
 
 bool fdct_planes(int ncomp, const unsigned char* const planes[3], const unsigned int strides[3],
                  const unsigned int blocks_w[3], const unsigned int blocks_h[3], const unsigned short* const qtables[3],
                  short* const coefs[3], uhdr_error_info_t* st) {
-  if (!cur()) return false;
-  for (int c = 0; c < ncomp; c++) {
-    *st = uhdr_hip_fdct_quant(cur(), planes[c], strides[c], (int)blocks_w[c], (int)blocks_h[c], qtables[c], coefs[c]);
-    if (st->error_code != UHDR_CODEC_OK) return c == 0 ? handled(*st, "fdct_planes") : true;
-  }
-  handled(*st, "fdct_planes");
-  return true;
+  // every exit that leaves the work to the reference's CPU code drops the device-resident copies: that code may write the
+  // host buffers in place
+  const bool on_device_ = [&]() -> bool {
+    if (!cur()) return false;
+    for (int c = 0; c < ncomp; c++) {
+      *st = uhdr_hip_fdct_quant(cur(), planes[c], strides[c], (int)blocks_w[c], (int)blocks_h[c], qtables[c], coefs[c]);
+      if (st->error_code != UHDR_CODEC_OK) return c == 0 ? handled(*st, "fdct_planes") : true;
+    }
+    handled(*st, "fdct_planes");
+    return true;
+  }();
+  if (!on_device_) drop_resident();
+  return on_device_;
 }
 
 bool idct_planes(int ncomp, const short* const coefs[3], const unsigned int blocks_w[3], const unsigned int blocks_h[3],
                  const unsigned short* const qtables[3], unsigned char* const planes[3], const unsigned int strides[3],
                  uhdr_error_info_t* st) {
-  if (!cur()) return false;
-  for (int c = 0; c < ncomp; c++) {
-    *st = uhdr_hip_idct_dequant(cur(), coefs[c], (int)blocks_w[c], (int)blocks_h[c], qtables[c], planes[c], strides[c]);
-    if (st->error_code != UHDR_CODEC_OK) return c == 0 ? handled(*st, "idct_planes") : true;
-  }
-  handled(*st, "idct_planes");
-  return true;
+  // every exit that leaves the work to the reference's CPU code drops the device-resident copies: that code may write the
+  // host buffers in place
+  const bool on_device_ = [&]() -> bool {
+    if (!cur()) return false;
+    for (int c = 0; c < ncomp; c++) {
+      *st = uhdr_hip_idct_dequant(cur(), coefs[c], (int)blocks_w[c], (int)blocks_h[c], qtables[c], planes[c], strides[c]);
+      if (st->error_code != UHDR_CODEC_OK) return c == 0 ? handled(*st, "idct_planes") : true;
+    }
+    handled(*st, "idct_planes");
+    return true;
+  }();
+  if (!on_device_) drop_resident();
+  return on_device_;
 }
 
 bool decode_scan(const void* hdr, const unsigned char* data, size_t bytes, int out_channels, int libjpeg_variant,
                  unsigned char* const planes[3], const unsigned int hstride[3], const unsigned int vstride[3],
                  uhdr_error_info_t* st) {
-  if (!cur()) return false;
-  enter();
-  *st = uhdr_hip_jpeg_decode_scan(cur(), static_cast<const uhdr_hip_jpeg_header_t*>(hdr), data, bytes, out_channels, libjpeg_variant, planes,
-                                  hstride, vstride);
-  // corrupt entropy-coded data: libjpeg decodes such files with warnings and padding; that behaviour stays libjpeg's
-  if (st->error_code == UHDR_CODEC_INVALID_PARAM) {
-    if (trace_on()) fprintf(stderr, "uhdr_hip_seam: jpeg_decode_scan -> reference CPU path (%s)\n", st->has_detail ? st->detail : "");
-    return false;
-  }
-  return handled(*st, "jpeg_decode_scan");
+  // every exit that leaves the work to the reference's CPU code drops the device-resident copies: that code may write the
+  // host buffers in place
+  const bool on_device_ = [&]() -> bool {
+    if (!cur()) return false;
+    enter();
+    *st = uhdr_hip_jpeg_decode_scan(cur(), static_cast<const uhdr_hip_jpeg_header_t*>(hdr), data, bytes, out_channels, libjpeg_variant, planes,
+                                    hstride, vstride);
+    // corrupt entropy-coded data: libjpeg decodes such files with warnings and padding; that behaviour stays libjpeg's
+    if (st->error_code == UHDR_CODEC_INVALID_PARAM) {
+      if (trace_on()) fprintf(stderr, "uhdr_hip_seam: jpeg_decode_scan -> reference CPU path (%s)\n", st->has_detail ? st->detail : "");
+      return false;
+    }
+    return handled(*st, "jpeg_decode_scan");
+  }();
+  if (!on_device_) drop_resident();
+  return on_device_;
 }
 
 bool encode_scan(const void* scan, const void* qtables, const unsigned char* const planes[3], const unsigned int strides[3],
                  int rgb_channels, unsigned char* out, size_t cap, size_t* bytes, uhdr_error_info_t* st) {
-  if (!cur()) return false;
-  enter();
-  // the IMAGE's planes with the caller's strides: partial edge blocks are padded on the device by the helper's own rules
-  *st = uhdr_hip_jpeg_encode_image(cur(), static_cast<const uhdr_hip_jpeg_scan_t*>(scan), static_cast<const uint16_t(*)[64]>(qtables), planes, strides,
-                                   rgb_channels, out, cap, bytes);
-  return handled(*st, "jpeg_encode_scan");
+  // every exit that leaves the work to the reference's CPU code drops the device-resident copies: that code may write the
+  // host buffers in place
+  const bool on_device_ = [&]() -> bool {
+    if (!cur()) return false;
+    enter();
+    // the IMAGE's planes with the caller's strides: partial edge blocks are padded on the device by the helper's own rules
+    *st = uhdr_hip_jpeg_encode_image(cur(), static_cast<const uhdr_hip_jpeg_scan_t*>(scan), static_cast<const uint16_t(*)[64]>(qtables), planes, strides,
+                                     rgb_channels, out, cap, bytes);
+    return handled(*st, "jpeg_encode_scan");
+  }();
+  if (!on_device_) drop_resident();
+  return on_device_;
 }
 
 bool effect(int kind, int p0, int p1, int dst_w, int dst_h, uhdr_raw_image_t* src,
             std::unique_ptr<ultrahdr::uhdr_raw_image_ext_t>* dst) {
-  if (!cur() || !src || dst_w <= 0 || dst_h <= 0) return false;
-  auto img = std::make_unique<ultrahdr::uhdr_raw_image_ext_t>(src->fmt, src->cg, src->ct, src->range, (unsigned)dst_w, (unsigned)dst_h, 64);
-  const uhdr_error_info_t s = uhdr_hip_apply_effect(cur(), kind, p0, p1, src, img.get());
-  if (!handled(s, kind == 0 ? "effect_rotate" : kind == 1 ? "effect_mirror" : kind == 2 ? "effect_crop" : "effect_resize")) return false;
-  if (s.error_code != UHDR_CODEC_OK) {  // an argument the reference's own code would also refuse, or a device error: let the CPU code speak
-    fprintf(stderr, "uhdr_hip_seam: effect %d failed on the device: %s\n", kind, s.has_detail ? s.detail : "");
-    return false;
-  }
-  *dst = std::move(img);
-  return true;
+  // every exit that leaves the work to the reference's CPU code drops the device-resident copies: that code may write the
+  // host buffers in place
+  const bool on_device_ = [&]() -> bool {
+    if (!cur() || !src || dst_w <= 0 || dst_h <= 0) return false;
+    auto img = std::make_unique<ultrahdr::uhdr_raw_image_ext_t>(src->fmt, src->cg, src->ct, src->range, (unsigned)dst_w, (unsigned)dst_h, 64);
+    const uhdr_error_info_t s = uhdr_hip_apply_effect(cur(), kind, p0, p1, src, img.get());
+    if (!handled(s, kind == 0 ? "effect_rotate" : kind == 1 ? "effect_mirror" : kind == 2 ? "effect_crop" : "effect_resize")) return false;
+    if (s.error_code != UHDR_CODEC_OK) {  // an argument the reference's own code would also refuse, or a device error: let the CPU code speak
+      fprintf(stderr, "uhdr_hip_seam: effect %d failed on the device: %s\n", kind, s.has_detail ? s.detail : "");
+      return false;
+    }
+    *dst = std::move(img);
+    return true;
+  }();
+  if (!on_device_) drop_resident();
+  return on_device_;
 }
 
 bool jpeg_rgb_to_ycc(const uhdr_raw_image_t* rgb, uhdr_raw_image_t* ycc, uhdr_error_info_t* st) {
-  if (!cur()) return false;
-  *st = uhdr_hip_jpeg_rgb_to_ycc(cur(), rgb, ycc);
-  return handled(*st, "jpeg_rgb_to_ycc");
+  // every exit that leaves the work to the reference's CPU code drops the device-resident copies: that code may write the
+  // host buffers in place
+  const bool on_device_ = [&]() -> bool {
+    if (!cur()) return false;
+    *st = uhdr_hip_jpeg_rgb_to_ycc(cur(), rgb, ycc);
+    return handled(*st, "jpeg_rgb_to_ycc");
+  }();
+  if (!on_device_) drop_resident();
+  return on_device_;
 }
 bool jpeg_ycc_to_rgb(const uhdr_raw_image_t* ycc, int libjpeg_variant, uhdr_raw_image_t* rgb, uhdr_error_info_t* st) {
   if (!cur()) return false;
@@ -248,5 +314,8 @@ bool jpeg_ycc_to_rgb(const uhdr_raw_image_t* ycc, int libjpeg_variant, uhdr_raw_
   return handled(*st, "jpeg_ycc_to_rgb");
 }
 bool enabled() { return cur() != nullptr; }
+void drop_resident() {
+  if (cur()) uhdr_hip_resident_begin(cur());
+}
 
 }  // namespace uhdr_hip_seam

@@ -105,6 +105,10 @@ bool jpeg_rgb_to_ycc(const uhdr_raw_image_t* rgb, uhdr_raw_image_t* ycc, uhdr_er
 bool jpeg_ycc_to_rgb(const uhdr_raw_image_t* ycc, int libjpeg_variant, uhdr_raw_image_t* rgb, uhdr_error_info_t* st);
 // is a device context current on this thread (i.e. are we inside an accelerated uhdr_encode / uhdr_decode)?
 bool enabled();
+// The reference's CPU code is about to run in place of a device stage: device-resident copies of host buffers (kept between the
+// stages of one accelerated call) are dropped, because that code may rewrite those buffers.  Called by every seam entry point
+// that returns false.
+void drop_resident();
 
 }  // namespace uhdr_hip_seam
 

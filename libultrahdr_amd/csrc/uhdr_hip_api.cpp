@@ -246,9 +246,10 @@ ImageViewMut view_mut_of(const uhdr_raw_image_t* im) {
 // Stage a host image into device scratch `slot` (all planes packed back to back, 256-B aligned);
 // *dev gets device plane pointers.  upload=false only reserves space (outputs).
 // a host buffer is about to be (re)written by the library: whatever device copy was kept for it is stale
-void resident_drop(uhdr_hip_ctx* c, const void* host_plane0) {
+void resident_drop(uhdr_hip_ctx* c, const void* host_plane) {  // any plane of a kept image
+  if (!host_plane) return;
   for (auto& r : c->resident)
-    if (r.valid && r.host[0] == host_plane0) r.valid = false;
+    if (r.valid && (r.host[0] == host_plane || r.host[1] == host_plane || r.host[2] == host_plane)) r.valid = false;
 }
 
 uhdr_error_info_t stage_in(uhdr_hip_ctx* c, int slot, const uhdr_raw_image_t* host, uhdr_raw_image_t* dev,
@@ -1333,8 +1334,19 @@ uhdr_error_info_t uhdr_hip_comm_all_reduce_min_dev(uhdr_hip_ctx_t* c, float* buf
 // enqueued on the context's stream.  Without a communicator: a copy.
 uhdr_error_info_t uhdr_hip_comm_all_gather_dev(uhdr_hip_ctx_t* c, const void* send, void* recv, size_t bytes) {
   if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
-  if (!send || !recv || bytes == 0) return err_status(UHDR_CODEC_INVALID_PARAM, "all_gather: nullptr buffer or zero size");
+  if (bytes == 0) return err_status(UHDR_CODEC_INVALID_PARAM, "all_gather: zero size");  // (the same on every rank: nobody enters the collective)
   HIP_TRY(hipSetDevice(c->device));
+  // a rank that was handed a nullptr still joins the collective (zeros from / into scratch) and reports afterwards: its peers
+  // must not wait for it forever
+  uhdr_error_info_t local = ok_status();
+  if (!send || !recv) {
+    local = err_status(UHDR_CODEC_INVALID_PARAM, "all_gather: nullptr buffer");
+    const size_t nr = (size_t)(c->comm_size > 0 ? c->comm_size : 1);
+    UHDR_TRY(ensure(c->scratch[6], bytes * (nr + 1)));
+    HIP_TRY(hipMemsetAsync(c->scratch[6].p, 0, bytes * (nr + 1), c->stream));
+    recv = c->scratch[6].p;
+    send = (const char*)c->scratch[6].p + bytes * nr;
+  }
   if (c->comm_custom) {
     if (!c->comm_ops.all_gather) return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "custom transport without all_gather");
     const int rc = c->comm_ops.all_gather(c->comm_ops.user, send, recv, bytes, (void*)c->stream);
@@ -1344,7 +1356,7 @@ uhdr_error_info_t uhdr_hip_comm_all_gather_dev(uhdr_hip_ctx_t* c, const void* se
   } else {
     if (send != recv) HIP_TRY(hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, c->stream));
   }
-  return ok_status();
+  return local;
 }
 
 // Stripes of unequal size to one rank -- the merge of the stripes' outputs into one image (the reference's threads write
@@ -1354,20 +1366,34 @@ uhdr_error_info_t uhdr_hip_comm_all_gather_dev(uhdr_hip_ctx_t* c, const void* se
 uhdr_error_info_t uhdr_hip_comm_gather_dev(uhdr_hip_ctx_t* c, const void* send, size_t send_bytes, void* recv, const size_t* counts, int root) {
   if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
   const int n = c->comm_size > 0 ? c->comm_size : 1, rank = c->comm_size > 0 ? c->comm_rank : 0;
+  // Without `counts` or a valid root nobody knows what to exchange: that is the one failure that needs the communicator aborted.
   if (!counts || root < 0 || root >= n) return err_status(UHDR_CODEC_INVALID_PARAM, "gather: nullptr counts or root %d outside 0..%d", root, n - 1);
-  if (counts[rank] != send_bytes) return err_status(UHDR_CODEC_INVALID_PARAM, "gather: counts[%d] = %zu but this rank sends %zu bytes", rank, counts[rank], send_bytes);
-  if ((send_bytes && !send) || (rank == root && !recv)) return err_status(UHDR_CODEC_INVALID_PARAM, "gather: nullptr buffer");
   HIP_TRY(hipSetDevice(c->device));
+  // Every other local failure is RECORDED and the rank still takes part in the exchange exactly as `counts` says -- with a
+  // scratch buffer in place of the one it cannot use -- so that its peers do not wait in ncclRecv / ncclSend forever (the
+  // pattern of uhdr_hip_generate_gainmap_striped_dev).  The error is returned afterwards.
+  uhdr_error_info_t local = ok_status();
+  if (counts[rank] != send_bytes) local = err_status(UHDR_CODEC_INVALID_PARAM, "gather: counts[%d] = %zu but this rank sends %zu bytes", rank, counts[rank], send_bytes);
+  else if ((send_bytes && !send) || (rank == root && !recv)) local = err_status(UHDR_CODEC_INVALID_PARAM, "gather: nullptr buffer");
+  if (local.error_code != UHDR_CODEC_OK) {
+    size_t total = 0;
+    for (int r = 0; r < n; r++) total += counts[r];
+    UHDR_TRY(ensure(c->scratch[6], (total ? total : 1) + counts[rank]));
+    HIP_TRY(hipMemsetAsync(c->scratch[6].p, 0, (total ? total : 1) + counts[rank], c->stream));
+    recv = c->scratch[6].p;                          // (root) somewhere to receive
+    send = (const char*)c->scratch[6].p + total;      // counts[rank] zero bytes to send
+    send_bytes = counts[rank];
+  }
   if (c->comm_custom) {
-    if (!c->comm_ops.gather_v) return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "custom transport without gather_v");
+    if (!c->comm_ops.gather_v) return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "custom transport without gather_v");  // (the same on every rank)
     const int rc = c->comm_ops.gather_v(c->comm_ops.user, send, send_bytes, recv, counts, root, (void*)c->stream);
     if (rc != 0) return err_status(UHDR_CODEC_ERROR, "custom transport: gather_v failed (%d)", rc);
-    return ok_status();
+    return local;
   }
   size_t off = 0;
   if (!c->comm) {
-    if (send_bytes && send != recv) HIP_TRY(hipMemcpyAsync(recv, send, send_bytes, hipMemcpyDeviceToDevice, c->stream));
-    return ok_status();
+    if (local.error_code == UHDR_CODEC_OK && send_bytes && send != recv) HIP_TRY(hipMemcpyAsync(recv, send, send_bytes, hipMemcpyDeviceToDevice, c->stream));
+    return local;
   }
   RCCL_TRY(rccl().GroupStart());
   ncclResult_t r1 = ncclSuccess;
@@ -1387,7 +1413,7 @@ uhdr_error_info_t uhdr_hip_comm_gather_dev(uhdr_hip_ctx_t* c, const void* send, 
     for (int r = 0; r < root; r++) mine += counts[r];
     if ((char*)recv + mine != (const char*)send) HIP_TRY(hipMemcpyAsync((char*)recv + mine, send, send_bytes, hipMemcpyDeviceToDevice, c->stream));
   }
-  return ok_status();
+  return local;
 }
 
 // A rank must never leave this function without having taken part in the collective: the other ranks would wait in it
@@ -2274,6 +2300,7 @@ uhdr_error_info_t uhdr_hip_idct_dequant(uhdr_hip_ctx_t* c, const int16_t* coef, 
   UHDR_TRY(ensure(c->scratch[1], dpitch * (size_t)bh * 8));
   HIP_TRY(hipMemcpyAsync(c->scratch[0].p, coef, in_bytes, hipMemcpyHostToDevice, c->stream));
   UHDR_TRY(uhdr_hip_idct_dequant_dev(c, (const int16_t*)c->scratch[0].p, bw, bh, qt, (uint8_t*)c->scratch[1].p, dpitch));
+  resident_drop(c, plane);  //  a device copy kept for this host plane is stale from here on
   HIP_TRY(hipMemcpy2DAsync(plane, stride, c->scratch[1].p, dpitch, (size_t)bw * 8, (size_t)bh * 8, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return ok_status();
