@@ -88,7 +88,9 @@ static void fill_quant(const uint16_t* qt_luma, const uint16_t* qt_chroma, Quant
 // One wave, up to eight blocks: row pass results `out` of lane (row rr, block rb) -> transposed through the wave's LDS workspace
 // -> column pass + quantizer with lane (block cb, column cc) -> transposed back -> lane (rr, rb) holds one coefficient row of
 // its block in v[0..7].  `active`: the lane's block exists.  (jcdctmgr.c forward_DCT's quantizer, branch free: fdct_quant.hip)
-__device__ __forceinline__ void column_pass_and_quantize(int* ws, int lane, const int row_out[8], const uint32_t qv[8], const uint32_t qm[8], int v[8]) {
+// q: this table's 64 {divisor, reciprocal} pairs in LDS (natural order) -- the lane's eight pairs of column cc are read where they
+// are used instead of living in 16 registers per table (map_blocks_kernel: 133 -> ~100 VGPRs)
+__device__ __forceinline__ void column_pass_and_quantize(int* ws, int lane, const int row_out[8], const uint2* q, int v[8]) {
   const int cb = lane >> 3, cc = lane & 7, rr = lane >> 3, rb = lane & 7;
   int in[8], out[8];
 #pragma unroll
@@ -102,9 +104,10 @@ __device__ __forceinline__ void column_pass_and_quantize(int* ws, int lane, cons
   for (int r = 0; r < 8; r++) {
     const int x = out[r];
     const int sgn = x >> 31;
-    const uint32_t a = (uint32_t)((x ^ sgn) - sgn) + (qv[r] >> 1);
-    const uint32_t q = __umulhi(a, qm[r]);
-    out[r] = (int)(q ^ (uint32_t)sgn) - sgn;
+    const uint2 qe = q[r * 8 + cc];
+    const uint32_t a = (uint32_t)((x ^ sgn) - sgn) + (qe.x >> 1);
+    const uint32_t qq = __umulhi(a, qe.y);
+    out[r] = (int)(qq ^ (uint32_t)sgn) - sgn;
   }
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -137,10 +140,14 @@ struct MapBlocksParams {
 };
 
 #define FIX16(x) ((int)((x) * 65536.0 + 0.5))
+constexpr int kMapBlock = 512;  // eight waves share one copy of the step tables (24 KB): three workgroups = 24 waves per CU
 template <int NCH>
-__global__ __launch_bounds__(kBlock) void map_blocks_kernel(const MapBlocksParams p) {
+__global__ __launch_bounds__(kMapBlock) void map_blocks_kernel(const MapBlocksParams p) {
+  constexpr int kBlock = kMapBlock;  // (shadows the file's 256 inside this kernel)
   __shared__ int s_ws[kBlock / 64][8 * 8 * 9];
   __shared__ uint2 s_tab[NCH][kAffTabMax];
+  __shared__ uint2 s_q[2][64];
+  if (threadIdx.x < 128) s_q[threadIdx.x >> 6][threadIdx.x & 63] = uint2{p.q.qv[threadIdx.x >> 6][threadIdx.x & 63], p.q.qm[threadIdx.x >> 6][threadIdx.x & 63]};
   StepTab st[3];
   bool tabs = true;
 #pragma unroll
@@ -161,13 +168,7 @@ __global__ __launch_bounds__(kBlock) void map_blocks_kernel(const MapBlocksParam
   int* ws = s_ws[wv];
   const int groups_x = (p.bw + 7) >> 3, total = groups_x * p.bh;
   const int gwave = blockIdx.x * (kBlock / 64) + wv, nwaves = gridDim.x * (kBlock / 64);
-  const int cc = lane & 7, rr = lane >> 3, rb = lane & 7;
-  uint32_t qvy[8], qmy[8], qvc[8], qmc[8];
-#pragma unroll
-  for (int r = 0; r < 8; r++) {
-    qvy[r] = p.q.qv[0][r * 8 + cc]; qmy[r] = p.q.qm[0][r * 8 + cc];
-    qvc[r] = p.q.qv[1][r * 8 + cc]; qmc[r] = p.q.qm[1][r * 8 + cc];
-  }
+  const int rr = lane >> 3, rb = lane & 7;
   const uint32_t map_w = (uint32_t)p.bw * 8;
   for (int t = gwave; t < total; t += nwaves) {
     const int by = t / groups_x, gx = t - by * groups_x;
@@ -177,51 +178,57 @@ __global__ __launch_bounds__(kBlock) void map_blocks_kernel(const MapBlocksParam
     if (active) {
       const uint32_t y = by * 8 + rr, x0 = bx * 8;
       const float4* src = (const float4*)(p.ratio + ((size_t)y * map_w + x0) * NCH);
-      float g[8 * NCH];
+      float4 g[2 * NCH];
 #pragma unroll
-      for (int k = 0; k < 2 * NCH; k++) {
-        const float4 f = src[k];
-        g[4 * k] = f.x; g[4 * k + 1] = f.y; g[4 * k + 2] = f.z; g[4 * k + 3] = f.w;
-      }
-      uint32_t b[8 * NCH];
+      for (int k = 0; k < 2 * NCH; k++) g[k] = src[k];
+      uint32_t w[2 * NCH];  // the 8 * NCH map bytes of this row, packed as they come
       if (tabs) {
 #pragma unroll
-        for (int e = 0; e < 8 * NCH; e++) b[e] = step_code(g[e], s_tab[e % NCH], st[e % NCH]);
-      } else {  // a channel without a table (gamma is 1 here, the launcher checks): the per-sample evaluation of generate_gainmap.hip
-#pragma unroll 1
-        for (int e = 0; e < 8 * NCH; e++) {
-          const int c = e % NCH;
-          const float lg = gain_log2_of_ratio(g[e], p.math_tab);
-          float m = div_by_rcp64(lg - p.dev->mn[c], p.dev->range_rcp[c]);
-          m *= 255.0f;
-          float t2 = m + 0.5f;
-          t2 = (t2 < 0.0f) ? 0.0f : ((t2 > 255.0f) ? 255.0f : t2);
-          b[e] = (uint32_t)t2;
+        for (int k = 0; k < 2 * NCH; k++) {
+          const float f[4] = {g[k].x, g[k].y, g[k].z, g[k].w};
+          uint32_t acc = 0;
+#pragma unroll
+          for (int i = 0; i < 4; i++) acc |= step_code(f[i], s_tab[(4 * k + i) % NCH], st[(4 * k + i) % NCH]) << (8 * i);
+          w[k] = acc;
         }
+      } else {  // a channel without a table (gamma is 1 here, the launcher checks): the per-sample evaluation of generate_gainmap.hip,
+                // as a rolled loop that parks its words in the wave's (idle) LDS workspace -- its float64 arithmetic must not
+                // set the register count of the table path
+        const float* gp = (const float*)src;
+#pragma unroll 1
+        for (int k = 0; k < 2 * NCH; k++) {
+          uint32_t acc = 0;
+#pragma unroll 1
+          for (int i = 0; i < 4; i++) {
+            const int c = (4 * k + i) % NCH;
+            const float lg = gain_log2_of_ratio(gp[4 * k + i], p.math_tab);
+            float m = div_by_rcp64(lg - p.dev->mn[c], p.dev->range_rcp[c]);
+            m *= 255.0f;
+            float t2 = m + 0.5f;
+            t2 = (t2 < 0.0f) ? 0.0f : ((t2 > 255.0f) ? 255.0f : t2);
+            acc |= (uint32_t)t2 << (8 * i);
+          }
+          ws[lane * 9 + k] = (int)acc;
+        }
+#pragma unroll
+        for (int k = 0; k < 2 * NCH; k++) w[k] = (uint32_t)ws[lane * 9 + k];
       }
       if (p.map_out) {
         uint8_t* o = p.map_out + ((size_t)y * p.out_stride + x0) * NCH;
-        if (NCH == 3) {
-          uint32_t w[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-          for (int e = 0; e < 24; e++) w[e >> 2] |= b[e] << (8 * (e & 3));
-          *(uint2*)o = uint2{w[0], w[1]};
-          *(uint2*)(o + 8) = uint2{w[2], w[3]};
-          *(uint2*)(o + 16) = uint2{w[4], w[5]};
-        } else {
-          *(uint2*)o = uint2{b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24), b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24)};
-        }
+        for (int k = 0; k < NCH; k++) *(uint2*)(o + 8 * k) = uint2{w[2 * k], w[2 * k + 1]};
       }
+      auto byte_at = [&](int e) -> int { return (int)((w[e >> 2] >> (8 * (e & 3))) & 0xffu); };
 #pragma unroll
       for (int k = 0; k < 8; k++) {
         if (NCH == 3) {  // jccolor.c rgb_ycc_convert (fdct_quant.hip / jpeg_decode.hip: both published constant sets give these bytes)
-          const int r = (int)b[3 * k], gg = (int)b[3 * k + 1], bb = (int)b[3 * k + 2];
+          const int r = byte_at(3 * k), gg = byte_at(3 * k + 1), bb = byte_at(3 * k + 2);
           const int half = 1 << 15, off = 128 << 16;
           comp[0][k] = ((__mul24(FIX16(0.29900), r) + __mul24(FIX16(0.58700), gg) + __mul24(FIX16(0.11400), bb) + half) >> 16) - 128;
           comp[1][k] = ((__mul24(-FIX16(0.16874), r) + __mul24(-FIX16(0.33126), gg) + __mul24(FIX16(0.50000), bb) + off + half - 1) >> 16) - 128;
           comp[2][k] = ((__mul24(FIX16(0.50000), r) + __mul24(-FIX16(0.41869), gg) + __mul24(-FIX16(0.08131), bb) + off + half - 1) >> 16) - 128;
         } else {
-          comp[0][k] = (int)b[k] - 128;
+          comp[0][k] = byte_at(k) - 128;
         }
       }
     }
@@ -234,7 +241,7 @@ __global__ __launch_bounds__(kBlock) void map_blocks_kernel(const MapBlocksParam
 #pragma unroll
         for (int c = 0; c < 8; c++) out[c] = 0;
       }
-      column_pass_and_quantize(ws, lane, out, ci == 0 ? qvy : qvc, ci == 0 ? qmy : qmc, v);
+      column_pass_and_quantize(ws, lane, out, s_q[ci == 0 ? 0 : 1], v);
       if (active) store_coef_row(p.coef[ci] + ((size_t)by * p.bw + bx) * 64 + rr * 8, v);
     }
   }
@@ -267,13 +274,10 @@ __global__ __launch_bounds__(kBlock) void base_blocks_kernel(const BaseBlocksPar
   uint8_t* tcr = s_c[wv][1];
   const int pairs_x = (p.mcus_x + 1) >> 1, total = pairs_x * p.mcus_y;
   const int gwave = blockIdx.x * (kBlock / 64) + wv, nwaves = gridDim.x * (kBlock / 64);
-  const int cc = lane & 7, rr = lane >> 3, rb = lane & 7;
-  uint32_t qvy[8], qmy[8], qvc[8], qmc[8];
-#pragma unroll
-  for (int r = 0; r < 8; r++) {
-    qvy[r] = p.q.qv[0][r * 8 + cc]; qmy[r] = p.q.qm[0][r * 8 + cc];
-    qvc[r] = p.q.qv[1][r * 8 + cc]; qmc[r] = p.q.qm[1][r * 8 + cc];
-  }
+  const int rr = lane >> 3, rb = lane & 7;
+  __shared__ uint2 s_q[2][64];
+  if (threadIdx.x < 128) s_q[threadIdx.x >> 6][threadIdx.x & 63] = uint2{p.q.qv[threadIdx.x >> 6][threadIdx.x & 63], p.q.qm[threadIdx.x >> 6][threadIdx.x & 63]};
+  __syncthreads();
   const int bw_y = p.mcus_x * 2, bw_c = p.mcus_x;
   for (int t = gwave; t < total; t += nwaves) {
     const int my = t / pairs_x, mp = t - my * pairs_x;
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(kBlock) void base_blocks_kernel(const BaseBlocksPar
 #pragma unroll
         for (int c = 0; c < 8; c++) out[c] = 0;
       }
-      column_pass_and_quantize(ws, lane, out, qvy, qmy, v);
+      column_pass_and_quantize(ws, lane, out, s_q[0], v);
       if (active) {
         const size_t bx = (size_t)(mx0 + m) * 2 + bxx, by = (size_t)my * 2 + byy;
         store_coef_row(p.coef[0] + (by * bw_y + bx) * 64 + rr * 8, v);
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(kBlock) void base_blocks_kernel(const BaseBlocksPar
 #pragma unroll
         for (int c = 0; c < 8; c++) out[c] = 0;
       }
-      column_pass_and_quantize(ws, lane, out, qvc, qmc, v);
+      column_pass_and_quantize(ws, lane, out, s_q[1], v);
       if (active) store_coef_row(p.coef[1 + comp] + ((size_t)my * bw_c + (mx0 + m)) * 64 + rr * 8, v);
     }
     __builtin_amdgcn_wave_barrier();
@@ -377,9 +381,11 @@ hipError_t launch_map_blocks(const float* ratio, const AffineDev* dev, const dou
   p.ratio = ratio; p.dev = dev; p.math_tab = math_tab; p.map_out = map_out; p.out_stride = out_stride; p.bw = bw; p.bh = bh;
   for (int i = 0; i < nch; i++) p.coef[i] = coef[i];
   fill_quant(qt_luma, qt_chroma, &p.q);
-  const int grid = resident_grid(((bw + 7) / 8) * bh, 4);  // 33 KB of LDS (tables + workspaces): four workgroups per CU
-  if (nch == 3) hipLaunchKernelGGL((map_blocks_kernel<3>), dim3(grid), dim3(kBlock), 0, s, p);
-  else hipLaunchKernelGGL((map_blocks_kernel<1>), dim3(grid), dim3(kBlock), 0, s, p);
+  int grid = (((bw + 7) / 8) * bh + kMapBlock / 64 - 1) / (kMapBlock / 64);
+  const int cap = resident_grid(1 << 30, 3);  // 44 KB of LDS (tables + workspaces) per 512 threads: three workgroups per CU
+  if (grid > cap) grid = cap;
+  if (nch == 3) hipLaunchKernelGGL((map_blocks_kernel<3>), dim3(grid), dim3(kMapBlock), 0, s, p);
+  else hipLaunchKernelGGL((map_blocks_kernel<1>), dim3(grid), dim3(kMapBlock), 0, s, p);
   return hipGetLastError();
 }
 

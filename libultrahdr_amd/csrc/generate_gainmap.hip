@@ -152,17 +152,21 @@ __global__ __launch_bounds__(kTabBlock) void minmax_table_kernel(const MinmaxTab
   __shared__ double s_T[kMathTabDoubles];  // the log2 tables: every bisection step is a dependent table read
   const int c = blockIdx.x;  // channel
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // this thread's partials first, THEN the table staging: both round trips to memory are in flight together (the kernel is a
+  // chain of latencies -- 6 of its 9 us were loads waiting for one another)
+  float a = UHDR_RATIO_MIN_INIT, b = UHDR_RATIO_MAX_INIT;
+  if (p.do_reduce && !p.empty)
+    for (int i = tid; i < p.n_partials; i += kTabBlock) {
+      a = fminf(a, p.partials[(size_t)i * 6 + c]);
+      b = fmaxf(b, p.partials[(size_t)i * 6 + 3 + c]);
+    }
+  float merged_min = 0.0f, merged_max = 0.0f;
+  if (p.do_finalize && p.merged_in) { merged_min = p.merged_in[c]; merged_max = -p.merged_in[3 + c]; }
   for (int i = tid; i < kMathTabDoubles; i += kTabBlock) s_T[i] = p.math_tab[i];
   __syncthreads();
   const double* T = s_T;
   float gmin, gmax;
   if (p.do_reduce) {  // ratio extrema of this channel over the partials of pass 1 -> the reference's log2 extrema
-    float a = UHDR_RATIO_MIN_INIT, b = UHDR_RATIO_MAX_INIT;
-    if (!p.empty)
-      for (int i = tid; i < p.n_partials; i += kTabBlock) {
-        a = fminf(a, p.partials[(size_t)i * 6 + c]);
-        b = fmaxf(b, p.partials[(size_t)i * 6 + 3 + c]);
-      }
     a = wave_min(a);
     b = wave_max(b);
     if (lane == 0) { s_red[wv][0] = a; s_red[wv][1] = b; }
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(kTabBlock) void minmax_table_kernel(const MinmaxTab
   }
   if (!p.do_finalize && !p.do_table) return;
   if (p.do_finalize) {  // jpegr.cpp:969-986: clamp to [-14.3, 15.6], the user's min / max content-boost hints, the epsilon guard
-    if (p.merged_in) { gmin = p.merged_in[c]; gmax = -p.merged_in[3 + c]; }
+    if (p.merged_in) { gmin = merged_min; gmax = merged_max; }
     if (c < p.nch) {
       gmin = gmin < -14.3f ? -14.3f : (gmin > 15.6f ? 15.6f : gmin);
       gmax = gmax < -14.3f ? -14.3f : (gmax > 15.6f ? 15.6f : gmax);

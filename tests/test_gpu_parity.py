@@ -201,6 +201,12 @@ GEN_CASES = [
     (dict(kind="1010102", ct=A.UHDR_CT_PQ), "rgba8888", dict(preset=A.UHDR_USAGE_REALTIME, use_luminance=0, use_multi_channel_gainmap=0, map_dimension_scale_factor=2, gamma=1.4)),
     (dict(kind="1010102", ct=A.UHDR_CT_HLG, cg=A.UHDR_CG_DISPLAY_P3), "rgba8888", dict(min_content_boost=0.8, max_content_boost=6.0, target_disp_peak_nits=1600.0)),
     (dict(kind="p010", ct=A.UHDR_CT_HLG), "yuv420", dict(sdr_is_601=1, gamma=0.8, use_multi_channel_gainmap=0, map_dimension_scale_factor=3)),
+    # round 4 (two-pass maps are ratio planes + per-channel step tables built on the device): ranges the table builder must cope with
+    # -- user hints that cut the range down to 1.4e-4 log2 units (too dense for a table: pass 2 evaluates per sample), a range of
+    # one binade, and gamma != 1 at full resolution with three channels (no tables at all: the per-sample kernel)
+    (dict(kind="p010", ct=A.UHDR_CT_HLG), "yuv420", dict(min_content_boost=2.0, max_content_boost=2.0002)),
+    (dict(kind="p010", ct=A.UHDR_CT_PQ), "yuv420", dict(min_content_boost=1.0, max_content_boost=2.0)),
+    (dict(kind="p010", ct=A.UHDR_CT_HLG), "yuv420", dict(gamma=1.25)),
 ]
 
 
@@ -960,15 +966,18 @@ def test_fused_api0_front_end_equals_the_three_operators(hip_ctx, ct, cg, cfg_kw
         assert_close_codes(gm_f.to_host().valid(0), gm_o.valid(0), 1, tol, "fused gain map")
 
 
-@pytest.mark.parametrize("w,h,scale,multi,convert", [(640, 352, 1, True, True), (336, 208, 1, True, False), (1280, 704, 4, False, True),
-                                                    (16, 16, 1, True, True), (272, 48, 2, False, True), (1296, 720, 1, True, True)])
-def test_api1_fused_chain_equals_the_operators(hip_ctx, w, h, scale, multi, convert):
+@pytest.mark.parametrize("w,h,scale,multi,convert,hints", [(640, 352, 1, True, True, None), (336, 208, 1, True, False, None), (1280, 704, 4, False, True, None),
+                                                          (16, 16, 1, True, True, None), (272, 48, 2, False, True, None), (1296, 720, 1, True, True, None),
+                                                          (640, 352, 1, True, True, (2.0, 2.0002)), (336, 208, 2, False, True, (1.5, 1.50004))])
+def test_api1_fused_chain_equals_the_operators(hip_ctx, w, h, scale, multi, convert, hints):
     """uhdr_hip_encode_api1_fused_dev (pass 1 -> range + tables -> pass 2 fused with rgb->ycc + FDCT; convertYuv fused with the
     base image's three FDCTs) == generateGainMap -> fdct_quant_rgb / fdct_quant, convertYuv -> 3 x fdct_quant: coefficient
     blocks, the 8-bit map and the metadata, bit for bit."""
     import torch
 
     cfg = A.default_encode_cfg(map_dimension_scale_factor=scale, use_multi_channel_gainmap=int(multi), preset=A.UHDR_USAGE_BEST_QUALITY)
+    if hints:  # a range too narrow for a step table: the fused map kernel's per-sample path
+        cfg.min_content_boost, cfg.max_content_boost = hints
     u = _uhdr_for(hip_ctx, cfg)
     sdr = synth.make_sdr_yuv420(w, h, seed=w + h)
     hdr = synth.make_hdr_p010(w, h, ct=A.UHDR_CT_HLG, seed=w * 3 + h)
@@ -994,6 +1003,10 @@ def test_api1_fused_chain_equals_the_operators(hip_ctx, w, h, scale, multi, conv
     hip_ctx.synchronize()
     assert md_f.as_dict() == md_s.as_dict() == md_n.as_dict()
     assert planes_equal(gm_f, gm_s)
+    if hints:
+        st = A.Stats()
+        hip_ctx.lib.uhdr_hip_get_stats(hip_ctx.handle, C.byref(st))
+        assert st.generate_channels_per_sample > 0
     for i in range(3):
         assert torch.equal(base_f[i], base_s[i].reshape(base_f[i].shape)), f"base component {i}"
         assert torch.equal(base_n[i], base_f[i])
