@@ -6,11 +6,11 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/final_smoke.log 2>&1; tail -1 gpurun_out/final_smoke.log
-python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r03_bench_head.json 2> gpurun_out/r03_bench_head.err; tail -c 300 gpurun_out/r03_bench_head.json
-UHDR_BENCH_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 --no-extra --no-cpu > gpurun_out/r03_bench_gloo_2ranks.json 2> gpurun_out/r03_bench_gloo_2ranks.err; tail -c 200 gpurun_out/r03_bench_gloo_2ranks.json
+python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r04_bench_head.json 2> gpurun_out/r04_bench_head.err; tail -c 300 gpurun_out/r04_bench_head.json
+UHDR_BENCH_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 --no-extra --no-cpu > gpurun_out/r04_bench_gloo_2ranks.json 2> gpurun_out/r04_bench_gloo_2ranks.err; tail -c 200 gpurun_out/r04_bench_gloo_2ranks.json
 [ "$1" = "noprof" ] && exit 0
-PROF_DIR=prof_all3 bash tools/profile_all.sh > gpurun_out/prof_all3.log 2>&1; tail -2 gpurun_out/prof_all3.log | cut -c1-160
+PROF_DIR=prof_all4 bash tools/profile_all.sh > gpurun_out/prof_all4.log 2>&1; tail -2 gpurun_out/prof_all4.log | cut -c1-160
 cd $R
 [ "$1" = "nobenchprof" ] && exit 0
-bash tools/profile_bench.sh > gpurun_out/prof_bench3.log 2>&1; tail -4 gpurun_out/prof_bench3.log | cut -c1-200
+bash tools/profile_bench.sh > gpurun_out/prof_bench4.log 2>&1; tail -4 gpurun_out/prof_bench4.log | cut -c1-200
 du -sh gpurun_out

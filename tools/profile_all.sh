@@ -8,7 +8,7 @@ KEEP=$PWD/gpurun_out/${PROF_DIR:-prof_all}
 OUT=/tmp/${PROF_DIR:-prof_all}
 rm -rf $OUT; mkdir -p $OUT $KEEP
 R=${GRAFT_REPO_ROOT:-/root/repo}
-CASES="${@:-8kC 8kB 8kA 4kAhlg 4kApq b32hlg tm4k gen4k gen4k1 tm8k api0f fdct4k idct4k cvt4k huff4k}"
+CASES="${@:-8kC 8kB 8kA 4kAhlg 4kApq b32hlg tm4k gen4k gen4k1 tm8k api0f api1f api1f8k fdct4k idct4k cvt4k huff4k}"
 export QB_REPS=1 QB_ITERS=4 QB_NO_SERIAL=1
 LIMIT=${LIMIT:-200}
 limited() {  # run "$@" in its own session; SIGKILL the whole group after $LIMIT seconds (a profiler that does not come back must not eat the box's time)

@@ -16,7 +16,7 @@ summary, committed_as = sys.argv[1], sys.argv[2]
 fetch = write = None
 nf = nw = 0
 for line in open(summary):
-    if "apply_quad_kernel" in line and "<0, 2, 0, 0, 0>" in line:
+    if "apply_quad_kernel<0, 2, 0," in line:
         m = re.search(r"(FETCH_SIZE|WRITE_SIZE)\s+n=(\d+)\s+avg=([0-9.]+)", line)
         if m and m.group(1) == "FETCH_SIZE":
             fetch, nf = float(m.group(3)), int(m.group(2))
