@@ -205,12 +205,15 @@ uhdr_error_info_t uhdr_hip_generate_gainmap_dev(uhdr_hip_ctx_t* ctx,
                                                 uhdr_gainmap_metadata_t* gainmap_metadata,
                                                 uhdr_raw_image_t* gainmap_img);
 /* two-pass generation split at its only exchange step (jpegr.cpp:932-938: the min/max merge):
- *   pass1: per map pixel log2 gain -> gain_log2 (device floats, w/scale * h/scale * (3|1)),
- *          per-channel min/max of this stripe -> minmax_dev[6] = {min0,min1,min2,max0,max1,max2}
- *          (device floats; initialise nothing, the call does)
+ *   pass1: per map pixel gain -> gain_log2_dev (device floats, w/scale * h/scale * (3|1): an OPAQUE plane that only pass2
+ *          reads -- since round 4 it holds the gain ratio (hdr + eps) / (sdr + eps), not its log2: min / max commute with the
+ *          monotone log2 and pass 2's byte is a step function of the ratio, see csrc/generate_gainmap.hip),
+ *          per-channel min/max of this stripe's LOG2 gains, exactly the reference's six floats
+ *          -> minmax_dev[6] = {min0,min1,min2,max0,max1,max2} (device floats; initialise nothing, the call does)
  *   <all-reduce minmax_dev across ranks: MIN on [0..2], MAX on [3..5]>
  *   finalize: clamp / hints / epsilon guard + metadata fill (jpegr.cpp:969-986, 1031-1048), host
- *   pass2: affine map to u8 (jpegr.cpp:992-1013) */
+ *   pass2: affine map to u8 (jpegr.cpp:992-1013): per-channel step tables built on the device from the final range, then a
+ *          table lookup per sample (a user gamma != 1 or a range too narrow for a table: per-sample evaluation) */
 uhdr_error_info_t uhdr_hip_generate_gainmap_pass1_dev(uhdr_hip_ctx_t* ctx,
                                                       const uhdr_raw_image_t* sdr_intent,
                                                       const uhdr_raw_image_t* hdr_intent,
