@@ -119,6 +119,9 @@ def fuzz_generate():
     cfg = A.default_encode_cfg(map_dimension_scale_factor=int(rng.choice([1, 1, 2, 4])), use_multi_channel_gainmap=int(rng.integers(0, 2)),
                                preset=int(rng.choice([A.UHDR_USAGE_REALTIME, A.UHDR_USAGE_BEST_QUALITY])), use_luminance=int(rng.integers(0, 2)),
                                sdr_is_601=int(rng.integers(0, 2)), gamma=1.0 if rng.random() < 0.7 else float(rng.uniform(0.6, 2.0)))
+    if rng.random() < 0.3:  # user hints on the content boost: from ordinary to so narrow that pass 2 gets no step table (round 4)
+        lo = float(rng.uniform(0.5, 3.0))
+        cfg.min_content_boost, cfg.max_content_boost = lo, lo * float(rng.choice([1.00005, 1.001, 1.5, 8.0]))
     md_w, gm_w = L.generate_gainmap(KIND, sdr, hdr, cfg)
     from libultrahdr_amd.ultrahdr import UltraHdr as UH
 
@@ -353,11 +356,82 @@ def fuzz_huffman_streams():
 JOBS = None
 
 
+def fuzz_api1_fused():
+    """uhdr_hip_encode_api1_fused_dev against the operators it fuses (round 4): coefficient blocks, map bytes and metadata."""
+    import torch
+
+    from libultrahdr_amd.ultrahdr import UltraHdr as UH
+
+    w, h = 16 * int(rng.integers(1, 24)), 16 * int(rng.integers(1, 12))
+    scale = int(rng.choice([1, 1, 2]))
+    if (w // scale) % 8 or (h // scale) % 8:
+        scale = 1
+    multi = bool(rng.integers(0, 2))
+    cfg = A.default_encode_cfg(map_dimension_scale_factor=scale, use_multi_channel_gainmap=int(multi), use_luminance=int(rng.integers(0, 2)))
+    if rng.random() < 0.25:
+        lo = float(rng.uniform(0.5, 3.0))
+        cfg.min_content_boost, cfg.max_content_boost = lo, lo * float(rng.choice([1.00005, 1.01, 4.0]))
+    ct = int(rng.choice([A.UHDR_CT_HLG, A.UHDR_CT_PQ]))
+    sdr = synth.make_sdr_yuv420(w, h, seed=int(rng.integers(1 << 30)), cg=int(rng.integers(0, 3)), noise=0.06).to("cuda:0")
+    hdr = synth.make_hdr_p010(w, h, seed=int(rng.integers(1 << 30)), ct=ct, cg=int(rng.integers(0, 3)), noise=0.06,
+                              rng_range=int(rng.choice([A.UHDR_CR_LIMITED_RANGE, A.UHDR_CR_FULL_RANGE]))).to("cuda:0")
+    g = UH(ctx=ctx, mapDimensionScaleFactor=scale, useMultiChannelGainMap=multi, preset=cfg.preset, minContentBoost=cfg.min_content_boost,
+           maxContentBoost=cfg.max_content_boost)
+    ql, qc = L.quant_table_port(int(rng.integers(50, 100)), False), L.quant_table_port(int(rng.integers(50, 100)), True)
+    enc = int(rng.choice([A.UHDR_CG_UNSPECIFIED, A.UHDR_CG_DISPLAY_P3, A.UHDR_CG_BT_709]))
+    base_f, map_f, md_f, gm_f = g.encodeApi1Fused(sdr, hdr, enc, (ql, qc), (ql, qc), want_map=True, use_luminance=bool(cfg.use_luminance))
+    md_s, gm_s = g.generateGainMap(sdr, hdr, False, bool(cfg.use_luminance))
+    base = sdr.clone()
+    if enc != A.UHDR_CG_UNSPECIFIED:
+        g.convertYuv(base, sdr.raw.cg, enc)
+    ok = md_f.as_dict() == md_s.as_dict() and torch.equal(gm_f.buf, gm_s.buf)
+    for i in range(3):
+        ref_c = g.fdct_quant(base.plane_tensor(i), base.raw.stride[i], (w if i == 0 else w // 2) // 8, (h if i == 0 else h // 2) // 8, ql if i == 0 else qc)
+        ok = ok and torch.equal(base_f[i], ref_c.reshape(base_f[i].shape))
+    map_s = g.fdct_quant_rgb(gm_s, ql, qc) if multi else [g.fdct_quant(gm_s.plane_tensor(0), gm_s.raw.stride[0], gm_s.w // 8, gm_s.h // 8, ql)]
+    for i in range(len(map_s)):
+        ok = ok and torch.equal(map_f[i], map_s[i].reshape(map_f[i].shape))
+    ctx.synchronize()
+    note("api1_fused", bool(ok), f"{w}x{h} s{scale} mc{int(multi)} enc{enc} ct{ct} hints {cfg.min_content_boost:.5g}..{cfg.max_content_boost:.5g}")
+
+
+def fuzz_encode_image():
+    """uhdr_hip_jpeg_encode_image (partial edge blocks padded on the device, round 4) against the REAL reference's entropy-coded bytes."""
+    if KIND != "ref":
+        return
+    from libultrahdr_amd.images import Image
+    from libultrahdr_amd.ultrahdr import UltraHdr as UH
+
+    u = UH(ctx=ctx)
+    kind = int(rng.integers(0, 3))
+    w, h = int(rng.integers(1, 200)), int(rng.integers(1, 120))
+    align = int(rng.choice([1, 1, 16, 64]))
+    q = int(rng.integers(40, 100))
+    if kind == 0:
+        w, h = max(2, w & ~1), max(2, h & ~1)
+        img, samp, rgb = Image(A.UHDR_IMG_FMT_12bppYCbCr420, w, h, align=align), [(2, 2), (1, 1), (1, 1)], 0
+    elif kind == 1:
+        img, samp, rgb = Image(A.UHDR_IMG_FMT_8bppYCbCr400, w, h, align=align), [(1, 1)], 0
+    else:
+        img, samp, rgb = Image(A.UHDR_IMG_FMT_24bppRGB888, w, h, align=max(align, 1)), [(1, 1)] * 3, 3
+    for i, pl in enumerate(img.layout):
+        if pl is not None:
+            img.plane(i)[...] = rng.integers(0, 256, img.plane(i).shape, dtype=np.uint8)
+    jpeg = L.ref_jpeg_compress(img, q)
+    hd = u.jpeg_parse(jpeg)
+    want = jpeg[hd.scan_offset: hd.scan_offset + hd.scan_bytes]
+    ql = np.array(hd.qtable[0][:], dtype=np.uint16)
+    qc = np.array(hd.qtable[1][:] if hd.scan.num_components == 3 else hd.qtable[0][:], dtype=np.uint16)
+    planes = img.plane(0).reshape(h, img.raw.stride[0], 3) if rgb else [img.plane(i) for i, pl in enumerate(img.layout) if pl is not None]
+    got = u.jpeg_encode_image(planes, w, h, samp, ql, qc, rgb_channels=rgb)
+    note("encode_image", got == want, f"kind{kind} {w}x{h} align{align} q{q} {len(got)} vs {len(want)} bytes")
+
+
 def run(seconds, seed=1, context=None, log=None):
     """Runs the sweep for `seconds`; returns (stats, mismatches).  `log`: a path that receives the summary line."""
     init(seed, context)
     jobs = [fuzz_huffman, fuzz_apply, fuzz_apply, fuzz_apply, fuzz_generate, fuzz_generate_formats, fuzz_tonemap, fuzz_tonemap_formats,
-            fuzz_converts, fuzz_decode_fused, fuzz_huffman_streams]
+            fuzz_converts, fuzz_decode_fused, fuzz_huffman_streams, fuzz_api1_fused, fuzz_encode_image]
     t_end = time.time() + seconds
     i = 0
     while time.time() < t_end:
