@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -2170,6 +2171,9 @@ uhdr_error_info_t uhdr_hip_encode_api1_fused_dev(uhdr_hip_ctx_t* c, const uhdr_r
   auto note_hip = [&](hipError_t e, const char* what) {
     if (e != hipSuccess && local.error_code == UHDR_CODEC_OK) local = err_status(UHDR_CODEC_ERROR, "%s: %s", what, hipGetErrorString(e));
   };
+  // profiling: the per-stage families below, and ONE event pair around the whole chain ("encode_api1_chain": first launch's start to
+  // last launch's end, the gaps between the four launches included) -- destroyed, i.e. recorded, before the metadata copy
+  std::unique_ptr<ProfScope> chain(new ProfScope(c, "encode_api1_chain"));
   {
     ProfScope ps(c, "generate_gainmap");
     if (run) {
@@ -2213,6 +2217,7 @@ uhdr_error_info_t uhdr_hip_encode_api1_fused_dev(uhdr_hip_ctx_t* c, const uhdr_r
                                blocks->map_coef, map_out, map_stride, c->stream), "map blocks");
     note_hip(launch_base_blocks(view_of(sdr), convert ? &conv : nullptr, qt_base[0], qt_base[1], blocks->base_coef, c->stream), "base blocks");
   }
+  chain.reset();
   note_hip(hipMemcpyAsync(c->h_mm, final_mm, 9 * sizeof(float), hipMemcpyDeviceToHost, c->stream), "metadata copy");
   note_hip(hipStreamSynchronize(c->stream), "synchronize");  // the only host synchronisation: the metadata needs the (merged) range
   if (xchg.error_code != UHDR_CODEC_OK) return xchg;
