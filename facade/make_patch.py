@@ -42,11 +42,18 @@ def api_cpp(t):
     scope = ("#ifdef UHDR_ENABLE_HIP\n  uhdr_hip_seam::Scope hip_scope(handle->m_enable_hip, &handle->m_uhdr_hip_ctxt);\n"
              "  if (hip_scope.failed()) {\n    status = hip_scope.error();\n    return status;\n  }\n#endif\n")
     t = insert_after(t, "  uhdr_error_info_t& status = handle->m_encode_call_status;\n", scope)
-    t = insert_after(t, "  status = uhdr_dec_probe(dec);\n  if (status.error_code != UHDR_CODEC_OK) return status;\n\n  handle->m_sailed = true;\n", scope)
+    # uhdr_decode: decoded images may stay on the device unless effects are queued (apply_effects reads the gain-map image on the host)
+    t = insert_after(t, "  status = uhdr_dec_probe(dec);\n  if (status.error_code != UHDR_CODEC_OK) return status;\n\n  handle->m_sailed = true;\n",
+                     scope.replace("&handle->m_uhdr_hip_ctxt);", "&handle->m_uhdr_hip_ctxt,\n                                  /* lazy_downloads */ handle->m_effects.empty());"))
+    t = insert_before(t, "  return handle->m_gainmap_img_buffer.get();\n",
+                      "#ifdef UHDR_ENABLE_HIP\n  if (!uhdr_hip_seam::materialize(handle->m_uhdr_hip_ctxt)) return nullptr;\n#endif\n")
     t = insert_after(t, "#ifdef UHDR_ENABLE_GLES\n  codec->m_enable_gles = enable;\n#endif\n",
                      "#ifdef UHDR_ENABLE_HIP\n  codec->m_enable_hip = enable;\n#endif\n")
     for nth in (0, 1):  # uhdr_reset_encoder, uhdr_reset_decoder
-        t = insert_before(t, "    handle->m_sailed = false;\n", "#ifdef UHDR_ENABLE_HIP\n    handle->m_enable_hip = false;\n#endif\n", nth)
+        t = insert_before(t, "    handle->m_sailed = false;\n",
+                          "#ifdef UHDR_ENABLE_HIP\n    handle->m_enable_hip = false;\n" +
+                          ("    uhdr_hip_seam::forget(handle->m_uhdr_hip_ctxt);  // a deferred gain-map image copy: its destination goes away below\n" if nth == 1 else "") +
+                          "#endif\n", nth)
     return t
 EDITS["lib/src/ultrahdr_api.cpp"] = api_cpp
 
@@ -68,6 +75,16 @@ def jpegr_cpp(t):
                       "#ifdef UHDR_ENABLE_HIP\n  {\n    uhdr_error_info_t hip_status;\n"
                       "    if (uhdr_hip_seam::apply_gainmap(sdr_intent, gainmap_img, gainmap_metadata, output_ct, output_format,\n"
                       "                                     max_display_boost, dest, &hip_status))\n      return hip_status;\n  }\n#endif\n")
+    # decodeJPEGR: the two decoded images stay on the device; the copy into the caller's gain-map image is deferred
+    t = insert_before(t, "  UHDR_ERR_CHECK(jpeg_dec_obj_sdr.decompressImage(\n      primary_jpeg_image.data, primary_jpeg_image.data_sz,\n"
+                         "      (output_ct == UHDR_CT_SRGB) ? DECODE_TO_RGB_CS : DECODE_TO_YCBCR_CS));\n\n  JpegDecoderHelper jpeg_dec_obj_gm;\n",
+                      "#ifdef UHDR_ENABLE_HIP\n  uhdr_hip_seam::lazy_downloads(output_ct != UHDR_CT_SRGB);  // the planes' only reader is applyGainMap below\n#endif\n")
+    t = insert_before(t, "    UHDR_ERR_CHECK(jpeg_dec_obj_gm.decompressImage(gainmap_jpeg_image.data,\n"
+                         "                                                   gainmap_jpeg_image.data_sz, DECODE_STREAM));\n"
+                         "    gainmap = jpeg_dec_obj_gm.getDecompressedImage();\n    if (gainmap_img != nullptr) {\n",
+                      "#ifdef UHDR_ENABLE_HIP\n    uhdr_hip_seam::lazy_downloads(true);  // readers: the copy below and applyGainMap\n#endif\n")
+    t = insert_before(t, "      UHDR_ERR_CHECK(copy_raw_image(&gainmap, gainmap_img));\n    }\n    gainmap.cg =\n",
+                      "#ifdef UHDR_ENABLE_HIP\n      uhdr_hip_seam::lazy_downloads(false);\n      if (!uhdr_hip_seam::defer_copy(&gainmap, gainmap_img))\n#endif\n")
     t = insert_after(t, "uhdr_error_info_t UltraHdr::toneMap(uhdr_raw_image_t* hdr_intent, uhdr_raw_image_t* sdr_intent) {\n",
                      "#ifdef UHDR_ENABLE_HIP\n  {\n    uhdr_error_info_t hip_status;\n"
                      "    if (uhdr_hip_seam::tone_map(hdr_intent, sdr_intent, &hip_status)) return hip_status;\n  }\n#endif\n")

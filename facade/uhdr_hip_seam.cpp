@@ -15,6 +15,7 @@ namespace uhdr_hip_seam {
 
 namespace {
 thread_local void* tl_ctxt = nullptr;
+thread_local bool tl_lazy_ok = false;
 std::atomic<unsigned long> g_calls{0};
 
 uhdr_hip_ctx_t* cur() { return static_cast<uhdr_hip_ctx_t*>(tl_ctxt); }
@@ -47,8 +48,9 @@ bool handled(const uhdr_error_info_t& s, const char* stage) {
 }
 }  // namespace
 
-Scope::Scope(bool enable, void** slot) : mPrev(tl_ctxt), mFailed(false) {
+Scope::Scope(bool enable, void** slot, bool lazy) : mPrev(tl_ctxt), mFailed(false) {
   memset(&mError, 0, sizeof mError);
+  tl_lazy_ok = enable && lazy && !getenv("UHDR_HIP_SEAM_EAGER_DOWNLOADS");
   if (!enable) {
     tl_ctxt = nullptr;
     return;
@@ -75,6 +77,39 @@ Scope::~Scope() {
   if (tl_ctxt && trace_on()) fprintf(stderr, "uhdr_hip_seam: [%8.2f ms] accelerated call ends\n", now_ms());
   if (tl_ctxt) uhdr_hip_resident_end(cur());
   tl_ctxt = mPrev;
+  tl_lazy_ok = false;
+}
+
+void lazy_downloads(bool on) {
+  if (cur()) uhdr_hip_resident_lazy(cur(), on && tl_lazy_ok);
+}
+bool defer_copy(uhdr_raw_image_t* src, uhdr_raw_image_t* dst) {
+  if (!cur() || !src || !dst) return false;
+  if (uhdr_hip_resident_adopt(cur(), src, dst)) {
+    dst->cg = src->cg;  // gainmapmath.cpp:1505-1507
+    dst->ct = src->ct;
+    dst->range = src->range;
+    if (trace_on()) fprintf(stderr, "uhdr_hip_seam: [%8.2f ms] gain-map image copy deferred: the image stays on the device until asked for\n", now_ms());
+    return true;
+  }
+  // the host copy reads the helper's buffer: it has to be written by now
+  const uhdr_error_info_t s = uhdr_hip_resident_flush(cur());
+  if (s.error_code != UHDR_CODEC_OK) fprintf(stderr, "uhdr_hip_seam: write-back of a decoded image failed: %s\n", s.has_detail ? s.detail : "");
+  return false;
+}
+bool materialize(void* ctxt) {
+  if (!ctxt) return true;
+  const double t0 = trace_on() ? now_ms() : 0.0;
+  const uhdr_error_info_t s = uhdr_hip_resident_materialize(static_cast<uhdr_hip_ctx_t*>(ctxt));
+  if (s.error_code != UHDR_CODEC_OK) {
+    fprintf(stderr, "uhdr_hip_seam: download of the gain-map image failed: %s\n", s.has_detail ? s.detail : "");
+    return false;
+  }
+  if (trace_on()) fprintf(stderr, "uhdr_hip_seam: [%8.2f ms, took %6.2f] gain-map image asked for\n", now_ms(), now_ms() - t0);
+  return true;
+}
+void forget(void* ctxt) {
+  if (ctxt) uhdr_hip_resident_forget(static_cast<uhdr_hip_ctx_t*>(ctxt));
 }
 
 void release(void* ctxt) {

@@ -38,9 +38,11 @@ namespace uhdr_hip_seam {
 
 // RAII: makes `*slot` (the codec's lazily created uhdr_hip context) current on this thread for one
 // uhdr_encode / uhdr_decode call.  enable == false: nothing happens, every seam returns false.
+// lazy_downloads: the call allows decoded images to stay on the device (see lazy_downloads() below); uhdr_decode passes
+// "no effects queued" -- apply_effects (ultrahdr_api.cpp:291-430) reads the gain-map image on the host.
 class Scope {
  public:
-  Scope(bool enable, void** slot);
+  Scope(bool enable, void** slot, bool lazy_downloads = false);
   ~Scope();
   bool failed() const { return mFailed; }
   uhdr_error_info_t error() const { return mError; }
@@ -52,6 +54,21 @@ class Scope {
 };
 // ~uhdr_codec_private
 void release(void* ctxt);
+
+// Lazy downloads of decodeJPEGR's decoded images (uhdr_hip_resident_lazy, include/uhdr_hip.h).
+//   lazy_downloads(on)   jpegr.cpp:1478-1488: switched on in front of a JpegDecoderHelper::decompressImage whose result has no
+//                        reader but applyGainMap and the copy below; the decode then leaves the helper's buffer unwritten.  Every
+//                        seam entry point that hands a stage back to the reference's CPU code writes the buffers first.
+//   defer_copy(src, dst) in place of copy_raw_image(&gainmap, gainmap_img) (jpegr.cpp:1490): true when the copy is now pending
+//                        on the device (dst's cg / ct / range are set as copy_raw_image sets them), false when the caller
+//                        copies on the host (the buffers are written by then).
+//   materialize(ctxt)    uhdr_get_decoded_gainmap_image (ultrahdr_api.cpp:2032-2043): makes the pending copy.  false: a
+//                        device error, there is no image to hand out.
+//   forget(ctxt)         uhdr_reset_decoder: the destination is about to be freed.
+void lazy_downloads(bool on);
+bool defer_copy(uhdr_raw_image_t* src, uhdr_raw_image_t* dst);
+bool materialize(void* ctxt);
+void forget(void* ctxt);
 // counters for tests / the demo app: how many stage calls ran on the device in this process
 unsigned long calls_on_device();
 

@@ -601,6 +601,31 @@ uhdr_error_info_t uhdr_hip_jpeg_encode_image(uhdr_hip_ctx_t* ctx, const uhdr_hip
 void uhdr_hip_resident_begin(uhdr_hip_ctx_t* ctx);
 void uhdr_hip_resident_end(uhdr_hip_ctx_t* ctx);
 
+/* ---- lazy downloads inside a resident session (round 4) ---------------------------------------------------------------
+ * decodeJPEGR's two decoded images have exactly two readers: applyGainMap (jpegr.cpp:1527), which on this path reads the
+ * device copies, and copy_raw_image(&gainmap, gainmap_img) (jpegr.cpp:1490), which fills the image uhdr_get_decoded_gainmap_
+ * image (ultrahdr_api.cpp:2031-2043) hands out -- rarely asked for, 33 MB for a full-resolution RGBA map.  So:
+ *   _lazy(ctx, 1)   until _lazy(ctx, 0) or _end: an image uhdr_hip_jpeg_decode_scan keeps on the device is NOT written to the
+ *                   caller's planes; the device copy IS the image.  Library entry points handed those planes read the device
+ *                   copy, and the library writes the planes back by itself before it would read them from the host or reuse
+ *                   the slot.  The caller calls _flush before anything ELSE reads them (the facade: before any CPU stage).
+ *   _flush          writes every unwritten image back to its host planes and performs every adopted copy, now.
+ *   _adopt(src,dst) stands for copy_raw_image(src, dst) of an unwritten single-plane image (8bppYCbCr400, RGB888, RGBA8888;
+ *                   same size, and same format or copy_raw_image's RGB888 -> RGBA8888 with alpha 255 -- what a build against
+ *                   IJG libjpeg decodes a three-channel map to): returns 1 when the copy is now the library's to make -- the device
+ *                   copy then outlives _end, and _materialize (or _flush, inside the session) makes it; 0 when src is not
+ *                   such an image and the caller copies on the host as before.  Only pixel data: cg / ct / range of dst are
+ *                   the caller's.  One copy can be pending per context; dst must stay allocated until _materialize or _forget.
+ *   _materialize    makes the pending copy (device -> dst planes); no-op when nothing is pending.
+ *   _forget         dst is going away (uhdr_reset_decoder, ~uhdr_codec_private): nothing is pending any more.
+ * _end discards unwritten images without writing them back: by ending the session the caller says nobody reads those host
+ * planes any more (decodeJPEGR's JpegDecoderHelper locals are gone by then).  _begin forgets a pending copy. */
+void uhdr_hip_resident_lazy(uhdr_hip_ctx_t* ctx, int on);
+uhdr_error_info_t uhdr_hip_resident_flush(uhdr_hip_ctx_t* ctx);
+int uhdr_hip_resident_adopt(uhdr_hip_ctx_t* ctx, const uhdr_raw_image_t* src, const uhdr_raw_image_t* dst);
+uhdr_error_info_t uhdr_hip_resident_materialize(uhdr_hip_ctx_t* ctx);
+void uhdr_hip_resident_forget(uhdr_hip_ctx_t* ctx);
+
 /* ---- API-1 encode chain without its round trips (MI355X extension, round 4) ---------------------------------------------
  * JpegR::encodeJPEGR API-1 (jpegr.cpp:253-316) = generateGainMap -> compress the map -> convertYuv of the base copy
  * (jpegr.cpp:436-518) -> compress the base.  This entry point runs the sample -> coefficient part of all of it in FOUR
@@ -642,6 +667,9 @@ typedef struct uhdr_hip_stats {
    * monotone) -- or a user gamma != 1 -- is evaluated per sample instead.  Both give the reference's bytes; this counts which ran. */
   unsigned long long generate_channels_tabled;    /* channels of two-pass calls mapped through a step table */
   unsigned long long generate_channels_per_sample;/* channels of two-pass calls evaluated per sample */
+  /* lazy downloads (uhdr_hip_resident_lazy) */
+  unsigned long long lazy_downloads_skipped;      /* decoded images left on the device instead of written to the caller's planes */
+  unsigned long long lazy_downloads_done;         /* of those, written back / copied out after all (_flush, _materialize, slot reuse) */
 } uhdr_hip_stats_t;
 void uhdr_hip_get_stats(uhdr_hip_ctx_t* ctx, uhdr_hip_stats_t* out);
 

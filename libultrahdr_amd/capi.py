@@ -165,7 +165,8 @@ class Api1Blocks(C.Structure):  # uhdr_hip_api1_blocks_t
 class Stats(C.Structure):
     _fields_ = [(n, C.c_ulonglong) for n in ("entropy_decode_parallel", "entropy_decode_intervals", "entropy_decode_single_lane",
                                               "entropy_decode_declined", "entropy_encode_stream", "entropy_encode_intervals", "resident_hits",
-                                              "generate_channels_tabled", "generate_channels_per_sample")]
+                                              "generate_channels_tabled", "generate_channels_per_sample", "lazy_downloads_skipped",
+                                              "lazy_downloads_done")]
 
 
 class CommOps(C.Structure):
@@ -245,6 +246,11 @@ _SIGS = {
     "uhdr_hip_get_stats": (None, [C.c_void_p, C.c_void_p]),
     "uhdr_hip_resident_begin": (None, [C.c_void_p]),
     "uhdr_hip_resident_end": (None, [C.c_void_p]),
+    "uhdr_hip_resident_lazy": (None, [C.c_void_p, C.c_int]),
+    "uhdr_hip_resident_flush": (ErrorInfo, [C.c_void_p]),
+    "uhdr_hip_resident_adopt": (C.c_int, [C.c_void_p, _P(RawImage), _P(RawImage)]),
+    "uhdr_hip_resident_materialize": (ErrorInfo, [C.c_void_p]),
+    "uhdr_hip_resident_forget": (None, [C.c_void_p]),
     "uhdr_hip_profile_enable": (None, [C.c_void_p, C.c_int]),
     "uhdr_hip_profile_read": (C.c_int, [C.c_void_p, C.c_char_p, _P(C.c_double), C.c_int]),
     "uhdr_hip_profile_read_list": (C.c_int, [C.c_void_p, C.c_char_p, _P(C.c_double), C.c_int, C.c_int]),

@@ -3,6 +3,7 @@
 // There is deliberately NO CPU implementation behind these entry points: if HIP is unusable the
 // calls fail with UHDR_CODEC_ERROR.
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -53,6 +54,15 @@ static uhdr_error_info_t err_status(uhdr_codec_err_t code, const char* fmt, ...)
   } while (0)
 
 namespace {
+// UHDR_HIP_CLOCK_DEBUG: host-side timestamps inside the JPEG decode entry points (where a call's wall time goes)
+struct DbgClock {
+  bool on;
+  std::chrono::steady_clock::time_point t0;
+  DbgClock() : on(getenv("UHDR_HIP_CLOCK_DEBUG") != nullptr), t0(std::chrono::steady_clock::now()) {}
+  void mark(const char* what) const {
+    if (on) fprintf(stderr, "uhdr_hip:   [%7.1f us] %s\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), what);
+  }
+};
 
 struct ProfEntry {
   hipEvent_t a, b;
@@ -108,9 +118,29 @@ struct uhdr_hip_ctx {
     size_t off[3] = {};
     unsigned int dev_stride[3] = {};
     unsigned int prows[3] = {}, pcols[3] = {};  // samples of every plane the device copy holds
+    // lazy downloads (uhdr_hip_resident_lazy): the host planes were NOT written, the device copy is the image
+    bool host_unwritten = false;
+    // uhdr_hip_resident_adopt: a copy_raw_image(this image, adopt_dst) the caller left to the library
+    bool adopted = false;
+    void* adopt_dst = nullptr;
+    unsigned int adopt_stride = 0, adopt_w = 0, adopt_h = 0;
+    bool adopt_expand = false;  // RGB888 kept, RGBA8888 wanted (copy_raw_image's conversion, gainmapmath.cpp:1566-1587)
   } resident[2];
+  // entropy decode: the subsequence size a scan with this many blocks per MCU settled at after a lost first attempt
+  struct HuffHint { uint32_t sub_bits = 0, bits_per_block = 0; } huff_hint[16];
   bool resident_on = false;
+  bool resident_lazy = false;
   unsigned int resident_next = 0;
+  // an adopted copy that outlived its session (uhdr_hip_resident_end): performed by uhdr_hip_resident_materialize
+  struct PendingCopy {
+    DeviceBuf buf;
+    bool on = false;
+    size_t off = 0, pitch = 0, dst_pitch = 0;
+    unsigned int w = 0, h = 0, bps = 0;
+    bool expand = false;
+    void* dst = nullptr;
+    DeviceBuf tmp;  // the RGBA8888 form of an RGB888 image on its way out
+  } pending;
   // A host-side model of the 256 MiB infinity cache, for one decision: whether applyGainMap's input planes are worth a read
   // sweep by prefetcher workgroups (apply_gainmap.hip).  Reads allocate there, the kernels' nontemporal output stores do not
   // (a frame's inputs are still cached when 102 MB of other frames' inputs were read in between, and are not after 255 MB:
@@ -247,10 +277,56 @@ ImageViewMut view_mut_of(const uhdr_raw_image_t* im) {
 // Stage a host image into device scratch `slot` (all planes packed back to back, 256-B aligned);
 // *dev gets device plane pointers.  upload=false only reserves space (outputs).
 // a host buffer is about to be (re)written by the library: whatever device copy was kept for it is stale
+// Lazy downloads.  write_back: bring the host planes of a kept image up to date (they were left unwritten) and perform the
+// copy the caller left to the library, both from the device copy; the entry stays valid.
+// device image -> host destination of an adopted copy; expand: RGB888 -> RGBA8888 with alpha 255 on the way
+uhdr_error_info_t adopted_copy_out(uhdr_hip_ctx* c, const void* src, size_t src_pitch, unsigned int bps, bool expand, unsigned int w, unsigned int h,
+                                   void* dst, size_t dst_pitch) {
+  if (expand) {
+    UHDR_TRY(ensure(c->pending.tmp, (size_t)w * 4 * h));
+    HIP_TRY(launch_repack(0, src, src_pitch, c->pending.tmp.p, (size_t)w * 4, w, h, c->stream));
+    HIP_TRY(hipMemcpy2DAsync(dst, dst_pitch, c->pending.tmp.p, (size_t)w * 4, (size_t)w * 4, h, hipMemcpyDeviceToHost, c->stream));
+  } else {
+    HIP_TRY(hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, (size_t)w * bps, h, hipMemcpyDeviceToHost, c->stream));
+  }
+  return ok_status();
+}
+uhdr_error_info_t resident_write_back(uhdr_hip_ctx* c, uhdr_hip_ctx::Resident& r) {
+  if (!r.valid || (!r.host_unwritten && !r.adopted)) return ok_status();
+  const size_t bps = bytes_per_sample(r.fmt);
+  if (r.host_unwritten)
+    for (int pl = 0; pl < 3; pl++) {
+      if (!r.host[pl]) continue;
+      HIP_TRY(hipMemcpy2DAsync((void*)r.host[pl], (size_t)r.host_stride[pl] * bps, (const char*)r.buf.p + r.off[pl], (size_t)r.dev_stride[pl] * bps,
+                               (size_t)r.pcols[pl] * bps, r.prows[pl], hipMemcpyDeviceToHost, c->stream));
+    }
+  if (r.adopted)
+    UHDR_TRY(adopted_copy_out(c, (const char*)r.buf.p + r.off[0], (size_t)r.dev_stride[0] * bps, (unsigned int)bps, r.adopt_expand, r.adopt_w, r.adopt_h,
+                              r.adopt_dst, (size_t)r.adopt_stride * (r.adopt_expand ? 4 : bps)));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  r.host_unwritten = false;
+  r.adopted = false;
+  c->stats.lazy_downloads_done++;
+  return ok_status();
+}
+uhdr_error_info_t resident_write_back_all(uhdr_hip_ctx* c) {
+  for (auto& r : c->resident) UHDR_TRY(resident_write_back(c, r));
+  return ok_status();
+}
+// a kept image is given up (its slot is needed, or its host buffer is about to be rewritten by the library)
+void resident_retire(uhdr_hip_ctx* c, uhdr_hip_ctx::Resident& r, bool host_is_rewritten) {
+  if (r.valid && (r.adopted || (r.host_unwritten && !host_is_rewritten))) {
+    if (host_is_rewritten) r.host_unwritten = false;
+    (void)resident_write_back(c, r);
+  }
+  r.valid = false;
+  r.host_unwritten = false;
+  r.adopted = false;
+}
 void resident_drop(uhdr_hip_ctx* c, const void* host_plane) {  // any plane of a kept image
   if (!host_plane) return;
   for (auto& r : c->resident)
-    if (r.valid && (r.host[0] == host_plane || r.host[1] == host_plane || r.host[2] == host_plane)) r.valid = false;
+    if (r.valid && (r.host[0] == host_plane || r.host[1] == host_plane || r.host[2] == host_plane)) resident_retire(c, r, true);
 }
 
 uhdr_error_info_t stage_in(uhdr_hip_ctx* c, int slot, const uhdr_raw_image_t* host, uhdr_raw_image_t* dev,
@@ -274,6 +350,7 @@ uhdr_error_info_t stage_in(uhdr_hip_ctx* c, int slot, const uhdr_raw_image_t* ho
       return ok_status();
     }
   }
+  if (upload && c->resident_on) UHDR_TRY(resident_write_back_all(c));  // host planes are read below: none may be a lazily kept image's
   size_t off[3] = {0, 0, 0}, total = 0;
   for (int pl = 0; pl < 3; pl++) {
     size_t b = plane_bytes(host, pl);
@@ -309,6 +386,7 @@ uhdr_error_info_t resident_keep(uhdr_hip_ctx* c, const uhdr_raw_image_t* dev, co
     if (b.p && d0 >= (const char*)b.p && d0 < (const char*)b.p + b.cap) slot ^= 1u;
   }
   uhdr_hip_ctx::Resident& r = c->resident[slot];
+  resident_retire(c, r, false);
   const DeviceBuf keep = r.buf;
   r = uhdr_hip_ctx::Resident();
   r.buf = keep;
@@ -590,6 +668,8 @@ void uhdr_hip_destroy(uhdr_hip_ctx_t* c) {
   for (auto& b : c->scratch) if (b.p) (void)hipFree(b.p);
   for (auto& b : c->jpg) if (b.p) (void)hipFree(b.p);
   for (auto& r : c->resident) if (r.buf.p) (void)hipFree(r.buf.p);
+  if (c->pending.buf.p) (void)hipFree(c->pending.buf.p);
+  if (c->pending.tmp.p) (void)hipFree(c->pending.tmp.p);
   if (c->minmax.p) (void)hipFree(c->minmax.p);
   if (c->d_coef_src) (void)hipFree(c->d_coef_src);
   if (c->d_huff) (void)hipFree(c->d_huff);
@@ -2683,6 +2763,7 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
     HIP_TRY(hipMemcpyAsync(c->d_huff, blob.data(), blob.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
   }
+  const DbgClock dbg;
   std::vector<HuffDecTable> tabs(4);
   std::vector<HuffFastTable> ftabs(4);
   bool fast_ok = true;
@@ -2727,6 +2808,7 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
   uint32_t* ends = starts + a.nseg;
   a.starts = starts;
   a.ends = ends;
+  dbg.mark("huffman_decode_dev: tables built");
   HIP_TRY(hipMemcpyAsync(base, tabs.data(), tab_bytes, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemsetAsync(a.status, 0, 16, c->stream));
   for (int i = 0; i < a.ncomp; i++) HIP_TRY(hipMemsetAsync(a.coef[i], 0, zero_bytes[i], c->stream));
@@ -2742,7 +2824,7 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
   const bool rst_sync = a.nseg > 1 && data_bytes / (size_t)a.nseg >= 320 && !getenv("UHDR_HIP_HUFF_RST_INTERVALS");
   if ((a.nseg == 1 || rst_sync) && data_bytes >= 4096 && data_bytes < ((size_t)1 << 29) && fast_ok && !getenv("UHDR_HIP_HUFF_SERIAL")) {
     // Subsequence size: a power of two >= 256 bits (the lanes' chunks are staged in LDS: 64 x sub_bits / 8 bytes per wave).
-    // Attempts, in order: the hypothesis scheme with seven overflow levels at 512 bits (4K q95 photo-like data: 390 us) -- denser
+    // Attempts, in order: the hypothesis scheme with seven (4:2:0; up to fifteen for fewer blocks per MCU) overflow levels at 512 bits (4K q95 photo-like data: 390 us) -- denser
     // streams start at 2048 / 4096 bits --, then at doubled sizes up to 4096 bits, then the rounds at 1024 bits.
     struct Attempt { uint32_t sub_bits; int levels; };  // levels 0: the rounds
     std::vector<Attempt> attempts;
@@ -2754,15 +2836,27 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
       if (vb_ok || el) {  // tuning / tests: exactly this configuration, then the rounds at the same size
         const uint32_t sbits = vb_ok ? (uint32_t)vb : 1024u;
         const int lv = el ? atoi(el) : (sbits <= 512 ? 7 : 4);
-        if (lv >= 1 && lv <= 7 && bpm * (lv + 1) <= kHuffHypSlots) attempts.push_back({sbits, lv});
+        if (lv >= 1 && lv <= 15 && bpm * (lv + 1) <= kHuffHypSlots) attempts.push_back({sbits, lv});
         attempts.push_back({sbits, 0});
       } else {
         // the window a path gets to fall in step (levels x subsequence) must cover the stream's synchronisation distance, which
         // grows with the bits per block (few EOBs in dense blocks): start where files of this density have settled, then widen
         const uint64_t bits_per_block = (uint64_t)data_bytes * 8u / (uint64_t)((uint64_t)a.total_mcus * (uint64_t)bpm);
-        const int lv = bpm * 8 <= kHuffHypSlots ? 7 : (bpm * 5 <= kHuffHypSlots ? 4 : 0);
+        // Overflow levels: as many as the slots allow, up to 15.  Every further level is one more FRESH path a straggler can fall in
+        // step with, and only stragglers pay for it (a path stops at its merge).  Flat image regions are where it matters: their
+        // bit pattern is periodic (4:4:4 gain maps: "DC 0, EOB" x 3 = 14 bits per MCU), a decoder started at the wrong phase stays
+        // wrong until the region ends, so a fresh path either merges at once or not at all -- seven trials lost the true path
+        // of a 4K three-channel map at 512 and at 1024 bits (249 and 13 unmerged paths of 110 K), fifteen do not.
+        const int lv_fit = kHuffHypSlots / bpm - 1;
+        const int lv = lv_fit >= 15 ? 15 : (lv_fit >= 11 ? 11 : (lv_fit >= 7 ? 7 : (lv_fit >= 4 ? 4 : 0)));
+        // ... and very sparse streams (under 64 bits per block: smooth content, long flat regions) start at 1024 for the same reason:
+        // the 4K map above (49 bits per block) still loses its true path at 512 x 15 (8 unmerged paths) and settles at 1024.
+        // A context also remembers the size a scan of the same shape and density settled at when the first attempt was lost.
+        uint32_t first = bits_per_block < 64 ? 1024u : (bits_per_block < 200 ? 512u : (bits_per_block < 400 ? 2048u : 4096u));
+        const uhdr_hip_ctx::HuffHint& hint = c->huff_hint[bpm & 15];
+        if (hint.sub_bits > first && bits_per_block * 4 >= hint.bits_per_block * 3 && bits_per_block * 4 <= hint.bits_per_block * 5) first = hint.sub_bits;
         if (lv > 0)
-          for (uint32_t sbits = bits_per_block < 200 ? 512u : (bits_per_block < 400 ? 2048u : 4096u); sbits <= 4096u; sbits <<= 1) attempts.push_back({sbits, lv});
+          for (uint32_t sbits = first; sbits <= 4096u; sbits <<= 1) attempts.push_back({sbits, lv});
         attempts.push_back({1024u, 0});
       }
     }
@@ -2835,6 +2929,7 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
       for (int t = 0; t < 4; t++) make_value_table(ftabs[(size_t)t], (t & 1) == 0, vtabs.data() + (size_t)t * kHuffValWords);
       HIP_TRY(hipMemcpyAsync(sb + o_vt, vtabs.data(), vtabs.size() * 4, hipMemcpyHostToDevice, c->stream));
       HIP_TRY(hipMemsetAsync(y.flags, 0, zero_bytes_sync, c->stream));  // flags, nblk, dcd and the restart map
+      dbg.mark("huffman_decode_dev: track / value tables built and enqueued");
       int final_buf = 0;
       uint32_t fl[18] = {};  // [9]: restart markers the unstuff pass dropped, [16] [17] / [0] [7]: their sequence sums as found / as due
       bool hyp_done = false, unstuffed = false, rounds_ran = false;
@@ -2868,9 +2963,16 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
             unstuffed = true;
             HIP_TRY(launch_huffman_decode_hyp(y, (int*)(sb + o_dcp), sb + o_ch, sb + o_ch + tiles_off, c->stream));
           }
+          dbg.mark("huffman_decode_dev: hypothesis attempt enqueued");
           HIP_TRY(hipMemcpyAsync(fl, y.flags, sizeof fl, hipMemcpyDeviceToHost, c->stream));
           HIP_TRY(hipStreamSynchronize(c->stream));
+          dbg.mark("huffman_decode_dev: hypothesis attempt finished");
           hyp_done = fl[2] == 0;
+          if (hyp_done && ti > 0) {  // where the next scan like this one starts
+            uhdr_hip_ctx::HuffHint& hint = c->huff_hint[bpm & 15];
+            hint.sub_bits = t.sub_bits;
+            hint.bits_per_block = (uint32_t)((uint64_t)data_bytes * 8u / ((uint64_t)a.total_mcus * (uint64_t)bpm));
+          }
           if (getenv("UHDR_HIP_HUFF_DEBUG")) {
             uint32_t hist[16] = {};
             (void)hipMemcpy(hist, y.flags, sizeof hist, hipMemcpyDeviceToHost);
@@ -3025,6 +3127,7 @@ static uhdr_error_info_t jpeg_encode_impl(uhdr_hip_ctx_t* c, const uhdr_hip_jpeg
       c->stats.resident_hits++;
       for (int i = 0; i < nc; i++) UHDR_TRY(fdct(i, (const uint8_t*)held->buf.p + held->off[i], held->dev_stride[i]));
     } else {
+      if (c->resident_on) UHDR_TRY(resident_write_back_all(c));  // the host planes are read below
       UHDR_TRY(ensure(c->jpg[4], total));
       for (int i = 0; i < nc; i++) {
         uint8_t* d = (uint8_t*)c->jpg[4].p + off[i];
@@ -3057,6 +3160,7 @@ static uhdr_error_info_t jpeg_encode_impl(uhdr_hip_ctx_t* c, const uhdr_hip_jpeg
       dsrc = (const uint8_t*)held->buf.p + held->off[0];
       dpitch = (size_t)held->dev_stride[0] * rgb_channels;
     } else {
+      if (c->resident_on) UHDR_TRY(resident_write_back_all(c));  // the host planes are read below
       const size_t pitch_px = ((size_t)sc.w + 15) & ~(size_t)15;
       UHDR_TRY(ensure(c->jpg[4], pitch_px * (size_t)rgb_channels * sc.h));
       HIP_TRY(hipMemcpy2DAsync(c->jpg[4].p, pitch_px * rgb_channels, planes[0], (size_t)strides[0] * rgb_channels, (size_t)sc.w * rgb_channels, sc.h,
@@ -3102,6 +3206,7 @@ uhdr_error_info_t uhdr_hip_jpeg_decode_scan(uhdr_hip_ctx_t* c, const uhdr_hip_jp
                                             const unsigned int vstride[3]) {
   if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
   if (!hdr || !scan_data || !planes || !hstride || !vstride) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument for jpeg_decode_scan");
+  const DbgClock dbg;
   if (out_channels != 0 && out_channels != 3 && out_channels != 4) return err_status(UHDR_CODEC_INVALID_PARAM, "out_channels is 0 (planes), 3 (RGB888) or 4 (RGBA8888), received %d", out_channels);
   uhdr_hip_jpeg_scan_t sc = hdr->scan;
   const int nc = sc.num_components;
@@ -3128,9 +3233,11 @@ uhdr_error_info_t uhdr_hip_jpeg_decode_scan(uhdr_hip_ctx_t* c, const uhdr_hip_jp
   }
   const size_t nbytes = e;
   if (nbytes == 0) return err_status(UHDR_CODEC_INVALID_PARAM, "no entropy-coded data");
+  dbg.mark("jpeg_decode_scan: end of the entropy-coded data found");
   HIP_TRY(hipSetDevice(c->device));
   UHDR_TRY(ensure(c->jpg[0], nbytes + 64));
   HIP_TRY(hipMemcpyAsync(c->jpg[0].p, scan_data, nbytes, hipMemcpyHostToDevice, c->stream));
+  dbg.mark("jpeg_decode_scan: compressed bytes on their way up");
   for (int i = 0; i < nc; i++) {
     UHDR_TRY(ensure(c->jpg[1 + i], (size_t)sc.blocks_w[i] * sc.blocks_h[i] * 64 * sizeof(int16_t)));
     sc.coef[i] = (const int16_t*)c->jpg[1 + i].p;
@@ -3139,13 +3246,21 @@ uhdr_error_info_t uhdr_hip_jpeg_decode_scan(uhdr_hip_ctx_t* c, const uhdr_hip_jp
   const uhdr_error_info_t hs = uhdr_hip_huffman_decode_dev(c, &sc, &hdr->tables, (const uint8_t*)c->jpg[0].p, nbytes);
   c->huff_serial_ok = true;
   if (hs.error_code != UHDR_CODEC_OK) return hs;
+  dbg.mark("jpeg_decode_scan: entropy decode returned");
   uhdr_hip_ctx::Resident* res = c->resident_on ? &c->resident[c->resident_next++ % 2] : nullptr;
   DeviceBuf* out_buf = res ? &res->buf : &c->jpg[4];
   if (res) {
+    resident_retire(c, *res, false);
     const DeviceBuf keep = res->buf;
     *res = uhdr_hip_ctx::Resident();
     res->buf = keep;
     resident_drop(c, planes[0]);  // an older copy of what this call overwrites on the host
+  }
+  // lazy downloads (uhdr_hip_resident_lazy): an image the handoff keeps is not written to the caller's planes
+  bool lazy = res && c->resident_lazy;
+  if (lazy && out_channels == 0) {
+    const int hs0 = nc == 3 ? sc.h_samp[0] : 1, vs0 = nc == 3 ? sc.v_samp[0] : 1;
+    lazy = (nc == 1 || (sc.h_samp[1] == 1 && sc.v_samp[1] == 1 && sc.h_samp[2] == 1 && sc.v_samp[2] == 1)) && hs0 <= 2 && vs0 <= 2 && !(hs0 == 1 && vs0 == 2);
   }
   if (out_channels == 0) {
     size_t pitch[3] = {0, 0, 0}, off[3] = {0, 0, 0}, total = 0;
@@ -3161,7 +3276,7 @@ uhdr_error_info_t uhdr_hip_jpeg_decode_scan(uhdr_hip_ctx_t* c, const uhdr_hip_jp
       UHDR_TRY(uhdr_hip_idct_dequant_dev(c, sc.coef[i], sc.blocks_w[i], sc.blocks_h[i], hdr->qtable[i], d, pitch[i]));
       const size_t cols = hstride[i] < (unsigned)sc.blocks_w[i] * 8 ? hstride[i] : (size_t)sc.blocks_w[i] * 8;
       const size_t rows = vstride[i] < (unsigned)sc.blocks_h[i] * 8 ? vstride[i] : (size_t)sc.blocks_h[i] * 8;
-      HIP_TRY(hipMemcpy2DAsync(planes[i], hstride[i], d, pitch[i], cols, rows, hipMemcpyDeviceToHost, c->stream));
+      if (!lazy) HIP_TRY(hipMemcpy2DAsync(planes[i], hstride[i], d, pitch[i], cols, rows, hipMemcpyDeviceToHost, c->stream));
       if (res) {
         res->host[i] = planes[i]; res->host_stride[i] = hstride[i]; res->off[i] = off[i]; res->dev_stride[i] = (unsigned int)pitch[i];
         res->prows[i] = (unsigned int)rows; res->pcols[i] = (unsigned int)cols;
@@ -3177,6 +3292,8 @@ uhdr_error_info_t uhdr_hip_jpeg_decode_scan(uhdr_hip_ctx_t* c, const uhdr_hip_jp
       res->h = vstride[0] < (unsigned)sc.blocks_h[0] * 8 ? vstride[0] : (unsigned)sc.blocks_h[0] * 8;
       bool plain = nc == 1 || (sc.h_samp[1] == 1 && sc.v_samp[1] == 1 && sc.h_samp[2] == 1 && sc.v_samp[2] == 1);
       res->valid = plain && res->fmt != UHDR_IMG_FMT_UNSPECIFIED;
+      if (lazy && !res->valid) return err_status(UHDR_CODEC_ERROR, "internal: lazy download of an image the handoff does not keep");
+      res->host_unwritten = lazy;
     }
   } else {
     uhdr_raw_image_t rgb;
@@ -3189,16 +3306,21 @@ uhdr_error_info_t uhdr_hip_jpeg_decode_scan(uhdr_hip_ctx_t* c, const uhdr_hip_jp
     rgb.planes[0] = out_buf->p;
     rgb.stride[0] = (unsigned int)pitch_px;
     UHDR_TRY(uhdr_hip_idct_dequant_rgb_dev(c, sc.coef[0], sc.coef[1], sc.coef[2], sc.blocks_w[0], sc.blocks_h[0], hdr->qtable[0], hdr->qtable[1], variant, &rgb));
-    HIP_TRY(hipMemcpy2DAsync(planes[0], (size_t)hstride[0] * out_channels, out_buf->p, pitch_px * out_channels, (size_t)sc.w * out_channels, sc.h,
-                             hipMemcpyDeviceToHost, c->stream));
+    if (!lazy)
+      HIP_TRY(hipMemcpy2DAsync(planes[0], (size_t)hstride[0] * out_channels, out_buf->p, pitch_px * out_channels, (size_t)sc.w * out_channels, sc.h,
+                               hipMemcpyDeviceToHost, c->stream));
     if (res) {
       res->fmt = rgb.fmt; res->w = sc.w; res->h = sc.h;
       res->host[0] = planes[0]; res->host_stride[0] = hstride[0]; res->off[0] = 0; res->dev_stride[0] = (unsigned int)pitch_px;
       res->prows[0] = sc.h; res->pcols[0] = sc.w;
       res->valid = true;
+      res->host_unwritten = lazy;
     }
   }
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (lazy) c->stats.lazy_downloads_skipped++;
+  dbg.mark("jpeg_decode_scan: IDCT (and download) enqueued");
+  HIP_TRY(hipStreamSynchronize(c->stream));  // (lazy: decode errors of the kernels above still surface in this call)
+  dbg.mark("jpeg_decode_scan: done");
   return ok_status();
 }
 
@@ -3210,12 +3332,73 @@ uhdr_error_info_t uhdr_hip_jpeg_decode_scan(uhdr_hip_ctx_t* c, const uhdr_hip_jp
 void uhdr_hip_resident_begin(uhdr_hip_ctx_t* c) {
   if (!c) return;
   c->resident_on = true;
-  for (auto& r : c->resident) r.valid = false;
+  c->resident_lazy = false;
+  c->pending.on = false;
+  // reopened inside a session (the facade, when a stage falls back to the reference's CPU code): that code reads the host planes
+  for (auto& r : c->resident) resident_retire(c, r, false);
 }
 void uhdr_hip_resident_end(uhdr_hip_ctx_t* c) {
   if (!c) return;
   c->resident_on = false;
-  for (auto& r : c->resident) r.valid = false;
+  c->resident_lazy = false;
+  for (auto& r : c->resident) {
+    if (r.valid && r.adopted) {  // the copy the caller left to the library outlives the session: the buffer changes hands
+      uhdr_hip_ctx::PendingCopy& p = c->pending;
+      std::swap(p.buf, r.buf);
+      const size_t bps = bytes_per_sample(r.fmt);
+      p.off = r.off[0]; p.pitch = (size_t)r.dev_stride[0] * bps; p.w = r.adopt_w; p.h = r.adopt_h; p.bps = (unsigned int)bps;
+      p.expand = r.adopt_expand;
+      p.dst = r.adopt_dst; p.dst_pitch = (size_t)r.adopt_stride * (r.adopt_expand ? 4 : bps);
+      p.on = true;
+    }
+    r.valid = false;
+    r.host_unwritten = false;
+    r.adopted = false;
+  }
+}
+void uhdr_hip_resident_lazy(uhdr_hip_ctx_t* c, int on) {
+  if (c) c->resident_lazy = c->resident_on && on != 0;
+}
+uhdr_error_info_t uhdr_hip_resident_flush(uhdr_hip_ctx_t* c) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  HIP_TRY(hipSetDevice(c->device));
+  return resident_write_back_all(c);
+}
+int uhdr_hip_resident_adopt(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* src, const uhdr_raw_image_t* dst) {
+  if (!c || !src || !dst || !c->resident_on || !dst->planes[0]) return 0;
+  const bool expand = src->fmt == UHDR_IMG_FMT_24bppRGB888 && dst->fmt == UHDR_IMG_FMT_32bppRGBA8888;
+  if ((src->fmt != dst->fmt && !expand) || src->w != dst->w || src->h != dst->h || dst->stride[0] < dst->w) return 0;
+  if (src->fmt != UHDR_IMG_FMT_8bppYCbCr400 && src->fmt != UHDR_IMG_FMT_24bppRGB888 && src->fmt != UHDR_IMG_FMT_32bppRGBA8888) return 0;
+  for (auto& r : c->resident) if (r.adopted) return 0;  // one at a time
+  for (auto& r : c->resident) {
+    if (!r.valid || !r.host_unwritten || r.fmt != src->fmt || r.host[0] != src->planes[0] || r.host_stride[0] != src->stride[0]) continue;
+    if (src->w > r.pcols[0] || src->h > r.prows[0]) continue;
+    r.adopted = true;
+    r.adopt_dst = dst->planes[0];
+    r.adopt_stride = dst->stride[0];
+    r.adopt_w = src->w;
+    r.adopt_h = src->h;
+    r.adopt_expand = expand;
+    return 1;
+  }
+  return 0;
+}
+uhdr_error_info_t uhdr_hip_resident_materialize(uhdr_hip_ctx_t* c) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  HIP_TRY(hipSetDevice(c->device));
+  UHDR_TRY(resident_write_back_all(c));  // inside the session: the same as _flush
+  uhdr_hip_ctx::PendingCopy& p = c->pending;
+  if (!p.on) return ok_status();
+  UHDR_TRY(adopted_copy_out(c, (const char*)p.buf.p + p.off, p.pitch, p.bps, p.expand, p.w, p.h, p.dst, p.dst_pitch));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  p.on = false;
+  c->stats.lazy_downloads_done++;
+  return ok_status();
+}
+void uhdr_hip_resident_forget(uhdr_hip_ctx_t* c) {
+  if (!c) return;
+  c->pending.on = false;
+  for (auto& r : c->resident) r.adopted = false;
 }
 
 // Host helper: a complete baseline JFIF file around entropy-coded data (marker order of jcmarker.c: SOI, APP0, DQT,

@@ -61,6 +61,10 @@ def load():
     lib.uhdr_get_encoded_stream.argtypes = [P]
     lib.uhdr_get_decoded_image.restype = C.POINTER(A.RawImage)
     lib.uhdr_get_decoded_image.argtypes = [P]
+    lib.uhdr_get_decoded_gainmap_image.restype = C.POINTER(A.RawImage)
+    lib.uhdr_get_decoded_gainmap_image.argtypes = [P]
+    lib.uhdr_reset_decoder.argtypes = [P]
+    lib.uhdr_reset_decoder.restype = None
     _lib = lib
     return lib
 
@@ -91,8 +95,9 @@ def _add_effects(lib, h, effects):
 last_call_seconds = 0.0  # wall time of the last uhdr_encode / uhdr_decode call itself (what bench.py's api_level reports)
 
 
-def encode(hdr, sdr=None, gpu=False, quality=95, preset=A.UHDR_USAGE_BEST_QUALITY, effects=None) -> bytes:
-    """uhdr_encode: API-1 (hdr + sdr raw intents) or API-0 (hdr only); host images (libultrahdr_amd.images.Image)."""
+def encode(hdr, sdr=None, gpu=False, quality=95, preset=A.UHDR_USAGE_BEST_QUALITY, effects=None, multi_channel=None, scale=None) -> bytes:
+    """uhdr_encode: API-1 (hdr + sdr raw intents) or API-0 (hdr only); host images (libultrahdr_amd.images.Image).
+    multi_channel / scale: uhdr_enc_set_using_multi_channel_gainmap / _gainmap_scale_factor (None: the API's defaults)."""
     global last_call_seconds
     import time
 
@@ -105,6 +110,10 @@ def encode(hdr, sdr=None, gpu=False, quality=95, preset=A.UHDR_USAGE_BEST_QUALIT
             _chk(lib.uhdr_enc_set_raw_image(h, C.byref(sdr.raw), UHDR_SDR_IMG))
         _chk(lib.uhdr_enc_set_quality(h, quality, UHDR_BASE_IMG))
         _chk(lib.uhdr_enc_set_preset(h, preset))
+        if multi_channel is not None:
+            _chk(lib.uhdr_enc_set_using_multi_channel_gainmap(h, int(multi_channel)))
+        if scale is not None:
+            _chk(lib.uhdr_enc_set_gainmap_scale_factor(h, int(scale)))
         if gpu:
             _chk(lib.uhdr_enable_gpu_acceleration(h, 1))
         t0 = time.perf_counter()
@@ -117,8 +126,16 @@ def encode(hdr, sdr=None, gpu=False, quality=95, preset=A.UHDR_USAGE_BEST_QUALIT
         lib.uhdr_release_encoder(h)
 
 
-def decode(jpeg: bytes, out_ct, out_fmt, gpu=False, effects=None) -> np.ndarray:
-    """uhdr_decode -> packed pixels as a (h, w, bytes-per-pixel) uint8 array."""
+def _packed(o):
+    bpp = {A.UHDR_IMG_FMT_64bppRGBAHalfFloat: 8, A.UHDR_IMG_FMT_8bppYCbCr400: 1, A.UHDR_IMG_FMT_24bppRGB888: 3}.get(o.fmt, 4)
+    a = np.ctypeslib.as_array(C.cast(o.planes[0], C.POINTER(C.c_uint8)), shape=(o.h, o.stride[0] * bpp))
+    return a[:, : o.w * bpp].reshape(o.h, o.w, bpp).copy()
+
+
+def decode(jpeg: bytes, out_ct, out_fmt, gpu=False, effects=None, want_gainmap=False, decodes=1):
+    """uhdr_decode -> packed pixels as a (h, w, bytes-per-pixel) uint8 array; with want_gainmap, (pixels, gain-map image
+    as uhdr_get_decoded_gainmap_image hands it out).  decodes > 1: uhdr_reset_decoder + the same decode again on the same
+    handle before the results are read (the facade's lazy gain-map download across a reset)."""
     global last_call_seconds
     import time
 
@@ -131,15 +148,28 @@ def decode(jpeg: bytes, out_ct, out_fmt, gpu=False, effects=None) -> np.ndarray:
         _chk(lib.uhdr_dec_set_image(h, C.byref(ci)))
         _chk(lib.uhdr_dec_set_out_color_transfer(h, out_ct))
         _chk(lib.uhdr_dec_set_out_img_format(h, out_fmt))
-        if gpu:
-            _chk(lib.uhdr_enable_gpu_acceleration(h, 1))
-        t0 = time.perf_counter()
-        st = lib.uhdr_decode(h)
-        last_call_seconds = time.perf_counter() - t0
-        _chk(st)
-        o = lib.uhdr_get_decoded_image(h).contents
-        bpp = 8 if o.fmt == A.UHDR_IMG_FMT_64bppRGBAHalfFloat else 4
-        a = np.ctypeslib.as_array(C.cast(o.planes[0], C.POINTER(C.c_uint8)), shape=(o.h, o.stride[0] * bpp))
-        return a[:, : o.w * bpp].reshape(o.h, o.w, bpp).copy()
+        for k in range(decodes):
+            if k:
+                lib.uhdr_reset_decoder(h)
+                _add_effects(lib, h, effects)
+                _chk(lib.uhdr_dec_set_image(h, C.byref(ci)))
+                _chk(lib.uhdr_dec_set_out_color_transfer(h, out_ct))
+                _chk(lib.uhdr_dec_set_out_img_format(h, out_fmt))
+            if gpu:
+                _chk(lib.uhdr_enable_gpu_acceleration(h, 1))
+            t0 = time.perf_counter()
+            st = lib.uhdr_decode(h)
+            last_call_seconds = time.perf_counter() - t0
+            _chk(st)
+        px = _packed(lib.uhdr_get_decoded_image(h).contents)
+        if not want_gainmap:
+            return px
+        g = lib.uhdr_get_decoded_gainmap_image(h)
+        if not g:
+            raise A.UhdrError(1, "uhdr_get_decoded_gainmap_image returned NULL")
+        gm = _packed(g.contents)
+        g2 = lib.uhdr_get_decoded_gainmap_image(h)  # asking twice hands out the same image
+        assert g2 and np.array_equal(gm, _packed(g2.contents))
+        return px, gm
     finally:
         lib.uhdr_release_decoder(h)

@@ -228,3 +228,39 @@ def test_sizes_with_partial_blocks_through_the_facade(w, h):
         pa, pb = F.read(os.path.join(d, "cpu.raw")), F.read(os.path.join(d, "gpu.raw"))
         assert pa.size == pb.size == w * h * 8
         assert np.array_equal(pa, pb), f"{int((pa != pb).sum())} differing bytes"
+
+
+@pytest.mark.parametrize("w,h", [(1280, 720), (1000, 562)])
+def test_gainmap_image_is_downloaded_only_when_asked_for(w, h):
+    """uhdr_decode leaves both decoded images on the device and defers copy_raw_image(&gainmap, gainmap_img) (jpegr.cpp:1490);
+    uhdr_get_decoded_gainmap_image (ultrahdr_api.cpp:2032-2043) downloads the image when -- and only when -- it is called.  What
+    it hands out, and the decoded frame, are the CPU reference's bytes: RGBA and single-channel maps, across a uhdr_reset_decoder,
+    for SDR output (no applyGainMap at all), and with an effect queued (apply_effects reads the image on the host: no deferral)."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ)
+    env["UHDR_HIP_SEAM_TRACE"] = "1"
+    env["PYTHONPATH"] = F.ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "facade_lazy_probe.py")
+    p = subprocess.run([sys.executable, probe, str(w), str(h)], cwd=F.ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    results = [l for l in p.stdout.splitlines() if l.startswith("===")]
+    assert len(results) == 10 and all("MATCH" in l for l in results), p.stdout
+    sections, cur = {}, None
+    for l in p.stderr.splitlines():
+        if l.startswith("--- "):
+            cur = l[4:]
+            sections[cur] = []
+        elif cur and l.startswith("uhdr_hip_seam:"):
+            sections[cur].append(l)
+    for name in ("rgb_map", "luma_map_scale4"):
+        asked, not_asked, reset, sdr_out, effects = (sections[f"{name} {k}"] for k in ("asked", "not_asked", "reset", "sdr_out", "effects"))
+        for sec in (asked, not_asked, reset):
+            assert len([l for l in sec if "jpeg_decode_scan -> device" in l]) == 2 * (2 if sec is reset else 1), sec
+            assert any("apply_gainmap -> device" in l for l in sec), sec
+        assert sum("copy deferred" in l for l in asked) == 1 and sum("gain-map image asked for" in l for l in asked) == 2, asked
+        assert sum("copy deferred" in l for l in not_asked) == 1 and not any("gain-map image asked for" in l for l in not_asked), not_asked
+        assert sum("copy deferred" in l for l in reset) == 2, reset
+        assert sum("copy deferred" in l for l in sdr_out) == 1 and not any("apply_gainmap" in l for l in sdr_out), sdr_out
+        assert not any("copy deferred" in l for l in effects), effects

@@ -406,6 +406,154 @@ def test_decoded_images_stay_on_the_device_for_the_apply_stage(uhdr):
     assert np.array_equal(apply(), want) and stats() == h0 + 5  # after _end nothing is kept
 
 
+def test_lazy_downloads_of_decoded_images(uhdr):
+    """uhdr_hip_resident_lazy: inside a session the decoded images are not written to the caller's planes; applyGainMap reads the
+    device copies; _flush writes the planes; _adopt + _materialize stand for copy_raw_image of the gain map (jpegr.cpp:1490), also
+    after _end; the library writes back by itself before a slot is reused or a host plane would be uploaded."""
+    from libultrahdr_amd.images import Image
+
+    w, h = 656, 352
+    rng = np.random.default_rng(777)
+    _, _, base_jpeg = _file(rng, w, h, S420, 0)
+    _, _, map_jpeg = _file(rng, w, h, S444, 0)
+    _, _, luma_jpeg = _file(rng, w, h, GRAY, 0)
+    lib, ctx = uhdr.lib, uhdr.ctx.handle
+
+    def raw(fmt, planes, strides):
+        r = A.RawImage()
+        r.fmt, r.cg, r.ct, r.range, r.w, r.h = fmt, A.UHDR_CG_DISPLAY_P3, A.UHDR_CT_SRGB, A.UHDR_CR_FULL_RANGE, w, h
+        for i, p in enumerate(planes):
+            r.planes[i], r.stride[i] = p.ctypes.data, strides[i]
+
+        class _Host:
+            device = None
+        o = _Host()
+        o.raw = r
+        return o
+
+    def stats():
+        st = A.Stats()
+        lib.uhdr_hip_get_stats(ctx, C.byref(st))
+        return st
+
+    def ok(st):
+        assert st.error_code == 0, st.detail
+
+    md = synth.default_metadata()
+
+    def apply(sdr_img, gm_img):
+        dest = Image(A.UHDR_IMG_FMT_64bppRGBAHalfFloat, w, h)
+        uhdr.applyGainMap(sdr_img, gm_img, md, A.UHDR_CT_LINEAR, A.UHDR_IMG_FMT_64bppRGBAHalfFloat, 4.0, dest)
+        return dest.buf.copy()
+
+    # eager reference
+    base_e = [np.zeros((h, w), np.uint8), np.zeros((h // 2, w // 2), np.uint8), np.zeros((h // 2, w // 2), np.uint8)]
+    gmap_e = [np.zeros((h, w, 4), np.uint8)]
+    luma_e = [np.zeros((h, w), np.uint8)]
+    uhdr.jpeg_decode(base_jpeg, outs=base_e)
+    uhdr.jpeg_decode(map_jpeg, 4, outs=gmap_e)
+    uhdr.jpeg_decode(luma_jpeg, outs=luma_e)
+    want = apply(raw(A.UHDR_IMG_FMT_12bppYCbCr420, base_e, [w, w // 2, w // 2]), raw(A.UHDR_IMG_FMT_32bppRGBA8888, gmap_e, [w]))
+
+    base = [np.full_like(p, 7) for p in base_e]
+    gmap = [np.full_like(gmap_e[0], 7)]
+    sdr_img = raw(A.UHDR_IMG_FMT_12bppYCbCr420, base, [w, w // 2, w // 2])
+    gm_img = raw(A.UHDR_IMG_FMT_32bppRGBA8888, gmap, [w])
+    dst = np.full((h, w + 8, 4), 9, np.uint8)  # a destination with its own stride
+    dst_img = raw(A.UHDR_IMG_FMT_32bppRGBA8888, [dst], [w + 8])
+    s0 = stats()
+    lib.uhdr_hip_resident_lazy(ctx, 1)  # outside a session: no effect
+    uhdr.jpeg_decode(base_jpeg, outs=base)
+    assert np.array_equal(base[0], base_e[0]) and stats().lazy_downloads_skipped == s0.lazy_downloads_skipped
+    for p in base:
+        p[:] = 7
+    lib.uhdr_hip_resident_begin(ctx)
+    try:
+        lib.uhdr_hip_resident_lazy(ctx, 1)
+        uhdr.jpeg_decode(base_jpeg, outs=base)
+        uhdr.jpeg_decode(map_jpeg, 4, outs=gmap)
+        lib.uhdr_hip_resident_lazy(ctx, 0)
+        assert stats().lazy_downloads_skipped == s0.lazy_downloads_skipped + 2
+        assert all((p == 7).all() for p in base) and (gmap[0] == 7).all(), "the caller's planes were left alone"
+        assert lib.uhdr_hip_resident_adopt(ctx, C.byref(sdr_img.raw), C.byref(dst_img.raw)) == 0  # three planes: not adoptable
+        assert lib.uhdr_hip_resident_adopt(ctx, C.byref(gm_img.raw), C.byref(dst_img.raw)) == 1
+        assert lib.uhdr_hip_resident_adopt(ctx, C.byref(gm_img.raw), C.byref(dst_img.raw)) == 0  # one at a time
+        got = apply(sdr_img, gm_img)
+        assert np.array_equal(got, want) and stats().resident_hits == s0.resident_hits + 2
+        assert (gmap[0] == 7).all() and (dst == 9).all()
+    finally:
+        lib.uhdr_hip_resident_end(ctx)
+    assert (gmap[0] == 7).all() and (dst == 9).all(), "_end discards without writing back"
+    ok(lib.uhdr_hip_resident_materialize(ctx))
+    assert np.array_equal(dst[:, :w], gmap_e[0]) and (dst[:, w:] == 9).all() and (gmap[0] == 7).all()
+    assert stats().lazy_downloads_done == s0.lazy_downloads_done + 1
+    dst[:] = 9
+    ok(lib.uhdr_hip_resident_materialize(ctx))  # nothing pending any more
+    assert (dst == 9).all()
+
+    # _flush inside the session: planes and the adopted copy, both; _forget after _end: nothing is written
+    lib.uhdr_hip_resident_begin(ctx)
+    try:
+        lib.uhdr_hip_resident_lazy(ctx, 1)
+        uhdr.jpeg_decode(base_jpeg, outs=base)
+        uhdr.jpeg_decode(map_jpeg, 4, outs=gmap)
+        assert lib.uhdr_hip_resident_adopt(ctx, C.byref(gm_img.raw), C.byref(dst_img.raw)) == 1
+        ok(lib.uhdr_hip_resident_flush(ctx))
+        for a, b in zip(base, base_e):
+            assert np.array_equal(a, b)
+        assert np.array_equal(gmap[0], gmap_e[0]) and np.array_equal(dst[:, :w], gmap_e[0]) and (dst[:, w:] == 9).all()
+        assert np.array_equal(apply(sdr_img, gm_img), want)  # still resident
+        # both images unwritten again; a third lazy decode takes the older slot (the base image's) and the library writes
+        # that image back first
+        for p in base + gmap:
+            p[:] = 7
+        dst[:] = 9
+        uhdr.jpeg_decode(base_jpeg, outs=base)
+        uhdr.jpeg_decode(map_jpeg, 4, outs=gmap)
+        assert all((p == 7).all() for p in base + gmap)
+        luma = [np.full((h, w), 7, np.uint8)]
+        uhdr.jpeg_decode(luma_jpeg, outs=luma)
+        for a, b in zip(base, base_e):
+            assert np.array_equal(a, b)
+        assert (gmap[0] == 7).all() and (luma[0] == 7).all()
+        # the base image is no longer kept: applyGainMap uploads its host planes -- and before the library reads ANY host plane it
+        # writes the unwritten ones
+        assert np.array_equal(apply(sdr_img, gm_img), want)
+        assert np.array_equal(gmap[0], gmap_e[0]) and np.array_equal(luma[0], luma_e[0])
+        # the session reopened (the facade's hand-back to the reference's CPU code): planes are written first
+        for p in gmap:
+            p[:] = 7
+        uhdr.jpeg_decode(map_jpeg, 4, outs=gmap)
+        assert (gmap[0] == 7).all()
+        lib.uhdr_hip_resident_begin(ctx)
+        assert np.array_equal(gmap[0], gmap_e[0])
+        # adopted, then forgotten before the session ends: nothing is copied afterwards
+        lib.uhdr_hip_resident_lazy(ctx, 1)
+        uhdr.jpeg_decode(map_jpeg, 4, outs=gmap)
+        dst[:] = 9
+        assert lib.uhdr_hip_resident_adopt(ctx, C.byref(gm_img.raw), C.byref(dst_img.raw)) == 1
+    finally:
+        lib.uhdr_hip_resident_end(ctx)
+    lib.uhdr_hip_resident_forget(ctx)
+    ok(lib.uhdr_hip_resident_materialize(ctx))
+    assert (dst == 9).all()
+
+    # copy_raw_image's one conversion on this path: an RGB888 image (what a build against IJG libjpeg decodes a three-channel map
+    # to) adopted by an RGBA8888 destination -- alpha 255 (gainmapmath.cpp:1566-1587)
+    rgb_e = uhdr.jpeg_decode(map_jpeg, 3)
+    rgb = [np.full((h, w, 3), 7, np.uint8)]
+    rgb_img = raw(A.UHDR_IMG_FMT_24bppRGB888, rgb, [w])
+    lib.uhdr_hip_resident_begin(ctx)
+    try:
+        lib.uhdr_hip_resident_lazy(ctx, 1)
+        uhdr.jpeg_decode(map_jpeg, 3, outs=rgb)
+        assert lib.uhdr_hip_resident_adopt(ctx, C.byref(rgb_img.raw), C.byref(dst_img.raw)) == 1
+    finally:
+        lib.uhdr_hip_resident_end(ctx)
+    ok(lib.uhdr_hip_resident_materialize(ctx))
+    assert (rgb[0] == 7).all() and np.array_equal(dst[:, :w, :3], rgb_e) and (dst[:, :w, 3] == 255).all() and (dst[:, w:] == 9).all()
+
+
 def test_progressive_files_are_not_for_this_path(uhdr):
     PILImage = pytest.importorskip("PIL.Image")
     import io

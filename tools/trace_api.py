@@ -23,3 +23,6 @@ for i in range(4):
     print(f"--- uhdr_decode #{i}", file=sys.stderr, flush=True)
     FA.decode(jpg, A.UHDR_CT_LINEAR, A.UHDR_IMG_FMT_64bppRGBAHalfFloat, gpu=True)
     print(f"--- uhdr_decode took {FA.last_call_seconds * 1e3:.2f} ms", file=sys.stderr, flush=True)
+print("--- uhdr_decode + uhdr_get_decoded_gainmap_image", file=sys.stderr, flush=True)
+FA.decode(jpg, A.UHDR_CT_LINEAR, A.UHDR_IMG_FMT_64bppRGBAHalfFloat, gpu=True, want_gainmap=True)
+print(f"--- uhdr_decode took {FA.last_call_seconds * 1e3:.2f} ms (the gain-map image download comes after it)", file=sys.stderr, flush=True)
