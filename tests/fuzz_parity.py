@@ -340,17 +340,33 @@ def fuzz_huffman_streams():
     ri = 0 if rng.random() < 0.3 else int(rng.integers(1, max(2, mcus // 2)))
     density = float(rng.choice([0.03, 0.08, 0.15]))
     amp = int(rng.choice([3, 40, 300]))
+    # noise: independent blocks; flat: constant blocks under a noisy band (a periodic bit pattern); smooth: a slowly varying DC
+    # with the two lowest AC terms now and then -- what a gain map looks like (few, short symbols per block: the content the
+    # self-synchronising decoder needs its longest windows for)
+    style = str(rng.choice(["noise", "noise", "flat", "smooth"]))
+    if style != "noise":
+        w, h = w * 2, h * 2
     coefs = []
     for hs, vs in sampling:
         cw, chh = -(-w * hs // hmax), -(-h * vs // vmax)
         bw, bh = -(-cw // 8), -(-chh // 8)
         a = (rng.integers(-amp, amp + 1, (bh, bw, 64)) * (rng.random((bh, bw, 64)) < density)).astype(np.int16)
         a[..., 0] = rng.integers(-1020, 1021, (bh, bw))
+        if style == "flat":
+            top = int(rng.integers(1, 4))
+            a[top:] = 0
+            a[top:, :, 0] = int(rng.integers(-300, 300))
+        elif style == "smooth":
+            a[:] = 0
+            a[..., 0] = np.clip(np.cumsum(rng.integers(-2, 3, (bh, bw)), axis=1) + int(rng.integers(-200, 200)), -1020, 1020)
+            for k in (1, 8):
+                a[..., k] = rng.integers(-2, 3, (bh, bw)) * (rng.random((bh, bw)) < 0.3)
         coefs.append(np.ascontiguousarray(a))
     scan = L.huffman_encode_port(coefs, w, h, sampling, ri)
     data = torch.from_numpy(np.frombuffer(scan, dtype=np.uint8).copy()).to("cuda:0")
     back = u.huffman_decode(data, [c.shape[:2] for c in coefs], w, h, sampling, ri)
-    note("huffman-decode-streams", all(np.array_equal(b.cpu().numpy(), c) for b, c in zip(back, coefs)), f"{w}x{h} {sampling} ri{ri} density{density} amp{amp} {len(scan)} B")
+    note("huffman-decode-streams", all(np.array_equal(b.cpu().numpy(), c) for b, c in zip(back, coefs)),
+         f"{w}x{h} {sampling} ri{ri} {style} density{density} amp{amp} {len(scan)} B")
 
 
 JOBS = None

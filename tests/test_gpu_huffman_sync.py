@@ -49,6 +49,62 @@ def test_sync_decoder_inverts_the_encoder(uhdr, kind):
             assert np.array_equal(got[c].cpu().numpy(), coefs[c]), (kind, w, h, c)
 
 
+def _smooth_coefs(rng, w, h, sampling, style):
+    """flat: constant blocks under a noisy band (a periodic bit pattern); smooth: a slowly varying DC with the two lowest AC
+    terms now and then -- the statistics of a gain map, the content the decoder needs its longest windows for."""
+    hmax, vmax = max(s[0] for s in sampling), max(s[1] for s in sampling)
+    out = []
+    for hs, vs in sampling:
+        cw, ch = -(-w * hs // hmax), -(-h * vs // vmax)
+        bw, bh = -(-cw // 8), -(-ch // 8)
+        a = np.zeros((bh, bw, 64), np.int16)
+        if style == "flat":
+            a[:2] = (rng.integers(-40, 41, (2, bw, 64)) * (rng.random((2, bw, 64)) < 0.1)).astype(np.int16)
+            a[:2, :, 0] = rng.integers(-500, 501, (2, bw))
+            a[2:, :, 0] = 77
+        else:
+            a[..., 0] = np.clip(np.cumsum(rng.integers(-2, 3, (bh, bw)), axis=1) + 100, -1020, 1020)
+            for k in (1, 8):
+                a[..., k] = rng.integers(-2, 3, (bh, bw)) * (rng.random((bh, bw)) < 0.3)
+        out.append(np.ascontiguousarray(a))
+    return out
+
+
+@pytest.mark.parametrize("style", ["flat", "smooth"])
+@pytest.mark.parametrize("sampling", [[(1, 1)] * 3, [(2, 2), (1, 1), (1, 1)], [(2, 1), (1, 1), (1, 1)], [(1, 1)]])
+def test_flat_and_smooth_content_takes_the_parallel_decoder(uhdr, style, sampling):
+    """Sparse streams (a few short symbols per block) are where a decoder started at the wrong bit takes longest to fall in step:
+    a 4K three-channel gain map lost its true path with seven overflow levels at 512 and 1024 bits.  Up to fifteen levels where the
+    slots allow (fewer than six blocks per MCU), and 1024-bit subsequences from the start below 64 bits per block: such scans are
+    decoded in one attempt -- and whatever the attempt ladder does, the coefficients are the ones that were coded."""
+    rng = np.random.default_rng(4100 + len(sampling) + sampling[0][0] * 7 + sampling[0][1])
+    w, h = 2048, 1024
+    coefs = _smooth_coefs(rng, w, h, sampling, style)
+    scan = L.huffman_encode_port(coefs, w, h, sampling, 0)
+    assert len(scan) >= 4096
+
+    def stats():
+        st = A.Stats()
+        uhdr.lib.uhdr_hip_get_stats(uhdr.ctx.handle, C.byref(st))
+        return st.entropy_decode_parallel, st.entropy_decode_declined, st.entropy_decode_single_lane
+
+    s0 = stats()
+    got = uhdr.huffman_decode(_dev(scan), [c.shape[:2] for c in coefs], w, h, sampling, 0)
+    s1 = stats()
+    assert (s1[0] - s0[0], s1[1] - s0[1], s1[2] - s0[2]) == (1, 0, 0)
+    for c in range(len(coefs)):
+        assert np.array_equal(got[c].cpu().numpy(), coefs[c]), (style, sampling, c)
+    # the overflow depth is a tuning knob, not part of the result: 1, 7 and the default give the same coefficients
+    for levels in ("1", "7"):
+        os.environ["UHDR_HIP_HUFF_LEVELS"] = levels
+        try:
+            again = uhdr.huffman_decode(_dev(scan), [c.shape[:2] for c in coefs], w, h, sampling, 0)
+        finally:
+            del os.environ["UHDR_HIP_HUFF_LEVELS"]
+        for c in range(len(coefs)):
+            assert np.array_equal(again[c].cpu().numpy(), coefs[c]), (style, sampling, levels, c)
+
+
 @pytest.mark.parametrize("sub_bits", ["256", "512", "2048", "4096"])  # the default is 1024
 def test_subsequence_size_does_not_change_the_result(uhdr, sub_bits):
     rng = np.random.default_rng(223)
