@@ -890,6 +890,14 @@ def api_level_section():
     # default since round 3: the whole compressImage on the device, marker-less Huffman coding included -> the reference's bytes
     jpg, t_enc = med(lambda: FA.encode(hdr, sdr, gpu=True), 5)
     _, t_dec = med(lambda: FA.decode(jpg, A.UHDR_CT_LINEAR, f16, gpu=True), 5)
+    # round 4: the decoded images stay on the device and the gain-map image is downloaded when uhdr_get_decoded_gainmap_image
+    # asks for it.  The cost of asking, and the round-3 behaviour (UHDR_HIP_SEAM_EAGER_DOWNLOADS=1) for comparison
+    t_gm = []
+    for _ in range(3):
+        FA.decode(jpg, A.UHDR_CT_LINEAR, f16, gpu=True, want_gainmap=True)
+        t_gm.append(FA.last_gainmap_seconds)
+    t_gm = sorted(t_gm)[1]
+    _, t_dec_eager = with_env("UHDR_HIP_SEAM_EAGER_DOWNLOADS", "1", lambda: med(lambda: FA.decode(jpg, A.UHDR_CT_LINEAR, f16, gpu=True), 5))
     # the round-2 default, kept as an option: device FDCT, libjpeg's Huffman pass on one CPU core (same bytes)
     jpg_cpu, t_enc_cpu = with_env("UHDR_HIP_SEAM_CPU_ENTROPY", "1", lambda: med(lambda: FA.encode(hdr, sdr, gpu=True), 2))
     # opt-in: restart intervals, one per wavefront
@@ -903,7 +911,11 @@ def api_level_section():
     return {"uhdr_encode_api1_4k_hip": row(t_enc, jpeg_bytes=len(jpg), same_bytes_as_the_libjpeg_entropy_route=bool(jpg == jpg_cpu),
                                            entropy_coding="device, no restart markers (the default): FDCT + quantize + Huffman coding in three passes, "
                                                           "the file is the reference's byte for byte"),
-            "uhdr_decode_4k_f16_hip": row(t_dec, entropy_decoding="device (self-synchronising decoder: the file has no restart markers)"),
+            "uhdr_decode_4k_f16_hip": row(t_dec, entropy_decoding="device (self-synchronising decoder: the file has no restart markers)",
+                                          gainmap_image="stays on the device; uhdr_get_decoded_gainmap_image downloads it when called",
+                                          get_decoded_gainmap_image_ms=round(t_gm * 1e3, 2)),
+            "uhdr_decode_4k_f16_hip_eager_downloads": row(t_dec_eager, note="UHDR_HIP_SEAM_EAGER_DOWNLOADS=1: both decoded images written to the JpegDecoderHelper "
+                                                          "buffers and the gain-map image copied inside uhdr_decode (the round-3 behaviour)"),
             "uhdr_encode_api1_4k_hip_libjpeg_entropy": row(t_enc_cpu, jpeg_bytes=len(jpg_cpu), entropy_coding="UHDR_HIP_SEAM_CPU_ENTROPY=1: device FDCT, libjpeg's Huffman pass on one CPU core (the round-2 default)"),
             "uhdr_encode_api1_4k_hip_restart_intervals": row(t_enc_ri, jpeg_bytes=len(jpg_ri), entropy_coding="UHDR_HIP_SEAM_RESTART_INTERVAL=max: device, one restart interval per wavefront: DRI + RSTn markers added, decoded pixels identical"),
             "uhdr_decode_4k_f16_hip_of_that_file": row(t_dec_ri, entropy_decoding="device (restart-interval file)"),

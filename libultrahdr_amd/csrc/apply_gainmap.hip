@@ -579,6 +579,8 @@ __device__ __forceinline__ void apply_quad_body(const ApplyParams& p) {
   (void)ru; (void)rv;
   const uint32_t sy = p.sdr.stride[0], su = p.sdr.stride[1], sv = p.sdr.stride[2];
   const uint32_t sm = p.gm.stride[0];
+  const bool map_even = (sm & 1u) == 0;  // RGB888 map: every row starts at an even byte offset
+  (void)map_even;
   constexpr uint32_t OPX = (OUT == 0) ? 8 : 4;  // output bytes per pixel
   const uint32_t sd = p.dst.stride[0] * OPX;    // destination row pitch in bytes
   const float k255 = 1 / 255.0f;
@@ -681,9 +683,19 @@ __device__ __forceinline__ void apply_quad_body(const ApplyParams& p) {
           // faster for 7 % fewer bytes (round 3: 0.646 against 0.719).  The LAST map row keeps the exact loads: two bytes
           // beyond it may be beyond the allocation (a 3840 x 2160 x 3 byte plane ends on a page boundary).
           if ((yg + k) < gmh1) {  // wave-uniform
-            const uint2 a = ld_u64(rm, xmap, mrow);
-            r.m[2 * k] = a.x;
-            r.m[2 * k + 1] = a.y;
+            if (map_even) {
+              // ... and that load naturally aligned (4 bytes) when the row pitch is even: the dword pair that holds the six bytes,
+              // shifted down by 0 or 16 bits
+              const uint32_t t = xmap + (mrow & 2u);
+              const uint2 a = ld_u64(rm, t & ~3u, mrow & ~3u);
+              const uint32_t sh = (t & 2u) * 8u;
+              r.m[2 * k] = __builtin_amdgcn_alignbit(a.y, a.x, sh);
+              r.m[2 * k + 1] = a.y >> sh;
+            } else {
+              const uint2 a = ld_u64(rm, xmap, mrow);
+              r.m[2 * k] = a.x;
+              r.m[2 * k + 1] = a.y;
+            }
           } else {
             r.m[2 * k] = ld_u16(rm, xmap, mrow) | (ld_u16(rm, xmap + 2, mrow) << 16);
             r.m[2 * k + 1] = ld_u16(rm, xmap + 4, mrow);

@@ -93,6 +93,7 @@ def _add_effects(lib, h, effects):
 
 
 last_call_seconds = 0.0  # wall time of the last uhdr_encode / uhdr_decode call itself (what bench.py's api_level reports)
+last_gainmap_seconds = 0.0  # wall time of the first uhdr_get_decoded_gainmap_image call after it (decode(..., want_gainmap=True))
 
 
 def encode(hdr, sdr=None, gpu=False, quality=95, preset=A.UHDR_USAGE_BEST_QUALITY, effects=None, multi_channel=None, scale=None) -> bytes:
@@ -136,7 +137,7 @@ def decode(jpeg: bytes, out_ct, out_fmt, gpu=False, effects=None, want_gainmap=F
     """uhdr_decode -> packed pixels as a (h, w, bytes-per-pixel) uint8 array; with want_gainmap, (pixels, gain-map image
     as uhdr_get_decoded_gainmap_image hands it out).  decodes > 1: uhdr_reset_decoder + the same decode again on the same
     handle before the results are read (the facade's lazy gain-map download across a reset)."""
-    global last_call_seconds
+    global last_call_seconds, last_gainmap_seconds
     import time
 
     lib = load()
@@ -164,7 +165,9 @@ def decode(jpeg: bytes, out_ct, out_fmt, gpu=False, effects=None, want_gainmap=F
         px = _packed(lib.uhdr_get_decoded_image(h).contents)
         if not want_gainmap:
             return px
+        t0 = time.perf_counter()
         g = lib.uhdr_get_decoded_gainmap_image(h)
+        last_gainmap_seconds = time.perf_counter() - t0
         if not g:
             raise A.UhdrError(1, "uhdr_get_decoded_gainmap_image returned NULL")
         gm = _packed(g.contents)
