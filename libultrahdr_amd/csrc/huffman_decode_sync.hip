@@ -723,96 +723,144 @@ __global__ __launch_bounds__(1024) void hyp_pass1_kernel(const HuffSyncArgs a) {
   }
 }
 
-// chain, step 1 (one workgroup per tile of kChainTile links): the tile's maps are staged in LDS with coalesced loads, every
-// thread composes its kChainPer consecutive links, a workgroup-wide scan over function composition turns these into the
-// map "slot at the tile's entry -> slot at the thread's entry"; that and the tile's total map go to global memory.
-constexpr int kChainPer = 4, kChainThreads = 256, kChainTile = kChainPer * kChainThreads;
-__global__ __launch_bounds__(kChainThreads) void hyp_chain_tiles_kernel(const HuffSyncArgs a, uint8_t* __restrict__ prefix /* [threads total][slots] */,
-                                                                        uint8_t* __restrict__ tile_map /* [tiles][slots] */) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_links[kChainTile * kHuffHypSlots];  // 48 KB
-  __shared__ __attribute__((aligned(16))) uint8_t s_map[kChainThreads][kHuffHypSlots];   // 12 KB
+// chain (round 4 form).  256 links per tile, function composition by CHASING instead of a scan over whole maps:
+//   tiles   the tile's 256 link maps (48 bytes each) are staged in LDS; thread (group g, slot s) follows slot s through the 16
+//           links of group g -- 16 dependent byte reads -- which gives the 16 group maps; 48 threads follow their slot through the
+//           16 group maps (the tile's total map, and the slot every group is entered in); then (g, s) walks its 16 links once
+//           more from there and writes, link by link, "slot at the tile's entry -> slot in front of this link" (the prefix maps);
+//   entry   one workgroup does the same over the tile maps, 256 tiles per pass, but only for the true path (slot 0 of
+//           subsequence 0): the slot the true path enters every tile in;
+//   walk    tile entry -> the thread's entry (one byte of its prefix map) -> its link: state[0][i] = true end state of
+//           subsequence i, nblk[i + 1] = blocks completed inside subsequence i + 1.
+// 3 x 16 dependent LDS reads per workgroup where the scan form (round 2: eight steps over 256 whole maps, 12 word reads + 48
+// dependent byte lookups + 12 writes per thread and step) took 18 us per workgroup, and 39 us with its 32-way bank conflicts (four
+// consecutive 48-byte rows per thread: banks (48 t + ...) mod 32).  LDS rows have a pitch of 13 words, so the rows of the
+// groups a wave spans start in different banks; lanes of one group read one row (broadcast within a word).
+constexpr int kChainThreads = 256, kChainTile = kChainThreads;     // the walk: one link per thread
+constexpr int kChainGroup = 16, kChainGroups = kChainTile / kChainGroup;
+constexpr int kChainWg = kChainGroups * kHuffHypSlots;            // 768 threads: (group, slot)
+constexpr int kMapPitch = kHuffHypSlots + 4;
+static_assert(kHuffHypSlots % 16 == 0 && ((kMapPitch / 4) & 1) == 1, "map rows: whole 16-byte words in memory, an odd word pitch in LDS");
+static_assert(kChainTile * kHuffHypSlots / 16 == kChainWg, "one 16-byte piece of the tile per thread");
+
+// rows [first, first + 256) of a [rows][48] byte array -> s_rows (identity maps beyond n)
+__device__ __forceinline__ void chain_stage_rows(uint8_t (*s_rows)[kMapPitch], int tid, const uint8_t* __restrict__ rows, int first, int n) {
+  const int row = tid / 3, part = tid - row * 3;
+  uint4 v;
+  if (first + row < n) {
+    v = *(const uint4*)(rows + (size_t)(first + row) * kHuffHypSlots + part * 16);
+  } else {
+    const uint32_t b0 = (uint32_t)(16 * part) * 0x01010101u + 0x03020100u;
+    v = make_uint4(b0, b0 + 0x04040404u, b0 + 0x08080808u, b0 + 0x0c0c0c0cu);
+  }
+  uint32_t* d = (uint32_t*)(s_rows[row] + part * 16);
+  d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+}
+__device__ __forceinline__ uint32_t chain_step(const uint8_t* row, uint32_t cur) { return cur == 0xffu ? 0xffu : (uint32_t)row[cur]; }
+
+__global__ __launch_bounds__(kChainWg) void hyp_chain_tiles_kernel(const HuffSyncArgs a, uint8_t* __restrict__ prefix /* [links][slots] */,
+                                                                   uint8_t* __restrict__ tile_map /* [tiles][slots] */) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_links[kChainTile][kMapPitch];  // 13 KB
+  __shared__ __attribute__((aligned(16))) uint8_t s_gmap[kChainGroups][kMapPitch];
+  __shared__ __attribute__((aligned(16))) uint8_t s_gpre[kChainGroups][kMapPitch];
   const int tid = (int)threadIdx.x;
   const uint32_t nclean = a.nbytes - *a.nstuffed, nbits = nclean * 8u;
   const int nsub = (int)((nbits + a.sub_bits - 1) / a.sub_bits);
   const int nlinks = nsub - 1;
   const int base = (int)blockIdx.x * kChainTile;
   if (base >= nlinks) return;
-  const int nhere = min(kChainTile, nlinks - base);
-  {  // coalesced copy of the tile's rows (rows are kHuffHypSlots = 48 bytes: whole 16-byte words)
-    const uint4* src = (const uint4*)(a.hyp_map + (size_t)base * kHuffHypSlots);
-    uint4* dst = (uint4*)s_links;
-    const int nvec = nhere * kHuffHypSlots / 16;
-    for (int v = tid; v < nvec; v += kChainThreads) dst[v] = src[v];
-  }
+  chain_stage_rows(s_links, tid, a.hyp_map, base, nlinks);
   __syncthreads();
-  const int SL = (a.hyp_levels + 1) * a.hyp_h;
-  const int lo = min(tid * kChainPer, nhere), hi = min(lo + kChainPer, nhere);
-  for (int s = 0; s < SL; s++) {
+  const int grp = tid / kHuffHypSlots, s = tid - grp * kHuffHypSlots;
+  {
     uint32_t cur = (uint32_t)s;
-    for (int i = lo; i < hi; i++) cur = cur == 0xffu ? 0xffu : (uint32_t)s_links[i * kHuffHypSlots + (int)cur];
-    s_map[tid][s] = (uint8_t)cur;
+#pragma unroll
+    for (int k = 0; k < kChainGroup; k++) cur = chain_step(s_links[grp * kChainGroup + k], cur);
+    s_gmap[grp][s] = (uint8_t)cur;
   }
   __syncthreads();
-  static_assert(kHuffHypSlots % 4 == 0, "map rows are moved as 32-bit words");
-  constexpr int kWordsPerMap = kHuffHypSlots / 4;
-  for (int d = 1; d < kChainThreads; d <<= 1) {  // inclusive scan: P[t] = F[t] o P[t - d]
-    uint32_t q[kWordsPerMap];
-    const bool on = tid >= d;
-    if (on) {
-      const uint32_t* part = (const uint32_t*)s_map[tid - d];  // the partner's map, four slots per read
+  if (tid < kHuffHypSlots) {
+    uint32_t c = (uint32_t)tid;
 #pragma unroll
-      for (int w = 0; w < kWordsPerMap; w++) {
-        const uint32_t pw = part[w];
-        uint32_t r = 0;
+    for (int g = 0; g < kChainGroups; g++) {
+      s_gpre[g][tid] = (uint8_t)c;
+      c = chain_step(s_gmap[g], c);
+    }
+    tile_map[(size_t)blockIdx.x * kHuffHypSlots + tid] = (uint8_t)c;
+  }
+  __syncthreads();
+  uint32_t cur = s_gpre[grp][s];
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-          const uint32_t v = (pw >> (8 * b)) & 255u;
-          const uint32_t x = v == 0xffu ? 0xffu : (uint32_t)s_map[tid][v];
-          r |= x << (8 * b);
-        }
-        q[w] = r;
+  for (int k = 0; k < kChainGroup; k++) {
+    const int link = grp * kChainGroup + k, i = base + link;
+    if (i < nlinks) prefix[(size_t)i * kHuffHypSlots + s] = (uint8_t)cur;
+    cur = chain_step(s_links[link], cur);
+  }
+}
+// one workgroup: tile_entry[t] = the slot the true path is in where tile t begins (0xff: lost before that)
+__global__ __launch_bounds__(kChainWg) void hyp_chain_entry_kernel(const HuffSyncArgs a, const uint8_t* __restrict__ tile_map, uint8_t* __restrict__ tile_entry) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_tiles[kChainTile][kMapPitch];
+  __shared__ __attribute__((aligned(16))) uint8_t s_gmap[kChainGroups][kMapPitch];
+  __shared__ uint32_t s_gentry[kChainGroups + 1];
+  const int tid = (int)threadIdx.x;
+  const uint32_t nclean = a.nbytes - *a.nstuffed, nbits = nclean * 8u;
+  const int nlinks = (int)((nbits + a.sub_bits - 1) / a.sub_bits) - 1;
+  const int ntiles = (nlinks + kChainTile - 1) / kChainTile;
+  const int grp = tid / kHuffHypSlots, s = tid - grp * kHuffHypSlots;
+  uint32_t carry = 0;  // the true path is slot 0 of subsequence 0
+  for (int c0 = 0; c0 < ntiles; c0 += kChainTile) {
+    chain_stage_rows(s_tiles, tid, tile_map, c0, ntiles);
+    __syncthreads();
+    {
+      uint32_t cur = (uint32_t)s;
+#pragma unroll
+      for (int k = 0; k < kChainGroup; k++) cur = chain_step(s_tiles[grp * kChainGroup + k], cur);
+      s_gmap[grp][s] = (uint8_t)cur;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t c = carry;
+      for (int g = 0; g < kChainGroups; g++) {
+        s_gentry[g] = c;
+        c = chain_step(s_gmap[g], c);
+      }
+      s_gentry[kChainGroups] = c;
+    }
+    __syncthreads();
+    if (tid < kChainGroups) {
+      uint32_t cur = s_gentry[tid];
+      for (int k = 0; k < kChainGroup; k++) {
+        const int tl = c0 + tid * kChainGroup + k;
+        if (tl < ntiles) tile_entry[tl] = (uint8_t)cur;
+        cur = chain_step(s_tiles[tid * kChainGroup + k], cur);
       }
     }
-    __syncthreads();
-    if (on) {
-      uint32_t* mine = (uint32_t*)s_map[tid];
-#pragma unroll
-      for (int w = 0; w < kWordsPerMap; w++) mine[w] = q[w];
-    }
-    __syncthreads();
+    carry = s_gentry[kChainGroups];
+    __syncthreads();  // the rows are rewritten by the next pass
   }
-  // prefix for thread t = inclusive map of thread t - 1 (identity for t = 0)
-  uint8_t* out = prefix + ((size_t)blockIdx.x * kChainThreads + tid) * kHuffHypSlots;
-  for (int s = 0; s < SL; s++) out[s] = tid == 0 ? (uint8_t)s : s_map[tid - 1][s];
-  if (tid == kChainThreads - 1)
-    for (int s = 0; s < SL; s++) tile_map[(size_t)blockIdx.x * kHuffHypSlots + s] = s_map[tid][s];
 }
-// chain, step 2: the tile's entry slot from the tile maps before it (a short sequential walk, the same in every thread),
-// the thread's entry slot from its prefix map, then kChainPer links: state[0][i] = true end state of subsequence i,
-// nblk[i + 1] = blocks completed inside subsequence i + 1
 __global__ __launch_bounds__(kChainThreads) void hyp_chain_walk_kernel(const HuffSyncArgs a, const uint8_t* __restrict__ prefix,
-                                                                       const uint8_t* __restrict__ tile_map) {
+                                                                       const uint8_t* __restrict__ tile_entry) {
   const int tid = (int)threadIdx.x;
   const uint32_t nclean = a.nbytes - *a.nstuffed, nbits = nclean * 8u;
   const int nsub = (int)((nbits + a.sub_bits - 1) / a.sub_bits);
   const int nlinks = nsub - 1;
-  const int base = (int)blockIdx.x * kChainTile;
-  if (base >= nlinks) return;
-  const int nhere = min(kChainTile, nlinks - base);
-  uint32_t g = 0;  // the true path is slot 0 of subsequence 0
-  for (int t = 0; t < (int)blockIdx.x && g != 0xffu; t++) g = tile_map[(size_t)t * kHuffHypSlots + g];
-  if (g != 0xffu) g = prefix[((size_t)blockIdx.x * kChainThreads + tid) * kHuffHypSlots + g];
-  const int lo = min(tid * kChainPer, nhere), hi = min(lo + kChainPer, nhere);
+  const int i = (int)blockIdx.x * kChainTile + tid;
   bool lost = false;
-  for (int i = base + lo; i < base + hi; i++) {
-    if (g == 0xffu) { lost = true; break; }
-    const size_t at = (size_t)i * kHuffHypSlots + g;
-    a.state[0][i] = a.hyp_state[at];
-    a.nblk[i + 1] = a.hyp_cnt[at];
-    g = a.hyp_map[at];
+  if (i < nlinks) {
+    uint32_t g = tile_entry[blockIdx.x];
+    if (g != 0xffu) g = prefix[(size_t)i * kHuffHypSlots + g];
+    if (g == 0xffu) {
+      lost = true;
+    } else {
+      const size_t at = (size_t)i * kHuffHypSlots + g;
+      a.state[0][i] = a.hyp_state[at];
+      a.nblk[i + 1] = a.hyp_cnt[at];
+      if (i == nlinks - 1 && a.hyp_map[at] == 0xffu) lost = true;  // the last link must resolve too
+    }
   }
-  if (lo < hi && base + hi == nlinks && !lost && g == 0xffu) lost = true;  // the last link must resolve too
-  if (lost) atomicOr(a.flags + 2, 1u);
+  const uint64_t m = __builtin_amdgcn_ballot_w64(lost);
+  if (m != 0 && (uint32_t)(tid & 63) == (uint32_t)__builtin_ctzll(m)) atomicOr(a.flags + 2, 1u);
 }
 
 // step 5: DC prediction = running sum of the differences over the component's blocks in scan order, as a three-kernel
@@ -980,9 +1028,9 @@ hipError_t launch_huffman_decode_sync(const HuffSyncArgs& a, int max_rounds, int
 
 size_t huff_hyp_chain_bytes(uint64_t nbytes, uint32_t sub_bits, size_t* tiles_offset) {
   const size_t nsub = huff_sync_max_subsequences(nbytes, sub_bits), ntiles = (nsub + kChainTile - 1) / kChainTile;
-  const size_t pre = ntiles * kChainThreads * kHuffHypSlots;
+  const size_t pre = ntiles * kChainThreads * kHuffHypSlots;  // the prefix maps; then the tile maps; then one entry byte per tile
   if (tiles_offset) *tiles_offset = pre;
-  return pre + ntiles * kHuffHypSlots;
+  return pre + ntiles * kHuffHypSlots + ((ntiles + 255) & ~(size_t)255);
 }
 
 // The hypothesis scheme (see above) in place of the rounds.  hyp_map must be filled with 0xff, hyp_cnt / nblk / dcd / flags
@@ -1010,8 +1058,10 @@ hipError_t launch_huffman_decode_hyp(const HuffSyncArgs& a, int* dc_partial, uin
   hipLaunchKernelGGL(hyp_pass1_kernel, dim3(grid), dim3(threads), lds1, s, a);
   mark();
   const int ntiles = (int)((nsub + kChainTile - 1) / kChainTile);
-  hipLaunchKernelGGL(hyp_chain_tiles_kernel, dim3(ntiles), dim3(kChainThreads), 0, s, a, chain_prefix, chain_tiles);
-  hipLaunchKernelGGL(hyp_chain_walk_kernel, dim3(ntiles), dim3(kChainThreads), 0, s, a, (const uint8_t*)chain_prefix, (const uint8_t*)chain_tiles);
+  uint8_t* chain_entry = chain_tiles + (size_t)ntiles * kHuffHypSlots;
+  hipLaunchKernelGGL(hyp_chain_tiles_kernel, dim3(ntiles), dim3(kChainWg), 0, s, a, chain_prefix, chain_tiles);
+  hipLaunchKernelGGL(hyp_chain_entry_kernel, dim3(1), dim3(kChainWg), 0, s, a, (const uint8_t*)chain_tiles, chain_entry);
+  hipLaunchKernelGGL(hyp_chain_walk_kernel, dim3(ntiles), dim3(kChainThreads), 0, s, a, (const uint8_t*)chain_prefix, (const uint8_t*)chain_entry);
   mark();
   {
     const int nt = (int)((nsub + kScanTile - 1) / kScanTile);
@@ -1025,7 +1075,7 @@ hipError_t launch_huffman_decode_hyp(const HuffSyncArgs& a, int* dc_partial, uin
   mark();
   if (dbg) {
     (void)hipStreamSynchronize(s);
-    static const char* names[] = {"pass0", "pass1", "chain x2", "nblk scan", "write", "dc x3"};
+    static const char* names[] = {"pass0", "pass1", "chain x3", "nblk scan", "write", "dc x3"};
     fprintf(stderr, "uhdr_hip: hypothesis decode kernels:");
     for (int i = 0; i + 1 < nev; i++) {
       float ms = 0;
