@@ -723,6 +723,76 @@ __global__ __launch_bounds__(1024) void hyp_pass1_kernel(const HuffSyncArgs a) {
   }
 }
 
+// pass 1, round 4 form: the workgroup's paths advance level by level in lockstep (one barrier per level), so that a path can
+// also fall in step with a path that is IN FLIGHT -- started later, inside this workgroup's 64 subsequences, and already
+// some levels old -- not only with the fresh paths of the subsequence it has just finished.  Two decoders on the same stream
+// converge on each other long before either meets a decoder that was started a moment ago: a straggler hands over to the
+// path one subsequence younger as soon as the two agree, and that one has more levels left than it.  The chain composes
+// such links like any other (map[j - 1][slot] = the in-flight slot at the end of j).  A slot m * H + t of subsequence j holds a
+// live state iff its owner's previous link continued into it (hyp_map[j - 1][(m - 1) * H + t] == m * H + t; the map is reset
+// to 0xff for every attempt), written one or more barriers ago by a lane of this workgroup -- owners in the NEXT workgroup
+// (start index beyond this one's last subsequence) are not looked at.  Youngest first: the younger the target, the more
+// levels it has left.
+__global__ __launch_bounds__(1024) void hyp_pass1q_kernel(const HuffSyncArgs a) {
+  extern __shared__ uint32_t s_stage[];
+  __shared__ ScanLds L;
+  load_scan_lds<true>(a, L);
+  const uint32_t lane = threadIdx.x & 63u, h = threadIdx.x >> 6, H = (uint32_t)a.hyp_h;
+  const uint32_t i = blockIdx.x * 64u + lane, i_last = blockIdx.x * 64u + 63u;
+  const uint32_t nclean = a.nbytes - *a.nstuffed, nbits = nclean * 8u;
+  const uint32_t nsub = (nbits + a.sub_bits - 1) / a.sub_bits;
+  const uint32_t cshift = 31u - (uint32_t)__builtin_clz(a.sub_bits >> 3);
+  const uint32_t first_byte = (blockIdx.x * 64u + 1u) * (a.sub_bits >> 3);  // the window starts one subsequence further on
+  stage_wave(a.clean, nclean, first_byte, cshift, s_stage, threadIdx.x, 64u + (uint32_t)a.hyp_levels, blockDim.x);
+  __syncthreads();
+  bool alive = i + 1 < nsub;
+  uint32_t p = 0, b = 0, k = 0;
+  if (alive) {
+    const uint64_t s0 = a.hyp_state[(size_t)i * kHuffHypSlots + h];
+    p = (uint32_t)s0; b = (uint32_t)(s0 >> 32) & 0xffu; k = (uint32_t)(s0 >> 40) & 0xffu;
+  }
+  uint32_t slot = h;
+  const Staged st = {s_stage, cshift};
+  for (uint32_t l = 1; l <= (uint32_t)a.hyp_levels; l++) {
+    const uint32_t j = i + l;
+    if (j >= nsub) alive = false;
+    if (alive) {
+      const uint32_t end_bit = min((j + 1) * a.sub_bits, nbits);
+      uint32_t nblk = 0;
+      if (p < end_bit) track_span(a, st, first_byte * 8u, L, p, b, k, end_bit, nblk);
+      const uint64_t e = pack_state(p, b, k);
+      const uint64_t* row = a.hyp_state + (size_t)j * kHuffHypSlots;
+      const uint8_t* prev = a.hyp_map + (size_t)(j - 1) * kHuffHypSlots;
+      uint32_t g = 0xffu;
+      for (uint32_t t = 0; t < H; t++)
+        if (row[t] == e && g == 0xffu) g = t;
+      const uint32_t m_lo = j > i_last + 1u ? j - i_last : 1u;  // owners started at j - m <= i_last
+      for (uint32_t m = m_lo; m < l && g == 0xffu; m++)
+        for (uint32_t t = 0; t < H; t++) {
+          const uint32_t sl = m * H + t;
+          if (g == 0xffu && prev[sl - H] == sl && row[sl] == e) g = sl;
+        }
+      const size_t at = (size_t)(j - 1) * kHuffHypSlots + slot;
+      a.hyp_cnt[at] = (uint16_t)nblk;
+      if (g != 0xffu) {
+        a.hyp_map[at] = (uint8_t)g;
+        if (a.hyp_hist) atomicAdd(a.flags + 9 + min(l, 6u), 1u);
+        alive = false;
+      } else if (l == (uint32_t)a.hyp_levels) {  // map stays 0xff: not merged within the budget
+        atomicAdd(a.flags + 3, 1u);
+        alive = false;
+      } else {
+        const uint32_t nslot = l * H + h;
+        a.hyp_state[(size_t)j * kHuffHypSlots + nslot] = e;
+        a.hyp_map[at] = (uint8_t)nslot;
+        slot = nslot;
+      }
+    }
+    __threadfence_block();
+    if (!__syncthreads_or(alive ? 1 : 0)) break;
+  }
+}
+
 // chain (round 4 form).  256 links per tile, function composition by CHASING instead of a scan over whole maps:
 //   tiles   the tile's 256 link maps (48 bytes each) are staged in LDS; thread (group g, slot s) follows slot s through the 16
 //           links of group g -- 16 dependent byte reads -- which gives the 16 group maps; 48 threads follow their slot through the
@@ -1055,7 +1125,9 @@ hipError_t launch_huffman_decode_hyp(const HuffSyncArgs& a, int* dc_partial, uin
   mark();
   hipLaunchKernelGGL(hyp_pass0_kernel, dim3(grid), dim3(threads), lds0, s, a);
   mark();
-  hipLaunchKernelGGL(hyp_pass1_kernel, dim3(grid), dim3(threads), lds1, s, a);
+  static const bool qmerge = !(getenv("UHDR_HIP_HUFF_QMERGE") && atoi(getenv("UHDR_HIP_HUFF_QMERGE")) == 0);
+  if (qmerge) hipLaunchKernelGGL(hyp_pass1q_kernel, dim3(grid), dim3(threads), lds1, s, a);
+  else hipLaunchKernelGGL(hyp_pass1_kernel, dim3(grid), dim3(threads), lds1, s, a);
   mark();
   const int ntiles = (int)((nsub + kChainTile - 1) / kChainTile);
   uint8_t* chain_entry = chain_tiles + (size_t)ntiles * kHuffHypSlots;
