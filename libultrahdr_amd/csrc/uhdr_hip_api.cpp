@@ -2843,13 +2843,13 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
         // grows with the bits per block (few EOBs in dense blocks): start where files of this density have settled, then widen
         const uint64_t bits_per_block = (uint64_t)data_bytes * 8u / (uint64_t)((uint64_t)a.total_mcus * (uint64_t)bpm);
         // Overflow levels: as many as the slots allow, up to 15.  Every further level is one more FRESH path a straggler can fall in
-        // step with, and only stragglers pay for it (a path stops at its merge).  Flat image regions are where it matters: their
-        // bit pattern is periodic (4:4:4 gain maps: "DC 0, EOB" x 3 = 14 bits per MCU), a decoder started at the wrong phase stays
-        // wrong until the region ends, so a fresh path either merges at once or not at all -- seven trials lost the true path
-        // of a 4K three-channel map at 512 and at 1024 bits (249 and 13 unmerged paths of 110 K), fifteen do not.
+        // step with, and only stragglers pay for it (a path stops at its merge).  Smooth content is where it matters (a gain map:
+        // 49 bits per block, a few short symbols each): seven trials lost the true path of a 4K three-channel map at 512 and at
+        // 1024 bits (249 and 13 unmerged paths of 110 K), fifteen at 1024 do not.  Exactly flat regions -- a periodic bit pattern --
+        // were the suspect and are not the problem (tools/flat_streams.py: one attempt each).
         const int lv_fit = kHuffHypSlots / bpm - 1;
         const int lv = lv_fit >= 15 ? 15 : (lv_fit >= 11 ? 11 : (lv_fit >= 7 ? 7 : (lv_fit >= 4 ? 4 : 0)));
-        // ... and very sparse streams (under 64 bits per block: smooth content, long flat regions) start at 1024 for the same reason:
+        // ... and very sparse streams (under 64 bits per block: smooth content) start at 1024 bits for the same reason:
         // the 4K map above (49 bits per block) still loses its true path at 512 x 15 (8 unmerged paths) and settles at 1024.
         // A context also remembers the size a scan of the same shape and density settled at when the first attempt was lost.
         uint32_t first = bits_per_block < 64 ? 1024u : (bits_per_block < 200 ? 512u : (bits_per_block < 400 ? 2048u : 4096u));
