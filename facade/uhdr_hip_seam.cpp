@@ -174,7 +174,12 @@ bool generate_gainmap(uhdr_raw_image_t* sdr_intent, uhdr_raw_image_t* hdr_intent
         hdr_intent->range, mw, mh, 64);  // jpegr.cpp:714-716
     uhdr_gainmap_metadata_t md;
     memset(&md, 0, sizeof md);
+    // the map's only reader is the compressImage that follows (jpegr.cpp:253-257 and its siblings), which finds it on the device:
+    // it is not downloaded (any CPU stage in between gets it written first, drop_resident)
+    const bool lazy = !getenv("UHDR_HIP_SEAM_EAGER_DOWNLOADS");
+    if (lazy) uhdr_hip_resident_lazy(cur(), 1);
     *st = uhdr_hip_generate_gainmap(cur(), sdr_intent, hdr_intent, &cfg, &md, img.get());
+    uhdr_hip_resident_lazy(cur(), 0);
     if (!handled(*st, "generate_gainmap")) return false;
     if (st->error_code == UHDR_CODEC_OK) {
       static_cast<uhdr_gainmap_metadata_t&>(*gainmap_metadata) = md;

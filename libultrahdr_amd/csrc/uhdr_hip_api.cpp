@@ -372,12 +372,16 @@ uhdr_error_info_t stage_in(uhdr_hip_ctx* c, int slot, const uhdr_raw_image_t* ho
 // stays on the device as well, keyed by the host planes it is being copied to: JpegR::encodeJPEGR hands exactly those
 // planes to JpegEncoderHelper::compressImage next (jpegr.cpp:253-316), and uhdr_hip_jpeg_encode_scan then reads the
 // device copy instead of uploading what was downloaded a moment ago.  One device-to-device copy (25 MB: ~10 us).
-uhdr_error_info_t resident_keep(uhdr_hip_ctx* c, const uhdr_raw_image_t* dev, const uhdr_raw_image_t* host) {
-  switch (host->fmt) {
+bool resident_keeps(int fmt) {
+  switch (fmt) {
     case UHDR_IMG_FMT_12bppYCbCr420: case UHDR_IMG_FMT_16bppYCbCr422: case UHDR_IMG_FMT_24bppYCbCr444: case UHDR_IMG_FMT_8bppYCbCr400:
-    case UHDR_IMG_FMT_24bppRGB888: case UHDR_IMG_FMT_32bppRGBA8888: break;
-    default: return ok_status();
+    case UHDR_IMG_FMT_24bppRGB888: case UHDR_IMG_FMT_32bppRGBA8888: return true;
+    default: return false;
   }
+}
+// host_unwritten: the caller did NOT copy the image to the host planes (lazy downloads): the device copy is the image
+uhdr_error_info_t resident_keep(uhdr_hip_ctx* c, const uhdr_raw_image_t* dev, const uhdr_raw_image_t* host, bool host_unwritten = false) {
+  if (!resident_keeps(host->fmt)) return ok_status();
   resident_drop(c, host->planes[0]);
   unsigned int slot = c->resident_next++ % 2;
   {  // an in-place operator may have worked ON a resident copy: that buffer is the source of the copy below, take the other one
@@ -414,11 +418,21 @@ uhdr_error_info_t resident_keep(uhdr_hip_ctx* c, const uhdr_raw_image_t* dev, co
   r.w = host->w;
   r.h = host->h;
   r.valid = true;
+  r.host_unwritten = host_unwritten;
   return ok_status();
 }
 // Copies back only the w samples of every row, so the caller's stride padding stays untouched
-// (the reference never writes there either).
+// (the reference never writes there either).  Lazy downloads (uhdr_hip_resident_lazy): an image the handoff keeps is not copied
+// back at all -- the generated gain map of an encode, whose only reader is the compressImage that follows (jpegr.cpp:253-257)
+// and finds it on the device; whoever else would read the host planes gets them written first (resident_write_back).
 uhdr_error_info_t stage_out(uhdr_hip_ctx* c, const uhdr_raw_image_t* dev, uhdr_raw_image_t* host) {
+  const bool lazy = c->resident_on && c->resident_lazy && resident_keeps(host->fmt) && host->planes[0];
+  if (lazy) {
+    UHDR_TRY(resident_keep(c, dev, host, true));
+    c->stats.lazy_downloads_skipped++;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ok_status();
+  }
   for (int pl = 0; pl < 3; pl++) {
     size_t rows, width;
     if (!plane_geom(host, pl, &rows, &width) || rows == 0 || !host->planes[pl]) continue;
