@@ -605,7 +605,9 @@ void uhdr_hip_resident_end(uhdr_hip_ctx_t* ctx);
  * decodeJPEGR's two decoded images have exactly two readers: applyGainMap (jpegr.cpp:1527), which on this path reads the
  * device copies, and copy_raw_image(&gainmap, gainmap_img) (jpegr.cpp:1490), which fills the image uhdr_get_decoded_gainmap_
  * image (ultrahdr_api.cpp:2031-2043) hands out -- rarely asked for, 33 MB for a full-resolution RGBA map.  So:
- *   _lazy(ctx, 1)   until _lazy(ctx, 0) or _end: an image uhdr_hip_jpeg_decode_scan keeps on the device is NOT written to the
+ *   _lazy(ctx, 1)   until _lazy(ctx, 0) or _end: an image the handoff keeps on the device -- what uhdr_hip_jpeg_decode_scan decodes,
+ *                   and an 8-bit image a host-buffer entry point produces (the facade switches it on around generateGainMap: the
+ *                   map's only reader is the compressImage that follows, jpegr.cpp:253-257) -- is NOT written to the
  *                   caller's planes; the device copy IS the image.  Library entry points handed those planes read the device
  *                   copy, and the library writes the planes back by itself before it would read them from the host or reuse
  *                   the slot.  The caller calls _flush before anything ELSE reads them (the facade: before any CPU stage).
