@@ -71,6 +71,33 @@ def jpegr_cpp(t):
                      "                                      mEncPreset, mMinContentBoost, mMaxContentBoost,\n"
                      "                                      mTargetDispPeakBrightness, &status))\n    return status;\n"
                      "  status = g_no_error;\n#endif\n")
+    # encodeJPEGR API-1: the whole sample -> bytes part in one device sequence (the stage seams take what it declines)
+    t = insert_after(t, "/* Encode API-1 */\nuhdr_error_info_t JpegR::encodeJPEGR(uhdr_raw_image_t* hdr_intent, uhdr_raw_image_t* sdr_intent,\n"
+                        "                                     uhdr_compressed_image_t* dest, int quality,\n"
+                        "                                     uhdr_mem_block_t* exif) {\n"
+                        "  // generate gain map\n  uhdr_gainmap_metadata_ext_t metadata(kJpegrVersion);\n",
+                     "#ifdef UHDR_ENABLE_HIP\n  if (uhdr_hip_seam::enabled()) {\n"
+                     "    std::shared_ptr<DataStruct> hip_icc_base = IccHelper::writeIccProfile(UHDR_CT_SRGB, sdr_intent->cg);\n"
+                     "    std::shared_ptr<DataStruct> hip_icc_map =  // compressGainMap's choice (jpegr.cpp:520-528)\n"
+                     "        kWriteXmpMetadata ? nullptr : IccHelper::writeIccProfile(hdr_intent->ct, hdr_intent->cg);\n"
+                     "    char hip_comment[255];  // JpegEncoderHelper::encode's COM marker of a gain-map image\n"
+                     "    snprintf(hip_comment, sizeof hip_comment,\n"
+                     "             \"Source: google libuhdr v%s, Coder: libjpeg v%d, Attrib: GainMap Image\",\n"
+                     "             UHDR_LIB_VERSION_STR, JPEG_LIB_VERSION);\n"
+                     "    uhdr_hip_seam::Api1Files hip_files;\n    uhdr_error_info_t hip_status;\n"
+                     "    if (uhdr_hip_seam::encode_api1(hdr_intent, sdr_intent, quality, mMapCompressQuality, &mMapDimensionScaleFactor,\n"
+                     "                                   mUseMultiChannelGainMap, mGamma, mEncPreset, mMinContentBoost,\n"
+                     "                                   mMaxContentBoost, mTargetDispPeakBrightness, hip_icc_base->getData(),\n"
+                     "                                   hip_icc_base->getLength(), hip_icc_map ? hip_icc_map->getData() : nullptr,\n"
+                     "                                   hip_icc_map ? hip_icc_map->getLength() : 0, hip_comment, &metadata, &hip_files,\n"
+                     "                                   &hip_status)) {\n"
+                     "      if (hip_status.error_code != UHDR_CODEC_OK) return hip_status;\n"
+                     "      uhdr_compressed_image_t gainmap_compressed = hip_files.gainmap();\n"
+                     "      uhdr_compressed_image_t sdr_intent_compressed = hip_files.base();\n"
+                     "      sdr_intent_compressed.cg = sdr_intent->cg;\n"
+                     "      UHDR_ERR_CHECK(appendGainMap(&sdr_intent_compressed, &gainmap_compressed, exif, /* icc */ nullptr,\n"
+                     "                                   /* icc size */ 0, &metadata, dest));\n"
+                     "      return g_no_error;\n    }\n  }\n#endif\n")
     t = insert_before(t, "#ifdef UHDR_ENABLE_GLES\n  if (mUhdrGLESCtxt != nullptr) {\n",
                       "#ifdef UHDR_ENABLE_HIP\n  {\n    uhdr_error_info_t hip_status;\n"
                       "    if (uhdr_hip_seam::apply_gainmap(sdr_intent, gainmap_img, gainmap_metadata, output_ct, output_format,\n"

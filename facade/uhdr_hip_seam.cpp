@@ -8,6 +8,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
 
 #include "uhdr_hip.h"  // after ultrahdr_api.h: reuses the reference's own structs
 
@@ -27,6 +30,35 @@ uhdr_hip_ctx_t* cur() { return static_cast<uhdr_hip_ctx_t*>(tl_ctxt); }
 bool trace_on() {
   static const bool on = getenv("UHDR_HIP_SEAM_TRACE") != nullptr;
   return on;
+}
+// Contexts outlive their codec (round 5).  An application creates one encoder / decoder per image (uhdr_create_encoder ..
+// uhdr_release_encoder around every frame is what ultrahdr_app and the reference's own tests do); a uhdr_hip context carries
+// a stream, the transfer-function tables, the entropy decoder's table forms, a pinned staging ring and device scratch sized
+// for the last image -- a few milliseconds of hipMalloc / hipHostMalloc / uploads that used to be paid inside every
+// uhdr_encode / uhdr_decode.  release() parks up to kPoolMax idle contexts, the next codec's first accelerated call takes one.
+// UHDR_HIP_SEAM_NO_CTX_POOL=1: one context per codec, destroyed with it (the round-4 behaviour).  Parked contexts are
+// never destroyed at process exit (the HIP runtime may be gone by then).
+constexpr size_t kPoolMax = 4;
+std::mutex g_pool_mu;
+std::vector<void*> g_pool;
+bool pool_on() {
+  static const bool on = getenv("UHDR_HIP_SEAM_NO_CTX_POOL") == nullptr;
+  return on;
+}
+void* pool_take() {
+  if (!pool_on()) return nullptr;
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  if (g_pool.empty()) return nullptr;
+  void* c = g_pool.back();
+  g_pool.pop_back();
+  return c;
+}
+bool pool_give(void* c) {
+  if (!pool_on()) return false;
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  if (g_pool.size() >= kPoolMax) return false;
+  g_pool.push_back(c);
+  return true;
 }
 thread_local double tl_enter_ms = -1.0;
 double now_ms() {
@@ -55,6 +87,7 @@ Scope::Scope(bool enable, void** slot, bool lazy) : mPrev(tl_ctxt), mFailed(fals
     tl_ctxt = nullptr;
     return;
   }
+  if (*slot == nullptr) *slot = pool_take();
   if (*slot == nullptr) {
     uhdr_error_info_t err;
     memset(&err, 0, sizeof err);
@@ -113,7 +146,9 @@ void forget(void* ctxt) {
 }
 
 void release(void* ctxt) {
-  if (ctxt) uhdr_hip_destroy(static_cast<uhdr_hip_ctx_t*>(ctxt));
+  if (!ctxt) return;
+  uhdr_hip_resident_forget(static_cast<uhdr_hip_ctx_t*>(ctxt));  // a deferred copy into the codec that is going away
+  if (!pool_give(ctxt)) uhdr_hip_destroy(static_cast<uhdr_hip_ctx_t*>(ctxt));
 }
 unsigned long calls_on_device() { return g_calls.load(std::memory_order_relaxed); }
 
@@ -190,6 +225,105 @@ bool generate_gainmap(uhdr_raw_image_t* sdr_intent, uhdr_raw_image_t* hdr_intent
   }();
   if (!on_device_) drop_resident();
   return on_device_;
+}
+
+bool encode_api1(uhdr_raw_image_t* hdr_intent, uhdr_raw_image_t* sdr_intent, int base_quality, int map_quality, int* scale_factor,
+                 bool multi_channel, float gamma, uhdr_enc_preset_t preset, float min_content_boost, float max_content_boost,
+                 float target_disp_peak_brightness, const void* base_icc, size_t base_icc_size, const void* map_icc,
+                 size_t map_icc_size, const char* map_comment, ultrahdr::uhdr_gainmap_metadata_ext_t* gainmap_metadata,
+                 Api1Files* out, uhdr_error_info_t* st) {
+  // declining costs nothing: no upload has happened, no resident copy exists yet -- the per-stage seams run as before
+  if (!cur() || !hdr_intent || !sdr_intent || !gainmap_metadata || !out || !scale_factor) return false;
+  if (getenv("UHDR_HIP_SEAM_NO_FUSED_ENCODE") || getenv("UHDR_HIP_SEAM_CPU_ENTROPY") || getenv("UHDR_HIP_SEAM_RESTART_INTERVAL") ||
+      getenv("UHDR_HIP_SEAM_DEVICE_ENTROPY") || getenv("UHDR_HIP_SEAM_EAGER_DOWNLOADS"))
+    return false;
+  if (sdr_intent->fmt != UHDR_IMG_FMT_12bppYCbCr420 || *scale_factor < 1) return false;
+  const unsigned w = sdr_intent->w, h = sdr_intent->h;
+  const int s = *scale_factor;
+  if (w == 0 || h == 0 || w % 16 || h % 16 || w > 65535 || h > 65535) return false;
+  const unsigned mw = w / (unsigned)s, mh = h / (unsigned)s;
+  if (mw == 0 || mh == 0 || mw % 8 || mh % 8) return false;  // (the tiny-image fallback of jpegr.cpp:690-706 stays with generate_gainmap)
+  if (base_icc_size > 65533 || map_icc_size > 65533 || (map_comment && strlen(map_comment) > 65533)) return false;
+  if (base_quality < 0 || base_quality > 100 || map_quality < 0 || map_quality > 100) return false;
+  enter();
+  uhdr_hip_encode_cfg_t cfg;
+  cfg.map_dimension_scale_factor = s;
+  cfg.use_multi_channel_gainmap = multi_channel;
+  cfg.gamma = gamma;
+  cfg.preset = preset;
+  cfg.min_content_boost = min_content_boost;
+  cfg.max_content_boost = max_content_boost;
+  cfg.target_disp_peak_nits = target_disp_peak_brightness;
+  cfg.sdr_is_601 = 0;     // generateGainMap's defaults, as encodeJPEGR API-1 calls it (jpegr.cpp:259)
+  cfg.use_luminance = 1;
+  uint16_t qt_base[2][64], qt_map[2][64];  // jpeg_set_quality(quality, TRUE) (jpegencoderhelper.cpp:187)
+  for (int t = 0; t < 2; t++) {
+    uhdr_hip_jpeg_quant_table(base_quality, t, qt_base[t]);
+    uhdr_hip_jpeg_quant_table(map_quality, t, qt_map[t]);
+  }
+  const int nch = multi_channel ? 3 : 1;
+  // the two files' headers first (their sizes place the scans inside the output buffers)
+  uhdr_hip_jpeg_scan_t sb, sm;
+  memset(&sb, 0, sizeof sb);
+  memset(&sm, 0, sizeof sm);
+  sb.num_components = 3;
+  sb.w = w; sb.h = h;
+  for (int i = 0; i < 3; i++) {
+    sb.blocks_w[i] = (int)(i ? w / 16 : w / 8);
+    sb.blocks_h[i] = (int)(i ? h / 16 : h / 8);
+    sb.h_samp[i] = sb.v_samp[i] = i ? 1 : 2;
+  }
+  sm.num_components = nch;
+  sm.w = mw; sm.h = mh;
+  for (int i = 0; i < nch; i++) { sm.blocks_w[i] = (int)(mw / 8); sm.blocks_h[i] = (int)(mh / 8); sm.h_samp[i] = sm.v_samp[i] = 1; }
+  unsigned char hb[2048], hm[2048];
+  const unsigned char none = 0;
+  const size_t nhb = uhdr_hip_jpeg_assemble(&sb, qt_base[0], qt_base[1], &none, 0, hb, sizeof hb);
+  const size_t nhm = uhdr_hip_jpeg_assemble(&sm, qt_map[0], qt_map[nch == 3 ? 1 : 0], &none, 0, hm, sizeof hm);
+  if (nhb < 22 || nhm < 22) return false;
+  // file = SOI + JFIF APP0 (20 bytes) | APP2 ICC | COM | DQT .. SOS | data | EOI  (jcmarker.c's order around the helper's markers)
+  auto lead = [](size_t nh, size_t icc, const char* com) { return 20 + (icc ? 4 + icc : 0) + (com ? 4 + strlen(com) : 0) + (nh - 22); };
+  const size_t lead_b = lead(nhb, base_icc ? base_icc_size : 0, nullptr), lead_m = lead(nhm, map_icc ? map_icc_size : 0, map_comment);
+  const size_t cap_b = (size_t)w * h * 3 / 2 + (1u << 16), cap_m = (size_t)mw * mh * nch + (1u << 16);  // one byte per coefficient: never seen exceeded
+  out->base_data.reset(new (std::nothrow) unsigned char[lead_b + cap_b + 2]);
+  out->gainmap_data.reset(new (std::nothrow) unsigned char[lead_m + cap_m + 2]);
+  if (!out->base_data || !out->gainmap_data) return false;
+  uhdr_gainmap_metadata_t md;
+  memset(&md, 0, sizeof md);
+  uhdr_raw_image_t gm_desc;
+  memset(&gm_desc, 0, sizeof gm_desc);
+  size_t nb = 0, nm = 0;
+  *st = uhdr_hip_encode_api1_scans(cur(), sdr_intent, hdr_intent, &cfg, UHDR_CG_DISPLAY_P3, qt_base, qt_map, &md, &gm_desc, out->base_data.get() + lead_b,
+                                   cap_b, &nb, out->gainmap_data.get() + lead_m, cap_m, &nm);
+  if (st->error_code == UHDR_CODEC_MEM_ERROR) {  // a stream busier than one byte per coefficient: the per-stage seams size their buffers from the answer
+    if (trace_on()) fprintf(stderr, "uhdr_hip_seam: encode_api1_fused -> per-stage seams (%s)\n", st->has_detail ? st->detail : "");
+    return false;
+  }
+  if (!handled(*st, "encode_api1_fused")) return false;
+  if (st->error_code != UHDR_CODEC_OK) return true;
+  auto finish = [](unsigned char* f, const unsigned char* hdr, size_t nh, const void* icc, size_t icc_size, const char* com, size_t lead_bytes, size_t scan_bytes) {
+    unsigned char* p = f;
+    memcpy(p, hdr, 20); p += 20;
+    auto marker = [&](int code, const void* d, size_t n) {
+      p[0] = 0xff; p[1] = (unsigned char)code; p[2] = (unsigned char)((n + 2) >> 8); p[3] = (unsigned char)((n + 2) & 0xff);
+      memcpy(p + 4, d, n);
+      p += 4 + n;
+    };
+    if (icc && icc_size) marker(0xe2, icc, icc_size);
+    if (com) marker(0xfe, com, strlen(com));
+    memcpy(p, hdr + 20, nh - 22); p += nh - 22;
+    (void)lead_bytes;  // == p - f: the scan is already in place behind it
+    p += scan_bytes;
+    p[0] = 0xff; p[1] = 0xd9;
+    return (size_t)(p + 2 - f);
+  };
+  out->base_size = finish(out->base_data.get(), hb, nhb, base_icc, base_icc ? base_icc_size : 0, nullptr, lead_b, nb);
+  out->gainmap_size = finish(out->gainmap_data.get(), hm, nhm, map_icc, map_icc ? map_icc_size : 0, map_comment, lead_m, nm);
+  out->base_capacity = lead_b + cap_b + 2;
+  out->gainmap_capacity = lead_m + cap_m + 2;
+  static_cast<uhdr_gainmap_metadata_t&>(*gainmap_metadata) = md;
+  *scale_factor = s;
+  return true;
 }
 
 bool tone_map(uhdr_raw_image_t* hdr_intent, uhdr_raw_image_t* sdr_intent, uhdr_error_info_t* st) {

@@ -11,6 +11,9 @@
 //   UltraHdr::applyGainMap          lib/src/jpegr.cpp:1533       uhdr_hip_seam::apply_gainmap
 //   UltraHdr::generateGainMap       lib/src/jpegr.cpp:530        uhdr_hip_seam::generate_gainmap
 //   UltraHdr::toneMap               lib/src/jpegr.cpp:1985       uhdr_hip_seam::tone_map
+//   JpegR::encodeJPEGR (API-1)      lib/src/jpegr.cpp:253        uhdr_hip_seam::encode_api1 (the whole sample -> bytes part of the
+//                                                                call in one device sequence; the four seams above and below
+//                                                                take over for what it declines)
 //   UltraHdr::convertYuv            lib/src/jpegr.cpp:436        uhdr_hip_seam::convert_yuv
 //   convert_raw_input_to_ycbcr      lib/src/gainmapmath.cpp:1291 uhdr_hip_seam::convert_raw_input_to_ycbcr
 //   JpegEncoderHelper::encode       lib/src/jpegencoderhelper.cpp:131  uhdr_hip_seam::fdct_planes (FDCT + quantize on
@@ -85,6 +88,36 @@ bool generate_gainmap(uhdr_raw_image_t* sdr_intent, uhdr_raw_image_t* hdr_intent
                       uhdr_enc_preset_t preset, float min_content_boost, float max_content_boost,
                       float target_disp_peak_brightness, uhdr_error_info_t* st);
 bool tone_map(uhdr_raw_image_t* hdr_intent, uhdr_raw_image_t* sdr_intent, uhdr_error_info_t* st);
+
+// JpegR::encodeJPEGR API-1 (lib/src/jpegr.cpp:253-316) as ONE device sequence (uhdr_hip_encode_api1_scans, include/uhdr_hip.h):
+// both raw intents go up once, generateGainMap (two passes) + compressGainMap + convertYuv + compressImage run without a sample
+// or a coefficient coming back, and the two entropy-coded scans come down into complete JPEG files -- the bytes
+// JpegEncoderHelper::compressImage (jpegencoderhelper.cpp:101-244) writes: SOI, JFIF APP0, the ICC profile as APP2, the gain
+// map's COM marker, DQT, SOF0, DHT, SOS, data, EOI.  The reference then calls appendGainMap on them as it does on its own.
+// false: not a combination for the fused chain (an RGB or 4:2:2 / 4:4:4 SDR intent, dimensions that are not multiples of 16,
+// the one-pass preset, gamma != 1, a route option such as UHDR_HIP_SEAM_CPU_ENTROPY) -- nothing happened, encodeJPEGR goes on
+// through the per-stage seams above.
+struct Api1Files {
+  std::unique_ptr<unsigned char[]> base_data, gainmap_data;  // (not vectors: 14 MB of capacity must not be zero-filled)
+  size_t base_size = 0, gainmap_size = 0, base_capacity = 0, gainmap_capacity = 0;
+  uhdr_compressed_image_t base() const {  // as JpegEncoderHelper::getCompressedImage (jpegencoderhelper.cpp:118-129)
+    uhdr_compressed_image_t i;
+    i.data = base_data.get(); i.data_sz = base_size; i.capacity = base_size;
+    i.cg = UHDR_CG_UNSPECIFIED; i.ct = UHDR_CT_UNSPECIFIED; i.range = UHDR_CR_UNSPECIFIED;
+    return i;
+  }
+  uhdr_compressed_image_t gainmap() const {
+    uhdr_compressed_image_t i;
+    i.data = gainmap_data.get(); i.data_sz = gainmap_size; i.capacity = gainmap_size;
+    i.cg = UHDR_CG_UNSPECIFIED; i.ct = UHDR_CT_UNSPECIFIED; i.range = UHDR_CR_UNSPECIFIED;
+    return i;
+  }
+};
+bool encode_api1(uhdr_raw_image_t* hdr_intent, uhdr_raw_image_t* sdr_intent, int base_quality, int map_quality, int* scale_factor,
+                 bool multi_channel, float gamma, uhdr_enc_preset_t preset, float min_content_boost, float max_content_boost,
+                 float target_disp_peak_brightness, const void* base_icc, size_t base_icc_size, const void* map_icc,
+                 size_t map_icc_size, const char* map_comment, ultrahdr::uhdr_gainmap_metadata_ext_t* gainmap_metadata,
+                 Api1Files* out, uhdr_error_info_t* st);
 bool convert_yuv(uhdr_raw_image_t* image, uhdr_color_gamut_t src_encoding, uhdr_color_gamut_t dst_encoding,
                  uhdr_error_info_t* st);
 bool convert_raw_input_to_ycbcr(uhdr_raw_image_t* src, bool chroma_sampling_enabled,

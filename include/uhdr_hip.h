@@ -651,6 +651,27 @@ uhdr_error_info_t uhdr_hip_encode_api1_fused_dev(uhdr_hip_ctx_t* ctx, const uhdr
                                                  const uint16_t qt_base[2][64], const uint16_t qt_map[2][64],
                                                  const uhdr_hip_api1_blocks_t* blocks, uhdr_gainmap_metadata_t* md, uhdr_raw_image_t* gm);
 
+/* ---- JpegR::encodeJPEGR API-1 behind ONE entry point (round 5; what the facade's seam at encodeJPEGR binds) ------------------
+ * jpegr.cpp:253-316 = generateGainMap -> compressGainMap -> convertYuv(base, BT.601) -> compressImage(base) -> appendGainMap.
+ * Everything of it that touches samples runs here as one device sequence on HOST images: the two raw intents go up once (a
+ * few threads feed a pinned ring, the DMA engine drains it), uhdr_hip_encode_api1_fused_dev leaves all coefficient blocks in
+ * HBM, uhdr_hip_huffman_encode_dev (restart_interval 0: the reference's own bytes) codes the base image's interleaved 4:2:0
+ * scan and the map's 4:4:4 (or one-component) scan, and only those two byte strings come down.  The 8-bit gain map and the
+ * converted base planes never exist; the container around the scans (SOI .. SOS headers, ICC, MPF, XMP / ISO metadata --
+ * jpegr.cpp:1100-1300) stays the caller's.
+ * sdr / hdr / cfg / base_encoding / qt_base / qt_map: as for uhdr_hip_encode_api1_fused_dev, with HOST plane pointers.
+ * gainmap_desc (may be NULL): receives fmt / w / h / cg / ct / range of the gain-map image generateGainMap would have
+ * allocated (jpegr.cpp:714-716); its planes are not touched.  base_scan / map_scan: HOST buffers; *_bytes = sizes written
+ * (UHDR_CODEC_MEM_ERROR with the needed size in the corresponding *_bytes when a capacity is too small -- call again).
+ * UHDR_CODEC_UNSUPPORTED_FEATURE: a combination the fused chain does not take (dimensions not multiples of 16, one-pass
+ * preset, gamma != 1 ...) -- nothing was uploaded; use the per-stage entry points.  Synchronous. */
+uhdr_error_info_t uhdr_hip_encode_api1_scans(uhdr_hip_ctx_t* ctx, const uhdr_raw_image_t* sdr, const uhdr_raw_image_t* hdr,
+                                             const uhdr_hip_encode_cfg_t* cfg, uhdr_color_gamut_t base_encoding,
+                                             const uint16_t qt_base[2][64], const uint16_t qt_map[2][64],
+                                             uhdr_gainmap_metadata_t* md, uhdr_raw_image_t* gainmap_desc,
+                                             uint8_t* base_scan, size_t base_capacity, size_t* base_bytes,
+                                             uint8_t* map_scan, size_t map_capacity, size_t* map_bytes);
+
 /* ---- which route did the entropy stage take? ---------------------------------------------------------------------
  * Counters of the context since its creation.  A scan the device declines (entropy_decode_declined: a marker-less stream so
  * dense that the parallel decoder does not settle, or Huffman tables outside its two-level form) is returned to the caller

@@ -640,6 +640,95 @@ __global__ __launch_bounds__(256) void sync_write_kernel(const HuffSyncArgs a, i
   }
 }
 
+// ---- the write pass, form 2 (round 5; marker-less scans) ---------------------------------------------------------------
+// Form 1 above pays, on nearly every symbol step of a wave (64 lanes in 64 different places: some lane ends a block on 9 steps
+// in 10), for the block's JBLOCK address (component, MCU row / column, edge test: eight LDS reads and a few multiplications), a
+// zig-zag lookup and a separate DC-difference store.  Form 2 stores where the decoder already is: block t of the scan at
+// coef_scan + 64 t, coefficient at its ZIG-ZAG index, the DC difference at [0] like any other value -- one predicated
+// 2-byte store per symbol, a pointer bump per block.  coef_place_kernel then reads the scratch once (coalesced), applies the
+// DC prediction (the running sums of dc_partial / dc_scan_partials over [0]) and writes every JBLOCK whole, in natural order --
+// so the component arrays need no zero fill any more, the scratch (scan order) gets it instead.
+struct Write2Lds {
+  uint32_t t[4][kHuffValWords];
+};
+__device__ __forceinline__ void write_span2(const HuffSyncArgs& a, const Staged& st, uint32_t region_bit, const Write2Lds& L, uint32_t p, uint32_t b, uint32_t k,
+                                            uint32_t end_bit, uint32_t& nblk, uint32_t blk) {
+  Bits r;
+  r.st = st;
+  r.region_bit = region_bit;
+  r.seek(p);
+  bool bad = false;
+  const uint32_t bpm = (uint32_t)a.blocks_per_mcu;
+  uint32_t cpack = 0;
+#pragma unroll
+  for (int j = 0; j < 16; j++) cpack |= ((uint32_t)a.comp_of[j] & 3u) << (2 * j);
+  const uint32_t* T = &L.t[0][0];
+  uint32_t cbase = ((cpack >> (2u * b)) & 3u) ? 2u * kHuffValWords : 0u;
+  int16_t* dst = a.coef_scan + (size_t)blk * 64;
+  int left = (int)(end_bit - p);
+  while (left > 0 && blk < a.total_blocks) {
+    r.fill();
+    const uint32_t w16 = r.peek(16);
+    const uint32_t tb = cbase + (k ? (uint32_t)kHuffValWords : 0u);
+    uint32_t e = T[tb + (w16 >> 7)];
+    if (__builtin_amdgcn_ballot_w64((e >> 31) != 0) != 0) {
+      const uint32_t e2 = T[tb + 512u + ((e >> 31) ? (e & 31u) : 0u) * 128u + (w16 & 127u)];
+      e = (e >> 31) ? e2 : e;
+    }
+    const uint32_t adv = e & 31u, kinc = (e >> 5) & 127u, sz = (e >> 12) & 15u;
+    const uint32_t ext = (1u << sz) - 1u;
+    const uint32_t raw = r.peek((int)adv) & ext;  // adv >= 1: every code is at least one bit long
+    const int value = (int)raw - (((raw << 1) > ext) ? 0 : (int)ext);  // HUFF_EXTEND; 0 when there are no magnitude bits
+    const uint32_t zzpos = k + kinc - 1u;  // DC: 0; AC symbol with a value: k + run
+    const bool over = sz != 0 && zzpos > 63u;  // (a DC symbol has zzpos 0)
+    bad = bad || ((e >> 16) & 1u) != 0 || over;
+    if (sz != 0 && !over) dst[zzpos] = (int16_t)value;
+    r.skip((int)adv);
+    left -= (int)adv;
+    k += kinc;
+    if (k >= 64u) {
+      k = 0;
+      b++;
+      nblk++;
+      blk++;
+      dst += 64;
+      if (b == bpm) b = 0;
+      cbase = ((cpack >> (2u * b)) & 3u) ? 2u * kHuffValWords : 0u;
+    }
+  }
+  if (bad) atomicOr(a.flags + 1, 2u);
+}
+__global__ __launch_bounds__(256) void sync_write2_kernel(const HuffSyncArgs a, int final_buf) {
+  extern __shared__ uint32_t s_stage_all[];
+  __shared__ Write2Lds L;
+  {
+    uint32_t* dst = &L.t[0][0];
+    for (uint32_t i = threadIdx.x; i < 4u * kHuffValWords; i += blockDim.x) dst[i] = a.vtabs[i];
+  }
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t nclean = a.nbytes - *a.nstuffed, nbits = nclean * 8u;
+  const uint32_t nsub = (nbits + a.sub_bits - 1) / a.sub_bits;
+  const uint32_t cshift = 31u - (uint32_t)__builtin_clz(a.sub_bits >> 3);
+  const uint32_t wv = threadIdx.x >> 6;
+  uint32_t* s_stage = s_stage_all + wv * ((64u * ((a.sub_bits >> 3) + 4u) + 64u) >> 2);
+  const uint32_t first_byte = (blockIdx.x * blockDim.x + wv * 64u) * (a.sub_bits >> 3);
+  stage_wave(a.clean, nclean, first_byte, cshift, s_stage, threadIdx.x & 63u);
+  __syncthreads();
+  if (i >= nsub) return;
+  uint32_t p = 0, b = 0, k = 0;
+  if (i > 0) {
+    const uint64_t s = a.state[final_buf][i - 1];
+    p = (uint32_t)s; b = (uint32_t)(s >> 32) & 0xffu; k = (uint32_t)(s >> 40) & 0xffu;
+  }
+  const uint32_t end_bit = min((i + 1) * a.sub_bits, nbits);
+  uint32_t nblk = 0;
+  const Staged st = {s_stage, cshift};
+  if (p < end_bit) write_span2(a, st, first_byte * 8u, L, p, b, k, end_bit, nblk, a.nblk[i]);  // nblk[] holds the exclusive scan by now
+  if (i == nsub - 1) {
+    if (a.nblk[i] + nblk < a.total_blocks) atomicOr(a.flags + 1, 8u);  // truncated data
+  }
+}
+
 // ---- hypothesis decode: the fixed point in a fixed number of passes ------------------------------------------------------
 // The rounds above converge slowly on interleaved scans: a lane that starts in the wrong BLOCK OF THE MCU reads luma
 // blocks with the chroma tables (or the reverse) and can only fall in step with the true decoder by luck, so the correct
@@ -674,7 +763,10 @@ __global__ __launch_bounds__(1024) void hyp_pass0_kernel(const HuffSyncArgs a) {
   const Staged st = {s_stage, cshift};
   track_span(a, st, first_byte * 8u, L, p, b, k, end_bit, nblk);
   a.hyp_state[(size_t)i * kHuffHypSlots + h] = pack_state(p, b, k);
-  if (i == 0 && h == 0) a.nblk[0] = nblk;
+  if (i == 0 && h == 0) {
+    a.nblk[0] = nblk;
+    a.flags[kHuffFlagStragglers] = 0;  // every attempt starts with pass 0: the list pass 1 hands to hyp_straggler_kernel is empty
+  }
 }
 
 __global__ __launch_bounds__(1024) void hyp_pass1_kernel(const HuffSyncArgs a) {
@@ -753,7 +845,9 @@ __global__ __launch_bounds__(1024) void hyp_pass1q_kernel(const HuffSyncArgs a) 
   }
   uint32_t slot = h;
   const Staged st = {s_stage, cshift};
-  for (uint32_t l = 1; l <= (uint32_t)a.hyp_levels; l++) {
+  // lockstep levels: all of them, or the first hyp_main_levels -- what is still alive then goes to hyp_straggler_kernel
+  const uint32_t l_main = (a.hyp_main_levels > 0 && a.hyp_main_levels < a.hyp_levels) ? (uint32_t)a.hyp_main_levels : (uint32_t)a.hyp_levels;
+  for (uint32_t l = 1; l <= l_main; l++) {
     const uint32_t j = i + l;
     if (j >= nsub) alive = false;
     if (alive) {
@@ -790,6 +884,146 @@ __global__ __launch_bounds__(1024) void hyp_pass1q_kernel(const HuffSyncArgs a) 
     }
     __threadfence_block();
     if (!__syncthreads_or(alive ? 1 : 0)) break;
+  }
+  if (l_main < (uint32_t)a.hyp_levels) {  // hand-off: (start subsequence, hypothesis, levels done); one atomic per wave
+    const uint64_t m = __builtin_amdgcn_ballot_w64(alive);
+    if (m != 0) {
+      uint32_t base = 0;
+      const uint32_t leader = (uint32_t)__builtin_ctzll(m);
+      if (lane == leader) base = atomicAdd(a.flags + kHuffFlagStragglers, (uint32_t)__builtin_popcountll(m));
+      base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
+      if (alive) {
+        const uint32_t at = base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+        if (at < a.strag_cap) {
+          a.strag_list[2 * at] = i;
+          a.strag_list[2 * at + 1] = h | (l_main << 8);
+        }
+      }
+    }
+  }
+}
+
+// ---- pass 1, the stragglers (round 5): one WAVE per path -------------------------------------------------------------------
+// A lane follows a path at ~460 cycles per symbol (two dependent LDS reads and ~25 dependent VALU instructions), so pass 1 in
+// lockstep lasts as long as its unluckiest path: levels x (symbols per subsequence) x 460 cycles.  Few paths get that far (4K
+// 4:2:0 q95: 8 % are alive after level 1, 0.5 % after level 2), so each of them gets a wave: lane o looks up the symbol that
+// WOULD start at bit p + o of the stream in all four tracking tables (two packed registers: luma DC | AC, chroma DC | AC) --
+// four LDS gathers for 64 bit positions at once -- and one scalar chain hops from boundary to boundary with v_readlane:
+// off += bits(entry[off]), k += advance, block / MCU bookkeeping in SGPRs.  ~40 cycles per symbol plus ~300 per 64-bit window.
+// Same state transitions as track_span (zeros past the end of the stream included); restart files do not come here.
+// Merge targets: the fresh slots of the subsequence just finished and the in-flight slots the lockstep levels wrote (their
+// owners' links are complete before this kernel starts); slots written by other stragglers are never looked at.
+constexpr int kStragWaves = 4;               // waves per workgroup (they share one copy of the tracking tables)
+constexpr int kStragStageWords = 132 + 4;    // a 4096-bit subsequence + the overhang of its last symbol, as big-endian words
+
+__global__ __launch_bounds__(64 * kStragWaves) void hyp_straggler_kernel(const HuffSyncArgs a) {
+  __shared__ ScanLds L;
+  __shared__ uint32_t s_bytes[kStragWaves][kStragStageWords];
+  load_scan_lds<true>(a, L);
+  __syncthreads();
+  // everything the scalar chain depends on is made wave-uniform explicitly (v_readfirstlane): the compiler cannot know that a
+  // value loaded from memory or derived from threadIdx.x >> 6 is the same in all 64 lanes, and would keep the walker's state in
+  // VGPRs behind exec-mask branches otherwise
+  auto uni = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); };
+  const uint32_t lane = threadIdx.x & 63u, wv = uni(threadIdx.x >> 6);
+  const uint32_t wave = blockIdx.x * kStragWaves + wv, nwaves = gridDim.x * kStragWaves;
+  uint32_t count = uni(a.flags[kHuffFlagStragglers]);
+  if (count > a.strag_cap) count = a.strag_cap;
+  const uint32_t nclean = uni(a.nbytes - *a.nstuffed), nbits = nclean * 8u;
+  const uint32_t nsub = (nbits + a.sub_bits - 1) / a.sub_bits;
+  const uint32_t H = (uint32_t)a.hyp_h, bpm = (uint32_t)a.blocks_per_mcu;
+  const uint32_t l_main = (uint32_t)a.hyp_main_levels;
+  uint32_t cpack = 0;
+#pragma unroll
+  for (int j = 0; j < 16; j++) cpack |= ((uint32_t)a.comp_of[j] & 3u) << (2 * j);
+  constexpr uint32_t kWords = sizeof(HuffFastTable) / 2;
+  const uint16_t* T = (const uint16_t*)L.t;
+  const uint32_t* clean32 = (const uint32_t*)a.clean;
+  uint32_t* stage = s_bytes[wv];
+  for (uint32_t idx = wave; idx < count; idx += nwaves) {
+    const uint32_t i = uni(a.strag_list[2 * idx]), hw = uni(a.strag_list[2 * idx + 1]);
+    const uint32_t h = hw & 0xffu, l0 = hw >> 8;
+    uint32_t slot = l0 * H + h;
+    const uint64_t s0 = a.hyp_state[(size_t)(i + l0) * kHuffHypSlots + slot];
+    uint32_t p = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)s0);
+    uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(s0 >> 32) & 0xffu));
+    uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(s0 >> 40) & 0xffu));
+    for (uint32_t l = l0 + 1; l <= (uint32_t)a.hyp_levels; l++) {
+      const uint32_t j = i + l;
+      if (j >= nsub) break;
+      const uint32_t end_bit = min((j + 1) * a.sub_bits, nbits);
+      uint32_t nblk = 0;
+      if (p < end_bit) {
+        // stage the words [p / 32, (end_bit + 31 + 16) / 32] of the clean stream, big-endian, zeros past its end
+        const uint32_t w0 = p >> 5, nw = ((end_bit + 63u) >> 5) - w0 + 2u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the previous level's reads of the stage are done
+        for (uint32_t d = lane; d < nw && d < (uint32_t)kStragStageWords; d += 64u) {
+          const uint32_t byte0 = (w0 + d) * 4u;
+          uint32_t v = 0;
+          if (byte0 < nclean) {
+            v = __builtin_bswap32(clean32[w0 + d]);
+            if (byte0 + 4u > nclean) v &= 0xffffffffu << (8u * (byte0 + 4u - nclean));
+          }
+          stage[d] = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        while (p < end_bit) {
+          const uint32_t q = p + lane - (w0 << 5);  // the lane's bit, relative to the stage
+          const uint32_t wi = min(q >> 5, (uint32_t)kStragStageWords - 2u);
+          const uint64_t two = ((uint64_t)stage[wi] << 32) | stage[wi + 1];
+          const uint32_t w16 = (uint32_t)(two >> (48u - (q & 31u))) & 0xffffu;
+          uint32_t ent[4];
+#pragma unroll
+          for (uint32_t t = 0; t < 4; t++) {
+            const uint32_t tb = t * kWords;
+            uint32_t e = T[tb + (w16 >> 7)];
+            const uint32_t e2 = T[tb + 512u + ((e & 0x8000u) ? (e & 31u) : 0u) * 128u + (w16 & 127u)];
+            ent[t] = (e & 0x8000u) ? e2 : e;
+          }
+          const int luma = (int)(ent[0] | (ent[1] << 16)), chroma = (int)(ent[2] | (ent[3] << 16));
+          const uint32_t lim = min(64u, end_bit - p);
+          uint32_t off = 0;
+          while (off < lim) {
+            const bool is_chroma = ((cpack >> (2u * b)) & 3u) != 0;
+            const uint32_t pair = (uint32_t)(is_chroma ? __builtin_amdgcn_readlane(chroma, (int)off) : __builtin_amdgcn_readlane(luma, (int)off));
+            const uint32_t e = (k ? pair >> 16 : pair) & 0xffffu;
+            off += e & 31u;
+            k += (e >> 5) & 127u;
+            if (k >= 64u) {
+              k = 0;
+              b++;
+              nblk++;
+              if (b == bpm) b = 0;
+            }
+          }
+          p += off;
+        }
+      }
+      const uint64_t e = pack_state(p, b, k);
+      const uint64_t* row = a.hyp_state + (size_t)j * kHuffHypSlots;
+      const uint8_t* prev = a.hyp_map + (size_t)(j - 1) * kHuffHypSlots;
+      // lane c looks at slot c: fresh (c < H), or in flight from a lockstep level m = c / H <= l_main, m < l, whose owner's link continued into it
+      bool match = false;
+      if (lane < H) match = row[lane] == e;
+      else if (lane < kHuffHypSlots && lane < l * H && lane / H <= l_main) match = prev[lane - H] == lane && row[lane] == e;
+      const uint64_t mm = __builtin_amdgcn_ballot_w64(match);
+      const size_t at = (size_t)(j - 1) * kHuffHypSlots + slot;
+      if (lane == 0) a.hyp_cnt[at] = (uint16_t)nblk;
+      if (mm != 0) {
+        if (lane == 0) a.hyp_map[at] = (uint8_t)__builtin_ctzll(mm);
+        break;
+      }
+      if (l == (uint32_t)a.hyp_levels) {  // map stays 0xff: not merged within the budget
+        if (lane == 0) atomicAdd(a.flags + 3, 1u);
+        break;
+      }
+      const uint32_t nslot = l * H + h;
+      if (lane == 0) {
+        a.hyp_state[(size_t)j * kHuffHypSlots + nslot] = e;
+        a.hyp_map[at] = (uint8_t)nslot;
+      }
+      slot = nslot;
+    }
   }
 }
 
@@ -960,6 +1194,66 @@ __global__ __launch_bounds__(1024) void dc_partial_kernel(const HuffSyncArgs a, 
   dc_block_scan(v, s_sum, tid);
   if (tid == 1023) { partial[blockIdx.x * 3] = v[0]; partial[blockIdx.x * 3 + 1] = v[1]; partial[blockIdx.x * 3 + 2] = v[2]; }
 }
+// form 2 of the write pass: the DC differences sit at [0] of every scan-order block
+__global__ __launch_bounds__(1024) void dc_partial2_kernel(const HuffSyncArgs a, int* __restrict__ partial) {
+  __shared__ int s_sum[3 * 1024];
+  const int tid = (int)threadIdx.x;
+  const uint32_t t = blockIdx.x * 1024u + (uint32_t)tid;
+  int v[3] = {0, 0, 0};
+  if (t < a.total_blocks) v[a.comp_of[t % (uint32_t)a.blocks_per_mcu]] = a.coef_scan[(size_t)t * 64];
+  dc_block_scan(v, s_sum, tid);
+  if (tid == 1023) { partial[blockIdx.x * 3] = v[0]; partial[blockIdx.x * 3 + 1] = v[1]; partial[blockIdx.x * 3 + 2] = v[2]; }
+}
+// ... and the kernel that finishes the decode: 1024 scan positions per workgroup.  DC prediction (a workgroup scan of the
+// differences on top of the chunk's carry-in), then every wave moves 64 of the chunk's blocks, two per step: a lane reads the
+// two coefficients of one natural-order pair from the block's zig-zag scratch row (one 128-byte line per block) and the wave
+// stores 2 x 128 contiguous bytes.  Dummy blocks of edge MCUs are dropped here.
+__global__ __launch_bounds__(1024) void coef_place_kernel(const HuffSyncArgs a, const int* __restrict__ partial) {
+  __shared__ int s_sum[3 * 1024];
+  __shared__ int16_t s_dc[1024];
+  __shared__ uint32_t s_dst[1024];  // component << 30 | JBLOCK index inside its array; ~0: a dummy block of an edge MCU
+  __shared__ uint8_t s_inv[64];     // natural index -> zig-zag position
+  const int tid = (int)threadIdx.x;
+  const uint32_t t0 = blockIdx.x * 1024u, t = t0 + (uint32_t)tid;
+  const uint32_t bpm = (uint32_t)a.blocks_per_mcu;
+  if (tid < 64) s_inv[a.zigzag[tid]] = (uint8_t)tid;  // zigzag[]: zig-zag position -> natural index
+  int v[3] = {0, 0, 0};
+  int c = 0;
+  uint32_t where = 0xffffffffu;
+  if (t < a.total_blocks) {
+    const uint32_t m = t / bpm, j = t - m * bpm;
+    c = a.comp_of[j];
+    v[c] = a.coef_scan[(size_t)t * 64];
+    const int my = (int)(m / (uint32_t)a.mcus_per_row), mx = (int)(m - (uint32_t)my * (uint32_t)a.mcus_per_row);
+    const int jj = (int)j - a.first_blk[c];
+    const int by = my * a.vs[c] + jj / a.hs[c], bx = mx * a.hs[c] + jj % a.hs[c];
+    if (by < a.bh[c] && bx < a.bw[c]) where = ((uint32_t)c << 30) | ((uint32_t)by * (uint32_t)a.bw[c] + (uint32_t)bx);
+  }
+  s_dst[tid] = where;
+  dc_block_scan(v, s_sum, tid);
+  s_dc[tid] = (int16_t)(partial[blockIdx.x * 3 + c] + v[c]);
+  __syncthreads();
+  const uint32_t lane = (uint32_t)tid & 63u, wv = (uint32_t)tid >> 6;
+  const uint32_t half = lane >> 5, n0 = (lane & 31u) * 2u;  // the lane's natural-order pair inside its block
+  const uint32_t z0 = s_inv[n0], z1 = s_inv[n0 + 1u];
+  int16_t* const c0 = a.coef[0];
+  int16_t* const c1 = a.coef[1];
+  int16_t* const c2 = a.coef[2];
+#pragma unroll 4
+  for (uint32_t s = 0; s < 32u; s++) {
+    const uint32_t loc = wv * 64u + s * 2u + half;
+    const uint32_t ent = s_dst[loc];
+    if (ent == 0xffffffffu) continue;
+    const int16_t* src = a.coef_scan + (size_t)(t0 + loc) * 64;
+    uint32_t lo = (uint16_t)src[z0];
+    const uint32_t hi = (uint16_t)src[z1];
+    if (n0 == 0) lo = (uint16_t)s_dc[loc];
+    const uint32_t cc = ent >> 30;
+    int16_t* base = cc == 0 ? c0 : (cc == 1 ? c1 : c2);
+    uint32_t* dst = (uint32_t*)(base + (size_t)(ent & 0x3fffffffu) * 64);
+    dst[lane & 31u] = lo | (hi << 16);
+  }
+}
 __global__ __launch_bounds__(1024) void dc_scan_partials_kernel(int* __restrict__ partial, int nchunks) {  // exclusive, in place
   __shared__ int s_sum[3 * 1024];
   const int tid = (int)threadIdx.x;
@@ -1051,6 +1345,34 @@ static void launch_write(const HuffSyncArgs& a, uint32_t nsub, int final_buf, hi
 
 int huff_sync_chunks(uint64_t nbytes) { return (int)((nbytes + kChunk - 1) / kChunk); }
 
+namespace {
+__global__ __launch_bounds__(256) void stray_marker_kernel(const uint8_t* __restrict__ data, uint32_t n, uint32_t* __restrict__ flag) {
+  const uint32_t base = (blockIdx.x * 256u + threadIdx.x) * 16u;
+  if (base >= n) return;
+  bool found = false;
+  if (base + 17u <= n && ((uintptr_t)(data + base) & 15u) == 0) {
+    const uint4 v = *(const uint4*)(data + base);
+    const uint32_t w[5] = {v.x, v.y, v.z, v.w, (uint32_t)data[base + 16u]};
+#pragma unroll
+    for (uint32_t i = 0; i < 16; i++) {
+      const uint32_t c0 = (w[i >> 2] >> (8u * (i & 3u))) & 0xffu, c1 = (w[(i + 1u) >> 2] >> (8u * ((i + 1u) & 3u))) & 0xffu;
+      found = found || (c0 == 0xffu && c1 != 0u && c1 != 0xffu && (c1 & 0xf8u) != 0xd0u);
+    }
+  } else {
+    for (uint32_t i = base; i < base + 16u && i + 1u < n; i++) {
+      const uint32_t c0 = data[i], c1 = data[i + 1u];
+      found = found || (c0 == 0xffu && c1 != 0u && c1 != 0xffu && (c1 & 0xf8u) != 0xd0u);
+    }
+  }
+  if (found) *(volatile uint32_t*)flag = 1u;  // a plain store: the word may be pinned host memory (no PCIe atomics needed)
+}
+}  // namespace
+hipError_t launch_stray_marker_check(const uint8_t* data, uint32_t nbytes, uint32_t* flag, hipStream_t s) {
+  const int grid = (int)((nbytes + 4095u) / 4096u);
+  hipLaunchKernelGGL(stray_marker_kernel, dim3(grid), dim3(256), 0, s, data, nbytes, flag);
+  return hipGetLastError();
+}
+
 // Step 1 (unstuff): chunk_counts becomes the exclusive scan, *nstuffed_dev the number of dropped bytes.
 // rst_map != nullptr: the stream has restart markers; they are dropped as well, rst_map (zero-initialised, one bit per byte)
 // gets the interval starts and rst_partial[chunk * 3 ..] the markers' count and sequence sums.
@@ -1063,6 +1385,21 @@ hipError_t launch_huffman_unstuff(const uint8_t* data, uint32_t nbytes, uint32_t
   if (rst_map) hipLaunchKernelGGL(unstuff_compact_kernel<true>, dim3(nchunks), dim3(256), 0, s, data, nbytes, (const uint32_t*)chunk_counts, clean, rst_map, rst_partial);
   else hipLaunchKernelGGL(unstuff_compact_kernel<false>, dim3(nchunks), dim3(256), 0, s, data, nbytes, (const uint32_t*)chunk_counts, clean, rst_map, rst_partial);
   return hipGetLastError();
+}
+static void launch_write2(const HuffSyncArgs& a, uint32_t nsub, int final_buf, hipStream_t s) {
+  const size_t per_wave = (size_t)64 * ((a.sub_bits >> 3) + 4) + 64;
+  const int waves = per_wave * 4 <= (20u << 10) ? 4 : (per_wave * 2 <= (20u << 10) ? 2 : 1);
+  const size_t lds = per_wave * waves;
+  const int threads = 64 * waves;
+  const int grid = (int)((nsub + threads - 1) / threads);
+  if (lds > (20u << 10)) (void)hipFuncSetAttribute((const void*)sync_write2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(sync_write2_kernel, dim3(grid), dim3(threads), lds, s, a, final_buf);
+}
+static void launch_place(const HuffSyncArgs& a, int* dc_partial, hipStream_t s) {
+  const int nch = (int)((a.total_blocks + 1023) / 1024);
+  hipLaunchKernelGGL(dc_partial2_kernel, dim3(nch), dim3(1024), 0, s, a, dc_partial);
+  hipLaunchKernelGGL(dc_scan_partials_kernel, dim3(1), dim3(1024), 0, s, dc_partial, nch);
+  hipLaunchKernelGGL(coef_place_kernel, dim3(nch), dim3(1024), 0, s, a, (const int*)dc_partial);
 }
 static void launch_dc(const HuffSyncArgs& a, int* dc_partial, hipStream_t s) {
   const int nch = (int)((a.total_blocks + 1023) / 1024);
@@ -1091,8 +1428,13 @@ hipError_t launch_huffman_decode_sync(const HuffSyncArgs& a, int max_rounds, int
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(nt), dim3(kScanThreads), 0, s, a.nblk, (int)nsub, a.scan_tmp);
     if (nt > 1) hipLaunchKernelGGL(scan_add_kernel, dim3(nt), dim3(kScanThreads), 0, s, a.nblk, (int)nsub, (const uint32_t*)a.scan_tmp);
   }
-  launch_write(a, nsub, *final_buf, s);
-  launch_dc(a, dc_partial, s);
+  if (a.coef_scan && !a.rst_map) {
+    launch_write2(a, nsub, *final_buf, s);
+    launch_place(a, dc_partial, s);
+  } else {
+    launch_write(a, nsub, *final_buf, s);
+    launch_dc(a, dc_partial, s);
+  }
   return hipGetLastError();
 }
 
@@ -1128,6 +1470,14 @@ hipError_t launch_huffman_decode_hyp(const HuffSyncArgs& a, int* dc_partial, uin
   static const bool qmerge = !(getenv("UHDR_HIP_HUFF_QMERGE") && atoi(getenv("UHDR_HIP_HUFF_QMERGE")) == 0);
   if (qmerge) hipLaunchKernelGGL(hyp_pass1q_kernel, dim3(grid), dim3(threads), lds1, s, a);
   else hipLaunchKernelGGL(hyp_pass1_kernel, dim3(grid), dim3(threads), lds1, s, a);
+  if (qmerge && a.hyp_main_levels > 0 && a.hyp_main_levels < a.hyp_levels) {
+    // the paths still alive after the lockstep levels, one wave each; the grid is sized for a thick tail (a wave takes the
+    // entries wave, wave + nwaves, ...), surplus waves leave at once
+    int sgrid = (int)((nsub * (uint32_t)a.hyp_h / 16u + kStragWaves - 1) / kStragWaves);
+    if (sgrid < 64) sgrid = 64;
+    if (sgrid > 4096) sgrid = 4096;
+    hipLaunchKernelGGL(hyp_straggler_kernel, dim3(sgrid), dim3(64 * kStragWaves), 0, s, a);
+  }
   mark();
   const int ntiles = (int)((nsub + kChainTile - 1) / kChainTile);
   uint8_t* chain_entry = chain_tiles + (size_t)ntiles * kHuffHypSlots;
@@ -1141,13 +1491,19 @@ hipError_t launch_huffman_decode_hyp(const HuffSyncArgs& a, int* dc_partial, uin
     if (nt > 1) hipLaunchKernelGGL(scan_add_kernel, dim3(nt), dim3(kScanThreads), 0, s, a.nblk, (int)nsub, (const uint32_t*)a.scan_tmp);
   }
   mark();
-  launch_write(a, nsub, 0, s);
-  mark();
-  launch_dc(a, dc_partial, s);
+  if (a.coef_scan && !a.rst_map) {
+    launch_write2(a, nsub, 0, s);
+    mark();
+    launch_place(a, dc_partial, s);
+  } else {
+    launch_write(a, nsub, 0, s);
+    mark();
+    launch_dc(a, dc_partial, s);
+  }
   mark();
   if (dbg) {
     (void)hipStreamSynchronize(s);
-    static const char* names[] = {"pass0", "pass1", "chain x3", "nblk scan", "write", "dc x3"};
+    static const char* names[] = {"pass0", "pass1 (+ stragglers)", "chain x3", "nblk scan", "write", "dc x3 / place", "-"};
     fprintf(stderr, "uhdr_hip: hypothesis decode kernels:");
     for (int i = 0; i + 1 < nev; i++) {
       float ms = 0;

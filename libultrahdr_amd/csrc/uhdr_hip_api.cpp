@@ -8,9 +8,11 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "exact_math.h"
@@ -105,6 +107,7 @@ struct uhdr_hip_ctx {
   DeviceBuf scratch[8];
   uhdr_hip_stats_t stats = {};    // uhdr_hip_get_stats: which route the entropy stage took, call by call
   bool huff_serial_ok = true;  // uhdr_hip_jpeg_decode_scan clears it: a large marker-less scan that the parallel decoder cannot settle goes back to the caller
+  DeviceBuf enc[3];  // uhdr_hip_encode_api1_scans: the six coefficient arrays | base scan | map scan
   DeviceBuf jpg[6];  // uhdr_hip_jpeg_decode_scan: entropy-coded data | coefficient arrays x 3 | decoded planes / pixels
   // uhdr_hip_resident_begin .. _end: the images uhdr_hip_jpeg_decode_scan wrote to the caller's buffers stay on the device,
   // keyed by those host pointers, so that the host variant of uhdr_hip_apply_gainmap does not upload them again
@@ -128,6 +131,21 @@ struct uhdr_hip_ctx {
   } resident[2];
   // entropy decode: the subsequence size a scan with this many blocks per MCU settled at after a lost first attempt
   struct HuffHint { uint32_t sub_bits = 0, bits_per_block = 0; } huff_hint[16];
+  // entropy decode (round 5): the decode forms of the last DHT set seen stay on the device (every file of one encoder carries the
+  // same four tables: building the five forms and uploading 73 KB per call was 40 us of host time), keyed by the DHT bytes
+  struct HuffTabCache {
+    bool valid = false, fast_ok = false;
+    uint8_t key[4 * (17 + 256)] = {};
+    DeviceBuf dev;  // HuffDecTable x 4 | HuffFastTable x 8 (symbol form, tracking form) | value form 4 x kHuffValWords words
+  } huff_tabs;
+  // host -> device staging of large caller-owned (pageable) planes (round 5, fast_h2d): pinned ring + the event of its last copy
+  struct PinArena {
+    void* p = nullptr;
+    size_t cap = 0, off = 0;
+    hipEvent_t ev = nullptr;
+    bool ev_pending = false;
+  } pin;
+  uint32_t* h_flags = nullptr;  // pinned: status words of the entropy decoder come back here (a pageable read-back is a staged, blocking copy)
   bool resident_on = false;
   bool resident_lazy = false;
   unsigned int resident_next = 0;
@@ -329,6 +347,78 @@ void resident_drop(uhdr_hip_ctx* c, const void* host_plane) {  // any plane of a
     if (r.valid && (r.host[0] == host_plane || r.host[1] == host_plane || r.host[2] == host_plane)) resident_retire(c, r, true);
 }
 
+// Host -> device copy of a large caller-owned buffer.  hipMemcpyAsync from pageable memory is staged by the runtime on the
+// calling thread: one core's memcpy into its bounce buffers, ~7 GB/s end to end (37 MB of P010 + 4:2:0 planes: 5.3 of the 6.1 ms
+// of a 4K uhdr_encode, profiles/r04_api_trace.txt).  Here a few threads copy 1 MiB pieces into a pinned ring while the calling
+// thread hands every finished run of pieces to the DMA engine: the link, not a core, sets the pace.  The reference itself runs
+// its per-pixel loops on up to four threads (JobQueue users, jpegr.cpp:845-864); so does this.  UHDR_HIP_UPLOAD_THREADS=0: the
+// runtime's path.
+uhdr_error_info_t fast_h2d(uhdr_hip_ctx* c, void* dst, const void* src, size_t bytes) {
+  static const int nthreads = [] {
+    const char* e = getenv("UHDR_HIP_UPLOAD_THREADS");
+    int v = e ? atoi(e) : 4;
+    const unsigned hw = std::thread::hardware_concurrency();
+    if (hw && (unsigned)v > hw) v = (int)hw;
+    return v < 0 ? 0 : (v > 16 ? 16 : v);
+  }();
+  constexpr size_t kPiece = (size_t)1 << 20;
+  if (nthreads == 0 || bytes < 4 * kPiece) {
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    return ok_status();
+  }
+  uhdr_hip_ctx::PinArena& pa = c->pin;
+  const size_t need = (bytes + 4095) & ~(size_t)4095;
+  if (!pa.ev) HIP_TRY(hipEventCreateWithFlags(&pa.ev, hipEventDisableTiming));
+  if (pa.cap < need) {
+    if (pa.ev_pending) { HIP_TRY(hipEventSynchronize(pa.ev)); pa.ev_pending = false; }
+    if (pa.p) (void)hipHostFree(pa.p);
+    pa.p = nullptr;
+    pa.cap = pa.off = 0;
+    size_t want = need + need / 2;
+    if (want < ((size_t)64 << 20)) want = (size_t)64 << 20;
+    HIP_TRY(hipHostMalloc(&pa.p, want, hipHostMallocDefault));
+    pa.cap = want;
+  }
+  if (pa.off + need > pa.cap) {  // wrap: everything copied out of the ring so far must have left it
+    if (pa.ev_pending) { HIP_TRY(hipEventSynchronize(pa.ev)); pa.ev_pending = false; }
+    pa.off = 0;
+  }
+  uint8_t* stage = (uint8_t*)pa.p + pa.off;
+  const size_t npieces = (bytes + kPiece - 1) / kPiece;
+  std::unique_ptr<std::atomic<unsigned char>[]> done(new std::atomic<unsigned char>[npieces]);
+  for (size_t i = 0; i < npieces; i++) done[i].store(0, std::memory_order_relaxed);
+  std::atomic<size_t> next{0};
+  auto work = [&]() {
+    for (;;) {
+      const size_t i = next.fetch_add(1, std::memory_order_relaxed);
+      if (i >= npieces) return;
+      const size_t o = i * kPiece, n = o + kPiece <= bytes ? kPiece : bytes - o;
+      memcpy(stage + o, (const uint8_t*)src + o, n);
+      done[i].store(1, std::memory_order_release);
+    }
+  };
+  std::vector<std::thread> pool;
+  const int nt = (size_t)nthreads < npieces ? nthreads : (int)npieces;
+  pool.reserve((size_t)nt);
+  for (int t = 0; t < nt; t++) pool.emplace_back(work);
+  hipError_t err = hipSuccess;
+  size_t i = 0;
+  while (i < npieces) {
+    while (!done[i].load(std::memory_order_acquire)) std::this_thread::yield();
+    size_t j = i + 1;
+    while (j < npieces && j - i < 8 && done[j].load(std::memory_order_acquire)) j++;
+    const size_t o = i * kPiece, n = (j * kPiece <= bytes ? j * kPiece : bytes) - o;
+    if (err == hipSuccess) err = hipMemcpyAsync((uint8_t*)dst + o, stage + o, n, hipMemcpyHostToDevice, c->stream);
+    i = j;
+  }
+  for (auto& t : pool) t.join();
+  HIP_TRY(err);
+  HIP_TRY(hipEventRecord(pa.ev, c->stream));
+  pa.ev_pending = true;
+  pa.off += need;
+  return ok_status();
+}
+
 uhdr_error_info_t stage_in(uhdr_hip_ctx* c, int slot, const uhdr_raw_image_t* host, uhdr_raw_image_t* dev,
                            bool upload) {
   if (!upload && c->resident_on) resident_drop(c, host->planes[0]);  // an output: stage_out will overwrite the host planes
@@ -364,7 +454,7 @@ uhdr_error_info_t stage_in(uhdr_hip_ctx* c, int slot, const uhdr_raw_image_t* ho
   for (int pl = 0; pl < 3; pl++) {
     size_t b = plane_bytes(host, pl);
     dev->planes[pl] = b ? (char*)c->scratch[slot].p + off[pl] : nullptr;
-    if (b && upload) HIP_TRY(hipMemcpyAsync(dev->planes[pl], host->planes[pl], b, hipMemcpyHostToDevice, c->stream));
+    if (b && upload) UHDR_TRY(fast_h2d(c, dev->planes[pl], host->planes[pl], b));
   }
   return ok_status();
 }
@@ -681,6 +771,7 @@ void uhdr_hip_destroy(uhdr_hip_ctx_t* c) {
   }
   for (auto& b : c->scratch) if (b.p) (void)hipFree(b.p);
   for (auto& b : c->jpg) if (b.p) (void)hipFree(b.p);
+  for (auto& b : c->enc) if (b.p) (void)hipFree(b.p);
   for (auto& r : c->resident) if (r.buf.p) (void)hipFree(r.buf.p);
   if (c->pending.buf.p) (void)hipFree(c->pending.buf.p);
   if (c->pending.tmp.p) (void)hipFree(c->pending.tmp.p);
@@ -695,6 +786,10 @@ void uhdr_hip_destroy(uhdr_hip_ctx_t* c) {
   if (c->affine.p) (void)hipFree(c->affine.p);
   if (c->d_srgb_of_byte) (void)hipFree(c->d_srgb_of_byte);
   if (c->h_mm) (void)hipHostFree(c->h_mm);
+  if (c->h_flags) (void)hipHostFree(c->h_flags);
+  if (c->pin.p) (void)hipHostFree(c->pin.p);
+  if (c->pin.ev) (void)hipEventDestroy(c->pin.ev);
+  if (c->huff_tabs.dev.p) (void)hipFree(c->huff_tabs.dev.p);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -2322,6 +2417,93 @@ uhdr_error_info_t uhdr_hip_encode_api1_fused_dev(uhdr_hip_ctx_t* c, const uhdr_r
   return uhdr_hip_generate_gainmap_finalize_md(cfg, hdr->ct, use_base_cg, mm, md);
 }
 
+// JpegR::encodeJPEGR API-1 (jpegr.cpp:253-316) from its two raw intents to its two entropy-coded scans in ONE entry point: the
+// intents go up once (fast_h2d), the fused chain leaves coefficient blocks in HBM, the marker-less Huffman coder turns them into
+// the reference's bytes, and only those come down.  What the facade's seam at encodeJPEGR calls.
+uhdr_error_info_t uhdr_hip_encode_api1_scans(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* sdr, const uhdr_raw_image_t* hdr, const uhdr_hip_encode_cfg_t* cfg,
+                                             uhdr_color_gamut_t base_encoding, const uint16_t qt_base[2][64], const uint16_t qt_map[2][64],
+                                             uhdr_gainmap_metadata_t* md, uhdr_raw_image_t* gainmap_desc, uint8_t* base_scan, size_t base_capacity,
+                                             size_t* base_bytes, uint8_t* map_scan, size_t map_capacity, size_t* map_bytes) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  if (!sdr || !hdr || !cfg || !qt_base || !qt_map || !md || !base_scan || !map_scan || !base_bytes || !map_bytes)
+    return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument");
+  // what the fused chain would decline is declined before 37 MB go up for nothing (the same conditions, uhdr_hip_encode_api1_fused_dev)
+  if (sdr->fmt != UHDR_IMG_FMT_12bppYCbCr420 || sdr->w % 16 || sdr->h % 16 || sdr->w == 0 || sdr->h == 0)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "the fused API-1 chain takes a UHDR_IMG_FMT_12bppYCbCr420 base image whose dimensions are multiples of 16 "
+                      "(received format %d, %ux%u); use the operators", sdr->fmt, sdr->w, sdr->h);
+  if (cfg->preset == UHDR_USAGE_REALTIME) return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "the fused API-1 chain is the two-pass (best quality) encode");
+  if (cfg->gamma != 1.0f) return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "the fused API-1 chain needs gain-map gamma 1 (received %f)", cfg->gamma);
+  const int scale = cfg->map_dimension_scale_factor;
+  if (scale < 1 || sdr->w / (unsigned)scale == 0 || sdr->h / (unsigned)scale == 0 || (sdr->w / (unsigned)scale) % 8 || (sdr->h / (unsigned)scale) % 8)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "the fused API-1 chain needs map dimensions that are multiples of 8 (scale factor %d on %ux%u)", scale, sdr->w, sdr->h);
+  if (hdr->w != sdr->w || hdr->h != sdr->h)
+    return err_status(UHDR_CODEC_INVALID_PARAM, "sdr intent resolution %ux%u and hdr intent resolution %ux%u do not match", sdr->w, sdr->h, hdr->w, hdr->h);
+  if (c->comm != nullptr || c->comm_custom) return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "a context with a communicator encodes stripes (uhdr_hip_encode_api1_fused_dev)");
+  UHDR_TRY(validate_image(sdr, "sdr intent"));
+  UHDR_TRY(validate_image(hdr, "hdr intent"));
+  HIP_TRY(hipSetDevice(c->device));
+  const unsigned w = sdr->w, h = sdr->h, mw = w / (unsigned)scale, mh = h / (unsigned)scale;
+  const int nch = cfg->use_multi_channel_gainmap ? 3 : 1;
+  uhdr_raw_image_t ds, dh;
+  if (c->resident_on) UHDR_TRY(resident_write_back_all(c));
+  UHDR_TRY(stage_in(c, 0, sdr, &ds, true));
+  UHDR_TRY(stage_in(c, 1, hdr, &dh, true));
+  // coefficient arrays: base Y, Cb, Cr, then the map's 1 or 3 components; 256-byte aligned
+  const size_t nb[3] = {(size_t)(w / 8) * (h / 8), (size_t)(w / 16) * (h / 16), (size_t)(w / 16) * (h / 16)};
+  const size_t nm = (size_t)(mw / 8) * (mh / 8);
+  size_t off = 0, o_base[3], o_map[3] = {0, 0, 0};
+  for (int i = 0; i < 3; i++) { o_base[i] = off; off += (nb[i] * 128 + 255) & ~(size_t)255; }
+  for (int i = 0; i < nch; i++) { o_map[i] = off; off += (nm * 128 + 255) & ~(size_t)255; }
+  UHDR_TRY(ensure(c->enc[0], off));
+  uhdr_hip_api1_blocks_t blocks;
+  memset(&blocks, 0, sizeof blocks);
+  for (int i = 0; i < 3; i++) blocks.base_coef[i] = (int16_t*)((uint8_t*)c->enc[0].p + o_base[i]);
+  for (int i = 0; i < nch; i++) blocks.map_coef[i] = (int16_t*)((uint8_t*)c->enc[0].p + o_map[i]);
+  uhdr_raw_image_t gm;
+  memset(&gm, 0, sizeof gm);
+  UHDR_TRY(uhdr_hip_encode_api1_fused_dev(c, &ds, &dh, cfg, base_encoding, qt_base, qt_map, &blocks, md, nullptr));
+  if (gainmap_desc) {  // what generateGainMap's freshly allocated image would say (jpegr.cpp:714-716); planes untouched
+    gainmap_desc->fmt = nch == 3 ? UHDR_IMG_FMT_24bppRGB888 : UHDR_IMG_FMT_8bppYCbCr400;
+    gainmap_desc->cg = hdr->cg; gainmap_desc->ct = hdr->ct; gainmap_desc->range = hdr->range;
+    gainmap_desc->w = mw; gainmap_desc->h = mh;
+  }
+  // the two scans: device buffers as large as the caller's, then one copy each
+  uhdr_hip_jpeg_scan_t sb, sm;
+  memset(&sb, 0, sizeof sb);
+  memset(&sm, 0, sizeof sm);
+  sb.num_components = 3;
+  sb.w = w; sb.h = h;
+  for (int i = 0; i < 3; i++) {
+    sb.coef[i] = blocks.base_coef[i];
+    sb.blocks_w[i] = (int)(i ? w / 16 : w / 8);
+    sb.blocks_h[i] = (int)(i ? h / 16 : h / 8);
+    sb.h_samp[i] = sb.v_samp[i] = i ? 1 : 2;
+  }
+  sm.num_components = nch;
+  sm.w = mw; sm.h = mh;
+  for (int i = 0; i < nch; i++) {
+    sm.coef[i] = blocks.map_coef[i];
+    sm.blocks_w[i] = (int)(mw / 8);
+    sm.blocks_h[i] = (int)(mh / 8);
+    sm.h_samp[i] = sm.v_samp[i] = 1;
+  }
+  if (base_capacity > 0xFFFFFFF0u) base_capacity = 0xFFFFFFF0u;
+  if (map_capacity > 0xFFFFFFF0u) map_capacity = 0xFFFFFFF0u;
+  UHDR_TRY(ensure(c->enc[1], base_capacity + 64));
+  UHDR_TRY(ensure(c->enc[2], map_capacity + 64));
+  size_t nbs = 0, nms = 0;
+  const uhdr_error_info_t eb = uhdr_hip_huffman_encode_dev(c, &sb, (uint8_t*)c->enc[1].p, base_capacity, &nbs);
+  *base_bytes = nbs;
+  if (eb.error_code != UHDR_CODEC_OK) { *map_bytes = 0; return eb; }
+  HIP_TRY(hipMemcpyAsync(base_scan, c->enc[1].p, nbs, hipMemcpyDeviceToHost, c->stream));  // overlaps the map's entropy coding
+  const uhdr_error_info_t em = uhdr_hip_huffman_encode_dev(c, &sm, (uint8_t*)c->enc[2].p, map_capacity, &nms);
+  *map_bytes = nms;
+  if (em.error_code != UHDR_CODEC_OK) { (void)hipStreamSynchronize(c->stream); return em; }
+  HIP_TRY(hipMemcpyAsync(map_scan, c->enc[2].p, nms, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return ok_status();
+}
+
 // -------------------------------------------------------------------------------------------------
 // copy_raw_image (gainmapmath.cpp:1492-1613), device to device
 // -------------------------------------------------------------------------------------------------
@@ -2778,20 +2960,52 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
     HIP_TRY(hipStreamSynchronize(c->stream));
   }
   const DbgClock dbg;
-  std::vector<HuffDecTable> tabs(4);
-  std::vector<HuffFastTable> ftabs(4);
-  bool fast_ok = true;
-  for (int t = 0; t < 4; t++) {
-    uint8_t bits[17], vals[256];
-    if (tables) {
-      memcpy(bits, tables->bits[t], 17);
-      memcpy(vals, tables->vals[t], 256);
-    } else {
-      host::jpeg_std_huff_table(t & 1, t >> 1, bits, vals);
+  // the five decode forms of the file's tables, resident on the device (huff_tabs: rebuilt only when the DHT bytes change)
+  constexpr size_t kTabDec = 0, kTabFast = (sizeof(HuffDecTable) * 4 + 255) & ~(size_t)255,
+                   kTabVal = (kTabFast + sizeof(HuffFastTable) * 8 + 255) & ~(size_t)255, kTabBytes = kTabVal + (size_t)4 * kHuffValWords * 4;
+  {
+    uint8_t key[4 * (17 + 256)];
+    for (int t = 0; t < 4; t++) {
+      uint8_t* bits = key + (size_t)t * (17 + 256);
+      uint8_t* vals = bits + 17;
+      if (tables) {
+        memcpy(bits, tables->bits[t], 17);
+        memcpy(vals, tables->vals[t], 256);
+      } else {
+        memset(bits, 0, 17 + 256);
+        host::jpeg_std_huff_table(t & 1, t >> 1, bits, vals);
+      }
     }
-    if (!make_dec_table(bits, vals, &tabs[(size_t)t])) return err_status(UHDR_CODEC_INVALID_PARAM, "Huffman table %d is not a valid DHT table", t);
-    fast_ok = make_fast_table(bits, vals, &ftabs[(size_t)t]) && fast_ok;
+    uhdr_hip_ctx::HuffTabCache& hc = c->huff_tabs;
+    if (!hc.valid || memcmp(hc.key, key, sizeof key) != 0) {
+      hc.valid = false;
+      std::vector<HuffDecTable> tabs(4);
+      std::vector<HuffFastTable> ftabs(8);
+      std::vector<uint32_t> vtabs((size_t)4 * kHuffValWords);
+      bool fast_ok = true;
+      for (int t = 0; t < 4; t++) {
+        const uint8_t* bits = key + (size_t)t * (17 + 256);
+        if (!make_dec_table(bits, bits + 17, &tabs[(size_t)t])) return err_status(UHDR_CODEC_INVALID_PARAM, "Huffman table %d is not a valid DHT table", t);
+        fast_ok = make_fast_table(bits, bits + 17, &ftabs[(size_t)t]) && fast_ok;
+      }
+      if (fast_ok)
+        for (int t = 0; t < 4; t++) {
+          make_track_table(ftabs[(size_t)t], (t & 1) == 0, &ftabs[(size_t)t + 4]);
+          make_value_table(ftabs[(size_t)t], (t & 1) == 0, vtabs.data() + (size_t)t * kHuffValWords);
+        }
+      UHDR_TRY(ensure(hc.dev, kTabBytes));
+      HIP_TRY(hipStreamSynchronize(c->stream));  // nothing in flight reads the old tables
+      HIP_TRY(hipMemcpy((uint8_t*)hc.dev.p + kTabDec, tabs.data(), sizeof(HuffDecTable) * 4, hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy((uint8_t*)hc.dev.p + kTabFast, ftabs.data(), sizeof(HuffFastTable) * 8, hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy((uint8_t*)hc.dev.p + kTabVal, vtabs.data(), vtabs.size() * 4, hipMemcpyHostToDevice));
+      memcpy(hc.key, key, sizeof key);
+      hc.fast_ok = fast_ok;
+      hc.valid = true;
+    }
   }
+  const bool fast_ok = c->huff_tabs.fast_ok;
+  const uint8_t* tabs_dev = (const uint8_t*)c->huff_tabs.dev.p;
+  if (!c->h_flags) HIP_TRY(hipHostMalloc((void**)&c->h_flags, 64 * sizeof(uint32_t), hipHostMallocDefault));
   HuffDecArgs a;
   memset(&a, 0, sizeof a);
   a.ncomp = sc->num_components;
@@ -2809,23 +3023,28 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
   a.data = data;
   a.nbytes = (uint32_t)data_bytes;
   a.zigzag = (const uint8_t*)(c->d_huff + host::kHuffTabWords);
-  // scratch: tables | status[2] | chunk counts | starts | ends
+  // scratch: status[4] | chunk counts | starts | ends
   const int nchunks = huff_marker_chunks(data_bytes);
-  const size_t tab_bytes = sizeof(HuffDecTable) * 4;
-  const size_t need = tab_bytes + 16 + ((size_t)nchunks + 2 * (size_t)a.nseg) * sizeof(uint32_t);
+  const size_t need = 16 + ((size_t)nchunks + 2 * (size_t)a.nseg) * sizeof(uint32_t);
   UHDR_TRY(ensure(c->scratch[5], need));
   uint8_t* base = (uint8_t*)c->scratch[5].p;
-  a.tabs = (const HuffDecTable*)base;
-  a.status = (uint32_t*)(base + tab_bytes);
+  a.tabs = (const HuffDecTable*)(tabs_dev + kTabDec);
+  a.status = (uint32_t*)base;
   uint32_t* counts = a.status + 4;
   uint32_t* starts = counts + nchunks;
   uint32_t* ends = starts + a.nseg;
   a.starts = starts;
   a.ends = ends;
-  dbg.mark("huffman_decode_dev: tables built");
-  HIP_TRY(hipMemcpyAsync(base, tabs.data(), tab_bytes, hipMemcpyHostToDevice, c->stream));
+  dbg.mark("huffman_decode_dev: tables ready");
   HIP_TRY(hipMemsetAsync(a.status, 0, 16, c->stream));
-  for (int i = 0; i < a.ncomp; i++) HIP_TRY(hipMemsetAsync(a.coef[i], 0, zero_bytes[i], c->stream));
+  const bool rst_sync = a.nseg > 1 && data_bytes / (size_t)a.nseg >= 320 && !getenv("UHDR_HIP_HUFF_RST_INTERVALS");
+  const bool try_sync = (a.nseg == 1 || rst_sync) && data_bytes >= 4096 && data_bytes < ((size_t)1 << 29) && fast_ok && !getenv("UHDR_HIP_HUFF_SERIAL") && bpm <= 16;
+  // write pass, form 2 (marker-less scans): a scan-order scratch takes the zero fill, the JBLOCK arrays are written whole
+  static const int write_form = [] { const char* e = getenv("UHDR_HIP_HUFF_WRITE"); return e ? atoi(e) : 2; }();
+  const bool form2 = try_sync && !rst_sync && write_form != 1;
+  bool coef_zeroed = !form2;  // the interval / single-lane decoder below stores into zero-initialised arrays
+  if (!form2)
+    for (int i = 0; i < a.ncomp; i++) HIP_TRY(hipMemsetAsync(a.coef[i], 0, zero_bytes[i], c->stream));
   // A scan without restart markers (every file the reference writes) is ONE interval: the per-interval kernel would
   // decode it on a single lane.  The self-synchronising decoder (huffman_decode_sync.hip) parallelises it; should its
   // fixed-point search not settle within the round budget (never seen; pathological streams), the serial kernel runs.
@@ -2835,8 +3054,7 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
   // device idle (3240 intervals of 1 KB in a 4K file with ri = 10: 1081 us on 51 wavefronts): the unstuff pass drops the
   // markers, the decoders hop over the padding bits at the flagged interval starts and the DC scan starts over there
   // (huffman_decode_sync.hip: restart_jump).  Short intervals (a few hundred bytes) are faster one lane each.
-  const bool rst_sync = a.nseg > 1 && data_bytes / (size_t)a.nseg >= 320 && !getenv("UHDR_HIP_HUFF_RST_INTERVALS");
-  if ((a.nseg == 1 || rst_sync) && data_bytes >= 4096 && data_bytes < ((size_t)1 << 29) && fast_ok && !getenv("UHDR_HIP_HUFF_SERIAL")) {
+  if (try_sync) {
     // Subsequence size: a power of two >= 256 bits (the lanes' chunks are staged in LDS: 64 x sub_bits / 8 bytes per wave).
     // Attempts, in order: the hypothesis scheme with seven (4:2:0; up to fifteen for fewer blocks per MCU) overflow levels at 512 bits (4K q95 photo-like data: 390 us) -- denser
     // streams start at 2048 / 4096 bits --, then at doubled sizes up to 4096 bits, then the rounds at 1024 bits.
@@ -2900,6 +3118,10 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
     const size_t o_ch = use_hyp ? take(huff_hyp_chain_bytes(data_bytes, sub_bits, &chain_tiles_off)) : 0;  // sized for the smallest subsequences
     (void)chain_tiles_off;
     const size_t o_ds = rst_sync ? take((size_t)a.nseg * 12) : 0, o_rp = rst_sync ? take((size_t)nch * 12) : 0;
+    // round 5: the straggler list of pass 1 (every path could end up on it) and the scan-order coefficient scratch of write form 2
+    const size_t o_sl = use_hyp ? take((size_t)nsub * (size_t)bpm * 8) : 0;
+    const size_t scan_bytes = form2 ? (size_t)total_blocks * 64 * sizeof(int16_t) : 0;
+    const size_t o_cs = form2 ? take(scan_bytes + 256) : 0;
     UHDR_TRY(ensure(c->scratch[6], off));
     uint8_t* sb = (uint8_t*)c->scratch[6].p;
     HuffSyncArgs y;
@@ -2931,27 +3153,35 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
       y.first_blk[i] = j;
       for (int k = 0; k < a.hs[i] * a.vs[i] && j < 16; k++) y.comp_of[j++] = (uint8_t)i;
     }
-    y.ftabs = (const HuffFastTable*)(sb + o_ft);
+    y.ftabs = (const HuffFastTable*)(tabs_dev + kTabFast);
     y.ttabs = y.ftabs + 4;
-    y.vtabs = (const uint32_t*)(sb + o_vt);
+    y.vtabs = (const uint32_t*)(tabs_dev + kTabVal);
     y.zigzag = a.zigzag;
+    (void)o_ft; (void)o_vt;
+    if (use_hyp) {
+      y.strag_list = (uint32_t*)(sb + o_sl);
+      y.strag_cap = nsub * (uint32_t)bpm;
+    }
+    if (form2) y.coef_scan = (int16_t*)(sb + o_cs);
+    // lockstep levels of pass 1 before the stragglers get a wave each (0: all levels in lockstep, the round-4 form); restart files keep the lockstep form
+    static const int main_levels_env = [] { const char* e = getenv("UHDR_HIP_HUFF_MAIN_LEVELS"); return e ? atoi(e) : 2; }();
     if (j == bpm && bpm <= 16) {
-      ftabs.resize(8);
-      for (int t = 0; t < 4; t++) make_track_table(ftabs[(size_t)t], (t & 1) == 0, &ftabs[(size_t)t + 4]);
-      HIP_TRY(hipMemcpyAsync(sb + o_ft, ftabs.data(), sizeof(HuffFastTable) * 8, hipMemcpyHostToDevice, c->stream));
-      std::vector<uint32_t> vtabs((size_t)4 * kHuffValWords);
-      for (int t = 0; t < 4; t++) make_value_table(ftabs[(size_t)t], (t & 1) == 0, vtabs.data() + (size_t)t * kHuffValWords);
-      HIP_TRY(hipMemcpyAsync(sb + o_vt, vtabs.data(), vtabs.size() * 4, hipMemcpyHostToDevice, c->stream));
       HIP_TRY(hipMemsetAsync(y.flags, 0, zero_bytes_sync, c->stream));  // flags, nblk, dcd and the restart map
-      dbg.mark("huffman_decode_dev: track / value tables built and enqueued");
+      if (form2) HIP_TRY(hipMemsetAsync(y.coef_scan, 0, scan_bytes, c->stream));
+      dbg.mark("huffman_decode_dev: fills enqueued");
       int final_buf = 0;
-      uint32_t fl[18] = {};  // [9]: restart markers the unstuff pass dropped, [16] [17] / [0] [7]: their sequence sums as found / as due
+      uint32_t* fl = c->h_flags;  // pinned; [9]: restart markers the unstuff pass dropped, [16] [17] / [0] [7]: their sequence sums as found / as due
+      for (int q = 0; q < 24; q++) fl[q] = 0;
       bool hyp_done = false, unstuffed = false, rounds_ran = false;
       auto start_over = [&]() -> uhdr_error_info_t {  // an attempt failed: everything it wrote goes back to its initial state
         HIP_TRY(hipMemsetAsync(y.flags, 0, 32, c->stream));  // not [8]: the stuffed-byte count stays
         HIP_TRY(hipMemsetAsync(y.nblk, 0, (size_t)nsub * 4 + 4, c->stream));
-        HIP_TRY(hipMemsetAsync(y.dcd, 0, (size_t)total_blocks * 4, c->stream));
-        for (int i = 0; i < a.ncomp; i++) HIP_TRY(hipMemsetAsync(a.coef[i], 0, zero_bytes[i], c->stream));
+        if (form2) {
+          HIP_TRY(hipMemsetAsync(y.coef_scan, 0, scan_bytes, c->stream));
+        } else {
+          HIP_TRY(hipMemsetAsync(y.dcd, 0, (size_t)total_blocks * 4, c->stream));
+          for (int i = 0; i < a.ncomp; i++) HIP_TRY(hipMemsetAsync(a.coef[i], 0, zero_bytes[i], c->stream));
+        }
         return ok_status();
       };
       for (size_t ti = 0; ti < attempts.size() && !hyp_done && !rounds_ran; ti++) {
@@ -2962,6 +3192,7 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
         if (t.levels > 0) {
           y.hyp_h = bpm;
           y.hyp_levels = t.levels;
+          y.hyp_main_levels = rst_sync ? 0 : main_levels_env;
           y.hyp_state = (uint64_t*)(sb + o_hs);
           y.hyp_map = sb + o_hm;
           y.hyp_cnt = (uint16_t*)(sb + o_hc);
@@ -2978,7 +3209,7 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
             HIP_TRY(launch_huffman_decode_hyp(y, (int*)(sb + o_dcp), sb + o_ch, sb + o_ch + tiles_off, c->stream));
           }
           dbg.mark("huffman_decode_dev: hypothesis attempt enqueued");
-          HIP_TRY(hipMemcpyAsync(fl, y.flags, sizeof fl, hipMemcpyDeviceToHost, c->stream));
+          HIP_TRY(hipMemcpyAsync(fl, y.flags, 24 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
           HIP_TRY(hipStreamSynchronize(c->stream));
           dbg.mark("huffman_decode_dev: hypothesis attempt finished");
           hyp_done = fl[2] == 0;
@@ -2990,8 +3221,8 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
           if (getenv("UHDR_HIP_HUFF_DEBUG")) {
             uint32_t hist[16] = {};
             (void)hipMemcpy(hist, y.flags, sizeof hist, hipMemcpyDeviceToHost);
-            fprintf(stderr, "uhdr_hip: hypothesis decode of %zu bytes, %u subsequences of %u bits x %d: merges per level %u %u %u %u %u %u+, %u paths unmerged after %d levels, true path %s\n",
-                    data_bytes, nsub_t, t.sub_bits, bpm, hist[10], hist[11], hist[12], hist[13], hist[14], hist[15], fl[3], t.levels, hyp_done ? "resolved" : "LOST (next attempt)");
+            fprintf(stderr, "uhdr_hip: hypothesis decode of %zu bytes, %u subsequences of %u bits x %d: merges per level %u %u %u %u %u %u+, %u paths unmerged after %d levels (%d in lockstep, %u paths handed to the straggler waves), true path %s\n",
+                    data_bytes, nsub_t, t.sub_bits, bpm, hist[10], hist[11], hist[12], hist[13], hist[14], hist[15], fl[3], t.levels, y.hyp_main_levels, fl[kHuffFlagStragglers], hyp_done ? "resolved" : "LOST (next attempt)");
           }
         } else {
           {
@@ -3000,7 +3231,7 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
             unstuffed = true;
             HIP_TRY(launch_huffman_decode_sync(y, max_rounds, (int*)(sb + o_dcp), &final_buf, c->stream));
           }
-          HIP_TRY(hipMemcpyAsync(fl, y.flags, sizeof fl, hipMemcpyDeviceToHost, c->stream));
+          HIP_TRY(hipMemcpyAsync(fl, y.flags, 24 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
           HIP_TRY(hipStreamSynchronize(c->stream));
           rounds_ran = true;
         }
@@ -3013,6 +3244,7 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
         // a restart file that is not what its headers say (markers missing, misplaced or out of step, damaged data): the
         // interval decoder below looks at every marker and words the error
         for (int i = 0; i < a.ncomp; i++) HIP_TRY(hipMemsetAsync(a.coef[i], 0, zero_bytes[i], c->stream));
+        coef_zeroed = true;
       } else if (settled) {  // the fixed point was reached: the decode is the true one
         if (fl[1] & 8u) return err_status(UHDR_CODEC_INVALID_PARAM, "corrupt entropy-coded data (the scan ends before its last block)");
         if (fl[1] & 2u) return err_status(UHDR_CODEC_INVALID_PARAM, "corrupt entropy-coded data (undefined Huffman code or a run past the end of a block)");
@@ -3023,6 +3255,7 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
           return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "the parallel entropy decode did not settle in %d rounds; %zu bytes on one lane would take longer than the CPU", max_rounds, data_bytes);
         }
         for (int i = 0; i < a.ncomp; i++) HIP_TRY(hipMemsetAsync(a.coef[i], 0, zero_bytes[i], c->stream));
+        coef_zeroed = true;
       }
     }
   }
@@ -3037,6 +3270,8 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
     c->stats.entropy_decode_declined++;
     return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "a %zu-byte scan without restart markers that the parallel decoder does not take (Huffman tables outside its two-level form)", data_bytes);
   }
+  if (!coef_zeroed)
+    for (int i = 0; i < a.ncomp; i++) HIP_TRY(hipMemsetAsync(a.coef[i], 0, zero_bytes[i], c->stream));
   {
     ProfScope ps(c, "huffman_decode");
     HIP_TRY(launch_huffman_decode(a, counts, starts, ends, c->stream));
@@ -3045,7 +3280,7 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
   else c->stats.entropy_decode_intervals++;
   uint32_t st[2] = {0, 0};
   HIP_TRY(hipMemcpyAsync(st, a.status, sizeof st, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));  // also keeps `tabs` alive until the upload has happened
+  HIP_TRY(hipStreamSynchronize(c->stream));
   if (st[1] != (uint32_t)(a.nseg - 1))
     return err_status(UHDR_CODEC_INVALID_PARAM, "found %u restart markers, a restart interval of %d MCUs over %d MCUs needs %d", st[1], a.ri,
                       a.total_mcus, a.nseg - 1);
@@ -3234,30 +3469,53 @@ uhdr_error_info_t uhdr_hip_jpeg_decode_scan(uhdr_hip_ctx_t* c, const uhdr_hip_jp
     if (!planes[0] || hstride[0] < sc.w || vstride[0] < sc.h) return err_status(UHDR_CODEC_INVALID_PARAM, "destination smaller than the %ux%u image", sc.w, sc.h);
   }
   // the entropy-coded data ends at the first marker that is neither a stuffed zero, a fill byte nor RSTn (T.81 B.1.1.2 / B.2.1)
-  size_t e = 0;
-  while (e < scan_bytes) {
-    const uint8_t* f = (const uint8_t*)memchr(scan_data + e, 0xff, scan_bytes - e);
-    if (!f) { e = scan_bytes; break; }
-    e = (size_t)(f - scan_data);
-    if (e + 1 >= scan_bytes) { e = scan_bytes; break; }
-    const uint8_t m = scan_data[e + 1];
-    if (m == 0x00 || (m & 0xf8) == 0xd0) { e += 2; continue; }
-    if (m == 0xff) { e += 1; continue; }
-    break;
-  }
-  const size_t nbytes = e;
+  auto walk = [&]() -> size_t {
+    size_t e = 0;
+    while (e < scan_bytes) {
+      const uint8_t* f = (const uint8_t*)memchr(scan_data + e, 0xff, scan_bytes - e);
+      if (!f) { e = scan_bytes; break; }
+      e = (size_t)(f - scan_data);
+      if (e + 1 >= scan_bytes) { e = scan_bytes; break; }
+      const uint8_t m = scan_data[e + 1];
+      if (m == 0x00 || (m & 0xf8) == 0xd0) { e += 2; continue; }
+      if (m == 0xff) { e += 1; continue; }
+      break;
+    }
+    return e;
+  };
+  // Round 5: that walk reads every byte on the host (0.1 ms for a 4K frame) to find what is nearly always the EOI marker in the
+  // buffer's last two bytes.  So: take that for the end, and let the device -- which reads every byte anyway -- report any other
+  // marker inside (stray_marker check, a pinned status word); only then is the walk made and the decode repeated on its prefix.
+  static const bool always_walk = getenv("UHDR_HIP_JPEG_WALK") != nullptr;
+  bool guessed = !always_walk && scan_bytes >= 3 && scan_bytes < 0xFFFFFFF0ull && scan_data[scan_bytes - 2] == 0xff && scan_data[scan_bytes - 1] == 0xd9;
+  size_t nbytes = guessed ? scan_bytes - 2 : walk();
   if (nbytes == 0) return err_status(UHDR_CODEC_INVALID_PARAM, "no entropy-coded data");
   dbg.mark("jpeg_decode_scan: end of the entropy-coded data found");
   HIP_TRY(hipSetDevice(c->device));
   UHDR_TRY(ensure(c->jpg[0], nbytes + 64));
   HIP_TRY(hipMemcpyAsync(c->jpg[0].p, scan_data, nbytes, hipMemcpyHostToDevice, c->stream));
   dbg.mark("jpeg_decode_scan: compressed bytes on their way up");
+  if (!c->h_flags) HIP_TRY(hipHostMalloc((void**)&c->h_flags, 64 * sizeof(uint32_t), hipHostMallocDefault));
+  uint32_t* stray = c->h_flags + 40;
+  if (guessed) {
+    *stray = 0;
+    HIP_TRY(launch_stray_marker_check((const uint8_t*)c->jpg[0].p, (uint32_t)nbytes, stray, c->stream));
+  }
   for (int i = 0; i < nc; i++) {
     UHDR_TRY(ensure(c->jpg[1 + i], (size_t)sc.blocks_w[i] * sc.blocks_h[i] * 64 * sizeof(int16_t)));
     sc.coef[i] = (const int16_t*)c->jpg[1 + i].p;
   }
   c->huff_serial_ok = false;
-  const uhdr_error_info_t hs = uhdr_hip_huffman_decode_dev(c, &sc, &hdr->tables, (const uint8_t*)c->jpg[0].p, nbytes);
+  uhdr_error_info_t hs = uhdr_hip_huffman_decode_dev(c, &sc, &hdr->tables, (const uint8_t*)c->jpg[0].p, nbytes);
+  if (guessed) {
+    if (hs.error_code != UHDR_CODEC_OK) HIP_TRY(hipStreamSynchronize(c->stream));  // (an early return may have skipped the decoder's own)
+    if (*stray != 0) {  // a marker inside what was taken for entropy-coded data: the data ends there (libjpeg stops at it too)
+      guessed = false;
+      nbytes = walk();
+      if (nbytes == 0) { c->huff_serial_ok = true; return err_status(UHDR_CODEC_INVALID_PARAM, "no entropy-coded data"); }
+      hs = uhdr_hip_huffman_decode_dev(c, &sc, &hdr->tables, (const uint8_t*)c->jpg[0].p, nbytes);
+    }
+  }
   c->huff_serial_ok = true;
   if (hs.error_code != UHDR_CODEC_OK) return hs;
   dbg.mark("jpeg_decode_scan: entropy decode returned");
@@ -3333,7 +3591,9 @@ uhdr_error_info_t uhdr_hip_jpeg_decode_scan(uhdr_hip_ctx_t* c, const uhdr_hip_jp
   }
   if (lazy) c->stats.lazy_downloads_skipped++;
   dbg.mark("jpeg_decode_scan: IDCT (and download) enqueued");
-  HIP_TRY(hipStreamSynchronize(c->stream));  // (lazy: decode errors of the kernels above still surface in this call)
+  // lazy: nothing was copied to the caller's planes and whoever reads the device copy does so on this stream, in order -- no
+  // host synchronisation (the entropy decoder above has made its own: malformed data has surfaced by now)
+  if (!lazy) HIP_TRY(hipStreamSynchronize(c->stream));
   dbg.mark("jpeg_decode_scan: done");
   return ok_status();
 }

@@ -376,6 +376,17 @@ struct HuffSyncArgs {
   uint8_t* hyp_map;           // [nsub][kHuffHypSlots]: the slot of subsequence i + 1 the path is in at ITS end (0xff: none)
   uint16_t* hyp_cnt;          // [nsub][kHuffHypSlots]: blocks the path completes while crossing subsequence i + 1
   int hyp_hist;               // debug: count the merges per level in flags[10..15]
+  // round 5: pass 1 runs hyp_main_levels levels in lockstep (0: all of them) and hands the paths still alive to
+  // hyp_straggler_kernel, one WAVE per path (lane o looks the symbol at bit o of a 64-bit window up in all four tables, one
+  // scalar chain follows the true boundaries with v_readlane): strag_list[n] = {start subsequence, hypothesis | level << 8},
+  // n = flags[kHuffFlagStragglers] (zeroed by pass 0)
+  int hyp_main_levels;
+  uint32_t* strag_list;
+  uint32_t strag_cap;
+  // round 5: write pass, form 2 (marker-less scans): coefficients go to a scan-order scratch (block t at coef_scan + 64 t, zig-zag
+  // order, the DC DIFFERENCE at [0]; zero-initialised) and coef_place_kernel moves them to the component arrays in natural
+  // order with the DC prediction applied; nullptr: form 1 (stores into zero-initialised JBLOCK arrays + dcd[])
+  int16_t* coef_scan;
   // restart intervals (nullptr / 0: a scan without markers): see restart_jump in huffman_decode_sync.hip
   const uint32_t* rst_map;    // one bit per byte of the clean stream: an interval starts here
   uint32_t rst_blocks;        // blocks per interval (restart interval x blocks per MCU)
@@ -384,6 +395,8 @@ struct HuffSyncArgs {
   uint32_t rst_chunks;
 };
 constexpr int kHuffHypSlots = 48;
+constexpr int kHuffFlagStragglers = 20;  // flags[] word: paths handed to hyp_straggler_kernel
+constexpr int kHuffFlagStray = 21;       // flags[] word: != 0 when the uploaded bytes hold a marker other than RSTn / a stuffed zero / a fill byte
 // scratch of the chain kernels: per-thread prefix maps, then the tile maps
 size_t huff_hyp_chain_bytes(uint64_t nbytes, uint32_t sub_bits, size_t* tiles_offset);
 hipError_t launch_huffman_decode_hyp(const HuffSyncArgs& a, int* dc_partial, uint8_t* chain_prefix, uint8_t* chain_tiles, hipStream_t s);
@@ -393,6 +406,9 @@ hipError_t launch_huffman_unstuff(const uint8_t* data, uint32_t nbytes, uint32_t
                                   uint32_t* rst_map = nullptr, uint32_t* rst_partial = nullptr);
 hipError_t launch_huffman_decode_sync(const HuffSyncArgs& a, int max_rounds, int* dc_partial, int* final_buf, hipStream_t s);
 int huff_marker_chunks(uint64_t nbytes);
+// *flag (device-visible, e.g. pinned host memory) |= 1 when data[0, nbytes) holds a 0xFF followed by anything but 0x00 (stuffing),
+// RSTn or another 0xFF (fill byte), i.e. a marker that ends the entropy-coded data before nbytes
+hipError_t launch_stray_marker_check(const uint8_t* data, uint32_t nbytes, uint32_t* flag, hipStream_t s);
 hipError_t launch_huffman_decode(const HuffDecArgs& a, uint32_t* counts, uint32_t* starts, uint32_t* ends, hipStream_t s);
 
 hipError_t launch_idct_dequant(const int16_t* coef, int bw, int bh, const uint16_t* qt_host, uint8_t* plane,

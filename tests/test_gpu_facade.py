@@ -34,13 +34,20 @@ def test_config1_encode_through_the_facade_equals_the_cpu_reference():
         rc, _, err, trace = F.encode_api1(p, y, 1280, 720, "gpu.jpg", True, d)
         assert rc == 0, err
         st = _stages(trace)
-        # API-1: generateGainMap, convertYuv (BT.709 -> the P3/601 encoding of the base JPEG), and both compressImage calls
-        # (base image, gain map) whole on the device: FDCT + quantize + marker-less Huffman coding -- no libjpeg entropy pass
-        assert "generate_gainmap" in st and "convert_yuv" in st and "jpeg_encode_scan" in st and "fdct_planes" not in st, trace
-        assert len([l for l in trace if "jpeg_encode_scan -> device" in l]) == 2, trace
+        # round 5: the seam at JpegR::encodeJPEGR (API-1) runs generateGainMap + compressGainMap + convertYuv + compressImage as ONE
+        # device sequence (uhdr_hip_encode_api1_scans): a single stage line, none of the per-stage seams, no libjpeg entropy pass
+        assert st == ["encode_api1_fused"], trace
         a, b = F.read(os.path.join(d, "cpu.jpg")), F.read(os.path.join(d, "gpu.jpg"))
         assert a.size == b.size == 85449
         assert np.array_equal(a, b), f"{int((a != b).sum())} differing bytes"
+        # the per-stage seams (what the fused seam falls back to for geometries it declines): generateGainMap, convertYuv (BT.709 ->
+        # the P3/601 encoding of the base JPEG) and both compressImage calls whole on the device -- the same file
+        rc, _, err, trace = F.encode_api1(p, y, 1280, 720, "gpu1.jpg", True, d, env_extra={"UHDR_HIP_SEAM_NO_FUSED_ENCODE": "1"})
+        assert rc == 0, err
+        st = _stages(trace)
+        assert "generate_gainmap" in st and "convert_yuv" in st and "jpeg_encode_scan" in st and "fdct_planes" not in st and "encode_api1_fused" not in st, trace
+        assert len([l for l in trace if "jpeg_encode_scan -> device" in l]) == 2, trace
+        assert np.array_equal(a, F.read(os.path.join(d, "gpu1.jpg")))
         # the older route (device FDCT, libjpeg's Huffman pass) still gives the same file
         rc, _, err, trace = F.encode_api1(p, y, 1280, 720, "gpu2.jpg", True, d, env_extra={"UHDR_HIP_SEAM_CPU_ENTROPY": "1"})
         assert rc == 0, err
@@ -64,10 +71,14 @@ def test_4k_encode_through_the_facade_equals_the_cpu_reference_file():
         assert rc == 0, err
         rc, _, err, trace = F.encode_api1("in.p010", "in.yuv420", w, h, "gpu.jpg", True, d)
         assert rc == 0, err
-        assert len([l for l in trace if "jpeg_encode_scan -> device" in l]) == 2 and "fdct_planes" not in _stages(trace), trace
+        assert _stages(trace) == ["encode_api1_fused"], trace  # one device sequence for the whole call (round 5)
         a, b = F.read(os.path.join(d, "cpu.jpg")), F.read(os.path.join(d, "gpu.jpg"))
         assert a.size == b.size, (a.size, b.size)
         assert np.array_equal(a, b), f"{int((a != b).sum())} differing bytes"
+        rc, _, err, trace = F.encode_api1("in.p010", "in.yuv420", w, h, "gpu1.jpg", True, d, env_extra={"UHDR_HIP_SEAM_NO_FUSED_ENCODE": "1"})
+        assert rc == 0, err
+        assert len([l for l in trace if "jpeg_encode_scan -> device" in l]) == 2 and "fdct_planes" not in _stages(trace), trace
+        assert np.array_equal(a, F.read(os.path.join(d, "gpu1.jpg")))
 
 
 @pytest.mark.parametrize("ct,fmt,bpp", [(0, 4, 8), (1, 5, 4), (2, 5, 4)])  # linear F16, HLG 1010102, PQ 1010102
