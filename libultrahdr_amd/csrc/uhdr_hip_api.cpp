@@ -3040,7 +3040,7 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
   const bool rst_sync = a.nseg > 1 && data_bytes / (size_t)a.nseg >= 320 && !getenv("UHDR_HIP_HUFF_RST_INTERVALS");
   const bool try_sync = (a.nseg == 1 || rst_sync) && data_bytes >= 4096 && data_bytes < ((size_t)1 << 29) && fast_ok && !getenv("UHDR_HIP_HUFF_SERIAL") && bpm <= 16;
   // write pass, form 2 (marker-less scans): a scan-order scratch takes the zero fill, the JBLOCK arrays are written whole
-  static const int write_form = [] { const char* e = getenv("UHDR_HIP_HUFF_WRITE"); return e ? atoi(e) : 2; }();
+  const int write_form = [] { const char* e = getenv("UHDR_HIP_HUFF_WRITE"); return e ? atoi(e) : 2; }();  // (read per call: tools/huff_exp.py sweeps it)
   const bool form2 = try_sync && !rst_sync && write_form != 1;
   bool coef_zeroed = !form2;  // the interval / single-lane decoder below stores into zero-initialised arrays
   if (!form2)
@@ -3164,7 +3164,7 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
     }
     if (form2) y.coef_scan = (int16_t*)(sb + o_cs);
     // lockstep levels of pass 1 before the stragglers get a wave each (0: all levels in lockstep, the round-4 form); restart files keep the lockstep form
-    static const int main_levels_env = [] { const char* e = getenv("UHDR_HIP_HUFF_MAIN_LEVELS"); return e ? atoi(e) : 2; }();
+    const int main_levels_env = [] { const char* e = getenv("UHDR_HIP_HUFF_MAIN_LEVELS"); return e ? atoi(e) : 2; }();
     if (j == bpm && bpm <= 16) {
       HIP_TRY(hipMemsetAsync(y.flags, 0, zero_bytes_sync, c->stream));  // flags, nblk, dcd and the restart map
       if (form2) HIP_TRY(hipMemsetAsync(y.coef_scan, 0, scan_bytes, c->stream));
