@@ -1057,6 +1057,9 @@ def api_level_section():
     _, t_dec_eager = with_env("UHDR_HIP_SEAM_EAGER_DOWNLOADS", "1", lambda: med(lambda: FA.decode(jpg, A.UHDR_CT_LINEAR, f16, gpu=True), 5))
     # the round-2 default, kept as an option: device FDCT, libjpeg's Huffman pass on one CPU core (same bytes)
     jpg_cpu, t_enc_cpu = with_env("UHDR_HIP_SEAM_CPU_ENTROPY", "1", lambda: med(lambda: FA.encode(hdr, sdr, gpu=True), 2))
+    # the round-4 route: four per-stage seams instead of the one at encodeJPEGR (same bytes)
+    jpg_ps, t_enc_ps = with_env("UHDR_HIP_SEAM_NO_FUSED_ENCODE", "1", lambda: med(lambda: FA.encode(hdr, sdr, gpu=True), 5))
+    jpg2, t_enc2 = med(lambda: FA.encode(hdr, sdr, gpu=True), 5)  # ... and the fused seam once more, later in the process
     # opt-in: restart intervals, one per wavefront
     with_env("UHDR_HIP_SEAM_RESTART_INTERVAL", "max", lambda: FA.encode(hdr, sdr, gpu=True))
     jpg_ri, t_enc_ri = with_env("UHDR_HIP_SEAM_RESTART_INTERVAL", "max", lambda: med(lambda: FA.encode(hdr, sdr, gpu=True), 5))
@@ -1088,6 +1091,8 @@ def api_level_section():
                                           get_decoded_gainmap_image_ms=round(t_gm * 1e3, 2)),
             "uhdr_decode_4k_f16_hip_eager_downloads": row(t_dec_eager, note="UHDR_HIP_SEAM_EAGER_DOWNLOADS=1: both decoded images written to the JpegDecoderHelper "
                                                           "buffers and the gain-map image copied inside uhdr_decode (the round-3 behaviour)"),
+            "uhdr_encode_api1_4k_hip_per_stage_seams": row(t_enc_ps, same_bytes=bool(jpg_ps == jpg), note="UHDR_HIP_SEAM_NO_FUSED_ENCODE=1: generate_gainmap, convert_yuv and 2 x jpeg_encode_scan seams (round 4)"),
+            "uhdr_encode_api1_4k_hip_again": row(t_enc2, same_bytes=bool(jpg2 == jpg)),
             "uhdr_encode_api1_4k_hip_libjpeg_entropy": row(t_enc_cpu, jpeg_bytes=len(jpg_cpu), entropy_coding="UHDR_HIP_SEAM_CPU_ENTROPY=1: device FDCT, libjpeg's Huffman pass on one CPU core (the round-2 default)"),
             "uhdr_encode_api1_4k_hip_restart_intervals": row(t_enc_ri, jpeg_bytes=len(jpg_ri), entropy_coding="UHDR_HIP_SEAM_RESTART_INTERVAL=max: device, one restart interval per wavefront: DRI + RSTn markers added, decoded pixels identical"),
             "uhdr_decode_4k_f16_hip_of_that_file": row(t_dec_ri, entropy_decoding="device (restart-interval file)"),
@@ -1330,19 +1335,27 @@ def extras(ctx, u, device):
                 outs_ = u.jpeg_decode(file_, rgb_)
                 outs_ = outs_ if isinstance(outs_, list) else [outs_]
                 clock_ramp(ctx, lambda: u.jpeg_decode(file_, rgb_, outs=outs_), seconds=0.3)
-                walls_ = []
-                ctx.profile(True)
-                ctx.profile_read(None, reset=True)
-                for _ in range(7):
+                walls_, cwalls_ = [], []
+                stx_ = A.Stats()
+                for _ in range(7):  # (no per-launch events here: they cost the call host time)
                     t0_ = time.perf_counter()
                     u.jpeg_decode(file_, rgb_, outs=outs_)
                     walls_.append(time.perf_counter() - t0_)
+                    u.lib.uhdr_hip_get_stats(ctx.handle, C.byref(stx_))
+                    cwalls_.append(stx_.last_jpeg_decode_scan_ns * 1e-9)
+                ctx.profile(True)
+                ctx.profile_read(None, reset=True)
+                for _ in range(3):
+                    u.jpeg_decode(file_, rgb_, outs=outs_)
                 n_, kms_ = ctx.profile_read(None, reset=True)
                 ctx.profile(False)
                 u.lib.uhdr_hip_resident_end(ctx.handle)
                 walls_.sort()
-                res[f"jpeg_decode_scan_4k_{nm_}_lazy"] = {"wall_us": round(walls_[len(walls_) // 2] * 1e6, 1), "kernels_us": round(kms_ / 7 * 1e3, 1),
-                                                          "launches": n_ // 7, "file_bytes": len(file_)}
+                cwalls_.sort()
+                res[f"jpeg_decode_scan_4k_{nm_}_lazy"] = {"c_call_wall_us": round(cwalls_[len(cwalls_) // 2] * 1e6, 1), "kernels_us": round(kms_ / 3 * 1e3, 1),
+                                                          "python_wrapper_wall_us": round(walls_[len(walls_) // 2] * 1e6, 1), "launches": n_ // 3, "file_bytes": len(file_),
+                                                          "note": "c_call_wall_us: steady_clock inside uhdr_hip_jpeg_decode_scan (uhdr_hip_stats_t::last_jpeg_decode_scan_ns), what the facade pays; "
+                                                                  "python_wrapper_wall_us adds ctypes marshalling, the header parse and the stream ordering of the Python binding"}
     except Exception as e:  # noqa: BLE001
         res["huffman_decode_4k_420_q95_no_restart_markers"] = {"error": f"{type(e).__name__}: {e}"}
     del hco, hout

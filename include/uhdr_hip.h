@@ -693,6 +693,10 @@ typedef struct uhdr_hip_stats {
   /* lazy downloads (uhdr_hip_resident_lazy) */
   unsigned long long lazy_downloads_skipped;      /* decoded images left on the device instead of written to the caller's planes */
   unsigned long long lazy_downloads_done;         /* of those, written back / copied out after all (_flush, _materialize, slot reuse) */
+  /* wall-clock time the library itself spent in its most recent call of these two entry points, in nanoseconds (round 5): what a
+   * C / C++ caller such as the facade pays, without the overhead of whatever binding drives the library */
+  unsigned long long last_jpeg_decode_scan_ns;
+  unsigned long long last_encode_api1_scans_ns;
 } uhdr_hip_stats_t;
 void uhdr_hip_get_stats(uhdr_hip_ctx_t* ctx, uhdr_hip_stats_t* out);
 
@@ -704,6 +708,10 @@ void uhdr_hip_profile_enable(uhdr_hip_ctx_t* ctx, int enable);
 int uhdr_hip_profile_read(uhdr_hip_ctx_t* ctx, const char* family, double* total_ms, int reset);
 /* the same, launch by launch: the first min(n, capacity) durations go to ms[] in launch order; returns n */
 int uhdr_hip_profile_read_list(uhdr_hip_ctx_t* ctx, const char* family, double* ms, int capacity, int reset);
+/* Section marker for external profilers (round 5): launches the empty kernel `uhdr_profile_mark_kernel` on the context's stream.
+ * A rocprofv3 kernel trace / counter collection of a process that runs several cases is cut at these launches, so that durations
+ * and HBM counters can be reported per (kernel, case) instead of per kernel name (tools/qbench.py, tools/read_prof.py). */
+void uhdr_hip_profile_mark(uhdr_hip_ctx_t* ctx);
 
 #ifdef __cplusplus
 }

@@ -166,7 +166,7 @@ class Stats(C.Structure):
     _fields_ = [(n, C.c_ulonglong) for n in ("entropy_decode_parallel", "entropy_decode_intervals", "entropy_decode_single_lane",
                                               "entropy_decode_declined", "entropy_encode_stream", "entropy_encode_intervals", "resident_hits",
                                               "generate_channels_tabled", "generate_channels_per_sample", "lazy_downloads_skipped",
-                                              "lazy_downloads_done")]
+                                              "lazy_downloads_done", "last_jpeg_decode_scan_ns", "last_encode_api1_scans_ns")]
 
 
 class CommOps(C.Structure):
@@ -256,6 +256,7 @@ _SIGS = {
     "uhdr_hip_profile_enable": (None, [C.c_void_p, C.c_int]),
     "uhdr_hip_profile_read": (C.c_int, [C.c_void_p, C.c_char_p, _P(C.c_double), C.c_int]),
     "uhdr_hip_profile_read_list": (C.c_int, [C.c_void_p, C.c_char_p, _P(C.c_double), C.c_int, C.c_int]),
+    "uhdr_hip_profile_mark": (None, [C.c_void_p]),
 }
 ABI_SYMBOLS = tuple(_SIGS)
 

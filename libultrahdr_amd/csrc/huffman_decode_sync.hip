@@ -825,79 +825,125 @@ __global__ __launch_bounds__(1024) void hyp_pass1_kernel(const HuffSyncArgs a) {
 // to 0xff for every attempt), written one or more barriers ago by a lane of this workgroup -- owners in the NEXT workgroup
 // (start index beyond this one's last subsequence) are not looked at.  Youngest first: the younger the target, the more
 // levels it has left.
+// Round 5: (a) the level loop is COMPACTED.  After level 1 some 8 % of a 4:2:0 workgroup's 384 paths are alive -- about five per
+// wave, so that nearly every wave still ran level 2 at the full cost of its slowest lane (the second level took 50 us of the
+// kernel's 148, the first 70).  Survivors now go into an LDS list and level l >= 2 is run by the first ceil(n / 64) waves, one
+// list entry per thread; the barriers (and with them the in-flight merging) stay.  (b) the candidates' states are loaded in
+// batches, not one dependent global load per candidate.  (c) after hyp_main_levels levels the list goes to hyp_straggler_kernel.
+__device__ __forceinline__ uint32_t hyp_find_slot(const uint64_t* __restrict__ row, const uint8_t* __restrict__ prev, uint64_t e, uint32_t H, uint32_t l,
+                                                  uint32_t m_lo) {
+  uint32_t g = 0xffu;
+  for (uint32_t t0 = 0; t0 < H; t0 += 4) {  // fresh slots: four independent loads in flight
+    uint64_t v[4];
+#pragma unroll
+    for (uint32_t q = 0; q < 4; q++) v[q] = row[min(t0 + q, H - 1u)];
+#pragma unroll
+    for (uint32_t q = 0; q < 4; q++)
+      if (t0 + q < H && v[q] == e && g == 0xffu) g = t0 + q;
+  }
+  for (uint32_t m = m_lo; m < l && g == 0xffu; m++)  // in flight, youngest first
+    for (uint32_t t0 = 0; t0 < H; t0 += 4) {
+      uint64_t v[4];
+      uint32_t o[4];
+#pragma unroll
+      for (uint32_t q = 0; q < 4; q++) {
+        const uint32_t sl = m * H + min(t0 + q, H - 1u);
+        o[q] = prev[sl - H];
+        v[q] = row[sl];
+      }
+#pragma unroll
+      for (uint32_t q = 0; q < 4; q++) {
+        const uint32_t sl = m * H + t0 + q;
+        if (t0 + q < H && g == 0xffu && o[q] == sl && v[q] == e) g = sl;
+      }
+    }
+  return g;
+}
 __global__ __launch_bounds__(1024) void hyp_pass1q_kernel(const HuffSyncArgs a) {
   extern __shared__ uint32_t s_stage[];
   __shared__ ScanLds L;
+  __shared__ uint32_t s_n;
   load_scan_lds<true>(a, L);
-  const uint32_t lane = threadIdx.x & 63u, h = threadIdx.x >> 6, H = (uint32_t)a.hyp_h;
-  const uint32_t i = blockIdx.x * 64u + lane, i_last = blockIdx.x * 64u + 63u;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, H = (uint32_t)a.hyp_h;
+  const uint32_t i0 = blockIdx.x * 64u, i_last = i0 + 63u;
   const uint32_t nclean = a.nbytes - *a.nstuffed, nbits = nclean * 8u;
   const uint32_t nsub = (nbits + a.sub_bits - 1) / a.sub_bits;
   const uint32_t cshift = 31u - (uint32_t)__builtin_clz(a.sub_bits >> 3);
-  const uint32_t first_byte = (blockIdx.x * 64u + 1u) * (a.sub_bits >> 3);  // the window starts one subsequence further on
-  stage_wave(a.clean, nclean, first_byte, cshift, s_stage, threadIdx.x, 64u + (uint32_t)a.hyp_levels, blockDim.x);
+  const uint32_t first_byte = (i0 + 1u) * (a.sub_bits >> 3);  // the window starts one subsequence further on
+  const uint32_t nchunks = 64u + (uint32_t)a.hyp_levels;
+  // the survivor list behind the staged bytes: blockDim.x states (2 x 4 bytes), then blockDim.x ids (lane | hypothesis << 6)
+  const uint32_t stage_words = (nchunks * ((a.sub_bits >> 3) + 4u) + 16u + 7u) >> 2;
+  uint32_t* s_lo = s_stage + ((stage_words + 1u) & ~1u);  // (two words per state: the dynamic segment is only known to be 4-byte aligned)
+  uint32_t* s_hi = s_lo + blockDim.x;
+  uint16_t* s_id = (uint16_t*)(s_hi + blockDim.x);
+  if (tid == 0) s_n = 0;
+  stage_wave(a.clean, nclean, first_byte, cshift, s_stage, tid, nchunks, blockDim.x);
   __syncthreads();
-  bool alive = i + 1 < nsub;
-  uint32_t p = 0, b = 0, k = 0;
-  if (alive) {
-    const uint64_t s0 = a.hyp_state[(size_t)i * kHuffHypSlots + h];
-    p = (uint32_t)s0; b = (uint32_t)(s0 >> 32) & 0xffu; k = (uint32_t)(s0 >> 40) & 0xffu;
-  }
-  uint32_t slot = h;
   const Staged st = {s_stage, cshift};
   // lockstep levels: all of them, or the first hyp_main_levels -- what is still alive then goes to hyp_straggler_kernel
   const uint32_t l_main = (a.hyp_main_levels > 0 && a.hyp_main_levels < a.hyp_levels) ? (uint32_t)a.hyp_main_levels : (uint32_t)a.hyp_levels;
-  for (uint32_t l = 1; l <= l_main; l++) {
-    const uint32_t j = i + l;
+  uint32_t n_in = blockDim.x;  // level 1: every thread has its own path (lane, hypothesis = wave)
+  uint32_t l = 1;
+  for (; l <= l_main; l++) {
+    bool alive = tid < n_in;
+    uint32_t il = lane, h = tid >> 6;
+    uint64_t s0 = 0;
+    if (l > 1) {
+      if (alive) {
+        const uint32_t id = s_id[tid];
+        il = id & 63u;
+        h = id >> 6;
+        s0 = (uint64_t)s_lo[tid] | ((uint64_t)s_hi[tid] << 32);
+      }
+      __syncthreads();  // every entry of the list is in registers ...
+      if (tid == 0) s_n = 0;
+      __syncthreads();  // ... before the survivors of this level are appended from its start
+    }
+    const uint32_t i = i0 + il, j = i + l;
     if (j >= nsub) alive = false;
     if (alive) {
+      const uint32_t slot = (l - 1u) * H + h;
+      if (l == 1) s0 = a.hyp_state[(size_t)i * kHuffHypSlots + h];
+      uint32_t p = (uint32_t)s0, b = (uint32_t)(s0 >> 32) & 0xffu, k = (uint32_t)(s0 >> 40) & 0xffu;
       const uint32_t end_bit = min((j + 1) * a.sub_bits, nbits);
       uint32_t nblk = 0;
       if (p < end_bit) track_span(a, st, first_byte * 8u, L, p, b, k, end_bit, nblk);
       const uint64_t e = pack_state(p, b, k);
       const uint64_t* row = a.hyp_state + (size_t)j * kHuffHypSlots;
       const uint8_t* prev = a.hyp_map + (size_t)(j - 1) * kHuffHypSlots;
-      uint32_t g = 0xffu;
-      for (uint32_t t = 0; t < H; t++)
-        if (row[t] == e && g == 0xffu) g = t;
       const uint32_t m_lo = j > i_last + 1u ? j - i_last : 1u;  // owners started at j - m <= i_last
-      for (uint32_t m = m_lo; m < l && g == 0xffu; m++)
-        for (uint32_t t = 0; t < H; t++) {
-          const uint32_t sl = m * H + t;
-          if (g == 0xffu && prev[sl - H] == sl && row[sl] == e) g = sl;
-        }
+      const uint32_t g = hyp_find_slot(row, prev, e, H, l, m_lo);
       const size_t at = (size_t)(j - 1) * kHuffHypSlots + slot;
       a.hyp_cnt[at] = (uint16_t)nblk;
       if (g != 0xffu) {
         a.hyp_map[at] = (uint8_t)g;
         if (a.hyp_hist) atomicAdd(a.flags + 9 + min(l, 6u), 1u);
-        alive = false;
       } else if (l == (uint32_t)a.hyp_levels) {  // map stays 0xff: not merged within the budget
         atomicAdd(a.flags + 3, 1u);
-        alive = false;
       } else {
         const uint32_t nslot = l * H + h;
         a.hyp_state[(size_t)j * kHuffHypSlots + nslot] = e;
         a.hyp_map[at] = (uint8_t)nslot;
-        slot = nslot;
+        const uint32_t w = atomicAdd(&s_n, 1u);  // survives: onto the list (its order does not matter)
+        s_lo[w] = (uint32_t)e;
+        s_hi[w] = (uint32_t)(e >> 32);
+        s_id[w] = (uint16_t)(il | (h << 6));
       }
     }
     __threadfence_block();
-    if (!__syncthreads_or(alive ? 1 : 0)) break;
+    __syncthreads();
+    n_in = s_n;
+    if (n_in == 0) break;
   }
-  if (l_main < (uint32_t)a.hyp_levels) {  // hand-off: (start subsequence, hypothesis, levels done); one atomic per wave
-    const uint64_t m = __builtin_amdgcn_ballot_w64(alive);
-    if (m != 0) {
-      uint32_t base = 0;
-      const uint32_t leader = (uint32_t)__builtin_ctzll(m);
-      if (lane == leader) base = atomicAdd(a.flags + kHuffFlagStragglers, (uint32_t)__builtin_popcountll(m));
-      base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
-      if (alive) {
-        const uint32_t at = base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-        if (at < a.strag_cap) {
-          a.strag_list[2 * at] = i;
-          a.strag_list[2 * at + 1] = h | (l_main << 8);
-        }
+  if (n_in != 0 && l_main < (uint32_t)a.hyp_levels) {  // hand-off: (start subsequence, hypothesis | levels done << 8)
+    __shared__ uint32_t s_base;
+    if (tid == 0) s_base = atomicAdd(a.flags + kHuffFlagStragglers, n_in);
+    __syncthreads();
+    if (tid < n_in) {
+      const uint32_t at = s_base + tid, id = s_id[tid];
+      if (at < a.strag_cap) {
+        a.strag_list[2 * at] = i0 + (id & 63u);
+        a.strag_list[2 * at + 1] = (id >> 6) | (l_main << 8);
       }
     }
   }
@@ -980,15 +1026,24 @@ __global__ __launch_bounds__(64 * kStragWaves) void hyp_straggler_kernel(const H
             const uint32_t e2 = T[tb + 512u + ((e & 0x8000u) ? (e & 31u) : 0u) * 128u + (w16 & 127u)];
             ent[t] = (e & 0x8000u) ? e2 : e;
           }
-          const int luma = (int)(ent[0] | (ent[1] << 16)), chroma = (int)(ent[2] | (ent[3] << 16));
           const uint32_t lim = min(64u, end_bit - p);
           uint32_t off = 0;
+          // The chain: per block one DC step, then AC steps until the zig-zag index passes 63 -- the inner loop is the whole cost
+          // (24 of 25 symbols of a busy block): v_readlane, two field extractions, two additions, two compares.  The component's
+          // entry registers are picked once per block, not per symbol.
           while (off < lim) {
             const bool is_chroma = ((cpack >> (2u * b)) & 3u) != 0;
-            const uint32_t pair = (uint32_t)(is_chroma ? __builtin_amdgcn_readlane(chroma, (int)off) : __builtin_amdgcn_readlane(luma, (int)off));
-            const uint32_t e = (k ? pair >> 16 : pair) & 0xffffu;
-            off += e & 31u;
-            k += (e >> 5) & 127u;
+            const int dc = (int)(is_chroma ? ent[2] : ent[0]), ac = (int)(is_chroma ? ent[3] : ent[1]);
+            if (k == 0) {
+              const uint32_t e = (uint32_t)__builtin_amdgcn_readlane(dc, (int)off);
+              off += e & 31u;
+              k = (e >> 5) & 127u;  // 1 for every DC symbol
+            }
+            while ((int32_t)((k - 64u) & (off - lim)) < 0) {  // k < 64 && off < lim (both small): one compare
+              const uint32_t e = (uint32_t)__builtin_amdgcn_readlane(ac, (int)off);
+              off += e & 31u;
+              k += (e >> 5) & 127u;
+            }
             if (k >= 64u) {
               k = 0;
               b++;
@@ -1194,27 +1249,45 @@ __global__ __launch_bounds__(1024) void dc_partial_kernel(const HuffSyncArgs a, 
   dc_block_scan(v, s_sum, tid);
   if (tid == 1023) { partial[blockIdx.x * 3] = v[0]; partial[blockIdx.x * 3 + 1] = v[1]; partial[blockIdx.x * 3 + 2] = v[2]; }
 }
-// form 2 of the write pass: the DC differences sit at [0] of every scan-order block
-__global__ __launch_bounds__(1024) void dc_partial2_kernel(const HuffSyncArgs a, int* __restrict__ partial) {
-  __shared__ int s_sum[3 * 1024];
+// form 2 of the write pass: the DC differences sit at [0] of every scan-order block.  Chunks of kPlaceChunk scan positions
+// (1024 left a 4K 4:2:0 frame with 190 workgroups for 256 CUs, each spending most of its time in a ten-step scan).
+constexpr int kPlaceChunk = 256;
+__device__ __forceinline__ void dc_chunk_scan(int v[3], int* s_sum /* 3 x kPlaceChunk */, int tid) {
+#pragma unroll
+  for (int c = 0; c < 3; c++) s_sum[c * kPlaceChunk + tid] = v[c];
+  __syncthreads();
+  for (int d = 1; d < kPlaceChunk; d <<= 1) {
+    int y[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) y[c] = tid >= d ? s_sum[c * kPlaceChunk + tid - d] : 0;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 3; c++) s_sum[c * kPlaceChunk + tid] += y[c];
+    __syncthreads();
+  }
+#pragma unroll
+  for (int c = 0; c < 3; c++) v[c] = s_sum[c * kPlaceChunk + tid];  // inclusive
+}
+__global__ __launch_bounds__(kPlaceChunk) void dc_partial2_kernel(const HuffSyncArgs a, int* __restrict__ partial) {
+  __shared__ int s_sum[3 * kPlaceChunk];
   const int tid = (int)threadIdx.x;
-  const uint32_t t = blockIdx.x * 1024u + (uint32_t)tid;
+  const uint32_t t = blockIdx.x * (uint32_t)kPlaceChunk + (uint32_t)tid;
   int v[3] = {0, 0, 0};
   if (t < a.total_blocks) v[a.comp_of[t % (uint32_t)a.blocks_per_mcu]] = a.coef_scan[(size_t)t * 64];
-  dc_block_scan(v, s_sum, tid);
-  if (tid == 1023) { partial[blockIdx.x * 3] = v[0]; partial[blockIdx.x * 3 + 1] = v[1]; partial[blockIdx.x * 3 + 2] = v[2]; }
+  dc_chunk_scan(v, s_sum, tid);
+  if (tid == kPlaceChunk - 1) { partial[blockIdx.x * 3] = v[0]; partial[blockIdx.x * 3 + 1] = v[1]; partial[blockIdx.x * 3 + 2] = v[2]; }
 }
-// ... and the kernel that finishes the decode: 1024 scan positions per workgroup.  DC prediction (a workgroup scan of the
+// ... and the kernel that finishes the decode: kPlaceChunk scan positions per workgroup.  DC prediction (a workgroup scan of the
 // differences on top of the chunk's carry-in), then every wave moves 64 of the chunk's blocks, two per step: a lane reads the
 // two coefficients of one natural-order pair from the block's zig-zag scratch row (one 128-byte line per block) and the wave
 // stores 2 x 128 contiguous bytes.  Dummy blocks of edge MCUs are dropped here.
-__global__ __launch_bounds__(1024) void coef_place_kernel(const HuffSyncArgs a, const int* __restrict__ partial) {
-  __shared__ int s_sum[3 * 1024];
-  __shared__ int16_t s_dc[1024];
-  __shared__ uint32_t s_dst[1024];  // component << 30 | JBLOCK index inside its array; ~0: a dummy block of an edge MCU
-  __shared__ uint8_t s_inv[64];     // natural index -> zig-zag position
+__global__ __launch_bounds__(kPlaceChunk) void coef_place_kernel(const HuffSyncArgs a, const int* __restrict__ partial) {
+  __shared__ int s_sum[3 * kPlaceChunk];
+  __shared__ int16_t s_dc[kPlaceChunk];
+  __shared__ uint32_t s_dst[kPlaceChunk];  // component << 30 | JBLOCK index inside its array; ~0: a dummy block of an edge MCU
+  __shared__ uint8_t s_inv[64];            // natural index -> zig-zag position
   const int tid = (int)threadIdx.x;
-  const uint32_t t0 = blockIdx.x * 1024u, t = t0 + (uint32_t)tid;
+  const uint32_t t0 = blockIdx.x * (uint32_t)kPlaceChunk, t = t0 + (uint32_t)tid;
   const uint32_t bpm = (uint32_t)a.blocks_per_mcu;
   if (tid < 64) s_inv[a.zigzag[tid]] = (uint8_t)tid;  // zigzag[]: zig-zag position -> natural index
   int v[3] = {0, 0, 0};
@@ -1230,7 +1303,7 @@ __global__ __launch_bounds__(1024) void coef_place_kernel(const HuffSyncArgs a, 
     if (by < a.bh[c] && bx < a.bw[c]) where = ((uint32_t)c << 30) | ((uint32_t)by * (uint32_t)a.bw[c] + (uint32_t)bx);
   }
   s_dst[tid] = where;
-  dc_block_scan(v, s_sum, tid);
+  dc_chunk_scan(v, s_sum, tid);
   s_dc[tid] = (int16_t)(partial[blockIdx.x * 3 + c] + v[c]);
   __syncthreads();
   const uint32_t lane = (uint32_t)tid & 63u, wv = (uint32_t)tid >> 6;
@@ -1396,11 +1469,12 @@ static void launch_write2(const HuffSyncArgs& a, uint32_t nsub, int final_buf, h
   hipLaunchKernelGGL(sync_write2_kernel, dim3(grid), dim3(threads), lds, s, a, final_buf);
 }
 static void launch_place(const HuffSyncArgs& a, int* dc_partial, hipStream_t s) {
-  const int nch = (int)((a.total_blocks + 1023) / 1024);
-  hipLaunchKernelGGL(dc_partial2_kernel, dim3(nch), dim3(1024), 0, s, a, dc_partial);
+  const int nch = (int)((a.total_blocks + kPlaceChunk - 1) / kPlaceChunk);
+  hipLaunchKernelGGL(dc_partial2_kernel, dim3(nch), dim3(kPlaceChunk), 0, s, a, dc_partial);
   hipLaunchKernelGGL(dc_scan_partials_kernel, dim3(1), dim3(1024), 0, s, dc_partial, nch);
-  hipLaunchKernelGGL(coef_place_kernel, dim3(nch), dim3(1024), 0, s, a, (const int*)dc_partial);
+  hipLaunchKernelGGL(coef_place_kernel, dim3(nch), dim3(kPlaceChunk), 0, s, a, (const int*)dc_partial);
 }
+int huff_place_chunk() { return kPlaceChunk; }
 static void launch_dc(const HuffSyncArgs& a, int* dc_partial, hipStream_t s) {
   const int nch = (int)((a.total_blocks + 1023) / 1024);
   hipLaunchKernelGGL(dc_partial_kernel, dim3(nch), dim3(1024), 0, s, a, dc_partial);
@@ -1452,7 +1526,19 @@ hipError_t launch_huffman_decode_hyp(const HuffSyncArgs& a, int* dc_partial, uin
   const int grid = (int)((nsub + 63) / 64);
   const int threads = 64 * a.hyp_h;
   const size_t lds0 = (size_t)64 * ((a.sub_bits >> 3) + 4) + 64;
-  const size_t lds1 = (size_t)(64 + a.hyp_levels) * ((a.sub_bits >> 3) + 4) + 64;
+  // pass 1: 64 + levels staged chunks (+ the 16-byte overhang), then the survivor list: 10 bytes per thread
+  const size_t lds1_stage = ((((size_t)(64 + a.hyp_levels) * ((a.sub_bits >> 3) + 4) + 16 + 7) >> 2) + 1 & ~(size_t)1) * 4;
+  const size_t lds1 = lds1_stage + (size_t)threads * 10 + 16;
+  {
+    // static LDS of the pass-1 kernels (tables + scan layout) + this must fit the 64 KB a workgroup gets without opting in
+    // (4096 bits x 15 levels: 63.6 KB); beyond that the opt-in (gfx950: up to 160 KB per workgroup)
+    static size_t opted = 0;
+    if (lds1 + 21504 > (64u << 10) && lds1 > opted) {
+      const hipError_t e1 = hipFuncSetAttribute((const void*)hyp_pass1q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+      if (e1 != hipSuccess) return e1;
+      opted = lds1;
+    }
+  }
   // UHDR_HIP_HUFF_DEBUG: per-kernel times on stderr (events between the launches)
   const bool dbg = getenv("UHDR_HIP_HUFF_DEBUG") != nullptr;
   hipEvent_t ev[9];
@@ -1470,6 +1556,10 @@ hipError_t launch_huffman_decode_hyp(const HuffSyncArgs& a, int* dc_partial, uin
   static const bool qmerge = !(getenv("UHDR_HIP_HUFF_QMERGE") && atoi(getenv("UHDR_HIP_HUFF_QMERGE")) == 0);
   if (qmerge) hipLaunchKernelGGL(hyp_pass1q_kernel, dim3(grid), dim3(threads), lds1, s, a);
   else hipLaunchKernelGGL(hyp_pass1_kernel, dim3(grid), dim3(threads), lds1, s, a);
+  {
+    const hipError_t e1 = hipGetLastError();  // a launch that fails (LDS beyond the limit) must not read as a "lost" true path
+    if (e1 != hipSuccess) return e1;
+  }
   if (qmerge && a.hyp_main_levels > 0 && a.hyp_main_levels < a.hyp_levels) {
     // the paths still alive after the lockstep levels, one wave each; the grid is sized for a thick tail (a wave takes the
     // entries wave, wave + nwaves, ...), surplus waves leave at once

@@ -128,4 +128,8 @@ hipError_t launch_selftest(int which, unsigned long long* out, uint32_t arg0, ui
   return hipGetLastError();
 }
 
+// uhdr_hip_profile_mark: an empty kernel with a name of its own (extern "C": no mangling) for cutting profiler traces into sections
+extern "C" __global__ void uhdr_profile_mark_kernel() {}
+void launch_profile_mark(hipStream_t s) { hipLaunchKernelGGL(uhdr_profile_mark_kernel, dim3(1), dim3(64), 0, s); }
+
 }  // namespace uhdr

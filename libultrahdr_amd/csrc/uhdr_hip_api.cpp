@@ -839,6 +839,12 @@ int uhdr_hip_profile_read(uhdr_hip_ctx_t* c, const char* family, double* total_m
   return n;
 }
 
+void uhdr_hip_profile_mark(uhdr_hip_ctx_t* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  launch_profile_mark(c->stream);
+}
+
 int uhdr_hip_profile_read_list(uhdr_hip_ctx_t* c, const char* family, double* ms_out, int capacity, int reset) {
   if (!c) return 0;
   (void)hipStreamSynchronize(c->stream);
@@ -2420,10 +2426,24 @@ uhdr_error_info_t uhdr_hip_encode_api1_fused_dev(uhdr_hip_ctx_t* c, const uhdr_r
 // JpegR::encodeJPEGR API-1 (jpegr.cpp:253-316) from its two raw intents to its two entropy-coded scans in ONE entry point: the
 // intents go up once (fast_h2d), the fused chain leaves coefficient blocks in HBM, the marker-less Huffman coder turns them into
 // the reference's bytes, and only those come down.  What the facade's seam at encodeJPEGR calls.
+static uhdr_error_info_t encode_api1_scans_impl(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* sdr, const uhdr_raw_image_t* hdr, const uhdr_hip_encode_cfg_t* cfg,
+                                                uhdr_color_gamut_t base_encoding, const uint16_t qt_base[2][64], const uint16_t qt_map[2][64],
+                                                uhdr_gainmap_metadata_t* md, uhdr_raw_image_t* gainmap_desc, uint8_t* base_scan, size_t base_capacity,
+                                                size_t* base_bytes, uint8_t* map_scan, size_t map_capacity, size_t* map_bytes);
 uhdr_error_info_t uhdr_hip_encode_api1_scans(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* sdr, const uhdr_raw_image_t* hdr, const uhdr_hip_encode_cfg_t* cfg,
                                              uhdr_color_gamut_t base_encoding, const uint16_t qt_base[2][64], const uint16_t qt_map[2][64],
                                              uhdr_gainmap_metadata_t* md, uhdr_raw_image_t* gainmap_desc, uint8_t* base_scan, size_t base_capacity,
                                              size_t* base_bytes, uint8_t* map_scan, size_t map_capacity, size_t* map_bytes) {
+  const auto t0 = std::chrono::steady_clock::now();
+  const uhdr_error_info_t r = encode_api1_scans_impl(c, sdr, hdr, cfg, base_encoding, qt_base, qt_map, md, gainmap_desc, base_scan, base_capacity, base_bytes,
+                                                     map_scan, map_capacity, map_bytes);
+  if (c) c->stats.last_encode_api1_scans_ns = (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+  return r;
+}
+static uhdr_error_info_t encode_api1_scans_impl(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* sdr, const uhdr_raw_image_t* hdr, const uhdr_hip_encode_cfg_t* cfg,
+                                                uhdr_color_gamut_t base_encoding, const uint16_t qt_base[2][64], const uint16_t qt_map[2][64],
+                                                uhdr_gainmap_metadata_t* md, uhdr_raw_image_t* gainmap_desc, uint8_t* base_scan, size_t base_capacity,
+                                                size_t* base_bytes, uint8_t* map_scan, size_t map_capacity, size_t* map_bytes) {
   if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
   if (!sdr || !hdr || !cfg || !qt_base || !qt_map || !md || !base_scan || !map_scan || !base_bytes || !map_bytes)
     return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument");
@@ -3060,6 +3080,7 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
     // streams start at 2048 / 4096 bits --, then at doubled sizes up to 4096 bits, then the rounds at 1024 bits.
     struct Attempt { uint32_t sub_bits; int levels; };  // levels 0: the rounds
     std::vector<Attempt> attempts;
+    bool sparse = false;  // under 64 bits per block: long subsequences, many levels -- the stragglers' waves take over after ONE lockstep level
     {
       const char* eb = getenv("UHDR_HIP_HUFF_SUB_BITS");
       const char* el = getenv("UHDR_HIP_HUFF_LEVELS");
@@ -3084,6 +3105,7 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
         // ... and very sparse streams (under 64 bits per block: smooth content) start at 1024 bits for the same reason:
         // the 4K map above (49 bits per block) still loses its true path at 512 x 15 (8 unmerged paths) and settles at 1024.
         // A context also remembers the size a scan of the same shape and density settled at when the first attempt was lost.
+        sparse = bits_per_block < 64;
         uint32_t first = bits_per_block < 64 ? 1024u : (bits_per_block < 200 ? 512u : (bits_per_block < 400 ? 2048u : 4096u));
         const uhdr_hip_ctx::HuffHint& hint = c->huff_hint[bpm & 15];
         if (hint.sub_bits > first && bits_per_block * 4 >= hint.bits_per_block * 3 && bits_per_block * 4 <= hint.bits_per_block * 5) first = hint.sub_bits;
@@ -3110,7 +3132,7 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
     // hypothesis scheme (interleaved scans): one decode per possible block position instead of rounds
     const size_t o_s0 = take((size_t)nsub * 8), o_hm = use_hyp ? take((size_t)nsub * kHuffHypSlots) : 0;
     const size_t ff_bytes = off - o_s0;
-    const size_t o_s1 = take((size_t)nsub * 8), o_c0 = take(nsub), o_c1 = take(nsub), o_dcp = take((size_t)((total_blocks + 1023) / 1024) * 12 + 16),
+    const size_t o_s1 = take((size_t)nsub * 8), o_c0 = take(nsub), o_c1 = take(nsub), o_dcp = take((size_t)((total_blocks + 255) / 256) * 12 + 16),  // (form 1: chunks of 1024; form 2: huff_place_chunk() = 256)
                  o_ft = take(sizeof(HuffFastTable) * 8),  // symbol form x 4, state-tracking form x 4
                  o_st = take(((size_t)nsub / 2048 + 2) * 4), o_vt = take((size_t)4 * kHuffValWords * 4);
     const size_t o_hs = use_hyp ? take((size_t)nsub * kHuffHypSlots * 8) : 0, o_hc = use_hyp ? take((size_t)nsub * kHuffHypSlots * 2) : 0;
@@ -3164,7 +3186,9 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
     }
     if (form2) y.coef_scan = (int16_t*)(sb + o_cs);
     // lockstep levels of pass 1 before the stragglers get a wave each (0: all levels in lockstep, the round-4 form); restart files keep the lockstep form
-    const int main_levels_env = [] { const char* e = getenv("UHDR_HIP_HUFF_MAIN_LEVELS"); return e ? atoi(e) : 2; }();
+    // (a lane walks a 1024-bit subsequence in ~33 us, a straggler's wave in ~10: 4K three-channel gain map 634 us with all 15
+    // levels in lockstep, 517 with two, 491 with one; the 4:2:0 base image's 512-bit levels are cheap in lockstep once compacted)
+    const int main_levels_env = [&] { const char* e = getenv("UHDR_HIP_HUFF_MAIN_LEVELS"); return e ? atoi(e) : (sparse ? 1 : 2); }();
     if (j == bpm && bpm <= 16) {
       HIP_TRY(hipMemsetAsync(y.flags, 0, zero_bytes_sync, c->stream));  // flags, nblk, dcd and the restart map
       if (form2) HIP_TRY(hipMemsetAsync(y.coef_scan, 0, scan_bytes, c->stream));
@@ -3450,9 +3474,20 @@ uhdr_error_info_t uhdr_hip_jpeg_encode_image(uhdr_hip_ctx_t* c, const uhdr_hip_j
 // JpegDecoderHelper::decompressImage (jpegdecoderhelper.cpp:169-535) for a baseline file whose headers are parsed: entropy
 // decode, dequantization, JDCT_ISLOW IDCT and (for RGB / RGBA output of a 4:4:4 file) ycc_rgb_convert on the device; only
 // the compressed bytes go up and only the decoded samples come down.
+static uhdr_error_info_t jpeg_decode_scan_impl(uhdr_hip_ctx_t* c, const uhdr_hip_jpeg_header_t* hdr, const uint8_t* scan_data, size_t scan_bytes,
+                                               int out_channels, int variant, uint8_t* const planes[3], const unsigned int hstride[3],
+                                               const unsigned int vstride[3]);
 uhdr_error_info_t uhdr_hip_jpeg_decode_scan(uhdr_hip_ctx_t* c, const uhdr_hip_jpeg_header_t* hdr, const uint8_t* scan_data, size_t scan_bytes,
                                             int out_channels, int variant, uint8_t* const planes[3], const unsigned int hstride[3],
                                             const unsigned int vstride[3]) {
+  const auto t0 = std::chrono::steady_clock::now();
+  const uhdr_error_info_t r = jpeg_decode_scan_impl(c, hdr, scan_data, scan_bytes, out_channels, variant, planes, hstride, vstride);
+  if (c) c->stats.last_jpeg_decode_scan_ns = (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+  return r;
+}
+static uhdr_error_info_t jpeg_decode_scan_impl(uhdr_hip_ctx_t* c, const uhdr_hip_jpeg_header_t* hdr, const uint8_t* scan_data, size_t scan_bytes,
+                                               int out_channels, int variant, uint8_t* const planes[3], const unsigned int hstride[3],
+                                               const unsigned int vstride[3]) {
   if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
   if (!hdr || !scan_data || !planes || !hstride || !vstride) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument for jpeg_decode_scan");
   const DbgClock dbg;

@@ -405,7 +405,9 @@ uint32_t huff_sync_max_subsequences(uint64_t nbytes, uint32_t sub_bits);
 hipError_t launch_huffman_unstuff(const uint8_t* data, uint32_t nbytes, uint32_t* chunk_counts, uint32_t* nstuffed_dev, uint8_t* clean, hipStream_t s,
                                   uint32_t* rst_map = nullptr, uint32_t* rst_partial = nullptr);
 hipError_t launch_huffman_decode_sync(const HuffSyncArgs& a, int max_rounds, int* dc_partial, int* final_buf, hipStream_t s);
+void launch_profile_mark(hipStream_t s);  // selftest.hip: the empty kernel profilers cut their traces at
 int huff_marker_chunks(uint64_t nbytes);
+int huff_place_chunk();  // scan positions per DC-prediction chunk of write form 2 (sizes the partial-sum scratch)
 // *flag (device-visible, e.g. pinned host memory) |= 1 when data[0, nbytes) holds a 0xFF followed by anything but 0x00 (stuffing),
 // RSTn or another 0xFF (fill byte), i.e. a marker that ends the entropy-coded data before nbytes
 hipError_t launch_stray_marker_check(const uint8_t* data, uint32_t nbytes, uint32_t* flag, hipStream_t s);

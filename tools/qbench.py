@@ -68,7 +68,11 @@ def main():
             enc_inputs["hdr"] = synth.make_hdr_p010(w4, h4, ct=A.UHDR_CT_HLG).to(dev)
         return enc_inputs["sdr"], enc_inputs["hdr"]
 
-    for c in cases:
+    for n_case, c in enumerate(cases):
+        # section marker: an empty kernel of its own name, so that a profiler's kernel trace / counter rows can be cut per case
+        # (tools/read_prof.py); the mapping section -> case is this line of the log
+        ctx.lib.uhdr_hip_profile_mark(ctx.handle)
+        print(f"MARK {n_case} {c}", flush=True)
         if c[:2] in ("8k", "4k") and len(c) >= 3 and c[2] in "ABC":
             w, h = (7680, 4320) if c[0] == "8" else (w4, h4)
             ct = A.UHDR_CT_HLG if "hlg" in c else A.UHDR_CT_PQ if "pq" in c else A.UHDR_CT_LINEAR

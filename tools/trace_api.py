@@ -15,7 +15,7 @@ from libultrahdr_amd import synth  # noqa: E402
 w, h = 3840, 2160
 hdr = synth.make_hdr_p010(w, h, ct=A.UHDR_CT_HLG)
 sdr = synth.make_sdr_yuv420(w, h)
-for i in range(3):
+for i in range(8):
     print(f"--- uhdr_encode #{i}", file=sys.stderr, flush=True)
     jpg = FA.encode(hdr, sdr, gpu=True)
     print(f"--- uhdr_encode took {FA.last_call_seconds * 1e3:.2f} ms", file=sys.stderr, flush=True)
