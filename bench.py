@@ -948,6 +948,49 @@ def config4_section(ctx, u, device, rank, world, backend):
         stripes.all_reduce_probe(ctx)
     sync_all()
     allreduce_us = (time.perf_counter() - t0) / 50 * 1e6
+    # N = 1 only: the WHOLE 16384 x 16384 image of configs[3] on one GPU (it fits: 1.2 GB of intents, 5.6 GB of coefficients and
+    # gain ratios) -- the denominator of the strong-scaling point an 8-GPU run of this section gives (8 ranks x 2048 rows)
+    full = None
+    if world == 1 and not os.environ.get("UHDR_BENCH_NO_FULL_16K"):
+        try:
+            nrep = 16384 // hs
+
+            def tiled(img):  # the stripe's planes stacked nrep times, on the device (no 268-Mpx synthesis on the host)
+                big = Image(img.fmt, ws, hs * nrep, img.raw.cg, img.raw.ct, img.raw.range, align=64, device=device)
+                for pl, lay in enumerate(img.layout):
+                    if lay is None:
+                        continue
+                    src = img.plane_tensor(pl)
+                    dstp = big.plane_tensor(pl)
+                    for r in range(nrep):
+                        dstp[r * src.shape[0]:(r + 1) * src.shape[0]].copy_(src)
+                torch.cuda.synchronize()
+                return big
+
+            sdr_f, hdr_f = tiled(sdr_s), tiled(hdr_s)
+            hf = hs * nrep
+
+            def full_image():
+                base, mapc, md_, _ = enc.encodeApi1Fused(sdr_f, hdr_f, A.UHDR_CG_DISPLAY_P3, (qy, qc), (qy, qc), want_map=False)
+                eb_ = u.huffman_encode(base, ws, hf, s420, ri420)
+                em_ = u.huffman_encode(list(mapc), ws, hf, s444, ri444)
+                return int(eb_.numel()), int(em_.numel())
+
+            for _ in range(2):
+                nbm = full_image()
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                nbm = full_image()
+            ctx.synchronize()
+            el_f = (time.perf_counter() - t0) / 3
+            full = {"workload": f"the whole {ws}x{hf} image on one GPU: fused API-1 chain + Huffman coding (restart intervals), no stripes, no exchange",
+                    "ms_per_image": round(el_f * 1e3, 3), "Mpx/s": round(ws * hf / el_f / 1e6, 1), "jpeg_scan_bytes_base_and_map": list(nbm),
+                    "ratio_to_one_2048_row_stripe": round(el_f / (el / iters), 2)}
+            del sdr_f, hdr_f
+            torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001
+            full = {"error": f"{type(e).__name__}: {e}"}
     return {"workload": f"configs[3]: API-1 encode of a {ws}x{hs * world} P010 + YCbCr 4:2:0 image, {hs} rows per rank, {world} rank(s): the fused chain "
                         "(two-pass 3-channel generateGainMap whose pass 2 feeds the map's rgb->ycc + FDCT directly, convertYuv inside the base image's FDCT: "
                         "uhdr_hip_encode_api1_fused_dev) + Huffman coding (restart intervals) + gather of the entropy-coded streams to rank 0",
@@ -956,7 +999,7 @@ def config4_section(ctx, u, device, rank, world, backend):
             "transport": "host relay over torch.distributed (dry run: the ranks share devices)" if relay else "RCCL (ncclAllReduce / ncclAllGather / ncclSend + ncclRecv)",
             "ncclCommCount": nranks, "images": iters, "ms_per_image": round(el / iters * 1e3, 3), "Mpx/s": round(px * iters / el / 1e6, 1),
             "rank0_us_per_image": fam, "all_reduce_us_back_to_back": round(allreduce_us, 1), "jpeg_scan_bytes_base_and_map": out_bytes,
-            "striped_decode": striped_decode,
+            "striped_decode": striped_decode, "full_16k_x_16k_one_gpu": full,
             "max_content_boost": [round(float(v), 6) for v in md.max_content_boost]}
 
 

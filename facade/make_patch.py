@@ -41,7 +41,9 @@ def api_cpp(t):
                      "#ifdef UHDR_ENABLE_HIP\n  uhdr_hip_seam::release(m_uhdr_hip_ctxt);\n#endif\n")
     scope = ("#ifdef UHDR_ENABLE_HIP\n  uhdr_hip_seam::Scope hip_scope(handle->m_enable_hip, &handle->m_uhdr_hip_ctxt);\n"
              "  if (hip_scope.failed()) {\n    status = hip_scope.error();\n    return status;\n  }\n#endif\n")
-    t = insert_after(t, "  uhdr_error_info_t& status = handle->m_encode_call_status;\n", scope)
+    # uhdr_encode: the generated gain map may stay on the device -- every encodeJPEGR variant hands it straight to compressGainMap
+    t = insert_after(t, "  uhdr_error_info_t& status = handle->m_encode_call_status;\n",
+                     scope.replace("&handle->m_uhdr_hip_ctxt);", "&handle->m_uhdr_hip_ctxt, /* lazy_downloads */ true);"))
     # uhdr_decode: decoded images may stay on the device unless effects are queued (apply_effects reads the gain-map image on the host)
     t = insert_after(t, "  status = uhdr_dec_probe(dec);\n  if (status.error_code != UHDR_CODEC_OK) return status;\n\n  handle->m_sailed = true;\n",
                      scope.replace("&handle->m_uhdr_hip_ctxt);", "&handle->m_uhdr_hip_ctxt,\n                                  /* lazy_downloads */ handle->m_effects.empty());"))

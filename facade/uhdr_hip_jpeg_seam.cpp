@@ -334,6 +334,12 @@ bool jpeg_decompress_on_device(jpeg_decompress_struct* cinfo, bool want_rgb, uns
     // scans, a source manager that does not hold the rest of the file -- takes jpeg_read_coefficients() below.
     if (!getenv("UHDR_HIP_SEAM_CPU_ENTROPY") && device_scan_decode(cinfo, want_rgb, dest, hstride, vstride, fmt, out_fmt, st)) return true;
 
+    // everything that can still hand the image back to the reference's row-by-row CPU path has to be decided BEFORE
+    // jpeg_read_coefficients: after it the object is in DSTATE_RDCOEFS and jpeg_start_decompress would raise JERR_BAD_STATE
+    for (int c = 0; c < nc; c++) {
+      const jpeg_component_info* ci = &cinfo->comp_info[c];
+      if ((size_t)ci->width_in_blocks * ci->height_in_blocks * 64 * sizeof(short) > (size_t)900000000) return false;  // beyond one libjpeg allocation (Scratch::get)
+    }
     jvirt_barray_ptr* arrays = jpeg_read_coefficients(cinfo);  // the Huffman decode of the whole scan
     Scratch sc((j_common_ptr)cinfo);
     unsigned bw[3] = {0, 0, 0}, bh[3] = {0, 0, 0};
@@ -351,7 +357,14 @@ bool jpeg_decompress_on_device(jpeg_decompress_struct* cinfo, bool want_rgb, uns
       qt[c] = tbl->quantval;
       coef[c] = static_cast<short*>(sc.get((size_t)bw[c] * bh[c] * 64 * sizeof(short)));
       pl[c] = static_cast<unsigned char*>(sc.get((size_t)bw[c] * 8 * bh[c] * 8));
-      if (!coef[c] || !pl[c]) { sc.drop(); return false; }
+      if (!coef[c] || !pl[c]) {  // cannot happen after the size check above; if it does, it is an error, not a fallback (the coefficients are consumed)
+        sc.drop();
+        memset(st, 0, sizeof *st);
+        st->error_code = UHDR_CODEC_MEM_ERROR;
+        st->has_detail = 1;
+        snprintf(st->detail, sizeof st->detail, "scratch for component %d of a %ux%u image exceeds one libjpeg allocation", c, cinfo->image_width, cinfo->image_height);
+        return true;
+      }
       ps[c] = bw[c] * 8;
       for (unsigned by = 0; by < bh[c]; by++) {
         JBLOCKARRAY rows = (*cinfo->mem->access_virt_barray)((j_common_ptr)cinfo, arrays[c], by, 1, FALSE);

@@ -19,6 +19,7 @@ namespace uhdr_hip_seam {
 namespace {
 thread_local void* tl_ctxt = nullptr;
 thread_local bool tl_lazy_ok = false;
+thread_local bool tl_lazy_now = false;  // what uhdr_hip_resident_lazy was last told on this thread's context
 std::atomic<unsigned long> g_calls{0};
 
 uhdr_hip_ctx_t* cur() { return static_cast<uhdr_hip_ctx_t*>(tl_ctxt); }
@@ -101,6 +102,7 @@ Scope::Scope(bool enable, void** slot, bool lazy) : mPrev(tl_ctxt), mFailed(fals
     }
   }
   tl_ctxt = *slot;
+  tl_lazy_now = false;
   // one uhdr_encode / uhdr_decode: what the JPEG decode stage leaves in the JpegDecoderHelper buffers stays on the device
   // for the stage that reads those buffers next (decodeJPEGR -> applyGainMap, jpegr.cpp:1478-1530)
   uhdr_hip_resident_begin(cur());
@@ -114,7 +116,9 @@ Scope::~Scope() {
 }
 
 void lazy_downloads(bool on) {
-  if (cur()) uhdr_hip_resident_lazy(cur(), on && tl_lazy_ok);
+  if (!cur()) return;
+  tl_lazy_now = on && tl_lazy_ok;
+  uhdr_hip_resident_lazy(cur(), tl_lazy_now);
 }
 bool defer_copy(uhdr_raw_image_t* src, uhdr_raw_image_t* dst) {
   if (!cur() || !src || !dst) return false;
@@ -211,10 +215,12 @@ bool generate_gainmap(uhdr_raw_image_t* sdr_intent, uhdr_raw_image_t* hdr_intent
     memset(&md, 0, sizeof md);
     // the map's only reader is the compressImage that follows (jpegr.cpp:253-257 and its siblings), which finds it on the device:
     // it is not downloaded (any CPU stage in between gets it written first, drop_resident)
-    const bool lazy = !getenv("UHDR_HIP_SEAM_EAGER_DOWNLOADS");
-    if (lazy) uhdr_hip_resident_lazy(cur(), 1);
+    // ... only inside a call whose Scope allows it (uhdr_encode passes lazy_downloads = true: every encodeJPEGR variant hands the
+    // map straight to compressGainMap, jpegr.cpp:211-217, 253-257, 316-320, 377-381), and the previous state comes back afterwards
+    const bool was = tl_lazy_now;
+    if (tl_lazy_ok) uhdr_hip_resident_lazy(cur(), 1);
     *st = uhdr_hip_generate_gainmap(cur(), sdr_intent, hdr_intent, &cfg, &md, img.get());
-    uhdr_hip_resident_lazy(cur(), 0);
+    uhdr_hip_resident_lazy(cur(), was ? 1 : 0);
     if (!handled(*st, "generate_gainmap")) return false;
     if (st->error_code == UHDR_CODEC_OK) {
       static_cast<uhdr_gainmap_metadata_t&>(*gainmap_metadata) = md;

@@ -400,12 +400,17 @@ __global__ __launch_bounds__(kBlock) void affine_exact_kernel(const AffineParams
 }
 
 int gen_grid(uint32_t tiles) {
-  static const int resident = [] {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 1024;
+  // residency of the CURRENT device (the entry points make their context's device current first), cached per device id: a
+  // process that drives contexts on different devices must not inherit the first one's CU count
+  static int resident_of[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (resident_of[dev] == 0) {
+    int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    return cus * 3;  // 512-thread workgroups, 25 KB of LDS tables each: three are resident per CU (24 waves, the VGPR limit)
-  }();
+    resident_of[dev] = cus * 3;  // 512-thread workgroups, 25 KB of LDS tables each: three are resident per CU (24 waves, the VGPR limit)
+  }
+  const int resident = resident_of[dev];
   uint32_t g = tiles < (uint32_t)resident ? tiles : (uint32_t)resident;
   if (g > kMaxGrid) g = kMaxGrid;
   if (g < 1) g = 1;

@@ -148,6 +148,9 @@ struct uhdr_hip_ctx {
   uint32_t* h_flags = nullptr;  // pinned: status words of the entropy decoder come back here (a pageable read-back is a staged, blocking copy)
   bool resident_on = false;
   bool resident_lazy = false;
+  // a lazily kept image whose write-back failed when its slot was given up (resident_retire cannot return it): latched, and returned
+  // by the next entry point that stages an image or flushes -- the call fails instead of going on with an unwritten host buffer
+  uhdr_error_info_t sticky = {};
   unsigned int resident_next = 0;
   // an adopted copy that outlived its session (uhdr_hip_resident_end): performed by uhdr_hip_resident_materialize
   struct PendingCopy {
@@ -335,7 +338,11 @@ uhdr_error_info_t resident_write_back_all(uhdr_hip_ctx* c) {
 void resident_retire(uhdr_hip_ctx* c, uhdr_hip_ctx::Resident& r, bool host_is_rewritten) {
   if (r.valid && (r.adopted || (r.host_unwritten && !host_is_rewritten))) {
     if (host_is_rewritten) r.host_unwritten = false;
-    (void)resident_write_back(c, r);
+    const uhdr_error_info_t wb = resident_write_back(c, r);
+    if (wb.error_code != UHDR_CODEC_OK && c->sticky.error_code == UHDR_CODEC_OK) {
+      c->sticky = wb;
+      fprintf(stderr, "uhdr_hip: write-back of a device-resident image failed (%s): the next call on this context reports it\n", wb.has_detail ? wb.detail : "");
+    }
   }
   r.valid = false;
   r.host_unwritten = false;
@@ -421,6 +428,11 @@ uhdr_error_info_t fast_h2d(uhdr_hip_ctx* c, void* dst, const void* src, size_t b
 
 uhdr_error_info_t stage_in(uhdr_hip_ctx* c, int slot, const uhdr_raw_image_t* host, uhdr_raw_image_t* dev,
                            bool upload) {
+  if (c->sticky.error_code != UHDR_CODEC_OK) {  // see uhdr_hip_ctx::sticky
+    const uhdr_error_info_t e = c->sticky;
+    c->sticky = ok_status();
+    return e;
+  }
   if (!upload && c->resident_on) resident_drop(c, host->planes[0]);  // an output: stage_out will overwrite the host planes
   if (upload && c->resident_on) {  // an image uhdr_hip_jpeg_decode_scan wrote in this session is still on the device
     for (auto& r : c->resident) {
@@ -3671,6 +3683,11 @@ void uhdr_hip_resident_lazy(uhdr_hip_ctx_t* c, int on) {
 uhdr_error_info_t uhdr_hip_resident_flush(uhdr_hip_ctx_t* c) {
   if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
   HIP_TRY(hipSetDevice(c->device));
+  if (c->sticky.error_code != UHDR_CODEC_OK) {
+    const uhdr_error_info_t e = c->sticky;
+    c->sticky = ok_status();
+    return e;
+  }
   return resident_write_back_all(c);
 }
 int uhdr_hip_resident_adopt(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* src, const uhdr_raw_image_t* dst) {
