@@ -181,6 +181,8 @@ def main():
     from libultrahdr_amd.images import Image
     from libultrahdr_amd.ultrahdr import Context, UltraHdr
 
+    if rank == 0 and world == 1 and not args.no_extra:
+        os.environ.setdefault("UHDR_HIP_SEAM_TRACE", "1")  # the facade reads it once: api_level_section parses the stage lines (stderr)
     ctx = Context(dev_index)
     u = UltraHdr(ctx=ctx)
     f16 = A.UHDR_IMG_FMT_64bppRGBAHalfFloat
@@ -416,6 +418,8 @@ def order_for_readers(out):
              ("enc_api0_8k_chain_us", ("encode", "config3_api0_8k", "us")), ("enc_api0_8k_frac", ("encode", "config3_api0_8k", "roofline", "frac")),
              ("tonemap_4k_p010_us", ("extra", "tonemap_4k_p010", "us")),
              ("uhdr_encode_4k_ms", ("api_level", "uhdr_encode_api1_4k_hip", "ms")), ("uhdr_decode_4k_ms", ("api_level", "uhdr_decode_4k_f16_hip", "ms")),
+             ("uhdr_encode_4k_device_ms", ("api_level", "seam_trace_split", "uhdr_encode_4k_device_stages_ms")),
+             ("uhdr_decode_4k_device_ms", ("api_level", "seam_trace_split", "uhdr_decode_4k_device_stages_ms")),
              ("uhdr_encode_8k_ms", ("api_level", "uhdr_encode_api1_8k_hip", "ms")), ("uhdr_decode_8k_ms", ("api_level", "uhdr_decode_8k_f16_hip", "ms")),
              ("config4_ms_per_image", ("config4", "ms_per_image")), ("config4_all_reduce_us", ("config4", "all_reduce_us_back_to_back")),
              ("config4_full_16k_ms", ("config4", "full_16k_x_16k_one_gpu", "ms_per_image")))
@@ -1055,6 +1059,46 @@ def config5_section(ctx, u, device):
     return res
 
 
+def capture_stderr(fn):
+    """fn() with file descriptor 2 redirected to a temporary file (the facade's UHDR_HIP_SEAM_TRACE lines are C stdio) -> (result, text)."""
+    import tempfile
+
+    sys.stderr.flush()
+    C.CDLL(None).fflush(None)
+    saved = os.dup(2)
+    with tempfile.TemporaryFile() as tf:
+        os.dup2(tf.fileno(), 2)
+        try:
+            r = fn()
+        finally:
+            C.CDLL(None).fflush(None)
+            os.dup2(saved, 2)
+            os.close(saved)
+        tf.seek(0)
+        text = tf.read().decode(errors="replace")
+    return r, text
+
+
+def seam_ms(trace_text):
+    """Per uhdr_encode / uhdr_decode call of a UHDR_HIP_SEAM_TRACE log: (summed 'took' of its device stages, begin -> end) in ms."""
+    import re
+
+    calls, cur, t_begin = [], None, None
+    for line in trace_text.splitlines():
+        m = re.search(r"\[\s*([0-9.]+) ms(?:, took\s*([0-9.]+))?\]\s*(.*)", line)
+        if not m:
+            continue
+        t, took, what = float(m.group(1)), m.group(2), m.group(3)
+        if "accelerated call begins" in what:
+            cur, t_begin = 0.0, t
+        elif "accelerated call ends" in what and cur is not None:
+            calls.append((cur, t - t_begin))
+            cur = None
+        elif took is not None and "-> device" in what and cur is not None:
+            cur += float(took)
+    return calls
+
+
 def api_level_section():
     """SURVEY.md 8(d) configs[1] at the API level: the reference's own uhdr_decode / uhdr_encode through the drop-in
     libuhdr.so (facade/), with uhdr_enable_gpu_acceleration(codec, 1) -- host buffers in and out, PCIe and the CPU-side
@@ -1103,6 +1147,23 @@ def api_level_section():
     # the round-4 route: four per-stage seams instead of the one at encodeJPEGR (same bytes)
     jpg_ps, t_enc_ps = with_env("UHDR_HIP_SEAM_NO_FUSED_ENCODE", "1", lambda: med(lambda: FA.encode(hdr, sdr, gpu=True), 5))
     jpg2, t_enc2 = med(lambda: FA.encode(hdr, sdr, gpu=True), 5)  # ... and the fused seam once more, later in the process
+    # where the time of those two calls goes: the seam's own stage trace (UHDR_HIP_SEAM_TRACE, switched on by main()) of five more calls
+    # each -- the device stages against the reference's own host code around them (uhdr_encode: a value-initialised w x h x 6 byte
+    # output buffer, ultrahdr_api.cpp:1296-1299, and two ICC profiles; uhdr_decode: buffer allocation, parsing, copies)
+    split = {}
+    try:
+        _, txt = capture_stderr(lambda: [FA.encode(hdr, sdr, gpu=True) for _ in range(5)])
+        ce = sorted(seam_ms(txt))
+        _, txt = capture_stderr(lambda: [FA.decode(jpg, A.UHDR_CT_LINEAR, f16, gpu=True) for _ in range(5)])
+        cd = sorted(seam_ms(txt))
+        if ce:
+            split["uhdr_encode_4k_device_stages_ms"] = round(ce[len(ce) // 2][0], 2)
+            split["uhdr_encode_4k_scope_ms"] = round(sorted(c_[1] for c_ in ce)[len(ce) // 2], 2)
+        if cd:
+            split["uhdr_decode_4k_device_stages_ms"] = round(cd[len(cd) // 2][0], 2)
+            split["uhdr_decode_4k_scope_ms"] = round(sorted(c_[1] for c_ in cd)[len(cd) // 2], 2)
+    except Exception as e:  # noqa: BLE001
+        split = {"error": f"{type(e).__name__}: {e}"}
     # opt-in: restart intervals, one per wavefront
     with_env("UHDR_HIP_SEAM_RESTART_INTERVAL", "max", lambda: FA.encode(hdr, sdr, gpu=True))
     jpg_ri, t_enc_ri = with_env("UHDR_HIP_SEAM_RESTART_INTERVAL", "max", lambda: med(lambda: FA.encode(hdr, sdr, gpu=True), 5))
@@ -1126,7 +1187,7 @@ def api_level_section():
     except Exception as e:  # noqa: BLE001
         rows8 = {"uhdr_8k": {"error": f"{type(e).__name__}: {e}"}}
 
-    return {**rows8, "uhdr_encode_api1_4k_hip": row(t_enc, jpeg_bytes=len(jpg), same_bytes_as_the_libjpeg_entropy_route=bool(jpg == jpg_cpu),
+    return {**rows8, "seam_trace_split": split, "uhdr_encode_api1_4k_hip": row(t_enc, jpeg_bytes=len(jpg), same_bytes_as_the_libjpeg_entropy_route=bool(jpg == jpg_cpu),
                                            entropy_coding="device, no restart markers (the default): FDCT + quantize + Huffman coding in three passes, "
                                                           "the file is the reference's byte for byte"),
             "uhdr_decode_4k_f16_hip": row(t_dec, entropy_decoding="device (self-synchronising decoder: the file has no restart markers)",

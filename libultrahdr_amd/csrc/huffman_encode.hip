@@ -40,10 +40,28 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
   return v;
 }
 
-// jchuff.c encode_one_block as a walk that reports every (code, length) pair to `put`
+// Round 5: the walk visits the NON-ZERO coefficients only.  A lane used to step through all 63 AC positions of its block (a
+// zig-zag lookup and a coefficient read from LDS per step, twice: once for the lengths, once to emit) although a busy 4:2:0 q95
+// block has ~25 of them non-zero and a gain-map block three.  The wave first builds every block's 64-bit occupancy map in
+// zig-zag order cooperatively -- lane L reads zig-zag position L of block b, one v_cmp gives the whole map of block b as a wave
+// mask (64 x ~6 instructions for 64 blocks) -- and the walk then hops from set bit to set bit (run = distance - 1).
+// s_coef: the wave's staged blocks, kCoefRow words per block; zz_of_lane = natural index of zig-zag position `lane`.
+__device__ __forceinline__ uint64_t zigzag_nonzero_map(const uint32_t* s_coef, uint32_t zz_of_lane, uint32_t lane) {
+  uint64_t mine = 0;
+  const uint32_t word = zz_of_lane >> 1, sh = (zz_of_lane & 1u) * 16u;
+#pragma unroll 4
+  for (uint32_t b = 0; b < (uint32_t)kSegBlocks; b++) {
+    const uint32_t v = (s_coef[b * kCoefRow + word] >> sh) & 0xffffu;
+    const uint64_t m = __builtin_amdgcn_ballot_w64(v != 0);
+    if (lane == b) mine = m;
+  }
+  return mine;
+}
+// jchuff.c encode_one_block as a walk that reports every (code, length) pair to `put`; nz: the block's occupancy map (bit k =
+// zig-zag position k holds a non-zero coefficient)
 template <typename Put>
 __device__ __forceinline__ void walk_block(const uint32_t* dct, const uint32_t* act, int dc_diff, bool real, const uint32_t* coef_row,
-                                           const uint8_t* zz, uint32_t& out_of_range, Put put) {
+                                           const uint8_t* zz, uint64_t nz, uint32_t& out_of_range, Put put) {
   int temp = dc_diff, temp2 = dc_diff;
   if (temp < 0) { temp = -temp; temp2--; }
   uint32_t nbits = 32u - (uint32_t)__clz(temp);  // 0 for temp == 0
@@ -51,13 +69,17 @@ __device__ __forceinline__ void walk_block(const uint32_t* dct, const uint32_t* 
   uint32_t e = dct[nbits & 15u];
   put(e & 0xffffu, e >> 16);
   if (nbits) put((uint32_t)temp2 & ((1u << nbits) - 1u), nbits);
-  uint32_t r = 0;
+  uint32_t prev = 0;  // zig-zag position of the last coefficient coded (0: the DC term)
   if (real) {
-    for (int k = 1; k < 64; k++) {
+    uint64_t m = nz & ~1ull;
+    while (m != 0) {
+      const uint32_t k = (uint32_t)__builtin_ctzll(m);
+      m &= m - 1ull;
+      uint32_t r = k - prev - 1u;  // zeros since the last coefficient
+      prev = k;
       const uint32_t idx = zz[k];
       const uint32_t wd = coef_row[idx >> 1];
       temp = (idx & 1u) ? ((int)wd >> 16) : (int)(int16_t)(wd & 0xffffu);
-      if (temp == 0) { r++; continue; }
       while (r > 15) {
         e = act[0xf0];
         put(e & 0xffffu, e >> 16);
@@ -70,12 +92,9 @@ __device__ __forceinline__ void walk_block(const uint32_t* dct, const uint32_t* 
       e = act[((r << 4) + nbits) & 255u];
       put(e & 0xffffu, e >> 16);
       put((uint32_t)temp2 & ((1u << (nbits & 31u)) - 1u), nbits);
-      r = 0;
     }
-  } else {
-    r = 63;  // dummy block: all AC terms zero
   }
-  if (r > 0) {
+  if (prev < 63u) {  // trailing zeros (a dummy block: all 63 AC terms): EOB
     e = act[0];
     put(e & 0xffffu, e >> 16);
   }
@@ -162,10 +181,11 @@ __global__ __launch_bounds__(64) void huff_encode_kernel(const HuffArgs a) {
     const uint32_t* dct = s_tab + (c ? (16 + 256) : 0);
     const uint32_t* act = dct + 16;
     const int diff = dcv - pred;
+    const uint64_t nz = zigzag_nonzero_map(s_coef, s_zz[lane], lane);  // (rows of lanes without a real block hold stale words: never walked)
 
     // ---- pass 1: code lengths -> bit offsets inside the lane's interval ---------------------------------------------------
     uint32_t len = 0, oob = 0;
-    if (active) walk_block(dct, act, diff, real, crow, s_zz, oob, [&](uint32_t, uint32_t n) { len += n; });
+    if (active) walk_block(dct, act, diff, real, crow, s_zz, nz, oob, [&](uint32_t, uint32_t n) { len += n; });
     const uint32_t incl = wave_incl_scan(len, lane);
     // every lane takes part in both shuffles (a lane that sits out cannot be read from)
     const int first = g * per, last = min(first + per - 1, 63);
@@ -189,7 +209,7 @@ __global__ __launch_bounds__(64) void huff_encode_kernel(const HuffArgs a) {
     if (active && fits) {
       uint64_t acc = 0;
       uint32_t cnt = off & 31u, w = gbase + (off >> 5);
-      walk_block(dct, act, diff, real, crow, s_zz, oob, [&](uint32_t code, uint32_t n) {
+      walk_block(dct, act, diff, real, crow, s_zz, nz, oob, [&](uint32_t code, uint32_t n) {
         acc = (acc << n) | (uint64_t)code;
         cnt += n;
         if (cnt >= 32u) {
@@ -387,8 +407,9 @@ __global__ __launch_bounds__(64) void huff_stream_kernel(const HuffArgs a, const
     const uint32_t* dct = s_tab + (c ? (16 + 256) : 0);
     const uint32_t* act = dct + 16;
     const int diff = dcv - pred;
+    const uint64_t nz = zigzag_nonzero_map(s_coef, s_zz[lane], lane);  // (only rows of emitting lanes with a real block are ever walked)
     uint32_t len = 0, oob = 0;
-    if (emits) walk_block(dct, act, diff, real, crow, s_zz, oob, [&](uint32_t, uint32_t n) { len += n; });
+    if (emits) walk_block(dct, act, diff, real, crow, s_zz, nz, oob, [&](uint32_t, uint32_t n) { len += n; });
     const uint32_t incl = wave_incl_scan(len, lane);
     const uint32_t total_bits = (uint32_t)__shfl((int)incl, 63, 64);
     if constexpr (PASS == 0) {
@@ -404,7 +425,7 @@ __global__ __launch_bounds__(64) void huff_stream_kernel(const HuffArgs a, const
         const uint32_t off = phase + incl - len;
         uint64_t acc = 0;
         uint32_t cnt = off & 31u, w = off >> 5;
-        walk_block(dct, act, diff, real, crow, s_zz, oob, [&](uint32_t code, uint32_t n) {
+        walk_block(dct, act, diff, real, crow, s_zz, nz, oob, [&](uint32_t code, uint32_t n) {
           acc = (acc << n) | (uint64_t)code;
           cnt += n;
           if (cnt >= 32u) {
