@@ -1,4 +1,4 @@
-// Run-time binding of the handful of RCCL entry points the stripe exchange uses (uhdr_hip_api.cpp:
+// Run-time binding of the handful of RCCL entry points the stripe exchange uses (api_stripes.cpp:
 // uhdr_hip_comm_*, uhdr_hip_generate_gainmap_striped_dev).  libuhdr_hip.so does not link against librccl: a process
 // that already carries a copy (PyTorch ships its own) keeps using that one, otherwise librccl.so.1 is loaded on the
 // first communicator call; single-GPU users never load it.

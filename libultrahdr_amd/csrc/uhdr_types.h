@@ -1,4 +1,4 @@
-// Internal types shared between the host layer (uhdr_hip_api.cpp, host_tables.cpp) and the
+// Internal types shared between the host layer (api_*.cpp, host_tables.cpp) and the
 // kernel translation units.  Nothing here is part of the C ABI (include/uhdr_hip.h).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -75,7 +75,7 @@ struct ApplyTables {  // layout of the device table block, in floats
 };
 
 // batch mode: per-frame plane pointers; geometry / strides / metadata are shared
-constexpr int kMaxBatchFrames = 16;  // frames per launch (uhdr_hip_api.cpp: beyond ~16 separate allocations DRAM locality drops)
+constexpr int kMaxBatchFrames = 16;  // frames per launch (api_gainmap.cpp: beyond ~16 separate allocations DRAM locality drops)
 struct FramePtrs {
   const uint8_t *y, *u, *v, *map;
   uint8_t* dst;
@@ -104,7 +104,7 @@ struct ApplyParams {
   uint32_t tiles_per_wave;  // quad kernel: loop trip count (even), set by the launcher
   uint32_t touch_ahead;     // quad kernel: 1 = the launch opens with a grid-wide read sweep over the input planes (set by the launcher)
   uint32_t prefetch_wgs;    // quad kernel: the first prefetch_wgs workgroups only stream the input planes into L2 / the infinity cache (set by the launcher)
-  uint32_t inputs_hot;      // the host layer's guess that the input planes still sit in the infinity cache (uhdr_hip_api.cpp: mall_model): no prefetchers then
+  uint32_t inputs_hot;      // the host layer's guess that the input planes still sit in the infinity cache (api_gainmap.cpp: mall_model): no prefetchers then
   uint32_t row_groups;      // quad kernel: quad-row step of a wave, set by the launcher
   uint32_t n_frames;        // 0/1: single image; > 1: batch through `frame_tab` (quad kernel only)
   uint32_t scale;           // integer map scale factor (table path) or 0
