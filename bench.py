@@ -631,9 +631,11 @@ def encode_section(ctx, u, device):
             rows, stride, wv = img.layout[c]
             u.fdct_quant(img.plane_tensor(c), stride, wv // 8, rows // 8, tables[c])
 
-    def roof(px, kernels, bytes_per_px):
+    def roof(px, kernels, bytes_per_px, traffic_key=None):
         tot_us = sum(k["us"] for k in kernels.values())
         b = sum(bytes_per_px.values()) * px
+        # HBM bytes of the chain's kernels from the counter passes of a profiled run of THIS library (profiles/traffic.json, round 5)
+        tr, tr_src = measured_traffic(traffic_key) if traffic_key else (None, None)
         for name, k in kernels.items():
             k["bytes_per_px"] = bytes_per_px.get(name)
             if bytes_per_px.get(name):
@@ -641,7 +643,7 @@ def encode_section(ctx, u, device):
                 k["frac"] = round(k["GB/s"] / HBM_PEAK_GBS, 4)
         return {"bound": "hbm", "achieved": round(b / (tot_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(b / (tot_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": int(b), "chain_us": round(tot_us, 1),
-                "traffic": None, "kernels": kernels}
+                "traffic": tr, "traffic_source": tr_src, "kernels": kernels}
 
     # ---- BASELINE config 3: API-0, 8K RGBA1010102 PQ ------------------------------------------------------------------
     w8, h8 = 7680, 4320
@@ -670,7 +672,9 @@ def encode_section(ctx, u, device):
 
     k = family_times(ctx, api0_fused, fams, iters=3, warm=1)
     # fused front end: 4 in, 3 + 3 out; base FDCT 3 + 6; fused map rgb->ycc + FDCT 3 + 6 (both under "fdct_quant")
-    r = roof(px8, k, {"encode_api0_fused": 10.0, "fdct_quant": 18.0})
+    r = roof(px8, k, {"encode_api0_fused": 10.0, "fdct_quant": 18.0}, "encode.config3_api0_8k")
+    if r.get("traffic") is not None:
+        r["traffic_note"] = "the fused front-end kernel only (10 B/px of the 28): the six FDCTs behind it were not in the profiled case"
     res["config3_api0_8k"] = {
         "workload": "configs[2] with the MI355X-first fusion: one front-end kernel (tone map + gain map + YCbCr 4:4:4) + "
                     "3 x fdct_quant + fused (rgb->ycc + 3 x fdct_quant) of the map; same bytes out as the reference operators",
@@ -711,7 +715,7 @@ def encode_section(ctx, u, device):
     fn4 = fused_chain(enc1, sdr, hdr)
     k = family_times(ctx, fn4, fams + ["encode_api1_chain"], iters=5, warm=2)
     chain4 = k.pop("encode_api1_chain", None)
-    r = roof(px, k, {"generate_gainmap": 16.5, "fdct_quant": 18.0 + 4.5})
+    r = roof(px, k, {"generate_gainmap": 16.5, "fdct_quant": 18.0 + 4.5}, "encode.api1_4k")
     st = A.Stats()
     ctx.lib.uhdr_hip_get_stats(ctx.handle, C.byref(st))
     res["api1_4k"] = {
@@ -734,7 +738,7 @@ def encode_section(ctx, u, device):
     fn8 = fused_chain(enc1, sdr, hdr)
     k = family_times(ctx, fn8, fams + ["encode_api1_chain"], iters=3, warm=1)
     chain8 = k.pop("encode_api1_chain", None)
-    r = roof(px, k, {"generate_gainmap": 16.5, "fdct_quant": 18.0 + 4.5})
+    r = roof(px, k, {"generate_gainmap": 16.5, "fdct_quant": 18.0 + 4.5}, "encode.api1_8k")
     res["api1_8k"] = {"workload": "the fused API-1 chain at 7680x4320", "us": r["chain_us"], "chain_us_one_event_pair": chain8["us"] if chain8 else None,
                       "wall_us_per_chain": round(time_region(ctx, fn8, iters=6, warm=1, reps=3) * 1e3, 1), "Mpx/s": round(px / r["chain_us"], 1), "roofline": r}
     return res

@@ -50,14 +50,37 @@ __device__ __forceinline__ bool is_dropped(const uint8_t* __restrict__ d, uint32
   return is_rst_first(d, i, n) || (i > 0 && (d[i] & 0xf8u) == 0xd0u && d[i - 1] == 0xffu);
 }
 
+// Round 5: 16 bytes per thread as ONE 16-byte load (+ the byte in front of it) and a 16-bit drop mask instead of sixteen byte
+// loads with a neighbour look-up each.  dropmask16: bit k set = byte base + k is dropped.
+template <bool RST>
+__device__ __forceinline__ uint32_t dropmask16(const uint8_t* __restrict__ data, uint32_t base, uint32_t n) {
+  uint32_t m = 0;
+  if (base + 17u <= n && base > 0 && ((uintptr_t)(data + base) & 15u) == 0) {
+    const uint4 v = *(const uint4*)(data + base);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t prev = data[base - 1];
+    const uint32_t next = data[base + 16u];
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) {
+      const uint32_t cur = (w[k >> 2] >> (8u * (k & 3u))) & 0xffu;
+      const uint32_t nx = k < 15 ? (w[(k + 1u) >> 2] >> (8u * ((k + 1u) & 3u))) & 0xffu : next;
+      bool drop = cur == 0u && prev == 0xffu;                                        // a stuffed zero
+      if (RST) drop = drop || (cur == 0xffu && (nx & 0xf8u) == 0xd0u) || ((cur & 0xf8u) == 0xd0u && prev == 0xffu);  // both bytes of an RSTn marker
+      m |= drop ? (1u << k) : 0u;
+      prev = cur;
+    }
+  } else {
+    for (uint32_t k = 0; k < 16 && base + k < n; k++) m |= is_dropped<RST>(data, base + k, n) ? (1u << k) : 0u;
+  }
+  return m;
+}
 template <bool RST>
 __global__ __launch_bounds__(256) void unstuff_count_kernel(const uint8_t* __restrict__ data, uint32_t n, uint32_t* __restrict__ counts) {
   __shared__ uint32_t s_cnt;
   if (threadIdx.x == 0) s_cnt = 0;
   __syncthreads();
   const uint32_t base = blockIdx.x * kChunk + threadIdx.x * 16;
-  uint32_t c = 0;
-  for (uint32_t i = base; i < base + 16 && i < n; i++) c += is_dropped<RST>(data, i, n) ? 1u : 0u;
+  const uint32_t c = base < n ? (uint32_t)__builtin_popcount(dropmask16<RST>(data, base, n)) : 0u;
   if (c) atomicAdd(&s_cnt, c);
   __syncthreads();
   if (threadIdx.x == 0) counts[blockIdx.x] = s_cnt;
@@ -154,8 +177,8 @@ __global__ __launch_bounds__(256) void unstuff_compact_kernel(const uint8_t* __r
   __shared__ uint32_t s_rst[3];
   const uint32_t tid = threadIdx.x, base = blockIdx.x * kChunk + tid * 16;
   if (RST && tid < 3) s_rst[tid] = 0;
-  uint32_t c = 0;
-  for (uint32_t i = base; i < base + 16 && i < n; i++) c += is_dropped<RST>(data, i, n) ? 1u : 0u;
+  const uint32_t mask = base < n ? dropmask16<RST>(data, base, n) : 0u;
+  const uint32_t c = (uint32_t)__builtin_popcount(mask);
   s_scan[tid] = c;
   __syncthreads();
   for (uint32_t d = 1; d < 256; d <<= 1) {
@@ -165,19 +188,30 @@ __global__ __launch_bounds__(256) void unstuff_compact_kernel(const uint8_t* __r
     __syncthreads();
   }
   uint32_t dropped = chunk_base[blockIdx.x] + s_scan[tid] - c;  // dropped bytes before this thread's first byte
-  for (uint32_t i = base; i < base + 16 && i < n; i++) {
-    if (RST && is_rst_first(data, i, n)) {
-      const uint32_t at = i - dropped;  // where the next interval's first byte lands
-      atomicOr(rst_map + (at >> 5), 1u << (at & 31u));
-      // the marker's number (RST0..RST7 in turn), folded into two position-weighted sums; the write pass forms the same
-      // sums from the numbers the interval ends SHOULD have (rst_weight above)
-      const uint32_t m = (data[i + 1] & 7u) + 1u;
-      atomicAdd(&s_rst[0], 1u);
-      atomicAdd(&s_rst[1], rst_weight1(at) * m);
-      atomicAdd(&s_rst[2], rst_weight2(at) * m);
+  if (mask == 0 && base + 16u <= n && ((uintptr_t)(data + base) & 15u) == 0) {
+    // nothing dropped in these 16 bytes (15 threads in 16 of a stuffed stream): four dword stores at the shifted, in general
+    // unaligned, destination (global memory takes unaligned dword accesses) instead of sixteen byte stores
+    const uint4 v = *(const uint4*)(data + base);
+    uint8_t* d = clean + (base - dropped);
+    __builtin_memcpy(d, &v.x, 4);
+    __builtin_memcpy(d + 4, &v.y, 4);
+    __builtin_memcpy(d + 8, &v.z, 4);
+    __builtin_memcpy(d + 12, &v.w, 4);
+  } else {
+    for (uint32_t i = base; i < base + 16 && i < n; i++) {
+      if (RST && is_rst_first(data, i, n)) {
+        const uint32_t at = i - dropped;  // where the next interval's first byte lands
+        atomicOr(rst_map + (at >> 5), 1u << (at & 31u));
+        // the marker's number (RST0..RST7 in turn), folded into two position-weighted sums; the write pass forms the same
+        // sums from the numbers the interval ends SHOULD have (rst_weight above)
+        const uint32_t m = (data[i + 1] & 7u) + 1u;
+        atomicAdd(&s_rst[0], 1u);
+        atomicAdd(&s_rst[1], rst_weight1(at) * m);
+        atomicAdd(&s_rst[2], rst_weight2(at) * m);
+      }
+      if ((mask >> (i - base)) & 1u) dropped++;
+      else clean[i - dropped] = data[i];
     }
-    if (is_dropped<RST>(data, i, n)) dropped++;
-    else clean[i - dropped] = data[i];
   }
   if (RST) {
     __syncthreads();
