@@ -775,13 +775,21 @@ def api1_roundtrip_section(ctx, u, device):
         out_m = torch.empty(px * 4, dtype=torch.uint8, device=device)
         box = {}
 
-        def enc():
+        def enc(two=True):
             cb, cm, md_, _ = enc1.encodeApi1Fused(sdr, hdr, A.UHDR_CG_DISPLAY_P3, (qy, qc), (qy, qc), want_map=False)
-            box["nb"] = int(u.huffman_encode(cb, w, h, S420, 0, out=out_b).numel())
-            box["nm"] = int(u.huffman_encode(cm, w, h, S444, 0, out=out_m).numel())
+            if two:  # both scans at once: the map's on the context's auxiliary stream (uhdr_hip_huffman_encode2_dev)
+                eb, em = u.huffman_encode2(cb, w, h, S420, cm, w, h, S444, 0, outs=[out_b, out_m])
+                box["nb"], box["nm"] = int(eb.numel()), int(em.numel())
+            else:
+                box["nb"] = int(u.huffman_encode(cb, w, h, S420, 0, out=out_b).numel())
+                box["nm"] = int(u.huffman_encode(cm, w, h, S444, 0, out=out_m).numel())
             box["md"], box["shp_b"], box["shp_m"] = md_, [tuple(c.shape[:2]) for c in cb], [tuple(c.shape[:2]) for c in cm]
 
+        enc(False)
+        ms_enc_seq = time_region(ctx, lambda: enc(False), iters=it, warm=2, reps=3)
+        seq_sizes = (box["nb"], box["nm"])
         enc()
+        assert seq_sizes == (box["nb"], box["nm"])
         ms_enc = time_region(ctx, enc, iters=it, warm=2, reps=3)
         k_enc = family_times(ctx, enc, fams, iters=3, warm=1)
         sb, sm = out_b[: box["nb"]].clone(), out_m[: box["nm"]].clone()
@@ -791,9 +799,12 @@ def api1_roundtrip_section(ctx, u, device):
         st0 = A.Stats()
         ctx.lib.uhdr_hip_get_stats(ctx.handle, C.byref(st0))
 
-        def dec():
-            cb = u.huffman_decode(sb, box["shp_b"], w, h, S420, 0)
-            cm = u.huffman_decode(sm, box["shp_m"], w, h, S444, 0)
+        def dec(two=True):
+            if two:  # uhdr_hip_huffman_decode2_dev
+                cb, cm = u.huffman_decode2(sb, box["shp_b"], w, h, S420, sm, box["shp_m"], w, h, S444, 0)
+            else:
+                cb = u.huffman_decode(sb, box["shp_b"], w, h, S420, 0)
+                cm = u.huffman_decode(sm, box["shp_m"], w, h, S444, 0)
             u.idct_dequant_rgb(cm, qy, qc, w, h, rgba, 0, dst=gm3)
             u.applyGainMapFromCoefficients(cb, qts, w, h, A.UHDR_CG_BT_709, gm3, box["md"], A.UHDR_CT_LINEAR, f16, A.FLT_MAX, dst)
 
@@ -808,9 +819,11 @@ def api1_roundtrip_section(ctx, u, device):
         else:
             ms_dec = time_region(ctx, dec, iters=it, warm=2, reps=3)
             k_dec = family_times(ctx, dec, fams, iters=3, warm=1)
+            res[f"api1_{tag}_dec_one_scan_at_a_time_us"] = round(time_region(ctx, lambda: dec(False), iters=it, warm=2, reps=3) * 1e3, 1)
         st1 = A.Stats()
         ctx.lib.uhdr_hip_get_stats(ctx.handle, C.byref(st1))
         res[f"api1_{tag}_enc_us"] = round(ms_enc * 1e3, 1)
+        res[f"api1_{tag}_enc_one_scan_at_a_time_us"] = round(ms_enc_seq * 1e3, 1)
         res[f"api1_{tag}_dec_us"] = round(ms_dec * 1e3, 1)
         res[f"api1_{tag}_roundtrip_Mpxs"] = round(px / ((ms_enc + ms_dec) * 1e-3) / 1e6, 1)
         res[f"api1_{tag}_enc_kernels_us"] = round(sum(v["us"] for v in k_enc.values()), 1)
@@ -829,8 +842,9 @@ def api1_roundtrip_section(ctx, u, device):
         del sdr, hdr, out_b, out_m, sb, sm, gm3, dst
         torch.cuda.empty_cache()
     res["api1_note"] = ("device-resident API-1 round trip, synthetic noisy frames at q95 (dense streams: ~3.3 MB base scan per 4K frame); enc_us / dec_us: "
-                        "one HIP-event pair around back-to-back calls, host gaps of the synchronous entropy entry points included; *_kernels_us: sum of the "
-                        "per-launch HIP events of the same calls")
+                        "one HIP-event pair around back-to-back calls, host gaps of the synchronous entropy entry points included, the file's two scans "
+                        "entropy-coded concurrently (uhdr_hip_huffman_{encode,decode}2_dev; *_one_scan_at_a_time_us = the same with two single-scan "
+                        "calls); *_kernels_us: sum of the per-launch HIP events of the same calls (overlapping launches counted in full)")
     return res
 
 

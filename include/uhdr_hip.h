@@ -513,6 +513,18 @@ typedef struct uhdr_hip_huff_tables {
 uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* ctx, const uhdr_hip_jpeg_scan_t* scan,
                                               const uhdr_hip_huff_tables_t* tables, const uint8_t* data,
                                               size_t data_bytes);
+/* Round 5: the TWO scans of one UltraHDR file (base image and gain map) coded / decoded concurrently -- same arguments, results
+ * and error behaviour as two calls of uhdr_hip_huffman_encode_dev / _decode_dev (scan a on the context's stream from the calling
+ * thread, scan b on an auxiliary stream of the same device from a second thread; the first error is returned).  The entropy
+ * stages are latency- and occupancy-bound for long stretches, which the two streams overlap (4K API-1 pair: see DESIGN.md 5.5).
+ * Synchronous; the context's stream is synchronised first (the inputs of both scans were produced on it). */
+uhdr_error_info_t uhdr_hip_huffman_encode2_dev(uhdr_hip_ctx_t* ctx, const uhdr_hip_jpeg_scan_t* scan_a, uint8_t* out_a, size_t capacity_a,
+                                               size_t* bytes_a, const uhdr_hip_jpeg_scan_t* scan_b, uint8_t* out_b, size_t capacity_b,
+                                               size_t* bytes_b);
+uhdr_error_info_t uhdr_hip_huffman_decode2_dev(uhdr_hip_ctx_t* ctx, const uhdr_hip_jpeg_scan_t* scan_a,
+                                               const uhdr_hip_huff_tables_t* tables_a, const uint8_t* data_a, size_t data_bytes_a,
+                                               const uhdr_hip_jpeg_scan_t* scan_b, const uhdr_hip_huff_tables_t* tables_b,
+                                               const uint8_t* data_b, size_t data_bytes_b);
 /* Host helper (no device work): wraps entropy-coded data (HOST pointer) into a complete baseline JFIF file -- SOI,
  * APP0, DQT (natural-order tables as uhdr_hip_jpeg_quant_table returns them; component 0 uses qtable_luma, the others
  * qtable_chroma), SOF0, DHT (Annex K), DRI, SOS, data, EOI, the marker order of libjpeg's jcmarker.c.  scan->coef is

@@ -205,6 +205,8 @@ _SIGS = {
     "uhdr_hip_exact_math_eval": (C.c_int, [C.c_int, _P(C.c_float), _P(C.c_float), C.c_size_t]),
     "uhdr_hip_encode_api1_fused_dev": (ErrorInfo, [C.c_void_p, _P(RawImage), _P(RawImage), _P(EncodeCfg), C.c_int, C.c_void_p, C.c_void_p, _P(Api1Blocks),
                                                    _P(GainmapMetadata), _P(RawImage)]),
+    "uhdr_hip_huffman_encode2_dev": (ErrorInfo, [C.c_void_p, _P(JpegScan), C.c_void_p, C.c_size_t, _P(C.c_size_t), _P(JpegScan), C.c_void_p, C.c_size_t, _P(C.c_size_t)]),
+    "uhdr_hip_huffman_decode2_dev": (ErrorInfo, [C.c_void_p, _P(JpegScan), _P(HuffTables), C.c_void_p, C.c_size_t, _P(JpegScan), _P(HuffTables), C.c_void_p, C.c_size_t]),
     "uhdr_hip_encode_api1_scans": (ErrorInfo, [C.c_void_p, _P(RawImage), _P(RawImage), _P(EncodeCfg), C.c_int, C.c_void_p, C.c_void_p, _P(GainmapMetadata),
                                                _P(RawImage), C.c_void_p, C.c_size_t, _P(C.c_size_t), C.c_void_p, C.c_size_t, _P(C.c_size_t)]),
     "uhdr_hip_comm_all_reduce_min_dev": (ErrorInfo, [C.c_void_p, C.c_void_p, C.c_size_t]),

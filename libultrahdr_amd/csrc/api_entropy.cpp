@@ -607,3 +607,66 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
   if (st[0] & 2u) return err_status(UHDR_CODEC_INVALID_PARAM, "corrupt entropy-coded data (undefined Huffman code or a run past the end of a block)");
   return ok_status();
 }
+
+// ---- the two scans of one UltraHDR file at once (round 5) ------------------------------------------------------------------
+// JpegR::encodeJPEGR codes the gain map, then the base image (jpegr.cpp:253-316); JpegR::decodeJPEGR decodes the base image, then
+// the map (jpegr.cpp:1478-1488) -- one after the other because libjpeg is serial anyway.  On the device the two scans are independent
+// work whose passes are latency- or occupancy-bound for long stretches (single-workgroup scans, the write pass at under one wave per
+// SIMD, the stragglers' scalar chains): the second scan runs on the context's auxiliary context (own stream, scratch and table
+// cache) from a second host thread, the first on the caller's thread; both entry points are synchronous like their single-scan forms.
+namespace {
+uhdr_error_info_t aux_context(uhdr_hip_ctx* c, uhdr_hip_ctx** out) {
+  if (!c->aux) {
+    uhdr_error_info_t e = ok_status();
+    c->aux = uhdr_hip_create(c->device, &e);
+    if (!c->aux) return e.error_code != UHDR_CODEC_OK ? e : err_status(UHDR_CODEC_ERROR, "could not create the auxiliary context");
+  }
+  c->aux->prof = c->prof;
+  c->aux->huff_serial_ok = c->huff_serial_ok;
+  *out = c->aux;
+  return ok_status();
+}
+void aux_merge(uhdr_hip_ctx* c) {  // what the second scan counted and timed belongs to the caller's context
+  uhdr_hip_ctx* x = c->aux;
+  c->stats.entropy_decode_parallel += x->stats.entropy_decode_parallel;
+  c->stats.entropy_decode_intervals += x->stats.entropy_decode_intervals;
+  c->stats.entropy_decode_single_lane += x->stats.entropy_decode_single_lane;
+  c->stats.entropy_decode_declined += x->stats.entropy_decode_declined;
+  c->stats.entropy_encode_stream += x->stats.entropy_encode_stream;
+  c->stats.entropy_encode_intervals += x->stats.entropy_encode_intervals;
+  x->stats = uhdr_hip_stats_t();
+  for (auto& e : x->prof_entries) c->prof_entries.push_back(e);
+  x->prof_entries.clear();
+}
+}  // namespace
+
+uhdr_error_info_t uhdr_hip_huffman_encode2_dev(uhdr_hip_ctx_t* c, const uhdr_hip_jpeg_scan_t* scan_a, uint8_t* out_a, size_t cap_a, size_t* bytes_a,
+                                               const uhdr_hip_jpeg_scan_t* scan_b, uint8_t* out_b, size_t cap_b, size_t* bytes_b) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  HIP_TRY(hipSetDevice(c->device));
+  uhdr_hip_ctx* x = nullptr;
+  UHDR_TRY(aux_context(c, &x));
+  HIP_TRY(hipStreamSynchronize(c->stream));  // the coefficients both scans read were produced on this stream
+  uhdr_error_info_t rb = ok_status();
+  std::thread second([&] { rb = uhdr_hip_huffman_encode_dev(x, scan_b, out_b, cap_b, bytes_b); });
+  const uhdr_error_info_t ra = uhdr_hip_huffman_encode_dev(c, scan_a, out_a, cap_a, bytes_a);
+  second.join();
+  aux_merge(c);
+  return ra.error_code != UHDR_CODEC_OK ? ra : rb;
+}
+
+uhdr_error_info_t uhdr_hip_huffman_decode2_dev(uhdr_hip_ctx_t* c, const uhdr_hip_jpeg_scan_t* scan_a, const uhdr_hip_huff_tables_t* tables_a, const uint8_t* data_a,
+                                               size_t bytes_a, const uhdr_hip_jpeg_scan_t* scan_b, const uhdr_hip_huff_tables_t* tables_b,
+                                               const uint8_t* data_b, size_t bytes_b) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  HIP_TRY(hipSetDevice(c->device));
+  uhdr_hip_ctx* x = nullptr;
+  UHDR_TRY(aux_context(c, &x));
+  HIP_TRY(hipStreamSynchronize(c->stream));  // the bytes of both scans may have come up on this stream
+  uhdr_error_info_t rb = ok_status();
+  std::thread second([&] { rb = uhdr_hip_huffman_decode_dev(x, scan_b, tables_b, data_b, bytes_b); });
+  const uhdr_error_info_t ra = uhdr_hip_huffman_decode_dev(c, scan_a, tables_a, data_a, bytes_a);
+  second.join();
+  aux_merge(c);
+  return ra.error_code != UHDR_CODEC_OK ? ra : rb;
+}

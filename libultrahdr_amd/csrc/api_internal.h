@@ -114,6 +114,10 @@ struct uhdr_hip_ctx {
   uhdr_hip_stats_t stats = {};    // uhdr_hip_get_stats: which route the entropy stage took, call by call
   bool huff_serial_ok = true;  // uhdr_hip_jpeg_decode_scan clears it: a large marker-less scan that the parallel decoder cannot settle goes back to the caller
   DeviceBuf enc[3];  // uhdr_hip_encode_api1_scans: the six coefficient arrays | base scan | map scan
+  // round 5: a second context on the same device (own stream, scratch, table cache), created on first use by the entry points that
+  // code the TWO scans of an UltraHDR file concurrently (uhdr_hip_huffman_encode2_dev / _decode2_dev): the entropy stages are
+  // latency- and occupancy-bound for long stretches (one-workgroup scans, the write pass, the stragglers), which two streams overlap
+  uhdr_hip_ctx* aux = nullptr;
   DeviceBuf jpg[6];  // uhdr_hip_jpeg_decode_scan: entropy-coded data | coefficient arrays x 3 | decoded planes / pixels
   // uhdr_hip_resident_begin .. _end: the images uhdr_hip_jpeg_decode_scan wrote to the caller's buffers stay on the device,
   // keyed by those host pointers, so that the host variant of uhdr_hip_apply_gainmap does not upload them again

@@ -420,13 +420,12 @@ static uhdr_error_info_t encode_api1_scans_impl(uhdr_hip_ctx_t* c, const uhdr_ra
   UHDR_TRY(ensure(c->enc[1], base_capacity + 64));
   UHDR_TRY(ensure(c->enc[2], map_capacity + 64));
   size_t nbs = 0, nms = 0;
-  const uhdr_error_info_t eb = uhdr_hip_huffman_encode_dev(c, &sb, (uint8_t*)c->enc[1].p, base_capacity, &nbs);
+  // both scans at once (round 5): the base image on this context's stream, the map on the auxiliary one
+  const uhdr_error_info_t e2 = uhdr_hip_huffman_encode2_dev(c, &sb, (uint8_t*)c->enc[1].p, base_capacity, &nbs, &sm, (uint8_t*)c->enc[2].p, map_capacity, &nms);
   *base_bytes = nbs;
-  if (eb.error_code != UHDR_CODEC_OK) { *map_bytes = 0; return eb; }
-  HIP_TRY(hipMemcpyAsync(base_scan, c->enc[1].p, nbs, hipMemcpyDeviceToHost, c->stream));  // overlaps the map's entropy coding
-  const uhdr_error_info_t em = uhdr_hip_huffman_encode_dev(c, &sm, (uint8_t*)c->enc[2].p, map_capacity, &nms);
   *map_bytes = nms;
-  if (em.error_code != UHDR_CODEC_OK) { (void)hipStreamSynchronize(c->stream); return em; }
+  if (e2.error_code != UHDR_CODEC_OK) return e2;
+  HIP_TRY(hipMemcpyAsync(base_scan, c->enc[1].p, nbs, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(map_scan, c->enc[2].p, nms, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return ok_status();

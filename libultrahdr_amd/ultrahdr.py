@@ -379,6 +379,31 @@ class UltraHdr:
                    C.c_void_p(data.data_ptr()), data.numel())
         return coefs
 
+    def huffman_encode2(self, coefs_a, w_a, h_a, sampling_a, coefs_b, w_b, h_b, sampling_b, restart_interval: int = 0, outs=None):
+        """The two scans of one UltraHDR file (base image, gain map) coded concurrently (uhdr_hip_huffman_encode2_dev): two
+        huffman_encode calls' arguments, returns the two uint8 CUDA tensors."""
+        import torch
+
+        sa, sb = self._scan(coefs_a, w_a, h_a, sampling_a, restart_interval), self._scan(coefs_b, w_b, h_b, sampling_b, restart_interval)
+        if outs is None:
+            outs = [torch.empty(sum(int(c.numel()) for c in cf) // 64 * 416 + 4096, dtype=torch.uint8, device=cf[0].device) for cf in (coefs_a, coefs_b)]
+        na, nb = C.c_size_t(0), C.c_size_t(0)
+        self._call(True, self.lib.uhdr_hip_huffman_encode2_dev, self.ctx.handle, C.byref(sa), C.c_void_p(outs[0].data_ptr()), outs[0].numel(), C.byref(na),
+                   C.byref(sb), C.c_void_p(outs[1].data_ptr()), outs[1].numel(), C.byref(nb))
+        return outs[0][: na.value], outs[1][: nb.value]
+
+    def huffman_decode2(self, data_a, shapes_a, w_a, h_a, sampling_a, data_b, shapes_b, w_b, h_b, sampling_b, restart_interval: int = 0):
+        """The two scans of one UltraHDR file decoded concurrently (uhdr_hip_huffman_decode2_dev), Annex K tables: returns the two
+        lists of int16 [blocks_h, blocks_w, 64] CUDA tensors."""
+        import torch
+
+        ca = [torch.empty((bh, bw, 64), dtype=torch.int16, device=data_a.device) for (bh, bw) in shapes_a]
+        cb = [torch.empty((bh, bw, 64), dtype=torch.int16, device=data_b.device) for (bh, bw) in shapes_b]
+        sa, sb = self._scan(ca, w_a, h_a, sampling_a, restart_interval), self._scan(cb, w_b, h_b, sampling_b, restart_interval)
+        self._call(True, self.lib.uhdr_hip_huffman_decode2_dev, self.ctx.handle, C.byref(sa), None, C.c_void_p(data_a.data_ptr()), data_a.numel(),
+                   C.byref(sb), None, C.c_void_p(data_b.data_ptr()), data_b.numel())
+        return ca, cb
+
     def jpeg_parse(self, jpeg: bytes) -> "A.JpegHeader":
         """Host helper: the headers of a baseline JPEG file in the form the device decode path takes (ValueError with the
         library's code for files outside that path, e.g. -8 for progressive)."""

@@ -274,3 +274,42 @@ def test_restart_files_that_are_not_what_the_header_says_are_reported(uhdr):
     again = uhdr.huffman_decode(_dev(bytes(scan)), shapes, w, h, sampling, ri)
     for c in range(3):
         assert np.array_equal(again[c].cpu().numpy(), coefs[c]), c
+
+
+@pytest.mark.parametrize("ri", [0, 6])
+def test_two_scans_at_once_equal_two_calls(uhdr, ri):
+    """uhdr_hip_huffman_encode2_dev / _decode2_dev (the base image's and the gain map's scans of one file, the second on the context's
+    auxiliary stream) give the bytes and coefficients of two single-scan calls -- and of the oracle --, repeatedly, with the roles of
+    the scans exchanged, and an error in either scan is the call's error."""
+    import torch
+
+    rng = np.random.default_rng(977 + ri)
+    wa, ha, sa = 1280, 720, [(2, 2), (1, 1), (1, 1)]
+    wb, hb, sb = 640, 360, [(1, 1)] * 3
+    ca, cb = _random_coefs(rng, wa, ha, sa, "dense"), _random_coefs(rng, wb, hb, sb, "sparse")
+    da, db = [torch.from_numpy(c).to("cuda:0") for c in ca], [torch.from_numpy(c).to("cuda:0") for c in cb]
+    one_a = bytes(uhdr.huffman_encode(da, wa, ha, sa, ri).cpu().numpy())
+    one_b = bytes(uhdr.huffman_encode(db, wb, hb, sb, ri).cpu().numpy())
+    assert one_a == L.huffman_encode_port(ca, wa, ha, sa, ri)
+    for rep in range(3):
+        ea, eb = uhdr.huffman_encode2(da, wa, ha, sa, db, wb, hb, sb, ri)
+        assert bytes(ea.cpu().numpy()) == one_a and bytes(eb.cpu().numpy()) == one_b, rep
+        eb2, ea2 = uhdr.huffman_encode2(db, wb, hb, sb, da, wa, ha, sa, ri)
+        assert bytes(ea2.cpu().numpy()) == one_a and bytes(eb2.cpu().numpy()) == one_b, rep
+        ga, gb = uhdr.huffman_decode2(_dev(one_a), [c.shape[:2] for c in ca], wa, ha, sa, _dev(one_b), [c.shape[:2] for c in cb], wb, hb, sb, ri)
+        for c in range(3):
+            assert np.array_equal(ga[c].cpu().numpy(), ca[c]) and np.array_equal(gb[c].cpu().numpy(), cb[c]), (rep, c)
+    # a scan cut short: the same status whichever slot it is in
+    short = _dev(one_b[: len(one_b) // 2])
+    with pytest.raises(Exception) as e1:
+        uhdr.huffman_decode(short, [c.shape[:2] for c in cb], wb, hb, sb, ri)
+    for first in (True, False):
+        with pytest.raises(Exception) as e2:
+            if first:
+                uhdr.huffman_decode2(short, [c.shape[:2] for c in cb], wb, hb, sb, _dev(one_a), [c.shape[:2] for c in ca], wa, ha, sa, ri)
+            else:
+                uhdr.huffman_decode2(_dev(one_a), [c.shape[:2] for c in ca], wa, ha, sa, short, [c.shape[:2] for c in cb], wb, hb, sb, ri)
+        assert str(e2.value) == str(e1.value)
+    # and the context still works
+    ga, gb = uhdr.huffman_decode2(_dev(one_a), [c.shape[:2] for c in ca], wa, ha, sa, _dev(one_b), [c.shape[:2] for c in cb], wb, hb, sb, ri)
+    assert np.array_equal(ga[0].cpu().numpy(), ca[0]) and np.array_equal(gb[2].cpu().numpy(), cb[2])

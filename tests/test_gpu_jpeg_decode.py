@@ -59,6 +59,29 @@ def test_rgb_output_equals_the_oracles_colour_conversion(uhdr, channels, variant
         assert np.array_equal(got, want), (w, h, ri, int((got != want).sum()))
 
 
+@pytest.mark.parametrize("ri", [0, 4])
+def test_the_end_of_the_scan_is_found_on_the_device_or_by_the_walk(uhdr, ri):
+    """Round 5: uhdr_hip_jpeg_decode_scan takes the EOI marker from the buffer's last two bytes and lets the device report any
+    OTHER marker inside what it took for entropy-coded data (a pinned status word); only then does it walk the scan on the host
+    (T.81 B.1.1.2) and decode the prefix.  All four situations give the planes of the plain file: (a) the file as it is (EOI last:
+    the guess holds); (b) bytes behind EOI that do not end in FF D9 (no guess: the walk); (c) bytes behind EOI that DO end in FF D9
+    (the guess is wrong, the device sees the real EOI as a stray marker, the walk cuts there); (d) UHDR_HIP_JPEG_WALK semantics are
+    those of (b): the same code path as rounds 1-4."""
+    rng = np.random.default_rng(4242 + ri)
+    w, h = 640, 480
+    coefs, (ql, qc), jpeg = _file(rng, w, h, S420, ri)
+    want = uhdr.jpeg_decode(jpeg)
+    st0 = A.Stats()
+    uhdr.lib.uhdr_hip_get_stats(uhdr.ctx.handle, C.byref(st0))
+    for tail in (b"\x00\x11\x22\x33", b"\x12\x34\x56\xff\xd9", b"\xff\xd9", b"\xff\xe1\x00\x04ab\xff\xd9"):
+        got = uhdr.jpeg_decode(jpeg + tail)
+        for c in range(3):
+            assert np.array_equal(got[c], want[c]), (tail, c)
+    st1 = A.Stats()
+    uhdr.lib.uhdr_hip_get_stats(uhdr.ctx.handle, C.byref(st1))
+    assert st1.entropy_decode_declined == st0.entropy_decode_declined  # nothing was handed back to the caller on the way
+
+
 def test_rgb_output_of_a_subsampled_file_is_refused(uhdr):
     rng = np.random.default_rng(5)
     _, _, jpeg = _file(rng, 640, 480, S420, 0)
