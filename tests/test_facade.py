@@ -73,3 +73,34 @@ def test_unaccelerated_decode_hands_out_the_gainmap_image_as_before():
         assert np.array_equal(gm, gm3)
         _, gm4 = FA.decode(jpg, lin, f16, gpu=False, effects=[("mirror", 0)], want_gainmap=True)
         assert np.array_equal(gm4[::-1], gm)
+
+
+def test_every_encode_variant_compresses_the_gain_map_right_after_generating_it():
+    """The generate seam leaves the map in HBM (lazy download) for the compress seam that follows.  That rests on the reference
+    calling compressGainMap on the same image directly after generateGainMap in every encodeJPEGR variant, with no host code
+    reading `gainmap` in between (jpegr.cpp:211-217, 253-257, 316-320, 377-381).  Pinned here against the reference source the
+    facade is built from: a release that puts a reader between the two calls fails this test instead of reading unwritten memory."""
+    import os
+    import re
+
+    src = "/root/reference/lib/src/jpegr.cpp"
+    if not os.path.exists(src):
+        pytest.skip("reference source not on this machine")
+    lines = open(src).read().split("\n")
+    gen = [i for i, l in enumerate(lines) if re.search(r"\bgenerateGainMap\(", l) and "UHDR_ERR_CHECK" in "".join(lines[max(0, i - 1): i + 1])]
+    assert len(gen) == 4, gen
+    for g in gen:
+        j = g
+        while not lines[j].rstrip().endswith(";"):
+            j += 1
+        between = []
+        k = j + 1
+        while "compressGainMap(" not in lines[k]:
+            code = lines[k].split("//")[0].strip()
+            if code:
+                between.append(code)
+            k += 1
+            assert k - j < 12, (g, "compressGainMap does not follow generateGainMap")
+        assert "compressGainMap(gainmap.get()" in lines[k]
+        # what may stand between: the declaration of the JPEG encoder object that compressGainMap fills -- nothing that names the map
+        assert all("gainmap" not in c.replace("jpeg_enc_obj_gm", "") for c in between), (g, between)
