@@ -29,13 +29,31 @@ EDITS = {}
 
 # ---- ultrahdrcommon.h: per-codec switch + lazily created context (next to the GLES members) -------------------
 def common_h(t):
+    # uhdr_memory_block: zero-filled as before, but by calloc (facade/uhdr_zero_pages.h) -- pages the kernel hands out zeroed are
+    # not written a second time (a 4K encode's 49.8 MB output buffer, of which 4 MB are used)
+    t = t.replace("  std::unique_ptr<uint8_t[]> m_buffer; /**< data */\n",
+                  "#ifdef UHDR_ENABLE_HIP\n  std::unique_ptr<uint8_t[], uhdr_zero_pages::block_free> m_buffer; /**< data */\n#else\n"
+                  "  std::unique_ptr<uint8_t[]> m_buffer; /**< data */\n#endif\n", 1)
+    t = insert_after(t, '#include "ultrahdr_api.h"\n', '#ifdef UHDR_ENABLE_HIP\n#include "uhdr_zero_pages.h"\n#endif\n')
     return insert_before(t, "  bool m_sailed;\n\n  virtual ~uhdr_codec_private();",
                          "#ifdef UHDR_ENABLE_HIP\n  bool m_enable_hip = false;         // uhdr_enable_gpu_acceleration()\n"
                          "  void* m_uhdr_hip_ctxt = nullptr;   // uhdr_hip context, created by the first accelerated call\n#endif\n")
 EDITS["lib/include/ultrahdr/ultrahdrcommon.h"] = common_h
 
+# ---- jpegdecoderhelper.h: the decoded-image buffer, zero-filled without touching fresh pages ---------------------
+def dec_h(t):
+    t = t.replace("  std::vector<JOCTET> mResultBuffer;       // buffer to store decoded data\n",
+                  "#ifdef UHDR_ENABLE_HIP\n  uhdr_zero_pages::bytes mResultBuffer;    // buffer to store decoded data (zero-filled by calloc)\n#else\n"
+                  "  std::vector<JOCTET> mResultBuffer;       // buffer to store decoded data\n#endif\n", 1)
+    assert "uhdr_zero_pages::bytes" in t
+    return insert_after(t, '#include "ultrahdr_api.h"\n', '#ifdef UHDR_ENABLE_HIP\n#include "uhdr_zero_pages.h"\n#endif\n')
+EDITS["lib/include/ultrahdr/jpegdecoderhelper.h"] = dec_h
+
 # ---- ultrahdr_api.cpp -------------------------------------------------------------------------------------------
 def api_cpp(t):
+    t = t.replace("  m_buffer = std::make_unique<uint8_t[]>(capacity);\n",
+                  "#ifdef UHDR_ENABLE_HIP\n  m_buffer.reset(uhdr_zero_pages::zeroed(capacity));  // the same zero-filled block, fresh pages left alone\n#else\n"
+                  "  m_buffer = std::make_unique<uint8_t[]>(capacity);\n#endif\n", 1)
     t = insert_after(t, '#include "ultrahdr/jpegr.h"\n', '#ifdef UHDR_ENABLE_HIP\n#include "uhdr_hip_seam.h"\n#endif\n')
     t = insert_after(t, "uhdr_codec_private::~uhdr_codec_private() {\n",
                      "#ifdef UHDR_ENABLE_HIP\n  uhdr_hip_seam::release(m_uhdr_hip_ctxt);\n#endif\n")
