@@ -1151,6 +1151,7 @@ def api_level_section():
     FA.encode(hdr, sdr, gpu=True)  # warm-up: context creation, tables
     # default since round 3: the whole compressImage on the device, marker-less Huffman coding included -> the reference's bytes
     jpg, t_enc = med(lambda: FA.encode(hdr, sdr, gpu=True), 5)
+    FA.decode(jpg, A.UHDR_CT_LINEAR, f16, gpu=True)  # warm-up: the decoder's table forms and scratch on the pooled context
     _, t_dec = med(lambda: FA.decode(jpg, A.UHDR_CT_LINEAR, f16, gpu=True), 5)
     # round 4: the decoded images stay on the device and the gain-map image is downloaded when uhdr_get_decoded_gainmap_image
     # asks for it.  The cost of asking, and the round-3 behaviour (UHDR_HIP_SEAM_EAGER_DOWNLOADS=1) for comparison
@@ -1166,8 +1167,8 @@ def api_level_section():
     jpg_ps, t_enc_ps = with_env("UHDR_HIP_SEAM_NO_FUSED_ENCODE", "1", lambda: med(lambda: FA.encode(hdr, sdr, gpu=True), 5))
     jpg2, t_enc2 = med(lambda: FA.encode(hdr, sdr, gpu=True), 5)  # ... and the fused seam once more, later in the process
     # where the time of those two calls goes: the seam's own stage trace (UHDR_HIP_SEAM_TRACE, switched on by main()) of five more calls
-    # each -- the device stages against the reference's own host code around them (uhdr_encode: a value-initialised w x h x 6 byte
-    # output buffer, ultrahdr_api.cpp:1296-1299, and two ICC profiles; uhdr_decode: buffer allocation, parsing, copies)
+    # each -- the device stages against the reference's own host code around them (two ICC profiles, container parsing and writing,
+    # copies; until round 5 also 50-110 MB of value-initialised buffers per call, which the facade's blocks now get from calloc)
     split = {}
     try:
         _, txt = capture_stderr(lambda: [FA.encode(hdr, sdr, gpu=True) for _ in range(5)])
