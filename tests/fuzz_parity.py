@@ -443,11 +443,59 @@ def fuzz_encode_image():
     note("encode_image", got == want, f"kind{kind} {w}x{h} align{align} q{q} {len(got)} vs {len(want)} bytes")
 
 
+def fuzz_encode_errors():
+    """Randomly poisoned descriptors (formats with their real layouts, gamut / transfer / range codes in and out of range, several at
+    once so that the ORDER of the checks matters) through generateGainMap and toneMap, host and device entry points: the error code
+    the real reference returns for the same descriptors (jpegr.cpp:536-562, 1986-2037); the matrices of tests/test_gpu_validation.py
+    cover the single rejections one by one, this arm their combinations."""
+    if os.path.dirname(os.path.abspath(__file__)) not in sys.path:
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_gpu_validation as V
+
+    def codes(n):
+        return int(rng.choice([-1, 0, 1, 2, n, n + 1, n + 4]))
+
+    sdr_fmts = [A.UHDR_IMG_FMT_12bppYCbCr420, A.UHDR_IMG_FMT_12bppYCbCr420, A.UHDR_IMG_FMT_32bppRGBA8888, A.UHDR_IMG_FMT_24bppYCbCr444,
+                A.UHDR_IMG_FMT_16bppYCbCr422, A.UHDR_IMG_FMT_8bppYCbCr400, A.UHDR_IMG_FMT_24bppYCbCrP010, A.UHDR_IMG_FMT_32bppRGBA1010102]
+    hdr_fmts = [A.UHDR_IMG_FMT_24bppYCbCrP010, A.UHDR_IMG_FMT_24bppYCbCrP010, A.UHDR_IMG_FMT_32bppRGBA1010102, A.UHDR_IMG_FMT_64bppRGBAHalfFloat,
+                A.UHDR_IMG_FMT_12bppYCbCr420, A.UHDR_IMG_FMT_32bppRGBA8888]
+
+    def mk_pair():
+        sf, hf = int(rng.choice(sdr_fmts)), int(rng.choice(hdr_fmts))
+        kw_s, kw_h = {}, {}
+        if rng.random() < 0.4:
+            kw_s["cg"] = codes(3)
+        if rng.random() < 0.2:
+            kw_s["fmt"] = int(rng.choice([A.UHDR_IMG_FMT_UNSPECIFIED, 40]))
+        if rng.random() < 0.4:
+            kw_h["cg"] = codes(3)
+        if rng.random() < 0.4:
+            kw_h["ct"] = codes(4)
+        if rng.random() < 0.2:
+            kw_h["range"] = codes(2)
+        return (lambda: V.poison(V.sdr_of(sf), **kw_s)), (lambda: V.poison(V.hdr_of(hf, ct=A.UHDR_CT_HLG), **kw_h)), (sf, hf, kw_s, kw_h)
+
+    device = bool(rng.integers(0, 2))
+    mk_sdr, mk_hdr, what = mk_pair()
+    cfg = V.default_cfg()
+    if rng.random() < 0.3:
+        cfg.map_dimension_scale_factor = int(rng.choice([1, 2, 4, 128]))
+    want, _ = V.ref_code_generate(mk_sdr(), mk_hdr(), cfg)
+    got, detail = V.hip_code_generate(ctx, mk_sdr(), mk_hdr(), cfg, device)
+    note("generate-error" if want else "generate-accepted", got == want, f"dev{int(device)} {what}: hip {got} ({detail!r}), reference {want}")
+    # toneMap: hdr descriptor poisoned the same way, destination of a random format
+    mk_sdr, mk_hdr, what = mk_pair()
+    df = int(rng.choice([A.UHDR_IMG_FMT_12bppYCbCr420, A.UHDR_IMG_FMT_32bppRGBA8888, A.UHDR_IMG_FMT_24bppYCbCr444, A.UHDR_IMG_FMT_8bppYCbCr400]))
+    want, _ = V.ref_code_tonemap(mk_hdr(), V.tm_sdr(df))
+    got, detail = V.hip_code_tonemap(ctx, mk_hdr(), V.tm_sdr(df), device)
+    note("tonemap-error" if want else "tonemap-accepted", got == want, f"dev{int(device)} {what[1]} {what[3]} -> fmt{df}: hip {got} ({detail!r}), reference {want}")
+
+
 def run(seconds, seed=1, context=None, log=None):
     """Runs the sweep for `seconds`; returns (stats, mismatches).  `log`: a path that receives the summary line."""
     init(seed, context)
     jobs = [fuzz_huffman, fuzz_apply, fuzz_apply, fuzz_apply, fuzz_generate, fuzz_generate_formats, fuzz_tonemap, fuzz_tonemap_formats,
-            fuzz_converts, fuzz_decode_fused, fuzz_huffman_streams, fuzz_api1_fused, fuzz_encode_image]
+            fuzz_converts, fuzz_decode_fused, fuzz_huffman_streams, fuzz_api1_fused, fuzz_encode_image, fuzz_encode_errors]
     t_end = time.time() + seconds
     i = 0
     while time.time() < t_end:

@@ -54,3 +54,30 @@ def test_convert_yuv_codes_port_equals_reference(fmt):
             assert got == want, (fmt, src, dst)
             if want == 0:
                 assert np.array_equal(a.buf, b.buf)
+
+
+def test_random_combinations_of_bad_descriptor_fields_port_vs_reference(monkeypatch):
+    """The fuzz sweep's `generate-error` / `tonemap-error` arm (tests/fuzz_parity.py::fuzz_encode_errors: several poisoned fields at
+    once, so the ORDER of the checks matters) with the C port in the HIP path's place: 400 random descriptor pairs, the reference's code."""
+    import ctypes as C
+
+    import fuzz_parity as FZ
+    import test_gpu_validation as V
+
+    if L.ref() is None:
+        pytest.skip("oracle/_ref not built")
+
+    def port_generate(ctx, sdr, hdr, cfg, device):
+        gm = Image(A.UHDR_IMG_FMT_24bppRGB888, max(sdr.w, 1), max(sdr.h, 1), align=64)
+        md = A.GainmapMetadata()
+        return L.port().uo_generate_gainmap(C.byref(sdr.raw), C.byref(hdr.raw), C.byref(cfg), C.byref(md), C.byref(gm.raw)), ""
+
+    monkeypatch.setattr(V, "hip_code_generate", port_generate)
+    monkeypatch.setattr(V, "hip_code_tonemap", lambda ctx, hdr, sdr, device: (L.port().uo_tone_map(C.byref(hdr.raw), C.byref(sdr.raw)), ""))
+    monkeypatch.setattr(FZ, "rng", np.random.default_rng(77))
+    monkeypatch.setattr(FZ, "stats", {})
+    monkeypatch.setattr(FZ, "bad", 0)
+    for _ in range(400):
+        FZ.fuzz_encode_errors()
+    assert FZ.bad == 0, FZ.stats
+    assert FZ.stats["generate-error"][0] > 100 and FZ.stats["tonemap-error"][0] > 100
