@@ -198,7 +198,14 @@ uhdr_error_info_t fast_h2d(uhdr_hip_ctx* c, void* dst, const void* src, size_t b
   std::vector<std::thread> pool;
   const int nt = (size_t)nthreads < npieces ? nthreads : (int)npieces;
   pool.reserve((size_t)nt);
-  for (int t = 0; t < nt; t++) pool.emplace_back(work);
+  for (int t = 0; t < nt; t++) {
+    try {
+      pool.emplace_back(work);
+    } catch (...) {  // no thread to be had (a process at its limit): whoever started, or this thread alone, does the copying
+      break;
+    }
+  }
+  if (pool.empty()) work();
   hipError_t err = hipSuccess;
   size_t i = 0;
   while (i < npieces) {
@@ -338,7 +345,11 @@ static void populate_pages(void* p, size_t bytes) {
   std::vector<std::thread> pool;
   for (uintptr_t o = a; o < e; o += per) {
     const size_t n = o + per <= e ? per : e - o;
-    pool.emplace_back([o, n] { (void)madvise((void*)o, n, MADV_POPULATE_WRITE); });
+    try {
+      pool.emplace_back([o, n] { (void)madvise((void*)o, n, MADV_POPULATE_WRITE); });
+    } catch (...) {  // no thread to be had: the rest of the range is faulted in by the copy itself
+      break;
+    }
   }
   for (auto& t : pool) t.join();
 }

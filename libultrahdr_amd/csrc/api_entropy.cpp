@@ -648,9 +648,15 @@ uhdr_error_info_t uhdr_hip_huffman_encode2_dev(uhdr_hip_ctx_t* c, const uhdr_hip
   UHDR_TRY(aux_context(c, &x));
   HIP_TRY(hipStreamSynchronize(c->stream));  // the coefficients both scans read were produced on this stream
   uhdr_error_info_t rb = ok_status();
-  std::thread second([&] { rb = uhdr_hip_huffman_encode_dev(x, scan_b, out_b, cap_b, bytes_b); });
+  auto job_b = [&] { rb = uhdr_hip_huffman_encode_dev(x, scan_b, out_b, cap_b, bytes_b); };
+  std::thread second;
+  try {
+    second = std::thread(job_b);
+  } catch (...) {  // no thread to be had: one scan after the other, still on two streams
+  }
   const uhdr_error_info_t ra = uhdr_hip_huffman_encode_dev(c, scan_a, out_a, cap_a, bytes_a);
-  second.join();
+  if (second.joinable()) second.join();
+  else job_b();
   aux_merge(c);
   return ra.error_code != UHDR_CODEC_OK ? ra : rb;
 }
@@ -664,9 +670,15 @@ uhdr_error_info_t uhdr_hip_huffman_decode2_dev(uhdr_hip_ctx_t* c, const uhdr_hip
   UHDR_TRY(aux_context(c, &x));
   HIP_TRY(hipStreamSynchronize(c->stream));  // the bytes of both scans may have come up on this stream
   uhdr_error_info_t rb = ok_status();
-  std::thread second([&] { rb = uhdr_hip_huffman_decode_dev(x, scan_b, tables_b, data_b, bytes_b); });
+  auto job_b = [&] { rb = uhdr_hip_huffman_decode_dev(x, scan_b, tables_b, data_b, bytes_b); };
+  std::thread second;
+  try {
+    second = std::thread(job_b);
+  } catch (...) {
+  }
   const uhdr_error_info_t ra = uhdr_hip_huffman_decode_dev(c, scan_a, tables_a, data_a, bytes_a);
-  second.join();
+  if (second.joinable()) second.join();
+  else job_b();
   aux_merge(c);
   return ra.error_code != UHDR_CODEC_OK ? ra : rb;
 }
