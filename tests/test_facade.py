@@ -104,3 +104,18 @@ def test_every_encode_variant_compresses_the_gain_map_right_after_generating_it(
         assert "compressGainMap(gainmap.get()" in lines[k]
         # what may stand between: the declaration of the JPEG encoder object that compressGainMap fills -- nothing that names the map
         assert all("gainmap" not in c.replace("jpeg_enc_obj_gm", "") for c in between), (g, between)
+
+
+def test_zero_page_blocks_behave_like_the_containers_they_replace(tmp_path):
+    """facade/uhdr_zero_pages.h (the calloc-backed blocks the patch puts behind uhdr_memory_block and
+    JpegDecoderHelper::mResultBuffer) against std::vector<uint8_t>: 4000 random clear / resize / write steps, contents equal after
+    each -- new elements are zero on fresh, recycled, grown and reallocated blocks."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "zero_pages_check")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(root, "facade"), os.path.join(root, "tests", "cpp", "zero_pages_check.cpp"), "-o", exe],
+                   check=True, capture_output=True, text=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "zero_pages ok" in r.stdout, r.stdout + r.stderr
