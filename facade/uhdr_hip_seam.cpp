@@ -428,6 +428,16 @@ bool decode_scan(const void* hdr, const unsigned char* data, size_t bytes, int o
   const bool on_device_ = [&]() -> bool {
     if (!cur()) return false;
     enter();
+    // The compressed bytes go up from a buffer that lives as long as the thread and keeps its address: the caller's copy of the
+    // file is a fresh allocation per codec, and the runtime's pageable upload of such memory stalled for 10-16 ms in one call
+    // out of four (profiles/r05_decode_stalls.txt).  UHDR_HIP_SEAM_NO_SCAN_STAGING=1: hand over the caller's pointer as before.
+    static const bool stage = getenv("UHDR_HIP_SEAM_NO_SCAN_STAGING") == nullptr;
+    thread_local std::vector<unsigned char> staged;
+    if (stage && bytes <= ((size_t)256 << 20)) {
+      if (staged.size() < bytes) staged.resize(bytes + bytes / 4);
+      memcpy(staged.data(), data, bytes);
+      data = staged.data();
+    }
     *st = uhdr_hip_jpeg_decode_scan(cur(), static_cast<const uhdr_hip_jpeg_header_t*>(hdr), data, bytes, out_channels, libjpeg_variant, planes,
                                     hstride, vstride);
     // corrupt entropy-coded data: libjpeg decodes such files with warnings and padding; that behaviour stays libjpeg's
