@@ -44,8 +44,8 @@ def encode_api1(p010_path, yuv_path, w, h, out, gpu, cwd, extra=(), env_extra=No
                     "-R", 0, "-z", out] + list(extra), gpu, cwd, env_extra=env_extra)
 
 
-def decode(jpg, ct, fmt, out, gpu, cwd):
-    return run_app(["-m", 1, "-j", jpg, "-o", ct, "-O", fmt, "-z", out], gpu, cwd)
+def decode(jpg, ct, fmt, out, gpu, cwd, env_extra=None):
+    return run_app(["-m", 1, "-j", jpg, "-o", ct, "-O", fmt, "-z", out], gpu, cwd, env_extra=env_extra)
 
 
 def read(path):
