@@ -10,6 +10,9 @@ import torch  # noqa: F401
 
 import bench as B
 from libultrahdr_amd import capi as A
+
+if os.environ.get("UHDR_EXP_LIB"):  # an experimental build of the library (tools/code4_exp.py)
+    A.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.environ["UHDR_EXP_LIB"])
 from libultrahdr_amd import synth
 from libultrahdr_amd.images import Image
 from libultrahdr_amd.ultrahdr import Context, UltraHdr
