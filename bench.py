@@ -154,6 +154,67 @@ def time_region(ctx, fn, iters=30, warm=6, reps=3, adaptive_ramp=False):
     return out[len(out) // 2]
 
 
+METRIC = "Mpixels/s encode+decode (API-1 P010+YUV420, 4K), device-resident round trip"
+DETAIL_NAME = "bench_detail.json"
+COMPACT_LIMIT = 4096  # bytes: the driver keeps a 16 KB tail of stdout; the round-5 line (24 KB) was cut and could not be parsed
+
+
+def make_roundtrip(ctx, u, device, w, h, seed=1234):
+    """One API-1 round trip on device-resident images, as two closures (bytes <-> pixels, what BASELINE.json's metric names):
+      enc(): uhdr_hip_encode_api1_fused_dev (two-pass 3-channel gain map at scale 1, convertYuv, every FDCT) + the file's two
+             scans Huffman-coded without restart markers (the reference's bytes) -> two entropy-coded scans in HBM
+             (JpegR::encodeJPEGR API-1, jpegr.cpp:253-316, without the container's host byte shuffling);
+      dec(): the two scans Huffman-decoded + the map's dequant / IDCT / ycc->rgb + applyGainMap with the base image's dequant +
+             IDCT inside the kernel -> RGBA_F16 linear (JpegR::decodeJPEGR, jpegr.cpp:1469-1531, after parsing).
+    `two=False` codes the scans one after the other instead of concurrently."""
+    from libultrahdr_amd import capi as A
+    from libultrahdr_amd import synth
+    from libultrahdr_amd.images import Image
+    from libultrahdr_amd.ultrahdr import UltraHdr
+    import torch
+
+    px = w * h
+    qy, qc = u.quant_table(95, False), u.quant_table(95, True)
+    enc1 = UltraHdr(ctx=ctx, mapDimensionScaleFactor=1, useMultiChannelGainMap=True, preset=A.UHDR_USAGE_BEST_QUALITY)
+    f16, rgba = A.UHDR_IMG_FMT_64bppRGBAHalfFloat, A.UHDR_IMG_FMT_32bppRGBA8888
+    S420, S444 = [(2, 2), (1, 1), (1, 1)], [(1, 1)] * 3
+    sdr = synth.make_sdr_yuv420(w, h, seed=seed).to(device)
+    hdr = synth.make_hdr_p010(w, h, ct=A.UHDR_CT_HLG, seed=seed).to(device)
+    out_b = torch.empty(px * 2, dtype=torch.uint8, device=device)
+    out_m = torch.empty(px * 4, dtype=torch.uint8, device=device)
+    box = {"keep": (sdr, hdr, out_b, out_m)}
+
+    def enc(two=True):
+        cb, cm, md_, _ = enc1.encodeApi1Fused(sdr, hdr, A.UHDR_CG_DISPLAY_P3, (qy, qc), (qy, qc), want_map=False)
+        if two:  # both scans at once: the map's on the context's auxiliary stream (uhdr_hip_huffman_encode2_dev)
+            eb, em = u.huffman_encode2(cb, w, h, S420, cm, w, h, S444, 0, outs=[out_b, out_m])
+            box["nb"], box["nm"] = int(eb.numel()), int(em.numel())
+        else:
+            box["nb"] = int(u.huffman_encode(cb, w, h, S420, 0, out=out_b).numel())
+            box["nm"] = int(u.huffman_encode(cm, w, h, S444, 0, out=out_m).numel())
+        box["md"], box["shp_b"], box["shp_m"] = md_, [tuple(c.shape[:2]) for c in cb], [tuple(c.shape[:2]) for c in cm]
+
+    enc()
+    ctx.synchronize()
+    box["sb"], box["sm"] = out_b[: box["nb"]].clone(), out_m[: box["nm"]].clone()
+    gm3 = Image(rgba, w, h, A.UHDR_CG_BT_2100, align=64, device=device)
+    dst = Image(f16, w, h, align=64, device=device)
+    box["dst"] = dst
+    qts = [qy, qc, qc]
+
+    def dec(two=True):
+        sb, sm = box["sb"], box["sm"]
+        if two:  # uhdr_hip_huffman_decode2_dev
+            cb, cm = u.huffman_decode2(sb, box["shp_b"], w, h, S420, sm, box["shp_m"], w, h, S444, 0)
+        else:
+            cb = u.huffman_decode(sb, box["shp_b"], w, h, S420, 0)
+            cm = u.huffman_decode(sm, box["shp_m"], w, h, S444, 0)
+        u.idct_dequant_rgb(cm, qy, qc, w, h, rgba, 0, dst=gm3)
+        u.applyGainMapFromCoefficients(cb, qts, w, h, A.UHDR_CG_BT_709, gm3, box["md"], A.UHDR_CT_LINEAR, f16, A.FLT_MAX, dst)
+
+    return enc, dec, box
+
+
 def main():
     args = parse()
     import torch
@@ -177,41 +238,21 @@ def main():
     device = f"cuda:{dev_index}"
 
     from libultrahdr_amd import capi as A
-    from libultrahdr_amd import synth
-    from libultrahdr_amd.images import Image
     from libultrahdr_amd.ultrahdr import Context, UltraHdr
 
-    if rank == 0 and world == 1 and not args.no_extra:
-        os.environ.setdefault("UHDR_HIP_SEAM_TRACE", "1")  # the facade reads it once: api_level_section parses the stage lines (stderr)
     ctx = Context(dev_index)
     u = UltraHdr(ctx=ctx)
-    f16 = A.UHDR_IMG_FMT_64bppRGBAHalfFloat
     w, h = args.width, args.height
-    md = synth.default_metadata(use_base_cg=0)  # BT.709 base, BT.2100 gain-map space: the SDR-side 3x3 is active
-    frames = make_frames(args.batch, w, h, args.map, device, f16, seed0=1234 + 1000 * rank)
-    for _, gm, _ in frames:
-        gm.raw.cg = A.UHDR_CG_BT_2100
-    for sdr, _, _ in frames:
-        sdr.raw.cg = A.UHDR_CG_BT_709
+    headline_only = bool(os.environ.get("UHDR_BENCH_HEADLINE_ONLY"))
 
-    lib, hnd = ctx.lib, ctx.handle
-    calls = [(C.byref(s.raw), C.byref(g.raw), C.byref(md), C.byref(d.raw)) for s, g, d in frames]
-    nb = len(frames)
-    arr_s = (A.RawImage * nb)(*[s.raw for s, _, _ in frames])
-    arr_g = (A.RawImage * nb)(*[g.raw for _, g, _ in frames])
-    arr_d = (A.RawImage * nb)(*[d.raw for _, _, d in frames])
+    # ---- the headline: BASELINE.json's metric as worded.  One step = one API-1 round trip of this rank's 4K frame, inputs
+    # resident in HBM: P010 + YCbCr 4:2:0 -> two entropy-coded JPEG scans -> RGBA_F16 linear.  Frames are independent: N ranks
+    # shard by frame with no data-path collective (weak scaling); value = pixels of all ranks / max-over-ranks time.
+    enc, dec, box = make_roundtrip(ctx, u, device, w, h, seed=1234 + 1000 * rank)
 
-    if args.launch == "batch":
-        def step():
-            st = lib.uhdr_hip_apply_gainmap_batch_dev(hnd, nb, arr_s, arr_g, C.byref(md), A.UHDR_CT_LINEAR, f16, A.FLT_MAX, arr_d)
-            if st.error_code != 0:
-                raise RuntimeError(st.detail)
-    else:
-        def step():
-            for s_, g_, m_, d_ in calls:
-                st = lib.uhdr_hip_apply_gainmap_dev(hnd, s_, g_, m_, A.UHDR_CT_LINEAR, f16, A.FLT_MAX, d_, 0, 0)
-                if st.error_code != 0:
-                    raise RuntimeError(st.detail)
+    def step():
+        enc()
+        dec()
 
     def barrier():
         ctx.synchronize()
@@ -220,26 +261,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # the OTHER clock regime first (round 4): the first 20 steps after 2 s of idle, no ramp, no warm-up -- what a service
-    # that decodes one batch now and then sees (the part starts from its 1.4 GHz idle clock)
-    cold = None
-    if not os.environ.get("UHDR_BENCH_HEADLINE_ONLY"):
-        ctx.synchronize()
-        time.sleep(2.0)
-        ctx.profile(True)
-        ctx.profile_read(None, reset=True)
-        for _ in range(20):
-            step()
-        ctx.synchronize()
-        cold = ctx.profile_read_list("apply_gainmap", reset=True)
-        ctx.profile(False)
+    step()
+    st0 = A.Stats()
+    ctx.lib.uhdr_hip_get_stats(ctx.handle, C.byref(st0))
     ramp_t0 = time.perf_counter()
     ramp_steps = clock_ramp(ctx, step, adaptive=True)  # untimed, before the W warm-up steps: see clock_ramp
     ramp_seconds = time.perf_counter() - ramp_t0
     for _ in range(args.warmup):
         step()
     barrier()
-    # timed region: exactly K steps, HIP events around every launch (kernel-only durations)
+    # timed region: exactly K steps between two barriers; per-family HIP-event pairs ride along (the library wraps every launch)
+    fams = ["generate_gainmap", "fdct_quant", "huffman_encode", "huffman_decode", "idct_dequant", "apply_gainmap"]
     ctx.profile(True)
     ctx.profile_read(None, reset=True)
     t0 = time.perf_counter()
@@ -247,28 +279,24 @@ def main():
         step()
     barrier()
     t1 = time.perf_counter()
-    launch_ms = ctx.profile_read_list("apply_gainmap", reset=True)
-    n_launch, kern_ms = len(launch_ms), sum(launch_ms)
+    fam_us = {}
+    for f in fams:
+        n_f, ms_f = ctx.profile_read(f, reset=True)
+        if n_f:
+            fam_us[f] = {"us": round(ms_f / args.steps * 1e3, 2), "launches": n_f // max(args.steps, 1)}
+    ctx.profile_read(None, reset=True)
     ctx.profile(False)
+    st1 = A.Stats()
+    ctx.lib.uhdr_hip_get_stats(ctx.handle, C.byref(st1))
     elapsed = t1 - t0
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    value = w * h * world * args.steps / elapsed / 1e6
 
-    px_per_step = args.batch * w * h * world
-    value = px_per_step * args.steps / elapsed / 1e6
-    avg_launch_s = (kern_ms / 1e3) / max(n_launch, 1)
-    # the library issues batches above 16 frames as several launches: derive the frames per launch from the count
-    frames_per_launch = (args.steps * nb) // max(n_launch, 1) if args.launch == "batch" else 1
-    algo_b = algo_bytes_per_px(args.map) * w * h * frames_per_launch
-    achieved = algo_b / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-
-    kernel_name = "apply_quad_kernel<F16," + {"A": "Y400,scale4>", "B": "RGB888,scale1>", "C": "RGBA8888,scale1>"}[args.map]
-    traffic, traffic_src = measured_traffic(f"{kernel_name}|{frames_per_launch}x{w}x{h}")
-
-    out = {
-        "metric": "Mpixels/s decode (applyGainMap, YCbCr420 + gain map -> RGBA_F16 linear), 4K frames resident in HBM",
+    full = {
+        "metric": METRIC,
         "value": round(value, 1),
         "unit": "Mpixels/s",
         "n_gpus": world,
@@ -281,100 +309,61 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"configs[1]: decode {w}x{h} YCbCr420 base + " + MAP_DESC[args.map]
-                        + " -> RGBA_F16 linear, applyGainMap kernel, device-resident",
-            "frames_per_rank_per_step": args.batch,
-            "launch": "one batched launch per step" if args.launch == "batch" else "one launch per frame",
-            "clock_ramp": f"{ramp_steps} untimed steps ({ramp_seconds:.1f} s: at least {CLOCK_RAMP_S} s, then until the step time has stopped falling, at most {CLOCK_RAMP_MAX_S} s) before the {args.warmup} warm-up steps: the part needs ~0.5 s of load to "
-                          "leave its 1.4 GHz idle clock (profiles/r03_clock_ramp.txt); roofline.cold_start_frac is the same launch WITHOUT any ramp",
+            "workload": f"API-1 {w}x{h} round trip per step: encode (P010 HLG + YCbCr420 -> two-pass 3-ch gain map at scale 1, FDCT q95, "
+                        "Huffman: two JPEG scans) + decode (Huffman, IDCT, applyGainMap -> RGBA_F16 linear); frames resident in HBM",
+            "frames_per_rank_per_step": 1,
+            "clock_ramp": f"{ramp_steps} untimed steps ({ramp_seconds:.1f} s) before the {args.warmup} warm-up steps (profiles/r03_clock_ramp.txt)",
             "sharding": f"frames x{world} ranks, no data-path collective",
         },
-        "roofline": {
-            "bound": "hbm",
-            "kernel": kernel_name,
-            "frames_per_launch": frames_per_launch,
-            "achieved": round(achieved, 1),
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": traffic,  # HBM bytes per launch from the PMC counters of a separate rocprofv3 pass (None: not profiled)
-            "traffic_source": traffic_src,
-            "algorithmic_bytes_per_launch": int(algo_b),
-            "avg_launch_us": round(avg_launch_s * 1e6, 3),
-            "launches_timed": n_launch,
-            "launch_us": launch_stats(launch_ms),  # per-launch HIP-event durations over the timed region
-            "frac_at_median": round(algo_b / (launch_stats(launch_ms)["median"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if launch_ms else None,
-        },
+        "step": {"kernel_families_us_per_step": fam_us, "scan_bytes_base": box["nb"], "scan_bytes_map": box["nm"],
+                 "decode_route": {"parallel": int(st1.entropy_decode_parallel - st0.entropy_decode_parallel),
+                                  "single_lane": int(st1.entropy_decode_single_lane - st0.entropy_decode_single_lane),
+                                  "declined": int(st1.entropy_decode_declined - st0.entropy_decode_declined)}},
+        "roofline": {"bound": "hbm", "kernel": None, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None},
     }
-    if cold:  # per-launch HIP events of the first 20 steps after 2 s of idle (frames_per_launch launches of the same kernel)
-        cold_avg_s = sum(cold) / len(cold) / 1e3
-        out["roofline"]["cold_start_frac"] = round(algo_b / cold_avg_s / 1e9 / HBM_PEAK_GBS, 4)
-        out["roofline"]["cold_start_avg_launch_us"] = round(cold_avg_s * 1e6, 2)
-        out["roofline"]["cold_start_first_launch_us"] = round(cold[0] * 1e3, 2)
-        out["roofline"]["cold_start_note"] = "the first 20 steps after 2 s of idle, no clock ramp, no warm-up (sclk starts at its 1.4 GHz idle state)"
+    del enc, dec, box, step
+    torch.cuda.empty_cache()
 
-    # the on-box copy ceiling measured in this very run, and the north-star configuration (ONE 8K frame per
-    # launch -> RGBA_F16) as sustained per-launch times, both inside `roofline` (rank 0; they take a few milliseconds)
-    if rank == 0 and not os.environ.get("UHDR_BENCH_HEADLINE_ONLY"):  # (tools/profile_bench.sh profiles the headline launch alone)
+    # ---- roofline: the dominant HBM kernel of the path -- applyGainMap -> RGBA_F16 -- at the north-star size (ONE 7680x4320
+    # frame per launch, RGBA8888 map at scale 1), HIP events around every launch on the library's stream, live in this run (rank 0)
+    if rank == 0:
         try:
-            out["roofline"].update(onbox_ceiling(device))
-            ns = north_star_8k(ctx, device)
-            out["roofline"]["north_star_8k"] = ns
-            # the same figures as scalars of `roofline` (round 4: a reader that keeps only scalars sees them)
-            for key, short in (("mapC", "mapC"), ("mapB", "mapB"), ("mapA", "mapA_hot"), ("mapA_cold_inputs", "mapA_cold")):
-                e = ns.get(key)
-                if isinstance(e, dict) and "frac" in e:
-                    out["roofline"][f"ns8k_{short}_frac"] = e["frac"]
-                    out["roofline"][f"ns8k_{short}_us"] = e["sustained_us"]
-                    out["roofline"][f"ns8k_{short}_p10_us"] = e["launch_us"]["p10"] if e.get("launch_us") else None
-                    out["roofline"][f"ns8k_{short}_p90_us"] = e["launch_us"]["p90"] if e.get("launch_us") else None
+            full["roofline"] = roofline_section(ctx, device, w, h, light=headline_only)
         except Exception as e:  # noqa: BLE001
-            out["roofline"]["north_star_8k"] = {"error": f"{type(e).__name__}: {e}"}
-
-    # BASELINE.json's metric as worded -- encode + decode, API-1, 4K and 8K -- device resident (rank 0, N = 1; after the timed region)
-    if rank == 0 and world == 1 and not args.no_extra and not os.environ.get("UHDR_BENCH_HEADLINE_ONLY"):
-        try:
-            out["api1_roundtrip"] = api1_roundtrip_section(ctx, u, device)
-        except Exception as e:  # noqa: BLE001
-            out["api1_roundtrip"] = {"error": f"{type(e).__name__}: {e}"}
+            full["roofline"]["error"] = f"{type(e).__name__}: {e}"
 
     # BASELINE configs[3]: the row-striped API-1 two-pass encode, the one place where the path has a collective.  Every
     # rank runs it (also at N = 1: a one-rank communicator), after the headline's timed region.
-    if not args.no_config4:
+    if not args.no_config4 and not headline_only:
         # The headline is measured; nothing after it may cost the line.  An exception is caught below, but a collective that
         # never returns (a communicator that cannot form on some node) cannot be: a watchdog prints the line and leaves.
-        dog = arm_watchdog(180.0 if world > 1 else 600.0, out, rank, "config4")
+        dog = arm_watchdog(180.0 if world > 1 else 600.0, full, rank, "config4")
         try:
             c4 = config4_section(ctx, u, device, rank, world, backend)
         except Exception as e:  # noqa: BLE001
             c4 = {"error": f"{type(e).__name__}: {e}"}
         dog.cancel()
         if rank == 0:
-            out["config4"] = c4
+            full["config4"] = c4
 
     # the stage measurements and the CPU baseline run AFTER the timed region; a failure there (e.g. an
     # out-of-memory on a smaller device) must not cost the headline line
-    if rank == 0 and world == 1 and not args.no_extra:
-        for key, fn in (("encode", lambda: encode_section(ctx, u, device)), ("config5", lambda: config5_section(ctx, u, device)),
+    if rank == 0 and world == 1 and not args.no_extra and not headline_only:
+        for key, fn in (("api1_roundtrip", lambda: api1_roundtrip_section(ctx, u, device)),
+                        ("headline_16x4k", lambda: batch16_section(ctx, u, device, args)),
+                        ("encode", lambda: encode_section(ctx, u, device)), ("config5", lambda: config5_section(ctx, u, device)),
                         ("extra", lambda: extras(ctx, u, device)), ("api_level", lambda: api_level_section())):
             try:
-                out[key] = fn()
+                full[key] = fn()
             except Exception as e:  # noqa: BLE001  (a failure in one section must not cost the headline line)
-                out[key] = {"error": f"{type(e).__name__}: {e}"}
+                full[key] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu:
         try:
-            out["cpu_baseline"] = cpu_baseline(w, h, args.map, md, args.cpu_seconds)
+            full["cpu_baseline"] = cpu_baseline(w, h, args.cpu_seconds, stages=not args.no_extra)
         except Exception as e:  # noqa: BLE001
-            out["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port", "sample": f"failed: {type(e).__name__}: {e}"}
+            full["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port", "sample": f"failed: {type(e).__name__}: {e}"}
     if rank == 0:
-        out = order_for_readers(out)
-        # RCCL reports its version through C stdio; drain that first so that the JSON line is the LAST line on stdout
-        try:
-            C.CDLL(None).fflush(None)
-        except Exception:  # noqa: BLE001
-            pass
-        sys.stdout.flush()
-        print(json.dumps(out), flush=True)
+        emit(full)
     if world > 1:  # the line is out: a teardown that hangs must not keep the launcher waiting
         arm_watchdog(60.0, None, rank, "teardown")
     ctx.close()
@@ -386,65 +375,171 @@ def main():
         dist.destroy_process_group()
 
 
-def order_for_readers(out):
-    """A reader that keeps only the first couple of dozen scalars of `roofline`, or only the tail of the line, must still see
-    the figures that matter (round-4 review): the required roofline keys first, then the BASELINE metric's own round-trip
-    scalars, the north-star fractions, the entropy stage, the encode chains and the API-level calls -- every one a copy of a
-    value that also sits in its own section; the sections themselves are emitted with the bulky ones (extra, cpu stages) first
-    and the summaries last."""
-    def dig(d, *path):
-        for k in path:
-            if not isinstance(d, dict) or k not in d:
-                return None
-            d = d[k]
-        return d
+def dig(d, *path):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
 
-    r = out.get("roofline", {})
-    head = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic") if k in r}
-    rt = out.get("api1_roundtrip") or {}
-    for k in ("api1_4k_enc_us", "api1_4k_dec_us", "api1_4k_roundtrip_Mpxs", "api1_8k_enc_us", "api1_8k_dec_us", "api1_8k_roundtrip_Mpxs"):
-        if k in rt:
-            head[k] = rt[k]
-    for k in ("ns8k_mapC_frac", "ns8k_mapB_frac", "ns8k_mapA_hot_frac", "ns8k_mapA_cold_frac", "cold_start_frac"):
-        if k in r:
-            head[k] = r[k]
-    picks = (("config5_frac", ("config5", "frac_of_8TBs")), ("config5_graph_replay_us", ("config5", "graph_replay_us_per_batch")),
-             ("huff_dec_4k_base_us", ("extra", "huffman_decode_4k_420_q95_no_restart_markers", "us")),
-             ("huff_dec_4k_ri10_us", ("extra", "huffman_decode_4k_420_q95_ri10", "us")),
-             ("huff_dec_4k_map3ch_us", ("extra", "huffman_decode_4k_444_map_no_restart_markers", "us")),
-             ("huff_enc_4k_base_us", ("extra", "huffman_encode_4k_420_q95_no_restart_markers", "us")),
-             ("enc_api1_4k_chain_us", ("encode", "api1_4k", "chain_us_one_event_pair")), ("enc_api1_4k_frac", ("encode", "api1_4k", "chain_frac_one_event_pair")),
-             ("enc_api1_8k_chain_us", ("encode", "api1_8k", "chain_us_one_event_pair")),
-             ("enc_api0_8k_chain_us", ("encode", "config3_api0_8k", "us")), ("enc_api0_8k_frac", ("encode", "config3_api0_8k", "roofline", "frac")),
-             ("tonemap_4k_p010_us", ("extra", "tonemap_4k_p010", "us")),
-             ("uhdr_encode_4k_ms", ("api_level", "uhdr_encode_api1_4k_hip", "ms")), ("uhdr_decode_4k_ms", ("api_level", "uhdr_decode_4k_f16_hip", "ms")),
-             ("uhdr_encode_4k_device_ms", ("api_level", "seam_trace_split", "uhdr_encode_4k_device_stages_ms")),
-             ("uhdr_decode_4k_device_ms", ("api_level", "seam_trace_split", "uhdr_decode_4k_device_stages_ms")),
-             ("uhdr_encode_8k_ms", ("api_level", "uhdr_encode_api1_8k_hip", "ms")), ("uhdr_decode_8k_ms", ("api_level", "uhdr_decode_8k_f16_hip", "ms")),
-             ("config4_ms_per_image", ("config4", "ms_per_image")), ("config4_all_reduce_us", ("config4", "all_reduce_us_back_to_back")),
-             ("config4_full_16k_ms", ("config4", "full_16k_x_16k_one_gpu", "ms_per_image")))
-    for name, path in picks:
-        v = dig(out, *path)
+
+# the scalars the compact line carries inside `roofline` beyond the contract's keys: (name on the line, path in the full record)
+ROOFLINE_SCALARS = (
+    ("api1_4k_enc_us", ("api1_roundtrip", "api1_4k_enc_us")), ("api1_4k_dec_us", ("api1_roundtrip", "api1_4k_dec_us")),
+    ("api1_8k_enc_us", ("api1_roundtrip", "api1_8k_enc_us")), ("api1_8k_dec_us", ("api1_roundtrip", "api1_8k_dec_us")),
+    ("api1_8k_roundtrip_Mpxs", ("api1_roundtrip", "api1_8k_roundtrip_Mpxs")),
+    ("ns8k_mapA_cold_frac", ("roofline", "ns8k_mapA_cold_frac")), ("ns8k_mapB_frac", ("roofline", "ns8k_mapB_frac")),
+    ("ns8k_mapC_frac", ("roofline", "ns8k_mapC_frac")),
+    ("config5_frac", ("config5", "frac_of_8TBs")), ("headline_16x4k_frac", ("headline_16x4k", "frac")),
+    ("config4_ms_per_image", ("config4", "ms_per_image")), ("config4_all_reduce_us", ("config4", "all_reduce_us_back_to_back")),
+    ("config4_full_16k_ms", ("config4", "full_16k_x_16k_one_gpu", "ms_per_image")),
+)
+ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes", "avg_launch_us", "launches_timed")
+
+
+def compact_line(full, detail_path=None):
+    """The ONE line the driver parses (<= COMPACT_LIMIT bytes): the contract's keys, `roofline` for the dominant HBM kernel with a
+    dozen scalars of the other sections, `cpu_baseline`.  Everything else is in the detail file."""
+    out = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                "vs_baseline", "dtype", "data") if k in full}
+    cfg = full.get("config") or {}
+    out["config"] = {k: (v if not isinstance(v, str) else v[:400]) for k, v in cfg.items() if k in ("workload", "frames_per_rank_per_step", "sharding", "clock_ramp")}
+    r = full.get("roofline") or {}
+    roof = {k: r.get(k) for k in ROOFLINE_KEYS}
+    for name, path in ROOFLINE_SCALARS:
+        v = dig(full, *path)
         if isinstance(v, (int, float)):
-            head[name] = v
-    for k, v in r.items():
-        if k not in head:
-            head[k] = v
-    out["roofline"] = head
-    first = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline")
-    bulky = ("extra", "cpu_baseline_stages", "api_level")
-    last = ("encode", "config5", "config4", "api1_roundtrip", "cpu_baseline")
-    ordered = {k: out[k] for k in first if k in out}
-    for k in bulky:
-        if k in out:
-            ordered[k] = out[k]
-    for k in out:
-        if k not in ordered and k not in last:
-            ordered[k] = out[k]
-    for k in last:
-        if k in out:
-            ordered[k] = out[k]
-    return ordered
+            roof[name] = v
+    if isinstance(r.get("error"), str):
+        roof["error"] = r["error"][:200]
+    out["roofline"] = roof
+    cb = full.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {k: (cb.get(k) if not isinstance(cb.get(k), str) else cb.get(k)[:300]) for k in ("value", "unit", "cores", "kind", "sample")}
+    errs = [k for k, v in full.items() if isinstance(v, dict) and isinstance(v.get("error"), str)]
+    if errs:
+        out["sections_with_errors"] = errs[:8]
+    if detail_path:
+        out["detail"] = detail_path
+    line = json.dumps(out, separators=(",", ":"))
+    if len(line) > COMPACT_LIMIT:  # cannot happen with the bounded fields above; never let a long string cost the record
+        for k in ("clock_ramp", "sharding"):
+            out["config"].pop(k, None)
+        out.pop("sections_with_errors", None)
+        if "cpu_baseline" in out and isinstance(out["cpu_baseline"].get("sample"), str):
+            out["cpu_baseline"]["sample"] = out["cpu_baseline"]["sample"][:120]
+        line = json.dumps(out, separators=(",", ":"))
+    assert len(line) <= COMPACT_LIMIT, len(line)
+    return line
+
+
+def emit(full):
+    """Write the full record next to the script (and into gpurun_out/ when that exists, so that a gpurun call brings it back),
+    say where it is on an EARLIER line, then print the compact line as the LAST line of stdout."""
+    paths = [os.path.join(ROOT, DETAIL_NAME)]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        paths.append(os.path.join(ROOT, "gpurun_out", DETAIL_NAME))
+    written = None
+    for p in paths:
+        try:
+            with open(p, "w") as f:
+                json.dump(full, f, indent=1)
+            written = written or p
+        except OSError:
+            pass
+    # RCCL reports its version through C stdio; drain that first so that the JSON line is the LAST line on stdout
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+    sys.stdout.flush()
+    if written:
+        print(f"bench detail: {written}", flush=True)
+    print(compact_line(full, DETAIL_NAME if written else None), flush=True)
+
+
+def roofline_section(ctx, device, w, h, light=False):
+    """`roofline` of the bench line: applyGainMap of ONE 7680x4320 frame per launch -> RGBA_F16 with the RGBA8888 map at scale 1 (the
+    north-star configuration; 13.5 algorithmic B/px), per-launch HIP events on the library's stream over 60
+    launches after the clock ramp, three rotating buffer sets.  The other map layouts and the on-box copy ceiling ride along."""
+    ns = north_star_8k(ctx, device, kinds=(("mapC", "C", 3),) if light else None)
+    c = ns["mapC"]
+    each = c.pop("launch_ms_each")
+    avg_s = sum(each) / len(each) / 1e3
+    algo_b = c["algorithmic_bytes_per_launch"]
+    kernel_name = "apply_quad_kernel<F16,RGBA8888,scale1>"
+    traffic, traffic_src = measured_traffic(f"{kernel_name}|1x7680x4320")
+    r = {"bound": "hbm", "kernel": kernel_name + " 7680x4320, one frame per launch", "achieved": round(algo_b / avg_s / 1e9, 1), "peak": HBM_PEAK_GBS,
+         "unit": "GB/s", "frac": round(algo_b / avg_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+         "algorithmic_bytes": int(algo_b), "avg_launch_us": round(avg_s * 1e6, 3), "launches_timed": len(each),
+         "launch_us": launch_stats(each), "north_star_8k": ns}
+    for key, short in (("mapC", "mapC"), ("mapB", "mapB"), ("mapA", "mapA_hot"), ("mapA_cold_inputs", "mapA_cold")):
+        e = ns.get(key)
+        if isinstance(e, dict) and "frac" in e:
+            e.pop("launch_ms_each", None)
+            r[f"ns8k_{short}_frac"] = e["frac"]
+            r[f"ns8k_{short}_us"] = e["sustained_us"]
+    if not light:
+        r.update(onbox_ceiling(device))
+    return r
+
+
+def batch16_section(ctx, u, device, args):
+    """Rounds 1-5's headline, kept as a section: applyGainMap of 16 distinct resident 4K frames per launch -> RGBA_F16
+    (uhdr_hip_apply_gainmap_batch_dev), map C; per-launch HIP events; plus the same launch from an idle clock."""
+    from libultrahdr_amd import capi as A
+    from libultrahdr_amd import synth
+    import torch
+
+    w, h, nb = 3840, 2160, args.batch
+    f16 = A.UHDR_IMG_FMT_64bppRGBAHalfFloat
+    md = synth.default_metadata(use_base_cg=0)  # BT.709 base, BT.2100 gain-map space: the SDR-side 3x3 is active
+    frames = make_frames(nb, w, h, args.map, device, f16, seed0=1234)
+    for s_, g_, _ in frames:
+        s_.raw.cg, g_.raw.cg = A.UHDR_CG_BT_709, A.UHDR_CG_BT_2100
+    arr_s = (A.RawImage * nb)(*[s.raw for s, _, _ in frames])
+    arr_g = (A.RawImage * nb)(*[g.raw for _, g, _ in frames])
+    arr_d = (A.RawImage * nb)(*[d.raw for _, _, d in frames])
+
+    def step():
+        st = ctx.lib.uhdr_hip_apply_gainmap_batch_dev(ctx.handle, nb, arr_s, arr_g, C.byref(md), A.UHDR_CT_LINEAR, f16, A.FLT_MAX, arr_d)
+        if st.error_code != 0:
+            raise RuntimeError(st.detail)
+
+    step()
+    ctx.synchronize()
+    time.sleep(2.0)  # the OTHER clock regime: the first 20 launches after 2 s of idle, no ramp, no warm-up
+    ctx.profile(True)
+    ctx.profile_read(None, reset=True)
+    for _ in range(20):
+        step()
+    ctx.synchronize()
+    cold = ctx.profile_read_list("apply_gainmap", reset=True)
+    ctx.profile(False)
+    clock_ramp(ctx, step, adaptive=True)
+    ctx.profile(True)
+    ctx.profile_read(None, reset=True)
+    for _ in range(40):
+        step()
+    each = ctx.profile_read_list("apply_gainmap", reset=True)
+    ctx.profile(False)
+    fpl = (40 * nb) // max(len(each), 1)
+    algo_b = algo_bytes_per_px(args.map) * w * h * fpl
+    avg_s = sum(each) / len(each) / 1e3
+    kernel_name = "apply_quad_kernel<F16," + {"A": "Y400,scale4>", "B": "RGB888,scale1>", "C": "RGBA8888,scale1>"}[args.map]
+    traffic, traffic_src = measured_traffic(f"{kernel_name}|{fpl}x{w}x{h}")
+    res = {"workload": f"{nb} x {w}x{h} YCbCr420 + " + MAP_DESC[args.map] + " -> RGBA_F16, one batched launch", "frames_per_launch": fpl,
+           "avg_launch_us": round(avg_s * 1e6, 2), "frac": round(algo_b / avg_s / 1e9 / HBM_PEAK_GBS, 4), "GB/s": round(algo_b / avg_s / 1e9, 1),
+           "Mpx/s": round(fpl * w * h / avg_s / 1e6, 1), "algorithmic_bytes_per_launch": int(algo_b), "traffic": traffic, "traffic_source": traffic_src,
+           "launch_us": launch_stats(each)}
+    if cold:
+        cold_s = sum(cold) / len(cold) / 1e3
+        res["cold_start_frac"] = round(algo_b / cold_s / 1e9 / HBM_PEAK_GBS, 4)
+        res["cold_start_avg_launch_us"] = round(cold_s * 1e6, 2)
+        res["cold_start_note"] = "the first 20 launches after 2 s of idle, no clock ramp, no warm-up (sclk starts at its 1.4 GHz idle state)"
+    del frames
+    torch.cuda.empty_cache()
+    return res
 
 
 def onbox_ceiling(device):
@@ -476,7 +571,7 @@ def onbox_ceiling(device):
             "onbox_copy_note": "torch device-to-device copy of 1 GiB (bytes read + bytes written) / time, best of 3 x 10 calls, in this run"}
 
 
-def north_star_8k(ctx, device):
+def north_star_8k(ctx, device, kinds=None):
     """BASELINE north star: applyGainMap of ONE 7680x4320 frame per launch -> RGBA_F16, frames rotating through enough buffer
     sets that neither inputs nor outputs stay in the 256 MiB infinity cache.  Per map kind: the sustained time per launch
     (one HIP-event pair around 30 back-to-back launches, median of 5 regions) and the spread of the individual launches."""
@@ -489,7 +584,7 @@ def north_star_8k(ctx, device):
     f16 = A.UHDR_IMG_FMT_64bppRGBAHalfFloat
     md = synth.default_metadata(use_base_cg=0)
     w, h = 7680, 4320
-    for key, kind, nsets in (("mapC", "C", 3), ("mapB", "B", 3), ("mapA", "A", 3), ("mapA_cold_inputs", "A", 6)):
+    for key, kind, nsets in (kinds or (("mapC", "C", 3), ("mapB", "B", 3), ("mapA", "A", 3), ("mapA_cold_inputs", "A", 6))):
         sets = make_frames(nsets, w, h, kind, device, f16, seed0=4242)
         for s_, g_, _ in sets:
             s_.raw.cg, g_.raw.cg = A.UHDR_CG_BT_709, A.UHDR_CG_BT_2100
@@ -514,7 +609,8 @@ def north_star_8k(ctx, device):
         st = launch_stats(each)
         res[key] = {"map": MAP_DESC[kind], "algorithmic_bytes_per_launch": int(b), "sustained_us": round(ms * 1e3, 2),
                              "frac": round(b / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4), "GB/s": round(b / (ms / 1e3) / 1e9, 1),
-                             "launch_us": st, "p90_over_p10": round(st["p90"] / st["p10"], 3) if st else None, "buffer_sets": nsets}
+                             "launch_us": st, "p90_over_p10": round(st["p90"] / st["p10"], 3) if st else None, "buffer_sets": nsets,
+                             "launch_ms_each": each}
         del sets, argv
         torch.cuda.empty_cache()
     res["timing"] = ("sustained_us: one HIP-event pair around 30 back-to-back launches, median of 5 regions; launch_us: per-launch HIP events "
@@ -538,7 +634,7 @@ def arm_watchdog(seconds, out, rank, section):
                 C.CDLL(None).fflush(None)
             except Exception:  # noqa: BLE001
                 pass
-            print(json.dumps(out), flush=True)
+            emit(out)
         os._exit(0)
 
     t = threading.Timer(seconds, fire)
@@ -745,46 +841,18 @@ def encode_section(ctx, u, device):
 
 
 def api1_roundtrip_section(ctx, u, device):
-    """BASELINE.json's own metric -- "Mpixels/s encode+decode (API-1 P010+YUV420, 4K/8K)" -- device resident, bytes <-> pixels:
-      encode = uhdr_hip_encode_api1_fused_dev (two-pass 3-channel map at scale 1, convertYuv to BT.601, all FDCTs: 4 launches)
-               + 2 x uhdr_hip_huffman_encode_dev without restart markers (the reference's bytes): P010 + 4:2:0 planes in HBM
-               -> the two entropy-coded scans in HBM (what JpegR::encodeJPEGR API-1, jpegr.cpp:253-316, computes; the container
-               around them is host byte shuffling, out of scope);
-      decode = 2 x uhdr_hip_huffman_decode_dev (self-synchronising parallel decoder: marker-less scans) + the 3-channel map's
-               dequant + IDCT + ycc->rgb + applyGainMap with the base image's dequant + IDCT inside the kernel -> RGBA_F16
-               (what JpegR::decodeJPEGR, jpegr.cpp:1469-1531, computes after parsing).
+    """BASELINE.json's own metric -- "Mpixels/s encode+decode (API-1 P010+YUV420, 4K/8K)" -- device resident, bytes <-> pixels, each
+    direction on its own (make_roundtrip's two closures) at 4K and at 8K.
     ONE pair of HIP events on the library's stream around `iters` back-to-back calls per direction (the entropy entry points are
     synchronous -- they read a byte count / status word back --, so host gaps are inside the pair), plus the per-family kernel sums."""
     from libultrahdr_amd import capi as A
-    from libultrahdr_amd import synth
-    from libultrahdr_amd.images import Image
-    from libultrahdr_amd.ultrahdr import UltraHdr
     import torch
 
     res = {}
-    qy, qc = u.quant_table(95, False), u.quant_table(95, True)
-    enc1 = UltraHdr(ctx=ctx, mapDimensionScaleFactor=1, useMultiChannelGainMap=True, preset=A.UHDR_USAGE_BEST_QUALITY)
-    f16, rgba = A.UHDR_IMG_FMT_64bppRGBAHalfFloat, A.UHDR_IMG_FMT_32bppRGBA8888
-    S420, S444 = [(2, 2), (1, 1), (1, 1)], [(1, 1)] * 3
     fams = ["generate_gainmap", "fdct_quant", "huffman_encode", "huffman_decode", "idct_dequant", "apply_gainmap"]
     for tag, w, h, it in (("4k", 3840, 2160, 8), ("8k", 7680, 4320, 4)):
         px = w * h
-        sdr = synth.make_sdr_yuv420(w, h).to(device)
-        hdr = synth.make_hdr_p010(w, h, ct=A.UHDR_CT_HLG).to(device)
-        out_b = torch.empty(px * 2, dtype=torch.uint8, device=device)
-        out_m = torch.empty(px * 4, dtype=torch.uint8, device=device)
-        box = {}
-
-        def enc(two=True):
-            cb, cm, md_, _ = enc1.encodeApi1Fused(sdr, hdr, A.UHDR_CG_DISPLAY_P3, (qy, qc), (qy, qc), want_map=False)
-            if two:  # both scans at once: the map's on the context's auxiliary stream (uhdr_hip_huffman_encode2_dev)
-                eb, em = u.huffman_encode2(cb, w, h, S420, cm, w, h, S444, 0, outs=[out_b, out_m])
-                box["nb"], box["nm"] = int(eb.numel()), int(em.numel())
-            else:
-                box["nb"] = int(u.huffman_encode(cb, w, h, S420, 0, out=out_b).numel())
-                box["nm"] = int(u.huffman_encode(cm, w, h, S444, 0, out=out_m).numel())
-            box["md"], box["shp_b"], box["shp_m"] = md_, [tuple(c.shape[:2]) for c in cb], [tuple(c.shape[:2]) for c in cm]
-
+        enc, dec, box = make_roundtrip(ctx, u, device, w, h)
         enc(False)
         ms_enc_seq = time_region(ctx, lambda: enc(False), iters=it, warm=2, reps=3)
         seq_sizes = (box["nb"], box["nm"])
@@ -792,22 +860,8 @@ def api1_roundtrip_section(ctx, u, device):
         assert seq_sizes == (box["nb"], box["nm"])
         ms_enc = time_region(ctx, enc, iters=it, warm=2, reps=3)
         k_enc = family_times(ctx, enc, fams, iters=3, warm=1)
-        sb, sm = out_b[: box["nb"]].clone(), out_m[: box["nm"]].clone()
-        gm3 = Image(rgba, w, h, A.UHDR_CG_BT_2100, align=64, device=device)
-        dst = Image(f16, w, h, align=64, device=device)
-        qts = [qy, qc, qc]
         st0 = A.Stats()
         ctx.lib.uhdr_hip_get_stats(ctx.handle, C.byref(st0))
-
-        def dec(two=True):
-            if two:  # uhdr_hip_huffman_decode2_dev
-                cb, cm = u.huffman_decode2(sb, box["shp_b"], w, h, S420, sm, box["shp_m"], w, h, S444, 0)
-            else:
-                cb = u.huffman_decode(sb, box["shp_b"], w, h, S420, 0)
-                cm = u.huffman_decode(sm, box["shp_m"], w, h, S444, 0)
-            u.idct_dequant_rgb(cm, qy, qc, w, h, rgba, 0, dst=gm3)
-            u.applyGainMapFromCoefficients(cb, qts, w, h, A.UHDR_CG_BT_709, gm3, box["md"], A.UHDR_CT_LINEAR, f16, A.FLT_MAX, dst)
-
         dec()
         ctx.synchronize()
         t0 = time.perf_counter()
@@ -839,7 +893,7 @@ def api1_roundtrip_section(ctx, u, device):
             "decode_algorithmic_bytes": int(34.0 * px + box["nb"] + box["nm"])}
         res[f"api1_{tag}_enc_frac"] = round(res[f"api1_{tag}_detail"]["encode_algorithmic_bytes"] / (ms_enc * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         res[f"api1_{tag}_dec_frac"] = round(res[f"api1_{tag}_detail"]["decode_algorithmic_bytes"] / (ms_dec * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-        del sdr, hdr, out_b, out_m, sb, sm, gm3, dst
+        del enc, dec, box
         torch.cuda.empty_cache()
     res["api1_note"] = ("device-resident API-1 round trip, synthetic noisy frames at q95 (dense streams: ~3.3 MB base scan per 4K frame); enc_us / dec_us: "
                         "one HIP-event pair around back-to-back calls, host gaps of the synchronous entropy entry points included, the file's two scans "
@@ -1077,44 +1131,18 @@ def config5_section(ctx, u, device):
     return res
 
 
-def capture_stderr(fn):
-    """fn() with file descriptor 2 redirected to a temporary file (the facade's UHDR_HIP_SEAM_TRACE lines are C stdio) -> (result, text)."""
-    import tempfile
+def seam_split(fn, n):
+    """Per-call medians are not available from tallies: run fn() n times between a reset and a read of the facade's stage table
+    (uhdr_hip_seam_stats) -> (mean ms of the device stages per call, mean ms of the whole accelerated call, {stage: calls})."""
+    from libultrahdr_amd import capi as A
 
-    sys.stderr.flush()
-    C.CDLL(None).fflush(None)
-    saved = os.dup(2)
-    with tempfile.TemporaryFile() as tf:
-        os.dup2(tf.fileno(), 2)
-        try:
-            r = fn()
-        finally:
-            C.CDLL(None).fflush(None)
-            os.dup2(saved, 2)
-            os.close(saved)
-        tf.seek(0)
-        text = tf.read().decode(errors="replace")
-    return r, text
-
-
-def seam_ms(trace_text):
-    """Per uhdr_encode / uhdr_decode call of a UHDR_HIP_SEAM_TRACE log: (summed 'took' of its device stages, begin -> end) in ms."""
-    import re
-
-    calls, cur, t_begin = [], None, None
-    for line in trace_text.splitlines():
-        m = re.search(r"\[\s*([0-9.]+) ms(?:, took\s*([0-9.]+))?\]\s*(.*)", line)
-        if not m:
-            continue
-        t, took, what = float(m.group(1)), m.group(2), m.group(3)
-        if "accelerated call begins" in what:
-            cur, t_begin = 0.0, t
-        elif "accelerated call ends" in what and cur is not None:
-            calls.append((cur, t - t_begin))
-            cur = None
-        elif took is not None and "-> device" in what and cur is not None:
-            cur += float(took)
-    return calls
+    A.seam_stats(reset=True)
+    for _ in range(n):
+        fn()
+    st = A.seam_stats(reset=True)
+    call = st.pop("uhdr_call", None)
+    stages = sum(v["device_ms"] for k, v in st.items() if k not in ("gainmap_copy_deferred", "gainmap_image_asked_for"))
+    return stages / n, (call["device_ms"] / n if call else None), {k: v["device"] for k, v in st.items()}
 
 
 def api_level_section():
@@ -1166,21 +1194,17 @@ def api_level_section():
     # the round-4 route: four per-stage seams instead of the one at encodeJPEGR (same bytes)
     jpg_ps, t_enc_ps = with_env("UHDR_HIP_SEAM_NO_FUSED_ENCODE", "1", lambda: med(lambda: FA.encode(hdr, sdr, gpu=True), 5))
     jpg2, t_enc2 = med(lambda: FA.encode(hdr, sdr, gpu=True), 5)  # ... and the fused seam once more, later in the process
-    # where the time of those two calls goes: the seam's own stage trace (UHDR_HIP_SEAM_TRACE, switched on by main()) of five more calls
+    # where the time of those two calls goes: the seam's own stage table (uhdr_hip_seam_stats) over five more calls
     # each -- the device stages against the reference's own host code around them (two ICC profiles, container parsing and writing,
     # copies; until round 5 also 50-110 MB of value-initialised buffers per call, which the facade's blocks now get from calloc)
     split = {}
     try:
-        _, txt = capture_stderr(lambda: [FA.encode(hdr, sdr, gpu=True) for _ in range(5)])
-        ce = sorted(seam_ms(txt))
-        _, txt = capture_stderr(lambda: [FA.decode(jpg, A.UHDR_CT_LINEAR, f16, gpu=True) for _ in range(5)])
-        cd = sorted(seam_ms(txt))
-        if ce:
-            split["uhdr_encode_4k_device_stages_ms"] = round(ce[len(ce) // 2][0], 2)
-            split["uhdr_encode_4k_scope_ms"] = round(sorted(c_[1] for c_ in ce)[len(ce) // 2], 2)
-        if cd:
-            split["uhdr_decode_4k_device_stages_ms"] = round(cd[len(cd) // 2][0], 2)
-            split["uhdr_decode_4k_scope_ms"] = round(sorted(c_[1] for c_ in cd)[len(cd) // 2], 2)
+        se, ce, ne = seam_split(lambda: FA.encode(hdr, sdr, gpu=True), 5)
+        sd, cd, nd = seam_split(lambda: FA.decode(jpg, A.UHDR_CT_LINEAR, f16, gpu=True), 5)
+        split = {"uhdr_encode_4k_device_stages_ms": round(se, 2), "uhdr_encode_4k_scope_ms": round(ce, 2) if ce is not None else None,
+                 "uhdr_encode_4k_stage_calls": ne,
+                 "uhdr_decode_4k_device_stages_ms": round(sd, 2), "uhdr_decode_4k_scope_ms": round(cd, 2) if cd is not None else None,
+                 "uhdr_decode_4k_stage_calls": nd, "note": "means over 5 calls, from the library's stage table (uhdr_hip_seam_stats)"}
     except Exception as e:  # noqa: BLE001
         split = {"error": f"{type(e).__name__}: {e}"}
     # opt-in: restart intervals, one per wavefront
@@ -1570,44 +1594,69 @@ def extras(ctx, u, device):
     return res
 
 
-def cpu_baseline(w, h, map_kind, md, budget_s):
-    """The reference's CPU path on this box's host cores, bounded sample, rank 0 only."""
+def cpu_baseline(w, h, budget_s, stages=True):
+    """The reference's CPU path for the SAME workload on this box's host cores, bounded sample, rank 0 only: whole uhdr_encode
+    (API-1, ultrahdr_api.cpp:1200) + uhdr_decode (-> RGBA_F16 linear, ultrahdr_api.cpp:1918) calls of the real reference
+    (oracle/_ref: libultrahdr built from its own sources) on host buffers, timed around the C calls.  Without oracle/_ref the C
+    port has no codec layer: it then times generateGainMap + applyGainMap only and says so."""
+    import ctypes
+    import numpy as np
+
     from libultrahdr_amd import capi as A
     from libultrahdr_amd import synth
     from oracle import loader as L
 
-    kind = "reference" if L.ref() is not None else "port"
     sdr = synth.make_sdr_yuv420(w, h, seed=1234)
-    gm = (synth.make_gainmap(w // 4, h // 4, 1, seed=1334) if map_kind == "A"
-          else synth.make_gainmap(w, h, 3, alpha=(map_kind == "C"), seed=1334))
-    sdr.raw.cg, gm.raw.cg = A.UHDR_CG_BT_709, A.UHDR_CG_BT_2100
-    which = "ref" if kind == "reference" else "port"
-    L.apply_gainmap(which, sdr, gm, md, A.UHDR_CT_LINEAR)  # warm-up (builds the reference's static LUTs)
-    n, t0 = 0, time.perf_counter()
-    while True:
-        L.apply_gainmap(which, sdr, gm, md, A.UHDR_CT_LINEAR)
-        n += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or n >= 64:
-            break
-    cores = min(os.cpu_count() or 1, 4) if kind == "reference" else 1
-    stages = None
-    if kind == "reference":
-        try:
-            stages = cpu_stage_baselines(3840, 2160)
-        except Exception as e:  # noqa: BLE001
-            stages = {"error": f"{type(e).__name__}: {e}"}
-    return {
-        "stages": stages,
-        "value": round(n * w * h / el / 1e6, 2),
-        "unit": "Mpixels/s",
-        "cores": cores,
-        "kind": kind,
-        "sample": f"{n} x applyGainMap {w}x{h} YCbCr420 + map {map_kind} -> RGBA_F16 on host buffers ({el:.1f} s); "
-                  + ("libultrahdr 2.0.2 built from /root/reference, its own min(hw,4)-thread job queue" if kind == "reference"
-                     else "single-threaded C restatement (oracle/uhdr_oracle.c)")
-                  + f"; host has {os.cpu_count()} logical cores",
-    }
+    hdr = synth.make_hdr_p010(w, h, ct=A.UHDR_CT_HLG, seed=1234)
+    px = w * h
+    if L.ref() is not None:
+        lib = L.ref()
+        cap = px * 6
+        buf = (ctypes.c_uint8 * cap)()
+        dest = np.empty((h, w, 8), dtype=np.uint8)
+        ow, oh = ctypes.c_int(0), ctypes.c_int(0)
+        f16 = A.UHDR_IMG_FMT_64bppRGBAHalfFloat
+
+        def trip():
+            t0 = time.perf_counter()
+            n = lib.ref_uhdr_encode(ctypes.byref(hdr.raw), ctypes.byref(sdr.raw), 95, A.UHDR_USAGE_BEST_QUALITY, buf, cap)
+            t1 = time.perf_counter()
+            if n <= 0:
+                raise RuntimeError(f"ref_uhdr_encode failed: {n}")
+            rc = lib.ref_uhdr_decode(buf, n, A.UHDR_CT_LINEAR, f16, dest.ctypes.data, dest.nbytes, ctypes.byref(ow), ctypes.byref(oh))
+            t2 = time.perf_counter()
+            if rc != 0:
+                raise RuntimeError(f"ref_uhdr_decode failed: {rc}")
+            return t1 - t0, t2 - t1, n
+
+        trip()  # warm-up: the reference builds its static LUTs on first use
+        te, td, n, nbytes, t_start = 0.0, 0.0, 0, 0, time.perf_counter()
+        while True:
+            e_, d_, nbytes = trip()
+            te, td, n = te + e_, td + d_, n + 1
+            if time.perf_counter() - t_start >= budget_s or n >= 32:
+                break
+        cores = min(os.cpu_count() or 1, 4)
+        res = {"value": round(n * px / (te + td) / 1e6, 2), "unit": "Mpixels/s", "cores": cores, "kind": "reference",
+               "sample": f"{n} x (uhdr_encode API-1 q95 + uhdr_decode -> RGBA_F16) of the same {w}x{h} frame on host buffers: "
+                         f"encode {te / n * 1e3:.0f} ms + decode {td / n * 1e3:.0f} ms per frame, {nbytes} byte file; libultrahdr built from /root/reference "
+                         f"(oracle/_ref), its own min(hw,4)-thread job queue, libjpeg on one thread; host has {os.cpu_count()} logical cores",
+               "encode_ms": round(te / n * 1e3, 1), "decode_ms": round(td / n * 1e3, 1)}
+        if stages:
+            try:
+                res["stages"] = cpu_stage_baselines(w, h)
+            except Exception as e:  # noqa: BLE001
+                res["stages"] = {"error": f"{type(e).__name__}: {e}"}
+        return res
+    cfg = A.default_encode_cfg()
+    md_, gm = L.generate_gainmap("port", sdr, hdr, cfg)
+    t0 = time.perf_counter()
+    md_, gm = L.generate_gainmap("port", sdr, hdr, cfg)
+    L.apply_gainmap("port", sdr, gm, md_, A.UHDR_CT_LINEAR)
+    el = time.perf_counter() - t0
+    return {"value": round(px / el / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+            "sample": f"1 x (generateGainMap + applyGainMap) {w}x{h}, single-threaded C restatement (oracle/uhdr_oracle.c), JPEG stages NOT included "
+                      f"(oracle/_ref absent): {el:.1f} s"}
 
 
 def cpu_stage_baselines(w, h):

@@ -66,15 +66,21 @@ double now_ms() {
   static const auto t0 = std::chrono::steady_clock::now();
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
-void enter() { if (trace_on()) tl_enter_ms = now_ms(); }
+thread_local double tl_scope_ms = -1.0;
+void enter() { tl_enter_ms = now_ms(); }
+// every stage outcome goes to the library's process-wide tally (uhdr_hip_seam_stats, include/uhdr_hip.h): tests, bench.py and
+// applications read that table; the stderr trace is only for a person watching a run
+void note(const char* stage, bool dev, const char* why) {
+  const double t = now_ms(), took = tl_enter_ms >= 0 ? t - tl_enter_ms : 0.0;
+  tl_enter_ms = -1.0;
+  uhdr_hip_seam_note(stage, dev ? 1 : 0, took);
+  if (trace_on())
+    fprintf(stderr, "uhdr_hip_seam: [%8.2f ms, took %6.2f] %s -> %s%s%s\n", t, took, stage, dev ? "device" : "reference CPU path (", dev ? "" : (why ? why : ""),
+            dev ? "" : ")");
+}
 bool handled(const uhdr_error_info_t& s, const char* stage) {
   const bool dev = s.error_code != UHDR_CODEC_UNSUPPORTED_FEATURE;
-  if (trace_on()) {
-    const double t = now_ms();
-    fprintf(stderr, "uhdr_hip_seam: [%8.2f ms, took %6.2f] %s -> %s%s%s\n", t, tl_enter_ms >= 0 ? t - tl_enter_ms : 0.0, stage, dev ? "device" : "reference CPU path (", dev ? "" : (s.has_detail ? s.detail : ""),
-            dev ? "" : ")");
-    tl_enter_ms = -1.0;
-  }
+  note(stage, dev, s.has_detail ? s.detail : "");
   if (dev) g_calls.fetch_add(1, std::memory_order_relaxed);
   else if (cur()) uhdr_hip_resident_begin(cur());  // the reference's CPU code runs next and may write in place: drop the device copies
   return dev;
@@ -106,11 +112,14 @@ Scope::Scope(bool enable, void** slot, bool lazy) : mPrev(tl_ctxt), mFailed(fals
   // one uhdr_encode / uhdr_decode: what the JPEG decode stage leaves in the JpegDecoderHelper buffers stays on the device
   // for the stage that reads those buffers next (decodeJPEGR -> applyGainMap, jpegr.cpp:1478-1530)
   uhdr_hip_resident_begin(cur());
-  if (trace_on()) fprintf(stderr, "uhdr_hip_seam: [%8.2f ms] accelerated call begins\n", now_ms());
+  tl_scope_ms = now_ms();
+  if (trace_on()) fprintf(stderr, "uhdr_hip_seam: [%8.2f ms] accelerated call begins\n", tl_scope_ms);
 }
 Scope::~Scope() {
   if (tl_ctxt && trace_on()) fprintf(stderr, "uhdr_hip_seam: [%8.2f ms] accelerated call ends\n", now_ms());
   if (tl_ctxt) uhdr_hip_resident_end(cur());
+  if (tl_ctxt && tl_scope_ms >= 0) uhdr_hip_seam_note("uhdr_call", 1, now_ms() - tl_scope_ms);  // the whole accelerated uhdr_encode / uhdr_decode
+  tl_scope_ms = -1.0;
   tl_ctxt = mPrev;
   tl_lazy_ok = false;
 }
@@ -126,6 +135,7 @@ bool defer_copy(uhdr_raw_image_t* src, uhdr_raw_image_t* dst) {
     dst->cg = src->cg;  // gainmapmath.cpp:1505-1507
     dst->ct = src->ct;
     dst->range = src->range;
+    uhdr_hip_seam_note("gainmap_copy_deferred", 1, 0.0);
     if (trace_on()) fprintf(stderr, "uhdr_hip_seam: [%8.2f ms] gain-map image copy deferred: the image stays on the device until asked for\n", now_ms());
     return true;
   }
@@ -136,12 +146,13 @@ bool defer_copy(uhdr_raw_image_t* src, uhdr_raw_image_t* dst) {
 }
 bool materialize(void* ctxt) {
   if (!ctxt) return true;
-  const double t0 = trace_on() ? now_ms() : 0.0;
+  const double t0 = now_ms();
   const uhdr_error_info_t s = uhdr_hip_resident_materialize(static_cast<uhdr_hip_ctx_t*>(ctxt));
   if (s.error_code != UHDR_CODEC_OK) {
     fprintf(stderr, "uhdr_hip_seam: download of the gain-map image failed: %s\n", s.has_detail ? s.detail : "");
     return false;
   }
+  uhdr_hip_seam_note("gainmap_image_asked_for", 1, now_ms() - t0);
   if (trace_on()) fprintf(stderr, "uhdr_hip_seam: [%8.2f ms, took %6.2f] gain-map image asked for\n", now_ms(), now_ms() - t0);
   return true;
 }
@@ -302,7 +313,7 @@ bool encode_api1(uhdr_raw_image_t* hdr_intent, uhdr_raw_image_t* sdr_intent, int
   *st = uhdr_hip_encode_api1_scans(cur(), sdr_intent, hdr_intent, &cfg, UHDR_CG_DISPLAY_P3, qt_base, qt_map, &md, &gm_desc, out->base_data.get() + lead_b,
                                    cap_b, &nb, out->gainmap_data.get() + lead_m, cap_m, &nm);
   if (st->error_code == UHDR_CODEC_MEM_ERROR) {  // a stream busier than one byte per coefficient: the per-stage seams size their buffers from the answer
-    if (trace_on()) fprintf(stderr, "uhdr_hip_seam: encode_api1_fused -> per-stage seams (%s)\n", st->has_detail ? st->detail : "");
+    note("encode_api1_fused", false, st->has_detail ? st->detail : "per-stage seams");
     return false;
   }
   if (!handled(*st, "encode_api1_fused")) return false;
@@ -337,6 +348,7 @@ bool tone_map(uhdr_raw_image_t* hdr_intent, uhdr_raw_image_t* sdr_intent, uhdr_e
   // host buffers in place
   const bool on_device_ = [&]() -> bool {
     if (!cur()) return false;
+    enter();
     *st = uhdr_hip_tone_map(cur(), hdr_intent, sdr_intent);
     return handled(*st, "tone_map");
   }();
@@ -350,6 +362,7 @@ bool convert_yuv(uhdr_raw_image_t* image, uhdr_color_gamut_t src_encoding, uhdr_
   // host buffers in place
   const bool on_device_ = [&]() -> bool {
     if (!cur()) return false;
+    enter();
     *st = uhdr_hip_convert_yuv(cur(), image, src_encoding, dst_encoding);
     return handled(*st, "convert_yuv");
   }();
@@ -366,6 +379,7 @@ bool convert_raw_input_to_ycbcr(uhdr_raw_image_t* src, bool chroma_sampling_enab
     if (src->fmt != UHDR_IMG_FMT_32bppRGBA1010102 && src->fmt != UHDR_IMG_FMT_32bppRGBA8888 && src->fmt != UHDR_IMG_FMT_24bppRGB888)
       return false;  // YCbCr inputs are a plain copy in the reference (gainmapmath.cpp:1475-1480)
     if (src->cg != UHDR_CG_BT_709 && src->cg != UHDR_CG_DISPLAY_P3 && src->cg != UHDR_CG_BT_2100) return false;
+    enter();
     const bool ten = src->fmt == UHDR_IMG_FMT_32bppRGBA1010102;
     const uhdr_img_fmt_t fmt = ten ? (chroma_sampling_enabled ? UHDR_IMG_FMT_24bppYCbCrP010 : UHDR_IMG_FMT_30bppYCbCr444)
                                    : (chroma_sampling_enabled ? UHDR_IMG_FMT_12bppYCbCr420 : UHDR_IMG_FMT_24bppYCbCr444);
@@ -391,6 +405,7 @@ bool fdct_planes(int ncomp, const unsigned char* const planes[3], const unsigned
   // host buffers in place
   const bool on_device_ = [&]() -> bool {
     if (!cur()) return false;
+    enter();
     for (int c = 0; c < ncomp; c++) {
       *st = uhdr_hip_fdct_quant(cur(), planes[c], strides[c], (int)blocks_w[c], (int)blocks_h[c], qtables[c], coefs[c]);
       if (st->error_code != UHDR_CODEC_OK) return c == 0 ? handled(*st, "fdct_planes") : true;
@@ -409,6 +424,7 @@ bool idct_planes(int ncomp, const short* const coefs[3], const unsigned int bloc
   // host buffers in place
   const bool on_device_ = [&]() -> bool {
     if (!cur()) return false;
+    enter();
     for (int c = 0; c < ncomp; c++) {
       *st = uhdr_hip_idct_dequant(cur(), coefs[c], (int)blocks_w[c], (int)blocks_h[c], qtables[c], planes[c], strides[c]);
       if (st->error_code != UHDR_CODEC_OK) return c == 0 ? handled(*st, "idct_planes") : true;
@@ -442,7 +458,7 @@ bool decode_scan(const void* hdr, const unsigned char* data, size_t bytes, int o
                                     hstride, vstride);
     // corrupt entropy-coded data: libjpeg decodes such files with warnings and padding; that behaviour stays libjpeg's
     if (st->error_code == UHDR_CODEC_INVALID_PARAM) {
-      if (trace_on()) fprintf(stderr, "uhdr_hip_seam: jpeg_decode_scan -> reference CPU path (%s)\n", st->has_detail ? st->detail : "");
+      note("jpeg_decode_scan", false, st->has_detail ? st->detail : "");
       return false;
     }
     return handled(*st, "jpeg_decode_scan");
@@ -473,6 +489,7 @@ bool effect(int kind, int p0, int p1, int dst_w, int dst_h, uhdr_raw_image_t* sr
   // host buffers in place
   const bool on_device_ = [&]() -> bool {
     if (!cur() || !src || dst_w <= 0 || dst_h <= 0) return false;
+    enter();
     auto img = std::make_unique<ultrahdr::uhdr_raw_image_ext_t>(src->fmt, src->cg, src->ct, src->range, (unsigned)dst_w, (unsigned)dst_h, 64);
     const uhdr_error_info_t s = uhdr_hip_apply_effect(cur(), kind, p0, p1, src, img.get());
     if (!handled(s, kind == 0 ? "effect_rotate" : kind == 1 ? "effect_mirror" : kind == 2 ? "effect_crop" : "effect_resize")) return false;
@@ -492,6 +509,7 @@ bool jpeg_rgb_to_ycc(const uhdr_raw_image_t* rgb, uhdr_raw_image_t* ycc, uhdr_er
   // host buffers in place
   const bool on_device_ = [&]() -> bool {
     if (!cur()) return false;
+    enter();
     *st = uhdr_hip_jpeg_rgb_to_ycc(cur(), rgb, ycc);
     return handled(*st, "jpeg_rgb_to_ycc");
   }();
@@ -500,6 +518,7 @@ bool jpeg_rgb_to_ycc(const uhdr_raw_image_t* rgb, uhdr_raw_image_t* ycc, uhdr_er
 }
 bool jpeg_ycc_to_rgb(const uhdr_raw_image_t* ycc, int libjpeg_variant, uhdr_raw_image_t* rgb, uhdr_error_info_t* st) {
   if (!cur()) return false;
+  enter();
   *st = uhdr_hip_jpeg_ycc_to_rgb(cur(), ycc, libjpeg_variant, rgb);
   return handled(*st, "jpeg_ycc_to_rgb");
 }

@@ -712,6 +712,25 @@ typedef struct uhdr_hip_stats {
 } uhdr_hip_stats_t;
 void uhdr_hip_get_stats(uhdr_hip_ctx_t* ctx, uhdr_hip_stats_t* out);
 
+/* ---- where did the stages of a drop-in call run? (round 6) -----------------------------------------------------------
+ * Process-wide tallies, one row per stage name, kept by the library for whatever sits above it: the libuhdr.so facade reports
+ * every stage of an accelerated uhdr_encode / uhdr_decode here (facade/uhdr_hip_seam.cpp) -- on the device, or handed back to
+ * the reference's CPU code -- and the whole accelerated call as the stage "uhdr_call".  Tests, bench.py and applications read
+ * the table instead of parsing a stderr trace.  Thread-safe; rows come back in the order the stages were first seen since the
+ * last reset (first_seq = that position, counted over all notes).  UHDR_HIP_SEAM_STATS_FILE=<path> in the environment: the table
+ * is also written there as JSON when the process exits (for a process one cannot call into, e.g. the reference's ultrahdr_app). */
+typedef struct uhdr_hip_seam_stage {
+  char name[40];
+  unsigned long long device_calls;     /* the device produced the stage's result */
+  unsigned long long reference_calls;  /* left to the reference's CPU code */
+  unsigned long long first_seq;
+  double device_ms;                    /* wall time of the device calls, summed */
+  double last_ms;                      /* wall time of the most recent call (either kind) */
+} uhdr_hip_seam_stage_t;
+void uhdr_hip_seam_note(const char* stage, int on_device, double ms);
+int uhdr_hip_seam_stats(uhdr_hip_seam_stage_t* out, int capacity); /* -> number of rows (may exceed capacity) */
+void uhdr_hip_seam_stats_reset(void);
+
 /* ---- timing hook for bench.py ------------------------------------------------------------------
  * HIP events recorded on the context's stream around every kernel launch of the named family
  * ("apply_gainmap", "generate_gainmap", ...) since the last reset; returns the number of launches

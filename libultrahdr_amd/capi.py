@@ -169,6 +169,11 @@ class Stats(C.Structure):
                                               "lazy_downloads_done", "last_jpeg_decode_scan_ns", "last_encode_api1_scans_ns")]
 
 
+class SeamStage(C.Structure):  # uhdr_hip_seam_stage_t
+    _fields_ = [("name", C.c_char * 40), ("device_calls", C.c_ulonglong), ("reference_calls", C.c_ulonglong), ("first_seq", C.c_ulonglong),
+                ("device_ms", C.c_double), ("last_ms", C.c_double)]
+
+
 class CommOps(C.Structure):
     _fields_ = [("user", C.c_void_p), ("all_reduce_min_f32", ALL_REDUCE_MIN_FN), ("all_gather", ALL_GATHER_FN), ("gather_v", GATHER_V_FN)]
 
@@ -248,6 +253,9 @@ _SIGS = {
     "uhdr_hip_comm_gather_dev": (ErrorInfo, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, _P(C.c_size_t), C.c_int]),
     "uhdr_hip_generate_gainmap_striped_dev": (ErrorInfo, [C.c_void_p, _P(RawImage), _P(RawImage), _P(EncodeCfg), _P(GainmapMetadata), _P(RawImage)]),
     "uhdr_hip_get_stats": (None, [C.c_void_p, C.c_void_p]),
+    "uhdr_hip_seam_note": (None, [C.c_char_p, C.c_int, C.c_double]),
+    "uhdr_hip_seam_stats": (C.c_int, [C.c_void_p, C.c_int]),
+    "uhdr_hip_seam_stats_reset": (None, []),
     "uhdr_hip_resident_begin": (None, [C.c_void_p]),
     "uhdr_hip_resident_end": (None, [C.c_void_p]),
     "uhdr_hip_resident_lazy": (None, [C.c_void_p, C.c_int]),
@@ -290,3 +298,18 @@ def load() -> C.CDLL:
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def seam_stats(reset: bool = False) -> dict:
+    """The facade's stage tallies (uhdr_hip_seam_stats): {stage: {"device": n, "reference": n, "device_ms": t, "last_ms": t}} in
+    the order the stages were first seen since the last reset."""
+    lib = load()
+    rows = (SeamStage * 64)()
+    n = min(lib.uhdr_hip_seam_stats(rows, 64), 64)
+    out = {}
+    for r in sorted(rows[:n], key=lambda r: r.first_seq):
+        out[r.name.decode()] = {"device": int(r.device_calls), "reference": int(r.reference_calls), "device_ms": float(r.device_ms),
+                                "last_ms": float(r.last_ms)}
+    if reset:
+        lib.uhdr_hip_seam_stats_reset()
+    return out

@@ -2,6 +2,7 @@
 #include "api_internal.h"
 
 #include <sys/mman.h>
+#include <mutex>
 
 namespace uhdr_api {
 uhdr_error_info_t ensure(DeviceBuf& b, size_t bytes) {
@@ -652,6 +653,65 @@ void uhdr_hip_get_stats(uhdr_hip_ctx_t* c, uhdr_hip_stats_t* out) {
   if (!out) return;
   if (!c) { memset(out, 0, sizeof *out); return; }
   *out = c->stats;
+}
+
+// ---- the seam's stage tallies (include/uhdr_hip.h) ------------------------------------------------------------------
+namespace {
+std::mutex g_seam_mu;
+std::vector<uhdr_hip_seam_stage_t> g_seam_rows;
+unsigned long long g_seam_seq = 0;
+// UHDR_HIP_SEAM_STATS_FILE=<path>: the table is written there as JSON when the process exits -- how a test reads it out of a
+// process it cannot call into (the reference's own ultrahdr_app linked against the facade)
+void seam_dump_at_exit() {
+  const char* path = getenv("UHDR_HIP_SEAM_STATS_FILE");
+  FILE* f = path ? fopen(path, "w") : nullptr;
+  if (!f) return;
+  std::lock_guard<std::mutex> lk(g_seam_mu);
+  fprintf(f, "{");
+  for (size_t i = 0; i < g_seam_rows.size(); i++) {
+    const auto& r = g_seam_rows[i];
+    fprintf(f, "%s\"%s\": {\"device\": %llu, \"reference\": %llu, \"device_ms\": %.3f, \"first_seq\": %llu}", i ? ", " : "", r.name, r.device_calls,
+            r.reference_calls, r.device_ms, r.first_seq);
+  }
+  fprintf(f, "}\n");
+  fclose(f);
+}
+}  // namespace
+
+void uhdr_hip_seam_note(const char* stage, int on_device, double ms) {
+  if (!stage) return;
+  static const bool dump = [] { return getenv("UHDR_HIP_SEAM_STATS_FILE") ? (atexit(seam_dump_at_exit), true) : false; }();
+  (void)dump;
+  std::lock_guard<std::mutex> lk(g_seam_mu);
+  uhdr_hip_seam_stage_t* row = nullptr;
+  for (auto& r : g_seam_rows)
+    if (!strncmp(r.name, stage, sizeof r.name - 1)) { row = &r; break; }
+  if (!row) {
+    if (g_seam_rows.size() >= 64) return;  // the facade has 16 stage names
+    uhdr_hip_seam_stage_t r;
+    memset(&r, 0, sizeof r);
+    strncpy(r.name, stage, sizeof r.name - 1);
+    r.first_seq = g_seam_seq;
+    g_seam_rows.push_back(r);
+    row = &g_seam_rows.back();
+  }
+  g_seam_seq++;
+  if (on_device) { row->device_calls++; row->device_ms += ms; }
+  else row->reference_calls++;
+  row->last_ms = ms;
+}
+
+int uhdr_hip_seam_stats(uhdr_hip_seam_stage_t* out, int capacity) {
+  std::lock_guard<std::mutex> lk(g_seam_mu);
+  const int n = (int)g_seam_rows.size();
+  for (int i = 0; out && i < n && i < capacity; i++) out[i] = g_seam_rows[i];
+  return n;
+}
+
+void uhdr_hip_seam_stats_reset(void) {
+  std::lock_guard<std::mutex> lk(g_seam_mu);
+  g_seam_rows.clear();
+  g_seam_seq = 0;
 }
 
 void uhdr_hip_profile_enable(uhdr_hip_ctx_t* c, int enable) {

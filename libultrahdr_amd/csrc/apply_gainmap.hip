@@ -1042,16 +1042,13 @@ __global__ __launch_bounds__(quad_block<OUT>()) __attribute__((amdgpu_num_sgpr(9
 }
 // The HLG / PQ variants that interpolate a THREE-channel map (OUT != 0, MAPFMT != 0, SMODE 1) do not fit the 80 VGPRs that six
 // waves per SIMD (two 768-thread workgroups per CU) leave a wave: 60 - 164 bytes per lane went to scratch (round-4 review).
-// This entry point asks for three waves per SIMD (one workgroup per CU, up to 168 VGPRs): no private segment.  Which of the
-// two is faster is a measurement (bench.py extra: apply_4k_hlg_map3ch_s2 / _s4), selected by quad_spill_wpe3().
+// This entry point asks for three waves per SIMD (one workgroup per CU, up to 168 VGPRs): no private segment.  It is the only
+// form of those variants in the library: the six-wave spilling build lost by 3 - 25 % (profiles/r05_spill_wpe{3,6}.txt; the A/B
+// arm is kept as tools/spill_exp.patch, not in the product).
 template <int OUT, int MAPFMT, int SMODE, int BASE, int SRC = 0>
 __global__ __launch_bounds__(quad_block<OUT>()) __attribute__((amdgpu_num_sgpr(96), amdgpu_waves_per_eu(3, 8))) void apply_quad_kernel_s96w3(const ApplyParams p) {
   static_assert(quad_sgprs<SMODE, SRC>() == 96 && OUT != 0 && MAPFMT != 0 && SMODE == 1 && SRC == 0, "the spilling HLG / PQ variants only");
   apply_quad_body<OUT, MAPFMT, SMODE, BASE, SRC>(p);
-}
-inline bool quad_spill_wpe3() {
-  static const bool on = [] { const char* e = getenv("UHDR_HIP_SPILL_WPE3"); return e ? atoi(e) != 0 : true; }();
-  return on;
 }
 
 // Resident workgroups of a kernel on the current device = CUs x blocks per CU (occupancy API; the
@@ -1080,8 +1077,7 @@ hipError_t launch_quad(const ApplyParams& p, hipStream_t s) {
   constexpr bool kSpills = !k80 && OUT != 0 && MAPFMT != 0 && SMODE == 1;  // see apply_quad_kernel_s96w3
   static const int resident = [] {
     if constexpr (k80) return resident_blocks(apply_quad_kernel<OUT, MAPFMT, SMODE, BASE>, BLK, 80);
-    else if constexpr (kSpills) return quad_spill_wpe3() ? resident_blocks(apply_quad_kernel_s96w3<OUT, MAPFMT, SMODE, BASE>, BLK, 96)
-                                                         : resident_blocks(apply_quad_kernel_s96<OUT, MAPFMT, SMODE, BASE>, BLK, 96);
+    else if constexpr (kSpills) return resident_blocks(apply_quad_kernel_s96w3<OUT, MAPFMT, SMODE, BASE>, BLK, 96);
     else return resident_blocks(apply_quad_kernel_s96<OUT, MAPFMT, SMODE, BASE>, BLK, 96);
   }();
   const uint32_t n_frames = p.n_frames ? p.n_frames : 1;
@@ -1134,8 +1130,7 @@ hipError_t launch_quad(const ApplyParams& p, hipStream_t s) {
   if constexpr (k80) {
     hipLaunchKernelGGL((apply_quad_kernel<OUT, MAPFMT, SMODE, BASE>), dim3(grid), dim3(BLK), 0, s, q);
   } else if constexpr (kSpills) {
-    if (quad_spill_wpe3()) hipLaunchKernelGGL((apply_quad_kernel_s96w3<OUT, MAPFMT, SMODE, BASE>), dim3(grid), dim3(BLK), 0, s, q);
-    else hipLaunchKernelGGL((apply_quad_kernel_s96<OUT, MAPFMT, SMODE, BASE>), dim3(grid), dim3(BLK), 0, s, q);
+    hipLaunchKernelGGL((apply_quad_kernel_s96w3<OUT, MAPFMT, SMODE, BASE>), dim3(grid), dim3(BLK), 0, s, q);
   } else {
     hipLaunchKernelGGL((apply_quad_kernel_s96<OUT, MAPFMT, SMODE, BASE>), dim3(grid), dim3(BLK), 0, s, q);
   }

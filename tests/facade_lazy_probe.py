@@ -1,6 +1,8 @@
-"""Run as a subprocess by tests/test_gpu_facade.py (UHDR_HIP_SEAM_TRACE=1): uhdr_decode through the facade with and without
+"""Run as a subprocess by tests/test_gpu_facade.py: uhdr_decode through the facade with and without
 acceleration, the decoded image AND the gain-map image of uhdr_get_decoded_gainmap_image compared; one '=== name: MATCH' line
-per case on stdout, '--- name' markers on stderr between the seam's trace lines."""
+per case on stdout, and one '--- name {stage table}' line per section: the library's own tallies (uhdr_hip_seam_stats) of the
+accelerated calls made in that section."""
+import json
 import sys
 
 import numpy as np
@@ -10,8 +12,16 @@ from libultrahdr_amd import facade as FA
 from libultrahdr_amd import synth
 
 
+_section = [None]
+
+
 def mark(s):
-    print("--- " + s, file=sys.stderr, flush=True)
+    """Close the running section -- print its stage table -- and open the next."""
+    if _section[0] is not None:
+        print("--- " + _section[0] + " " + json.dumps(A.seam_stats(reset=True)), flush=True)
+    else:
+        A.seam_stats(reset=True)
+    _section[0] = s
 
 
 def main():

@@ -27,15 +27,37 @@ def built():
     return os.path.isfile(APP) and os.path.isfile(FACADE)
 
 
+class Stages(dict):
+    """The facade's stage table of one process (uhdr_hip_seam_stats, include/uhdr_hip.h): {stage: {"device": n, "reference": n, ...}}."""
+
+    def on(self, where="device"):
+        return sorted(k for k, v in self.items() if v[where] > 0 and k not in ("uhdr_call", "gainmap_copy_deferred", "gainmap_image_asked_for"))
+
+    def n(self, stage, where="device"):
+        return self.get(stage, {}).get(where, 0)
+
+
 def run_app(args, gpu, cwd, timeout=600, env_extra=None):
-    """-> (returncode, stdout, stderr, stage lines of the seam trace)."""
+    """-> (returncode, stdout, stderr, Stages: where every stage of the run's accelerated calls ran).  The app is the reference's own
+    binary: the library writes its stage table to UHDR_HIP_SEAM_STATS_FILE when the process exits -- nothing is parsed off stderr."""
+    import json
+    import tempfile
+
     env = dict(os.environ)
-    env["UHDR_HIP_SEAM_TRACE"] = "1"
+    env.pop("UHDR_HIP_SEAM_TRACE", None)
+    fd, stats_path = tempfile.mkstemp(suffix=".json", dir=cwd)
+    os.close(fd)
+    env["UHDR_HIP_SEAM_STATS_FILE"] = stats_path
     env.update(env_extra or {})
     cmd = [APP] + [str(a) for a in args] + (["-u", "1"] if gpu else [])
     p = subprocess.run(cmd, cwd=cwd, env=env, capture_output=True, text=True, timeout=timeout)
-    trace = [l for l in p.stderr.splitlines() if l.startswith("uhdr_hip_seam:")]
-    return p.returncode, p.stdout, p.stderr, trace
+    try:
+        with open(stats_path) as f:
+            text = f.read()
+        stages = Stages(json.loads(text) if text.strip() else {})
+    finally:
+        os.unlink(stats_path)
+    return p.returncode, p.stdout, p.stderr, stages
 
 
 def encode_api1(p010_path, yuv_path, w, h, out, gpu, cwd, extra=(), env_extra=None):

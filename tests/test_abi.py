@@ -31,6 +31,19 @@ def test_library_exports_every_declared_symbol():
     assert lib.uhdr_hip_version().startswith(b"libuhdr_hip")
 
 
+def test_no_kernel_of_the_product_uses_scratch_memory():
+    """Round 6: experiments that spill stay out of libuhdr_hip.so (the round-5 binary carried sixteen spilling A/B instantiations)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("spill_check", os.path.join(ROOT, "tools", "spill_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ks = mod.kernels(A.LIB_PATH)
+    assert len(ks) > 100  # the metadata was really parsed
+    spill = [(k["name"], k["private_segment_fixed_size"]) for k in ks if k["private_segment_fixed_size"] > 0]
+    assert not spill, spill
+
+
 def test_struct_layouts_match_reference_abi():
     # ultrahdr_api.h:220-283 on LP64: error info 264 B, raw image 64 B, metadata 72 B
     assert C.sizeof(A.ErrorInfo) == 264

@@ -16,7 +16,7 @@ pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not F.built(), reason="facade 
 
 
 def _stages(trace, where="device"):
-    return sorted({l.split(" -> ")[0].split()[-1] for l in trace if l.endswith("-> " + where)})
+    return trace.on(where)  # tests/facade_util.Stages: the library's own stage table of that process, not stderr text
 
 
 def _fixture(d):
@@ -46,7 +46,7 @@ def test_config1_encode_through_the_facade_equals_the_cpu_reference():
         assert rc == 0, err
         st = _stages(trace)
         assert "generate_gainmap" in st and "convert_yuv" in st and "jpeg_encode_scan" in st and "fdct_planes" not in st and "encode_api1_fused" not in st, trace
-        assert len([l for l in trace if "jpeg_encode_scan -> device" in l]) == 2, trace
+        assert trace.n("jpeg_encode_scan") == 2, trace
         assert np.array_equal(a, F.read(os.path.join(d, "gpu1.jpg")))
         # the older route (device FDCT, libjpeg's Huffman pass) still gives the same file
         rc, _, err, trace = F.encode_api1(p, y, 1280, 720, "gpu2.jpg", True, d, env_extra={"UHDR_HIP_SEAM_CPU_ENTROPY": "1"})
@@ -77,7 +77,7 @@ def test_4k_encode_through_the_facade_equals_the_cpu_reference_file():
         assert np.array_equal(a, b), f"{int((a != b).sum())} differing bytes"
         rc, _, err, trace = F.encode_api1("in.p010", "in.yuv420", w, h, "gpu1.jpg", True, d, env_extra={"UHDR_HIP_SEAM_NO_FUSED_ENCODE": "1"})
         assert rc == 0, err
-        assert len([l for l in trace if "jpeg_encode_scan -> device" in l]) == 2 and "fdct_planes" not in _stages(trace), trace
+        assert trace.n("jpeg_encode_scan") == 2 and "fdct_planes" not in _stages(trace), trace
         assert np.array_equal(a, F.read(os.path.join(d, "gpu1.jpg")))
 
 
@@ -125,7 +125,7 @@ def test_4k_decode_through_the_facade_equals_the_cpu_reference():
         # (round 5): the same pixels
         rc, _, err, trace = F.decode("in.jpg", 0, 4, "gpu1.raw", True, d, env_extra={"UHDR_HIP_SEAM_NO_SCAN_STAGING": "1"})
         assert rc == 0, err
-        assert len([l for l in trace if "jpeg_decode_scan -> device" in l]) == 2, trace
+        assert trace.n("jpeg_decode_scan") == 2, trace
         assert np.array_equal(a, F.read(os.path.join(d, "gpu1.raw")))
 
 
@@ -170,8 +170,7 @@ def test_encode_with_device_entropy_coding_decodes_to_the_same_pixels(multi):
         assert rc == 0, err
         rc, _, err, trace = F.encode_api1(p, y, 1280, 720, "dev.jpg", True, d, extra=extra, env_extra={"UHDR_HIP_SEAM_RESTART_INTERVAL": "max"})
         assert rc == 0, err
-        lines = [l for l in trace if "jpeg_encode_scan -> device" in l]
-        assert len(lines) == 2 and "fdct_planes" not in _stages(trace), trace  # base image and gain map
+        assert trace.n("jpeg_encode_scan") == 2 and "fdct_planes" not in _stages(trace), trace  # base image and gain map
         a, b = F.read(os.path.join(d, "cpu.jpg")), F.read(os.path.join(d, "dev.jpg"))
         assert b.size > a.size and bytes(b[:2]) == b"\xff\xd8"
         assert bytes([0xff, 0xdd]) in b.tobytes() and bytes([0xff, 0xdd]) not in a.tobytes()[:2000]
@@ -210,8 +209,8 @@ def test_partial_block_encodes_run_on_the_device(w, h, extra, what):
         assert rc == 0, err
         rc, _, err, trace = F.encode_api1("in.p010", "in.yuv420", w, h, "gpu.jpg", True, d, extra=extra)
         assert rc == 0, err
-        assert len([l for l in trace if "jpeg_encode_scan -> device" in l]) == 2, (what, trace)
-        assert not [l for l in trace if "jpeg_encode_scan" in l and "-> device" not in l], (what, trace)
+        assert trace.n("jpeg_encode_scan") == 2, (what, trace)
+        assert trace.n("jpeg_encode_scan", "reference") == 0, (what, trace)
         a, b = F.read(os.path.join(d, "cpu.jpg")), F.read(os.path.join(d, "gpu.jpg"))
         assert a.size == b.size and np.array_equal(a, b), (what, a.size, b.size)
 
@@ -234,7 +233,7 @@ def test_sizes_with_partial_blocks_through_the_facade(w, h):
         rc, _, err, trace = F.encode_api1("in.p010", "in.yuv420", w, h, "gpu.jpg", True, d)
         assert rc == 0, err
         assert "generate_gainmap" in _stages(trace), trace
-        assert len([l for l in trace if "jpeg_encode_scan -> device" in l]) == 2, trace
+        assert trace.n("jpeg_encode_scan") == 2, trace
         a, b = F.read(os.path.join(d, "cpu.jpg")), F.read(os.path.join(d, "gpu.jpg"))
         assert np.array_equal(a, b), f"{int((a != b).sum()) if a.size == b.size else 'size'} differing bytes"
         rc, _, err, _ = F.decode("cpu.jpg", 0, 4, "cpu.raw", False, d)
@@ -256,28 +255,29 @@ def test_gainmap_image_is_downloaded_only_when_asked_for(w, h):
     import subprocess
     import sys
 
+    import json
+
     env = dict(os.environ)
-    env["UHDR_HIP_SEAM_TRACE"] = "1"
+    env.pop("UHDR_HIP_SEAM_TRACE", None)
     env["PYTHONPATH"] = F.ROOT + os.pathsep + env.get("PYTHONPATH", "")
     probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "facade_lazy_probe.py")
     p = subprocess.run([sys.executable, probe, str(w), str(h)], cwd=F.ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     results = [l for l in p.stdout.splitlines() if l.startswith("===")]
     assert len(results) == 10 and all("MATCH" in l for l in results), p.stdout
-    sections, cur = {}, None
-    for l in p.stderr.splitlines():
+    # the probe prints the library's stage table (uhdr_hip_seam_stats) of every section as one "--- name {json}" line
+    sections = {}
+    for l in p.stdout.splitlines():
         if l.startswith("--- "):
-            cur = l[4:]
-            sections[cur] = []
-        elif cur and l.startswith("uhdr_hip_seam:"):
-            sections[cur].append(l)
+            name, _, js = l[4:].partition(" {")
+            sections[name] = F.Stages(json.loads("{" + js))
     for name in ("rgb_map", "luma_map_scale4"):
         asked, not_asked, reset, sdr_out, effects = (sections[f"{name} {k}"] for k in ("asked", "not_asked", "reset", "sdr_out", "effects"))
         for sec in (asked, not_asked, reset):
-            assert len([l for l in sec if "jpeg_decode_scan -> device" in l]) == 2 * (2 if sec is reset else 1), sec
-            assert any("apply_gainmap -> device" in l for l in sec), sec
-        assert sum("copy deferred" in l for l in asked) == 1 and sum("gain-map image asked for" in l for l in asked) == 2, asked
-        assert sum("copy deferred" in l for l in not_asked) == 1 and not any("gain-map image asked for" in l for l in not_asked), not_asked
-        assert sum("copy deferred" in l for l in reset) == 2, reset
-        assert sum("copy deferred" in l for l in sdr_out) == 1 and not any("apply_gainmap" in l for l in sdr_out), sdr_out
-        assert not any("copy deferred" in l for l in effects), effects
+            assert sec.n("jpeg_decode_scan") == 2 * (2 if sec is reset else 1), sec
+            assert sec.n("apply_gainmap") >= 1, sec
+        assert asked.n("gainmap_copy_deferred") == 1 and asked.n("gainmap_image_asked_for") == 2, asked
+        assert not_asked.n("gainmap_copy_deferred") == 1 and not_asked.n("gainmap_image_asked_for") == 0, not_asked
+        assert reset.n("gainmap_copy_deferred") == 2, reset
+        assert sdr_out.n("gainmap_copy_deferred") == 1 and sdr_out.n("apply_gainmap") == 0 and sdr_out.n("apply_gainmap", "reference") == 0, sdr_out
+        assert effects.n("gainmap_copy_deferred") == 0, effects
