@@ -161,12 +161,12 @@ COMPACT_LIMIT = 4096  # bytes: the driver keeps a 16 KB tail of stdout; the roun
 
 def make_roundtrip(ctx, u, device, w, h, seed=1234):
     """One API-1 round trip on device-resident images, as two closures (bytes <-> pixels, what BASELINE.json's metric names):
-      enc(): uhdr_hip_encode_api1_fused_dev (two-pass 3-channel gain map at scale 1, convertYuv, every FDCT) + the file's two
-             scans Huffman-coded without restart markers (the reference's bytes) -> two entropy-coded scans in HBM
+      enc(): uhdr_hip_encode_api1_scans_dev -- the fused chain (two-pass 3-channel gain map at scale 1, convertYuv, every FDCT) + the
+             file's two scans Huffman-coded without restart markers (the reference's bytes) -> two entropy-coded scans in HBM
              (JpegR::encodeJPEGR API-1, jpegr.cpp:253-316, without the container's host byte shuffling);
-      dec(): the two scans Huffman-decoded + the map's dequant / IDCT / ycc->rgb + applyGainMap with the base image's dequant +
-             IDCT inside the kernel -> RGBA_F16 linear (JpegR::decodeJPEGR, jpegr.cpp:1469-1531, after parsing).
-    `two=False` codes the scans one after the other instead of concurrently."""
+      dec(): uhdr_hip_decode_api1_scans_dev -- the two scans Huffman-decoded + the map's dequant / IDCT / ycc->rgb + applyGainMap with
+             the base image's dequant + IDCT inside the kernel -> RGBA_F16 linear (JpegR::decodeJPEGR, jpegr.cpp:1469-1531, after parsing).
+    `two=False`: the round-5 form -- one C call per stage, the scans coded one after the other."""
     from libultrahdr_amd import capi as A
     from libultrahdr_amd import synth
     from libultrahdr_amd.images import Image
@@ -184,19 +184,23 @@ def make_roundtrip(ctx, u, device, w, h, seed=1234):
     out_m = torch.empty(px * 4, dtype=torch.uint8, device=device)
     box = {"keep": (sdr, hdr, out_b, out_m)}
 
+    hb = u.jpeg_header(w, h, S420, [qy, qc, qc])
+    hm = u.jpeg_header(w, h, S444, [qy, qc, qc])
+
     def enc(two=True):
+        if two:  # ONE C call: the fused chain + both scans coded concurrently (uhdr_hip_encode_api1_scans_dev)
+            box["nb"], box["nm"], box["md"] = enc1.encodeApi1Scans(sdr, hdr, A.UHDR_CG_DISPLAY_P3, (qy, qc), (qy, qc), out_b, out_m)
+            return
         cb, cm, md_, _ = enc1.encodeApi1Fused(sdr, hdr, A.UHDR_CG_DISPLAY_P3, (qy, qc), (qy, qc), want_map=False)
-        if two:  # both scans at once: the map's on the context's auxiliary stream (uhdr_hip_huffman_encode2_dev)
-            eb, em = u.huffman_encode2(cb, w, h, S420, cm, w, h, S444, 0, outs=[out_b, out_m])
-            box["nb"], box["nm"] = int(eb.numel()), int(em.numel())
-        else:
-            box["nb"] = int(u.huffman_encode(cb, w, h, S420, 0, out=out_b).numel())
-            box["nm"] = int(u.huffman_encode(cm, w, h, S444, 0, out=out_m).numel())
-        box["md"], box["shp_b"], box["shp_m"] = md_, [tuple(c.shape[:2]) for c in cb], [tuple(c.shape[:2]) for c in cm]
+        box["nb"] = int(u.huffman_encode(cb, w, h, S420, 0, out=out_b).numel())
+        box["nm"] = int(u.huffman_encode(cm, w, h, S444, 0, out=out_m).numel())
+        box["md"] = md_
 
     enc()
     ctx.synchronize()
     box["sb"], box["sm"] = out_b[: box["nb"]].clone(), out_m[: box["nm"]].clone()
+    box["shp_b"] = [(h // 8, w // 8), (h // 16, w // 16), (h // 16, w // 16)]
+    box["shp_m"] = [(h // 8, w // 8)] * 3
     gm3 = Image(rgba, w, h, A.UHDR_CG_BT_2100, align=64, device=device)
     dst = Image(f16, w, h, align=64, device=device)
     box["dst"] = dst
@@ -204,11 +208,11 @@ def make_roundtrip(ctx, u, device, w, h, seed=1234):
 
     def dec(two=True):
         sb, sm = box["sb"], box["sm"]
-        if two:  # uhdr_hip_huffman_decode2_dev
-            cb, cm = u.huffman_decode2(sb, box["shp_b"], w, h, S420, sm, box["shp_m"], w, h, S444, 0)
-        else:
-            cb = u.huffman_decode(sb, box["shp_b"], w, h, S420, 0)
-            cm = u.huffman_decode(sm, box["shp_m"], w, h, S444, 0)
+        if two:  # ONE C call: both scans decoded concurrently + the map's IDCT + applyGainMap from coefficients (uhdr_hip_decode_api1_scans_dev)
+            u.decodeApi1Scans(hb, sb, A.UHDR_CG_BT_709, hm, sm, A.UHDR_CG_BT_2100, box["md"], A.UHDR_CT_LINEAR, f16, A.FLT_MAX, dst)
+            return
+        cb = u.huffman_decode(sb, box["shp_b"], w, h, S420, 0)
+        cm = u.huffman_decode(sm, box["shp_m"], w, h, S444, 0)
         u.idct_dequant_rgb(cm, qy, qc, w, h, rgba, 0, dst=gm3)
         u.applyGainMapFromCoefficients(cb, qts, w, h, A.UHDR_CG_BT_709, gm3, box["md"], A.UHDR_CT_LINEAR, f16, A.FLT_MAX, dst)
 

@@ -684,6 +684,30 @@ uhdr_error_info_t uhdr_hip_encode_api1_scans(uhdr_hip_ctx_t* ctx, const uhdr_raw
                                              uint8_t* base_scan, size_t base_capacity, size_t* base_bytes,
                                              uint8_t* map_scan, size_t map_capacity, size_t* map_bytes);
 
+/* The same on DEVICE-resident intents into DEVICE buffers, and its inverse (round 6): one entry point per direction of the API-1
+ * round trip, for callers whose images live in HBM (a transcoding service; bench.py's headline).
+ * uhdr_hip_encode_api1_scans_dev: JpegR::encodeJPEGR API-1 (jpegr.cpp:253-316) without the container -- sdr / hdr are device images,
+ * base_scan / map_scan device buffers; everything else as uhdr_hip_encode_api1_scans.  Synchronous (the byte counts come back).
+ * uhdr_hip_decode_api1_scans_dev: JpegR::decodeJPEGR behind its container parsing (jpegr.cpp:1469-1531) -- the two JPEG streams'
+ * headers (uhdr_hip_jpeg_parse, or filled by the caller: scan geometry, DQT, DHT -- all zeros selects the Annex K tables; scan.coef is ignored) and their entropy-coded
+ * bytes in device memory (between the SOS header and the marker that ends them) -> both scans entropy-decoded concurrently ->
+ * the gain map's dequant + IDCT (+ ycc -> rgb, alpha 255, for a three-channel map) -> applyGainMap (base image's dequant + IDCT inside
+ * the kernel) -> dest (device image).  base: a 4:2:0 three-component scan; map: one component, or three at 4:4:4.  base_cg / map_cg:
+ * what the decoded images' uhdr_raw_image_t::cg would carry (the ICC profile's gamut; the gain map's from the metadata's use_base_cg
+ * logic upstream); libjpeg_variant: the ycc -> rgb constants of a three-channel map, as for uhdr_hip_jpeg_ycc_to_rgb (0: libjpeg-turbo, which
+ * the reference pins).  The entropy stage is synchronous; the two sample-domain launches behind it are only enqueued. */
+uhdr_error_info_t uhdr_hip_encode_api1_scans_dev(uhdr_hip_ctx_t* ctx, const uhdr_raw_image_t* sdr, const uhdr_raw_image_t* hdr,
+                                                 const uhdr_hip_encode_cfg_t* cfg, uhdr_color_gamut_t base_encoding,
+                                                 const uint16_t qt_base[2][64], const uint16_t qt_map[2][64],
+                                                 uhdr_gainmap_metadata_t* md, uhdr_raw_image_t* gainmap_desc,
+                                                 uint8_t* base_scan, size_t base_capacity, size_t* base_bytes,
+                                                 uint8_t* map_scan, size_t map_capacity, size_t* map_bytes);
+uhdr_error_info_t uhdr_hip_decode_api1_scans_dev(uhdr_hip_ctx_t* ctx, const uhdr_hip_jpeg_header_t* base, const uint8_t* base_data,
+                                                 size_t base_bytes, uhdr_color_gamut_t base_cg, const uhdr_hip_jpeg_header_t* map,
+                                                 const uint8_t* map_data, size_t map_bytes, uhdr_color_gamut_t map_cg,
+                                                 int libjpeg_variant, const uhdr_gainmap_metadata_t* md, uhdr_color_transfer_t output_ct,
+                                                 uhdr_img_fmt_t output_format, float max_display_boost, uhdr_raw_image_t* dest);
+
 /* ---- which route did the entropy stage take? ---------------------------------------------------------------------
  * Counters of the context since its creation.  A scan the device declines (entropy_decode_declined: a marker-less stream so
  * dense that the parallel decoder does not settle, or Huffman tables outside its two-level form) is returned to the caller

@@ -621,6 +621,7 @@ void uhdr_hip_destroy(uhdr_hip_ctx_t* c) {
   for (float* q : c->d_lin10) if (q) (void)hipFree(q);
   for (auto& g : c->gain_tabs) if (g.d) (void)hipFree(g.d);
   uhdr_hip_comm_destroy(c);
+  aux_worker_destroy(c);
   if (c->aux) uhdr_hip_destroy(c->aux);
   if (c->exchange.p) (void)hipFree(c->exchange.p);
   if (c->affine.p) (void)hipFree(c->affine.p);

@@ -1,6 +1,10 @@
 // api_entropy.cpp -- baseline Huffman coding of coefficient blocks behind the C ABI (see api_internal.h).
 #include "api_internal.h"
 
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+
 // -------------------------------------------------------------------------------------------------
 // JPEG entropy stage: baseline Huffman coding of coefficient blocks, one restart interval per wavefront
 // -------------------------------------------------------------------------------------------------
@@ -258,6 +262,84 @@ static void make_value_table(const HuffFastTable& f, bool is_dc, uint32_t* out /
     for (int i = 0; i < 128; i++) out[512 + s * 128 + i] = conv(f.l2[s][i], false);
 }
 
+// The pair form of a tracking table (uhdr_types.h: kHuffPairBits; huffman_decode_sync.hip: track_span_pair).  f / t: the table in
+// symbol and in tracking form; t_ac: the AC table of the same component in tracking form, f_ac in symbol form -- the table the symbol AFTER
+// a DC or AC symbol of this table is read with, as long as the block does not end (the kernel checks that, and that the
+// subsequence does not end, before it takes the second symbol).  A second symbol is entered only when its CODE lies wholly inside
+// the index bits that the first symbol leaves (a prefix code: the bits beyond cannot change which code it is).
+static void make_pair_table(const HuffFastTable& f, const HuffFastTable& t, const HuffFastTable& f_ac, const HuffFastTable& t_ac, uint32_t* out /* kHuffPairWords */) {
+  constexpr int B = kHuffPairBits;
+  for (int idx = 0; idx < kHuffPairWords; idx++) {
+    const int p9 = idx >> (B - 9);
+    const uint16_t e = f.l1[p9];
+    uint32_t first;  // tracking form of the first symbol: bits | advance << 5
+    bool defined;
+    if (e & 0x8000u) {
+      const int sub = e & 31, rest = (idx & ((1 << (B - 9)) - 1)) << (16 - B);  // the index bits beyond the ninth, as the top bits of the 7-bit remainder
+      const uint16_t e2 = f.l2[sub][rest];
+      if (e2 == 0 || (int)((e2 >> 8) & 31u) > B) {  // not decided by the index bits
+        out[idx] = 0x80000000u | (uint32_t)sub;
+        continue;
+      }
+      first = t.l2[sub][rest];
+      defined = true;
+    } else {
+      first = t.l1[p9];
+      defined = e != 0;
+    }
+    uint32_t word = first & 0xfffu;
+    const int adv1 = (int)(first & 31u), kinc1 = (int)((first >> 5) & 127u);
+    if (defined && kinc1 < 64 && adv1 < B) {
+      const int r = B - adv1;  // index bits left for the second code
+      const int next9 = ((idx << adv1) & (kHuffPairWords - 1)) >> (B - 9);
+      const uint16_t n = f_ac.l1[next9];
+      if (n != 0 && !(n & 0x8000u) && (int)((n >> 8) & 31u) <= r) {
+        const uint32_t second = t_ac.l1[next9];
+        word |= (second & 31u) << 12 | ((second >> 5) & 127u) << 17;
+      }
+    }
+    out[idx] = word;
+  }
+}
+
+// ... and the pair form of the VALUE tables (write form 2, huffman_decode_sync.hip: write_span2): two words per index, the first symbol
+// and the AC symbol behind it (0: none), each in make_value_table's form.  v / v_ac: the value forms (kHuffValWords words: first
+// level, then the sub-tables).  A first symbol that is malformed, or whose code is longer than the index, is marked 0x80000000 | sub-table
+// (its first-level word when the code has no sub-table: the kernel then reads the one-symbol entry the slow way).
+static void make_pair_value_table(const HuffFastTable& f, const uint32_t* v, const HuffFastTable& f_ac, const uint32_t* v_ac, uint32_t* out /* 2 x kHuffPairWords */) {
+  constexpr int B = kHuffPairBits;
+  for (int idx = 0; idx < kHuffPairWords; idx++) {
+    const int p9 = idx >> (B - 9);
+    const uint16_t e = f.l1[p9];
+    uint32_t first;
+    bool defined;
+    if (e & 0x8000u) {
+      const int sub = e & 31, rest = (idx & ((1 << (B - 9)) - 1)) << (16 - B);
+      const uint16_t e2 = f.l2[sub][rest];
+      if (e2 == 0 || (int)((e2 >> 8) & 31u) > B) {
+        out[2 * idx] = 0x80000000u | (uint32_t)sub;
+        out[2 * idx + 1] = 0;
+        continue;
+      }
+      first = v[512 + sub * 128 + rest];
+      defined = true;
+    } else {
+      first = v[p9];
+      defined = e != 0;
+    }
+    uint32_t second = 0;
+    const int adv1 = (int)(first & 31u), kinc1 = (int)((first >> 5) & 127u);
+    if (defined && !((first >> 16) & 1u) && kinc1 < 64 && adv1 < B) {
+      const int r = B - adv1;
+      const int next9 = ((idx << adv1) & (kHuffPairWords - 1)) >> (B - 9);
+      const uint16_t n = f_ac.l1[next9];
+      if (n != 0 && !(n & 0x8000u) && (int)((n >> 8) & 31u) <= r) second = v_ac[next9];
+    }
+    out[2 * idx] = first;
+    out[2 * idx + 1] = second;
+  }
+}
+
 uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_jpeg_scan_t* sc, const uhdr_hip_huff_tables_t* tables,
                                               const uint8_t* data, size_t data_bytes) {
   if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
@@ -277,7 +359,8 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
   const DbgClock dbg;
   // the five decode forms of the file's tables, resident on the device (huff_tabs: rebuilt only when the DHT bytes change)
   constexpr size_t kTabDec = 0, kTabFast = (sizeof(HuffDecTable) * 4 + 255) & ~(size_t)255,
-                   kTabVal = (kTabFast + sizeof(HuffFastTable) * 8 + 255) & ~(size_t)255, kTabBytes = kTabVal + (size_t)4 * kHuffValWords * 4;
+                   kTabVal = (kTabFast + sizeof(HuffFastTable) * 8 + 255) & ~(size_t)255, kTabPair = kTabVal + (size_t)4 * kHuffValWords * 4,
+                   kTabPairVal = kTabPair + (size_t)kHuffPairBlobWords * 4, kTabBytes = kTabPairVal + (size_t)kHuffPairValBlobWords * 4;
   {
     uint8_t key[4 * (17 + 256)];
     for (int t = 0; t < 4; t++) {
@@ -296,7 +379,7 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
       hc.valid = false;
       std::vector<HuffDecTable> tabs(4);
       std::vector<HuffFastTable> ftabs(8);
-      std::vector<uint32_t> vtabs((size_t)4 * kHuffValWords);
+      std::vector<uint32_t> vtabs((size_t)4 * kHuffValWords), ptabs((size_t)kHuffPairBlobWords), pvtabs((size_t)kHuffPairValBlobWords);
       bool fast_ok = true;
       for (int t = 0; t < 4; t++) {
         const uint8_t* bits = key + (size_t)t * (17 + 256);
@@ -308,11 +391,28 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
           make_track_table(ftabs[(size_t)t], (t & 1) == 0, &ftabs[(size_t)t + 4]);
           make_value_table(ftabs[(size_t)t], (t & 1) == 0, vtabs.data() + (size_t)t * kHuffValWords);
         }
+      if (fast_ok)
+        for (int t = 0; t < 4; t++)  // (after the loop above: the AC tables' tracking forms exist)
+        {
+          make_pair_table(ftabs[(size_t)t], ftabs[(size_t)t + 4], ftabs[(size_t)(t | 1)], ftabs[(size_t)(t | 1) + 4], ptabs.data() + (size_t)t * kHuffPairWords);
+          make_pair_value_table(ftabs[(size_t)t], vtabs.data() + (size_t)t * kHuffValWords, ftabs[(size_t)(t | 1)], vtabs.data() + (size_t)(t | 1) * kHuffValWords,
+                                pvtabs.data() + (size_t)t * 2 * kHuffPairWords);
+          // the second levels behind them, 16 bits per entry (the kernels' LDS structs are copies of these blobs)
+          uint16_t* l2t = (uint16_t*)(ptabs.data() + (size_t)4 * kHuffPairWords) + (size_t)t * kHuffL2Max * 128;
+          uint16_t* l2v = (uint16_t*)(pvtabs.data() + (size_t)8 * kHuffPairWords) + (size_t)t * kHuffL2Max * 128;
+          for (int i = 0; i < kHuffL2Max * 128; i++) {
+            l2t[i] = ftabs[(size_t)t + 4].l2[i / 128][i % 128];
+            const uint32_t v = vtabs[(size_t)t * kHuffValWords + 512 + (size_t)i];
+            l2v[i] = (uint16_t)(((v >> 16) & 1u) ? 0u : (v & 0xffffu));
+          }
+        }
       UHDR_TRY(ensure(hc.dev, kTabBytes));
       HIP_TRY(hipStreamSynchronize(c->stream));  // nothing in flight reads the old tables
       HIP_TRY(hipMemcpy((uint8_t*)hc.dev.p + kTabDec, tabs.data(), sizeof(HuffDecTable) * 4, hipMemcpyHostToDevice));
       HIP_TRY(hipMemcpy((uint8_t*)hc.dev.p + kTabFast, ftabs.data(), sizeof(HuffFastTable) * 8, hipMemcpyHostToDevice));
       HIP_TRY(hipMemcpy((uint8_t*)hc.dev.p + kTabVal, vtabs.data(), vtabs.size() * 4, hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy((uint8_t*)hc.dev.p + kTabPair, ptabs.data(), ptabs.size() * 4, hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy((uint8_t*)hc.dev.p + kTabPairVal, pvtabs.data(), pvtabs.size() * 4, hipMemcpyHostToDevice));
       memcpy(hc.key, key, sizeof key);
       hc.fast_ok = fast_ok;
       hc.valid = true;
@@ -473,6 +573,8 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
     y.ftabs = (const HuffFastTable*)(tabs_dev + kTabFast);
     y.ttabs = y.ftabs + 4;
     y.vtabs = (const uint32_t*)(tabs_dev + kTabVal);
+    y.ptabs = (const uint32_t*)(tabs_dev + kTabPair);
+    y.pvtabs = (const uint32_t*)(tabs_dev + kTabPairVal);
     y.zigzag = a.zigzag;
     (void)o_ft; (void)o_vt;
     if (use_hyp) {
@@ -640,6 +742,76 @@ void aux_merge(uhdr_hip_ctx* c) {  // what the second scan counted and timed bel
 }
 }  // namespace
 
+// The auxiliary context's thread (round 6).  One job at a time: run(job) hands it over and returns, wait() blocks until it is done.
+struct AuxWorker {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::function<void()> job;
+  bool has = false, quit = false;
+  AuxWorker() {
+    th = std::thread([this] {
+      std::unique_lock<std::mutex> lk(mu);
+      for (;;) {
+        cv.wait(lk, [this] { return has || quit; });
+        if (quit) return;
+        std::function<void()> j = std::move(job);
+        lk.unlock();
+        j();
+        lk.lock();
+        has = false;
+        cv.notify_all();
+      }
+    });
+  }
+  void run(std::function<void()> j) {
+    std::lock_guard<std::mutex> lk(mu);
+    job = std::move(j);
+    has = true;
+    cv.notify_all();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [this] { return !has; });
+  }
+  ~AuxWorker() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      quit = true;
+      cv.notify_all();
+    }
+    if (th.joinable()) th.join();
+  }
+};
+void aux_worker_destroy(uhdr_hip_ctx* c) {
+  if (c && c->aux_worker) {
+    delete c->aux_worker;
+    c->aux_worker = nullptr;
+  }
+}
+namespace {
+// job_b on the context's worker thread while job_a runs on the caller's; without a thread to be had: one after the other (still on two streams)
+template <typename FA, typename FB>
+void run_pair(uhdr_hip_ctx* c, FA&& job_a, FB&& job_b) {
+  static const bool no_thread = getenv("UHDR_HIP_NO_AUX_THREAD") != nullptr;
+  if (!c->aux_worker && !no_thread) {
+    try {
+      c->aux_worker = new AuxWorker();
+    } catch (...) {
+      c->aux_worker = nullptr;
+    }
+  }
+  if (c->aux_worker) {
+    c->aux_worker->run(job_b);
+    job_a();
+    c->aux_worker->wait();
+  } else {
+    job_a();
+    job_b();
+  }
+}
+}  // namespace
+
 uhdr_error_info_t uhdr_hip_huffman_encode2_dev(uhdr_hip_ctx_t* c, const uhdr_hip_jpeg_scan_t* scan_a, uint8_t* out_a, size_t cap_a, size_t* bytes_a,
                                                const uhdr_hip_jpeg_scan_t* scan_b, uint8_t* out_b, size_t cap_b, size_t* bytes_b) {
   if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
@@ -647,16 +819,10 @@ uhdr_error_info_t uhdr_hip_huffman_encode2_dev(uhdr_hip_ctx_t* c, const uhdr_hip
   uhdr_hip_ctx* x = nullptr;
   UHDR_TRY(aux_context(c, &x));
   HIP_TRY(hipStreamSynchronize(c->stream));  // the coefficients both scans read were produced on this stream
-  uhdr_error_info_t rb = ok_status();
-  auto job_b = [&] { rb = uhdr_hip_huffman_encode_dev(x, scan_b, out_b, cap_b, bytes_b); };
-  std::thread second;
-  try {
-    second = std::thread(job_b);
-  } catch (...) {  // no thread to be had: one scan after the other, still on two streams
-  }
-  const uhdr_error_info_t ra = uhdr_hip_huffman_encode_dev(c, scan_a, out_a, cap_a, bytes_a);
-  if (second.joinable()) second.join();
-  else job_b();
+  uhdr_error_info_t ra = ok_status(), rb = ok_status();
+  const int dev = c->device;
+  run_pair(c, [&] { ra = uhdr_hip_huffman_encode_dev(c, scan_a, out_a, cap_a, bytes_a); },
+           [&, dev] { (void)hipSetDevice(dev); rb = uhdr_hip_huffman_encode_dev(x, scan_b, out_b, cap_b, bytes_b); });
   aux_merge(c);
   return ra.error_code != UHDR_CODEC_OK ? ra : rb;
 }
@@ -669,16 +835,10 @@ uhdr_error_info_t uhdr_hip_huffman_decode2_dev(uhdr_hip_ctx_t* c, const uhdr_hip
   uhdr_hip_ctx* x = nullptr;
   UHDR_TRY(aux_context(c, &x));
   HIP_TRY(hipStreamSynchronize(c->stream));  // the bytes of both scans may have come up on this stream
-  uhdr_error_info_t rb = ok_status();
-  auto job_b = [&] { rb = uhdr_hip_huffman_decode_dev(x, scan_b, tables_b, data_b, bytes_b); };
-  std::thread second;
-  try {
-    second = std::thread(job_b);
-  } catch (...) {
-  }
-  const uhdr_error_info_t ra = uhdr_hip_huffman_decode_dev(c, scan_a, tables_a, data_a, bytes_a);
-  if (second.joinable()) second.join();
-  else job_b();
+  uhdr_error_info_t ra = ok_status(), rb = ok_status();
+  const int dev = c->device;
+  run_pair(c, [&] { ra = uhdr_hip_huffman_decode_dev(c, scan_a, tables_a, data_a, bytes_a); },
+           [&, dev] { (void)hipSetDevice(dev); rb = uhdr_hip_huffman_decode_dev(x, scan_b, tables_b, data_b, bytes_b); });
   aux_merge(c);
   return ra.error_code != UHDR_CODEC_OK ? ra : rb;
 }

@@ -118,6 +118,9 @@ struct uhdr_hip_ctx {
   // code the TWO scans of an UltraHDR file concurrently (uhdr_hip_huffman_encode2_dev / _decode2_dev): the entropy stages are
   // latency- and occupancy-bound for long stretches (one-workgroup scans, the write pass, the stragglers), which two streams overlap
   uhdr_hip_ctx* aux = nullptr;
+  // round 6: the thread that drives the auxiliary context, kept for the life of the context (a std::thread per call cost 40-60 us of
+  // an 800 us round trip: creation, first scheduling, join); see AuxWorker in api_entropy.cpp
+  struct AuxWorker* aux_worker = nullptr;
   DeviceBuf jpg[6];  // uhdr_hip_jpeg_decode_scan: entropy-coded data | coefficient arrays x 3 | decoded planes / pixels
   // uhdr_hip_resident_begin .. _end: the images uhdr_hip_jpeg_decode_scan wrote to the caller's buffers stay on the device,
   // keyed by those host pointers, so that the host variant of uhdr_hip_apply_gainmap does not upload them again
@@ -267,5 +270,7 @@ uhdr_error_info_t comm_all_reduce_min(uhdr_hip_ctx* c, float* buf, size_t n);
 uhdr_error_info_t check_scan(const uhdr_hip_jpeg_scan_t* sc, bool need_coef, int* mcus_per_row, int* mcu_rows, int* blocks_per_mcu);
 }  // namespace uhdr_api
 using namespace uhdr_api;
+
+void aux_worker_destroy(uhdr_hip_ctx* c);  // api_entropy.cpp: stops and joins the context's worker thread
 
 #endif  // UHDR_HIP_API_INTERNAL_H

@@ -337,7 +337,16 @@ uhdr_error_info_t uhdr_hip_encode_api1_fused_dev(uhdr_hip_ctx_t* c, const uhdr_r
 static uhdr_error_info_t encode_api1_scans_impl(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* sdr, const uhdr_raw_image_t* hdr, const uhdr_hip_encode_cfg_t* cfg,
                                                 uhdr_color_gamut_t base_encoding, const uint16_t qt_base[2][64], const uint16_t qt_map[2][64],
                                                 uhdr_gainmap_metadata_t* md, uhdr_raw_image_t* gainmap_desc, uint8_t* base_scan, size_t base_capacity,
-                                                size_t* base_bytes, uint8_t* map_scan, size_t map_capacity, size_t* map_bytes);
+                                                size_t* base_bytes, uint8_t* map_scan, size_t map_capacity, size_t* map_bytes, bool dev = false);
+// ... and on DEVICE-resident intents, into DEVICE buffers (round 6): one call per direction of the round trip, so that no binding
+// layer sits between the stages (a Python caller's 30-100 us between two entry points were a third of a 4K round trip)
+uhdr_error_info_t uhdr_hip_encode_api1_scans_dev(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* sdr, const uhdr_raw_image_t* hdr, const uhdr_hip_encode_cfg_t* cfg,
+                                                 uhdr_color_gamut_t base_encoding, const uint16_t qt_base[2][64], const uint16_t qt_map[2][64],
+                                                 uhdr_gainmap_metadata_t* md, uhdr_raw_image_t* gainmap_desc, uint8_t* base_scan, size_t base_capacity,
+                                                 size_t* base_bytes, uint8_t* map_scan, size_t map_capacity, size_t* map_bytes) {
+  return encode_api1_scans_impl(c, sdr, hdr, cfg, base_encoding, qt_base, qt_map, md, gainmap_desc, base_scan, base_capacity, base_bytes, map_scan, map_capacity,
+                                map_bytes, true);
+}
 uhdr_error_info_t uhdr_hip_encode_api1_scans(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* sdr, const uhdr_raw_image_t* hdr, const uhdr_hip_encode_cfg_t* cfg,
                                              uhdr_color_gamut_t base_encoding, const uint16_t qt_base[2][64], const uint16_t qt_map[2][64],
                                              uhdr_gainmap_metadata_t* md, uhdr_raw_image_t* gainmap_desc, uint8_t* base_scan, size_t base_capacity,
@@ -351,7 +360,7 @@ uhdr_error_info_t uhdr_hip_encode_api1_scans(uhdr_hip_ctx_t* c, const uhdr_raw_i
 static uhdr_error_info_t encode_api1_scans_impl(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* sdr, const uhdr_raw_image_t* hdr, const uhdr_hip_encode_cfg_t* cfg,
                                                 uhdr_color_gamut_t base_encoding, const uint16_t qt_base[2][64], const uint16_t qt_map[2][64],
                                                 uhdr_gainmap_metadata_t* md, uhdr_raw_image_t* gainmap_desc, uint8_t* base_scan, size_t base_capacity,
-                                                size_t* base_bytes, uint8_t* map_scan, size_t map_capacity, size_t* map_bytes) {
+                                                size_t* base_bytes, uint8_t* map_scan, size_t map_capacity, size_t* map_bytes, bool dev) {
   if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
   if (!sdr || !hdr || !cfg || !qt_base || !qt_map || !md || !base_scan || !map_scan || !base_bytes || !map_bytes)
     return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument");
@@ -373,9 +382,14 @@ static uhdr_error_info_t encode_api1_scans_impl(uhdr_hip_ctx_t* c, const uhdr_ra
   const unsigned w = sdr->w, h = sdr->h, mw = w / (unsigned)scale, mh = h / (unsigned)scale;
   const int nch = cfg->use_multi_channel_gainmap ? 3 : 1;
   uhdr_raw_image_t ds, dh;
-  if (c->resident_on) UHDR_TRY(resident_write_back_all(c));
-  UHDR_TRY(stage_in(c, 0, sdr, &ds, true));
-  UHDR_TRY(stage_in(c, 1, hdr, &dh, true));
+  if (dev) {
+    ds = *sdr;
+    dh = *hdr;
+  } else {
+    if (c->resident_on) UHDR_TRY(resident_write_back_all(c));
+    UHDR_TRY(stage_in(c, 0, sdr, &ds, true));
+    UHDR_TRY(stage_in(c, 1, hdr, &dh, true));
+  }
   // coefficient arrays: base Y, Cb, Cr, then the map's 1 or 3 components; 256-byte aligned
   const size_t nb[3] = {(size_t)(w / 8) * (h / 8), (size_t)(w / 16) * (h / 16), (size_t)(w / 16) * (h / 16)};
   const size_t nm = (size_t)(mw / 8) * (mh / 8);
@@ -417,9 +431,15 @@ static uhdr_error_info_t encode_api1_scans_impl(uhdr_hip_ctx_t* c, const uhdr_ra
   }
   if (base_capacity > 0xFFFFFFF0u) base_capacity = 0xFFFFFFF0u;
   if (map_capacity > 0xFFFFFFF0u) map_capacity = 0xFFFFFFF0u;
+  size_t nbs = 0, nms = 0;
+  if (dev) {  // straight into the caller's device buffers
+    const uhdr_error_info_t e2 = uhdr_hip_huffman_encode2_dev(c, &sb, base_scan, base_capacity, &nbs, &sm, map_scan, map_capacity, &nms);
+    *base_bytes = nbs;
+    *map_bytes = nms;
+    return e2;
+  }
   UHDR_TRY(ensure(c->enc[1], base_capacity + 64));
   UHDR_TRY(ensure(c->enc[2], map_capacity + 64));
-  size_t nbs = 0, nms = 0;
   // both scans at once (round 5): the base image on this context's stream, the map on the auxiliary one
   const uhdr_error_info_t e2 = uhdr_hip_huffman_encode2_dev(c, &sb, (uint8_t*)c->enc[1].p, base_capacity, &nbs, &sm, (uint8_t*)c->enc[2].p, map_capacity, &nms);
   *base_bytes = nbs;
@@ -883,6 +903,106 @@ static uhdr_error_info_t jpeg_decode_scan_impl(uhdr_hip_ctx_t* c, const uhdr_hip
   if (!lazy) HIP_TRY(hipStreamSynchronize(c->stream));
   dbg.mark("jpeg_decode_scan: done");
   return ok_status();
+}
+
+// JpegR::decodeJPEGR behind its container parsing (jpegr.cpp:1469-1531) on DEVICE-resident data in ONE entry point (round 6): the two
+// JPEG streams' parsed headers + their entropy-coded bytes in HBM -> [both scans entropy-decoded concurrently] -> the gain map's
+// dequant + IDCT (+ ycc -> rgb for a three-channel map) -> applyGainMap with the base image's dequant + IDCT inside the kernel -> dest.
+// Only enqueues the two sample-domain launches after the (synchronous) entropy stage: dest is ready in stream order.
+uhdr_error_info_t uhdr_hip_decode_api1_scans_dev(uhdr_hip_ctx_t* c, const uhdr_hip_jpeg_header_t* base, const uint8_t* base_data, size_t base_bytes,
+                                                 uhdr_color_gamut_t base_cg, const uhdr_hip_jpeg_header_t* map, const uint8_t* map_data, size_t map_bytes,
+                                                 uhdr_color_gamut_t map_cg, int libjpeg_variant, const uhdr_gainmap_metadata_t* md,
+                                                 uhdr_color_transfer_t output_ct, uhdr_img_fmt_t output_format, float max_display_boost,
+                                                 uhdr_raw_image_t* dest) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  if (!base || !base_data || !map || !map_data || !md || !dest) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument for decode_api1_scans");
+  if (libjpeg_variant != 0 && libjpeg_variant != 1) return err_status(UHDR_CODEC_INVALID_PARAM, "unknown libjpeg variant %d", libjpeg_variant);
+  uhdr_hip_jpeg_scan_t sb = base->scan, sm = map->scan;
+  int mpr = 0, mrows = 0, bpm = 0;
+  UHDR_TRY(check_scan(&sb, false, &mpr, &mrows, &bpm));
+  if (sb.num_components != 3 || sb.h_samp[0] != 2 || sb.v_samp[0] != 2 || sb.h_samp[1] != 1 || sb.v_samp[1] != 1 || sb.h_samp[2] != 1 || sb.v_samp[2] != 1)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "decode_api1_scans takes a 4:2:0 base image (the form JpegR writes); decode the scans with uhdr_hip_jpeg_decode_scan");
+  UHDR_TRY(check_scan(&sm, false, &mpr, &mrows, &bpm));
+  const int nm = sm.num_components;
+  if (nm == 3 && (bpm != 3 || memcmp(map->qtable[1], map->qtable[2], sizeof map->qtable[1])))
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "a three-channel gain map is a 4:4:4 scan with one chroma quantization table here");
+  if (base_bytes == 0 || map_bytes == 0 || base_bytes > 0xFFFFFFF0ull || map_bytes > 0xFFFFFFF0ull) return err_status(UHDR_CODEC_INVALID_PARAM, "received no (or too much) entropy-coded data");
+  HIP_TRY(hipSetDevice(c->device));
+  // coefficient arrays: the base image's in jpg[1..3], the map's behind one another in enc[0]
+  for (int i = 0; i < 3; i++) {
+    UHDR_TRY(ensure(c->jpg[1 + i], (size_t)sb.blocks_w[i] * sb.blocks_h[i] * 128));
+    sb.coef[i] = (const int16_t*)c->jpg[1 + i].p;
+  }
+  size_t off = 0, o_map[3] = {0, 0, 0};
+  for (int i = 0; i < nm; i++) { o_map[i] = off; off += ((size_t)sm.blocks_w[i] * sm.blocks_h[i] * 128 + 255) & ~(size_t)255; }
+  UHDR_TRY(ensure(c->enc[0], off));
+  for (int i = 0; i < nm; i++) sm.coef[i] = (const int16_t*)((const uint8_t*)c->enc[0].p + o_map[i]);
+  c->huff_serial_ok = false;  // a scan the parallel decoder declines goes back to the caller (UNSUPPORTED_FEATURE), not to one lane
+  auto tables_of = [](const uhdr_hip_jpeg_header_t* h) -> const uhdr_hip_huff_tables_t* {  // an all-zero DHT block: the Annex K tables
+    for (int t = 0; t < 4; t++)
+      for (int l = 0; l < 17; l++)
+        if (h->tables.bits[t][l]) return &h->tables;
+    return nullptr;
+  };
+  const uhdr_error_info_t hs = uhdr_hip_huffman_decode2_dev(c, &sb, tables_of(base), base_data, base_bytes, &sm, tables_of(map), map_data, map_bytes);
+  c->huff_serial_ok = true;
+  if (hs.error_code != UHDR_CODEC_OK) return hs;
+  // the decoded gain-map image, device resident
+  uhdr_raw_image_t gm;
+  memset(&gm, 0, sizeof gm);
+  gm.cg = map_cg;
+  gm.ct = UHDR_CT_UNSPECIFIED;
+  gm.range = UHDR_CR_FULL_RANGE;
+  gm.w = sm.w;
+  gm.h = sm.h;
+  const size_t pitch_px = ((size_t)sm.w + 63) & ~(size_t)63;
+  if (nm == 3) {
+    gm.fmt = UHDR_IMG_FMT_32bppRGBA8888;
+    UHDR_TRY(ensure(c->jpg[4], pitch_px * 4 * sm.h));
+    gm.planes[0] = c->jpg[4].p;
+    gm.stride[0] = (unsigned int)pitch_px;
+    UHDR_TRY(uhdr_hip_idct_dequant_rgb_dev(c, sm.coef[0], sm.coef[1], sm.coef[2], sm.blocks_w[0], sm.blocks_h[0], map->qtable[0], map->qtable[1], libjpeg_variant, &gm));
+  } else {
+    gm.fmt = UHDR_IMG_FMT_8bppYCbCr400;
+    const size_t pitch = ((size_t)sm.blocks_w[0] * 8 + 63) & ~(size_t)63;
+    UHDR_TRY(ensure(c->jpg[4], pitch * (size_t)sm.blocks_h[0] * 8));
+    gm.planes[0] = c->jpg[4].p;
+    gm.stride[0] = (unsigned int)pitch;
+    UHDR_TRY(uhdr_hip_idct_dequant_dev(c, sm.coef[0], sm.blocks_w[0], sm.blocks_h[0], map->qtable[0], (uint8_t*)c->jpg[4].p, pitch));
+  }
+  uhdr_hip_jpeg_coefficients_t bc;
+  memset(&bc, 0, sizeof bc);
+  for (int i = 0; i < 3; i++) {
+    bc.coef[i] = sb.coef[i];
+    bc.blocks_w[i] = sb.blocks_w[i];
+    bc.blocks_h[i] = sb.blocks_h[i];
+    memcpy(bc.qtable[i], base->qtable[i], sizeof bc.qtable[i]);
+  }
+  uhdr_error_info_t ap = uhdr_hip_apply_gainmap_coef_dev(c, &bc, sb.w, sb.h, base_cg, &gm, md, output_ct, output_format, max_display_boost, dest);
+  if (ap.error_code != UHDR_CODEC_UNSUPPORTED_FEATURE) return ap;
+  // a geometry the coefficient-input kernel does not take: the planes after all (three IDCT launches), then the operator
+  size_t ppitch[3], poff[3], total = 0;
+  for (int i = 0; i < 3; i++) {
+    ppitch[i] = ((size_t)sb.blocks_w[i] * 8 + 63) & ~(size_t)63;
+    poff[i] = total;
+    total += ppitch[i] * (size_t)sb.blocks_h[i] * 8;
+  }
+  UHDR_TRY(ensure(c->jpg[0], total));
+  uhdr_raw_image_t bi;
+  memset(&bi, 0, sizeof bi);
+  bi.fmt = UHDR_IMG_FMT_12bppYCbCr420;
+  bi.cg = base_cg;
+  bi.ct = UHDR_CT_SRGB;
+  bi.range = UHDR_CR_FULL_RANGE;
+  bi.w = sb.w;
+  bi.h = sb.h;
+  for (int i = 0; i < 3; i++) {
+    uint8_t* d = (uint8_t*)c->jpg[0].p + poff[i];
+    UHDR_TRY(uhdr_hip_idct_dequant_dev(c, sb.coef[i], sb.blocks_w[i], sb.blocks_h[i], base->qtable[i], d, ppitch[i]));
+    bi.planes[i] = d;
+    bi.stride[i] = (unsigned int)ppitch[i];
+  }
+  return uhdr_hip_apply_gainmap_dev(c, &bi, &gm, md, output_ct, output_format, max_display_boost, dest, 0, 0);
 }
 
 // Host helper: a complete baseline JFIF file around entropy-coded data (marker order of jcmarker.c: SOI, APP0, DQT,

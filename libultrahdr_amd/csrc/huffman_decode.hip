@@ -14,6 +14,7 @@
 //      restart interval) raises a status flag: UHDR_CODEC_INVALID_PARAM at the API.
 // Tables are whatever the file's DHT segments hold (built on the host from BITS / HUFFVAL, T.81 Annex C / F.2.2.3).
 // A stream without restart markers is one interval: correct, but decoded by a single lane.
+#include "lds_copy.h"
 #include "uhdr_types.h"
 
 namespace uhdr {
@@ -138,12 +139,11 @@ __device__ __forceinline__ int receive_extend(BitReader& r, int s) {  // jdhuff.
 }
 
 __global__ __launch_bounds__(64) void huff_decode_kernel(const HuffDecArgs a) {
-  __shared__ HuffDecTable s_t[4];
+  __shared__ __attribute__((aligned(16))) HuffDecTable s_t[4];
   __shared__ uint8_t s_zz[64];
   {
-    const uint32_t* src = (const uint32_t*)a.tabs;
-    uint32_t* dst = (uint32_t*)s_t;
-    for (uint32_t i = threadIdx.x; i < sizeof(HuffDecTable) * 4 / 4; i += 64) dst[i] = src[i];
+    static_assert(sizeof(HuffDecTable) * 4 % 16 == 0, "staged with 16-byte loads");
+    copy_words_to_lds<4>((uint32_t*)s_t, (const uint32_t*)a.tabs, (uint32_t)(sizeof(HuffDecTable) * 4 / 4), threadIdx.x, 64);
     s_zz[threadIdx.x] = a.zigzag[threadIdx.x];
   }
   __syncthreads();

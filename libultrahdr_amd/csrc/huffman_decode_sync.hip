@@ -25,6 +25,7 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include "lds_copy.h"
 #include "uhdr_types.h"
 
 namespace uhdr {
@@ -324,7 +325,7 @@ __device__ __forceinline__ Step decode_step(Bits& r, const HuffFastTable* tabs, 
 __device__ __forceinline__ uint64_t pack_state(uint32_t p, uint32_t b, uint32_t k) { return (uint64_t)p | ((uint64_t)b << 32) | ((uint64_t)k << 40); }
 
 // per-workgroup constants of the scan layout, in LDS
-struct ScanLds {
+struct __attribute__((aligned(16))) ScanLds {
   HuffFastTable t[4];
   uint8_t zz[64];
   uint8_t comp[16], yo[16], xo[16];  // block inside the MCU -> component, row / column of the block inside the component's MCU tile
@@ -334,9 +335,7 @@ struct ScanLds {
 // TRACK: the state-tracking form of the tables (see track_span) instead of the symbol form
 template <bool TRACK = false>
 __device__ __forceinline__ void load_scan_lds(const HuffSyncArgs& a, ScanLds& L) {
-  const uint32_t* src = (const uint32_t*)(TRACK ? a.ttabs : a.ftabs);
-  uint32_t* dst = (uint32_t*)L.t;
-  for (uint32_t i = threadIdx.x; i < sizeof(HuffFastTable) * 4 / 4; i += blockDim.x) dst[i] = src[i];
+  copy_words_to_lds((uint32_t*)L.t, (const uint32_t*)(TRACK ? a.ttabs : a.ftabs), (uint32_t)(sizeof(HuffFastTable) * 4 / 4), threadIdx.x, blockDim.x);
   if (threadIdx.x < 64) L.zz[threadIdx.x] = a.zigzag[threadIdx.x];
   if (threadIdx.x < 16) {
     const int j = (int)threadIdx.x;
@@ -421,6 +420,67 @@ __device__ __forceinline__ void track_span(const HuffSyncArgs& a, const Staged& 
   p = r.pos();
 }
 
+// Round 6: the same walk, up to two symbols per step (pair tables: uhdr_types.h kHuffPairBits, host make_pair_table).  The
+// tracking passes are VALU-issue bound -- ~50 instructions per step for a wave whose 64 lanes are in 64 different places, 6 hypotheses
+// x 2 passes over every bit of a 4:2:0 scan -- so the number of steps is the cost.  A table entry covers the AC symbol that follows
+// the first one when its code lies inside the same 10 index bits; the step takes it unless the first symbol ends the block (the
+// next table would be another one) or reaches the end of the subsequence (the walk must stop at the FIRST boundary at or beyond
+// end_bit): then exactly the single-symbol transition happens.  4K 4:2:0 q95: 0.59 steps per symbol, gain map 0.60.
+// Every state this walk passes through is a state of track_span's walk, and the final state is the same.
+struct __attribute__((aligned(16))) PairLds {  // == the layout of HuffSyncArgs::ptabs
+  uint32_t p[4][kHuffPairWords];        // 16 KB
+  uint16_t l2[4][kHuffL2Max * 128];     // 16 KB: the second level of the tracking form, for codes longer than the index
+};
+static_assert(sizeof(PairLds) == kHuffPairBlobWords * 4, "PairLds is one copy of the host's blob");
+__device__ __forceinline__ void load_pair_lds(const HuffSyncArgs& a, PairLds& L) {
+  copy_words_to_lds((uint32_t*)&L, a.ptabs, (uint32_t)kHuffPairBlobWords, threadIdx.x, blockDim.x);
+}
+__device__ __forceinline__ void track_span_pair(const HuffSyncArgs& a, const Staged& st, uint32_t region_bit, const PairLds& L, uint32_t& p, uint32_t& b,
+                                                uint32_t& k, uint32_t end_bit, uint32_t& nblk) {
+  Bits r;
+  r.st = st;
+  r.region_bit = region_bit;
+  r.seek(p);
+  const uint32_t bpm = (uint32_t)a.blocks_per_mcu;
+  uint32_t cpack = 0;
+#pragma unroll
+  for (int j = 0; j < 16; j++) cpack |= ((uint32_t)a.comp_of[j] & 3u) << (2 * j);
+  const uint32_t* P = &L.p[0][0];
+  const uint16_t* S = &L.l2[0][0];
+  uint32_t cls = ((cpack >> (2u * b)) & 3u) ? 2u : 0u;  // the component's DC table; its AC table follows
+  int left = (int)(end_bit - p);
+  while (left > 0) {
+    r.fill();
+    const uint32_t w16 = r.peek(16);
+    const uint32_t ti = cls + (k ? 1u : 0u);
+    uint32_t e = P[ti * (uint32_t)kHuffPairWords + (w16 >> (16 - kHuffPairBits))];
+    if (__builtin_amdgcn_ballot_w64((e >> 31) != 0) != 0) {
+      const uint32_t e2 = S[ti * (uint32_t)(kHuffL2Max * 128) + ((e >> 31) ? (e & 15u) : 0u) * 128u + (w16 & 127u)];
+      e = (e >> 31) ? e2 : e;  // tracking form: no second symbol
+    }
+    const uint32_t adv1 = e & 31u, kinc1 = (e >> 5) & 127u, adv2 = (e >> 12) & 31u, kinc2 = (e >> 17) & 127u;
+    const bool two = adv2 != 0u && k + kinc1 < 64u && left > (int)adv1;
+    const uint32_t adv = adv1 + (two ? adv2 : 0u);
+    r.skip((int)adv);
+    left -= (int)adv;
+    k += kinc1 + (two ? kinc2 : 0u);
+    if (k >= 64u) {
+      k = 0;
+      b++;
+      nblk++;
+      if (b == bpm) {
+        b = 0;
+        if (a.rst_map) {  // restart intervals: see restart_jump
+          const uint32_t pad = restart_jump(a, r, end_bit - (uint32_t)left);
+          if (pad != kNoJump) left -= (int)pad;
+        }
+      }
+      cls = ((cpack >> (2u * b)) & 3u) ? 2u : 0u;
+    }
+  }
+  p = r.pos();
+}
+
 // Decodes from state (p, b, k) to the first symbol boundary at or beyond end_bit.  WRITE: store coefficients / DC
 // differences for the blocks [blk, total_blocks) and flag malformed data; else just track the state.
 template <bool WRITE>
@@ -482,7 +542,7 @@ __device__ __forceinline__ void run_span(const HuffSyncArgs& a, const Staged& st
 //   bits 0-4 bits consumed (code + magnitude), 5-11 zig-zag advance (as in the tracking form), 12-15 magnitude bits s,
 //   16 malformed (undefined code / DC category beyond 15), 31 "longer code: sub-table in bits 0-4" (first level only).
 // One lookup yields everything a symbol needs: the value is the last s of the consumed bits, HUFF_EXTENDed.
-struct WriteLds {
+struct __attribute__((aligned(16))) WriteLds {
   uint32_t t[4][kHuffValWords];
   uint8_t zz[64];
   uint8_t comp[16], yo[16], xo[16];
@@ -490,8 +550,7 @@ struct WriteLds {
   int16_t* coef[4];
 };
 __device__ __forceinline__ void load_write_lds(const HuffSyncArgs& a, WriteLds& L) {
-  uint32_t* dst = &L.t[0][0];
-  for (uint32_t i = threadIdx.x; i < 4u * kHuffValWords; i += blockDim.x) dst[i] = a.vtabs[i];
+  copy_words_to_lds(&L.t[0][0], a.vtabs, 4u * kHuffValWords, threadIdx.x, blockDim.x);
   if (threadIdx.x < 64) L.zz[threadIdx.x] = a.zigzag[threadIdx.x];
   if (threadIdx.x < 16) {
     const int j = (int)threadIdx.x;
@@ -682,8 +741,13 @@ __global__ __launch_bounds__(256) void sync_write_kernel(const HuffSyncArgs a, i
 // 2-byte store per symbol, a pointer bump per block.  coef_place_kernel then reads the scratch once (coalesced), applies the
 // DC prediction (the running sums of dc_partial / dc_scan_partials over [0]) and writes every JBLOCK whole, in natural order --
 // so the component arrays need no zero fill any more, the scratch (scan order) gets it instead.
-struct Write2Lds {
-  uint32_t t[4][kHuffValWords];
+// Round 6: up to two symbols per step here as well (pair form of the value tables, host make_pair_value_table): this pass has one
+// lane per subsequence -- 290 waves for a 4K gain map, 790 for the base image, on 1024 SIMDs -- so it runs at the latency of one
+// lane's symbol chain, and 0.6 steps per symbol are 0.6 of its time.
+struct __attribute__((aligned(16))) Write2Lds {  // == the layout of HuffSyncArgs::pvtabs
+  uint2 p[4][kHuffPairWords];             // 32 KB: {first symbol, second symbol or 0}, value form
+  uint16_t l2[4][kHuffL2Max * 128];       // 16 KB: the sub-tables of the value form (codes longer than the index): bits | advance << 5 |
+                                          // magnitude bits << 12; 0 = a malformed code (16 bits, to the end of the block / one DC step)
 };
 __device__ __forceinline__ void write_span2(const HuffSyncArgs& a, const Staged& st, uint32_t region_bit, const Write2Lds& L, uint32_t p, uint32_t b, uint32_t k,
                                             uint32_t end_bit, uint32_t& nblk, uint32_t blk) {
@@ -696,30 +760,40 @@ __device__ __forceinline__ void write_span2(const HuffSyncArgs& a, const Staged&
   uint32_t cpack = 0;
 #pragma unroll
   for (int j = 0; j < 16; j++) cpack |= ((uint32_t)a.comp_of[j] & 3u) << (2 * j);
-  const uint32_t* T = &L.t[0][0];
-  uint32_t cbase = ((cpack >> (2u * b)) & 3u) ? 2u * kHuffValWords : 0u;
+  const uint2* P = &L.p[0][0];
+  const uint16_t* S = &L.l2[0][0];
+  uint32_t cls = ((cpack >> (2u * b)) & 3u) ? 2u : 0u;
   int16_t* dst = a.coef_scan + (size_t)blk * 64;
   int left = (int)(end_bit - p);
   while (left > 0 && blk < a.total_blocks) {
     r.fill();
     const uint32_t w16 = r.peek(16);
-    const uint32_t tb = cbase + (k ? (uint32_t)kHuffValWords : 0u);
-    uint32_t e = T[tb + (w16 >> 7)];
-    if (__builtin_amdgcn_ballot_w64((e >> 31) != 0) != 0) {
-      const uint32_t e2 = T[tb + 512u + ((e >> 31) ? (e & 31u) : 0u) * 128u + (w16 & 127u)];
-      e = (e >> 31) ? e2 : e;
+    const uint32_t ti = cls + (k ? 1u : 0u);
+    const uint2 e = P[ti * (uint32_t)kHuffPairWords + (w16 >> (16 - kHuffPairBits))];
+    uint32_t e1 = e.x, e2 = e.y;
+    if (__builtin_amdgcn_ballot_w64((e1 >> 31) != 0) != 0) {  // a code longer than the index: its sub-table, one symbol
+      uint32_t s2 = S[ti * (uint32_t)(kHuffL2Max * 128) + ((e1 >> 31) ? (e1 & 15u) : 0u) * 128u + (w16 & 127u)];
+      s2 = s2 ? s2 : (16u | ((k ? 64u : 1u) << 5) | (1u << 16));  // malformed: make_value_table's entry for an undefined code
+      e1 = (e1 >> 31) ? s2 : e1;
     }
-    const uint32_t adv = e & 31u, kinc = (e >> 5) & 127u, sz = (e >> 12) & 15u;
-    const uint32_t ext = (1u << sz) - 1u;
-    const uint32_t raw = r.peek((int)adv) & ext;  // adv >= 1: every code is at least one bit long
-    const int value = (int)raw - (((raw << 1) > ext) ? 0 : (int)ext);  // HUFF_EXTEND; 0 when there are no magnitude bits
-    const uint32_t zzpos = k + kinc - 1u;  // DC: 0; AC symbol with a value: k + run
-    const bool over = sz != 0 && zzpos > 63u;  // (a DC symbol has zzpos 0)
-    bad = bad || ((e >> 16) & 1u) != 0 || over;
-    if (sz != 0 && !over) dst[zzpos] = (int16_t)value;
+    const uint32_t adv1 = e1 & 31u, kinc1 = (e1 >> 5) & 127u, sz1 = (e1 >> 12) & 15u;
+    const bool two = e2 != 0u && k + kinc1 < 64u && left > (int)adv1;
+    e2 = two ? e2 : 0u;
+    const uint32_t adv2 = e2 & 31u, kinc2 = (e2 >> 5) & 127u, sz2 = (e2 >> 12) & 15u;
+    const uint32_t adv = adv1 + adv2;
+    const uint32_t bits = r.peek((int)adv);  // adv >= 1: every code is at least one bit long
+    const uint32_t ext1 = (1u << sz1) - 1u, ext2 = (1u << sz2) - 1u;
+    const uint32_t raw1 = (bits >> adv2) & ext1, raw2 = bits & ext2;
+    const int v1 = (int)raw1 - (((raw1 << 1) > ext1) ? 0 : (int)ext1);  // HUFF_EXTEND; 0 when there are no magnitude bits
+    const int v2 = (int)raw2 - (((raw2 << 1) > ext2) ? 0 : (int)ext2);
+    const uint32_t zz1 = k + kinc1 - 1u, zz2 = zz1 + kinc2;  // DC: 0; AC symbol with a value: k + run
+    const bool over1 = sz1 != 0 && zz1 > 63u, over2 = sz2 != 0 && zz2 > 63u;  // (a DC symbol has zzpos 0)
+    bad = bad || ((e1 >> 16) & 1u) != 0 || over1 || over2;
+    if (sz1 != 0 && !over1) dst[zz1] = (int16_t)v1;
+    if (sz2 != 0 && !over2) dst[zz2] = (int16_t)v2;
     r.skip((int)adv);
     left -= (int)adv;
-    k += kinc;
+    k += kinc1 + kinc2;
     if (k >= 64u) {
       k = 0;
       b++;
@@ -727,18 +801,18 @@ __device__ __forceinline__ void write_span2(const HuffSyncArgs& a, const Staged&
       blk++;
       dst += 64;
       if (b == bpm) b = 0;
-      cbase = ((cpack >> (2u * b)) & 3u) ? 2u * kHuffValWords : 0u;
+      cls = ((cpack >> (2u * b)) & 3u) ? 2u : 0u;
     }
   }
   if (bad) atomicOr(a.flags + 1, 2u);
 }
 __global__ __launch_bounds__(256) void sync_write2_kernel(const HuffSyncArgs a, int final_buf) {
-  extern __shared__ uint32_t s_stage_all[];
-  __shared__ Write2Lds L;
-  {
-    uint32_t* dst = &L.t[0][0];
-    for (uint32_t i = threadIdx.x; i < 4u * kHuffValWords; i += blockDim.x) dst[i] = a.vtabs[i];
-  }
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+  // the tables sit in the dynamic segment as well (static + dynamic LDS beyond 64 KB needs the opt-in either way)
+  Write2Lds& L = *(Write2Lds*)s_dyn;
+  uint32_t* s_stage_all = s_dyn + sizeof(Write2Lds) / 4;
+  static_assert(sizeof(Write2Lds) == kHuffPairValBlobWords * 4, "Write2Lds is one copy of the host's blob");
+  copy_words_to_lds(s_dyn, a.pvtabs, (uint32_t)kHuffPairValBlobWords, threadIdx.x, blockDim.x);
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t nclean = a.nbytes - *a.nstuffed, nbits = nclean * 8u;
   const uint32_t nsub = (nbits + a.sub_bits - 1) / a.sub_bits;
@@ -781,8 +855,8 @@ __global__ __launch_bounds__(256) void sync_write2_kernel(const HuffSyncArgs a, 
 
 __global__ __launch_bounds__(1024) void hyp_pass0_kernel(const HuffSyncArgs a) {
   extern __shared__ uint32_t s_stage[];
-  __shared__ ScanLds L;
-  load_scan_lds<true>(a, L);
+  __shared__ PairLds L;
+  load_pair_lds(a, L);
   const uint32_t lane = threadIdx.x & 63u, h = threadIdx.x >> 6;
   const uint32_t i = blockIdx.x * 64u + lane;
   const uint32_t nclean = a.nbytes - *a.nstuffed, nbits = nclean * 8u;
@@ -795,7 +869,7 @@ __global__ __launch_bounds__(1024) void hyp_pass0_kernel(const HuffSyncArgs a) {
   uint32_t p = i * a.sub_bits, b = h, k = 0, nblk = 0;
   const uint32_t end_bit = min((i + 1) * a.sub_bits, nbits);
   const Staged st = {s_stage, cshift};
-  track_span(a, st, first_byte * 8u, L, p, b, k, end_bit, nblk);
+  track_span_pair(a, st, first_byte * 8u, L, p, b, k, end_bit, nblk);
   a.hyp_state[(size_t)i * kHuffHypSlots + h] = pack_state(p, b, k);
   if (i == 0 && h == 0) {
     a.nblk[0] = nblk;
@@ -895,9 +969,9 @@ __device__ __forceinline__ uint32_t hyp_find_slot(const uint64_t* __restrict__ r
 }
 __global__ __launch_bounds__(1024) void hyp_pass1q_kernel(const HuffSyncArgs a) {
   extern __shared__ uint32_t s_stage[];
-  __shared__ ScanLds L;
+  __shared__ PairLds L;
   __shared__ uint32_t s_n;
-  load_scan_lds<true>(a, L);
+  load_pair_lds(a, L);
   const uint32_t tid = threadIdx.x, lane = tid & 63u, H = (uint32_t)a.hyp_h;
   const uint32_t i0 = blockIdx.x * 64u, i_last = i0 + 63u;
   const uint32_t nclean = a.nbytes - *a.nstuffed, nbits = nclean * 8u;
@@ -941,7 +1015,7 @@ __global__ __launch_bounds__(1024) void hyp_pass1q_kernel(const HuffSyncArgs a) 
       uint32_t p = (uint32_t)s0, b = (uint32_t)(s0 >> 32) & 0xffu, k = (uint32_t)(s0 >> 40) & 0xffu;
       const uint32_t end_bit = min((j + 1) * a.sub_bits, nbits);
       uint32_t nblk = 0;
-      if (p < end_bit) track_span(a, st, first_byte * 8u, L, p, b, k, end_bit, nblk);
+      if (p < end_bit) track_span_pair(a, st, first_byte * 8u, L, p, b, k, end_bit, nblk);
       const uint64_t e = pack_state(p, b, k);
       const uint64_t* row = a.hyp_state + (size_t)j * kHuffHypSlots;
       const uint8_t* prev = a.hyp_map + (size_t)(j - 1) * kHuffHypSlots;
@@ -1496,10 +1570,14 @@ hipError_t launch_huffman_unstuff(const uint8_t* data, uint32_t nbytes, uint32_t
 static void launch_write2(const HuffSyncArgs& a, uint32_t nsub, int final_buf, hipStream_t s) {
   const size_t per_wave = (size_t)64 * ((a.sub_bits >> 3) + 4) + 64;
   const int waves = per_wave * 4 <= (20u << 10) ? 4 : (per_wave * 2 <= (20u << 10) ? 2 : 1);
-  const size_t lds = per_wave * waves;
+  const size_t lds = sizeof(Write2Lds) + per_wave * waves;  // 48 KB of pair tables + the staged bytes: beyond the 64 KB default, opt in
   const int threads = 64 * waves;
   const int grid = (int)((nsub + threads - 1) / threads);
-  if (lds > (20u << 10)) (void)hipFuncSetAttribute((const void*)sync_write2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static size_t opted = 0;
+  if (lds > opted) {
+    (void)hipFuncSetAttribute((const void*)sync_write2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    opted = lds;
+  }
   hipLaunchKernelGGL(sync_write2_kernel, dim3(grid), dim3(threads), lds, s, a, final_buf);
 }
 static void launch_place(const HuffSyncArgs& a, int* dc_partial, hipStream_t s) {
@@ -1567,7 +1645,7 @@ hipError_t launch_huffman_decode_hyp(const HuffSyncArgs& a, int* dc_partial, uin
     // static LDS of the pass-1 kernels (tables + scan layout) + this must fit the 64 KB a workgroup gets without opting in
     // (4096 bits x 15 levels: 63.6 KB); beyond that the opt-in (gfx950: up to 160 KB per workgroup)
     static size_t opted = 0;
-    if (lds1 + 21504 > (64u << 10) && lds1 > opted) {
+    if (lds1 + sizeof(PairLds) + 64 > (64u << 10) && lds1 > opted) {
       const hipError_t e1 = hipFuncSetAttribute((const void*)hyp_pass1q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
       if (e1 != hipSuccess) return e1;
       opted = lds1;
@@ -1597,7 +1675,8 @@ hipError_t launch_huffman_decode_hyp(const HuffSyncArgs& a, int* dc_partial, uin
   if (qmerge && a.hyp_main_levels > 0 && a.hyp_main_levels < a.hyp_levels) {
     // the paths still alive after the lockstep levels, one wave each; the grid is sized for a thick tail (a wave takes the
     // entries wave, wave + nwaves, ...), surplus waves leave at once
-    int sgrid = (int)((nsub * (uint32_t)a.hyp_h / 16u + kStragWaves - 1) / kStragWaves);
+    static const int smul = [] { const char* e = getenv("UHDR_HIP_HUFF_STRAG_MUL"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 16 ? v : 1; }();
+    int sgrid = (int)((nsub * (uint32_t)a.hyp_h / 16u + kStragWaves - 1) / kStragWaves) * smul;
     if (sgrid < 64) sgrid = 64;
     if (sgrid > 4096) sgrid = 4096;
     hipLaunchKernelGGL(hyp_straggler_kernel, dim3(sgrid), dim3(64 * kStragWaves), 0, s, a);

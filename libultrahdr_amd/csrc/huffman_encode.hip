@@ -22,6 +22,7 @@
 //      prefix sum of the 0xFF counts) and written to the interval's slot in device memory.
 // Two launches of that kernel (size classes of the LDS bit buffer, see below), then a tiny kernel turns the interval
 // sizes into offsets and a gather kernel copies the slots into the final stream with the RSTn markers in between.
+#include "lds_copy.h"
 #include "uhdr_types.h"
 
 namespace uhdr {
@@ -113,7 +114,7 @@ constexpr uint32_t kRetry = 0xFFFFFFFEu, kBadCoef = 0xFFFFFFFFu;
 // one wave-wide scan minus the scan value in front of the group, and the pad / stuff / store steps run once per group.
 template <int WORDS, bool RETRY>
 __global__ __launch_bounds__(64) void huff_encode_kernel(const HuffArgs a) {
-  __shared__ uint32_t s_tab[2 * (16 + 256)];
+  __shared__ __attribute__((aligned(16))) uint32_t s_tab[2 * (16 + 256)];
   __shared__ uint32_t s_coef[kSegBlocks * kCoefRow];
   __shared__ uint32_t s_bits[kSegBlocks * WORDS + 2];
   __shared__ int s_dc[kSegBlocks];
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(64) void huff_encode_kernel(const HuffArgs a) {
   __shared__ uint32_t s_gbits[kSegBlocks];  // bits of group g's interval
   __shared__ uint8_t s_zz[64];
   const uint32_t lane = threadIdx.x;
-  for (uint32_t i = lane; i < 2 * (16 + 256); i += 64) s_tab[i] = a.tables[i];
+  copy_words_to_lds<4>(s_tab, a.tables, 2 * (16 + 256), lane, 64);
   s_zz[lane] = a.zigzag[lane];
   const int bpm = a.blocks_per_mcu;
   const int per = a.ri * bpm;                                // blocks per interval (<= 64, checked by the host)
@@ -332,21 +333,21 @@ __global__ __launch_bounds__(256) void huff_gather_kernel(const uint8_t* __restr
 //   pass B  emit: same walk, bits go to the LDS buffer at phase (first bit & 31) and from there to the unstuffed stream in
 //           memory: interior words are plain stores, the first / last word of a segment is OR-ed in (its neighbour writes the
 //           rest); the last segment appends flush_bits' one-padding
-//   stuff   0xFF counts per 1 KiB chunk -> scan -> scatter with the stuffed zero bytes (jchuff.c emit_bits)
+//   stuff   0xFF counts per 4 KiB chunk -> scan -> scatter with the stuffed zero bytes (jchuff.c emit_bits)
 // The result equals libjpeg's entropy-coded segment byte for byte (tests: against the sequential CPU restatement of jchuff.c
 // at restart_interval 0 and against the files the reference encoder writes).
-constexpr int kStuffChunk = 1024;  // raw bytes per workgroup of the stuffing passes (256 threads x 4 bytes)
+constexpr int kStuffChunk = 4096;  // raw bytes per workgroup of the stuffing passes (256 threads x 16 bytes)
 
 template <int WORDS, int PASS>  // PASS 0: lengths; 1: emit, small LDS buffer; 2: emit, worst-case buffer
 __global__ __launch_bounds__(64) void huff_stream_kernel(const HuffArgs a, const HuffStream t) {
-  __shared__ uint32_t s_tab[2 * (16 + 256)];
+  __shared__ __attribute__((aligned(16))) uint32_t s_tab[2 * (16 + 256)];
   __shared__ uint32_t s_coef[kSegBlocks * kCoefRow];
   __shared__ uint32_t s_bits[PASS == 0 ? 1 : kSegBlocks * WORDS + 2];
   __shared__ int s_dc[kSegBlocks];
   __shared__ int s_real[kSegBlocks];
   __shared__ uint8_t s_zz[64];
   const uint32_t lane = threadIdx.x;
-  for (uint32_t i = lane; i < 2 * (16 + 256); i += 64) s_tab[i] = a.tables[i];
+  copy_words_to_lds<4>(s_tab, a.tables, 2 * (16 + 256), lane, 64);
   s_zz[lane] = a.zigzag[lane];
   const int bpm = a.blocks_per_mcu;
   constexpr uint32_t kCapBits = (uint32_t)(kSegBlocks * WORDS) * 32u;
@@ -456,39 +457,66 @@ __global__ __launch_bounds__(64) void huff_stream_kernel(const HuffArgs a, const
   }
 }
 
+// One 1024-thread workgroup scans n words in tiles of 8192: a tile is loaded COALESCED into LDS (eight words per thread), every
+// thread adds up its eight consecutive words there, a ten-step block scan gives the threads' offsets, `sink(index, value, exclusive
+// prefix)` is called for every element.  Round 5's form walked `per` consecutive elements per thread straight from global memory --
+// one cache line per lane and instruction, each load waiting for the one before: 40 us for the 6075 chunk counts of a 4K map.
+constexpr int kScanTileWords = 8192;
+template <typename Sink>
+__device__ __forceinline__ uint64_t wg_scan_tiles(const uint32_t* __restrict__ v, int n, uint32_t* s_val /* kScanTileWords */, uint64_t* s_sum /* 1024 */, Sink sink) {
+  const int tid = (int)threadIdx.x;
+  uint64_t carry = 0;
+  for (int base = 0; base < n; base += kScanTileWords) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int i = base + j * 1024 + tid;
+      s_val[j * 1024 + tid] = i < n ? v[i] : 0u;
+    }
+    __syncthreads();
+    uint32_t x[8];
+    uint64_t sum = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { x[j] = s_val[tid * 8 + j]; sum += x[j]; }
+    s_sum[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      const uint64_t y = tid >= d ? s_sum[tid - d] : 0;
+      __syncthreads();
+      s_sum[tid] += y;
+      __syncthreads();
+    }
+    uint64_t run = carry + s_sum[tid] - sum;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int i = base + tid * 8 + j;
+      if (i < n) sink(i, x[j], run);
+      run += x[j];
+    }
+    carry += s_sum[1023];
+    __syncthreads();  // s_val / s_sum are rewritten by the next tile
+  }
+  return carry;
+}
+
 // seg_start = exclusive scan of seg_bits (bit offsets), seg_start[nseg] = total; meta[0..1] = total bits, meta[2] = status
 // (1: coefficients outside the baseline range); every word that two segments share (and the word behind the last bit) is zeroed
 __global__ __launch_bounds__(1024) void huff_stream_scan_kernel(const uint32_t* __restrict__ seg_bits, int nseg, const HuffStream t) {
+  __shared__ uint32_t s_val[kScanTileWords];
   __shared__ uint64_t s_sum[1024];
   __shared__ uint32_t s_bad;
   const int tid = (int)threadIdx.x;
   if (tid == 0) s_bad = 0;
   __syncthreads();
-  const int per = (nseg + 1023) / 1024, lo = min(tid * per, nseg), hi = min(lo + per, nseg);
-  uint64_t sum = 0;
   bool bad = false;
-  for (int i = lo; i < hi; i++) {
-    const uint32_t n = seg_bits[i];
+  // (a segment that must be redone -- kRetry / kBadCoef -- poisons the sums behind it; the status word makes the host discard them)
+  const uint64_t total = wg_scan_tiles(seg_bits, nseg, s_val, s_sum, [&](int i, uint32_t n, uint64_t run) {
     bad |= n >= kRetry;
-    sum += n;
-  }
-  if (bad) atomicOr(&s_bad, 1u);
-  s_sum[tid] = sum;
-  __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {
-    const uint64_t y = tid >= d ? s_sum[tid - d] : 0;
-    __syncthreads();
-    s_sum[tid] += y;
-    __syncthreads();
-  }
-  uint64_t run = s_sum[tid] - sum;
-  for (int i = lo; i < hi; i++) {
     t.seg_start[i] = run;
     if ((run >> 5) < t.raw_words) t.raw[run >> 5] = 0u;
-    run += seg_bits[i];
-  }
+  });
+  if (bad) atomicOr(&s_bad, 1u);
+  __syncthreads();
   if (tid == 1023) {
-    const uint64_t total = s_sum[1023];
     t.seg_start[nseg] = total;
     if ((total >> 5) < t.raw_words) t.raw[total >> 5] = 0u;
     t.meta[0] = (uint32_t)total;
@@ -497,70 +525,67 @@ __global__ __launch_bounds__(1024) void huff_stream_scan_kernel(const uint32_t* 
   if (tid == 0) t.meta[2] = s_bad;
 }
 
-// 0xFF bytes per chunk of the unstuffed stream
+// 0xFF bytes per chunk of the unstuffed stream.  Round 6: sixteen bytes per thread (one 16-byte load; chunks of 4 KiB) instead of four,
+// and grids sized for the stream that exists (the host passes the capacity; blocks beyond the last raw byte leave at once).
+__device__ __forceinline__ uint32_t ff_mask16(const uint4& v, uint32_t nv) {  // bit k set: byte k (of the first nv) is 0xFF
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  uint32_t m = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < 16; k++) m |= (k < nv && ((w[k >> 2] >> (8u * (k & 3u))) & 0xffu) == 0xffu) ? (1u << k) : 0u;
+  return m;
+}
+__device__ __forceinline__ uint4 raw_load16(const HuffStream& t, uint64_t base) {  // raw[] is word-addressed and 16-byte aligned (hipMalloc)
+  const uint64_t w = base >> 2;
+  if (w + 4u <= t.raw_words) return *(const uint4*)(t.raw + w);
+  uint32_t x[4] = {0, 0, 0, 0};
+  for (uint32_t k = 0; k < 4; k++)
+    if (w + k < t.raw_words) x[k] = t.raw[w + k];
+  return make_uint4(x[0], x[1], x[2], x[3]);
+}
 __global__ __launch_bounds__(256) void huff_stuff_count_kernel(const HuffStream t, uint32_t* __restrict__ counts) {
   __shared__ uint32_t s_n;
   const uint64_t total_bits = (uint64_t)t.meta[0] | ((uint64_t)t.meta[1] << 32);
   const uint64_t nraw = (total_bits + 7u) >> 3;
-  const uint64_t base = (uint64_t)blockIdx.x * kStuffChunk + threadIdx.x * 4u;
+  const uint64_t base = (uint64_t)blockIdx.x * kStuffChunk + threadIdx.x * 16u;
+  if ((uint64_t)blockIdx.x * kStuffChunk >= nraw) {  // (wave-uniform) nothing of the stream in this chunk
+    if (threadIdx.x == 0) counts[blockIdx.x] = 0;
+    return;
+  }
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
   uint32_t n = 0;
-  if (base < nraw && (base >> 2) < t.raw_words) {
-    const uint32_t wd = t.raw[base >> 2];
-    const uint32_t nv = (uint32_t)min((uint64_t)4, nraw - base);
-#pragma unroll
-    for (uint32_t k = 0; k < 4; k++) n += (k < nv && ((wd >> (8 * k)) & 0xffu) == 0xffu) ? 1u : 0u;
-  }
+  if (base < nraw) n = (uint32_t)__builtin_popcount(ff_mask16(raw_load16(t, base), (uint32_t)min((uint64_t)16, nraw - base)));
   n = wave_incl_scan(n, threadIdx.x & 63);
-  if ((threadIdx.x & 63) == 63) atomicAdd(&s_n, n);
+  if ((threadIdx.x & 63) == 63 && n) atomicAdd(&s_n, n);
   __syncthreads();
   if (threadIdx.x == 0) counts[blockIdx.x] = s_n;
 }
 
 // exclusive scan of the chunk counts in place (one workgroup); out_bytes = raw bytes + stuffed zeros
 __global__ __launch_bounds__(1024) void huff_stuff_scan_kernel(uint32_t* __restrict__ counts, int nchunks, const HuffStream t, uint64_t* __restrict__ out_bytes) {
+  __shared__ uint32_t s_val[kScanTileWords];
   __shared__ uint64_t s_sum[1024];
-  const int tid = (int)threadIdx.x;
-  const int per = (nchunks + 1023) / 1024, lo = min(tid * per, nchunks), hi = min(lo + per, nchunks);
-  uint64_t sum = 0;
-  for (int i = lo; i < hi; i++) sum += counts[i];
-  s_sum[tid] = sum;
-  __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {
-    const uint64_t y = tid >= d ? s_sum[tid - d] : 0;
-    __syncthreads();
-    s_sum[tid] += y;
-    __syncthreads();
-  }
-  uint64_t run = s_sum[tid] - sum;
-  for (int i = lo; i < hi; i++) {
-    const uint32_t n = counts[i];
-    counts[i] = (uint32_t)run;  // < 2^32: the stream is bounded by the 32-bit capacity checked on the host
-    run += n;
-  }
-  if (tid == 1023) {
-    const uint64_t total_bits = (uint64_t)t.meta[0] | ((uint64_t)t.meta[1] << 32);
-    *out_bytes = ((total_bits + 7u) >> 3) + s_sum[1023];
-  }
+  const uint64_t total_bits = (uint64_t)t.meta[0] | ((uint64_t)t.meta[1] << 32);
+  const uint64_t nraw = (total_bits + 7u) >> 3;
+  const int used = (int)min((uint64_t)nchunks, (nraw + kStuffChunk - 1) / kStuffChunk);  // chunks beyond the stream hold zeros and are never read
+  // (< 2^32: the stream is bounded by the 32-bit capacity checked on the host)
+  const uint64_t total = wg_scan_tiles(counts, used, s_val, s_sum, [&](int i, uint32_t, uint64_t run) { counts[i] = (uint32_t)run; });
+  if (threadIdx.x == 1023) *out_bytes = nraw + total;
 }
 
 __global__ __launch_bounds__(256) void huff_stuff_scatter_kernel(const HuffStream t, const uint32_t* __restrict__ chunk_base, uint8_t* __restrict__ out, uint64_t cap) {
   __shared__ uint32_t s_wave[4];
   const uint64_t total_bits = (uint64_t)t.meta[0] | ((uint64_t)t.meta[1] << 32);
   const uint64_t nraw = (total_bits + 7u) >> 3;
-  const uint64_t base = (uint64_t)blockIdx.x * kStuffChunk + threadIdx.x * 4u;
-  uint32_t wd = 0, nv = 0, nff = 0;
-  if (base < nraw && (base >> 2) < t.raw_words) {
-    wd = t.raw[base >> 2];
-    nv = (uint32_t)min((uint64_t)4, nraw - base);
+  if ((uint64_t)blockIdx.x * kStuffChunk >= nraw) return;  // (wave-uniform)
+  const uint64_t base = (uint64_t)blockIdx.x * kStuffChunk + threadIdx.x * 16u;
+  uint4 v = make_uint4(0, 0, 0, 0);
+  uint32_t nv = 0;
+  if (base < nraw) {
+    v = raw_load16(t, base);
+    nv = (uint32_t)min((uint64_t)16, nraw - base);
   }
-  uint32_t b[4];
-#pragma unroll
-  for (uint32_t k = 0; k < 4; k++) {
-    b[k] = (wd >> (8 * k)) & 0xffu;
-    if (k < nv && b[k] == 0xffu) nff++;
-  }
+  const uint32_t mask = ff_mask16(v, nv), nff = (uint32_t)__builtin_popcount(mask);
   const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t incl = wave_incl_scan(nff, lane);
   if (lane == 63) s_wave[wv] = incl;
@@ -568,15 +593,23 @@ __global__ __launch_bounds__(256) void huff_stuff_scatter_kernel(const HuffStrea
   uint32_t before = chunk_base[blockIdx.x] + incl - nff;
   for (uint32_t k = 0; k < wv; k++) before += s_wave[k];
   uint64_t pos = base + before;
-#pragma unroll
-  for (uint32_t k = 0; k < 4; k++) {
-    if (k < nv) {
-      if (pos < cap) out[pos] = (uint8_t)b[k];
+  if (mask == 0 && nv == 16 && pos + 16 <= cap) {
+    // no 0xFF among these sixteen bytes (15 threads in 16): four dword stores at the shifted, in general unaligned, destination
+    uint8_t* d = out + pos;
+    __builtin_memcpy(d, &v.x, 4);
+    __builtin_memcpy(d + 4, &v.y, 4);
+    __builtin_memcpy(d + 8, &v.z, 4);
+    __builtin_memcpy(d + 12, &v.w, 4);
+    return;
+  }
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  for (uint32_t k = 0; k < nv; k++) {
+    const uint32_t b = (w[k >> 2] >> (8u * (k & 3u))) & 0xffu;
+    if (pos < cap) out[pos] = (uint8_t)b;
+    pos++;
+    if (b == 0xffu) {
+      if (pos < cap) out[pos] = 0;
       pos++;
-      if (b[k] == 0xffu) {
-        if (pos < cap) out[pos] = 0;
-        pos++;
-      }
     }
   }
 }

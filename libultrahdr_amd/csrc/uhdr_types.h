@@ -349,6 +349,16 @@ struct HuffFastTable {          // two-level decode form of one DHT table: 9 bit
   uint16_t l2[kHuffL2Max][128]; // length << 8 | symbol;  0 = undefined
 };
 constexpr int kHuffValWords = 512 + kHuffL2Max * 128;  // one table of the write pass: first level, then the sub-tables
+// Round 6: the state-tracking passes take up to TWO symbols per step.  Pair form of one table (host: make_pair_table), indexed by the
+// next kHuffPairBits bits of the stream: bits 0-4 bits consumed by the first symbol (code + magnitude), 5-11 its zig-zag advance,
+// 12-16 / 17-23 the same for the AC symbol that follows it IF its code also lies inside the index (0: no second symbol);
+// bit 31: the first code is longer than the index, bits 0-3 = its second-level sub-table (tracking form, as before).
+constexpr int kHuffPairBits = 10, kHuffPairWords = 1 << kHuffPairBits;
+// the blobs the kernels stage with ONE copy: ptabs = 4 pair tables, then the four tracking tables' second levels (uint16); pvtabs = 4 x
+// kHuffPairWords x {first, second} value words, then the four value tables' second levels as uint16 (bits | advance << 5 | magnitude bits
+// << 12; 0 = malformed)
+constexpr int kHuffPairBlobWords = 4 * kHuffPairWords + 4 * kHuffL2Max * 128 / 2;
+constexpr int kHuffPairValBlobWords = 8 * kHuffPairWords + 4 * kHuffL2Max * 128 / 2;
 struct HuffSyncArgs {
   const uint8_t* clean;       // unstuffed entropy-coded bytes (device)
   uint32_t nbytes;            // size of the STUFFED stream (upper bound of the clean size)
@@ -368,6 +378,8 @@ struct HuffSyncArgs {
   const HuffFastTable* ftabs; // DC luma, AC luma, DC chroma, AC chroma
   const HuffFastTable* ttabs; // the same four tables in state-tracking form: bits consumed | zig-zag advance << 5 (make_track_table)
   const uint32_t* vtabs;      // ... and in value form for the write pass, 4 x kHuffValWords words (make_value_table)
+  const uint32_t* ptabs;      // ... and in pair form for the tracking passes of the hypothesis scheme, 4 x kHuffPairWords words (make_pair_table)
+  const uint32_t* pvtabs;     // ... and the pair form of the VALUE tables for write form 2: 4 x kHuffPairWords x {first symbol, second symbol or 0} (make_pair_value_table)
   const uint8_t* zigzag;
   // hypothesis decode (launch_huffman_decode_hyp): slot s < hyp_h is "started at the subsequence's first bit as block s of
   // an MCU"; slot l * hyp_h + h is the path of hypothesis h of the subsequence l places back that has not merged yet

@@ -230,6 +230,50 @@ class UltraHdr:
             gm.sync_meta_from_raw()
         return base, mapc, md, gm
 
+    # ---- one entry point per direction of the API-1 round trip, device resident (round 6) -----------------
+    def encodeApi1Scans(self, sdr_intent: Image, hdr_intent: Image, base_encoding: int, qt_base, qt_map, out_base, out_map,
+                        sdr_is_601=False, use_luminance=True):
+        """JpegR::encodeJPEGR API-1 (jpegr.cpp:253-316) without the container, on device images: the fused sample -> coefficient
+        chain and both scans' Huffman coding in ONE C call (uhdr_hip_encode_api1_scans_dev).  out_base / out_map: uint8 CUDA tensors
+        that receive the entropy-coded scans.  Returns (bytes of the base scan, bytes of the map scan, metadata)."""
+        assert _is_dev(sdr_intent, hdr_intent) and out_base.is_cuda and out_map.is_cuda
+        qb = np.ascontiguousarray(np.stack([np.asarray(q, dtype=np.uint16) for q in qt_base]))
+        qm = np.ascontiguousarray(np.stack([np.asarray(q, dtype=np.uint16) for q in qt_map]))
+        md = A.GainmapMetadata()
+        cfg = self.encode_cfg(sdr_is_601, use_luminance)
+        nb, nm = C.c_size_t(0), C.c_size_t(0)
+        self._call(True, self.lib.uhdr_hip_encode_api1_scans_dev, self.ctx.handle, C.byref(sdr_intent.raw), C.byref(hdr_intent.raw), C.byref(cfg), base_encoding,
+                   C.c_void_p(qb.ctypes.data), C.c_void_p(qm.ctypes.data), C.byref(md), None, C.c_void_p(out_base.data_ptr()), int(out_base.numel()), C.byref(nb),
+                   C.c_void_p(out_map.data_ptr()), int(out_map.numel()), C.byref(nm))
+        return int(nb.value), int(nm.value), md
+
+    @staticmethod
+    def jpeg_header(w: int, h: int, sampling, qtables, restart_interval: int = 0) -> "A.JpegHeader":
+        """What uhdr_hip_jpeg_parse fills for a baseline file with the Annex K Huffman tables: scan geometry of a w x h image with the
+        given sampling factors [(h, v)] per component, and its quantization tables (one per component)."""
+        hd = A.JpegHeader()
+        sc = hd.scan
+        sc.num_components = len(sampling)
+        hmax, vmax = max(s[0] for s in sampling), max(s[1] for s in sampling)
+        for i, (hs, vs) in enumerate(sampling):
+            sc.h_samp[i], sc.v_samp[i] = hs, vs
+            pw, ph = (w * hs + hmax - 1) // hmax, (h * vs + vmax - 1) // vmax
+            sc.blocks_w[i], sc.blocks_h[i] = (pw + 7) // 8, (ph + 7) // 8
+            for k in range(64):
+                hd.qtable[i][k] = int(qtables[i][k])
+        sc.w, sc.h, sc.restart_interval = w, h, restart_interval
+        return hd  # (tables left zero: the Annex K tables)
+
+    def decodeApi1Scans(self, base_hdr: "A.JpegHeader", base_data, base_cg: int, map_hdr: "A.JpegHeader", map_data, map_cg: int,
+                        gainmap_metadata: A.GainmapMetadata, output_ct: int, output_format: int, max_display_boost: float, dest: Image,
+                        libjpeg_variant: int = 0):
+        """JpegR::decodeJPEGR behind its container parsing (jpegr.cpp:1469-1531) on device data in ONE C call
+        (uhdr_hip_decode_api1_scans_dev): both scans entropy-decoded, the map's IDCT, applyGainMap with the base image's IDCT inside."""
+        assert base_data.is_cuda and map_data.is_cuda and _is_dev(dest)
+        self._call(True, self.lib.uhdr_hip_decode_api1_scans_dev, self.ctx.handle, C.byref(base_hdr), C.c_void_p(base_data.data_ptr()), int(base_data.numel()), base_cg,
+                   C.byref(map_hdr), C.c_void_p(map_data.data_ptr()), int(map_data.numel()), map_cg, libjpeg_variant, C.byref(gainmap_metadata), output_ct, output_format,
+                   max_display_boost, C.byref(dest.raw))
+
     # ---- applyGainMap (ultrahdrcommon.h:531-534) -----------------------------------------------
     def applyGainMap(self, sdr_intent: Image, gainmap_img: Image, gainmap_metadata: A.GainmapMetadata,
                      output_ct: int, output_format: int, max_display_boost: float, dest: Image,

@@ -1,0 +1,140 @@
+"""GPU: the two whole-direction, device-resident entry points of round 6 (uhdr_hip_encode_api1_scans_dev / uhdr_hip_decode_api1_scans_dev --
+what bench.py's headline step calls) against the REAL reference:
+  encode  the two entropy-coded scans, wrapped into JPEG files, are byte for byte what the reference's JpegEncoderHelper::compressImage
+          writes for the reference's own generateGainMap / convertYuv outputs (oracle/_ref), and the metadata is the reference's;
+  decode  the pixels are what the reference's JpegDecoderHelper::decompressImage + UltraHdr::applyGainMap give for the same two files."""
+import numpy as np
+import pytest
+
+from libultrahdr_amd import capi as A
+from libultrahdr_amd import synth
+from libultrahdr_amd.images import Image
+from oracle import loader as L
+
+pytestmark = pytest.mark.gpu
+S420, S444 = [(2, 2), (1, 1), (1, 1)], [(1, 1)] * 3
+
+
+@pytest.fixture(scope="module")
+def uhdr(hip_ctx):
+    from libultrahdr_amd.ultrahdr import UltraHdr
+
+    return UltraHdr(ctx=hip_ctx)
+
+
+def _scan_of(jpeg: bytes, u):
+    """The entropy-coded bytes of a baseline file (between the SOS header and EOI)."""
+    hd = u.jpeg_parse(jpeg)
+    return jpeg[hd.scan_offset: hd.scan_offset + hd.scan_bytes]
+
+
+@pytest.mark.parametrize("w,h,multi", [(1280, 720, True), (640, 368, True), (1280, 720, False)])
+def test_round_trip_entry_points_equal_the_reference(uhdr, hip_ctx, w, h, multi):
+    import torch
+
+    from libultrahdr_amd.ultrahdr import UltraHdr
+
+    if L.ref() is None:
+        pytest.skip("oracle/_ref not built")
+    dev = "cuda:0"
+    u = uhdr
+    enc = UltraHdr(ctx=hip_ctx, mapDimensionScaleFactor=1, useMultiChannelGainMap=multi, preset=A.UHDR_USAGE_BEST_QUALITY)
+    sdr = synth.make_sdr_yuv420(w, h, seed=77)
+    hdr = synth.make_hdr_p010(w, h, ct=A.UHDR_CT_HLG, seed=77)
+    qy, qc = u.quant_table(95, False), u.quant_table(95, True)
+    out_b = torch.empty(w * h * 2, dtype=torch.uint8, device=dev)
+    out_m = torch.empty(w * h * 4, dtype=torch.uint8, device=dev)
+    nb, nm, md = enc.encodeApi1Scans(sdr.to(dev), hdr.to(dev), A.UHDR_CG_DISPLAY_P3, (qy, qc), (qy, qc), out_b, out_m)
+    hip_ctx.synchronize()
+    scan_b, scan_m = out_b[:nb].cpu().numpy().tobytes(), out_m[:nm].cpu().numpy().tobytes()
+
+    # ---- encode side: the reference's operators on the same intents, its JPEG encoder on their outputs
+    cfg = enc.encode_cfg()
+    md_ref, gm_ref = L.generate_gainmap("ref", sdr, hdr, cfg)
+    for name in ("max_content_boost", "min_content_boost", "gamma", "offset_sdr", "offset_hdr"):
+        assert list(getattr(md, name)) == list(getattr(md_ref, name)), name
+    assert (md.hdr_capacity_min, md.hdr_capacity_max, md.use_base_cg) == (md_ref.hdr_capacity_min, md_ref.hdr_capacity_max, md_ref.use_base_cg)
+    base601 = L.convert_yuv("ref", sdr, A.UHDR_CG_BT_709, A.UHDR_CG_DISPLAY_P3)
+    jpg_b, jpg_m = L.ref_jpeg_compress(base601, 95), L.ref_jpeg_compress(gm_ref, 95)
+    assert scan_b == _scan_of(jpg_b, u), "base scan differs from the reference encoder's"
+    assert scan_m == _scan_of(jpg_m, u), "gain-map scan differs from the reference encoder's"
+
+    # ---- decode side: the reference's decoder + applyGainMap on those files
+    f16 = A.UHDR_IMG_FMT_64bppRGBAHalfFloat
+    hb, hm = u.jpeg_parse(jpg_b), u.jpeg_parse(jpg_m)
+    dst = Image(f16, w, h, align=64, device=dev)
+    base_cg, map_cg = A.UHDR_CG_DISPLAY_P3, A.UHDR_CG_BT_2100
+    # libjpeg_variant 1: oracle/_ref links the image's IJG libjpeg 9, whose ycc -> rgb green constants differ from libjpeg-turbo's for 59
+    # (Cb, Cr) pairs (include/uhdr_hip.h)
+    u.decodeApi1Scans(hb, out_b[:nb], base_cg, hm, out_m[:nm], map_cg, md, A.UHDR_CT_LINEAR, f16, A.FLT_MAX, dst, libjpeg_variant=1)
+    hip_ctx.synchronize()
+    db, bb = L.ref_jpeg_decompress(jpg_b, 0)  # planar YCbCr 4:2:0
+    base_img = Image(A.UHDR_IMG_FMT_12bppYCbCr420, w, h, base_cg, A.UHDR_CT_SRGB, A.UHDR_CR_FULL_RANGE, align=2)
+    assert (db.w, db.h) == (w, h)
+    o = 0
+    for c in range(3):
+        ph, pw = base_img.valid(c).shape
+        st = int(db.stride[c])
+        base_img.valid(c)[:] = bb[o: o + st * ph].reshape(ph, st)[:, :pw]
+        o += st * ph
+    dm, bm = L.ref_jpeg_decompress(jpg_m, 1)  # the stream's own space: RGB888 / Y400
+    nch = 3 if multi else 1
+    gm_img = Image(A.UHDR_IMG_FMT_24bppRGB888 if multi else A.UHDR_IMG_FMT_8bppYCbCr400, w, h, map_cg, align=1)
+    st = int(dm.stride[0])
+    gm_img.valid(0)[:] = bm[: st * h * nch].reshape(h, st * nch)[:, : w * nch].reshape(gm_img.valid(0).shape)
+    want = L.apply_gainmap("ref", base_img, gm_img, md_ref, A.UHDR_CT_LINEAR)
+    got = dst.to_host()
+    assert np.array_equal(got.valid(0), want.valid(0)), f"{int((got.valid(0) != want.valid(0)).sum())} differing samples"
+
+
+def test_the_one_call_forms_equal_the_staged_forms(uhdr, hip_ctx):
+    """Same bytes and pixels as the round-5 route (one C call per stage)."""
+    import torch
+
+    from libultrahdr_amd.ultrahdr import UltraHdr
+
+    dev, w, h = "cuda:0", 1920, 1088
+    u = uhdr
+    enc = UltraHdr(ctx=hip_ctx, mapDimensionScaleFactor=1, useMultiChannelGainMap=True, preset=A.UHDR_USAGE_BEST_QUALITY)
+    sdr, hdr = synth.make_sdr_yuv420(w, h, seed=5).to(dev), synth.make_hdr_p010(w, h, ct=A.UHDR_CT_PQ, seed=5).to(dev)
+    qy, qc = u.quant_table(90, False), u.quant_table(90, True)
+    out_b = torch.empty(w * h * 2, dtype=torch.uint8, device=dev)
+    out_m = torch.empty(w * h * 4, dtype=torch.uint8, device=dev)
+    nb, nm, md = enc.encodeApi1Scans(sdr, hdr, A.UHDR_CG_DISPLAY_P3, (qy, qc), (qy, qc), out_b, out_m)
+    cb, cm, md2, _ = enc.encodeApi1Fused(sdr, hdr, A.UHDR_CG_DISPLAY_P3, (qy, qc), (qy, qc), want_map=False)
+    eb, em = u.huffman_encode(cb, w, h, S420, 0), u.huffman_encode(cm, w, h, S444, 0)
+    assert torch.equal(eb, out_b[:nb]) and torch.equal(em, out_m[:nm])
+    assert list(md.max_content_boost) == list(md2.max_content_boost) and list(md.min_content_boost) == list(md2.min_content_boost)
+    f16, rgba = A.UHDR_IMG_FMT_64bppRGBAHalfFloat, A.UHDR_IMG_FMT_32bppRGBA8888
+    hb, hm = u.jpeg_header(w, h, S420, [qy, qc, qc]), u.jpeg_header(w, h, S444, [qy, qc, qc])
+    d1, d2 = Image(f16, w, h, align=64, device=dev), Image(f16, w, h, align=64, device=dev)
+    u.decodeApi1Scans(hb, out_b[:nb], A.UHDR_CG_BT_709, hm, out_m[:nm], A.UHDR_CG_BT_2100, md, A.UHDR_CT_HLG, A.UHDR_IMG_FMT_32bppRGBA1010102, A.FLT_MAX,
+                      Image(A.UHDR_IMG_FMT_32bppRGBA1010102, w, h, align=64, device=dev))  # another output form runs too
+    u.decodeApi1Scans(hb, out_b[:nb], A.UHDR_CG_BT_709, hm, out_m[:nm], A.UHDR_CG_BT_2100, md, A.UHDR_CT_LINEAR, f16, A.FLT_MAX, d1)
+    shp_b, shp_m = [tuple(c.shape[:2]) for c in cb], [tuple(c.shape[:2]) for c in cm]
+    kb, km = u.huffman_decode(eb, shp_b, w, h, S420, 0), u.huffman_decode(em, shp_m, w, h, S444, 0)
+    gm3 = Image(rgba, w, h, A.UHDR_CG_BT_2100, align=64, device=dev)
+    u.idct_dequant_rgb(km, qy, qc, w, h, rgba, 0, dst=gm3)
+    u.applyGainMapFromCoefficients(kb, [qy, qc, qc], w, h, A.UHDR_CG_BT_709, gm3, md, A.UHDR_CT_LINEAR, f16, A.FLT_MAX, d2)
+    hip_ctx.synchronize()
+    assert np.array_equal(d1.to_host().valid(0), d2.to_host().valid(0))
+
+
+def test_rejections(uhdr, hip_ctx):
+    import torch
+
+    dev, w, h = "cuda:0", 256, 128
+    u = uhdr
+    qy, qc = u.quant_table(95, False), u.quant_table(95, True)
+    f16 = A.UHDR_IMG_FMT_64bppRGBAHalfFloat
+    dst = Image(f16, w, h, align=64, device=dev)
+    data = torch.zeros(4096, dtype=torch.uint8, device=dev)
+    md = synth.default_metadata()
+    h444 = u.jpeg_header(w, h, S444, [qy, qc, qc])
+    with pytest.raises(A.UhdrError) as e:  # a 4:4:4 base image: not the form JpegR writes
+        u.decodeApi1Scans(h444, data, A.UHDR_CG_BT_709, h444, data, A.UHDR_CG_BT_709, md, A.UHDR_CT_LINEAR, f16, A.FLT_MAX, dst)
+    assert e.value.code == A.UHDR_CODEC_UNSUPPORTED_FEATURE
+    h420 = u.jpeg_header(w, h, S420, [qy, qc, qc])
+    with pytest.raises(A.UhdrError) as e:  # zeros are not a scan of 128 blocks: malformed data surfaces as INVALID_PARAM
+        u.decodeApi1Scans(h420, data, A.UHDR_CG_BT_709, h444, data, A.UHDR_CG_BT_709, md, A.UHDR_CT_LINEAR, f16, A.FLT_MAX, dst)
+    assert e.value.code in (A.UHDR_CODEC_INVALID_PARAM, A.UHDR_CODEC_UNSUPPORTED_FEATURE)
