@@ -105,11 +105,16 @@ uhdr_error_info_t uhdr_hip_huffman_encode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
       HIP_TRY(launch_huffman_encode_stream(a, t, chunk_counts, d_total, out, (uint64_t)out_capacity, c->stream));
     }
     c->stats.entropy_encode_stream++;
+    // the stuffed size and the meta words sit next to each other: ONE copy into pinned memory (round 6: were two copies into the stack,
+    // i.e. two staged pageable transfers)
+    if (!c->h_flags) HIP_TRY(hipHostMalloc((void**)&c->h_flags, 64 * sizeof(uint32_t), hipHostMallocDefault));
+    uint32_t* hp = c->h_flags + 48;
+    HIP_TRY(hipMemcpyAsync(hp, d_total, sizeof(uint64_t) + 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     uint64_t total = 0;
     uint32_t meta[4] = {0, 0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(&total, d_total, sizeof total, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(meta, t.meta, sizeof meta, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(&total, hp, sizeof total);
+    memcpy(meta, hp + 2, sizeof meta);
     if (meta[2]) return err_status(UHDR_CODEC_INVALID_PARAM, "coefficients outside the baseline range (DC difference beyond 11 bits / AC beyond 10 bits)");
     const uint64_t raw_bytes = ((((uint64_t)meta[1] << 32) | meta[0]) + 7) / 8;
     if (raw_bytes > t.raw_words * 4u) total = raw_bytes + raw_bytes / 64 + 64;  // the stuffing passes saw a truncated stream: ask for room to spare
@@ -588,17 +593,20 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
     const int main_levels_env = [&] { const char* e = getenv("UHDR_HIP_HUFF_MAIN_LEVELS"); return e ? atoi(e) : (sparse ? 1 : 2); }();
     if (j == bpm && bpm <= 16) {
       HIP_TRY(hipMemsetAsync(y.flags, 0, zero_bytes_sync, c->stream));  // flags, nblk, dcd and the restart map
-      if (form2) HIP_TRY(hipMemsetAsync(y.coef_scan, 0, scan_bytes, c->stream));
+      // form 2's scratch: zero-filled by pass 0 of a hypothesis attempt itself (round 6: a 25-50 MB fill was a launch of its own at the head of
+      // the decode); the rounds scheme gets a fill
+      auto pass0_zeroes = [&](const Attempt& t) { return form2 && t.levels > 0 && scan_bytes % 16 == 0 && scan_bytes / 16 < 0xFFFFFFFFull; };
+      if (form2 && !pass0_zeroes(attempts[0])) HIP_TRY(hipMemsetAsync(y.coef_scan, 0, scan_bytes, c->stream));
       dbg.mark("huffman_decode_dev: fills enqueued");
       int final_buf = 0;
       uint32_t* fl = c->h_flags;  // pinned; [9]: restart markers the unstuff pass dropped, [16] [17] / [0] [7]: their sequence sums as found / as due
       for (int q = 0; q < 24; q++) fl[q] = 0;
       bool hyp_done = false, unstuffed = false, rounds_ran = false;
-      auto start_over = [&]() -> uhdr_error_info_t {  // an attempt failed: everything it wrote goes back to its initial state
+      auto start_over = [&](const Attempt& next) -> uhdr_error_info_t {  // an attempt failed: everything it wrote goes back to its initial state
         HIP_TRY(hipMemsetAsync(y.flags, 0, 32, c->stream));  // not [8]: the stuffed-byte count stays
         HIP_TRY(hipMemsetAsync(y.nblk, 0, (size_t)nsub * 4 + 4, c->stream));
         if (form2) {
-          HIP_TRY(hipMemsetAsync(y.coef_scan, 0, scan_bytes, c->stream));
+          if (!pass0_zeroes(next)) HIP_TRY(hipMemsetAsync(y.coef_scan, 0, scan_bytes, c->stream));
         } else {
           HIP_TRY(hipMemsetAsync(y.dcd, 0, (size_t)total_blocks * 4, c->stream));
           for (int i = 0; i < a.ncomp; i++) HIP_TRY(hipMemsetAsync(a.coef[i], 0, zero_bytes[i], c->stream));
@@ -607,8 +615,10 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
       };
       for (size_t ti = 0; ti < attempts.size() && !hyp_done && !rounds_ran; ti++) {
         const Attempt& t = attempts[ti];
-        if (ti > 0) UHDR_TRY(start_over());
+        if (ti > 0) UHDR_TRY(start_over(t));
         y.sub_bits = t.sub_bits;
+        y.zero_ptr = pass0_zeroes(t) ? (uint4*)y.coef_scan : nullptr;
+        y.zero_vec = pass0_zeroes(t) ? (uint32_t)(scan_bytes / 16) : 0u;
         const uint32_t nsub_t = huff_sync_max_subsequences(data_bytes, t.sub_bits);
         if (t.levels > 0) {
           y.hyp_h = bpm;
@@ -818,7 +828,11 @@ uhdr_error_info_t uhdr_hip_huffman_encode2_dev(uhdr_hip_ctx_t* c, const uhdr_hip
   HIP_TRY(hipSetDevice(c->device));
   uhdr_hip_ctx* x = nullptr;
   UHDR_TRY(aux_context(c, &x));
-  HIP_TRY(hipStreamSynchronize(c->stream));  // the coefficients both scans read were produced on this stream
+  // the coefficients both scans read were produced on this stream: the auxiliary stream waits for them by event (round 6: was a host
+  // synchronisation, i.e. the device idled while the entropy stage's first launches were being prepared)
+  if (!c->aux_ev) HIP_TRY(hipEventCreateWithFlags(&c->aux_ev, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(c->aux_ev, c->stream));
+  HIP_TRY(hipStreamWaitEvent(x->stream, c->aux_ev, 0));
   uhdr_error_info_t ra = ok_status(), rb = ok_status();
   const int dev = c->device;
   run_pair(c, [&] { ra = uhdr_hip_huffman_encode_dev(c, scan_a, out_a, cap_a, bytes_a); },
@@ -834,7 +848,10 @@ uhdr_error_info_t uhdr_hip_huffman_decode2_dev(uhdr_hip_ctx_t* c, const uhdr_hip
   HIP_TRY(hipSetDevice(c->device));
   uhdr_hip_ctx* x = nullptr;
   UHDR_TRY(aux_context(c, &x));
-  HIP_TRY(hipStreamSynchronize(c->stream));  // the bytes of both scans may have come up on this stream
+  // the bytes of both scans may have come up on this stream: ordered by event, as above
+  if (!c->aux_ev) HIP_TRY(hipEventCreateWithFlags(&c->aux_ev, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(c->aux_ev, c->stream));
+  HIP_TRY(hipStreamWaitEvent(x->stream, c->aux_ev, 0));
   uhdr_error_info_t ra = ok_status(), rb = ok_status();
   const int dev = c->device;
   run_pair(c, [&] { ra = uhdr_hip_huffman_decode_dev(c, scan_a, tables_a, data_a, bytes_a); },

@@ -203,6 +203,12 @@ struct uhdr_hip_ctx {
   DeviceBuf affine;              // AffineDev + pass 2's per-channel step tables (kAffineDevBytes)
   float* d_srgb_of_byte = nullptr;  // 256: byte -> sRGB inverse OETF (the fused API-0 front end)
   float* h_mm = nullptr;         // pinned: the final {min, max} for the metadata fill
+  // round 6: uhdr_hip_encode_api1_scans_dev lets the entropy stage's launches follow the fused chain without a host synchronisation in
+  // between: the chain leaves the metadata's inputs here (the copy to h_mm is enqueued) and the entry point finishes them after the
+  // entropy stage's own synchronisation
+  bool defer_md = false;
+  struct DeferredMd { bool valid = false, run = false; uhdr_hip_encode_cfg_t cfg; uhdr_color_transfer_t hdr_ct; int use_base_cg = 1; } deferred_md;
+  hipEvent_t aux_ev = nullptr;   // orders the auxiliary context's stream behind this one (two-scan entropy entry points)
   // profiling
   bool prof = false;
   std::vector<ProfEntry> prof_entries;

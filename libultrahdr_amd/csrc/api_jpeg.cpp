@@ -322,6 +322,15 @@ uhdr_error_info_t uhdr_hip_encode_api1_fused_dev(uhdr_hip_ctx_t* c, const uhdr_r
   }
   chain.reset();
   note_hip(hipMemcpyAsync(c->h_mm, final_mm, 9 * sizeof(float), hipMemcpyDeviceToHost, c->stream), "metadata copy");
+  if (c->defer_md && !striped) {  // the caller synchronises later and finishes the metadata then (finish_deferred_md)
+    if (local.error_code != UHDR_CODEC_OK) return local;
+    c->deferred_md.valid = true;
+    c->deferred_md.run = run;
+    c->deferred_md.cfg = *cfg;
+    c->deferred_md.hdr_ct = hdr->ct;
+    c->deferred_md.use_base_cg = use_base_cg;
+    return ok_status();
+  }
   note_hip(hipStreamSynchronize(c->stream), "synchronize");  // the only host synchronisation: the metadata needs the (merged) range
   if (xchg.error_code != UHDR_CODEC_OK) return xchg;
   if (local.error_code != UHDR_CODEC_OK) return local;
@@ -403,7 +412,19 @@ static uhdr_error_info_t encode_api1_scans_impl(uhdr_hip_ctx_t* c, const uhdr_ra
   for (int i = 0; i < nch; i++) blocks.map_coef[i] = (int16_t*)((uint8_t*)c->enc[0].p + o_map[i]);
   uhdr_raw_image_t gm;
   memset(&gm, 0, sizeof gm);
-  UHDR_TRY(uhdr_hip_encode_api1_fused_dev(c, &ds, &dh, cfg, base_encoding, qt_base, qt_map, &blocks, md, nullptr));
+  c->defer_md = dev;  // device-resident callers: no host synchronisation between the chain and the entropy stage
+  c->deferred_md.valid = false;
+  const uhdr_error_info_t fs = uhdr_hip_encode_api1_fused_dev(c, &ds, &dh, cfg, base_encoding, qt_base, qt_map, &blocks, md, nullptr);
+  c->defer_md = false;
+  if (fs.error_code != UHDR_CODEC_OK) return fs;
+  auto finish_deferred_md = [&]() -> uhdr_error_info_t {  // (after a synchronisation of c->stream)
+    if (!c->deferred_md.valid) return ok_status();
+    c->deferred_md.valid = false;
+    float mm[6];
+    memcpy(mm, c->h_mm, sizeof mm);
+    if (c->deferred_md.run) note_table_stats(c, &c->deferred_md.cfg);
+    return generate_gainmap_finalize_md(&c->deferred_md.cfg, c->deferred_md.hdr_ct, c->deferred_md.use_base_cg, mm, md);
+  };
   if (gainmap_desc) {  // what generateGainMap's freshly allocated image would say (jpegr.cpp:714-716); planes untouched
     gainmap_desc->fmt = nch == 3 ? UHDR_IMG_FMT_24bppRGB888 : UHDR_IMG_FMT_8bppYCbCr400;
     gainmap_desc->cg = hdr->cg; gainmap_desc->ct = hdr->ct; gainmap_desc->range = hdr->range;
@@ -436,7 +457,13 @@ static uhdr_error_info_t encode_api1_scans_impl(uhdr_hip_ctx_t* c, const uhdr_ra
     const uhdr_error_info_t e2 = uhdr_hip_huffman_encode2_dev(c, &sb, base_scan, base_capacity, &nbs, &sm, map_scan, map_capacity, &nms);
     *base_bytes = nbs;
     *map_bytes = nms;
-    return e2;
+    if (e2.error_code != UHDR_CODEC_OK) {
+      (void)hipStreamSynchronize(c->stream);
+      c->deferred_md.valid = false;
+      return e2;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));  // (the entropy stage has synchronised already: the metadata's copy is long done)
+    return finish_deferred_md();
   }
   UHDR_TRY(ensure(c->enc[1], base_capacity + 64));
   UHDR_TRY(ensure(c->enc[2], map_capacity + 64));

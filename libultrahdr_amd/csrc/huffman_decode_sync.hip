@@ -75,6 +75,11 @@ __device__ __forceinline__ uint32_t dropmask16(const uint8_t* __restrict__ data,
   }
   return m;
 }
+// Round 6, measured and dropped: folding the three single-workgroup steps of this file (this scan, the chain's tile-entry walk, the DC
+// partials' scan) into the kernels that feed them by the "last workgroup to finish does it" pattern.  The agent-scope release every
+// workgroup has to make before it takes its ticket (per-XCD L2s are not coherent: buffer_wbl2) costs far more than the 5 us launch it
+// saves once a kernel has hundreds of workgroups: unstuff_count 6 -> 19 us, dc_partial2 7 -> 18 / 10 -> 36 us, chain tiles 5 -> 10 /
+// 7 -> 21 us, the encoder's stuff_count (8100 workgroups) 5 -> 144 us (profiles/r06_last_workgroup_merge_no.txt).
 template <bool RST>
 __global__ __launch_bounds__(256) void unstuff_count_kernel(const uint8_t* __restrict__ data, uint32_t n, uint32_t* __restrict__ counts) {
   __shared__ uint32_t s_cnt;
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(1024) void sync_scan_kernel(uint32_t* __restrict__ 
 // Exclusive scan of n words over many workgroups (the single-workgroup kernel above walks its elements with a stride
 // between lanes: one cache line per lane and instruction, all on one CU -- 80 us for 50 K elements).  Step 1: a workgroup
 // scans its kScanTile consecutive elements (coalesced loads, eight per thread) and publishes their sum; step 2: every
-// workgroup adds the sums of the tiles before it (at most a few dozen).
+// consumer adds the sums of the tiles before it (at most a few dozen): tile_offset below.
 constexpr int kScanThreads = 256, kScanPer = 8, kScanTile = kScanThreads * kScanPer;
 __global__ __launch_bounds__(kScanThreads) void scan_tiles_kernel(uint32_t* __restrict__ v, int n, uint32_t* __restrict__ tile_sum) {
   __shared__ uint32_t s_val[kScanTile];
@@ -158,15 +163,14 @@ __global__ __launch_bounds__(kScanThreads) void scan_tiles_kernel(uint32_t* __re
   }
   if (tid == kScanThreads - 1) tile_sum[blockIdx.x] = s_sum[tid];
 }
-__global__ __launch_bounds__(kScanThreads) void scan_add_kernel(uint32_t* __restrict__ v, int n, const uint32_t* __restrict__ tile_sum) {
+// The block counts' scan is left per tile (scan_tiles_kernel: kScanTile subsequences each, tile sums in scan_tmp); a write-pass workgroup
+// -- 64 to 256 subsequences, never across a tile boundary -- adds the sums of the tiles in front of its own (round 6: was a launch of
+// its own, scan_add_kernel).  Wave-uniform: scalar loads.
+__device__ __forceinline__ uint32_t tile_offset(const HuffSyncArgs& a) {
+  const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x) / (uint32_t)kScanTile));
   uint32_t off = 0;
-  for (int t = 0; t < (int)blockIdx.x; t++) off += tile_sum[t];
-  const int base = (int)blockIdx.x * kScanTile;
-#pragma unroll
-  for (int j = 0; j < kScanPer; j++) {
-    const int i = base + j * kScanThreads + (int)threadIdx.x;
-    if (i < n) v[i] += off;
-  }
+  for (uint32_t t = 0; t < tile; t++) off += a.scan_tmp[t];
+  return off;
 }
 // RST: rst_map gets bit (clean byte index) set where an interval starts (zero-initialised by the caller); rst_partial[chunk]
 // = {markers found, their two sequence sums} -- per chunk, because thousands of atomics on three global words are serialised
@@ -726,10 +730,11 @@ __global__ __launch_bounds__(256) void sync_write_kernel(const HuffSyncArgs a, i
   const uint32_t end_bit = min((i + 1) * a.sub_bits, nbits);
   uint32_t nblk = 0;
   const Staged st = {s_stage, cshift};
-  if (p < end_bit) write_span(a, st, first_byte * 8u, L, p, b, k, end_bit, nblk, a.nblk[i]);  // nblk[] holds the exclusive scan by now
+  const uint32_t blk0 = a.nblk[i] + tile_offset(a);  // nblk[] holds the per-tile exclusive scan by now
+  if (p < end_bit) write_span(a, st, first_byte * 8u, L, p, b, k, end_bit, nblk, blk0);
   if (i == nsub - 1) {
     // the scan must hold exactly total_blocks blocks: fewer = truncated data, more cannot be seen (the loop stops there)
-    if (a.nblk[i] + nblk < a.total_blocks) atomicOr(a.flags + 1, 8u);
+    if (blk0 + nblk < a.total_blocks) atomicOr(a.flags + 1, 8u);
   }
 }
 
@@ -831,9 +836,10 @@ __global__ __launch_bounds__(256) void sync_write2_kernel(const HuffSyncArgs a, 
   const uint32_t end_bit = min((i + 1) * a.sub_bits, nbits);
   uint32_t nblk = 0;
   const Staged st = {s_stage, cshift};
-  if (p < end_bit) write_span2(a, st, first_byte * 8u, L, p, b, k, end_bit, nblk, a.nblk[i]);  // nblk[] holds the exclusive scan by now
+  const uint32_t blk0 = a.nblk[i] + tile_offset(a);  // nblk[] holds the per-tile exclusive scan by now
+  if (p < end_bit) write_span2(a, st, first_byte * 8u, L, p, b, k, end_bit, nblk, blk0);
   if (i == nsub - 1) {
-    if (a.nblk[i] + nblk < a.total_blocks) atomicOr(a.flags + 1, 8u);  // truncated data
+    if (blk0 + nblk < a.total_blocks) atomicOr(a.flags + 1, 8u);  // truncated data
   }
 }
 
@@ -857,6 +863,10 @@ __global__ __launch_bounds__(1024) void hyp_pass0_kernel(const HuffSyncArgs a) {
   extern __shared__ uint32_t s_stage[];
   __shared__ PairLds L;
   load_pair_lds(a, L);
+  if (a.zero_vec) {  // the write pass's scan-order scratch: zeros, written while this pass waits on its lookups
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < a.zero_vec; v += gridDim.x * blockDim.x) a.zero_ptr[v] = z;
+  }
   const uint32_t lane = threadIdx.x & 63u, h = threadIdx.x >> 6;
   const uint32_t i = blockIdx.x * 64u + lane;
   const uint32_t nclean = a.nbytes - *a.nstuffed, nbits = nclean * 8u;
@@ -1225,50 +1235,10 @@ __device__ __forceinline__ void chain_stage_rows(uint8_t (*s_rows)[kMapPitch], i
 }
 __device__ __forceinline__ uint32_t chain_step(const uint8_t* row, uint32_t cur) { return cur == 0xffu ? 0xffu : (uint32_t)row[cur]; }
 
-__global__ __launch_bounds__(kChainWg) void hyp_chain_tiles_kernel(const HuffSyncArgs a, uint8_t* __restrict__ prefix /* [links][slots] */,
-                                                                   uint8_t* __restrict__ tile_map /* [tiles][slots] */) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_links[kChainTile][kMapPitch];  // 13 KB
-  __shared__ __attribute__((aligned(16))) uint8_t s_gmap[kChainGroups][kMapPitch];
-  __shared__ __attribute__((aligned(16))) uint8_t s_gpre[kChainGroups][kMapPitch];
-  const int tid = (int)threadIdx.x;
-  const uint32_t nclean = a.nbytes - *a.nstuffed, nbits = nclean * 8u;
-  const int nsub = (int)((nbits + a.sub_bits - 1) / a.sub_bits);
-  const int nlinks = nsub - 1;
-  const int base = (int)blockIdx.x * kChainTile;
-  if (base >= nlinks) return;
-  chain_stage_rows(s_links, tid, a.hyp_map, base, nlinks);
-  __syncthreads();
-  const int grp = tid / kHuffHypSlots, s = tid - grp * kHuffHypSlots;
-  {
-    uint32_t cur = (uint32_t)s;
-#pragma unroll
-    for (int k = 0; k < kChainGroup; k++) cur = chain_step(s_links[grp * kChainGroup + k], cur);
-    s_gmap[grp][s] = (uint8_t)cur;
-  }
-  __syncthreads();
-  if (tid < kHuffHypSlots) {
-    uint32_t c = (uint32_t)tid;
-#pragma unroll
-    for (int g = 0; g < kChainGroups; g++) {
-      s_gpre[g][tid] = (uint8_t)c;
-      c = chain_step(s_gmap[g], c);
-    }
-    tile_map[(size_t)blockIdx.x * kHuffHypSlots + tid] = (uint8_t)c;
-  }
-  __syncthreads();
-  uint32_t cur = s_gpre[grp][s];
-#pragma unroll
-  for (int k = 0; k < kChainGroup; k++) {
-    const int link = grp * kChainGroup + k, i = base + link;
-    if (i < nlinks) prefix[(size_t)i * kHuffHypSlots + s] = (uint8_t)cur;
-    cur = chain_step(s_links[link], cur);
-  }
-}
-// one workgroup: tile_entry[t] = the slot the true path is in where tile t begins (0xff: lost before that)
-__global__ __launch_bounds__(kChainWg) void hyp_chain_entry_kernel(const HuffSyncArgs a, const uint8_t* __restrict__ tile_map, uint8_t* __restrict__ tile_entry) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_tiles[kChainTile][kMapPitch];
-  __shared__ __attribute__((aligned(16))) uint8_t s_gmap[kChainGroups][kMapPitch];
-  __shared__ uint32_t s_gentry[kChainGroups + 1];
+// tile_entry[t] = the slot the true path is in where tile t begins (0xff: lost before that): one workgroup's walk over the tile maps, 256
+// tiles per pass.  s_tiles / s_gmap: LDS of the caller (the tiles kernel's own arrays, free by then).
+__device__ __forceinline__ void chain_entry_walk(const HuffSyncArgs& a, const uint8_t* __restrict__ tile_map, uint8_t* __restrict__ tile_entry,
+                                                 uint8_t (*s_tiles)[kMapPitch], uint8_t (*s_gmap)[kMapPitch], uint32_t* s_gentry /* kChainGroups + 1 */) {
   const int tid = (int)threadIdx.x;
   const uint32_t nclean = a.nbytes - *a.nstuffed, nbits = nclean * 8u;
   const int nlinks = (int)((nbits + a.sub_bits - 1) / a.sub_bits) - 1;
@@ -1305,6 +1275,54 @@ __global__ __launch_bounds__(kChainWg) void hyp_chain_entry_kernel(const HuffSyn
     carry = s_gentry[kChainGroups];
     __syncthreads();  // the rows are rewritten by the next pass
   }
+}
+// tiles: the prefix maps of every link and the tile's total map
+__global__ __launch_bounds__(kChainWg) void hyp_chain_tiles_kernel(const HuffSyncArgs a, uint8_t* __restrict__ prefix /* [links][slots] */,
+                                                                   uint8_t* __restrict__ tile_map /* [tiles][slots] */) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_links[kChainTile][kMapPitch];  // 13 KB
+  __shared__ __attribute__((aligned(16))) uint8_t s_gmap[kChainGroups][kMapPitch];
+  __shared__ __attribute__((aligned(16))) uint8_t s_gpre[kChainGroups][kMapPitch];
+  const int tid = (int)threadIdx.x;
+  const uint32_t nclean = a.nbytes - *a.nstuffed, nbits = nclean * 8u;
+  const int nsub = (int)((nbits + a.sub_bits - 1) / a.sub_bits);
+  const int nlinks = nsub - 1;
+  const int base = (int)blockIdx.x * kChainTile;
+  if (base < nlinks) {  // (the grid is sized for the stuffed stream)
+    chain_stage_rows(s_links, tid, a.hyp_map, base, nlinks);
+    __syncthreads();
+    const int grp = tid / kHuffHypSlots, s = tid - grp * kHuffHypSlots;
+    {
+      uint32_t cur = (uint32_t)s;
+#pragma unroll
+      for (int k = 0; k < kChainGroup; k++) cur = chain_step(s_links[grp * kChainGroup + k], cur);
+      s_gmap[grp][s] = (uint8_t)cur;
+    }
+    __syncthreads();
+    if (tid < kHuffHypSlots) {
+      uint32_t c = (uint32_t)tid;
+#pragma unroll
+      for (int g = 0; g < kChainGroups; g++) {
+        s_gpre[g][tid] = (uint8_t)c;
+        c = chain_step(s_gmap[g], c);
+      }
+      tile_map[(size_t)blockIdx.x * kHuffHypSlots + tid] = (uint8_t)c;
+    }
+    __syncthreads();
+    uint32_t cur = s_gpre[grp][s];
+#pragma unroll
+    for (int k = 0; k < kChainGroup; k++) {
+      const int link = grp * kChainGroup + k, i = base + link;
+      if (i < nlinks) prefix[(size_t)i * kHuffHypSlots + s] = (uint8_t)cur;
+      cur = chain_step(s_links[link], cur);
+    }
+  }
+}
+// one workgroup: the walk over the tile maps
+__global__ __launch_bounds__(kChainWg) void hyp_chain_entry_kernel(const HuffSyncArgs a, const uint8_t* __restrict__ tile_map, uint8_t* __restrict__ tile_entry) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_tiles[kChainTile][kMapPitch];
+  __shared__ __attribute__((aligned(16))) uint8_t s_gmap[kChainGroups][kMapPitch];
+  __shared__ uint32_t s_gentry[kChainGroups + 1];
+  chain_entry_walk(a, tile_map, tile_entry, s_tiles, s_gmap, s_gentry);
 }
 __global__ __launch_bounds__(kChainThreads) void hyp_chain_walk_kernel(const HuffSyncArgs a, const uint8_t* __restrict__ prefix,
                                                                        const uint8_t* __restrict__ tile_entry) {
@@ -1611,8 +1629,7 @@ hipError_t launch_huffman_decode_sync(const HuffSyncArgs& a, int max_rounds, int
   *final_buf = 0;
   {
     const int nt = (int)((nsub + kScanTile - 1) / kScanTile);
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3(nt), dim3(kScanThreads), 0, s, a.nblk, (int)nsub, a.scan_tmp);
-    if (nt > 1) hipLaunchKernelGGL(scan_add_kernel, dim3(nt), dim3(kScanThreads), 0, s, a.nblk, (int)nsub, (const uint32_t*)a.scan_tmp);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(nt), dim3(kScanThreads), 0, s, a.nblk, (int)nsub, a.scan_tmp);  // (the write pass adds the tile sums: tile_offset)
   }
   if (a.coef_scan && !a.rst_map) {
     launch_write2(a, nsub, *final_buf, s);
@@ -1690,8 +1707,7 @@ hipError_t launch_huffman_decode_hyp(const HuffSyncArgs& a, int* dc_partial, uin
   mark();
   {
     const int nt = (int)((nsub + kScanTile - 1) / kScanTile);
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3(nt), dim3(kScanThreads), 0, s, a.nblk, (int)nsub, a.scan_tmp);
-    if (nt > 1) hipLaunchKernelGGL(scan_add_kernel, dim3(nt), dim3(kScanThreads), 0, s, a.nblk, (int)nsub, (const uint32_t*)a.scan_tmp);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(nt), dim3(kScanThreads), 0, s, a.nblk, (int)nsub, a.scan_tmp);  // (the write pass adds the tile sums: tile_offset)
   }
   mark();
   if (a.coef_scan && !a.rst_map) {

@@ -462,15 +462,15 @@ __global__ __launch_bounds__(64) void huff_stream_kernel(const HuffArgs a, const
 // prefix)` is called for every element.  Round 5's form walked `per` consecutive elements per thread straight from global memory --
 // one cache line per lane and instruction, each load waiting for the one before: 40 us for the 6075 chunk counts of a 4K map.
 constexpr int kScanTileWords = 8192;
-template <typename Sink>
-__device__ __forceinline__ uint64_t wg_scan_tiles(const uint32_t* __restrict__ v, int n, uint32_t* s_val /* kScanTileWords */, uint64_t* s_sum /* 1024 */, Sink sink) {
+template <int NT = 1024, typename Sink>  // NT threads; tiles of 8 * NT words
+__device__ __forceinline__ uint64_t wg_scan_tiles(const uint32_t* __restrict__ v, int n, uint32_t* s_val /* 8 * NT */, uint64_t* s_sum /* NT */, Sink sink) {
   const int tid = (int)threadIdx.x;
   uint64_t carry = 0;
-  for (int base = 0; base < n; base += kScanTileWords) {
+  for (int base = 0; base < n; base += 8 * NT) {
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-      const int i = base + j * 1024 + tid;
-      s_val[j * 1024 + tid] = i < n ? v[i] : 0u;
+      const int i = base + j * NT + tid;
+      s_val[j * NT + tid] = i < n ? v[i] : 0u;
     }
     __syncthreads();
     uint32_t x[8];
@@ -479,7 +479,7 @@ __device__ __forceinline__ uint64_t wg_scan_tiles(const uint32_t* __restrict__ v
     for (int j = 0; j < 8; j++) { x[j] = s_val[tid * 8 + j]; sum += x[j]; }
     s_sum[tid] = sum;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
+    for (int d = 1; d < NT; d <<= 1) {
       const uint64_t y = tid >= d ? s_sum[tid - d] : 0;
       __syncthreads();
       s_sum[tid] += y;
@@ -492,7 +492,7 @@ __device__ __forceinline__ uint64_t wg_scan_tiles(const uint32_t* __restrict__ v
       if (i < n) sink(i, x[j], run);
       run += x[j];
     }
-    carry += s_sum[1023];
+    carry += s_sum[NT - 1];
     __syncthreads();  // s_val / s_sum are rewritten by the next tile
   }
   return carry;
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(256) void huff_stuff_count_kernel(const HuffStream 
   const uint64_t total_bits = (uint64_t)t.meta[0] | ((uint64_t)t.meta[1] << 32);
   const uint64_t nraw = (total_bits + 7u) >> 3;
   const uint64_t base = (uint64_t)blockIdx.x * kStuffChunk + threadIdx.x * 16u;
-  if ((uint64_t)blockIdx.x * kStuffChunk >= nraw) {  // (wave-uniform) nothing of the stream in this chunk
+  if ((uint64_t)blockIdx.x * kStuffChunk >= nraw) {  // (workgroup-uniform) nothing of the stream in this chunk
     if (threadIdx.x == 0) counts[blockIdx.x] = 0;
     return;
   }
@@ -561,7 +561,8 @@ __global__ __launch_bounds__(256) void huff_stuff_count_kernel(const HuffStream 
   if (threadIdx.x == 0) counts[blockIdx.x] = s_n;
 }
 
-// exclusive scan of the chunk counts in place (one workgroup); out_bytes = raw bytes + stuffed zeros
+// exclusive scan of the chunk counts in place (one workgroup); out_bytes = raw bytes + stuffed zeros.  (Folding this into the count
+// kernel's last workgroup was measured and dropped: see huffman_decode_sync.hip, unstuff_count_kernel.)
 __global__ __launch_bounds__(1024) void huff_stuff_scan_kernel(uint32_t* __restrict__ counts, int nchunks, const HuffStream t, uint64_t* __restrict__ out_bytes) {
   __shared__ uint32_t s_val[kScanTileWords];
   __shared__ uint64_t s_sum[1024];
@@ -569,7 +570,7 @@ __global__ __launch_bounds__(1024) void huff_stuff_scan_kernel(uint32_t* __restr
   const uint64_t nraw = (total_bits + 7u) >> 3;
   const int used = (int)min((uint64_t)nchunks, (nraw + kStuffChunk - 1) / kStuffChunk);  // chunks beyond the stream hold zeros and are never read
   // (< 2^32: the stream is bounded by the 32-bit capacity checked on the host)
-  const uint64_t total = wg_scan_tiles(counts, used, s_val, s_sum, [&](int i, uint32_t, uint64_t run) { counts[i] = (uint32_t)run; });
+  const uint64_t total = wg_scan_tiles<1024>(counts, used, s_val, s_sum, [&](int i, uint32_t, uint64_t run) { counts[i] = (uint32_t)run; });
   if (threadIdx.x == 1023) *out_bytes = nraw + total;
 }
 

@@ -399,6 +399,10 @@ struct HuffSyncArgs {
   // order, the DC DIFFERENCE at [0]; zero-initialised) and coef_place_kernel moves them to the component arrays in natural
   // order with the DC prediction applied; nullptr: form 1 (stores into zero-initialised JBLOCK arrays + dcd[])
   int16_t* coef_scan;
+  // round 6: pass 0 zero-fills that scratch on the side (its lanes wait on table lookups, the memory system is idle): zero_vec 16-byte
+  // pieces from zero_ptr, grid-stride; 0: the host has enqueued a fill instead (the rounds scheme)
+  uint4* zero_ptr;
+  uint32_t zero_vec;
   // restart intervals (nullptr / 0: a scan without markers): see restart_jump in huffman_decode_sync.hip
   const uint32_t* rst_map;    // one bit per byte of the clean stream: an interval starts here
   uint32_t rst_blocks;        // blocks per interval (restart interval x blocks per MCU)
