@@ -14,6 +14,7 @@
 //                          accepts (RGB888 base, odd sizes, odd or non-integer scale, gamma != 1 at scale > 1).
 // HBM-bound by design: 1.5 B (4:2:0) + map + 8 B (F16) per pixel, no intermediate buffers.
 #include <cstdlib>
+#include "lds_copy.h"
 #include <type_traits>
 
 #include "idct_core.h"
@@ -238,9 +239,9 @@ __global__ __launch_bounds__(kBlock) void apply_generic_kernel(const ApplyParams
   __shared__ float s_srgb[kSrgbN];
   __shared__ float s_gain[3 * kGainN];
   __shared__ float s_u8f[256];
-  for (uint32_t i = threadIdx.x; i < kSrgbN; i += kBlock) s_srgb[i] = p.tables[ApplyTables::kSrgbOff + i];
-  for (uint32_t i = threadIdx.x; i < 3 * kGainN; i += kBlock) s_gain[i] = p.tables[ApplyTables::kGainOff + i];
-  for (uint32_t i = threadIdx.x; i < 256; i += kBlock) s_u8f[i] = p.tables[ApplyTables::kU8fOff + i];
+  copy_to_lds(s_srgb, p.tables + ApplyTables::kSrgbOff, kSrgbN, threadIdx.x, kBlock);
+  copy_to_lds(s_gain, p.tables + ApplyTables::kGainOff, 3 * kGainN, threadIdx.x, kBlock);
+  copy_to_lds(s_u8f, p.tables + ApplyTables::kU8fOff, 256u, threadIdx.x, kBlock);
   __syncthreads();
   const float* srgb = s_srgb;
   const float* gain_tab = s_gain;
@@ -484,12 +485,12 @@ __device__ __forceinline__ void apply_quad_body(const ApplyParams& p) {
   // 16-byte copies: every region of the table block the host laid out as an LDS image (uhdr_types.h: ApplyTables) is a
   // multiple of four floats and starts on a 16-byte boundary
   auto copy16 = [&](float* dst, const float* src, uint32_t nfloats) {
-    for (uint32_t i = tid; i < nfloats / 4; i += BLK) ((float4*)dst)[i] = ((const float4*)src)[i];
+    copy_words_to_lds<4>((uint32_t*)dst, (const uint32_t*)src, nfloats, tid, BLK);  // (lds_copy.h: four 16-byte loads in flight per thread)
   };
   auto stage_tables = [&]() {
     copy16(s_srgb, p.tables + ApplyTables::kSrgbPadOff, kSrgbPad);
     if constexpr (OUT != 0) {
-      for (uint32_t i = tid; i < p.oetf_n; i += BLK) s_code[i] = p.oetf_buckets[i];
+      copy_to_lds(s_code, p.oetf_buckets, p.oetf_n * (uint32_t)(sizeof(s_code[0]) / 4), tid, BLK);
     }
     if constexpr (BASE == 0 || BASE == 3) {
       copy16(s_cv, p.tables + ApplyTables::kChromaVOff, 512);

@@ -15,6 +15,7 @@
 //
 // Coefficients are bit-identical to the unfused chain (tests/test_gpu_parity.py::test_api1_fused_chain_equals_the_operators).
 #include <string.h>
+#include "lds_copy.h"
 
 #include "encode_core.h"
 
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(kMapBlock) void map_blocks_kernel(const MapBlocksPa
     const uint2* src = (const uint2*)((const char*)p.dev + kAffineTablesOff);
 #pragma unroll
     for (int c = 0; c < NCH; c++)
-      for (uint32_t i = threadIdx.x; i < st[c].n; i += kBlock) s_tab[c][i] = src[(size_t)c * kAffTabMax + i];
+      copy_to_lds(s_tab[c], src + (size_t)c * kAffTabMax, st[c].n * 2u, threadIdx.x, kBlock);
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;

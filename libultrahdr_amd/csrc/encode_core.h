@@ -16,6 +16,7 @@
 //     max commute with the monotone log2, and pass 2's byte is a step function of the ratio (generate_gainmap.hip).
 #pragma once
 #include "exact_math.h"
+#include "lds_copy.h"
 #include "pixel_io.h"
 #include "uhdr_types.h"
 
@@ -104,13 +105,11 @@ __device__ __forceinline__ uint32_t step_code(float v, const uint2* tab, const S
   return code;
 }
 __device__ __forceinline__ void stage_step_tab(uint2* dst, const StepTab& t, uint32_t tid, uint32_t nthreads) {
-  if (t.tab)
-    for (uint32_t i = tid; i < t.n; i += nthreads) dst[i] = t.tab[i];
+  if (t.tab) copy_to_lds(dst, t.tab, t.n * 2u, tid, nthreads);  // (lds_copy.h: several 16-byte loads in flight per thread)
 }
 // the float64 pow table of srgbOetf (exact_math.h: pow_direct_f32), 16-byte copies
 __device__ __forceinline__ void stage_pow_tab(double* dst, const double* math_tab, uint32_t tid, uint32_t nthreads) {
-  const double2* src = (const double2*)(math_tab + kPowDirOff);
-  for (uint32_t i = tid; i < (uint32_t)kPowDirN; i += nthreads) ((double2*)dst)[i] = src[i];
+  copy_to_lds(dst, math_tab + kPowDirOff, (uint32_t)kPowDirN * 4u, tid, nthreads);
 }
 
 // linear HDR rgb -> linear Display-P3 SDR rgb in [0, 1]: globalTonemap (jpegr.cpp:1951-1977), gamut conversion to P3, clamp.

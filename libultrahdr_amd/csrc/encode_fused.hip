@@ -14,6 +14,7 @@
 // outputs against tone_map -> generate_gainmap -> convert_raw_input_to_ycbcr, bit for bit.
 // Conditions: RGB HDR input (RGBA1010102 / RGBA-F16), gain map at full resolution (scale 1).
 #include "encode_core.h"
+#include "lds_copy.h"
 
 namespace uhdr {
 int fused_grid(uint32_t tiles, int per_cu);
@@ -37,13 +38,12 @@ template <int HDRF, bool TWO_PASS>
 __global__ __launch_bounds__(kBlock) void encode_api0_fused_kernel(const FusedParams p, float* partials) {
   __shared__ FusedLds<HDRF> L;
   const uint32_t tid = threadIdx.x;
-  for (uint32_t i = tid; i < 256; i += kBlock) L.srgb_of_byte[i] = p.gen.srgb_of_byte[i];
+  copy_to_lds(L.srgb_of_byte, p.gen.srgb_of_byte, 256u, tid, kBlock);
   constexpr bool code_lin = HDRF == UHDR_IMG_FMT_32bppRGBA1010102;  // launch_encode_api0_fused checks that lin10 is there
   if constexpr (code_lin) {
-    for (uint32_t i = tid; i < 1024; i += kBlock) L.hdr[i] = p.tm.lin10[i];
+    copy_to_lds(L.hdr, p.tm.lin10, 1024u, tid, kBlock);
   } else {
-    if (p.tm.hdr_inv_lut)
-      for (uint32_t i = tid; i < (uint32_t)p.tm.hdr_inv_n; i += kBlock) L.hdr[i] = p.tm.hdr_inv_lut[i];
+    if (p.tm.hdr_inv_lut) copy_to_lds(L.hdr, p.tm.hdr_inv_lut, (uint32_t)p.tm.hdr_inv_n, tid, kBlock);
   }
   stage_step_tab(L.srgb8, p.tm.srgb8, tid, kBlock);
   stage_step_tab(L.gain8, p.gen.gain8, tid, kBlock);
@@ -112,8 +112,9 @@ template <bool TWO_PASS, int GM, int MC, int TG>  // GM: 0 no gamut conversion o
 __global__ __launch_bounds__(kBlock) void encode_api0_fused4_kernel(const FusedParams p, float* partials) {
   __shared__ Fused4Lds L;
   const uint32_t tid = threadIdx.x;
-  for (uint32_t i = tid; i < 256; i += kBlock) { L.srgb_of_byte[i] = p.gen.srgb_of_byte[i]; L.u8[i] = (float)i / 255.0f; }
-  for (uint32_t i = tid; i < 1024; i += kBlock) L.hdr[i] = p.tm.lin10[i];
+  copy_to_lds(L.srgb_of_byte, p.gen.srgb_of_byte, 256u, tid, kBlock);
+  for (uint32_t i = tid; i < 256; i += kBlock) L.u8[i] = (float)i / 255.0f;
+  copy_to_lds(L.hdr, p.tm.lin10, 1024u, tid, kBlock);
   stage_step_tab(L.srgb8, p.tm.srgb8, tid, kBlock);
   if constexpr (!TWO_PASS) stage_step_tab(L.gain8, p.gen.gain8, tid, kBlock);
   __syncthreads();

@@ -19,6 +19,7 @@
 // Across GPUs the six log2 extrema are all-reduced by the host layer (one RCCL min over {min, -max}) between the
 // reduce and the finalize halves of that kernel.
 #include "encode_core.h"
+#include "lds_copy.h"
 
 namespace uhdr {
 namespace {
@@ -301,7 +302,7 @@ __device__ __forceinline__ bool stage_affine_tabs(const AffineParams& p, AffineL
     const uint2* src = (const uint2*)((const char*)p.dev + kAffineTablesOff);
 #pragma unroll
     for (int c = 0; c < NCH; c++)
-      for (uint32_t i = tid; i < st[c].n; i += nthreads) L.tab[c][i] = src[(size_t)c * kAffTabMax + i];
+      copy_to_lds(L.tab[c], src + (size_t)c * kAffTabMax, st[c].n * 2u, tid, nthreads);
   }
   __syncthreads();
   return ok;

@@ -31,5 +31,31 @@ __device__ __forceinline__ void copy_words_to_lds(uint32_t* dst, const uint32_t*
   }
 }
 
+// Any word count, any alignment: 16-byte loads when both sides allow it, else dword loads -- UNROLL of them in flight either way.
+template <int UNROLL = 8>
+__device__ __forceinline__ void copy_to_lds(void* dst_, const void* __restrict__ src_, uint32_t nwords, uint32_t tid, uint32_t nthreads) {
+  uint32_t* dst = (uint32_t*)dst_;
+  const uint32_t* src = (const uint32_t*)src_;
+  if ((((uintptr_t)src | (uintptr_t)dst) & 15u) == 0) {
+    const uint32_t body = nwords & ~3u;
+    copy_words_to_lds<UNROLL>(dst, src, body, tid, nthreads);
+    if (body + tid < nwords) dst[body + tid] = src[body + tid];  // (at most three words)
+    return;
+  }
+  for (uint32_t i = tid; i < nwords; i += UNROLL * nthreads) {
+    uint32_t v[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+      const uint32_t j = i + (uint32_t)u * nthreads;
+      v[u] = src[j < nwords ? j : i];
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+      const uint32_t j = i + (uint32_t)u * nthreads;
+      if (j < nwords) dst[j] = v[u];
+    }
+  }
+}
+
 }  // namespace uhdr
 #endif

@@ -11,6 +11,7 @@
 // consecutive quads / pixels of one row.  Round 4: Markstein divisions, v_cvt_rpi table indices and the direct pow
 // table (encode_core.h) -- P010 4K 51 -> see DESIGN.md 5.2.
 #include "encode_core.h"
+#include "lds_copy.h"
 
 namespace uhdr {
 namespace {
@@ -49,8 +50,7 @@ constexpr int kQuadBlock = 512;
 template <int GAMUT, bool LUT>
 __global__ __launch_bounds__(kQuadBlock) void tonemap_p010_kernel(const ToneMapParams p) {
   __shared__ ToneLds L;
-  if (LUT)
-    for (uint32_t i = threadIdx.x; i < (uint32_t)p.hdr_inv_n; i += kQuadBlock) L.hdr[i] = p.hdr_inv_lut[i];
+  if (LUT) copy_to_lds(L.hdr, p.hdr_inv_lut, (uint32_t)p.hdr_inv_n, threadIdx.x, kQuadBlock);
   stage_pow_tab(L.powt, p.math_tab, threadIdx.x, kQuadBlock);
   fill_unorm_tables(L.unorm, threadIdx.x, kQuadBlock);
   __syncthreads();
@@ -123,9 +123,9 @@ __global__ __launch_bounds__(kBlock) void tonemap_pixel_kernel(const ToneMapPara
   const bool code_lin = HDRF == UHDR_IMG_FMT_32bppRGBA1010102 && p.lin10 != nullptr;
   const bool bytes_tab = p.sdr.fmt == UHDR_IMG_FMT_32bppRGBA8888 && p.srgb8.tab != nullptr;
   if (code_lin) {
-    for (uint32_t i = threadIdx.x; i < 1024; i += kBlock) L.hdr[i] = p.lin10[i];
+    copy_to_lds(L.hdr, p.lin10, 1024u, threadIdx.x, kBlock);
   } else if (p.hdr_inv_lut) {
-    for (uint32_t i = threadIdx.x; i < (uint32_t)p.hdr_inv_n; i += kBlock) L.hdr[i] = p.hdr_inv_lut[i];
+    copy_to_lds(L.hdr, p.hdr_inv_lut, (uint32_t)p.hdr_inv_n, threadIdx.x, kBlock);
   }
   if (bytes_tab) stage_step_tab(s_srgb8, p.srgb8, threadIdx.x, kBlock);
   else stage_pow_tab(L.powt, p.math_tab, threadIdx.x, kBlock);
