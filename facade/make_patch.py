@@ -107,8 +107,10 @@ def jpegr_cpp(t):
                      "    uhdr_hip_seam::Api1Files hip_files;\n    uhdr_error_info_t hip_status;\n"
                      "    if (uhdr_hip_seam::encode_api1(hdr_intent, sdr_intent, quality, mMapCompressQuality, &mMapDimensionScaleFactor,\n"
                      "                                   mUseMultiChannelGainMap, mGamma, mEncPreset, mMinContentBoost,\n"
-                     "                                   mMaxContentBoost, mTargetDispPeakBrightness, hip_icc_base->getData(),\n"
-                     "                                   hip_icc_base->getLength(), hip_icc_map ? hip_icc_map->getData() : nullptr,\n"
+                     "                                   mMaxContentBoost, mTargetDispPeakBrightness,\n"
+                     "                                   hip_icc_base ? hip_icc_base->getData() : nullptr,  // (nullptr for a gamut IccHelper does not know:\n"
+                     "                                   hip_icc_base ? hip_icc_base->getLength() : 0,      //  the device call then words the reference's error)\n"
+                     "                                   hip_icc_map ? hip_icc_map->getData() : nullptr,\n"
                      "                                   hip_icc_map ? hip_icc_map->getLength() : 0, hip_comment, &metadata, &hip_files,\n"
                      "                                   &hip_status)) {\n"
                      "      if (hip_status.error_code != UHDR_CODEC_OK) return hip_status;\n"
@@ -118,6 +120,40 @@ def jpegr_cpp(t):
                      "      UHDR_ERR_CHECK(appendGainMap(&sdr_intent_compressed, &gainmap_compressed, exif, /* icc */ nullptr,\n"
                      "                                   /* icc size */ 0, &metadata, dest));\n"
                      "      return g_no_error;\n    }\n  }\n#endif\n")
+    # encodeJPEGR API-0 (round 6): RGBA1010102 / RGBA half-float intents as one device sequence (BASELINE config 3); P010 keeps the stage seams
+    t = insert_before(t, "  std::unique_ptr<uhdr_raw_image_ext_t> sdr_intent = std::make_unique<uhdr_raw_image_ext_t>(\n"
+                         "      sdr_intent_fmt, UHDR_CG_UNSPECIFIED, UHDR_CT_UNSPECIFIED, UHDR_CR_UNSPECIFIED, hdr_intent->w,\n"
+                         "      hdr_intent->h, 64);\n\n  // tone map\n",
+                      "#ifdef UHDR_ENABLE_HIP\n  if (uhdr_hip_seam::enabled() && sdr_intent_fmt == UHDR_IMG_FMT_32bppRGBA8888) {\n"
+                      "    uhdr_gainmap_metadata_ext_t hip_metadata(kJpegrVersion);\n"
+                      "    std::shared_ptr<DataStruct> hip_icc_map =  // compressGainMap's choice (jpegr.cpp:520-528)\n"
+                      "        kWriteXmpMetadata ? nullptr : IccHelper::writeIccProfile(hdr_intent->ct, hdr_intent->cg);\n"
+                      "    char hip_comment[255];  // JpegEncoderHelper::encode's COM marker of a gain-map image\n"
+                      "    snprintf(hip_comment, sizeof hip_comment,\n"
+                      "             \"Source: google libuhdr v%s, Coder: libjpeg v%d, Attrib: GainMap Image\",\n"
+                      "             UHDR_LIB_VERSION_STR, JPEG_LIB_VERSION);\n"
+                      "    std::shared_ptr<DataStruct> hip_icc_base;  // written once the device has said which gamut the rendition has\n"
+                      "    auto hip_icc_cb = [](void* user, uhdr_color_gamut_t cg) -> uhdr_hip_seam::IccBytes {\n"
+                      "      auto* slot = static_cast<std::shared_ptr<DataStruct>*>(user);\n"
+                      "      *slot = IccHelper::writeIccProfile(UHDR_CT_SRGB, cg);\n"
+                      "      return *slot ? uhdr_hip_seam::IccBytes{(*slot)->getData(), (size_t)(*slot)->getLength()}\n"
+                      "                   : uhdr_hip_seam::IccBytes{nullptr, 0};\n    };\n"
+                      "    uhdr_hip_seam::Api1Files hip_files;\n    uhdr_error_info_t hip_status;\n"
+                      "    uhdr_color_gamut_t hip_sdr_cg = UHDR_CG_UNSPECIFIED;\n"
+                      "    if (uhdr_hip_seam::encode_api0(hdr_intent, quality, mMapCompressQuality, &mMapDimensionScaleFactor,\n"
+                      "                                   mUseMultiChannelGainMap, mGamma, mMinContentBoost, mMaxContentBoost,\n"
+                      "                                   mTargetDispPeakBrightness, hip_icc_cb, &hip_icc_base,\n"
+                      "                                   hip_icc_map ? hip_icc_map->getData() : nullptr,\n"
+                      "                                   hip_icc_map ? hip_icc_map->getLength() : 0, hip_comment, &hip_metadata,\n"
+                      "                                   &hip_sdr_cg, &hip_files, &hip_status)) {\n"
+                      "      if (hip_status.error_code != UHDR_CODEC_OK) return hip_status;\n"
+                      "      mEncPreset = UHDR_USAGE_REALTIME;  // as below\n"
+                      "      uhdr_compressed_image_t gainmap_compressed = hip_files.gainmap();\n"
+                      "      uhdr_compressed_image_t sdr_intent_compressed = hip_files.base();\n"
+                      "      sdr_intent_compressed.cg = hip_sdr_cg;\n"
+                      "      UHDR_ERR_CHECK(appendGainMap(&sdr_intent_compressed, &gainmap_compressed, exif, /* icc */ nullptr,\n"
+                      "                                   /* icc size */ 0, &hip_metadata, dest));\n"
+                      "      return g_no_error;\n    }\n  }\n#endif\n")
     t = insert_before(t, "#ifdef UHDR_ENABLE_GLES\n  if (mUhdrGLESCtxt != nullptr) {\n",
                       "#ifdef UHDR_ENABLE_HIP\n  {\n    uhdr_error_info_t hip_status;\n"
                       "    if (uhdr_hip_seam::apply_gainmap(sdr_intent, gainmap_img, gainmap_metadata, output_ct, output_format,\n"

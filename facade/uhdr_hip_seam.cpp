@@ -343,6 +343,114 @@ bool encode_api1(uhdr_raw_image_t* hdr_intent, uhdr_raw_image_t* sdr_intent, int
   return true;
 }
 
+namespace {
+// file = SOI + JFIF APP0 (20 bytes) | APP2 ICC | COM | DQT .. SOS | data | EOI  (jcmarker.c's order around the helper's markers); the scan
+// already sits at f + lead
+size_t finish_file(unsigned char* f, const unsigned char* hdr, size_t nh, const void* icc, size_t icc_size, const char* com, size_t scan_bytes) {
+  unsigned char* p = f;
+  memcpy(p, hdr, 20); p += 20;
+  auto marker = [&](int code, const void* d, size_t n) {
+    p[0] = 0xff; p[1] = (unsigned char)code; p[2] = (unsigned char)((n + 2) >> 8); p[3] = (unsigned char)((n + 2) & 0xff);
+    memcpy(p + 4, d, n);
+    p += 4 + n;
+  };
+  if (icc && icc_size) marker(0xe2, icc, icc_size);
+  if (com) marker(0xfe, com, strlen(com));
+  memcpy(p, hdr + 20, nh - 22); p += nh - 22;
+  p += scan_bytes;
+  p[0] = 0xff; p[1] = 0xd9;
+  return (size_t)(p + 2 - f);
+}
+size_t lead_bytes(size_t nh, size_t icc, const char* com) { return 20 + (icc ? 4 + icc : 0) + (com ? 4 + strlen(com) : 0) + (nh - 22); }
+}  // namespace
+
+bool encode_api0(uhdr_raw_image_t* hdr_intent, int base_quality, int map_quality, int* scale_factor, bool multi_channel, float gamma,
+                 float min_content_boost, float max_content_boost, float target_disp_peak_brightness,
+                 IccBytes (*base_icc)(void* user, uhdr_color_gamut_t cg), void* icc_user, const void* map_icc, size_t map_icc_size,
+                 const char* map_comment, ultrahdr::uhdr_gainmap_metadata_ext_t* gainmap_metadata, uhdr_color_gamut_t* sdr_cg, Api1Files* out,
+                 uhdr_error_info_t* st) {
+  // declining costs nothing: no upload has happened -- the per-stage seams (tone_map, generate_gainmap, convert_raw_input_to_ycbcr, 2 x
+  // jpeg_encode_scan) run as before
+  if (!cur() || !hdr_intent || !gainmap_metadata || !out || !scale_factor || !base_icc || !sdr_cg) return false;
+  if (getenv("UHDR_HIP_SEAM_NO_FUSED_ENCODE") || getenv("UHDR_HIP_SEAM_CPU_ENTROPY") || getenv("UHDR_HIP_SEAM_RESTART_INTERVAL") ||
+      getenv("UHDR_HIP_SEAM_DEVICE_ENTROPY") || getenv("UHDR_HIP_SEAM_EAGER_DOWNLOADS"))
+    return false;
+  if (hdr_intent->fmt != UHDR_IMG_FMT_32bppRGBA1010102 && hdr_intent->fmt != UHDR_IMG_FMT_64bppRGBAHalfFloat) return false;
+  if (*scale_factor != 1) return false;
+  const unsigned w = hdr_intent->w, h = hdr_intent->h;
+  if (w == 0 || h == 0 || w % 8 || h % 8 || w > 65535 || h > 65535) return false;
+  if (map_icc_size > 65533 || (map_comment && strlen(map_comment) > 65533)) return false;
+  if (base_quality < 0 || base_quality > 100 || map_quality < 0 || map_quality > 100) return false;
+  enter();
+  uhdr_hip_encode_cfg_t cfg;
+  cfg.map_dimension_scale_factor = 1;
+  cfg.use_multi_channel_gainmap = multi_channel;
+  cfg.gamma = gamma;
+  cfg.preset = UHDR_USAGE_REALTIME;  // jpegr.cpp:207
+  cfg.min_content_boost = min_content_boost;
+  cfg.max_content_boost = max_content_boost;
+  cfg.target_disp_peak_nits = target_disp_peak_brightness;
+  cfg.sdr_is_601 = 0;
+  cfg.use_luminance = 0;  // jpegr.cpp:213-214
+  uint16_t qt_base[2][64], qt_map[2][64];
+  for (int t = 0; t < 2; t++) {
+    uhdr_hip_jpeg_quant_table(base_quality, t, qt_base[t]);
+    uhdr_hip_jpeg_quant_table(map_quality, t, qt_map[t]);
+  }
+  const int nch = multi_channel ? 3 : 1;
+  uhdr_hip_jpeg_scan_t sb, sm;
+  memset(&sb, 0, sizeof sb);
+  memset(&sm, 0, sizeof sm);
+  sb.num_components = 3;
+  sm.num_components = nch;
+  sb.w = sm.w = w;
+  sb.h = sm.h = h;
+  for (int i = 0; i < 3; i++) { sb.blocks_w[i] = (int)(w / 8); sb.blocks_h[i] = (int)(h / 8); sb.h_samp[i] = sb.v_samp[i] = 1; }
+  for (int i = 0; i < nch; i++) { sm.blocks_w[i] = (int)(w / 8); sm.blocks_h[i] = (int)(h / 8); sm.h_samp[i] = sm.v_samp[i] = 1; }
+  unsigned char hb[2048], hm[2048];
+  const unsigned char none = 0;
+  const size_t nhb = uhdr_hip_jpeg_assemble(&sb, qt_base[0], qt_base[1], &none, 0, hb, sizeof hb);
+  const size_t nhm = uhdr_hip_jpeg_assemble(&sm, qt_map[0], qt_map[nch == 3 ? 1 : 0], &none, 0, hm, sizeof hm);
+  if (nhb < 22 || nhm < 22) return false;
+  // the base file's ICC profile depends on the gamut the tone map gives its rendition: room for the largest the helper writes is left in
+  // front of the scan, the file is closed up afterwards
+  constexpr size_t kIccRoom = 4096;
+  const size_t lead_m = lead_bytes(nhm, map_icc ? map_icc_size : 0, map_comment);
+  const size_t lead_b_max = lead_bytes(nhb, kIccRoom, nullptr);
+  const size_t cap_b = (size_t)w * h * 3 + (1u << 16), cap_m = (size_t)w * h * nch + (1u << 16);  // one byte per coefficient: never seen exceeded
+  out->base_data.reset(new (std::nothrow) unsigned char[lead_b_max + cap_b + 2]);
+  out->gainmap_data.reset(new (std::nothrow) unsigned char[lead_m + cap_m + 2]);
+  if (!out->base_data || !out->gainmap_data) return false;
+  uhdr_gainmap_metadata_t md;
+  memset(&md, 0, sizeof md);
+  uhdr_raw_image_t gm_desc;
+  memset(&gm_desc, 0, sizeof gm_desc);
+  size_t nb = 0, nm = 0;
+  uhdr_color_gamut_t cg = UHDR_CG_UNSPECIFIED;
+  *st = uhdr_hip_encode_api0_scans(cur(), hdr_intent, &cfg, qt_base, qt_map, &md, &gm_desc, &cg, out->base_data.get() + lead_b_max, cap_b, &nb,
+                                   out->gainmap_data.get() + lead_m, cap_m, &nm);
+  if (st->error_code == UHDR_CODEC_MEM_ERROR) {  // a stream busier than one byte per coefficient: the per-stage seams size their buffers from the answer
+    note("encode_api0_fused", false, st->has_detail ? st->detail : "per-stage seams");
+    return false;
+  }
+  if (!handled(*st, "encode_api0_fused")) return false;
+  if (st->error_code != UHDR_CODEC_OK) return true;
+  const IccBytes icc = base_icc(icc_user, cg);
+  if (icc.size > kIccRoom || icc.size > 65533) {
+    note("encode_api0_fused", false, "ICC profile larger than expected");
+    return false;
+  }
+  const size_t lead_b = lead_bytes(nhb, icc.data ? icc.size : 0, nullptr);
+  if (lead_b != lead_b_max) memmove(out->base_data.get() + lead_b, out->base_data.get() + lead_b_max, nb);
+  out->base_size = finish_file(out->base_data.get(), hb, nhb, icc.data, icc.data ? icc.size : 0, nullptr, nb);
+  out->gainmap_size = finish_file(out->gainmap_data.get(), hm, nhm, map_icc, map_icc ? map_icc_size : 0, map_comment, nm);
+  out->base_capacity = lead_b_max + cap_b + 2;
+  out->gainmap_capacity = lead_m + cap_m + 2;
+  static_cast<uhdr_gainmap_metadata_t&>(*gainmap_metadata) = md;
+  *sdr_cg = cg;
+  return true;
+}
+
 bool tone_map(uhdr_raw_image_t* hdr_intent, uhdr_raw_image_t* sdr_intent, uhdr_error_info_t* st) {
   // every exit that leaves the work to the reference's CPU code drops the device-resident copies: that code may write the
   // host buffers in place

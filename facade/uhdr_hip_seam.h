@@ -118,6 +118,17 @@ bool encode_api1(uhdr_raw_image_t* hdr_intent, uhdr_raw_image_t* sdr_intent, int
                  float target_disp_peak_brightness, const void* base_icc, size_t base_icc_size, const void* map_icc,
                  size_t map_icc_size, const char* map_comment, ultrahdr::uhdr_gainmap_metadata_ext_t* gainmap_metadata,
                  Api1Files* out, uhdr_error_info_t* st);
+// JpegR::encodeJPEGR API-0 (jpegr.cpp:179-244) as ONE device sequence for RGBA1010102 / RGBA half-float HDR intents (round 6; BASELINE
+// config 3): tone map + one-pass gain map + RGB -> YCbCr 4:4:4 fused, FDCTs, both scans Huffman-coded (uhdr_hip_encode_api0_scans).
+// base_icc(cg): the caller's IccHelper::writeIccProfile(UHDR_CT_SRGB, cg) for the gamut the tone-mapped rendition gets -- asked for through
+// the callback because that gamut is only known once the device has answered.  false: declined (P010 / YCbCr 4:4:4 intents, a scale factor
+// other than 1, dimensions that are not multiples of 8, ...): the per-stage seams run as before.
+struct IccBytes { const void* data; size_t size; };
+bool encode_api0(uhdr_raw_image_t* hdr_intent, int base_quality, int map_quality, int* scale_factor, bool multi_channel, float gamma,
+                 float min_content_boost, float max_content_boost, float target_disp_peak_brightness,
+                 IccBytes (*base_icc)(void* user, uhdr_color_gamut_t cg), void* icc_user, const void* map_icc, size_t map_icc_size,
+                 const char* map_comment, ultrahdr::uhdr_gainmap_metadata_ext_t* gainmap_metadata, uhdr_color_gamut_t* sdr_cg, Api1Files* out,
+                 uhdr_error_info_t* st);
 bool convert_yuv(uhdr_raw_image_t* image, uhdr_color_gamut_t src_encoding, uhdr_color_gamut_t dst_encoding,
                  uhdr_error_info_t* st);
 bool convert_raw_input_to_ycbcr(uhdr_raw_image_t* src, bool chroma_sampling_enabled,

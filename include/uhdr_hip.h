@@ -684,6 +684,18 @@ uhdr_error_info_t uhdr_hip_encode_api1_scans(uhdr_hip_ctx_t* ctx, const uhdr_raw
                                              uint8_t* base_scan, size_t base_capacity, size_t* base_bytes,
                                              uint8_t* map_scan, size_t map_capacity, size_t* map_bytes);
 
+/* JpegR::encodeJPEGR API-0 (lib/src/jpegr.cpp:179-244) for the HDR intents whose tone-mapped rendition is RGBA8888 -- RGBA1010102 and RGBA
+ * half float -- in ONE call (round 6): host intent in, the two entropy-coded scans out (host buffers).  uhdr_hip_encode_api0_fused_dev (tone
+ * map + one-pass gain map + RGB -> YCbCr 4:4:4) + FDCT / quantize + both scans Huffman-coded; what the facade binds at encodeJPEGR API-0.
+ * cfg: preset is overridden to UHDR_USAGE_REALTIME and use_luminance to 0, as the reference does on this path; scale factor 1 and
+ * dimensions that are multiples of 8 (UHDR_CODEC_UNSUPPORTED_FEATURE otherwise: the per-stage operators take those).  *sdr_cg: the colour
+ * gamut of the tone-mapped rendition (for the base file's ICC profile).  qt_base / qt_map: {luma, chroma} tables. */
+uhdr_error_info_t uhdr_hip_encode_api0_scans(uhdr_hip_ctx_t* ctx, const uhdr_raw_image_t* hdr, const uhdr_hip_encode_cfg_t* cfg,
+                                             const uint16_t qt_base[2][64], const uint16_t qt_map[2][64], uhdr_gainmap_metadata_t* md,
+                                             uhdr_raw_image_t* gainmap_desc, uhdr_color_gamut_t* sdr_cg, uint8_t* base_scan,
+                                             size_t base_capacity, size_t* base_bytes, uint8_t* map_scan, size_t map_capacity,
+                                             size_t* map_bytes);
+
 /* The same on DEVICE-resident intents into DEVICE buffers, and its inverse (round 6): one entry point per direction of the API-1
  * round trip, for callers whose images live in HBM (a transcoding service; bench.py's headline).
  * uhdr_hip_encode_api1_scans_dev: JpegR::encodeJPEGR API-1 (jpegr.cpp:253-316) without the container -- sdr / hdr are device images,

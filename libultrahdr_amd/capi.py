@@ -214,6 +214,8 @@ _SIGS = {
     "uhdr_hip_huffman_decode2_dev": (ErrorInfo, [C.c_void_p, _P(JpegScan), _P(HuffTables), C.c_void_p, C.c_size_t, _P(JpegScan), _P(HuffTables), C.c_void_p, C.c_size_t]),
     "uhdr_hip_encode_api1_scans": (ErrorInfo, [C.c_void_p, _P(RawImage), _P(RawImage), _P(EncodeCfg), C.c_int, C.c_void_p, C.c_void_p, _P(GainmapMetadata),
                                                _P(RawImage), C.c_void_p, C.c_size_t, _P(C.c_size_t), C.c_void_p, C.c_size_t, _P(C.c_size_t)]),
+    "uhdr_hip_encode_api0_scans": (ErrorInfo, [C.c_void_p, _P(RawImage), _P(EncodeCfg), C.c_void_p, C.c_void_p, _P(GainmapMetadata), _P(RawImage), _P(C.c_int),
+                                               C.c_void_p, C.c_size_t, _P(C.c_size_t), C.c_void_p, C.c_size_t, _P(C.c_size_t)]),
     "uhdr_hip_encode_api1_scans_dev": (ErrorInfo, [C.c_void_p, _P(RawImage), _P(RawImage), _P(EncodeCfg), C.c_int, C.c_void_p, C.c_void_p, _P(GainmapMetadata),
                                                    _P(RawImage), C.c_void_p, C.c_size_t, _P(C.c_size_t), C.c_void_p, C.c_size_t, _P(C.c_size_t)]),
     "uhdr_hip_decode_api1_scans_dev": (ErrorInfo, [C.c_void_p, _P(JpegHeader), C.c_void_p, C.c_size_t, C.c_int, _P(JpegHeader), C.c_void_p, C.c_size_t, C.c_int,

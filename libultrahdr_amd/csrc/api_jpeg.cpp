@@ -478,6 +478,100 @@ static uhdr_error_info_t encode_api1_scans_impl(uhdr_hip_ctx_t* c, const uhdr_ra
   return ok_status();
 }
 
+// JpegR::encodeJPEGR API-0 (jpegr.cpp:179-244) for the HDR intents its tone map renders to RGBA8888 -- RGBA1010102 (BASELINE config 3) and
+// RGBA half float -- from the raw intent to the two entropy-coded scans in ONE entry point (round 6; what the facade's seam at encodeJPEGR
+// API-0 calls): the intent goes up once, uhdr_hip_encode_api0_fused_dev leaves the YCbCr 4:4:4 base image and the one-pass gain map in HBM,
+// FDCT + quantize (rgb -> ycc inside for a three-channel map), both scans Huffman-coded concurrently, and only the bytes come down.
+// The reference overrides the preset to UHDR_USAGE_REALTIME on this path (jpegr.cpp:207) and passes use_luminance = false: so does this.
+uhdr_error_info_t uhdr_hip_encode_api0_scans(uhdr_hip_ctx_t* c, const uhdr_raw_image_t* hdr, const uhdr_hip_encode_cfg_t* cfg_in, const uint16_t qt_base[2][64],
+                                             const uint16_t qt_map[2][64], uhdr_gainmap_metadata_t* md, uhdr_raw_image_t* gainmap_desc,
+                                             uhdr_color_gamut_t* sdr_cg, uint8_t* base_scan, size_t base_capacity, size_t* base_bytes, uint8_t* map_scan,
+                                             size_t map_capacity, size_t* map_bytes) {
+  if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
+  if (!hdr || !cfg_in || !qt_base || !qt_map || !md || !base_scan || !map_scan || !base_bytes || !map_bytes)
+    return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr argument");
+  if (hdr->fmt != UHDR_IMG_FMT_32bppRGBA1010102 && hdr->fmt != UHDR_IMG_FMT_64bppRGBAHalfFloat)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "the fused API-0 chain takes UHDR_IMG_FMT_32bppRGBA1010102 or UHDR_IMG_FMT_64bppRGBAHalfFloat. Received %d", hdr->fmt);
+  if (cfg_in->map_dimension_scale_factor != 1)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "the fused API-0 chain needs a full-resolution gain map (scale factor 1), received %d", cfg_in->map_dimension_scale_factor);
+  if (hdr->w == 0 || hdr->h == 0 || hdr->w % 8 || hdr->h % 8 || hdr->w > 65535 || hdr->h > 65535)
+    return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "the fused API-0 chain needs dimensions that are multiples of 8 (received %ux%u); use the operators", hdr->w, hdr->h);
+  if (c->comm != nullptr || c->comm_custom) return err_status(UHDR_CODEC_UNSUPPORTED_FEATURE, "a context with a communicator encodes stripes");
+  UHDR_TRY(validate_image(hdr, "hdr intent"));
+  for (int t = 0; t < 2; t++)
+    for (int i = 0; i < 64; i++)
+      if (qt_base[t][i] == 0 || qt_base[t][i] > 255 || qt_map[t][i] == 0 || qt_map[t][i] > 255)
+        return err_status(UHDR_CODEC_INVALID_PARAM, "quantization table entry %d out of baseline range", i);
+  HIP_TRY(hipSetDevice(c->device));
+  uhdr_hip_encode_cfg_t cfg = *cfg_in;
+  cfg.preset = UHDR_USAGE_REALTIME;  // jpegr.cpp:207
+  cfg.sdr_is_601 = 0;                // jpegr.cpp:213-214
+  cfg.use_luminance = 0;
+  const unsigned w = hdr->w, h = hdr->h;
+  const int nch = cfg.use_multi_channel_gainmap ? 3 : 1;
+  uhdr_raw_image_t dh;
+  if (c->resident_on) UHDR_TRY(resident_write_back_all(c));
+  UHDR_TRY(stage_in(c, 1, hdr, &dh, true));
+  // device images: the base image's three 4:4:4 planes and the map (rows padded to 64 samples), then the coefficient arrays
+  const size_t pitch = ((size_t)w + 63) & ~(size_t)63, plane = pitch * h, map_pitch_px = pitch;
+  UHDR_TRY(ensure(c->enc[1], 3 * plane + 256));
+  UHDR_TRY(ensure(c->enc[2], map_pitch_px * (size_t)nch * h + 256));
+  const size_t nblk = (size_t)(w / 8) * (h / 8), cbytes = (nblk * 128 + 255) & ~(size_t)255;
+  UHDR_TRY(ensure(c->enc[0], cbytes * (size_t)(3 + nch)));
+  uhdr_raw_image_t ycc, gm;
+  memset(&ycc, 0, sizeof ycc);
+  memset(&gm, 0, sizeof gm);
+  for (int i = 0; i < 3; i++) {
+    ycc.planes[i] = (uint8_t*)c->enc[1].p + (size_t)i * plane;
+    ycc.stride[i] = (unsigned int)pitch;
+  }
+  gm.planes[0] = c->enc[2].p;
+  gm.stride[0] = (unsigned int)map_pitch_px;
+  UHDR_TRY(uhdr_hip_encode_api0_fused_dev(c, &dh, &cfg, nullptr, &ycc, md, &gm));
+  if (sdr_cg) *sdr_cg = ycc.cg;  // what toneMap gives its SDR rendition (jpegr.cpp:2024-2030) and convert_raw_input_to_ycbcr keeps
+  if (gainmap_desc) {
+    *gainmap_desc = gm;
+    gainmap_desc->planes[0] = gainmap_desc->planes[1] = gainmap_desc->planes[2] = nullptr;
+  }
+  int16_t* coef[6];
+  for (int i = 0; i < 3 + nch; i++) coef[i] = (int16_t*)((uint8_t*)c->enc[0].p + (size_t)i * cbytes);
+  for (int i = 0; i < 3; i++)
+    UHDR_TRY(uhdr_hip_fdct_quant_dev(c, (const uint8_t*)ycc.planes[i], pitch, (int)(w / 8), (int)(h / 8), qt_base[i ? 1 : 0], coef[i]));
+  if (nch == 3) UHDR_TRY(uhdr_hip_fdct_quant_rgb_dev(c, &gm, qt_map[0], qt_map[1], coef[3], coef[4], coef[5]));
+  else UHDR_TRY(uhdr_hip_fdct_quant_dev(c, (const uint8_t*)gm.planes[0], (size_t)gm.stride[0], (int)(w / 8), (int)(h / 8), qt_map[0], coef[3]));
+  uhdr_hip_jpeg_scan_t sb, sm;
+  memset(&sb, 0, sizeof sb);
+  memset(&sm, 0, sizeof sm);
+  sb.num_components = 3;
+  sm.num_components = nch;
+  sb.w = sm.w = w;
+  sb.h = sm.h = h;
+  for (int i = 0; i < 3; i++) {
+    sb.coef[i] = coef[i];
+    sb.blocks_w[i] = (int)(w / 8); sb.blocks_h[i] = (int)(h / 8);
+    sb.h_samp[i] = sb.v_samp[i] = 1;
+  }
+  for (int i = 0; i < nch; i++) {
+    sm.coef[i] = coef[3 + i];
+    sm.blocks_w[i] = (int)(w / 8); sm.blocks_h[i] = (int)(h / 8);
+    sm.h_samp[i] = sm.v_samp[i] = 1;
+  }
+  if (base_capacity > 0xFFFFFFF0u) base_capacity = 0xFFFFFFF0u;
+  if (map_capacity > 0xFFFFFFF0u) map_capacity = 0xFFFFFFF0u;
+  // the scans' device buffers: the image planes are free again once the FDCTs have run -- but those are only enqueued, so separate ones
+  UHDR_TRY(ensure(c->jpg[0], base_capacity + 64));
+  UHDR_TRY(ensure(c->jpg[4], map_capacity + 64));
+  size_t nbs = 0, nms = 0;
+  const uhdr_error_info_t e2 = uhdr_hip_huffman_encode2_dev(c, &sb, (uint8_t*)c->jpg[0].p, base_capacity, &nbs, &sm, (uint8_t*)c->jpg[4].p, map_capacity, &nms);
+  *base_bytes = nbs;
+  *map_bytes = nms;
+  if (e2.error_code != UHDR_CODEC_OK) return e2;
+  HIP_TRY(hipMemcpyAsync(base_scan, c->jpg[0].p, nbs, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(map_scan, c->jpg[4].p, nms, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return ok_status();
+}
+
 // -------------------------------------------------------------------------------------------------
 // JPEG decode stage: dequant + IDCT, libjpeg colour conversions
 // -------------------------------------------------------------------------------------------------

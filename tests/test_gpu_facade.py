@@ -145,8 +145,15 @@ def test_api0_encode_through_the_facade():
         assert rc == 0, err
         rc, _, err, trace = F.run_app(args + ["-z", "gpu.jpg"], True, d)
         assert rc == 0, err
+        # round 6: the seam at JpegR::encodeJPEGR API-0 -- tone map + one-pass gain map + RGB -> YCbCr 4:4:4 fused, FDCTs, both scans
+        # Huffman-coded (uhdr_hip_encode_api0_scans) -- is ONE stage for the input BASELINE config 3 names (RGBA1010102) ...
+        assert _stages(trace) == ["encode_api0_fused"], trace
+        # ... and writes the file the five per-stage seams write (what it falls back to for P010 intents, scale factors other than 1, ...)
+        rc, _, err, trace = F.run_app(args + ["-z", "gpu1.jpg"], True, d, env_extra={"UHDR_HIP_SEAM_NO_FUSED_ENCODE": "1"})
+        assert rc == 0, err
         st = _stages(trace)
-        assert "tone_map" in st and "generate_gainmap" in st and "convert_raw_input_to_ycbcr" in st, trace
+        assert "tone_map" in st and "generate_gainmap" in st and "convert_raw_input_to_ycbcr" in st and trace.n("jpeg_encode_scan") == 2, trace
+        assert np.array_equal(F.read(os.path.join(d, "gpu.jpg")), F.read(os.path.join(d, "gpu1.jpg")))
         for name in ("cpu", "gpu"):
             rc, _, err, _ = F.decode(name + ".jpg", 0, 4, name + ".raw", False, d)
             assert rc == 0, err
@@ -155,6 +162,75 @@ def test_api0_encode_through_the_facade():
         assert a.size == b.size == w * h * 4
         # a +-1 8-bit sample before the JPEG DCT moves a handful of decoded pixels slightly
         assert (a != b).mean() < 1e-3 and np.abs(a - b).max() < 0.25
+
+
+def test_api0_half_float_and_declined_shapes_through_the_facade():
+    """The fused API-0 seam also takes RGBA half float; a P010 intent and a scale factor other than 1 go through the per-stage seams.  Each
+    against the CPU reference's decoded pixels with the bar of test_api0_encode_through_the_facade."""
+    from libultrahdr_amd import capi as A
+    from libultrahdr_amd import synth
+
+    w, h = 640, 360
+    with tempfile.TemporaryDirectory() as d:
+        synth.make_hdr_rgba_f16(w, h, specials=False).valid(0).tofile(os.path.join(d, "f16.raw"))
+        hp = synth.make_hdr_p010(w, h, ct=A.UHDR_CT_HLG)
+        np.concatenate([hp.valid(0).ravel(), hp.valid(1).ravel()]).tofile(os.path.join(d, "in.p010"))
+        synth.make_hdr_rgba1010102(w, h, ct=A.UHDR_CT_PQ).valid(0).tofile(os.path.join(d, "in.raw"))
+        cases = (("f16", ["-m", 0, "-p", "f16.raw", "-w", w, "-h", h, "-a", 4, "-C", 2, "-t", 0, "-R", 1], ["encode_api0_fused"]),
+                 ("p010", ["-m", 0, "-p", "in.p010", "-w", w, "-h", h, "-a", 0, "-C", 2, "-t", 1, "-R", 0], None),
+                 ("s2", ["-m", 0, "-p", "in.raw", "-w", w, "-h", h, "-a", 5, "-C", 2, "-t", 2, "-R", 1, "-s", 2], None))
+        for name, args, want in cases:
+            rc, _, err, _ = F.run_app(args + ["-z", name + "_cpu.jpg"], False, d)
+            assert rc == 0, (name, err)
+            rc, _, err, trace = F.run_app(args + ["-z", name + "_gpu.jpg"], True, d)
+            assert rc == 0, (name, err)
+            st = _stages(trace)
+            if want is not None:
+                assert st == want, (name, trace)
+            else:
+                assert "encode_api0_fused" not in st and "tone_map" in st and "generate_gainmap" in st and trace.n("jpeg_encode_scan") == 2, (name, trace)
+            for side in ("cpu", "gpu"):
+                rc, _, err, _ = F.decode(f"{name}_{side}.jpg", 0, 4, f"{name}_{side}.raw", False, d)
+                assert rc == 0, (name, err)
+            a = np.fromfile(os.path.join(d, name + "_cpu.raw"), dtype=np.float16).astype(np.float32)
+            b = np.fromfile(os.path.join(d, name + "_gpu.raw"), dtype=np.float16).astype(np.float32)
+            assert a.size == b.size == w * h * 4
+            assert (a != b).mean() < 1e-3 and np.abs(a - b).max() < 0.25, (name, float((a != b).mean()), float(np.abs(a - b).max()))
+
+
+@pytest.mark.parametrize("api", [2, 3])
+def test_api2_and_api3_encode_through_the_facade(api):
+    """API-2 (raw HDR + raw SDR + compressed SDR) and API-3 (raw HDR + compressed SDR), jpegr.cpp:294-384.  API-2: generateGainMap on the two raw
+    intents (the compressed one is only parsed); API-3: the compressed SDR intent is decoded on the device from its bytes and generateGainMap
+    runs with sdr_is_601 = true.  Either way the map is compressed on the device and the caller's JPEG is passed through as the base image.  Files are compared with the CPU reference's: the base JPEG is the caller's, the gain map is the device's, whose bytes equal
+    the reference's -- whole files byte for byte."""
+    from libultrahdr_amd import capi as A
+    from libultrahdr_amd import synth
+    from oracle import loader as L
+
+    w, h = 1280, 720
+    with tempfile.TemporaryDirectory() as d:
+        hdr = synth.make_hdr_p010(w, h, ct=A.UHDR_CT_HLG)
+        sdr = synth.make_sdr_yuv420(w, h)
+        np.concatenate([hdr.valid(0).ravel(), hdr.valid(1).ravel()]).tofile(os.path.join(d, "in.p010"))
+        np.concatenate([sdr.valid(c).ravel() for c in range(3)]).tofile(os.path.join(d, "in.yuv420"))
+        # the compressed SDR intent: the SDR rendition as a BT.601 JPEG (what an application's camera pipeline would hand over)
+        if L.ref() is None:
+            pytest.skip("oracle/_ref not built")
+        open(os.path.join(d, "sdr.jpg"), "wb").write(L.ref_jpeg_compress(L.convert_yuv("ref", sdr, A.UHDR_CG_BT_709, A.UHDR_CG_DISPLAY_P3), 95))
+        args = ["-m", 0, "-p", "in.p010", "-i", "sdr.jpg", "-w", w, "-h", h, "-a", 0, "-C", 2, "-c", 0, "-t", 1, "-R", 0]
+        if api == 2:
+            args += ["-y", "in.yuv420", "-b", 1]
+        rc, _, err, _ = F.run_app(args + ["-z", "cpu.jpg"], False, d)
+        assert rc == 0, err
+        rc, _, err, trace = F.run_app(args + ["-z", "gpu.jpg"], True, d)
+        assert rc == 0, err
+        st = _stages(trace)
+        assert "generate_gainmap" in st and trace.n("jpeg_encode_scan") == 1, trace  # the map's compressImage; the base image is the caller's JPEG
+        if api == 3:
+            assert trace.n("jpeg_decode_scan") == 1, trace  # the compressed SDR intent, decoded on the device
+        a, b = F.read(os.path.join(d, "cpu.jpg")), F.read(os.path.join(d, "gpu.jpg"))
+        assert a.size == b.size and np.array_equal(a, b), f"{int((a != b).sum()) if a.size == b.size else (a.size, b.size)} differing bytes"
 
 
 @pytest.mark.parametrize("multi", [False, True])
