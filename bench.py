@@ -401,6 +401,7 @@ ROOFLINE_SCALARS = (
     ("config5_frac", ("config5", "frac_of_8TBs")), ("headline_16x4k_frac", ("headline_16x4k", "frac")),
     ("config4_ms_per_image", ("config4", "ms_per_image")), ("config4_all_reduce_us", ("config4", "all_reduce_us_back_to_back")),
     ("config4_full_16k_ms", ("config4", "full_16k_x_16k_one_gpu", "ms_per_image")),
+    ("uhdr_encode_api0_8k_ms", ("api_level", "uhdr_encode_api0_8k_hip", "ms")),
 )
 ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes", "avg_launch_us", "launches_timed")
 
@@ -1238,7 +1239,25 @@ def api_level_section():
     except Exception as e:  # noqa: BLE001
         rows8 = {"uhdr_8k": {"error": f"{type(e).__name__}: {e}"}}
 
-    return {**rows8, "seam_trace_split": split, "uhdr_encode_api1_4k_hip": row(t_enc, jpeg_bytes=len(jpg), same_bytes_as_the_libjpeg_entropy_route=bool(jpg == jpg_cpu),
+    # BASELINE config 3 through the drop-in (round 6): uhdr_encode API-0 of an 8K RGBA1010102 PQ intent -- one device sequence behind the seam at
+    # JpegR::encodeJPEGR API-0 (uhdr_hip_encode_api0_scans) -- and the five per-stage seams for comparison
+    rows0 = {}
+    try:
+        w8, h8 = 7680, 4320
+        hdr0 = synth.make_hdr_rgba1010102(w8, h8, ct=A.UHDR_CT_PQ)
+        FA.encode(hdr0, None, gpu=True)
+        A.seam_stats(reset=True)
+        jpg0, t0_ = med(lambda: FA.encode(hdr0, None, gpu=True), 3)
+        st0 = A.seam_stats(reset=True)
+        _, t0_ps = with_env("UHDR_HIP_SEAM_NO_FUSED_ENCODE", "1", lambda: med(lambda: FA.encode(hdr0, None, gpu=True), 2))
+        rows0 = {"uhdr_encode_api0_8k_hip": {"ms": round(t0_ * 1e3, 1), "Mpx/s": round(w8 * h8 / t0_ / 1e6, 1), "jpeg_bytes": len(jpg0),
+                                             "device_stages": {k: v["device"] for k, v in st0.items() if k != "uhdr_call"}},
+                 "uhdr_encode_api0_8k_hip_per_stage_seams": {"ms": round(t0_ps * 1e3, 1), "Mpx/s": round(w8 * h8 / t0_ps / 1e6, 1)}}
+        del hdr0, jpg0
+    except Exception as e:  # noqa: BLE001
+        rows0 = {"uhdr_encode_api0_8k_hip": {"error": f"{type(e).__name__}: {e}"}}
+
+    return {**rows8, **rows0, "seam_trace_split": split, "uhdr_encode_api1_4k_hip": row(t_enc, jpeg_bytes=len(jpg), same_bytes_as_the_libjpeg_entropy_route=bool(jpg == jpg_cpu),
                                            entropy_coding="device, no restart markers (the default): FDCT + quantize + Huffman coding in three passes, "
                                                           "the file is the reference's byte for byte"),
             "uhdr_decode_4k_f16_hip": row(t_dec, entropy_decoding="device (self-synchronising decoder: the file has no restart markers)",

@@ -40,25 +40,35 @@ bool trace_on() {
 // UHDR_HIP_SEAM_NO_CTX_POOL=1: one context per codec, destroyed with it (the round-4 behaviour).  Parked contexts are
 // never destroyed at process exit (the HIP runtime may be gone by then).
 constexpr size_t kPoolMax = 4;
+// what a parked context may keep allocated (device scratch + pinned ring): enough for 8K frames; a context that has seen a 16K x 16K image
+// gives the excess back before it is parked (uhdr_hip_recycle)
+constexpr size_t kPoolKeepBytes = (size_t)1 << 30;
 std::mutex g_pool_mu;
-std::vector<void*> g_pool;
+struct Parked { void* ctxt; int device; };
+std::vector<Parked> g_pool;
 bool pool_on() {
   static const bool on = getenv("UHDR_HIP_SEAM_NO_CTX_POOL") == nullptr;
   return on;
 }
-void* pool_take() {
+void* pool_take() {  // a context bound to the CALLING thread's current device only
   if (!pool_on()) return nullptr;
+  const int dev = uhdr_hip_current_device();
   std::lock_guard<std::mutex> lk(g_pool_mu);
-  if (g_pool.empty()) return nullptr;
-  void* c = g_pool.back();
-  g_pool.pop_back();
-  return c;
+  for (size_t i = g_pool.size(); i-- > 0;)
+    if (g_pool[i].device == dev) {
+      void* c = g_pool[i].ctxt;
+      g_pool.erase(g_pool.begin() + (long)i);
+      return c;
+    }
+  return nullptr;
 }
 bool pool_give(void* c) {
   if (!pool_on()) return false;
+  // the next codec must find nothing of this one's: latched errors, hints, counters, oversized buffers
+  const int dev = uhdr_hip_recycle(static_cast<uhdr_hip_ctx_t*>(c), kPoolKeepBytes);
   std::lock_guard<std::mutex> lk(g_pool_mu);
   if (g_pool.size() >= kPoolMax) return false;
-  g_pool.push_back(c);
+  g_pool.push_back({c, dev});
   return true;
 }
 thread_local double tl_enter_ms = -1.0;
@@ -552,16 +562,7 @@ bool decode_scan(const void* hdr, const unsigned char* data, size_t bytes, int o
   const bool on_device_ = [&]() -> bool {
     if (!cur()) return false;
     enter();
-    // The compressed bytes go up from a buffer that lives as long as the thread and keeps its address: the caller's copy of the
-    // file is a fresh allocation per codec, and the runtime's pageable upload of such memory stalled for 10-16 ms in one call
-    // out of four (profiles/r05_decode_stalls.txt).  UHDR_HIP_SEAM_NO_SCAN_STAGING=1: hand over the caller's pointer as before.
-    static const bool stage = getenv("UHDR_HIP_SEAM_NO_SCAN_STAGING") == nullptr;
-    thread_local std::vector<unsigned char> staged;
-    if (stage && bytes <= ((size_t)256 << 20)) {
-      if (staged.size() < bytes) staged.resize(bytes + bytes / 4);
-      memcpy(staged.data(), data, bytes);
-      data = staged.data();
-    }
+    // (the compressed bytes go up through the library's pinned ring -- round 6; round 5 kept a thread-lifetime copy of every scan here)
     *st = uhdr_hip_jpeg_decode_scan(cur(), static_cast<const uhdr_hip_jpeg_header_t*>(hdr), data, bytes, out_channels, libjpeg_variant, planes,
                                     hstride, vstride);
     // corrupt entropy-coded data: libjpeg decodes such files with warnings and padding; that behaviour stays libjpeg's

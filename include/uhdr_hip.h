@@ -720,6 +720,15 @@ uhdr_error_info_t uhdr_hip_decode_api1_scans_dev(uhdr_hip_ctx_t* ctx, const uhdr
                                                  int libjpeg_variant, const uhdr_gainmap_metadata_t* md, uhdr_color_transfer_t output_ct,
                                                  uhdr_img_fmt_t output_format, float max_display_boost, uhdr_raw_image_t* dest);
 
+/* ---- handing a context to its next user (round 6; what the facade's context pool calls when a codec lets go of one) --------------------
+ * Forgets everything that belonged to the previous user: the device-resident image copies, a write-back error that was latched for
+ * "the next call" (uhdr_hip_ctx::sticky), the entropy decoder's size hint, the counters of uhdr_hip_get_stats.  Device scratch,
+ * coefficient buffers and the pinned staging ring are kept for the next call only up to keep_bytes in total (largest buffers freed
+ * first; 0 frees them all): one 16K encode must not pin gigabytes of HBM for the life of the process.  Returns the device the context
+ * is bound to (a pool hands a context only to a caller on that device), -1 for a null context. */
+int uhdr_hip_recycle(uhdr_hip_ctx_t* ctx, size_t keep_bytes);
+int uhdr_hip_current_device(void); /* the calling thread's current device (what uhdr_hip_create(-1) would bind to); -1 without one */
+
 /* ---- which route did the entropy stage take? ---------------------------------------------------------------------
  * Counters of the context since its creation.  A scan the device declines (entropy_decode_declined: a marker-less stream so
  * dense that the parallel decoder does not settle, or Huffman tables outside its two-level form) is returned to the caller

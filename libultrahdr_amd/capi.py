@@ -259,6 +259,8 @@ _SIGS = {
     "uhdr_hip_comm_gather_dev": (ErrorInfo, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, _P(C.c_size_t), C.c_int]),
     "uhdr_hip_generate_gainmap_striped_dev": (ErrorInfo, [C.c_void_p, _P(RawImage), _P(RawImage), _P(EncodeCfg), _P(GainmapMetadata), _P(RawImage)]),
     "uhdr_hip_get_stats": (None, [C.c_void_p, C.c_void_p]),
+    "uhdr_hip_recycle": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "uhdr_hip_current_device": (C.c_int, []),
     "uhdr_hip_seam_note": (None, [C.c_char_p, C.c_int, C.c_double]),
     "uhdr_hip_seam_stats": (C.c_int, [C.c_void_p, C.c_int]),
     "uhdr_hip_seam_stats_reset": (None, []),

@@ -3,6 +3,7 @@
 
 #include <sys/mman.h>
 #include <mutex>
+#include <algorithm>
 
 namespace uhdr_api {
 uhdr_error_info_t ensure(DeviceBuf& b, size_t bytes) {
@@ -161,10 +162,15 @@ uhdr_error_info_t fast_h2d(uhdr_hip_ctx* c, void* dst, const void* src, size_t b
     return v < 0 ? 0 : (v > 16 ? 16 : v);
   }();
   constexpr size_t kPiece = (size_t)1 << 20;
-  if (nthreads == 0 || bytes < 4 * kPiece) {
+  // Round 6: the runtime's pageable path only for small copies.  A caller's buffer of a few MB (the compressed scans of a 4K file) that the
+  // runtime had never seen stalled its staged upload for 10-16 ms one call in four (profiles/r05_decode_stalls.txt); round 5 dodged that
+  // with a thread-lifetime copy in the facade.  From 64 KiB on the bytes go through this context's pinned ring instead -- below 4 MiB copied in
+  // by the calling thread alone -- so that the runtime only ever sees pinned memory.
+  if (nthreads == 0 || bytes < ((size_t)64 << 10)) {
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     return ok_status();
   }
+  const bool threaded = bytes >= 4 * kPiece;
   uhdr_hip_ctx::PinArena& pa = c->pin;
   const size_t need = (bytes + 4095) & ~(size_t)4095;
   if (!pa.ev) HIP_TRY(hipEventCreateWithFlags(&pa.ev, hipEventDisableTiming));
@@ -183,8 +189,17 @@ uhdr_error_info_t fast_h2d(uhdr_hip_ctx* c, void* dst, const void* src, size_t b
     pa.off = 0;
   }
   uint8_t* stage = (uint8_t*)pa.p + pa.off;
+  if (!threaded) {
+    memcpy(stage, src, bytes);
+    HIP_TRY(hipMemcpyAsync(dst, stage, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipEventRecord(pa.ev, c->stream));
+    pa.ev_pending = true;
+    pa.off += need;
+    return ok_status();
+  }
   const size_t npieces = (bytes + kPiece - 1) / kPiece;
-  std::unique_ptr<std::atomic<unsigned char>[]> done(new std::atomic<unsigned char>[npieces]);
+  std::unique_ptr<std::atomic<unsigned char>[]> done(new (std::nothrow) std::atomic<unsigned char>[npieces]);
+  if (!done) return err_status(UHDR_CODEC_MEM_ERROR, "could not allocate %zu bytes of upload bookkeeping", npieces);
   for (size_t i = 0; i < npieces; i++) done[i].store(0, std::memory_order_relaxed);
   std::atomic<size_t> next{0};
   auto work = [&]() {
@@ -198,8 +213,11 @@ uhdr_error_info_t fast_h2d(uhdr_hip_ctx* c, void* dst, const void* src, size_t b
   };
   std::vector<std::thread> pool;
   const int nt = (size_t)nthreads < npieces ? nthreads : (int)npieces;
-  pool.reserve((size_t)nt);
-  for (int t = 0; t < nt; t++) {
+  try {
+    pool.reserve((size_t)nt);
+  } catch (...) {  // (bad_alloc must not cross the C ABI: this thread alone copies, see below)
+  }
+  for (int t = 0; t < nt && pool.capacity() > pool.size(); t++) {
     try {
       pool.emplace_back(work);
     } catch (...) {  // no thread to be had (a process at its limit): whoever started, or this thread alone, does the copying
@@ -563,6 +581,12 @@ int uhdr_hip_device_count(void) {
   return n;
 }
 
+int uhdr_hip_current_device(void) {
+  int d = -1;
+  if (hipGetDevice(&d) != hipSuccess) return -1;
+  return d;
+}
+
 uhdr_hip_ctx_t* uhdr_hip_create(int device, uhdr_error_info_t* err) {
   auto fail = [&](const char* what, hipError_t e) -> uhdr_hip_ctx_t* {
     if (err) *err = err_status(UHDR_CODEC_ERROR, "uhdr_hip_create: %s failed: %s (no CPU fallback exists behind this library)",
@@ -634,6 +658,47 @@ void uhdr_hip_destroy(uhdr_hip_ctx_t* c) {
   if (c->huff_tabs.dev.p) (void)hipFree(c->huff_tabs.dev.p);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
+}
+
+int uhdr_hip_recycle(uhdr_hip_ctx_t* c, size_t keep_bytes) {
+  if (!c) return -1;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  uhdr_hip_resident_forget(c);
+  uhdr_hip_resident_begin(c);  // drops the resident copies (nothing of the previous user's is found by the next one)
+  uhdr_hip_resident_end(c);
+  c->sticky = ok_status();
+  for (auto& h : c->huff_hint) h = uhdr_hip_ctx::HuffHint();
+  c->stats = uhdr_hip_stats_t();
+  c->deferred_md.valid = false;
+  // the retained buffers, largest first, until the rest fits keep_bytes
+  std::vector<DeviceBuf*> bufs;
+  for (auto& b : c->scratch) bufs.push_back(&b);
+  for (auto& b : c->jpg) bufs.push_back(&b);
+  for (auto& b : c->enc) bufs.push_back(&b);
+  for (auto& r : c->resident) bufs.push_back(&r.buf);
+  bufs.push_back(&c->pending.buf);
+  bufs.push_back(&c->pending.tmp);
+  size_t total = c->pin.cap;
+  for (DeviceBuf* b : bufs) total += b->p ? b->cap : 0;
+  std::sort(bufs.begin(), bufs.end(), [](const DeviceBuf* a, const DeviceBuf* b) { return (a->p ? a->cap : 0) > (b->p ? b->cap : 0); });
+  for (DeviceBuf* b : bufs) {
+    if (total <= keep_bytes) break;
+    if (!b->p) continue;
+    (void)hipFree(b->p);
+    total -= b->cap;
+    b->p = nullptr;
+    b->cap = 0;
+  }
+  if (total > keep_bytes && c->pin.p) {
+    if (c->pin.ev_pending && c->pin.ev) (void)hipEventSynchronize(c->pin.ev);
+    (void)hipHostFree(c->pin.p);
+    c->pin.p = nullptr;
+    c->pin.cap = c->pin.off = 0;
+    c->pin.ev_pending = false;
+  }
+  if (c->aux) (void)uhdr_hip_recycle(c->aux, keep_bytes);
+  return c->device;
 }
 
 uhdr_error_info_t uhdr_hip_set_stream(uhdr_hip_ctx_t* c, void* hip_stream) {

@@ -921,7 +921,7 @@ static uhdr_error_info_t jpeg_decode_scan_impl(uhdr_hip_ctx_t* c, const uhdr_hip
   dbg.mark("jpeg_decode_scan: end of the entropy-coded data found");
   HIP_TRY(hipSetDevice(c->device));
   UHDR_TRY(ensure(c->jpg[0], nbytes + 64));
-  HIP_TRY(hipMemcpyAsync(c->jpg[0].p, scan_data, nbytes, hipMemcpyHostToDevice, c->stream));
+  UHDR_TRY(fast_h2d(c, c->jpg[0].p, scan_data, nbytes));  // through the pinned ring: the runtime never stages the caller's (fresh, pageable) copy of the file
   dbg.mark("jpeg_decode_scan: compressed bytes on their way up");
   if (!c->h_flags) HIP_TRY(hipHostMalloc((void**)&c->h_flags, 64 * sizeof(uint32_t), hipHostMallocDefault));
   uint32_t* stray = c->h_flags + 40;

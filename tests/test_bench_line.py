@@ -26,7 +26,7 @@ def _full():
                            "api1_8k_roundtrip_Mpxs": 11139.0, "api1_note": LONG},
         "config5": {"frac_of_8TBs": 0.367, "workload": LONG}, "headline_16x4k": {"frac": 0.67, "workload": LONG},
         "config4": {"ms_per_image": 1.9, "all_reduce_us_back_to_back": 21.0, "full_16k_x_16k_one_gpu": {"ms_per_image": 14.2}, "workload": LONG},
-        "encode": {"blob": [LONG] * 4}, "extra": {"blob": [LONG] * 8}, "api_level": {"blob": LONG},
+        "encode": {"blob": [LONG] * 4}, "extra": {"blob": [LONG] * 8}, "api_level": {"blob": LONG, "uhdr_encode_api0_8k_hip": {"ms": 31.0}},
         "cpu_baseline": {"value": 9.6, "unit": "Mpixels/s", "cores": 4, "kind": "reference", "sample": LONG, "stages": {"blob": LONG}},
     }
 

@@ -121,12 +121,7 @@ def test_4k_decode_through_the_facade_equals_the_cpu_reference():
         a, b = F.read(os.path.join(d, "cpu.raw")), F.read(os.path.join(d, "gpu.raw"))
         assert a.size == b.size == w * h * 8
         assert np.array_equal(a, b), f"{int((a != b).sum())} differing bytes"
-        # the compressed scans handed to the device from the codec's own copy of the file instead of the seam's long-lived buffer
-        # (round 5): the same pixels
-        rc, _, err, trace = F.decode("in.jpg", 0, 4, "gpu1.raw", True, d, env_extra={"UHDR_HIP_SEAM_NO_SCAN_STAGING": "1"})
-        assert rc == 0, err
-        assert trace.n("jpeg_decode_scan") == 2, trace
-        assert np.array_equal(a, F.read(os.path.join(d, "gpu1.raw")))
+        assert trace.n("jpeg_decode_scan") == 2, trace  # base image and gain map, from their compressed bytes
 
 
 def test_api0_encode_through_the_facade():
