@@ -754,42 +754,69 @@ void aux_merge(uhdr_hip_ctx* c) {  // what the second scan counted and timed bel
 
 // The auxiliary context's thread (round 6).  One job at a time: run(job) hands it over and returns, wait() blocks until it is done.
 struct AuxWorker {
+  // Both hand-overs spin for a moment before they sleep: a condition variable's wake-up is 10-30 us of scheduler latency, paid once when the job
+  // is handed over and once when the caller waits for it -- both on the critical path of a 900 us round trip.  The worker keeps polling for
+  // kSpinUs after a job (the next call of a busy service follows at once), the caller polls while the job runs its last microseconds.
+  static constexpr int kSpinUs = 300;
   std::thread th;
   std::mutex mu;
   std::condition_variable cv;
   std::function<void()> job;
-  bool has = false, quit = false;
+  std::atomic<int> state{0};  // 0 idle, 1 job posted, 2 quit
+  std::atomic<bool> busy{false};
+  static bool spin_until(const std::function<bool()>& pred, int us) {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (!pred()) {
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(us)) return pred();
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+    return true;
+  }
   AuxWorker() {
     th = std::thread([this] {
-      std::unique_lock<std::mutex> lk(mu);
       for (;;) {
-        cv.wait(lk, [this] { return has || quit; });
-        if (quit) return;
-        std::function<void()> j = std::move(job);
-        lk.unlock();
+        if (!spin_until([this] { return state.load(std::memory_order_acquire) != 0; }, kSpinUs)) {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [this] { return state.load(std::memory_order_acquire) != 0; });
+        }
+        if (state.load(std::memory_order_acquire) == 2) return;
+        std::function<void()> j;
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          j = std::move(job);
+          state.store(0, std::memory_order_release);
+        }
         j();
-        lk.lock();
-        has = false;
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          busy.store(false, std::memory_order_release);
+        }
         cv.notify_all();
       }
     });
   }
   void run(std::function<void()> j) {
-    std::lock_guard<std::mutex> lk(mu);
-    job = std::move(j);
-    has = true;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      job = std::move(j);
+      busy.store(true, std::memory_order_release);
+      state.store(1, std::memory_order_release);
+    }
     cv.notify_all();
   }
   void wait() {
+    if (spin_until([this] { return !busy.load(std::memory_order_acquire); }, kSpinUs)) return;
     std::unique_lock<std::mutex> lk(mu);
-    cv.wait(lk, [this] { return !has; });
+    cv.wait(lk, [this] { return !busy.load(std::memory_order_acquire); });
   }
   ~AuxWorker() {
     {
       std::lock_guard<std::mutex> lk(mu);
-      quit = true;
-      cv.notify_all();
+      state.store(2, std::memory_order_release);
     }
+    cv.notify_all();
     if (th.joinable()) th.join();
   }
 };

@@ -2,7 +2,8 @@
 """profiles/traffic.json from the rocprofv3 counter passes of one GPU call, keyed to the SHA-256 of the libuhdr_hip.so that was
 profiled (run it in the tree whose .so went to the GPU box): HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB; gfx950 tallies
 a 128-byte read request as 64 bytes, MI355X_MICROARCH.md).
-  * the headline kernel from a tools/profile_bench.sh run (gpurun_out/prof_bench/summary.txt);
+  * the roofline kernel of bench.py's line (applyGainMap, ONE 8K frame per launch, map C) from a tools/profile_bench.sh run
+    (gpurun_out/prof_bench/summary.txt);
   * round 5: the encode chains bench.py reports (encode.api1_4k / api1_8k / config3_api0_8k) from the sectioned summary of a
     tools/profile_all.sh run (cases api1f, api1f8k, api0f), per kernel family as bench.py names them.
     python tools/update_traffic.py gpurun_out/prof_bench/summary.txt profiles/r05_bench_mapC_batch16_rocprofv3.txt [gpurun_out/r05_prof/summary.txt profiles/r05_prof_all_summary.txt]"""
@@ -29,10 +30,10 @@ if fetch is None or write is None:
     sys.exit("no FETCH_SIZE / WRITE_SIZE rows for the headline kernel in " + summary)
 sha = bench.library_sha256()
 rd, wr = int(round(2 * fetch * 1024)), int(round(write * 1024))
-out = {"apply_quad_kernel<F16,RGBA8888,scale1>|16x3840x2160": {
+out = {"apply_quad_kernel<F16,RGBA8888,scale1>|1x7680x4320": {
     "traffic_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr, "library_sha256": sha,
     "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_bench.sh) of `python bench.py --steps 10 --warmup 2 --no-extra --no-cpu "
-              f"--no-config4` (headline launches only), {nf} / {nw} dispatches; FETCH_SIZE / WRITE_SIZE are in KiB, read bytes = 2 x FETCH_SIZE on gfx950 "
+              f"--no-config4` (UHDR_BENCH_HEADLINE_ONLY: the round-trip steps + the roofline kernel's 8K launches), {nf} / {nw} dispatches; FETCH_SIZE / WRITE_SIZE are in KiB, read bytes = 2 x FETCH_SIZE on gfx950 "
               f"(MI355X_MICROARCH.md); {committed_as}"}}
 if len(sys.argv) > 4:
     sect, sect_as = sys.argv[3], sys.argv[4]
