@@ -652,6 +652,7 @@ void uhdr_hip_destroy(uhdr_hip_ctx_t* c) {
   if (c->d_srgb_of_byte) (void)hipFree(c->d_srgb_of_byte);
   if (c->h_mm) (void)hipHostFree(c->h_mm);
   if (c->aux_ev) (void)hipEventDestroy(c->aux_ev);
+  if (c->aux_ev2) (void)hipEventDestroy(c->aux_ev2);
   if (c->h_flags) (void)hipHostFree(c->h_flags);
   if (c->pin.p) (void)hipHostFree(c->pin.p);
   if (c->pin.ev) (void)hipEventDestroy(c->pin.ev);

@@ -726,8 +726,7 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
 // work whose passes are latency- or occupancy-bound for long stretches (single-workgroup scans, the write pass at under one wave per
 // SIMD, the stragglers' scalar chains): the second scan runs on the context's auxiliary context (own stream, scratch and table
 // cache) from a second host thread, the first on the caller's thread; both entry points are synchronous like their single-scan forms.
-namespace {
-uhdr_error_info_t aux_context(uhdr_hip_ctx* c, uhdr_hip_ctx** out) {
+uhdr_error_info_t uhdr_api::aux_context(uhdr_hip_ctx* c, uhdr_hip_ctx** out) {
   if (!c->aux) {
     uhdr_error_info_t e = ok_status();
     c->aux = uhdr_hip_create(c->device, &e);
@@ -738,7 +737,8 @@ uhdr_error_info_t aux_context(uhdr_hip_ctx* c, uhdr_hip_ctx** out) {
   *out = c->aux;
   return ok_status();
 }
-void aux_merge(uhdr_hip_ctx* c) {  // what the second scan counted and timed belongs to the caller's context
+void uhdr_api::aux_merge(uhdr_hip_ctx* c) {  // what the auxiliary context counted and timed belongs to the caller's context
+  if (!c->aux) return;
   uhdr_hip_ctx* x = c->aux;
   c->stats.entropy_decode_parallel += x->stats.entropy_decode_parallel;
   c->stats.entropy_decode_intervals += x->stats.entropy_decode_intervals;
@@ -750,7 +750,6 @@ void aux_merge(uhdr_hip_ctx* c) {  // what the second scan counted and timed bel
   for (auto& e : x->prof_entries) c->prof_entries.push_back(e);
   x->prof_entries.clear();
 }
-}  // namespace
 
 // The auxiliary context's thread (round 6).  One job at a time: run(job) hands it over and returns, wait() blocks until it is done.
 struct AuxWorker {

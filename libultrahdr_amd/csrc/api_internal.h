@@ -209,6 +209,7 @@ struct uhdr_hip_ctx {
   bool defer_md = false;
   struct DeferredMd { bool valid = false, run = false; uhdr_hip_encode_cfg_t cfg; uhdr_color_transfer_t hdr_ct; int use_base_cg = 1; } deferred_md;
   hipEvent_t aux_ev = nullptr;   // orders the auxiliary context's stream behind this one (two-scan entropy entry points)
+  hipEvent_t aux_ev2 = nullptr;  // ... and this one behind the auxiliary stream (the fused API-1 chain's base-image launch)
   // profiling
   bool prof = false;
   std::vector<ProfEntry> prof_entries;
@@ -274,6 +275,9 @@ uhdr_error_info_t fill_tone_map_params(uhdr_hip_ctx* c, const uhdr_raw_image_t* 
 uhdr_error_info_t comm_all_reduce_min(uhdr_hip_ctx* c, float* buf, size_t n);
 // ---- api_entropy.cpp ----
 uhdr_error_info_t check_scan(const uhdr_hip_jpeg_scan_t* sc, bool need_coef, int* mcus_per_row, int* mcu_rows, int* blocks_per_mcu);
+// the context's auxiliary context (own stream, scratch, table cache; created on first use) and the hand-back of what it counted / timed
+uhdr_error_info_t aux_context(uhdr_hip_ctx* c, uhdr_hip_ctx** out);
+void aux_merge(uhdr_hip_ctx* c);
 }  // namespace uhdr_api
 using namespace uhdr_api;
 

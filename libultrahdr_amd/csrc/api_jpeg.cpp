@@ -277,6 +277,28 @@ uhdr_error_info_t uhdr_hip_encode_api1_fused_dev(uhdr_hip_ctx_t* c, const uhdr_r
   // profiling: the per-stage families below, and ONE event pair around the whole chain ("encode_api1_chain": first launch's start to
   // last launch's end, the gaps between the four launches included) -- destroyed, i.e. recorded, before the metadata copy
   std::unique_ptr<ProfScope> chain(new ProfScope(c, "encode_api1_chain"));
+  // Round 6: the base image's launch (convertYuv + three FDCTs) depends on nothing the gain-map passes compute -- it runs on the auxiliary
+  // stream UNDER pass 1 / the range kernel / the map's blocks instead of behind them (the chain's four launches were strictly serial: 21 of
+  // 103 us at 4K).  Whole images only (a stripe's chain keeps its order around the exchange); UHDR_HIP_NO_CHAIN_OVERLAP=1: the serial form.
+  uhdr_hip_ctx* side = nullptr;
+  if (run && !striped && !getenv("UHDR_HIP_NO_CHAIN_OVERLAP")) {
+    uhdr_hip_ctx* x = nullptr;
+    if (aux_context(c, &x).error_code == UHDR_CODEC_OK && x) {
+      hipError_t e = hipSuccess;
+      if (!c->aux_ev) e = hipEventCreateWithFlags(&c->aux_ev, hipEventDisableTiming);
+      if (e == hipSuccess && !c->aux_ev2) e = hipEventCreateWithFlags(&c->aux_ev2, hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventRecord(c->aux_ev, c->stream);  // the intents (and whatever produced them on this stream) are ready
+      if (e == hipSuccess) e = hipStreamWaitEvent(x->stream, c->aux_ev, 0);
+      if (e == hipSuccess) {
+        {
+          ProfScope ps(x, "fdct_quant");
+          note_hip(launch_base_blocks(view_of(sdr), convert ? &conv : nullptr, qt_base[0], qt_base[1], blocks->base_coef, x->stream), "base blocks");
+        }
+        note_hip(hipEventRecord(c->aux_ev2, x->stream), "base blocks event");
+        side = x;
+      }
+    }
+  }
   {
     ProfScope ps(c, "generate_gainmap");
     if (run) {
@@ -318,7 +340,11 @@ uhdr_error_info_t uhdr_hip_encode_api1_fused_dev(uhdr_hip_ctx_t* c, const uhdr_r
     ProfScope ps(c, "fdct_quant");
     note_hip(launch_map_blocks(p.gain_log2, (const AffineDev*)c->affine.p, c->d_math, nch, (int)(p.map_w / 8), (int)(p.map_h / 8), qt_map[0], qt_map[1],
                                blocks->map_coef, map_out, map_stride, c->stream), "map blocks");
-    note_hip(launch_base_blocks(view_of(sdr), convert ? &conv : nullptr, qt_base[0], qt_base[1], blocks->base_coef, c->stream), "base blocks");
+    if (!side) note_hip(launch_base_blocks(view_of(sdr), convert ? &conv : nullptr, qt_base[0], qt_base[1], blocks->base_coef, c->stream), "base blocks");
+  }
+  if (side) {  // the base image's coefficients belong to this stream's order from here on (whatever happened above)
+    note_hip(hipStreamWaitEvent(c->stream, c->aux_ev2, 0), "base blocks wait");
+    aux_merge(c);
   }
   chain.reset();
   note_hip(hipMemcpyAsync(c->h_mm, final_mm, 9 * sizeof(float), hipMemcpyDeviceToHost, c->stream), "metadata copy");

@@ -461,7 +461,6 @@ __global__ __launch_bounds__(64) void huff_stream_kernel(const HuffArgs a, const
 // thread adds up its eight consecutive words there, a ten-step block scan gives the threads' offsets, `sink(index, value, exclusive
 // prefix)` is called for every element.  Round 5's form walked `per` consecutive elements per thread straight from global memory --
 // one cache line per lane and instruction, each load waiting for the one before: 40 us for the 6075 chunk counts of a 4K map.
-constexpr int kScanTileWords = 8192;
 template <int NT = 1024, typename Sink>  // NT threads; tiles of 8 * NT words
 __device__ __forceinline__ uint64_t wg_scan_tiles(const uint32_t* __restrict__ v, int n, uint32_t* s_val /* 8 * NT */, uint64_t* s_sum /* NT */, Sink sink) {
   const int tid = (int)threadIdx.x;
@@ -500,23 +499,26 @@ __device__ __forceinline__ uint64_t wg_scan_tiles(const uint32_t* __restrict__ v
 
 // seg_start = exclusive scan of seg_bits (bit offsets), seg_start[nseg] = total; meta[0..1] = total bits, meta[2] = status
 // (1: coefficients outside the baseline range); every word that two segments share (and the word behind the last bit) is zeroed
-__global__ __launch_bounds__(1024) void huff_stream_scan_kernel(const uint32_t* __restrict__ seg_bits, int nseg, const HuffStream t) {
-  __shared__ uint32_t s_val[kScanTileWords];
-  __shared__ uint64_t s_sum[1024];
+// 256 threads (round 6: a 1024-thread workgroup with 40 KB of LDS waited 15-35 us for a CU with that much room while the other scan's kernels
+// filled the device; this one fits next to anything)
+constexpr int kStreamScanThreads = 256;
+__global__ __launch_bounds__(kStreamScanThreads) void huff_stream_scan_kernel(const uint32_t* __restrict__ seg_bits, int nseg, const HuffStream t) {
+  __shared__ uint32_t s_val[8 * kStreamScanThreads];
+  __shared__ uint64_t s_sum[kStreamScanThreads];
   __shared__ uint32_t s_bad;
   const int tid = (int)threadIdx.x;
   if (tid == 0) s_bad = 0;
   __syncthreads();
   bool bad = false;
   // (a segment that must be redone -- kRetry / kBadCoef -- poisons the sums behind it; the status word makes the host discard them)
-  const uint64_t total = wg_scan_tiles(seg_bits, nseg, s_val, s_sum, [&](int i, uint32_t n, uint64_t run) {
+  const uint64_t total = wg_scan_tiles<kStreamScanThreads>(seg_bits, nseg, s_val, s_sum, [&](int i, uint32_t n, uint64_t run) {
     bad |= n >= kRetry;
     t.seg_start[i] = run;
     if ((run >> 5) < t.raw_words) t.raw[run >> 5] = 0u;
   });
   if (bad) atomicOr(&s_bad, 1u);
   __syncthreads();
-  if (tid == 1023) {
+  if (tid == kStreamScanThreads - 1) {
     t.seg_start[nseg] = total;
     if ((total >> 5) < t.raw_words) t.raw[total >> 5] = 0u;
     t.meta[0] = (uint32_t)total;
@@ -563,15 +565,15 @@ __global__ __launch_bounds__(256) void huff_stuff_count_kernel(const HuffStream 
 
 // exclusive scan of the chunk counts in place (one workgroup); out_bytes = raw bytes + stuffed zeros.  (Folding this into the count
 // kernel's last workgroup was measured and dropped: see huffman_decode_sync.hip, unstuff_count_kernel.)
-__global__ __launch_bounds__(1024) void huff_stuff_scan_kernel(uint32_t* __restrict__ counts, int nchunks, const HuffStream t, uint64_t* __restrict__ out_bytes) {
-  __shared__ uint32_t s_val[kScanTileWords];
-  __shared__ uint64_t s_sum[1024];
+__global__ __launch_bounds__(kStreamScanThreads) void huff_stuff_scan_kernel(uint32_t* __restrict__ counts, int nchunks, const HuffStream t, uint64_t* __restrict__ out_bytes) {
+  __shared__ uint32_t s_val[8 * kStreamScanThreads];
+  __shared__ uint64_t s_sum[kStreamScanThreads];
   const uint64_t total_bits = (uint64_t)t.meta[0] | ((uint64_t)t.meta[1] << 32);
   const uint64_t nraw = (total_bits + 7u) >> 3;
   const int used = (int)min((uint64_t)nchunks, (nraw + kStuffChunk - 1) / kStuffChunk);  // chunks beyond the stream hold zeros and are never read
   // (< 2^32: the stream is bounded by the 32-bit capacity checked on the host)
-  const uint64_t total = wg_scan_tiles<1024>(counts, used, s_val, s_sum, [&](int i, uint32_t, uint64_t run) { counts[i] = (uint32_t)run; });
-  if (threadIdx.x == 1023) *out_bytes = nraw + total;
+  const uint64_t total = wg_scan_tiles<kStreamScanThreads>(counts, used, s_val, s_sum, [&](int i, uint32_t, uint64_t run) { counts[i] = (uint32_t)run; });
+  if (threadIdx.x == kStreamScanThreads - 1) *out_bytes = nraw + total;
 }
 
 __global__ __launch_bounds__(256) void huff_stuff_scatter_kernel(const HuffStream t, const uint32_t* __restrict__ chunk_base, uint8_t* __restrict__ out, uint64_t cap) {
@@ -642,11 +644,11 @@ hipError_t launch_huffman_encode_stream(const HuffArgs& a, const HuffStream& t, 
   const int grid = a.nseg < 16384 ? a.nseg : 16384;
   const int nchunks = huff_stuff_chunks(t.raw_words * 4u);
   hipLaunchKernelGGL((huff_stream_kernel<1, 0>), dim3(grid), dim3(64), 0, s, a, t);
-  hipLaunchKernelGGL(huff_stream_scan_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)t.seg_bits, a.nseg, t);
+  hipLaunchKernelGGL(huff_stream_scan_kernel, dim3(1), dim3(kStreamScanThreads), 0, s, (const uint32_t*)t.seg_bits, a.nseg, t);
   hipLaunchKernelGGL((huff_stream_kernel<kWordsSmall, 1>), dim3(grid), dim3(64), 0, s, a, t);
   hipLaunchKernelGGL((huff_stream_kernel<kWordsPerBlock, 2>), dim3(grid < 2048 ? grid : 2048), dim3(64), 0, s, a, t);
   hipLaunchKernelGGL(huff_stuff_count_kernel, dim3(nchunks), dim3(256), 0, s, t, chunk_counts);
-  hipLaunchKernelGGL(huff_stuff_scan_kernel, dim3(1), dim3(1024), 0, s, chunk_counts, nchunks, t, out_bytes);
+  hipLaunchKernelGGL(huff_stuff_scan_kernel, dim3(1), dim3(kStreamScanThreads), 0, s, chunk_counts, nchunks, t, out_bytes);
   hipLaunchKernelGGL(huff_stuff_scatter_kernel, dim3(nchunks), dim3(256), 0, s, t, (const uint32_t*)chunk_counts, out, cap);
   return hipGetLastError();
 }
