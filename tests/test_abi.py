@@ -44,6 +44,42 @@ def test_no_kernel_of_the_product_uses_scratch_memory():
     assert not spill, spill
 
 
+def test_seam_stage_table_and_context_recycling_without_a_gpu():
+    """Round 6: the stage tallies the facade reports into (uhdr_hip_seam_note / _stats / _stats_reset) are plain host code -- they work without
+    a device --, rows come back in first-seen order, and the context-pool helpers answer for a null context."""
+    lib = A.load()
+    lib.uhdr_hip_seam_stats_reset()
+    assert A.seam_stats() == {}
+    lib.uhdr_hip_seam_note(b"jpeg_decode_scan", 1, 1.5)
+    lib.uhdr_hip_seam_note(b"apply_gainmap", 1, 2.0)
+    lib.uhdr_hip_seam_note(b"jpeg_decode_scan", 1, 0.5)
+    lib.uhdr_hip_seam_note(b"tone_map", 0, 0.0)
+    st = A.seam_stats()
+    assert list(st) == ["jpeg_decode_scan", "apply_gainmap", "tone_map"]
+    assert st["jpeg_decode_scan"] == {"device": 2, "reference": 0, "device_ms": 2.0, "last_ms": 0.5}
+    assert st["tone_map"]["reference"] == 1 and st["tone_map"]["device"] == 0
+    assert C.sizeof(A.SeamStage) == 40 + 3 * 8 + 2 * 8
+    assert A.seam_stats(reset=True) == st and A.seam_stats() == {}
+    assert lib.uhdr_hip_recycle(None, 0) == -1
+
+
+def test_seam_stage_table_is_written_at_exit_when_asked(tmp_path):
+    """UHDR_HIP_SEAM_STATS_FILE: how tests read the table out of a process they cannot call into (the reference's ultrahdr_app)."""
+    import json
+    import sys
+
+    out = tmp_path / "stages.json"
+    code = ("import ctypes as C\n"
+            f"lib = C.CDLL({A.LIB_PATH!r})\n"
+            "lib.uhdr_hip_seam_note.argtypes = [C.c_char_p, C.c_int, C.c_double]\n"
+            "lib.uhdr_hip_seam_note(b'encode_api1_fused', 1, 3.25)\n"
+            "lib.uhdr_hip_seam_note(b'uhdr_call', 1, 4.0)\n")
+    env = dict(os.environ, UHDR_HIP_SEAM_STATS_FILE=str(out))
+    subprocess.check_call([sys.executable, "-c", code], env=env)
+    d = json.loads(out.read_text())
+    assert d["encode_api1_fused"]["device"] == 1 and d["encode_api1_fused"]["device_ms"] == 3.25 and d["uhdr_call"]["first_seq"] == 1
+
+
 def test_struct_layouts_match_reference_abi():
     # ultrahdr_api.h:220-283 on LP64: error info 264 B, raw image 64 B, metadata 72 B
     assert C.sizeof(A.ErrorInfo) == 264
