@@ -592,7 +592,20 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
     // levels in lockstep, 517 with two, 491 with one; the 4:2:0 base image's 512-bit levels are cheap in lockstep once compacted)
     const int main_levels_env = [&] { const char* e = getenv("UHDR_HIP_HUFF_MAIN_LEVELS"); return e ? atoi(e) : (sparse ? 1 : 2); }();
     if (j == bpm && bpm <= 16) {
-      HIP_TRY(hipMemsetAsync(y.flags, 0, zero_bytes_sync, c->stream));  // flags, nblk, dcd and the restart map
+      // Round 6: a first attempt of the hypothesis scheme gets its buffers' initial state from the decode's own first kernel (unstuff_count_kernel,
+      // HuffInitFill): flags, nblk, dcd and the restart map zero, state 0 and the hypothesis map 0xff.  The rounds scheme and every retry use fills.
+      const bool fills_in_unstuff = attempts[0].levels > 0 && zero_bytes_sync % 16 == 0 && ff_bytes % 16 == 0 && zero_bytes_sync / 16 < 0xFFFFFFFFull &&
+                                    ff_bytes / 16 < 0xFFFFFFFFull && !getenv("UHDR_HIP_HUFF_FILL_LAUNCHES");
+      HuffInitFill init_fill;
+      memset(&init_fill, 0, sizeof init_fill);
+      if (fills_in_unstuff) {
+        init_fill.zero_ptr = (uint4*)y.flags;
+        init_fill.zero_vec = (uint32_t)(zero_bytes_sync / 16);
+        init_fill.ff_ptr = (uint4*)y.state[0];
+        init_fill.ff_vec = (uint32_t)(ff_bytes / 16);
+      } else {
+        HIP_TRY(hipMemsetAsync(y.flags, 0, zero_bytes_sync, c->stream));  // flags, nblk, dcd and the restart map
+      }
       // form 2's scratch: zero-filled by pass 0 of a hypothesis attempt itself (round 6: a 25-50 MB fill was a launch of its own at the head of
       // the decode); the rounds scheme gets a fill
       auto pass0_zeroes = [&](const Attempt& t) { return form2 && t.levels > 0 && scan_bytes % 16 == 0 && scan_bytes / 16 < 0xFFFFFFFFull; };
@@ -629,13 +642,15 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
           y.hyp_cnt = (uint16_t*)(sb + o_hc);
           y.hyp_hist = getenv("UHDR_HIP_HUFF_DEBUG") ? 1 : 0;
           // hyp_map <- 0xff (unmapped); state[0] <- 0xff: a start state the write pass skips, should the chain be lost
-          HIP_TRY(hipMemsetAsync(y.state[0], 0xff, ff_bytes, c->stream));
+          if (!(fills_in_unstuff && ti == 0)) HIP_TRY(hipMemsetAsync(y.state[0], 0xff, ff_bytes, c->stream));
           // hyp_cnt needs no initialisation: a slot's count is written together with its map entry, and only mapped slots are read
           size_t tiles_off = 0;
           (void)huff_hyp_chain_bytes(data_bytes, t.sub_bits, &tiles_off);
           {
             ProfScope ps(c, "huffman_decode");
-            if (!unstuffed) HIP_TRY(launch_huffman_unstuff(data, (uint32_t)data_bytes, (uint32_t*)(sb + o_cnt), y.flags + 8, sb + o_clean, c->stream, rst_map, y.rst_partial));
+            if (!unstuffed)
+              HIP_TRY(launch_huffman_unstuff(data, (uint32_t)data_bytes, (uint32_t*)(sb + o_cnt), y.flags + 8, sb + o_clean, c->stream, rst_map, y.rst_partial,
+                                             fills_in_unstuff && ti == 0 ? &init_fill : nullptr));
             unstuffed = true;
             HIP_TRY(launch_huffman_decode_hyp(y, (int*)(sb + o_dcp), sb + o_ch, sb + o_ch + tiles_off, c->stream));
           }

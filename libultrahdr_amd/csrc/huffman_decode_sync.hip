@@ -24,6 +24,7 @@
 // on the true path; steps 2-3 treat them as ordinary (deterministic) state transitions of a decoder that is lost.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "lds_copy.h"
 #include "uhdr_types.h"
@@ -81,9 +82,17 @@ __device__ __forceinline__ uint32_t dropmask16(const uint8_t* __restrict__ data,
 // saves once a kernel has hundreds of workgroups: unstuff_count 6 -> 19 us, dc_partial2 7 -> 18 / 10 -> 36 us, chain tiles 5 -> 10 /
 // 7 -> 21 us, the encoder's stuff_count (8100 workgroups) 5 -> 144 us (profiles/r06_last_workgroup_merge_no.txt).
 template <bool RST>
-__global__ __launch_bounds__(256) void unstuff_count_kernel(const uint8_t* __restrict__ data, uint32_t n, uint32_t* __restrict__ counts) {
+__global__ __launch_bounds__(256) void unstuff_count_kernel(const uint8_t* __restrict__ data, uint32_t n, uint32_t* __restrict__ counts, const HuffInitFill fill) {
   __shared__ uint32_t s_cnt;
   if (threadIdx.x == 0) s_cnt = 0;
+  // the decoder's buffers get their initial state here (grid-stride; nothing in front of this kernel reads them, everything behind it is
+  // stream-ordered): three fill launches of 2-5 us each -- and the launch boundaries between them -- used to open every decode
+  {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x, nt = gridDim.x * 256u;
+    const uint4 z = make_uint4(0, 0, 0, 0), f = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+    for (uint32_t v = t; v < fill.zero_vec; v += nt) fill.zero_ptr[v] = z;
+    for (uint32_t v = t; v < fill.ff_vec; v += nt) fill.ff_ptr[v] = f;
+  }
   __syncthreads();
   const uint32_t base = blockIdx.x * kChunk + threadIdx.x * 16;
   const uint32_t c = base < n ? (uint32_t)__builtin_popcount(dropmask16<RST>(data, base, n)) : 0u;
@@ -1576,10 +1585,13 @@ hipError_t launch_stray_marker_check(const uint8_t* data, uint32_t nbytes, uint3
 // rst_map != nullptr: the stream has restart markers; they are dropped as well, rst_map (zero-initialised, one bit per byte)
 // gets the interval starts and rst_partial[chunk * 3 ..] the markers' count and sequence sums.
 hipError_t launch_huffman_unstuff(const uint8_t* data, uint32_t nbytes, uint32_t* chunk_counts, uint32_t* nstuffed_dev, uint8_t* clean, hipStream_t s,
-                                  uint32_t* rst_map, uint32_t* rst_partial) {
+                                  uint32_t* rst_map, uint32_t* rst_partial, const HuffInitFill* fill) {
   const int nchunks = huff_sync_chunks(nbytes);
-  if (rst_map) hipLaunchKernelGGL(unstuff_count_kernel<true>, dim3(nchunks), dim3(256), 0, s, data, nbytes, chunk_counts);
-  else hipLaunchKernelGGL(unstuff_count_kernel<false>, dim3(nchunks), dim3(256), 0, s, data, nbytes, chunk_counts);
+  HuffInitFill f;
+  memset(&f, 0, sizeof f);
+  if (fill) f = *fill;
+  if (rst_map) hipLaunchKernelGGL(unstuff_count_kernel<true>, dim3(nchunks), dim3(256), 0, s, data, nbytes, chunk_counts, f);
+  else hipLaunchKernelGGL(unstuff_count_kernel<false>, dim3(nchunks), dim3(256), 0, s, data, nbytes, chunk_counts, f);
   hipLaunchKernelGGL(sync_scan_kernel, dim3(1), dim3(1024), 0, s, chunk_counts, nchunks, nstuffed_dev);
   if (rst_map) hipLaunchKernelGGL(unstuff_compact_kernel<true>, dim3(nchunks), dim3(256), 0, s, data, nbytes, (const uint32_t*)chunk_counts, clean, rst_map, rst_partial);
   else hipLaunchKernelGGL(unstuff_compact_kernel<false>, dim3(nchunks), dim3(256), 0, s, data, nbytes, (const uint32_t*)chunk_counts, clean, rst_map, rst_partial);

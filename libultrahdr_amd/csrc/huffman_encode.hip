@@ -347,6 +347,9 @@ __global__ __launch_bounds__(64) void huff_stream_kernel(const HuffArgs a, const
   __shared__ int s_real[kSegBlocks];
   __shared__ uint8_t s_zz[64];
   const uint32_t lane = threadIdx.x;
+  if constexpr (PASS == 2) {
+    if (t.meta[3] == 0) return;  // no segment of the large size class (round 6: this launch used to stage its tables and walk the segment list for nothing)
+  }
   copy_words_to_lds<4>(s_tab, a.tables, 2 * (16 + 256), lane, 64);
   s_zz[lane] = a.zigzag[lane];
   const int bpm = a.blocks_per_mcu;
@@ -510,13 +513,16 @@ __global__ __launch_bounds__(kStreamScanThreads) void huff_stream_scan_kernel(co
   if (tid == 0) s_bad = 0;
   __syncthreads();
   bool bad = false;
+  uint32_t big = 0;  // segments of the large size class (emit pass 2): usually none -- that pass then leaves at once (meta[3])
   // (a segment that must be redone -- kRetry / kBadCoef -- poisons the sums behind it; the status word makes the host discard them)
   const uint64_t total = wg_scan_tiles<kStreamScanThreads>(seg_bits, nseg, s_val, s_sum, [&](int i, uint32_t n, uint64_t run) {
     bad |= n >= kRetry;
+    big += (n < kRetry && n + 32u > (uint32_t)(kSegBlocks * kWordsSmall) * 32u) ? 1u : 0u;
     t.seg_start[i] = run;
     if ((run >> 5) < t.raw_words) t.raw[run >> 5] = 0u;
   });
   if (bad) atomicOr(&s_bad, 1u);
+  if (big) atomicAdd(&s_bad, big << 1);  // (bit 0: bad; the count above it)
   __syncthreads();
   if (tid == kStreamScanThreads - 1) {
     t.seg_start[nseg] = total;
@@ -524,7 +530,10 @@ __global__ __launch_bounds__(kStreamScanThreads) void huff_stream_scan_kernel(co
     t.meta[0] = (uint32_t)total;
     t.meta[1] = (uint32_t)(total >> 32);
   }
-  if (tid == 0) t.meta[2] = s_bad;
+  if (tid == 0) {
+    t.meta[2] = s_bad & 1u;
+    t.meta[3] = s_bad >> 1;
+  }
 }
 
 // 0xFF bytes per chunk of the unstuffed stream.  Round 6: sixteen bytes per thread (one 16-byte load; chunks of 4 KiB) instead of four,

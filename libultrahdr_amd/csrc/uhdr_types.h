@@ -418,8 +418,16 @@ size_t huff_hyp_chain_bytes(uint64_t nbytes, uint32_t sub_bits, size_t* tiles_of
 hipError_t launch_huffman_decode_hyp(const HuffSyncArgs& a, int* dc_partial, uint8_t* chain_prefix, uint8_t* chain_tiles, hipStream_t s);
 int huff_sync_chunks(uint64_t nbytes);
 uint32_t huff_sync_max_subsequences(uint64_t nbytes, uint32_t sub_bits);
+// fill: the initial state of the decoder's buffers, written by the FIRST kernel of the decode instead of by fill launches of their own (round 6): zero_vec
+// 16-byte pieces of zeros from zero_ptr (flags, block counts, DC differences, restart map), ff_vec pieces of 0xff from ff_ptr (state 0, hypothesis map)
+struct HuffInitFill {
+  uint4* zero_ptr;
+  uint32_t zero_vec;
+  uint4* ff_ptr;
+  uint32_t ff_vec;
+};
 hipError_t launch_huffman_unstuff(const uint8_t* data, uint32_t nbytes, uint32_t* chunk_counts, uint32_t* nstuffed_dev, uint8_t* clean, hipStream_t s,
-                                  uint32_t* rst_map = nullptr, uint32_t* rst_partial = nullptr);
+                                  uint32_t* rst_map, uint32_t* rst_partial, const HuffInitFill* fill = nullptr);
 hipError_t launch_huffman_decode_sync(const HuffSyncArgs& a, int max_rounds, int* dc_partial, int* final_buf, hipStream_t s);
 void launch_profile_mark(hipStream_t s);  // selftest.hip: the empty kernel profilers cut their traces at
 int huff_marker_chunks(uint64_t nbytes);
