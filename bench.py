@@ -187,9 +187,11 @@ def make_roundtrip(ctx, u, device, w, h, seed=1234):
     hb = u.jpeg_header(w, h, S420, [qy, qc, qc])
     hm = u.jpeg_header(w, h, S444, [qy, qc, qc])
 
+    qts_enc = (qy, qc)
+
     def enc(two=True):
         if two:  # ONE C call: the fused chain + both scans coded concurrently (uhdr_hip_encode_api1_scans_dev)
-            box["nb"], box["nm"], box["md"] = enc1.encodeApi1Scans(sdr, hdr, A.UHDR_CG_DISPLAY_P3, (qy, qc), (qy, qc), out_b, out_m)
+            box["nb"], box["nm"], box["md"] = enc1.encodeApi1Scans(sdr, hdr, A.UHDR_CG_DISPLAY_P3, qts_enc, qts_enc, out_b, out_m)
             return
         cb, cm, md_, _ = enc1.encodeApi1Fused(sdr, hdr, A.UHDR_CG_DISPLAY_P3, (qy, qc), (qy, qc), want_map=False)
         box["nb"] = int(u.huffman_encode(cb, w, h, S420, 0, out=out_b).numel())

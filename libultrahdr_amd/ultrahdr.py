@@ -237,8 +237,7 @@ class UltraHdr:
         chain and both scans' Huffman coding in ONE C call (uhdr_hip_encode_api1_scans_dev).  out_base / out_map: uint8 CUDA tensors
         that receive the entropy-coded scans.  Returns (bytes of the base scan, bytes of the map scan, metadata)."""
         assert _is_dev(sdr_intent, hdr_intent) and out_base.is_cuda and out_map.is_cuda
-        qb = np.ascontiguousarray(np.stack([np.asarray(q, dtype=np.uint16) for q in qt_base]))
-        qm = np.ascontiguousarray(np.stack([np.asarray(q, dtype=np.uint16) for q in qt_map]))
+        qb, qm = self._qt_pair(qt_base), self._qt_pair(qt_map)
         md = A.GainmapMetadata()
         cfg = self.encode_cfg(sdr_is_601, use_luminance)
         nb, nm = C.c_size_t(0), C.c_size_t(0)
@@ -246,6 +245,20 @@ class UltraHdr:
                    C.c_void_p(qb.ctypes.data), C.c_void_p(qm.ctypes.data), C.byref(md), None, C.c_void_p(out_base.data_ptr()), int(out_base.numel()), C.byref(nb),
                    C.c_void_p(out_map.data_ptr()), int(out_map.numel()), C.byref(nm))
         return int(nb.value), int(nm.value), md
+
+    def _qt_pair(self, qt):
+        """(luma, chroma) quantization tables -> one contiguous uint16 [2][64] block; built once per pair of arrays (a per-frame caller hands in
+        the same two arrays every time: no numpy work between the frames)."""
+        key = (id(qt[0]), id(qt[1]))
+        cache = self.__dict__.setdefault("_qt_cache", {})
+        hit = cache.get(key)
+        if hit is not None and hit[0] is qt[0] and hit[1] is qt[1]:
+            return hit[2]
+        blk = np.ascontiguousarray(np.stack([np.asarray(q, dtype=np.uint16) for q in qt]))
+        if len(cache) > 64:
+            cache.clear()
+        cache[key] = (qt[0], qt[1], blk)
+        return blk
 
     @staticmethod
     def jpeg_header(w: int, h: int, sampling, qtables, restart_interval: int = 0) -> "A.JpegHeader":
