@@ -542,6 +542,17 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
     const size_t o_ds = rst_sync ? take((size_t)a.nseg * 12) : 0, o_rp = rst_sync ? take((size_t)nch * 12) : 0;
     // round 5: the straggler list of pass 1 (every path could end up on it) and the scan-order coefficient scratch of write form 2
     const size_t o_sl = use_hyp ? take((size_t)nsub * (size_t)bpm * 8) : 0;
+    // round 6: write-pass pieces (HuffSyncArgs::pieces): up to four pieces per subsequence, for marker-less scans through the hypothesis scheme
+    const int max_pieces = [&] {
+      const char* e = getenv("UHDR_HIP_HUFF_PIECES");
+      const int v = e ? atoi(e) : 4;
+      return (use_hyp && form2 && !rst_sync && v >= 1 && v <= 4) ? v : 1;
+    }();
+    const size_t o_ms = max_pieces > 1 ? take((size_t)nsub * kHuffHypSlots * (size_t)(max_pieces - 1) * 8) : 0;
+    const size_t o_mc = max_pieces > 1 ? take((size_t)nsub * kHuffHypSlots * (size_t)(max_pieces - 1) * 2) : 0;
+    const size_t o_pe = max_pieces > 1 ? take((size_t)nsub * (size_t)max_pieces * 8 + 64) : 0;
+    const size_t o_pc = max_pieces > 1 ? take(((size_t)nsub * (size_t)max_pieces + 4) * 4) : 0;
+    const size_t o_st2 = max_pieces > 1 ? take(((size_t)nsub * (size_t)max_pieces / 2048 + 4) * 4) : 0;
     const size_t scan_bytes = form2 ? (size_t)total_blocks * 64 * sizeof(int16_t) : 0;
     const size_t o_cs = form2 ? take(scan_bytes + 256) : 0;
     UHDR_TRY(ensure(c->scratch[6], off));
@@ -641,6 +652,24 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
           y.hyp_map = sb + o_hm;
           y.hyp_cnt = (uint16_t*)(sb + o_hc);
           y.hyp_hist = getenv("UHDR_HIP_HUFF_DEBUG") ? 1 : 0;
+          // pieces of (at least) 256 bits; the buffers were sized for the smallest subsequences of the attempt list
+          {
+            // Measured (4K API-1 pair): the map's 1024-bit subsequences in four pieces take its write pass from 75 to 35 us; the base image's
+            // 512-bit ones in two pieces gain nothing (40 -> 39 us: that launch already has 790 waves) and cost pass 1 four: pieces from 1024 bits on.
+            int q = t.sub_bits >= 1024u ? (int)(t.sub_bits / 256u) : 1;
+            if (getenv("UHDR_HIP_HUFF_PIECES_ALL")) q = (int)(t.sub_bits / 256u);
+            if (q > max_pieces) q = max_pieces;
+            if (q < 1) q = 1;
+            while (q > 1 && (t.sub_bits % (uint32_t)q || (t.sub_bits / (uint32_t)q) % 32u)) q--;
+            if (q == 3) q = 2;  // (the staged layout wants power-of-two pieces)
+            if (getenv("UHDR_HIP_HUFF_QMERGE") && atoi(getenv("UHDR_HIP_HUFF_QMERGE")) == 0) q = 1;  // the round-3 form of pass 1 keeps no notes
+            y.pieces = q;
+            y.mid_state = q > 1 ? (uint64_t*)(sb + o_ms) : nullptr;
+            y.mid_cnt = q > 1 ? (uint16_t*)(sb + o_mc) : nullptr;
+            y.pend = q > 1 ? (uint64_t*)(sb + o_pe) : nullptr;
+            y.pcnt = q > 1 ? (uint32_t*)(sb + o_pc) : nullptr;
+            y.scan_tmp = q > 1 ? (uint32_t*)(sb + o_st2) : (uint32_t*)(sb + o_st);
+          }
           // hyp_map <- 0xff (unmapped); state[0] <- 0xff: a start state the write pass skips, should the chain be lost
           if (!(fills_in_unstuff && ti == 0)) HIP_TRY(hipMemsetAsync(y.state[0], 0xff, ff_bytes, c->stream));
           // hyp_cnt needs no initialisation: a slot's count is written together with its map entry, and only mapped slots are read
@@ -671,6 +700,8 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
                     data_bytes, nsub_t, t.sub_bits, bpm, hist[10], hist[11], hist[12], hist[13], hist[14], hist[15], fl[3], t.levels, y.hyp_main_levels, fl[kHuffFlagStragglers], hyp_done ? "resolved" : "LOST (next attempt)");
           }
         } else {
+          y.pieces = 1;
+          y.scan_tmp = (uint32_t*)(sb + o_st);
           {
             ProfScope ps(c, "huffman_decode");
             if (!unstuffed) HIP_TRY(launch_huffman_unstuff(data, (uint32_t)data_bytes, (uint32_t*)(sb + o_cnt), y.flags + 8, sb + o_clean, c->stream, rst_map, y.rst_partial));

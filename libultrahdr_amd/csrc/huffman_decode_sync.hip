@@ -494,6 +494,29 @@ __device__ __forceinline__ void track_span_pair(const HuffSyncArgs& a, const Sta
   p = r.pos();
 }
 
+// The same walk with notes for the write pass's pieces (HuffSyncArgs::pieces): the subsequence that starts at bit sub_start is crossed piece by
+// piece; after piece q < pieces - 1 the state (the first symbol boundary at or beyond the cut) and the blocks completed inside the piece go to
+// mid[q] / cnt[q].  Same states as one track_span_pair call over the whole span (a walk's boundaries do not depend on where it pauses); the
+// price is that a wave's lanes wait for each other at every cut instead of only at the end.
+__device__ __forceinline__ void track_span_pieces(const HuffSyncArgs& a, const Staged& st, uint32_t region_bit, const PairLds& L, uint32_t& p, uint32_t& b,
+                                                  uint32_t& k, uint32_t sub_start, uint32_t end_bit, uint32_t& nblk, uint64_t* __restrict__ mid,
+                                                  uint16_t* __restrict__ cnt) {
+  const uint32_t Q = (uint32_t)a.pieces, piece = a.sub_bits / Q;
+#pragma unroll
+  for (uint32_t q = 0; q < 4u; q++) {  // (at most four pieces; unrolled: callers may keep mid / cnt in registers)
+    if (q < Q) {
+      const uint32_t cut = q + 1u < Q ? min(sub_start + (q + 1u) * piece, end_bit) : end_bit;
+      uint32_t nb = 0;
+      if (p < cut) track_span_pair(a, st, region_bit, L, p, b, k, cut, nb);
+      nblk += nb;
+      if (q + 1u < Q) {
+        mid[q] = pack_state(p, b, k);
+        cnt[q] = (uint16_t)nb;
+      }
+    }
+  }
+}
+
 // Decodes from state (p, b, k) to the first symbol boundary at or beyond end_bit.  WRITE: store coefficients / DC
 // differences for the blocks [blk, total_blocks) and flag malformed data; else just track the state.
 template <bool WRITE>
@@ -888,7 +911,22 @@ __global__ __launch_bounds__(1024) void hyp_pass0_kernel(const HuffSyncArgs a) {
   uint32_t p = i * a.sub_bits, b = h, k = 0, nblk = 0;
   const uint32_t end_bit = min((i + 1) * a.sub_bits, nbits);
   const Staged st = {s_stage, cshift};
-  track_span_pair(a, st, first_byte * 8u, L, p, b, k, end_bit, nblk);
+  if (a.pieces > 1 && blockIdx.x == 0 && h == 0) {
+    // the wave that holds the stream's first subsequence -- the true path's -- walks in pieces (the WHOLE wave: a branch for that one lane would
+    // make the wave walk twice, and this pass lasts as long as its slowest wave); lane 0's notes go where the chain's walk puts all the others
+    uint64_t m[3] = {0, 0, 0};
+    uint16_t c16[3] = {0, 0, 0};
+    track_span_pieces(a, st, first_byte * 8u, L, p, b, k, i * a.sub_bits, end_bit, nblk, m, c16);
+    if (i == 0) {
+      uint32_t sum = 0;
+#pragma unroll
+      for (int q = 0; q < 3; q++)
+        if (q + 1 < a.pieces) { a.pend[q] = m[q]; a.pcnt[q] = c16[q]; sum += c16[q]; }
+      a.pcnt[a.pieces - 1] = nblk - sum;
+    }
+  } else {
+    track_span_pair(a, st, first_byte * 8u, L, p, b, k, end_bit, nblk);
+  }
   a.hyp_state[(size_t)i * kHuffHypSlots + h] = pack_state(p, b, k);
   if (i == 0 && h == 0) {
     a.nblk[0] = nblk;
@@ -1034,13 +1072,18 @@ __global__ __launch_bounds__(1024) void hyp_pass1q_kernel(const HuffSyncArgs a) 
       uint32_t p = (uint32_t)s0, b = (uint32_t)(s0 >> 32) & 0xffu, k = (uint32_t)(s0 >> 40) & 0xffu;
       const uint32_t end_bit = min((j + 1) * a.sub_bits, nbits);
       uint32_t nblk = 0;
-      if (p < end_bit) track_span_pair(a, st, first_byte * 8u, L, p, b, k, end_bit, nblk);
+      const size_t at = (size_t)(j - 1) * kHuffHypSlots + slot;
+      if (a.pieces > 1) {
+        const size_t mo = at * (size_t)(a.pieces - 1);
+        track_span_pieces(a, st, first_byte * 8u, L, p, b, k, j * a.sub_bits, end_bit, nblk, a.mid_state + mo, a.mid_cnt + mo);
+      } else if (p < end_bit) {
+        track_span_pair(a, st, first_byte * 8u, L, p, b, k, end_bit, nblk);
+      }
       const uint64_t e = pack_state(p, b, k);
       const uint64_t* row = a.hyp_state + (size_t)j * kHuffHypSlots;
       const uint8_t* prev = a.hyp_map + (size_t)(j - 1) * kHuffHypSlots;
       const uint32_t m_lo = j > i_last + 1u ? j - i_last : 1u;  // owners started at j - m <= i_last
       const uint32_t g = hyp_find_slot(row, prev, e, H, l, m_lo);
-      const size_t at = (size_t)(j - 1) * kHuffHypSlots + slot;
       a.hyp_cnt[at] = (uint16_t)nblk;
       if (g != 0xffu) {
         a.hyp_map[at] = (uint8_t)g;
@@ -1140,7 +1183,13 @@ __global__ __launch_bounds__(64 * kStragWaves) void hyp_straggler_kernel(const H
           stage[d] = v;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        while (p < end_bit) {
+        // the write pass's pieces (HuffSyncArgs::pieces): the chain pauses at every interior cut and lane 0 notes the state and the blocks so far
+        const uint32_t Q = (uint32_t)a.pieces, piece_bits = a.sub_bits / Q;
+        const size_t mo = ((size_t)(j - 1) * kHuffHypSlots + slot) * (size_t)(Q - 1u);
+        uint32_t blk_noted = 0;
+        for (uint32_t pq = 0; pq < Q; pq++) {
+        const uint32_t cut = pq + 1u < Q ? min(j * a.sub_bits + (pq + 1u) * piece_bits, end_bit) : end_bit;
+        while (p < cut) {
           const uint32_t q = p + lane - (w0 << 5);  // the lane's bit, relative to the stage
           const uint32_t wi = min(q >> 5, (uint32_t)kStragStageWords - 2u);
           const uint64_t two = ((uint64_t)stage[wi] << 32) | stage[wi + 1];
@@ -1153,7 +1202,7 @@ __global__ __launch_bounds__(64 * kStragWaves) void hyp_straggler_kernel(const H
             const uint32_t e2 = T[tb + 512u + ((e & 0x8000u) ? (e & 31u) : 0u) * 128u + (w16 & 127u)];
             ent[t] = (e & 0x8000u) ? e2 : e;
           }
-          const uint32_t lim = min(64u, end_bit - p);
+          const uint32_t lim = min(64u, cut - p);
           uint32_t off = 0;
           // The chain: per block one DC step, then AC steps until the zig-zag index passes 63 -- the inner loop is the whole cost
           // (24 of 25 symbols of a busy block): v_readlane, two field extractions, two additions, two compares.  The component's
@@ -1179,6 +1228,18 @@ __global__ __launch_bounds__(64 * kStragWaves) void hyp_straggler_kernel(const H
             }
           }
           p += off;
+        }
+        if (pq + 1u < Q && lane == 0) {
+          a.mid_state[mo + pq] = pack_state(p, b, k);
+          a.mid_cnt[mo + pq] = (uint16_t)(nblk - blk_noted);
+        }
+        blk_noted = nblk;
+        }
+      } else if (a.pieces > 1 && lane == 0) {  // already beyond the subsequence: every cut sees the same state, no block completes
+        const size_t mo = ((size_t)(j - 1) * kHuffHypSlots + slot) * (size_t)(a.pieces - 1);
+        for (int pq = 0; pq + 1 < a.pieces; pq++) {
+          a.mid_state[mo + pq] = pack_state(p, b, k);
+          a.mid_cnt[mo + pq] = 0;
         }
       }
       const uint64_t e = pack_state(p, b, k);
@@ -1348,8 +1409,23 @@ __global__ __launch_bounds__(kChainThreads) void hyp_chain_walk_kernel(const Huf
       lost = true;
     } else {
       const size_t at = (size_t)i * kHuffHypSlots + g;
-      a.state[0][i] = a.hyp_state[at];
-      a.nblk[i + 1] = a.hyp_cnt[at];
+      const uint64_t end_i = a.hyp_state[at];
+      const uint32_t cnt_next = a.hyp_cnt[at];
+      a.state[0][i] = end_i;
+      a.nblk[i + 1] = cnt_next;
+      if (a.pieces > 1) {  // (see HuffSyncArgs::pieces) piece ends of subsequence i + 1 from the notes of the path that crossed it, and i's own end
+        const uint32_t Q = (uint32_t)a.pieces;
+        a.pend[(size_t)i * Q + (Q - 1u)] = end_i;
+        const size_t mo = at * (size_t)(Q - 1u);
+        uint32_t sum = 0;
+        for (uint32_t q = 0; q + 1u < Q; q++) {
+          const uint32_t cq = a.mid_cnt[mo + q];
+          a.pend[(size_t)(i + 1) * Q + q] = a.mid_state[mo + q];
+          a.pcnt[(size_t)(i + 1) * Q + q] = cq;
+          sum += cq;
+        }
+        a.pcnt[(size_t)(i + 1) * Q + (Q - 1u)] = cnt_next - sum;
+      }
       if (i == nlinks - 1 && a.hyp_map[at] == 0xffu) lost = true;  // the last link must resolve too
     }
   }
@@ -1717,13 +1793,22 @@ hipError_t launch_huffman_decode_hyp(const HuffSyncArgs& a, int* dc_partial, uin
   hipLaunchKernelGGL(hyp_chain_entry_kernel, dim3(1), dim3(kChainWg), 0, s, a, (const uint8_t*)chain_tiles, chain_entry);
   hipLaunchKernelGGL(hyp_chain_walk_kernel, dim3(ntiles), dim3(kChainThreads), 0, s, a, (const uint8_t*)chain_prefix, (const uint8_t*)chain_entry);
   mark();
+  // the write pass: on pieces of a subsequence when the tracking passes noted them (HuffSyncArgs::pieces), else on whole subsequences
+  HuffSyncArgs w = a;
+  uint32_t nw = nsub;
+  if (a.pieces > 1 && a.coef_scan && !a.rst_map) {
+    w.sub_bits = a.sub_bits / (uint32_t)a.pieces;
+    w.state[0] = a.pend;
+    w.nblk = a.pcnt;
+    nw = nsub * (uint32_t)a.pieces;
+  }
   {
-    const int nt = (int)((nsub + kScanTile - 1) / kScanTile);
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3(nt), dim3(kScanThreads), 0, s, a.nblk, (int)nsub, a.scan_tmp);  // (the write pass adds the tile sums: tile_offset)
+    const int nt = (int)((nw + kScanTile - 1) / kScanTile);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(nt), dim3(kScanThreads), 0, s, w.nblk, (int)nw, w.scan_tmp);  // (the write pass adds the tile sums: tile_offset)
   }
   mark();
   if (a.coef_scan && !a.rst_map) {
-    launch_write2(a, nsub, 0, s);
+    launch_write2(w, nw, 0, s);
     mark();
     launch_place(a, dc_partial, s);
   } else {

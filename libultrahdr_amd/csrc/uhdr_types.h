@@ -403,6 +403,16 @@ struct HuffSyncArgs {
   // pieces from zero_ptr, grid-stride; 0: the host has enqueued a fill instead (the rounds scheme)
   uint4* zero_ptr;
   uint32_t zero_vec;
+  // round 6: the write pass runs on PIECES of a subsequence.  It has one lane per subsequence -- 290 waves for a 4K gain map -- and therefore
+  // runs at one lane's latency; the tracking passes (pass 1's lockstep levels, the stragglers, pass 0's very first lane) already walk every
+  // subsequence along what may be the true path, so they also note the state at the first symbol boundary at or beyond each interior cut
+  // (pieces - 1 of them) and the blocks completed inside each piece, per (subsequence, slot) like hyp_cnt; the chain's walk picks the true
+  // path's notes (pend / pcnt), and the write pass is launched with pieces x the lanes on pieces of sub_bits / pieces bits.  1: off.
+  int pieces;
+  uint64_t* mid_state;  // [nsub][kHuffHypSlots][pieces - 1]
+  uint16_t* mid_cnt;    // [nsub][kHuffHypSlots][pieces - 1]
+  uint64_t* pend;       // [nsub * pieces]: the true path's state at the end of every piece (the write pass's state[] array)
+  uint32_t* pcnt;       // [nsub * pieces + 1]: blocks completed inside every piece, then their exclusive scan (the write pass's nblk[] array)
   // restart intervals (nullptr / 0: a scan without markers): see restart_jump in huffman_decode_sync.hip
   const uint32_t* rst_map;    // one bit per byte of the clean stream: an interval starts here
   uint32_t rst_blocks;        // blocks per interval (restart interval x blocks per MCU)
