@@ -694,10 +694,12 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
             hint.bits_per_block = (uint32_t)((uint64_t)data_bytes * 8u / ((uint64_t)a.total_mcus * (uint64_t)bpm));
           }
           if (getenv("UHDR_HIP_HUFF_DEBUG")) {
-            uint32_t hist[16] = {};
+            uint32_t hist[32] = {};
             (void)hipMemcpy(hist, y.flags, sizeof hist, hipMemcpyDeviceToHost);
             fprintf(stderr, "uhdr_hip: hypothesis decode of %zu bytes, %u subsequences of %u bits x %d: merges per level %u %u %u %u %u %u+, %u paths unmerged after %d levels (%d in lockstep, %u paths handed to the straggler waves), true path %s\n",
                     data_bytes, nsub_t, t.sub_bits, bpm, hist[10], hist[11], hist[12], hist[13], hist[14], hist[15], fl[3], t.levels, y.hyp_main_levels, fl[kHuffFlagStragglers], hyp_done ? "resolved" : "LOST (next attempt)");
+            fprintf(stderr, "uhdr_hip: the stragglers' merges at level 2 .. 10, 11+: %u %u %u %u %u %u %u %u %u %u\n", hist[22], hist[23], hist[24], hist[25], hist[26], hist[27], hist[28], hist[29],
+                    hist[30], hist[31]);
           }
         } else {
           y.pieces = 1;

@@ -27,6 +27,7 @@
 #include <cstring>
 
 #include "lds_copy.h"
+#include "wg_scan.h"
 #include "uhdr_types.h"
 
 namespace uhdr {
@@ -102,38 +103,32 @@ __global__ __launch_bounds__(256) void unstuff_count_kernel(const uint8_t* __res
 }
 // single workgroup: counts[nchunks] -> exclusive prefix sums in place, total -> *total
 __global__ __launch_bounds__(1024) void sync_scan_kernel(uint32_t* __restrict__ counts, int n, uint32_t* __restrict__ total) {
-  __shared__ uint32_t s_sum[1024];
+  __shared__ uint32_t s_w[16];
   const int tid = (int)threadIdx.x;
   const int per = (n + 1023) / 1024, lo = min(tid * per, n), hi = min(lo + per, n);
-  // eight independent loads at a time: a plain "sum += counts[i]" loop waits a full memory latency per element
+  // eight independent loads at a time (clamped index, no branch around a load: the compiler would wait for each inside its branch)
   uint32_t sum = 0;
   for (int i0 = lo; i0 < hi; i0 += 8) {
     uint32_t v[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) v[j] = (i0 + j < hi) ? counts[i0 + j] : 0u;
+    for (int j = 0; j < 8; j++) v[j] = counts[min(i0 + j, hi - 1)];
 #pragma unroll
-    for (int j = 0; j < 8; j++) sum += v[j];
+    for (int j = 0; j < 8; j++) sum += (i0 + j < hi) ? v[j] : 0u;
   }
-  s_sum[tid] = sum;
-  __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {
-    const uint32_t y = tid >= d ? s_sum[tid - d] : 0u;
-    __syncthreads();
-    s_sum[tid] += y;
-    __syncthreads();
-  }
-  uint32_t run = s_sum[tid] - sum;
+  uint32_t sc[1] = {sum}, all[1];
+  wg_incl_scan<1024, 1>(sc, s_w, all);
+  uint32_t run = sc[0] - sum;
   for (int i0 = lo; i0 < hi; i0 += 8) {
     uint32_t v[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) v[j] = (i0 + j < hi) ? counts[i0 + j] : 0u;
+    for (int j = 0; j < 8; j++) v[j] = counts[min(i0 + j, hi - 1)];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       if (i0 + j < hi) counts[i0 + j] = run;
       run += v[j];
     }
   }
-  if (tid == 1023 && total) *total = s_sum[1023];
+  if (tid == 1023 && total) *total = all[0];
 }
 // Exclusive scan of n words over many workgroups (the single-workgroup kernel above walks its elements with a stride
 // between lanes: one cache line per lane and instruction, all on one CU -- 80 us for 50 K elements).  Step 1: a workgroup
@@ -142,26 +137,20 @@ __global__ __launch_bounds__(1024) void sync_scan_kernel(uint32_t* __restrict__ 
 constexpr int kScanThreads = 256, kScanPer = 8, kScanTile = kScanThreads * kScanPer;
 __global__ __launch_bounds__(kScanThreads) void scan_tiles_kernel(uint32_t* __restrict__ v, int n, uint32_t* __restrict__ tile_sum) {
   __shared__ uint32_t s_val[kScanTile];
-  __shared__ uint32_t s_sum[kScanThreads];
+  __shared__ uint32_t s_w[kScanThreads / 64];
   const int tid = (int)threadIdx.x, base = (int)blockIdx.x * kScanTile;
+  uint32_t ld[kScanPer];
 #pragma unroll
-  for (int j = 0; j < kScanPer; j++) {
-    const int i = base + j * kScanThreads + tid;
-    s_val[j * kScanThreads + tid] = i < n ? v[i] : 0u;
-  }
+  for (int j = 0; j < kScanPer; j++) ld[j] = v[min(base + j * kScanThreads + tid, n - 1)];  // (all eight in flight; base < n for every workgroup)
+#pragma unroll
+  for (int j = 0; j < kScanPer; j++) s_val[j * kScanThreads + tid] = base + j * kScanThreads + tid < n ? ld[j] : 0u;
   __syncthreads();
   uint32_t x[kScanPer], sum = 0;
 #pragma unroll
   for (int j = 0; j < kScanPer; j++) { x[j] = s_val[tid * kScanPer + j]; sum += x[j]; }
-  s_sum[tid] = sum;
-  __syncthreads();
-  for (int d = 1; d < kScanThreads; d <<= 1) {
-    const uint32_t y = tid >= d ? s_sum[tid - d] : 0u;
-    __syncthreads();
-    s_sum[tid] += y;
-    __syncthreads();
-  }
-  uint32_t run = s_sum[tid] - sum;
+  uint32_t sc[1] = {sum}, all[1];
+  wg_incl_scan<kScanThreads, 1>(sc, s_w, all);  // (its first barrier: every x[] has been read)
+  uint32_t run = sc[0] - sum;
 #pragma unroll
   for (int j = 0; j < kScanPer; j++) { s_val[tid * kScanPer + j] = run; run += x[j]; }
   __syncthreads();
@@ -170,7 +159,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_tiles_kernel(uint32_t* __re
     const int i = base + j * kScanThreads + tid;
     if (i < n) v[i] = s_val[j * kScanThreads + tid];
   }
-  if (tid == kScanThreads - 1) tile_sum[blockIdx.x] = s_sum[tid];
+  if (tid == kScanThreads - 1) tile_sum[blockIdx.x] = all[0];
 }
 // The block counts' scan is left per tile (scan_tiles_kernel: kScanTile subsequences each, tile sums in scan_tmp); a write-pass workgroup
 // -- 64 to 256 subsequences, never across a tile boundary -- adds the sums of the tiles in front of its own (round 6: was a launch of
@@ -1156,11 +1145,34 @@ __global__ __launch_bounds__(64 * kStragWaves) void hyp_straggler_kernel(const H
   const uint16_t* T = (const uint16_t*)L.t;
   const uint32_t* clean32 = (const uint32_t*)a.clean;
   uint32_t* stage = s_bytes[wv];
+  // One level's global reads do not depend on the path's state: the words of subsequence j (the path enters it at a bit p >= j * sub_bits and
+  // leaves it less than a symbol beyond its end) and the merge candidates of j.  Both are issued one level ahead -- the words -- or at the head of
+  // the level -- the candidates -- and consumed after the scalar chain, which used to wait ~2 us for each of them per level (round 6).
+  const uint32_t nw = min((a.sub_bits >> 5) + 4u, (uint32_t)kStragStageWords);
+  // (raw loads only, at a clamped index: anything done with the value here would put the wait for it here)
+  const uint32_t last_word = nclean > 4u ? (nclean - 1u) >> 2 : 0u;
+  auto load_words = [&](uint32_t jj, uint32_t (&v)[3]) {
+    const uint32_t w0 = (jj * a.sub_bits) >> 5;
+#pragma unroll
+    for (uint32_t q = 0; q < 3; q++) v[q] = clean32[min(w0 + lane + 64u * q, last_word)];
+  };
+  auto stage_words = [&](uint32_t jj, const uint32_t (&v)[3]) {  // -> big-endian, zeros past the end of the stream
+    const uint32_t w0 = (jj * a.sub_bits) >> 5;
+#pragma unroll
+    for (uint32_t q = 0; q < 3; q++) {
+      const uint32_t d = lane + 64u * q, byte0 = (w0 + d) * 4u;
+      uint32_t x = __builtin_bswap32(v[q]);
+      if (byte0 + 4u > nclean) x = byte0 < nclean ? x & (0xffffffffu << (8u * (byte0 + 4u - nclean))) : 0u;
+      if (d < nw) stage[d] = x;
+    }
+  };
   for (uint32_t idx = wave; idx < count; idx += nwaves) {
     const uint32_t i = uni(a.strag_list[2 * idx]), hw = uni(a.strag_list[2 * idx + 1]);
     const uint32_t h = hw & 0xffu, l0 = hw >> 8;
     uint32_t slot = l0 * H + h;
     const uint64_t s0 = a.hyp_state[(size_t)(i + l0) * kHuffHypSlots + slot];
+    uint32_t nx[3];
+    load_words(i + l0 + 1u, nx);
     uint32_t p = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)s0);
     uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(s0 >> 32) & 0xffu));
     uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(s0 >> 40) & 0xffu));
@@ -1169,19 +1181,18 @@ __global__ __launch_bounds__(64 * kStragWaves) void hyp_straggler_kernel(const H
       if (j >= nsub) break;
       const uint32_t end_bit = min((j + 1) * a.sub_bits, nbits);
       uint32_t nblk = 0;
+      const uint32_t w0 = (j * a.sub_bits) >> 5;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the previous level's reads of the stage are done
+      stage_words(j, nx);
+      // lane c looks at slot c: fresh (c < H), or in flight from a lockstep level m = c / H <= l_main, m < l, whose owner's link continued into it
+      const uint64_t* row = a.hyp_state + (size_t)j * kHuffHypSlots;
+      const uint8_t* prev = a.hyp_map + (size_t)(j - 1) * kHuffHypSlots;
+      const bool fresh = lane < H, flight = !fresh && lane < kHuffHypSlots && lane < l * H && lane / H <= l_main;
+      const uint32_t cl = min(lane, (uint32_t)kHuffHypSlots - 1u);
+      const uint64_t cand = row[cl];
+      const uint32_t owner = prev[max(cl, H) - H];
+      load_words(j + 1u, nx);
       if (p < end_bit) {
-        // stage the words [p / 32, (end_bit + 31 + 16) / 32] of the clean stream, big-endian, zeros past its end
-        const uint32_t w0 = p >> 5, nw = ((end_bit + 63u) >> 5) - w0 + 2u;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the previous level's reads of the stage are done
-        for (uint32_t d = lane; d < nw && d < (uint32_t)kStragStageWords; d += 64u) {
-          const uint32_t byte0 = (w0 + d) * 4u;
-          uint32_t v = 0;
-          if (byte0 < nclean) {
-            v = __builtin_bswap32(clean32[w0 + d]);
-            if (byte0 + 4u > nclean) v &= 0xffffffffu << (8u * (byte0 + 4u - nclean));
-          }
-          stage[d] = v;
-        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         // the write pass's pieces (HuffSyncArgs::pieces): the chain pauses at every interior cut and lane 0 notes the state and the blocks so far
         const uint32_t Q = (uint32_t)a.pieces, piece_bits = a.sub_bits / Q;
@@ -1243,17 +1254,15 @@ __global__ __launch_bounds__(64 * kStragWaves) void hyp_straggler_kernel(const H
         }
       }
       const uint64_t e = pack_state(p, b, k);
-      const uint64_t* row = a.hyp_state + (size_t)j * kHuffHypSlots;
-      const uint8_t* prev = a.hyp_map + (size_t)(j - 1) * kHuffHypSlots;
-      // lane c looks at slot c: fresh (c < H), or in flight from a lockstep level m = c / H <= l_main, m < l, whose owner's link continued into it
-      bool match = false;
-      if (lane < H) match = row[lane] == e;
-      else if (lane < kHuffHypSlots && lane < l * H && lane / H <= l_main) match = prev[lane - H] == lane && row[lane] == e;
+      const bool match = (fresh || (flight && owner == lane)) && cand == e;
       const uint64_t mm = __builtin_amdgcn_ballot_w64(match);
       const size_t at = (size_t)(j - 1) * kHuffHypSlots + slot;
       if (lane == 0) a.hyp_cnt[at] = (uint16_t)nblk;
       if (mm != 0) {
-        if (lane == 0) a.hyp_map[at] = (uint8_t)__builtin_ctzll(mm);
+        if (lane == 0) {
+          a.hyp_map[at] = (uint8_t)__builtin_ctzll(mm);
+          if (a.hyp_hist) atomicAdd(a.flags + 22 + min(l - 2u, 9u), 1u);  // debug: the stragglers' merges per level 2 .. 10, 11+ in flags[22..31]
+        }
         break;
       }
       if (l == (uint32_t)a.hyp_levels) {  // map stays 0xff: not merged within the budget
@@ -1435,24 +1444,13 @@ __global__ __launch_bounds__(kChainThreads) void hyp_chain_walk_kernel(const Huf
 
 // step 5: DC prediction = running sum of the differences over the component's blocks in scan order, as a three-kernel
 // scan over chunks of 1024 scan positions (per-chunk sums per component -> scan of the chunk sums -> rescan + store).
-__device__ __forceinline__ void dc_block_scan(int v[3], int* s_sum /* 3 x 1024 */, int tid) {
-#pragma unroll
-  for (int c = 0; c < 3; c++) s_sum[c * 1024 + tid] = v[c];
-  __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {
-    int y[3];
-#pragma unroll
-    for (int c = 0; c < 3; c++) y[c] = tid >= d ? s_sum[c * 1024 + tid - d] : 0;
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < 3; c++) s_sum[c * 1024 + tid] += y[c];
-    __syncthreads();
-  }
-#pragma unroll
-  for (int c = 0; c < 3; c++) v[c] = s_sum[c * 1024 + tid];  // inclusive
+__device__ __forceinline__ void dc_block_scan(int v[3], int* s_sum /* 3 x 16 */, int) {
+  int x[3] = {v[0], v[1], v[2]}, all[3];
+  wg_incl_scan<1024, 3>(x, s_sum, all);
+  v[0] = x[0]; v[1] = x[1]; v[2] = x[2];  // inclusive
 }
 __global__ __launch_bounds__(1024) void dc_partial_kernel(const HuffSyncArgs a, int* __restrict__ partial) {
-  __shared__ int s_sum[3 * 1024];
+  __shared__ int s_sum[3 * 16];
   const int tid = (int)threadIdx.x;
   const uint32_t t = blockIdx.x * 1024u + (uint32_t)tid;
   int v[3] = {0, 0, 0};
@@ -1463,24 +1461,13 @@ __global__ __launch_bounds__(1024) void dc_partial_kernel(const HuffSyncArgs a, 
 // form 2 of the write pass: the DC differences sit at [0] of every scan-order block.  Chunks of kPlaceChunk scan positions
 // (1024 left a 4K 4:2:0 frame with 190 workgroups for 256 CUs, each spending most of its time in a ten-step scan).
 constexpr int kPlaceChunk = 256;
-__device__ __forceinline__ void dc_chunk_scan(int v[3], int* s_sum /* 3 x kPlaceChunk */, int tid) {
-#pragma unroll
-  for (int c = 0; c < 3; c++) s_sum[c * kPlaceChunk + tid] = v[c];
-  __syncthreads();
-  for (int d = 1; d < kPlaceChunk; d <<= 1) {
-    int y[3];
-#pragma unroll
-    for (int c = 0; c < 3; c++) y[c] = tid >= d ? s_sum[c * kPlaceChunk + tid - d] : 0;
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < 3; c++) s_sum[c * kPlaceChunk + tid] += y[c];
-    __syncthreads();
-  }
-#pragma unroll
-  for (int c = 0; c < 3; c++) v[c] = s_sum[c * kPlaceChunk + tid];  // inclusive
+__device__ __forceinline__ void dc_chunk_scan(int v[3], int* s_sum /* 3 x kPlaceChunk / 64 */, int) {
+  int x[3] = {v[0], v[1], v[2]}, all[3];
+  wg_incl_scan<kPlaceChunk, 3>(x, s_sum, all);
+  v[0] = x[0]; v[1] = x[1]; v[2] = x[2];  // inclusive
 }
 __global__ __launch_bounds__(kPlaceChunk) void dc_partial2_kernel(const HuffSyncArgs a, int* __restrict__ partial) {
-  __shared__ int s_sum[3 * kPlaceChunk];
+  __shared__ int s_sum[3 * (kPlaceChunk / 64)];
   const int tid = (int)threadIdx.x;
   const uint32_t t = blockIdx.x * (uint32_t)kPlaceChunk + (uint32_t)tid;
   int v[3] = {0, 0, 0};
@@ -1493,7 +1480,7 @@ __global__ __launch_bounds__(kPlaceChunk) void dc_partial2_kernel(const HuffSync
 // two coefficients of one natural-order pair from the block's zig-zag scratch row (one 128-byte line per block) and the wave
 // stores 2 x 128 contiguous bytes.  Dummy blocks of edge MCUs are dropped here.
 __global__ __launch_bounds__(kPlaceChunk) void coef_place_kernel(const HuffSyncArgs a, const int* __restrict__ partial) {
-  __shared__ int s_sum[3 * kPlaceChunk];
+  __shared__ int s_sum[3 * (kPlaceChunk / 64)];
   __shared__ int16_t s_dc[kPlaceChunk];
   __shared__ uint32_t s_dst[kPlaceChunk];  // component << 30 | JBLOCK index inside its array; ~0: a dummy block of an edge MCU
   __shared__ uint8_t s_inv[64];            // natural index -> zig-zag position
@@ -1539,7 +1526,7 @@ __global__ __launch_bounds__(kPlaceChunk) void coef_place_kernel(const HuffSyncA
   }
 }
 __global__ __launch_bounds__(1024) void dc_scan_partials_kernel(int* __restrict__ partial, int nchunks) {  // exclusive, in place
-  __shared__ int s_sum[3 * 1024];
+  __shared__ int s_sum[3 * 16];
   const int tid = (int)threadIdx.x;
   const int per = (nchunks + 1023) / 1024, lo = min(tid * per, nchunks), hi = min(lo + per, nchunks);
   int v[3] = {0, 0, 0};
@@ -1556,7 +1543,7 @@ __global__ __launch_bounds__(1024) void dc_scan_partials_kernel(int* __restrict_
     }
 }
 __global__ __launch_bounds__(1024) void dc_apply_kernel(const HuffSyncArgs a, const int* __restrict__ partial) {
-  __shared__ int s_sum[3 * 1024];
+  __shared__ int s_sum[3 * 16];
   const int tid = (int)threadIdx.x;
   const uint32_t t = blockIdx.x * 1024u + (uint32_t)tid;
   const uint32_t bpm = (uint32_t)a.blocks_per_mcu;

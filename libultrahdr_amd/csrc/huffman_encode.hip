@@ -23,6 +23,7 @@
 // Two launches of that kernel (size classes of the LDS bit buffer, see below), then a tiny kernel turns the interval
 // sizes into offsets and a gather kernel copies the slots into the final stream with the RSTn markers in between.
 #include "lds_copy.h"
+#include "wg_scan.h"
 #include "uhdr_types.h"
 
 namespace uhdr {
@@ -465,37 +466,32 @@ __global__ __launch_bounds__(64) void huff_stream_kernel(const HuffArgs a, const
 // prefix)` is called for every element.  Round 5's form walked `per` consecutive elements per thread straight from global memory --
 // one cache line per lane and instruction, each load waiting for the one before: 40 us for the 6075 chunk counts of a 4K map.
 template <int NT = 1024, typename Sink>  // NT threads; tiles of 8 * NT words
-__device__ __forceinline__ uint64_t wg_scan_tiles(const uint32_t* __restrict__ v, int n, uint32_t* s_val /* 8 * NT */, uint64_t* s_sum /* NT */, Sink sink) {
+__device__ __forceinline__ uint64_t wg_scan_tiles(const uint32_t* __restrict__ v, int n, uint32_t* s_val /* 8 * NT */, uint64_t* s_sum /* NT / 64 */, Sink sink) {
   const int tid = (int)threadIdx.x;
   uint64_t carry = 0;
   for (int base = 0; base < n; base += 8 * NT) {
+    // all eight loads in flight (clamped index; "i < n ? v[i] : 0" compiles to a branch per load with the wait for it inside: eight memory
+    // latencies per tile on the one workgroup everything behind this kernel waits for -- round 6, tools/lds_staging_check.py)
+    uint32_t ld[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const int i = base + j * NT + tid;
-      s_val[j * NT + tid] = i < n ? v[i] : 0u;
-    }
+    for (int j = 0; j < 8; j++) ld[j] = v[min(base + j * NT + tid, n - 1)];
+#pragma unroll
+    for (int j = 0; j < 8; j++) s_val[j * NT + tid] = base + j * NT + tid < n ? ld[j] : 0u;
     __syncthreads();
     uint32_t x[8];
     uint64_t sum = 0;
 #pragma unroll
     for (int j = 0; j < 8; j++) { x[j] = s_val[tid * 8 + j]; sum += x[j]; }
-    s_sum[tid] = sum;
-    __syncthreads();
-    for (int d = 1; d < NT; d <<= 1) {
-      const uint64_t y = tid >= d ? s_sum[tid - d] : 0;
-      __syncthreads();
-      s_sum[tid] += y;
-      __syncthreads();
-    }
-    uint64_t run = carry + s_sum[tid] - sum;
+    uint64_t sc[1] = {sum}, all[1];
+    wg_incl_scan<NT, 1>(sc, s_sum, all);  // (ends with a barrier: s_val may be rewritten by the next tile)
+    uint64_t run = carry + sc[0] - sum;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const int i = base + tid * 8 + j;
       if (i < n) sink(i, x[j], run);
       run += x[j];
     }
-    carry += s_sum[NT - 1];
-    __syncthreads();  // s_val / s_sum are rewritten by the next tile
+    carry += all[0];
   }
   return carry;
 }
@@ -507,7 +503,7 @@ __device__ __forceinline__ uint64_t wg_scan_tiles(const uint32_t* __restrict__ v
 constexpr int kStreamScanThreads = 256;
 __global__ __launch_bounds__(kStreamScanThreads) void huff_stream_scan_kernel(const uint32_t* __restrict__ seg_bits, int nseg, const HuffStream t) {
   __shared__ uint32_t s_val[8 * kStreamScanThreads];
-  __shared__ uint64_t s_sum[kStreamScanThreads];
+  __shared__ uint64_t s_sum[kStreamScanThreads / 64];
   __shared__ uint32_t s_bad;
   const int tid = (int)threadIdx.x;
   if (tid == 0) s_bad = 0;
@@ -576,7 +572,7 @@ __global__ __launch_bounds__(256) void huff_stuff_count_kernel(const HuffStream 
 // kernel's last workgroup was measured and dropped: see huffman_decode_sync.hip, unstuff_count_kernel.)
 __global__ __launch_bounds__(kStreamScanThreads) void huff_stuff_scan_kernel(uint32_t* __restrict__ counts, int nchunks, const HuffStream t, uint64_t* __restrict__ out_bytes) {
   __shared__ uint32_t s_val[8 * kStreamScanThreads];
-  __shared__ uint64_t s_sum[kStreamScanThreads];
+  __shared__ uint64_t s_sum[kStreamScanThreads / 64];
   const uint64_t total_bits = (uint64_t)t.meta[0] | ((uint64_t)t.meta[1] << 32);
   const uint64_t nraw = (total_bits + 7u) >> 3;
   const int used = (int)min((uint64_t)nchunks, (nraw + kStuffChunk - 1) / kStuffChunk);  // chunks beyond the stream hold zeros and are never read

@@ -23,10 +23,13 @@ __device__ __forceinline__ void copy_words_to_lds(uint32_t* dst, const uint32_t*
       const uint32_t j = i + (uint32_t)u * nthreads;
       v[u] = s4[j < nv ? j : i];  // (a clamped index instead of a branch: the loads stay back to back)
     }
+    // Unconditional stores (beyond the end: element i once more, the same value from the same thread).  With "if (j < nv) d4[j] = v[u]" the
+    // compiler sinks every load into the branch of its store and waits for it there -- one latency per element again (seen in the ISA of
+    // hyp_straggler_kernel, round 6; a compiler barrier between the two loops does not stop it).
 #pragma unroll
     for (int u = 0; u < UNROLL; u++) {
       const uint32_t j = i + (uint32_t)u * nthreads;
-      if (j < nv) d4[j] = v[u];
+      d4[j < nv ? j : i] = v[u];
     }
   }
 }
@@ -52,7 +55,7 @@ __device__ __forceinline__ void copy_to_lds(void* dst_, const void* __restrict__
 #pragma unroll
     for (int u = 0; u < UNROLL; u++) {
       const uint32_t j = i + (uint32_t)u * nthreads;
-      if (j < nwords) dst[j] = v[u];
+      dst[j < nwords ? j : i] = v[u];
     }
   }
 }

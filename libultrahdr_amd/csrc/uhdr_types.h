@@ -387,7 +387,7 @@ struct HuffSyncArgs {
   uint64_t* hyp_state;        // [nsub][kHuffHypSlots]: state of the slot's path at the END of the subsequence
   uint8_t* hyp_map;           // [nsub][kHuffHypSlots]: the slot of subsequence i + 1 the path is in at ITS end (0xff: none)
   uint16_t* hyp_cnt;          // [nsub][kHuffHypSlots]: blocks the path completes while crossing subsequence i + 1
-  int hyp_hist;               // debug: count the merges per level in flags[10..15]
+  int hyp_hist;               // debug: count the merges per level in flags[10..15], the stragglers' in flags[22..31]
   // round 5: pass 1 runs hyp_main_levels levels in lockstep (0: all of them) and hands the paths still alive to
   // hyp_straggler_kernel, one WAVE per path (lane o looks the symbol at bit o of a 64-bit window up in all four tables, one
   // scalar chain follows the true boundaries with v_readlane): strag_list[n] = {start subsequence, hypothesis | level << 8},
