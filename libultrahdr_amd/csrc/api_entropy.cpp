@@ -178,7 +178,7 @@ static bool make_dec_table(const uint8_t bits[17], const uint8_t vals[256], Huff
 }
 
 // two-level form for the self-synchronising decoder; false when the table needs more than kHuffL2Max sub-tables
-static bool make_fast_table(const uint8_t bits[17], const uint8_t vals[256], HuffFastTable* t) {
+static bool make_fast_table(const uint8_t bits[17], const uint8_t vals[256], HuffFastTable* t, int* nsub_out = nullptr) {
   memset(t, 0, sizeof *t);
   int code = 0, k = 0, nsub = 0;
   int sub_of[512];
@@ -202,6 +202,7 @@ static bool make_fast_table(const uint8_t bits[17], const uint8_t vals[256], Huf
     }
     code <<= 1;
   }
+  if (nsub_out) *nsub_out = nsub;
   return true;
 }
 
@@ -272,7 +273,7 @@ static void make_value_table(const HuffFastTable& f, bool is_dc, uint32_t* out /
 // a DC or AC symbol of this table is read with, as long as the block does not end (the kernel checks that, and that the
 // subsequence does not end, before it takes the second symbol).  A second symbol is entered only when its CODE lies wholly inside
 // the index bits that the first symbol leaves (a prefix code: the bits beyond cannot change which code it is).
-static void make_pair_table(const HuffFastTable& f, const HuffFastTable& t, const HuffFastTable& f_ac, const HuffFastTable& t_ac, uint32_t* out /* kHuffPairWords */) {
+static void make_pair_table(const HuffFastTable& f, const HuffFastTable& t, const HuffFastTable& f_ac, const HuffFastTable& t_ac, int l2_base, uint32_t* out /* kHuffPairWords */) {
   constexpr int B = kHuffPairBits;
   for (int idx = 0; idx < kHuffPairWords; idx++) {
     const int p9 = idx >> (B - 9);
@@ -283,7 +284,7 @@ static void make_pair_table(const HuffFastTable& f, const HuffFastTable& t, cons
       const int sub = e & 31, rest = (idx & ((1 << (B - 9)) - 1)) << (16 - B);  // the index bits beyond the ninth, as the top bits of the 7-bit remainder
       const uint16_t e2 = f.l2[sub][rest];
       if (e2 == 0 || (int)((e2 >> 8) & 31u) > B) {  // not decided by the index bits
-        out[idx] = 0x80000000u | (uint32_t)sub;
+        out[idx] = 0x80000000u | (uint32_t)(l2_base + sub);  // (the index into the packed sub-tables of all four tables)
         continue;
       }
       first = t.l2[sub][rest];
@@ -311,7 +312,7 @@ static void make_pair_table(const HuffFastTable& f, const HuffFastTable& t, cons
 // and the AC symbol behind it (0: none), each in make_value_table's form.  v / v_ac: the value forms (kHuffValWords words: first
 // level, then the sub-tables).  A first symbol that is malformed, or whose code is longer than the index, is marked 0x80000000 | sub-table
 // (its first-level word when the code has no sub-table: the kernel then reads the one-symbol entry the slow way).
-static void make_pair_value_table(const HuffFastTable& f, const uint32_t* v, const HuffFastTable& f_ac, const uint32_t* v_ac, uint32_t* out /* 2 x kHuffPairWords */) {
+static void make_pair_value_table(const HuffFastTable& f, const uint32_t* v, const HuffFastTable& f_ac, const uint32_t* v_ac, int l2_base, uint32_t* out /* 2 x kHuffPairWords */) {
   constexpr int B = kHuffPairBits;
   for (int idx = 0; idx < kHuffPairWords; idx++) {
     const int p9 = idx >> (B - 9);
@@ -322,7 +323,7 @@ static void make_pair_value_table(const HuffFastTable& f, const uint32_t* v, con
       const int sub = e & 31, rest = (idx & ((1 << (B - 9)) - 1)) << (16 - B);
       const uint16_t e2 = f.l2[sub][rest];
       if (e2 == 0 || (int)((e2 >> 8) & 31u) > B) {
-        out[2 * idx] = 0x80000000u | (uint32_t)sub;
+        out[2 * idx] = 0x80000000u | (uint32_t)(l2_base + sub);
         out[2 * idx + 1] = 0;
         continue;
       }
@@ -386,11 +387,15 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
       std::vector<HuffFastTable> ftabs(8);
       std::vector<uint32_t> vtabs((size_t)4 * kHuffValWords), ptabs((size_t)kHuffPairBlobWords), pvtabs((size_t)kHuffPairValBlobWords);
       bool fast_ok = true;
+      int l2_count[4] = {0, 0, 0, 0};
       for (int t = 0; t < 4; t++) {
         const uint8_t* bits = key + (size_t)t * (17 + 256);
         if (!make_dec_table(bits, bits + 17, &tabs[(size_t)t])) return err_status(UHDR_CODEC_INVALID_PARAM, "Huffman table %d is not a valid DHT table", t);
-        fast_ok = make_fast_table(bits, bits + 17, &ftabs[(size_t)t]) && fast_ok;
+        fast_ok = make_fast_table(bits, bits + 17, &ftabs[(size_t)t], &l2_count[t]) && fast_ok;
       }
+      int l2_base[4] = {0, 0, 0, 0};
+      for (int t = 1; t < 4; t++) l2_base[t] = l2_base[t - 1] + l2_count[t - 1];
+      if (l2_base[3] + l2_count[3] > kHuffL2Total) fast_ok = false;  // more long-code prefixes than the packed sub-table array holds
       if (fast_ok)
         for (int t = 0; t < 4; t++) {
           make_track_table(ftabs[(size_t)t], (t & 1) == 0, &ftabs[(size_t)t + 4]);
@@ -399,13 +404,13 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
       if (fast_ok)
         for (int t = 0; t < 4; t++)  // (after the loop above: the AC tables' tracking forms exist)
         {
-          make_pair_table(ftabs[(size_t)t], ftabs[(size_t)t + 4], ftabs[(size_t)(t | 1)], ftabs[(size_t)(t | 1) + 4], ptabs.data() + (size_t)t * kHuffPairWords);
+          make_pair_table(ftabs[(size_t)t], ftabs[(size_t)t + 4], ftabs[(size_t)(t | 1)], ftabs[(size_t)(t | 1) + 4], l2_base[t], ptabs.data() + (size_t)t * kHuffPairWords);
           make_pair_value_table(ftabs[(size_t)t], vtabs.data() + (size_t)t * kHuffValWords, ftabs[(size_t)(t | 1)], vtabs.data() + (size_t)(t | 1) * kHuffValWords,
-                                pvtabs.data() + (size_t)t * 2 * kHuffPairWords);
+                                l2_base[t], pvtabs.data() + (size_t)t * 2 * kHuffPairWords);
           // the second levels behind them, 16 bits per entry (the kernels' LDS structs are copies of these blobs)
-          uint16_t* l2t = (uint16_t*)(ptabs.data() + (size_t)4 * kHuffPairWords) + (size_t)t * kHuffL2Max * 128;
-          uint16_t* l2v = (uint16_t*)(pvtabs.data() + (size_t)8 * kHuffPairWords) + (size_t)t * kHuffL2Max * 128;
-          for (int i = 0; i < kHuffL2Max * 128; i++) {
+          uint16_t* l2t = (uint16_t*)(ptabs.data() + (size_t)4 * kHuffPairWords) + (size_t)l2_base[t] * 128;
+          uint16_t* l2v = (uint16_t*)(pvtabs.data() + (size_t)8 * kHuffPairWords) + (size_t)l2_base[t] * 128;
+          for (int i = 0; i < l2_count[t] * 128; i++) {
             l2t[i] = ftabs[(size_t)t + 4].l2[i / 128][i % 128];
             const uint32_t v = vtabs[(size_t)t * kHuffValWords + 512 + (size_t)i];
             l2v[i] = (uint16_t)(((v >> 16) & 1u) ? 0u : (v & 0xffffu));
@@ -648,6 +653,7 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
           y.hyp_h = bpm;
           y.hyp_levels = t.levels;
           y.hyp_main_levels = rst_sync ? 0 : main_levels_env;
+          y.strag_levels = [&] { const char* e = getenv("UHDR_HIP_HUFF_STRAG_LEVELS"); return e ? atoi(e) : t.levels; }();
           y.hyp_state = (uint64_t*)(sb + o_hs);
           y.hyp_map = sb + o_hm;
           y.hyp_cnt = (uint16_t*)(sb + o_hc);

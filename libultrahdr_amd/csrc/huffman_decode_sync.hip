@@ -431,7 +431,7 @@ __device__ __forceinline__ void track_span(const HuffSyncArgs& a, const Staged& 
 // Every state this walk passes through is a state of track_span's walk, and the final state is the same.
 struct __attribute__((aligned(16))) PairLds {  // == the layout of HuffSyncArgs::ptabs
   uint32_t p[4][kHuffPairWords];        // 16 KB
-  uint16_t l2[4][kHuffL2Max * 128];     // 16 KB: the second level of the tracking form, for codes longer than the index
+  uint16_t l2[kHuffL2Total * 128];      // 8 KB: the second level of the tracking form, for codes longer than the index (all four tables', packed)
 };
 static_assert(sizeof(PairLds) == kHuffPairBlobWords * 4, "PairLds is one copy of the host's blob");
 __device__ __forceinline__ void load_pair_lds(const HuffSyncArgs& a, PairLds& L) {
@@ -448,7 +448,7 @@ __device__ __forceinline__ void track_span_pair(const HuffSyncArgs& a, const Sta
 #pragma unroll
   for (int j = 0; j < 16; j++) cpack |= ((uint32_t)a.comp_of[j] & 3u) << (2 * j);
   const uint32_t* P = &L.p[0][0];
-  const uint16_t* S = &L.l2[0][0];
+  const uint16_t* S = &L.l2[0];
   uint32_t cls = ((cpack >> (2u * b)) & 3u) ? 2u : 0u;  // the component's DC table; its AC table follows
   int left = (int)(end_bit - p);
   while (left > 0) {
@@ -457,7 +457,7 @@ __device__ __forceinline__ void track_span_pair(const HuffSyncArgs& a, const Sta
     const uint32_t ti = cls + (k ? 1u : 0u);
     uint32_t e = P[ti * (uint32_t)kHuffPairWords + (w16 >> (16 - kHuffPairBits))];
     if (__builtin_amdgcn_ballot_w64((e >> 31) != 0) != 0) {
-      const uint32_t e2 = S[ti * (uint32_t)(kHuffL2Max * 128) + ((e >> 31) ? (e & 15u) : 0u) * 128u + (w16 & 127u)];
+      const uint32_t e2 = S[((e >> 31) ? (e & 63u) : 0u) * 128u + (w16 & 127u)];
       e = (e >> 31) ? e2 : e;  // tracking form: no second symbol
     }
     const uint32_t adv1 = e & 31u, kinc1 = (e >> 5) & 127u, adv2 = (e >> 12) & 31u, kinc2 = (e >> 17) & 127u;
@@ -772,7 +772,7 @@ __global__ __launch_bounds__(256) void sync_write_kernel(const HuffSyncArgs a, i
 // lane's symbol chain, and 0.6 steps per symbol are 0.6 of its time.
 struct __attribute__((aligned(16))) Write2Lds {  // == the layout of HuffSyncArgs::pvtabs
   uint2 p[4][kHuffPairWords];             // 32 KB: {first symbol, second symbol or 0}, value form
-  uint16_t l2[4][kHuffL2Max * 128];       // 16 KB: the sub-tables of the value form (codes longer than the index): bits | advance << 5 |
+  uint16_t l2[kHuffL2Total * 128];        // 8 KB: the sub-tables of the value form, packed (codes longer than the index): bits | advance << 5 |
                                           // magnitude bits << 12; 0 = a malformed code (16 bits, to the end of the block / one DC step)
 };
 __device__ __forceinline__ void write_span2(const HuffSyncArgs& a, const Staged& st, uint32_t region_bit, const Write2Lds& L, uint32_t p, uint32_t b, uint32_t k,
@@ -787,7 +787,7 @@ __device__ __forceinline__ void write_span2(const HuffSyncArgs& a, const Staged&
 #pragma unroll
   for (int j = 0; j < 16; j++) cpack |= ((uint32_t)a.comp_of[j] & 3u) << (2 * j);
   const uint2* P = &L.p[0][0];
-  const uint16_t* S = &L.l2[0][0];
+  const uint16_t* S = &L.l2[0];
   uint32_t cls = ((cpack >> (2u * b)) & 3u) ? 2u : 0u;
   int16_t* dst = a.coef_scan + (size_t)blk * 64;
   int left = (int)(end_bit - p);
@@ -798,7 +798,7 @@ __device__ __forceinline__ void write_span2(const HuffSyncArgs& a, const Staged&
     const uint2 e = P[ti * (uint32_t)kHuffPairWords + (w16 >> (16 - kHuffPairBits))];
     uint32_t e1 = e.x, e2 = e.y;
     if (__builtin_amdgcn_ballot_w64((e1 >> 31) != 0) != 0) {  // a code longer than the index: its sub-table, one symbol
-      uint32_t s2 = S[ti * (uint32_t)(kHuffL2Max * 128) + ((e1 >> 31) ? (e1 & 15u) : 0u) * 128u + (w16 & 127u)];
+      uint32_t s2 = S[((e1 >> 31) ? (e1 & 63u) : 0u) * 128u + (w16 & 127u)];
       s2 = s2 ? s2 : (16u | ((k ? 64u : 1u) << 5) | (1u << 16));  // malformed: make_value_table's entry for an undefined code
       e1 = (e1 >> 31) ? s2 : e1;
     }
@@ -1138,6 +1138,7 @@ __global__ __launch_bounds__(64 * kStragWaves) void hyp_straggler_kernel(const H
   const uint32_t nsub = (nbits + a.sub_bits - 1) / a.sub_bits;
   const uint32_t H = (uint32_t)a.hyp_h, bpm = (uint32_t)a.blocks_per_mcu;
   const uint32_t l_main = (uint32_t)a.hyp_main_levels;
+  const uint32_t l_cap = (uint32_t)min(a.hyp_levels, a.strag_levels);
   uint32_t cpack = 0;
 #pragma unroll
   for (int j = 0; j < 16; j++) cpack |= ((uint32_t)a.comp_of[j] & 3u) << (2 * j);
@@ -1176,7 +1177,7 @@ __global__ __launch_bounds__(64 * kStragWaves) void hyp_straggler_kernel(const H
     uint32_t p = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)s0);
     uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(s0 >> 32) & 0xffu));
     uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(s0 >> 40) & 0xffu));
-    for (uint32_t l = l0 + 1; l <= (uint32_t)a.hyp_levels; l++) {
+    for (uint32_t l = l0 + 1; l <= l_cap; l++) {
       const uint32_t j = i + l;
       if (j >= nsub) break;
       const uint32_t end_bit = min((j + 1) * a.sub_bits, nbits);
@@ -1265,7 +1266,7 @@ __global__ __launch_bounds__(64 * kStragWaves) void hyp_straggler_kernel(const H
         }
         break;
       }
-      if (l == (uint32_t)a.hyp_levels) {  // map stays 0xff: not merged within the budget
+      if (l == l_cap) {  // map stays 0xff: not merged within the budget
         if (lane == 0) atomicAdd(a.flags + 3, 1u);
         break;
       }

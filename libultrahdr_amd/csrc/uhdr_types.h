@@ -357,8 +357,12 @@ constexpr int kHuffPairBits = 10, kHuffPairWords = 1 << kHuffPairBits;
 // the blobs the kernels stage with ONE copy: ptabs = 4 pair tables, then the four tracking tables' second levels (uint16); pvtabs = 4 x
 // kHuffPairWords x {first, second} value words, then the four value tables' second levels as uint16 (bits | advance << 5 | magnitude bits
 // << 12; 0 = malformed)
-constexpr int kHuffPairBlobWords = 4 * kHuffPairWords + 4 * kHuffL2Max * 128 / 2;
-constexpr int kHuffPairValBlobWords = 8 * kHuffPairWords + 4 * kHuffL2Max * 128 / 2;
+// The sub-tables of all four tables are PACKED behind the pair words (round 6): kHuffL2Total of them in all -- the Annex K tables use 0 + 5 + 1 + 5 -- and a
+// long-code entry carries the index into the packed array.  (Four times kHuffL2Max sub-tables, 16 KB of which 13 held nothing, were LDS that kept a
+// workgroup of the other scan's kernels off the CU.)
+constexpr int kHuffL2Total = 32;
+constexpr int kHuffPairBlobWords = 4 * kHuffPairWords + kHuffL2Total * 128 / 2;
+constexpr int kHuffPairValBlobWords = 8 * kHuffPairWords + kHuffL2Total * 128 / 2;
 struct HuffSyncArgs {
   const uint8_t* clean;       // unstuffed entropy-coded bytes (device)
   uint32_t nbytes;            // size of the STUFFED stream (upper bound of the clean size)
@@ -393,6 +397,7 @@ struct HuffSyncArgs {
   // scalar chain follows the true boundaries with v_readlane): strag_list[n] = {start subsequence, hypothesis | level << 8},
   // n = flags[kHuffFlagStragglers] (zeroed by pass 0)
   int hyp_main_levels;
+  int strag_levels;           // the last level a straggler's wave walks (<= hyp_levels); a path still unmerged there is given up (its map stays 0xff)
   uint32_t* strag_list;
   uint32_t strag_cap;
   // round 5: write pass, form 2 (marker-less scans): coefficients go to a scan-order scratch (block t at coef_scan + 64 t, zig-zag
