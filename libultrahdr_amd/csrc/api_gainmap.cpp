@@ -242,8 +242,15 @@ uhdr_error_info_t uhdr_hip_apply_gainmap_coef_dev(uhdr_hip_ctx_t* c, const uhdr_
                       "aligned destination rows, gain map at scale 1 or an even scale <= 8 with gamma 1); decode with idct_dequant and call apply_gainmap");
   constexpr unsigned int kSlots = 8;
   if (!c->d_coef_src) HIP_TRY(hipMalloc((void**)&c->d_coef_src, sizeof(CoefSrc) * kSlots));
-  CoefSrc* slot = c->d_coef_src + (c->coef_src_next++ % kSlots);
-  HIP_TRY(hipMemcpyAsync(slot, &cs, sizeof cs, hipMemcpyHostToDevice, c->stream));  // pageable source: staged before return
+  CoefSrc* slot = c->coef_src_last_slot;
+  if (!slot || c->coef_src_last.size() != sizeof cs || memcmp(c->coef_src_last.data(), &cs, sizeof cs) != 0) {
+    // (a service decodes frame after frame of one geometry into the same buffers: the descriptor of the latest upload is the one wanted again,
+    // and a 7 us staged copy in front of every launch goes away)
+    slot = c->d_coef_src + (c->coef_src_next++ % kSlots);
+    HIP_TRY(hipMemcpyAsync(slot, &cs, sizeof cs, hipMemcpyHostToDevice, c->stream));  // pageable source: staged before return
+    c->coef_src_last.assign((const uint8_t*)&cs, (const uint8_t*)&cs + sizeof cs);
+    c->coef_src_last_slot = slot;
+  }
   p.coef_src = slot;
   {
     ProfScope ps(c, "apply_gainmap");

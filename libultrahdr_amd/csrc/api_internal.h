@@ -187,6 +187,8 @@ struct uhdr_hip_ctx {
   uint32_t* d_huff = nullptr;     // Annex K code tables (kHuffTabWords) followed by the 64-byte zig-zag map
   CoefSrc* d_coef_src = nullptr;  // apply_gainmap_coef descriptors (rotating slots)
   unsigned int coef_src_next = 0;
+  CoefSrc* coef_src_last_slot = nullptr;  // the slot of the latest upload, and what went up: the same descriptor again takes no copy
+  std::vector<uint8_t> coef_src_last;
   // encode-side step tables (host_tables.cpp): sRGB byte of the tone mapper (one per context), 10-bit code -> linear
   // value per HDR transfer, encodeGain's byte per (min boost, max boost)
   float* d_srgb8 = nullptr;
