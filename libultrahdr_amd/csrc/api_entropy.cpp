@@ -879,6 +879,23 @@ void aux_worker_destroy(uhdr_hip_ctx* c) {
     c->aux_worker = nullptr;
   }
 }
+bool uhdr_api::aux_post(uhdr_hip_ctx* c, std::function<void()> job) {
+  static const bool no_thread = getenv("UHDR_HIP_NO_AUX_THREAD") != nullptr;
+  if (no_thread) return false;
+  if (!c->aux_worker) {
+    try {
+      c->aux_worker = new AuxWorker();
+    } catch (...) {
+      c->aux_worker = nullptr;
+    }
+  }
+  if (!c->aux_worker) return false;
+  c->aux_worker->run(std::move(job));
+  return true;
+}
+void uhdr_api::aux_wait(uhdr_hip_ctx* c) {
+  if (c->aux_worker) c->aux_worker->wait();
+}
 namespace {
 // job_b on the context's worker thread while job_a runs on the caller's; without a thread to be had: one after the other (still on two streams)
 template <typename FA, typename FB>

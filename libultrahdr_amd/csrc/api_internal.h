@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstring>
 #include <atomic>
+#include <functional>
 #include <map>
 #include <memory>
 #include <string>
@@ -209,6 +210,11 @@ struct uhdr_hip_ctx {
   // between: the chain leaves the metadata's inputs here (the copy to h_mm is enqueued) and the entry point finishes them after the
   // entropy stage's own synchronisation
   bool defer_md = false;
+  // uhdr_hip_encode_api1_scans_dev (round 6): called by the fused chain as soon as the base image's blocks are enqueued on the auxiliary stream -- the
+  // caller posts the base scan's entropy coding to the worker thread there, two kernels into the chain instead of behind it.  side_job_posted: the
+  // auxiliary context belongs to that job until the caller has waited for it.
+  std::function<void()> on_side_launched;
+  bool side_job_posted = false;
   struct DeferredMd { bool valid = false, run = false; uhdr_hip_encode_cfg_t cfg; uhdr_color_transfer_t hdr_ct; int use_base_cg = 1; } deferred_md;
   hipEvent_t aux_ev = nullptr;   // orders the auxiliary context's stream behind this one (two-scan entropy entry points)
   hipEvent_t aux_ev2 = nullptr;  // ... and this one behind the auxiliary stream (the fused API-1 chain's base-image launch)
@@ -280,6 +286,9 @@ uhdr_error_info_t check_scan(const uhdr_hip_jpeg_scan_t* sc, bool need_coef, int
 // the context's auxiliary context (own stream, scratch, table cache; created on first use) and the hand-back of what it counted / timed
 uhdr_error_info_t aux_context(uhdr_hip_ctx* c, uhdr_hip_ctx** out);
 void aux_merge(uhdr_hip_ctx* c);
+// a job for the context's worker thread (created on first use; false: no thread to be had, nothing posted) / wait for it
+bool aux_post(uhdr_hip_ctx* c, std::function<void()> job);
+void aux_wait(uhdr_hip_ctx* c);
 }  // namespace uhdr_api
 using namespace uhdr_api;
 

@@ -296,6 +296,7 @@ uhdr_error_info_t uhdr_hip_encode_api1_fused_dev(uhdr_hip_ctx_t* c, const uhdr_r
         }
         note_hip(hipEventRecord(c->aux_ev2, x->stream), "base blocks event");
         side = x;
+        if (c->on_side_launched) c->on_side_launched();
       }
     }
   }
@@ -344,7 +345,7 @@ uhdr_error_info_t uhdr_hip_encode_api1_fused_dev(uhdr_hip_ctx_t* c, const uhdr_r
   }
   if (side) {  // the base image's coefficients belong to this stream's order from here on (whatever happened above)
     note_hip(hipStreamWaitEvent(c->stream, c->aux_ev2, 0), "base blocks wait");
-    aux_merge(c);
+    if (!c->side_job_posted) aux_merge(c);  // (else the auxiliary context is the worker thread's until the caller has waited for its job)
   }
   chain.reset();
   note_hip(hipMemcpyAsync(c->h_mm, final_mm, 9 * sizeof(float), hipMemcpyDeviceToHost, c->stream), "metadata copy");
@@ -438,25 +439,7 @@ static uhdr_error_info_t encode_api1_scans_impl(uhdr_hip_ctx_t* c, const uhdr_ra
   for (int i = 0; i < nch; i++) blocks.map_coef[i] = (int16_t*)((uint8_t*)c->enc[0].p + o_map[i]);
   uhdr_raw_image_t gm;
   memset(&gm, 0, sizeof gm);
-  c->defer_md = dev;  // device-resident callers: no host synchronisation between the chain and the entropy stage
-  c->deferred_md.valid = false;
-  const uhdr_error_info_t fs = uhdr_hip_encode_api1_fused_dev(c, &ds, &dh, cfg, base_encoding, qt_base, qt_map, &blocks, md, nullptr);
-  c->defer_md = false;
-  if (fs.error_code != UHDR_CODEC_OK) return fs;
-  auto finish_deferred_md = [&]() -> uhdr_error_info_t {  // (after a synchronisation of c->stream)
-    if (!c->deferred_md.valid) return ok_status();
-    c->deferred_md.valid = false;
-    float mm[6];
-    memcpy(mm, c->h_mm, sizeof mm);
-    if (c->deferred_md.run) note_table_stats(c, &c->deferred_md.cfg);
-    return generate_gainmap_finalize_md(&c->deferred_md.cfg, c->deferred_md.hdr_ct, c->deferred_md.use_base_cg, mm, md);
-  };
-  if (gainmap_desc) {  // what generateGainMap's freshly allocated image would say (jpegr.cpp:714-716); planes untouched
-    gainmap_desc->fmt = nch == 3 ? UHDR_IMG_FMT_24bppRGB888 : UHDR_IMG_FMT_8bppYCbCr400;
-    gainmap_desc->cg = hdr->cg; gainmap_desc->ct = hdr->ct; gainmap_desc->range = hdr->range;
-    gainmap_desc->w = mw; gainmap_desc->h = mh;
-  }
-  // the two scans: device buffers as large as the caller's, then one copy each
+  // the two scans
   uhdr_hip_jpeg_scan_t sb, sm;
   memset(&sb, 0, sizeof sb);
   memset(&sm, 0, sizeof sm);
@@ -479,8 +462,57 @@ static uhdr_error_info_t encode_api1_scans_impl(uhdr_hip_ctx_t* c, const uhdr_ra
   if (base_capacity > 0xFFFFFFF0u) base_capacity = 0xFFFFFFF0u;
   if (map_capacity > 0xFFFFFFF0u) map_capacity = 0xFFFFFFF0u;
   size_t nbs = 0, nms = 0;
+  // Round 6, device-resident callers: the base image's scan is coded on the auxiliary stream, straight behind the base image's blocks there -- the
+  // worker thread gets the job the moment that launch is out, while this thread is still enqueuing the gain-map passes -- and the map's scan on
+  // this stream behind the map's blocks.  (Both scans used to wait, by event, for the WHOLE chain: the base image's 150 us of entropy coding
+  // started 80 us later than its input was ready, and ended the encode.)
+  uhdr_error_info_t rb = ok_status();
+  static const bool late_base = getenv("UHDR_HIP_NO_EARLY_BASE_SCAN") != nullptr;
+  if (dev && !late_base) {
+    const int devno = c->device;
+    c->on_side_launched = [&, devno] {
+      uhdr_hip_ctx* x = c->aux;
+      c->side_job_posted = aux_post(c, [&, x, devno] {
+        (void)hipSetDevice(devno);
+        rb = uhdr_hip_huffman_encode_dev(x, &sb, base_scan, base_capacity, &nbs);
+      });
+    };
+  }
+  c->side_job_posted = false;
+  c->defer_md = dev;  // device-resident callers: no host synchronisation between the chain and the entropy stage
+  c->deferred_md.valid = false;
+  const uhdr_error_info_t fs = uhdr_hip_encode_api1_fused_dev(c, &ds, &dh, cfg, base_encoding, qt_base, qt_map, &blocks, md, nullptr);
+  c->defer_md = false;
+  c->on_side_launched = nullptr;
+  const bool base_posted = c->side_job_posted;
+  c->side_job_posted = false;
+  if (fs.error_code != UHDR_CODEC_OK) {
+    if (base_posted) { aux_wait(c); aux_merge(c); }
+    return fs;
+  }
+  auto finish_deferred_md = [&]() -> uhdr_error_info_t {  // (after a synchronisation of c->stream)
+    if (!c->deferred_md.valid) return ok_status();
+    c->deferred_md.valid = false;
+    float mm[6];
+    memcpy(mm, c->h_mm, sizeof mm);
+    if (c->deferred_md.run) note_table_stats(c, &c->deferred_md.cfg);
+    return generate_gainmap_finalize_md(&c->deferred_md.cfg, c->deferred_md.hdr_ct, c->deferred_md.use_base_cg, mm, md);
+  };
+  if (gainmap_desc) {  // what generateGainMap's freshly allocated image would say (jpegr.cpp:714-716); planes untouched
+    gainmap_desc->fmt = nch == 3 ? UHDR_IMG_FMT_24bppRGB888 : UHDR_IMG_FMT_8bppYCbCr400;
+    gainmap_desc->cg = hdr->cg; gainmap_desc->ct = hdr->ct; gainmap_desc->range = hdr->range;
+    gainmap_desc->w = mw; gainmap_desc->h = mh;
+  }
   if (dev) {  // straight into the caller's device buffers
-    const uhdr_error_info_t e2 = uhdr_hip_huffman_encode2_dev(c, &sb, base_scan, base_capacity, &nbs, &sm, map_scan, map_capacity, &nms);
+    uhdr_error_info_t e2;
+    if (base_posted) {
+      const uhdr_error_info_t ra = uhdr_hip_huffman_encode_dev(c, &sm, map_scan, map_capacity, &nms);
+      aux_wait(c);
+      aux_merge(c);
+      e2 = rb.error_code != UHDR_CODEC_OK ? rb : ra;
+    } else {
+      e2 = uhdr_hip_huffman_encode2_dev(c, &sb, base_scan, base_capacity, &nbs, &sm, map_scan, map_capacity, &nms);
+    }
     *base_bytes = nbs;
     *map_bytes = nms;
     if (e2.error_code != UHDR_CODEC_OK) {
