@@ -884,10 +884,6 @@ __global__ __launch_bounds__(1024) void hyp_pass0_kernel(const HuffSyncArgs a) {
   extern __shared__ uint32_t s_stage[];
   __shared__ PairLds L;
   load_pair_lds(a, L);
-  if (a.zero_vec) {  // the write pass's scan-order scratch: zeros, written while this pass waits on its lookups
-    const uint4 z = make_uint4(0, 0, 0, 0);
-    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < a.zero_vec; v += gridDim.x * blockDim.x) a.zero_ptr[v] = z;
-  }
   const uint32_t lane = threadIdx.x & 63u, h = threadIdx.x >> 6;
   const uint32_t i = blockIdx.x * 64u + lane;
   const uint32_t nclean = a.nbytes - *a.nstuffed, nbits = nclean * 8u;
@@ -895,6 +891,13 @@ __global__ __launch_bounds__(1024) void hyp_pass0_kernel(const HuffSyncArgs a) {
   const uint32_t cshift = 31u - (uint32_t)__builtin_clz(a.sub_bits >> 3);
   const uint32_t first_byte = blockIdx.x * 64u * (a.sub_bits >> 3);
   stage_wave(a.clean, nclean, first_byte, cshift, s_stage, threadIdx.x, 64u, blockDim.x);
+  if (a.zero_vec) {
+    // the write pass's scan-order scratch: zeros (25-50 MB at 4K).  BEHIND the last global load of this kernel: the walk below reads LDS only, so
+    // the stores drain while it runs.  In front of the staging loads (where this loop stood until round 6) every wave waited for its 56 KB of
+    // stores before its first symbol -- memory operations of a wave complete in order.
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < a.zero_vec; v += gridDim.x * blockDim.x) a.zero_ptr[v] = z;
+  }
   __syncthreads();
   if (i >= nsub) return;
   uint32_t p = i * a.sub_bits, b = h, k = 0, nblk = 0;
