@@ -47,6 +47,24 @@ uhdr_error_info_t uhdr_api::check_scan(const uhdr_hip_jpeg_scan_t* sc, bool need
   return ok_status();
 }
 
+// Wait for everything enqueued on the context's stream.  hipStreamSynchronize blocks on the queue's completion signal (an interrupt and a
+// scheduler wake-up); the entropy coder's waits sit at the end of sub-millisecond calls, so they poll the stream for a bounded while first
+// (UHDR_HIP_SYNC_SPIN_US, default 2000; 0: the blocking wait only).
+static hipError_t wait_stream(uhdr_hip_ctx* c) {
+  static const int spin_us = [] { const char* e = getenv("UHDR_HIP_SYNC_SPIN_US"); return e ? atoi(e) : 2000; }();
+  if (spin_us > 0) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      const hipError_t q = hipStreamQuery(c->stream);
+      if (q == hipSuccess) return hipSuccess;
+      if (q != hipErrorNotReady) return q;
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) break;
+    }
+  }
+  return hipStreamSynchronize(c->stream);
+}
+
+
 uhdr_error_info_t uhdr_hip_huffman_encode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_jpeg_scan_t* sc, uint8_t* out, size_t out_capacity,
                                               size_t* out_bytes) {
   if (!c) return err_status(UHDR_CODEC_INVALID_PARAM, "received nullptr for uhdr_hip context");
@@ -110,7 +128,7 @@ uhdr_error_info_t uhdr_hip_huffman_encode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
     if (!c->h_flags) HIP_TRY(hipHostMalloc((void**)&c->h_flags, 64 * sizeof(uint32_t), hipHostMallocDefault));
     uint32_t* hp = c->h_flags + 48;
     HIP_TRY(hipMemcpyAsync(hp, d_total, sizeof(uint64_t) + 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(wait_stream(c));
     uint64_t total = 0;
     uint32_t meta[4] = {0, 0, 0, 0};
     memcpy(&total, hp, sizeof total);
@@ -141,7 +159,7 @@ uhdr_error_info_t uhdr_hip_huffman_encode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
   uint32_t bad = 0;
   HIP_TRY(hipMemcpyAsync(&total, offsets + a.nseg, sizeof total, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(&bad, status, sizeof bad, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(wait_stream(c));
   if (bad) return err_status(UHDR_CODEC_INVALID_PARAM, "coefficients outside the baseline range (DC difference beyond 11 bits / AC beyond 10 bits)");
   *out_bytes = (size_t)total;
   if (total > out_capacity)
@@ -691,7 +709,7 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
           }
           dbg.mark("huffman_decode_dev: hypothesis attempt enqueued");
           HIP_TRY(hipMemcpyAsync(fl, y.flags, 24 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-          HIP_TRY(hipStreamSynchronize(c->stream));
+          HIP_TRY(wait_stream(c));
           dbg.mark("huffman_decode_dev: hypothesis attempt finished");
           hyp_done = fl[2] == 0;
           if (hyp_done && ti > 0) {  // where the next scan like this one starts
@@ -717,7 +735,7 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
             HIP_TRY(launch_huffman_decode_sync(y, max_rounds, (int*)(sb + o_dcp), &final_buf, c->stream));
           }
           HIP_TRY(hipMemcpyAsync(fl, y.flags, 24 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-          HIP_TRY(hipStreamSynchronize(c->stream));
+          HIP_TRY(wait_stream(c));
           rounds_ran = true;
         }
       }
@@ -765,7 +783,7 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
   else c->stats.entropy_decode_intervals++;
   uint32_t st[2] = {0, 0};
   HIP_TRY(hipMemcpyAsync(st, a.status, sizeof st, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(wait_stream(c));
   if (st[1] != (uint32_t)(a.nseg - 1))
     return err_status(UHDR_CODEC_INVALID_PARAM, "found %u restart markers, a restart interval of %d MCUs over %d MCUs needs %d", st[1], a.ri,
                       a.total_mcus, a.nseg - 1);
