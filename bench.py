@@ -189,9 +189,12 @@ def make_roundtrip(ctx, u, device, w, h, seed=1234):
 
     qts_enc = (qy, qc)
 
+    # (arguments marshalled once: UltraHdr.bindEncodeApi1Scans / bindDecodeApi1Scans -- a per-frame caller's steady state)
+    enc_run = enc1.bindEncodeApi1Scans(sdr, hdr, A.UHDR_CG_DISPLAY_P3, qts_enc, qts_enc, out_b, out_m)
+
     def enc(two=True):
         if two:  # ONE C call: the fused chain + both scans coded concurrently (uhdr_hip_encode_api1_scans_dev)
-            box["nb"], box["nm"], box["md"] = enc1.encodeApi1Scans(sdr, hdr, A.UHDR_CG_DISPLAY_P3, qts_enc, qts_enc, out_b, out_m)
+            box["nb"], box["nm"], box["md"] = enc_run()
             return
         cb, cm, md_, _ = enc1.encodeApi1Fused(sdr, hdr, A.UHDR_CG_DISPLAY_P3, (qy, qc), (qy, qc), want_map=False)
         box["nb"] = int(u.huffman_encode(cb, w, h, S420, 0, out=out_b).numel())
@@ -208,10 +211,12 @@ def make_roundtrip(ctx, u, device, w, h, seed=1234):
     box["dst"] = dst
     qts = [qy, qc, qc]
 
+    dec_run = u.bindDecodeApi1Scans(hb, box["sb"], A.UHDR_CG_BT_709, hm, box["sm"], A.UHDR_CG_BT_2100, box["md"], A.UHDR_CT_LINEAR, f16, A.FLT_MAX, dst)
+
     def dec(two=True):
         sb, sm = box["sb"], box["sm"]
         if two:  # ONE C call: both scans decoded concurrently + the map's IDCT + applyGainMap from coefficients (uhdr_hip_decode_api1_scans_dev)
-            u.decodeApi1Scans(hb, sb, A.UHDR_CG_BT_709, hm, sm, A.UHDR_CG_BT_2100, box["md"], A.UHDR_CT_LINEAR, f16, A.FLT_MAX, dst)
+            dec_run()
             return
         cb = u.huffman_decode(sb, box["shp_b"], w, h, S420, 0)
         cm = u.huffman_decode(sm, box["shp_m"], w, h, S444, 0)

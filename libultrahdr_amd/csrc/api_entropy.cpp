@@ -651,6 +651,7 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
       bool hyp_done = false, unstuffed = false, rounds_ran = false;
       auto start_over = [&](const Attempt& next) -> uhdr_error_info_t {  // an attempt failed: everything it wrote goes back to its initial state
         HIP_TRY(hipMemsetAsync(y.flags, 0, 32, c->stream));  // not [8]: the stuffed-byte count stays
+        HIP_TRY(hipMemsetAsync(y.flags + kHuffFlagStragglers, 0, 4, c->stream));  // (hyp_pass01_kernel appends to the list it finds)
         HIP_TRY(hipMemsetAsync(y.nblk, 0, (size_t)nsub * 4 + 4, c->stream));
         if (form2) {
           if (!pass0_zeroes(next)) HIP_TRY(hipMemsetAsync(y.coef_scan, 0, scan_bytes, c->stream));

@@ -1111,6 +1111,111 @@ __global__ __launch_bounds__(1024) void hyp_pass1q_kernel(const HuffSyncArgs a) 
   }
 }
 
+// ---- passes 0 and 1 in ONE launch, for one lockstep level (hyp_main_levels == 1: sparse scans -- the gain map) (round 6) ----------------------
+// A workgroup walks 64 subsequences' fresh paths (pass 0) and, from registers, the next subsequence of the first 63 of them (level 1 of pass 1):
+// the fresh end states that level 1 compares with are this workgroup's own (LDS), the bytes are staged once, the tables once, and the launch
+// boundary between the two passes -- on the critical chain of the decode -- is gone.  Workgroups therefore advance by 63 subsequences: the
+// 64th fresh walk of one is the first of the next (1.6 % of the walks twice, same result).  More than one lockstep level would need fresh states of
+// the NEXT workgroup's subsequences inside this kernel; those scans keep the two launches.  What is still alive after level 1 goes to the
+// straggler waves exactly as from hyp_pass1q_kernel.  flags[kHuffFlagStragglers] is zero when this kernel starts (the decode's initial fill / start_over).
+constexpr uint32_t kFusedStride = 63;
+__global__ __launch_bounds__(1024) void hyp_pass01_kernel(const HuffSyncArgs a) {
+  extern __shared__ uint32_t s_stage[];
+  __shared__ PairLds L;
+  __shared__ uint32_t s_n, s_base;
+  load_pair_lds(a, L);
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, h = tid >> 6, H = (uint32_t)a.hyp_h;
+  const uint32_t i0 = blockIdx.x * kFusedStride, i = i0 + lane;
+  const uint32_t nclean = a.nbytes - *a.nstuffed, nbits = nclean * 8u;
+  const uint32_t nsub = (nbits + a.sub_bits - 1) / a.sub_bits;
+  const uint32_t cshift = 31u - (uint32_t)__builtin_clz(a.sub_bits >> 3);
+  const uint32_t first_byte = i0 * (a.sub_bits >> 3);
+  // behind the staged bytes: the fresh end states of the 64 subsequences (two words each), then the survivors' ids (lane | hypothesis << 6)
+  const uint32_t stage_words = ((64u * ((a.sub_bits >> 3) + 4u) + 16u + 7u) >> 2) + 1u & ~1u;
+  uint32_t* s_fresh_lo = s_stage + stage_words;
+  uint32_t* s_fresh_hi = s_fresh_lo + 64u * H;
+  uint16_t* s_id = (uint16_t*)(s_fresh_hi + 64u * H);
+  if (tid == 0) s_n = 0;
+  stage_wave(a.clean, nclean, first_byte, cshift, s_stage, tid, 64u, blockDim.x);
+  if (a.zero_vec) {  // (behind the last global load, as in hyp_pass0_kernel)
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (uint32_t v = blockIdx.x * blockDim.x + tid; v < a.zero_vec; v += gridDim.x * blockDim.x) a.zero_ptr[v] = z;
+  }
+  __syncthreads();
+  const Staged st = {s_stage, cshift};
+  const bool have = i < nsub;
+  uint32_t p = i * a.sub_bits, b = h, k = 0;
+  if (have) {  // ---- pass 0: the fresh path (subsequence i, hypothesis h)
+    uint32_t nblk = 0;
+    const uint32_t end_bit = min((i + 1) * a.sub_bits, nbits);
+    if (a.pieces > 1 && blockIdx.x == 0 && h == 0) {  // (see hyp_pass0_kernel: the wave of the stream's first subsequence notes its pieces)
+      uint64_t m[3] = {0, 0, 0};
+      uint16_t c16[3] = {0, 0, 0};
+      track_span_pieces(a, st, first_byte * 8u, L, p, b, k, i * a.sub_bits, end_bit, nblk, m, c16);
+      if (i == 0) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+          if (q + 1 < a.pieces) { a.pend[q] = m[q]; a.pcnt[q] = c16[q]; sum += c16[q]; }
+        a.pcnt[a.pieces - 1] = nblk - sum;
+      }
+    } else {
+      track_span_pair(a, st, first_byte * 8u, L, p, b, k, end_bit, nblk);
+    }
+    a.hyp_state[(size_t)i * kHuffHypSlots + h] = pack_state(p, b, k);  // (the 64th walk: also written, with the same value, by the next workgroup)
+    if (i == 0 && h == 0) a.nblk[0] = nblk;
+  }
+  const uint64_t e0 = pack_state(p, b, k);
+  s_fresh_lo[lane * H + h] = (uint32_t)e0;
+  s_fresh_hi[lane * H + h] = (uint32_t)(e0 >> 32);
+  __syncthreads();
+  // ---- level 1: the same path through subsequence j = i + 1; merge targets: the fresh paths of j
+  const uint32_t j = i + 1u;
+  if (have && lane < kFusedStride && j < nsub) {
+    const uint32_t end_bit = min((j + 1) * a.sub_bits, nbits);
+    uint32_t nblk = 0;
+    const size_t at = (size_t)i * kHuffHypSlots + h;  // link (j - 1, slot h)
+    if (a.pieces > 1) {
+      const size_t mo = at * (size_t)(a.pieces - 1);
+      track_span_pieces(a, st, first_byte * 8u, L, p, b, k, j * a.sub_bits, end_bit, nblk, a.mid_state + mo, a.mid_cnt + mo);
+    } else if (p < end_bit) {
+      track_span_pair(a, st, first_byte * 8u, L, p, b, k, end_bit, nblk);
+    }
+    const uint64_t e = pack_state(p, b, k);
+    uint32_t g = 0xffu;
+    for (uint32_t t = 0; t < H; t++) {
+      const uint64_t f = (uint64_t)s_fresh_lo[(lane + 1u) * H + t] | ((uint64_t)s_fresh_hi[(lane + 1u) * H + t] << 32);
+      if (f == e && g == 0xffu) g = t;
+    }
+    a.hyp_cnt[at] = (uint16_t)nblk;
+    if (g != 0xffu) {
+      a.hyp_map[at] = (uint8_t)g;
+      if (a.hyp_hist) atomicAdd(a.flags + 10, 1u);
+    } else if (a.hyp_levels == 1) {  // map stays 0xff: not merged within the budget
+      atomicAdd(a.flags + 3, 1u);
+    } else {
+      const uint32_t nslot = H + h;
+      a.hyp_state[(size_t)j * kHuffHypSlots + nslot] = e;
+      a.hyp_map[at] = (uint8_t)nslot;
+      const uint32_t w = atomicAdd(&s_n, 1u);
+      s_id[w] = (uint16_t)(lane | (h << 6));
+    }
+  }
+  __syncthreads();
+  const uint32_t n_in = s_n;
+  if (n_in != 0) {  // hand-off: (start subsequence, hypothesis | levels done << 8)
+    if (tid == 0) s_base = atomicAdd(a.flags + kHuffFlagStragglers, n_in);
+    __syncthreads();
+    if (tid < n_in) {
+      const uint32_t at = s_base + tid, id = s_id[tid];
+      if (at < a.strag_cap) {
+        a.strag_list[2 * at] = i0 + (id & 63u);
+        a.strag_list[2 * at + 1] = (id >> 6) | (1u << 8);
+      }
+    }
+  }
+}
+
 // ---- pass 1, the stragglers (round 5): one WAVE per path -------------------------------------------------------------------
 // A lane follows a path at ~460 cycles per symbol (two dependent LDS reads and ~25 dependent VALU instructions), so pass 1 in
 // lockstep lasts as long as its unluckiest path: levels x (symbols per subsequence) x 460 cycles.  Few paths get that far (4K
@@ -1759,11 +1864,19 @@ hipError_t launch_huffman_decode_hyp(const HuffSyncArgs& a, int* dc_partial, uin
     }
   };
   mark();
-  hipLaunchKernelGGL(hyp_pass0_kernel, dim3(grid), dim3(threads), lds0, s, a);
-  mark();
   static const bool qmerge = !(getenv("UHDR_HIP_HUFF_QMERGE") && atoi(getenv("UHDR_HIP_HUFF_QMERGE")) == 0);
-  if (qmerge) hipLaunchKernelGGL(hyp_pass1q_kernel, dim3(grid), dim3(threads), lds1, s, a);
-  else hipLaunchKernelGGL(hyp_pass1_kernel, dim3(grid), dim3(threads), lds1, s, a);
+  static const bool no_fused = getenv("UHDR_HIP_HUFF_NO_FUSED_PASSES") != nullptr;
+  const size_t lds01 = (((((size_t)64 * ((a.sub_bits >> 3) + 4) + 16 + 7) >> 2) + 1) & ~(size_t)1) * 4 + (size_t)64 * a.hyp_h * 8 + (size_t)threads * 2 + 16;
+  if (qmerge && !no_fused && a.hyp_main_levels == 1 && a.hyp_levels > 1 && !a.rst_map && lds01 + sizeof(PairLds) + 64 <= (64u << 10)) {
+    // one lockstep level: passes 0 and 1 in one launch (hyp_pass01_kernel)
+    hipLaunchKernelGGL(hyp_pass01_kernel, dim3((nsub + kFusedStride - 1) / kFusedStride), dim3(threads), lds01, s, a);
+    mark();
+  } else {
+    hipLaunchKernelGGL(hyp_pass0_kernel, dim3(grid), dim3(threads), lds0, s, a);
+    mark();
+    if (qmerge) hipLaunchKernelGGL(hyp_pass1q_kernel, dim3(grid), dim3(threads), lds1, s, a);
+    else hipLaunchKernelGGL(hyp_pass1_kernel, dim3(grid), dim3(threads), lds1, s, a);
+  }
   {
     const hipError_t e1 = hipGetLastError();  // a launch that fails (LDS beyond the limit) must not read as a "lost" true path
     if (e1 != hipSuccess) return e1;

@@ -246,6 +246,48 @@ class UltraHdr:
                    C.c_void_p(out_map.data_ptr()), int(out_map.numel()), C.byref(nm))
         return int(nb.value), int(nm.value), md
 
+    def bindEncodeApi1Scans(self, sdr_intent: Image, hdr_intent: Image, base_encoding: int, qt_base, qt_map, out_base, out_map,
+                            sdr_is_601=False, use_luminance=True):
+        """encodeApi1Scans with every argument marshalled ONCE: returns run() -> (bytes of the base scan, bytes of the map scan, metadata) for a
+        caller that codes frame after frame from and into the same device buffers (a service's steady state; ~5 us of ctypes work per call
+        otherwise).  The images, tables and outputs must stay alive and in place; stream ordering against torch as in every device call."""
+        assert _is_dev(sdr_intent, hdr_intent) and out_base.is_cuda and out_map.is_cuda
+        qb, qm = self._qt_pair(qt_base), self._qt_pair(qt_map)
+        md = A.GainmapMetadata()
+        cfg = self.encode_cfg(sdr_is_601, use_luminance)
+        nb, nm = C.c_size_t(0), C.c_size_t(0)
+        fn = self.lib.uhdr_hip_encode_api1_scans_dev
+        args = (self.ctx.handle, C.byref(sdr_intent.raw), C.byref(hdr_intent.raw), C.byref(cfg), base_encoding, C.c_void_p(qb.ctypes.data),
+                C.c_void_p(qm.ctypes.data), C.byref(md), None, C.c_void_p(out_base.data_ptr()), int(out_base.numel()), C.byref(nb),
+                C.c_void_p(out_map.data_ptr()), int(out_map.numel()), C.byref(nm))
+        keep = (sdr_intent, hdr_intent, qb, qm, cfg, out_base, out_map)
+        ordered, check = self.ctx.ordered, A.check
+
+        def run(_keep=keep):
+            with ordered():
+                check(fn(*args))
+            return nb.value, nm.value, md
+
+        return run
+
+    def bindDecodeApi1Scans(self, base_hdr: "A.JpegHeader", base_data, base_cg: int, map_hdr: "A.JpegHeader", map_data, map_cg: int,
+                            gainmap_metadata: A.GainmapMetadata, output_ct: int, output_format: int, max_display_boost: float, dest: Image,
+                            libjpeg_variant: int = 0):
+        """decodeApi1Scans with the arguments marshalled once (see bindEncodeApi1Scans): returns run()."""
+        assert base_data.is_cuda and map_data.is_cuda and _is_dev(dest)
+        fn = self.lib.uhdr_hip_decode_api1_scans_dev
+        args = (self.ctx.handle, C.byref(base_hdr), C.c_void_p(base_data.data_ptr()), int(base_data.numel()), base_cg, C.byref(map_hdr),
+                C.c_void_p(map_data.data_ptr()), int(map_data.numel()), map_cg, libjpeg_variant, C.byref(gainmap_metadata), output_ct, output_format,
+                max_display_boost, C.byref(dest.raw))
+        keep = (base_hdr, base_data, map_hdr, map_data, gainmap_metadata, dest)
+        ordered, check = self.ctx.ordered, A.check
+
+        def run(_keep=keep):
+            with ordered():
+                check(fn(*args))
+
+        return run
+
     def _qt_pair(self, qt):
         """(luma, chroma) quantization tables -> one contiguous uint16 [2][64] block; built once per pair of arrays (a per-frame caller hands in
         the same two arrays every time: no numpy work between the frames)."""

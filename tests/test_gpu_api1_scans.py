@@ -120,6 +120,38 @@ def test_the_one_call_forms_equal_the_staged_forms(uhdr, hip_ctx):
     assert np.array_equal(d1.to_host().valid(0), d2.to_host().valid(0))
 
 
+def test_bound_calls_equal_the_plain_ones(uhdr, hip_ctx):
+    """bindEncodeApi1Scans / bindDecodeApi1Scans (arguments marshalled once; what bench.py's step calls): same bytes, same pixels, call after call."""
+    import torch
+
+    from libultrahdr_amd.ultrahdr import UltraHdr
+
+    dev, w, h = "cuda:0", 1280, 720
+    u = uhdr
+    enc = UltraHdr(ctx=hip_ctx, mapDimensionScaleFactor=1, useMultiChannelGainMap=True, preset=A.UHDR_USAGE_BEST_QUALITY)
+    sdr, hdr = synth.make_sdr_yuv420(w, h, seed=11).to(dev), synth.make_hdr_p010(w, h, ct=A.UHDR_CT_HLG, seed=11).to(dev)
+    qy, qc = u.quant_table(95, False), u.quant_table(95, True)
+    ob, om = torch.empty(w * h * 2, dtype=torch.uint8, device=dev), torch.empty(w * h * 4, dtype=torch.uint8, device=dev)
+    ob2, om2 = torch.empty_like(ob), torch.empty_like(om)
+    nb, nm, md = enc.encodeApi1Scans(sdr, hdr, A.UHDR_CG_DISPLAY_P3, (qy, qc), (qy, qc), ob, om)
+    run = enc.bindEncodeApi1Scans(sdr, hdr, A.UHDR_CG_DISPLAY_P3, (qy, qc), (qy, qc), ob2, om2)
+    f16 = A.UHDR_IMG_FMT_64bppRGBAHalfFloat
+    hb, hm = u.jpeg_header(w, h, S420, [qy, qc, qc]), u.jpeg_header(w, h, S444, [qy, qc, qc])
+    d1, d2 = Image(f16, w, h, align=64, device=dev), Image(f16, w, h, align=64, device=dev)
+    u.decodeApi1Scans(hb, ob[:nb], A.UHDR_CG_DISPLAY_P3, hm, om[:nm], A.UHDR_CG_BT_2100, md, A.UHDR_CT_LINEAR, f16, A.FLT_MAX, d1)
+    for _ in range(3):
+        ob2.zero_()
+        om2.zero_()
+        nb2, nm2, md2 = run()
+        assert (nb2, nm2) == (nb, nm) and torch.equal(ob2[:nb], ob[:nb]) and torch.equal(om2[:nm], om[:nm])
+        assert list(md2.max_content_boost) == list(md.max_content_boost) and list(md2.min_content_boost) == list(md.min_content_boost)
+        drun = u.bindDecodeApi1Scans(hb, ob2[:nb], A.UHDR_CG_DISPLAY_P3, hm, om2[:nm], A.UHDR_CG_BT_2100, md2, A.UHDR_CT_LINEAR, f16, A.FLT_MAX, d2)
+        drun()
+        drun()
+        hip_ctx.synchronize()
+        assert np.array_equal(d1.to_host().valid(0), d2.to_host().valid(0))
+
+
 def test_rejections(uhdr, hip_ctx):
     import torch
 
