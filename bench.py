@@ -365,6 +365,7 @@ def main():
     # out-of-memory on a smaller device) must not cost the headline line
     if rank == 0 and world == 1 and not args.no_extra and not headline_only:
         for key, fn in (("api1_roundtrip", lambda: api1_roundtrip_section(ctx, u, device)),
+                        ("api1_concurrent", lambda: concurrent_section(device, dev_index)),
                         ("headline_16x4k", lambda: batch16_section(ctx, u, device, args)),
                         ("encode", lambda: encode_section(ctx, u, device)), ("config5", lambda: config5_section(ctx, u, device)),
                         ("extra", lambda: extras(ctx, u, device)), ("api_level", lambda: api_level_section())):
@@ -403,6 +404,7 @@ ROOFLINE_SCALARS = (
     ("api1_4k_enc_us", ("api1_roundtrip", "api1_4k_enc_us")), ("api1_4k_dec_us", ("api1_roundtrip", "api1_4k_dec_us")),
     ("api1_8k_enc_us", ("api1_roundtrip", "api1_8k_enc_us")), ("api1_8k_dec_us", ("api1_roundtrip", "api1_8k_dec_us")),
     ("api1_8k_roundtrip_Mpxs", ("api1_roundtrip", "api1_8k_roundtrip_Mpxs")),
+    ("api1_4k_x4_in_flight_Mpxs", ("api1_concurrent", "frames_in_flight_4_Mpxs")),
     ("ns8k_mapA_cold_frac", ("roofline", "ns8k_mapA_cold_frac")), ("ns8k_mapB_frac", ("roofline", "ns8k_mapB_frac")),
     ("ns8k_mapC_frac", ("roofline", "ns8k_mapC_frac")),
     ("config5_frac", ("config5", "frac_of_8TBs")), ("headline_16x4k_frac", ("headline_16x4k", "frac")),
@@ -917,6 +919,69 @@ def api1_roundtrip_section(ctx, u, device):
                         "one HIP-event pair around back-to-back calls, host gaps of the synchronous entropy entry points included, the file's two scans "
                         "entropy-coded concurrently (uhdr_hip_huffman_{encode,decode}2_dev; *_one_scan_at_a_time_us = the same with two single-scan "
                         "calls); *_kernels_us: sum of the per-launch HIP events of the same calls (overlapping launches counted in full)")
+    return res
+
+
+def concurrent_section(device, dev_index, nctx=4, steps=12, warmup=3):
+    """The same 4K API-1 round trip with SEVERAL frames in flight: `nctx` contexts (own streams, scratch, worker thread), one host thread each,
+    every thread loops encode + decode of its own frame.  One round trip alone is a chain of latency-bound launches that leaves most of the device
+    idle; a service that transcodes independent frames fills it this way.  Whole-job rate = frames x pixels / wall clock between two
+    barriers (all threads synchronised their contexts before each).  Not the line's `value` (one frame per step): a second figure beside it."""
+    import threading
+
+    from libultrahdr_amd.ultrahdr import Context, UltraHdr
+
+    w, h = 3840, 2160
+    res = {}
+    for n in (2, nctx):
+        ctxs = [Context(dev_index) for _ in range(n)]
+        work = []
+        for i, c in enumerate(ctxs):
+            enc, dec, box = make_roundtrip(c, UltraHdr(ctx=c), device, w, h, seed=4321 + i)
+            c.stream_safe = False
+            work.append((enc, dec, box))
+        bar = threading.Barrier(n + 1)
+        errs = []
+
+        def loop(i):
+            enc, dec, _ = work[i]
+            try:
+                for _ in range(warmup):
+                    enc()
+                    dec()
+                ctxs[i].synchronize()
+                bar.wait()
+                for _ in range(steps):
+                    enc()
+                    dec()
+                ctxs[i].synchronize()
+                bar.wait()
+            except Exception as e:  # noqa: BLE001
+                errs.append(repr(e))
+                bar.abort()
+
+        th = [threading.Thread(target=loop, args=(i,)) for i in range(n)]
+        for t in th:
+            t.start()
+        try:
+            bar.wait()
+            t0 = time.perf_counter()
+            bar.wait()
+            dt = time.perf_counter() - t0
+        except threading.BrokenBarrierError:
+            dt = None
+        for t in th:
+            t.join()
+        if errs or dt is None:
+            raise RuntimeError("; ".join(errs) or "barrier broken")
+        res[f"frames_in_flight_{n}_Mpxs"] = round(n * steps * w * h / dt / 1e6, 1)
+        res[f"frames_in_flight_{n}_ms_per_round_trip"] = round(dt / steps * 1e3, 4)
+        del work, ctxs
+        import torch
+
+        torch.cuda.empty_cache()
+    res["workload"] = (f"4K API-1 round trip (the line's step), 2 and {nctx} independent frames in flight: one context + one host thread per frame, {steps} round trips each "
+                       "after a warm-up, wall clock between two barriers; Mpixels/s of all frames together")
     return res
 
 

@@ -24,6 +24,7 @@ def _full():
         "roofline": roof,
         "api1_roundtrip": {"api1_4k_enc_us": 518.3, "api1_4k_dec_us": 689.0, "api1_8k_enc_us": 1425.0, "api1_8k_dec_us": 1553.0,
                            "api1_8k_roundtrip_Mpxs": 11139.0, "api1_note": LONG},
+        "api1_concurrent": {"frames_in_flight_2_Mpxs": 15000.0, "frames_in_flight_4_Mpxs": 24000.0, "workload": LONG},
         "config5": {"frac_of_8TBs": 0.367, "workload": LONG}, "headline_16x4k": {"frac": 0.67, "workload": LONG},
         "config4": {"ms_per_image": 1.9, "all_reduce_us_back_to_back": 21.0, "full_16k_x_16k_one_gpu": {"ms_per_image": 14.2}, "workload": LONG},
         "encode": {"blob": [LONG] * 4}, "extra": {"blob": [LONG] * 8}, "api_level": {"blob": LONG, "uhdr_encode_api0_8k_hip": {"ms": 31.0}},
@@ -52,7 +53,7 @@ def test_compact_line_is_small_and_complete():
 
 def test_compact_line_survives_failed_sections():
     full = _full()
-    for k in ("api1_roundtrip", "config5", "headline_16x4k", "config4", "encode", "extra", "api_level"):
+    for k in ("api1_roundtrip", "api1_concurrent", "config5", "headline_16x4k", "config4", "encode", "extra", "api_level"):
         full[k] = {"error": "RuntimeError: " + LONG}
     full["roofline"] = {"bound": "hbm", "kernel": None, "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None, "error": LONG}
     full["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port", "sample": "failed: " + LONG}
