@@ -173,24 +173,33 @@ __device__ __forceinline__ uint32_t tile_offset(const HuffSyncArgs& a) {
 // RST: rst_map gets bit (clean byte index) set where an interval starts (zero-initialised by the caller); rst_partial[chunk]
 // = {markers found, their two sequence sums} -- per chunk, because thousands of atomics on three global words are serialised
 // (3239 markers: 88 us for this kernel instead of 15)
+// chunk_base: the chunks' drop counts -- scanned (exclusive) by sync_scan_kernel when `total` is null; else RAW, and every workgroup adds up the
+// counts in front of its chunk itself (round 6: one launch less at the head of every decode; up to kUnstuffSelfPrefix chunks -- the reads grow
+// with the square of the count) and the last one leaves the stream's total in *total.
+constexpr int kUnstuffSelfPrefix = 4096;
 template <bool RST>
 __global__ __launch_bounds__(256) void unstuff_compact_kernel(const uint8_t* __restrict__ data, uint32_t n, const uint32_t* __restrict__ chunk_base,
-                                                              uint8_t* __restrict__ clean, uint32_t* __restrict__ rst_map, uint32_t* __restrict__ rst_partial) {
-  __shared__ uint32_t s_scan[256];
+                                                              uint8_t* __restrict__ clean, uint32_t* __restrict__ rst_map, uint32_t* __restrict__ rst_partial,
+                                                              uint32_t* __restrict__ total) {
+  __shared__ uint32_t s_w[4];
   __shared__ uint32_t s_rst[3];
   const uint32_t tid = threadIdx.x, base = blockIdx.x * kChunk + tid * 16;
   if (RST && tid < 3) s_rst[tid] = 0;
   const uint32_t mask = base < n ? dropmask16<RST>(data, base, n) : 0u;
   const uint32_t c = (uint32_t)__builtin_popcount(mask);
-  s_scan[tid] = c;
-  __syncthreads();
-  for (uint32_t d = 1; d < 256; d <<= 1) {
-    const uint32_t y = tid >= d ? s_scan[tid - d] : 0u;
-    __syncthreads();
-    s_scan[tid] += y;
-    __syncthreads();
+  uint32_t before = 0;
+  if (total) {
+    uint32_t part[1] = {0}, all[1];
+    for (uint32_t i = tid; i < blockIdx.x; i += 256u) part[0] += chunk_base[i];
+    wg_incl_scan<256, 1>(part, s_w, all);
+    before = all[0];
+  } else {
+    before = chunk_base[blockIdx.x];
   }
-  uint32_t dropped = chunk_base[blockIdx.x] + s_scan[tid] - c;  // dropped bytes before this thread's first byte
+  uint32_t sc[1] = {c}, mine[1];
+  wg_incl_scan<256, 1>(sc, s_w, mine);
+  if (total && blockIdx.x == gridDim.x - 1 && tid == 0) *total = before + mine[0];
+  uint32_t dropped = before + sc[0] - c;  // dropped bytes before this thread's first byte
   if (mask == 0 && base + 16u <= n && ((uintptr_t)(data + base) & 15u) == 0) {
     // nothing dropped in these 16 bytes (15 threads in 16 of a stuffed stream): four dword stores at the shifted, in general
     // unaligned, destination (global memory takes unaligned dword accesses) instead of sixteen byte stores
@@ -1588,7 +1597,10 @@ __global__ __launch_bounds__(kPlaceChunk) void dc_partial2_kernel(const HuffSync
 // differences on top of the chunk's carry-in), then every wave moves 64 of the chunk's blocks, two per step: a lane reads the
 // two coefficients of one natural-order pair from the block's zig-zag scratch row (one 128-byte line per block) and the wave
 // stores 2 x 128 contiguous bytes.  Dummy blocks of edge MCUs are dropped here.
-__global__ __launch_bounds__(kPlaceChunk) void coef_place_kernel(const HuffSyncArgs a, const int* __restrict__ partial) {
+// partial: the chunks' per-component DC sums -- scanned (exclusive) by dc_scan_partials_kernel when self_prefix == 0; else raw, every workgroup adding
+// up the chunks in front of its own (round 6: one launch less; up to kPlaceSelfPrefix chunks).
+constexpr int kPlaceSelfPrefix = 4096;
+__global__ __launch_bounds__(kPlaceChunk) void coef_place_kernel(const HuffSyncArgs a, const int* __restrict__ partial, int self_prefix) {
   __shared__ int s_sum[3 * (kPlaceChunk / 64)];
   __shared__ int16_t s_dc[kPlaceChunk];
   __shared__ uint32_t s_dst[kPlaceChunk];  // component << 30 | JBLOCK index inside its array; ~0: a dummy block of an edge MCU
@@ -1610,8 +1622,22 @@ __global__ __launch_bounds__(kPlaceChunk) void coef_place_kernel(const HuffSyncA
     if (by < a.bh[c] && bx < a.bw[c]) where = ((uint32_t)c << 30) | ((uint32_t)by * (uint32_t)a.bw[c] + (uint32_t)bx);
   }
   s_dst[tid] = where;
+  int carry[3];
+  if (self_prefix) {
+    int part[3] = {0, 0, 0};
+    for (uint32_t i = (uint32_t)tid; i < blockIdx.x; i += (uint32_t)kPlaceChunk) {
+      part[0] += partial[i * 3];
+      part[1] += partial[i * 3 + 1];
+      part[2] += partial[i * 3 + 2];
+    }
+    wg_incl_scan<kPlaceChunk, 3>(part, s_sum, carry);
+  } else {
+    carry[0] = partial[blockIdx.x * 3];
+    carry[1] = partial[blockIdx.x * 3 + 1];
+    carry[2] = partial[blockIdx.x * 3 + 2];
+  }
   dc_chunk_scan(v, s_sum, tid);
-  s_dc[tid] = (int16_t)(partial[blockIdx.x * 3 + c] + v[c]);
+  s_dc[tid] = (int16_t)((c == 0 ? carry[0] : (c == 1 ? carry[1] : carry[2])) + v[c]);
   __syncthreads();
   const uint32_t lane = (uint32_t)tid & 63u, wv = (uint32_t)tid >> 6;
   const uint32_t half = lane >> 5, n0 = (lane & 31u) * 2u;  // the lane's natural-order pair inside its block
@@ -1764,9 +1790,13 @@ hipError_t launch_huffman_unstuff(const uint8_t* data, uint32_t nbytes, uint32_t
   if (fill) f = *fill;
   if (rst_map) hipLaunchKernelGGL(unstuff_count_kernel<true>, dim3(nchunks), dim3(256), 0, s, data, nbytes, chunk_counts, f);
   else hipLaunchKernelGGL(unstuff_count_kernel<false>, dim3(nchunks), dim3(256), 0, s, data, nbytes, chunk_counts, f);
-  hipLaunchKernelGGL(sync_scan_kernel, dim3(1), dim3(1024), 0, s, chunk_counts, nchunks, nstuffed_dev);
-  if (rst_map) hipLaunchKernelGGL(unstuff_compact_kernel<true>, dim3(nchunks), dim3(256), 0, s, data, nbytes, (const uint32_t*)chunk_counts, clean, rst_map, rst_partial);
-  else hipLaunchKernelGGL(unstuff_compact_kernel<false>, dim3(nchunks), dim3(256), 0, s, data, nbytes, (const uint32_t*)chunk_counts, clean, rst_map, rst_partial);
+  uint32_t* total = nstuffed_dev;
+  if (nchunks > kUnstuffSelfPrefix) {
+    hipLaunchKernelGGL(sync_scan_kernel, dim3(1), dim3(1024), 0, s, chunk_counts, nchunks, nstuffed_dev);
+    total = nullptr;
+  }
+  if (rst_map) hipLaunchKernelGGL(unstuff_compact_kernel<true>, dim3(nchunks), dim3(256), 0, s, data, nbytes, (const uint32_t*)chunk_counts, clean, rst_map, rst_partial, total);
+  else hipLaunchKernelGGL(unstuff_compact_kernel<false>, dim3(nchunks), dim3(256), 0, s, data, nbytes, (const uint32_t*)chunk_counts, clean, rst_map, rst_partial, total);
   return hipGetLastError();
 }
 static void launch_write2(const HuffSyncArgs& a, uint32_t nsub, int final_buf, hipStream_t s) {
@@ -1785,8 +1815,9 @@ static void launch_write2(const HuffSyncArgs& a, uint32_t nsub, int final_buf, h
 static void launch_place(const HuffSyncArgs& a, int* dc_partial, hipStream_t s) {
   const int nch = (int)((a.total_blocks + kPlaceChunk - 1) / kPlaceChunk);
   hipLaunchKernelGGL(dc_partial2_kernel, dim3(nch), dim3(kPlaceChunk), 0, s, a, dc_partial);
-  hipLaunchKernelGGL(dc_scan_partials_kernel, dim3(1), dim3(1024), 0, s, dc_partial, nch);
-  hipLaunchKernelGGL(coef_place_kernel, dim3(nch), dim3(kPlaceChunk), 0, s, a, (const int*)dc_partial);
+  const int self_prefix = nch <= kPlaceSelfPrefix ? 1 : 0;
+  if (!self_prefix) hipLaunchKernelGGL(dc_scan_partials_kernel, dim3(1), dim3(1024), 0, s, dc_partial, nch);
+  hipLaunchKernelGGL(coef_place_kernel, dim3(nch), dim3(kPlaceChunk), 0, s, a, (const int*)dc_partial, self_prefix);
 }
 int huff_place_chunk() { return kPlaceChunk; }
 static void launch_dc(const HuffSyncArgs& a, int* dc_partial, hipStream_t s) {
