@@ -151,7 +151,10 @@ def fuzz_tonemap():
             pg, pw = pg.view(np.uint8), pw.view(np.uint8)
         d = np.abs(pg.astype(np.int32) - pw.astype(np.int32))
         n += int((d != 0).sum()); tot += d.size; mx = max(mx, int(d.max()))
-    note("tonemap", mx <= 1 and n / tot <= 1e-4, f"{kind} ct{ct} cg{cg} max {mx} differ {n}/{tot}")
+    # +-1 on <= 1e-4 of the samples; a single differing sample passes whatever the image's size (these frames have 3-25 K samples): the reference's
+    # srgbOetf goes through glibc's powf (faithfully rounded), the device's is correctly rounded -- about one code in 1e7-1e8 samples (DESIGN.md 1, row
+    # a4-a8; seen once in 2.4e8 samples of a 480 s sweep, profiles/r06_fuzz_parity_long.log)
+    note("tonemap", mx <= 1 and (n <= 1 or n / tot <= 1e-4), f"{kind} ct{ct} cg{cg} max {mx} differ {n}/{tot}")
 
 
 def _uh_for(cfg):
@@ -217,7 +220,7 @@ def fuzz_tonemap_formats():
             pg, pw = pg.view(np.uint8), pw.view(np.uint8)
         d = np.abs(pg.astype(np.int32) - pw.astype(np.int32))
         n += int((d != 0).sum()); tot += d.size; mx = max(mx, int(d.max()))
-    note("tonemap-formats", mx <= 1 and n / tot <= 1e-4, f"fmt{hdr.fmt} ct{hdr.raw.ct} cg{hdr.raw.cg} max {mx} differ {n}/{tot}")
+    note("tonemap-formats", mx <= 1 and (n <= 1 or n / tot <= 1e-4), f"fmt{hdr.fmt} ct{hdr.raw.ct} cg{hdr.raw.cg} max {mx} differ {n}/{tot}")
 
 
 def fuzz_converts():
