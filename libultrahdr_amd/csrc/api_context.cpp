@@ -653,6 +653,8 @@ void uhdr_hip_destroy(uhdr_hip_ctx_t* c) {
   if (c->h_mm) (void)hipHostFree(c->h_mm);
   if (c->aux_ev) (void)hipEventDestroy(c->aux_ev);
   if (c->aux_ev2) (void)hipEventDestroy(c->aux_ev2);
+  if (c->md_ev) (void)hipEventDestroy(c->md_ev);
+  if (c->md_stream) (void)hipStreamDestroy(c->md_stream);
   if (c->h_flags) (void)hipHostFree(c->h_flags);
   if (c->pin.p) (void)hipHostFree(c->pin.p);
   if (c->pin.ev) (void)hipEventDestroy(c->pin.ev);

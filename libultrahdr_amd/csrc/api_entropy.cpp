@@ -479,7 +479,6 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
   a.starts = starts;
   a.ends = ends;
   dbg.mark("huffman_decode_dev: tables ready");
-  HIP_TRY(hipMemsetAsync(a.status, 0, 16, c->stream));
   const bool rst_sync = a.nseg > 1 && data_bytes / (size_t)a.nseg >= 320 && !getenv("UHDR_HIP_HUFF_RST_INTERVALS");
   const bool try_sync = (a.nseg == 1 || rst_sync) && data_bytes >= 4096 && data_bytes < ((size_t)1 << 29) && fast_ok && !getenv("UHDR_HIP_HUFF_SERIAL") && bpm <= 16;
   // write pass, form 2 (marker-less scans): a scan-order scratch takes the zero fill, the JBLOCK arrays are written whole
@@ -776,6 +775,7 @@ uhdr_error_info_t uhdr_hip_huffman_decode_dev(uhdr_hip_ctx_t* c, const uhdr_hip_
   }
   if (!coef_zeroed)
     for (int i = 0; i < a.ncomp; i++) HIP_TRY(hipMemsetAsync(a.coef[i], 0, zero_bytes[i], c->stream));
+  HIP_TRY(hipMemsetAsync(a.status, 0, 16, c->stream));  // (only this route reads it: the fill used to be the first launch of every decode, 5 us in front of the parallel route too)
   {
     ProfScope ps(c, "huffman_decode");
     HIP_TRY(launch_huffman_decode(a, counts, starts, ends, c->stream));

@@ -210,6 +210,10 @@ struct uhdr_hip_ctx {
   // between: the chain leaves the metadata's inputs here (the copy to h_mm is enqueued) and the entry point finishes them after the
   // entropy stage's own synchronisation
   bool defer_md = false;
+  // (round 6) with defer_md the range's read-back leaves the main stream: an event behind the range kernel, the copy on md_stream -- it used to sit, with its
+  // launch gaps, between the map's blocks and the map scan's first entropy kernel
+  hipStream_t md_stream = nullptr;
+  hipEvent_t md_ev = nullptr;
   // uhdr_hip_encode_api1_scans_dev (round 6): called by the fused chain as soon as the base image's blocks are enqueued on the auxiliary stream -- the
   // caller posts the base scan's entropy coding to the worker thread there, two kernels into the chain instead of behind it.  side_job_posted: the
   // auxiliary context belongs to that job until the caller has waited for it.

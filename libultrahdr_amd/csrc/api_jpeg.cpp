@@ -271,6 +271,7 @@ uhdr_error_info_t uhdr_hip_encode_api1_fused_dev(uhdr_hip_ctx_t* c, const uhdr_r
   float* merged = (float*)c->exchange.p;
   float* final_mm = (float*)((char*)c->exchange.p + 192);
   uhdr_error_info_t xchg = ok_status();
+  bool md_on_side = false;
   auto note_hip = [&](hipError_t e, const char* what) {
     if (e != hipSuccess && local.error_code == UHDR_CODEC_OK) local = err_status(UHDR_CODEC_ERROR, "%s: %s", what, hipGetErrorString(e));
   };
@@ -323,6 +324,16 @@ uhdr_error_info_t uhdr_hip_encode_api1_fused_dev(uhdr_hip_ctx_t* c, const uhdr_r
     if (!striped) {  // one launch for everything between the passes
       t.do_reduce = t.do_finalize = t.do_table = 1;
       note_hip(launch_minmax_table(t, c->stream), "minmax / tables");
+      if (c->defer_md) {  // the range is final here: its read-back goes to a side stream, behind this event
+        if (!c->md_stream) note_hip(hipStreamCreateWithFlags(&c->md_stream, hipStreamNonBlocking), "metadata stream");
+        if (!c->md_ev) note_hip(hipEventCreateWithFlags(&c->md_ev, hipEventDisableTiming), "metadata event");
+        if (c->md_stream && c->md_ev) {
+          note_hip(hipEventRecord(c->md_ev, c->stream), "metadata event record");
+          note_hip(hipStreamWaitEvent(c->md_stream, c->md_ev, 0), "metadata stream wait");
+          note_hip(hipMemcpyAsync(c->h_mm, final_mm, 9 * sizeof(float), hipMemcpyDeviceToHost, c->md_stream), "metadata copy");
+          md_on_side = true;
+        }
+      }
     } else {
       MinmaxTableParams r = t;
       r.do_reduce = 1;
@@ -348,7 +359,7 @@ uhdr_error_info_t uhdr_hip_encode_api1_fused_dev(uhdr_hip_ctx_t* c, const uhdr_r
     if (!c->side_job_posted) aux_merge(c);  // (else the auxiliary context is the worker thread's until the caller has waited for its job)
   }
   chain.reset();
-  note_hip(hipMemcpyAsync(c->h_mm, final_mm, 9 * sizeof(float), hipMemcpyDeviceToHost, c->stream), "metadata copy");
+  if (!md_on_side) note_hip(hipMemcpyAsync(c->h_mm, final_mm, 9 * sizeof(float), hipMemcpyDeviceToHost, c->stream), "metadata copy");
   if (c->defer_md && !striped) {  // the caller synchronises later and finishes the metadata then (finish_deferred_md)
     if (local.error_code != UHDR_CODEC_OK) return local;
     c->deferred_md.valid = true;
@@ -492,6 +503,7 @@ static uhdr_error_info_t encode_api1_scans_impl(uhdr_hip_ctx_t* c, const uhdr_ra
   }
   auto finish_deferred_md = [&]() -> uhdr_error_info_t {  // (after a synchronisation of c->stream)
     if (!c->deferred_md.valid) return ok_status();
+    if (c->md_stream) HIP_TRY(hipStreamSynchronize(c->md_stream));  // (the range's copy left long ago: behind the range kernel)
     c->deferred_md.valid = false;
     float mm[6];
     memcpy(mm, c->h_mm, sizeof mm);
