@@ -1,5 +1,5 @@
-/* The three tone-map samples that tools/r06_tonemap_hunt.py found (HIP one code below the reference): the oracle's per-pixel pipeline with glibc's powf and
-   with a correctly rounded pow in srgbOetf.   gcc -O2 -o /tmp/tm_site tools/r06_tonemap_site.c -lm && /tmp/tm_site   (from the repo root: cd tools) */
+/* The three tone-map samples that tests/probe_tonemap_hunt.py found (HIP one code below the reference): the oracle's per-pixel pipeline with glibc's powf and
+   with a correctly rounded pow in srgbOetf.   cd tests && gcc -O2 -o /tmp/tm_site probe_tonemap_site.c -lm && /tmp/tm_site     (tests/test_tonemap_site.py runs it) */
 #include "../oracle/uhdr_oracle.c"  /* test infrastructure: this probe runs on the CPU only */
 #include <stdio.h>
 static float srgb_oetf_cr(float e) { /* the same formula with a correctly rounded pow (long double, then rounded once) */
