@@ -973,10 +973,15 @@ def concurrent_section(device, dev_index, nctx=4, steps=12, warmup=3):
         for t in th:
             t.join()
         if errs or dt is None:
+            for c in ctxs:
+                c.close()
             raise RuntimeError("; ".join(errs) or "barrier broken")
         res[f"frames_in_flight_{n}_Mpxs"] = round(n * steps * w * h / dt / 1e6, 1)
         res[f"frames_in_flight_{n}_ms_per_round_trip"] = round(dt / steps * 1e3, 4)
-        del work, ctxs
+        del work
+        for c in ctxs:  # (explicitly: a context owns a stream, an auxiliary context and its worker thread)
+            c.close()
+        del ctxs
         import torch
 
         torch.cuda.empty_cache()
