@@ -124,6 +124,20 @@ def test_4k_decode_through_the_facade_equals_the_cpu_reference():
         assert trace.n("jpeg_decode_scan") == 2, trace  # base image and gain map, from their compressed bytes
 
 
+def test_a_scan_larger_than_the_first_guess_is_coded_again_not_handed_back():
+    """The fused encode seams size their output buffers at one byte per coefficient; a busier stream makes the entropy coder report the size it needs
+    (UHDR_CODEC_MEM_ERROR + the byte counts).  The seam then runs the device chain once more with room for that -- it used to fall to the per-stage seams,
+    i.e. every intermediate over PCIe (round-5 advice).  UHDR_HIP_SEAM_TEST_SMALL_CAP shrinks the first guess so that an ordinary frame takes that route."""
+    with tempfile.TemporaryDirectory() as d:
+        p, y = _fixture(d)
+        rc, _, err, _ = F.encode_api1(p, y, 1280, 720, "cpu.jpg", False, d)
+        assert rc == 0, err
+        rc, _, err, trace = F.encode_api1(p, y, 1280, 720, "gpu.jpg", True, d, env_extra={"UHDR_HIP_SEAM_TEST_SMALL_CAP": "256"})
+        assert rc == 0, err
+        assert _stages(trace) == ["encode_api1_fused"] and trace.n("encode_api1_fused") == 2 and trace.n("encode_api1_fused", "reference") == 0, trace
+        assert np.array_equal(F.read(os.path.join(d, "cpu.jpg")), F.read(os.path.join(d, "gpu.jpg")))
+
+
 def test_api0_encode_through_the_facade():
     """API-0 (HDR only): toneMap + generateGainMap + convert_raw_input_to_ycbcr on the device.  toneMap's sRGB OETF is
     correctly rounded on the device and faithfully rounded in glibc: the files may differ in the rare
