@@ -1,6 +1,11 @@
 // uhdr_hip_seam.cpp -- implementation of the facade's HIP seam (see uhdr_hip_seam.h).
 // Compiled by g++ with the REFERENCE's headers on the include path (facade/Makefile) and linked against
 // libuhdr_hip.so; it only marshals between the reference's C++ types and the C ABI of include/uhdr_hip.h.
+#ifdef UHDR_ENABLE_HEIF
+// HeifUltraHdr / AvifUltraHdr call the patched UltraHdr::generateGainMap too and hand the map to a CPU encoder with no seam behind it: the lazy
+// gain-map download (tl_lazy_ok) is only sound while JpegR is the one caller.  A facade built with HEIF support has to flush residents there first.
+#error "the facade's lazy gain-map download assumes JpegR is the only caller of generateGainMap: build without UHDR_ENABLE_HEIF or add the write-back"
+#endif
 #include "uhdr_hip_seam.h"
 
 #include <atomic>
